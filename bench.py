@@ -1,0 +1,248 @@
+#!/usr/bin/env python3
+"""bench.py — BASELINE.json's metric on its config: descriptor-pair distances/s for exhaustive
+SIFT matching (all-pairs 128-D u8 dot products + top-2 + acos ratio/distance tests + cross check)
+of N images x 4096 descriptors on MI355X.
+
+A "step" is one full pass of the hot path over the workload: every image pair of the set goes
+through libamc.so's amc_match_pairs (match kernel -> finalize -> match tables on the host), with
+descriptors already resident in HBM when the timed region starts.
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+N=1 workload = BASELINE.json configs[1] (500 x 4096, 124,750 pairs, 2.09e12 distances).
+N>1: weak scaling — the image set grows as 500*sqrt(N) so every rank matches ~124,750 pairs of
+one replicated descriptor arena; ranks exchange their match tables with one RCCL all-gather at
+the end of each step (the exchange step north_star names).
+
+Prints ONE JSON line (rank 0).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+INT8_DENSE_PEAK_OPS = 5.0e15  # gfx950 dense int8 MFMA: 2x the 2.5 PF bf16 dense peak
+                              # (/opt/skills/guides/MI355X_MICROARCH.md: "I8 ... ~2x bf16 rate")
+OPS_PER_DISTANCE = 256        # 128 int8 MACs
+
+
+def make_arena_torch(num_images: int, feats: int, seed: int, device):
+    """Seeded SIFT-like scene descriptors generated on the GPU (same recipe as
+    pycolmap_amd.synth.scene_images: shared landmark prototypes + per-image noise + pure-noise
+    padding, L2-normalised, x512, rounded, clamped to uint8)."""
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    visible_frac, sigma_d = 0.35, 0.08
+    L = max(8, int(feats / visible_frac * 0.6))
+    proto = torch.randn(L, 128, generator=g, device=device).abs().pow(3.0)
+    proto = proto / proto.norm(dim=1, keepdim=True)
+    k = min(feats, int(round(visible_frac * L)))
+    arena = torch.empty(num_images, feats, 128, dtype=torch.uint8, device=device)
+    for i in range(num_images):
+        vis = torch.randperm(L, generator=g, device=device)[:k]
+        d = proto[vis] + torch.randn(k, 128, generator=g, device=device) * sigma_d * proto[vis].mean()
+        if k < feats:
+            noise = torch.randn(feats - k, 128, generator=g, device=device).abs().pow(3.0) * 0.1
+            d = torch.cat([d, noise], 0)
+        d = d[torch.randperm(feats, generator=g, device=device)].clamp_min(0)
+        d = d / d.norm(dim=1, keepdim=True).clamp_min(1e-12)
+        arena[i] = torch.round(512.0 * d).clamp(0, 255).to(torch.uint8)
+    return arena
+
+
+def cpu_baseline(arena_cpu: np.ndarray, s1: np.ndarray, s2: np.ndarray, sample_pairs: int, threads: int):
+    """Time the CPU oracle ("port": oracle/match_oracle.c, the literal restatement of COLMAP's
+    brute-force matcher) on a bounded seeded sample of the same workload."""
+    sys.path.insert(0, str(ROOT / "tests"))
+    import oracle_lib
+    rng = np.random.default_rng(1234)
+    idx = np.sort(rng.choice(len(s1), size=min(sample_pairs, len(s1)), replace=False))
+    used = np.unique(np.concatenate([s1[idx], s2[idx]]))
+    remap = {int(u): k for k, u in enumerate(used)}
+    imgs = [arena_cpu[int(u)] for u in used]
+    a = np.array([remap[int(x)] for x in s1[idx]], np.uint32)
+    b = np.array([remap[int(x)] for x in s2[idx]], np.uint32)
+    t0 = time.perf_counter()
+    off, m = oracle_lib.match_pairs(imgs, a, b, threads=threads)
+    dt = time.perf_counter() - t0
+    ndist = float(sum(len(imgs[int(x)]) * len(imgs[int(y)]) for x, y in zip(a, b)))
+    return ndist / dt, len(idx), dt, (idx, off, m)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--images", type=int, default=500, help="images at N=1 (BASELINE configs[1])")
+    ap.add_argument("--feats", type=int, default=4096)
+    ap.add_argument("--kernel", default="auto", choices=["auto", "mfma", "dot4"])
+    ap.add_argument("--cpu-sample-pairs", type=int, default=32)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from pycolmap_amd import _capi, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the measured path")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=device)
+
+    # ---- workload ------------------------------------------------------------------------
+    num_images = args.images if world == 1 else int(round(args.images * math.sqrt(world)))
+    arena = make_arena_torch(num_images, args.feats, seed=0, device=device)
+    s1_all, s2_all = synth.exhaustive_pairs(num_images)
+    # shard: order by image 2 (the kernel's L2-friendly order), deal contiguous slices to ranks
+    order = np.lexsort((s1_all, s2_all))
+    per = (len(order) + world - 1) // world
+    mine = order[rank * per:(rank + 1) * per]
+    s1, s2 = s1_all[mine], s2_all[mine]
+
+    ctx = _capi.Context(local_rank)
+    stream = torch.cuda.current_stream()
+    ctx.set_stream(stream.cuda_stream)
+    ctx.reserve_slots(num_images)
+    for i in range(num_images):
+        ctx.upload_descriptors_device(i, arena[i].data_ptr(), args.feats)
+    torch.cuda.synchronize()
+
+    def step():
+        off, m, st = ctx.match_pairs(s1, s2, kernel=args.kernel)
+        gathered = None
+        if world > 1:
+            # RCCL all-gather of the match tables: counts first, then padded tables
+            cnt = torch.tensor([m.shape[0]], device=device, dtype=torch.int64)
+            cnts = torch.empty(world, device=device, dtype=torch.int64)
+            dist.all_gather_into_tensor(cnts, cnt)
+            mx = int(cnts.max().item())
+            buf = torch.zeros(max(mx, 1), 2, device=device, dtype=torch.int32)
+            if m.shape[0]:
+                buf[:m.shape[0]] = torch.from_numpy(m.view(np.int32)).to(device, non_blocking=True)
+            allbuf = torch.empty(world * max(mx, 1), 2, device=device, dtype=torch.int32)
+            dist.all_gather_into_tensor(allbuf, buf)
+            gathered = (cnts, allbuf)
+        return off, m, st, gathered
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    kern_ms, kern_launches, ndist_local, last = 0.0, 0, 0, None
+    for _ in range(args.steps):
+        last = step()
+        kern_ms += last[2]["match_kernel_ms"]
+        kern_launches += last[2]["match_kernel_launches"]
+        ndist_local = last[2]["num_distances"]
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        nd = torch.tensor([ndist_local], device=device, dtype=torch.float64)
+        dist.all_reduce(nd, op=dist.ReduceOp.SUM)
+        ndist_total = float(nd.item())
+    else:
+        ndist_total = float(ndist_local)
+
+    if rank == 0:
+        off, m, st, _ = last
+        ms_per_step = 1e3 * elapsed / args.steps
+        value = ndist_total * args.steps / elapsed
+        # dominant kernel: the match kernel; live HIP-event duration per launch (rank 0)
+        avg_kernel_s = (kern_ms / max(kern_launches, 1)) * 1e-3
+        launches_per_step = max(kern_launches // max(args.steps, 1), 1)
+        ops_per_launch = ndist_local * OPS_PER_DISTANCE / launches_per_step
+        achieved = ops_per_launch / avg_kernel_s if avg_kernel_s > 0 else 0.0
+        out = {
+            "metric": "descriptor-pair distances/sec (exhaustive SIFT match: dot + top-2 + ratio + cross-check)",
+            "value": value,
+            "unit": "distances/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8 descriptors, int8 MFMA / int32 accumulate",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{num_images} images x {args.feats} descriptors, exhaustive match + "
+                            f"ratio test + cross-check (BASELINE.json configs[1] at N=1)",
+                "pairs_total": int(len(s1_all)),
+                "pairs_per_rank": int(len(s1)),
+                "distances_total": ndist_total,
+                "kernel": args.kernel,
+                "pairs_mfma": st["pairs_mfma"],
+                "pairs_dot4": st["pairs_dot4"],
+                "matches_rank0": int(m.shape[0]),
+                "sharding": "pairs sorted by image 2, contiguous slice per rank, arena replicated"
+                            + ("; RCCL all-gather of match tables per step" if world > 1 else ""),
+            },
+            "roofline": {
+                "bound": "mfma",
+                "achieved": achieved / 1e12,
+                "peak": INT8_DENSE_PEAK_OPS / 1e12,
+                "unit": "TOP/s (int8; 256 ops per descriptor-pair distance)",
+                "frac": achieved / INT8_DENSE_PEAK_OPS,
+                "traffic": None,
+                "kernel": "match_mfma_kernel" if st["pairs_mfma"] else "match_dot4_kernel",
+                "avg_kernel_ms": avg_kernel_s * 1e3,
+                "launches_per_step": launches_per_step,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            cores = os.cpu_count() or 1
+            arena_cpu = arena.cpu().numpy()
+            v, npairs, dt, (idx, coff, cm) = cpu_baseline(arena_cpu, s1, s2, args.cpu_sample_pairs, cores)
+            # the sample doubles as a full-size parity spot check of the timed GPU result
+            mism = 0
+            for k, p in enumerate(idx):
+                g = m[int(off[p]):int(off[p + 1])]
+                c = cm[int(coff[k]):int(coff[k + 1])]
+                if g.shape != c.shape or not np.array_equal(g, c):
+                    mism += 1
+            out["cpu_baseline"] = {
+                "value": v, "unit": "distances/s", "cores": cores, "kind": "port",
+                "sample": f"{npairs} seeded pairs of the same {num_images}x{args.feats} workload, "
+                          f"oracle/match_oracle.c (-O2, OpenMP, one pair per thread), {dt:.1f} s",
+                "gpu_vs_oracle_mismatching_pairs": mism,
+            }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,140 @@
+/*
+ * oracle/match_oracle.c — CPU restatement of COLMAP 3.9.1's brute-force SIFT matcher.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under pycolmap_amd/ may link, import or call this
+ * file; only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it, and
+ * only as the checker / the timed CPU baseline.
+ *
+ * PARITY UNPINNED: the arithmetic of this path lives in the un-vendored dependency
+ * COLMAP 3.9.1 (/root/reference/CMakeLists.txt:17, /root/reference/pyproject.toml:36),
+ * which is neither under /root/reference nor installable here, and the reference has no
+ * tests or golden vectors for this path (/root/reference/pyproject.toml:33 only imports
+ * the module).  This file restates the published algorithm of
+ *   colmap/feature/sift.cc: ComputeSiftDistanceMatrix, FindBestMatchesOneWayBruteForce,
+ *   FindBestMatchesBruteForce                                   
+ * anchored on the reference-side facts that ARE verifiable:
+ *   - descriptors are uint8, value = round(512 * v)     /root/reference/pycolmap/feature/sift.h:76-77
+ *   - option names max_ratio / max_distance / cross_check
+ *                                       /root/reference/pycolmap/pipeline/match_features.h:82-91
+ *   - matches are (uint32 idx1, uint32 idx2) rows /root/reference/pycolmap/estimators/two_view_geometry.h:19-29
+ *
+ * The restatement is deliberately literal (full int32 distance matrix, two scans), because
+ * it doubles as the "port" CPU baseline that bench.py times.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define AMC_DIM 128
+
+/* colmap/feature/sift.cc ComputeSiftDistanceMatrix: dists(i1,i2) = <d1[i1], d2[i2]> in int32.
+ * (SURVEY.md A.2 line "dist(i1,i2) = sum_k int(d1[i1][k]) * int(d2[i2][k])") */
+void oracle_sift_distance_matrix(const uint8_t* d1, int n1, const uint8_t* d2, int n2,
+                                 int32_t* dists /* n1*n2 row-major */) {
+    for (int i1 = 0; i1 < n1; ++i1) {
+        const uint8_t* a = d1 + (size_t)i1 * AMC_DIM;
+        for (int i2 = 0; i2 < n2; ++i2) {
+            const uint8_t* b = d2 + (size_t)i2 * AMC_DIM;
+            int32_t s = 0;
+            for (int k = 0; k < AMC_DIM; ++k) s += (int32_t)a[k] * (int32_t)b[k];
+            dists[(size_t)i1 * n2 + i2] = s;
+        }
+    }
+}
+
+/* colmap/feature/sift.cc FindBestMatchesOneWayBruteForce (SURVEY.md A.2 "one_way").
+ * `dists` is addressed as dists[r*row_stride + c*col_stride] so that the same code scans the
+ * matrix and its transpose (COLMAP passes dists.transpose()). */
+static void one_way(const int32_t* dists, int rows, int cols, size_t row_stride, size_t col_stride,
+                    float max_ratio, float max_distance, int32_t* matches /* rows */) {
+    const float kDistNorm = 1.0f / (512.0f * 512.0f);
+    for (int i1 = 0; i1 < rows; ++i1) {
+        int best_i2 = -1;
+        int32_t best = 0, second = 0;
+        matches[i1] = -1;
+        for (int i2 = 0; i2 < cols; ++i2) {
+            const int32_t d = dists[(size_t)i1 * row_stride + (size_t)i2 * col_stride];
+            if (d > best) {
+                best_i2 = i2;
+                second = best;
+                best = d;
+            } else if (d > second) {
+                second = d;
+            }
+        }
+        if (best_i2 == -1) continue;
+        const float best_dist_normed = acosf(fminf(kDistNorm * (float)best, 1.0f));
+        if (best_dist_normed > max_distance) continue;
+        const float second_best_dist_normed = acosf(fminf(kDistNorm * (float)second, 1.0f));
+        if (best_dist_normed >= max_ratio * second_best_dist_normed) continue;
+        matches[i1] = best_i2;
+    }
+}
+
+/* colmap/feature/sift.cc FindBestMatchesBruteForce (SURVEY.md A.2 "match").
+ * out_matches must hold 2*min(n1,n2) uint32 (idx1, idx2 interleaved). Returns #matches, or -1
+ * on allocation failure. max_ratio / max_distance are the double options cast to float at the
+ * call, as COLMAP does. */
+int oracle_match(const uint8_t* d1, int n1, const uint8_t* d2, int n2, double max_ratio,
+                 double max_distance, int cross_check, uint32_t* out_matches) {
+    if (n1 <= 0 || n2 <= 0) return 0;
+    int32_t* dists = (int32_t*)malloc((size_t)n1 * n2 * sizeof(int32_t));
+    int32_t* m12 = (int32_t*)malloc((size_t)n1 * sizeof(int32_t));
+    int32_t* m21 = (int32_t*)malloc((size_t)n2 * sizeof(int32_t));
+    if (!dists || !m12 || !m21) {
+        free(dists); free(m12); free(m21);
+        return -1;
+    }
+    oracle_sift_distance_matrix(d1, n1, d2, n2, dists);
+    const float r = (float)max_ratio, t = (float)max_distance;
+    one_way(dists, n1, n2, (size_t)n2, 1, r, t, m12);
+    if (cross_check) one_way(dists, n2, n1, 1, (size_t)n2, r, t, m21);
+    int num = 0;
+    for (int i1 = 0; i1 < n1; ++i1) {
+        if (m12[i1] == -1) continue;
+        if (cross_check && m21[m12[i1]] != i1) continue;
+        out_matches[2 * num] = (uint32_t)i1;
+        out_matches[2 * num + 1] = (uint32_t)m12[i1];
+        ++num;
+    }
+    free(dists); free(m12); free(m21);
+    return num;
+}
+
+/* Batched driver used by tests and by bench.py's cpu_baseline leg: descriptors of image s
+ * start at arena + row_offset[s]*128 and have rows[s] rows.  One pair per OpenMP thread
+ * ("one image pair per thread").  Results: counts[p] and matches at
+ * out_matches + 2*out_offsets[p] (caller sizes out_offsets by min(n1,n2) per pair).
+ * Returns 0, or -1 if any pair failed to allocate. */
+int oracle_match_pairs(const uint8_t* arena, const uint64_t* row_offset, const uint32_t* rows,
+                       const uint32_t* slot1, const uint32_t* slot2, size_t npairs,
+                       double max_ratio, double max_distance, int cross_check,
+                       const uint64_t* out_offsets, uint32_t* counts, uint32_t* out_matches,
+                       int num_threads) {
+    int failed = 0;
+    (void)num_threads;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 1) num_threads(num_threads > 0 ? num_threads : 1)
+#endif
+    for (long p = 0; p < (long)npairs; ++p) {
+        const uint32_t s1 = slot1[p], s2 = slot2[p];
+        const int c = oracle_match(arena + row_offset[s1] * AMC_DIM, (int)rows[s1],
+                                   arena + row_offset[s2] * AMC_DIM, (int)rows[s2], max_ratio,
+                                   max_distance, cross_check, out_matches + 2 * out_offsets[p]);
+        if (c < 0) {
+            failed = 1;
+            counts[p] = 0;
+        } else {
+            counts[p] = (uint32_t)c;
+        }
+    }
+    return failed ? -1 : 0;
+}
+
+/* acosf LUT exactly as the thresholds see it: lut[d] = acosf(min(d/512^2, 1)), d in [0, 262144].
+ * Exposed so tests can check the product's host-built LUT bit-for-bit against the same libm. */
+void oracle_acos_lut(float* lut /* 262145 */) {
+    const float kDistNorm = 1.0f / (512.0f * 512.0f);
+    for (int d = 0; d <= 262144; ++d) lut[d] = acosf(fminf(kDistNorm * (float)d, 1.0f));
+}

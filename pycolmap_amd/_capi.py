@@ -1,0 +1,170 @@
+"""ctypes view of libamc.so's C ABI (include/amc.h).
+
+Thin by design: every function here maps 1:1 to an `amc_*` entry point; no computation happens
+in Python and there is no fallback — if libamc.so is missing or no gfx950 device is visible the
+calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+import numpy as np
+
+_PKG = Path(__file__).resolve().parent
+LIB_PATH = _PKG / "libamc.so"
+
+AMC_OK = 0
+AMC_E_INVALID, AMC_E_HIP, AMC_E_NOMEM, AMC_E_STATE = -1, -2, -3, -4
+KERNEL_AUTO, KERNEL_MFMA, KERNEL_DOT4 = 0, 1, 2
+KERNELS = {"auto": KERNEL_AUTO, "mfma": KERNEL_MFMA, "dot4": KERNEL_DOT4}
+
+# every symbol include/amc.h declares (tests check the library exports all of them)
+EXPORTED_SYMBOLS = [
+    "amc_last_error", "amc_abi_version", "amc_device_count", "amc_ctx_create", "amc_ctx_destroy",
+    "amc_ctx_set_stream", "amc_ctx_reserve_slots", "amc_upload_descriptors",
+    "amc_upload_descriptors_device", "amc_match_pairs", "amc_match_result_free",
+    "amc_match_opts_default", "amc_get_acos_lut",
+]
+
+
+class AmcError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"amc error {code}: {msg}")
+        self.code = code
+
+
+class MatchOpts(C.Structure):
+    _fields_ = [("max_ratio", C.c_double), ("max_distance", C.c_double),
+                ("cross_check", C.c_int32), ("kernel", C.c_int32)]
+
+
+class MatchResult(C.Structure):
+    _fields_ = [("npairs", C.c_size_t), ("offsets", C.POINTER(C.c_uint64)),
+                ("matches", C.POINTER(C.c_uint32)), ("num_distances", C.c_uint64),
+                ("pairs_mfma", C.c_uint64), ("pairs_dot4", C.c_uint64),
+                ("device_ms", C.c_double), ("match_kernel_ms", C.c_double),
+                ("match_kernel_launches", C.c_uint32), ("_priv", C.c_void_p)]
+
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load libamc.so (raises if it has not been built: there is no fallback path)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise ImportError(
+            f"{LIB_PATH} not found — run `python -m pycolmap_amd.build` (hipcc, gfx950). "
+            "pycolmap_amd has no CPU fallback.")
+    lib = C.CDLL(str(LIB_PATH))
+    lib.amc_last_error.restype = C.c_char_p
+    lib.amc_abi_version.restype = C.c_int
+    lib.amc_device_count.restype = C.c_int
+    lib.amc_ctx_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+    lib.amc_ctx_destroy.argtypes = [C.c_void_p]
+    lib.amc_ctx_destroy.restype = None
+    lib.amc_ctx_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+    lib.amc_ctx_reserve_slots.argtypes = [C.c_void_p, C.c_uint32]
+    lib.amc_upload_descriptors.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
+    lib.amc_upload_descriptors_device.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
+    lib.amc_match_pairs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                    C.POINTER(MatchOpts), C.POINTER(MatchResult)]
+    lib.amc_match_result_free.argtypes = [C.POINTER(MatchResult)]
+    lib.amc_match_result_free.restype = None
+    lib.amc_match_opts_default.argtypes = [C.POINTER(MatchOpts)]
+    lib.amc_match_opts_default.restype = None
+    lib.amc_get_acos_lut.argtypes = [C.c_void_p, C.c_void_p]
+    _lib = lib
+    return lib
+
+
+def _check(rc: int) -> None:
+    if rc != AMC_OK:
+        raise AmcError(rc, load().amc_last_error().decode(errors="replace"))
+
+
+def device_count() -> int:
+    n = load().amc_device_count()
+    if n < 0:
+        _check(n)
+    return n
+
+
+class Context:
+    """One amc_ctx (one GPU). Owns device copies of every uploaded image."""
+
+    def __init__(self, device_id: int = 0):
+        self._lib = load()
+        h = C.c_void_p()
+        _check(self._lib.amc_ctx_create(device_id, C.byref(h)))
+        self._h = h
+        self.device_id = device_id
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._lib.amc_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def set_stream(self, hip_stream: int | None) -> None:
+        _check(self._lib.amc_ctx_set_stream(self._h, C.c_void_p(hip_stream or 0)))
+
+    def reserve_slots(self, n: int) -> None:
+        _check(self._lib.amc_ctx_reserve_slots(self._h, n))
+
+    def upload_descriptors(self, slot: int, desc: np.ndarray) -> None:
+        d = np.ascontiguousarray(desc, dtype=np.uint8)
+        if d.size and (d.ndim != 2 or d.shape[1] != 128):
+            raise ValueError(f"descriptors must be N x 128 uint8, got {d.shape}")
+        rows = d.shape[0] if d.ndim == 2 else 0
+        _check(self._lib.amc_upload_descriptors(self._h, slot, d.ctypes.data_as(C.c_void_p), rows))
+
+    def upload_descriptors_device(self, slot: int, dev_ptr: int, rows: int) -> None:
+        _check(self._lib.amc_upload_descriptors_device(self._h, slot, C.c_void_p(dev_ptr), rows))
+
+    def match_pairs(self, slot1, slot2, max_ratio: float = 0.8, max_distance: float = 0.7,
+                    cross_check: bool = True, kernel: str = "auto"):
+        """Returns (offsets uint64[npairs+1], matches uint32[M,2], stats dict)."""
+        s1 = np.ascontiguousarray(slot1, dtype=np.uint32)
+        s2 = np.ascontiguousarray(slot2, dtype=np.uint32)
+        if s1.shape != s2.shape or s1.ndim != 1:
+            raise ValueError("slot1/slot2 must be equal-length 1-D arrays")
+        opts = MatchOpts(max_ratio, max_distance, 1 if cross_check else 0, KERNELS[kernel])
+        res = MatchResult()
+        _check(self._lib.amc_match_pairs(self._h, s1.ctypes.data_as(C.c_void_p),
+                                         s2.ctypes.data_as(C.c_void_p), s1.size, C.byref(opts),
+                                         C.byref(res)))
+        try:
+            n = int(res.npairs)
+            offsets = np.ctypeslib.as_array(res.offsets, shape=(n + 1,)).copy()
+            total = int(offsets[-1])
+            if total:
+                matches = np.ctypeslib.as_array(res.matches, shape=(total, 2)).copy()
+            else:
+                matches = np.zeros((0, 2), dtype=np.uint32)
+            stats = dict(num_distances=int(res.num_distances), pairs_mfma=int(res.pairs_mfma),
+                         pairs_dot4=int(res.pairs_dot4), device_ms=float(res.device_ms),
+                         match_kernel_ms=float(res.match_kernel_ms),
+                         match_kernel_launches=int(res.match_kernel_launches))
+        finally:
+            self._lib.amc_match_result_free(C.byref(res))
+        return offsets, matches, stats
+
+    def acos_lut(self) -> np.ndarray:
+        out = np.empty(262145, dtype=np.float32)
+        _check(self._lib.amc_get_acos_lut(self._h, out.ctypes.data_as(C.c_void_p)))
+        return out

@@ -1,0 +1,85 @@
+"""Build libamc.so (HIP kernels + C-ABI, gfx950) in-tree with hipcc.
+
+`python -m pycolmap_amd.build` or `pycolmap_amd.build.build_all()`.  hipcc cross-compiles for
+gfx950 without a GPU, so this runs in the CPU-only container; the resulting .so files travel to
+the GPU box with the repo snapshot.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+from pathlib import Path
+
+PKG = Path(__file__).resolve().parent
+ROOT = PKG.parent
+CSRC = PKG / "csrc"
+OBJ = CSRC / "_obj"
+LIB = PKG / "libamc.so"
+
+HIP_SOURCES = ["amc_api.hip", "match_common.hip", "match_dot4.hip", "match_mfma.hip", "tvg.hip"]
+HIPCC_FLAGS = [
+    "--offload-arch=gfx950",
+    "-O3",
+    "-std=c++17",
+    "-fPIC",
+    "-ffp-contract=off",  # host<->device FP64 bit parity for the verification kernels
+    "-fno-fast-math",
+    "-Wall",
+    "-Wno-unused-function",
+]
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and Path(cand).exists():
+            return cand
+    raise RuntimeError("hipcc not found: libamc.so cannot be built (there is no CPU fallback)")
+
+
+def _stale(target: Path, deps: list[Path]) -> bool:
+    if not target.exists():
+        return True
+    t = target.stat().st_mtime
+    return any(d.exists() and d.stat().st_mtime > t for d in deps)
+
+
+def build_libamc(force: bool = False, verbose: bool = True) -> Path:
+    hipcc = _hipcc()
+    OBJ.mkdir(exist_ok=True)
+    headers = list(CSRC.glob("*.h")) + list((ROOT / "include").glob("*.h"))
+    objs = []
+    for name in HIP_SOURCES:
+        src = CSRC / name
+        if not src.exists():
+            continue
+        obj = OBJ / (src.stem + ".o")
+        if force or _stale(obj, [src] + headers):
+            cmd = [hipcc, *HIPCC_FLAGS, "-c", str(src), "-o", str(obj)]
+            if verbose:
+                print("[build]", " ".join(cmd), flush=True)
+            subprocess.run(cmd, check=True)
+        objs.append(obj)
+    if force or _stale(LIB, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB), *map(str, objs)]
+        if verbose:
+            print("[build]", " ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+    return LIB
+
+
+def build_oracle(verbose: bool = True) -> Path:
+    """Compile the CPU oracle (test infrastructure; building the checker is not using it)."""
+    out = subprocess.run(["make", "-C", str(ROOT / "oracle")], capture_output=not verbose, check=True)
+    del out
+    return ROOT / "oracle" / "_build" / "liboracle.so"
+
+
+def build_all(force: bool = False, verbose: bool = True) -> None:
+    build_libamc(force=force, verbose=verbose)
+    build_oracle(verbose=verbose)
+
+
+if __name__ == "__main__":
+    build_all(force="--force" in sys.argv)

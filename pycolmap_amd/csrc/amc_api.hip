@@ -1,0 +1,540 @@
+// amc_api.hip — host side of libamc.so: implements include/amc.h on top of the HIP kernels.
+// No CPU fallback: every entry point that computes needs a gfx950 device.
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "amc_internal.h"
+
+using namespace amc;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                        \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess)                                                               \
+            return fail(AMC_E_HIP, "%s:%d: %s -> %s", __FILE__, __LINE__, #expr,            \
+                        hipGetErrorString(e_));                                             \
+    } while (0)
+
+inline uint32_t round_up(uint32_t x, uint32_t m) { return (x + m - 1) / m * m; }
+
+struct Slot {
+    void* base = nullptr;  // one allocation: raw | prep | rs128
+    ImageDev dev{};
+    uint32_t maxsq = 0;    // max_r |raw[r]|^2
+    bool valid = false;
+};
+
+// grow-only device / pinned-host scratch
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t n) {
+        if (n <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = std::max(n, (size_t)16);
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), want * sizeof(T));
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+template <typename T>
+struct PinBuf {
+    T* p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t n) {
+        if (n <= cap) return hipSuccess;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = std::max(n, (size_t)16);
+        hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&p), want * sizeof(T), 0);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+}  // namespace
+
+struct amc_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    std::vector<Slot> slots;
+    bool table_dirty = true;
+    DevBuf<ImageDev> d_imgs;
+    float* d_lut = nullptr;
+    std::vector<float> h_lut;
+    uint32_t* d_scalars = nullptr;  // [0] cursor, [1] queue head, [2] maxsq scratch
+    // per-batch scratch
+    DevBuf<PairDev> d_pairs;
+    DevBuf<Dot4Work> d_work;
+    DevBuf<uint32_t> d_order;
+    DevBuf<Top2> d_rowbuf, d_colbuf;
+    DevBuf<uint32_t> d_pair_off, d_pair_cnt, d_matches;
+    PinBuf<PairDev> h_pairs;
+    PinBuf<Dot4Work> h_work;
+    PinBuf<uint32_t> h_order, h_pair_off, h_pair_cnt, h_matches, h_scalars;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+};
+
+extern "C" {
+
+const char* amc_last_error(void) { return g_err.c_str(); }
+int amc_abi_version(void) { return AMC_ABI_VERSION; }
+
+int amc_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        if (e == hipErrorNoDevice) return 0;
+        return fail(AMC_E_HIP, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    }
+    return n;
+}
+
+void amc_match_opts_default(amc_match_opts* o) {
+    if (!o) return;
+    o->max_ratio = 0.8;     // SiftMatchingOptions defaults, SURVEY.md A.2
+    o->max_distance = 0.7;
+    o->cross_check = 1;
+    o->kernel = AMC_KERNEL_AUTO;
+}
+
+int amc_ctx_create(int device_id, amc_ctx** out) {
+    if (!out) return fail(AMC_E_INVALID, "amc_ctx_create: out is NULL");
+    *out = nullptr;
+    int n = 0;
+    HIPCHK(hipGetDeviceCount(&n));
+    if (device_id < 0 || device_id >= n)
+        return fail(AMC_E_INVALID, "amc_ctx_create: device %d out of range (%d devices)",
+                    device_id, n);
+    HIPCHK(hipSetDevice(device_id));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device_id));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(AMC_E_HIP, "amc_ctx_create: device %d is %s; this library is gfx950-only",
+                    device_id, prop.gcnArchName);
+    amc_ctx* c = new (std::nothrow) amc_ctx();
+    if (!c) return fail(AMC_E_NOMEM, "amc_ctx_create: out of host memory");
+    c->device = device_id;
+    hipError_t e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete c;
+        return fail(AMC_E_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
+    }
+    c->stream = c->own_stream;
+    for (auto& ev : c->ev) (void)hipEventCreate(&ev);
+    // acos table with the HOST libm (the same one COLMAP's CPU path and the oracle call)
+    c->h_lut.resize(kAcosLutSize);
+    const float kDistNorm = 1.0f / (512.0f * 512.0f);
+    for (int d = 0; d < kAcosLutSize; ++d)
+        c->h_lut[d] = acosf(std::fmin(kDistNorm * (float)d, 1.0f));
+    if (hipMalloc(reinterpret_cast<void**>(&c->d_lut), kAcosLutSize * sizeof(float)) !=
+            hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&c->d_scalars), 16 * sizeof(uint32_t)) !=
+            hipSuccess ||
+        hipMemcpy(c->d_lut, c->h_lut.data(), kAcosLutSize * sizeof(float),
+                  hipMemcpyHostToDevice) != hipSuccess ||
+        c->h_scalars.ensure(16) != hipSuccess) {
+        amc_ctx_destroy(c);
+        return fail(AMC_E_HIP, "amc_ctx_create: device allocation failed");
+    }
+    *out = c;
+    return AMC_OK;
+}
+
+static void free_slot(Slot& s) {
+    if (s.base) (void)hipFree(s.base);
+    s = Slot();
+}
+
+void amc_ctx_destroy(amc_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    for (auto& s : c->slots) free_slot(s);
+    c->d_imgs.release();
+    if (c->d_lut) (void)hipFree(c->d_lut);
+    if (c->d_scalars) (void)hipFree(c->d_scalars);
+    c->d_pairs.release(); c->d_work.release(); c->d_order.release();
+    c->d_rowbuf.release(); c->d_colbuf.release();
+    c->d_pair_off.release(); c->d_pair_cnt.release(); c->d_matches.release();
+    c->h_pairs.release(); c->h_work.release(); c->h_order.release();
+    c->h_pair_off.release(); c->h_pair_cnt.release(); c->h_matches.release();
+    c->h_scalars.release();
+    for (auto& ev : c->ev)
+        if (ev) (void)hipEventDestroy(ev);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+int amc_ctx_set_stream(amc_ctx* c, void* hip_stream) {
+    if (!c) return fail(AMC_E_INVALID, "amc_ctx_set_stream: ctx is NULL");
+    c->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : c->own_stream;
+    return AMC_OK;
+}
+
+int amc_ctx_reserve_slots(amc_ctx* c, uint32_t num_slots) {
+    if (!c) return fail(AMC_E_INVALID, "amc_ctx_reserve_slots: ctx is NULL");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (auto& s : c->slots) free_slot(s);
+    c->slots.assign(num_slots, Slot());
+    c->table_dirty = true;
+    return AMC_OK;
+}
+
+static int upload_common(amc_ctx* c, uint32_t slot, const void* src, uint32_t rows,
+                         hipMemcpyKind kind) {
+    if (!c) return fail(AMC_E_INVALID, "upload_descriptors: ctx is NULL");
+    if (slot >= c->slots.size())
+        return fail(AMC_E_INVALID, "upload_descriptors: slot %u >= reserved %zu", slot,
+                    c->slots.size());
+    if (rows > 0 && !src) return fail(AMC_E_INVALID, "upload_descriptors: NULL data, rows=%u", rows);
+    if (rows > (1u << 30)) return fail(AMC_E_INVALID, "upload_descriptors: rows=%u too large", rows);
+    HIPCHK(hipSetDevice(c->device));
+    Slot& s = c->slots[slot];
+    if (s.base) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        free_slot(s);
+    }
+    c->table_dirty = true;
+    s.valid = true;
+    s.dev.rows = rows;
+    s.dev.rows_pad = round_up(rows, kRowPad);
+    s.maxsq = 0;
+    if (rows == 0) return AMC_OK;
+    const size_t rp = s.dev.rows_pad;
+    const size_t bytes = rp * kDim * 2 + rp * sizeof(int32_t);
+    hipError_t e = hipMalloc(&s.base, bytes);
+    if (e != hipSuccess) {
+        s = Slot();
+        return fail(AMC_E_NOMEM, "upload_descriptors: hipMalloc(%zu): %s", bytes,
+                    hipGetErrorString(e));
+    }
+    uint8_t* raw = static_cast<uint8_t*>(s.base);
+    uint8_t* prep = raw + rp * kDim;
+    int32_t* rs = reinterpret_cast<int32_t*>(prep + rp * kDim);
+    s.dev.raw = raw;
+    s.dev.prep = prep;
+    s.dev.rs128 = rs;
+    HIPCHK(hipMemcpyAsync(raw, src, (size_t)rows * kDim, kind, c->stream));
+    if (rp > rows)
+        HIPCHK(hipMemsetAsync(raw + (size_t)rows * kDim, 0, (rp - rows) * kDim, c->stream));
+    HIPCHK(hipMemsetAsync(c->d_scalars + 2, 0, sizeof(uint32_t), c->stream));
+    launch_prep(raw, prep, rs, s.dev.rows_pad, c->d_scalars + 2, c->stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(c->h_scalars.p + 2, c->d_scalars + 2, sizeof(uint32_t),
+                          hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    s.maxsq = c->h_scalars.p[2];
+    return AMC_OK;
+}
+
+int amc_upload_descriptors(amc_ctx* c, uint32_t slot, const uint8_t* host_desc, uint32_t rows) {
+    return upload_common(c, slot, host_desc, rows, hipMemcpyHostToDevice);
+}
+int amc_upload_descriptors_device(amc_ctx* c, uint32_t slot, const void* dev_desc,
+                                  uint32_t rows) {
+    return upload_common(c, slot, dev_desc, rows, hipMemcpyDeviceToDevice);
+}
+
+int amc_get_acos_lut(amc_ctx* c, float* out) {
+    if (!c || !out) return fail(AMC_E_INVALID, "amc_get_acos_lut: NULL argument");
+    HIPCHK(hipSetDevice(c->device));
+    // read it back from the device so the test sees what the kernels see
+    HIPCHK(hipMemcpy(out, c->d_lut, kAcosLutSize * sizeof(float), hipMemcpyDeviceToHost));
+    return AMC_OK;
+}
+
+namespace {
+
+struct ResultPriv {
+    std::vector<uint64_t> offsets;
+    std::vector<uint32_t> matches;
+};
+
+int ceil_log2(uint32_t x) {
+    int b = 0;
+    while ((1u << b) < x) ++b;
+    return b;
+}
+
+// limits for one batch (bytes of device scratch)
+constexpr size_t kMaxTop2Entries = (size_t)48 << 20;   // 48 Mi entries x 16 B = 768 MiB per side
+constexpr size_t kMaxMatchCap = (size_t)48 << 20;      // 48 Mi matches x 8 B = 384 MiB
+
+}  // namespace
+
+int amc_match_pairs(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, size_t npairs,
+                    const amc_match_opts* opts_in, amc_match_result* out) {
+    if (!c || !out) return fail(AMC_E_INVALID, "amc_match_pairs: NULL ctx/out");
+    std::memset(out, 0, sizeof *out);
+    if (npairs > 0 && (!slot1 || !slot2))
+        return fail(AMC_E_INVALID, "amc_match_pairs: NULL pair arrays");
+    amc_match_opts o;
+    if (opts_in) o = *opts_in; else amc_match_opts_default(&o);
+    if (o.kernel != AMC_KERNEL_AUTO && o.kernel != AMC_KERNEL_MFMA && o.kernel != AMC_KERNEL_DOT4)
+        return fail(AMC_E_INVALID, "amc_match_pairs: unknown kernel %d", o.kernel);
+    for (size_t i = 0; i < npairs; ++i) {
+        if (slot1[i] >= c->slots.size() || slot2[i] >= c->slots.size())
+            return fail(AMC_E_INVALID, "amc_match_pairs: pair %zu references slot out of range", i);
+        if (!c->slots[slot1[i]].valid || !c->slots[slot2[i]].valid)
+            return fail(AMC_E_STATE, "amc_match_pairs: pair %zu references a slot with no "
+                        "descriptors uploaded", i);
+    }
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+
+    if (c->table_dirty) {
+        HIPCHK(c->d_imgs.ensure(c->slots.size()));
+        std::vector<ImageDev> t(c->slots.size());
+        for (size_t i = 0; i < t.size(); ++i) t[i] = c->slots[i].dev;
+        if (!t.empty())
+            HIPCHK(hipMemcpy(c->d_imgs.p, t.data(), t.size() * sizeof(ImageDev),
+                             hipMemcpyHostToDevice));
+        c->table_dirty = false;
+    }
+
+    ResultPriv* priv = new (std::nothrow) ResultPriv();
+    if (!priv) return fail(AMC_E_NOMEM, "amc_match_pairs: out of host memory");
+    priv->offsets.assign(npairs + 1, 0);
+
+    const float max_ratio_f = (float)o.max_ratio;
+    // value-mode cross check (mfma kernel) is exact iff ties always fail the ratio test
+    const bool value_mode_ok = !o.cross_check || (max_ratio_f <= 1.0f);
+    const size_t mfma_max_cols = match_mfma_max_cols();
+
+    uint64_t num_dist = 0, n_mfma = 0, n_dot4 = 0;
+    double kernel_ms = 0.0;
+    uint32_t kernel_launches = 0;
+    HIPCHK(hipEventRecord(c->ev[0], st));
+
+    size_t begin = 0;
+    int rc = AMC_OK;
+    while (begin < npairs && rc == AMC_OK) {
+        // ---- carve a batch ---------------------------------------------------------------
+        size_t end = begin, top_rows = 0, top_cols = 0, cap = 0;
+        while (end < npairs) {
+            const Slot& a = c->slots[slot1[end]];
+            const Slot& b = c->slots[slot2[end]];
+            const size_t nr = a.dev.rows_pad, nc = b.dev.rows_pad;
+            const size_t mc = std::min(a.dev.rows, b.dev.rows);
+            if (end > begin && (top_rows + nr > kMaxTop2Entries || top_cols + nc > kMaxTop2Entries ||
+                                cap + mc > kMaxMatchCap || end - begin >= (1u << 24)))
+                break;
+            top_rows += nr; top_cols += nc; cap += mc; ++end;
+        }
+        const size_t nb = end - begin;
+        auto hc = [&](hipError_t e, const char* what) {
+            if (e != hipSuccess && rc == AMC_OK)
+                rc = fail(AMC_E_HIP, "amc_match_pairs: %s: %s", what, hipGetErrorString(e));
+            return e == hipSuccess;
+        };
+        if (!hc(c->h_pairs.ensure(nb), "pinned pairs") || !hc(c->d_pairs.ensure(nb), "dev pairs") ||
+            !hc(c->h_order.ensure(nb), "pinned order") || !hc(c->d_order.ensure(nb), "dev order") ||
+            !hc(c->d_rowbuf.ensure(top_rows), "row top2") || !hc(c->d_colbuf.ensure(top_cols), "col top2") ||
+            !hc(c->d_pair_off.ensure(nb), "pair_off") || !hc(c->d_pair_cnt.ensure(nb), "pair_cnt") ||
+            !hc(c->h_pair_off.ensure(nb), "pinned pair_off") || !hc(c->h_pair_cnt.ensure(nb), "pinned pair_cnt") ||
+            !hc(c->d_matches.ensure(2 * cap), "dev matches") || !hc(c->h_matches.ensure(2 * cap), "pinned matches"))
+            break;
+
+        // ---- route each pair to a kernel -------------------------------------------------
+        uint32_t max_cols_mfma = 0;
+        std::vector<uint8_t> want_mfma(nb, 0);
+        for (size_t i = 0; i < nb; ++i) {
+            const Slot& a = c->slots[slot1[begin + i]];
+            const Slot& b = c->slots[slot2[begin + i]];
+            const bool nonempty = a.dev.rows > 0 && b.dev.rows > 0;
+            bool ok = nonempty && o.kernel != AMC_KERNEL_DOT4 && value_mode_ok &&
+                      b.dev.rows_pad <= mfma_max_cols;
+            want_mfma[i] = ok;
+            if (ok) max_cols_mfma = std::max(max_cols_mfma, b.dev.rows_pad);
+        }
+        const int shift = std::min(13, std::max(10, ceil_log2(std::max(max_cols_mfma, 1u))));
+        const uint64_t vlimit = 1ull << (32 - shift);  // need max dot < vlimit
+        size_t row_off = 0, col_off = 0, nwork = 0, nord = 0;
+        for (size_t i = 0; i < nb; ++i) {
+            const Slot& a = c->slots[slot1[begin + i]];
+            const Slot& b = c->slots[slot2[begin + i]];
+            if (want_mfma[i]) {
+                // Cauchy-Schwarz: dot^2 <= |a|^2 |b|^2
+                const uint64_t prod = (uint64_t)a.maxsq * (uint64_t)b.maxsq;
+                if (prod >= vlimit * vlimit) want_mfma[i] = 0;
+            }
+            const bool nonempty = a.dev.rows > 0 && b.dev.rows > 0;
+            if (o.kernel == AMC_KERNEL_MFMA && nonempty && !want_mfma[i]) {
+                rc = fail(AMC_E_INVALID,
+                          "amc_match_pairs: kernel=MFMA forced but pair %zu is not eligible "
+                          "(cols_pad=%u, maxsq=%u,%u, max_ratio=%g)", begin + i, b.dev.rows_pad,
+                          a.maxsq, b.maxsq, o.max_ratio);
+                break;
+            }
+            PairDev& pd = c->h_pairs.p[i];
+            pd.slot1 = slot1[begin + i];
+            pd.slot2 = slot2[begin + i];
+            pd.mode = want_mfma[i] ? 1u : 0u;
+            pd.pad = 0;
+            pd.row_off = row_off;
+            pd.col_off = col_off;
+            row_off += a.dev.rows_pad;
+            col_off += b.dev.rows_pad;
+            num_dist += (uint64_t)a.dev.rows * b.dev.rows;
+            if (!nonempty) continue;
+            if (want_mfma[i]) {
+                c->h_order.p[nord++] = (uint32_t)i;
+                ++n_mfma;
+            } else {
+                nwork += (a.dev.rows + 63) / 64;
+                if (o.cross_check) nwork += (b.dev.rows + 63) / 64;
+                ++n_dot4;
+            }
+        }
+        if (rc != AMC_OK) break;
+        // mfma queue order: group by image 2 so co-resident workgroups stream the same B
+        std::stable_sort(c->h_order.p, c->h_order.p + nord, [&](uint32_t x, uint32_t y) {
+            const PairDev& px = c->h_pairs.p[x];
+            const PairDev& py = c->h_pairs.p[y];
+            return px.slot2 != py.slot2 ? px.slot2 < py.slot2 : px.slot1 < py.slot1;
+        });
+        if (nwork) {
+            if (!hc(c->h_work.ensure(nwork), "pinned work") || !hc(c->d_work.ensure(nwork), "dev work"))
+                break;
+            size_t w = 0;
+            for (size_t i = 0; i < nb; ++i) {
+                if (c->h_pairs.p[i].mode) continue;
+                const Slot& a = c->slots[slot1[begin + i]];
+                const Slot& b = c->slots[slot2[begin + i]];
+                if (a.dev.rows == 0 || b.dev.rows == 0) continue;
+                for (uint32_t rb = 0; rb < (a.dev.rows + 63) / 64; ++rb)
+                    c->h_work.p[w++] = Dot4Work{(uint32_t)i, 0u, rb};
+                if (o.cross_check)
+                    for (uint32_t rb = 0; rb < (b.dev.rows + 63) / 64; ++rb)
+                        c->h_work.p[w++] = Dot4Work{(uint32_t)i, 1u, rb};
+            }
+        }
+
+        // ---- enqueue ------------------------------------------------------------------
+        bool okq = hc(hipMemcpyAsync(c->d_pairs.p, c->h_pairs.p, nb * sizeof(PairDev),
+                                     hipMemcpyHostToDevice, st), "H2D pairs") &&
+                   hc(hipMemsetAsync(c->d_scalars, 0, 2 * sizeof(uint32_t), st), "memset cursor");
+        if (okq && nord)
+            okq = hc(hipMemcpyAsync(c->d_order.p, c->h_order.p, nord * sizeof(uint32_t),
+                                    hipMemcpyHostToDevice, st), "H2D order");
+        if (okq && nwork)
+            okq = hc(hipMemcpyAsync(c->d_work.p, c->h_work.p, nwork * sizeof(Dot4Work),
+                                    hipMemcpyHostToDevice, st), "H2D work");
+        if (!okq) break;
+        (void)hipEventRecord(c->ev[2], st);
+        if (nord)
+            launch_match_mfma(c->d_imgs.p, c->d_pairs.p, c->d_order.p, (uint32_t)nord, shift,
+                              o.cross_check, c->d_scalars + 1, c->d_rowbuf.p, c->d_colbuf.p, st);
+        if (nwork)
+            launch_match_dot4(c->d_imgs.p, c->d_pairs.p, c->d_work.p, (uint32_t)nwork,
+                              c->d_rowbuf.p, c->d_colbuf.p, st);
+        (void)hipEventRecord(c->ev[3], st);
+        kernel_launches += (nord ? 1 : 0) + (nwork ? 1 : 0);
+        FinalizeParams fp;
+        fp.max_ratio = max_ratio_f;
+        fp.max_distance = (float)o.max_distance;
+        fp.cross_check = o.cross_check ? 1 : 0;
+        fp.value_mode = 0;
+        launch_finalize(c->d_imgs.p, c->d_pairs.p, (uint32_t)nb, c->d_rowbuf.p, c->d_colbuf.p,
+                        c->d_lut, fp, c->d_scalars, (uint32_t)std::min(cap, (size_t)0xFFFFFFFFu),
+                        c->d_pair_off.p, c->d_pair_cnt.p, c->d_matches.p, st);
+        if (!hc(hipGetLastError(), "kernel launch")) break;
+        if (!hc(hipMemcpyAsync(c->h_scalars.p, c->d_scalars, sizeof(uint32_t),
+                               hipMemcpyDeviceToHost, st), "D2H cursor") ||
+            !hc(hipMemcpyAsync(c->h_pair_off.p, c->d_pair_off.p, nb * sizeof(uint32_t),
+                               hipMemcpyDeviceToHost, st), "D2H pair_off") ||
+            !hc(hipMemcpyAsync(c->h_pair_cnt.p, c->d_pair_cnt.p, nb * sizeof(uint32_t),
+                               hipMemcpyDeviceToHost, st), "D2H pair_cnt") ||
+            !hc(hipStreamSynchronize(st), "sync after batch kernels"))
+            break;
+        const uint32_t total = c->h_scalars.p[0];
+        if (total > cap) {
+            rc = fail(AMC_E_HIP, "amc_match_pairs: internal: %u matches exceed capacity %zu",
+                      total, cap);
+            break;
+        }
+        if (total &&
+            (!hc(hipMemcpyAsync(c->h_matches.p, c->d_matches.p, (size_t)total * 2 * sizeof(uint32_t),
+                                hipMemcpyDeviceToHost, st), "D2H matches") ||
+             !hc(hipStreamSynchronize(st), "sync after D2H")))
+            break;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, c->ev[2], c->ev[3]) == hipSuccess) kernel_ms += ms;
+        // ---- scatter into the CSR (pairs keep the caller's order) --------------------------
+        for (size_t i = 0; i < nb; ++i) {
+            const uint32_t cnt = c->h_pair_cnt.p[i];
+            const uint32_t off = c->h_pair_off.p[i];
+            priv->offsets[begin + i + 1] = priv->offsets[begin + i] + cnt;
+            if (cnt)
+                priv->matches.insert(priv->matches.end(), c->h_matches.p + 2ull * off,
+                                     c->h_matches.p + 2ull * (off + cnt));
+        }
+        begin = end;
+    }
+    if (rc != AMC_OK) {
+        delete priv;
+        return rc;
+    }
+    HIPCHK(hipEventRecord(c->ev[1], st));
+    HIPCHK(hipEventSynchronize(c->ev[1]));
+    float total_ms = 0.f;
+    (void)hipEventElapsedTime(&total_ms, c->ev[0], c->ev[1]);
+
+    out->npairs = npairs;
+    out->offsets = priv->offsets.data();
+    out->matches = priv->matches.empty() ? nullptr : priv->matches.data();
+    out->num_distances = num_dist;
+    out->pairs_mfma = n_mfma;
+    out->pairs_dot4 = n_dot4;
+    out->device_ms = total_ms;
+    out->match_kernel_ms = kernel_ms;
+    out->match_kernel_launches = kernel_launches;
+    out->_priv = priv;
+    return AMC_OK;
+}
+
+void amc_match_result_free(amc_match_result* r) {
+    if (!r) return;
+    delete static_cast<ResultPriv*>(r->_priv);
+    std::memset(r, 0, sizeof *r);
+}
+
+}  // extern "C"

@@ -1,0 +1,87 @@
+// amc_internal.h — shared between the host-side C-ABI implementation and the HIP kernels.
+// gfx950-only; no CPU fallback anywhere in this directory.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/amc.h"
+
+namespace amc {
+
+// ----- arena geometry -------------------------------------------------------------------
+// Every image's descriptor block is zero-padded to a multiple of kRowPad rows.  A zero
+// descriptor has dot product 0 with everything, and COLMAP's scan only admits values > 0
+// (best=0, second=0 floors, strict '>'), so padded rows/columns can never
+// become a best or raise a second: no bounds checks inside the kernels.
+constexpr int kDim = AMC_DESC_DIM;   // 128 bytes per descriptor
+constexpr int kRowPad = 256;         // = MFMA kernel's column chunk; multiple of every tile
+constexpr int kAcosLutSize = 262145; // d in [0, 512*512]
+
+// Device-side view of one image slot.
+struct ImageDev {
+    const uint8_t* raw;    // rows_pad x 128 u8, row-major, zero padded (dot4 kernel)
+    const uint8_t* prep;   // rows_pad x 128, bytes ^0x80 (= u8-128 as i8), 16-B slots of row r
+                           // stored at slot (q ^ ((r>>1)&7)) (LDS-bank swizzle), zero rows = 0x80
+    const int32_t* rs128;  // rows_pad: 128 * sum_k raw[r][k]
+    uint32_t rows;
+    uint32_t rows_pad;
+};
+
+// One-way top-2 record, the common intermediate of both match kernels (16 B).
+//   best_v   : best dot product (true value), 0 if none > 0
+//   best_idx : its index (lowest index among ties); 0xFFFFFFFF if none or if the producing
+//              kernel does not track indices for this side (value-mode columns)
+//   second_v : second-largest value with multiplicity, floor 0
+struct Top2 {
+    uint32_t best_v;
+    uint32_t best_idx;
+    uint32_t second_v;
+    uint32_t pad;
+};
+
+// A pair inside one batch.
+struct PairDev {
+    uint32_t slot1, slot2;
+    uint32_t mode;     // 1: produced by the mfma kernel (value-mode columns), 0: dot4 kernel
+    uint32_t pad;
+    uint64_t row_off;  // into the batch's Top2 row buffer (rows_pad(slot1) entries)
+    uint64_t col_off;  // into the batch's Top2 col buffer (rows_pad(slot2) entries)
+};
+
+// dot4 work item: one 64-row block of one direction of one pair.
+struct Dot4Work {
+    uint32_t pair;   // index into PairDev[]
+    uint32_t dir;    // 0: rows = image1 vs image2 ; 1: rows = image2 vs image1
+    uint32_t rb;     // 64-row block index
+};
+
+struct FinalizeParams {
+    float max_ratio;
+    float max_distance;
+    int cross_check;
+    int value_mode;  // 1: columns carry no index; cross-check by value equality (needs
+                     // max_ratio <= 1); 0: compare indices
+};
+
+// ----- launchers (defined in the .hip files) ---------------------------------------------
+void launch_prep(const uint8_t* raw, uint8_t* prep, int32_t* rs128, uint32_t rows_pad,
+                 uint32_t* maxsq_out, hipStream_t s);
+
+void launch_match_dot4(const ImageDev* imgs, const PairDev* pairs, const Dot4Work* work,
+                       uint32_t nwork, Top2* rowbuf, Top2* colbuf, hipStream_t s);
+
+// mfma: one workgroup per pair, dynamic queue over `order` (pair indices, sorted for L2 reuse).
+// shift = index bits of the packed row keys (all pairs in the launch satisfy
+// rows_pad(slot2) <= 1<<shift and max dot < 1<<(32-shift)).
+void launch_match_mfma(const ImageDev* imgs, const PairDev* pairs, const uint32_t* order,
+                       uint32_t npairs, int shift, int cross_check, uint32_t* queue_head,
+                       Top2* rowbuf, Top2* colbuf, hipStream_t s);
+size_t match_mfma_max_cols();  // largest rows_pad(slot2) the mfma kernel's LDS layout admits
+
+void launch_finalize(const ImageDev* imgs, const PairDev* pairs, uint32_t npairs,
+                     const Top2* rowbuf, const Top2* colbuf, const float* acos_lut,
+                     FinalizeParams fp, uint32_t* cursor, uint32_t capacity, uint32_t* pair_off,
+                     uint32_t* pair_cnt, uint32_t* matches, hipStream_t s);
+
+}  // namespace amc

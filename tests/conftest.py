@@ -1,0 +1,31 @@
+import os
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _have_gpu() -> bool:
+    try:
+        from pycolmap_amd import _capi
+        return _capi.device_count() > 0
+    except Exception:
+        return False
+
+
+@pytest.fixture(scope="session")
+def amc_ctx():
+    """A live libamc context on device 0.  GPU tests must FAIL (not skip) if the native library
+    is missing: there is no fallback path to hide behind."""
+    from pycolmap_amd import _capi
+    ctx = _capi.Context(0)
+    yield ctx
+    ctx.close()

@@ -1,0 +1,180 @@
+"""GPU parity tests: libamc.so (HIP kernels through the C ABI) vs the CPU oracle on identical
+seeded inputs.  Bit-exact: integer match indices must be identical (BASELINE.json north_star).
+Both kernels (int8-MFMA and u8 dot4) are exercised explicitly and via AUTO routing."""
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import oracle_lib
+from pycolmap_amd import _capi, synth
+
+pytestmark = pytest.mark.gpu
+GOLDEN = Path(__file__).parent / "golden" / "match_golden_v1.npz"
+
+
+def upload(ctx, imgs):
+    ctx.reserve_slots(len(imgs))
+    for k, im in enumerate(imgs):
+        ctx.upload_descriptors(k, im)
+
+
+def assert_same(ctx, imgs, s1, s2, kernel, opts=(0.8, 0.7, True), expect_kernel=None):
+    off, m, st = ctx.match_pairs(s1, s2, *opts, kernel=kernel)
+    woff, wm = oracle_lib.match_pairs(imgs, s1, s2, *opts)
+    np.testing.assert_array_equal(off, woff)
+    np.testing.assert_array_equal(m, wm)
+    rows = np.array([len(i) for i in imgs], dtype=np.int64)
+    assert st["num_distances"] == int((rows[s1] * rows[s2]).sum())
+    if expect_kernel == "mfma":
+        assert st["pairs_mfma"] > 0 and st["pairs_dot4"] == 0
+    if expect_kernel == "dot4":
+        assert st["pairs_dot4"] > 0 and st["pairs_mfma"] == 0
+    return off, m, st
+
+
+def test_acos_lut_is_the_host_libm_table(amc_ctx):
+    np.testing.assert_array_equal(amc_ctx.acos_lut().view(np.uint32),
+                                  oracle_lib.acos_lut().view(np.uint32))
+
+
+@pytest.mark.parametrize("kernel", ["dot4", "mfma", "auto"])
+def test_golden_fixture_all_settings(amc_ctx, kernel):
+    g = np.load(GOLDEN)
+    imgs = [g[f"desc_{k}"] for k in range(int(g["num_images"]))]
+    upload(amc_ctx, imgs)
+    for name in ("default", "nocross", "loose", "tight"):
+        r, d, cc = g[f"{name}_opts"]
+        off, m, _ = amc_ctx.match_pairs(g["slot1"], g["slot2"], float(r), float(d), bool(cc),
+                                        kernel=kernel)
+        np.testing.assert_array_equal(off, g[f"{name}_offsets"])
+        np.testing.assert_array_equal(m, g[f"{name}_matches"])
+
+
+@pytest.mark.parametrize("kernel", ["dot4", "mfma"])
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_scene_pairs_ragged_sizes(amc_ctx, kernel, seed):
+    rng = np.random.default_rng(seed)
+    sizes = [512, 300, 777, 64, 1, 1025]
+    imgs = []
+    for n in sizes:
+        imgs += synth.scene_images(rng, 1, n, num_landmarks=900, visible_frac=0.4)
+    # same landmark prototypes across images need one generator call; add a coherent group too
+    imgs += synth.scene_images(rng, 3, 640, num_landmarks=1000, visible_frac=0.5)
+    s1, s2 = synth.exhaustive_pairs(len(imgs))
+    upload(amc_ctx, imgs)
+    off, m, _ = assert_same(amc_ctx, imgs, s1, s2, kernel, expect_kernel=kernel)
+    assert off[-1] > 100  # the coherent group matches
+    # reversed pair order (image 2 has fewer/more rows than image 1)
+    assert_same(amc_ctx, imgs, s2, s1, kernel, expect_kernel=kernel)
+
+
+@pytest.mark.parametrize("kernel", ["dot4", "mfma"])
+@pytest.mark.parametrize("opts", [(0.8, 0.7, False), (0.95, 1.3, True), (1.0, 2.0, True),
+                                  (0.5, 0.4, True)])
+def test_option_variants(amc_ctx, kernel, opts):
+    rng = np.random.default_rng(11)
+    imgs = synth.scene_images(rng, 4, 600, num_landmarks=1000, visible_frac=0.5)
+    s1, s2 = synth.exhaustive_pairs(4)
+    upload(amc_ctx, imgs)
+    assert_same(amc_ctx, imgs, s1, s2, kernel, opts, expect_kernel=kernel)
+
+
+@pytest.mark.parametrize("kernel", ["dot4", "mfma"])
+def test_adversarial_ties_zeros_duplicates(amc_ctx, kernel):
+    rng = np.random.default_rng(5)
+    a = synth.random_descriptors(rng, 300)
+    b = a[rng.permutation(300)].copy()
+    b[10] = b[11]            # duplicated column: tie for best of one row
+    b[20] = 0                # zero column
+    a[30] = 0                # zero row
+    a[40] = a[41]            # duplicated rows: tie in the column direction
+    c = np.concatenate([a[:100], a[:100]])   # every row duplicated
+    imgs = [a, b, c, np.zeros((0, 128), np.uint8), a[:1].copy()]
+    s1 = np.array([0, 1, 0, 2, 2, 0, 3, 4, 4, 0], np.uint32)
+    s2 = np.array([1, 0, 2, 0, 2, 3, 0, 0, 4, 0], np.uint32)
+    upload(amc_ctx, imgs)
+    for opts in [(0.8, 0.7, True), (0.99, 3.0, True), (0.99, 3.0, False)]:
+        assert_same(amc_ctx, imgs, s1, s2, kernel, opts)
+
+
+def test_unnormalised_and_saturated_fall_back_to_dot4(amc_ctx):
+    """Raw random bytes break the packed-key value bound: AUTO must route them to the dot4
+    kernel (and forcing MFMA must be refused), results still bit-exact."""
+    rng = np.random.default_rng(6)
+    a = rng.integers(0, 256, size=(200, 128), dtype=np.uint8)
+    b = rng.integers(0, 256, size=(150, 128), dtype=np.uint8)
+    sat = np.full((70, 128), 255, np.uint8)
+    imgs = [a, b, sat]
+    s1, s2 = synth.exhaustive_pairs(3)
+    upload(amc_ctx, imgs)
+    for opts in [(0.8, 0.7, True), (0.99, 3.0, False)]:
+        assert_same(amc_ctx, imgs, s1, s2, "auto", opts, expect_kernel="dot4")
+    with pytest.raises(_capi.AmcError):
+        amc_ctx.match_pairs(s1, s2, kernel="mfma")
+
+
+def test_max_ratio_above_one_routes_to_index_tracking_kernel(amc_ctx):
+    """max_ratio > 1 lets tied bests through the ratio test; the value-mode cross check is
+    not exact there, so AUTO must use the index-tracking dot4 kernel."""
+    rng = np.random.default_rng(7)
+    a = synth.random_descriptors(rng, 128)
+    b = np.concatenate([a, a])  # every column duplicated -> ties everywhere
+    imgs = [a, b]
+    upload(amc_ctx, imgs)
+    s1 = np.array([0, 1], np.uint32); s2 = np.array([1, 0], np.uint32)
+    assert_same(amc_ctx, imgs, s1, s2, "auto", (1.5, 3.0, True), expect_kernel="dot4")
+    assert_same(amc_ctx, imgs, s1, s2, "auto", (1.5, 3.0, False))
+
+
+def test_invalid_arguments_raise(amc_ctx):
+    amc_ctx.reserve_slots(2)
+    amc_ctx.upload_descriptors(0, np.zeros((4, 128), np.uint8))
+    with pytest.raises(_capi.AmcError) as e:      # slot 1 never uploaded
+        amc_ctx.match_pairs([0], [1])
+    assert e.value.code == _capi.AMC_E_STATE
+    with pytest.raises(_capi.AmcError) as e:      # slot out of range
+        amc_ctx.match_pairs([0], [7])
+    assert e.value.code == _capi.AMC_E_INVALID
+    with pytest.raises(_capi.AmcError):
+        amc_ctx.upload_descriptors(5, np.zeros((4, 128), np.uint8))
+    off, m, _ = amc_ctx.match_pairs([], [])
+    assert off.tolist() == [0] and m.shape == (0, 2)
+
+
+def test_full_size_properties_4096(amc_ctx):
+    """BASELINE config-2 image size (4096 descriptors): too slow for the scalar oracle on every
+    pair, so (a) one pair against the oracle, (b) the two independent kernels against each other
+    on all pairs, (c) transpose symmetry of the cross-checked match set, (d) self-match identity."""
+    rng = np.random.default_rng(8)
+    imgs = synth.scene_images(rng, 6, 4096, num_landmarks=8000, visible_frac=0.35)
+    s1, s2 = synth.exhaustive_pairs(6)
+    upload(amc_ctx, imgs)
+    off_m, m_m, st_m = amc_ctx.match_pairs(s1, s2, kernel="mfma")
+    off_d, m_d, st_d = amc_ctx.match_pairs(s1, s2, kernel="dot4")
+    assert st_m["pairs_mfma"] == len(s1) and st_d["pairs_dot4"] == len(s1)
+    np.testing.assert_array_equal(off_m, off_d)
+    np.testing.assert_array_equal(m_m, m_d)
+    assert off_m[-1] > 1000
+    # (a) oracle on the first pair
+    np.testing.assert_array_equal(m_m[off_m[0]:off_m[1]], oracle_lib.match(imgs[0], imgs[1]))
+    # (c) transpose symmetry
+    off_t, m_t, _ = amc_ctx.match_pairs(s2, s1, kernel="mfma")
+    for p in range(len(s1)):
+        a = {(int(i), int(j)) for i, j in m_m[off_m[p]:off_m[p + 1]]}
+        b = {(int(j), int(i)) for i, j in m_t[off_t[p]:off_t[p + 1]]}
+        assert a == b
+    # (d) self match: every accepted row maps to itself
+    off_s, m_s, _ = amc_ctx.match_pairs([0], [0], kernel="mfma")
+    assert len(m_s) > 0 and np.all(m_s[:, 0] == m_s[:, 1])
+
+
+def test_8192_rows_uses_13_bit_keys(amc_ctx):
+    rng = np.random.default_rng(9)
+    imgs = synth.scene_images(rng, 2, 8192, num_landmarks=16000, visible_frac=0.4)
+    upload(amc_ctx, imgs)
+    off, m, st = amc_ctx.match_pairs([0], [1], kernel="auto")
+    assert st["pairs_mfma"] == 1
+    off_d, m_d, _ = amc_ctx.match_pairs([0], [1], kernel="dot4")
+    np.testing.assert_array_equal(m, m_d)
+    assert len(m) > 500

@@ -1,0 +1,152 @@
+"""CPU tests: the match oracle against an independent numpy restatement, hand-computable
+known answers, and the committed golden fixtures (SURVEY.md section 8c lists which to create,
+since the reference has none)."""
+import numpy as np
+import pytest
+
+import oracle_lib
+from pycolmap_amd import synth
+
+GOLDEN = __import__("pathlib").Path(__file__).parent / "golden" / "match_golden_v1.npz"
+
+
+def numpy_match(d1, d2, max_ratio=0.8, max_distance=0.7, cross_check=True):
+    """Independent restatement of SURVEY.md A.2 with numpy primitives (argmax = first maximum,
+    second = partition), float64 acos. Returns (matches, ambiguous_rows) where ambiguous marks
+    rows whose accept/reject margin is below float32 resolution."""
+    D = d1.astype(np.int32) @ d2.astype(np.int32).T
+
+    def one_way(M):
+        R, Cn = M.shape
+        best_idx = M.argmax(axis=1)
+        best = M[np.arange(R), best_idx]
+        if Cn > 1:
+            second = np.partition(M, Cn - 2, axis=1)[:, Cn - 2]
+        else:
+            second = np.zeros(R, M.dtype)
+        second = np.maximum(second, 0)
+        a_b = np.arccos(np.minimum(best / 262144.0, 1.0))
+        a_s = np.arccos(np.minimum(second / 262144.0, 1.0))
+        ok = (best > 0) & ~(a_b > max_distance) & ~(a_b >= max_ratio * a_s)
+        margin = np.minimum(np.abs(a_b - max_distance), np.abs(a_b - max_ratio * a_s))
+        amb = (best > 0) & (margin < 1e-5)
+        return np.where(ok, best_idx, -1), amb
+
+    m12, amb1 = one_way(D)
+    m21, amb2 = one_way(D.T)
+    out = []
+    for i in range(len(d1)):
+        j = m12[i]
+        if j < 0:
+            continue
+        if cross_check and m21[j] != i:
+            continue
+        out.append((i, j))
+    return np.array(out, dtype=np.uint32).reshape(-1, 2), amb1.any() or amb2.any()
+
+
+def test_distance_matrix_equals_numpy_gram():
+    rng = np.random.default_rng(0)
+    a = rng.integers(0, 256, size=(37, 128), dtype=np.uint8)
+    b = rng.integers(0, 256, size=(53, 128), dtype=np.uint8)
+    D = oracle_lib.distance_matrix(a, b)
+    assert D.dtype == np.int32
+    np.testing.assert_array_equal(D, a.astype(np.int32) @ b.astype(np.int32).T)
+    # the documented maximum: 128 * 255^2
+    sat = np.full((1, 128), 255, np.uint8)
+    assert oracle_lib.distance_matrix(sat, sat)[0, 0] == 128 * 255 * 255 == 8323200
+
+
+@pytest.mark.parametrize("seed", range(5))
+@pytest.mark.parametrize("opts", [(0.8, 0.7, True), (0.8, 0.7, False), (0.95, 1.3, True)])
+def test_oracle_vs_numpy_restatement(seed, opts):
+    rng = np.random.default_rng(seed)
+    imgs = synth.scene_images(rng, 2, 150 + 7 * seed, num_landmarks=260, visible_frac=0.5)
+    got = oracle_lib.match(imgs[0], imgs[1], *opts)
+    want, ambiguous = numpy_match(imgs[0], imgs[1], *opts)
+    if ambiguous:
+        pytest.skip("a row sits within float32 resolution of a threshold")
+    np.testing.assert_array_equal(got, want)
+    assert len(got) > 10  # the synthetic scene really produces matches
+
+
+def _unit(k):
+    v = np.zeros(128, np.uint8)
+    v[k] = 255
+    return v
+
+
+def test_kat_identity_and_order():
+    # 4 orthogonal "one-hot" descriptors (255 at one position): dist(i,i)=65025, else 0.
+    d = np.stack([_unit(k) for k in range(4)])
+    # best=65025 -> acos(65025/262144)=1.32 > 0.7: rejected by max_distance
+    assert len(oracle_lib.match(d, d)) == 0
+    # allow the distance: second=0 -> acos(0)=pi/2, 1.32 < 0.8*1.5708=1.2566? no -> rejected by ratio
+    assert len(oracle_lib.match(d, d, max_ratio=0.8, max_distance=2.0)) == 0
+    m = oracle_lib.match(d, d, max_ratio=0.9, max_distance=2.0)
+    np.testing.assert_array_equal(m, np.array([[0, 0], [1, 1], [2, 2], [3, 3]], np.uint32))
+    # permuted second image: matches follow the permutation, ascending in idx1
+    perm = np.array([2, 0, 3, 1])
+    m = oracle_lib.match(d, d[perm], max_ratio=0.9, max_distance=2.0)
+    np.testing.assert_array_equal(m[:, 0], np.arange(4))
+    np.testing.assert_array_equal(perm[m[:, 1]], np.arange(4))
+
+
+def test_kat_ties_zeros_and_saturation():
+    rng = np.random.default_rng(3)
+    base = synth.random_descriptors(rng, 8)
+    # duplicate column in image 2: best == second for the matching row -> ratio test rejects
+    d2 = base.copy()
+    d2[5] = d2[4]
+    m = oracle_lib.match(base[:5], d2, max_ratio=0.99, max_distance=3.0, cross_check=False)
+    assert 4 not in m[:, 0]
+    # all-zero query row: no distance > 0 -> never matched; all-zero column never chosen
+    z1 = base.copy(); z1[2] = 0
+    m = oracle_lib.match(z1, base, max_ratio=0.99, max_distance=3.0, cross_check=False)
+    assert 2 not in m[:, 0]
+    # saturated descriptors: dist >= 512^2 clamps acos to 0 for best and second -> 0 >= r*0 rejects
+    s = np.full((3, 128), 255, np.uint8)
+    assert len(oracle_lib.match(s, s, max_ratio=0.99, max_distance=3.0, cross_check=False)) == 0
+    # lowest index wins a tie for best (strict '>'), but the tie also makes second==best, so the
+    # row is rejected whenever max_ratio <= 1; with max_ratio > 1 the lowest index must be reported
+    q = base[:1]
+    dup = np.concatenate([base[3:4], base[0:1], base[0:1]])
+    m = oracle_lib.match(q, dup, max_ratio=1.5, max_distance=3.0, cross_check=False)
+    np.testing.assert_array_equal(m, np.array([[0, 1]], np.uint32))
+
+
+def test_kat_empty_and_single():
+    rng = np.random.default_rng(4)
+    d = synth.random_descriptors(rng, 5)
+    e = np.zeros((0, 128), np.uint8)
+    assert oracle_lib.match(e, d).shape == (0, 2)
+    assert oracle_lib.match(d, e).shape == (0, 2)
+    # single column: second = 0 -> acos(0)=pi/2
+    m = oracle_lib.match(d[:1], d[:1], max_ratio=0.8, max_distance=0.7)
+    np.testing.assert_array_equal(m, np.array([[0, 0]], np.uint32))
+
+
+def test_cross_check_is_transpose_symmetric():
+    rng = np.random.default_rng(5)
+    imgs = synth.scene_images(rng, 2, 200, num_landmarks=350, visible_frac=0.5)
+    ab = oracle_lib.match(imgs[0], imgs[1])
+    ba = oracle_lib.match(imgs[1], imgs[0])
+    a = {(int(i), int(j)) for i, j in ab}
+    b = {(int(j), int(i)) for i, j in ba}
+    assert a == b and len(a) > 0
+
+
+def test_acos_lut_semantics():
+    lut = oracle_lib.acos_lut()
+    assert lut[0] == np.float32(np.pi / 2) and lut[262144] == 0.0
+    assert np.all(np.diff(lut.astype(np.float64)) <= 0)
+
+
+def test_golden_fixtures():
+    g = np.load(GOLDEN)
+    imgs = [g[f"desc_{k}"] for k in range(int(g["num_images"]))]
+    for name in ("default", "nocross", "loose", "tight"):
+        r, d, cc = g[f"{name}_opts"]
+        off, m = oracle_lib.match_pairs(imgs, g["slot1"], g["slot2"], float(r), float(d), bool(cc), threads=2)
+        np.testing.assert_array_equal(off, g[f"{name}_offsets"])
+        np.testing.assert_array_equal(m, g[f"{name}_matches"])
