@@ -39,21 +39,27 @@ OPS_PER_DISTANCE = 256        # 128 int8 MACs
 
 
 def make_arena_torch(num_images: int, feats: int, seed: int, device):
-    """Seeded SIFT-like scene descriptors generated on the GPU (same recipe as
-    pycolmap_amd.synth.scene_images: shared landmark prototypes + per-image noise + pure-noise
-    padding, L2-normalised, x512, rounded, clamped to uint8)."""
+    """Seeded SIFT-like descriptors generated on the GPU (SURVEY.md section 8d recipe).
+
+    Landmarks sit on a ring; image i views a window of the ring that overlaps its ~8 nearest
+    neighbours on either side and nothing else — like an exhaustive match of a real capture,
+    most of the N^2/2 pairs have no true overlap.  Per image: 60 % noisy copies of visible
+    landmark prototypes + 40 % pure-noise features, shuffled, L2-normalised, x512, rounded,
+    clamped to uint8 (COLMAP's storage convention)."""
     import torch
     g = torch.Generator(device=device)
     g.manual_seed(seed)
-    visible_frac, sigma_d = 0.35, 0.08
-    L = max(8, int(feats / visible_frac * 0.6))
+    sigma_d = 0.08
+    k = int(0.6 * feats)            # landmark features per image
+    W = 2 * k                       # window of the ring an image can see
+    stride = max(1, W // 8)         # neighbours up to 8 apart share landmarks
+    L = max(W, num_images * stride)
     proto = torch.randn(L, 128, generator=g, device=device).abs().pow(3.0)
     proto = proto / proto.norm(dim=1, keepdim=True)
-    k = min(feats, int(round(visible_frac * L)))
     arena = torch.empty(num_images, feats, 128, dtype=torch.uint8, device=device)
     for i in range(num_images):
-        vis = torch.randperm(L, generator=g, device=device)[:k]
-        d = proto[vis] + torch.randn(k, 128, generator=g, device=device) * sigma_d * proto[vis].mean()
+        win = (i * stride + torch.randperm(W, generator=g, device=device)[:k]) % L
+        d = proto[win] + torch.randn(k, 128, generator=g, device=device) * sigma_d * proto[win].mean()
         if k < feats:
             noise = torch.randn(feats - k, 128, generator=g, device=device).abs().pow(3.0) * 0.1
             d = torch.cat([d, noise], 0)
@@ -92,6 +98,8 @@ def main():
     ap.add_argument("--kernel", default="auto", choices=["auto", "mfma", "dot4"])
     ap.add_argument("--cpu-sample-pairs", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cross-check", action="store_true",
+                    help="diagnostic: one-way matching only (NOT the BASELINE workload)")
     args = ap.parse_args()
 
     import torch
@@ -130,7 +138,7 @@ def main():
     torch.cuda.synchronize()
 
     def step():
-        off, m, st = ctx.match_pairs(s1, s2, kernel=args.kernel)
+        off, m, st = ctx.match_pairs(s1, s2, kernel=args.kernel, cross_check=not args.no_cross_check)
         gathered = None
         if world > 1:
             # RCCL all-gather of the match tables: counts first, then padded tables

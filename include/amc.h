@@ -58,8 +58,9 @@ enum {
     AMC_E_STATE = -4    /* e.g. slot not uploaded */
 };
 
-/* Which match kernel to run.  AUTO picks the int8-MFMA kernel whenever its exactness
- * preconditions hold (see DESIGN.md "match kernels") and the u8 dot4 kernel otherwise. */
+/* Which match kernel to run.  AUTO picks the int8-MFMA kernel (exact for any u8 values) unless
+ * image 2 has more than 8192 descriptors and cross_check is on (candidate bitmap limit), where
+ * it uses the u8 dot4 kernel (see DESIGN.md "match kernels"). */
 enum { AMC_KERNEL_AUTO = 0, AMC_KERNEL_MFMA = 1, AMC_KERNEL_DOT4 = 2 };
 
 typedef struct amc_ctx amc_ctx;
@@ -85,7 +86,9 @@ typedef struct amc_match_result {
     uint64_t pairs_mfma;      /* pairs routed to the int8-MFMA kernel */
     uint64_t pairs_dot4;      /* pairs routed to the u8 dot4 kernel */
     double device_ms;         /* first kernel launch -> last result byte on host, HIP events */
-    double match_kernel_ms;   /* sum of match-kernel launch durations, HIP events on the stream */
+    double match_kernel_ms;   /* sum of one-way match-kernel launch durations (image 1 -> image 2
+                                 scan), HIP events on the stream */
+    double cross_kernel_ms;   /* candidate selection + reverse scan of candidate columns */
     uint32_t match_kernel_launches;
     void* _priv;
 } amc_match_result;

@@ -73,7 +73,8 @@ static void one_way(const int32_t* dists, int rows, int cols, size_t row_stride,
 }
 
 /* colmap/feature/sift.cc FindBestMatchesBruteForce (SURVEY.md A.2 "match").
- * out_matches must hold 2*min(n1,n2) uint32 (idx1, idx2 interleaved). Returns #matches, or -1
+ * out_matches must hold 2*n1 uint32 (idx1, idx2 interleaved; with cross_check the count is
+ * additionally bounded by n2). Returns #matches, or -1
  * on allocation failure. max_ratio / max_distance are the double options cast to float at the
  * call, as COLMAP does. */
 int oracle_match(const uint8_t* d1, int n1, const uint8_t* d2, int n2, double max_ratio,
@@ -105,7 +106,7 @@ int oracle_match(const uint8_t* d1, int n1, const uint8_t* d2, int n2, double ma
 /* Batched driver used by tests and by bench.py's cpu_baseline leg: descriptors of image s
  * start at arena + row_offset[s]*128 and have rows[s] rows.  One pair per OpenMP thread
  * ("one image pair per thread").  Results: counts[p] and matches at
- * out_matches + 2*out_offsets[p] (caller sizes out_offsets by min(n1,n2) per pair).
+ * out_matches + 2*out_offsets[p] (caller sizes out_offsets by n1 per pair).
  * Returns 0, or -1 if any pair failed to allocate. */
 int oracle_match_pairs(const uint8_t* arena, const uint64_t* row_offset, const uint32_t* rows,
                        const uint32_t* slot1, const uint32_t* slot2, size_t npairs,

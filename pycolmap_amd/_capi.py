@@ -44,6 +44,7 @@ class MatchResult(C.Structure):
                 ("matches", C.POINTER(C.c_uint32)), ("num_distances", C.c_uint64),
                 ("pairs_mfma", C.c_uint64), ("pairs_dot4", C.c_uint64),
                 ("device_ms", C.c_double), ("match_kernel_ms", C.c_double),
+                ("cross_kernel_ms", C.c_double),
                 ("match_kernel_launches", C.c_uint32), ("_priv", C.c_void_p)]
 
 
@@ -159,6 +160,7 @@ class Context:
             stats = dict(num_distances=int(res.num_distances), pairs_mfma=int(res.pairs_mfma),
                          pairs_dot4=int(res.pairs_dot4), device_ms=float(res.device_ms),
                          match_kernel_ms=float(res.match_kernel_ms),
+                         cross_kernel_ms=float(res.cross_kernel_ms),
                          match_kernel_launches=int(res.match_kernel_launches))
         finally:
             self._lib.amc_match_result_free(C.byref(res))

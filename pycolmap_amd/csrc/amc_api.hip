@@ -102,13 +102,13 @@ struct amc_ctx {
     // per-batch scratch
     DevBuf<PairDev> d_pairs;
     DevBuf<Dot4Work> d_work;
-    DevBuf<uint32_t> d_order;
+    DevBuf<uint32_t> d_order, d_order2;
     DevBuf<Top2> d_rowbuf, d_colbuf;
-    DevBuf<uint32_t> d_pair_off, d_pair_cnt, d_matches;
+    DevBuf<uint32_t> d_pair_off, d_pair_cnt, d_matches, d_cand_cnt, d_candbuf;
     PinBuf<PairDev> h_pairs;
     PinBuf<Dot4Work> h_work;
-    PinBuf<uint32_t> h_order, h_pair_off, h_pair_cnt, h_matches, h_scalars;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    PinBuf<uint32_t> h_order, h_order2, h_pair_off, h_pair_cnt, h_matches, h_scalars;
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 
 extern "C" {
@@ -190,10 +190,11 @@ void amc_ctx_destroy(amc_ctx* c) {
     c->d_imgs.release();
     if (c->d_lut) (void)hipFree(c->d_lut);
     if (c->d_scalars) (void)hipFree(c->d_scalars);
-    c->d_pairs.release(); c->d_work.release(); c->d_order.release();
+    c->d_pairs.release(); c->d_work.release(); c->d_order.release(); c->d_order2.release();
     c->d_rowbuf.release(); c->d_colbuf.release();
     c->d_pair_off.release(); c->d_pair_cnt.release(); c->d_matches.release();
-    c->h_pairs.release(); c->h_work.release(); c->h_order.release();
+    c->d_cand_cnt.release(); c->d_candbuf.release();
+    c->h_pairs.release(); c->h_work.release(); c->h_order.release(); c->h_order2.release();
     c->h_pair_off.release(); c->h_pair_cnt.release(); c->h_matches.release();
     c->h_scalars.release();
     for (auto& ev : c->ev)
@@ -335,12 +336,10 @@ int amc_match_pairs(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, si
     priv->offsets.assign(npairs + 1, 0);
 
     const float max_ratio_f = (float)o.max_ratio;
-    // value-mode cross check (mfma kernel) is exact iff ties always fail the ratio test
-    const bool value_mode_ok = !o.cross_check || (max_ratio_f <= 1.0f);
-    const size_t mfma_max_cols = match_mfma_max_cols();
+    const size_t mfma_max_cols = kSelectMaxCols;  // cross-check candidate bitmap (image 2 rows)
 
     uint64_t num_dist = 0, n_mfma = 0, n_dot4 = 0;
-    double kernel_ms = 0.0;
+    double kernel_ms = 0.0, cross_ms = 0.0;
     uint32_t kernel_launches = 0;
     HIPCHK(hipEventRecord(c->ev[0], st));
 
@@ -353,7 +352,9 @@ int amc_match_pairs(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, si
             const Slot& a = c->slots[slot1[end]];
             const Slot& b = c->slots[slot2[end]];
             const size_t nr = a.dev.rows_pad, nc = b.dev.rows_pad;
-            const size_t mc = std::min(a.dev.rows, b.dev.rows);
+            // cross-checked matches are one-to-one; without the cross check every row of image 1
+            // may match (several rows may share a column)
+            const size_t mc = o.cross_check ? std::min(a.dev.rows, b.dev.rows) : a.dev.rows;
             if (end > begin && (top_rows + nr > kMaxTop2Entries || top_cols + nc > kMaxTop2Entries ||
                                 cap + mc > kMaxMatchCap || end - begin >= (1u << 24)))
                 break;
@@ -370,38 +371,31 @@ int amc_match_pairs(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, si
             !hc(c->d_rowbuf.ensure(top_rows), "row top2") || !hc(c->d_colbuf.ensure(top_cols), "col top2") ||
             !hc(c->d_pair_off.ensure(nb), "pair_off") || !hc(c->d_pair_cnt.ensure(nb), "pair_cnt") ||
             !hc(c->h_pair_off.ensure(nb), "pinned pair_off") || !hc(c->h_pair_cnt.ensure(nb), "pinned pair_cnt") ||
-            !hc(c->d_matches.ensure(2 * cap), "dev matches") || !hc(c->h_matches.ensure(2 * cap), "pinned matches"))
+            !hc(c->d_matches.ensure(2 * cap), "dev matches") || !hc(c->h_matches.ensure(2 * cap), "pinned matches") ||
+            !hc(c->d_cand_cnt.ensure(nb), "cand_cnt") || !hc(c->d_candbuf.ensure(top_cols), "candbuf"))
             break;
 
         // ---- route each pair to a kernel -------------------------------------------------
-        uint32_t max_cols_mfma = 0;
+        // mfma: exact for any u8 values and sizes; the lazy cross check's candidate bitmap
+        // (select_candidates_kernel) holds 8192 image-2 rows, larger images take the dot4 path.
         std::vector<uint8_t> want_mfma(nb, 0);
         for (size_t i = 0; i < nb; ++i) {
             const Slot& a = c->slots[slot1[begin + i]];
             const Slot& b = c->slots[slot2[begin + i]];
             const bool nonempty = a.dev.rows > 0 && b.dev.rows > 0;
-            bool ok = nonempty && o.kernel != AMC_KERNEL_DOT4 && value_mode_ok &&
-                      b.dev.rows_pad <= mfma_max_cols;
-            want_mfma[i] = ok;
-            if (ok) max_cols_mfma = std::max(max_cols_mfma, b.dev.rows_pad);
+            want_mfma[i] = nonempty && o.kernel != AMC_KERNEL_DOT4 &&
+                           (!o.cross_check || b.dev.rows_pad <= mfma_max_cols);
         }
-        const int shift = std::min(13, std::max(10, ceil_log2(std::max(max_cols_mfma, 1u))));
-        const uint64_t vlimit = 1ull << (32 - shift);  // need max dot < vlimit
         size_t row_off = 0, col_off = 0, nwork = 0, nord = 0;
         for (size_t i = 0; i < nb; ++i) {
             const Slot& a = c->slots[slot1[begin + i]];
             const Slot& b = c->slots[slot2[begin + i]];
-            if (want_mfma[i]) {
-                // Cauchy-Schwarz: dot^2 <= |a|^2 |b|^2
-                const uint64_t prod = (uint64_t)a.maxsq * (uint64_t)b.maxsq;
-                if (prod >= vlimit * vlimit) want_mfma[i] = 0;
-            }
             const bool nonempty = a.dev.rows > 0 && b.dev.rows > 0;
             if (o.kernel == AMC_KERNEL_MFMA && nonempty && !want_mfma[i]) {
                 rc = fail(AMC_E_INVALID,
                           "amc_match_pairs: kernel=MFMA forced but pair %zu is not eligible "
-                          "(cols_pad=%u, maxsq=%u,%u, max_ratio=%g)", begin + i, b.dev.rows_pad,
-                          a.maxsq, b.maxsq, o.max_ratio);
+                          "(rows_pad=%u, cols_pad=%u > %zu)", begin + i, a.dev.rows_pad,
+                          b.dev.rows_pad, mfma_max_cols);
                 break;
             }
             PairDev& pd = c->h_pairs.p[i];
@@ -451,7 +445,8 @@ int amc_match_pairs(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, si
         // ---- enqueue ------------------------------------------------------------------
         bool okq = hc(hipMemcpyAsync(c->d_pairs.p, c->h_pairs.p, nb * sizeof(PairDev),
                                      hipMemcpyHostToDevice, st), "H2D pairs") &&
-                   hc(hipMemsetAsync(c->d_scalars, 0, 2 * sizeof(uint32_t), st), "memset cursor");
+                   hc(hipMemsetAsync(c->d_scalars, 0, 2 * sizeof(uint32_t), st), "memset cursor") &&
+                   hc(hipMemsetAsync(c->d_scalars + 3, 0, sizeof(uint32_t), st), "memset errcount");
         if (okq && nord)
             okq = hc(hipMemcpyAsync(c->d_order.p, c->h_order.p, nord * sizeof(uint32_t),
                                     hipMemcpyHostToDevice, st), "H2D order");
@@ -459,25 +454,51 @@ int amc_match_pairs(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, si
             okq = hc(hipMemcpyAsync(c->d_work.p, c->h_work.p, nwork * sizeof(Dot4Work),
                                     hipMemcpyHostToDevice, st), "H2D work");
         if (!okq) break;
+        FinalizeParams fp;
+        fp.max_ratio = max_ratio_f;
+        fp.max_distance = (float)o.max_distance;
+        fp.cross_check = o.cross_check ? 1 : 0;
+        fp.reserved = 0;
         (void)hipEventRecord(c->ev[2], st);
         if (nord)
-            launch_match_mfma(c->d_imgs.p, c->d_pairs.p, c->d_order.p, (uint32_t)nord, shift,
-                              o.cross_check, c->d_scalars + 1, c->d_rowbuf.p, c->d_colbuf.p, st);
+            launch_match_mfma(0, c->d_imgs.p, c->d_pairs.p, c->d_order.p, (uint32_t)nord,
+                              c->d_scalars + 1, c->d_cand_cnt.p, c->d_candbuf.p, c->d_rowbuf.p, st);
         if (nwork)
             launch_match_dot4(c->d_imgs.p, c->d_pairs.p, c->d_work.p, (uint32_t)nwork,
                               c->d_rowbuf.p, c->d_colbuf.p, st);
         (void)hipEventRecord(c->ev[3], st);
         kernel_launches += (nord ? 1 : 0) + (nwork ? 1 : 0);
-        FinalizeParams fp;
-        fp.max_ratio = max_ratio_f;
-        fp.max_distance = (float)o.max_distance;
-        fp.cross_check = o.cross_check ? 1 : 0;
-        fp.value_mode = 0;
+        if (nord)  // tile -> exact index for the accepted rows
+            launch_resolve_index(0, c->d_imgs.p, c->d_pairs.p, (uint32_t)nb, c->d_rowbuf.p, c->d_lut,
+                                 fp, c->d_cand_cnt.p, c->d_candbuf.p, c->d_scalars + 3, st);
+        if (nord && o.cross_check) {
+            // lazy cross check: reverse scan only for the columns accepted rows point at
+            launch_select_candidates(c->d_imgs.p, c->d_pairs.p, (uint32_t)nb, c->d_rowbuf.p,
+                                     c->d_lut, fp, c->d_cand_cnt.p, c->d_candbuf.p, st);
+            // streamed image is image 1 now: a second queue order, sorted by it
+            if (!hc(c->h_order2.ensure(nord), "pinned order2") || !hc(c->d_order2.ensure(nord), "dev order2"))
+                break;
+            std::copy(c->h_order.p, c->h_order.p + nord, c->h_order2.p);
+            std::stable_sort(c->h_order2.p, c->h_order2.p + nord, [&](uint32_t x, uint32_t y) {
+                const PairDev& px = c->h_pairs.p[x];
+                const PairDev& py = c->h_pairs.p[y];
+                return px.slot1 != py.slot1 ? px.slot1 < py.slot1 : px.slot2 < py.slot2;
+            });
+            uint32_t* d_order2 = c->d_order2.p;
+            if (!hc(hipMemcpyAsync(d_order2, c->h_order2.p, nord * sizeof(uint32_t),
+                                   hipMemcpyHostToDevice, st), "H2D order2"))
+                break;
+            launch_match_mfma(1, c->d_imgs.p, c->d_pairs.p, d_order2, (uint32_t)nord,
+                              c->d_scalars + 1, c->d_cand_cnt.p, c->d_candbuf.p, c->d_colbuf.p, st);
+            launch_resolve_index(1, c->d_imgs.p, c->d_pairs.p, (uint32_t)nb, c->d_colbuf.p, c->d_lut,
+                                 fp, c->d_cand_cnt.p, c->d_candbuf.p, c->d_scalars + 3, st);
+        }
+        (void)hipEventRecord(c->ev[4], st);
         launch_finalize(c->d_imgs.p, c->d_pairs.p, (uint32_t)nb, c->d_rowbuf.p, c->d_colbuf.p,
                         c->d_lut, fp, c->d_scalars, (uint32_t)std::min(cap, (size_t)0xFFFFFFFFu),
                         c->d_pair_off.p, c->d_pair_cnt.p, c->d_matches.p, st);
         if (!hc(hipGetLastError(), "kernel launch")) break;
-        if (!hc(hipMemcpyAsync(c->h_scalars.p, c->d_scalars, sizeof(uint32_t),
+        if (!hc(hipMemcpyAsync(c->h_scalars.p, c->d_scalars, 4 * sizeof(uint32_t),
                                hipMemcpyDeviceToHost, st), "D2H cursor") ||
             !hc(hipMemcpyAsync(c->h_pair_off.p, c->d_pair_off.p, nb * sizeof(uint32_t),
                                hipMemcpyDeviceToHost, st), "D2H pair_off") ||
@@ -486,6 +507,11 @@ int amc_match_pairs(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, si
             !hc(hipStreamSynchronize(st), "sync after batch kernels"))
             break;
         const uint32_t total = c->h_scalars.p[0];
+        if (c->h_scalars.p[3] != 0) {
+            rc = fail(AMC_E_HIP, "amc_match_pairs: internal: %u accepted rows could not be resolved "
+                      "to an index (scan/recompute mismatch)", c->h_scalars.p[3]);
+            break;
+        }
         if (total > cap) {
             rc = fail(AMC_E_HIP, "amc_match_pairs: internal: %u matches exceed capacity %zu",
                       total, cap);
@@ -498,6 +524,7 @@ int amc_match_pairs(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, si
             break;
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, c->ev[2], c->ev[3]) == hipSuccess) kernel_ms += ms;
+        if (hipEventElapsedTime(&ms, c->ev[3], c->ev[4]) == hipSuccess) cross_ms += ms;
         // ---- scatter into the CSR (pairs keep the caller's order) --------------------------
         for (size_t i = 0; i < nb; ++i) {
             const uint32_t cnt = c->h_pair_cnt.p[i];
@@ -527,6 +554,7 @@ int amc_match_pairs(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, si
     out->device_ms = total_ms;
     out->match_kernel_ms = kernel_ms;
     out->match_kernel_launches = kernel_launches;
+    out->cross_kernel_ms = cross_ms;
     out->_priv = priv;
     return AMC_OK;
 }

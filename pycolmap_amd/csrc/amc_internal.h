@@ -30,8 +30,9 @@ struct ImageDev {
 
 // One-way top-2 record, the common intermediate of both match kernels (16 B).
 //   best_v   : best dot product (true value), 0 if none > 0
-//   best_idx : its index (lowest index among ties); 0xFFFFFFFF if none or if the producing
-//              kernel does not track indices for this side (value-mode columns)
+//   best_idx : its index (lowest index among ties); 0xFFFFFFFF if none.  Straight out of the
+//              mfma kernel it is the 32-row TILE holding the best; resolve_index_kernel
+//              replaces it by the exact index for the rows that pass the acceptance tests.
 //   second_v : second-largest value with multiplicity, floor 0
 struct Top2 {
     uint32_t best_v;
@@ -43,7 +44,7 @@ struct Top2 {
 // A pair inside one batch.
 struct PairDev {
     uint32_t slot1, slot2;
-    uint32_t mode;     // 1: produced by the mfma kernel (value-mode columns), 0: dot4 kernel
+    uint32_t mode;     // 1: mfma kernel (column table computed lazily for candidates), 0: dot4
     uint32_t pad;
     uint64_t row_off;  // into the batch's Top2 row buffer (rows_pad(slot1) entries)
     uint64_t col_off;  // into the batch's Top2 col buffer (rows_pad(slot2) entries)
@@ -60,8 +61,7 @@ struct FinalizeParams {
     float max_ratio;
     float max_distance;
     int cross_check;
-    int value_mode;  // 1: columns carry no index; cross-check by value equality (needs
-                     // max_ratio <= 1); 0: compare indices
+    int reserved;
 };
 
 // ----- launchers (defined in the .hip files) ---------------------------------------------
@@ -71,13 +71,24 @@ void launch_prep(const uint8_t* raw, uint8_t* prep, int32_t* rs128, uint32_t row
 void launch_match_dot4(const ImageDev* imgs, const PairDev* pairs, const Dot4Work* work,
                        uint32_t nwork, Top2* rowbuf, Top2* colbuf, hipStream_t s);
 
-// mfma: one workgroup per pair, dynamic queue over `order` (pair indices, sorted for L2 reuse).
-// shift = index bits of the packed row keys (all pairs in the launch satisfy
-// rows_pad(slot2) <= 1<<shift and max dot < 1<<(32-shift)).
-void launch_match_mfma(const ImageDev* imgs, const PairDev* pairs, const uint32_t* order,
-                       uint32_t npairs, int shift, int cross_check, uint32_t* queue_head,
-                       Top2* rowbuf, Top2* colbuf, hipStream_t s);
-size_t match_mfma_max_cols();  // largest rows_pad(slot2) the mfma kernel's LDS layout admits
+// mfma: one workgroup per work item, dynamic queue over `order` (pair indices, sorted by the
+// streamed image for L2 reuse).  mode 0: rows of image 1 vs image 2 -> rowbuf + row_off.
+// mode 1: candidate rows of image 2 (candbuf + col_off, cand_cnt[pair] of them) vs image 1 ->
+// colbuf + col_off (scattered by row index).
+void launch_match_mfma(int mode, const ImageDev* imgs, const PairDev* pairs,
+                       const uint32_t* order, uint32_t nitems, uint32_t* queue_head,
+                       const uint32_t* cand_cnt, const uint32_t* candbuf, Top2* outbuf,
+                       hipStream_t s);
+
+void launch_resolve_index(int side, const ImageDev* imgs, const PairDev* pairs, uint32_t npairs,
+                          Top2* table, const float* acos_lut, FinalizeParams fp,
+                          const uint32_t* cand_cnt, const uint32_t* candbuf, uint32_t* err_count,
+                          hipStream_t s);
+constexpr uint32_t kSelectMaxCols = 8192;  // select_candidates' LDS bitmap
+
+void launch_select_candidates(const ImageDev* imgs, const PairDev* pairs, uint32_t npairs,
+                              const Top2* rowbuf, const float* acos_lut, FinalizeParams fp,
+                              uint32_t* cand_cnt, uint32_t* candbuf, hipStream_t s);
 
 void launch_finalize(const ImageDev* imgs, const PairDev* pairs, uint32_t npairs,
                      const Top2* rowbuf, const Top2* colbuf, const float* acos_lut,

@@ -86,7 +86,6 @@ __global__ __launch_bounds__(256) void finalize_kernel(
     const Top2* rows = rowbuf + p.row_off;
     const Top2* cols = colbuf + p.col_off;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const bool value_mode = (p.mode != 0);
 
     auto is_match = [&](uint32_t i, uint32_t& j_out) -> bool {
         if (i >= n1 || n2 == 0) return false;
@@ -94,13 +93,13 @@ __global__ __launch_bounds__(256) void finalize_kernel(
         if (!one_way_accepts(t, lut, fp.max_ratio, fp.max_distance)) return false;
         const uint32_t j = t.best_idx;
         j_out = j;
+        if (j >= n2) return false;  // unresolved (counted as an internal error upstream)
         if (!fp.cross_check) return true;
         const Top2 c = cols[j];
         if (!one_way_accepts(c, lut, fp.max_ratio, fp.max_distance)) return false;
-        // value mode: column j accepted => its maximum is unique (ties fail the ratio test
-        // whenever max_ratio <= 1), and dist(i,j) == t.best_v lies in column j, so i is the
-        // column's argmax iff the values agree.
-        return value_mode ? (c.best_v == t.best_v) : (c.best_idx == i);
+        // cols[j] exists for every j an accepted row points at: the dot4 path scans all columns,
+        // the mfma path scans exactly those (select_candidates_kernel)
+        return c.best_idx == i;
     };
 
     // pass 1: count
@@ -142,6 +141,145 @@ __global__ __launch_bounds__(256) void finalize_kernel(
         }
         running += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
     }
+}
+
+// ---------------------------------------------------------------------------------------
+// resolve_index: the mfma kernel reports, per X row, the best VALUE and the 32-row TILE of Y
+// holding it.  For the rows that pass COLMAP's acceptance tests (the only ones whose index is
+// ever used) recompute the 32 dot products of that tile on the raw u8 descriptors and take the
+// lowest row whose value equals the best: COLMAP's strict-'>' scan keeps exactly that one.
+// side 0: X rows = all rows of image 1, table = rowbuf.  side 1: X rows = the candidate rows of
+// image 2 (candbuf), table = colbuf.  One workgroup per pair, a wave per accepted row in turn:
+// lane = (Y row of the tile, half of the 128 bytes).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void resolve_index_kernel(
+    int side, const ImageDev* __restrict__ imgs, const PairDev* __restrict__ pairs,
+    Top2* __restrict__ table, const float* __restrict__ lut, FinalizeParams fp,
+    const uint32_t* __restrict__ cand_cnt, const uint32_t* __restrict__ candbuf,
+    uint32_t* __restrict__ err_count) {
+    const PairDev p = pairs[blockIdx.x];
+    if (p.mode == 0) return;  // dot4 pairs carry exact indices already
+    const ImageDev X = imgs[side == 0 ? p.slot1 : p.slot2];
+    const ImageDev Y = imgs[side == 0 ? p.slot2 : p.slot1];
+    const uint32_t n = side == 0 ? X.rows : cand_cnt[blockIdx.x];
+    if (n == 0 || Y.rows == 0) return;
+    Top2* tab = table + (side == 0 ? p.row_off : p.col_off);
+    const uint32_t* list = candbuf + p.col_off;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const uint32_t l31 = lane & 31, half = lane >> 5;
+    for (uint32_t base = wid * 64; base < n; base += 256) {
+        const uint32_t e = base + lane;
+        uint32_t row = 0;
+        Top2 t = Top2{0u, 0xFFFFFFFFu, 0u, 0u};
+        bool acc = false;
+        if (e < n) {
+            row = side == 0 ? e : list[e];
+            t = tab[row];
+            acc = one_way_accepts(t, lut, fp.max_ratio, fp.max_distance);
+        }
+        uint32_t resolved = 0xFFFFFFFFu;
+        unsigned long long mask = __ballot(acc);
+        while (mask) {
+            const int b = __ffsll((long long)mask) - 1;
+            mask &= mask - 1;
+            const uint32_t xrow = __shfl(row, b);
+            const uint32_t tile = __shfl(t.best_idx, b);
+            const uint32_t val = __shfl(t.best_v, b);
+            const uint32_t jj = tile * 32 + l31;
+            uint32_t sum = 0;
+            if (jj < Y.rows_pad) {
+                const uint4* xp = reinterpret_cast<const uint4*>(X.raw + (size_t)xrow * kDim + half * 64);
+                const uint4* yp = reinterpret_cast<const uint4*>(Y.raw + (size_t)jj * kDim + half * 64);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint4 a = xp[k], c = yp[k];
+                    sum = __builtin_amdgcn_udot4(a.x, c.x, sum, false);
+                    sum = __builtin_amdgcn_udot4(a.y, c.y, sum, false);
+                    sum = __builtin_amdgcn_udot4(a.z, c.z, sum, false);
+                    sum = __builtin_amdgcn_udot4(a.w, c.w, sum, false);
+                }
+            }
+            sum += __shfl_xor(sum, 32);
+            const bool eq = (sum == val) && (jj < Y.rows);
+            const uint32_t m = (uint32_t)(__ballot(eq) & 0xFFFFFFFFull);
+            const uint32_t j = m ? tile * 32 + (uint32_t)(__ffs(m) - 1) : 0xFFFFFFFFu;
+            if ((int)lane == b) {
+                resolved = j;
+                if (!m) atomicAdd(err_count, 1u);  // scan and recomputation disagree: a bug
+            }
+        }
+        if (e < n) tab[row].best_idx = resolved;  // unaccepted rows: index never used
+    }
+}
+
+void launch_resolve_index(int side, const ImageDev* imgs, const PairDev* pairs, uint32_t npairs,
+                          Top2* table, const float* acos_lut, FinalizeParams fp,
+                          const uint32_t* cand_cnt, const uint32_t* candbuf, uint32_t* err_count,
+                          hipStream_t s) {
+    if (npairs == 0) return;
+    hipLaunchKernelGGL(resolve_index_kernel, dim3(npairs), dim3(256), 0, s, side, imgs, pairs,
+                       table, acos_lut, fp, cand_cnt, candbuf, err_count);
+}
+
+// ---------------------------------------------------------------------------------------
+// select_candidates: which rows of image 2 ("columns") does the cross check need?  Exactly
+// those some accepted row of image 1 points at.  One workgroup per pair: rows that pass
+// COLMAP's one-way tests set bit best_idx in an LDS bitmap (<= 8192 columns on the mfma path);
+// the bitmap is then compacted, ascending, into candbuf[col_off ...] and counted.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void select_candidates_kernel(
+    const ImageDev* __restrict__ imgs, const PairDev* __restrict__ pairs,
+    const Top2* __restrict__ rowbuf, const float* __restrict__ lut, FinalizeParams fp,
+    uint32_t* __restrict__ cand_cnt, uint32_t* __restrict__ candbuf) {
+    __shared__ uint32_t bits[256];  // 8192 columns
+    __shared__ uint32_t wsum[4];
+    const PairDev p = pairs[blockIdx.x];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (p.mode == 0) {  // dot4 pair: its column table is complete already
+        if (tid == 0) cand_cnt[blockIdx.x] = 0;
+        return;
+    }
+    const uint32_t n1 = imgs[p.slot1].rows, n2 = imgs[p.slot2].rows;
+    const Top2* rows = rowbuf + p.row_off;
+    bits[tid] = 0;
+    __syncthreads();
+    if (n2 != 0) {
+        for (uint32_t i = tid; i < n1; i += 256) {
+            const Top2 t = rows[i];
+            if (one_way_accepts(t, lut, fp.max_ratio, fp.max_distance) && t.best_idx < n2)
+                atomicOr(&bits[t.best_idx >> 5], 1u << (t.best_idx & 31));
+        }
+    }
+    __syncthreads();
+    const uint32_t w = bits[tid];
+    const uint32_t c = __popc(w);
+    // inclusive scan over the 256 words
+    uint32_t inc = c;
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+        const uint32_t o = __shfl_up(inc, m);
+        if (lane >= (uint32_t)m) inc += o;
+    }
+    if (lane == 63) wsum[wid] = inc;
+    __syncthreads();
+    uint32_t base = 0;
+    for (uint32_t k = 0; k < wid; ++k) base += wsum[k];
+    uint32_t* dst = candbuf + p.col_off + base + inc - c;
+    uint32_t ww = w;
+    while (ww) {
+        const uint32_t b = __ffs(ww) - 1;
+        *dst++ = tid * 32 + b;
+        ww &= ww - 1;
+    }
+    if (tid == 255) cand_cnt[blockIdx.x] = base + inc;
+}
+
+void launch_select_candidates(const ImageDev* imgs, const PairDev* pairs, uint32_t npairs,
+                              const Top2* rowbuf, const float* acos_lut, FinalizeParams fp,
+                              uint32_t* cand_cnt, uint32_t* candbuf, hipStream_t s) {
+    if (npairs == 0) return;
+    hipLaunchKernelGGL(select_candidates_kernel, dim3(npairs), dim3(256), 0, s, imgs, pairs,
+                       rowbuf, acos_lut, fp, cand_cnt, candbuf);
 }
 
 void launch_finalize(const ImageDev* imgs, const PairDev* pairs, uint32_t npairs,

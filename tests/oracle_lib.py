@@ -41,7 +41,7 @@ def _p(a: np.ndarray):
 def match(d1: np.ndarray, d2: np.ndarray, max_ratio=0.8, max_distance=0.7, cross_check=True):
     d1 = np.ascontiguousarray(d1, dtype=np.uint8).reshape(-1, 128)
     d2 = np.ascontiguousarray(d2, dtype=np.uint8).reshape(-1, 128)
-    out = np.zeros((max(1, min(len(d1), len(d2))), 2), dtype=np.uint32)
+    out = np.zeros((max(1, len(d1)), 2), dtype=np.uint32)
     n = load().oracle_match(_p(d1), len(d1), _p(d2), len(d2), max_ratio, max_distance,
                             int(cross_check), _p(out))
     assert n >= 0
@@ -66,7 +66,7 @@ def match_pairs(images, slot1, slot2, max_ratio=0.8, max_distance=0.7, cross_che
     arena = np.ascontiguousarray(arena)
     s1 = np.ascontiguousarray(slot1, dtype=np.uint32)
     s2 = np.ascontiguousarray(slot2, dtype=np.uint32)
-    cap = np.minimum(rows[s1], rows[s2]).astype(np.uint64)
+    cap = rows[s1].astype(np.uint64)
     out_off = np.zeros(len(s1) + 1, dtype=np.uint64)
     out_off[1:] = np.cumsum(cap)
     counts = np.zeros(len(s1), dtype=np.uint32)

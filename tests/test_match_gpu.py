@@ -98,33 +98,48 @@ def test_adversarial_ties_zeros_duplicates(amc_ctx, kernel):
         assert_same(amc_ctx, imgs, s1, s2, kernel, opts)
 
 
-def test_unnormalised_and_saturated_fall_back_to_dot4(amc_ctx):
-    """Raw random bytes break the packed-key value bound: AUTO must route them to the dot4
-    kernel (and forcing MFMA must be refused), results still bit-exact."""
+def test_unnormalised_and_saturated_descriptors(amc_ctx):
+    """Raw random bytes and saturated rows (dot up to 128*255^2) are exact on BOTH kernels: the
+    mfma scan works on full-range int32 values, no norm precondition."""
     rng = np.random.default_rng(6)
     a = rng.integers(0, 256, size=(200, 128), dtype=np.uint8)
     b = rng.integers(0, 256, size=(150, 128), dtype=np.uint8)
     sat = np.full((70, 128), 255, np.uint8)
-    imgs = [a, b, sat]
-    s1, s2 = synth.exhaustive_pairs(3)
+    mixed = np.concatenate([sat[:5], a[:40], np.zeros((3, 128), np.uint8), b[:30]])
+    big = rng.integers(0, 256, size=(4096, 128), dtype=np.uint8)
+    imgs = [a, b, sat, mixed, big]
+    s1, s2 = synth.exhaustive_pairs(len(imgs))
     upload(amc_ctx, imgs)
-    for opts in [(0.8, 0.7, True), (0.99, 3.0, False)]:
-        assert_same(amc_ctx, imgs, s1, s2, "auto", opts, expect_kernel="dot4")
-    with pytest.raises(_capi.AmcError):
-        amc_ctx.match_pairs(s1, s2, kernel="mfma")
+    for kernel in ("mfma", "dot4"):
+        for opts in [(0.8, 0.7, True), (0.99, 3.0, True), (0.99, 3.0, False)]:
+            assert_same(amc_ctx, imgs, s1, s2, kernel, opts, expect_kernel=kernel)
+            assert_same(amc_ctx, imgs, s2, s1, kernel, opts, expect_kernel=kernel)
 
 
-def test_max_ratio_above_one_routes_to_index_tracking_kernel(amc_ctx):
-    """max_ratio > 1 lets tied bests through the ratio test; the value-mode cross check is
-    not exact there, so AUTO must use the index-tracking dot4 kernel."""
+def test_max_ratio_above_one_ties_pass_the_ratio_test(amc_ctx):
+    """max_ratio > 1 lets tied bests through the ratio test: the lowest index among the ties
+    must be reported in both directions (exact index cross check on both kernels)."""
     rng = np.random.default_rng(7)
     a = synth.random_descriptors(rng, 128)
     b = np.concatenate([a, a])  # every column duplicated -> ties everywhere
     imgs = [a, b]
     upload(amc_ctx, imgs)
     s1 = np.array([0, 1], np.uint32); s2 = np.array([1, 0], np.uint32)
-    assert_same(amc_ctx, imgs, s1, s2, "auto", (1.5, 3.0, True), expect_kernel="dot4")
-    assert_same(amc_ctx, imgs, s1, s2, "auto", (1.5, 3.0, False))
+    for kernel in ("mfma", "dot4"):
+        assert_same(amc_ctx, imgs, s1, s2, kernel, (1.5, 3.0, True), expect_kernel=kernel)
+        assert_same(amc_ctx, imgs, s1, s2, kernel, (1.5, 3.0, False), expect_kernel=kernel)
+
+
+@pytest.mark.parametrize("kernel", ["dot4", "mfma"])
+def test_without_cross_check_more_matches_than_columns(amc_ctx, kernel):
+    rng = np.random.default_rng(12)
+    b = synth.random_descriptors(rng, 40)
+    a = np.concatenate([b] * 5)[rng.permutation(200)]
+    imgs = [a, b]
+    upload(amc_ctx, imgs)
+    off, m, _ = assert_same(amc_ctx, imgs, np.array([0], np.uint32), np.array([1], np.uint32),
+                            kernel, (0.99, 3.0, False))
+    assert off[-1] == 200
 
 
 def test_invalid_arguments_raise(amc_ctx):
@@ -169,7 +184,7 @@ def test_full_size_properties_4096(amc_ctx):
     assert len(m_s) > 0 and np.all(m_s[:, 0] == m_s[:, 1])
 
 
-def test_8192_rows_uses_13_bit_keys(amc_ctx):
+def test_8192_rows(amc_ctx):
     rng = np.random.default_rng(9)
     imgs = synth.scene_images(rng, 2, 8192, num_landmarks=16000, visible_frac=0.4)
     upload(amc_ctx, imgs)

@@ -126,6 +126,16 @@ def test_kat_empty_and_single():
     np.testing.assert_array_equal(m, np.array([[0, 0]], np.uint32))
 
 
+def test_without_cross_check_rows_may_share_a_column():
+    """No cross check: up to n1 matches even when n2 < n1 (several rows -> one column)."""
+    rng = np.random.default_rng(12)
+    b = synth.random_descriptors(rng, 3)
+    a = np.concatenate([b, b, b])[rng.permutation(9)]
+    m = oracle_lib.match(a, b, max_ratio=0.99, max_distance=3.0, cross_check=False)
+    assert len(m) == 9 and len(set(m[:, 1].tolist())) == 3
+    assert len(oracle_lib.match(a, b, max_ratio=0.99, max_distance=3.0, cross_check=True)) == 0
+
+
 def test_cross_check_is_transpose_symmetric():
     rng = np.random.default_rng(5)
     imgs = synth.scene_images(rng, 2, 200, num_landmarks=350, visible_frac=0.5)

@@ -1,0 +1,56 @@
+// ubench_mix.hip — do int8 MFMA and half-rate VALU overlap on one SIMD?  Per iteration: 4 MFMAs
+// (32x32x32 i8, 4 independent accumulators) each followed by N independent v_max3_i32.
+// If the pipes overlap: cycles/MFMA = max(~35, 4N [or 2N]); if they serialise: ~35 + 4N.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+template <int N, int OPK>
+__global__ __launch_bounds__(1024) void k(int* out, int iters) {
+    i32x4 a = {1, 2, 3, (int)threadIdx.x}, b = {4, 5, 6, 7};
+    i32x16 acc[4];
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 16; ++j) acc[i][j] = 0;
+    int v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = threadIdx.x + i;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            acc[m] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, acc[m], 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < N; ++u) {
+                if (OPK == 0) asm volatile("v_max3_i32 %0, %0, %1, %2" : "+v"(v[u & 7]) : "v"(v[(u + 3) & 7]), "v"(v[(u + 5) & 7]));
+                if (OPK == 1) asm volatile("v_add_u32 %0, %0, %1" : "+v"(v[u & 7]) : "v"(v[(u + 3) & 7]));
+            }
+        }
+    }
+    int s = 0;
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 16; ++j) s += acc[i][j];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += v[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+template <int N, int OPK>
+void run(int* out, int waves_per_simd) {
+    const int CUS = 256, iters = 3000;
+    const int threads = 256 * waves_per_simd;  // one block per CU
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    hipLaunchKernelGGL((k<N, OPK>), dim3(CUS), dim3(threads), 0, 0, out, iters);
+    (void)hipDeviceSynchronize();
+    (void)hipEventRecord(e0);
+    hipLaunchKernelGGL((k<N, OPK>), dim3(CUS), dim3(threads), 0, 0, out, iters);
+    (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+    float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+    const double mf_per_simd = (double)iters * 4 * waves_per_simd;
+    const double cyc = ms * 1e-3 * 2.4e9 / mf_per_simd;
+    printf("%s N=%2d waves/SIMD=%d: %7.3f ms  cycles per (MFMA + N valu) per SIMD @2.4GHz = %6.1f   (serial model %3d, overlap model %3d)\n",
+           OPK == 0 ? "v_max3_i32" : "v_add_u32 ", N, waves_per_simd, ms, cyc, 35 + (OPK == 0 ? 4 : 2) * N, (OPK == 0 ? 4 : 2) * N > 35 ? (OPK == 0 ? 4 : 2) * N : 35);
+}
+int main() {
+    int* out; (void)hipMalloc(&out, 256 * 1024 * sizeof(int));
+    for (int w = 1; w <= 4; ++w) {
+        run<0, 0>(out, w); run<6, 0>(out, w); run<8, 0>(out, w); run<10, 0>(out, w); run<12, 0>(out, w); run<16, 0>(out, w);
+        run<10, 1>(out, w); run<20, 1>(out, w);
+    }
+    return 0;
+}
