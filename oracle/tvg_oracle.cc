@@ -1,0 +1,1264 @@
+/*
+ * oracle/tvg_oracle.cc — CPU restatement of COLMAP 3.9.1's two-view geometric verification
+ * (EstimateTwoViewGeometry: LO-RANSAC over F (7-pt / 8-pt), H (DLT), E (5-pt), model selection,
+ * watermark test), SURVEY.md Appendix A.3.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under pycolmap_amd/ may link, import or call this file.
+ *
+ * PARITY UNPINNED.  The arithmetic lives in the un-vendored COLMAP 3.9.1
+ * (/root/reference/CMakeLists.txt:17) which is not available here, and the reference has no
+ * tests for this path.  This file restates the published control flow literally —
+ *   colmap/optim/loransac.h  LORANSAC::Estimate            -> lo_ransac()
+ *   colmap/optim/ransac.h    RANSAC ctor, ComputeNumTrials  -> compute_num_trials(), ransac_max_trials()
+ *   colmap/optim/support_measurement.cc InlierSupportMeasurer -> evaluate_support(), better()
+ *   colmap/optim/random_sampler.cc, colmap/math/random.cc   -> Prng, Sampler (std::mt19937 +
+ *        std::uniform_int_distribution<uint32_t>, exactly what COLMAP calls)
+ *   colmap/estimators/fundamental_matrix.cc  7-point / 8-point
+ *   colmap/estimators/homography_matrix.cc   normalised DLT
+ *   colmap/estimators/utils.cc   CenterAndNormalizeImagePoints, ComputeSquaredSampsonError
+ *   colmap/estimators/translation_transform.h
+ *   colmap/estimators/two_view_geometry.cc   Estimate{Calibrated,Uncalibrated}TwoViewGeometry,
+ *        DetectWatermark
+ * anchored on the reference-side facts that ARE verifiable:
+ *   estimator pairs 7pt/8pt, H/H, 5pt/5pt   /root/reference/pycolmap/estimators/fundamental_matrix.h:26-28,
+ *        homography_matrix.h:25, essential_matrix.h:48-49
+ *   SetPRNGSeed(0) before each single-pair estimate   .../fundamental_matrix.h:21
+ *   E threshold = mean of max_error / focal            .../essential_matrix.h:41-46
+ *   option names + Python-side RANSAC defaults         /root/reference/pycolmap/optim/bindings.h:10-25,
+ *        .../estimators/two_view_geometry.h:41-63; config enum order ...:67-77
+ *
+ * Deliberate, documented deviations (COLMAP leans on Eigen, absent here):
+ *   D1  Null spaces come from Gauss-Jordan elimination with full pivoting (minimal solvers) or
+ *       the smallest eigenvector of A^T A by cyclic Jacobi (least-squares solvers) instead of
+ *       Eigen::JacobiSVD; rank-2 enforcement projects out the smallest right singular vector.
+ *   D2  Polynomial roots by bracketing + bisection on the real line instead of companion-matrix
+ *       eigenvalues; models are tried in ascending root order.
+ *   D3  Sums over correspondences (centroids, A^T A, inlier residual sums) use a fixed 64-way
+ *       strided + butterfly order (det_sum64) so that a 64-lane wavefront reproduces them
+ *       bit-for-bit; COLMAP sums sequentially.  Same values up to rounding.
+ *   D4  Per-pair reseed: the PRNG is re-created with seed 0 at the start of every image pair
+ *       (COLMAP's pipeline carries a thread_local PRNG across pairs and is therefore not
+ *       reproducible run-to-run).
+ * Compile with -ffp-contract=off (oracle/Makefile): no FMA contraction, IEEE double throughout.
+ */
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <limits>
+#include <random>
+#include <vector>
+
+namespace {
+
+// ----------------------------------------------------------------------------------------------
+// options / types (mirrors of COLMAP structs; field names as pycolmap exposes them)
+// ----------------------------------------------------------------------------------------------
+struct RansacOptions {
+    double max_error;
+    double min_inlier_ratio;
+    double confidence;
+    double dyn_num_trials_multiplier;
+    int64_t min_num_trials;
+    int64_t max_num_trials;
+};
+
+struct TvgOptions {
+    int32_t min_num_inliers;
+    double min_E_F_inlier_ratio;
+    double max_H_inlier_ratio;
+    double watermark_min_inlier_ratio;
+    double watermark_border_size;
+    int32_t detect_watermark;
+    int32_t multiple_ignore_watermark;
+    int32_t force_H_use;
+    int32_t compute_relative_pose;
+    int32_t multiple_models;
+    RansacOptions ransac;
+};
+
+struct Camera {
+    int32_t model_id;  // 0 SIMPLE_PINHOLE (f,cx,cy), 1 PINHOLE (fx,fy,cx,cy)
+    int32_t has_prior_focal_length;
+    uint64_t width, height;
+    double params[12];
+};
+
+enum Config { UNDEFINED = 0, DEGENERATE = 1, CALIBRATED = 2, UNCALIBRATED = 3, PLANAR = 4,
+              PANORAMIC = 5, PLANAR_OR_PANORAMIC = 6, WATERMARK = 7, MULTIPLE = 8 };
+
+struct Pt { double x, y; };
+struct Mat3 { double m[9]; };  // row-major
+
+struct Support {
+    size_t num_inliers = 0;
+    double residual_sum = std::numeric_limits<double>::max();
+};
+
+struct Report {
+    bool success = false;
+    size_t num_trials = 0;
+    Support support;
+    std::vector<char> inlier_mask;
+    Mat3 model{};
+};
+
+// ----------------------------------------------------------------------------------------------
+// D3: deterministic 64-way sum.  partial[k & 63] accumulates term k in increasing k; then a
+// butterfly (xor 32,16,8,4,2,1).  A 64-lane wave computes exactly this.
+// ----------------------------------------------------------------------------------------------
+template <typename F>
+double det_sum64(size_t n, F term) {
+    double p[64];
+    for (int l = 0; l < 64; ++l) p[l] = 0.0;
+    for (size_t k = 0; k < n; ++k) p[k & 63] += term(k);
+    for (int m = 32; m >= 1; m >>= 1) {
+        double q[64];
+        for (int l = 0; l < 64; ++l) q[l] = p[l] + p[l ^ m];
+        for (int l = 0; l < 64; ++l) p[l] = q[l];
+    }
+    return p[0];
+}
+
+// ----------------------------------------------------------------------------------------------
+// PRNG + sampler: colmap/math/random.{h,cc}, colmap/optim/random_sampler.cc
+// ----------------------------------------------------------------------------------------------
+struct Prng {
+    std::mt19937 gen;
+    explicit Prng(uint32_t seed) : gen(seed) {}
+    // RandomUniformInteger<uint32_t>(lo, hi): a fresh distribution object per call
+    uint32_t uniform(uint32_t lo, uint32_t hi) {
+        std::uniform_int_distribution<uint32_t> d(lo, hi);
+        return d(gen);
+    }
+};
+
+struct Sampler {
+    size_t k;
+    std::vector<size_t> idx;
+    explicit Sampler(size_t num_samples) : k(num_samples) {}
+    void initialize(size_t total) {
+        idx.resize(total);
+        for (size_t i = 0; i < total; ++i) idx[i] = i;
+    }
+    // Shuffle(k, &idx): partial Fisher-Yates; the permutation persists across trials
+    void sample(Prng& prng, size_t* out) {
+        const uint32_t last = static_cast<uint32_t>(idx.size() - 1);
+        for (uint32_t i = 0; i < static_cast<uint32_t>(k); ++i) {
+            const uint32_t j = prng.uniform(i, last);
+            std::swap(idx[i], idx[j]);
+        }
+        for (size_t i = 0; i < k; ++i) out[i] = idx[i];
+    }
+};
+
+// ----------------------------------------------------------------------------------------------
+// RANSAC bookkeeping: colmap/optim/ransac.h
+// ----------------------------------------------------------------------------------------------
+size_t compute_num_trials(size_t num_inliers, size_t num_samples, double confidence,
+                          double multiplier, int min_num_samples) {
+    const double inlier_ratio = num_inliers / static_cast<double>(num_samples);
+    const double nom = 1 - confidence;
+    if (nom <= 0) return std::numeric_limits<size_t>::max();
+    const double denom = 1 - std::pow(inlier_ratio, min_num_samples);
+    if (denom <= 0) return 1;
+    if (denom == 1.0) return std::numeric_limits<size_t>::max();
+    return static_cast<size_t>(std::ceil(std::log(nom) / std::log(denom) * multiplier));
+}
+
+// RANSAC constructor: clamp max_num_trials by the trials needed at min_inlier_ratio
+size_t ransac_max_trials(const RansacOptions& o, int min_num_samples) {
+    const size_t kNumSamples = 100000;
+    const size_t dyn = compute_num_trials(static_cast<size_t>(o.min_inlier_ratio * kNumSamples),
+                                          kNumSamples, o.confidence, o.dyn_num_trials_multiplier,
+                                          min_num_samples);
+    return std::min<size_t>(static_cast<size_t>(o.max_num_trials), dyn);
+}
+
+// InlierSupportMeasurer::Evaluate (sum in det_sum64 order, D3)
+Support evaluate_support(const std::vector<double>& r, double max_residual) {
+    Support s;
+    s.num_inliers = 0;
+    for (double v : r)
+        if (v <= max_residual) s.num_inliers += 1;
+    s.residual_sum = det_sum64(r.size(), [&](size_t k) { return r[k] <= max_residual ? r[k] : 0.0; });
+    return s;
+}
+bool better(const Support& a, const Support& b) {
+    if (a.num_inliers > b.num_inliers) return true;
+    return a.num_inliers == b.num_inliers && a.residual_sum < b.residual_sum;
+}
+
+// ----------------------------------------------------------------------------------------------
+// small dense linear algebra (D1, D2)
+// ----------------------------------------------------------------------------------------------
+Mat3 mat3_mul(const Mat3& a, const Mat3& b) {
+    Mat3 c;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            c.m[3 * i + j] = a.m[3 * i + 0] * b.m[0 + j] + a.m[3 * i + 1] * b.m[3 + j] +
+                             a.m[3 * i + 2] * b.m[6 + j];
+    return c;
+}
+Mat3 mat3_t(const Mat3& a) {
+    Mat3 c;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) c.m[3 * i + j] = a.m[3 * j + i];
+    return c;
+}
+
+// cyclic Jacobi eigen-decomposition of a symmetric n x n matrix (n <= 9), fixed rotation order.
+// a is destroyed (diagonal = eigenvalues); v = eigenvectors in columns (row-major n x n).
+void jacobi_eigen(int n, double* a, double* v) {
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) v[i * n + j] = (i == j) ? 1.0 : 0.0;
+    double total = 0.0;
+    for (int i = 0; i < n * n; ++i) total += a[i] * a[i];
+    const double tol = total * 1e-32;
+    for (int sweep = 0; sweep < 40; ++sweep) {
+        double off = 0.0;
+        for (int p = 0; p < n - 1; ++p)
+            for (int q = p + 1; q < n; ++q) off += a[p * n + q] * a[p * n + q];
+        if (!(off > tol)) break;
+        for (int p = 0; p < n - 1; ++p) {
+            for (int q = p + 1; q < n; ++q) {
+                const double apq = a[p * n + q];
+                if (apq == 0.0) continue;
+                const double theta = (a[q * n + q] - a[p * n + p]) / (2.0 * apq);
+                const double t = (theta >= 0.0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+                const double c = 1.0 / std::sqrt(t * t + 1.0);
+                const double s = t * c;
+                for (int k = 0; k < n; ++k) {  // columns p,q of A
+                    const double akp = a[k * n + p], akq = a[k * n + q];
+                    a[k * n + p] = c * akp - s * akq;
+                    a[k * n + q] = s * akp + c * akq;
+                }
+                for (int k = 0; k < n; ++k) {  // rows p,q of A
+                    const double apk = a[p * n + k], aqk = a[q * n + k];
+                    a[p * n + k] = c * apk - s * aqk;
+                    a[q * n + k] = s * apk + c * aqk;
+                }
+                for (int k = 0; k < n; ++k) {
+                    const double vkp = v[k * n + p], vkq = v[k * n + q];
+                    v[k * n + p] = c * vkp - s * vkq;
+                    v[k * n + q] = s * vkp + c * vkq;
+                }
+            }
+        }
+    }
+}
+
+// eigenvector of the smallest eigenvalue of the symmetric 9x9 matrix ata (destroyed)
+void smallest_eigvec9(double* ata, double* x) {
+    double v[81];
+    jacobi_eigen(9, ata, v);
+    int best = 0;
+    for (int i = 1; i < 9; ++i)
+        if (ata[i * 9 + i] < ata[best * 9 + best]) best = i;
+    for (int i = 0; i < 9; ++i) x[i] = v[i * 9 + best];
+}
+
+// null space of an R x 9 matrix (R <= 8) by Gauss-Jordan elimination with full pivoting.
+// Writes 9-R basis vectors into ns (row k = k-th basis vector).  a is destroyed.
+void nullspace9(int R, double* a /* R x 9 */, double* ns /* (9-R) x 9 */) {
+    int perm[9];
+    for (int j = 0; j < 9; ++j) perm[j] = j;
+    for (int r = 0; r < R; ++r) {
+        int pi = r, pj = r;
+        double pv = -1.0;
+        for (int i = r; i < R; ++i)
+            for (int j = r; j < 9; ++j) {
+                const double v = std::fabs(a[i * 9 + j]);
+                if (v > pv) { pv = v; pi = i; pj = j; }
+            }
+        if (pi != r)
+            for (int j = 0; j < 9; ++j) std::swap(a[r * 9 + j], a[pi * 9 + j]);
+        if (pj != r) {
+            for (int i = 0; i < R; ++i) std::swap(a[i * 9 + r], a[i * 9 + pj]);
+            std::swap(perm[r], perm[pj]);
+        }
+        const double inv = 1.0 / a[r * 9 + r];
+        for (int j = 0; j < 9; ++j) a[r * 9 + j] = a[r * 9 + j] * inv;
+        for (int i = 0; i < R; ++i) {
+            if (i == r) continue;
+            const double f = a[i * 9 + r];
+            for (int j = 0; j < 9; ++j) a[i * 9 + j] = a[i * 9 + j] - f * a[r * 9 + j];
+        }
+    }
+    for (int k = 0; k < 9 - R; ++k) {
+        double* x = ns + k * 9;
+        for (int j = 0; j < 9; ++j) x[j] = 0.0;
+        x[perm[R + k]] = 1.0;
+        for (int i = 0; i < R; ++i) x[perm[i]] = -a[i * 9 + (R + k)];
+    }
+}
+
+double poly_eval(const double* c, int deg, double x) {  // c[0] + c[1] x + ...
+    double v = c[deg];
+    for (int i = deg - 1; i >= 0; --i) v = v * x + c[i];
+    return v;
+}
+
+// real roots of one polynomial whose derivative's real roots (`crit`, ascending) are known:
+// between consecutive critical points the polynomial is monotone, so each sign change brackets
+// exactly one root; fixed-length bisection (runs until the interval cannot be split further).
+int roots_between(const double* c, int deg, const double* crit, int nc, double* roots) {
+    if (deg == 1) {
+        roots[0] = -c[0] / c[1];
+        return 1;
+    }
+    double bound = 0.0;  // Cauchy bound on the root magnitudes
+    for (int i = 0; i < deg; ++i) bound = std::max(bound, std::fabs(c[i] / c[deg]));
+    bound = 1.0 + bound;
+    double edges[12];
+    int ne = 0;
+    edges[ne++] = -bound;
+    for (int i = 0; i < nc; ++i)
+        if (crit[i] > -bound && crit[i] < bound) edges[ne++] = crit[i];
+    edges[ne++] = bound;
+    int nr = 0;
+    for (int i = 0; i + 1 < ne; ++i) {
+        double lo = edges[i], hi = edges[i + 1];
+        double flo = poly_eval(c, deg, lo);
+        const double fhi = poly_eval(c, deg, hi);
+        if (flo == 0.0) {
+            if (nr == 0 || roots[nr - 1] != lo) roots[nr++] = lo;
+            continue;
+        }
+        if (fhi == 0.0) continue;  // picked up as lo of the next interval (or below)
+        if ((flo < 0.0) == (fhi < 0.0)) continue;
+        for (int it = 0; it < 200; ++it) {
+            const double mid = 0.5 * (lo + hi);
+            if (mid == lo || mid == hi) break;
+            const double fm = poly_eval(c, deg, mid);
+            if (fm == 0.0) { lo = mid; hi = mid; break; }
+            if ((fm < 0.0) == (flo < 0.0)) { lo = mid; flo = fm; } else { hi = mid; }
+        }
+        roots[nr++] = 0.5 * (lo + hi);
+    }
+    if (poly_eval(c, deg, edges[ne - 1]) == 0.0 && (nr == 0 || roots[nr - 1] != edges[ne - 1]))
+        roots[nr++] = edges[ne - 1];
+    return nr;
+}
+
+// all real roots of a polynomial of degree <= 10, ascending (D2): bottom-up over the chain of
+// derivatives (degree 1 first), each level bracketed by the roots of the level below.
+int real_roots(const double* c_in, int deg_in, double* roots) {
+    int deg = deg_in;
+    while (deg > 0 && c_in[deg] == 0.0) --deg;
+    if (deg == 0) return 0;
+    double chain[11][11];  // chain[j] = j-th derivative, degree deg - j
+    for (int i = 0; i <= deg; ++i) chain[0][i] = c_in[i];
+    for (int j = 1; j < deg; ++j)
+        for (int i = 1; i <= deg - j + 1; ++i) chain[j][i - 1] = chain[j - 1][i] * i;
+    double crit[10], cur[10];
+    int nc = 0;
+    for (int j = deg - 1; j >= 0; --j) {
+        const int n = roots_between(chain[j], deg - j, crit, nc, cur);
+        nc = n;
+        for (int i = 0; i < n; ++i) crit[i] = cur[i];
+    }
+    for (int i = 0; i < nc; ++i) roots[i] = crit[i];
+    return nc;
+}
+
+// ----------------------------------------------------------------------------------------------
+// estimators/utils.cc
+// ----------------------------------------------------------------------------------------------
+void center_and_normalize(const std::vector<Pt>& pts, std::vector<Pt>* normed, Mat3* T) {
+    const size_t n = pts.size();
+    const double cx = det_sum64(n, [&](size_t k) { return pts[k].x; }) / n;
+    const double cy = det_sum64(n, [&](size_t k) { return pts[k].y; }) / n;
+    double rms = det_sum64(n, [&](size_t k) {
+        const double dx = pts[k].x - cx, dy = pts[k].y - cy;
+        return dx * dx + dy * dy;
+    });
+    rms = std::sqrt(rms / n);
+    const double nf = std::sqrt(2.0) / rms;
+    T->m[0] = nf; T->m[1] = 0; T->m[2] = -nf * cx;
+    T->m[3] = 0; T->m[4] = nf; T->m[5] = -nf * cy;
+    T->m[6] = 0; T->m[7] = 0; T->m[8] = 1;
+    normed->resize(n);
+    const double* M = T->m;
+    for (size_t i = 0; i < n; ++i) {
+        const double p0 = pts[i].x, p1 = pts[i].y;
+        const double np0 = M[0] * p0 + M[1] * p1 + M[2];
+        const double np1 = M[3] * p0 + M[4] * p1 + M[5];
+        const double np2 = M[6] * p0 + M[7] * p1 + M[8];
+        const double inv = 1.0 / np2;
+        (*normed)[i].x = np0 * inv;
+        (*normed)[i].y = np1 * inv;
+    }
+}
+
+// ComputeSquaredSampsonError, exact operation order of SURVEY.md A.3
+double sampson(const Mat3& E, const Pt& p1, const Pt& p2) {
+    const double* e = E.m;
+    const double x1_0 = p1.x, x1_1 = p1.y, x2_0 = p2.x, x2_1 = p2.y;
+    const double Ex1_0 = e[0] * x1_0 + e[1] * x1_1 + e[2];
+    const double Ex1_1 = e[3] * x1_0 + e[4] * x1_1 + e[5];
+    const double Ex1_2 = e[6] * x1_0 + e[7] * x1_1 + e[8];
+    const double Etx2_0 = e[0] * x2_0 + e[3] * x2_1 + e[6];
+    const double Etx2_1 = e[1] * x2_0 + e[4] * x2_1 + e[7];
+    const double x2tEx1 = x2_0 * Ex1_0 + x2_1 * Ex1_1 + Ex1_2;
+    return x2tEx1 * x2tEx1 /
+           (Ex1_0 * Ex1_0 + Ex1_1 * Ex1_1 + Etx2_0 * Etx2_0 + Etx2_1 * Etx2_1);
+}
+
+// HomographyMatrixEstimator::Residuals (forward transfer error in image 2)
+double h_residual(const Mat3& Hm, const Pt& p1, const Pt& p2) {
+    const double* H = Hm.m;
+    const double s_0 = p1.x, s_1 = p1.y, d_0 = p2.x, d_1 = p2.y;
+    const double pd_0 = H[0] * s_0 + H[1] * s_1 + H[2];
+    const double pd_1 = H[3] * s_0 + H[4] * s_1 + H[5];
+    const double pd_2 = H[6] * s_0 + H[7] * s_1 + H[8];
+    const double inv_pd_2 = 1.0 / pd_2;
+    const double dd_0 = d_0 - pd_0 * inv_pd_2;
+    const double dd_1 = d_1 - pd_1 * inv_pd_2;
+    return dd_0 * dd_0 + dd_1 * dd_1;
+}
+
+// ----------------------------------------------------------------------------------------------
+// estimators
+// ----------------------------------------------------------------------------------------------
+enum EstKind { EST_F7 = 0, EST_F8 = 1, EST_H = 2, EST_T = 3, EST_E5 = 4 };
+int est_min_samples(EstKind k) {
+    switch (k) {
+        case EST_F7: return 7;
+        case EST_F8: return 8;
+        case EST_H: return 4;
+        case EST_T: return 1;
+        case EST_E5: return 5;
+    }
+    return 0;
+}
+
+// FundamentalMatrixSevenPointEstimator::Estimate
+std::vector<Mat3> estimate_f7(const std::vector<Pt>& p1, const std::vector<Pt>& p2) {
+    double A[7 * 9];
+    for (int i = 0; i < 7; ++i) {
+        const double x0 = p1[i].x, y0 = p1[i].y, x1 = p2[i].x, y1 = p2[i].y;
+        double* r = A + i * 9;
+        r[0] = x1 * x0; r[1] = x1 * y0; r[2] = x1;
+        r[3] = y1 * x0; r[4] = y1 * y0; r[5] = y1;
+        r[6] = x0; r[7] = y0; r[8] = 1;
+    }
+    double ns[2 * 9];
+    nullspace9(7, A, ns);
+    double f1[9], f2[9];
+    for (int i = 0; i < 9; ++i) { f2[i] = ns[9 + i]; f1[i] = ns[i] - f2[i]; }
+    // det(lambda * f1 + f2) = c3 l^3 + c2 l^2 + c1 l + c0, entries e_ij = f1_ij l + f2_ij
+    auto mul11 = [](const double* a, const double* b, double* o) {  // (a0 + a1 l)(b0 + b1 l)
+        o[0] = a[0] * b[0];
+        o[1] = a[0] * b[1] + a[1] * b[0];
+        o[2] = a[1] * b[1];
+    };
+    auto minor2 = [&](int i, int j, int k, int l, double* o) {  // e_i e_j - e_k e_l (degree 2)
+        const double a[2] = {f2[i], f1[i]}, b[2] = {f2[j], f1[j]};
+        const double c[2] = {f2[k], f1[k]}, d[2] = {f2[l], f1[l]};
+        double u[3], w[3];
+        mul11(a, b, u);
+        mul11(c, d, w);
+        for (int t = 0; t < 3; ++t) o[t] = u[t] - w[t];
+    };
+    double m0[3], m1[3], m2[3];
+    minor2(4, 8, 5, 7, m0);
+    minor2(3, 8, 5, 6, m1);
+    minor2(3, 7, 4, 6, m2);
+    double c[4] = {0, 0, 0, 0};
+    auto acc = [&](int idx, const double* m, double sign) {  // c += sign * e_idx * m
+        const double e0 = f2[idx], e1 = f1[idx];
+        c[0] += sign * (e0 * m[0]);
+        c[1] += sign * (e0 * m[1] + e1 * m[0]);
+        c[2] += sign * (e0 * m[2] + e1 * m[1]);
+        c[3] += sign * (e1 * m[2]);
+    };
+    acc(0, m0, 1.0);
+    acc(1, m1, -1.0);
+    acc(2, m2, 1.0);
+    double roots[3];
+    const int nr = real_roots(c, 3, roots);
+    std::vector<Mat3> models;
+    for (int i = 0; i < nr; ++i) {
+        const double lambda = roots[i];
+        Mat3 F;
+        for (int k = 0; k < 9; ++k) F.m[k] = lambda * f1[k] + f2[k];
+        const double kEps = 1e-10;
+        if (std::fabs(F.m[8]) < kEps) continue;
+        const double inv = F.m[8];
+        for (int k = 0; k < 9; ++k) F.m[k] = F.m[k] / inv;
+        models.push_back(F);
+    }
+    return models;
+}
+
+// A^T A of the K x 9 design matrix whose k-th row is row(k, out9), summed in det_sum64 order
+template <typename RowFn>
+void accumulate_ata(size_t K, RowFn row, double* ata /* 81 */) {
+    std::vector<double> rows(K * 9);
+    for (size_t k = 0; k < K; ++k) row(k, rows.data() + k * 9);
+    for (int i = 0; i < 9; ++i)
+        for (int j = i; j < 9; ++j) {
+            const double s = det_sum64(K, [&](size_t k) { return rows[k * 9 + i] * rows[k * 9 + j]; });
+            ata[i * 9 + j] = s;
+            ata[j * 9 + i] = s;
+        }
+}
+
+// FundamentalMatrixEightPointEstimator::Estimate
+std::vector<Mat3> estimate_f8(const std::vector<Pt>& p1, const std::vector<Pt>& p2) {
+    std::vector<Pt> n1, n2;
+    Mat3 T1, T2;
+    center_and_normalize(p1, &n1, &T1);
+    center_and_normalize(p2, &n2, &T2);
+    double ata[81];
+    accumulate_ata(p1.size(), [&](size_t k, double* r) {
+        r[0] = n1[k].x * n2[k].x; r[1] = n1[k].y * n2[k].x; r[2] = n2[k].x;
+        r[3] = n1[k].x * n2[k].y; r[4] = n1[k].y * n2[k].y; r[5] = n2[k].y;
+        r[6] = n1[k].x; r[7] = n1[k].y; r[8] = 1.0;
+    }, ata);
+    double f[9];
+    smallest_eigvec9(ata, f);
+    Mat3 Fh;
+    for (int k = 0; k < 9; ++k) Fh.m[k] = f[k];
+    // rank 2: remove the component along the smallest right singular vector v3 of Fh
+    // (= smallest eigenvector of Fh^T Fh):  F' = Fh - (Fh v3) v3^T
+    double ftf[9], v[9];
+    const Mat3 FtF = mat3_mul(mat3_t(Fh), Fh);
+    for (int k = 0; k < 9; ++k) ftf[k] = FtF.m[k];
+    jacobi_eigen(3, ftf, v);
+    int b = 0;
+    for (int i = 1; i < 3; ++i)
+        if (ftf[i * 3 + i] < ftf[b * 3 + b]) b = i;
+    const double v3[3] = {v[0 * 3 + b], v[1 * 3 + b], v[2 * 3 + b]};
+    Mat3 Fr;
+    for (int i = 0; i < 3; ++i) {
+        const double fv = Fh.m[3 * i] * v3[0] + Fh.m[3 * i + 1] * v3[1] + Fh.m[3 * i + 2] * v3[2];
+        for (int j = 0; j < 3; ++j) Fr.m[3 * i + j] = Fh.m[3 * i + j] - fv * v3[j];
+    }
+    return {mat3_mul(mat3_mul(mat3_t(T2), Fr), T1)};
+}
+
+// HomographyMatrixEstimator::Estimate (normalised DLT); minimal case (N == 4) through the
+// 8 x 9 null space, over-determined through A^T A (D1)
+std::vector<Mat3> estimate_h(const std::vector<Pt>& p1, const std::vector<Pt>& p2) {
+    const size_t N = p1.size();
+    std::vector<Pt> n1, n2;
+    Mat3 T1, T2;
+    center_and_normalize(p1, &n1, &T1);
+    center_and_normalize(p2, &n2, &T2);
+    auto row_a = [&](size_t i, double* r) {
+        const double s_0 = n1[i].x, s_1 = n1[i].y, d_0 = n2[i].x;
+        r[0] = -s_0; r[1] = -s_1; r[2] = -1; r[3] = 0; r[4] = 0; r[5] = 0;
+        r[6] = s_0 * d_0; r[7] = s_1 * d_0; r[8] = d_0;
+    };
+    auto row_b = [&](size_t i, double* r) {
+        const double s_0 = n1[i].x, s_1 = n1[i].y, d_1 = n2[i].y;
+        r[0] = 0; r[1] = 0; r[2] = 0; r[3] = -s_0; r[4] = -s_1; r[5] = -1;
+        r[6] = s_0 * d_1; r[7] = s_1 * d_1; r[8] = d_1;
+    };
+    double h[9];
+    if (N == 4) {
+        double A[8 * 9];
+        for (size_t i = 0; i < 4; ++i) { row_a(i, A + i * 9); row_b(i, A + (4 + i) * 9); }
+        nullspace9(8, A, h);
+    } else {
+        double ata[81];
+        // rows 0..N-1 are the "a" rows, N..2N-1 the "b" rows (COLMAP's i / j = N + i layout)
+        accumulate_ata(2 * N, [&](size_t k, double* r) { if (k < N) row_a(k, r); else row_b(k - N, r); }, ata);
+        smallest_eigvec9(ata, h);
+    }
+    Mat3 Hh;
+    for (int k = 0; k < 9; ++k) Hh.m[k] = h[k];
+    // T2^-1 in closed form for the similarity [nf 0 -nf cx; 0 nf -nf cy; 0 0 1]
+    Mat3 T2i;
+    const double inv_nf = 1.0 / T2.m[0];
+    T2i.m[0] = inv_nf; T2i.m[1] = 0; T2i.m[2] = -T2.m[2] * inv_nf;
+    T2i.m[3] = 0; T2i.m[4] = inv_nf; T2i.m[5] = -T2.m[5] * inv_nf;
+    T2i.m[6] = 0; T2i.m[7] = 0; T2i.m[8] = 1;
+    return {mat3_mul(mat3_mul(T2i, Hh), T1)};
+}
+
+// TranslationTransformEstimator<2>::Estimate: model = mean(dst) - mean(src), stored in m[0..1]
+std::vector<Mat3> estimate_t(const std::vector<Pt>& p1, const std::vector<Pt>& p2) {
+    const size_t n = p1.size();
+    const double sx = det_sum64(n, [&](size_t k) { return p1[k].x; }) / n;
+    const double sy = det_sum64(n, [&](size_t k) { return p1[k].y; }) / n;
+    const double dx = det_sum64(n, [&](size_t k) { return p2[k].x; }) / n;
+    const double dy = det_sum64(n, [&](size_t k) { return p2[k].y; }) / n;
+    Mat3 t{};
+    t.m[0] = dx - sx;
+    t.m[1] = dy - sy;
+    return {t};
+}
+double t_residual(const Mat3& t, const Pt& p1, const Pt& p2) {
+    const double d0 = p2.x - p1.x - t.m[0];
+    const double d1 = p2.y - p1.y - t.m[1];
+    return d0 * d0 + d1 * d1;
+}
+
+std::vector<Mat3> estimate_e5(const std::vector<Pt>& p1, const std::vector<Pt>& p2);  // below
+
+std::vector<Mat3> estimate(EstKind k, const std::vector<Pt>& a, const std::vector<Pt>& b) {
+    switch (k) {
+        case EST_F7: return estimate_f7(a, b);
+        case EST_F8: return estimate_f8(a, b);
+        case EST_H: return estimate_h(a, b);
+        case EST_T: return estimate_t(a, b);
+        case EST_E5: return estimate_e5(a, b);
+    }
+    return {};
+}
+void residuals(EstKind k, const std::vector<Pt>& X, const std::vector<Pt>& Y, const Mat3& M,
+               std::vector<double>* r) {
+    r->resize(X.size());
+    for (size_t i = 0; i < X.size(); ++i) {
+        switch (k) {
+            case EST_F7: case EST_F8: case EST_E5: (*r)[i] = sampson(M, X[i], Y[i]); break;
+            case EST_H: (*r)[i] = h_residual(M, X[i], Y[i]); break;
+            case EST_T: (*r)[i] = t_residual(M, X[i], Y[i]); break;
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
+// LORANSAC<Estimator, LocalEstimator>::Estimate (colmap/optim/loransac.h), literal control flow
+// ----------------------------------------------------------------------------------------------
+Report lo_ransac(EstKind est, EstKind local_est, const RansacOptions& opt_in, Prng& prng,
+                 const std::vector<Pt>& X, const std::vector<Pt>& Y) {
+    const int kMin = est_min_samples(est), kLocalMin = est_min_samples(local_est);
+    RansacOptions options = opt_in;
+    options.max_num_trials = static_cast<int64_t>(ransac_max_trials(opt_in, kMin));
+
+    Report report;
+    report.success = false;
+    report.num_trials = 0;
+    const size_t num_samples = X.size();
+    if (num_samples < static_cast<size_t>(kMin)) return report;
+
+    Support best_support;
+    Mat3 best_model{};
+    bool best_model_is_local = false;
+    bool abort = false;
+    const double max_residual = options.max_error * options.max_error;
+
+    std::vector<double> res, best_local_res;
+    std::vector<Pt> X_inlier, Y_inlier, X_rand(kMin), Y_rand(kMin);
+    std::vector<size_t> sidx(kMin);
+
+    Sampler sampler(kMin);
+    sampler.initialize(num_samples);
+    size_t max_num_trials = static_cast<size_t>(options.max_num_trials);
+    size_t dyn_max_num_trials = max_num_trials;
+
+    for (report.num_trials = 0; report.num_trials < max_num_trials; ++report.num_trials) {
+        if (abort) {
+            report.num_trials += 1;
+            break;
+        }
+        sampler.sample(prng, sidx.data());
+        for (int i = 0; i < kMin; ++i) { X_rand[i] = X[sidx[i]]; Y_rand[i] = Y[sidx[i]]; }
+        const std::vector<Mat3> sample_models = estimate(est, X_rand, Y_rand);
+        for (const Mat3& sample_model : sample_models) {
+            residuals(est, X, Y, sample_model, &res);
+            const Support support = evaluate_support(res, max_residual);
+            if (better(support, best_support)) {
+                best_support = support;
+                best_model = sample_model;
+                best_model_is_local = false;
+                if (support.num_inliers > static_cast<size_t>(kMin) &&
+                    support.num_inliers >= static_cast<size_t>(kLocalMin)) {
+                    const size_t kMaxNumLocalTrials = 10;
+                    for (size_t lt = 0; lt < kMaxNumLocalTrials; ++lt) {
+                        X_inlier.clear();
+                        Y_inlier.clear();
+                        for (size_t i = 0; i < res.size(); ++i)
+                            if (res[i] <= max_residual) { X_inlier.push_back(X[i]); Y_inlier.push_back(Y[i]); }
+                        const std::vector<Mat3> local_models = estimate(local_est, X_inlier, Y_inlier);
+                        const size_t prev_best_num_inliers = best_support.num_inliers;
+                        for (const Mat3& local_model : local_models) {
+                            residuals(local_est, X, Y, local_model, &res);
+                            const Support local_support = evaluate_support(res, max_residual);
+                            if (better(local_support, best_support)) {
+                                best_support = local_support;
+                                best_model = local_model;
+                                best_model_is_local = true;
+                                std::swap(res, best_local_res);
+                            }
+                        }
+                        if (best_support.num_inliers <= prev_best_num_inliers) break;
+                        std::swap(res, best_local_res);
+                    }
+                }
+                dyn_max_num_trials = compute_num_trials(best_support.num_inliers, num_samples,
+                                                        options.confidence,
+                                                        options.dyn_num_trials_multiplier, kMin);
+            }
+            if (report.num_trials >= dyn_max_num_trials &&
+                report.num_trials >= static_cast<size_t>(options.min_num_trials)) {
+                abort = true;
+                break;
+            }
+        }
+    }
+    report.support = best_support;
+    report.model = best_model;
+    if (report.support.num_inliers < static_cast<size_t>(kMin)) return report;
+    report.success = true;
+    residuals(best_model_is_local ? local_est : est, X, Y, report.model, &res);
+    report.inlier_mask.resize(num_samples);
+    for (size_t i = 0; i < res.size(); ++i) report.inlier_mask[i] = res[i] <= max_residual;
+    return report;
+}
+
+// ----------------------------------------------------------------------------------------------
+// cameras (subset): SIMPLE_PINHOLE, PINHOLE
+// ----------------------------------------------------------------------------------------------
+bool camera_supported(const Camera& c) { return c.model_id == 0 || c.model_id == 1; }
+Pt cam_from_img(const Camera& c, const Pt& p) {
+    if (c.model_id == 0) return Pt{(p.x - c.params[1]) / c.params[0], (p.y - c.params[2]) / c.params[0]};
+    return Pt{(p.x - c.params[2]) / c.params[0], (p.y - c.params[3]) / c.params[1]};
+}
+double cam_from_img_threshold(const Camera& c, double threshold) {
+    const double mean_f = c.model_id == 0 ? c.params[0] : (c.params[0] + c.params[1]) / 2.0;
+    return threshold / mean_f;
+}
+
+// ----------------------------------------------------------------------------------------------
+// two_view_geometry.cc
+// ----------------------------------------------------------------------------------------------
+struct Tvg {
+    int config = UNDEFINED;
+    Mat3 E{}, F{}, H{};
+    std::vector<char> inlier_mask;  // over the input matches
+    size_t num_inliers = 0;
+    size_t trials[4] = {0, 0, 0, 0};   // E, F, H, watermark
+    size_t inl[3] = {0, 0, 0};         // E, F, H support
+};
+
+bool in_bbox(const Pt& p, double minx, double maxx, double miny, double maxy) {
+    return p.x >= minx && p.x <= maxx && p.y >= miny && p.y <= maxy;
+}
+
+bool detect_watermark(const Camera& c1, const std::vector<Pt>& p1, const Camera& c2,
+                      const std::vector<Pt>& p2, size_t num_inliers,
+                      const std::vector<char>& mask, const TvgOptions& o, Prng& prng, size_t* trials) {
+    if (!o.detect_watermark) return false;
+    const double diagonal1 = std::sqrt(static_cast<double>(c1.width * c1.width + c1.height * c1.height));
+    const double diagonal2 = std::sqrt(static_cast<double>(c2.width * c2.width + c2.height * c2.height));
+    const double minx1 = o.watermark_border_size * diagonal1, miny1 = minx1;
+    const double maxx1 = c1.width - minx1, maxy1 = c1.height - miny1;
+    const double minx2 = o.watermark_border_size * diagonal2, miny2 = minx2;
+    const double maxx2 = c2.width - minx2, maxy2 = c2.height - miny2;
+    std::vector<Pt> ip1(num_inliers), ip2(num_inliers);
+    size_t num_in_border = 0, j = 0;
+    for (size_t i = 0; i < mask.size(); ++i) {
+        if (mask[i]) {
+            ip1[j] = p1[i];
+            ip2[j] = p2[i];
+            j += 1;
+            if (!in_bbox(p1[i], minx1, maxx1, miny1, maxy1) && !in_bbox(p2[i], minx2, maxx2, miny2, maxy2))
+                num_in_border += 1;
+        }
+    }
+    const double ratio = static_cast<double>(num_in_border) / num_inliers;
+    if (ratio < o.watermark_min_inlier_ratio) return false;
+    RansacOptions ro = o.ransac;
+    ro.min_inlier_ratio = o.watermark_min_inlier_ratio;
+    const Report rep = lo_ransac(EST_T, EST_T, ro, prng, ip1, ip2);
+    *trials = rep.num_trials;
+    const double inlier_ratio = static_cast<double>(rep.support.num_inliers) / num_inliers;
+    return inlier_ratio >= o.watermark_min_inlier_ratio;
+}
+
+Tvg estimate_two_view_geometry(const Camera& c1, const std::vector<Pt>& pts1, const Camera& c2,
+                               const std::vector<Pt>& pts2, const uint32_t* matches, size_t M,
+                               const TvgOptions& o, uint32_t seed) {
+    Tvg g;
+    Prng prng(seed);  // D4: per-pair reseed
+    const size_t min_num_inliers = static_cast<size_t>(o.min_num_inliers);
+    if (M < min_num_inliers) {
+        g.config = DEGENERATE;
+        return g;
+    }
+    std::vector<Pt> mp1(M), mp2(M);
+    for (size_t i = 0; i < M; ++i) { mp1[i] = pts1[matches[2 * i]]; mp2[i] = pts2[matches[2 * i + 1]]; }
+
+    const bool calibrated = !o.force_H_use && c1.has_prior_focal_length && c2.has_prior_focal_length;
+    Report E_rep, F_rep, H_rep;
+    if (calibrated) {
+        std::vector<Pt> n1(M), n2(M);
+        for (size_t i = 0; i < M; ++i) { n1[i] = cam_from_img(c1, mp1[i]); n2[i] = cam_from_img(c2, mp2[i]); }
+        RansacOptions eo = o.ransac;
+        eo.max_error = (cam_from_img_threshold(c1, o.ransac.max_error) +
+                        cam_from_img_threshold(c2, o.ransac.max_error)) / 2;
+        E_rep = lo_ransac(EST_E5, EST_E5, eo, prng, n1, n2);
+        g.E = E_rep.model;
+        g.trials[0] = E_rep.num_trials;
+        g.inl[0] = E_rep.support.num_inliers;
+    }
+    if (!o.force_H_use) {
+        F_rep = lo_ransac(EST_F7, EST_F8, o.ransac, prng, mp1, mp2);
+        g.F = F_rep.model;
+        g.trials[1] = F_rep.num_trials;
+        g.inl[1] = F_rep.support.num_inliers;
+    }
+    H_rep = lo_ransac(EST_H, EST_H, o.ransac, prng, mp1, mp2);
+    g.H = H_rep.model;
+    g.trials[2] = H_rep.num_trials;
+    g.inl[2] = H_rep.support.num_inliers;
+
+    const std::vector<char>* best_mask = nullptr;
+    size_t num_inliers = 0;
+    if (o.force_H_use) {
+        // EstimateCalibratedHomography
+        if (!H_rep.success || H_rep.support.num_inliers < min_num_inliers) { g.config = DEGENERATE; return g; }
+        g.config = PLANAR_OR_PANORAMIC;
+        best_mask = &H_rep.inlier_mask;
+        num_inliers = H_rep.support.num_inliers;
+    } else if (calibrated) {
+        if ((!E_rep.success && !F_rep.success && !H_rep.success) ||
+            (E_rep.support.num_inliers < min_num_inliers && F_rep.support.num_inliers < min_num_inliers &&
+             H_rep.support.num_inliers < min_num_inliers)) {
+            g.config = DEGENERATE;
+            return g;
+        }
+        const double E_F = static_cast<double>(E_rep.support.num_inliers) / F_rep.support.num_inliers;
+        const double H_F = static_cast<double>(H_rep.support.num_inliers) / F_rep.support.num_inliers;
+        const double H_E = static_cast<double>(H_rep.support.num_inliers) / E_rep.support.num_inliers;
+        if (E_rep.success && E_F > o.min_E_F_inlier_ratio && E_rep.support.num_inliers >= min_num_inliers) {
+            if (E_rep.support.num_inliers >= F_rep.support.num_inliers) {
+                num_inliers = E_rep.support.num_inliers;
+                best_mask = &E_rep.inlier_mask;
+            } else {
+                num_inliers = F_rep.support.num_inliers;
+                best_mask = &F_rep.inlier_mask;
+            }
+            if (H_E > o.max_H_inlier_ratio) {
+                g.config = PLANAR_OR_PANORAMIC;
+                if (H_rep.support.num_inliers > num_inliers) {
+                    num_inliers = H_rep.support.num_inliers;
+                    best_mask = &H_rep.inlier_mask;
+                }
+            } else {
+                g.config = CALIBRATED;
+            }
+        } else if (F_rep.success && F_rep.support.num_inliers >= min_num_inliers) {
+            num_inliers = F_rep.support.num_inliers;
+            best_mask = &F_rep.inlier_mask;
+            if (H_F > o.max_H_inlier_ratio) {
+                g.config = PLANAR_OR_PANORAMIC;
+                if (H_rep.support.num_inliers > num_inliers) {
+                    num_inliers = H_rep.support.num_inliers;
+                    best_mask = &H_rep.inlier_mask;
+                }
+            } else {
+                g.config = UNCALIBRATED;
+            }
+        } else if (H_rep.success && H_rep.support.num_inliers >= min_num_inliers) {
+            num_inliers = H_rep.support.num_inliers;
+            best_mask = &H_rep.inlier_mask;
+            g.config = PLANAR_OR_PANORAMIC;
+        } else {
+            g.config = DEGENERATE;
+            return g;
+        }
+    } else {
+        if ((!F_rep.success && !H_rep.success) ||
+            (F_rep.support.num_inliers < min_num_inliers && H_rep.support.num_inliers < min_num_inliers)) {
+            g.config = DEGENERATE;
+            return g;
+        }
+        const double H_F = static_cast<double>(H_rep.support.num_inliers) / F_rep.support.num_inliers;
+        best_mask = &F_rep.inlier_mask;
+        num_inliers = F_rep.support.num_inliers;
+        if (H_F > o.max_H_inlier_ratio) {
+            g.config = PLANAR_OR_PANORAMIC;
+            if (H_rep.support.num_inliers >= F_rep.support.num_inliers) {
+                num_inliers = H_rep.support.num_inliers;
+                best_mask = &H_rep.inlier_mask;
+            }
+        } else {
+            g.config = UNCALIBRATED;
+        }
+    }
+    g.num_inliers = num_inliers;
+    g.inlier_mask.assign(M, 0);
+    if (best_mask != nullptr && !best_mask->empty())
+        for (size_t i = 0; i < M; ++i) g.inlier_mask[i] = (*best_mask)[i];
+    else
+        g.num_inliers = 0;
+    if (o.detect_watermark && best_mask != nullptr && !best_mask->empty() &&
+        detect_watermark(c1, mp1, c2, mp2, num_inliers, *best_mask, o, prng, &g.trials[3]))
+        g.config = WATERMARK;
+    return g;
+}
+
+// ----------------------------------------------------------------------------------------------
+// 5-point essential matrix (Nister / Stewenius formulation, re-derived; D1, D2).
+// E = x E1 + y E2 + z E3 + E4 over the 4-D null space of the 5 x 9 epipolar constraints;
+// det(E) = 0 and 2 E E^T E - tr(E E^T) E = 0 give 10 cubics in (x, y, z).  Monomials are ordered
+// so that Gauss-Jordan on the 10 x 20 coefficient matrix leaves every equation with only
+// z-polynomial multiples of {x, y, 1}; three combinations make a 3 x 3 polynomial matrix B(z)
+// whose determinant is the degree-10 polynomial in z.
+// ----------------------------------------------------------------------------------------------
+// Multivariate polynomials in (x, y, z) by degree class, fixed monomial orders:
+//  P1 (4):  x  y  z  1
+//  P2 (10): x^2  y^2  xy  xz  x  yz  y  z^2  z  1
+//  P3 (20): 0 x^3   1 y^3   2 x^2 y  3 x y^2  4 x^2 z  5 x^2   6 y^2 z  7 y^2   8 x y z  9 x y
+//          10 x z^2 11 x z  12 x    13 y z^2 14 y z   15 y    16 z^3   17 z^2  18 z    19 1
+// Products accumulate in the fixed (i, j) loop order of the tables below (no data-dependent
+// skipping), so a device implementation with the same tables is bit-identical.
+constexpr int kE1[4][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}, {0, 0, 0}};
+constexpr int kE2[10][3] = {{2, 0, 0}, {0, 2, 0}, {1, 1, 0}, {1, 0, 1}, {1, 0, 0},
+                            {0, 1, 1}, {0, 1, 0}, {0, 0, 2}, {0, 0, 1}, {0, 0, 0}};
+constexpr int kE3[20][3] = {
+    {3, 0, 0}, {0, 3, 0}, {2, 1, 0}, {1, 2, 0}, {2, 0, 1}, {2, 0, 0}, {0, 2, 1}, {0, 2, 0},
+    {1, 1, 1}, {1, 1, 0}, {1, 0, 2}, {1, 0, 1}, {1, 0, 0}, {0, 1, 2}, {0, 1, 1}, {0, 1, 0},
+    {0, 0, 3}, {0, 0, 2}, {0, 0, 1}, {0, 0, 0}};
+constexpr int idx2(int ex, int ey, int ez) {
+    for (int i = 0; i < 10; ++i)
+        if (kE2[i][0] == ex && kE2[i][1] == ey && kE2[i][2] == ez) return i;
+    return -1;
+}
+constexpr int idx3(int ex, int ey, int ez) {
+    for (int i = 0; i < 20; ++i)
+        if (kE3[i][0] == ex && kE3[i][1] == ey && kE3[i][2] == ez) return i;
+    return -1;
+}
+struct P1 { double c[4]; };
+struct P2 { double c[10]; };
+struct Poly3 { double c[20]; };
+P2 mul11(const P1& a, const P1& b) {
+    P2 r{};
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j)
+            r.c[idx2(kE1[i][0] + kE1[j][0], kE1[i][1] + kE1[j][1], kE1[i][2] + kE1[j][2])] += a.c[i] * b.c[j];
+    return r;
+}
+Poly3 mul21(const P2& a, const P1& b) {
+    Poly3 r{};
+    for (int i = 0; i < 10; ++i)
+        for (int j = 0; j < 4; ++j)
+            r.c[idx3(kE2[i][0] + kE1[j][0], kE2[i][1] + kE1[j][1], kE2[i][2] + kE1[j][2])] += a.c[i] * b.c[j];
+    return r;
+}
+P2 add2(const P2& a, const P2& b) { P2 r; for (int i = 0; i < 10; ++i) r.c[i] = a.c[i] + b.c[i]; return r; }
+P2 sub2(const P2& a, const P2& b) { P2 r; for (int i = 0; i < 10; ++i) r.c[i] = a.c[i] - b.c[i]; return r; }
+Poly3 poly_add(const Poly3& a, const Poly3& b) { Poly3 r; for (int i = 0; i < 20; ++i) r.c[i] = a.c[i] + b.c[i]; return r; }
+Poly3 poly_sub(const Poly3& a, const Poly3& b) { Poly3 r; for (int i = 0; i < 20; ++i) r.c[i] = a.c[i] - b.c[i]; return r; }
+Poly3 poly_scale(const Poly3& a, double s) { Poly3 r; for (int i = 0; i < 20; ++i) r.c[i] = a.c[i] * s; return r; }
+
+// univariate polynomial in z (degree <= 10)
+struct PolyZ { double c[11]; int deg; };
+PolyZ pz(int deg) { PolyZ p; for (int i = 0; i < 11; ++i) p.c[i] = 0.0; p.deg = deg; return p; }
+PolyZ pz_mul(const PolyZ& a, const PolyZ& b) {
+    PolyZ r = pz(a.deg + b.deg);
+    for (int i = 0; i <= a.deg; ++i)
+        for (int j = 0; j <= b.deg; ++j) r.c[i + j] += a.c[i] * b.c[j];
+    return r;
+}
+PolyZ pz_sub(const PolyZ& a, const PolyZ& b) {
+    PolyZ r = pz(std::max(a.deg, b.deg));
+    for (int i = 0; i <= r.deg; ++i) r.c[i] = (i <= a.deg ? a.c[i] : 0.0) - (i <= b.deg ? b.c[i] : 0.0);
+    return r;
+}
+PolyZ pz_add(const PolyZ& a, const PolyZ& b) {
+    PolyZ r = pz(std::max(a.deg, b.deg));
+    for (int i = 0; i <= r.deg; ++i) r.c[i] = (i <= a.deg ? a.c[i] : 0.0) + (i <= b.deg ? b.c[i] : 0.0);
+    return r;
+}
+
+std::vector<Mat3> estimate_e5(const std::vector<Pt>& p1, const std::vector<Pt>& p2) {
+    // 5-point is also COLMAP's local estimator: with more than 5 points it uses the 4 smallest
+    // right singular vectors of the N x 9 system; we take the 4 smallest eigenvectors of A^T A.
+    const size_t N = p1.size();
+    double nsp[4 * 9];
+    auto fill_row = [&](size_t i, double* r) {
+        const double x1 = p1[i].x, y1 = p1[i].y, x2 = p2[i].x, y2 = p2[i].y;
+        r[0] = x2 * x1; r[1] = x2 * y1; r[2] = x2;
+        r[3] = y2 * x1; r[4] = y2 * y1; r[5] = y2;
+        r[6] = x1; r[7] = y1; r[8] = 1;
+    };
+    if (N == 5) {
+        double A[5 * 9];
+        for (size_t i = 0; i < 5; ++i) fill_row(i, A + i * 9);
+        nullspace9(5, A, nsp);
+    } else {
+        double ata[81], v[81];
+        accumulate_ata(N, fill_row, ata);
+        jacobi_eigen(9, ata, v);
+        int order[9];
+        for (int i = 0; i < 9; ++i) order[i] = i;
+        for (int i = 0; i < 9; ++i)  // selection sort by eigenvalue, stable
+            for (int j = i + 1; j < 9; ++j)
+                if (ata[order[j] * 9 + order[j]] < ata[order[i] * 9 + order[i]]) std::swap(order[i], order[j]);
+        for (int k = 0; k < 4; ++k)
+            for (int i = 0; i < 9; ++i) nsp[k * 9 + i] = v[i * 9 + order[3 - k]];
+    }
+    // E(x,y,z) entries as linear forms: x*nsp[0] + y*nsp[1] + z*nsp[2] + nsp[3]
+    P1 e[9];
+    for (int k = 0; k < 9; ++k) e[k] = P1{{nsp[0 * 9 + k], nsp[1 * 9 + k], nsp[2 * 9 + k], nsp[3 * 9 + k]}};
+    // det(E)
+    Poly3 eq[10];
+    eq[0] = poly_add(poly_sub(mul21(sub2(mul11(e[4], e[8]), mul11(e[5], e[7])), e[0]),
+                              mul21(sub2(mul11(e[3], e[8]), mul11(e[5], e[6])), e[1])),
+                     mul21(sub2(mul11(e[3], e[7]), mul11(e[4], e[6])), e[2]));
+    // EEt = E E^T (degree 2), tr = trace(EEt)
+    P2 eet[9];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            eet[3 * i + j] = add2(add2(mul11(e[3 * i], e[3 * j]), mul11(e[3 * i + 1], e[3 * j + 1])),
+                                  mul11(e[3 * i + 2], e[3 * j + 2]));
+    const P2 tr = add2(add2(eet[0], eet[4]), eet[8]);
+    // 2 EEt E - tr E
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            const Poly3 sacc = poly_add(poly_add(mul21(eet[3 * i], e[j]), mul21(eet[3 * i + 1], e[3 + j])),
+                                        mul21(eet[3 * i + 2], e[6 + j]));
+            eq[1 + 3 * i + j] = poly_sub(poly_scale(sacc, 2.0), mul21(tr, e[3 * i + j]));
+        }
+    // Gauss-Jordan on the 10 x 20 matrix, pivoting within the first 10 columns (rows only)
+    double G[10][20];
+    for (int r = 0; r < 10; ++r)
+        for (int c = 0; c < 20; ++c) G[r][c] = eq[r].c[c];
+    for (int col = 0; col < 10; ++col) {
+        int piv = col;
+        double pv = std::fabs(G[col][col]);
+        for (int r = col + 1; r < 10; ++r)
+            if (std::fabs(G[r][col]) > pv) { pv = std::fabs(G[r][col]); piv = r; }
+        if (piv != col)
+            for (int c = 0; c < 20; ++c) std::swap(G[col][c], G[piv][c]);
+        const double inv = 1.0 / G[col][col];
+        for (int c = 0; c < 20; ++c) G[col][c] = G[col][c] * inv;
+        for (int r = 0; r < 10; ++r) {
+            if (r == col) continue;
+            const double f = G[r][col];
+            for (int c = 0; c < 20; ++c) G[r][c] = G[r][c] - f * G[col][c];
+        }
+    }
+    // After elimination row r reads  mono_r + sum_{c>=10} G[r][c] mono_c = 0  with
+    // mono_4 = x^2 z, mono_5 = x^2, mono_6 = y^2 z, mono_7 = y^2, mono_8 = xyz, mono_9 = xy.
+    // <k> := row(2k+4) - z * row(2k+5), k = 0,1,2 cancels the leading monomials and leaves
+    //   x * a(z) + y * b(z) + c(z) = 0  with deg a,b <= 3, deg c <= 4.
+    PolyZ B[3][3];
+    for (int k = 0; k < 3; ++k) {
+        const double* hi = G[4 + 2 * k];  // leading x^2 z / y^2 z / xyz
+        const double* lo = G[5 + 2 * k];  // leading x^2 / y^2 / xy
+        PolyZ a = pz(3), b = pz(3), c = pz(4);
+        // hi: x z^2 (10), x z (11), x (12), y z^2 (13), y z (14), y (15), z^3 (16), z^2 (17), z (18), 1 (19)
+        a.c[2] += hi[10]; a.c[1] += hi[11]; a.c[0] += hi[12];
+        b.c[2] += hi[13]; b.c[1] += hi[14]; b.c[0] += hi[15];
+        c.c[3] += hi[16]; c.c[2] += hi[17]; c.c[1] += hi[18]; c.c[0] += hi[19];
+        // minus z * lo
+        a.c[3] -= lo[10]; a.c[2] -= lo[11]; a.c[1] -= lo[12];
+        b.c[3] -= lo[13]; b.c[2] -= lo[14]; b.c[1] -= lo[15];
+        c.c[4] -= lo[16]; c.c[3] -= lo[17]; c.c[2] -= lo[18]; c.c[1] -= lo[19];
+        B[k][0] = a; B[k][1] = b; B[k][2] = c;
+    }
+    // det B(z): degree 10
+    const PolyZ m0 = pz_sub(pz_mul(B[1][1], B[2][2]), pz_mul(B[1][2], B[2][1]));
+    const PolyZ m1 = pz_sub(pz_mul(B[1][0], B[2][2]), pz_mul(B[1][2], B[2][0]));
+    const PolyZ m2 = pz_sub(pz_mul(B[1][0], B[2][1]), pz_mul(B[1][1], B[2][0]));
+    const PolyZ det = pz_add(pz_sub(pz_mul(B[0][0], m0), pz_mul(B[0][1], m1)), pz_mul(B[0][2], m2));
+    double roots[10];
+    const int nr = real_roots(det.c, 10, roots);
+    std::vector<Mat3> models;
+    for (int i = 0; i < nr; ++i) {
+        const double z = roots[i];
+        // solve the 2x2 system from rows 0,1 of B(z): [a0 b0; a1 b1] [x y]^T = -[c0 c1]^T
+        const double a0 = poly_eval(B[0][0].c, 3, z), b0 = poly_eval(B[0][1].c, 3, z), c0 = poly_eval(B[0][2].c, 4, z);
+        const double a1 = poly_eval(B[1][0].c, 3, z), b1 = poly_eval(B[1][1].c, 3, z), c1 = poly_eval(B[1][2].c, 4, z);
+        const double dd = a0 * b1 - a1 * b0;
+        const double x = (b0 * c1 - b1 * c0) / dd;
+        const double y = (a1 * c0 - a0 * c1) / dd;
+        Mat3 E;
+        for (int k = 0; k < 9; ++k) E.m[k] = x * nsp[k] + y * nsp[9 + k] + z * nsp[18 + k] + nsp[27 + k];
+        models.push_back(E);
+    }
+    return models;
+}
+
+}  // namespace
+
+// ----------------------------------------------------------------------------------------------
+// C API (ctypes) for tests and the CPU baseline
+// ----------------------------------------------------------------------------------------------
+extern "C" {
+
+struct oracle_tvg_options {
+    int32_t min_num_inliers;
+    int32_t detect_watermark;
+    int32_t multiple_ignore_watermark;
+    int32_t force_H_use;
+    int32_t compute_relative_pose;
+    int32_t multiple_models;
+    double min_E_F_inlier_ratio;
+    double max_H_inlier_ratio;
+    double watermark_min_inlier_ratio;
+    double watermark_border_size;
+    double max_error;
+    double min_inlier_ratio;
+    double confidence;
+    double dyn_num_trials_multiplier;
+    int64_t min_num_trials;
+    int64_t max_num_trials;
+};
+
+struct oracle_camera {
+    int32_t model_id;
+    int32_t has_prior_focal_length;
+    uint64_t width, height;
+    double params[12];
+};
+
+struct oracle_tvg_result {
+    int32_t config;
+    int32_t num_inliers;
+    double E[9], F[9], H[9];
+    int64_t trials[4];
+    int64_t inl[3];
+};
+
+static TvgOptions to_opts(const oracle_tvg_options* o) {
+    TvgOptions t;
+    t.min_num_inliers = o->min_num_inliers;
+    t.min_E_F_inlier_ratio = o->min_E_F_inlier_ratio;
+    t.max_H_inlier_ratio = o->max_H_inlier_ratio;
+    t.watermark_min_inlier_ratio = o->watermark_min_inlier_ratio;
+    t.watermark_border_size = o->watermark_border_size;
+    t.detect_watermark = o->detect_watermark;
+    t.multiple_ignore_watermark = o->multiple_ignore_watermark;
+    t.force_H_use = o->force_H_use;
+    t.compute_relative_pose = o->compute_relative_pose;
+    t.multiple_models = o->multiple_models;
+    t.ransac = RansacOptions{o->max_error, o->min_inlier_ratio, o->confidence,
+                             o->dyn_num_trials_multiplier, o->min_num_trials, o->max_num_trials};
+    return t;
+}
+static Camera to_cam(const oracle_camera* c) {
+    Camera r;
+    r.model_id = c->model_id;
+    r.has_prior_focal_length = c->has_prior_focal_length;
+    r.width = c->width;
+    r.height = c->height;
+    std::memcpy(r.params, c->params, sizeof r.params);
+    return r;
+}
+
+// C++ defaults of TwoViewGeometryOptions
+void oracle_tvg_options_default(oracle_tvg_options* o) {
+    o->min_num_inliers = 15;
+    o->detect_watermark = 1;
+    o->multiple_ignore_watermark = 1;
+    o->force_H_use = 0;
+    o->compute_relative_pose = 0;
+    o->multiple_models = 0;
+    o->min_E_F_inlier_ratio = 0.95;
+    o->max_H_inlier_ratio = 0.8;
+    o->watermark_min_inlier_ratio = 0.7;
+    o->watermark_border_size = 0.1;
+    o->max_error = 4.0;
+    o->min_inlier_ratio = 0.25;
+    o->confidence = 0.999;
+    o->dyn_num_trials_multiplier = 3.0;
+    o->min_num_trials = 100;
+    o->max_num_trials = 10000;
+}
+
+// EstimateTwoViewGeometry for one pair. pts: all keypoints (x,y) of each image as doubles;
+// matches: M x 2 uint32.  inlier_mask: M chars out.  Returns 0, or -1 for unsupported input.
+int oracle_estimate_two_view_geometry(const oracle_camera* cam1, const double* pts1, size_t n1,
+                                      const oracle_camera* cam2, const double* pts2, size_t n2,
+                                      const uint32_t* matches, size_t M,
+                                      const oracle_tvg_options* opts, uint32_t seed,
+                                      oracle_tvg_result* out, char* inlier_mask) {
+    const Camera c1 = to_cam(cam1), c2 = to_cam(cam2);
+    if (!camera_supported(c1) || !camera_supported(c2)) return -1;
+    if (opts->multiple_models || opts->compute_relative_pose) return -1;
+    for (size_t i = 0; i < M; ++i)
+        if (matches[2 * i] >= n1 || matches[2 * i + 1] >= n2) return -1;
+    std::vector<Pt> a(n1), b(n2);
+    for (size_t i = 0; i < n1; ++i) a[i] = Pt{pts1[2 * i], pts1[2 * i + 1]};
+    for (size_t i = 0; i < n2; ++i) b[i] = Pt{pts2[2 * i], pts2[2 * i + 1]};
+    const Tvg g = estimate_two_view_geometry(c1, a, c2, b, matches, M, to_opts(opts), seed);
+    out->config = g.config;
+    out->num_inliers = static_cast<int32_t>(g.num_inliers);
+    std::memcpy(out->E, g.E.m, sizeof out->E);
+    std::memcpy(out->F, g.F.m, sizeof out->F);
+    std::memcpy(out->H, g.H.m, sizeof out->H);
+    for (int i = 0; i < 4; ++i) out->trials[i] = static_cast<int64_t>(g.trials[i]);
+    for (int i = 0; i < 3; ++i) out->inl[i] = static_cast<int64_t>(g.inl[i]);
+    for (size_t i = 0; i < M; ++i) inlier_mask[i] = i < g.inlier_mask.size() ? g.inlier_mask[i] : 0;
+    return 0;
+}
+
+// Single-model LO-RANSAC with a fresh PRNG(seed): the semantics of pycolmap's
+// fundamental_matrix_estimation / homography_matrix_estimation / essential_matrix_estimation
+// (/root/reference/pycolmap/estimators/fundamental_matrix.h:17-39).  kind: 0 = F (7pt/8pt),
+// 1 = H, 2 = E (points already in camera coordinates).  Returns success (0/1).
+int oracle_ransac_estimate(int kind, const double* p1, const double* p2, size_t n,
+                           const oracle_tvg_options* ro, uint32_t seed, double* model9,
+                           int64_t* num_inliers, int64_t* num_trials, char* inlier_mask) {
+    std::vector<Pt> a(n), b(n);
+    for (size_t i = 0; i < n; ++i) { a[i] = Pt{p1[2 * i], p1[2 * i + 1]}; b[i] = Pt{p2[2 * i], p2[2 * i + 1]}; }
+    Prng prng(seed);
+    const RansacOptions o{ro->max_error, ro->min_inlier_ratio, ro->confidence,
+                          ro->dyn_num_trials_multiplier, ro->min_num_trials, ro->max_num_trials};
+    const EstKind e = kind == 0 ? EST_F7 : kind == 1 ? EST_H : EST_E5;
+    const EstKind l = kind == 0 ? EST_F8 : kind == 1 ? EST_H : EST_E5;
+    const Report r = lo_ransac(e, l, o, prng, a, b);
+    std::memcpy(model9, r.model.m, 9 * sizeof(double));
+    *num_inliers = static_cast<int64_t>(r.support.num_inliers);
+    *num_trials = static_cast<int64_t>(r.num_trials);
+    for (size_t i = 0; i < n; ++i) inlier_mask[i] = (r.success && i < r.inlier_mask.size()) ? r.inlier_mask[i] : 0;
+    return r.success ? 1 : 0;
+}
+
+// unit-test hooks ------------------------------------------------------------------------------
+void oracle_sampson_error(const double* p1, const double* p2, size_t n, const double* E9, double* out) {
+    Mat3 E;
+    std::memcpy(E.m, E9, sizeof E.m);
+    for (size_t i = 0; i < n; ++i) out[i] = sampson(E, Pt{p1[2 * i], p1[2 * i + 1]}, Pt{p2[2 * i], p2[2 * i + 1]});
+}
+void oracle_h_residuals(const double* p1, const double* p2, size_t n, const double* H9, double* out) {
+    Mat3 H;
+    std::memcpy(H.m, H9, sizeof H.m);
+    for (size_t i = 0; i < n; ++i) out[i] = h_residual(H, Pt{p1[2 * i], p1[2 * i + 1]}, Pt{p2[2 * i], p2[2 * i + 1]});
+}
+// kind: 0 F7 (n==7), 1 F8, 2 H, 4 E5.  Writes up to 10 models; returns the count.
+int oracle_estimate_models(int kind, const double* p1, const double* p2, size_t n, double* models) {
+    std::vector<Pt> a(n), b(n);
+    for (size_t i = 0; i < n; ++i) { a[i] = Pt{p1[2 * i], p1[2 * i + 1]}; b[i] = Pt{p2[2 * i], p2[2 * i + 1]}; }
+    const std::vector<Mat3> ms = estimate(static_cast<EstKind>(kind), a, b);
+    for (size_t k = 0; k < ms.size() && k < 10; ++k) std::memcpy(models + 9 * k, ms[k].m, 9 * sizeof(double));
+    return static_cast<int>(std::min<size_t>(ms.size(), 10));
+}
+// the sample stream of RandomSampler(k) over `total` items after SetPRNGSeed(seed): trials x k
+void oracle_sample_stream(uint32_t seed, uint32_t total, uint32_t k, uint32_t trials, uint32_t* out) {
+    Prng prng(seed);
+    Sampler s(k);
+    s.initialize(total);
+    std::vector<size_t> idx(k);
+    for (uint32_t t = 0; t < trials; ++t) {
+        s.sample(prng, idx.data());
+        for (uint32_t i = 0; i < k; ++i) out[t * k + i] = static_cast<uint32_t>(idx[i]);
+    }
+}
+// raw std::uniform_int_distribution<uint32_t>(lo, hi) draws from mt19937(seed)
+void oracle_uniform_draws(uint32_t seed, const uint32_t* lo, const uint32_t* hi, uint32_t n, uint32_t* out) {
+    Prng prng(seed);
+    for (uint32_t i = 0; i < n; ++i) out[i] = prng.uniform(lo[i], hi[i]);
+}
+int64_t oracle_compute_num_trials(int64_t num_inliers, int64_t num_samples, double confidence,
+                                  double multiplier, int min_num_samples) {
+    const size_t v = compute_num_trials(static_cast<size_t>(num_inliers), static_cast<size_t>(num_samples),
+                                        confidence, multiplier, min_num_samples);
+    return v > static_cast<size_t>(std::numeric_limits<int64_t>::max()) ? std::numeric_limits<int64_t>::max()
+                                                                         : static_cast<int64_t>(v);
+}
+int oracle_real_roots(const double* coeffs, int deg, double* roots) { return real_roots(coeffs, deg, roots); }
+void oracle_jacobi_eigen(int n, double* a, double* v) { jacobi_eigen(n, a, v); }
+double oracle_det_sum64(const double* x, size_t n) { return det_sum64(n, [&](size_t k) { return x[k]; }); }
+
+}  // extern "C"

@@ -53,3 +53,78 @@ def exhaustive_pairs(num_images: int) -> tuple[np.ndarray, np.ndarray]:
     (SURVEY.md A.4); block ordering is a host-layer concern."""
     i, j = np.triu_indices(num_images, k=1)
     return i.astype(np.uint32), j.astype(np.uint32)
+
+
+# ------------------------------------------------------------------------------------------------
+# two-view scenes for the verification path (SURVEY.md section 8d)
+# ------------------------------------------------------------------------------------------------
+def _rot(rng, max_angle):
+    ax = rng.normal(size=3)
+    ax /= np.linalg.norm(ax)
+    ang = rng.uniform(-max_angle, max_angle)
+    K = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+    return np.eye(3) + np.sin(ang) * K + (1 - np.cos(ang)) * (K @ K)
+
+
+PLANE_N = np.array([0.1, -0.15, 1.0])
+PLANE_D = 6.0
+
+
+def two_view_scene(rng, num_inliers=300, num_outliers=100, noise=0.5, planar=False, pure_rotation=False,
+                   f=1200.0, width=1600, height=1200, extra_keypoints=50):
+    """Keypoints of two PINHOLE views of one scene + a match list with planted inliers/outliers.
+
+    Returns dict(pts1 [n1,2], pts2, matches [M,2] uint32, inlier [M] bool, K, R, t, F_true, E_true,
+    H_true or None).  Keypoints are rounded through float32 like the `keypoints` blob COLMAP reads
+     and returned as float64.
+    """
+    cx, cy = width / 2.0, height / 2.0
+    K = np.array([[f, 0, cx], [0, f, cy], [0, 0, 1.0]])
+    R = _rot(rng, 0.25)
+    if pure_rotation:
+        t = np.zeros(3)
+    else:
+        t = rng.normal(size=3) * np.array([1.0, 0.3, 0.2])
+        t = t / np.linalg.norm(t) * 0.8
+    P1, P2 = [], []
+    while len(P1) < num_inliers:
+        X = rng.uniform([-3, -2.2, 4], [3, 2.2, 9], size=(num_inliers * 2, 3))
+        if planar:
+            X[:, 2] = (PLANE_D - X[:, 0] * PLANE_N[0] - X[:, 1] * PLANE_N[1]) / PLANE_N[2]
+        x1 = (K @ X.T).T
+        x1 = x1[:, :2] / x1[:, 2:]
+        Xc2 = (R @ X.T).T + t
+        x2 = (K @ Xc2.T).T
+        x2 = x2[:, :2] / x2[:, 2:]
+        ok = ((x1[:, 0] > 5) & (x1[:, 0] < width - 5) & (x1[:, 1] > 5) & (x1[:, 1] < height - 5) &
+              (x2[:, 0] > 5) & (x2[:, 0] < width - 5) & (x2[:, 1] > 5) & (x2[:, 1] < height - 5) &
+              (Xc2[:, 2] > 0.5))
+        P1 += list(x1[ok])
+        P2 += list(x2[ok])
+    x1 = np.array(P1[:num_inliers]).reshape(-1, 2) + rng.normal(0, noise, size=(num_inliers, 2))
+    x2 = np.array(P2[:num_inliers]).reshape(-1, 2) + rng.normal(0, noise, size=(num_inliers, 2))
+    o1 = rng.uniform([5, 5], [width - 5, height - 5], size=(num_outliers, 2))
+    o2 = rng.uniform([5, 5], [width - 5, height - 5], size=(num_outliers, 2))
+    e1 = rng.uniform([5, 5], [width - 5, height - 5], size=(extra_keypoints, 2))
+    e2 = rng.uniform([5, 5], [width - 5, height - 5], size=(extra_keypoints, 2))
+    pts1 = np.concatenate([x1, o1, e1]).astype(np.float32).astype(np.float64)
+    pts2 = np.concatenate([x2, o2, e2]).astype(np.float32).astype(np.float64)
+    M = num_inliers + num_outliers
+    perm1, perm2 = rng.permutation(len(pts1)), rng.permutation(len(pts2))
+    inv1, inv2 = np.argsort(perm1), np.argsort(perm2)
+    pts1, pts2 = pts1[perm1], pts2[perm2]
+    matches = np.stack([inv1[:M], inv2[:M]], axis=1).astype(np.uint32)
+    inlier = np.arange(M) < num_inliers
+    order = rng.permutation(M)
+    matches, inlier = matches[order], inlier[order]
+    tx = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]])
+    E = tx @ R
+    Kinv = np.linalg.inv(K)
+    F = Kinv.T @ E @ Kinv
+    H = None
+    if planar:
+        H = K @ (R + np.outer(t, PLANE_N) / PLANE_D) @ Kinv
+    if pure_rotation:
+        H = K @ R @ Kinv
+    return dict(pts1=pts1, pts2=pts2, matches=matches, inlier=inlier, K=K, R=R, t=t, F_true=F,
+                E_true=E, H_true=H, f=f, width=width, height=height)

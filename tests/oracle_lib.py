@@ -86,3 +86,169 @@ def acos_lut():
     out = np.empty(262145, dtype=np.float32)
     load().oracle_acos_lut(_p(out))
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# two-view geometry oracle (oracle/tvg_oracle.cc)
+# ------------------------------------------------------------------------------------------------
+class TvgOptions(C.Structure):
+    _fields_ = [("min_num_inliers", C.c_int32), ("detect_watermark", C.c_int32),
+                ("multiple_ignore_watermark", C.c_int32), ("force_H_use", C.c_int32),
+                ("compute_relative_pose", C.c_int32), ("multiple_models", C.c_int32),
+                ("min_E_F_inlier_ratio", C.c_double), ("max_H_inlier_ratio", C.c_double),
+                ("watermark_min_inlier_ratio", C.c_double), ("watermark_border_size", C.c_double),
+                ("max_error", C.c_double), ("min_inlier_ratio", C.c_double),
+                ("confidence", C.c_double), ("dyn_num_trials_multiplier", C.c_double),
+                ("min_num_trials", C.c_int64), ("max_num_trials", C.c_int64)]
+
+
+class OCamera(C.Structure):
+    _fields_ = [("model_id", C.c_int32), ("has_prior_focal_length", C.c_int32),
+                ("width", C.c_uint64), ("height", C.c_uint64), ("params", C.c_double * 12)]
+
+
+class TvgResult(C.Structure):
+    _fields_ = [("config", C.c_int32), ("num_inliers", C.c_int32), ("E", C.c_double * 9),
+                ("F", C.c_double * 9), ("H", C.c_double * 9), ("trials", C.c_int64 * 4),
+                ("inl", C.c_int64 * 3)]
+
+
+CONFIG_NAMES = ["UNDEFINED", "DEGENERATE", "CALIBRATED", "UNCALIBRATED", "PLANAR", "PANORAMIC",
+                "PLANAR_OR_PANORAMIC", "WATERMARK", "MULTIPLE"]
+
+
+def tvg_default_options(**kw) -> TvgOptions:
+    o = TvgOptions()
+    load().oracle_tvg_options_default(C.byref(o))
+    for k, v in kw.items():
+        assert hasattr(o, k), k
+        setattr(o, k, v)
+    return o
+
+
+def ransac_options(max_error=4.0, min_inlier_ratio=0.01, confidence=0.9999,
+                   dyn_num_trials_multiplier=3.0, min_num_trials=1000, max_num_trials=100000):
+    """pycolmap's Python-side RANSACOptions defaults (/root/reference/pycolmap/optim/bindings.h:10-18)."""
+    return tvg_default_options(max_error=max_error, min_inlier_ratio=min_inlier_ratio,
+                               confidence=confidence, dyn_num_trials_multiplier=dyn_num_trials_multiplier,
+                               min_num_trials=min_num_trials, max_num_trials=max_num_trials)
+
+
+def make_camera(model="PINHOLE", width=1600, height=1200, params=(1200.0, 1200.0, 800.0, 600.0),
+                prior=False) -> OCamera:
+    c = OCamera()
+    c.model_id = {"SIMPLE_PINHOLE": 0, "PINHOLE": 1}[model]
+    c.has_prior_focal_length = int(prior)
+    c.width, c.height = width, height
+    for i, v in enumerate(params):
+        c.params[i] = float(v)
+    return c
+
+
+def _d(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def estimate_two_view_geometry(cam1, pts1, cam2, pts2, matches, opts=None, seed=0):
+    lib = load()
+    opts = opts or tvg_default_options()
+    p1, p2 = _d(pts1).reshape(-1, 2), _d(pts2).reshape(-1, 2)
+    m = np.ascontiguousarray(matches, dtype=np.uint32).reshape(-1, 2)
+    res = TvgResult()
+    mask = np.zeros(max(1, len(m)), dtype=np.uint8)
+    lib.oracle_estimate_two_view_geometry.restype = C.c_int
+    rc = lib.oracle_estimate_two_view_geometry(
+        C.byref(cam1), _p(p1), C.c_size_t(len(p1)), C.byref(cam2), _p(p2), C.c_size_t(len(p2)),
+        _p(m), C.c_size_t(len(m)), C.byref(opts), C.c_uint32(seed), C.byref(res), _p(mask))
+    assert rc == 0, "oracle: unsupported input"
+    return dict(config=int(res.config), config_name=CONFIG_NAMES[res.config],
+                num_inliers=int(res.num_inliers), E=np.array(res.E).reshape(3, 3),
+                F=np.array(res.F).reshape(3, 3), H=np.array(res.H).reshape(3, 3),
+                trials=list(res.trials), inl=list(res.inl), inlier_mask=mask[:len(m)].astype(bool))
+
+
+def ransac_estimate(kind, p1, p2, opts=None, seed=0):
+    """kind: 'F' | 'H' | 'E'. Mirrors pycolmap's *_matrix_estimation (seed 0 per call)."""
+    lib = load()
+    opts = opts or ransac_options()
+    a, b = _d(p1).reshape(-1, 2), _d(p2).reshape(-1, 2)
+    model = np.zeros(9)
+    ninl, ntr = C.c_int64(), C.c_int64()
+    mask = np.zeros(max(1, len(a)), dtype=np.uint8)
+    lib.oracle_ransac_estimate.restype = C.c_int
+    ok = lib.oracle_ransac_estimate({"F": 0, "H": 1, "E": 2}[kind], _p(a), _p(b), C.c_size_t(len(a)),
+                                    C.byref(opts), C.c_uint32(seed), _p(model), C.byref(ninl),
+                                    C.byref(ntr), _p(mask))
+    return dict(model=model.reshape(3, 3), num_inliers=ninl.value, num_trials=ntr.value,
+                inliers=mask[:len(a)].astype(bool), success=bool(ok))
+
+
+def sampson_error(p1, p2, E):
+    a, b, e = _d(p1).reshape(-1, 2), _d(p2).reshape(-1, 2), _d(E).reshape(9)
+    out = np.zeros(len(a))
+    load().oracle_sampson_error(_p(a), _p(b), C.c_size_t(len(a)), _p(e), _p(out))
+    return out
+
+
+def h_residuals(p1, p2, H):
+    a, b, h = _d(p1).reshape(-1, 2), _d(p2).reshape(-1, 2), _d(H).reshape(9)
+    out = np.zeros(len(a))
+    load().oracle_h_residuals(_p(a), _p(b), C.c_size_t(len(a)), _p(h), _p(out))
+    return out
+
+
+EST_KINDS = {"F7": 0, "F8": 1, "H": 2, "T": 3, "E5": 4}
+
+
+def estimate_models(kind, p1, p2):
+    a, b = _d(p1).reshape(-1, 2), _d(p2).reshape(-1, 2)
+    models = np.zeros((10, 9))
+    lib = load()
+    lib.oracle_estimate_models.restype = C.c_int
+    n = lib.oracle_estimate_models(EST_KINDS[kind], _p(a), _p(b), C.c_size_t(len(a)), _p(models))
+    return models[:n].reshape(n, 3, 3).copy()
+
+
+def sample_stream(seed, total, k, trials):
+    out = np.zeros((trials, k), dtype=np.uint32)
+    load().oracle_sample_stream(C.c_uint32(seed), C.c_uint32(total), C.c_uint32(k), C.c_uint32(trials), _p(out))
+    return out
+
+
+def uniform_draws(seed, lo, hi):
+    lo = np.ascontiguousarray(lo, dtype=np.uint32)
+    hi = np.ascontiguousarray(hi, dtype=np.uint32)
+    out = np.zeros(len(lo), dtype=np.uint32)
+    load().oracle_uniform_draws(C.c_uint32(seed), _p(lo), _p(hi), C.c_uint32(len(lo)), _p(out))
+    return out
+
+
+def compute_num_trials(num_inliers, num_samples, confidence, multiplier, kmin):
+    lib = load()
+    lib.oracle_compute_num_trials.restype = C.c_int64
+    return lib.oracle_compute_num_trials(C.c_int64(num_inliers), C.c_int64(num_samples),
+                                         C.c_double(confidence), C.c_double(multiplier), C.c_int(kmin))
+
+
+def real_roots(coeffs_low_to_high):
+    c = _d(coeffs_low_to_high)
+    out = np.zeros(12)
+    lib = load()
+    lib.oracle_real_roots.restype = C.c_int
+    n = lib.oracle_real_roots(_p(c), C.c_int(len(c) - 1), _p(out))
+    return out[:n].copy()
+
+
+def jacobi_eigen(a):
+    a = _d(a).copy()
+    n = a.shape[0]
+    v = np.zeros((n, n))
+    load().oracle_jacobi_eigen(C.c_int(n), _p(a), _p(v))
+    return np.diag(a).copy(), v
+
+
+def det_sum64(x):
+    x = _d(x)
+    lib = load()
+    lib.oracle_det_sum64.restype = C.c_double
+    return lib.oracle_det_sum64(_p(x), C.c_size_t(len(x)))
