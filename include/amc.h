@@ -134,6 +134,94 @@ void amc_match_opts_default(amc_match_opts* opts);
  * d in [0, 262144].  Copies 262145 floats. (Test hook: must equal the oracle's table.) */
 int amc_get_acos_lut(amc_ctx* ctx, float* out);
 
+/* ------------------------------------------------------------------------------------------
+ * Two-view geometric verification (COLMAP EstimateTwoViewGeometry)
+ * ------------------------------------------------------------------------------------------ */
+
+/* RANSACOptions (/root/reference/pycolmap/optim/bindings.h:19-25). */
+typedef struct amc_ransac_opts {
+    double max_error;
+    double min_inlier_ratio;
+    double confidence;
+    double dyn_num_trials_multiplier;
+    int64_t min_num_trials;
+    int64_t max_num_trials;
+} amc_ransac_opts;
+
+/* TwoViewGeometryOptions (/root/reference/pycolmap/estimators/two_view_geometry.h:41-63). */
+typedef struct amc_tvg_opts {
+    int32_t min_num_inliers;
+    int32_t detect_watermark;
+    int32_t multiple_ignore_watermark;
+    int32_t force_H_use;
+    int32_t compute_relative_pose; /* must be 0 (next) */
+    int32_t multiple_models;       /* must be 0 (next) */
+    double min_E_F_inlier_ratio;
+    double max_H_inlier_ratio;
+    double watermark_min_inlier_ratio;
+    double watermark_border_size;
+    amc_ransac_opts ransac;
+} amc_tvg_opts;
+
+/* TwoViewGeometry::ConfigurationType, same values and order as
+ * /root/reference/pycolmap/estimators/two_view_geometry.h:67-77. */
+enum {
+    AMC_TVG_UNDEFINED = 0, AMC_TVG_DEGENERATE = 1, AMC_TVG_CALIBRATED = 2, AMC_TVG_UNCALIBRATED = 3,
+    AMC_TVG_PLANAR = 4, AMC_TVG_PANORAMIC = 5, AMC_TVG_PLANAR_OR_PANORAMIC = 6, AMC_TVG_WATERMARK = 7,
+    AMC_TVG_MULTIPLE = 8
+};
+
+/* Camera models accepted by the E path (ids as in COLMAP). */
+enum { AMC_CAM_SIMPLE_PINHOLE = 0, AMC_CAM_PINHOLE = 1 };
+
+/* One pair's TwoViewGeometry (/root/reference/pycolmap/estimators/two_view_geometry.h:79-93):
+ * config, E/F/H row-major (the three RANSAC report models, as COLMAP stores them), the size of
+ * the selected inlier set; plus diagnostics (trials of the E, F, H, watermark RANSACs and the
+ * support of E, F, H). */
+typedef struct amc_tvg {
+    int32_t config;
+    int32_t num_inliers;
+    double E[9], F[9], H[9];
+    int64_t num_trials[4];
+    int64_t model_inliers[3];
+} amc_tvg;
+
+typedef struct amc_verify_result {
+    size_t npairs;
+    amc_tvg* tvg;          /* npairs */
+    uint8_t* inlier_mask;  /* one byte per input match, same CSR offsets as the input;
+                              inlier_matches = matches[mask] (ExtractInlierMatches) */
+    double device_ms;      /* first launch -> results on host */
+    double kernel_ms;      /* verification kernel launches, HIP events on the stream */
+    uint32_t kernel_launches;
+    void* _priv;
+} amc_verify_result;
+
+/* C++ defaults of TwoViewGeometryOptions / its RANSACOptions member: what
+ * pycolmap.TwoViewGeometryOptions() carries (py::init<>() of the C++ struct). */
+void amc_tvg_opts_default(amc_tvg_opts* opts);
+
+/* Keypoints of an image: rows x stride float32, x = [0], y = [1] (COLMAP `keypoints` blob has
+ * 2, 4 or 6 columns).  Converted to double exactly as
+ * FeatureKeypointsToPointsVector does. */
+int amc_upload_keypoints(amc_ctx* ctx, uint32_t slot, const float* xy, uint32_t rows,
+                         uint32_t stride_floats);
+
+/* Camera of an image (COLMAP Camera: model id, size, params, has_prior_focal_length). */
+int amc_upload_camera(amc_ctx* ctx, uint32_t slot, int32_t model_id, uint64_t width,
+                      uint64_t height, const double* params, int32_t num_params,
+                      int32_t has_prior_focal_length);
+
+/* EstimateTwoViewGeometry for every listed pair.  matches of pair p: uint32 (idx1, idx2) rows
+ * matches[2*match_offsets[p] .. 2*match_offsets[p+1]).  The PRNG is re-seeded with `seed` at the
+ * start of every pair (COLMAP's pipeline PRNG is thread_local and not reproducible across
+ * pairs; pycolmap's single-pair estimators reseed with 0:
+ * /root/reference/pycolmap/estimators/fundamental_matrix.h:21).  Blocking. */
+int amc_verify_pairs(amc_ctx* ctx, const uint32_t* slot1, const uint32_t* slot2, size_t npairs,
+                     const uint64_t* match_offsets, const uint32_t* matches,
+                     const amc_tvg_opts* opts, uint32_t seed, amc_verify_result* out);
+void amc_verify_result_free(amc_verify_result* r);
+
 #ifdef __cplusplus
 }
 #endif

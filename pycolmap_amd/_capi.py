@@ -25,6 +25,8 @@ EXPORTED_SYMBOLS = [
     "amc_ctx_set_stream", "amc_ctx_reserve_slots", "amc_upload_descriptors",
     "amc_upload_descriptors_device", "amc_match_pairs", "amc_match_result_free",
     "amc_match_opts_default", "amc_get_acos_lut",
+    "amc_tvg_opts_default", "amc_upload_keypoints", "amc_upload_camera", "amc_verify_pairs",
+    "amc_verify_result_free",
 ]
 
 
@@ -47,6 +49,40 @@ class MatchResult(C.Structure):
                 ("cross_kernel_ms", C.c_double),
                 ("match_kernel_launches", C.c_uint32), ("_priv", C.c_void_p)]
 
+
+class RansacOpts(C.Structure):
+    _fields_ = [("max_error", C.c_double), ("min_inlier_ratio", C.c_double),
+                ("confidence", C.c_double), ("dyn_num_trials_multiplier", C.c_double),
+                ("min_num_trials", C.c_int64), ("max_num_trials", C.c_int64)]
+
+
+class TvgOpts(C.Structure):
+    _fields_ = [("min_num_inliers", C.c_int32), ("detect_watermark", C.c_int32),
+                ("multiple_ignore_watermark", C.c_int32), ("force_H_use", C.c_int32),
+                ("compute_relative_pose", C.c_int32), ("multiple_models", C.c_int32),
+                ("min_E_F_inlier_ratio", C.c_double), ("max_H_inlier_ratio", C.c_double),
+                ("watermark_min_inlier_ratio", C.c_double), ("watermark_border_size", C.c_double),
+                ("ransac", RansacOpts)]
+
+
+class Tvg(C.Structure):
+    _fields_ = [("config", C.c_int32), ("num_inliers", C.c_int32), ("E", C.c_double * 9),
+                ("F", C.c_double * 9), ("H", C.c_double * 9), ("num_trials", C.c_int64 * 4),
+                ("model_inliers", C.c_int64 * 3)]
+
+
+class VerifyResult(C.Structure):
+    _fields_ = [("npairs", C.c_size_t), ("tvg", C.POINTER(Tvg)), ("inlier_mask", C.POINTER(C.c_uint8)),
+                ("device_ms", C.c_double), ("kernel_ms", C.c_double), ("kernel_launches", C.c_uint32),
+                ("_priv", C.c_void_p)]
+
+
+TVG_DTYPE = np.dtype([("config", np.int32), ("num_inliers", np.int32), ("E", np.float64, (3, 3)),
+                      ("F", np.float64, (3, 3)), ("H", np.float64, (3, 3)),
+                      ("num_trials", np.int64, (4,)), ("model_inliers", np.int64, (3,))])
+CAMERA_MODELS = {"SIMPLE_PINHOLE": 0, "PINHOLE": 1}
+CONFIG_NAMES = ["UNDEFINED", "DEGENERATE", "CALIBRATED", "UNCALIBRATED", "PLANAR", "PANORAMIC",
+                "PLANAR_OR_PANORAMIC", "WATERMARK", "MULTIPLE"]
 
 _lib = None
 
@@ -78,6 +114,15 @@ def load() -> C.CDLL:
     lib.amc_match_opts_default.argtypes = [C.POINTER(MatchOpts)]
     lib.amc_match_opts_default.restype = None
     lib.amc_get_acos_lut.argtypes = [C.c_void_p, C.c_void_p]
+    lib.amc_tvg_opts_default.argtypes = [C.POINTER(TvgOpts)]
+    lib.amc_tvg_opts_default.restype = None
+    lib.amc_upload_keypoints.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32]
+    lib.amc_upload_camera.argtypes = [C.c_void_p, C.c_uint32, C.c_int32, C.c_uint64, C.c_uint64,
+                                      C.c_void_p, C.c_int32, C.c_int32]
+    lib.amc_verify_pairs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
+                                     C.c_void_p, C.POINTER(TvgOpts), C.c_uint32, C.POINTER(VerifyResult)]
+    lib.amc_verify_result_free.argtypes = [C.POINTER(VerifyResult)]
+    lib.amc_verify_result_free.restype = None
     _lib = lib
     return lib
 
@@ -85,6 +130,22 @@ def load() -> C.CDLL:
 def _check(rc: int) -> None:
     if rc != AMC_OK:
         raise AmcError(rc, load().amc_last_error().decode(errors="replace"))
+
+
+def tvg_options(**kw) -> TvgOpts:
+    """TwoViewGeometryOptions with COLMAP's C++ defaults; keyword overrides; `ransac` may be a
+    dict of RANSACOptions fields."""
+    o = TvgOpts()
+    load().amc_tvg_opts_default(C.byref(o))
+    for k, v in kw.items():
+        if k == "ransac":
+            for rk, rv in v.items():
+                assert hasattr(o.ransac, rk), rk
+                setattr(o.ransac, rk, rv)
+        else:
+            assert hasattr(o, k), k
+            setattr(o, k, v)
+    return o
 
 
 def device_count() -> int:
@@ -165,6 +226,54 @@ class Context:
         finally:
             self._lib.amc_match_result_free(C.byref(res))
         return offsets, matches, stats
+
+    def upload_keypoints(self, slot: int, kp: np.ndarray) -> None:
+        k = np.ascontiguousarray(kp, dtype=np.float32)
+        if k.size and (k.ndim != 2 or k.shape[1] < 2):
+            raise ValueError(f"keypoints must be N x (>=2) float32, got {k.shape}")
+        rows = k.shape[0] if k.ndim == 2 else 0
+        stride = k.shape[1] if k.ndim == 2 and rows else 2
+        _check(self._lib.amc_upload_keypoints(self._h, slot, k.ctypes.data_as(C.c_void_p), rows, stride))
+
+    def upload_camera(self, slot: int, model: str | int, width: int, height: int, params,
+                      has_prior_focal_length: bool = False) -> None:
+        p = np.ascontiguousarray(params, dtype=np.float64)
+        mid = CAMERA_MODELS[model] if isinstance(model, str) else int(model)
+        _check(self._lib.amc_upload_camera(self._h, slot, mid, width, height,
+                                           p.ctypes.data_as(C.c_void_p), p.size,
+                                           int(has_prior_focal_length)))
+
+    def verify_pairs(self, slot1, slot2, match_offsets, matches, opts: TvgOpts | None = None, seed: int = 0):
+        """EstimateTwoViewGeometry per pair. Returns (tvg structured array [npairs], inlier_mask
+        bool [total matches], stats)."""
+        s1 = np.ascontiguousarray(slot1, dtype=np.uint32)
+        s2 = np.ascontiguousarray(slot2, dtype=np.uint32)
+        off = np.ascontiguousarray(match_offsets, dtype=np.uint64)
+        m = np.ascontiguousarray(matches, dtype=np.uint32).reshape(-1, 2)
+        if off.shape != (s1.size + 1,) or s1.shape != s2.shape:
+            raise ValueError("match_offsets must have npairs + 1 entries")
+        if int(off[-1]) != m.shape[0]:
+            raise ValueError("match_offsets[-1] must equal the number of matches")
+        o = opts if opts is not None else tvg_options()
+        res = VerifyResult()
+        _check(self._lib.amc_verify_pairs(self._h, s1.ctypes.data_as(C.c_void_p), s2.ctypes.data_as(C.c_void_p),
+                                          s1.size, off.ctypes.data_as(C.c_void_p), m.ctypes.data_as(C.c_void_p),
+                                          C.byref(o), seed, C.byref(res)))
+        try:
+            n = int(res.npairs)
+            assert C.sizeof(Tvg) == TVG_DTYPE.itemsize
+            if n:
+                buf = C.string_at(res.tvg, n * C.sizeof(Tvg))
+                tvg = np.frombuffer(buf, dtype=TVG_DTYPE).copy()
+            else:
+                tvg = np.zeros(0, dtype=TVG_DTYPE)
+            total = m.shape[0]
+            mask = (np.ctypeslib.as_array(res.inlier_mask, shape=(total,)).astype(bool) if total
+                    else np.zeros(0, dtype=bool))
+            stats = dict(device_ms=float(res.device_ms), kernel_ms=float(res.kernel_ms))
+        finally:
+            self._lib.amc_verify_result_free(C.byref(res))
+        return tvg, mask, stats
 
     def acos_lut(self) -> np.ndarray:
         out = np.empty(262145, dtype=np.float32)

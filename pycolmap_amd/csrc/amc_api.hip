@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <new>
 #include <string>
 #include <vector>
@@ -43,6 +44,10 @@ struct Slot {
     ImageDev dev{};
     uint32_t maxsq = 0;    // max_r |raw[r]|^2
     bool valid = false;
+    float* kp = nullptr;   // rows x 2 float32 keypoints (x, y)
+    uint32_t kp_rows = 0;
+    bool has_kp = false, has_cam = false;
+    CameraDev cam{};
 };
 
 // grow-only device / pinned-host scratch
@@ -109,6 +114,13 @@ struct amc_ctx {
     PinBuf<Dot4Work> h_work;
     PinBuf<uint32_t> h_order, h_order2, h_pair_off, h_pair_cnt, h_matches, h_scalars;
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    // verification scratch
+    DevBuf<TvgImage> d_timgs;
+    DevBuf<TvgPair> d_tpairs;
+    DevBuf<uint32_t> d_tmatches, d_ttabs, d_mtinit;
+    DevBuf<double> d_tws;
+    DevBuf<uint8_t> d_tmaskws, d_toutmask;
+    DevBuf<TvgOut> d_tout;
 };
 
 extern "C" {
@@ -179,6 +191,7 @@ int amc_ctx_create(int device_id, amc_ctx** out) {
 
 static void free_slot(Slot& s) {
     if (s.base) (void)hipFree(s.base);
+    if (s.kp) (void)hipFree(s.kp);
     s = Slot();
 }
 
@@ -197,6 +210,9 @@ void amc_ctx_destroy(amc_ctx* c) {
     c->h_pairs.release(); c->h_work.release(); c->h_order.release(); c->h_order2.release();
     c->h_pair_off.release(); c->h_pair_cnt.release(); c->h_matches.release();
     c->h_scalars.release();
+    c->d_timgs.release(); c->d_tpairs.release(); c->d_tmatches.release(); c->d_ttabs.release();
+    c->d_mtinit.release(); c->d_tws.release(); c->d_tmaskws.release(); c->d_toutmask.release();
+    c->d_tout.release();
     for (auto& ev : c->ev)
         if (ev) (void)hipEventDestroy(ev);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -231,7 +247,8 @@ static int upload_common(amc_ctx* c, uint32_t slot, const void* src, uint32_t ro
     Slot& s = c->slots[slot];
     if (s.base) {
         HIPCHK(hipStreamSynchronize(c->stream));
-        free_slot(s);
+        (void)hipFree(s.base);
+        s.base = nullptr;
     }
     c->table_dirty = true;
     s.valid = true;
@@ -243,7 +260,8 @@ static int upload_common(amc_ctx* c, uint32_t slot, const void* src, uint32_t ro
     const size_t bytes = rp * kDim * 2 + rp * sizeof(int32_t);
     hipError_t e = hipMalloc(&s.base, bytes);
     if (e != hipSuccess) {
-        s = Slot();
+        s.valid = false;
+        s.dev = ImageDev{};
         return fail(AMC_E_NOMEM, "upload_descriptors: hipMalloc(%zu): %s", bytes,
                     hipGetErrorString(e));
     }
@@ -562,6 +580,273 @@ int amc_match_pairs(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, si
 void amc_match_result_free(amc_match_result* r) {
     if (!r) return;
     delete static_cast<ResultPriv*>(r->_priv);
+    std::memset(r, 0, sizeof *r);
+}
+
+// ------------------------------------------------------------------------------------------------
+// two-view verification
+// ------------------------------------------------------------------------------------------------
+void amc_tvg_opts_default(amc_tvg_opts* o) {
+    if (!o) return;
+    o->min_num_inliers = 15;          // TwoViewGeometryOptions C++ defaults, SURVEY.md A.3
+    o->detect_watermark = 1;
+    o->multiple_ignore_watermark = 1;
+    o->force_H_use = 0;
+    o->compute_relative_pose = 0;
+    o->multiple_models = 0;
+    o->min_E_F_inlier_ratio = 0.95;
+    o->max_H_inlier_ratio = 0.8;
+    o->watermark_min_inlier_ratio = 0.7;
+    o->watermark_border_size = 0.1;
+    o->ransac.max_error = 4.0;
+    o->ransac.min_inlier_ratio = 0.25;
+    o->ransac.confidence = 0.999;
+    o->ransac.dyn_num_trials_multiplier = 3.0;
+    o->ransac.min_num_trials = 100;
+    o->ransac.max_num_trials = 10000;
+}
+
+int amc_upload_keypoints(amc_ctx* c, uint32_t slot, const float* xy, uint32_t rows,
+                         uint32_t stride_floats) {
+    if (!c) return fail(AMC_E_INVALID, "amc_upload_keypoints: ctx is NULL");
+    if (slot >= c->slots.size())
+        return fail(AMC_E_INVALID, "amc_upload_keypoints: slot %u >= reserved %zu", slot, c->slots.size());
+    if (rows > 0 && (!xy || stride_floats < 2))
+        return fail(AMC_E_INVALID, "amc_upload_keypoints: need x,y columns (stride %u) and data", stride_floats);
+    HIPCHK(hipSetDevice(c->device));
+    Slot& s = c->slots[slot];
+    if (s.kp) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        (void)hipFree(s.kp);
+        s.kp = nullptr;
+    }
+    s.kp_rows = rows;
+    s.has_kp = true;
+    if (rows == 0) return AMC_OK;
+    std::vector<float> packed((size_t)rows * 2);
+    for (uint32_t i = 0; i < rows; ++i) {
+        packed[2 * (size_t)i] = xy[(size_t)i * stride_floats];
+        packed[2 * (size_t)i + 1] = xy[(size_t)i * stride_floats + 1];
+    }
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&s.kp), packed.size() * sizeof(float));
+    if (e != hipSuccess) {
+        s.has_kp = false;
+        return fail(AMC_E_NOMEM, "amc_upload_keypoints: hipMalloc: %s", hipGetErrorString(e));
+    }
+    HIPCHK(hipMemcpy(s.kp, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
+    return AMC_OK;
+}
+
+int amc_upload_camera(amc_ctx* c, uint32_t slot, int32_t model_id, uint64_t width, uint64_t height,
+                      const double* params, int32_t num_params, int32_t has_prior) {
+    if (!c) return fail(AMC_E_INVALID, "amc_upload_camera: ctx is NULL");
+    if (slot >= c->slots.size())
+        return fail(AMC_E_INVALID, "amc_upload_camera: slot %u >= reserved %zu", slot, c->slots.size());
+    if (num_params < 0 || (num_params > 0 && !params))
+        return fail(AMC_E_INVALID, "amc_upload_camera: bad params");
+    Slot& s = c->slots[slot];
+    s.cam = CameraDev{};
+    s.cam.model_id = model_id;
+    s.cam.has_prior = has_prior ? 1 : 0;
+    s.cam.width = width;
+    s.cam.height = height;
+    for (int i = 0; i < num_params && i < 4; ++i) s.cam.params[i] = params[i];
+    s.has_cam = true;
+    return AMC_OK;
+}
+
+namespace {
+
+// RANSAC::ComputeNumTrials (colmap/optim/ransac.h) with the HOST libm, as COLMAP evaluates it
+size_t compute_num_trials_host(size_t num_inliers, size_t num_samples, double confidence,
+                               double multiplier, int kmin) {
+    const double inlier_ratio = num_inliers / static_cast<double>(num_samples);
+    const double nom = 1 - confidence;
+    if (nom <= 0) return std::numeric_limits<size_t>::max();
+    const double denom = 1 - std::pow(inlier_ratio, kmin);
+    if (denom <= 0) return 1;
+    if (denom == 1.0) return std::numeric_limits<size_t>::max();
+    return static_cast<size_t>(std::ceil(std::log(nom) / std::log(denom) * multiplier));
+}
+size_t ransac_max_trials_host(const amc_ransac_opts& o, double min_inlier_ratio, int kmin) {
+    const size_t kNumSamples = 100000;
+    const size_t dyn = compute_num_trials_host(static_cast<size_t>(min_inlier_ratio * kNumSamples), kNumSamples,
+                                               o.confidence, o.dyn_num_trials_multiplier, kmin);
+    return std::min<size_t>(static_cast<size_t>(o.max_num_trials), dyn);
+}
+
+struct VerifyPriv {
+    std::vector<amc_tvg> tvg;
+    std::vector<uint8_t> mask;
+};
+
+}  // namespace
+
+int amc_verify_pairs(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, size_t npairs,
+                     const uint64_t* match_offsets, const uint32_t* matches,
+                     const amc_tvg_opts* opts_in, uint32_t seed, amc_verify_result* out) {
+    if (!c || !out) return fail(AMC_E_INVALID, "amc_verify_pairs: NULL ctx/out");
+    std::memset(out, 0, sizeof *out);
+    if (npairs > 0 && (!slot1 || !slot2 || !match_offsets))
+        return fail(AMC_E_INVALID, "amc_verify_pairs: NULL pair arrays");
+    amc_tvg_opts o;
+    if (opts_in) o = *opts_in; else amc_tvg_opts_default(&o);
+    if (o.compute_relative_pose || o.multiple_models)
+        return fail(AMC_E_INVALID, "amc_verify_pairs: compute_relative_pose / multiple_models are not "
+                    "implemented (SURVEY.md 8f rank 4)");
+    if (o.ransac.max_num_trials < 0 || o.ransac.min_num_trials < 0 || o.ransac.max_num_trials > (1 << 30))
+        return fail(AMC_E_INVALID, "amc_verify_pairs: bad trial limits");
+    const uint64_t total = npairs ? match_offsets[npairs] : 0;
+    if (total > 0 && !matches) return fail(AMC_E_INVALID, "amc_verify_pairs: NULL matches");
+    uint32_t maxM = 0;
+    for (size_t p = 0; p < npairs; ++p) {
+        if (slot1[p] >= c->slots.size() || slot2[p] >= c->slots.size())
+            return fail(AMC_E_INVALID, "amc_verify_pairs: pair %zu references slot out of range", p);
+        const Slot& a = c->slots[slot1[p]];
+        const Slot& b = c->slots[slot2[p]];
+        if (!a.has_kp || !b.has_kp || !a.has_cam || !b.has_cam)
+            return fail(AMC_E_STATE, "amc_verify_pairs: pair %zu: keypoints/camera not uploaded", p);
+        if (match_offsets[p + 1] < match_offsets[p])
+            return fail(AMC_E_INVALID, "amc_verify_pairs: match_offsets not monotone at %zu", p);
+        const uint64_t M = match_offsets[p + 1] - match_offsets[p];
+        if (M > 65535) return fail(AMC_E_INVALID, "amc_verify_pairs: pair %zu has %llu matches (> 65535)", p,
+                                   (unsigned long long)M);
+        maxM = std::max<uint32_t>(maxM, (uint32_t)M);
+        for (uint64_t k = match_offsets[p]; k < match_offsets[p + 1]; ++k)
+            if (matches[2 * k] >= a.kp_rows || matches[2 * k + 1] >= b.kp_rows)
+                return fail(AMC_E_INVALID, "amc_verify_pairs: pair %zu match %llu indexes past the keypoints",
+                            p, (unsigned long long)(k - match_offsets[p]));
+        if (!o.force_H_use && a.cam.has_prior && b.cam.has_prior &&
+            ((a.cam.model_id != AMC_CAM_SIMPLE_PINHOLE && a.cam.model_id != AMC_CAM_PINHOLE) ||
+             (b.cam.model_id != AMC_CAM_SIMPLE_PINHOLE && b.cam.model_id != AMC_CAM_PINHOLE)))
+            return fail(AMC_E_INVALID, "amc_verify_pairs: pair %zu: calibrated path supports SIMPLE_PINHOLE / "
+                        "PINHOLE cameras only", p);
+    }
+    TvgParams P{};
+    P.min_num_inliers = o.min_num_inliers;
+    P.detect_watermark = o.detect_watermark;
+    P.force_H_use = o.force_H_use;
+    P.min_num_trials = (int32_t)std::min<int64_t>(o.ransac.min_num_trials, 1 << 30);
+    P.max_trials[0] = (int32_t)ransac_max_trials_host(o.ransac, o.ransac.min_inlier_ratio, 5);
+    P.max_trials[1] = (int32_t)ransac_max_trials_host(o.ransac, o.ransac.min_inlier_ratio, 7);
+    P.max_trials[2] = (int32_t)ransac_max_trials_host(o.ransac, o.ransac.min_inlier_ratio, 4);
+    P.max_trials[3] = (int32_t)ransac_max_trials_host(o.ransac, o.watermark_min_inlier_ratio, 1);
+    P.min_E_F_inlier_ratio = o.min_E_F_inlier_ratio;
+    P.max_H_inlier_ratio = o.max_H_inlier_ratio;
+    P.watermark_min_inlier_ratio = o.watermark_min_inlier_ratio;
+    P.watermark_border_size = o.watermark_border_size;
+    P.max_error = o.ransac.max_error;
+    if (o.detect_watermark && P.max_trials[3] > P.min_num_trials)
+        return fail(AMC_E_INVALID, "amc_verify_pairs: unsupported option combination: the watermark RANSAC "
+                    "may run %d trials > min_num_trials %d (its dynamic trial count is not tabulated)",
+                    P.max_trials[3], P.min_num_trials);
+
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    VerifyPriv* priv = new (std::nothrow) VerifyPriv();
+    if (!priv) return fail(AMC_E_NOMEM, "amc_verify_pairs: out of host memory");
+    priv->tvg.resize(npairs);
+    priv->mask.assign(total, 0);
+    out->npairs = npairs;
+    out->_priv = priv;
+    out->tvg = priv->tvg.data();
+    out->inlier_mask = priv->mask.data();
+    if (npairs == 0) return AMC_OK;
+
+    // image table
+    std::vector<TvgImage> timgs(c->slots.size());
+    for (size_t i = 0; i < timgs.size(); ++i) {
+        timgs[i].kp = c->slots[i].kp;
+        timgs[i].rows = c->slots[i].kp_rows;
+        timgs[i].pad = 0;
+        timgs[i].cam = c->slots[i].cam;
+    }
+    // dyn_max_num_trials tables, one set per distinct match count
+    std::vector<uint32_t> tabs;
+    std::vector<int64_t> tab_of_M((size_t)maxM + 1, -1);
+    std::vector<TvgPair> tp(npairs);
+    const int kmins[3] = {5, 7, 4};
+    uint64_t mask_bytes = 0;
+    for (size_t p = 0; p < npairs; ++p) {
+        const uint32_t M = (uint32_t)(match_offsets[p + 1] - match_offsets[p]);
+        if (tab_of_M[M] < 0) {
+            tab_of_M[M] = (int64_t)tabs.size();
+            for (int t = 0; t < 3; ++t)
+                for (uint32_t i = 0; i <= M; ++i) {
+                    const size_t v = M ? compute_num_trials_host(i, M, o.ransac.confidence,
+                                                                 o.ransac.dyn_num_trials_multiplier, kmins[t])
+                                       : 0;
+                    tabs.push_back(v > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)v);
+                }
+        }
+        tp[p].slot1 = slot1[p];
+        tp[p].slot2 = slot2[p];
+        tp[p].match_off = match_offsets[p];
+        tp[p].mask_off = mask_bytes;
+        mask_bytes += ((uint64_t)M + 127) / 128 * 128;
+        tp[p].M = M;
+        for (int t = 0; t < 3; ++t) tp[p].tab_off[t] = (uint32_t)(tab_of_M[M] + (int64_t)t * (M + 1));
+    }
+    // std::mt19937(seed) initial state
+    uint32_t mt0[624];
+    mt0[0] = seed;
+    for (int i = 1; i < 624; ++i) mt0[i] = 1812433253u * (mt0[i - 1] ^ (mt0[i - 1] >> 30)) + (uint32_t)i;
+
+    const uint32_t mcap = std::max<uint32_t>(64, round_up(maxM, 64));
+    int cus = 256;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device);
+    const size_t lds_block = tvg_lds_bytes(mcap, 4);
+    const uint32_t blocks_per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / std::max<size_t>(lds_block, 1)));
+    uint32_t num_waves = (uint32_t)std::min<size_t>((npairs + 0), (size_t)cus * blocks_per_cu * 4);
+    num_waves = std::max<uint32_t>(4, (num_waves + 3) / 4 * 4);
+
+    HIPCHK(c->d_timgs.ensure(timgs.size()));
+    HIPCHK(c->d_tpairs.ensure(npairs));
+    HIPCHK(c->d_tmatches.ensure(std::max<size_t>(2 * total, 2)));
+    HIPCHK(c->d_ttabs.ensure(std::max<size_t>(tabs.size(), 1)));
+    HIPCHK(c->d_mtinit.ensure(624));
+    HIPCHK(c->d_tws.ensure((size_t)num_waves * tvg_ws_doubles_host(mcap)));
+    HIPCHK(c->d_tmaskws.ensure((size_t)num_waves * tvg_ws_mask_bytes_host(mcap)));
+    HIPCHK(c->d_toutmask.ensure(std::max<size_t>(mask_bytes, 128)));
+    HIPCHK(c->d_tout.ensure(npairs));
+    HIPCHK(hipEventRecord(c->ev[0], st));
+    HIPCHK(hipMemcpyAsync(c->d_timgs.p, timgs.data(), timgs.size() * sizeof(TvgImage), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(c->d_tpairs.p, tp.data(), npairs * sizeof(TvgPair), hipMemcpyHostToDevice, st));
+    if (total)
+        HIPCHK(hipMemcpyAsync(c->d_tmatches.p, matches, 2 * total * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    if (!tabs.empty())
+        HIPCHK(hipMemcpyAsync(c->d_ttabs.p, tabs.data(), tabs.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(c->d_mtinit.p, mt0, sizeof mt0, hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));  // the host staging vectors above go out of scope
+    HIPCHK(hipEventRecord(c->ev[2], st));
+    HIPCHK(launch_tvg(c->d_timgs.p, c->d_tpairs.p, (uint32_t)npairs, c->d_tmatches.p, c->d_ttabs.p,
+                      c->d_mtinit.p, P, c->d_tws.p, c->d_tmaskws.p, mcap, num_waves, c->d_scalars + 1,
+                      c->d_tout.p, c->d_toutmask.p, st));
+    HIPCHK(hipEventRecord(c->ev[3], st));
+    std::vector<TvgOut> h_out(npairs);
+    std::vector<uint8_t> h_mask(std::max<size_t>(mask_bytes, 1));
+    HIPCHK(hipMemcpyAsync(h_out.data(), c->d_tout.p, npairs * sizeof(TvgOut), hipMemcpyDeviceToHost, st));
+    if (mask_bytes)
+        HIPCHK(hipMemcpyAsync(h_mask.data(), c->d_toutmask.p, mask_bytes, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipEventRecord(c->ev[1], st));
+    HIPCHK(hipEventSynchronize(c->ev[1]));
+    for (size_t p = 0; p < npairs; ++p) {
+        priv->tvg[p] = h_out[p].g;
+        if (tp[p].M)
+            std::memcpy(priv->mask.data() + match_offsets[p], h_mask.data() + tp[p].mask_off, tp[p].M);
+    }
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[1]);
+    out->device_ms = ms;
+    (void)hipEventElapsedTime(&ms, c->ev[2], c->ev[3]);
+    out->kernel_ms = ms;
+    out->kernel_launches = 1;
+    return AMC_OK;
+}
+
+void amc_verify_result_free(amc_verify_result* r) {
+    if (!r) return;
+    delete static_cast<VerifyPriv*>(r->_priv);
     std::memset(r, 0, sizeof *r);
 }
 

@@ -95,4 +95,45 @@ void launch_finalize(const ImageDev* imgs, const PairDev* pairs, uint32_t npairs
                      FinalizeParams fp, uint32_t* cursor, uint32_t capacity, uint32_t* pair_off,
                      uint32_t* pair_cnt, uint32_t* matches, hipStream_t s);
 
+// ----- two-view verification (tvg.hip) ------------------------------------------------------
+struct CameraDev {
+    int32_t model_id;
+    int32_t has_prior;
+    uint64_t width, height;
+    double params[4];
+};
+struct TvgImage {
+    const float* kp;  // rows x 2 float32 (x, y)
+    uint32_t rows;
+    uint32_t pad;
+    CameraDev cam;
+};
+struct TvgPair {
+    uint32_t slot1, slot2;
+    uint64_t match_off;   // into the batch's match array (in matches, not uint32s)
+    uint64_t mask_off;    // into the device mask buffer; 128-B aligned so that no two pairs (=
+                          // two waves, possibly on different XCDs with non-coherent L2s) ever
+                          // write bytes of the same cache line
+    uint32_t M;
+    uint32_t tab_off[3];  // dyn_max_num_trials tables for the E (k=5), F (k=7), H (k=4) RANSACs
+};
+// device-side result record: amc_tvg padded to its own cache lines (same reason)
+struct alignas(128) TvgOut {
+    amc_tvg g;
+};
+struct TvgParams {
+    int32_t min_num_inliers, detect_watermark, force_H_use, min_num_trials;
+    int32_t max_trials[4];  // E, F, H, watermark translation — clamped as the RANSAC ctor does
+    double min_E_F_inlier_ratio, max_H_inlier_ratio, watermark_min_inlier_ratio,
+        watermark_border_size, max_error;
+};
+size_t tvg_ws_doubles_host(uint32_t mcap);
+size_t tvg_ws_mask_bytes_host(uint32_t mcap);
+size_t tvg_lds_bytes(uint32_t mcap, int waves);
+hipError_t launch_tvg(const TvgImage* imgs, const TvgPair* pairs, uint32_t npairs,
+                      const uint32_t* matches, const uint32_t* trial_tabs, const uint32_t* mt_init,
+                      const TvgParams& P, double* ws, uint8_t* mask_ws, uint32_t mcap,
+                      uint32_t num_waves, uint32_t* queue_head, TvgOut* out, uint8_t* out_mask,
+                      hipStream_t s);
+
 }  // namespace amc

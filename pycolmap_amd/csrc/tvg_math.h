@@ -1,0 +1,515 @@
+// tvg_math.h — lane-local FP64 numerics of the two-view verification kernels (csrc/tvg.hip).
+//
+// Every function here is straight-line scalar code one GPU lane runs on its own data (one
+// RANSAC trial per lane for the minimal solvers; lane 0 for the local-optimisation solvers).
+// AMC_HD makes them callable from the host as well, so tests can compare them bit-for-bit with
+// the CPU oracle without a GPU.  No fast-math, no FMA contraction (-ffp-contract=off): IEEE
+// double throughout, operation order fixed by the source.
+//
+// Algorithms (own restatement; COLMAP uses Eigen):
+//   null spaces      Gauss-Jordan with full pivoting (minimal solvers)
+//   least squares    smallest eigenvector(s) of A^T A by cyclic Jacobi
+//   rank-2           project out the smallest right singular vector
+//   roots            bottom-up bracketing over the derivative chain + bisection
+#pragma once
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define AMC_HD __host__ __device__ inline
+#else
+#define AMC_HD inline
+#endif
+
+#include <stdint.h>
+
+namespace amc {
+namespace tvg {
+
+AMC_HD double dabs(double x) { return x < 0.0 ? -x : x; }
+AMC_HD double dmax(double a, double b) { return a > b ? a : b; }  // std::max(a, b) semantics
+#if defined(__HIP_DEVICE_COMPILE__)
+AMC_HD double dsqrt(double x) { return __dsqrt_rn(x); }
+#else
+}  // namespace tvg
+}  // namespace amc
+#include <cmath>
+namespace amc {
+namespace tvg {
+AMC_HD double dsqrt(double x) { return std::sqrt(x); }
+#endif
+
+AMC_HD void mat3_mul(const double* a, const double* b, double* c) {
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            c[3 * i + j] = a[3 * i + 0] * b[0 + j] + a[3 * i + 1] * b[3 + j] + a[3 * i + 2] * b[6 + j];
+}
+AMC_HD void mat3_t(const double* a, double* c) {
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) c[3 * i + j] = a[3 * j + i];
+}
+
+// ---- residuals (colmap/estimators/utils.cc ComputeSquaredSampsonError; homography_matrix.cc;
+//      translation_transform.h), exact operation order of SURVEY.md A.3 -------------------------
+AMC_HD double sampson(const double* e, double x1_0, double x1_1, double x2_0, double x2_1) {
+    const double Ex1_0 = e[0] * x1_0 + e[1] * x1_1 + e[2];
+    const double Ex1_1 = e[3] * x1_0 + e[4] * x1_1 + e[5];
+    const double Ex1_2 = e[6] * x1_0 + e[7] * x1_1 + e[8];
+    const double Etx2_0 = e[0] * x2_0 + e[3] * x2_1 + e[6];
+    const double Etx2_1 = e[1] * x2_0 + e[4] * x2_1 + e[7];
+    const double x2tEx1 = x2_0 * Ex1_0 + x2_1 * Ex1_1 + Ex1_2;
+    return x2tEx1 * x2tEx1 / (Ex1_0 * Ex1_0 + Ex1_1 * Ex1_1 + Etx2_0 * Etx2_0 + Etx2_1 * Etx2_1);
+}
+AMC_HD double h_residual(const double* H, double s_0, double s_1, double d_0, double d_1) {
+    const double pd_0 = H[0] * s_0 + H[1] * s_1 + H[2];
+    const double pd_1 = H[3] * s_0 + H[4] * s_1 + H[5];
+    const double pd_2 = H[6] * s_0 + H[7] * s_1 + H[8];
+    const double inv_pd_2 = 1.0 / pd_2;
+    const double dd_0 = d_0 - pd_0 * inv_pd_2;
+    const double dd_1 = d_1 - pd_1 * inv_pd_2;
+    return dd_0 * dd_0 + dd_1 * dd_1;
+}
+AMC_HD double t_residual(const double* t, double s_0, double s_1, double d_0, double d_1) {
+    const double d0 = d_0 - s_0 - t[0];
+    const double d1 = d_1 - s_1 - t[1];
+    return d0 * d0 + d1 * d1;
+}
+
+// ---- cyclic Jacobi eigen-decomposition, symmetric n x n (n <= 9), fixed rotation order --------
+AMC_HD void jacobi_eigen(int n, double* a, double* v) {
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) v[i * n + j] = (i == j) ? 1.0 : 0.0;
+    double total = 0.0;
+    for (int i = 0; i < n * n; ++i) total += a[i] * a[i];
+    const double tol = total * 1e-32;
+    for (int sweep = 0; sweep < 40; ++sweep) {
+        double off = 0.0;
+        for (int p = 0; p < n - 1; ++p)
+            for (int q = p + 1; q < n; ++q) off += a[p * n + q] * a[p * n + q];
+        if (!(off > tol)) break;
+        for (int p = 0; p < n - 1; ++p) {
+            for (int q = p + 1; q < n; ++q) {
+                const double apq = a[p * n + q];
+                if (apq == 0.0) continue;
+                const double theta = (a[q * n + q] - a[p * n + p]) / (2.0 * apq);
+                const double t = (theta >= 0.0 ? 1.0 : -1.0) / (dabs(theta) + dsqrt(theta * theta + 1.0));
+                const double c = 1.0 / dsqrt(t * t + 1.0);
+                const double s = t * c;
+                for (int k = 0; k < n; ++k) {
+                    const double akp = a[k * n + p], akq = a[k * n + q];
+                    a[k * n + p] = c * akp - s * akq;
+                    a[k * n + q] = s * akp + c * akq;
+                }
+                for (int k = 0; k < n; ++k) {
+                    const double apk = a[p * n + k], aqk = a[q * n + k];
+                    a[p * n + k] = c * apk - s * aqk;
+                    a[q * n + k] = s * apk + c * aqk;
+                }
+                for (int k = 0; k < n; ++k) {
+                    const double vkp = v[k * n + p], vkq = v[k * n + q];
+                    v[k * n + p] = c * vkp - s * vkq;
+                    v[k * n + q] = s * vkp + c * vkq;
+                }
+            }
+        }
+    }
+}
+AMC_HD void smallest_eigvec9(double* ata, double* x) {
+    double v[81];
+    jacobi_eigen(9, ata, v);
+    int best = 0;
+    for (int i = 1; i < 9; ++i)
+        if (ata[i * 9 + i] < ata[best * 9 + best]) best = i;
+    for (int i = 0; i < 9; ++i) x[i] = v[i * 9 + best];
+}
+
+// ---- null space of an R x 9 matrix (R <= 8), Gauss-Jordan with full pivoting -------------------
+AMC_HD void nullspace9(int R, double* a, double* ns) {
+    int perm[9];
+    for (int j = 0; j < 9; ++j) perm[j] = j;
+    for (int r = 0; r < R; ++r) {
+        int pi = r, pj = r;
+        double pv = -1.0;
+        for (int i = r; i < R; ++i)
+            for (int j = r; j < 9; ++j) {
+                const double v = dabs(a[i * 9 + j]);
+                if (v > pv) { pv = v; pi = i; pj = j; }
+            }
+        if (pi != r)
+            for (int j = 0; j < 9; ++j) { const double t = a[r * 9 + j]; a[r * 9 + j] = a[pi * 9 + j]; a[pi * 9 + j] = t; }
+        if (pj != r) {
+            for (int i = 0; i < R; ++i) { const double t = a[i * 9 + r]; a[i * 9 + r] = a[i * 9 + pj]; a[i * 9 + pj] = t; }
+            const int t = perm[r]; perm[r] = perm[pj]; perm[pj] = t;
+        }
+        const double inv = 1.0 / a[r * 9 + r];
+        for (int j = 0; j < 9; ++j) a[r * 9 + j] = a[r * 9 + j] * inv;
+        for (int i = 0; i < R; ++i) {
+            if (i == r) continue;
+            const double f = a[i * 9 + r];
+            for (int j = 0; j < 9; ++j) a[i * 9 + j] = a[i * 9 + j] - f * a[r * 9 + j];
+        }
+    }
+    for (int k = 0; k < 9 - R; ++k) {
+        double* x = ns + k * 9;
+        for (int j = 0; j < 9; ++j) x[j] = 0.0;
+        x[perm[R + k]] = 1.0;
+        for (int i = 0; i < R; ++i) x[perm[i]] = -a[i * 9 + (R + k)];
+    }
+}
+
+// ---- real roots, ascending --------------------------------------------------------------------
+AMC_HD double poly_eval(const double* c, int deg, double x) {
+    double v = c[deg];
+    for (int i = deg - 1; i >= 0; --i) v = v * x + c[i];
+    return v;
+}
+AMC_HD int roots_between(const double* c, int deg, const double* crit, int nc, double* roots) {
+    if (deg == 1) {
+        roots[0] = -c[0] / c[1];
+        return 1;
+    }
+    double bound = 0.0;
+    for (int i = 0; i < deg; ++i) bound = dmax(bound, dabs(c[i] / c[deg]));
+    bound = 1.0 + bound;
+    double edges[12];
+    int ne = 0;
+    edges[ne++] = -bound;
+    for (int i = 0; i < nc; ++i)
+        if (crit[i] > -bound && crit[i] < bound) edges[ne++] = crit[i];
+    edges[ne++] = bound;
+    int nr = 0;
+    for (int i = 0; i + 1 < ne; ++i) {
+        double lo = edges[i], hi = edges[i + 1];
+        double flo = poly_eval(c, deg, lo);
+        const double fhi = poly_eval(c, deg, hi);
+        if (flo == 0.0) {
+            if (nr == 0 || roots[nr - 1] != lo) roots[nr++] = lo;
+            continue;
+        }
+        if (fhi == 0.0) continue;
+        if ((flo < 0.0) == (fhi < 0.0)) continue;
+        for (int it = 0; it < 200; ++it) {
+            const double mid = 0.5 * (lo + hi);
+            if (mid == lo || mid == hi) break;
+            const double fm = poly_eval(c, deg, mid);
+            if (fm == 0.0) { lo = mid; hi = mid; break; }
+            if ((fm < 0.0) == (flo < 0.0)) { lo = mid; flo = fm; } else { hi = mid; }
+        }
+        roots[nr++] = 0.5 * (lo + hi);
+    }
+    if (poly_eval(c, deg, edges[ne - 1]) == 0.0 && (nr == 0 || roots[nr - 1] != edges[ne - 1]))
+        roots[nr++] = edges[ne - 1];
+    return nr;
+}
+AMC_HD int real_roots(const double* c_in, int deg_in, double* roots) {
+    int deg = deg_in;
+    while (deg > 0 && c_in[deg] == 0.0) --deg;
+    if (deg == 0) return 0;
+    double chain[11][11];
+    for (int i = 0; i <= deg; ++i) chain[0][i] = c_in[i];
+    for (int j = 1; j < deg; ++j)
+        for (int i = 1; i <= deg - j + 1; ++i) chain[j][i - 1] = chain[j - 1][i] * i;
+    double crit[10], cur[10];
+    int nc = 0;
+    for (int j = deg - 1; j >= 0; --j) {
+        const int n = roots_between(chain[j], deg - j, crit, nc, cur);
+        nc = n;
+        for (int i = 0; i < n; ++i) crit[i] = cur[i];
+    }
+    for (int i = 0; i < nc; ++i) roots[i] = crit[i];
+    return nc;
+}
+
+// ---- 7-point fundamental matrix (FundamentalMatrixSevenPointEstimator::Estimate) ---------------
+// x1/y1: image-1 coords of the 7 samples, x2/y2: image-2.  Returns #models (<= 3), row-major.
+AMC_HD int estimate_f7(const double* x1s, const double* y1s, const double* x2s, const double* y2s,
+                       double* models /* 3 x 9 */) {
+    double A[7 * 9];
+    for (int i = 0; i < 7; ++i) {
+        const double x0 = x1s[i], y0 = y1s[i], x1 = x2s[i], y1 = y2s[i];
+        double* r = A + i * 9;
+        r[0] = x1 * x0; r[1] = x1 * y0; r[2] = x1;
+        r[3] = y1 * x0; r[4] = y1 * y0; r[5] = y1;
+        r[6] = x0; r[7] = y0; r[8] = 1;
+    }
+    double ns[2 * 9];
+    nullspace9(7, A, ns);
+    double f1[9], f2[9];
+    for (int i = 0; i < 9; ++i) { f2[i] = ns[9 + i]; f1[i] = ns[i] - f2[i]; }
+    // det(lambda f1 + f2): entries e = f2 + f1 lambda; 2x2 minors (degree 2), then expansion
+    double mn[3][3];
+    const int mi[3][4] = {{4, 8, 5, 7}, {3, 8, 5, 6}, {3, 7, 4, 6}};
+    for (int m = 0; m < 3; ++m) {
+        const int i = mi[m][0], j = mi[m][1], k = mi[m][2], l = mi[m][3];
+        const double u0 = f2[i] * f2[j], u1 = f2[i] * f1[j] + f1[i] * f2[j], u2 = f1[i] * f1[j];
+        const double w0 = f2[k] * f2[l], w1 = f2[k] * f1[l] + f1[k] * f2[l], w2 = f1[k] * f1[l];
+        mn[m][0] = u0 - w0; mn[m][1] = u1 - w1; mn[m][2] = u2 - w2;
+    }
+    double c[4] = {0, 0, 0, 0};
+    const double sg[3] = {1.0, -1.0, 1.0};
+    for (int m = 0; m < 3; ++m) {
+        const double e0 = f2[m], e1 = f1[m];
+        c[0] += sg[m] * (e0 * mn[m][0]);
+        c[1] += sg[m] * (e0 * mn[m][1] + e1 * mn[m][0]);
+        c[2] += sg[m] * (e0 * mn[m][2] + e1 * mn[m][1]);
+        c[3] += sg[m] * (e1 * mn[m][2]);
+    }
+    double roots[3];
+    const int nr = real_roots(c, 3, roots);
+    int nm = 0;
+    for (int i = 0; i < nr; ++i) {
+        const double lambda = roots[i];
+        double* F = models + 9 * nm;
+        for (int k = 0; k < 9; ++k) F[k] = lambda * f1[k] + f2[k];
+        if (dabs(F[8]) < 1e-10) continue;
+        const double inv = F[8];
+        for (int k = 0; k < 9; ++k) F[k] = F[k] / inv;
+        ++nm;
+    }
+    return nm;
+}
+
+// ---- 8-point tail: from A^T A of the normalised design matrix to F ----------------------------
+AMC_HD void f8_from_ata(double* ata, const double* T1, const double* T2, double* F) {
+    double f[9];
+    smallest_eigvec9(ata, f);
+    double Fh[9], Ft[9], ftf[9], v[9];
+    for (int k = 0; k < 9; ++k) Fh[k] = f[k];
+    mat3_t(Fh, Ft);
+    mat3_mul(Ft, Fh, ftf);
+    jacobi_eigen(3, ftf, v);
+    int b = 0;
+    for (int i = 1; i < 3; ++i)
+        if (ftf[i * 3 + i] < ftf[b * 3 + b]) b = i;
+    const double v3[3] = {v[0 * 3 + b], v[1 * 3 + b], v[2 * 3 + b]};
+    double Fr[9];
+    for (int i = 0; i < 3; ++i) {
+        const double fv = Fh[3 * i] * v3[0] + Fh[3 * i + 1] * v3[1] + Fh[3 * i + 2] * v3[2];
+        for (int j = 0; j < 3; ++j) Fr[3 * i + j] = Fh[3 * i + j] - fv * v3[j];
+    }
+    double T2t[9], tmp[9];
+    mat3_t(T2, T2t);
+    mat3_mul(T2t, Fr, tmp);
+    mat3_mul(tmp, T1, F);
+}
+
+// ---- homography tail: H = T2^-1 * Hhat * T1 ---------------------------------------------------
+AMC_HD void h_denormalize(const double* h, const double* T1, const double* T2, double* H) {
+    double T2i[9];
+    const double inv_nf = 1.0 / T2[0];
+    T2i[0] = inv_nf; T2i[1] = 0; T2i[2] = -T2[2] * inv_nf;
+    T2i[3] = 0; T2i[4] = inv_nf; T2i[5] = -T2[5] * inv_nf;
+    T2i[6] = 0; T2i[7] = 0; T2i[8] = 1;
+    double tmp[9];
+    mat3_mul(T2i, h, tmp);
+    mat3_mul(tmp, T1, H);
+}
+
+// CenterAndNormalizeImagePoints for exactly 4 points in the oracle's det_sum64 order, which for
+// n = 4 reduces to (v0 + v2) + (v1 + v3).  Writes normalised points and T (row-major).
+AMC_HD void normalize4(const double* x, const double* y, double* nx, double* ny, double* T) {
+    const double cx = ((x[0] + x[2]) + (x[1] + x[3])) / 4;
+    const double cy = ((y[0] + y[2]) + (y[1] + y[3])) / 4;
+    double d[4];
+    for (int i = 0; i < 4; ++i) {
+        const double dx = x[i] - cx, dy = y[i] - cy;
+        d[i] = dx * dx + dy * dy;
+    }
+    double rms = (d[0] + d[2]) + (d[1] + d[3]);
+    rms = dsqrt(rms / 4);
+    const double nf = dsqrt(2.0) / rms;
+    T[0] = nf; T[1] = 0; T[2] = -nf * cx;
+    T[3] = 0; T[4] = nf; T[5] = -nf * cy;
+    T[6] = 0; T[7] = 0; T[8] = 1;
+    for (int i = 0; i < 4; ++i) {
+        const double np0 = T[0] * x[i] + T[1] * y[i] + T[2];
+        const double np1 = T[3] * x[i] + T[4] * y[i] + T[5];
+        const double np2 = T[6] * x[i] + T[7] * y[i] + T[8];
+        const double inv = 1.0 / np2;
+        nx[i] = np0 * inv;
+        ny[i] = np1 * inv;
+    }
+}
+
+// minimal 4-point homography
+AMC_HD void estimate_h4(const double* x1, const double* y1, const double* x2, const double* y2, double* H) {
+    double n1x[4], n1y[4], n2x[4], n2y[4], T1[9], T2[9];
+    normalize4(x1, y1, n1x, n1y, T1);
+    normalize4(x2, y2, n2x, n2y, T2);
+    double A[8 * 9];
+    for (int i = 0; i < 4; ++i) {
+        const double s_0 = n1x[i], s_1 = n1y[i], d_0 = n2x[i], d_1 = n2y[i];
+        double* ra = A + i * 9;
+        double* rb = A + (4 + i) * 9;
+        ra[0] = -s_0; ra[1] = -s_1; ra[2] = -1; ra[3] = 0; ra[4] = 0; ra[5] = 0;
+        ra[6] = s_0 * d_0; ra[7] = s_1 * d_0; ra[8] = d_0;
+        rb[0] = 0; rb[1] = 0; rb[2] = 0; rb[3] = -s_0; rb[4] = -s_1; rb[5] = -1;
+        rb[6] = s_0 * d_1; rb[7] = s_1 * d_1; rb[8] = d_1;
+    }
+    double h[9];
+    nullspace9(8, A, h);
+    h_denormalize(h, T1, T2, H);
+}
+
+// ---- 5-point essential matrix -------------------------------------------------------------------
+// Monomial tables shared with the oracle's formulation (P1: x y z 1; P2: x^2 y^2 xy xz x yz y z^2 z 1;
+// P3: x^3 y^3 x^2y xy^2 x^2z x^2 y^2z y^2 xyz xy xz^2 xz x yz^2 yz y z^3 z^2 z 1).
+// kM11[i][j] = P2 index of P1[i]*P1[j]; kM21[i][j] = P3 index of P2[i]*P1[j].
+#define AMC_M11 {{0, 2, 3, 4}, {2, 1, 5, 6}, {3, 5, 7, 8}, {4, 6, 8, 9}}
+#define AMC_M21 {{0, 2, 4, 5}, {3, 1, 6, 7}, {2, 3, 8, 9}, {4, 8, 10, 11}, {5, 9, 11, 12}, \
+                 {8, 6, 13, 14}, {9, 7, 14, 15}, {10, 13, 16, 17}, {11, 14, 17, 18}, {12, 15, 18, 19}}
+
+AMC_HD void e5_mul11(const double* a, const double* b, double* r) {
+    const int M[4][4] = AMC_M11;
+    for (int i = 0; i < 10; ++i) r[i] = 0.0;
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) r[M[i][j]] += a[i] * b[j];
+}
+AMC_HD void e5_mul21(const double* a, const double* b, double* r) {
+    const int M[10][4] = AMC_M21;
+    for (int i = 0; i < 20; ++i) r[i] = 0.0;
+    for (int i = 0; i < 10; ++i)
+        for (int j = 0; j < 4; ++j) r[M[i][j]] += a[i] * b[j];
+}
+
+// nsp: 4 x 9 basis (rows: x, y, z, 1 directions).  Returns #models (<= 10), row-major.
+AMC_HD int e5_from_nullspace(const double* nsp, double* models /* 10 x 9 */) {
+    double e[9][4];
+    for (int k = 0; k < 9; ++k)
+        for (int d = 0; d < 4; ++d) e[k][d] = nsp[d * 9 + k];
+    double G[10][20];
+    {   // det(E) -> row 0
+        double a[10], b[10], d[10], t0[20], t1[20], t2[20];
+        e5_mul11(e[4], e[8], a); e5_mul11(e[5], e[7], b);
+        for (int i = 0; i < 10; ++i) d[i] = a[i] - b[i];
+        e5_mul21(d, e[0], t0);
+        e5_mul11(e[3], e[8], a); e5_mul11(e[5], e[6], b);
+        for (int i = 0; i < 10; ++i) d[i] = a[i] - b[i];
+        e5_mul21(d, e[1], t1);
+        e5_mul11(e[3], e[7], a); e5_mul11(e[4], e[6], b);
+        for (int i = 0; i < 10; ++i) d[i] = a[i] - b[i];
+        e5_mul21(d, e[2], t2);
+        for (int i = 0; i < 20; ++i) G[0][i] = (t0[i] - t1[i]) + t2[i];
+    }
+    double eet[9][10], tr[10];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double a[10], b[10], c[10];
+            e5_mul11(e[3 * i], e[3 * j], a);
+            e5_mul11(e[3 * i + 1], e[3 * j + 1], b);
+            e5_mul11(e[3 * i + 2], e[3 * j + 2], c);
+            for (int t = 0; t < 10; ++t) eet[3 * i + j][t] = (a[t] + b[t]) + c[t];
+        }
+    for (int t = 0; t < 10; ++t) tr[t] = (eet[0][t] + eet[4][t]) + eet[8][t];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double a[20], b[20], c[20], d[20];
+            e5_mul21(eet[3 * i], e[j], a);
+            e5_mul21(eet[3 * i + 1], e[3 + j], b);
+            e5_mul21(eet[3 * i + 2], e[6 + j], c);
+            e5_mul21(tr, e[3 * i + j], d);
+            for (int t = 0; t < 20; ++t) G[1 + 3 * i + j][t] = ((a[t] + b[t]) + c[t]) * 2.0 - d[t];
+        }
+    for (int col = 0; col < 10; ++col) {
+        int piv = col;
+        double pv = dabs(G[col][col]);
+        for (int r = col + 1; r < 10; ++r)
+            if (dabs(G[r][col]) > pv) { pv = dabs(G[r][col]); piv = r; }
+        if (piv != col)
+            for (int c = 0; c < 20; ++c) { const double t = G[col][c]; G[col][c] = G[piv][c]; G[piv][c] = t; }
+        const double inv = 1.0 / G[col][col];
+        for (int c = 0; c < 20; ++c) G[col][c] = G[col][c] * inv;
+        for (int r = 0; r < 10; ++r) {
+            if (r == col) continue;
+            const double f = G[r][col];
+            for (int c = 0; c < 20; ++c) G[r][c] = G[r][c] - f * G[col][c];
+        }
+    }
+    double B[3][3][5];  // B[k][0..1]: degree 3, B[k][2]: degree 4 (low -> high)
+    for (int k = 0; k < 3; ++k) {
+        const double* hi = G[4 + 2 * k];
+        const double* lo = G[5 + 2 * k];
+        for (int t = 0; t < 3; ++t)
+            for (int d = 0; d < 5; ++d) B[k][t][d] = 0.0;
+        double* a = B[k][0];
+        double* b = B[k][1];
+        double* c = B[k][2];
+        a[2] += hi[10]; a[1] += hi[11]; a[0] += hi[12];
+        b[2] += hi[13]; b[1] += hi[14]; b[0] += hi[15];
+        c[3] += hi[16]; c[2] += hi[17]; c[1] += hi[18]; c[0] += hi[19];
+        a[3] -= lo[10]; a[2] -= lo[11]; a[1] -= lo[12];
+        b[3] -= lo[13]; b[2] -= lo[14]; b[1] -= lo[15];
+        c[4] -= lo[16]; c[3] -= lo[17]; c[2] -= lo[18]; c[1] -= lo[19];
+    }
+    // det B(z) with the oracle's accumulation order: pz_mul (i outer, j inner), sub, add
+    auto pmul = [](const double* a, int da, const double* b, int db, double* r) {
+        for (int i = 0; i <= da + db; ++i) r[i] = 0.0;
+        for (int i = 0; i <= da; ++i)
+            for (int j = 0; j <= db; ++j) r[i + j] += a[i] * b[j];
+    };
+    double u[11], w[11], m0[11], m1[11], m2[11];
+    pmul(B[1][1], 3, B[2][2], 4, u); pmul(B[1][2], 4, B[2][1], 3, w);
+    for (int i = 0; i <= 7; ++i) m0[i] = u[i] - w[i];
+    pmul(B[1][0], 3, B[2][2], 4, u); pmul(B[1][2], 4, B[2][0], 3, w);
+    for (int i = 0; i <= 7; ++i) m1[i] = u[i] - w[i];
+    pmul(B[1][0], 3, B[2][1], 3, u); pmul(B[1][1], 3, B[2][0], 3, w);
+    for (int i = 0; i <= 6; ++i) m2[i] = u[i] - w[i];
+    double q0[11], q1[11], q2[11], det[11];
+    pmul(B[0][0], 3, m0, 7, q0);
+    pmul(B[0][1], 3, m1, 7, q1);
+    pmul(B[0][2], 4, m2, 6, q2);
+    for (int i = 0; i <= 10; ++i) det[i] = (q0[i] - q1[i]) + q2[i];
+    double roots[10];
+    const int nr = real_roots(det, 10, roots);
+    for (int i = 0; i < nr; ++i) {
+        const double z = roots[i];
+        const double a0 = poly_eval(B[0][0], 3, z), b0 = poly_eval(B[0][1], 3, z), c0 = poly_eval(B[0][2], 4, z);
+        const double a1 = poly_eval(B[1][0], 3, z), b1 = poly_eval(B[1][1], 3, z), c1 = poly_eval(B[1][2], 4, z);
+        const double dd = a0 * b1 - a1 * b0;
+        const double x = (b0 * c1 - b1 * c0) / dd;
+        const double y = (a1 * c0 - a0 * c1) / dd;
+        double* E = models + 9 * i;
+        for (int k = 0; k < 9; ++k) E[k] = x * nsp[k] + y * nsp[9 + k] + z * nsp[18 + k] + nsp[27 + k];
+    }
+    return nr;
+}
+
+// minimal 5-point
+AMC_HD int estimate_e5_minimal(const double* x1, const double* y1, const double* x2, const double* y2,
+                               double* models) {
+    double A[5 * 9];
+    for (int i = 0; i < 5; ++i) {
+        double* r = A + i * 9;
+        r[0] = x2[i] * x1[i]; r[1] = x2[i] * y1[i]; r[2] = x2[i];
+        r[3] = y2[i] * x1[i]; r[4] = y2[i] * y1[i]; r[5] = y2[i];
+        r[6] = x1[i]; r[7] = y1[i]; r[8] = 1;
+    }
+    double nsp[4 * 9];
+    nullspace9(5, A, nsp);
+    return e5_from_nullspace(nsp, models);
+}
+// least-squares 5-point (local optimisation): 4 smallest eigenvectors of A^T A
+AMC_HD int e5_from_ata(double* ata, double* models) {
+    double v[81];
+    jacobi_eigen(9, ata, v);
+    int order[9];
+    for (int i = 0; i < 9; ++i) order[i] = i;
+    for (int i = 0; i < 9; ++i)
+        for (int j = i + 1; j < 9; ++j)
+            if (ata[order[j] * 9 + order[j]] < ata[order[i] * 9 + order[i]]) { const int t = order[i]; order[i] = order[j]; order[j] = t; }
+    double nsp[4 * 9];
+    for (int k = 0; k < 4; ++k)
+        for (int i = 0; i < 9; ++i) nsp[k * 9 + i] = v[i * 9 + order[3 - k]];
+    return e5_from_nullspace(nsp, models);
+}
+
+// ---- mt19937 tempering + libstdc++ uniform_int_distribution<uint32_t> (Lemire) ------------------
+AMC_HD uint32_t mt_temper(uint32_t y) {
+    y ^= (y >> 11);
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= (y >> 18);
+    return y;
+}
+
+}  // namespace tvg
+}  // namespace amc

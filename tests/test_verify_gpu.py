@@ -1,0 +1,154 @@
+"""GPU parity tests of two-view verification: libamc.so's amc_verify_pairs vs the CPU oracle on
+identical seeded inputs.  Bit-exact: configs, inlier masks, trial counts AND the bit patterns of
+the E/F/H models (FP64, same operation order, no contraction)."""
+import numpy as np
+import pytest
+
+import oracle_lib as o
+from pycolmap_amd import _capi, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+def build_batch(scenes, priors):
+    """One image slot pair per scene."""
+    slots, cams = [], []
+    for sc, prior in zip(scenes, priors):
+        cam = dict(model="PINHOLE", width=sc["width"], height=sc["height"],
+                   params=(sc["f"], sc["f"], sc["width"] / 2.0, sc["height"] / 2.0), prior=prior)
+        slots += [sc["pts1"], sc["pts2"]]
+        cams += [cam, cam]
+    return slots, cams
+
+
+def run_both(ctx, scenes, priors, opts_kw=None, seed=0):
+    opts_kw = opts_kw or {}
+    slots, cams = build_batch(scenes, priors)
+    ctx.reserve_slots(len(slots))
+    for i, (kp, cam) in enumerate(zip(slots, cams)):
+        ctx.upload_keypoints(i, kp.astype(np.float32))
+        ctx.upload_camera(i, cam["model"], cam["width"], cam["height"], cam["params"], cam["prior"])
+    s1 = np.arange(0, len(slots), 2, dtype=np.uint32)
+    s2 = s1 + 1
+    off = np.zeros(len(scenes) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(sc["matches"]) for sc in scenes])
+    matches = np.concatenate([sc["matches"] for sc in scenes]) if scenes else np.zeros((0, 2), np.uint32)
+    ransac_kw = opts_kw.get("ransac", {})
+    tvg, mask, st = ctx.verify_pairs(s1, s2, off, matches, _capi.tvg_options(**opts_kw), seed=seed)
+    okw = {k: v for k, v in opts_kw.items() if k != "ransac"}
+    okw.update(ransac_kw)
+    want = []
+    for sc, prior in zip(scenes, priors):
+        cam = o.make_camera("PINHOLE", sc["width"], sc["height"],
+                            (sc["f"], sc["f"], sc["width"] / 2.0, sc["height"] / 2.0), prior=prior)
+        want.append(o.estimate_two_view_geometry(cam, sc["pts1"], cam, sc["pts2"], sc["matches"],
+                                                 o.tvg_default_options(**okw), seed=seed))
+    return tvg, mask, off, want
+
+
+def assert_pair_equal(p, tvg, mask, off, want):
+    g, w = tvg[p], want[p]
+    name = _capi.CONFIG_NAMES[g["config"]]
+    assert name == w["config_name"], f"pair {p}: {name} != {w['config_name']}"
+    assert g["num_trials"].tolist() == w["trials"], f"pair {p} trials {g['num_trials']} vs {w['trials']}"
+    assert g["model_inliers"].tolist() == w["inl"], f"pair {p}"
+    assert g["num_inliers"] == w["num_inliers"], f"pair {p}"
+    np.testing.assert_array_equal(mask[int(off[p]):int(off[p + 1])], w["inlier_mask"], err_msg=f"pair {p}")
+    for k in "EFH":
+        np.testing.assert_array_equal(bits(g[k]), bits(w[k]), err_msg=f"pair {p} model {k}")
+
+
+def test_uncalibrated_general_and_planar(amc_ctx):
+    rng = np.random.default_rng(0)
+    scenes = [synth.two_view_scene(rng, num_inliers=300, num_outliers=100),
+              synth.two_view_scene(rng, num_inliers=200, num_outliers=150, planar=True),
+              synth.two_view_scene(rng, num_inliers=60, num_outliers=40, noise=1.0),
+              synth.two_view_scene(rng, num_inliers=0, num_outliers=30)]
+    tvg, mask, off, want = run_both(amc_ctx, scenes, [False] * 4)
+    for p in range(4):
+        assert_pair_equal(p, tvg, mask, off, want)
+    names = [_capi.CONFIG_NAMES[c] for c in tvg["config"]]
+    assert names[0] == "UNCALIBRATED" and names[1] == "PLANAR_OR_PANORAMIC" and names[3] == "DEGENERATE"
+
+
+def test_calibrated_with_essential_matrix(amc_ctx):
+    rng = np.random.default_rng(1)
+    scenes = [synth.two_view_scene(rng, num_inliers=250, num_outliers=90),
+              synth.two_view_scene(rng, num_inliers=150, num_outliers=60, planar=True),
+              synth.two_view_scene(rng, num_inliers=80, num_outliers=120)]
+    tvg, mask, off, want = run_both(amc_ctx, scenes, [True] * 3)
+    for p in range(3):
+        assert_pair_equal(p, tvg, mask, off, want)
+    assert _capi.CONFIG_NAMES[tvg["config"][0]] == "CALIBRATED" and tvg["num_trials"][0][0] > 0
+
+
+def test_mixed_batch_sizes_and_edge_cases(amc_ctx):
+    rng = np.random.default_rng(2)
+    scenes = [synth.two_view_scene(rng, num_inliers=ni, num_outliers=no, planar=pl)
+              for ni, no, pl in [(20, 5, False), (14, 0, False), (15, 0, False), (700, 300, False),
+                                 (33, 31, True), (64, 0, False), (65, 63, False), (128, 128, True)]]
+    priors = [False, False, True, False, True, False, True, False]
+    tvg, mask, off, want = run_both(amc_ctx, scenes, priors)
+    for p in range(len(scenes)):
+        assert_pair_equal(p, tvg, mask, off, want)
+    assert _capi.CONFIG_NAMES[tvg["config"][1]] == "DEGENERATE"      # 14 matches < min_num_inliers
+
+
+def test_watermark_and_option_variants(amc_ctx):
+    rng = np.random.default_rng(9)
+    w, h, n = 1600, 1200, 80
+    x = np.r_[rng.uniform(5, 150, n // 2), rng.uniform(w - 150, w - 5, n // 2)]
+    y = rng.uniform(5, 150, n)
+    p1 = np.c_[x, y].astype(np.float32).astype(np.float64)
+    p2 = (p1 + np.array([3.0, -2.0]) + rng.normal(0, 0.05, size=(n, 2))).astype(np.float32).astype(np.float64)
+    wm = dict(pts1=p1, pts2=p2, matches=np.c_[np.arange(n), np.arange(n)].astype(np.uint32),
+              width=w, height=h, f=1200.0)
+    gen = synth.two_view_scene(rng, num_inliers=200, num_outliers=100)
+    tvg, mask, off, want = run_both(amc_ctx, [wm, gen], [False, False])
+    assert_pair_equal(0, tvg, mask, off, want)
+    assert_pair_equal(1, tvg, mask, off, want)
+    assert _capi.CONFIG_NAMES[tvg["config"][0]] == "WATERMARK"
+    for kw in [dict(detect_watermark=0), dict(force_H_use=1), dict(min_num_inliers=30, max_H_inlier_ratio=0.5),
+               dict(ransac=dict(max_error=2.0, confidence=0.99, min_num_trials=50, max_num_trials=2000))]:
+        tvg, mask, off, want = run_both(amc_ctx, [wm, gen], [True, True], kw)
+        assert_pair_equal(0, tvg, mask, off, want)
+        assert_pair_equal(1, tvg, mask, off, want)
+
+
+def test_seed_changes_the_stream_and_is_reproducible(amc_ctx):
+    rng = np.random.default_rng(3)
+    sc = [synth.two_view_scene(rng, num_inliers=120, num_outliers=120)]
+    a = run_both(amc_ctx, sc, [False], seed=0)
+    b = run_both(amc_ctx, sc, [False], seed=0)
+    c = run_both(amc_ctx, sc, [False], seed=7)
+    assert_pair_equal(0, *a)
+    assert_pair_equal(0, *c)
+    np.testing.assert_array_equal(bits(a[0]["F"][0]), bits(b[0]["F"][0]))
+    assert a[0]["num_trials"][0].tolist() != c[0]["num_trials"][0].tolist() or \
+        not np.array_equal(bits(a[0]["F"][0]), bits(c[0]["F"][0]))
+
+
+def test_invalid_inputs_raise(amc_ctx):
+    rng = np.random.default_rng(4)
+    sc = synth.two_view_scene(rng, num_inliers=30, num_outliers=0)
+    amc_ctx.reserve_slots(2)
+    amc_ctx.upload_keypoints(0, sc["pts1"].astype(np.float32))
+    with pytest.raises(_capi.AmcError) as e:   # slot 1 has no keypoints/camera
+        amc_ctx.verify_pairs([0], [1], [0, len(sc["matches"])], sc["matches"])
+    assert e.value.code == _capi.AMC_E_STATE
+    amc_ctx.upload_keypoints(1, sc["pts2"].astype(np.float32))
+    for s in (0, 1):
+        amc_ctx.upload_camera(s, "PINHOLE", 1600, 1200, (1200, 1200, 800, 600), False)
+    bad = sc["matches"].copy()
+    bad[0, 0] = 10 ** 6
+    with pytest.raises(_capi.AmcError) as e:
+        amc_ctx.verify_pairs([0], [1], [0, len(bad)], bad)
+    assert e.value.code == _capi.AMC_E_INVALID
+    with pytest.raises(_capi.AmcError):
+        amc_ctx.verify_pairs([0], [1], [0, len(bad)], sc["matches"], _capi.tvg_options(multiple_models=1))
+    tvg, mask, _ = amc_ctx.verify_pairs([], [], [0], np.zeros((0, 2), np.uint32))
+    assert len(tvg) == 0 and len(mask) == 0
