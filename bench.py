@@ -88,6 +88,72 @@ def cpu_baseline(arena_cpu: np.ndarray, s1: np.ndarray, s2: np.ndarray, sample_p
     return ndist / dt, len(idx), dt, (idx, off, m)
 
 
+def verify_leg(ctx_factory, device_index: int, npairs: int, steps: int, warmup: int, cpu_sample: int):
+    """BASELINE's second metric: verified image-pairs/s.  Workload (configs[2] style): `npairs`
+    synthetic calibrated two-view scenes (PINHOLE, prior focal length => E, F and H LO-RANSACs +
+    model selection + watermark test all run), ~300 planted inliers + ~100 outliers each, a
+    quarter of the scenes planar.  64 distinct seeded scenes are reused round-robin."""
+    from pycolmap_amd import _capi, synth
+    rng = np.random.default_rng(7)
+    distinct = 64
+    scenes = [synth.two_view_scene(rng, num_inliers=int(rng.integers(150, 450)),
+                                   num_outliers=int(rng.integers(50, 200)), planar=(k % 4 == 3))
+              for k in range(distinct)]
+    ctx = ctx_factory()
+    ctx.reserve_slots(2 * distinct)
+    for k, sc in enumerate(scenes):
+        for j, pts in enumerate((sc["pts1"], sc["pts2"])):
+            ctx.upload_keypoints(2 * k + j, pts.astype(np.float32))
+            ctx.upload_camera(2 * k + j, "PINHOLE", sc["width"], sc["height"],
+                              (sc["f"], sc["f"], sc["width"] / 2.0, sc["height"] / 2.0), True)
+    which = np.arange(npairs) % distinct
+    s1 = (2 * which).astype(np.uint32)
+    s2 = s1 + 1
+    counts = np.array([len(scenes[w]["matches"]) for w in which], dtype=np.uint64)
+    off = np.zeros(npairs + 1, dtype=np.uint64)
+    off[1:] = np.cumsum(counts)
+    matches = np.concatenate([scenes[w]["matches"] for w in which])
+    opts = _capi.tvg_options()
+    for _ in range(warmup):
+        ctx.verify_pairs(s1, s2, off, matches, opts)
+    t0 = time.perf_counter()
+    kms = 0.0
+    for _ in range(steps):
+        tvg, mask, st = ctx.verify_pairs(s1, s2, off, matches, opts)
+        kms += st["kernel_ms"]
+    dt = time.perf_counter() - t0
+    out = {
+        "metric": "verified image-pairs/sec (E+F+H LO-RANSAC, model selection, watermark test)",
+        "value": npairs * steps / dt, "unit": "pairs/s", "pairs": npairs, "steps": steps,
+        "ms_per_step": 1e3 * dt / steps, "kernel_ms_per_step": kms / steps,
+        "mean_matches_per_pair": float(counts.mean()), "dtype": "f64",
+        "configs": {_capi.CONFIG_NAMES[c]: int(n) for c, n in zip(*np.unique(tvg["config"], return_counts=True))},
+        "mean_trials_E_F_H": [float(x) for x in tvg["num_trials"][:, :3].mean(axis=0)],
+    }
+    if cpu_sample > 0:
+        sys.path.insert(0, str(ROOT / "tests"))
+        import oracle_lib as o
+        t0 = time.perf_counter()
+        mism = 0
+        for k in range(min(cpu_sample, distinct)):
+            sc = scenes[k]
+            cam = o.make_camera("PINHOLE", sc["width"], sc["height"],
+                                (sc["f"], sc["f"], sc["width"] / 2.0, sc["height"] / 2.0), prior=True)
+            w = o.estimate_two_view_geometry(cam, sc["pts1"], cam, sc["pts2"], sc["matches"])
+            g = tvg[k]
+            m = mask[int(off[k]):int(off[k + 1])]
+            if (g["config"] != w["config"] or not np.array_equal(m, w["inlier_mask"]) or
+                    not np.array_equal(g["F"].view(np.uint64), w["F"].view(np.uint64))):
+                mism += 1
+        cdt = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": min(cpu_sample, distinct) / cdt, "unit": "pairs/s", "cores": 1,
+                               "kind": "port", "sample": f"{min(cpu_sample, distinct)} of the same scenes, "
+                               f"oracle/tvg_oracle.cc single thread, {cdt:.1f} s",
+                               "gpu_vs_oracle_mismatching_pairs": mism}
+    ctx.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -98,6 +164,8 @@ def main():
     ap.add_argument("--kernel", default="auto", choices=["auto", "mfma", "dot4"])
     ap.add_argument("--cpu-sample-pairs", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--verify-pairs", type=int, default=4096,
+                    help="pairs in the verification leg (0 = skip); reported under \"verify\"")
     ap.add_argument("--no-cross-check", action="store_true",
                     help="diagnostic: one-way matching only (NOT the BASELINE workload)")
     args = ap.parse_args()
@@ -246,6 +314,10 @@ def main():
                           f"oracle/match_oracle.c (-O2, OpenMP, one pair per thread), {dt:.1f} s",
                 "gpu_vs_oracle_mismatching_pairs": mism,
             }
+        if args.verify_pairs > 0 and world == 1:
+            out["verify"] = verify_leg(lambda: _capi.Context(local_rank), local_rank, args.verify_pairs,
+                                       max(1, args.steps), min(1, args.warmup),
+                                       0 if args.no_cpu_baseline else 16)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

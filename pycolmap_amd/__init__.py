@@ -1,0 +1,29 @@
+"""pycolmap_amd — MI355X-native exhaustive/sequential SIFT matching + two-view verification behind
+the pycolmap API.
+
+    import pycolmap_amd as pycolmap
+    pycolmap.match_exhaustive(database_path)        # same signature as the reference
+    pycolmap.verify_matches(database_path, pairs_path)
+
+The compiled host layer (`_pycolmap`, C++/pybind11) drives `libamc.so` (HIP kernels behind a C ABI,
+include/amc.h).  There is no CPU fallback: importing works anywhere, computing needs a gfx950 GPU.
+"""
+from __future__ import annotations
+
+__version__ = "0.1.0"
+
+try:  # the compiled host layer; absent only before `python -m pycolmap_amd.build`
+    from ._pycolmap import (  # noqa: F401
+        COLMAP_version, Database, Device, ExhaustiveMatchingOptions, RANSACOptions,
+        SequentialMatchingOptions, SiftMatchingOptions, TwoViewGeometry, TwoViewGeometryConfiguration,
+        TwoViewGeometryOptions, has_cuda, has_hip, last_run_stats, match_exhaustive, match_sequential,
+        match_spatial, match_vocabtree, verify_matches,
+    )
+    _HOST_LAYER_ERROR = None
+except ImportError as _e:  # pragma: no cover - exercised only on an unbuilt tree
+    _HOST_LAYER_ERROR = _e
+
+    def __getattr__(name):
+        raise ImportError(
+            f"pycolmap_amd.{name}: the compiled host layer is missing ({_HOST_LAYER_ERROR}); run "
+            "`python -m pycolmap_amd.build` (needs hipcc + g++). pycolmap_amd has no Python/CPU fallback.")

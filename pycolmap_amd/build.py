@@ -69,6 +69,35 @@ def build_libamc(force: bool = False, verbose: bool = True) -> Path:
     return LIB
 
 
+HOST_SOURCES = ["module.cc", "controller.cc", "database.cc"]
+
+
+def build_host(force: bool = False, verbose: bool = True) -> Path:
+    """The C++/pybind11 host layer (pycolmap API surface) -> pycolmap_amd/_pycolmap*.so, linked
+    against libamc.so (C ABI) and the system SQLite."""
+    import sysconfig
+
+    import pybind11
+    host = CSRC / "host"
+    ext = sysconfig.get_config_var("EXT_SUFFIX") or ".so"
+    out = PKG / f"_pycolmap{ext}"
+    srcs = [host / n for n in HOST_SOURCES]
+    deps = srcs + list(host.glob("*.h")) + list((ROOT / "include").glob("*.h")) + [LIB]
+    if not force and not _stale(out, deps):
+        return out
+    sqlite_inc = next((p for p in ("/usr/include", "/opt/conda/include") if (Path(p) / "sqlite3.h").exists()), None)
+    if sqlite_inc is None:
+        raise RuntimeError("sqlite3.h not found")
+    cmd = ["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-fvisibility=hidden", "-Wall",
+           f"-I{pybind11.get_include()}", f"-I{sysconfig.get_paths()['include']}", f"-I{sqlite_inc}",
+           *map(str, srcs), f"-L{PKG}", "-l:libamc.so", "-l:libsqlite3.so.0", "-Wl,-rpath,$ORIGIN",
+           "-o", str(out)]
+    if verbose:
+        print("[build]", " ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    return out
+
+
 def build_oracle(verbose: bool = True) -> Path:
     """Compile the CPU oracle (test infrastructure; building the checker is not using it)."""
     out = subprocess.run(["make", "-C", str(ROOT / "oracle")], capture_output=not verbose, check=True)
@@ -78,6 +107,7 @@ def build_oracle(verbose: bool = True) -> Path:
 
 def build_all(force: bool = False, verbose: bool = True) -> None:
     build_libamc(force=force, verbose=verbose)
+    build_host(force=force, verbose=verbose)
     build_oracle(verbose=verbose)
 
 

@@ -1,0 +1,299 @@
+#include "controller.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+#include <unordered_map>
+#include <unordered_set>
+
+namespace amchost {
+
+namespace {
+void Check(int rc, const char* what) {
+    if (rc != AMC_OK) throw AmcFailure(rc, std::string(what) + ": " + amc_last_error());
+}
+double NowMs() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+}  // namespace
+
+amc_tvg_opts ToAmc(const TwoViewGeometryOptions& o) {
+    amc_tvg_opts t;
+    amc_tvg_opts_default(&t);
+    t.min_num_inliers = o.min_num_inliers;
+    t.min_E_F_inlier_ratio = o.min_E_F_inlier_ratio;
+    t.max_H_inlier_ratio = o.max_H_inlier_ratio;
+    t.watermark_min_inlier_ratio = o.watermark_min_inlier_ratio;
+    t.watermark_border_size = o.watermark_border_size;
+    t.detect_watermark = o.detect_watermark;
+    t.multiple_ignore_watermark = o.multiple_ignore_watermark;
+    t.force_H_use = o.force_H_use;
+    t.compute_relative_pose = o.compute_relative_pose;
+    t.multiple_models = o.multiple_models;
+    t.ransac.max_error = o.ransac_options.max_error;
+    t.ransac.min_inlier_ratio = o.ransac_options.min_inlier_ratio;
+    t.ransac.confidence = o.ransac_options.confidence;
+    t.ransac.dyn_num_trials_multiplier = o.ransac_options.dyn_num_trials_multiplier;
+    t.ransac.min_num_trials = static_cast<int64_t>(o.ransac_options.min_num_trials);
+    t.ransac.max_num_trials = static_cast<int64_t>(std::min<size_t>(o.ransac_options.max_num_trials, size_t(1) << 30));
+    return t;
+}
+
+MatchController::MatchController(const std::string& database_path, const SiftMatchingOptions& sift,
+                                 const TwoViewGeometryOptions& tvg, int device_id)
+    : path_(database_path), sift_(sift), tvg_(tvg), device_id_(device_id) {}
+
+MatchController::~MatchController() {
+    if (ctx_) amc_ctx_destroy(ctx_);
+}
+
+uint32_t MatchController::SlotOf(image_t id) const {
+    if (id >= slot_of_image_.size() || slot_of_image_[id] == 0xFFFFFFFFu)
+        throw std::invalid_argument("unknown image_id " + std::to_string(id));
+    return slot_of_image_[id];
+}
+
+// FeatureMatcherCache::Setup + the GPU matcher's descriptor upload.  The LRU cache over SQLite is
+// replaced by a device-resident arena holding every image.
+void MatchController::Setup() {
+    db_ = std::make_unique<Database>(path_);
+    images_ = db_->ReadAllImages();
+    const std::vector<CameraRow> cams = db_->ReadAllCameras();
+    std::unordered_map<camera_t, const CameraRow*> cam_by_id;
+    for (const auto& c : cams) cam_by_id[c.camera_id] = &c;
+    Check(amc_ctx_create(device_id_, &ctx_), "amc_ctx_create");
+    Check(amc_ctx_reserve_slots(ctx_, static_cast<uint32_t>(images_.size())), "amc_ctx_reserve_slots");
+    image_t max_id = 0;
+    for (const auto& im : images_) max_id = std::max(max_id, im.image_id);
+    slot_of_image_.assign(static_cast<size_t>(max_id) + 1, 0xFFFFFFFFu);
+    for (uint32_t s = 0; s < images_.size(); ++s) {
+        const ImageRow& im = images_[s];
+        slot_of_image_[im.image_id] = s;
+        uint32_t drows = 0, krows = 0;
+        const std::vector<uint8_t> desc = db_->ReadDescriptors(im.image_id, &drows);
+        const std::vector<float> kp = db_->ReadKeypointsXY(im.image_id, &krows);
+        // COLMAP's GPU matcher clamps to the first max_num_matches features
+        // (WarnIfMaxNumMatchesReachedGPU; SiftMatchingOptions.max_num_matches)
+        const uint32_t use = std::min<uint32_t>(drows, static_cast<uint32_t>(std::max(sift_.max_num_matches, 0)));
+        Check(amc_upload_descriptors(ctx_, s, desc.data(), use), "amc_upload_descriptors");
+        Check(amc_upload_keypoints(ctx_, s, kp.data(), krows, 2), "amc_upload_keypoints");
+        auto it = cam_by_id.find(im.camera_id);
+        if (it == cam_by_id.end()) throw std::runtime_error("image " + im.name + " references a missing camera");
+        const CameraRow& c = *it->second;
+        Check(amc_upload_camera(ctx_, s, c.model_id, c.width, c.height, c.params.data(),
+                                static_cast<int32_t>(c.params.size()), c.has_prior_focal_length),
+              "amc_upload_camera");
+    }
+}
+
+// FeatureMatcherController::Match (colmap/controllers/feature_matching_utils.cc), batched
+void MatchController::Match(const ImagePairs& image_pairs) {
+    if (image_pairs.empty()) return;
+    struct Job {
+        image_t id1, id2;
+        bool have_matches;
+        std::vector<uint32_t> matches;
+        TwoViewGeometryRow tvg;
+    };
+    std::vector<Job> jobs;
+    std::unordered_set<image_pair_t> seen;
+    seen.reserve(image_pairs.size());
+    const double t_db0 = NowMs();
+    for (const auto& pr : image_pairs) {
+        if (pr.first == pr.second) continue;  // avoid self-matches
+        const image_pair_t pid = Database::ImagePairToPairId(pr.first, pr.second);
+        if (!seen.insert(pid).second) continue;  // avoid duplicate image pairs
+        const bool exists_matches = db_->ExistsMatches(pr.first, pr.second);
+        const bool exists_inlier = db_->ExistsInlierMatches(pr.first, pr.second);
+        if (exists_matches && exists_inlier) { ++stats.pairs_skipped; continue; }  // resume
+        // one of the two rows missing: recompute from scratch, delete what exists first
+        if (exists_inlier) db_->DeleteInlierMatches(pr.first, pr.second);
+        Job j;
+        j.id1 = pr.first;
+        j.id2 = pr.second;
+        j.have_matches = exists_matches;
+        if (exists_matches) {
+            j.matches = db_->ReadMatches(pr.first, pr.second);
+            db_->DeleteMatches(pr.first, pr.second);
+        }
+        jobs.push_back(std::move(j));
+    }
+    stats.db_ms += NowMs() - t_db0;
+    if (jobs.empty()) return;
+
+    // ---- FeatureMatcherWorker: descriptor matching for the pairs without stored matches ----
+    std::vector<uint32_t> s1, s2;
+    std::vector<size_t> which;
+    for (size_t k = 0; k < jobs.size(); ++k)
+        if (!jobs[k].have_matches) {
+            s1.push_back(SlotOf(jobs[k].id1));
+            s2.push_back(SlotOf(jobs[k].id2));
+            which.push_back(k);
+        }
+    if (!which.empty()) {
+        amc_match_opts mo;
+        amc_match_opts_default(&mo);
+        mo.max_ratio = sift_.max_ratio;
+        mo.max_distance = sift_.max_distance;
+        mo.cross_check = sift_.cross_check;
+        amc_match_result r;
+        Check(amc_match_pairs(ctx_, s1.data(), s2.data(), which.size(), &mo, &r), "amc_match_pairs");
+        for (size_t p = 0; p < which.size(); ++p) {
+            Job& j = jobs[which[p]];
+            j.matches.assign(r.matches + 2 * r.offsets[p], r.matches + 2 * r.offsets[p + 1]);
+        }
+        stats.match_device_ms += r.device_ms;
+        stats.num_distances += r.num_distances;
+        stats.pairs_matched += which.size();
+        amc_match_result_free(&r);
+    }
+
+    // ---- VerifierWorker: only pairs with >= min_num_inliers matches are estimated ----------
+    const size_t min_inl = static_cast<size_t>(std::max(tvg_.min_num_inliers, 0));
+    std::vector<uint32_t> v1, v2, vmatches;
+    std::vector<uint64_t> voff{0};
+    std::vector<size_t> vwhich;
+    for (size_t k = 0; k < jobs.size(); ++k) {
+        const size_t m = jobs[k].matches.size() / 2;
+        if (m >= min_inl) {
+            v1.push_back(SlotOf(jobs[k].id1));
+            v2.push_back(SlotOf(jobs[k].id2));
+            vmatches.insert(vmatches.end(), jobs[k].matches.begin(), jobs[k].matches.end());
+            voff.push_back(voff.back() + m);
+            vwhich.push_back(k);
+        }
+    }
+    if (!vwhich.empty()) {
+        const amc_tvg_opts to = ToAmc(tvg_);
+        amc_verify_result vr;
+        Check(amc_verify_pairs(ctx_, v1.data(), v2.data(), vwhich.size(), voff.data(), vmatches.data(), &to,
+                               /*seed=*/0, &vr),
+              "amc_verify_pairs");
+        for (size_t p = 0; p < vwhich.size(); ++p) {
+            Job& j = jobs[vwhich[p]];
+            const amc_tvg& g = vr.tvg[p];
+            j.tvg.config = g.config;
+            std::memcpy(j.tvg.E.data(), g.E, sizeof g.E);
+            std::memcpy(j.tvg.F.data(), g.F, sizeof g.F);
+            std::memcpy(j.tvg.H.data(), g.H, sizeof g.H);
+            const uint8_t* mask = vr.inlier_mask + voff[p];
+            const size_t m = j.matches.size() / 2;
+            for (size_t i = 0; i < m; ++i)  // ExtractInlierMatches
+                if (mask[i]) {
+                    j.tvg.inlier_matches.push_back(j.matches[2 * i]);
+                    j.tvg.inlier_matches.push_back(j.matches[2 * i + 1]);
+                }
+        }
+        stats.verify_device_ms += vr.device_ms;
+        stats.pairs_verified += vwhich.size();
+        amc_verify_result_free(&vr);
+    }
+
+    // ---- controller thread: drop results below min_num_inliers, write both tables ----------
+    const double t_db1 = NowMs();
+    for (Job& j : jobs) {
+        if (j.matches.size() / 2 < min_inl) j.matches.clear();
+        if (j.tvg.inlier_matches.size() / 2 < min_inl) j.tvg = TwoViewGeometryRow();
+        db_->WriteMatches(j.id1, j.id2, j.matches);
+        db_->WriteTwoViewGeometry(j.id1, j.id2, j.tvg);
+    }
+    stats.db_ms += NowMs() - t_db1;
+}
+
+// ExhaustiveFeatureMatcher::Run: block pairs, one transaction + Match() each
+std::vector<ImagePairs> ExhaustiveBlocks(const std::vector<image_t>& ids, int block_size) {
+    if (block_size <= 1) throw std::invalid_argument("block_size must be > 1");
+    const size_t B = static_cast<size_t>(block_size);
+    const size_t num_blocks = (ids.size() + B - 1) / B;
+    std::vector<ImagePairs> out;
+    for (size_t sb1 = 0; sb1 < num_blocks; ++sb1) {
+        const size_t s1 = sb1 * B, e1 = std::min(ids.size(), s1 + B);
+        for (size_t sb2 = 0; sb2 < num_blocks; ++sb2) {
+            const size_t s2 = sb2 * B, e2 = std::min(ids.size(), s2 + B);
+            ImagePairs pairs;
+            for (size_t i1 = s1; i1 < e1; ++i1)
+                for (size_t i2 = s2; i2 < e2; ++i2) {
+                    const size_t b1 = i1 % B, b2 = i2 % B;
+                    if ((i1 > i2 && b1 <= b2) || (i1 < i2 && b1 < b2)) pairs.emplace_back(ids[i1], ids[i2]);
+                }
+            out.push_back(std::move(pairs));
+        }
+    }
+    return out;
+}
+void RunExhaustive(MatchController& c, const ExhaustiveMatchingOptions& o) {
+    std::vector<image_t> ids;
+    for (const auto& im : c.Images()) ids.push_back(im.image_id);
+    for (const ImagePairs& pairs : ExhaustiveBlocks(ids, o.block_size)) {
+        if (c.StopRequested()) break;
+        DatabaseTransaction tx(&c.Db());
+        c.Match(pairs);
+    }
+}
+
+// SequentialFeatureMatcher::Run without loop detection (needs a FLANN vocabulary tree file:
+// SURVEY.md 8f rank 1)
+std::vector<ImagePairs> SequentialBlocks(const std::vector<image_t>& ids, int overlap, bool quadratic_overlap) {
+    if (overlap <= 0) throw std::invalid_argument("overlap must be > 0");
+    std::vector<ImagePairs> out;
+    for (size_t i1 = 0; i1 < ids.size(); ++i1) {
+        ImagePairs pairs;
+        for (int i = 0; i < overlap; ++i) {
+            const size_t i2 = i1 + static_cast<size_t>(i);
+            if (i2 >= ids.size()) break;
+            pairs.emplace_back(ids[i1], ids[i2]);
+            if (quadratic_overlap && i < 31) {
+                const size_t i2q = i1 + (size_t(1) << i);
+                if (i2q < ids.size()) pairs.emplace_back(ids[i1], ids[i2q]);
+            }
+        }
+        out.push_back(std::move(pairs));
+    }
+    return out;
+}
+void RunSequential(MatchController& c, const SequentialMatchingOptions& o) {
+    if (o.loop_detection)
+        throw std::invalid_argument("loop_detection needs a vocabulary tree (FLANN) and is not implemented");
+    std::vector<ImageRow> ordered = c.Images();  // GetOrderedImageIds: by name
+    std::sort(ordered.begin(), ordered.end(), [](const ImageRow& a, const ImageRow& b) { return a.name < b.name; });
+    std::vector<image_t> ids;
+    for (const auto& im : ordered) ids.push_back(im.image_id);
+    for (const ImagePairs& pairs : SequentialBlocks(ids, o.overlap, o.quadratic_overlap)) {
+        if (c.StopRequested()) break;
+        DatabaseTransaction tx(&c.Db());
+        c.Match(pairs);
+    }
+}
+
+// ImagePairsFeatureMatcher::Run: "name1 name2" lines, blank lines and '#' comments skipped
+void RunImagePairs(MatchController& c, const std::string& pairs_path, int block_size) {
+    std::unordered_map<std::string, image_t> by_name;
+    for (const auto& im : c.Images()) by_name[im.name] = im.image_id;
+    std::ifstream f(pairs_path);
+    if (!f) throw std::invalid_argument("cannot read " + pairs_path);
+    ImagePairs all;
+    std::unordered_set<image_pair_t> seen;
+    std::string line;
+    while (std::getline(f, line)) {
+        const size_t a = line.find_first_not_of(" \t\r\n");
+        if (a == std::string::npos || line[a] == '#') continue;
+        std::istringstream ss(line);
+        std::string n1, n2;
+        ss >> n1 >> n2;
+        auto i1 = by_name.find(n1), i2 = by_name.find(n2);
+        if (i1 == by_name.end() || i2 == by_name.end()) continue;  // COLMAP logs an error and skips
+        const image_pair_t pid = Database::ImagePairToPairId(i1->second, i2->second);
+        if (!seen.insert(pid).second) continue;
+        all.emplace_back(i1->second, i2->second);
+    }
+    const size_t B = static_cast<size_t>(std::max(block_size, 1));
+    for (size_t s = 0; s < all.size() && !c.StopRequested(); s += B) {
+        ImagePairs block(all.begin() + s, all.begin() + std::min(all.size(), s + B));
+        DatabaseTransaction tx(&c.Db());
+        c.Match(block);
+    }
+}
+
+}  // namespace amchost

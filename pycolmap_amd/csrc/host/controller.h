@@ -1,0 +1,117 @@
+// controller.h — host scheduler of the match + verify path: what COLMAP's
+// ExhaustiveFeatureMatcher / SequentialFeatureMatcher / ImagePairsFeatureMatcher +
+// FeatureMatcherController + workers do, driving libamc.so.
+#pragma once
+
+#include <atomic>
+#include <functional>
+#include <memory>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../../include/amc.h"
+#include "database.h"
+
+namespace amchost {
+
+// option structs: field names and defaults of the pycolmap-visible classes
+// (/root/reference/pycolmap/pipeline/match_features.h:73-152,
+//  /root/reference/pycolmap/estimators/two_view_geometry.h:41-63)
+struct SiftMatchingOptions {
+    int num_threads = -1;
+    std::string gpu_index = "-1";
+    double max_ratio = 0.8;
+    double max_distance = 0.7;
+    bool cross_check = true;
+    int max_num_matches = 32768;
+    bool guided_matching = false;
+};
+struct ExhaustiveMatchingOptions {
+    int block_size = 50;
+};
+struct SequentialMatchingOptions {
+    int overlap = 10;
+    bool quadratic_overlap = true;
+    bool loop_detection = false;
+    int loop_detection_num_images = 50;
+    int loop_detection_num_nearest_neighbors = 1;
+    int loop_detection_num_checks = 256;
+    int loop_detection_num_images_after_verification = 0;
+    int loop_detection_max_num_features = -1;
+    std::string vocab_tree_path = "";
+};
+struct RANSACOptions {  // C++ defaults of TwoViewGeometryOptions::ransac_options
+    double max_error = 4.0;
+    double min_inlier_ratio = 0.25;
+    double confidence = 0.999;
+    double dyn_num_trials_multiplier = 3.0;
+    size_t min_num_trials = 100;
+    size_t max_num_trials = 10000;
+};
+struct TwoViewGeometryOptions {
+    int min_num_inliers = 15;
+    double min_E_F_inlier_ratio = 0.95;
+    double max_H_inlier_ratio = 0.8;
+    double watermark_min_inlier_ratio = 0.7;
+    double watermark_border_size = 0.1;
+    bool detect_watermark = true;
+    bool multiple_ignore_watermark = true;
+    bool force_H_use = false;
+    bool compute_relative_pose = false;
+    bool multiple_models = false;
+    RANSACOptions ransac_options;
+};
+amc_tvg_opts ToAmc(const TwoViewGeometryOptions& o);
+
+using ImagePairs = std::vector<std::pair<image_t, image_t>>;
+
+// exception carrying an amc status, so the bindings can map AMC_E_INVALID to ValueError
+struct AmcFailure : std::runtime_error {
+    int code;
+    AmcFailure(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+struct MatchStats {
+    size_t pairs_matched = 0, pairs_verified = 0, pairs_skipped = 0;
+    double match_device_ms = 0, verify_device_ms = 0, db_ms = 0;
+    uint64_t num_distances = 0;
+};
+
+class MatchController {
+  public:
+    MatchController(const std::string& database_path, const SiftMatchingOptions& sift,
+                    const TwoViewGeometryOptions& tvg, int device_id);
+    ~MatchController();
+    void Setup();  // read cameras/images/keypoints/descriptors, fill the GPU arena
+    // FeatureMatcherController::Match: filter, match, verify, write
+    void Match(const ImagePairs& pairs);
+    const std::vector<ImageRow>& Images() const { return images_; }
+    Database& Db() { return *db_; }
+    void RequestStop() { stop_.store(true); }
+    bool StopRequested() const { return stop_.load(); }
+    MatchStats stats;
+
+  private:
+    std::string path_;
+    SiftMatchingOptions sift_;
+    TwoViewGeometryOptions tvg_;
+    int device_id_;
+    std::unique_ptr<Database> db_;
+    std::vector<ImageRow> images_;
+    std::vector<uint32_t> slot_of_image_;  // image_id -> slot (dense table)
+    amc_ctx* ctx_ = nullptr;
+    std::atomic<bool> stop_{false};
+    uint32_t SlotOf(image_t id) const;
+};
+
+// pair generators as pure functions: one entry per Match() call / DB transaction
+std::vector<ImagePairs> ExhaustiveBlocks(const std::vector<image_t>& ids, int block_size);
+std::vector<ImagePairs> SequentialBlocks(const std::vector<image_t>& ordered_ids, int overlap,
+                                         bool quadratic_overlap);
+
+void RunExhaustive(MatchController& c, const ExhaustiveMatchingOptions& o);
+void RunSequential(MatchController& c, const SequentialMatchingOptions& o);
+void RunImagePairs(MatchController& c, const std::string& pairs_path, int block_size = 1225);
+
+}  // namespace amchost

@@ -1,0 +1,261 @@
+#include "database.h"
+
+#include <sqlite3.h>
+
+#include <cmath>
+#include <cstring>
+
+namespace amchost {
+
+namespace {
+[[noreturn]] void Fail(sqlite3* db, const std::string& what) {
+    throw std::runtime_error("SQLite error (" + what + "): " + (db ? sqlite3_errmsg(db) : "no db"));
+}
+struct Stmt {
+    sqlite3_stmt* s = nullptr;
+    sqlite3* db;
+    Stmt(sqlite3* d, const char* sql) : db(d) {
+        if (sqlite3_prepare_v2(d, sql, -1, &s, nullptr) != SQLITE_OK) Fail(d, sql);
+    }
+    ~Stmt() { sqlite3_finalize(s); }
+    bool Step() {
+        const int rc = sqlite3_step(s);
+        if (rc == SQLITE_ROW) return true;
+        if (rc == SQLITE_DONE) return false;
+        Fail(db, "step");
+    }
+};
+}  // namespace
+
+// TwoViewGeometry::Invert (colmap/scene/two_view_geometry.cc): F <- F^T, E <- E^T, H <- H^-1,
+// swap the match columns.  (Relative pose is not computed on this path; identity stays identity.)
+void TwoViewGeometryRow::Invert() {
+    auto transpose = [](std::array<double, 9>& m) {
+        std::swap(m[1], m[3]);
+        std::swap(m[2], m[6]);
+        std::swap(m[5], m[7]);
+    };
+    transpose(F);
+    transpose(E);
+    const std::array<double, 9> h = H;
+    const double c00 = h[4] * h[8] - h[5] * h[7], c01 = h[5] * h[6] - h[3] * h[8], c02 = h[3] * h[7] - h[4] * h[6];
+    const double det = h[0] * c00 + h[1] * c01 + h[2] * c02;
+    if (det != 0.0 && std::isfinite(det)) {
+        const double inv = 1.0 / det;
+        H[0] = c00 * inv; H[1] = (h[2] * h[7] - h[1] * h[8]) * inv; H[2] = (h[1] * h[5] - h[2] * h[4]) * inv;
+        H[3] = c01 * inv; H[4] = (h[0] * h[8] - h[2] * h[6]) * inv; H[5] = (h[2] * h[3] - h[0] * h[5]) * inv;
+        H[6] = c02 * inv; H[7] = (h[1] * h[6] - h[0] * h[7]) * inv; H[8] = (h[0] * h[4] - h[1] * h[3]) * inv;
+    }
+    for (size_t i = 0; i + 1 < inlier_matches.size(); i += 2) std::swap(inlier_matches[i], inlier_matches[i + 1]);
+}
+
+Database::Database(const std::string& path) {
+    if (sqlite3_open_v2(path.c_str(), &db_, SQLITE_OPEN_READWRITE, nullptr) != SQLITE_OK) {
+        const std::string msg = db_ ? sqlite3_errmsg(db_) : "out of memory";
+        sqlite3_close(db_);
+        db_ = nullptr;
+        throw std::runtime_error("cannot open database " + path + ": " + msg);
+    }
+    Exec("PRAGMA synchronous=OFF");       // as COLMAP's Database::Open
+    Exec("PRAGMA journal_mode=WAL");
+    Exec("PRAGMA foreign_keys=ON");
+}
+Database::~Database() {
+    if (db_) sqlite3_close(db_);
+}
+void Database::Exec(const char* sql) const {
+    char* err = nullptr;
+    if (sqlite3_exec(db_, sql, nullptr, nullptr, &err) != SQLITE_OK) {
+        const std::string msg = err ? err : "?";
+        sqlite3_free(err);
+        throw std::runtime_error(std::string("SQLite exec failed: ") + sql + ": " + msg);
+    }
+}
+void Database::BeginTransaction() { Exec("BEGIN TRANSACTION"); }
+void Database::EndTransaction() { Exec("END TRANSACTION"); }
+
+image_pair_t Database::ImagePairToPairId(image_t id1, image_t id2) {
+    if (id1 >= kMaxNumImages || id2 >= kMaxNumImages) throw std::invalid_argument("image_id out of range");
+    if (SwapImagePair(id1, id2)) return kMaxNumImages * id2 + id1;
+    return kMaxNumImages * id1 + id2;
+}
+void Database::PairIdToImagePair(image_pair_t pair_id, image_t* id1, image_t* id2) {
+    *id2 = static_cast<image_t>(pair_id % kMaxNumImages);
+    *id1 = static_cast<image_t>((pair_id - *id2) / kMaxNumImages);
+}
+
+size_t Database::Count(const char* table) const {
+    Stmt st(db_, (std::string("SELECT COUNT(*) FROM ") + table).c_str());
+    st.Step();
+    return static_cast<size_t>(sqlite3_column_int64(st.s, 0));
+}
+size_t Database::SumRows(const char* table) const {
+    Stmt st(db_, (std::string("SELECT SUM(rows) FROM ") + table).c_str());
+    st.Step();
+    return static_cast<size_t>(sqlite3_column_int64(st.s, 0));
+}
+
+std::vector<CameraRow> Database::ReadAllCameras() const {
+    std::vector<CameraRow> out;
+    Stmt st(db_, "SELECT camera_id, model, width, height, params, prior_focal_length FROM cameras ORDER BY camera_id");
+    while (st.Step()) {
+        CameraRow c;
+        c.camera_id = static_cast<camera_t>(sqlite3_column_int64(st.s, 0));
+        c.model_id = sqlite3_column_int(st.s, 1);
+        c.width = static_cast<uint64_t>(sqlite3_column_int64(st.s, 2));
+        c.height = static_cast<uint64_t>(sqlite3_column_int64(st.s, 3));
+        const int nbytes = sqlite3_column_bytes(st.s, 4);
+        c.params.resize(nbytes / sizeof(double));
+        if (nbytes) std::memcpy(c.params.data(), sqlite3_column_blob(st.s, 4), c.params.size() * sizeof(double));
+        c.has_prior_focal_length = sqlite3_column_int(st.s, 5) != 0;
+        out.push_back(std::move(c));
+    }
+    return out;
+}
+std::vector<ImageRow> Database::ReadAllImages() const {
+    std::vector<ImageRow> out;
+    Stmt st(db_, "SELECT image_id, name, camera_id FROM images ORDER BY image_id");
+    while (st.Step()) {
+        ImageRow r;
+        r.image_id = static_cast<image_t>(sqlite3_column_int64(st.s, 0));
+        r.name = reinterpret_cast<const char*>(sqlite3_column_text(st.s, 1));
+        r.camera_id = static_cast<camera_t>(sqlite3_column_int64(st.s, 2));
+        out.push_back(std::move(r));
+    }
+    return out;
+}
+std::vector<float> Database::ReadKeypointsXY(image_t image_id, uint32_t* rows) const {
+    *rows = 0;
+    Stmt st(db_, "SELECT rows, cols, data FROM keypoints WHERE image_id = ?");
+    sqlite3_bind_int64(st.s, 1, image_id);
+    std::vector<float> out;
+    if (!st.Step()) return out;
+    const uint32_t r = static_cast<uint32_t>(sqlite3_column_int64(st.s, 0));
+    const uint32_t c = static_cast<uint32_t>(sqlite3_column_int64(st.s, 1));
+    const int nbytes = sqlite3_column_bytes(st.s, 2);
+    if (r == 0) return out;
+    if (c < 2 || static_cast<size_t>(nbytes) != static_cast<size_t>(r) * c * sizeof(float))
+        throw std::runtime_error("keypoints blob of image " + std::to_string(image_id) + " has inconsistent shape");
+    const float* src = static_cast<const float*>(sqlite3_column_blob(st.s, 2));
+    out.resize(static_cast<size_t>(r) * 2);
+    for (uint32_t i = 0; i < r; ++i) {
+        out[2 * i] = src[static_cast<size_t>(i) * c];
+        out[2 * i + 1] = src[static_cast<size_t>(i) * c + 1];
+    }
+    *rows = r;
+    return out;
+}
+std::vector<uint8_t> Database::ReadDescriptors(image_t image_id, uint32_t* rows) const {
+    *rows = 0;
+    Stmt st(db_, "SELECT rows, cols, data FROM descriptors WHERE image_id = ?");
+    sqlite3_bind_int64(st.s, 1, image_id);
+    std::vector<uint8_t> out;
+    if (!st.Step()) return out;
+    const uint32_t r = static_cast<uint32_t>(sqlite3_column_int64(st.s, 0));
+    const uint32_t c = static_cast<uint32_t>(sqlite3_column_int64(st.s, 1));
+    const int nbytes = sqlite3_column_bytes(st.s, 2);
+    if (r == 0) return out;
+    if (c != 128 || static_cast<size_t>(nbytes) != static_cast<size_t>(r) * 128)
+        throw std::runtime_error("descriptors blob of image " + std::to_string(image_id) + " is not rows x 128 uint8");
+    out.resize(static_cast<size_t>(nbytes));
+    std::memcpy(out.data(), sqlite3_column_blob(st.s, 2), out.size());
+    *rows = r;
+    return out;
+}
+
+bool Database::ExistsPair(const char* table, image_pair_t pair_id) const {
+    Stmt st(db_, (std::string("SELECT 1 FROM ") + table + " WHERE pair_id = ?").c_str());
+    sqlite3_bind_int64(st.s, 1, static_cast<sqlite3_int64>(pair_id));
+    return st.Step();
+}
+bool Database::ExistsMatches(image_t id1, image_t id2) const { return ExistsPair("matches", ImagePairToPairId(id1, id2)); }
+bool Database::ExistsInlierMatches(image_t id1, image_t id2) const {
+    return ExistsPair("two_view_geometries", ImagePairToPairId(id1, id2));
+}
+
+static std::vector<uint32_t> BlobToMatches(sqlite3_stmt* s, int col_rows, int col_data, bool swap) {
+    const uint32_t rows = static_cast<uint32_t>(sqlite3_column_int64(s, col_rows));
+    std::vector<uint32_t> m(static_cast<size_t>(rows) * 2);
+    if (rows) {
+        if (static_cast<size_t>(sqlite3_column_bytes(s, col_data)) != m.size() * sizeof(uint32_t))
+            throw std::runtime_error("matches blob has inconsistent shape");
+        std::memcpy(m.data(), sqlite3_column_blob(s, col_data), m.size() * sizeof(uint32_t));
+        if (swap)
+            for (size_t i = 0; i + 1 < m.size(); i += 2) std::swap(m[i], m[i + 1]);
+    }
+    return m;
+}
+std::vector<uint32_t> Database::ReadMatches(image_t id1, image_t id2) const {
+    Stmt st(db_, "SELECT rows, cols, data FROM matches WHERE pair_id = ?");
+    sqlite3_bind_int64(st.s, 1, static_cast<sqlite3_int64>(ImagePairToPairId(id1, id2)));
+    if (!st.Step()) return {};
+    return BlobToMatches(st.s, 0, 2, SwapImagePair(id1, id2));
+}
+TwoViewGeometryRow Database::ReadTwoViewGeometry(image_t id1, image_t id2) const {
+    TwoViewGeometryRow t;
+    Stmt st(db_, "SELECT rows, cols, data, config, F, E, H, qvec, tvec FROM two_view_geometries WHERE pair_id = ?");
+    sqlite3_bind_int64(st.s, 1, static_cast<sqlite3_int64>(ImagePairToPairId(id1, id2)));
+    if (!st.Step()) return t;
+    t.inlier_matches = BlobToMatches(st.s, 0, 2, false);
+    t.config = sqlite3_column_int(st.s, 3);
+    auto rd = [&](int col, double* dst, int n) {
+        if (sqlite3_column_bytes(st.s, col) == static_cast<int>(n * sizeof(double)))
+            std::memcpy(dst, sqlite3_column_blob(st.s, col), n * sizeof(double));
+    };
+    rd(4, t.F.data(), 9);
+    rd(5, t.E.data(), 9);
+    rd(6, t.H.data(), 9);
+    rd(7, t.qvec.data(), 4);
+    rd(8, t.tvec.data(), 3);
+    if (SwapImagePair(id1, id2)) t.Invert();
+    return t;
+}
+
+void Database::WriteMatches(image_t id1, image_t id2, const std::vector<uint32_t>& matches) {
+    std::vector<uint32_t> m = matches;
+    if (SwapImagePair(id1, id2))
+        for (size_t i = 0; i + 1 < m.size(); i += 2) std::swap(m[i], m[i + 1]);
+    Stmt st(db_, "INSERT INTO matches(pair_id, rows, cols, data) VALUES(?, ?, ?, ?)");
+    sqlite3_bind_int64(st.s, 1, static_cast<sqlite3_int64>(ImagePairToPairId(id1, id2)));
+    sqlite3_bind_int64(st.s, 2, static_cast<sqlite3_int64>(m.size() / 2));
+    sqlite3_bind_int64(st.s, 3, 2);
+    sqlite3_bind_blob(st.s, 4, m.empty() ? "" : reinterpret_cast<const char*>(m.data()),
+                      static_cast<int>(m.size() * sizeof(uint32_t)), SQLITE_TRANSIENT);
+    st.Step();
+}
+void Database::WriteTwoViewGeometry(image_t id1, image_t id2, const TwoViewGeometryRow& in) {
+    TwoViewGeometryRow t = in;
+    if (SwapImagePair(id1, id2)) t.Invert();
+    Stmt st(db_, "INSERT INTO two_view_geometries(pair_id, rows, cols, data, config, F, E, H, qvec, tvec) "
+                 "VALUES(?, ?, ?, ?, ?, ?, ?, ?, ?, ?)");
+    sqlite3_bind_int64(st.s, 1, static_cast<sqlite3_int64>(ImagePairToPairId(id1, id2)));
+    sqlite3_bind_int64(st.s, 2, static_cast<sqlite3_int64>(t.inlier_matches.size() / 2));
+    sqlite3_bind_int64(st.s, 3, 2);
+    sqlite3_bind_blob(st.s, 4, t.inlier_matches.empty() ? "" : reinterpret_cast<const char*>(t.inlier_matches.data()),
+                      static_cast<int>(t.inlier_matches.size() * sizeof(uint32_t)), SQLITE_TRANSIENT);
+    sqlite3_bind_int64(st.s, 5, t.config);
+    // COLMAP stores the matrices only when there are inlier matches, empty blobs otherwise
+    const bool has = !t.inlier_matches.empty();
+    auto wr = [&](int col, const double* src, int n) {
+        sqlite3_bind_blob(st.s, col, has ? reinterpret_cast<const char*>(src) : "", has ? static_cast<int>(n * sizeof(double)) : 0,
+                          SQLITE_TRANSIENT);
+    };
+    wr(6, t.F.data(), 9);
+    wr(7, t.E.data(), 9);
+    wr(8, t.H.data(), 9);
+    wr(9, t.qvec.data(), 4);
+    wr(10, t.tvec.data(), 3);
+    st.Step();
+}
+void Database::DeleteMatches(image_t id1, image_t id2) {
+    Stmt st(db_, "DELETE FROM matches WHERE pair_id = ?");
+    sqlite3_bind_int64(st.s, 1, static_cast<sqlite3_int64>(ImagePairToPairId(id1, id2)));
+    st.Step();
+}
+void Database::DeleteInlierMatches(image_t id1, image_t id2) {
+    Stmt st(db_, "DELETE FROM two_view_geometries WHERE pair_id = ?");
+    sqlite3_bind_int64(st.s, 1, static_cast<sqlite3_int64>(ImagePairToPairId(id1, id2)));
+    st.Step();
+}
+
+}  // namespace amchost

@@ -1,0 +1,101 @@
+// database.h — minimal C++ access to a COLMAP SQLite database (schema: SURVEY.md A.5, which
+// mirrors COLMAP's scripts/python/database.py).  Only what the match + verify path touches:
+// cameras, images, keypoints, descriptors, matches, two_view_geometries.
+// Python surface mirrored: /root/reference/pycolmap/scene/database.h:9-46.
+#pragma once
+
+#include <array>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+struct sqlite3;
+struct sqlite3_stmt;
+
+namespace amchost {
+
+using image_t = uint32_t;
+using camera_t = uint32_t;
+using image_pair_t = uint64_t;
+
+constexpr uint64_t kMaxNumImages = 2147483647ull;  // COLMAP Database::kMaxNumImages
+
+struct CameraRow {
+    camera_t camera_id = 0;
+    int model_id = 0;
+    uint64_t width = 0, height = 0;
+    std::vector<double> params;
+    bool has_prior_focal_length = false;
+};
+struct ImageRow {
+    image_t image_id = 0;
+    std::string name;
+    camera_t camera_id = 0;
+};
+struct TwoViewGeometryRow {
+    int config = 0;  // UNDEFINED
+    std::array<double, 9> F{}, E{}, H{};  // row-major
+    std::vector<uint32_t> inlier_matches;  // rows x 2
+    std::array<double, 4> qvec{{1, 0, 0, 0}};
+    std::array<double, 3> tvec{{0, 0, 0}};
+    void Invert();  // TwoViewGeometry::Invert: swap roles of the two images
+};
+
+class Database {
+  public:
+    explicit Database(const std::string& path);
+    ~Database();
+    Database(const Database&) = delete;
+    Database& operator=(const Database&) = delete;
+
+    // pair id helpers (COLMAP Database::ImagePairToPairId / SwapImagePair / PairIdToImagePair)
+    static bool SwapImagePair(image_t id1, image_t id2) { return id1 > id2; }
+    static image_pair_t ImagePairToPairId(image_t id1, image_t id2);
+    static void PairIdToImagePair(image_pair_t pair_id, image_t* id1, image_t* id2);
+
+    size_t NumCameras() const { return Count("cameras"); }
+    size_t NumImages() const { return Count("images"); }
+    size_t NumKeypoints() const { return SumRows("keypoints"); }
+    size_t NumDescriptors() const { return SumRows("descriptors"); }
+    size_t NumMatches() const { return SumRows("matches"); }
+    size_t NumInlierMatches() const { return SumRows("two_view_geometries"); }
+    size_t NumMatchedImagePairs() const { return Count("matches"); }
+    size_t NumVerifiedImagePairs() const { return Count("two_view_geometries"); }
+
+    std::vector<CameraRow> ReadAllCameras() const;
+    std::vector<ImageRow> ReadAllImages() const;  // ordered by image_id
+    // keypoints blob: rows x cols float32; returns x,y only (rows x 2)
+    std::vector<float> ReadKeypointsXY(image_t image_id, uint32_t* rows) const;
+    std::vector<uint8_t> ReadDescriptors(image_t image_id, uint32_t* rows) const;
+
+    bool ExistsMatches(image_t id1, image_t id2) const;
+    bool ExistsInlierMatches(image_t id1, image_t id2) const;
+    // matches as stored for the ordered pair (id1, id2): columns swapped back if id1 > id2
+    std::vector<uint32_t> ReadMatches(image_t id1, image_t id2) const;
+    TwoViewGeometryRow ReadTwoViewGeometry(image_t id1, image_t id2) const;
+    void WriteMatches(image_t id1, image_t id2, const std::vector<uint32_t>& matches);
+    void WriteTwoViewGeometry(image_t id1, image_t id2, const TwoViewGeometryRow& tvg);
+    void DeleteMatches(image_t id1, image_t id2);
+    void DeleteInlierMatches(image_t id1, image_t id2);
+
+    void BeginTransaction();
+    void EndTransaction();
+
+  private:
+    size_t Count(const char* table) const;
+    size_t SumRows(const char* table) const;
+    bool ExistsPair(const char* table, image_pair_t pair_id) const;
+    void Exec(const char* sql) const;
+    sqlite3* db_ = nullptr;
+};
+
+class DatabaseTransaction {
+  public:
+    explicit DatabaseTransaction(Database* db) : db_(db) { db_->BeginTransaction(); }
+    ~DatabaseTransaction() { db_->EndTransaction(); }
+  private:
+    Database* db_;
+};
+
+}  // namespace amchost

@@ -1,0 +1,405 @@
+// module.cc — the Python-visible host layer: a C++/pybind11 extension with pycolmap's API
+// surface for the match + verify path, implemented over libamc.so (C ABI) + SQLite.
+//
+// Mirrors (names, argument meaning, error behaviour):
+//   match_exhaustive / match_sequential / verify_matches    /root/reference/pycolmap/pipeline/match_features.h:22-68, 219-260
+//   SiftMatchingOptions / ExhaustiveMatchingOptions / SequentialMatchingOptions      ...:71-152
+//   TwoViewGeometryOptions / TwoViewGeometryConfiguration / TwoViewGeometry
+//                                                           /root/reference/pycolmap/estimators/two_view_geometry.h:41-93
+//   RANSACOptions (Python-side defaults)                    /root/reference/pycolmap/optim/bindings.h:10-25
+//   Device enum + GPU parameter check                       /root/reference/pycolmap/utils.h:9-31, main.cc:102-106
+//   option "dataclass" protocol (summary/todict/mergedict, dict/kwargs ctors, implicit dict
+//   conversion, copy, pickle)                               /root/reference/pycolmap/helpers.h:217-283
+//   interruptible blocking wait                             /root/reference/pycolmap/helpers.h:306-347
+//   Database                                                /root/reference/pycolmap/scene/database.h:9-46
+#include <pybind11/numpy.h>
+#include <pybind11/pybind11.h>
+#include <pybind11/stl.h>
+
+#include <atomic>
+#include <chrono>
+#include <exception>
+#include <fstream>
+#include <sstream>
+#include <thread>
+
+#include "controller.h"
+
+namespace py = pybind11;
+using namespace pybind11::literals;
+using namespace amchost;
+
+namespace {
+
+enum class Device { AUTO = -1, CPU = 0, CUDA = 1 };
+
+std::string PathToString(const py::object& p) {
+    return py::module_::import("os").attr("fspath")(p).cast<std::string>();
+}
+void CheckFileExists(const std::string& path) {
+    std::ifstream f(path);
+    if (!f.good()) throw py::value_error("[pycolmap_amd] Check Failed: file " + path + " does not exist.");
+}
+// VerifyGPUParams analogue.  This package is the accelerator path only.
+void RequireAccelerator(Device d) {
+    if (d == Device::CPU)
+        throw py::value_error(
+            "pycolmap_amd implements the accelerated (MI355X) matcher only and has no CPU fallback; "
+            "set device='auto' or device='cuda', or use the reference pycolmap for device='cpu'.");
+}
+
+// ---- option "dataclass" protocol --------------------------------------------------------------
+void MergeDict(py::object self, const py::dict& d, const std::vector<std::string>& fields) {
+    for (auto item : d) {
+        const std::string key = py::str(item.first);
+        if (std::find(fields.begin(), fields.end(), key) == fields.end()) {
+            std::string known;
+            for (const auto& f : fields) known += (known.empty() ? "" : ", ") + f;
+            throw py::value_error(py::str(self.attr("__class__").attr("__name__")).cast<std::string>() +
+                                  ": unknown option '" + key + "' (valid: " + known + ")");
+        }
+        py::object cur = self.attr(key.c_str());
+        py::object val = py::reinterpret_borrow<py::object>(item.second);
+        if (py::isinstance<py::dict>(val) && py::hasattr(cur, "mergedict")) {
+            cur.attr("mergedict")(val);  // nested options: recursive merge into the defaults
+            self.attr(key.c_str()) = cur;
+        } else {
+            self.attr(key.c_str()) = val;
+        }
+    }
+}
+py::dict ToDict(const py::object& self, const std::vector<std::string>& fields) {
+    py::dict d;
+    for (const auto& f : fields) {
+        py::object v = self.attr(f.c_str());
+        d[py::str(f)] = py::hasattr(v, "todict") ? v.attr("todict")() : v;
+    }
+    return d;
+}
+std::string Summary(const py::object& self, const std::vector<std::string>& fields, int indent) {
+    std::ostringstream ss;
+    ss << py::str(self.attr("__class__").attr("__name__")).cast<std::string>() << ":";
+    for (const auto& f : fields) {
+        py::object v = self.attr(f.c_str());
+        ss << "\n" << std::string(indent + 4, ' ') << f << " = ";
+        if (py::hasattr(v, "summary"))
+            ss << v.attr("summary")(indent + 4).cast<std::string>();
+        else
+            ss << py::repr(v).cast<std::string>();
+    }
+    return ss.str();
+}
+
+template <typename T>
+void MakeDataclass(py::class_<T>& cls, const std::vector<std::string>& fields) {
+    cls.def(py::init([fields](const py::dict& d) {
+        auto self = std::make_unique<T>();
+        py::object o = py::cast(self.get(), py::return_value_policy::reference);
+        MergeDict(o, d, fields);
+        return self;
+    }));
+    cls.def(py::init([fields](const py::kwargs& kw) {
+        auto self = std::make_unique<T>();
+        py::object o = py::cast(self.get(), py::return_value_policy::reference);
+        MergeDict(o, py::dict(kw), fields);
+        return self;
+    }));
+    py::implicitly_convertible<py::dict, T>();
+    cls.def("mergedict", [fields](py::object self, const py::dict& d) { MergeDict(self, d, fields); });
+    cls.def("todict", [fields](py::object self) { return ToDict(self, fields); });
+    cls.def("summary", [fields](py::object self, int indent) { return Summary(self, fields, indent); },
+            "indent"_a = 0);
+    cls.def("__repr__", [fields](py::object self) { return Summary(self, fields, 0); });
+    cls.def("__copy__", [](const T& self) { return T(self); });
+    cls.def("__deepcopy__", [](const T& self, const py::dict&) { return T(self); });
+    cls.def(py::pickle([fields](py::object self) { return ToDict(self, fields); },
+                       [fields](const py::dict& d) {
+                           auto self = std::make_unique<T>();
+                           py::object o = py::cast(self.get(), py::return_value_policy::reference);
+                           MergeDict(o, d, fields);
+                           return self;
+                       }));
+}
+
+// ---- interruptible blocking run (PyWait analogue) ------------------------------------------------
+void RunInterruptible(MatchController& ctrl, const std::function<void()>& work) {
+    std::exception_ptr err;
+    std::atomic<bool> done{false};
+    std::thread th([&] {
+        try {
+            work();
+        } catch (...) {
+            err = std::current_exception();
+        }
+        done.store(true);
+    });
+    bool interrupted = false;
+    {
+        py::gil_scoped_release release;
+        while (!done.load()) {
+            std::this_thread::sleep_for(std::chrono::milliseconds(50));
+            py::gil_scoped_acquire acquire;
+            if (PyErr_CheckSignals() != 0) {  // Ctrl-C: stop cooperatively between blocks
+                interrupted = true;
+                ctrl.RequestStop();
+                break;
+            }
+        }
+        th.join();
+    }
+    if (interrupted) throw py::error_already_set();
+    if (err) {
+        try {
+            std::rethrow_exception(err);
+        } catch (const AmcFailure& e) {
+            if (e.code == AMC_E_INVALID) throw py::value_error(e.what());
+            throw std::runtime_error(e.what());
+        } catch (const std::invalid_argument& e) {
+            throw py::value_error(e.what());
+        }
+    }
+}
+
+struct PyTwoViewGeometry {
+    int config = 0;
+    std::array<double, 9> E{}, F{}, H{};
+    std::vector<uint32_t> inlier_matches;
+    double tri_angle = 0.0;
+};
+py::array_t<double> Mat3(const std::array<double, 9>& m) {
+    py::array_t<double> a({3, 3});
+    std::memcpy(a.mutable_data(), m.data(), sizeof(double) * 9);
+    return a;
+}
+py::array_t<uint32_t> MatchesArray(const std::vector<uint32_t>& m) {
+    py::array_t<uint32_t> a({static_cast<py::ssize_t>(m.size() / 2), static_cast<py::ssize_t>(2)});
+    if (!m.empty()) std::memcpy(a.mutable_data(), m.data(), m.size() * sizeof(uint32_t));
+    return a;
+}
+
+py::dict StatsDict(const MatchStats& s) {
+    return py::dict("pairs_matched"_a = s.pairs_matched, "pairs_verified"_a = s.pairs_verified,
+                    "pairs_skipped"_a = s.pairs_skipped, "match_device_ms"_a = s.match_device_ms,
+                    "verify_device_ms"_a = s.verify_device_ms, "db_ms"_a = s.db_ms,
+                    "num_distances"_a = s.num_distances);
+}
+
+}  // namespace
+
+PYBIND11_MODULE(_pycolmap, m) {
+    m.doc() = "MI355X-native match + verify path behind the pycolmap API (pycolmap_amd)";
+    m.attr("has_cuda") = true;  // drop-in: "an accelerator is available" (it is an MI355X)
+    m.attr("has_hip") = true;
+    m.attr("COLMAP_version") = "3.9.1-semantics";
+
+    py::enum_<Device> PyDevice(m, "Device");
+    PyDevice.value("auto", Device::AUTO).value("cpu", Device::CPU).value("cuda", Device::CUDA);
+    PyDevice.def(py::init([](const std::string& s) {
+        if (s == "auto") return Device::AUTO;
+        if (s == "cpu") return Device::CPU;
+        if (s == "cuda" || s == "hip") return Device::CUDA;
+        throw py::value_error("Invalid string value " + s + " for enum Device");
+    }));
+    py::implicitly_convertible<std::string, Device>();
+
+    // ---- RANSACOptions: Python-side defaults differ from the C++ struct's -------------------
+    py::class_<RANSACOptions> PyRANSAC(m, "RANSACOptions");
+    PyRANSAC.def(py::init([]() {
+        RANSACOptions o;  // /root/reference/pycolmap/optim/bindings.h:10-18
+        o.max_error = 4.0;
+        o.min_inlier_ratio = 0.01;
+        o.confidence = 0.9999;
+        o.min_num_trials = 1000;
+        o.max_num_trials = 100000;
+        return o;
+    }));
+    PyRANSAC.def_readwrite("max_error", &RANSACOptions::max_error)
+        .def_readwrite("min_inlier_ratio", &RANSACOptions::min_inlier_ratio)
+        .def_readwrite("confidence", &RANSACOptions::confidence)
+        .def_readwrite("dyn_num_trials_multiplier", &RANSACOptions::dyn_num_trials_multiplier)
+        .def_readwrite("min_num_trials", &RANSACOptions::min_num_trials)
+        .def_readwrite("max_num_trials", &RANSACOptions::max_num_trials);
+    MakeDataclass(PyRANSAC, {"max_error", "min_inlier_ratio", "confidence", "dyn_num_trials_multiplier",
+                             "min_num_trials", "max_num_trials"});
+
+    py::class_<SiftMatchingOptions> PySift(m, "SiftMatchingOptions");
+    PySift.def(py::init<>())
+        .def_readwrite("num_threads", &SiftMatchingOptions::num_threads)
+        .def_readwrite("gpu_index", &SiftMatchingOptions::gpu_index,
+                       "Index of the GPU used for feature matching. For multi-GPU matching, you should "
+                       "separate multiple GPU indices by comma, e.g., \"0,1,2,3\".")
+        .def_readwrite("max_ratio", &SiftMatchingOptions::max_ratio,
+                       "Maximum distance ratio between first and second best match.")
+        .def_readwrite("max_distance", &SiftMatchingOptions::max_distance, "Maximum distance to best match.")
+        .def_readwrite("cross_check", &SiftMatchingOptions::cross_check,
+                       "Whether to enable cross checking in matching.")
+        .def_readwrite("max_num_matches", &SiftMatchingOptions::max_num_matches, "Maximum number of matches.")
+        .def_readwrite("guided_matching", &SiftMatchingOptions::guided_matching,
+                       "Whether to perform guided matching, if geometric verification succeeds.");
+    MakeDataclass(PySift, {"num_threads", "gpu_index", "max_ratio", "max_distance", "cross_check",
+                           "max_num_matches", "guided_matching"});
+
+    py::class_<ExhaustiveMatchingOptions> PyExh(m, "ExhaustiveMatchingOptions");
+    PyExh.def(py::init<>()).def_readwrite("block_size", &ExhaustiveMatchingOptions::block_size);
+    MakeDataclass(PyExh, {"block_size"});
+
+    py::class_<SequentialMatchingOptions> PySeq(m, "SequentialMatchingOptions");
+    PySeq.def(py::init<>())
+        .def_readwrite("overlap", &SequentialMatchingOptions::overlap, "Number of overlapping image pairs.")
+        .def_readwrite("quadratic_overlap", &SequentialMatchingOptions::quadratic_overlap,
+                       "Whether to match images against their quadratic neighbors.")
+        .def_readwrite("loop_detection", &SequentialMatchingOptions::loop_detection)
+        .def_readwrite("loop_detection_num_images", &SequentialMatchingOptions::loop_detection_num_images)
+        .def_readwrite("loop_detection_num_nearest_neighbors",
+                       &SequentialMatchingOptions::loop_detection_num_nearest_neighbors)
+        .def_readwrite("loop_detection_num_checks", &SequentialMatchingOptions::loop_detection_num_checks)
+        .def_readwrite("loop_detection_num_images_after_verification",
+                       &SequentialMatchingOptions::loop_detection_num_images_after_verification)
+        .def_readwrite("loop_detection_max_num_features",
+                       &SequentialMatchingOptions::loop_detection_max_num_features)
+        .def_readwrite("vocab_tree_path", &SequentialMatchingOptions::vocab_tree_path);
+    MakeDataclass(PySeq, {"overlap", "quadratic_overlap", "loop_detection", "loop_detection_num_images",
+                          "loop_detection_num_nearest_neighbors", "loop_detection_num_checks",
+                          "loop_detection_num_images_after_verification", "loop_detection_max_num_features",
+                          "vocab_tree_path"});
+
+    py::class_<TwoViewGeometryOptions> PyTvgO(m, "TwoViewGeometryOptions");
+    PyTvgO.def(py::init<>())  // C++ defaults, incl. the C++ RANSAC defaults
+        .def_readwrite("min_num_inliers", &TwoViewGeometryOptions::min_num_inliers)
+        .def_readwrite("min_E_F_inlier_ratio", &TwoViewGeometryOptions::min_E_F_inlier_ratio)
+        .def_readwrite("max_H_inlier_ratio", &TwoViewGeometryOptions::max_H_inlier_ratio)
+        .def_readwrite("watermark_min_inlier_ratio", &TwoViewGeometryOptions::watermark_min_inlier_ratio)
+        .def_readwrite("watermark_border_size", &TwoViewGeometryOptions::watermark_border_size)
+        .def_readwrite("detect_watermark", &TwoViewGeometryOptions::detect_watermark)
+        .def_readwrite("multiple_ignore_watermark", &TwoViewGeometryOptions::multiple_ignore_watermark)
+        .def_readwrite("force_H_use", &TwoViewGeometryOptions::force_H_use)
+        .def_readwrite("compute_relative_pose", &TwoViewGeometryOptions::compute_relative_pose)
+        .def_readwrite("multiple_models", &TwoViewGeometryOptions::multiple_models)
+        .def_readwrite("ransac", &TwoViewGeometryOptions::ransac_options);
+    MakeDataclass(PyTvgO, {"min_num_inliers", "min_E_F_inlier_ratio", "max_H_inlier_ratio",
+                           "watermark_min_inlier_ratio", "watermark_border_size", "detect_watermark",
+                           "multiple_ignore_watermark", "force_H_use", "compute_relative_pose",
+                           "multiple_models", "ransac"});
+
+    py::class_<PyTwoViewGeometry> PyTvg(m, "TwoViewGeometry");
+    py::object cfg_enum = py::module_::import("enum").attr("IntEnum")(
+        "TwoViewGeometryConfiguration",
+        py::dict("UNDEFINED"_a = 0, "DEGENERATE"_a = 1, "CALIBRATED"_a = 2, "UNCALIBRATED"_a = 3, "PLANAR"_a = 4,
+                 "PANORAMIC"_a = 5, "PLANAR_OR_PANORAMIC"_a = 6, "WATERMARK"_a = 7, "MULTIPLE"_a = 8));
+    m.attr("TwoViewGeometryConfiguration") = cfg_enum;
+    PyTvg.def(py::init<>())
+        .def_property_readonly("config", [cfg_enum](const PyTwoViewGeometry& s) { return cfg_enum(s.config); })
+        .def_property_readonly("E", [](const PyTwoViewGeometry& s) { return Mat3(s.E); })
+        .def_property_readonly("F", [](const PyTwoViewGeometry& s) { return Mat3(s.F); })
+        .def_property_readonly("H", [](const PyTwoViewGeometry& s) { return Mat3(s.H); })
+        .def_property_readonly("cam2_from_cam1", [](const PyTwoViewGeometry&) { return py::none(); })
+        .def_property_readonly("inlier_matches",
+                               [](const PyTwoViewGeometry& s) { return MatchesArray(s.inlier_matches); })
+        .def_readonly("tri_angle", &PyTwoViewGeometry::tri_angle);
+
+    // ---- Database ---------------------------------------------------------------------------
+    py::class_<Database>(m, "Database")
+        .def(py::init([](const py::object& path) {
+                 const std::string p = PathToString(path);
+                 CheckFileExists(p);
+                 return std::make_unique<Database>(p);
+             }),
+             "path"_a)
+        .def_property_readonly("num_cameras", &Database::NumCameras)
+        .def_property_readonly("num_images", &Database::NumImages)
+        .def_property_readonly("num_keypoints", &Database::NumKeypoints)
+        .def_property_readonly("num_descriptors", &Database::NumDescriptors)
+        .def_property_readonly("num_matches", &Database::NumMatches)
+        .def_property_readonly("num_inlier_matches", &Database::NumInlierMatches)
+        .def_property_readonly("num_matched_image_pairs", &Database::NumMatchedImagePairs)
+        .def_property_readonly("num_verified_image_pairs", &Database::NumVerifiedImagePairs)
+        .def_static("image_pair_to_pair_id", &Database::ImagePairToPairId, "image_id1"_a, "image_id2"_a)
+        .def_static("pair_id_to_image_pair",
+                    [](image_pair_t pid) {
+                        image_t a, b;
+                        Database::PairIdToImagePair(pid, &a, &b);
+                        return std::make_pair(a, b);
+                    },
+                    "pair_id"_a)
+        .def("exists_matches", &Database::ExistsMatches, "image_id1"_a, "image_id2"_a)
+        .def("exists_inlier_matches", &Database::ExistsInlierMatches, "image_id1"_a, "image_id2"_a)
+        .def("read_matches",
+             [](const Database& db, image_t a, image_t b) { return MatchesArray(db.ReadMatches(a, b)); },
+             "image_id1"_a, "image_id2"_a)
+        .def("read_two_view_geometry",
+             [](const Database& db, image_t a, image_t b) {
+                 const TwoViewGeometryRow r = db.ReadTwoViewGeometry(a, b);
+                 PyTwoViewGeometry g;
+                 g.config = r.config;
+                 g.E = r.E;
+                 g.F = r.F;
+                 g.H = r.H;
+                 g.inlier_matches = r.inlier_matches;
+                 return g;
+             },
+             "image_id1"_a, "image_id2"_a);
+
+    // ---- pipeline entry points ----------------------------------------------------------------
+    auto run_pipeline = [](const py::object& database_path, const SiftMatchingOptions& sift,
+                           const TwoViewGeometryOptions& tvg, Device device,
+                           const std::function<void(MatchController&)>& body) {
+        const std::string db_path = PathToString(database_path);
+        CheckFileExists(db_path);
+        RequireAccelerator(device);
+        int dev = 0;  // gpu_index "-1" = default device; "k[,..]" = first listed device
+        if (!sift.gpu_index.empty() && sift.gpu_index != "-1") dev = std::stoi(sift.gpu_index);
+        MatchController ctrl(db_path, sift, tvg, dev);
+        RunInterruptible(ctrl, [&] {
+            ctrl.Setup();
+            body(ctrl);
+        });
+        py::module_::import("pycolmap_amd._pycolmap").attr("_last_stats") = StatsDict(ctrl.stats);
+    };
+
+    m.def(
+        "match_exhaustive",
+        [run_pipeline](const py::object& database_path, const SiftMatchingOptions& sift,
+                       const ExhaustiveMatchingOptions& mo, const TwoViewGeometryOptions& tvg, Device device) {
+            run_pipeline(database_path, sift, tvg, device, [&](MatchController& c) { RunExhaustive(c, mo); });
+        },
+        "database_path"_a, "sift_options"_a = SiftMatchingOptions(),
+        "matching_options"_a = ExhaustiveMatchingOptions(), "verification_options"_a = TwoViewGeometryOptions(),
+        "device"_a = Device::AUTO, "Exhaustive feature matching");
+    m.def(
+        "match_sequential",
+        [run_pipeline](const py::object& database_path, const SiftMatchingOptions& sift,
+                       const SequentialMatchingOptions& mo, const TwoViewGeometryOptions& tvg, Device device) {
+            run_pipeline(database_path, sift, tvg, device, [&](MatchController& c) { RunSequential(c, mo); });
+        },
+        "database_path"_a, "sift_options"_a = SiftMatchingOptions(),
+        "matching_options"_a = SequentialMatchingOptions(), "verification_options"_a = TwoViewGeometryOptions(),
+        "device"_a = Device::AUTO, "Sequential feature matching");
+    m.def(
+        "verify_matches",
+        [run_pipeline](const py::object& database_path, const py::object& pairs_path,
+                       const TwoViewGeometryOptions& tvg) {
+            const std::string pp = PathToString(pairs_path);
+            CheckFileExists(PathToString(database_path));
+            CheckFileExists(pp);
+            run_pipeline(database_path, SiftMatchingOptions(), tvg, Device::AUTO,
+                         [&](MatchController& c) { RunImagePairs(c, pp); });
+        },
+        "database_path"_a, "pairs_path"_a, "options"_a = TwoViewGeometryOptions(),
+        "Run geometric verification of the matches");
+    auto unsupported = [](const char* what) {
+        return [what](const py::args&, const py::kwargs&) {
+            throw py::value_error(std::string(what) +
+                                  " needs FLANN / spatial indexing and is outside pycolmap_amd's scope "
+                                  "(SURVEY.md section 8f); use match_exhaustive, match_sequential or verify_matches.");
+        };
+    };
+    m.def("_exhaustive_blocks", &ExhaustiveBlocks, "image_ids"_a, "block_size"_a,
+          "Pair blocks of ExhaustiveFeatureMatcher::Run (test hook)");
+    m.def("_sequential_blocks", &SequentialBlocks, "ordered_image_ids"_a, "overlap"_a, "quadratic_overlap"_a,
+          "Pair blocks of SequentialFeatureMatcher::Run (test hook)");
+    m.def("match_spatial", unsupported("match_spatial"));
+    m.def("match_vocabtree", unsupported("match_vocabtree"));
+    m.attr("_last_stats") = py::dict();
+    m.def("last_run_stats", []() { return py::module_::import("pycolmap_amd._pycolmap").attr("_last_stats"); },
+          "Timing / counters of the most recent match_* / verify_matches call (pycolmap_amd extension).");
+}

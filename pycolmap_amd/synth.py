@@ -128,3 +128,41 @@ def two_view_scene(rng, num_inliers=300, num_outliers=100, noise=0.5, planar=Fal
         H = K @ R @ Kinv
     return dict(pts1=pts1, pts2=pts2, matches=matches, inlier=inlier, K=K, R=R, t=t, F_true=F,
                 E_true=E, H_true=H, f=f, width=width, height=height)
+
+
+def multiview_scene(rng, num_images=6, n_feats=600, num_landmarks=900, f=1200.0, width=1600, height=1200,
+                    sigma_px=0.5, sigma_d=0.06):
+    """Images of one 3-D scene with geometrically consistent keypoints AND matching descriptors:
+    the input of the whole match + verify pipeline.  Cameras sit on an arc and
+    look at the landmark cloud; each image keeps up to 70 % landmark features (projection + pixel
+    noise, descriptor = noisy landmark prototype) and is padded with pure-noise features.
+    Returns a list of dict(name, keypoints [n,4] float32 (x, y, scale, orientation), descriptors
+    [n,128] uint8, model=1 (PINHOLE), width, height, params)."""
+    X = rng.uniform([-4, -2.5, -2], [4, 2.5, 2], size=(num_landmarks, 3))
+    proto = rng.gamma(0.7, 1.0, size=(num_landmarks, 128))
+    proto /= np.linalg.norm(proto, axis=1, keepdims=True)
+    K = np.array([[f, 0, width / 2.0], [0, f, height / 2.0], [0, 0, 1.0]])
+    images = []
+    for i in range(num_images):
+        ang = (i - (num_images - 1) / 2.0) * 0.12
+        C = np.array([9.0 * np.sin(ang), 0.3 * np.cos(3 * ang), -9.0 * np.cos(ang)])
+        z = -C / np.linalg.norm(C)
+        x = np.cross([0, 1.0, 0], z)
+        x /= np.linalg.norm(x)
+        y = np.cross(z, x)
+        R = np.stack([x, y, z])
+        Xc = (X - C) @ R.T
+        uv = (Xc @ K.T)
+        uv = uv[:, :2] / uv[:, 2:]
+        vis = np.where((Xc[:, 2] > 1) & (uv[:, 0] > 8) & (uv[:, 0] < width - 8) & (uv[:, 1] > 8) & (uv[:, 1] < height - 8))[0]
+        vis = rng.permutation(vis)[:int(0.7 * n_feats)]
+        kp = uv[vis] + rng.normal(0, sigma_px, size=(len(vis), 2))
+        d = proto[vis] + rng.normal(0, sigma_d, size=(len(vis), 128)) * proto[vis].mean()
+        nn = n_feats - len(vis)
+        kp = np.concatenate([kp, rng.uniform([8, 8], [width - 8, height - 8], size=(nn, 2))])
+        d = np.concatenate([d, rng.gamma(0.7, 1.0, size=(nn, 128)) * 0.1])
+        perm = rng.permutation(n_feats)
+        kp4 = np.c_[kp[perm], rng.uniform(1, 4, n_feats), rng.uniform(-3.1, 3.1, n_feats)].astype(np.float32)
+        images.append(dict(name=f"img_{i:04d}.jpg", keypoints=kp4, descriptors=quantize_descriptors(d[perm]),
+                           model=1, width=width, height=height, params=(f, f, width / 2.0, height / 2.0)))
+    return images

@@ -1,0 +1,121 @@
+"""CPU tests of the C++/pybind11 host layer (pycolmap_amd._pycolmap): API surface, option
+"dataclass" protocol, device/error conventions, pair generators, SQLite schema round trips.
+No GPU compute here (the drop-in boundary)."""
+import copy
+import itertools
+import pickle
+
+import numpy as np
+import pytest
+
+import colmap_db
+import pycolmap_amd as pycolmap
+from pycolmap_amd import synth
+
+
+def test_option_defaults_match_the_reference():
+    s = pycolmap.SiftMatchingOptions()
+    assert (s.max_ratio, s.max_distance, s.cross_check, s.max_num_matches, s.guided_matching,
+            s.num_threads, s.gpu_index) == (0.8, 0.7, True, 32768, False, -1, "-1")
+    assert pycolmap.ExhaustiveMatchingOptions().block_size == 50
+    q = pycolmap.SequentialMatchingOptions()
+    assert (q.overlap, q.quadratic_overlap, q.loop_detection) == (10, True, False)
+    # RANSACOptions(): Python-side overrides (/root/reference/pycolmap/optim/bindings.h:10-18)
+    r = pycolmap.RANSACOptions()
+    assert (r.max_error, r.min_inlier_ratio, r.confidence, r.min_num_trials, r.max_num_trials) == \
+        (4.0, 0.01, 0.9999, 1000, 100000)
+    # TwoViewGeometryOptions(): py::init<>() of the C++ struct -> C++ RANSAC defaults
+    t = pycolmap.TwoViewGeometryOptions()
+    assert (t.min_num_inliers, t.min_E_F_inlier_ratio, t.max_H_inlier_ratio, t.detect_watermark) == \
+        (15, 0.95, 0.8, True)
+    assert (t.ransac.min_inlier_ratio, t.ransac.confidence, t.ransac.min_num_trials, t.ransac.max_num_trials) == \
+        (0.25, 0.999, 100, 10000)
+
+
+def test_dataclass_protocol():
+    o = pycolmap.TwoViewGeometryOptions({"min_num_inliers": 20, "ransac": {"max_error": 2.0}})
+    assert o.min_num_inliers == 20 and o.ransac.max_error == 2.0 and o.ransac.confidence == 0.999
+    o2 = pycolmap.SiftMatchingOptions(max_ratio=0.7, cross_check=False)
+    assert o2.max_ratio == 0.7 and o2.cross_check is False
+    d = o.todict()
+    assert d["ransac"]["max_error"] == 2.0 and d["force_H_use"] is False
+    o.mergedict({"ransac": {"confidence": 0.99}})
+    assert o.ransac.confidence == 0.99 and o.ransac.max_error == 2.0
+    assert "min_num_inliers = 20" in o.summary() and "max_error = 2.0" in o.summary()
+    with pytest.raises(ValueError):
+        pycolmap.SiftMatchingOptions({"no_such_option": 1})
+    with pytest.raises((TypeError, ValueError)):
+        pycolmap.SiftMatchingOptions(max_ratio="abc")
+    for c in (copy.copy(o), copy.deepcopy(o), pickle.loads(pickle.dumps(o))):
+        assert c.todict() == o.todict()
+    c = copy.deepcopy(o)
+    c.ransac.max_error = 9.0
+    o.min_num_inliers = 33
+    assert c.min_num_inliers == 20
+
+
+def test_device_enum_and_error_conventions(tmp_path):
+    assert pycolmap.Device("auto") == pycolmap.Device.auto and pycolmap.Device("cuda") == pycolmap.Device.cuda
+    with pytest.raises(ValueError):
+        pycolmap.Device("tpu")
+    with pytest.raises(ValueError, match="does not exist"):
+        pycolmap.match_exhaustive(tmp_path / "missing.db")
+    db = tmp_path / "a.db"
+    colmap_db.create(db, [])
+    with pytest.raises(ValueError, match="no CPU fallback"):
+        pycolmap.match_exhaustive(db, device="cpu")           # implicit str -> Device
+    with pytest.raises(ValueError, match="does not exist"):
+        pycolmap.verify_matches(db, tmp_path / "nopairs.txt")
+    with pytest.raises((TypeError, ValueError)):   # failed implicit dict -> options conversion
+        pycolmap.match_exhaustive(str(db), sift_options={"bogus": 1})
+    with pytest.raises(ValueError):
+        pycolmap.match_vocabtree(db)
+    assert pycolmap.has_cuda is True
+
+
+@pytest.mark.parametrize("n,B", [(1, 2), (5, 2), (7, 3), (20, 50), (23, 5), (50, 50), (51, 50)])
+def test_exhaustive_blocks_cover_every_pair_exactly_once(n, B):
+    ids = list(range(10, 10 + n))
+    blocks = pycolmap._pycolmap._exhaustive_blocks(ids, B)
+    nb = (n + B - 1) // B
+    assert len(blocks) == nb * nb
+    flat = [tuple(p) for b in blocks for p in b]
+    assert all(a != b for a, b in flat)
+    unordered = [tuple(sorted(p)) for p in flat]
+    assert len(set(unordered)) == len(unordered) == n * (n - 1) // 2
+    assert set(unordered) == set(itertools.combinations(ids, 2))
+
+
+def test_sequential_blocks_follow_colmap():
+    ids = list(range(1, 21))
+    blocks = pycolmap._pycolmap._sequential_blocks(ids, 4, True)
+    assert len(blocks) == 20
+    # image 1 (idx 0): linear offsets 0..3 and quadratic 1,2,4,8
+    assert [tuple(p) for p in blocks[0]] == [(1, 1), (1, 2), (1, 2), (1, 3), (1, 3), (1, 5), (1, 4), (1, 9)]
+    assert [tuple(p) for p in blocks[18]] == [(19, 19), (19, 20), (19, 20)]
+    lin = pycolmap._pycolmap._sequential_blocks(ids, 3, False)
+    assert [tuple(p) for p in lin[5]] == [(6, 6), (6, 7), (6, 8)]
+
+
+def test_database_binding_reads_colmap_schema(tmp_path):
+    rng = np.random.default_rng(0)
+    imgs = synth.multiview_scene(rng, num_images=3, n_feats=40, num_landmarks=60)
+    db_path = tmp_path / "s.db"
+    ids = colmap_db.create(db_path, imgs)
+    m = np.array([[0, 5], [3, 7], [9, 1]], np.uint32)
+    colmap_db.write_matches(db_path, ids[0], ids[1], m)
+    colmap_db.write_matches(db_path, ids[2], ids[0], m)   # stored swapped
+    db = pycolmap.Database(db_path)
+    assert (db.num_cameras, db.num_images, db.num_keypoints, db.num_descriptors) == (3, 3, 120, 120)
+    assert db.num_matched_image_pairs == 2 and db.num_matches == 6 and db.num_verified_image_pairs == 0
+    pid = pycolmap.Database.image_pair_to_pair_id(ids[0], ids[1])
+    assert pid == colmap_db.pair_id(ids[0], ids[1]) == pycolmap.Database.image_pair_to_pair_id(ids[1], ids[0])
+    assert pycolmap.Database.pair_id_to_image_pair(pid) == (ids[0], ids[1])
+    np.testing.assert_array_equal(db.read_matches(ids[0], ids[1]), m)
+    np.testing.assert_array_equal(db.read_matches(ids[1], ids[0]), m[:, ::-1])
+    np.testing.assert_array_equal(db.read_matches(ids[2], ids[0]), m)
+    assert db.exists_matches(ids[0], ids[2]) and not db.exists_inlier_matches(ids[0], ids[1])
+    g = db.read_two_view_geometry(ids[0], ids[1])
+    assert g.config == pycolmap.TwoViewGeometryConfiguration.UNDEFINED and g.inlier_matches.shape == (0, 2)
+    with pytest.raises(ValueError):
+        pycolmap.Database(tmp_path / "nope.db")

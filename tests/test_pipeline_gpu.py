@@ -1,0 +1,133 @@
+"""End-to-end GPU tests of the drop-in API: COLMAP-schema SQLite in -> pycolmap_amd.match_exhaustive /
+match_sequential / verify_matches -> SQLite out, compared row by row with the CPU oracles run in the
+controller's own pair order (BASELINE.json configs[0] shape, scaled)."""
+import numpy as np
+import pytest
+
+import colmap_db
+import oracle_lib as o
+import pycolmap_amd as pycolmap
+from pycolmap_amd import synth
+
+pytestmark = pytest.mark.gpu
+MIN_INL = 15
+
+
+def expected_rows(images, ids, blocks, sift=(0.8, 0.7, True), prior=False, tvg_kw=None):
+    """What COLMAP's controller would store for the given pair blocks (oracle matcher + oracle TVG)."""
+    by_id = {i: im for i, im in zip(ids, images)}
+    exp_m, exp_t, seen = {}, {}, set()
+    for block in blocks:
+        for id1, id2 in block:
+            if id1 == id2:
+                continue
+            pid = colmap_db.pair_id(id1, id2)
+            if pid in seen:
+                continue
+            seen.add(pid)
+            a, b = by_id[id1], by_id[id2]
+            m = o.match(a["descriptors"], b["descriptors"], *sift)
+            tv = None
+            if len(m) >= MIN_INL:
+                cam1 = o.make_camera("PINHOLE", a["width"], a["height"], a["params"], prior=prior)
+                cam2 = o.make_camera("PINHOLE", b["width"], b["height"], b["params"], prior=prior)
+                r = o.estimate_two_view_geometry(cam1, a["keypoints"][:, :2].astype(np.float64), cam2,
+                                                 b["keypoints"][:, :2].astype(np.float64), m,
+                                                 o.tvg_default_options(**(tvg_kw or {})))
+                inl = m[r["inlier_mask"]]
+                if len(inl) >= MIN_INL:
+                    tv = dict(config=r["config"], F=r["F"], E=r["E"], H=r["H"], inl=inl)
+            else:
+                m = np.zeros((0, 2), np.uint32)
+            swap = id1 > id2
+            exp_m[pid] = np.ascontiguousarray(m[:, ::-1]) if swap else m
+            if tv is None:
+                exp_t[pid] = dict(config=0, inl=np.zeros((0, 2), np.uint32), F=None, E=None, H=None)
+            elif swap:
+                exp_t[pid] = dict(config=tv["config"], inl=np.ascontiguousarray(tv["inl"][:, ::-1]), F=tv["F"].T,
+                                  E=tv["E"].T, H=np.linalg.inv(tv["H"]), H_approx=True)
+            else:
+                exp_t[pid] = tv
+    return exp_m, exp_t
+
+
+def compare(db_path, exp_m, exp_t):
+    got_m, got_t = colmap_db.read_all(db_path)
+    assert set(got_m) == set(exp_m) and set(got_t) == set(exp_t)
+    nver = 0
+    for pid in exp_m:
+        np.testing.assert_array_equal(got_m[pid], exp_m[pid], err_msg=f"matches of pair {pid}")
+        g, e = got_t[pid], exp_t[pid]
+        assert g["config"] == e["config"], f"pair {pid}"
+        np.testing.assert_array_equal(g["inlier_matches"], e["inl"], err_msg=f"inliers of pair {pid}")
+        if len(e["inl"]) == 0:
+            assert g["F"] is None and g["E"] is None and g["H"] is None   # empty blobs, like COLMAP
+            continue
+        nver += 1
+        for k in "FE":
+            np.testing.assert_array_equal(g[k].view(np.uint64), np.ascontiguousarray(e[k]).view(np.uint64))
+        if e.get("H_approx"):
+            np.testing.assert_allclose(g["H"], e["H"], rtol=1e-9, atol=1e-12)
+        else:
+            np.testing.assert_array_equal(g["H"].view(np.uint64), e["H"].view(np.uint64))
+    return nver
+
+
+@pytest.mark.parametrize("prior", [False, True])
+def test_match_exhaustive_end_to_end(tmp_path, prior):
+    rng = np.random.default_rng(1 if prior else 0)
+    images = synth.multiview_scene(rng, num_images=7, n_feats=512)
+    for im in images:
+        im["prior"] = prior
+    db = tmp_path / "db.db"
+    ids = colmap_db.create(db, images)
+    pycolmap.match_exhaustive(db, matching_options={"block_size": 3})      # several blocks, swapped pairs
+    blocks = pycolmap._pycolmap._exhaustive_blocks(ids, 3)
+    exp_m, exp_t = expected_rows(images, ids, blocks, prior=prior)
+    assert len(exp_m) == 21
+    assert compare(db, exp_m, exp_t) >= 5
+    st = pycolmap.last_run_stats()
+    assert st["pairs_matched"] == 21 and st["pairs_skipped"] == 0
+    # resume: everything exists -> nothing recomputed, rows unchanged
+    pycolmap.match_exhaustive(db, matching_options={"block_size": 3})
+    st = pycolmap.last_run_stats()
+    assert st["pairs_matched"] == 0 and st["pairs_skipped"] == 21
+    compare(db, exp_m, exp_t)
+    d = pycolmap.Database(db)
+    assert d.num_matched_image_pairs == 21 and d.num_verified_image_pairs == 21
+
+
+def test_match_sequential_and_options(tmp_path):
+    rng = np.random.default_rng(2)
+    images = synth.multiview_scene(rng, num_images=8, n_feats=400)
+    db = tmp_path / "db.db"
+    ids = colmap_db.create(db, images)
+    sift = pycolmap.SiftMatchingOptions(max_ratio=0.9, cross_check=False)
+    pycolmap.match_sequential(db, sift_options=sift, matching_options={"overlap": 3, "quadratic_overlap": True},
+                              verification_options={"detect_watermark": False, "ransac": {"max_error": 3.0}})
+    blocks = pycolmap._pycolmap._sequential_blocks(ids, 3, True)      # names are already ordered
+    exp_m, exp_t = expected_rows(images, ids, blocks, sift=(0.9, 0.7, False),
+                                 tvg_kw=dict(detect_watermark=0, max_error=3.0))
+    assert compare(db, exp_m, exp_t) >= 4
+
+
+def test_verify_matches_reads_stored_matches(tmp_path):
+    rng = np.random.default_rng(3)
+    images = synth.multiview_scene(rng, num_images=4, n_feats=512)
+    db = tmp_path / "db.db"
+    ids = colmap_db.create(db, images)
+    pairs = [(ids[0], ids[1]), (ids[2], ids[1]), (ids[0], ids[3])]
+    stored = {}
+    for a, b in pairs:
+        ia, ib = ids.index(a), ids.index(b)
+        m = o.match(images[ia]["descriptors"], images[ib]["descriptors"])
+        colmap_db.write_matches(db, a, b, m)
+        stored[(a, b)] = m
+    pairs_txt = tmp_path / "pairs.txt"
+    pairs_txt.write_text("# comment\n\n" + "\n".join(f"{images[ids.index(a)]['name']} {images[ids.index(b)]['name']}"
+                                                     for a, b in pairs) + "\n")
+    pycolmap.verify_matches(db, pairs_txt)
+    st = pycolmap.last_run_stats()
+    assert st["pairs_matched"] == 0 and st["pairs_verified"] >= 2
+    exp_m, exp_t = expected_rows(images, ids, [pairs])
+    compare(db, exp_m, exp_t)
