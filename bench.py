@@ -192,10 +192,8 @@ def main():
     arena = make_arena_torch(num_images, args.feats, seed=0, device=device)
     s1_all, s2_all = synth.exhaustive_pairs(num_images)
     # shard: order by image 2 (the kernel's L2-friendly order), deal contiguous slices to ranks
-    order = np.lexsort((s1_all, s2_all))
-    per = (len(order) + world - 1) // world
-    mine = order[rank * per:(rank + 1) * per]
-    s1, s2 = s1_all[mine], s2_all[mine]
+    from pycolmap_amd import distributed as D
+    s1, s2, mine = D.shard_pairs(s1_all, s2_all, rank, world)
 
     ctx = _capi.Context(local_rank)
     stream = torch.cuda.current_stream()
@@ -209,17 +207,9 @@ def main():
         off, m, st = ctx.match_pairs(s1, s2, kernel=args.kernel, cross_check=not args.no_cross_check)
         gathered = None
         if world > 1:
-            # RCCL all-gather of the match tables: counts first, then padded tables
-            cnt = torch.tensor([m.shape[0]], device=device, dtype=torch.int64)
-            cnts = torch.empty(world, device=device, dtype=torch.int64)
-            dist.all_gather_into_tensor(cnts, cnt)
-            mx = int(cnts.max().item())
-            buf = torch.zeros(max(mx, 1), 2, device=device, dtype=torch.int32)
-            if m.shape[0]:
-                buf[:m.shape[0]] = torch.from_numpy(m.view(np.int32)).to(device, non_blocking=True)
-            allbuf = torch.empty(world * max(mx, 1), 2, device=device, dtype=torch.int32)
-            dist.all_gather_into_tensor(allbuf, buf)
-            gathered = (cnts, allbuf)
+            # the exchange step: RCCL all-gather of the match tables (sizes, then padded tables);
+            # afterwards every rank holds the whole match graph (rank 0 would feed the SQLite writer)
+            gathered = D.all_gather_match_tables(mine, off, m, device=device)
         return off, m, st, gathered
 
     def fence():

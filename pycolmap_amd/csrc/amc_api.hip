@@ -795,7 +795,7 @@ int amc_verify_pairs(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, s
     const uint32_t mcap = std::max<uint32_t>(64, round_up(maxM, 64));
     int cus = 256;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device);
-    const size_t lds_block = tvg_lds_bytes(mcap, 4);
+    const size_t lds_block = tvg_lds_bytes(mcap, tvg_pts_cap(mcap), 4);
     const uint32_t blocks_per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / std::max<size_t>(lds_block, 1)));
     uint32_t num_waves = (uint32_t)std::min<size_t>((npairs + 0), (size_t)cus * blocks_per_cu * 4);
     num_waves = std::max<uint32_t>(4, (num_waves + 3) / 4 * 4);
@@ -830,6 +830,14 @@ int amc_verify_pairs(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, s
         HIPCHK(hipMemcpyAsync(h_mask.data(), c->d_toutmask.p, mask_bytes, hipMemcpyDeviceToHost, st));
     HIPCHK(hipEventRecord(c->ev[1], st));
     HIPCHK(hipEventSynchronize(c->ev[1]));
+    if (std::getenv("AMC_TVG_PROFILE")) {
+        unsigned long long acc[5] = {0, 0, 0, 0, 0};
+        for (size_t p = 0; p < npairs; ++p)
+            for (int i = 0; i < 5; ++i) acc[i] += h_out[p].prof[i];
+        std::fprintf(stderr, "[amc tvg profile] pairs=%zu cycles/pair: sampling=%.0f minimal=%.0f replay+score=%.0f "
+                     "(of which LO=%.0f) total=%.0f\n", npairs, (double)acc[0] / npairs, (double)acc[1] / npairs,
+                     (double)acc[2] / npairs, (double)acc[3] / npairs, (double)acc[4] / npairs);
+    }
     for (size_t p = 0; p < npairs; ++p) {
         priv->tvg[p] = h_out[p].g;
         if (tp[p].M)

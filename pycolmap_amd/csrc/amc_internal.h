@@ -120,6 +120,9 @@ struct TvgPair {
 // device-side result record: amc_tvg padded to its own cache lines (same reason)
 struct alignas(128) TvgOut {
     amc_tvg g;
+    // shader-clock cycles spent per phase (diagnostics; printed with AMC_TVG_PROFILE=1):
+    // 0 sampling, 1 minimal solvers, 2 scoring of sample models, 3 local optimisation, 4 total
+    unsigned long long prof[8];
 };
 struct TvgParams {
     int32_t min_num_inliers, detect_watermark, force_H_use, min_num_trials;
@@ -129,7 +132,8 @@ struct TvgParams {
 };
 size_t tvg_ws_doubles_host(uint32_t mcap);
 size_t tvg_ws_mask_bytes_host(uint32_t mcap);
-size_t tvg_lds_bytes(uint32_t mcap, int waves);
+size_t tvg_lds_bytes(uint32_t mcap, uint32_t pts_cap, int waves);
+uint32_t tvg_pts_cap(uint32_t mcap);
 hipError_t launch_tvg(const TvgImage* imgs, const TvgPair* pairs, uint32_t npairs,
                       const uint32_t* matches, const uint32_t* trial_tabs, const uint32_t* mt_init,
                       const TvgParams& P, double* ws, uint8_t* mask_ws, uint32_t mcap,

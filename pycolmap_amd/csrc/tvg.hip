@@ -44,12 +44,17 @@ __host__ __device__ inline size_t tvg_ws_bytes_extra(uint32_t mcap) { return (si
 
 struct Wave {
     int lane;
+    unsigned long long prof[5];
     // LDS
     uint32_t* mt;      // 624
     uint32_t* snap;    // 624
     uint16_t* sidx;    // 64 x 8
     uint32_t* rawcnt;  // 64
     uint16_t* perm;    // mcap
+    double* lpts;      // 4 x pts_cap: the active RANSAC's correspondences, when they fit (LDS)
+    uint32_t pts_cap;
+    double* jacA;      // 81: A^T A / eigenvalues (LDS)
+    double* jacV;      // 81: eigenvectors (LDS)
     int mti;           // uniform
     // global workspace
     double* ws;
@@ -64,6 +69,14 @@ struct Wave {
 __device__ __forceinline__ void wave_mem_sync() {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     __builtin_amdgcn_wave_barrier();
+}
+
+// broadcast lane `src`'s double to the whole wave through the scalar unit (src is wave-uniform)
+__device__ __forceinline__ double readlane_f64(double v, int src) {
+    const unsigned long long u = __double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, src);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), src);
+    return __longlong_as_double(((unsigned long long)hi << 32) | lo);
 }
 
 // ---- wave reductions in the oracle's det_sum64 order ---------------------------------------------
@@ -135,20 +148,27 @@ __device__ __forceinline__ bool better(const Support a, const Support b) {
     if (a.cnt > b.cnt) return true;
     return a.cnt == b.cnt && a.sum < b.sum;
 }
+// InlierSupportMeasurer::Evaluate.  The count comes from ballots (wave-uniform by construction);
+// the residual sum is only ever consulted when the count ties or beats the best so far
+// (Compare()), so its 64-way butterfly is skipped otherwise (`need_sum_from` = that count).
 __device__ Support score(int kind, const double* m, const double* x1, const double* y1,
-                         const double* x2, const double* y2, int M, double max_res, int lane) {
+                         const double* x2, const double* y2, int M, double max_res, int lane,
+                         int need_sum_from) {
     double acc = 0.0;
     int cnt = 0;
-    for (int k = lane; k < M; k += 64) {
-        const double r = residual_k(kind, m, x1, y1, x2, y2, k);
-        if (r <= max_res) {
-            ++cnt;
-            acc += r;
+    for (int k0 = 0; k0 < M; k0 += 64) {
+        const int k = k0 + lane;
+        bool in = false;
+        if (k < M) {
+            const double r = residual_k(kind, m, x1, y1, x2, y2, k);
+            in = r <= max_res;
+            if (in) acc += r;
         }
+        cnt += __popcll(__ballot(in));
     }
     Support s;
-    s.cnt = wave_sum_int(cnt);
-    s.sum = butterfly(acc);
+    s.cnt = cnt;
+    s.sum = cnt >= need_sum_from ? butterfly(acc) : 1.7976931348623157e308;
     return s;
 }
 
@@ -203,21 +223,85 @@ __device__ __forceinline__ void design_row(int mode, const double* x1, const dou
         r[6] = s_0 * d_1; r[7] = s_1 * d_1; r[8] = d_1;
     }
 }
-// A^T A (9 x 9, symmetric) over `rows` design rows, every entry in det_sum64 order
+// A^T A (9 x 9, symmetric) over `rows` design rows, every entry in det_sum64 order: each lane keeps
+// the 45 partial sums of its strided rows (one pass over the data), then 45 butterflies
 __device__ void accumulate_ata(int mode, const double* x1, const double* y1, const double* x2,
                                const double* y2, int K, int rows, double* ata, int lane) {
+    double acc[45];
+#pragma unroll
+    for (int e = 0; e < 45; ++e) acc[e] = 0.0;
+    for (int k = lane; k < rows; k += 64) {
+        double r[9];
+        design_row(mode, x1, y1, x2, y2, K, k, r);
+        int e = 0;
+#pragma unroll
+        for (int i = 0; i < 9; ++i)
+#pragma unroll
+            for (int j = i; j < 9; ++j) acc[e++] += r[i] * r[j];
+    }
+    int e = 0;
+#pragma unroll
     for (int i = 0; i < 9; ++i)
+#pragma unroll
         for (int j = i; j < 9; ++j) {
-            double acc = 0.0;
-            for (int k = lane; k < rows; k += 64) {
-                double r[9];
-                design_row(mode, x1, y1, x2, y2, K, k, r);
-                acc += r[i] * r[j];
-            }
-            const double s = butterfly(acc);
-            ata[i * 9 + j] = s;
-            ata[j * 9 + i] = s;
+            const double sres = butterfly(acc[e++]);
+            ata[i * 9 + j] = sres;
+            ata[j * 9 + i] = sres;
         }
+}
+
+// Cyclic Jacobi on a symmetric n x n matrix held in LDS, the whole wave cooperating: the
+// rotation parameters are wave-uniform; lanes 0..n-1 update the n entries of the two columns,
+// then of the two rows, lanes 32..32+n-1 the eigenvector columns.  Every element sees exactly the
+// arithmetic of the scalar jacobi_eigen (tvg_math.h) in the same order, so results are
+// bit-identical; only the memory (LDS instead of scratch) and the parallelism differ.
+__device__ void jacobi_eigen_wave(int n, double* A, double* V, int lane) {
+    for (int i = lane; i < n * n; i += 64) V[i] = ((i / n) == (i % n)) ? 1.0 : 0.0;
+    __builtin_amdgcn_wave_barrier();
+    double total = 0.0;
+    for (int i = 0; i < n * n; ++i) total += A[i] * A[i];
+    const double tol = total * 1e-32;
+    for (int sweep = 0; sweep < 40; ++sweep) {
+        double off = 0.0;
+        for (int p = 0; p < n - 1; ++p)
+            for (int q = p + 1; q < n; ++q) off += A[p * n + q] * A[p * n + q];
+        if (!(off > tol)) break;
+        for (int p = 0; p < n - 1; ++p) {
+            for (int q = p + 1; q < n; ++q) {
+                const double apq = A[p * n + q];
+                if (apq == 0.0) continue;
+                const double theta = (A[q * n + q] - A[p * n + p]) / (2.0 * apq);
+                const double t = (theta >= 0.0 ? 1.0 : -1.0) / (dabs(theta) + dsqrt(theta * theta + 1.0));
+                const double c = 1.0 / dsqrt(t * t + 1.0);
+                const double s = t * c;
+                const int k = lane & 31;
+                const bool colA = lane < n, colV = lane >= 32 && k < n;
+                double* Mx = colV ? V : A;
+                double xp = 0.0, xq = 0.0;
+                if (colA || colV) { xp = Mx[k * n + p]; xq = Mx[k * n + q]; }
+                __builtin_amdgcn_wave_barrier();
+                if (colA || colV) {
+                    Mx[k * n + p] = c * xp - s * xq;
+                    Mx[k * n + q] = s * xp + c * xq;
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (colA) { xp = A[p * n + k]; xq = A[q * n + k]; }
+                __builtin_amdgcn_wave_barrier();
+                if (colA) {
+                    A[p * n + k] = c * xp - s * xq;
+                    A[q * n + k] = s * xp + c * xq;
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    }
+}
+// eigenvector of the smallest eigenvalue after jacobi_eigen_wave (first minimum, like the oracle)
+__device__ void smallest_eigvec9_wave(const double* A, const double* V, double* x) {
+    int best = 0;
+    for (int i = 1; i < 9; ++i)
+        if (A[i * 9 + i] < A[best * 9 + best]) best = i;
+    for (int i = 0; i < 9; ++i) x[i] = V[i * 9 + best];
 }
 
 // local estimator on the K inlier correspondences in the I arrays -> models (uniform), count
@@ -240,9 +324,12 @@ __device__ int local_estimate(Wave& w, int kind, int K, double* models) {
             for (int i = 0; i < 5; ++i) { a[i] = ix1[i]; b[i] = iy1[i]; c[i] = ix2[i]; d[i] = iy2[i]; }
             return estimate_e5_minimal(a, b, c, d, models);
         }
-        double ata[81];
-        accumulate_ata(0, ix1, iy1, ix2, iy2, K, K, ata, lane);
-        return e5_from_ata(ata, models);
+        accumulate_ata(0, ix1, iy1, ix2, iy2, K, K, w.jacA, lane);
+        __builtin_amdgcn_wave_barrier();
+        jacobi_eigen_wave(9, w.jacA, w.jacV, lane);
+        double nsp[4 * 9];
+        e5_nullspace_from_eig(w.jacA, w.jacV, nsp);
+        return e5_from_nullspace(nsp, models);
     }
     if (kind == K_H && K == 4) {
         double a[4], b[4], c[4], d[4];
@@ -250,17 +337,24 @@ __device__ int local_estimate(Wave& w, int kind, int K, double* models) {
         estimate_h4(a, b, c, d, models);
         return 1;
     }
-    double T1[9], T2[9], ata[81];
+    double T1[9], T2[9];
+    double* ata = w.jacA;
     double *jx1 = w.arr(W_JX1), *jy1 = w.arr(W_JY1), *jx2 = w.arr(W_JX2), *jy2 = w.arr(W_JY2);
     center_and_normalize(ix1, iy1, K, jx1, jy1, T1, lane);
     center_and_normalize(ix2, iy2, K, jx2, jy2, T2, lane);
     if (kind == K_F8) {
         accumulate_ata(0, jx1, jy1, jx2, jy2, K, K, ata, lane);
-        f8_from_ata(ata, T1, T2, models);
+        __builtin_amdgcn_wave_barrier();
+        jacobi_eigen_wave(9, w.jacA, w.jacV, lane);
+        double f[9];
+        smallest_eigvec9_wave(w.jacA, w.jacV, f);
+        f8_from_vec(f, T1, T2, models);
     } else {
         accumulate_ata(1, jx1, jy1, jx2, jy2, K, 2 * K, ata, lane);
+        __builtin_amdgcn_wave_barrier();
+        jacobi_eigen_wave(9, w.jacA, w.jacV, lane);
         double h[9];
-        smallest_eigvec9(ata, h);
+        smallest_eigvec9_wave(w.jacA, w.jacV, h);
         h_denormalize(h, T1, T2, models);
     }
     return 1;
@@ -321,8 +415,20 @@ __device__ Report lo_ransac(Wave& w, const RansacCfg& cfg, const double* x1, con
     bool best_is_local = false;
     uint32_t dyn_max = (uint32_t)cfg.max_trials;
 
-    // sampler.Initialize(M)
+    // correspondences into LDS when they fit: every scoring pass and every sample gather reads them
+    if ((uint32_t)M <= w.pts_cap) {
+        double *l0 = w.lpts, *l1 = l0 + w.pts_cap, *l2 = l1 + w.pts_cap, *l3 = l2 + w.pts_cap;
+        for (int k = lane; k < M; k += 64) { l0[k] = x1[k]; l1[k] = y1[k]; l2[k] = x2[k]; l3[k] = y2[k]; }
+        __builtin_amdgcn_wave_barrier();
+        x1 = l0; y1 = l1; x2 = l2; y2 = l3;
+    }
+
+    // sampler.Initialize(M).  The first kMin entries of the persistent permutation are touched by
+    // every draw: they live in (wave-uniform) registers, the rest in LDS.
     for (int k = lane; k < M; k += 64) w.perm[k] = (uint16_t)k;
+    uint32_t pr[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) pr[i] = (uint32_t)i;
     __builtin_amdgcn_wave_barrier();
 
     double* models = w.models();
@@ -336,53 +442,101 @@ __device__ Report lo_ransac(Wave& w, const RansacCfg& cfg, const double* x1, con
         __builtin_amdgcn_wave_barrier();
         uint32_t nraw = 0;
         const uint32_t last = (uint32_t)(M - 1);
+        unsigned long long tp0 = __builtin_readcyclecounter();
         for (int t = 0; t < nT; ++t) {
-            for (int i = 0; i < kMin; ++i) {
-                const uint32_t j = rng_uniform(w, (uint32_t)i, last, nraw);
-                const uint16_t a = w.perm[i], b = w.perm[j];
-                __builtin_amdgcn_wave_barrier();
-                w.perm[i] = b;
-                w.perm[j] = a;
-                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 0; i < 7; ++i) {
+                if (i < kMin) {
+                    const uint32_t j = rng_uniform(w, (uint32_t)i, last, nraw);
+                    // swap(perm[i], perm[j])
+                    if (j < (uint32_t)kMin) {
+                        uint32_t vj = pr[0];
+#pragma unroll
+                        for (int q = 1; q < 7; ++q) vj = (j == (uint32_t)q) ? pr[q] : vj;
+                        const uint32_t vi = pr[i];
+#pragma unroll
+                        for (int q = 0; q < 7; ++q) pr[q] = (j == (uint32_t)q) ? vi : pr[q];
+                        pr[i] = vj;
+                    } else {
+                        const uint32_t vj = w.perm[j];
+                        w.perm[j] = (uint16_t)pr[i];
+                        pr[i] = vj;
+                    }
+                }
             }
-            if (lane < kMin) w.sidx[t * 8 + lane] = w.perm[lane];
-            if (lane == 0) w.rawcnt[t] = nraw;
-            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) {
+#pragma unroll
+                for (int i = 0; i < 7; ++i) w.sidx[t * 8 + i] = (uint16_t)pr[i];
+                w.rawcnt[t] = nraw;
+            }
         }
-        // ---- 64 minimal problems, one per lane ------------------------------------------------
+        __builtin_amdgcn_wave_barrier();
+        { const unsigned long long tp1 = __builtin_readcyclecounter(); w.prof[0] += tp1 - tp0; tp0 = tp1; }
+        // ---- 64 minimal problems, one per lane.  F / H / T models stay in the solving lane's
+        //      registers (slot i = i-th root; `valid` marks the ones the estimator returned) and are
+        //      broadcast with __shfl during the replay; E models (up to 10) go through global memory.
         int nmod = 0;
+        unsigned valid = 0;
+        double mym[27];
+#pragma unroll
+        for (int i = 0; i < 27; ++i) mym[i] = 0.0;
         if (lane < nT) {
-            double sx1[7], sy1[7], sx2[7], sy2[7];
-            for (int i = 0; i < kMin; ++i) {
-                const int s = w.sidx[lane * 8 + i];
-                sx1[i] = x1[s]; sy1[i] = y1[s]; sx2[i] = x2[s]; sy2[i] = y2[s];
-            }
-            double* mine = models + (size_t)lane * kMaxModels * 9;
             if (cfg.est == K_F7) {
-                nmod = estimate_f7(sx1, sy1, sx2, sy2, mine);
+                double sx1[7], sy1[7], sx2[7], sy2[7];
+#pragma unroll
+                for (int i = 0; i < 7; ++i) {
+                    const int sI = w.sidx[lane * 8 + i];
+                    sx1[i] = x1[sI]; sy1[i] = y1[sI]; sx2[i] = x2[sI]; sy2[i] = y2[sI];
+                }
+                nmod = estimate_f7(sx1, sy1, sx2, sy2, mym);
+                valid = (1u << nmod) - 1u;
             } else if (cfg.est == K_H) {
-                estimate_h4(sx1, sy1, sx2, sy2, mine);
+                double sx1[4], sy1[4], sx2[4], sy2[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int sI = w.sidx[lane * 8 + i];
+                    sx1[i] = x1[sI]; sy1[i] = y1[sI]; sx2[i] = x2[sI]; sy2[i] = y2[sI];
+                }
+                estimate_h4(sx1, sy1, sx2, sy2, mym);
                 nmod = 1;
+                valid = 1u;
             } else if (cfg.est == K_E5) {
-                nmod = estimate_e5_minimal(sx1, sy1, sx2, sy2, mine);
+                double sx1[5], sy1[5], sx2[5], sy2[5];
+#pragma unroll
+                for (int i = 0; i < 5; ++i) {
+                    const int sI = w.sidx[lane * 8 + i];
+                    sx1[i] = x1[sI]; sy1[i] = y1[sI]; sx2[i] = x2[sI]; sy2[i] = y2[sI];
+                }
+                nmod = estimate_e5_minimal(sx1, sy1, sx2, sy2, models + (size_t)lane * kMaxModels * 9);
             } else {  // K_T: model = dst - src of the single sample
-                for (int i = 0; i < 9; ++i) mine[i] = 0.0;
-                mine[0] = sx2[0] - sx1[0];
-                mine[1] = sy2[0] - sy1[0];
+                const int sI = w.sidx[lane * 8];
+                mym[0] = x2[sI] - x1[sI];
+                mym[1] = y2[sI] - y1[sI];
                 nmod = 1;
+                valid = 1u;
             }
         }
         wave_mem_sync();
+        { const unsigned long long tp1 = __builtin_readcyclecounter(); w.prof[1] += tp1 - tp0; tp0 = tp1; }
         // ---- replay in trial order ------------------------------------------------------------
         for (int t = 0; t < nT && !aborted; ++t) {
             const int trial = chunk + t;
             const int n = __shfl(nmod, t);
             for (int m = 0; m < n; ++m) {
                 double sm[9];
-                const double* src = models + ((size_t)t * kMaxModels + m) * 9;
-                for (int i = 0; i < 9; ++i) sm[i] = src[i];
-                const Support sup = score(cfg.est, sm, x1, y1, x2, y2, M, cfg.max_res, lane);
+                if (cfg.est == K_E5) {
+                    const double* src = models + ((size_t)t * kMaxModels + m) * 9;
+                    for (int i = 0; i < 9; ++i) sm[i] = src[i];
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) {
+                        const double mine = m == 0 ? mym[i] : (m == 1 ? mym[9 + i] : mym[18 + i]);
+                        sm[i] = readlane_f64(mine, t);
+                    }
+                }
+                const Support sup = score(cfg.est, sm, x1, y1, x2, y2, M, cfg.max_res, lane, best.cnt);
                 if (better(sup, best)) {
+                    const unsigned long long tl0 = __builtin_readcyclecounter();
                     best = sup;
                     for (int i = 0; i < 9; ++i) best_model[i] = sm[i];
                     best_is_local = false;
@@ -399,7 +553,7 @@ __device__ Report lo_ransac(Wave& w, const RansacCfg& cfg, const double* x1, con
                             const int prev = best.cnt;
                             for (int q = 0; q < nl; ++q) {
                                 const Support ls = score(cfg.local_est, lm + 9 * q, x1, y1, x2, y2, M,
-                                                         cfg.max_res, lane);
+                                                         cfg.max_res, lane, best.cnt);
                                 if (better(ls, best)) {
                                     best = ls;
                                     for (int i = 0; i < 9; ++i) best_model[i] = lm[9 * q + i];
@@ -412,6 +566,7 @@ __device__ Report lo_ransac(Wave& w, const RansacCfg& cfg, const double* x1, con
                         }
                     }
                     dyn_max = cfg.dyn_tab ? cfg.dyn_tab[best.cnt] : 0xFFFFFFFFu;
+                    w.prof[3] += __builtin_readcyclecounter() - tl0;
                 }
                 if ((uint32_t)trial >= dyn_max && trial >= cfg.min_trials) {
                     aborted = true;
@@ -420,6 +575,7 @@ __device__ Report lo_ransac(Wave& w, const RansacCfg& cfg, const double* x1, con
                 }
             }
         }
+        { const unsigned long long tp1 = __builtin_readcyclecounter(); w.prof[2] += tp1 - tp0; }
         if (aborted) {
             // roll the generator back to where the sequential algorithm stopped drawing
             __builtin_amdgcn_wave_barrier();
@@ -459,6 +615,8 @@ __device__ __noinline__ void process_pair(Wave& w, uint32_t q, const TvgImage* _
                                           TvgOut* __restrict__ out, uint8_t* __restrict__ out_mask) {
     const int lane = w.lane;
     const uint32_t mcap = w.mcap;
+    for (int i = 0; i < 5; ++i) w.prof[i] = 0;
+    const unsigned long long tstart = __builtin_readcyclecounter();
     const TvgPair pr = pairs[q];
     const TvgImage im1 = imgs[pr.slot1], im2 = imgs[pr.slot2];
     const int M = (int)pr.M;
@@ -642,23 +800,32 @@ __device__ __noinline__ void process_pair(Wave& w, uint32_t q, const TvgImage* _
             }
         }
     }
-    if (lane == 0) out[q].g = g;
+    if (lane == 0) {
+        out[q].g = g;
+        w.prof[4] = __builtin_readcyclecounter() - tstart;
+        for (int i = 0; i < 5; ++i) out[q].prof[i] = w.prof[i];
+    }
 }
 
 __global__ __launch_bounds__(256) void tvg_kernel(
     const TvgImage* __restrict__ imgs, const TvgPair* __restrict__ pairs, uint32_t npairs,
     const uint32_t* __restrict__ matches, const uint32_t* __restrict__ trial_tabs,
     const uint32_t* __restrict__ mt_init, TvgParams P, double* __restrict__ ws_all,
-    uint8_t* __restrict__ mask_ws_all, uint32_t mcap, uint32_t* __restrict__ queue_head,
+    uint8_t* __restrict__ mask_ws_all, uint32_t mcap, uint32_t pts_cap, uint32_t* __restrict__ queue_head,
     TvgOut* __restrict__ out, uint8_t* __restrict__ out_mask) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wid = threadIdx.x >> 6;
-    const size_t lds_per_wave = (size_t)(624 + 624 + 64) * 4 + 64 * 8 * 2 + (size_t)((mcap + 7) / 8 * 8) * 2;
+    const size_t lds_per_wave = (size_t)162 * 8 + (size_t)4 * pts_cap * 8 + (size_t)(624 + 624 + 64) * 4 +
+                                64 * 8 * 2 + (size_t)((mcap + 7) / 8 * 8) * 2;
     char* base = smem + (size_t)wid * ((lds_per_wave + 15) / 16 * 16);
     Wave w;
     w.lane = lane;
-    w.mt = reinterpret_cast<uint32_t*>(base);
+    w.jacA = reinterpret_cast<double*>(base);
+    w.jacV = w.jacA + 81;
+    w.lpts = w.jacA + 162;
+    w.pts_cap = pts_cap;
+    w.mt = reinterpret_cast<uint32_t*>(base + (162 + (size_t)4 * pts_cap) * 8);
     w.snap = w.mt + 624;
     w.rawcnt = w.snap + 624;
     w.sidx = reinterpret_cast<uint16_t*>(w.rawcnt + 64);
@@ -680,9 +847,18 @@ __global__ __launch_bounds__(256) void tvg_kernel(
 size_t tvg_ws_doubles_host(uint32_t mcap) { return tvg_ws_doubles(mcap); }
 size_t tvg_ws_mask_bytes_host(uint32_t mcap) { return tvg_ws_bytes_extra(mcap); }
 
-size_t tvg_lds_bytes(uint32_t mcap, int waves) {
-    const size_t per = (size_t)(624 + 624 + 64) * 4 + 64 * 8 * 2 + (size_t)((mcap + 7) / 8 * 8) * 2;
+size_t tvg_lds_bytes(uint32_t mcap, uint32_t pts_cap, int waves) {
+    const size_t per = (size_t)162 * 8 + (size_t)4 * pts_cap * 8 + (size_t)(624 + 624 + 64) * 4 + 64 * 8 * 2 +
+                       (size_t)((mcap + 7) / 8 * 8) * 2;
     return (size_t)waves * ((per + 15) / 16 * 16);
+}
+// how many correspondences of the active RANSAC fit in LDS next to everything else (4 waves/block)
+uint32_t tvg_pts_cap(uint32_t mcap) {
+    const size_t budget = 160 * 1024 / 4;
+    const size_t other = tvg_lds_bytes(mcap, 0, 1) + 64;
+    if (other >= budget) return 0;
+    const size_t cap = (budget - other) / 32 / 64 * 64;
+    return (uint32_t)(cap < mcap ? cap : mcap);
 }
 
 hipError_t launch_tvg(const TvgImage* imgs, const TvgPair* pairs, uint32_t npairs,
@@ -693,14 +869,15 @@ hipError_t launch_tvg(const TvgImage* imgs, const TvgPair* pairs, uint32_t npair
     if (npairs == 0) return hipSuccess;
     const int waves_per_block = 4;
     const uint32_t blocks = (num_waves + waves_per_block - 1) / waves_per_block;
-    const size_t lds = tvg_lds_bytes(mcap, waves_per_block);
+    const uint32_t pts_cap = tvg_pts_cap(mcap);
+    const size_t lds = tvg_lds_bytes(mcap, pts_cap, waves_per_block);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tvg_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(queue_head, 0, sizeof(uint32_t), s);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(tvg_kernel, dim3(blocks), dim3(64 * waves_per_block), lds, s, imgs, pairs,
-                       npairs, matches, trial_tabs, mt_init, P, ws, mask_ws, mcap, queue_head, out,
+                       npairs, matches, trial_tabs, mt_init, P, ws, mask_ws, mcap, pts_cap, queue_head, out,
                        out_mask);
     return hipGetLastError();
 }

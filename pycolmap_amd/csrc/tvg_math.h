@@ -156,6 +156,73 @@ AMC_HD void nullspace9(int R, double* a, double* ns) {
     }
 }
 
+// Same algorithm, fully unrolled with compile-time indices: the matrix lives in registers, row and
+// column swaps are predicated selects (no dynamic indexing => no scratch memory on the GPU).
+// Identical arithmetic and identical pivot choice (first maximum in row-major scan order).
+template <int R>
+AMC_HD void nullspace_reg(double (&a)[R][9], double (&ns)[9 - R][9]) {
+    int perm[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) perm[j] = j;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        int pi = r, pj = r;
+        double pv = -1.0;
+#pragma unroll
+        for (int i = r; i < R; ++i)
+#pragma unroll
+            for (int j = r; j < 9; ++j) {
+                const double v = dabs(a[i][j]);
+                const bool g = v > pv;
+                pv = g ? v : pv;
+                pi = g ? i : pi;
+                pj = g ? j : pj;
+            }
+#pragma unroll
+        for (int i = r + 1; i < R; ++i) {
+            const bool sw = (pi == i);
+#pragma unroll
+            for (int j = 0; j < 9; ++j) {
+                const double t = a[r][j], u = a[i][j];
+                a[r][j] = sw ? u : t;
+                a[i][j] = sw ? t : u;
+            }
+        }
+#pragma unroll
+        for (int j = r + 1; j < 9; ++j) {
+            const bool sw = (pj == j);
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+                const double t = a[i][r], u = a[i][j];
+                a[i][r] = sw ? u : t;
+                a[i][j] = sw ? t : u;
+            }
+            const int tp = perm[r], up = perm[j];
+            perm[r] = sw ? up : tp;
+            perm[j] = sw ? tp : up;
+        }
+        const double inv = 1.0 / a[r][r];
+#pragma unroll
+        for (int j = 0; j < 9; ++j) a[r][j] = a[r][j] * inv;
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            if (i == r) continue;
+            const double f = a[i][r];
+#pragma unroll
+            for (int j = 0; j < 9; ++j) a[i][j] = a[i][j] - f * a[r][j];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 9 - R; ++k)
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            double v = (perm[R + k] == j) ? 1.0 : 0.0;
+#pragma unroll
+            for (int i = 0; i < R; ++i) v = (perm[i] == j) ? -a[i][R + k] : v;
+            ns[k][j] = v;
+        }
+}
+
 // ---- real roots, ascending --------------------------------------------------------------------
 AMC_HD double poly_eval(const double* c, int deg, double x) {
     double v = c[deg];
@@ -223,18 +290,19 @@ AMC_HD int real_roots(const double* c_in, int deg_in, double* roots) {
 // x1/y1: image-1 coords of the 7 samples, x2/y2: image-2.  Returns #models (<= 3), row-major.
 AMC_HD int estimate_f7(const double* x1s, const double* y1s, const double* x2s, const double* y2s,
                        double* models /* 3 x 9 */) {
-    double A[7 * 9];
+    double A[7][9];
+#pragma unroll
     for (int i = 0; i < 7; ++i) {
         const double x0 = x1s[i], y0 = y1s[i], x1 = x2s[i], y1 = y2s[i];
-        double* r = A + i * 9;
-        r[0] = x1 * x0; r[1] = x1 * y0; r[2] = x1;
-        r[3] = y1 * x0; r[4] = y1 * y0; r[5] = y1;
-        r[6] = x0; r[7] = y0; r[8] = 1;
+        A[i][0] = x1 * x0; A[i][1] = x1 * y0; A[i][2] = x1;
+        A[i][3] = y1 * x0; A[i][4] = y1 * y0; A[i][5] = y1;
+        A[i][6] = x0; A[i][7] = y0; A[i][8] = 1;
     }
-    double ns[2 * 9];
-    nullspace9(7, A, ns);
+    double ns[2][9];
+    nullspace_reg<7>(A, ns);
     double f1[9], f2[9];
-    for (int i = 0; i < 9; ++i) { f2[i] = ns[9 + i]; f1[i] = ns[i] - f2[i]; }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { f2[i] = ns[1][i]; f1[i] = ns[0][i] - f2[i]; }
     // det(lambda f1 + f2): entries e = f2 + f1 lambda; 2x2 minors (degree 2), then expansion
     double mn[3][3];
     const int mi[3][4] = {{4, 8, 5, 7}, {3, 8, 5, 6}, {3, 7, 4, 6}};
@@ -253,25 +321,33 @@ AMC_HD int estimate_f7(const double* x1s, const double* y1s, const double* x2s, 
         c[2] += sg[m] * (e0 * mn[m][2] + e1 * mn[m][1]);
         c[3] += sg[m] * (e1 * mn[m][2]);
     }
-    double roots[3];
+    double roots[3] = {0.0, 0.0, 0.0};
     const int nr = real_roots(c, 3, roots);
+    // models are the accepted roots in ascending order; compaction with predicated static slots
     int nm = 0;
-    for (int i = 0; i < nr; ++i) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
         const double lambda = roots[i];
-        double* F = models + 9 * nm;
+        double F[9];
+#pragma unroll
         for (int k = 0; k < 9; ++k) F[k] = lambda * f1[k] + f2[k];
-        if (dabs(F[8]) < 1e-10) continue;
+        const bool ok = (i < nr) && !(dabs(F[8]) < 1e-10);
         const double inv = F[8];
+#pragma unroll
         for (int k = 0; k < 9; ++k) F[k] = F[k] / inv;
-        ++nm;
+#pragma unroll
+        for (int sl = 0; sl < 3; ++sl) {
+            const bool put = ok && (nm == sl);
+#pragma unroll
+            for (int k = 0; k < 9; ++k) models[9 * sl + k] = put ? F[k] : models[9 * sl + k];
+        }
+        nm += ok ? 1 : 0;
     }
     return nm;
 }
 
 // ---- 8-point tail: from A^T A of the normalised design matrix to F ----------------------------
-AMC_HD void f8_from_ata(double* ata, const double* T1, const double* T2, double* F) {
-    double f[9];
-    smallest_eigvec9(ata, f);
+AMC_HD void f8_from_vec(const double* f, const double* T1, const double* T2, double* F) {
     double Fh[9], Ft[9], ftf[9], v[9];
     for (int k = 0; k < 9; ++k) Fh[k] = f[k];
     mat3_t(Fh, Ft);
@@ -290,6 +366,11 @@ AMC_HD void f8_from_ata(double* ata, const double* T1, const double* T2, double*
     mat3_t(T2, T2t);
     mat3_mul(T2t, Fr, tmp);
     mat3_mul(tmp, T1, F);
+}
+AMC_HD void f8_from_ata(double* ata, const double* T1, const double* T2, double* F) {
+    double f[9];
+    smallest_eigvec9(ata, f);
+    f8_from_vec(f, T1, T2, F);
 }
 
 // ---- homography tail: H = T2^-1 * Hhat * T1 ---------------------------------------------------
@@ -335,19 +416,18 @@ AMC_HD void estimate_h4(const double* x1, const double* y1, const double* x2, co
     double n1x[4], n1y[4], n2x[4], n2y[4], T1[9], T2[9];
     normalize4(x1, y1, n1x, n1y, T1);
     normalize4(x2, y2, n2x, n2y, T2);
-    double A[8 * 9];
+    double A[8][9];
+#pragma unroll
     for (int i = 0; i < 4; ++i) {
         const double s_0 = n1x[i], s_1 = n1y[i], d_0 = n2x[i], d_1 = n2y[i];
-        double* ra = A + i * 9;
-        double* rb = A + (4 + i) * 9;
-        ra[0] = -s_0; ra[1] = -s_1; ra[2] = -1; ra[3] = 0; ra[4] = 0; ra[5] = 0;
-        ra[6] = s_0 * d_0; ra[7] = s_1 * d_0; ra[8] = d_0;
-        rb[0] = 0; rb[1] = 0; rb[2] = 0; rb[3] = -s_0; rb[4] = -s_1; rb[5] = -1;
-        rb[6] = s_0 * d_1; rb[7] = s_1 * d_1; rb[8] = d_1;
+        A[i][0] = -s_0; A[i][1] = -s_1; A[i][2] = -1; A[i][3] = 0; A[i][4] = 0; A[i][5] = 0;
+        A[i][6] = s_0 * d_0; A[i][7] = s_1 * d_0; A[i][8] = d_0;
+        A[4 + i][0] = 0; A[4 + i][1] = 0; A[4 + i][2] = 0; A[4 + i][3] = -s_0; A[4 + i][4] = -s_1; A[4 + i][5] = -1;
+        A[4 + i][6] = s_0 * d_1; A[4 + i][7] = s_1 * d_1; A[4 + i][8] = d_1;
     }
-    double h[9];
-    nullspace9(8, A, h);
-    h_denormalize(h, T1, T2, H);
+    double h[1][9];
+    nullspace_reg<8>(A, h);
+    h_denormalize(h[0], T1, T2, H);
 }
 
 // ---- 5-point essential matrix -------------------------------------------------------------------
@@ -476,29 +556,38 @@ AMC_HD int e5_from_nullspace(const double* nsp, double* models /* 10 x 9 */) {
 // minimal 5-point
 AMC_HD int estimate_e5_minimal(const double* x1, const double* y1, const double* x2, const double* y2,
                                double* models) {
-    double A[5 * 9];
+    double A[5][9];
+#pragma unroll
     for (int i = 0; i < 5; ++i) {
-        double* r = A + i * 9;
-        r[0] = x2[i] * x1[i]; r[1] = x2[i] * y1[i]; r[2] = x2[i];
-        r[3] = y2[i] * x1[i]; r[4] = y2[i] * y1[i]; r[5] = y2[i];
-        r[6] = x1[i]; r[7] = y1[i]; r[8] = 1;
+        A[i][0] = x2[i] * x1[i]; A[i][1] = x2[i] * y1[i]; A[i][2] = x2[i];
+        A[i][3] = y2[i] * x1[i]; A[i][4] = y2[i] * y1[i]; A[i][5] = y2[i];
+        A[i][6] = x1[i]; A[i][7] = y1[i]; A[i][8] = 1;
     }
+    double ns[4][9];
+    nullspace_reg<5>(A, ns);
     double nsp[4 * 9];
-    nullspace9(5, A, nsp);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int j = 0; j < 9; ++j) nsp[k * 9 + j] = ns[k][j];
     return e5_from_nullspace(nsp, models);
 }
 // least-squares 5-point (local optimisation): 4 smallest eigenvectors of A^T A
-AMC_HD int e5_from_ata(double* ata, double* models) {
-    double v[81];
-    jacobi_eigen(9, ata, v);
+// 4-D "null space" of the least-squares 5-point: the 4 smallest eigenvectors of A^T A, given its
+// eigen-decomposition (ata: eigenvalues on the diagonal, v: eigenvectors in columns)
+AMC_HD void e5_nullspace_from_eig(const double* ata, const double* v, double* nsp) {
     int order[9];
     for (int i = 0; i < 9; ++i) order[i] = i;
     for (int i = 0; i < 9; ++i)
         for (int j = i + 1; j < 9; ++j)
             if (ata[order[j] * 9 + order[j]] < ata[order[i] * 9 + order[i]]) { const int t = order[i]; order[i] = order[j]; order[j] = t; }
-    double nsp[4 * 9];
     for (int k = 0; k < 4; ++k)
         for (int i = 0; i < 9; ++i) nsp[k * 9 + i] = v[i * 9 + order[3 - k]];
+}
+AMC_HD int e5_from_ata(double* ata, double* models) {
+    double v[81], nsp[4 * 9];
+    jacobi_eigen(9, ata, v);
+    e5_nullspace_from_eig(ata, v, nsp);
     return e5_from_nullspace(nsp, models);
 }
 

@@ -6,6 +6,7 @@ extern "C" {
 int shim_estimate_f7(const double* p1, const double* p2, double* models) {
     double x1[7], y1[7], x2[7], y2[7];
     for (int i = 0; i < 7; ++i) { x1[i] = p1[2 * i]; y1[i] = p1[2 * i + 1]; x2[i] = p2[2 * i]; y2[i] = p2[2 * i + 1]; }
+    for (int i = 0; i < 27; ++i) models[i] = 0.0;
     return estimate_f7(x1, y1, x2, y2, models);
 }
 int shim_estimate_h4(const double* p1, const double* p2, double* models) {

@@ -1,0 +1,80 @@
+"""world_size-2 gloo tests of the N>1 path: pair sharding + the all-gather of match tables
+(pycolmap_amd/distributed.py).  The per-rank compute is the CPU oracle here (no GPU in this
+container); on the GPU box bench.py runs the same functions over RCCL with libamc.so."""
+import os
+import socket
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, str(ROOT))
+    sys.path.insert(0, str(ROOT / "tests"))
+    import torch.distributed as dist
+
+    import oracle_lib
+    from pycolmap_amd import distributed as D
+    from pycolmap_amd import synth
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(0)            # every rank builds the same replicated arena
+    imgs = synth.scene_images(rng, 7, 96, num_landmarks=160, visible_frac=0.5)
+    imgs.append(np.zeros((0, 128), np.uint8))
+    s1, s2 = synth.exhaustive_pairs(len(imgs))
+    a, b, mine = D.shard_pairs(s1, s2, rank, world)
+    off, m = oracle_lib.match_pairs(imgs, a, b, threads=1)
+    g_off, g_m = D.all_gather_match_tables(mine, off, m)
+    np.savez(Path(out_dir) / f"rank{rank}.npz", g_off=g_off, g_m=g_m, mine=mine)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_match_tables_equal_single_process(tmp_path, world):
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    sys.path.insert(0, str(ROOT / "tests"))
+    import oracle_lib
+    from pycolmap_amd import synth
+    rng = np.random.default_rng(0)
+    imgs = synth.scene_images(rng, 7, 96, num_landmarks=160, visible_frac=0.5)
+    imgs.append(np.zeros((0, 128), np.uint8))
+    s1, s2 = synth.exhaustive_pairs(len(imgs))
+    want_off, want_m = oracle_lib.match_pairs(imgs, s1, s2, threads=2)
+    assert want_off[-1] > 50
+    covered = []
+    for r in range(world):
+        z = np.load(tmp_path / f"rank{r}.npz")
+        np.testing.assert_array_equal(z["g_off"], want_off)     # every rank holds the whole graph
+        np.testing.assert_array_equal(z["g_m"], want_m)
+        covered.append(z["mine"])
+    allidx = np.concatenate(covered)
+    assert sorted(allidx.tolist()) == list(range(len(s1)))       # shards partition the pair list
+
+
+def test_shard_pairs_groups_by_streamed_image():
+    from pycolmap_amd import distributed as D
+    from pycolmap_amd import synth
+    s1, s2 = synth.exhaustive_pairs(40)
+    parts = [D.shard_pairs(s1, s2, r, 4) for r in range(4)]
+    sizes = [len(p[0]) for p in parts]
+    assert sum(sizes) == len(s1) and max(sizes) - min(sizes) <= 1 + (len(s1) % 4 != 0) * 4
+    for a, b, idx in parts:
+        assert np.all(np.diff(b.astype(np.int64)) >= 0)          # sorted by image 2 within a shard
+        np.testing.assert_array_equal(s1[idx], a)
+    assert D.shard_pairs(s1[:0], s2[:0], 0, 2)[0].size == 0
