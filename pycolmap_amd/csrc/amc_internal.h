@@ -132,6 +132,8 @@ struct TvgParams {
 };
 size_t tvg_ws_doubles_host(uint32_t mcap);
 size_t tvg_ws_mask_bytes_host(uint32_t mcap);
+// target occupancy of the verification kernel (waves per SIMD): sets its VGPR budget and LDS share
+constexpr int kTvgWavesPerSimd = 1;
 size_t tvg_lds_bytes(uint32_t mcap, uint32_t pts_cap, int waves);
 uint32_t tvg_pts_cap(uint32_t mcap);
 hipError_t launch_tvg(const TvgImage* imgs, const TvgPair* pairs, uint32_t npairs,

@@ -807,7 +807,7 @@ __device__ __noinline__ void process_pair(Wave& w, uint32_t q, const TvgImage* _
     }
 }
 
-__global__ __launch_bounds__(256) void tvg_kernel(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(kTvgWavesPerSimd, kTvgWavesPerSimd))) void tvg_kernel(
     const TvgImage* __restrict__ imgs, const TvgPair* __restrict__ pairs, uint32_t npairs,
     const uint32_t* __restrict__ matches, const uint32_t* __restrict__ trial_tabs,
     const uint32_t* __restrict__ mt_init, TvgParams P, double* __restrict__ ws_all,
@@ -854,7 +854,7 @@ size_t tvg_lds_bytes(uint32_t mcap, uint32_t pts_cap, int waves) {
 }
 // how many correspondences of the active RANSAC fit in LDS next to everything else (4 waves/block)
 uint32_t tvg_pts_cap(uint32_t mcap) {
-    const size_t budget = 160 * 1024 / 4;
+    const size_t budget = 160 * 1024 / (4 * kTvgWavesPerSimd);
     const size_t other = tvg_lds_bytes(mcap, 0, 1) + 64;
     if (other >= budget) return 0;
     const size_t cap = (budget - other) / 32 / 64 * 64;
