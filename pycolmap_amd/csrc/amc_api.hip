@@ -736,6 +736,11 @@ int amc_verify_pairs(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, s
     P.watermark_min_inlier_ratio = o.watermark_min_inlier_ratio;
     P.watermark_border_size = o.watermark_border_size;
     P.max_error = o.ransac.max_error;
+    {
+        const char* e = std::getenv("AMC_TVG_SLOW_SAMPLER");
+        P.force_slow_sampler = (e && e[0] == '1') ? 1 : 0;
+        P.pad_ = 0;
+    }
     if (o.detect_watermark && P.max_trials[3] > P.min_num_trials)
         return fail(AMC_E_INVALID, "amc_verify_pairs: unsupported option combination: the watermark RANSAC "
                     "may run %d trials > min_num_trials %d (its dynamic trial count is not tabulated)",

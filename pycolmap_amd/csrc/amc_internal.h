@@ -129,6 +129,8 @@ struct TvgParams {
     int32_t max_trials[4];  // E, F, H, watermark translation — clamped as the RANSAC ctor does
     double min_E_F_inlier_ratio, max_H_inlier_ratio, watermark_min_inlier_ratio,
         watermark_border_size, max_error;
+    int32_t force_slow_sampler;  // test hook (AMC_TVG_SLOW_SAMPLER=1): draw-by-draw sampler path only
+    int32_t pad_;
 };
 size_t tvg_ws_doubles_host(uint32_t mcap);
 size_t tvg_ws_mask_bytes_host(uint32_t mcap);

@@ -32,30 +32,44 @@ __device__ __forceinline__ int kmin_of(int kind) {
 }
 
 // per-wave global workspace (doubles), arrays of length Mcap each
-enum : int { W_X1 = 0, W_Y1, W_X2, W_Y2, W_NX1, W_NY1, W_NX2, W_NY2, W_IX1, W_IY1, W_IX2, W_IY2,
-             W_JX1, W_JY1, W_JX2, W_JY2, W_NUM_ARRAYS };
+enum : int { W_X1 = 0, W_Y1, W_X2, W_Y2, W_NX1, W_NY1, W_NX2, W_NY2, W_NUM_ARRAYS };
 constexpr int kMaxModels = 10;
 constexpr int kModelDoubles = 64 * kMaxModels * 9;
 
 __host__ __device__ inline size_t tvg_ws_doubles(uint32_t mcap) {
     return (size_t)W_NUM_ARRAYS * mcap + kModelDoubles;
 }
+// LDS bytes of one wave: jacA + jacV | points | mt, snap, rawcnt | sidx | perm | inl
+__host__ __device__ inline size_t tvg_lds_per_wave(uint32_t mcap, uint32_t pts_cap) {
+    const size_t per = (size_t)162 * 8 + (size_t)4 * pts_cap * 8 + (size_t)(624 + 624 + 64) * 4 + 64 * 8 * 2 +
+                       (size_t)((mcap + 7) / 8 * 8) * 2 * 2;
+    return (per + 15) / 16 * 16;
+}
 __host__ __device__ inline size_t tvg_ws_bytes_extra(uint32_t mcap) { return (size_t)4 * mcap; }  // 3 masks + pad
+
+// LDS objects are addressed through address-space-3 pointers so that every access is a ds_*
+// instruction (a generic pointer makes the compiler emit flat_* loads, which take the
+// vector-memory path and cost several hundred cycles each at one wave per SIMD).
+#define AMC_LDS __attribute__((address_space(3)))
+typedef AMC_LDS double lds_f64;
+typedef AMC_LDS uint32_t lds_u32;
+typedef AMC_LDS uint16_t lds_u16;
 
 struct Wave {
     int lane;
     unsigned long long prof[5];
     // LDS
-    uint32_t* mt;      // 624
-    uint32_t* snap;    // 624
-    uint16_t* sidx;    // 64 x 8
-    uint32_t* rawcnt;  // 64
-    uint16_t* perm;    // mcap
-    double* lpts;      // 4 x pts_cap: the active RANSAC's correspondences, when they fit (LDS)
+    lds_u32* mt;      // 624
+    lds_u32* snap;    // 624
+    lds_u16* sidx;    // 64 x 8
+    lds_u32* rawcnt;  // 64
+    lds_u16* perm;    // mcap
+    lds_u16* inl;     // mcap: ordered inlier index list of the local-optimisation step
+    lds_f64* lpts;    // 4 x pts_cap: the active RANSAC's correspondences, when they fit
     uint32_t pts_cap;
-    double* jacA;      // 81: A^T A / eigenvalues (LDS)
-    double* jacV;      // 81: eigenvectors (LDS)
-    int mti;           // uniform
+    lds_f64* jacA;    // 81: A^T A / eigenvalues
+    lds_f64* jacV;    // 81: eigenvectors
+    int mti;          // uniform
     // global workspace
     double* ws;
     uint8_t* masks;    // 3 x mcap
@@ -69,6 +83,13 @@ struct Wave {
 __device__ __forceinline__ void wave_mem_sync() {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     __builtin_amdgcn_wave_barrier();
+}
+// LDS hand-off inside the wave: LDS operations of a wave complete in order, the barrier only
+// stops the compiler from reordering across it
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 // broadcast lane `src`'s double to the whole wave through the scalar unit (src is wave-uniform)
@@ -92,7 +113,7 @@ __device__ __forceinline__ int wave_sum_int(int v) {
 }
 
 // ---- mt19937 (wave-cooperative twist, uniform extraction) ---------------------------------------
-__device__ void mt_twist(uint32_t* mt, int lane) {
+__device__ __noinline__ void mt_twist(lds_u32* mt, int lane) {
     for (int base = 0; base < 624; base += 64) {
         const int i = base + lane;
         uint32_t y = 0, m397 = 0;
@@ -101,45 +122,194 @@ __device__ void mt_twist(uint32_t* mt, int lane) {
             y = (a & 0x80000000u) | (b & 0x7fffffffu);
             m397 = mt[(i + 397) % 624];
         }
-        __builtin_amdgcn_wave_barrier();  // every lane has read before any lane writes
+        wave_lds_sync();  // every lane has read before any lane writes
         if (i < 624) mt[i] = m397 ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
-        __builtin_amdgcn_wave_barrier();
+        wave_lds_sync();
     }
 }
-__device__ __forceinline__ uint32_t rng_raw(Wave& w, uint32_t& nraw) {
-    if (w.mti >= 624) {
-        mt_twist(w.mt, w.lane);
-        w.mti = 0;
+// ---- RandomSampler::Sample for a chunk of nT consecutive trials -----------------------------------
+// The sample stream does not depend on the data, so a chunk's draws are produced ahead of the
+// trials that use them.  Per draw the sequential algorithm does j = uniform_int(i, M-1) and
+// swap(perm[i], perm[j]).  Fast path: all nT*kMin raw words are tempered and turned into j by
+// the lanes in parallel (Lemire's multiply-shift; the rejection branch `low < range` has
+// probability range / 2^32 per draw); only the swaps stay sequential, as wave-uniform scalar code
+// with the trial's LDS reads and writes in flight together.  If any draw of the chunk needs the
+// rejection branch the generator is restored and the chunk is redone draw by draw, exactly as
+// libstdc++ does it.  perm[0..kMin) lives in registers (pr), the rest in LDS.
+struct SamplerState {
+    int mti;
+    uint32_t pr[7];
+};
+__device__ __forceinline__ uint32_t sgpr(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
+__device__ __noinline__ SamplerState sample_chunk(lds_u32* mt, const lds_u32* snap, lds_u16* perm, lds_u16* sidx,
+                                                  lds_u32* rawcnt, SamplerState st, int M, int kMin, int nT,
+                                                  int lane, int force_slow) {
+    const int snap_mti = st.mti;
+    const int need = nT * kMin;
+    // ---- parallel: tempered raw word -> j, for the whole chunk ----
+    bool slowflag = force_slow != 0;
+    {
+        int mti = st.mti, done = 0;
+        while (done < need) {
+            if (mti >= 624) {
+                mt_twist(mt, lane);
+                mti = 0;
+            }
+            const int take = min(624 - mti, need - done);
+            for (int n0 = 0; n0 < take; n0 += 64) {
+                const int n = n0 + lane;
+                if (n < take) {
+                    const int gdraw = done + n;
+                    const int t = gdraw / kMin, i = gdraw - t * kMin;
+                    const uint32_t range = (uint32_t)(M - i);
+                    const uint64_t product = (uint64_t)mt_temper(mt[mti + n]) * (uint64_t)range;
+                    if ((uint32_t)product < range) slowflag = true;
+                    sidx[t * 8 + i] = (uint16_t)((uint32_t)i + (uint32_t)(product >> 32));
+                }
+            }
+            mti += take;
+            done += take;
+        }
+        st.mti = mti;
     }
-    ++nraw;
-    return mt_temper(w.mt[w.mti++]);
-}
-// std::uniform_int_distribution<uint32_t>(lo, hi) on mt19937, libstdc++ >= 11 (Lemire)
-__device__ uint32_t rng_uniform(Wave& w, uint32_t lo, uint32_t hi, uint32_t& nraw) {
-    const uint32_t urange = hi - lo;
-    if (urange == 0xFFFFFFFFu) return rng_raw(w, nraw) + lo;
-    const uint32_t range = urange + 1u;
-    uint64_t product = (uint64_t)rng_raw(w, nraw) * (uint64_t)range;
-    uint32_t low = (uint32_t)product;
-    if (low < range) {
-        const uint32_t threshold = (0u - range) % range;
-        while (low < threshold) {
-            product = (uint64_t)rng_raw(w, nraw) * (uint64_t)range;
-            low = (uint32_t)product;
+    wave_lds_sync();
+    if (__ballot(slowflag) == 0ull) {
+        // ---- sequential swaps, wave-uniform ----
+        uint32_t jrow = lane < 8 ? (uint32_t)sidx[lane] : 0u;
+        for (int t = 0; t < nT; ++t) {
+            const uint32_t jcur = jrow;
+            if (t + 1 < nT) jrow = lane < 8 ? (uint32_t)sidx[(t + 1) * 8 + lane] : 0u;  // prefetch
+            uint32_t j[7];
+            bool head = false;  // some j falls into the register-resident head of the permutation
+#pragma unroll
+            for (int i = 0; i < 7; ++i) {
+                j[i] = i < kMin ? (uint32_t)__builtin_amdgcn_readlane((int)jcur, i) : 0xFFFFu;
+                head |= j[i] < (uint32_t)kMin;
+            }
+            if (!head) {
+                uint32_t v[7];
+#pragma unroll
+                for (int i = 0; i < 7; ++i)
+                    if (i < kMin) {
+                        v[i] = perm[j[i]];
+                        perm[j[i]] = (uint16_t)st.pr[i];
+                    }
+#pragma unroll
+                for (int i = 0; i < 7; ++i)
+                    if (i < kMin) st.pr[i] = sgpr(v[i]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 7; ++i) {
+                    if (i < kMin) {
+                        if (j[i] < (uint32_t)kMin) {
+                            uint32_t vj = st.pr[0];
+#pragma unroll
+                            for (int q = 1; q < 7; ++q) vj = (j[i] == (uint32_t)q) ? st.pr[q] : vj;
+                            const uint32_t vi = st.pr[i];
+#pragma unroll
+                            for (int q = 0; q < 7; ++q) st.pr[q] = (j[i] == (uint32_t)q) ? vi : st.pr[q];
+                            st.pr[i] = vj;
+                        } else {
+                            const uint32_t vj = sgpr(perm[j[i]]);
+                            perm[j[i]] = (uint16_t)st.pr[i];
+                            st.pr[i] = vj;
+                        }
+                    }
+                }
+            }
+            if (lane == 0) {
+#pragma unroll
+                for (int i = 0; i < 7; ++i) sidx[t * 8 + i] = (uint16_t)st.pr[i];
+                rawcnt[t] = (uint32_t)((t + 1) * kMin);
+            }
+        }
+        wave_lds_sync();
+        return st;
+    }
+    // ---- a draw hit the rejection branch: restore the generator, redo the chunk draw by draw ----
+    for (int i = lane; i < 624; i += 64) mt[i] = snap[i];
+    wave_lds_sync();
+    int mti = snap_mti;
+    uint32_t nraw = 0;
+    for (int t = 0; t < nT; ++t) {
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            if (i < kMin) {
+                const uint32_t range = (uint32_t)(M - i);
+                uint64_t product;
+                uint32_t low;
+                {
+                    if (mti >= 624) { mt_twist(mt, lane); mti = 0; }
+                    ++nraw;
+                    product = (uint64_t)mt_temper(sgpr(mt[mti++])) * (uint64_t)range;
+                    low = (uint32_t)product;
+                }
+                if (low < range) {
+                    const uint32_t threshold = (0u - range) % range;
+                    while (low < threshold) {
+                        if (mti >= 624) { mt_twist(mt, lane); mti = 0; }
+                        ++nraw;
+                        product = (uint64_t)mt_temper(sgpr(mt[mti++])) * (uint64_t)range;
+                        low = (uint32_t)product;
+                    }
+                }
+                const uint32_t jj = (uint32_t)(product >> 32) + (uint32_t)i;
+                if (jj < (uint32_t)kMin) {
+                    uint32_t vj = st.pr[0];
+#pragma unroll
+                    for (int q = 1; q < 7; ++q) vj = (jj == (uint32_t)q) ? st.pr[q] : vj;
+                    const uint32_t vi = st.pr[i];
+#pragma unroll
+                    for (int q = 0; q < 7; ++q) st.pr[q] = (jj == (uint32_t)q) ? vi : st.pr[q];
+                    st.pr[i] = vj;
+                } else {
+                    const uint32_t vj = sgpr(perm[jj]);
+                    perm[jj] = (uint16_t)st.pr[i];
+                    st.pr[i] = vj;
+                }
+            }
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < 7; ++i) sidx[t * 8 + i] = (uint16_t)st.pr[i];
+            rawcnt[t] = nraw;
         }
     }
-    return (uint32_t)(product >> 32) + lo;
+    st.mti = mti;
+    wave_lds_sync();
+    return st;
 }
 
-// ---- residual of correspondence k under a wave-uniform model ------------------------------------
-__device__ __forceinline__ double residual_k(int kind, const double* m, const double* x1,
-                                             const double* y1, const double* x2, const double* y2,
-                                             int k) {
-    if (kind == K_H) return h_residual(m, x1[k], y1[k], x2[k], y2[k]);
-    if (kind == K_T) return t_residual(m, x1[k], y1[k], x2[k], y2[k]);
-    return sampson(m, x1[k], y1[k], x2[k], y2[k]);
+// ---- the active RANSAC's correspondences: LDS copy when it fits, global arrays otherwise ---------
+struct Pts {
+    const lds_f64* l;  // x1 | y1 | x2 | y2, each `ls` long
+    const double* g;   // x1 | y1 | x2 | y2, each `gs` long
+    uint32_t ls, gs;
+    bool lds;          // wave-uniform
+};
+template <bool L>
+__device__ __forceinline__ void load_pt(const Pts& P, int k, double& a, double& b, double& c, double& d) {
+    if (L) {
+        a = P.l[k]; b = P.l[P.ls + k]; c = P.l[2 * P.ls + k]; d = P.l[3 * P.ls + k];
+    } else {
+        a = P.g[k]; b = P.g[P.gs + k]; c = P.g[2 * (size_t)P.gs + k]; d = P.g[3 * (size_t)P.gs + k];
+    }
+}
+__device__ __forceinline__ void load_pt_any(const Pts& P, int k, double& a, double& b, double& c, double& d) {
+    if (P.lds) load_pt<true>(P, k, a, b, c, d);
+    else load_pt<false>(P, k, a, b, c, d);
 }
 
+__device__ __forceinline__ double residual_of(int kind, const double* m, double a, double b, double c, double d) {
+    if (kind == K_H) return h_residual(m, a, b, c, d);
+    if (kind == K_T) return t_residual(m, a, b, c, d);
+    return sampson(m, a, b, c, d);
+}
+
+struct Model9 {
+    double v[9];
+};
 struct Support {
     int cnt;
     double sum;
@@ -151,16 +321,19 @@ __device__ __forceinline__ bool better(const Support a, const Support b) {
 // InlierSupportMeasurer::Evaluate.  The count comes from ballots (wave-uniform by construction);
 // the residual sum is only ever consulted when the count ties or beats the best so far
 // (Compare()), so its 64-way butterfly is skipped otherwise (`need_sum_from` = that count).
-__device__ Support score(int kind, const double* m, const double* x1, const double* y1,
-                         const double* x2, const double* y2, int M, double max_res, int lane,
-                         int need_sum_from) {
+template <bool L, int KIND>
+__device__ __forceinline__ Support score_impl(const double* m, const Pts& P, int M, double max_res, int lane,
+                                              int need_sum_from) {
     double acc = 0.0;
     int cnt = 0;
     for (int k0 = 0; k0 < M; k0 += 64) {
         const int k = k0 + lane;
         bool in = false;
         if (k < M) {
-            const double r = residual_k(kind, m, x1, y1, x2, y2, k);
+            double a, b, c, d;
+            load_pt<L>(P, k, a, b, c, d);
+            const double r = KIND == K_H ? h_residual(m, a, b, c, d)
+                                         : (KIND == K_T ? t_residual(m, a, b, c, d) : sampson(m, a, b, c, d));
             in = r <= max_res;
             if (in) acc += r;
         }
@@ -171,17 +344,71 @@ __device__ Support score(int kind, const double* m, const double* x1, const doub
     s.sum = cnt >= need_sum_from ? butterfly(acc) : 1.7976931348623157e308;
     return s;
 }
+__device__ __noinline__ Support score(int kind, const Model9 mv, const Pts P, int M, double max_res, int lane,
+                                      int need_sum_from) {
+    const double* m = mv.v;
+    if (P.lds) {
+        if (kind == K_H) return score_impl<true, K_H>(m, P, M, max_res, lane, need_sum_from);
+        if (kind == K_T) return score_impl<true, K_T>(m, P, M, max_res, lane, need_sum_from);
+        return score_impl<true, K_F7>(m, P, M, max_res, lane, need_sum_from);
+    }
+    if (kind == K_H) return score_impl<false, K_H>(m, P, M, max_res, lane, need_sum_from);
+    if (kind == K_T) return score_impl<false, K_T>(m, P, M, max_res, lane, need_sum_from);
+    return score_impl<false, K_F7>(m, P, M, max_res, lane, need_sum_from);
+}
 
-// CenterAndNormalizeImagePoints over K points (src -> dst), wave-cooperative
-__device__ void center_and_normalize(const double* sx, const double* sy, int K, double* dx,
-                                     double* dy, double* T, int lane) {
+// ---- local optimisation over the ordered inlier list w.inl[0..K) ---------------------------------
+// ordered compaction of the inlier indices of `model` (kind); returns K
+template <bool L>
+__device__ __forceinline__ int extract_impl(lds_u16* inl, int lane, int kind, const double* model, const Pts& P,
+                                            int M, double max_res) {
+    int base = 0;
+    for (int k0 = 0; k0 < M; k0 += 64) {
+        const int k = k0 + lane;
+        bool in = false;
+        if (k < M) {
+            double a, b, c, d;
+            load_pt<L>(P, k, a, b, c, d);
+            in = residual_of(kind, model, a, b, c, d) <= max_res;
+        }
+        const unsigned long long bal = __ballot(in);
+        if (in) inl[base + __popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)k;
+        base += __popcll(bal);
+    }
+    wave_lds_sync();
+    return base;
+}
+__device__ __noinline__ int extract_inliers(lds_u16* inl, int lane, int kind, const Model9 mv, const Pts P, int M,
+                                            double max_res) {
+    return P.lds ? extract_impl<true>(inl, lane, kind, mv.v, P, M, max_res)
+                 : extract_impl<false>(inl, lane, kind, mv.v, P, M, max_res);
+}
+
+// CenterAndNormalizeImagePoints over the K listed points of image `img` (0: x1,y1; 1: x2,y2):
+// only the transform T is produced; the normalised coordinates are recomputed where they are
+// consumed (apply_T), with the operations of the reference loop, instead of being stored.
+struct LoCtx {  // what the local estimators need of the wave, passed by value (registers)
+    lds_u16* inl;
+    lds_f64* jacA;
+    lds_f64* jacV;
+    int lane;
+};
+template <bool L>
+__device__ __forceinline__ void center_T_impl(const LoCtx& w, const Pts& P, int img, int K, double* T) {
+    const int lane = w.lane;
     double ax = 0.0, ay = 0.0;
-    for (int k = lane; k < K; k += 64) { ax += sx[k]; ay += sy[k]; }
+    for (int k = lane; k < K; k += 64) {
+        double p[4];
+        load_pt<L>(P, w.inl[k], p[0], p[1], p[2], p[3]);
+        ax += p[2 * img]; ay += p[2 * img + 1];
+    }
     const double cx = butterfly(ax) / (double)K;
     const double cy = butterfly(ay) / (double)K;
     double ar = 0.0;
     for (int k = lane; k < K; k += 64) {
-        const double ddx = sx[k] - cx, ddy = sy[k] - cy;
+        double p[4];
+        load_pt<L>(P, w.inl[k], p[0], p[1], p[2], p[3]);
+        const double ddx = p[2 * img] - cx, ddy = p[2 * img + 1] - cy;
         ar += ddx * ddx + ddy * ddy;
     }
     double rms = butterfly(ar);
@@ -190,49 +417,48 @@ __device__ void center_and_normalize(const double* sx, const double* sy, int K, 
     T[0] = nf; T[1] = 0; T[2] = -nf * cx;
     T[3] = 0; T[4] = nf; T[5] = -nf * cy;
     T[6] = 0; T[7] = 0; T[8] = 1;
-    for (int k = lane; k < K; k += 64) {
-        const double p0 = sx[k], p1 = sy[k];
-        const double np0 = T[0] * p0 + T[1] * p1 + T[2];
-        const double np1 = T[3] * p0 + T[4] * p1 + T[5];
-        const double np2 = T[6] * p0 + T[7] * p1 + T[8];
-        const double inv = 1.0 / np2;
-        dx[k] = np0 * inv;
-        dy[k] = np1 * inv;
-    }
-    wave_mem_sync();
+}
+__device__ __forceinline__ void apply_T(const double* T, double p0, double p1, double& o0, double& o1) {
+    const double np0 = T[0] * p0 + T[1] * p1 + T[2];
+    const double np1 = T[3] * p0 + T[4] * p1 + T[5];
+    const double np2 = T[6] * p0 + T[7] * p1 + T[8];
+    const double inv = 1.0 / np2;
+    o0 = np0 * inv;
+    o1 = np1 * inv;
 }
 
-// design-matrix row of correspondence k for the local estimators
-//   mode 0: epipolar row [x1 x2, y1 x2, x2, x1 y2, y1 y2, y2, x1, y1, 1]      (F8 / E5)
-//   mode 1: homography rows; k < K -> "a" row, k >= K -> "b" row of point k-K   (H)
-__device__ __forceinline__ void design_row(int mode, const double* x1, const double* y1,
-                                           const double* x2, const double* y2, int K, int k,
-                                           double* r) {
-    if (mode == 0) {
-        r[0] = x1[k] * x2[k]; r[1] = y1[k] * x2[k]; r[2] = x2[k];
-        r[3] = x1[k] * y2[k]; r[4] = y1[k] * y2[k]; r[5] = y2[k];
-        r[6] = x1[k]; r[7] = y1[k]; r[8] = 1.0;
-    } else if (k < K) {
-        const double s_0 = x1[k], s_1 = y1[k], d_0 = x2[k];
-        r[0] = -s_0; r[1] = -s_1; r[2] = -1; r[3] = 0; r[4] = 0; r[5] = 0;
-        r[6] = s_0 * d_0; r[7] = s_1 * d_0; r[8] = d_0;
-    } else {
-        const int i = k - K;
-        const double s_0 = x1[i], s_1 = y1[i], d_1 = y2[i];
-        r[0] = 0; r[1] = 0; r[2] = 0; r[3] = -s_0; r[4] = -s_1; r[5] = -1;
-        r[6] = s_0 * d_1; r[7] = s_1 * d_1; r[8] = d_1;
-    }
-}
-// A^T A (9 x 9, symmetric) over `rows` design rows, every entry in det_sum64 order: each lane keeps
-// the 45 partial sums of its strided rows (one pass over the data), then 45 butterflies
-__device__ void accumulate_ata(int mode, const double* x1, const double* y1, const double* x2,
-                               const double* y2, int K, int rows, double* ata, int lane) {
+// A^T A (9 x 9, symmetric) over the design rows of the listed correspondences, every entry in
+// det_sum64 order: each lane keeps the 45 partial sums of its strided rows, then 45 butterflies.
+//   MODE 0: epipolar row [x1 x2, y1 x2, x2, x1 y2, y1 y2, y2, x1, y1, 1]      (F8 / E5), K rows
+//   MODE 1: homography rows; r < K -> "a" row of point r, r >= K -> "b" row of point r-K, 2K rows
+// NORM: correspondences are normalised by T1 / T2 first.
+template <bool L, int MODE, bool NORM>
+__device__ __forceinline__ void ata_impl(const LoCtx& w, const Pts& P, int K, const double* T1, const double* T2) {
+    const int lane = w.lane;
+    const int rows = MODE == 1 ? 2 * K : K;
     double acc[45];
 #pragma unroll
     for (int e = 0; e < 45; ++e) acc[e] = 0.0;
-    for (int k = lane; k < rows; k += 64) {
+    for (int r0 = lane; r0 < rows; r0 += 64) {
+        const int k = (MODE == 1 && r0 >= K) ? r0 - K : r0;
+        double x1, y1, x2, y2;
+        load_pt<L>(P, w.inl[k], x1, y1, x2, y2);
+        if (NORM) {
+            apply_T(T1, x1, y1, x1, y1);
+            apply_T(T2, x2, y2, x2, y2);
+        }
         double r[9];
-        design_row(mode, x1, y1, x2, y2, K, k, r);
+        if (MODE == 0) {
+            r[0] = x1 * x2; r[1] = y1 * x2; r[2] = x2;
+            r[3] = x1 * y2; r[4] = y1 * y2; r[5] = y2;
+            r[6] = x1; r[7] = y1; r[8] = 1.0;
+        } else if (r0 < K) {
+            r[0] = -x1; r[1] = -y1; r[2] = -1; r[3] = 0; r[4] = 0; r[5] = 0;
+            r[6] = x1 * x2; r[7] = y1 * x2; r[8] = x2;
+        } else {
+            r[0] = 0; r[1] = 0; r[2] = 0; r[3] = -x1; r[4] = -y1; r[5] = -1;
+            r[6] = x1 * y2; r[7] = y1 * y2; r[8] = y2;
+        }
         int e = 0;
 #pragma unroll
         for (int i = 0; i < 9; ++i)
@@ -245,9 +471,12 @@ __device__ void accumulate_ata(int mode, const double* x1, const double* y1, con
 #pragma unroll
         for (int j = i; j < 9; ++j) {
             const double sres = butterfly(acc[e++]);
-            ata[i * 9 + j] = sres;
-            ata[j * 9 + i] = sres;
+            if (lane == 0) {
+                w.jacA[i * 9 + j] = sres;
+                w.jacA[j * 9 + i] = sres;
+            }
         }
+    wave_lds_sync();
 }
 
 // Cyclic Jacobi on a symmetric n x n matrix held in LDS, the whole wave cooperating: the
@@ -255,9 +484,9 @@ __device__ void accumulate_ata(int mode, const double* x1, const double* y1, con
 // then of the two rows, lanes 32..32+n-1 the eigenvector columns.  Every element sees exactly the
 // arithmetic of the scalar jacobi_eigen (tvg_math.h) in the same order, so results are
 // bit-identical; only the memory (LDS instead of scratch) and the parallelism differ.
-__device__ void jacobi_eigen_wave(int n, double* A, double* V, int lane) {
+__device__ __noinline__ void jacobi_eigen_wave(int n, lds_f64* A, lds_f64* V, int lane) {
     for (int i = lane; i < n * n; i += 64) V[i] = ((i / n) == (i % n)) ? 1.0 : 0.0;
-    __builtin_amdgcn_wave_barrier();
+    wave_lds_sync();
     double total = 0.0;
     for (int i = 0; i < n * n; ++i) total += A[i] * A[i];
     const double tol = total * 1e-32;
@@ -276,41 +505,45 @@ __device__ void jacobi_eigen_wave(int n, double* A, double* V, int lane) {
                 const double s = t * c;
                 const int k = lane & 31;
                 const bool colA = lane < n, colV = lane >= 32 && k < n;
-                double* Mx = colV ? V : A;
+                lds_f64* Mx = colV ? V : A;
                 double xp = 0.0, xq = 0.0;
                 if (colA || colV) { xp = Mx[k * n + p]; xq = Mx[k * n + q]; }
-                __builtin_amdgcn_wave_barrier();
+                wave_lds_sync();
                 if (colA || colV) {
                     Mx[k * n + p] = c * xp - s * xq;
                     Mx[k * n + q] = s * xp + c * xq;
                 }
-                __builtin_amdgcn_wave_barrier();
+                wave_lds_sync();
                 if (colA) { xp = A[p * n + k]; xq = A[q * n + k]; }
-                __builtin_amdgcn_wave_barrier();
+                wave_lds_sync();
                 if (colA) {
                     A[p * n + k] = c * xp - s * xq;
                     A[q * n + k] = s * xp + c * xq;
                 }
-                __builtin_amdgcn_wave_barrier();
+                wave_lds_sync();
             }
         }
     }
 }
 // eigenvector of the smallest eigenvalue after jacobi_eigen_wave (first minimum, like the oracle)
-__device__ void smallest_eigvec9_wave(const double* A, const double* V, double* x) {
+__device__ void smallest_eigvec9_wave(const lds_f64* A, const lds_f64* V, double* x) {
     int best = 0;
     for (int i = 1; i < 9; ++i)
         if (A[i * 9 + i] < A[best * 9 + best]) best = i;
     for (int i = 0; i < 9; ++i) x[i] = V[i * 9 + best];
 }
 
-// local estimator on the K inlier correspondences in the I arrays -> models (uniform), count
-__device__ int local_estimate(Wave& w, int kind, int K, double* models) {
+// local estimator on the K listed inlier correspondences -> models (uniform), count
+template <bool L>
+__device__ __forceinline__ int local_estimate_impl(const LoCtx& w, int kind, const Pts& P, int K, double* models) {
     const int lane = w.lane;
-    const double *ix1 = w.arr(W_IX1), *iy1 = w.arr(W_IY1), *ix2 = w.arr(W_IX2), *iy2 = w.arr(W_IY2);
     if (kind == K_T) {
         double a = 0, b = 0, c = 0, d = 0;
-        for (int k = lane; k < K; k += 64) { a += ix1[k]; b += iy1[k]; c += ix2[k]; d += iy2[k]; }
+        for (int k = lane; k < K; k += 64) {
+            double p0, p1, p2, p3;
+            load_pt<L>(P, w.inl[k], p0, p1, p2, p3);
+            a += p0; b += p1; c += p2; d += p3;
+        }
         const double sx = butterfly(a) / (double)K, sy = butterfly(b) / (double)K;
         const double dx = butterfly(c) / (double)K, dy = butterfly(d) / (double)K;
         for (int i = 0; i < 9; ++i) models[i] = 0.0;
@@ -321,11 +554,10 @@ __device__ int local_estimate(Wave& w, int kind, int K, double* models) {
     if (kind == K_E5) {
         if (K == 5) {
             double a[5], b[5], c[5], d[5];
-            for (int i = 0; i < 5; ++i) { a[i] = ix1[i]; b[i] = iy1[i]; c[i] = ix2[i]; d[i] = iy2[i]; }
+            for (int i = 0; i < 5; ++i) load_pt<L>(P, w.inl[i], a[i], b[i], c[i], d[i]);
             return estimate_e5_minimal(a, b, c, d, models);
         }
-        accumulate_ata(0, ix1, iy1, ix2, iy2, K, K, w.jacA, lane);
-        __builtin_amdgcn_wave_barrier();
+        ata_impl<L, 0, false>(w, P, K, nullptr, nullptr);
         jacobi_eigen_wave(9, w.jacA, w.jacV, lane);
         double nsp[4 * 9];
         e5_nullspace_from_eig(w.jacA, w.jacV, nsp);
@@ -333,31 +565,31 @@ __device__ int local_estimate(Wave& w, int kind, int K, double* models) {
     }
     if (kind == K_H && K == 4) {
         double a[4], b[4], c[4], d[4];
-        for (int i = 0; i < 4; ++i) { a[i] = ix1[i]; b[i] = iy1[i]; c[i] = ix2[i]; d[i] = iy2[i]; }
+        for (int i = 0; i < 4; ++i) load_pt<L>(P, w.inl[i], a[i], b[i], c[i], d[i]);
         estimate_h4(a, b, c, d, models);
         return 1;
     }
     double T1[9], T2[9];
-    double* ata = w.jacA;
-    double *jx1 = w.arr(W_JX1), *jy1 = w.arr(W_JY1), *jx2 = w.arr(W_JX2), *jy2 = w.arr(W_JY2);
-    center_and_normalize(ix1, iy1, K, jx1, jy1, T1, lane);
-    center_and_normalize(ix2, iy2, K, jx2, jy2, T2, lane);
+    center_T_impl<L>(w, P, 0, K, T1);
+    center_T_impl<L>(w, P, 1, K, T2);
     if (kind == K_F8) {
-        accumulate_ata(0, jx1, jy1, jx2, jy2, K, K, ata, lane);
-        __builtin_amdgcn_wave_barrier();
+        ata_impl<L, 0, true>(w, P, K, T1, T2);
         jacobi_eigen_wave(9, w.jacA, w.jacV, lane);
         double f[9];
         smallest_eigvec9_wave(w.jacA, w.jacV, f);
         f8_from_vec(f, T1, T2, models);
     } else {
-        accumulate_ata(1, jx1, jy1, jx2, jy2, K, 2 * K, ata, lane);
-        __builtin_amdgcn_wave_barrier();
+        ata_impl<L, 1, true>(w, P, K, T1, T2);
         jacobi_eigen_wave(9, w.jacA, w.jacV, lane);
         double h[9];
         smallest_eigvec9_wave(w.jacA, w.jacV, h);
         h_denormalize(h, T1, T2, models);
     }
     return 1;
+}
+__device__ __noinline__ int local_estimate(const LoCtx w, int kind, const Pts P, int K, double* models) {
+    return P.lds ? local_estimate_impl<true>(w, kind, P, K, models)
+                 : local_estimate_impl<false>(w, kind, P, K, models);
 }
 
 struct Report {
@@ -373,34 +605,18 @@ struct RansacCfg {
     int max_trials;          // already clamped as the RANSAC constructor does
     int min_trials;
     const uint32_t* dyn_tab; // dyn_max_num_trials by num_inliers (host libm), or nullptr
+    int force_slow_sampler;  // test hook: always take the draw-by-draw sampler path
 };
 
-// ordered compaction of the inliers of `model` (kind) into the I arrays; returns K
-__device__ int extract_inliers(Wave& w, int kind, const double* model, const double* x1,
-                               const double* y1, const double* x2, const double* y2, int M,
-                               double max_res) {
-    double *ix1 = w.arr(W_IX1), *iy1 = w.arr(W_IY1), *ix2 = w.arr(W_IX2), *iy2 = w.arr(W_IY2);
-    int base = 0;
-    for (int k0 = 0; k0 < M; k0 += 64) {
-        const int k = k0 + w.lane;
-        bool in = false;
-        if (k < M) in = residual_k(kind, model, x1, y1, x2, y2, k) <= max_res;
-        const unsigned long long bal = __ballot(in);
-        if (in) {
-            const int pos = base + __popcll(bal & ((1ull << w.lane) - 1ull));
-            ix1[pos] = x1[k]; iy1[pos] = y1[k]; ix2[pos] = x2[k]; iy2[pos] = y2[k];
-        }
-        base += __popcll(bal);
-    }
-    wave_mem_sync();
-    return base;
-}
-
-// LORANSAC<est, local_est>::Estimate over the M correspondences (x1,y1)->(x2,y2); mask: M bytes
-__device__ Report lo_ransac(Wave& w, const RansacCfg& cfg, const double* x1, const double* y1,
-                            const double* x2, const double* y2, int M, uint8_t* mask) {
+// LORANSAC<est, local_est>::Estimate over the M correspondences in the four arrays at gx (x1 | y1
+// | x2 | y2, each gstride long); mask: M bytes
+__device__ Report lo_ransac(Wave& w_io, const RansacCfg& cfg, const double* gx, uint32_t gstride, int M,
+                            uint8_t* mask) {
+    Wave w = w_io;  // by-value copy: the fields live in registers, not behind a pointer
     const int lane = w.lane;
     const int kMin = kmin_of(cfg.est), kLocalMin = kmin_of(cfg.local_est);
+    LoCtx lo;
+    lo.inl = w.inl; lo.jacA = w.jacA; lo.jacV = w.jacV; lo.lane = lane;
     Report rep;
     rep.success = false;
     rep.num_trials = 0;
@@ -416,20 +632,25 @@ __device__ Report lo_ransac(Wave& w, const RansacCfg& cfg, const double* x1, con
     uint32_t dyn_max = (uint32_t)cfg.max_trials;
 
     // correspondences into LDS when they fit: every scoring pass and every sample gather reads them
-    if ((uint32_t)M <= w.pts_cap) {
-        double *l0 = w.lpts, *l1 = l0 + w.pts_cap, *l2 = l1 + w.pts_cap, *l3 = l2 + w.pts_cap;
-        for (int k = lane; k < M; k += 64) { l0[k] = x1[k]; l1[k] = y1[k]; l2[k] = x2[k]; l3[k] = y2[k]; }
-        __builtin_amdgcn_wave_barrier();
-        x1 = l0; y1 = l1; x2 = l2; y2 = l3;
+    Pts P;
+    P.g = gx; P.gs = gstride; P.l = w.lpts; P.ls = w.pts_cap;
+    P.lds = (uint32_t)M <= w.pts_cap;
+    if (P.lds) {
+        for (int k = lane; k < M; k += 64) {
+            w.lpts[k] = gx[k];
+            w.lpts[w.pts_cap + k] = gx[gstride + k];
+            w.lpts[2 * w.pts_cap + k] = gx[2 * (size_t)gstride + k];
+            w.lpts[3 * w.pts_cap + k] = gx[3 * (size_t)gstride + k];
+        }
     }
 
     // sampler.Initialize(M).  The first kMin entries of the persistent permutation are touched by
     // every draw: they live in (wave-uniform) registers, the rest in LDS.
     for (int k = lane; k < M; k += 64) w.perm[k] = (uint16_t)k;
-    uint32_t pr[7];
+    SamplerState ss;
 #pragma unroll
-    for (int i = 0; i < 7; ++i) pr[i] = (uint32_t)i;
-    __builtin_amdgcn_wave_barrier();
+    for (int i = 0; i < 7; ++i) ss.pr[i] = (uint32_t)i;
+    wave_lds_sync();
 
     double* models = w.models();
     bool aborted = false;
@@ -439,44 +660,16 @@ __device__ Report lo_ransac(Wave& w, const RansacCfg& cfg, const double* x1, con
         // ---- snapshot the generator, draw the chunk's samples (wave-uniform, sequential) ----
         for (int i = lane; i < 624; i += 64) w.snap[i] = w.mt[i];
         const int snap_mti = w.mti;
-        __builtin_amdgcn_wave_barrier();
-        uint32_t nraw = 0;
-        const uint32_t last = (uint32_t)(M - 1);
+        wave_lds_sync();
         unsigned long long tp0 = __builtin_readcyclecounter();
-        for (int t = 0; t < nT; ++t) {
-#pragma unroll
-            for (int i = 0; i < 7; ++i) {
-                if (i < kMin) {
-                    const uint32_t j = rng_uniform(w, (uint32_t)i, last, nraw);
-                    // swap(perm[i], perm[j])
-                    if (j < (uint32_t)kMin) {
-                        uint32_t vj = pr[0];
-#pragma unroll
-                        for (int q = 1; q < 7; ++q) vj = (j == (uint32_t)q) ? pr[q] : vj;
-                        const uint32_t vi = pr[i];
-#pragma unroll
-                        for (int q = 0; q < 7; ++q) pr[q] = (j == (uint32_t)q) ? vi : pr[q];
-                        pr[i] = vj;
-                    } else {
-                        const uint32_t vj = w.perm[j];
-                        w.perm[j] = (uint16_t)pr[i];
-                        pr[i] = vj;
-                    }
-                }
-            }
-            if (lane == 0) {
-#pragma unroll
-                for (int i = 0; i < 7; ++i) w.sidx[t * 8 + i] = (uint16_t)pr[i];
-                w.rawcnt[t] = nraw;
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
+        ss.mti = w.mti;
+        ss = sample_chunk(w.mt, w.snap, w.perm, w.sidx, w.rawcnt, ss, M, kMin, nT, lane, cfg.force_slow_sampler);
+        w.mti = ss.mti;
         { const unsigned long long tp1 = __builtin_readcyclecounter(); w.prof[0] += tp1 - tp0; tp0 = tp1; }
         // ---- 64 minimal problems, one per lane.  F / H / T models stay in the solving lane's
-        //      registers (slot i = i-th root; `valid` marks the ones the estimator returned) and are
-        //      broadcast with __shfl during the replay; E models (up to 10) go through global memory.
+        //      registers (slot i = i-th root) and are broadcast with v_readlane during the replay;
+        //      E models (up to 10) go through global memory.
         int nmod = 0;
-        unsigned valid = 0;
         double mym[27];
 #pragma unroll
         for (int i = 0; i < 27; ++i) mym[i] = 0.0;
@@ -484,36 +677,25 @@ __device__ Report lo_ransac(Wave& w, const RansacCfg& cfg, const double* x1, con
             if (cfg.est == K_F7) {
                 double sx1[7], sy1[7], sx2[7], sy2[7];
 #pragma unroll
-                for (int i = 0; i < 7; ++i) {
-                    const int sI = w.sidx[lane * 8 + i];
-                    sx1[i] = x1[sI]; sy1[i] = y1[sI]; sx2[i] = x2[sI]; sy2[i] = y2[sI];
-                }
+                for (int i = 0; i < 7; ++i) load_pt_any(P, w.sidx[lane * 8 + i], sx1[i], sy1[i], sx2[i], sy2[i]);
                 nmod = estimate_f7(sx1, sy1, sx2, sy2, mym);
-                valid = (1u << nmod) - 1u;
             } else if (cfg.est == K_H) {
                 double sx1[4], sy1[4], sx2[4], sy2[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int sI = w.sidx[lane * 8 + i];
-                    sx1[i] = x1[sI]; sy1[i] = y1[sI]; sx2[i] = x2[sI]; sy2[i] = y2[sI];
-                }
+                for (int i = 0; i < 4; ++i) load_pt_any(P, w.sidx[lane * 8 + i], sx1[i], sy1[i], sx2[i], sy2[i]);
                 estimate_h4(sx1, sy1, sx2, sy2, mym);
                 nmod = 1;
-                valid = 1u;
             } else if (cfg.est == K_E5) {
                 double sx1[5], sy1[5], sx2[5], sy2[5];
 #pragma unroll
-                for (int i = 0; i < 5; ++i) {
-                    const int sI = w.sidx[lane * 8 + i];
-                    sx1[i] = x1[sI]; sy1[i] = y1[sI]; sx2[i] = x2[sI]; sy2[i] = y2[sI];
-                }
+                for (int i = 0; i < 5; ++i) load_pt_any(P, w.sidx[lane * 8 + i], sx1[i], sy1[i], sx2[i], sy2[i]);
                 nmod = estimate_e5_minimal(sx1, sy1, sx2, sy2, models + (size_t)lane * kMaxModels * 9);
             } else {  // K_T: model = dst - src of the single sample
-                const int sI = w.sidx[lane * 8];
-                mym[0] = x2[sI] - x1[sI];
-                mym[1] = y2[sI] - y1[sI];
+                double a, b, c, d;
+                load_pt_any(P, w.sidx[lane * 8], a, b, c, d);
+                mym[0] = c - a;
+                mym[1] = d - b;
                 nmod = 1;
-                valid = 1u;
             }
         }
         wave_mem_sync();
@@ -521,9 +703,10 @@ __device__ Report lo_ransac(Wave& w, const RansacCfg& cfg, const double* x1, con
         // ---- replay in trial order ------------------------------------------------------------
         for (int t = 0; t < nT && !aborted; ++t) {
             const int trial = chunk + t;
-            const int n = __shfl(nmod, t);
+            const int n = __builtin_amdgcn_readlane(nmod, t);
             for (int m = 0; m < n; ++m) {
-                double sm[9];
+                Model9 smv;
+                double* sm = smv.v;
                 if (cfg.est == K_E5) {
                     const double* src = models + ((size_t)t * kMaxModels + m) * 9;
                     for (int i = 0; i < 9; ++i) sm[i] = src[i];
@@ -534,7 +717,7 @@ __device__ Report lo_ransac(Wave& w, const RansacCfg& cfg, const double* x1, con
                         sm[i] = readlane_f64(mine, t);
                     }
                 }
-                const Support sup = score(cfg.est, sm, x1, y1, x2, y2, M, cfg.max_res, lane, best.cnt);
+                const Support sup = score(cfg.est, smv, P, M, cfg.max_res, lane, best.cnt);
                 if (better(sup, best)) {
                     const unsigned long long tl0 = __builtin_readcyclecounter();
                     best = sup;
@@ -544,16 +727,17 @@ __device__ Report lo_ransac(Wave& w, const RansacCfg& cfg, const double* x1, con
                         // recursive local optimisation: inliers of the sample model first, then of
                         // the improved local model (COLMAP swaps residual vectors to the same effect)
                         int cur_kind = cfg.est;
-                        double cur[9];
-                        for (int i = 0; i < 9; ++i) cur[i] = sm[i];
+                        Model9 cur;
+                        for (int i = 0; i < 9; ++i) cur.v[i] = sm[i];
                         for (int lt = 0; lt < 10; ++lt) {
-                            const int K = extract_inliers(w, cur_kind, cur, x1, y1, x2, y2, M, cfg.max_res);
+                            const int K = extract_inliers(w.inl, lane, cur_kind, cur, P, M, cfg.max_res);
                             double lm[kMaxModels * 9];
-                            const int nl = local_estimate(w, cfg.local_est, K, lm);
+                            const int nl = local_estimate(lo, cfg.local_est, P, K, lm);
                             const int prev = best.cnt;
                             for (int q = 0; q < nl; ++q) {
-                                const Support ls = score(cfg.local_est, lm + 9 * q, x1, y1, x2, y2, M,
-                                                         cfg.max_res, lane, best.cnt);
+                                Model9 lmv;
+                                for (int i = 0; i < 9; ++i) lmv.v[i] = lm[9 * q + i];
+                                const Support ls = score(cfg.local_est, lmv, P, M, cfg.max_res, lane, best.cnt);
                                 if (better(ls, best)) {
                                     best = ls;
                                     for (int i = 0; i < 9; ++i) best_model[i] = lm[9 * q + i];
@@ -562,7 +746,7 @@ __device__ Report lo_ransac(Wave& w, const RansacCfg& cfg, const double* x1, con
                             }
                             if (best.cnt <= prev) break;
                             cur_kind = cfg.local_est;
-                            for (int i = 0; i < 9; ++i) cur[i] = best_model[i];
+                            for (int i = 0; i < 9; ++i) cur.v[i] = best_model[i];
                         }
                     }
                     dyn_max = cfg.dyn_tab ? cfg.dyn_tab[best.cnt] : 0xFFFFFFFFu;
@@ -578,13 +762,17 @@ __device__ Report lo_ransac(Wave& w, const RansacCfg& cfg, const double* x1, con
         { const unsigned long long tp1 = __builtin_readcyclecounter(); w.prof[2] += tp1 - tp0; }
         if (aborted) {
             // roll the generator back to where the sequential algorithm stopped drawing
-            __builtin_amdgcn_wave_barrier();
+            wave_lds_sync();
             for (int i = lane; i < 624; i += 64) w.mt[i] = w.snap[i];
             w.mti = snap_mti;
-            __builtin_amdgcn_wave_barrier();
-            const uint32_t consumed = w.rawcnt[abort_trial - chunk];
-            uint32_t dummy = 0;
-            for (uint32_t i = 0; i < consumed; ++i) (void)rng_raw(w, dummy);
+            wave_lds_sync();
+            int consumed = (int)sgpr(w.rawcnt[abort_trial - chunk]);
+            while (consumed > 0) {  // discard `consumed` raw words
+                if (w.mti >= 624) { mt_twist(w.mt, lane); w.mti = 0; }
+                const int step = min(624 - w.mti, consumed);
+                w.mti += step;
+                consumed -= step;
+            }
         }
     }
     // report.num_trials exactly as the for/abort dance of loransac.h leaves it
@@ -592,11 +780,16 @@ __device__ Report lo_ransac(Wave& w, const RansacCfg& cfg, const double* x1, con
                              : cfg.max_trials;
     rep.support = best;
     for (int i = 0; i < 9; ++i) rep.model[i] = best_model[i];
+    w_io.mti = w.mti;
+    for (int i = 0; i < 5; ++i) w_io.prof[i] = w.prof[i];
     if (best.cnt < kMin) return rep;
     rep.success = true;
     const int fk = best_is_local ? cfg.local_est : cfg.est;
-    for (int k = lane; k < M; k += 64)
-        mask[k] = residual_k(fk, rep.model, x1, y1, x2, y2, k) <= cfg.max_res ? 1 : 0;
+    for (int k = lane; k < M; k += 64) {
+        double a, b, c, d;
+        load_pt_any(P, k, a, b, c, d);
+        mask[k] = residual_of(fk, rep.model, a, b, c, d) <= cfg.max_res ? 1 : 0;
+    }
     wave_mem_sync();
     return rep;
 }
@@ -659,6 +852,7 @@ __device__ __noinline__ void process_pair(Wave& w, uint32_t q, const TvgImage* _
 
     RansacCfg cfg;
     cfg.min_trials = P.min_num_trials;
+    cfg.force_slow_sampler = P.force_slow_sampler;
     if (calibrated) {
         double *N1x = w.arr(W_NX1), *N1y = w.arr(W_NY1), *N2x = w.arr(W_NX2), *N2y = w.arr(W_NY2);
         const CameraDev c1 = im1.cam, c2 = im2.cam;
@@ -686,7 +880,7 @@ __device__ __noinline__ void process_pair(Wave& w, uint32_t q, const TvgImage* _
         cfg.max_res = e_err * e_err;
         cfg.max_trials = P.max_trials[0];
         cfg.dyn_tab = trial_tabs + pr.tab_off[0];
-        E_rep = lo_ransac(w, cfg, N1x, N1y, N2x, N2y, M, maskE);
+        E_rep = lo_ransac(w, cfg, N1x, mcap, M, maskE);
         for (int i = 0; i < 9; ++i) g.E[i] = E_rep.model[i];
         g.num_trials[0] = E_rep.num_trials;
         g.model_inliers[0] = E_rep.support.cnt;
@@ -696,7 +890,7 @@ __device__ __noinline__ void process_pair(Wave& w, uint32_t q, const TvgImage* _
         cfg.max_res = P.max_error * P.max_error;
         cfg.max_trials = P.max_trials[1];
         cfg.dyn_tab = trial_tabs + pr.tab_off[1];
-        F_rep = lo_ransac(w, cfg, X1, Y1, X2, Y2, M, maskF);
+        F_rep = lo_ransac(w, cfg, X1, mcap, M, maskF);
         for (int i = 0; i < 9; ++i) g.F[i] = F_rep.model[i];
         g.num_trials[1] = F_rep.num_trials;
         g.model_inliers[1] = F_rep.support.cnt;
@@ -705,7 +899,7 @@ __device__ __noinline__ void process_pair(Wave& w, uint32_t q, const TvgImage* _
     cfg.max_res = P.max_error * P.max_error;
     cfg.max_trials = P.max_trials[2];
     cfg.dyn_tab = trial_tabs + pr.tab_off[2];
-    H_rep = lo_ransac(w, cfg, X1, Y1, X2, Y2, M, maskH);
+    H_rep = lo_ransac(w, cfg, X1, mcap, M, maskH);
     for (int i = 0; i < 9; ++i) g.H[i] = H_rep.model[i];
     g.num_trials[2] = H_rep.num_trials;
     g.model_inliers[2] = H_rep.support.cnt;
@@ -793,7 +987,7 @@ __device__ __noinline__ void process_pair(Wave& w, uint32_t q, const TvgImage* _
                 cfg.max_res = P.max_error * P.max_error;
                 cfg.max_trials = P.max_trials[3];
                 cfg.dyn_tab = nullptr;  // never consulted: max_trials[3] <= min_num_trials (host check)
-                const Report T_rep = lo_ransac(w, cfg, ix1, iy1, ix2, iy2, num_inliers, w.masks + 3 * (size_t)mcap);
+                const Report T_rep = lo_ransac(w, cfg, ix1, mcap, num_inliers, w.masks + 3 * (size_t)mcap);
                 g.num_trials[3] = T_rep.num_trials;
                 const double inlier_ratio = (double)T_rep.support.cnt / (double)num_inliers;
                 if (inlier_ratio >= P.watermark_min_inlier_ratio) g.config = AMC_TVG_WATERMARK;
@@ -816,20 +1010,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(kTvgWavesPe
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wid = threadIdx.x >> 6;
-    const size_t lds_per_wave = (size_t)162 * 8 + (size_t)4 * pts_cap * 8 + (size_t)(624 + 624 + 64) * 4 +
-                                64 * 8 * 2 + (size_t)((mcap + 7) / 8 * 8) * 2;
-    char* base = smem + (size_t)wid * ((lds_per_wave + 15) / 16 * 16);
+    const size_t lds_per_wave = tvg_lds_per_wave(mcap, pts_cap);
+    AMC_LDS char* base = (AMC_LDS char*)smem + (size_t)wid * lds_per_wave;
     Wave w;
     w.lane = lane;
-    w.jacA = reinterpret_cast<double*>(base);
+    w.jacA = reinterpret_cast<lds_f64*>(base);
     w.jacV = w.jacA + 81;
     w.lpts = w.jacA + 162;
     w.pts_cap = pts_cap;
-    w.mt = reinterpret_cast<uint32_t*>(base + (162 + (size_t)4 * pts_cap) * 8);
+    w.mt = reinterpret_cast<lds_u32*>(base + (162 + (size_t)4 * pts_cap) * 8);
     w.snap = w.mt + 624;
     w.rawcnt = w.snap + 624;
-    w.sidx = reinterpret_cast<uint16_t*>(w.rawcnt + 64);
+    w.sidx = reinterpret_cast<lds_u16*>(w.rawcnt + 64);
     w.perm = w.sidx + 64 * 8;
+    w.inl = w.perm + (mcap + 7) / 8 * 8;
     w.mcap = mcap;
     const size_t gw = (size_t)blockIdx.x * (blockDim.x >> 6) + wid;
     w.ws = ws_all + gw * tvg_ws_doubles(mcap);
@@ -848,9 +1042,7 @@ size_t tvg_ws_doubles_host(uint32_t mcap) { return tvg_ws_doubles(mcap); }
 size_t tvg_ws_mask_bytes_host(uint32_t mcap) { return tvg_ws_bytes_extra(mcap); }
 
 size_t tvg_lds_bytes(uint32_t mcap, uint32_t pts_cap, int waves) {
-    const size_t per = (size_t)162 * 8 + (size_t)4 * pts_cap * 8 + (size_t)(624 + 624 + 64) * 4 + 64 * 8 * 2 +
-                       (size_t)((mcap + 7) / 8 * 8) * 2;
-    return (size_t)waves * ((per + 15) / 16 * 16);
+    return (size_t)waves * tvg_lds_per_wave(mcap, pts_cap);
 }
 // how many correspondences of the active RANSAC fit in LDS next to everything else (4 waves/block)
 uint32_t tvg_pts_cap(uint32_t mcap) {

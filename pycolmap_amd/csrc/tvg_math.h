@@ -575,7 +575,8 @@ AMC_HD int estimate_e5_minimal(const double* x1, const double* y1, const double*
 // least-squares 5-point (local optimisation): 4 smallest eigenvectors of A^T A
 // 4-D "null space" of the least-squares 5-point: the 4 smallest eigenvectors of A^T A, given its
 // eigen-decomposition (ata: eigenvalues on the diagonal, v: eigenvectors in columns)
-AMC_HD void e5_nullspace_from_eig(const double* ata, const double* v, double* nsp) {
+template <class PA, class PV>
+AMC_HD void e5_nullspace_from_eig(PA ata, PV v, double* nsp) {
     int order[9];
     for (int i = 0; i < 9; ++i) order[i] = i;
     for (int i = 0; i < 9; ++i)
