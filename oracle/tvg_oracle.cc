@@ -29,7 +29,7 @@
  *
  * Deliberate, documented deviations (COLMAP leans on Eigen, absent here):
  *   D1  Null spaces come from Gauss-Jordan elimination with full pivoting (minimal solvers) or
- *       the smallest eigenvector of A^T A by cyclic Jacobi (least-squares solvers) instead of
+ *       the smallest eigenvector of A^T A by round-robin Jacobi (least-squares solvers) instead of
  *       Eigen::JacobiSVD; rank-2 enforcement projects out the smallest right singular vector.
  *   D2  Polynomial roots by bracketing + bisection on the real line instead of companion-matrix
  *       eigenvalues; models are tried in ascending root order.
@@ -207,41 +207,79 @@ Mat3 mat3_t(const Mat3& a) {
     return c;
 }
 
-// cyclic Jacobi eigen-decomposition of a symmetric n x n matrix (n <= 9), fixed rotation order.
+// Jacobi eigen-decomposition of a symmetric n x n matrix (n <= 9) with the round-robin
+// ("tournament") ordering: a sweep is m rounds (m = n for odd n, n - 1 for even n); round r
+// rotates the disjoint index pairs {(r+k) mod m, (r-k) mod m}, k = 1..(m-1)/2 (plus {r, n-1} for
+// even n).  All rotations of a round are computed from the matrix as it stands at the start of
+// the round, then applied together: A <- A J (columns), then A <- J^T A (rows), V <- V J.  Disjoint
+// pairs touch disjoint columns in the first step and disjoint rows in the second, so the result
+// does not depend on the order in which the pairs of a round are processed - which is what lets
+// a GPU wave apply them concurrently and still match this bit for bit.
 // a is destroyed (diagonal = eigenvalues); v = eigenvectors in columns (row-major n x n).
+int jacobi_round_pairs(int n, int r, int (*pq)[2]) {
+    const int m = (n & 1) ? n : n - 1;
+    int cnt = 0;
+    for (int k = 1; k <= (m - 1) / 2; ++k) {
+        const int x = (r + k) % m, y = (r - k + m) % m;
+        pq[cnt][0] = x < y ? x : y;
+        pq[cnt][1] = x < y ? y : x;
+        ++cnt;
+    }
+    if (!(n & 1)) {
+        pq[cnt][0] = r;
+        pq[cnt][1] = n - 1;
+        ++cnt;
+    }
+    return cnt;
+}
 void jacobi_eigen(int n, double* a, double* v) {
     for (int i = 0; i < n; ++i)
         for (int j = 0; j < n; ++j) v[i * n + j] = (i == j) ? 1.0 : 0.0;
     double total = 0.0;
     for (int i = 0; i < n * n; ++i) total += a[i] * a[i];
     const double tol = total * 1e-32;
+    const int rounds = (n & 1) ? n : n - 1;
     for (int sweep = 0; sweep < 40; ++sweep) {
         double off = 0.0;
         for (int p = 0; p < n - 1; ++p)
             for (int q = p + 1; q < n; ++q) off += a[p * n + q] * a[p * n + q];
         if (!(off > tol)) break;
-        for (int p = 0; p < n - 1; ++p) {
-            for (int q = p + 1; q < n; ++q) {
+        for (int r = 0; r < rounds; ++r) {
+            int pq[5][2];
+            const int np = jacobi_round_pairs(n, r, pq);
+            double cs[5][2];
+            bool act[5];
+            for (int e = 0; e < np; ++e) {
+                const int p = pq[e][0], q = pq[e][1];
                 const double apq = a[p * n + q];
-                if (apq == 0.0) continue;
+                act[e] = apq != 0.0;
+                if (!act[e]) continue;
                 const double theta = (a[q * n + q] - a[p * n + p]) / (2.0 * apq);
                 const double t = (theta >= 0.0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
-                const double c = 1.0 / std::sqrt(t * t + 1.0);
-                const double s = t * c;
-                for (int k = 0; k < n; ++k) {  // columns p,q of A
-                    const double akp = a[k * n + p], akq = a[k * n + q];
-                    a[k * n + p] = c * akp - s * akq;
-                    a[k * n + q] = s * akp + c * akq;
-                }
-                for (int k = 0; k < n; ++k) {  // rows p,q of A
-                    const double apk = a[p * n + k], aqk = a[q * n + k];
-                    a[p * n + k] = c * apk - s * aqk;
-                    a[q * n + k] = s * apk + c * aqk;
-                }
+                cs[e][0] = 1.0 / std::sqrt(t * t + 1.0);
+                cs[e][1] = t * cs[e][0];
+            }
+            for (int e = 0; e < np; ++e) {  // columns of A and of V
+                if (!act[e]) continue;
+                const int p = pq[e][0], q = pq[e][1];
+                const double c = cs[e][0], sn = cs[e][1];
                 for (int k = 0; k < n; ++k) {
+                    const double akp = a[k * n + p], akq = a[k * n + q];
+                    a[k * n + p] = c * akp - sn * akq;
+                    a[k * n + q] = sn * akp + c * akq;
                     const double vkp = v[k * n + p], vkq = v[k * n + q];
-                    v[k * n + p] = c * vkp - s * vkq;
-                    v[k * n + q] = s * vkp + c * vkq;
+                    v[k * n + p] = c * vkp - sn * vkq;
+                    v[k * n + q] = sn * vkp + c * vkq;
+                }
+            }
+            for (int e = 0; e < np; ++e) {  // rows of A
+                if (!act[e]) continue;
+                const int p = pq[e][0], q = pq[e][1];
+                const double c = cs[e][0], sn = cs[e][1];
+                for (int k = 0; k < n; ++k) {
+                    const double apk = a[p * n + k], aqk = a[q * n + k];
+                    a[p * n + k] = c * apk - sn * aqk;
+                    a[q * n + k] = sn * apk + c * aqk;
                 }
             }
         }

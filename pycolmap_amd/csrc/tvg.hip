@@ -57,7 +57,7 @@ typedef AMC_LDS uint16_t lds_u16;
 
 struct Wave {
     int lane;
-    unsigned long long prof[5];
+    unsigned long long prof[8];
     // LDS
     lds_u32* mt;      // 624
     lds_u32* snap;    // 624
@@ -479,49 +479,54 @@ __device__ __forceinline__ void ata_impl(const LoCtx& w, const Pts& P, int K, co
     wave_lds_sync();
 }
 
-// Cyclic Jacobi on a symmetric n x n matrix held in LDS, the whole wave cooperating: the
-// rotation parameters are wave-uniform; lanes 0..n-1 update the n entries of the two columns,
-// then of the two rows, lanes 32..32+n-1 the eigenvector columns.  Every element sees exactly the
-// arithmetic of the scalar jacobi_eigen (tvg_math.h) in the same order, so results are
-// bit-identical; only the memory (LDS instead of scratch) and the parallelism differ.
+// Round-robin Jacobi (tvg_math.h jacobi_eigen) on a symmetric n x n matrix held in LDS, the whole
+// wave cooperating.  Per round: lane e < n/2 computes the rotation of the round's e-th pair; lane
+// (e, k) = e * n + k then updates entry k of columns p_e, q_e of A and V, and after a barrier entry
+// k of rows p_e, q_e of A.  Every element sees exactly the arithmetic of the scalar version, so the
+// results are bit-identical; the pairs of a round being disjoint, no two lanes touch one entry
+// within a phase.
 __device__ __noinline__ void jacobi_eigen_wave(int n, lds_f64* A, lds_f64* V, int lane) {
     for (int i = lane; i < n * n; i += 64) V[i] = ((i / n) == (i % n)) ? 1.0 : 0.0;
     wave_lds_sync();
     double total = 0.0;
     for (int i = 0; i < n * n; ++i) total += A[i] * A[i];
     const double tol = total * 1e-32;
+    const int rounds = jacobi_num_rounds(n), np = jacobi_pairs_per_round(n);
+    const int e_of = lane / n, k_of = lane - e_of * n;  // this lane's (pair, entry) in the update phases
     for (int sweep = 0; sweep < 40; ++sweep) {
         double off = 0.0;
         for (int p = 0; p < n - 1; ++p)
             for (int q = p + 1; q < n; ++q) off += A[p * n + q] * A[p * n + q];
         if (!(off > tol)) break;
-        for (int p = 0; p < n - 1; ++p) {
-            for (int q = p + 1; q < n; ++q) {
-                const double apq = A[p * n + q];
-                if (apq == 0.0) continue;
-                const double theta = (A[q * n + q] - A[p * n + p]) / (2.0 * apq);
-                const double t = (theta >= 0.0 ? 1.0 : -1.0) / (dabs(theta) + dsqrt(theta * theta + 1.0));
-                const double c = 1.0 / dsqrt(t * t + 1.0);
-                const double s = t * c;
-                const int k = lane & 31;
-                const bool colA = lane < n, colV = lane >= 32 && k < n;
-                lds_f64* Mx = colV ? V : A;
-                double xp = 0.0, xq = 0.0;
-                if (colA || colV) { xp = Mx[k * n + p]; xq = Mx[k * n + q]; }
-                wave_lds_sync();
-                if (colA || colV) {
-                    Mx[k * n + p] = c * xp - s * xq;
-                    Mx[k * n + q] = s * xp + c * xq;
-                }
-                wave_lds_sync();
-                if (colA) { xp = A[p * n + k]; xq = A[q * n + k]; }
-                wave_lds_sync();
-                if (colA) {
-                    A[p * n + k] = c * xp - s * xq;
-                    A[q * n + k] = s * xp + c * xq;
-                }
-                wave_lds_sync();
+        for (int r = 0; r < rounds; ++r) {
+            // rotation parameters: lane e computes pair e
+            double c = 1.0, s = 0.0;
+            bool act = false;
+            if (lane < np) {
+                int p, q;
+                jacobi_pair(n, r, lane, p, q);
+                act = jacobi_rotation(A[p * n + p], A[q * n + q], A[p * n + q], c, s);
             }
+            const double ce = __shfl(c, e_of), se = __shfl(s, e_of);
+            const bool acte = __shfl((int)act, e_of) != 0 && e_of < np;
+            int p = 0, q = 0;
+            if (e_of < np) jacobi_pair(n, r, e_of, p, q);
+            wave_lds_sync();
+            if (acte) {  // columns p, q of A and V, entry k
+                const double akp = A[k_of * n + p], akq = A[k_of * n + q];
+                const double vkp = V[k_of * n + p], vkq = V[k_of * n + q];
+                A[k_of * n + p] = ce * akp - se * akq;
+                A[k_of * n + q] = se * akp + ce * akq;
+                V[k_of * n + p] = ce * vkp - se * vkq;
+                V[k_of * n + q] = se * vkp + ce * vkq;
+            }
+            wave_lds_sync();
+            if (acte) {  // rows p, q of A, entry k
+                const double apk = A[p * n + k_of], aqk = A[q * n + k_of];
+                A[p * n + k_of] = ce * apk - se * aqk;
+                A[q * n + k_of] = se * apk + ce * aqk;
+            }
+            wave_lds_sync();
         }
     }
 }
@@ -590,6 +595,128 @@ __device__ __forceinline__ int local_estimate_impl(const LoCtx& w, int kind, con
 __device__ __noinline__ int local_estimate(const LoCtx w, int kind, const Pts P, int K, double* models) {
     return P.lds ? local_estimate_impl<true>(w, kind, P, K, models)
                  : local_estimate_impl<false>(w, kind, P, K, models);
+}
+
+// ---- a chunk's minimal problems and the inlier count of every resulting model --------------------
+// One minimal problem per lane (F / H / T models stay with the solving lane, slot i = i-th root; E
+// models, up to 10 per trial, go to global memory).  Then every model of the chunk is broadcast in
+// turn (v_readlane -> scalar registers) and the whole wave counts its inliers over the
+// correspondences (ballot + popcount).  A model can only change the course of the sequential
+// algorithm if its count reaches the best count so far, so all the replay needs per trial is the
+// largest count among its models; the few trials that qualify are re-scored in full there.
+struct ChunkModels {
+    double mym[27];
+    int nmod;    // models of this lane's trial
+    int maxcnt;  // max inlier count over them (-1: none)
+    unsigned long long cyc_solve, cyc_count;
+};
+template <bool L, int KIND>
+__device__ __forceinline__ int count_model(const double (&m)[9], const Pts& P, int M, double max_res, int lane) {
+    int cnt = 0;
+#pragma unroll 2
+    for (int k0 = 0; k0 < M; k0 += 64) {
+        const int k = k0 + lane;
+        bool in = false;
+        if (k < M) {
+            double a, b, c, d;
+            load_pt<L>(P, k, a, b, c, d);
+            const double r = KIND == K_H ? h_residual(m, a, b, c, d)
+                                         : (KIND == K_T ? t_residual(m, a, b, c, d) : sampson(m, a, b, c, d));
+            in = r <= max_res;
+        }
+        cnt += __popcll(__ballot(in));
+    }
+    return cnt;
+}
+template <bool L, int KIND, int NM>
+__device__ __forceinline__ int count_lane_models(const double (&mym)[27], int nmod, const Pts& P, int M,
+                                                 double max_res, int nT, int lane) {
+    int maxcnt = -1;
+    for (int t = 0; t < nT; ++t) {
+        const int n = __builtin_amdgcn_readlane(nmod, t);
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+            if (m < n) {
+                double sm[9];
+#pragma unroll
+                for (int i = 0; i < 9; ++i) sm[i] = readlane_f64(mym[9 * m + i], t);
+                const int c = count_model<L, KIND>(sm, P, M, max_res, lane);
+                if (lane == t) maxcnt = max(maxcnt, c);
+            }
+        }
+    }
+    return maxcnt;
+}
+template <bool L>
+__device__ __forceinline__ int count_global_models(const double* models, int nmod, const Pts& P, int M,
+                                                   double max_res, int nT, int lane) {
+    int maxcnt = -1;
+    for (int t = 0; t < nT; ++t) {
+        const int n = __builtin_amdgcn_readlane(nmod, t);
+        for (int m = 0; m < n; ++m) {
+            const double* src = models + ((size_t)t * kMaxModels + m) * 9;
+            double sm[9];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) sm[i] = readlane_f64(src[i], 0);
+            const int c = count_model<L, K_F7>(sm, P, M, max_res, lane);
+            if (lane == t) maxcnt = max(maxcnt, c);
+        }
+    }
+    return maxcnt;
+}
+
+__device__ __noinline__ void solve_count_chunk(ChunkModels* out, int est, const Pts P, const lds_u16* sidx, int M,
+                                               double max_res, int nT, int lane, double* models) {
+    const unsigned long long c0 = __builtin_readcyclecounter();
+    int nmod = 0;
+    double mym[27];
+#pragma unroll
+    for (int i = 0; i < 27; ++i) mym[i] = 0.0;
+    if (lane < nT) {
+        if (est == K_F7) {
+            double sx1[7], sy1[7], sx2[7], sy2[7];
+#pragma unroll
+            for (int i = 0; i < 7; ++i) load_pt_any(P, sidx[lane * 8 + i], sx1[i], sy1[i], sx2[i], sy2[i]);
+            nmod = estimate_f7(sx1, sy1, sx2, sy2, mym);
+        } else if (est == K_H) {
+            double sx1[4], sy1[4], sx2[4], sy2[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) load_pt_any(P, sidx[lane * 8 + i], sx1[i], sy1[i], sx2[i], sy2[i]);
+            estimate_h4(sx1, sy1, sx2, sy2, mym);
+            nmod = 1;
+        } else if (est == K_E5) {
+            double sx1[5], sy1[5], sx2[5], sy2[5];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) load_pt_any(P, sidx[lane * 8 + i], sx1[i], sy1[i], sx2[i], sy2[i]);
+            nmod = estimate_e5_minimal(sx1, sy1, sx2, sy2, models + (size_t)lane * kMaxModels * 9);
+        } else {  // K_T: model = dst - src of the single sample
+            double a, b, c, d;
+            load_pt_any(P, sidx[lane * 8], a, b, c, d);
+            mym[0] = c - a;
+            mym[1] = d - b;
+            nmod = 1;
+        }
+    }
+    wave_mem_sync();
+    const unsigned long long c1 = __builtin_readcyclecounter();
+    int maxcnt;
+    if (P.lds) {
+        if (est == K_F7) maxcnt = count_lane_models<true, K_F7, 3>(mym, nmod, P, M, max_res, nT, lane);
+        else if (est == K_H) maxcnt = count_lane_models<true, K_H, 1>(mym, nmod, P, M, max_res, nT, lane);
+        else if (est == K_T) maxcnt = count_lane_models<true, K_T, 1>(mym, nmod, P, M, max_res, nT, lane);
+        else maxcnt = count_global_models<true>(models, nmod, P, M, max_res, nT, lane);
+    } else {
+        if (est == K_F7) maxcnt = count_lane_models<false, K_F7, 3>(mym, nmod, P, M, max_res, nT, lane);
+        else if (est == K_H) maxcnt = count_lane_models<false, K_H, 1>(mym, nmod, P, M, max_res, nT, lane);
+        else if (est == K_T) maxcnt = count_lane_models<false, K_T, 1>(mym, nmod, P, M, max_res, nT, lane);
+        else maxcnt = count_global_models<false>(models, nmod, P, M, max_res, nT, lane);
+    }
+#pragma unroll
+    for (int i = 0; i < 27; ++i) out->mym[i] = mym[i];
+    out->nmod = nmod;
+    out->maxcnt = maxcnt;
+    out->cyc_solve = c1 - c0;
+    out->cyc_count = __builtin_readcyclecounter() - c1;
 }
 
 struct Report {
@@ -666,44 +793,27 @@ __device__ Report lo_ransac(Wave& w_io, const RansacCfg& cfg, const double* gx, 
         ss = sample_chunk(w.mt, w.snap, w.perm, w.sidx, w.rawcnt, ss, M, kMin, nT, lane, cfg.force_slow_sampler);
         w.mti = ss.mti;
         { const unsigned long long tp1 = __builtin_readcyclecounter(); w.prof[0] += tp1 - tp0; tp0 = tp1; }
-        // ---- 64 minimal problems, one per lane.  F / H / T models stay in the solving lane's
-        //      registers (slot i = i-th root) and are broadcast with v_readlane during the replay;
-        //      E models (up to 10) go through global memory.
-        int nmod = 0;
-        double mym[27];
-#pragma unroll
-        for (int i = 0; i < 27; ++i) mym[i] = 0.0;
-        if (lane < nT) {
-            if (cfg.est == K_F7) {
-                double sx1[7], sy1[7], sx2[7], sy2[7];
-#pragma unroll
-                for (int i = 0; i < 7; ++i) load_pt_any(P, w.sidx[lane * 8 + i], sx1[i], sy1[i], sx2[i], sy2[i]);
-                nmod = estimate_f7(sx1, sy1, sx2, sy2, mym);
-            } else if (cfg.est == K_H) {
-                double sx1[4], sy1[4], sx2[4], sy2[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) load_pt_any(P, w.sidx[lane * 8 + i], sx1[i], sy1[i], sx2[i], sy2[i]);
-                estimate_h4(sx1, sy1, sx2, sy2, mym);
-                nmod = 1;
-            } else if (cfg.est == K_E5) {
-                double sx1[5], sy1[5], sx2[5], sy2[5];
-#pragma unroll
-                for (int i = 0; i < 5; ++i) load_pt_any(P, w.sidx[lane * 8 + i], sx1[i], sy1[i], sx2[i], sy2[i]);
-                nmod = estimate_e5_minimal(sx1, sy1, sx2, sy2, models + (size_t)lane * kMaxModels * 9);
-            } else {  // K_T: model = dst - src of the single sample
-                double a, b, c, d;
-                load_pt_any(P, w.sidx[lane * 8], a, b, c, d);
-                mym[0] = c - a;
-                mym[1] = d - b;
-                nmod = 1;
-            }
-        }
-        wave_mem_sync();
-        { const unsigned long long tp1 = __builtin_readcyclecounter(); w.prof[1] += tp1 - tp0; tp0 = tp1; }
-        // ---- replay in trial order ------------------------------------------------------------
-        for (int t = 0; t < nT && !aborted; ++t) {
+        // ---- 64 minimal problems + the inlier count of every model (solve_count_chunk) ---------
+        ChunkModels cm;
+        solve_count_chunk(&cm, cfg.est, P, w.sidx, M, cfg.max_res, nT, lane, models);
+        w.prof[1] += cm.cyc_solve;
+        if (cfg.est == K_E5) w.prof[5] += cm.cyc_solve;
+        tp0 = __builtin_readcyclecounter();
+        // ---- replay in trial order.  Only two kinds of trial can change anything: one holding a
+        //      model whose count reaches the best so far (candidate: re-scored in full, exactly as
+        //      the sequential loop would), and the first trial with a model at or beyond the
+        //      adaptive trial limit (abort).  Everything in between is skipped.
+        const unsigned long long live = nT == 64 ? ~0ull : ((1ull << nT) - 1ull);
+        int t = 0;
+        while (!aborted) {
+            const long long lim = (long long)(dyn_max > (uint32_t)cfg.min_trials ? dyn_max : (uint32_t)cfg.min_trials) - chunk;
+            const unsigned long long cand = __ballot(cm.nmod > 0 && cm.maxcnt >= best.cnt);
+            const unsigned long long stop = __ballot(cm.nmod > 0 && (long long)lane >= lim);
+            const unsigned long long ev = (cand | stop) & live & (t >= 64 ? 0ull : (~0ull << t));
+            if (ev == 0ull) break;
+            t = (int)__builtin_ctzll(ev);
             const int trial = chunk + t;
-            const int n = __builtin_amdgcn_readlane(nmod, t);
+            const int n = __builtin_amdgcn_readlane(cm.nmod, t);
             for (int m = 0; m < n; ++m) {
                 Model9 smv;
                 double* sm = smv.v;
@@ -711,11 +821,7 @@ __device__ Report lo_ransac(Wave& w_io, const RansacCfg& cfg, const double* gx, 
                     const double* src = models + ((size_t)t * kMaxModels + m) * 9;
                     for (int i = 0; i < 9; ++i) sm[i] = src[i];
                 } else {
-#pragma unroll
-                    for (int i = 0; i < 9; ++i) {
-                        const double mine = m == 0 ? mym[i] : (m == 1 ? mym[9 + i] : mym[18 + i]);
-                        sm[i] = readlane_f64(mine, t);
-                    }
+                    for (int i = 0; i < 9; ++i) sm[i] = readlane_f64(cm.mym[9 * m + i], t);
                 }
                 const Support sup = score(cfg.est, smv, P, M, cfg.max_res, lane, best.cnt);
                 if (better(sup, best)) {
@@ -732,7 +838,10 @@ __device__ Report lo_ransac(Wave& w_io, const RansacCfg& cfg, const double* gx, 
                         for (int lt = 0; lt < 10; ++lt) {
                             const int K = extract_inliers(w.inl, lane, cur_kind, cur, P, M, cfg.max_res);
                             double lm[kMaxModels * 9];
+                            const unsigned long long tle = __builtin_readcyclecounter();
                             const int nl = local_estimate(lo, cfg.local_est, P, K, lm);
+                            if (cfg.local_est == K_E5) w.prof[6] += __builtin_readcyclecounter() - tle;
+                            else if (cfg.local_est == K_F8) w.prof[7] += __builtin_readcyclecounter() - tle;
                             const int prev = best.cnt;
                             for (int q = 0; q < nl; ++q) {
                                 Model9 lmv;
@@ -758,7 +867,9 @@ __device__ Report lo_ransac(Wave& w_io, const RansacCfg& cfg, const double* gx, 
                     break;
                 }
             }
+            ++t;
         }
+        w.prof[2] += cm.cyc_count;
         { const unsigned long long tp1 = __builtin_readcyclecounter(); w.prof[2] += tp1 - tp0; }
         if (aborted) {
             // roll the generator back to where the sequential algorithm stopped drawing
@@ -781,7 +892,7 @@ __device__ Report lo_ransac(Wave& w_io, const RansacCfg& cfg, const double* gx, 
     rep.support = best;
     for (int i = 0; i < 9; ++i) rep.model[i] = best_model[i];
     w_io.mti = w.mti;
-    for (int i = 0; i < 5; ++i) w_io.prof[i] = w.prof[i];
+    for (int i = 0; i < 8; ++i) w_io.prof[i] = w.prof[i];
     if (best.cnt < kMin) return rep;
     rep.success = true;
     const int fk = best_is_local ? cfg.local_est : cfg.est;
@@ -808,7 +919,7 @@ __device__ __noinline__ void process_pair(Wave& w, uint32_t q, const TvgImage* _
                                           TvgOut* __restrict__ out, uint8_t* __restrict__ out_mask) {
     const int lane = w.lane;
     const uint32_t mcap = w.mcap;
-    for (int i = 0; i < 5; ++i) w.prof[i] = 0;
+    for (int i = 0; i < 8; ++i) w.prof[i] = 0;
     const unsigned long long tstart = __builtin_readcyclecounter();
     const TvgPair pr = pairs[q];
     const TvgImage im1 = imgs[pr.slot1], im2 = imgs[pr.slot2];
@@ -997,7 +1108,7 @@ __device__ __noinline__ void process_pair(Wave& w, uint32_t q, const TvgImage* _
     if (lane == 0) {
         out[q].g = g;
         w.prof[4] = __builtin_readcyclecounter() - tstart;
-        for (int i = 0; i < 5; ++i) out[q].prof[i] = w.prof[i];
+        for (int i = 0; i < 8; ++i) out[q].prof[i] = w.prof[i];
     }
 }
 

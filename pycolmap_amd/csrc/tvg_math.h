@@ -8,7 +8,7 @@
 //
 // Algorithms (own restatement; COLMAP uses Eigen):
 //   null spaces      Gauss-Jordan with full pivoting (minimal solvers)
-//   least squares    smallest eigenvector(s) of A^T A by cyclic Jacobi
+//   least squares    smallest eigenvector(s) of A^T A by round-robin Jacobi
 //   rank-2           project out the smallest right singular vector
 //   roots            bottom-up bracketing over the derivative chain + bisection
 #pragma once
@@ -74,40 +74,76 @@ AMC_HD double t_residual(const double* t, double s_0, double s_1, double d_0, do
     return d0 * d0 + d1 * d1;
 }
 
-// ---- cyclic Jacobi eigen-decomposition, symmetric n x n (n <= 9), fixed rotation order --------
+// ---- Jacobi eigen-decomposition, symmetric n x n (n <= 9), round-robin ordering -----------------
+// A sweep is `m` rounds (m = n if n is odd, n - 1 otherwise); the pairs of a round are disjoint,
+// their rotations are computed from the matrix at the start of the round and applied as one
+// similarity transform: columns (A and V) first, rows second.  See oracle/tvg_oracle.cc.
+AMC_HD int jacobi_num_rounds(int n) { return (n & 1) ? n : n - 1; }
+AMC_HD int jacobi_pairs_per_round(int n) { return n / 2; }
+// e-th pair of round r -> (p, q), p < q
+AMC_HD void jacobi_pair(int n, int r, int e, int& p, int& q) {
+    const int m = jacobi_num_rounds(n);
+    int x, y;
+    if (e < (m - 1) / 2) {
+        x = (r + e + 1) % m;
+        y = (r - (e + 1) + m) % m;
+    } else {
+        x = r;
+        y = n - 1;
+    }
+    p = x < y ? x : y;
+    q = x < y ? y : x;
+}
+// rotation that annihilates a[p][q]; returns false (no rotation) when it is already zero
+AMC_HD bool jacobi_rotation(double app, double aqq, double apq, double& c, double& s) {
+    if (apq == 0.0) return false;
+    const double theta = (aqq - app) / (2.0 * apq);
+    const double t = (theta >= 0.0 ? 1.0 : -1.0) / (dabs(theta) + dsqrt(theta * theta + 1.0));
+    c = 1.0 / dsqrt(t * t + 1.0);
+    s = t * c;
+    return true;
+}
 AMC_HD void jacobi_eigen(int n, double* a, double* v) {
     for (int i = 0; i < n; ++i)
         for (int j = 0; j < n; ++j) v[i * n + j] = (i == j) ? 1.0 : 0.0;
     double total = 0.0;
     for (int i = 0; i < n * n; ++i) total += a[i] * a[i];
     const double tol = total * 1e-32;
+    const int rounds = jacobi_num_rounds(n), np = jacobi_pairs_per_round(n);
     for (int sweep = 0; sweep < 40; ++sweep) {
         double off = 0.0;
         for (int p = 0; p < n - 1; ++p)
             for (int q = p + 1; q < n; ++q) off += a[p * n + q] * a[p * n + q];
         if (!(off > tol)) break;
-        for (int p = 0; p < n - 1; ++p) {
-            for (int q = p + 1; q < n; ++q) {
-                const double apq = a[p * n + q];
-                if (apq == 0.0) continue;
-                const double theta = (a[q * n + q] - a[p * n + p]) / (2.0 * apq);
-                const double t = (theta >= 0.0 ? 1.0 : -1.0) / (dabs(theta) + dsqrt(theta * theta + 1.0));
-                const double c = 1.0 / dsqrt(t * t + 1.0);
-                const double s = t * c;
+        for (int r = 0; r < rounds; ++r) {
+            double c[5], s[5];
+            bool act[5];
+            for (int e = 0; e < np; ++e) {
+                int p, q;
+                jacobi_pair(n, r, e, p, q);
+                act[e] = jacobi_rotation(a[p * n + p], a[q * n + q], a[p * n + q], c[e], s[e]);
+            }
+            for (int e = 0; e < np; ++e) {
+                if (!act[e]) continue;
+                int p, q;
+                jacobi_pair(n, r, e, p, q);
                 for (int k = 0; k < n; ++k) {
                     const double akp = a[k * n + p], akq = a[k * n + q];
-                    a[k * n + p] = c * akp - s * akq;
-                    a[k * n + q] = s * akp + c * akq;
+                    a[k * n + p] = c[e] * akp - s[e] * akq;
+                    a[k * n + q] = s[e] * akp + c[e] * akq;
+                    const double vkp = v[k * n + p], vkq = v[k * n + q];
+                    v[k * n + p] = c[e] * vkp - s[e] * vkq;
+                    v[k * n + q] = s[e] * vkp + c[e] * vkq;
                 }
+            }
+            for (int e = 0; e < np; ++e) {
+                if (!act[e]) continue;
+                int p, q;
+                jacobi_pair(n, r, e, p, q);
                 for (int k = 0; k < n; ++k) {
                     const double apk = a[p * n + k], aqk = a[q * n + k];
-                    a[p * n + k] = c * apk - s * aqk;
-                    a[q * n + k] = s * apk + c * aqk;
-                }
-                for (int k = 0; k < n; ++k) {
-                    const double vkp = v[k * n + p], vkq = v[k * n + q];
-                    v[k * n + p] = c * vkp - s * vkq;
-                    v[k * n + q] = s * vkp + c * vkq;
+                    a[p * n + k] = c[e] * apk - s[e] * aqk;
+                    a[q * n + k] = s[e] * apk + c[e] * aqk;
                 }
             }
         }
@@ -224,20 +260,30 @@ AMC_HD void nullspace_reg(double (&a)[R][9], double (&ns)[9 - R][9]) {
 }
 
 // ---- real roots, ascending --------------------------------------------------------------------
+// Everything below is written with compile-time degrees and fully unrolled loops: coefficient
+// arrays are then indexed statically and live in registers on the GPU (a run-time degree puts them
+// in scratch memory, one dependent memory round trip per Horner step).
+template <int DEG>
+AMC_HD double poly_eval_t(const double (&c)[DEG + 1], double x) {
+    double v = c[DEG];
+#pragma unroll
+    for (int i = DEG - 1; i >= 0; --i) v = v * x + c[i];
+    return v;
+}
 AMC_HD double poly_eval(const double* c, int deg, double x) {
     double v = c[deg];
     for (int i = deg - 1; i >= 0; --i) v = v * x + c[i];
     return v;
 }
-AMC_HD int roots_between(const double* c, int deg, const double* crit, int nc, double* roots) {
-    if (deg == 1) {
-        roots[0] = -c[0] / c[1];
-        return 1;
-    }
+// real roots of c (degree DEG >= 2, c[DEG] != 0) given the real roots `crit` of its derivative:
+// one sign-change bisection per monotone interval, ascending
+template <int DEG>
+AMC_HD int roots_between_t(const double (&c)[DEG + 1], const double* crit, int nc, double* roots) {
     double bound = 0.0;
-    for (int i = 0; i < deg; ++i) bound = dmax(bound, dabs(c[i] / c[deg]));
+#pragma unroll
+    for (int i = 0; i < DEG; ++i) bound = dmax(bound, dabs(c[i] / c[DEG]));
     bound = 1.0 + bound;
-    double edges[12];
+    double edges[DEG + 1];
     int ne = 0;
     edges[ne++] = -bound;
     for (int i = 0; i < nc; ++i)
@@ -246,8 +292,8 @@ AMC_HD int roots_between(const double* c, int deg, const double* crit, int nc, d
     int nr = 0;
     for (int i = 0; i + 1 < ne; ++i) {
         double lo = edges[i], hi = edges[i + 1];
-        double flo = poly_eval(c, deg, lo);
-        const double fhi = poly_eval(c, deg, hi);
+        double flo = poly_eval_t<DEG>(c, lo);
+        const double fhi = poly_eval_t<DEG>(c, hi);
         if (flo == 0.0) {
             if (nr == 0 || roots[nr - 1] != lo) roots[nr++] = lo;
             continue;
@@ -257,33 +303,83 @@ AMC_HD int roots_between(const double* c, int deg, const double* crit, int nc, d
         for (int it = 0; it < 200; ++it) {
             const double mid = 0.5 * (lo + hi);
             if (mid == lo || mid == hi) break;
-            const double fm = poly_eval(c, deg, mid);
+            const double fm = poly_eval_t<DEG>(c, mid);
             if (fm == 0.0) { lo = mid; hi = mid; break; }
             if ((fm < 0.0) == (flo < 0.0)) { lo = mid; flo = fm; } else { hi = mid; }
         }
         roots[nr++] = 0.5 * (lo + hi);
     }
-    if (poly_eval(c, deg, edges[ne - 1]) == 0.0 && (nr == 0 || roots[nr - 1] != edges[ne - 1]))
+    if (poly_eval_t<DEG>(c, edges[ne - 1]) == 0.0 && (nr == 0 || roots[nr - 1] != edges[ne - 1]))
         roots[nr++] = edges[ne - 1];
     return nr;
 }
-AMC_HD int real_roots(const double* c_in, int deg_in, double* roots) {
-    int deg = deg_in;
-    while (deg > 0 && c_in[deg] == 0.0) --deg;
-    if (deg == 0) return 0;
-    double chain[11][11];
-    for (int i = 0; i <= deg; ++i) chain[0][i] = c_in[i];
-    for (int j = 1; j < deg; ++j)
-        for (int i = 1; i <= deg - j + 1; ++i) chain[j][i - 1] = chain[j - 1][i] * i;
-    double crit[10], cur[10];
-    int nc = 0;
-    for (int j = deg - 1; j >= 0; --j) {
-        const int n = roots_between(chain[j], deg - j, crit, nc, cur);
-        nc = n;
-        for (int i = 0; i < n; ++i) crit[i] = cur[i];
+// J-th derivative of c (degree DEG), coefficient by coefficient as the chain of successive
+// derivatives produces it: d[m] = (...((c[m+J] * (m+J)) * (m+J-1)) ... * (m+1))
+template <int DEG, int J>
+AMC_HD void poly_derivative_t(const double (&c)[DEG + 1], double (&d)[DEG - J + 1]) {
+#pragma unroll
+    for (int m = 0; m <= DEG - J; ++m) {
+        double v = c[m + J];
+#pragma unroll
+        for (int f = m + J; f > m; --f) v = v * f;
+        d[m] = v;
     }
-    for (int i = 0; i < nc; ++i) roots[i] = crit[i];
-    return nc;
+}
+// roots of the derivative of c that has degree R (the (DEG-R)-th), recursively from the roots of
+// the next one; the linear one is solved directly
+template <int DEG, int R>
+struct RootChain {
+    static AMC_HD int run(const double (&c)[DEG + 1], double* roots) {
+        double crit[R];
+        const int nc = RootChain<DEG, R - 1>::run(c, crit);
+        double d[R + 1];
+        poly_derivative_t<DEG, DEG - R>(c, d);
+        return roots_between_t<R>(d, crit, nc, roots);
+    }
+};
+template <int DEG>
+struct RootChain<DEG, 1> {
+    static AMC_HD int run(const double (&c)[DEG + 1], double* roots) {
+        double d[2];
+        poly_derivative_t<DEG, DEG - 1>(c, d);
+        roots[0] = -d[0] / d[1];
+        return 1;
+    }
+};
+// all real roots of a polynomial of degree <= DEG (low -> high coefficients), ascending;
+// leading zero coefficients lower the degree
+template <int DEG>
+struct RealRoots {
+    static AMC_HD int run(const double (&c)[DEG + 1], double* roots) {
+        if (c[DEG] == 0.0) {
+            double lower[DEG];
+#pragma unroll
+            for (int i = 0; i < DEG; ++i) lower[i] = c[i];
+            return RealRoots<DEG - 1>::run(lower, roots);
+        }
+        return RootChain<DEG, DEG>::run(c, roots);
+    }
+};
+template <>
+struct RealRoots<0> {
+    static AMC_HD int run(const double (&)[1], double*) { return 0; }
+};
+template <int DEG>
+AMC_HD int real_roots_t(const double (&c)[DEG + 1], double* roots) { return RealRoots<DEG>::run(c, roots); }
+// run-time degree (<= 10) front end
+AMC_HD int real_roots(const double* c_in, int deg_in, double* roots) {
+#define AMC_RR_CASE(D)                                   \
+    case D: {                                            \
+        double cc[D + 1];                                \
+        for (int i = 0; i <= D; ++i) cc[i] = c_in[i];    \
+        return real_roots_t<D>(cc, roots);               \
+    }
+    switch (deg_in) {
+        AMC_RR_CASE(1) AMC_RR_CASE(2) AMC_RR_CASE(3) AMC_RR_CASE(4) AMC_RR_CASE(5)
+        AMC_RR_CASE(6) AMC_RR_CASE(7) AMC_RR_CASE(8) AMC_RR_CASE(9) AMC_RR_CASE(10)
+        default: return 0;
+    }
+#undef AMC_RR_CASE
 }
 
 // ---- 7-point fundamental matrix (FundamentalMatrixSevenPointEstimator::Estimate) ---------------
@@ -322,7 +418,7 @@ AMC_HD int estimate_f7(const double* x1s, const double* y1s, const double* x2s, 
         c[3] += sg[m] * (e1 * mn[m][2]);
     }
     double roots[3] = {0.0, 0.0, 0.0};
-    const int nr = real_roots(c, 3, roots);
+    const int nr = real_roots_t<3>(c, roots);
     // models are the accepted roots in ascending order; compaction with predicated static slots
     int nm = 0;
 #pragma unroll
@@ -438,81 +534,138 @@ AMC_HD void estimate_h4(const double* x1, const double* y1, const double* x2, co
 #define AMC_M21 {{0, 2, 4, 5}, {3, 1, 6, 7}, {2, 3, 8, 9}, {4, 8, 10, 11}, {5, 9, 11, 12}, \
                  {8, 6, 13, 14}, {9, 7, 14, 15}, {10, 13, 16, 17}, {11, 14, 17, 18}, {12, 15, 18, 19}}
 
-AMC_HD void e5_mul11(const double* a, const double* b, double* r) {
-    const int M[4][4] = AMC_M11;
-    for (int i = 0; i < 10; ++i) r[i] = 0.0;
-    for (int i = 0; i < 4; ++i)
-        for (int j = 0; j < 4; ++j) r[M[i][j]] += a[i] * b[j];
+// index tables as constexpr functions so that, with the loops unrolled, every array index below is a
+// compile-time constant (registers instead of scratch memory on the GPU)
+AMC_HD constexpr int e5_m11(int i, int j) {
+    constexpr int M[4][4] = AMC_M11;
+    return M[i][j];
 }
-AMC_HD void e5_mul21(const double* a, const double* b, double* r) {
-    const int M[10][4] = AMC_M21;
+AMC_HD constexpr int e5_m21(int i, int j) {
+    constexpr int M[10][4] = AMC_M21;
+    return M[i][j];
+}
+// r = a * b for a, b linear in (x, y, z, 1): 10 quadratic monomial coefficients
+AMC_HD void e5_mul11(const double (&a)[4], const double (&b)[4], double (&r)[10]) {
+#pragma unroll
+    for (int i = 0; i < 10; ++i) r[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r[e5_m11(i, j)] += a[i] * b[j];
+}
+// r = a * b for a quadratic, b linear: 20 cubic monomial coefficients
+AMC_HD void e5_mul21(const double (&a)[10], const double (&b)[4], double (&r)[20]) {
+#pragma unroll
     for (int i = 0; i < 20; ++i) r[i] = 0.0;
+#pragma unroll
     for (int i = 0; i < 10; ++i)
-        for (int j = 0; j < 4; ++j) r[M[i][j]] += a[i] * b[j];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r[e5_m21(i, j)] += a[i] * b[j];
+}
+// r = a * b for univariate polynomials of degree DA, DB (low -> high), i outer / j inner
+template <int DA, int DB>
+AMC_HD void e5_pmul(const double (&a)[DA + 1], const double (&b)[DB + 1], double (&r)[DA + DB + 1]) {
+#pragma unroll
+    for (int i = 0; i <= DA + DB; ++i) r[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i <= DA; ++i)
+#pragma unroll
+        for (int j = 0; j <= DB; ++j) r[i + j] += a[i] * b[j];
 }
 
 // nsp: 4 x 9 basis (rows: x, y, z, 1 directions).  Returns #models (<= 10), row-major.
 AMC_HD int e5_from_nullspace(const double* nsp, double* models /* 10 x 9 */) {
     double e[9][4];
+#pragma unroll
     for (int k = 0; k < 9; ++k)
+#pragma unroll
         for (int d = 0; d < 4; ++d) e[k][d] = nsp[d * 9 + k];
     double G[10][20];
     {   // det(E) -> row 0
         double a[10], b[10], d[10], t0[20], t1[20], t2[20];
         e5_mul11(e[4], e[8], a); e5_mul11(e[5], e[7], b);
+#pragma unroll
         for (int i = 0; i < 10; ++i) d[i] = a[i] - b[i];
         e5_mul21(d, e[0], t0);
         e5_mul11(e[3], e[8], a); e5_mul11(e[5], e[6], b);
+#pragma unroll
         for (int i = 0; i < 10; ++i) d[i] = a[i] - b[i];
         e5_mul21(d, e[1], t1);
         e5_mul11(e[3], e[7], a); e5_mul11(e[4], e[6], b);
+#pragma unroll
         for (int i = 0; i < 10; ++i) d[i] = a[i] - b[i];
         e5_mul21(d, e[2], t2);
+#pragma unroll
         for (int i = 0; i < 20; ++i) G[0][i] = (t0[i] - t1[i]) + t2[i];
     }
-    double eet[9][10], tr[10];
-    for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) {
-            double a[10], b[10], c[10];
-            e5_mul11(e[3 * i], e[3 * j], a);
-            e5_mul11(e[3 * i + 1], e[3 * j + 1], b);
-            e5_mul11(e[3 * i + 2], e[3 * j + 2], c);
-            for (int t = 0; t < 10; ++t) eet[3 * i + j][t] = (a[t] + b[t]) + c[t];
-        }
-    for (int t = 0; t < 10; ++t) tr[t] = (eet[0][t] + eet[4][t]) + eet[8][t];
-    for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) {
-            double a[20], b[20], c[20], d[20];
-            e5_mul21(eet[3 * i], e[j], a);
-            e5_mul21(eet[3 * i + 1], e[3 + j], b);
-            e5_mul21(eet[3 * i + 2], e[6 + j], c);
-            e5_mul21(tr, e[3 * i + j], d);
-            for (int t = 0; t < 20; ++t) G[1 + 3 * i + j][t] = ((a[t] + b[t]) + c[t]) * 2.0 - d[t];
-        }
+    {
+        double eet[9][10], tr[10];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                double a[10], b[10], c[10];
+                e5_mul11(e[3 * i], e[3 * j], a);
+                e5_mul11(e[3 * i + 1], e[3 * j + 1], b);
+                e5_mul11(e[3 * i + 2], e[3 * j + 2], c);
+#pragma unroll
+                for (int t = 0; t < 10; ++t) eet[3 * i + j][t] = (a[t] + b[t]) + c[t];
+            }
+#pragma unroll
+        for (int t = 0; t < 10; ++t) tr[t] = (eet[0][t] + eet[4][t]) + eet[8][t];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                double a[20], b[20], c[20], d[20];
+                e5_mul21(eet[3 * i], e[j], a);
+                e5_mul21(eet[3 * i + 1], e[3 + j], b);
+                e5_mul21(eet[3 * i + 2], e[6 + j], c);
+                e5_mul21(tr, e[3 * i + j], d);
+#pragma unroll
+                for (int t = 0; t < 20; ++t) G[1 + 3 * i + j][t] = ((a[t] + b[t]) + c[t]) * 2.0 - d[t];
+            }
+    }
+    // Gauss-Jordan with partial pivoting on the left 10 x 10 block.  The only run-time index is the
+    // pivot row of the swap.
+#pragma unroll
     for (int col = 0; col < 10; ++col) {
         int piv = col;
         double pv = dabs(G[col][col]);
+#pragma unroll
         for (int r = col + 1; r < 10; ++r)
             if (dabs(G[r][col]) > pv) { pv = dabs(G[r][col]); piv = r; }
-        if (piv != col)
-            for (int c = 0; c < 20; ++c) { const double t = G[col][c]; G[col][c] = G[piv][c]; G[piv][c] = t; }
+        if (piv != col) {
+#pragma unroll
+            for (int r = col + 1; r < 10; ++r)
+                if (r == piv) {
+#pragma unroll
+                    for (int c = 0; c < 20; ++c) { const double t = G[col][c]; G[col][c] = G[r][c]; G[r][c] = t; }
+                }
+        }
         const double inv = 1.0 / G[col][col];
+#pragma unroll
         for (int c = 0; c < 20; ++c) G[col][c] = G[col][c] * inv;
+#pragma unroll
         for (int r = 0; r < 10; ++r) {
             if (r == col) continue;
             const double f = G[r][col];
+#pragma unroll
             for (int c = 0; c < 20; ++c) G[r][c] = G[r][c] - f * G[col][c];
         }
     }
     double B[3][3][5];  // B[k][0..1]: degree 3, B[k][2]: degree 4 (low -> high)
+#pragma unroll
     for (int k = 0; k < 3; ++k) {
-        const double* hi = G[4 + 2 * k];
-        const double* lo = G[5 + 2 * k];
+        const double (&hi)[20] = G[4 + 2 * k];
+        const double (&lo)[20] = G[5 + 2 * k];
+#pragma unroll
         for (int t = 0; t < 3; ++t)
+#pragma unroll
             for (int d = 0; d < 5; ++d) B[k][t][d] = 0.0;
-        double* a = B[k][0];
-        double* b = B[k][1];
-        double* c = B[k][2];
+        double (&a)[5] = B[k][0];
+        double (&b)[5] = B[k][1];
+        double (&c)[5] = B[k][2];
         a[2] += hi[10]; a[1] += hi[11]; a[0] += hi[12];
         b[2] += hi[13]; b[1] += hi[14]; b[0] += hi[15];
         c[3] += hi[16]; c[2] += hi[17]; c[1] += hi[18]; c[0] += hi[19];
@@ -520,26 +673,35 @@ AMC_HD int e5_from_nullspace(const double* nsp, double* models /* 10 x 9 */) {
         b[3] -= lo[13]; b[2] -= lo[14]; b[1] -= lo[15];
         c[4] -= lo[16]; c[3] -= lo[17]; c[2] -= lo[18]; c[1] -= lo[19];
     }
-    // det B(z) with the oracle's accumulation order: pz_mul (i outer, j inner), sub, add
-    auto pmul = [](const double* a, int da, const double* b, int db, double* r) {
-        for (int i = 0; i <= da + db; ++i) r[i] = 0.0;
-        for (int i = 0; i <= da; ++i)
-            for (int j = 0; j <= db; ++j) r[i + j] += a[i] * b[j];
-    };
-    double u[11], w[11], m0[11], m1[11], m2[11];
-    pmul(B[1][1], 3, B[2][2], 4, u); pmul(B[1][2], 4, B[2][1], 3, w);
-    for (int i = 0; i <= 7; ++i) m0[i] = u[i] - w[i];
-    pmul(B[1][0], 3, B[2][2], 4, u); pmul(B[1][2], 4, B[2][0], 3, w);
-    for (int i = 0; i <= 7; ++i) m1[i] = u[i] - w[i];
-    pmul(B[1][0], 3, B[2][1], 3, u); pmul(B[1][1], 3, B[2][0], 3, w);
-    for (int i = 0; i <= 6; ++i) m2[i] = u[i] - w[i];
-    double q0[11], q1[11], q2[11], det[11];
-    pmul(B[0][0], 3, m0, 7, q0);
-    pmul(B[0][1], 3, m1, 7, q1);
-    pmul(B[0][2], 4, m2, 6, q2);
-    for (int i = 0; i <= 10; ++i) det[i] = (q0[i] - q1[i]) + q2[i];
+    // det B(z) with the oracle's accumulation order: pz_mul (i outer, j inner), sub, add.  B[k][0]
+    // and B[k][1] are cubics stored in 5 slots: the products below use their 4 coefficients.
+    double det[11];
+    {
+        double b00[4], b01[4], b10[4], b11[4], b20[4], b21[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            b00[i] = B[0][0][i]; b01[i] = B[0][1][i]; b10[i] = B[1][0][i];
+            b11[i] = B[1][1][i]; b20[i] = B[2][0][i]; b21[i] = B[2][1][i];
+        }
+        double u8[8], w8[8], u7[7], w7[7], m0[8], m1[8], m2[7];
+        e5_pmul<3, 4>(b11, B[2][2], u8); e5_pmul<4, 3>(B[1][2], b21, w8);
+#pragma unroll
+        for (int i = 0; i <= 7; ++i) m0[i] = u8[i] - w8[i];
+        e5_pmul<3, 4>(b10, B[2][2], u8); e5_pmul<4, 3>(B[1][2], b20, w8);
+#pragma unroll
+        for (int i = 0; i <= 7; ++i) m1[i] = u8[i] - w8[i];
+        e5_pmul<3, 3>(b10, b21, u7); e5_pmul<3, 3>(b11, b20, w7);
+#pragma unroll
+        for (int i = 0; i <= 6; ++i) m2[i] = u7[i] - w7[i];
+        double q0[11], q1[11], q2[11];
+        e5_pmul<3, 7>(b00, m0, q0);
+        e5_pmul<3, 7>(b01, m1, q1);
+        e5_pmul<4, 6>(B[0][2], m2, q2);
+#pragma unroll
+        for (int i = 0; i <= 10; ++i) det[i] = (q0[i] - q1[i]) + q2[i];
+    }
     double roots[10];
-    const int nr = real_roots(det, 10, roots);
+    const int nr = real_roots_t<10>(det, roots);
     for (int i = 0; i < nr; ++i) {
         const double z = roots[i];
         const double a0 = poly_eval(B[0][0], 3, z), b0 = poly_eval(B[0][1], 3, z), c0 = poly_eval(B[0][2], 4, z);
