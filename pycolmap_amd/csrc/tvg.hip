@@ -288,6 +288,26 @@ struct Pts {
     uint32_t ls, gs;
     bool lds;          // wave-uniform
 };
+// wave-uniform values that arrive in vector registers (function arguments) -> scalar registers
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ double uni(double v) { return readlane_f64(v, 0); }
+template <class T>
+__device__ __forceinline__ T* uni_ptr(T* p) {
+    const unsigned long long u = (unsigned long long)p;
+    const unsigned lo = uni((uint32_t)u), hi = uni((uint32_t)(u >> 32));
+    return (T*)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ Pts uni(Pts P) {
+    Pts Q;
+    Q.l = (const lds_f64*)(uintptr_t)uni((uint32_t)(uintptr_t)P.l);
+    Q.g = uni_ptr(P.g);
+    Q.ls = uni(P.ls);
+    Q.gs = uni(P.gs);
+    Q.lds = uni((int)P.lds) != 0;
+    return Q;
+}
+
 template <bool L>
 __device__ __forceinline__ void load_pt(const Pts& P, int k, double& a, double& b, double& c, double& d) {
     if (L) {
@@ -344,9 +364,14 @@ __device__ __forceinline__ Support score_impl(const double* m, const Pts& P, int
     s.sum = cnt >= need_sum_from ? butterfly(acc) : 1.7976931348623157e308;
     return s;
 }
-__device__ __noinline__ Support score(int kind, const Model9 mv, const Pts P, int M, double max_res, int lane,
+__device__ __noinline__ Support score(int kind, const Model9 mv, const Pts P_, int M_, double max_res_, int lane,
                                       int need_sum_from) {
-    const double* m = mv.v;
+    double m[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) m[i] = uni(mv.v[i]);
+    const Pts P = uni(P_);
+    const int M = uni(M_);
+    const double max_res = uni(max_res_);
     if (P.lds) {
         if (kind == K_H) return score_impl<true, K_H>(m, P, M, max_res, lane, need_sum_from);
         if (kind == K_T) return score_impl<true, K_T>(m, P, M, max_res, lane, need_sum_from);
@@ -665,8 +690,8 @@ __device__ __forceinline__ int count_global_models(const double* models, int nmo
     return maxcnt;
 }
 
-__device__ __noinline__ void solve_count_chunk(ChunkModels* out, int est, const Pts P, const lds_u16* sidx, int M,
-                                               double max_res, int nT, int lane, double* models) {
+__device__ __noinline__ void solve_chunk(ChunkModels* out, int est, const Pts P, const lds_u16* sidx, int nT,
+                                         int lane, double* models) {
     const unsigned long long c0 = __builtin_readcyclecounter();
     int nmod = 0;
     double mym[27];
@@ -698,7 +723,23 @@ __device__ __noinline__ void solve_count_chunk(ChunkModels* out, int est, const 
         }
     }
     wave_mem_sync();
+#pragma unroll
+    for (int i = 0; i < 27; ++i) out->mym[i] = mym[i];
+    out->nmod = nmod;
+    out->cyc_solve = __builtin_readcyclecounter() - c0;
+}
+
+__device__ __noinline__ void count_chunk(ChunkModels* io, int est_, const Pts P_, int M_, double max_res_, int nT_,
+                                         int lane, const double* models_) {
     const unsigned long long c1 = __builtin_readcyclecounter();
+    const int est = uni(est_), M = uni(M_), nT = uni(nT_);
+    const double max_res = uni(max_res_);
+    const Pts P = uni(P_);
+    const double* models = uni_ptr(models_);
+    double mym[27];
+#pragma unroll
+    for (int i = 0; i < 27; ++i) mym[i] = io->mym[i];
+    const int nmod = io->nmod;
     int maxcnt;
     if (P.lds) {
         if (est == K_F7) maxcnt = count_lane_models<true, K_F7, 3>(mym, nmod, P, M, max_res, nT, lane);
@@ -711,12 +752,8 @@ __device__ __noinline__ void solve_count_chunk(ChunkModels* out, int est, const 
         else if (est == K_T) maxcnt = count_lane_models<false, K_T, 1>(mym, nmod, P, M, max_res, nT, lane);
         else maxcnt = count_global_models<false>(models, nmod, P, M, max_res, nT, lane);
     }
-#pragma unroll
-    for (int i = 0; i < 27; ++i) out->mym[i] = mym[i];
-    out->nmod = nmod;
-    out->maxcnt = maxcnt;
-    out->cyc_solve = c1 - c0;
-    out->cyc_count = __builtin_readcyclecounter() - c1;
+    io->maxcnt = maxcnt;
+    io->cyc_count = __builtin_readcyclecounter() - c1;
 }
 
 struct Report {
@@ -795,7 +832,8 @@ __device__ Report lo_ransac(Wave& w_io, const RansacCfg& cfg, const double* gx, 
         { const unsigned long long tp1 = __builtin_readcyclecounter(); w.prof[0] += tp1 - tp0; tp0 = tp1; }
         // ---- 64 minimal problems + the inlier count of every model (solve_count_chunk) ---------
         ChunkModels cm;
-        solve_count_chunk(&cm, cfg.est, P, w.sidx, M, cfg.max_res, nT, lane, models);
+        solve_chunk(&cm, cfg.est, P, w.sidx, nT, lane, models);
+        count_chunk(&cm, cfg.est, P, M, cfg.max_res, nT, lane, models);
         w.prof[1] += cm.cyc_solve;
         if (cfg.est == K_E5) w.prof[5] += cm.cyc_solve;
         tp0 = __builtin_readcyclecounter();
