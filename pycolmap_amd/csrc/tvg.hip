@@ -142,9 +142,10 @@ struct SamplerState {
 };
 __device__ __forceinline__ uint32_t sgpr(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
-__device__ __noinline__ SamplerState sample_chunk(lds_u32* mt, const lds_u32* snap, lds_u16* perm, lds_u16* sidx,
-                                                  lds_u32* rawcnt, SamplerState st, int M, int kMin, int nT,
-                                                  int lane, int force_slow) {
+template <int kMin>
+__device__ __forceinline__ SamplerState sample_chunk_t(lds_u32* mt, const lds_u32* snap, lds_u16* perm, lds_u16* sidx,
+                                                       lds_u32* rawcnt, SamplerState st, int M, int nT, int lane,
+                                                       int force_slow) {
     const int snap_mti = st.mti;
     const int need = nT * kMin;
     // ---- parallel: tempered raw word -> j, for the whole chunk ----
@@ -187,7 +188,9 @@ __device__ __noinline__ SamplerState sample_chunk(lds_u32* mt, const lds_u32* sn
                 j[i] = i < kMin ? (uint32_t)__builtin_amdgcn_readlane((int)jcur, i) : 0xFFFFu;
                 head |= j[i] < (uint32_t)kMin;
             }
+
             if (!head) {
+                // in-order LDS queue: read_i, write_i pairs of one trial are all in flight together
                 uint32_t v[7];
 #pragma unroll
                 for (int i = 0; i < 7; ++i)
@@ -279,6 +282,26 @@ __device__ __noinline__ SamplerState sample_chunk(lds_u32* mt, const lds_u32* sn
     st.mti = mti;
     wave_lds_sync();
     return st;
+}
+
+__device__ __noinline__ SamplerState sample_chunk(lds_u32* mt_, const lds_u32* snap_, lds_u16* perm_, lds_u16* sidx_,
+                                                  lds_u32* rawcnt_, SamplerState st, int M_, int kMin_, int nT_,
+                                                  int lane, int force_slow_) {
+    // everything but `lane` is wave-uniform: move it to scalar registers
+    lds_u32* mt = (lds_u32*)(uintptr_t)sgpr((uint32_t)(uintptr_t)mt_);
+    const lds_u32* snap = (const lds_u32*)(uintptr_t)sgpr((uint32_t)(uintptr_t)snap_);
+    lds_u16* perm = (lds_u16*)(uintptr_t)sgpr((uint32_t)(uintptr_t)perm_);
+    lds_u16* sidx = (lds_u16*)(uintptr_t)sgpr((uint32_t)(uintptr_t)sidx_);
+    lds_u32* rawcnt = (lds_u32*)(uintptr_t)sgpr((uint32_t)(uintptr_t)rawcnt_);
+    const int M = (int)sgpr((uint32_t)M_), kMin = (int)sgpr((uint32_t)kMin_), nT = (int)sgpr((uint32_t)nT_);
+    const int force_slow = (int)sgpr((uint32_t)force_slow_);
+    st.mti = (int)sgpr((uint32_t)st.mti);
+#pragma unroll
+    for (int i = 0; i < 7; ++i) st.pr[i] = sgpr(st.pr[i]);
+    if (kMin == 7) return sample_chunk_t<7>(mt, snap, perm, sidx, rawcnt, st, M, nT, lane, force_slow);
+    if (kMin == 4) return sample_chunk_t<4>(mt, snap, perm, sidx, rawcnt, st, M, nT, lane, force_slow);
+    if (kMin == 5) return sample_chunk_t<5>(mt, snap, perm, sidx, rawcnt, st, M, nT, lane, force_slow);
+    return sample_chunk_t<1>(mt, snap, perm, sidx, rawcnt, st, M, nT, lane, force_slow);
 }
 
 // ---- the active RANSAC's correspondences: LDS copy when it fits, global arrays otherwise ---------
@@ -635,19 +658,42 @@ struct ChunkModels {
     int maxcnt;  // max inlier count over them (-1: none)
     unsigned long long cyc_solve, cyc_count;
 };
+template <int KIND>
+__device__ __forceinline__ double residual_t(const double (&m)[9], double a, double b, double c, double d) {
+    return KIND == K_H ? h_residual(m, a, b, c, d) : (KIND == K_T ? t_residual(m, a, b, c, d) : sampson(m, a, b, c, d));
+}
+// inliers of U consecutive full 64-point batches starting at k0: U independent residual chains in
+// flight (at one wave per SIMD nothing else hides the FP64 and LDS latencies)
+template <bool L, int KIND, int U>
+__device__ __forceinline__ int count_batches(const double (&m)[9], const Pts& P, int k0, double max_res, int lane) {
+    double a[U], b[U], c[U], d[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) load_pt<L>(P, k0 + 64 * u + lane, a[u], b[u], c[u], d[u]);
+    int cnt = 0;
+#pragma unroll
+    for (int u = 0; u < U; ++u) cnt += __popcll(__ballot(residual_t<KIND>(m, a[u], b[u], c[u], d[u]) <= max_res));
+    return cnt;
+}
 template <bool L, int KIND>
 __device__ __forceinline__ int count_model(const double (&m)[9], const Pts& P, int M, double max_res, int lane) {
     int cnt = 0;
-#pragma unroll 2
-    for (int k0 = 0; k0 < M; k0 += 64) {
+    int k0 = 0;
+    for (; k0 + 256 <= M; k0 += 256) cnt += count_batches<L, KIND, 4>(m, P, k0, max_res, lane);
+    if (k0 + 128 <= M) {
+        cnt += count_batches<L, KIND, 2>(m, P, k0, max_res, lane);
+        k0 += 128;
+    }
+    if (k0 + 64 <= M) {
+        cnt += count_batches<L, KIND, 1>(m, P, k0, max_res, lane);
+        k0 += 64;
+    }
+    if (k0 < M) {  // ragged tail
         const int k = k0 + lane;
         bool in = false;
         if (k < M) {
             double a, b, c, d;
             load_pt<L>(P, k, a, b, c, d);
-            const double r = KIND == K_H ? h_residual(m, a, b, c, d)
-                                         : (KIND == K_T ? t_residual(m, a, b, c, d) : sampson(m, a, b, c, d));
-            in = r <= max_res;
+            in = residual_t<KIND>(m, a, b, c, d) <= max_res;
         }
         cnt += __popcll(__ballot(in));
     }
