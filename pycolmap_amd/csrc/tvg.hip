@@ -674,14 +674,23 @@ __device__ __forceinline__ int count_batches(const double (&m)[9], const Pts& P,
     for (int u = 0; u < U; ++u) cnt += __popcll(__ballot(residual_t<KIND>(m, a[u], b[u], c[u], d[u]) <= max_res));
     return cnt;
 }
+// Inlier count of one model, or - as soon as even counting every remaining correspondence as an
+// inlier could not reach `thr` - an upper bound below `thr`.  thr is the best count when the chunk
+// started: the best only grows, so such a model can never become a candidate and its exact count
+// is irrelevant (see the replay in lo_ransac).
 template <bool L, int KIND>
-__device__ __forceinline__ int count_model(const double (&m)[9], const Pts& P, int M, double max_res, int lane) {
+__device__ __forceinline__ int count_model(const double (&m)[9], const Pts& P, int M, double max_res, int lane,
+                                           int thr) {
     int cnt = 0;
     int k0 = 0;
-    for (; k0 + 256 <= M; k0 += 256) cnt += count_batches<L, KIND, 4>(m, P, k0, max_res, lane);
+    for (; k0 + 256 <= M; k0 += 256) {
+        cnt += count_batches<L, KIND, 4>(m, P, k0, max_res, lane);
+        if (cnt + (M - (k0 + 256)) < thr) return cnt + (M - (k0 + 256));
+    }
     if (k0 + 128 <= M) {
         cnt += count_batches<L, KIND, 2>(m, P, k0, max_res, lane);
         k0 += 128;
+        if (cnt + (M - k0) < thr) return cnt + (M - k0);
     }
     if (k0 + 64 <= M) {
         cnt += count_batches<L, KIND, 1>(m, P, k0, max_res, lane);
@@ -701,7 +710,7 @@ __device__ __forceinline__ int count_model(const double (&m)[9], const Pts& P, i
 }
 template <bool L, int KIND, int NM>
 __device__ __forceinline__ int count_lane_models(const double (&mym)[27], int nmod, const Pts& P, int M,
-                                                 double max_res, int nT, int lane) {
+                                                 double max_res, int nT, int lane, int thr) {
     int maxcnt = -1;
     for (int t = 0; t < nT; ++t) {
         const int n = __builtin_amdgcn_readlane(nmod, t);
@@ -711,7 +720,7 @@ __device__ __forceinline__ int count_lane_models(const double (&mym)[27], int nm
                 double sm[9];
 #pragma unroll
                 for (int i = 0; i < 9; ++i) sm[i] = readlane_f64(mym[9 * m + i], t);
-                const int c = count_model<L, KIND>(sm, P, M, max_res, lane);
+                const int c = count_model<L, KIND>(sm, P, M, max_res, lane, thr);
                 if (lane == t) maxcnt = max(maxcnt, c);
             }
         }
@@ -720,7 +729,7 @@ __device__ __forceinline__ int count_lane_models(const double (&mym)[27], int nm
 }
 template <bool L>
 __device__ __forceinline__ int count_global_models(const double* models, int nmod, const Pts& P, int M,
-                                                   double max_res, int nT, int lane) {
+                                                   double max_res, int nT, int lane, int thr) {
     int maxcnt = -1;
     for (int t = 0; t < nT; ++t) {
         const int n = __builtin_amdgcn_readlane(nmod, t);
@@ -729,7 +738,7 @@ __device__ __forceinline__ int count_global_models(const double* models, int nmo
             double sm[9];
 #pragma unroll
             for (int i = 0; i < 9; ++i) sm[i] = readlane_f64(src[i], 0);
-            const int c = count_model<L, K_F7>(sm, P, M, max_res, lane);
+            const int c = count_model<L, K_F7>(sm, P, M, max_res, lane, thr);
             if (lane == t) maxcnt = max(maxcnt, c);
         }
     }
@@ -776,9 +785,9 @@ __device__ __noinline__ void solve_chunk(ChunkModels* out, int est, const Pts P,
 }
 
 __device__ __noinline__ void count_chunk(ChunkModels* io, int est_, const Pts P_, int M_, double max_res_, int nT_,
-                                         int lane, const double* models_) {
+                                         int lane, const double* models_, int thr_) {
     const unsigned long long c1 = __builtin_readcyclecounter();
-    const int est = uni(est_), M = uni(M_), nT = uni(nT_);
+    const int est = uni(est_), M = uni(M_), nT = uni(nT_), thr = uni(thr_);
     const double max_res = uni(max_res_);
     const Pts P = uni(P_);
     const double* models = uni_ptr(models_);
@@ -788,15 +797,15 @@ __device__ __noinline__ void count_chunk(ChunkModels* io, int est_, const Pts P_
     const int nmod = io->nmod;
     int maxcnt;
     if (P.lds) {
-        if (est == K_F7) maxcnt = count_lane_models<true, K_F7, 3>(mym, nmod, P, M, max_res, nT, lane);
-        else if (est == K_H) maxcnt = count_lane_models<true, K_H, 1>(mym, nmod, P, M, max_res, nT, lane);
-        else if (est == K_T) maxcnt = count_lane_models<true, K_T, 1>(mym, nmod, P, M, max_res, nT, lane);
-        else maxcnt = count_global_models<true>(models, nmod, P, M, max_res, nT, lane);
+        if (est == K_F7) maxcnt = count_lane_models<true, K_F7, 3>(mym, nmod, P, M, max_res, nT, lane, thr);
+        else if (est == K_H) maxcnt = count_lane_models<true, K_H, 1>(mym, nmod, P, M, max_res, nT, lane, thr);
+        else if (est == K_T) maxcnt = count_lane_models<true, K_T, 1>(mym, nmod, P, M, max_res, nT, lane, thr);
+        else maxcnt = count_global_models<true>(models, nmod, P, M, max_res, nT, lane, thr);
     } else {
-        if (est == K_F7) maxcnt = count_lane_models<false, K_F7, 3>(mym, nmod, P, M, max_res, nT, lane);
-        else if (est == K_H) maxcnt = count_lane_models<false, K_H, 1>(mym, nmod, P, M, max_res, nT, lane);
-        else if (est == K_T) maxcnt = count_lane_models<false, K_T, 1>(mym, nmod, P, M, max_res, nT, lane);
-        else maxcnt = count_global_models<false>(models, nmod, P, M, max_res, nT, lane);
+        if (est == K_F7) maxcnt = count_lane_models<false, K_F7, 3>(mym, nmod, P, M, max_res, nT, lane, thr);
+        else if (est == K_H) maxcnt = count_lane_models<false, K_H, 1>(mym, nmod, P, M, max_res, nT, lane, thr);
+        else if (est == K_T) maxcnt = count_lane_models<false, K_T, 1>(mym, nmod, P, M, max_res, nT, lane, thr);
+        else maxcnt = count_global_models<false>(models, nmod, P, M, max_res, nT, lane, thr);
     }
     io->maxcnt = maxcnt;
     io->cyc_count = __builtin_readcyclecounter() - c1;
@@ -879,7 +888,7 @@ __device__ Report lo_ransac(Wave& w_io, const RansacCfg& cfg, const double* gx, 
         // ---- 64 minimal problems + the inlier count of every model (solve_count_chunk) ---------
         ChunkModels cm;
         solve_chunk(&cm, cfg.est, P, w.sidx, nT, lane, models);
-        count_chunk(&cm, cfg.est, P, M, cfg.max_res, nT, lane, models);
+        count_chunk(&cm, cfg.est, P, M, cfg.max_res, nT, lane, models, best.cnt);
         w.prof[1] += cm.cyc_solve;
         if (cfg.est == K_E5) w.prof[5] += cm.cyc_solve;
         tp0 = __builtin_readcyclecounter();
