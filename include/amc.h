@@ -207,6 +207,11 @@ void amc_tvg_opts_default(amc_tvg_opts* opts);
 int amc_upload_keypoints(amc_ctx* ctx, uint32_t slot, const float* xy, uint32_t rows,
                          uint32_t stride_floats);
 
+/* Image points in double precision, rows x 2 (x, y).  pycolmap's single-pair estimator bindings
+ * take float64 N x 2 arrays (/root/reference/pycolmap/pybind11_extension.h:70-85) and COLMAP's
+ * estimators work on them unchanged; this replaces the slot's float32 keypoints. */
+int amc_upload_points_f64(amc_ctx* ctx, uint32_t slot, const double* xy, uint32_t rows);
+
 /* Camera of an image (COLMAP Camera: model id, size, params, has_prior_focal_length). */
 int amc_upload_camera(amc_ctx* ctx, uint32_t slot, int32_t model_id, uint64_t width,
                       uint64_t height, const double* params, int32_t num_params,
@@ -221,6 +226,42 @@ int amc_verify_pairs(amc_ctx* ctx, const uint32_t* slot1, const uint32_t* slot2,
                      const uint64_t* match_offsets, const uint32_t* matches,
                      const amc_tvg_opts* opts, uint32_t seed, amc_verify_result* out);
 void amc_verify_result_free(amc_verify_result* r);
+
+/* ---- single LO-RANSAC per pair: the pycolmap estimator bindings ---------------------------------
+ * AMC_RANSAC_F  LORANSAC<FundamentalMatrixSevenPointEstimator, FundamentalMatrixEightPointEstimator>
+ *               (/root/reference/pycolmap/estimators/fundamental_matrix.h:17-39)
+ * AMC_RANSAC_H  LORANSAC<HomographyMatrixEstimator, HomographyMatrixEstimator>
+ *               (/root/reference/pycolmap/estimators/homography_matrix.h:16-37)
+ * AMC_RANSAC_E  LORANSAC<EssentialMatrixFivePointEstimator, ...> on CamFromImg-normalised points
+ *               with max_error = 0.5 * (e / f1 + e / f2)
+ *               (/root/reference/pycolmap/estimators/essential_matrix.h:19-52); needs both cameras
+ *               (SIMPLE_PINHOLE / PINHOLE).
+ * The correspondences of pair p are rows match_offsets[p] .. match_offsets[p+1] of `matches`
+ * (indices into the two slots' points).  The PRNG is seeded with `seed` per pair (the bindings
+ * call SetPRNGSeed(0)). */
+enum { AMC_RANSAC_F = 0, AMC_RANSAC_H = 1, AMC_RANSAC_E = 2 };
+typedef struct amc_ransac_report {
+    int32_t success;      /* report.success */
+    int32_t num_inliers;  /* report.support.num_inliers */
+    int64_t num_trials;   /* report.num_trials */
+    double model[9];      /* report.model, row-major */
+} amc_ransac_report;
+typedef struct amc_ransac_result {
+    size_t npairs;
+    amc_ransac_report* reports; /* npairs */
+    uint8_t* inlier_mask;       /* one byte per input correspondence (report.inlier_mask; zeros on failure) */
+    double device_ms;
+    void* _priv;
+} amc_ransac_result;
+int amc_ransac_pairs(amc_ctx* ctx, int kind, const uint32_t* slot1, const uint32_t* slot2, size_t npairs,
+                     const uint64_t* match_offsets, const uint32_t* matches,
+                     const amc_ransac_opts* opts, uint32_t seed, amc_ransac_result* out);
+void amc_ransac_result_free(amc_ransac_result* r);
+
+/* ComputeSquaredSampsonError (/root/reference/pycolmap/estimators/two_view_geometry.h:161-175):
+ * out[i] = (x2^T E x1)^2 / ((E x1)_0^2 + (E x1)_1^2 + (E^T x2)_0^2 + (E^T x2)_1^2), points n x 2. */
+int amc_squared_sampson_error(amc_ctx* ctx, const double* points1, const double* points2, size_t n,
+                              const double E[9], double* out);
 
 #ifdef __cplusplus
 }

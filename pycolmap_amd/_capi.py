@@ -26,8 +26,11 @@ EXPORTED_SYMBOLS = [
     "amc_upload_descriptors_device", "amc_match_pairs", "amc_match_result_free",
     "amc_match_opts_default", "amc_get_acos_lut",
     "amc_tvg_opts_default", "amc_upload_keypoints", "amc_upload_camera", "amc_verify_pairs",
-    "amc_verify_result_free",
+    "amc_verify_result_free", "amc_upload_points_f64", "amc_ransac_pairs", "amc_ransac_result_free",
+    "amc_squared_sampson_error",
 ]
+RANSAC_F, RANSAC_H, RANSAC_E = 0, 1, 2
+RANSAC_KINDS = {"F": RANSAC_F, "H": RANSAC_H, "E": RANSAC_E}
 
 
 class AmcError(RuntimeError):
@@ -77,6 +80,18 @@ class VerifyResult(C.Structure):
                 ("_priv", C.c_void_p)]
 
 
+class RansacReport(C.Structure):
+    _fields_ = [("success", C.c_int32), ("num_inliers", C.c_int32), ("num_trials", C.c_int64),
+                ("model", C.c_double * 9)]
+
+
+class RansacResult(C.Structure):
+    _fields_ = [("npairs", C.c_size_t), ("reports", C.POINTER(RansacReport)),
+                ("inlier_mask", C.POINTER(C.c_uint8)), ("device_ms", C.c_double), ("_priv", C.c_void_p)]
+
+
+RANSAC_DTYPE = np.dtype([("success", np.int32), ("num_inliers", np.int32), ("num_trials", np.int64),
+                         ("model", np.float64, (3, 3))])
 TVG_DTYPE = np.dtype([("config", np.int32), ("num_inliers", np.int32), ("E", np.float64, (3, 3)),
                       ("F", np.float64, (3, 3)), ("H", np.float64, (3, 3)),
                       ("num_trials", np.int64, (4,)), ("model_inliers", np.int64, (3,))])
@@ -123,6 +138,13 @@ def load() -> C.CDLL:
                                      C.c_void_p, C.POINTER(TvgOpts), C.c_uint32, C.POINTER(VerifyResult)]
     lib.amc_verify_result_free.argtypes = [C.POINTER(VerifyResult)]
     lib.amc_verify_result_free.restype = None
+    lib.amc_upload_points_f64.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
+    lib.amc_ransac_pairs.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
+                                     C.c_void_p, C.POINTER(RansacOpts), C.c_uint32, C.POINTER(RansacResult)]
+    lib.amc_ransac_result_free.argtypes = [C.POINTER(RansacResult)]
+    lib.amc_ransac_result_free.restype = None
+    lib.amc_squared_sampson_error.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
+                                              C.c_void_p]
     _lib = lib
     return lib
 
@@ -234,6 +256,59 @@ class Context:
         rows = k.shape[0] if k.ndim == 2 else 0
         stride = k.shape[1] if k.ndim == 2 and rows else 2
         _check(self._lib.amc_upload_keypoints(self._h, slot, k.ctypes.data_as(C.c_void_p), rows, stride))
+
+    def upload_points_f64(self, slot: int, pts: np.ndarray) -> None:
+        """Double-precision image points (N x 2), as pycolmap's estimator bindings take them."""
+        k = np.ascontiguousarray(pts, dtype=np.float64)
+        if k.size and (k.ndim != 2 or k.shape[1] != 2):
+            raise ValueError(f"points must be N x 2 float64, got {k.shape}")
+        rows = k.shape[0] if k.ndim == 2 else 0
+        _check(self._lib.amc_upload_points_f64(self._h, slot, k.ctypes.data_as(C.c_void_p), rows))
+
+    def ransac_pairs(self, kind, slot1, slot2, match_offsets, matches, ransac: dict | RansacOpts | None = None,
+                     seed: int = 0):
+        """One LO-RANSAC (kind 'F' | 'H' | 'E') per pair. Returns (reports structured array [npairs],
+        inlier_mask bool [total correspondences])."""
+        s1 = np.ascontiguousarray(slot1, dtype=np.uint32)
+        s2 = np.ascontiguousarray(slot2, dtype=np.uint32)
+        off = np.ascontiguousarray(match_offsets, dtype=np.uint64)
+        m = np.ascontiguousarray(matches, dtype=np.uint32).reshape(-1, 2)
+        if off.shape != (s1.size + 1,) or s1.shape != s2.shape:
+            raise ValueError("match_offsets must have npairs + 1 entries")
+        if int(off[-1]) != m.shape[0]:
+            raise ValueError("match_offsets[-1] must equal the number of matches")
+        if isinstance(ransac, RansacOpts):
+            ro = ransac
+        else:
+            ro = tvg_options(ransac=ransac or {}).ransac
+        k = RANSAC_KINDS[kind] if isinstance(kind, str) else int(kind)
+        res = RansacResult()
+        _check(self._lib.amc_ransac_pairs(self._h, k, s1.ctypes.data_as(C.c_void_p), s2.ctypes.data_as(C.c_void_p),
+                                          s1.size, off.ctypes.data_as(C.c_void_p), m.ctypes.data_as(C.c_void_p),
+                                          C.byref(ro), seed, C.byref(res)))
+        try:
+            n = int(res.npairs)
+            assert C.sizeof(RansacReport) == RANSAC_DTYPE.itemsize
+            rep = (np.frombuffer(C.string_at(res.reports, n * C.sizeof(RansacReport)), dtype=RANSAC_DTYPE).copy()
+                   if n else np.zeros(0, dtype=RANSAC_DTYPE))
+            total = m.shape[0]
+            mask = (np.ctypeslib.as_array(res.inlier_mask, shape=(total,)).astype(bool) if total
+                    else np.zeros(0, dtype=bool))
+        finally:
+            self._lib.amc_ransac_result_free(C.byref(res))
+        return rep, mask
+
+    def squared_sampson_error(self, points1, points2, E) -> np.ndarray:
+        p1 = np.ascontiguousarray(points1, dtype=np.float64).reshape(-1, 2)
+        p2 = np.ascontiguousarray(points2, dtype=np.float64).reshape(-1, 2)
+        if p1.shape != p2.shape:
+            raise ValueError("points1 and points2 must have the same shape")
+        e = np.ascontiguousarray(E, dtype=np.float64).reshape(9)
+        out = np.empty(p1.shape[0], dtype=np.float64)
+        _check(self._lib.amc_squared_sampson_error(self._h, p1.ctypes.data_as(C.c_void_p),
+                                                   p2.ctypes.data_as(C.c_void_p), p1.shape[0],
+                                                   e.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)))
+        return out
 
     def upload_camera(self, slot: int, model: str | int, width: int, height: int, params,
                       has_prior_focal_length: bool = False) -> None:

@@ -45,6 +45,7 @@ struct Slot {
     uint32_t maxsq = 0;    // max_r |raw[r]|^2
     bool valid = false;
     float* kp = nullptr;   // rows x 2 float32 keypoints (x, y)
+    double* kp64 = nullptr;  // or rows x 2 float64 points (amc_upload_points_f64)
     uint32_t kp_rows = 0;
     bool has_kp = false, has_cam = false;
     CameraDev cam{};
@@ -192,6 +193,7 @@ int amc_ctx_create(int device_id, amc_ctx** out) {
 static void free_slot(Slot& s) {
     if (s.base) (void)hipFree(s.base);
     if (s.kp) (void)hipFree(s.kp);
+    if (s.kp64) (void)hipFree(s.kp64);
     s = Slot();
 }
 
@@ -615,10 +617,12 @@ int amc_upload_keypoints(amc_ctx* c, uint32_t slot, const float* xy, uint32_t ro
         return fail(AMC_E_INVALID, "amc_upload_keypoints: need x,y columns (stride %u) and data", stride_floats);
     HIPCHK(hipSetDevice(c->device));
     Slot& s = c->slots[slot];
-    if (s.kp) {
+    if (s.kp || s.kp64) {
         HIPCHK(hipStreamSynchronize(c->stream));
-        (void)hipFree(s.kp);
+        if (s.kp) (void)hipFree(s.kp);
+        if (s.kp64) (void)hipFree(s.kp64);
         s.kp = nullptr;
+        s.kp64 = nullptr;
     }
     s.kp_rows = rows;
     s.has_kp = true;
@@ -634,6 +638,32 @@ int amc_upload_keypoints(amc_ctx* c, uint32_t slot, const float* xy, uint32_t ro
         return fail(AMC_E_NOMEM, "amc_upload_keypoints: hipMalloc: %s", hipGetErrorString(e));
     }
     HIPCHK(hipMemcpy(s.kp, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
+    return AMC_OK;
+}
+
+int amc_upload_points_f64(amc_ctx* c, uint32_t slot, const double* xy, uint32_t rows) {
+    if (!c) return fail(AMC_E_INVALID, "amc_upload_points_f64: ctx is NULL");
+    if (slot >= c->slots.size())
+        return fail(AMC_E_INVALID, "amc_upload_points_f64: slot %u >= reserved %zu", slot, c->slots.size());
+    if (rows > 0 && !xy) return fail(AMC_E_INVALID, "amc_upload_points_f64: NULL data");
+    HIPCHK(hipSetDevice(c->device));
+    Slot& s = c->slots[slot];
+    if (s.kp || s.kp64) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (s.kp) (void)hipFree(s.kp);
+        if (s.kp64) (void)hipFree(s.kp64);
+        s.kp = nullptr;
+        s.kp64 = nullptr;
+    }
+    s.kp_rows = rows;
+    s.has_kp = true;
+    if (rows == 0) return AMC_OK;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&s.kp64), (size_t)rows * 2 * sizeof(double));
+    if (e != hipSuccess) {
+        s.has_kp = false;
+        return fail(AMC_E_NOMEM, "amc_upload_points_f64: hipMalloc: %s", hipGetErrorString(e));
+    }
+    HIPCHK(hipMemcpy(s.kp64, xy, (size_t)rows * 2 * sizeof(double), hipMemcpyHostToDevice));
     return AMC_OK;
 }
 
@@ -682,9 +712,11 @@ struct VerifyPriv {
 
 }  // namespace
 
-int amc_verify_pairs(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, size_t npairs,
-                     const uint64_t* match_offsets, const uint32_t* matches,
-                     const amc_tvg_opts* opts_in, uint32_t seed, amc_verify_result* out) {
+// mode 0: EstimateTwoViewGeometry; 1 / 2 / 3: a single F / H / E LO-RANSAC per pair, reported
+// through the same record (config = success, num_inliers, the model, its trial count, the mask)
+static int verify_impl(amc_ctx* c, int mode, const uint32_t* slot1, const uint32_t* slot2, size_t npairs,
+                       const uint64_t* match_offsets, const uint32_t* matches,
+                       const amc_tvg_opts* opts_in, uint32_t seed, amc_verify_result* out) {
     if (!c || !out) return fail(AMC_E_INVALID, "amc_verify_pairs: NULL ctx/out");
     std::memset(out, 0, sizeof *out);
     if (npairs > 0 && (!slot1 || !slot2 || !match_offsets))
@@ -704,7 +736,8 @@ int amc_verify_pairs(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, s
             return fail(AMC_E_INVALID, "amc_verify_pairs: pair %zu references slot out of range", p);
         const Slot& a = c->slots[slot1[p]];
         const Slot& b = c->slots[slot2[p]];
-        if (!a.has_kp || !b.has_kp || !a.has_cam || !b.has_cam)
+        const bool need_cam = mode == 0 || mode == 3;
+        if (!a.has_kp || !b.has_kp || (need_cam && (!a.has_cam || !b.has_cam)))
             return fail(AMC_E_STATE, "amc_verify_pairs: pair %zu: keypoints/camera not uploaded", p);
         if (match_offsets[p + 1] < match_offsets[p])
             return fail(AMC_E_INVALID, "amc_verify_pairs: match_offsets not monotone at %zu", p);
@@ -716,7 +749,8 @@ int amc_verify_pairs(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, s
             if (matches[2 * k] >= a.kp_rows || matches[2 * k + 1] >= b.kp_rows)
                 return fail(AMC_E_INVALID, "amc_verify_pairs: pair %zu match %llu indexes past the keypoints",
                             p, (unsigned long long)(k - match_offsets[p]));
-        if (!o.force_H_use && a.cam.has_prior && b.cam.has_prior &&
+        const bool uses_E = mode == 0 ? (!o.force_H_use && a.cam.has_prior && b.cam.has_prior) : mode == 3;
+        if (uses_E &&
             ((a.cam.model_id != AMC_CAM_SIMPLE_PINHOLE && a.cam.model_id != AMC_CAM_PINHOLE) ||
              (b.cam.model_id != AMC_CAM_SIMPLE_PINHOLE && b.cam.model_id != AMC_CAM_PINHOLE)))
             return fail(AMC_E_INVALID, "amc_verify_pairs: pair %zu: calibrated path supports SIMPLE_PINHOLE / "
@@ -739,9 +773,9 @@ int amc_verify_pairs(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, s
     {
         const char* e = std::getenv("AMC_TVG_SLOW_SAMPLER");
         P.force_slow_sampler = (e && e[0] == '1') ? 1 : 0;
-        P.pad_ = 0;
+        P.mode = mode;
     }
-    if (o.detect_watermark && P.max_trials[3] > P.min_num_trials)
+    if (mode == 0 && o.detect_watermark && P.max_trials[3] > P.min_num_trials)
         return fail(AMC_E_INVALID, "amc_verify_pairs: unsupported option combination: the watermark RANSAC "
                     "may run %d trials > min_num_trials %d (its dynamic trial count is not tabulated)",
                     P.max_trials[3], P.min_num_trials);
@@ -762,6 +796,7 @@ int amc_verify_pairs(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, s
     std::vector<TvgImage> timgs(c->slots.size());
     for (size_t i = 0; i < timgs.size(); ++i) {
         timgs[i].kp = c->slots[i].kp;
+        timgs[i].kp64 = c->slots[i].kp64;
         timgs[i].rows = c->slots[i].kp_rows;
         timgs[i].pad = 0;
         timgs[i].cam = c->slots[i].cam;
@@ -857,6 +892,94 @@ int amc_verify_pairs(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, s
     out->kernel_ms = ms;
     out->kernel_launches = 1;
     return AMC_OK;
+}
+
+int amc_verify_pairs(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, size_t npairs,
+                     const uint64_t* match_offsets, const uint32_t* matches,
+                     const amc_tvg_opts* opts_in, uint32_t seed, amc_verify_result* out) {
+    return verify_impl(c, 0, slot1, slot2, npairs, match_offsets, matches, opts_in, seed, out);
+}
+
+namespace {
+struct RansacPriv {
+    std::vector<amc_ransac_report> reports;
+    std::vector<uint8_t> mask;
+};
+}  // namespace
+
+int amc_ransac_pairs(amc_ctx* c, int kind, const uint32_t* slot1, const uint32_t* slot2, size_t npairs,
+                     const uint64_t* match_offsets, const uint32_t* matches,
+                     const amc_ransac_opts* ropts, uint32_t seed, amc_ransac_result* out) {
+    if (!c || !out) return fail(AMC_E_INVALID, "amc_ransac_pairs: NULL ctx/out");
+    std::memset(out, 0, sizeof *out);
+    if (kind != AMC_RANSAC_F && kind != AMC_RANSAC_H && kind != AMC_RANSAC_E)
+        return fail(AMC_E_INVALID, "amc_ransac_pairs: unknown estimator kind %d", kind);
+    amc_tvg_opts o;
+    amc_tvg_opts_default(&o);
+    if (ropts) o.ransac = *ropts;
+    o.detect_watermark = 0;
+    amc_verify_result v;
+    const int mode = kind == AMC_RANSAC_F ? 1 : (kind == AMC_RANSAC_H ? 2 : 3);
+    const int rc = verify_impl(c, mode, slot1, slot2, npairs, match_offsets, matches, &o, seed, &v);
+    if (rc != AMC_OK) return rc;
+    RansacPriv* priv = new (std::nothrow) RansacPriv();
+    if (!priv) {
+        amc_verify_result_free(&v);
+        return fail(AMC_E_NOMEM, "amc_ransac_pairs: out of host memory");
+    }
+    const uint64_t total = npairs ? match_offsets[npairs] : 0;
+    priv->reports.resize(npairs);
+    priv->mask.assign(v.inlier_mask, v.inlier_mask + total);
+    const int which = kind == AMC_RANSAC_F ? 1 : (kind == AMC_RANSAC_H ? 2 : 0);  // num_trials / inliers slot
+    for (size_t p = 0; p < npairs; ++p) {
+        const amc_tvg& g = v.tvg[p];
+        amc_ransac_report& r = priv->reports[p];
+        r.success = g.config;
+        r.num_inliers = g.num_inliers;
+        r.num_trials = g.num_trials[which];
+        const double* m = kind == AMC_RANSAC_F ? g.F : (kind == AMC_RANSAC_H ? g.H : g.E);
+        for (int i = 0; i < 9; ++i) r.model[i] = m[i];
+    }
+    out->npairs = npairs;
+    out->reports = priv->reports.data();
+    out->inlier_mask = priv->mask.data();
+    out->device_ms = v.device_ms;
+    out->_priv = priv;
+    amc_verify_result_free(&v);
+    return AMC_OK;
+}
+
+void amc_ransac_result_free(amc_ransac_result* r) {
+    if (!r) return;
+    delete static_cast<RansacPriv*>(r->_priv);
+    std::memset(r, 0, sizeof *r);
+}
+
+int amc_squared_sampson_error(amc_ctx* c, const double* points1, const double* points2, size_t n,
+                              const double E[9], double* out) {
+    if (!c) return fail(AMC_E_INVALID, "amc_squared_sampson_error: ctx is NULL");
+    if (n == 0) return AMC_OK;
+    if (!points1 || !points2 || !E || !out) return fail(AMC_E_INVALID, "amc_squared_sampson_error: NULL argument");
+    HIPCHK(hipSetDevice(c->device));
+    DevBuf<double> buf;
+    HIPCHK(buf.ensure(5 * n + 16));
+    double* d1 = buf.p;
+    double* d2 = d1 + 2 * n;
+    double* dout = d2 + 2 * n;
+    double* dE = dout + n;
+    hipStream_t st = c->stream;
+    int rc = AMC_OK;
+    auto chk = [&](hipError_t e, const char* what) {
+        if (e != hipSuccess && rc == AMC_OK) rc = fail(AMC_E_HIP, "amc_squared_sampson_error: %s: %s", what, hipGetErrorString(e));
+    };
+    chk(hipMemcpyAsync(d1, points1, 2 * n * sizeof(double), hipMemcpyHostToDevice, st), "copy points1");
+    chk(hipMemcpyAsync(d2, points2, 2 * n * sizeof(double), hipMemcpyHostToDevice, st), "copy points2");
+    chk(hipMemcpyAsync(dE, E, 9 * sizeof(double), hipMemcpyHostToDevice, st), "copy E");
+    if (rc == AMC_OK) chk(launch_sampson(d1, d2, n, dE, dout, st), "launch");
+    if (rc == AMC_OK) chk(hipMemcpyAsync(out, dout, n * sizeof(double), hipMemcpyDeviceToHost, st), "copy out");
+    chk(hipStreamSynchronize(st), "sync");
+    buf.release();
+    return rc;
 }
 
 void amc_verify_result_free(amc_verify_result* r) {

@@ -103,7 +103,8 @@ struct CameraDev {
     double params[4];
 };
 struct TvgImage {
-    const float* kp;  // rows x 2 float32 (x, y)
+    const float* kp;     // rows x 2 float32 (x, y), or
+    const double* kp64;  // rows x 2 float64 when the points were uploaded in double precision
     uint32_t rows;
     uint32_t pad;
     CameraDev cam;
@@ -130,7 +131,7 @@ struct TvgParams {
     double min_E_F_inlier_ratio, max_H_inlier_ratio, watermark_min_inlier_ratio,
         watermark_border_size, max_error;
     int32_t force_slow_sampler;  // test hook (AMC_TVG_SLOW_SAMPLER=1): draw-by-draw sampler path only
-    int32_t pad_;
+    int32_t mode;                // 0: EstimateTwoViewGeometry; 1 / 2 / 3: a single F / H / E LO-RANSAC
 };
 size_t tvg_ws_doubles_host(uint32_t mcap);
 size_t tvg_ws_mask_bytes_host(uint32_t mcap);
@@ -138,6 +139,8 @@ size_t tvg_ws_mask_bytes_host(uint32_t mcap);
 constexpr int kTvgWavesPerSimd = 1;
 size_t tvg_lds_bytes(uint32_t mcap, uint32_t pts_cap, int waves);
 uint32_t tvg_pts_cap(uint32_t mcap);
+hipError_t launch_sampson(const double* p1, const double* p2, size_t n, const double* E9, double* out,
+                          hipStream_t s);
 hipError_t launch_tvg(const TvgImage* imgs, const TvgPair* pairs, uint32_t npairs,
                       const uint32_t* matches, const uint32_t* trial_tabs, const uint32_t* mt_init,
                       const TvgParams& P, double* ws, uint8_t* mask_ws, uint32_t mcap,

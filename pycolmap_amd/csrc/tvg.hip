@@ -20,6 +20,8 @@
 //
 // FP64 everywhere, -ffp-contract=off, IEEE divide/sqrt: results are bit-identical to
 // oracle/tvg_oracle.cc (inlier masks, configs, model bit patterns).
+#include <algorithm>
+
 #include "amc_internal.h"
 #include "tvg_math.h"
 
@@ -1026,7 +1028,7 @@ __device__ __noinline__ void process_pair(Wave& w, uint32_t q, const TvgImage* _
     uint8_t* omask = out_mask + pr.mask_off;
     for (int k = lane; k < M; k += 64) omask[k] = 0;
 
-    if (M < P.min_num_inliers) {
+    if (P.mode == 0 && M < P.min_num_inliers) {
         g.config = AMC_TVG_DEGENERATE;
         if (lane == 0) out[q].g = g;
         return;
@@ -1036,17 +1038,20 @@ __device__ __noinline__ void process_pair(Wave& w, uint32_t q, const TvgImage* _
     const uint32_t* mm = matches + 2 * pr.match_off;
     for (int k = lane; k < M; k += 64) {
         const uint32_t i1 = mm[2 * k], i2 = mm[2 * k + 1];
-        X1[k] = (double)im1.kp[2 * (size_t)i1];
-        Y1[k] = (double)im1.kp[2 * (size_t)i1 + 1];
-        X2[k] = (double)im2.kp[2 * (size_t)i2];
-        Y2[k] = (double)im2.kp[2 * (size_t)i2 + 1];
+        X1[k] = im1.kp64 ? im1.kp64[2 * (size_t)i1] : (double)im1.kp[2 * (size_t)i1];
+        Y1[k] = im1.kp64 ? im1.kp64[2 * (size_t)i1 + 1] : (double)im1.kp[2 * (size_t)i1 + 1];
+        X2[k] = im2.kp64 ? im2.kp64[2 * (size_t)i2] : (double)im2.kp[2 * (size_t)i2];
+        Y2[k] = im2.kp64 ? im2.kp64[2 * (size_t)i2 + 1] : (double)im2.kp[2 * (size_t)i2 + 1];
     }
     // ---- SetPRNGSeed(seed): generator state as std::mt19937(seed) leaves it ---------------
     for (int i = lane; i < 624; i += 64) w.mt[i] = mt_init[i];
     w.mti = 624;
     wave_mem_sync();
 
-    const bool calibrated = !P.force_H_use && im1.cam.has_prior && im2.cam.has_prior;
+    // mode 0: the EstimateTwoViewGeometry dispatch; modes 1 / 2 / 3: exactly one of F / H / E
+    const bool calibrated = P.mode == 0 ? (!P.force_H_use && im1.cam.has_prior && im2.cam.has_prior) : P.mode == 3;
+    const bool run_F = P.mode == 0 ? !P.force_H_use : P.mode == 1;
+    const bool run_H = P.mode == 0 || P.mode == 2;
     uint8_t *maskE = w.masks, *maskF = w.masks + mcap, *maskH = w.masks + 2 * (size_t)mcap;
     Report E_rep, F_rep, H_rep;
     E_rep.success = F_rep.success = H_rep.success = false;
@@ -1089,7 +1094,7 @@ __device__ __noinline__ void process_pair(Wave& w, uint32_t q, const TvgImage* _
         g.num_trials[0] = E_rep.num_trials;
         g.model_inliers[0] = E_rep.support.cnt;
     }
-    if (!P.force_H_use) {
+    if (run_F) {
         cfg.est = K_F7; cfg.local_est = K_F8;
         cfg.max_res = P.max_error * P.max_error;
         cfg.max_trials = P.max_trials[1];
@@ -1099,14 +1104,33 @@ __device__ __noinline__ void process_pair(Wave& w, uint32_t q, const TvgImage* _
         g.num_trials[1] = F_rep.num_trials;
         g.model_inliers[1] = F_rep.support.cnt;
     }
-    cfg.est = K_H; cfg.local_est = K_H;
-    cfg.max_res = P.max_error * P.max_error;
-    cfg.max_trials = P.max_trials[2];
-    cfg.dyn_tab = trial_tabs + pr.tab_off[2];
-    H_rep = lo_ransac(w, cfg, X1, mcap, M, maskH);
-    for (int i = 0; i < 9; ++i) g.H[i] = H_rep.model[i];
-    g.num_trials[2] = H_rep.num_trials;
-    g.model_inliers[2] = H_rep.support.cnt;
+    H_rep.num_trials = 0;
+    for (int i = 0; i < 9; ++i) H_rep.model[i] = 0;
+    if (run_H) {
+        cfg.est = K_H; cfg.local_est = K_H;
+        cfg.max_res = P.max_error * P.max_error;
+        cfg.max_trials = P.max_trials[2];
+        cfg.dyn_tab = trial_tabs + pr.tab_off[2];
+        H_rep = lo_ransac(w, cfg, X1, mcap, M, maskH);
+        for (int i = 0; i < 9; ++i) g.H[i] = H_rep.model[i];
+        g.num_trials[2] = H_rep.num_trials;
+        g.model_inliers[2] = H_rep.support.cnt;
+    }
+    if (P.mode != 0) {
+        // single-RANSAC report: config carries report.success, the mask is report.inlier_mask
+        const Report& r = P.mode == 1 ? F_rep : (P.mode == 2 ? H_rep : E_rep);
+        const uint8_t* rm = P.mode == 1 ? maskF : (P.mode == 2 ? maskH : maskE);
+        g.config = r.success ? 1 : 0;
+        g.num_inliers = r.support.cnt;
+        if (r.success)
+            for (int k = lane; k < M; k += 64) omask[k] = rm[k];
+        if (lane == 0) {
+            out[q].g = g;
+            w.prof[4] = __builtin_readcyclecounter() - tstart;
+            for (int i = 0; i < 8; ++i) out[q].prof[i] = w.prof[i];
+        }
+        return;
+    }
 
     // ---- model selection (two_view_geometry.cc), wave-uniform --------------------------------
     const int minI = P.min_num_inliers;
@@ -1255,6 +1279,24 @@ uint32_t tvg_pts_cap(uint32_t mcap) {
     if (other >= budget) return 0;
     const size_t cap = (budget - other) / 32 / 64 * 64;
     return (uint32_t)(cap < mcap ? cap : mcap);
+}
+
+// ComputeSquaredSampsonError over n correspondences (points n x 2, E row-major)
+__global__ __launch_bounds__(256) void sampson_kernel(const double* __restrict__ p1, const double* __restrict__ p2,
+                                                      size_t n, const double* __restrict__ E9,
+                                                      double* __restrict__ out) {
+    double e[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) e[i] = E9[i];
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        out[i] = sampson(e, p1[2 * i], p1[2 * i + 1], p2[2 * i], p2[2 * i + 1]);
+}
+hipError_t launch_sampson(const double* p1, const double* p2, size_t n, const double* E9, double* out,
+                          hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    const unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(sampson_kernel, dim3(blocks), dim3(256), 0, s, p1, p2, n, E9, out);
+    return hipGetLastError();
 }
 
 hipError_t launch_tvg(const TvgImage* imgs, const TvgPair* pairs, uint32_t npairs,
