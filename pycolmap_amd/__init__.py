@@ -4,6 +4,7 @@ the pycolmap API.
     import pycolmap_amd as pycolmap
     pycolmap.match_exhaustive(database_path)        # same signature as the reference
     pycolmap.verify_matches(database_path, pairs_path)
+    pycolmap.fundamental_matrix_estimation(points2D1, points2D2)   # ... and the other estimator bindings
 
 The compiled host layer (`_pycolmap`, C++/pybind11) drives `libamc.so` (HIP kernels behind a C ABI,
 include/amc.h).  There is no CPU fallback: importing works anywhere, computing needs a gfx950 GPU.
@@ -14,10 +15,12 @@ __version__ = "0.1.0"
 
 try:  # the compiled host layer; absent only before `python -m pycolmap_amd.build`
     from ._pycolmap import (  # noqa: F401
-        COLMAP_version, Database, Device, ExhaustiveMatchingOptions, RANSACOptions,
+        COLMAP_version, Camera, CameraModelId, Database, Device, ExhaustiveMatchingOptions, RANSACOptions,
         SequentialMatchingOptions, SiftMatchingOptions, TwoViewGeometry, TwoViewGeometryConfiguration,
-        TwoViewGeometryOptions, has_cuda, has_hip, last_run_stats, match_exhaustive, match_sequential,
-        match_spatial, match_vocabtree, verify_matches,
+        TwoViewGeometryOptions, essential_matrix_estimation, estimate_calibrated_two_view_geometry,
+        estimate_two_view_geometry, estimate_two_view_geometry_pose, fundamental_matrix_estimation, has_cuda,
+        has_hip, homography_matrix_estimation, last_run_stats, match_exhaustive, match_sequential,
+        match_spatial, match_vocabtree, squared_sampson_error, verify_matches,
     )
     _HOST_LAYER_ERROR = None
 except ImportError as _e:  # pragma: no cover - exercised only on an unbuilt tree

@@ -12,6 +12,7 @@
 //   conversion, copy, pickle)                               /root/reference/pycolmap/helpers.h:217-283
 //   interruptible blocking wait                             /root/reference/pycolmap/helpers.h:306-347
 //   Database                                                /root/reference/pycolmap/scene/database.h:9-46
+//   Camera, *_matrix_estimation, estimate_two_view_geometry, squared_sampson_error -> estimators.h
 #include <pybind11/numpy.h>
 #include <pybind11/pybind11.h>
 #include <pybind11/stl.h>
@@ -24,6 +25,8 @@
 #include <thread>
 
 #include "controller.h"
+#include "py_types.h"
+#include "estimators.h"
 
 namespace py = pybind11;
 using namespace pybind11::literals;
@@ -92,17 +95,19 @@ std::string Summary(const py::object& self, const std::vector<std::string>& fiel
 
 template <typename T>
 void MakeDataclass(py::class_<T>& cls, const std::vector<std::string>& fields) {
-    cls.def(py::init([fields](const py::dict& d) {
-        auto self = std::make_unique<T>();
-        py::object o = py::cast(self.get(), py::return_value_policy::reference);
-        MergeDict(o, d, fields);
-        return self;
+    // dict / kwargs construction starts from the class's *Python-side* default constructor (for
+    // RANSACOptions that is pycolmap's defaults, not the C++ struct's), then merges
+    // (/root/reference/pycolmap/helpers.h:258-268)
+    const py::object cls_obj = cls;
+    cls.def(py::init([fields, cls_obj](const py::dict& d) {
+        py::object self = cls_obj();
+        MergeDict(self, d, fields);
+        return self.cast<T>();
     }));
-    cls.def(py::init([fields](const py::kwargs& kw) {
-        auto self = std::make_unique<T>();
-        py::object o = py::cast(self.get(), py::return_value_policy::reference);
-        MergeDict(o, py::dict(kw), fields);
-        return self;
+    cls.def(py::init([fields, cls_obj](const py::kwargs& kw) {
+        py::object self = cls_obj();
+        MergeDict(self, py::dict(kw), fields);
+        return self.cast<T>();
     }));
     py::implicitly_convertible<py::dict, T>();
     cls.def("mergedict", [fields](py::object self, const py::dict& d) { MergeDict(self, d, fields); });
@@ -113,11 +118,10 @@ void MakeDataclass(py::class_<T>& cls, const std::vector<std::string>& fields) {
     cls.def("__copy__", [](const T& self) { return T(self); });
     cls.def("__deepcopy__", [](const T& self, const py::dict&) { return T(self); });
     cls.def(py::pickle([fields](py::object self) { return ToDict(self, fields); },
-                       [fields](const py::dict& d) {
-                           auto self = std::make_unique<T>();
-                           py::object o = py::cast(self.get(), py::return_value_policy::reference);
-                           MergeDict(o, d, fields);
-                           return self;
+                       [fields, cls_obj](const py::dict& d) {
+                           py::object self = cls_obj();
+                           MergeDict(self, d, fields);
+                           return self.cast<T>();
                        }));
 }
 
@@ -158,23 +162,6 @@ void RunInterruptible(MatchController& ctrl, const std::function<void()>& work) 
             throw py::value_error(e.what());
         }
     }
-}
-
-struct PyTwoViewGeometry {
-    int config = 0;
-    std::array<double, 9> E{}, F{}, H{};
-    std::vector<uint32_t> inlier_matches;
-    double tri_angle = 0.0;
-};
-py::array_t<double> Mat3(const std::array<double, 9>& m) {
-    py::array_t<double> a({3, 3});
-    std::memcpy(a.mutable_data(), m.data(), sizeof(double) * 9);
-    return a;
-}
-py::array_t<uint32_t> MatchesArray(const std::vector<uint32_t>& m) {
-    py::array_t<uint32_t> a({static_cast<py::ssize_t>(m.size() / 2), static_cast<py::ssize_t>(2)});
-    if (!m.empty()) std::memcpy(a.mutable_data(), m.data(), m.size() * sizeof(uint32_t));
-    return a;
 }
 
 py::dict StatsDict(const MatchStats& s) {
@@ -338,6 +325,10 @@ PYBIND11_MODULE(_pycolmap, m) {
                  return g;
              },
              "image_id1"_a, "image_id2"_a);
+
+    // ---- Camera + single-pair estimators (estimators.h) ------------------------------------------
+    BindCamera(m);
+    BindEstimators(m);
 
     // ---- pipeline entry points ----------------------------------------------------------------
     auto run_pipeline = [](const py::object& database_path, const SiftMatchingOptions& sift,

@@ -160,3 +160,72 @@ def test_two_view_geometry_on_f64_points(ctx):
         np.testing.assert_array_equal(mask[int(off[p]):int(off[p + 1])], w["inlier_mask"], err_msg=str(p))
         for k in "EFH":
             np.testing.assert_array_equal(bits(tvg[p][k]), bits(w[k]), err_msg=f"{p} {k}")
+
+
+def test_python_estimator_api_matches_oracle():
+    """The pycolmap-named functions end to end (pybind11 module -> C ABI -> kernel)."""
+    import pycolmap_amd as pc
+    rng = np.random.default_rng(16)
+    sc = synth.two_view_scene(rng, num_inliers=200, num_outliers=80)
+    p1, p2 = correspondences(sc, rng)
+    ro = pc.RANSACOptions()
+    oo = o.ransac_options(max_error=ro.max_error, min_inlier_ratio=ro.min_inlier_ratio, confidence=ro.confidence,
+                          min_num_trials=ro.min_num_trials, max_num_trials=ro.max_num_trials)
+    for fn, kind, key in ((pc.fundamental_matrix_estimation, "F", "F"), (pc.homography_matrix_estimation, "H", "H")):
+        got = fn(p1, p2)
+        want = o.ransac_estimate(kind, p1, p2, oo, seed=0)
+        assert want["success"] and got is not None
+        np.testing.assert_array_equal(bits(got[key]), bits(want["model"]))
+        assert got["num_inliers"] == want["num_inliers"]
+        np.testing.assert_array_equal(np.array(got["inliers"]), want["inliers"])
+    # a failed RANSAC returns None (fewer correspondences than the minimal sample)
+    assert pc.fundamental_matrix_estimation(p1[:5], p2[:5]) is None
+    assert pc.homography_matrix_estimation(p1[:3], p2[:3]) is None
+    # options as a dict, like the reference's implicit dict -> options conversion
+    got = pc.homography_matrix_estimation(p1, p2, dict(max_error=2.0))
+    want = o.ransac_estimate("H", p1, p2, o.ransac_options(max_error=2.0), seed=0)
+    assert (got is None) == (not want["success"])
+    if got is not None:
+        np.testing.assert_array_equal(bits(got["H"]), bits(want["model"]))
+
+    cam = pc.Camera(model="PINHOLE", width=sc["width"], height=sc["height"],
+                    params=[sc["f"], sc["f"], sc["width"] / 2.0, sc["height"] / 2.0])
+    gotE = pc.essential_matrix_estimation(p1, p2, cam, cam)
+    n1 = (p1 - [sc["width"] / 2.0, sc["height"] / 2.0]) / sc["f"]
+    n2 = (p2 - [sc["width"] / 2.0, sc["height"] / 2.0]) / sc["f"]
+    e = (ro.max_error / sc["f"] + ro.max_error / sc["f"]) / 2
+    wantE = o.ransac_estimate("E", n1, n2, o.ransac_options(max_error=e, min_inlier_ratio=ro.min_inlier_ratio,
+                                                           confidence=ro.confidence, min_num_trials=ro.min_num_trials,
+                                                           max_num_trials=ro.max_num_trials), seed=0)
+    assert gotE is not None and wantE["success"]
+    np.testing.assert_array_equal(bits(gotE["E"]), bits(wantE["model"]))
+    np.testing.assert_array_equal(np.array(gotE["inliers"]), wantE["inliers"])
+    assert gotE["cam2_from_cam1"] is None
+
+    res = pc.squared_sampson_error(n1, n2, gotE["E"])
+    np.testing.assert_array_equal(bits(np.array(res)), bits(o.sampson_error(n1, n2, gotE["E"])))
+
+    # estimate_two_view_geometry: explicit matches and the identity default
+    for prior in (False, True):
+        cam.has_prior_focal_length = prior
+        ocam = o.make_camera("PINHOLE", sc["width"], sc["height"],
+                             (sc["f"], sc["f"], sc["width"] / 2.0, sc["height"] / 2.0), prior=prior)
+        g = pc.estimate_two_view_geometry(cam, sc["pts1"], cam, sc["pts2"], sc["matches"])
+        w = o.estimate_two_view_geometry(ocam, sc["pts1"], ocam, sc["pts2"], sc["matches"], o.tvg_default_options())
+        assert g.config.name == w["config_name"]
+        np.testing.assert_array_equal(g.inlier_matches, sc["matches"][w["inlier_mask"]])
+        for k in "EFH":
+            np.testing.assert_array_equal(bits(getattr(g, k)), bits(w[k]))
+    ident = np.stack([np.arange(len(p1))] * 2, axis=1).astype(np.uint32)
+    g = pc.estimate_two_view_geometry(cam, p1, cam, p2)
+    w = o.estimate_two_view_geometry(ocam, p1, ocam, p2, ident, o.tvg_default_options())
+    assert g.config.name == w["config_name"]
+    np.testing.assert_array_equal(g.inlier_matches, ident[w["inlier_mask"]])
+    # the calibrated entry point runs E + F + H whatever has_prior_focal_length says
+    cam.has_prior_focal_length = False
+    gc = pc.estimate_calibrated_two_view_geometry(cam, p1, cam, p2)
+    ocam_p = o.make_camera("PINHOLE", sc["width"], sc["height"],
+                           (sc["f"], sc["f"], sc["width"] / 2.0, sc["height"] / 2.0), prior=True)
+    wc = o.estimate_two_view_geometry(ocam_p, p1, ocam_p, p2, ident, o.tvg_default_options())
+    assert gc.config.name == wc["config_name"]
+    np.testing.assert_array_equal(bits(gc.E), bits(wc["E"]))

@@ -119,3 +119,57 @@ def test_database_binding_reads_colmap_schema(tmp_path):
     assert g.config == pycolmap.TwoViewGeometryConfiguration.UNDEFINED and g.inlier_matches.shape == (0, 2)
     with pytest.raises(ValueError):
         pycolmap.Database(tmp_path / "nope.db")
+
+
+# ---- Camera + single-pair estimator bindings (surface only: no GPU here) --------------------------
+def test_camera_binding_surface():
+    import pycolmap_amd as pc
+    c = pc.Camera.create(3, "SIMPLE_PINHOLE", 1000.0, 1600, 1200)   # Camera::CreateFromModelId
+    assert c.camera_id == 3 and c.model == pc.CameraModelId.SIMPLE_PINHOLE
+    assert c.params.tolist() == [1000.0, 800.0, 600.0] and c.params_info == "f, cx, cy"
+    assert c.mean_focal_length() == 1000.0 and c.focal_length == 1000.0
+    assert c.cam_from_img_threshold(4.0) == 4.0 / 1000.0
+    assert not c.has_prior_focal_length
+    np.testing.assert_array_equal(c.calibration_matrix(), [[1000, 0, 800], [0, 1000, 600], [0, 0, 1]])
+    p = pc.Camera(model="PINHOLE", width=640, height=480, params=[500.0, 520.0, 320.0, 240.0],
+                  has_prior_focal_length=True)
+    assert p.mean_focal_length() == 510.0 and p.focal_length_x == 500.0 and p.focal_length_y == 520.0
+    assert p.principal_point_x == 320.0 and p.principal_point_y == 240.0 and p.has_prior_focal_length
+    assert p.verify_params()
+    p.params = [1.0, 2.0, 3.0]
+    assert not p.verify_params()
+    assert pc.CameraModelId.OPENCV == 4 and pc.CameraModelId["RADIAL"] == 3   # COLMAP's model ids
+    with pytest.raises(ValueError):
+        pc.Camera(model="PINHOLE", width=1, height=1, params=[1.0])
+    with pytest.raises(ValueError):
+        pc.Camera(model="NOT_A_MODEL", width=1, height=1, params=[])
+    assert "SIMPLE_PINHOLE" in repr(c)
+
+
+def test_estimator_bindings_argument_checks():
+    """Pre-flight failures are ValueErrors, as THROW_CHECK_EQ is in the reference; with matching sizes
+    the call reaches the accelerator and, on a box without one, fails loudly (no CPU fallback)."""
+    import pycolmap_amd as pc
+    a, b = np.zeros((5, 2)), np.zeros((6, 2))
+    for fn in (pc.fundamental_matrix_estimation, pc.homography_matrix_estimation):
+        with pytest.raises(ValueError, match="size"):
+            fn(a, b)
+        with pytest.raises(ValueError):
+            fn(np.zeros((5, 3)), np.zeros((5, 3)))
+    cam = pc.Camera.create(1, "SIMPLE_PINHOLE", 1000.0, 1600, 1200)
+    with pytest.raises(ValueError, match="size"):
+        pc.essential_matrix_estimation(a, b, cam, cam)
+    with pytest.raises(ValueError, match="PINHOLE"):
+        pc.essential_matrix_estimation(a, a, pc.Camera.create(1, "OPENCV", 1000.0, 1600, 1200), cam)
+    with pytest.raises(ValueError, match="size"):
+        pc.estimate_two_view_geometry(cam, a, cam, b)           # matches=None needs equal sizes
+    with pytest.raises(ValueError, match="size"):
+        pc.squared_sampson_error(a, b, np.eye(3))
+    with pytest.raises(ValueError):
+        pc.squared_sampson_error(a, a, np.eye(2))
+    with pytest.raises(ValueError):
+        pc.estimate_two_view_geometry_pose()
+    import torch
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match="amc_ctx_create"):
+            pc.fundamental_matrix_estimation(np.zeros((8, 2)), np.zeros((8, 2)))
