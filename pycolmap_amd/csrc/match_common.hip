@@ -147,7 +147,10 @@ __global__ __launch_bounds__(256) void finalize_kernel(
 // resolve_index: the mfma kernel reports, per X row, the best VALUE and the 32-row TILE of Y
 // holding it.  For the rows that pass COLMAP's acceptance tests (the only ones whose index is
 // ever used) recompute the 32 dot products of that tile on the raw u8 descriptors and take the
-// lowest row whose value equals the best: COLMAP's strict-'>' scan keeps exactly that one.
+// lowest row whose value equals the best: COLMAP's strict-'>' scan keeps exactly that one.  The
+// same 32 recomputed values complete the row's second-largest value (match_mfma.hip, valu16): the
+// scan's second_v is exact except for values inside the winning tile, and it can only grow here,
+// so a row rejected by the acceptance tests before this kernel stays rejected.
 // side 0: X rows = all rows of image 1, table = rowbuf.  side 1: X rows = the candidate rows of
 // image 2 (candbuf), table = colbuf.  One workgroup per pair, a wave per accepted row in turn:
 // lane = (Y row of the tile, half of the 128 bytes).
@@ -178,6 +181,7 @@ __global__ __launch_bounds__(256) void resolve_index_kernel(
             acc = one_way_accepts(t, lut, fp.max_ratio, fp.max_distance);
         }
         uint32_t resolved = 0xFFFFFFFFu;
+        uint32_t second = t.second_v;  // so far: the largest value outside the best's scan unit
         unsigned long long mask = __ballot(acc);
         while (mask) {
             const int b = __ffsll((long long)mask) - 1;
@@ -202,13 +206,23 @@ __global__ __launch_bounds__(256) void resolve_index_kernel(
             sum += __shfl_xor(sum, 32);
             const bool eq = (sum == val) && (jj < Y.rows);
             const uint32_t m = (uint32_t)(__ballot(eq) & 0xFFFFFFFFull);
-            const uint32_t j = m ? tile * 32 + (uint32_t)(__ffs(m) - 1) : 0xFFFFFFFFu;
+            const uint32_t first = m ? (uint32_t)(__ffs(m) - 1) : 0xFFFFFFFFu;
+            const uint32_t j = m ? tile * 32 + first : 0xFFFFFFFFu;
+            // second-largest of the tile's values, with multiplicity: everything but the one
+            // element that is the best (0 = COLMAP's floor for padding rows and the best itself)
+            uint32_t sw = (jj < Y.rows && l31 != first) ? sum : 0u;
+#pragma unroll
+            for (int d = 16; d >= 1; d >>= 1) sw = max(sw, (uint32_t)__shfl_xor(sw, d));
             if ((int)lane == b) {
                 resolved = j;
+                second = max(second, sw);
                 if (!m) atomicAdd(err_count, 1u);  // scan and recomputation disagree: a bug
             }
         }
-        if (e < n) tab[row].best_idx = resolved;  // unaccepted rows: index never used
+        if (e < n) {  // rows rejected above: index never used, second only ever grows
+            tab[row].best_idx = resolved;
+            tab[row].second_v = second;
+        }
     }
 }
 

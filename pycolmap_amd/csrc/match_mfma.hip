@@ -8,16 +8,22 @@
 //   MODE 1  X = image 2 (candidate rows only) , Y = image 1  -> column table, lazily: only the
 //           columns some accepted row points at (select_candidates_kernel); the cross check
 //           never looks at any other column, so results equal COLMAP's full transposed scan.
-// The kernel reports the best VALUE, the second value and the 32-row TILE of Y that holds the
-// best; resolve_index_kernel (match_common.hip) turns the tile into the exact lowest index by
-// recomputing those 32 dot products, only for rows that pass COLMAP's acceptance tests.
+// The kernel reports the best VALUE, the 32-row TILE of Y that holds it, and the largest value
+// OUTSIDE the best's 16-output unit (a lower bound of the second); resolve_index_kernel
+// (match_common.hip) turns the tile into the exact lowest index and completes the second value
+// by recomputing those 32 dot products, only for rows that can still pass COLMAP's acceptance
+// tests (a larger second only ever rejects).
 //
 // Why this shape (measured on MI355X, tools/ubench_ops.hip and tools/ubench_mix.hip):
 //   * every 32-bit min/max/med3/max3/shift/shift-add is HALF rate on gfx950 (4 clk / wave64);
 //   * on one SIMD an int8 MFMA (32 clk) hides only ~6 VALU instructions; each further one costs
 //     ~4.5 clk.  So the epilogue budget is 6 VALU per MFMA = 1.5 per output.
-// 1.5/output is exactly a values-only top-2 insertion (v_med3_i32 + v_max3_i32 + v_max_i32 per
-// TWO candidates).  Everything else is moved off the VALU:
+// A values-only top-2 insertion (v_med3_i32 + v_max3_i32 + v_max_i32 per TWO candidates) is
+// exactly 1.5/output, i.e. VALU-bound.  The scan therefore does less: it reduces each lane's 16
+// outputs of a unit to their maximum (8 x v_max3/v_max) and keeps the top two of those maxima
+// plus the tile of the best, 13 VALU per 16 outputs = 0.8/output, which leaves the matrix pipe as
+// the limiter.  The row's exact second-largest value is completed by resolve_index_kernel from
+// the winning tile (see valu16).  Everything else is moved off the VALU:
 //   * zero point: the matrix core is signed, the arena holds a' = a - 128 (bytes ^ 0x80) and
 //         sum a*b = sum a'*b' + 128*SX_i + 128*SY_j - 2^21        (SX, SY = byte sums, int32 exact)
 //     The MFMA's A operand is the streamed Y tile and its B operand the resident X tile, so a
@@ -184,19 +190,27 @@ __global__ __launch_bounds__(512) void match_mfma_kernel(
                 for (int s = 1; s < 4; ++s)
                     a = __builtin_amdgcn_mfma_i32_32x32x32_i8(y.f[s], xf[xt][s], a, 0, 0, 0);
             };
-            // 24 VALU for 16 outputs + 2 for the tile tracking
+            // 13 VALU for 16 outputs: the scan only keeps, per lane, the top two of the per-unit
+            // MAXIMA (8 v_max3/v_max for the maximum of the unit's 16 outputs, then one insertion)
+            // and the tile of the best.  The second-largest VALUE of the whole row is either the
+            // maximum of another unit - which the running `sec` then holds, ties included - or
+            // sits inside the winning tile, where resolve_index_kernel recomputes the 32 dot
+            // products anyway to find the index: it takes the second of those 32 as well and the
+            // row's second is the larger of the two.
             auto valu16 = [&](const i32x16& a, int xt, int tile) {
-                int b = best[xt], s = sec[xt];
-                const int b0 = b;
-#pragma unroll
-                for (int r = 0; r < 16; r += 2) {
-                    const int t = smed3(b, a[r], a[r + 1]);
-                    b = smax3(b, a[r], a[r + 1]);
-                    s = smax2(s, t);
-                }
+                int m0 = smax3(a[0], a[1], a[2]);
+                const int m1 = smax3(a[3], a[4], a[5]);
+                const int m2 = smax3(a[6], a[7], a[8]);
+                int m3 = smax3(a[9], a[10], a[11]);
+                const int m4 = smax3(a[12], a[13], a[14]);
+                m0 = smax3(m0, m1, m2);
+                m3 = smax3(m3, m4, a[15]);
+                const int m = smax2(m0, m3);
+                const int b0 = best[xt];
+                sec[xt] = smed3(b0, sec[xt], m);  // sec <= best always: the new second of the maxima
+                const int b = smax2(b0, m);
                 btile[xt] = (b != b0) ? tile : btile[xt];  // strict: first tile wins ties
                 best[xt] = b;
-                sec[xt] = s;
             };
 
             // ---- software-pipelined scan over all of Y -----------------------------------
