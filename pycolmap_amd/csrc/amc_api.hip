@@ -832,40 +832,80 @@ static int verify_impl(amc_ctx* c, int mode, const uint32_t* slot1, const uint32
     mt0[0] = seed;
     for (int i = 1; i < 624; ++i) mt0[i] = 1812433253u * (mt0[i - 1] ^ (mt0[i - 1] >> 30)) + (uint32_t)i;
 
-    const uint32_t mcap = std::max<uint32_t>(64, round_up(maxM, 64));
     int cus = 256;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device);
-    const size_t lds_block = tvg_lds_bytes(mcap, tvg_pts_cap(mcap), 4);
-    const uint32_t blocks_per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / std::max<size_t>(lds_block, 1)));
-    uint32_t num_waves = (uint32_t)std::min<size_t>((npairs + 0), (size_t)cus * blocks_per_cu * 4);
-    num_waves = std::max<uint32_t>(4, (num_waves + 3) / 4 * 4);
 
+    // Size classes.  A wave's LDS share holds, besides the generator state, two uint16 index
+    // arrays of mcap entries (the sampler's permutation and the inlier list).  Normal pairs run 4
+    // waves per workgroup (40 KB each); pairs too large for that run one wave per workgroup with up
+    // to the whole 160 KB (M <= ~38 k: covers max_num_matches = 32768); their points stay in HBM.
+    std::vector<size_t> cls[2];
+    for (size_t p = 0; p < npairs; ++p) {
+        const uint32_t mc = std::max<uint32_t>(64, round_up(tp[p].M, 64));
+        if (tvg_lds_bytes(mc, 0, 1) + 64 <= 160 * 1024 / 4) cls[0].push_back(p);
+        else if (tvg_lds_bytes(mc, 0, 1) + 64 <= 160 * 1024) cls[1].push_back(p);
+        else {
+            delete priv;
+            std::memset(out, 0, sizeof *out);
+            return fail(AMC_E_INVALID, "amc_verify_pairs: pair %zu has %u matches: more than the verification "
+                        "kernel's per-pair state can index in LDS (limit ~38000)", p, tp[p].M);
+        }
+    }
     HIPCHK(c->d_timgs.ensure(timgs.size()));
-    HIPCHK(c->d_tpairs.ensure(npairs));
     HIPCHK(c->d_tmatches.ensure(std::max<size_t>(2 * total, 2)));
     HIPCHK(c->d_ttabs.ensure(std::max<size_t>(tabs.size(), 1)));
     HIPCHK(c->d_mtinit.ensure(624));
-    HIPCHK(c->d_tws.ensure((size_t)num_waves * tvg_ws_doubles_host(mcap)));
-    HIPCHK(c->d_tmaskws.ensure((size_t)num_waves * tvg_ws_mask_bytes_host(mcap)));
     HIPCHK(c->d_toutmask.ensure(std::max<size_t>(mask_bytes, 128)));
-    HIPCHK(c->d_tout.ensure(npairs));
     HIPCHK(hipEventRecord(c->ev[0], st));
     HIPCHK(hipMemcpyAsync(c->d_timgs.p, timgs.data(), timgs.size() * sizeof(TvgImage), hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(c->d_tpairs.p, tp.data(), npairs * sizeof(TvgPair), hipMemcpyHostToDevice, st));
     if (total)
         HIPCHK(hipMemcpyAsync(c->d_tmatches.p, matches, 2 * total * sizeof(uint32_t), hipMemcpyHostToDevice, st));
     if (!tabs.empty())
         HIPCHK(hipMemcpyAsync(c->d_ttabs.p, tabs.data(), tabs.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(c->d_mtinit.p, mt0, sizeof mt0, hipMemcpyHostToDevice, st));
-    HIPCHK(hipStreamSynchronize(st));  // the host staging vectors above go out of scope
-    HIPCHK(hipEventRecord(c->ev[2], st));
-    HIPCHK(launch_tvg(c->d_timgs.p, c->d_tpairs.p, (uint32_t)npairs, c->d_tmatches.p, c->d_ttabs.p,
-                      c->d_mtinit.p, P, c->d_tws.p, c->d_tmaskws.p, mcap, num_waves, c->d_scalars + 1,
-                      c->d_tout.p, c->d_toutmask.p, st));
-    HIPCHK(hipEventRecord(c->ev[3], st));
+    HIPCHK(hipStreamSynchronize(st));
+
     std::vector<TvgOut> h_out(npairs);
     std::vector<uint8_t> h_mask(std::max<size_t>(mask_bytes, 1));
-    HIPCHK(hipMemcpyAsync(h_out.data(), c->d_tout.p, npairs * sizeof(TvgOut), hipMemcpyDeviceToHost, st));
+    double kernel_ms = 0.0;
+    uint32_t launches = 0;
+    for (int k = 0; k < 2; ++k) {
+        const std::vector<size_t>& idx = cls[k];
+        if (idx.empty()) continue;
+        const int wpb = k == 0 ? 4 : 1;
+        uint32_t cm = 0;
+        std::vector<TvgPair> sub(idx.size());
+        for (size_t i = 0; i < idx.size(); ++i) {
+            sub[i] = tp[idx[i]];
+            cm = std::max(cm, sub[i].M);
+        }
+        const uint32_t mcap = std::max<uint32_t>(64, round_up(cm, 64));
+        const size_t lds_block = tvg_lds_bytes(mcap, tvg_pts_cap(mcap, wpb), wpb);
+        // one wave per SIMD (the kernel's register budget): at most 4 waves per CU
+        const uint32_t blocks_per_cu =
+            (uint32_t)std::max<size_t>(1, std::min<size_t>(4 / wpb, (160 * 1024) / std::max<size_t>(lds_block, 1)));
+        uint32_t num_waves = (uint32_t)std::min<size_t>(idx.size(), (size_t)cus * blocks_per_cu * wpb);
+        num_waves = std::max<uint32_t>(wpb, (num_waves + wpb - 1) / wpb * wpb);
+        HIPCHK(c->d_tpairs.ensure(idx.size()));
+        HIPCHK(c->d_tws.ensure((size_t)num_waves * tvg_ws_doubles_host(mcap)));
+        HIPCHK(c->d_tmaskws.ensure((size_t)num_waves * tvg_ws_mask_bytes_host(mcap)));
+        HIPCHK(c->d_tout.ensure(idx.size()));
+        HIPCHK(hipMemcpyAsync(c->d_tpairs.p, sub.data(), sub.size() * sizeof(TvgPair), hipMemcpyHostToDevice, st));
+        HIPCHK(hipStreamSynchronize(st));  // `sub` goes out of scope at the end of the iteration
+        HIPCHK(hipEventRecord(c->ev[2], st));
+        HIPCHK(launch_tvg(c->d_timgs.p, c->d_tpairs.p, (uint32_t)idx.size(), c->d_tmatches.p, c->d_ttabs.p,
+                          c->d_mtinit.p, P, c->d_tws.p, c->d_tmaskws.p, mcap, num_waves, wpb, c->d_scalars + 1,
+                          c->d_tout.p, c->d_toutmask.p, st));
+        HIPCHK(hipEventRecord(c->ev[3], st));
+        std::vector<TvgOut> sub_out(idx.size());
+        HIPCHK(hipMemcpyAsync(sub_out.data(), c->d_tout.p, idx.size() * sizeof(TvgOut), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        for (size_t i = 0; i < idx.size(); ++i) h_out[idx[i]] = sub_out[i];
+        float kms = 0.f;
+        (void)hipEventElapsedTime(&kms, c->ev[2], c->ev[3]);
+        kernel_ms += kms;
+        ++launches;
+    }
     if (mask_bytes)
         HIPCHK(hipMemcpyAsync(h_mask.data(), c->d_toutmask.p, mask_bytes, hipMemcpyDeviceToHost, st));
     HIPCHK(hipEventRecord(c->ev[1], st));
@@ -888,9 +928,8 @@ static int verify_impl(amc_ctx* c, int mode, const uint32_t* slot1, const uint32
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[1]);
     out->device_ms = ms;
-    (void)hipEventElapsedTime(&ms, c->ev[2], c->ev[3]);
-    out->kernel_ms = ms;
-    out->kernel_launches = 1;
+    out->kernel_ms = kernel_ms;
+    out->kernel_launches = launches;
     return AMC_OK;
 }
 

@@ -138,13 +138,13 @@ size_t tvg_ws_mask_bytes_host(uint32_t mcap);
 // target occupancy of the verification kernel (waves per SIMD): sets its VGPR budget and LDS share
 constexpr int kTvgWavesPerSimd = 1;
 size_t tvg_lds_bytes(uint32_t mcap, uint32_t pts_cap, int waves);
-uint32_t tvg_pts_cap(uint32_t mcap);
+uint32_t tvg_pts_cap(uint32_t mcap, int waves_per_block);
 hipError_t launch_sampson(const double* p1, const double* p2, size_t n, const double* E9, double* out,
                           hipStream_t s);
 hipError_t launch_tvg(const TvgImage* imgs, const TvgPair* pairs, uint32_t npairs,
                       const uint32_t* matches, const uint32_t* trial_tabs, const uint32_t* mt_init,
                       const TvgParams& P, double* ws, uint8_t* mask_ws, uint32_t mcap,
-                      uint32_t num_waves, uint32_t* queue_head, TvgOut* out, uint8_t* out_mask,
-                      hipStream_t s);
+                      uint32_t num_waves, int waves_per_block, uint32_t* queue_head, TvgOut* out,
+                      uint8_t* out_mask, hipStream_t s);
 
 }  // namespace amc

@@ -1272,9 +1272,9 @@ size_t tvg_ws_mask_bytes_host(uint32_t mcap) { return tvg_ws_bytes_extra(mcap); 
 size_t tvg_lds_bytes(uint32_t mcap, uint32_t pts_cap, int waves) {
     return (size_t)waves * tvg_lds_per_wave(mcap, pts_cap);
 }
-// how many correspondences of the active RANSAC fit in LDS next to everything else (4 waves/block)
-uint32_t tvg_pts_cap(uint32_t mcap) {
-    const size_t budget = 160 * 1024 / (4 * kTvgWavesPerSimd);
+// how many correspondences of the active RANSAC fit in LDS next to everything else
+uint32_t tvg_pts_cap(uint32_t mcap, int waves_per_block) {
+    const size_t budget = 160 * 1024 / ((size_t)waves_per_block * kTvgWavesPerSimd);
     const size_t other = tvg_lds_bytes(mcap, 0, 1) + 64;
     if (other >= budget) return 0;
     const size_t cap = (budget - other) / 32 / 64 * 64;
@@ -1302,12 +1302,11 @@ hipError_t launch_sampson(const double* p1, const double* p2, size_t n, const do
 hipError_t launch_tvg(const TvgImage* imgs, const TvgPair* pairs, uint32_t npairs,
                       const uint32_t* matches, const uint32_t* trial_tabs, const uint32_t* mt_init,
                       const TvgParams& P, double* ws, uint8_t* mask_ws, uint32_t mcap,
-                      uint32_t num_waves, uint32_t* queue_head, TvgOut* out, uint8_t* out_mask,
-                      hipStream_t s) {
+                      uint32_t num_waves, int waves_per_block, uint32_t* queue_head, TvgOut* out,
+                      uint8_t* out_mask, hipStream_t s) {
     if (npairs == 0) return hipSuccess;
-    const int waves_per_block = 4;
     const uint32_t blocks = (num_waves + waves_per_block - 1) / waves_per_block;
-    const uint32_t pts_cap = tvg_pts_cap(mcap);
+    const uint32_t pts_cap = tvg_pts_cap(mcap, waves_per_block);
     const size_t lds = tvg_lds_bytes(mcap, pts_cap, waves_per_block);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tvg_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -98,6 +98,19 @@ def test_mixed_batch_sizes_and_edge_cases(amc_ctx):
     assert _capi.CONFIG_NAMES[tvg["config"][1]] == "DEGENERATE"      # 14 matches < min_num_inliers
 
 
+def test_large_match_counts(amc_ctx):
+    """Pairs whose correspondences do not fit a wave's LDS share (points stay in HBM), and pairs
+    whose index arrays need a whole workgroup's LDS (one wave per workgroup), mixed with small ones."""
+    rng = np.random.default_rng(21)
+    scenes = [synth.two_view_scene(rng, num_inliers=ni, num_outliers=no, planar=pl, extra_keypoints=10)
+              for ni, no, pl in [(3000, 2000, False), (100, 40, False), (6000, 3000, True), (900, 500, False),
+                                 (5000, 4500, False)]]
+    priors = [True, False, False, True, False]
+    tvg, mask, off, want = run_both(amc_ctx, scenes, priors)
+    for p in range(len(scenes)):
+        assert_pair_equal(p, tvg, mask, off, want)
+
+
 def test_watermark_and_option_variants(amc_ctx):
     rng = np.random.default_rng(9)
     w, h, n = 1600, 1200, 80

@@ -43,13 +43,13 @@ void run(int* out, int waves_per_simd) {
     float ms; (void)hipEventElapsedTime(&ms, e0, e1);
     const double mf_per_simd = (double)iters * 4 * waves_per_simd;
     const double cyc = ms * 1e-3 * 2.4e9 / mf_per_simd;
-    printf("%s N=%2d waves/SIMD=%d: %7.3f ms  cycles per (MFMA + N valu) per SIMD @2.4GHz = %6.1f   (serial model %3d, overlap model %3d)\n",
-           OPK == 0 ? "v_max3_i32" : "v_add_u32 ", N, waves_per_simd, ms, cyc, 35 + (OPK == 0 ? 4 : 2) * N, (OPK == 0 ? 4 : 2) * N > 35 ? (OPK == 0 ? 4 : 2) * N : 35);
+    printf("%s N=%2d waves/SIMD=%d: %7.3f ms  (%5.2f ns per MFMA per SIMD)  cycles per (MFMA + N valu) per SIMD @2.4GHz = %6.1f   (serial model %3d, overlap model %3d)\n",
+           OPK == 0 ? "v_max3_i32" : "v_add_u32 ", N, waves_per_simd, ms, ms * 1e6 / mf_per_simd, cyc, 35 + (OPK == 0 ? 4 : 2) * N, (OPK == 0 ? 4 : 2) * N > 35 ? (OPK == 0 ? 4 : 2) * N : 35);
 }
 int main() {
     int* out; (void)hipMalloc(&out, 256 * 1024 * sizeof(int));
     for (int w = 1; w <= 4; ++w) {
-        run<0, 0>(out, w); run<6, 0>(out, w); run<8, 0>(out, w); run<10, 0>(out, w); run<12, 0>(out, w); run<16, 0>(out, w);
+        run<0, 0>(out, w); run<3, 0>(out, w); run<4, 0>(out, w); run<6, 0>(out, w); run<8, 0>(out, w); run<10, 0>(out, w); run<12, 0>(out, w); run<16, 0>(out, w);
         run<10, 1>(out, w); run<20, 1>(out, w);
     }
     return 0;
