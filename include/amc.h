@@ -59,7 +59,7 @@ enum {
 };
 
 /* Which match kernel to run.  AUTO picks the int8-MFMA kernel (exact for any u8 values) unless
- * image 2 has more than 8192 descriptors and cross_check is on (candidate bitmap limit), where
+ * image 2 has more than 32768 descriptors and cross_check is on (candidate bitmap limit), where
  * it uses the u8 dot4 kernel (see DESIGN.md "match kernels"). */
 enum { AMC_KERNEL_AUTO = 0, AMC_KERNEL_MFMA = 1, AMC_KERNEL_DOT4 = 2 };
 

@@ -397,7 +397,7 @@ int amc_match_pairs(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, si
 
         // ---- route each pair to a kernel -------------------------------------------------
         // mfma: exact for any u8 values and sizes; the lazy cross check's candidate bitmap
-        // (select_candidates_kernel) holds 8192 image-2 rows, larger images take the dot4 path.
+        // (select_candidates_kernel) holds kSelectMaxCols image-2 rows, larger images take the dot4 path.
         std::vector<uint8_t> want_mfma(nb, 0);
         for (size_t i = 0; i < nb; ++i) {
             const Slot& a = c->slots[slot1[begin + i]];

@@ -84,7 +84,7 @@ void launch_resolve_index(int side, const ImageDev* imgs, const PairDev* pairs, 
                           Top2* table, const float* acos_lut, FinalizeParams fp,
                           const uint32_t* cand_cnt, const uint32_t* candbuf, uint32_t* err_count,
                           hipStream_t s);
-constexpr uint32_t kSelectMaxCols = 8192;  // select_candidates' LDS bitmap
+constexpr uint32_t kSelectMaxCols = 32768;  // select_candidates' LDS bitmap (4 KiB)
 
 void launch_select_candidates(const ImageDev* imgs, const PairDev* pairs, uint32_t npairs,
                               const Top2* rowbuf, const float* acos_lut, FinalizeParams fp,

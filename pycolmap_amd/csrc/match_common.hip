@@ -238,14 +238,16 @@ void launch_resolve_index(int side, const ImageDev* imgs, const PairDev* pairs, 
 // ---------------------------------------------------------------------------------------
 // select_candidates: which rows of image 2 ("columns") does the cross check need?  Exactly
 // those some accepted row of image 1 points at.  One workgroup per pair: rows that pass
-// COLMAP's one-way tests set bit best_idx in an LDS bitmap (<= 8192 columns on the mfma path);
+// COLMAP's one-way tests set bit best_idx in an LDS bitmap (<= kSelectMaxCols columns on the mfma path);
 // the bitmap is then compacted, ascending, into candbuf[col_off ...] and counted.
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void select_candidates_kernel(
     const ImageDev* __restrict__ imgs, const PairDev* __restrict__ pairs,
     const Top2* __restrict__ rowbuf, const float* __restrict__ lut, FinalizeParams fp,
     uint32_t* __restrict__ cand_cnt, uint32_t* __restrict__ candbuf) {
-    __shared__ uint32_t bits[256];  // 8192 columns
+    constexpr uint32_t kWords = kSelectMaxCols / 32;  // bitmap words
+    constexpr uint32_t kPer = kWords / 256;           // consecutive words per thread
+    __shared__ uint32_t bits[kWords];
     __shared__ uint32_t wsum[4];
     const PairDev p = pairs[blockIdx.x];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -255,7 +257,7 @@ __global__ __launch_bounds__(256) void select_candidates_kernel(
     }
     const uint32_t n1 = imgs[p.slot1].rows, n2 = imgs[p.slot2].rows;
     const Top2* rows = rowbuf + p.row_off;
-    bits[tid] = 0;
+    for (uint32_t k = tid; k < kWords; k += 256) bits[k] = 0;
     __syncthreads();
     if (n2 != 0) {
         for (uint32_t i = tid; i < n1; i += 256) {
@@ -265,9 +267,15 @@ __global__ __launch_bounds__(256) void select_candidates_kernel(
         }
     }
     __syncthreads();
-    const uint32_t w = bits[tid];
-    const uint32_t c = __popc(w);
-    // inclusive scan over the 256 words
+    // thread t owns words [t*kPer, (t+1)*kPer): ascending column order is thread order
+    uint32_t w[kPer];
+    uint32_t c = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < kPer; ++k) {
+        w[k] = bits[tid * kPer + k];
+        c += __popc(w[k]);
+    }
+    // inclusive scan over the 256 threads
     uint32_t inc = c;
 #pragma unroll
     for (int m = 1; m < 64; m <<= 1) {
@@ -279,11 +287,14 @@ __global__ __launch_bounds__(256) void select_candidates_kernel(
     uint32_t base = 0;
     for (uint32_t k = 0; k < wid; ++k) base += wsum[k];
     uint32_t* dst = candbuf + p.col_off + base + inc - c;
-    uint32_t ww = w;
-    while (ww) {
-        const uint32_t b = __ffs(ww) - 1;
-        *dst++ = tid * 32 + b;
-        ww &= ww - 1;
+#pragma unroll
+    for (uint32_t k = 0; k < kPer; ++k) {
+        uint32_t ww = w[k];
+        while (ww) {
+            const uint32_t b = __ffs(ww) - 1;
+            *dst++ = (tid * kPer + k) * 32 + b;
+            ww &= ww - 1;
+        }
     }
     if (tid == 255) cand_cnt[blockIdx.x] = base + inc;
 }

@@ -193,3 +193,25 @@ def test_8192_rows(amc_ctx):
     off_d, m_d, _ = amc_ctx.match_pairs([0], [1], kernel="dot4")
     np.testing.assert_array_equal(m, m_d)
     assert len(m) > 500
+
+
+def test_more_than_8192_rows_matches_oracle(amc_ctx):
+    """Images larger than BASELINE's biggest config (8192): still the mfma kernel (its candidate
+    bitmap holds 32768 columns), both kernels against the oracle.  Ragged, non-multiple-of-32 sizes."""
+    rng = np.random.default_rng(19)
+    big = synth.scene_images(rng, 2, 9001, num_landmarks=14000, visible_frac=0.4)
+    small = synth.scene_images(rng, 1, 777, num_landmarks=14000, visible_frac=0.4)[0]
+    imgs = [big[0], big[1][:8999], small]
+    upload(amc_ctx, imgs)
+    s1, s2 = [0, 2, 0], [1, 1, 2]
+    off, m, st = amc_ctx.match_pairs(s1, s2, kernel="auto")
+    assert st["pairs_mfma"] == 3
+    off_d, m_d, st_d = amc_ctx.match_pairs(s1, s2, kernel="dot4")
+    np.testing.assert_array_equal(off, off_d)
+    np.testing.assert_array_equal(m, m_d)
+    for p, (a, b) in enumerate(zip(s1, s2)):
+        np.testing.assert_array_equal(m[off[p]:off[p + 1]], oracle_lib.match(imgs[a], imgs[b]))
+    off_n, m_n, st_n = amc_ctx.match_pairs(s1, s2, kernel="auto", cross_check=False)
+    assert st_n["pairs_mfma"] == 3
+    for p, (a, b) in enumerate(zip(s1, s2)):
+        np.testing.assert_array_equal(m_n[off_n[p]:off_n[p + 1]], oracle_lib.match(imgs[a], imgs[b], cross_check=False))
