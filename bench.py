@@ -209,7 +209,7 @@ def main():
         if world > 1:
             # the exchange step: RCCL all-gather of the match tables (sizes, then padded tables);
             # afterwards every rank holds the whole match graph (rank 0 would feed the SQLite writer)
-            gathered = D.all_gather_match_tables(mine, off, m, device=device)
+            gathered = D.all_gather_match_tables(mine, off, m, device=device, as_numpy=False)
         return off, m, st, gathered
 
     def fence():

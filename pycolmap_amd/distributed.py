@@ -26,13 +26,15 @@ def shard_pairs(slot1: np.ndarray, slot2: np.ndarray, rank: int, world: int):
 
 
 def all_gather_match_tables(pair_index: np.ndarray, offsets: np.ndarray, matches: np.ndarray, device=None,
-                            group=None):
+                            group=None, as_numpy: bool = True):
     """Exchange per-rank CSR match tables.  Every rank passes the global indices of its pairs, its
     CSR offsets and its (M, 2) uint32 matches; every rank gets back the table for ALL pairs as
     (global_offsets, global_matches) in the global pair order.
 
-    Two collectives: an all-gather of the (npairs, nmatches) sizes, then padded all-gathers of the
-    per-pair counts / indices and of the match rows."""
+    Collectives: an all-gather of the (npairs, nmatches) sizes, then two padded all-gathers (per-pair
+    (index, count) and the match rows) - few and large, which is what xGMI's point-to-point rings
+    want.  The reassembly into the global CSR is a handful of tensor ops on `device` (scatter of the
+    counts, one cumulative sum, one indexed copy of the rows): no per-pair host work."""
     import torch
     import torch.distributed as dist
 
@@ -43,38 +45,40 @@ def all_gather_match_tables(pair_index: np.ndarray, offsets: np.ndarray, matches
     sizes = torch.tensor([npairs, nm], dtype=torch.int64, device=dev)
     all_sizes = torch.empty(world * 2, dtype=torch.int64, device=dev)
     dist.all_gather_into_tensor(all_sizes, sizes, group=group)
-    all_sizes = all_sizes.view(world, 2).cpu().numpy()
-    max_p, max_m = int(all_sizes[:, 0].max()), int(all_sizes[:, 1].max())
+    all_sizes = all_sizes.view(world, 2).cpu()
+    max_p, max_m = max(int(all_sizes[:, 0].max()), 1), max(int(all_sizes[:, 1].max()), 1)
 
-    meta = torch.zeros(max(max_p, 1), 2, dtype=torch.int64, device=dev)   # (global index, count)
+    meta = torch.zeros(max_p, 2, dtype=torch.int64, device=dev)   # (global index, count)
     if npairs:
         meta[:npairs, 0] = torch.from_numpy(np.asarray(pair_index, dtype=np.int64)).to(dev)
         meta[:npairs, 1] = torch.from_numpy(counts).to(dev)
-    all_meta = torch.empty(world * max(max_p, 1), 2, dtype=torch.int64, device=dev)
+    all_meta = torch.empty(world * max_p, 2, dtype=torch.int64, device=dev)
     dist.all_gather_into_tensor(all_meta, meta, group=group)
 
-    rows = torch.zeros(max(max_m, 1), 2, dtype=torch.int32, device=dev)
+    rows = torch.zeros(max_m, 2, dtype=torch.int32, device=dev)
     if nm:
         rows[:nm] = torch.from_numpy(np.ascontiguousarray(matches, dtype=np.uint32).view(np.int32)).to(dev)
-    all_rows = torch.empty(world * max(max_m, 1), 2, dtype=torch.int32, device=dev)
+    all_rows = torch.empty(world * max_m, 2, dtype=torch.int32, device=dev)
     dist.all_gather_into_tensor(all_rows, rows, group=group)
 
-    all_meta = all_meta.view(world, max(max_p, 1), 2).cpu().numpy()
-    all_rows = all_rows.view(world, max(max_m, 1), 2).cpu().numpy().view(np.uint32)
-    total_pairs = int(all_sizes[:, 0].sum())
-    g_counts = np.zeros(total_pairs, dtype=np.int64)
-    per_rank = []
-    for r in range(world):
-        p, m = int(all_sizes[r, 0]), int(all_sizes[r, 1])
-        idx, cnt = all_meta[r, :p, 0], all_meta[r, :p, 1]
-        g_counts[idx] = cnt
-        per_rank.append((idx, cnt, all_rows[r, :m]))
-    g_off = np.zeros(total_pairs + 1, dtype=np.uint64)
-    g_off[1:] = np.cumsum(g_counts)
-    g_matches = np.zeros((int(g_off[-1]), 2), dtype=np.uint32)
-    for idx, cnt, rws in per_rank:
-        src = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)
-        for k in range(len(idx)):
-            if cnt[k]:
-                g_matches[int(g_off[idx[k]]):int(g_off[idx[k]]) + int(cnt[k])] = rws[src[k]:src[k + 1]]
-    return g_off, g_matches
+    # ---- global CSR, on `dev` ----
+    np_r = all_sizes[:, 0].to(dev)
+    nm_r = all_sizes[:, 1].to(dev)
+    valid_p = (torch.arange(max_p, device=dev)[None, :] < np_r[:, None]).reshape(-1)
+    valid_m = (torch.arange(max_m, device=dev)[None, :] < nm_r[:, None]).reshape(-1)
+    idx = all_meta[valid_p, 0]          # rank-major concatenation of every rank's pairs ...
+    cnt = all_meta[valid_p, 1]
+    rows_cat = all_rows[valid_m]        # ... and of their rows, in the same order
+    total_pairs = int(idx.numel())
+    g_counts = torch.zeros(total_pairs, dtype=torch.int64, device=dev)
+    g_counts[idx] = cnt
+    g_off = torch.zeros(total_pairs + 1, dtype=torch.int64, device=dev)
+    g_off[1:] = torch.cumsum(g_counts, 0)
+    src_start = torch.cumsum(cnt, 0) - cnt                        # where each pair's rows start in rows_cat
+    shift = torch.repeat_interleave(g_off[idx] - src_start, cnt)  # per row: destination - source position
+    g_matches = torch.empty(int(rows_cat.shape[0]), 2, dtype=torch.int32, device=dev)
+    if rows_cat.shape[0]:
+        g_matches[torch.arange(rows_cat.shape[0], device=dev) + shift] = rows_cat
+    if not as_numpy:
+        return g_off, g_matches
+    return g_off.cpu().numpy().astype(np.uint64), g_matches.cpu().numpy().view(np.uint32)
