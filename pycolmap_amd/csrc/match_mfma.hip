@@ -190,6 +190,12 @@ __global__ __launch_bounds__(512) void match_mfma_kernel(
                 for (int s = 1; s < 4; ++s)
                     a = __builtin_amdgcn_mfma_i32_32x32x32_i8(y.f[s], xf[xt][s], a, 0, 0, 0);
             };
+            // One phase = the 4 MFMAs of the NEXT unit (into `an`) with the 13 VALU of the CURRENT
+            // unit (reading `ac`, completed by the previous phase) spread between them, -/4/4/5.
+            // Interleaved, the two waves of a SIMD keep the matrix pipe fed (15.6 ns per MFMA in
+            // tools/ubench_mix.hip); "4 MFMAs, then 13 VALU" leaves it idle whenever both waves are
+            // in their VALU stretch (18.3 ns).
+            //
             // 13 VALU for 16 outputs: the scan only keeps, per lane, the top two of the per-unit
             // MAXIMA (8 v_max3/v_max for the maximum of the unit's 16 outputs, then one insertion)
             // and the tile of the best.  The second-largest VALUE of the whole row is either the
@@ -197,20 +203,31 @@ __global__ __launch_bounds__(512) void match_mfma_kernel(
             // sits inside the winning tile, where resolve_index_kernel recomputes the 32 dot
             // products anyway to find the index: it takes the second of those 32 as well and the
             // row's second is the larger of the two.
-            auto valu16 = [&](const i32x16& a, int xt, int tile) {
-                int m0 = smax3(a[0], a[1], a[2]);
-                const int m1 = smax3(a[3], a[4], a[5]);
-                const int m2 = smax3(a[6], a[7], a[8]);
-                int m3 = smax3(a[9], a[10], a[11]);
-                const int m4 = smax3(a[12], a[13], a[14]);
+            auto phase = [&](i32x16& an, const YFrag& y, int xtn, const i32x16& ac, int xtc, int tile) {
+                an = __builtin_amdgcn_mfma_i32_32x32x32_i8(y.f[0], xf[xtn][0], y.ci, 0, 0, 0);
+                an = __builtin_amdgcn_mfma_i32_32x32x32_i8(y.f[1], xf[xtn][1], an, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                // first read of `ac`: two MFMAs have issued since the one that completed it
+                int m0 = smax3(ac[0], ac[1], ac[2]);
+                const int m1 = smax3(ac[3], ac[4], ac[5]);
+                const int m2 = smax3(ac[6], ac[7], ac[8]);
+                int m3 = smax3(ac[9], ac[10], ac[11]);
+                __builtin_amdgcn_sched_barrier(0);
+                an = __builtin_amdgcn_mfma_i32_32x32x32_i8(y.f[2], xf[xtn][2], an, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                const int m4 = smax3(ac[12], ac[13], ac[14]);
                 m0 = smax3(m0, m1, m2);
-                m3 = smax3(m3, m4, a[15]);
+                m3 = smax3(m3, m4, ac[15]);
                 const int m = smax2(m0, m3);
-                const int b0 = best[xt];
-                sec[xt] = smed3(b0, sec[xt], m);  // sec <= best always: the new second of the maxima
+                __builtin_amdgcn_sched_barrier(0);
+                an = __builtin_amdgcn_mfma_i32_32x32x32_i8(y.f[3], xf[xtn][3], an, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                const int b0 = best[xtc];
+                sec[xtc] = smed3(b0, sec[xtc], m);  // sec <= best always: the new second of the maxima
                 const int b = smax2(b0, m);
-                btile[xt] = (b != b0) ? tile : btile[xt];  // strict: first tile wins ties
-                best[xt] = b;
+                btile[xtc] = (b != b0) ? tile : btile[xtc];  // strict: first tile wins ties
+                best[xtc] = b;
+                __builtin_amdgcn_sched_barrier(0);
             };
 
             // ---- software-pipelined scan over all of Y -----------------------------------
@@ -227,15 +244,11 @@ __global__ __launch_bounds__(512) void match_mfma_kernel(
                 mfma4(accA, y0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            // one phase: the 4 MFMAs of the next unit, THEN the VALU of the current unit.  The
-            // sched_barriers keep that order: an accumulator is read (by inline asm, which hipcc
-            // does not hazard-check) only after the 4 MFMAs of the following unit have issued,
-            // i.e. >= 96 clk after the last MFMA that wrote it (a 16-pass MFMA takes 64).
-#define AMC_PHASE(accn, yfr, xtn, accc, xtc)                                                   \
-    mfma4(accn, yfr, xtn);                                                                     \
-    __builtin_amdgcn_sched_barrier(0);                                                         \
-    valu16(accc, xtc, tile);                                                                   \
-    __builtin_amdgcn_sched_barrier(0);
+            // The sched_barriers pin the interleaving.  An accumulator is read (by inline asm, which
+            // hipcc does not hazard-check) only after TWO further MFMAs have issued behind the one
+            // that completed it - the matrix pipe runs MFMAs in order, 32 clk each, so the value
+            // has been written back for well over the 11 wait states an 8-pass MFMA needs.
+#define AMC_PHASE(accn, yfr, xtn, accc, xtc) phase(accn, yfr, xtn, accc, xtc, tile);
             // one step = one Y tile held in `yc`; prefetches the next tile into `yn`
 #define AMC_STEP(yc, yn, c_, yt_)                                                              \
     {                                                                                          \
