@@ -42,6 +42,8 @@
 // arena is pre-swizzled so the linear DMA image is bank-conflict-free for ds_read_b128.
 // Each wave software-pipelines: the 4 MFMAs of unit u+1 are issued in front of the 24 VALU of
 // unit u (unit = 32 Y rows x 32 X rows), two accumulator sets.
+#include <climits>
+
 #include "amc_internal.h"
 
 namespace amc {
@@ -191,7 +193,7 @@ __global__ __launch_bounds__(512) void match_mfma_kernel(
                     a = __builtin_amdgcn_mfma_i32_32x32x32_i8(y.f[s], xf[xt][s], a, 0, 0, 0);
             };
             // One phase = the 4 MFMAs of the NEXT unit (into `an`) with the 13 VALU of the CURRENT
-            // unit (reading `ac`, completed by the previous phase) spread between them, -/4/4/5.
+            // unit (reading `ac`, completed by the previous phase) spread between them, 5/4/4/-.
             // Interleaved, the two waves of a SIMD keep the matrix pipe fed (15.6 ns per MFMA in
             // tools/ubench_mix.hip); "4 MFMAs, then 13 VALU" leaves it idle whenever both waves are
             // in their VALU stretch (18.3 ns).
@@ -203,8 +205,23 @@ __global__ __launch_bounds__(512) void match_mfma_kernel(
             // sits inside the winning tile, where resolve_index_kernel recomputes the 32 dot
             // products anyway to find the index: it takes the second of those 32 as well and the
             // row's second is the larger of the two.
+            // insertion of a unit maximum into a lane's (best, second, tile) state
+            auto insert = [&](int xt, int m, int tile) {
+                const int b0 = best[xt];
+                sec[xt] = smed3(b0, sec[xt], m);  // sec <= best always: the new second of the maxima
+                const int b = smax2(b0, m);
+                btile[xt] = (b != b0) ? tile : btile[xt];  // strict: first tile wins ties
+                best[xt] = b;
+            };
+            // The insertion of a unit's maximum does not touch accumulators, so it is deferred into
+            // the hazard slot of the NEXT phase (between its first two MFMAs): pm / ptile carry the
+            // pending maximum (of X tile (xtc + 3) & 3) from one phase to the next.
+            int pm = INT_MIN, ptile = 0;
             auto phase = [&](i32x16& an, const YFrag& y, int xtn, const i32x16& ac, int xtc, int tile) {
                 an = __builtin_amdgcn_mfma_i32_32x32x32_i8(y.f[0], xf[xtn][0], y.ci, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                insert((xtc + 3) & 3, pm, ptile);
+                __builtin_amdgcn_sched_barrier(0);
                 an = __builtin_amdgcn_mfma_i32_32x32x32_i8(y.f[1], xf[xtn][1], an, 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 // first read of `ac`: two MFMAs have issued since the one that completed it
@@ -218,15 +235,10 @@ __global__ __launch_bounds__(512) void match_mfma_kernel(
                 const int m4 = smax3(ac[12], ac[13], ac[14]);
                 m0 = smax3(m0, m1, m2);
                 m3 = smax3(m3, m4, ac[15]);
-                const int m = smax2(m0, m3);
+                pm = smax2(m0, m3);
+                ptile = tile;
                 __builtin_amdgcn_sched_barrier(0);
                 an = __builtin_amdgcn_mfma_i32_32x32x32_i8(y.f[3], xf[xtn][3], an, 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                const int b0 = best[xtc];
-                sec[xtc] = smed3(b0, sec[xtc], m);  // sec <= best always: the new second of the maxima
-                const int b = smax2(b0, m);
-                btile[xtc] = (b != b0) ? tile : btile[xtc];  // strict: first tile wins ties
-                best[xtc] = b;
                 __builtin_amdgcn_sched_barrier(0);
             };
 
@@ -281,6 +293,7 @@ __global__ __launch_bounds__(512) void match_mfma_kernel(
             }
 #undef AMC_STEP
 #undef AMC_PHASE
+            if (active) insert(3, pm, ptile);  // the last unit's maximum is still pending
 
             // ---- row block done: merge the two lane halves, decode, store -------------------
             if (active) {
