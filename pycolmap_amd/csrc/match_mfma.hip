@@ -53,7 +53,7 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(1))) const void gvoid_t;
 typedef __attribute__((address_space(3))) void lvoid_t;
 
-constexpr int kBN = 256;                // Y rows per LDS chunk
+constexpr int kBN = 256;                // Y rows per LDS chunk (= kRowPad); 512 measured 2 % slower
 constexpr int kYT = kBN / 32;           // Y tiles per chunk
 constexpr int kWaves = 8;               // waves per workgroup
 constexpr int kXT = 4;                  // resident X tiles (32 rows each) per wave
@@ -62,10 +62,13 @@ constexpr int kBM = kWaves * kWM;       // 1024 X rows per row block
 constexpr int kChunkBytes = kBN * kDim; // 32 KiB
 
 // single LDS object (a second __shared__ object de-pipelines the DMA waits)
-constexpr int kOffB = 0;                         // 2 x 32 KiB descriptor chunks
-constexpr int kOffRs = 2 * kChunkBytes;          // 2 x 1 KiB rs128 chunks
+constexpr int kOffRs = 0;                        // 2 x rs128 chunks (kBN ints each)
 constexpr int kOffQ = kOffRs + 2 * kBN * 4;      // queue slot
-constexpr int kLdsBytes = kOffQ + 16;
+constexpr int kOffB = kOffQ + 16;                // 2 x descriptor chunks
+constexpr int kLdsBytes = kOffB + 2 * kChunkBytes;
+static_assert(kBN == kRowPad, "a chunk is the row padding unit");
+static_assert(kBN % 64 == 0 && (kChunkBytes / 1024) % kWaves == 0, "chunk must split into tile pairs and 1 KiB DMA pieces per wave");
+static_assert(kLdsBytes <= 160 * 1024, "LDS of one CU");
 
 // v_med3_i32 / v_max3_i32 pinned by hand (hipcc pattern-matches them only some of the time).
 // They read MFMA results directly and hipcc does not pad hazards for inline asm, so the kernel
@@ -124,19 +127,19 @@ __global__ __launch_bounds__(512) void match_mfma_kernel(
         const int nrb = (nrows + kBM - 1) / kBM;
 
         auto stage = [&](int c, int buf) {
-            // 32 KiB descriptor chunk: 4 x (8 waves x 1 KiB); dest = wave-uniform base + lane*16
+            // the descriptor chunk in 1 KiB pieces dealt to the waves; dest = wave-uniform base + lane*16
             const char* src = reinterpret_cast<const char*>(Y.prep) + (size_t)c * kChunkBytes;
 #pragma unroll
-            for (int ps = 0; ps < 4; ++ps) {
+            for (int ps = 0; ps < kChunkBytes / 1024 / kWaves; ++ps) {
                 const int piece = ps * kWaves + wid;
                 __builtin_amdgcn_global_load_lds(
                     (gvoid_t*)(src + piece * 1024 + lane * 16),
                     (lvoid_t*)(smem + kOffB + buf * kChunkBytes + piece * 1024), 16, 0, 0);
             }
-            if (wid == 0) {  // 1 KiB of rs128 for this chunk's 256 rows
-                const char* rsrc = reinterpret_cast<const char*>(Y.rs128 + (size_t)c * kBN);
+            if (wid * 1024 + lane * 16 < kBN * 4) {  // rs128 of this chunk's rows, up to 1 KiB per wave
+                const char* rsrc = reinterpret_cast<const char*>(Y.rs128 + (size_t)c * kBN) + wid * 1024;
                 __builtin_amdgcn_global_load_lds((gvoid_t*)(rsrc + lane * 16),
-                                                 (lvoid_t*)(smem + kOffRs + buf * kBN * 4), 16,
+                                                 (lvoid_t*)(smem + kOffRs + buf * kBN * 4 + wid * 1024), 16,
                                                  0, 0);
             }
         };
@@ -171,7 +174,8 @@ __global__ __launch_bounds__(512) void match_mfma_kernel(
 #pragma unroll
                 for (int xt = 0; xt < kXT; ++xt) {
                     const int k = rowbase + xt * 32 + l31;
-                    const int row = MODE == 0 ? k : (int)list[min(k, nrows - 1)];
+                    // rows past the end of the block are clamped (their results are never stored)
+                    const int row = MODE == 0 ? min(k, (int)X.rows_pad - 1) : (int)list[min(k, nrows - 1)];
                     const char* rp = reinterpret_cast<const char*>(X.prep) + (size_t)row * kDim;
                     const int sw = (row >> 1) & 7;
 #pragma unroll
