@@ -107,11 +107,13 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
-    if not LIB_PATH.exists():
+    import os
+    path = Path(os.environ.get("AMC_LIB_PATH", LIB_PATH))  # override: A/B benchmarking of kernel builds
+    if not path.exists():
         raise ImportError(
-            f"{LIB_PATH} not found — run `python -m pycolmap_amd.build` (hipcc, gfx950). "
+            f"{path} not found — run `python -m pycolmap_amd.build` (hipcc, gfx950). "
             "pycolmap_amd has no CPU fallback.")
-    lib = C.CDLL(str(LIB_PATH))
+    lib = C.CDLL(str(path))
     lib.amc_last_error.restype = C.c_char_p
     lib.amc_abi_version.restype = C.c_int
     lib.amc_device_count.restype = C.c_int

@@ -163,6 +163,7 @@ __global__ __launch_bounds__(512) void match_mfma_kernel(
             }
         };
 
+        stage(0, 0);  // every row block starts from chunk 0; the next block's copy is issued early (below)
         for (int rb = 0; rb < nrb; ++rb) {
             const int rowbase = rb * kBM + wid * kWM;
             const bool active = rowbase < nrows;  // wave-uniform
@@ -251,8 +252,7 @@ __global__ __launch_bounds__(512) void match_mfma_kernel(
             // issues the MFMAs of the NEXT unit, then runs the VALU of the current one.
             YFrag y0, y1;
             i32x16 accA, accB;
-            stage(0, 0);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // chunk 0 (and this block's X rows) landed
             __syncthreads();
             if (nchunks > 1) stage(1, 1);
             if (active) {
@@ -298,6 +298,10 @@ __global__ __launch_bounds__(512) void match_mfma_kernel(
 #undef AMC_STEP
 #undef AMC_PHASE
             if (active) insert(3, pm, ptile);  // the last unit's maximum is still pending
+            __syncthreads();  // everyone is done with both LDS chunk buffers
+            // restart the stream for the next row block now: the copy runs under this block's
+            // epilogue and the next block's X loads
+            if (rb + 1 < nrb) stage(0, 0);
 
             // ---- row block done: merge the two lane halves, decode, store -------------------
             if (active) {
@@ -323,7 +327,6 @@ __global__ __launch_bounds__(512) void match_mfma_kernel(
                     }
                 }
             }
-            __syncthreads();  // everyone is done with both LDS chunk buffers
         }
     }
 }
