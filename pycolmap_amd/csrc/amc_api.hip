@@ -110,6 +110,7 @@ struct amc_ctx {
     DevBuf<Dot4Work> d_work;
     DevBuf<uint32_t> d_order, d_order2;
     DevBuf<Top2> d_rowbuf, d_colbuf;
+    DevBuf<uint32_t> d_accmask;  // one accept bit per row-table entry (mfma pairs)
     DevBuf<uint32_t> d_pair_off, d_pair_cnt, d_matches, d_cand_cnt, d_candbuf;
     PinBuf<PairDev> h_pairs;
     PinBuf<Dot4Work> h_work;
@@ -206,7 +207,7 @@ void amc_ctx_destroy(amc_ctx* c) {
     if (c->d_lut) (void)hipFree(c->d_lut);
     if (c->d_scalars) (void)hipFree(c->d_scalars);
     c->d_pairs.release(); c->d_work.release(); c->d_order.release(); c->d_order2.release();
-    c->d_rowbuf.release(); c->d_colbuf.release();
+    c->d_rowbuf.release(); c->d_colbuf.release(); c->d_accmask.release();
     c->d_pair_off.release(); c->d_pair_cnt.release(); c->d_matches.release();
     c->d_cand_cnt.release(); c->d_candbuf.release();
     c->h_pairs.release(); c->h_work.release(); c->h_order.release(); c->h_order2.release();
@@ -389,6 +390,7 @@ int amc_match_pairs(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, si
         if (!hc(c->h_pairs.ensure(nb), "pinned pairs") || !hc(c->d_pairs.ensure(nb), "dev pairs") ||
             !hc(c->h_order.ensure(nb), "pinned order") || !hc(c->d_order.ensure(nb), "dev order") ||
             !hc(c->d_rowbuf.ensure(top_rows), "row top2") || !hc(c->d_colbuf.ensure(top_cols), "col top2") ||
+            !hc(c->d_accmask.ensure(top_rows / 32 + 8), "accept mask") ||
             !hc(c->d_pair_off.ensure(nb), "pair_off") || !hc(c->d_pair_cnt.ensure(nb), "pair_cnt") ||
             !hc(c->h_pair_off.ensure(nb), "pinned pair_off") || !hc(c->h_pair_cnt.ensure(nb), "pinned pair_cnt") ||
             !hc(c->d_matches.ensure(2 * cap), "dev matches") || !hc(c->h_matches.ensure(2 * cap), "pinned matches") ||
@@ -469,7 +471,9 @@ int amc_match_pairs(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, si
                    hc(hipMemsetAsync(c->d_scalars + 3, 0, sizeof(uint32_t), st), "memset errcount");
         if (okq && nord)
             okq = hc(hipMemcpyAsync(c->d_order.p, c->h_order.p, nord * sizeof(uint32_t),
-                                    hipMemcpyHostToDevice, st), "H2D order");
+                                    hipMemcpyHostToDevice, st), "H2D order") &&
+                  // row blocks no wave owns (beyond an image's last row) never write their words
+                  hc(hipMemsetAsync(c->d_accmask.p, 0, (row_off / 32 + 8) * sizeof(uint32_t), st), "memset accmask");
         if (okq && nwork)
             okq = hc(hipMemcpyAsync(c->d_work.p, c->h_work.p, nwork * sizeof(Dot4Work),
                                     hipMemcpyHostToDevice, st), "H2D work");
@@ -482,18 +486,19 @@ int amc_match_pairs(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, si
         (void)hipEventRecord(c->ev[2], st);
         if (nord)
             launch_match_mfma(0, c->d_imgs.p, c->d_pairs.p, c->d_order.p, (uint32_t)nord,
-                              c->d_scalars + 1, c->d_cand_cnt.p, c->d_candbuf.p, c->d_rowbuf.p, st);
+                              c->d_scalars + 1, c->d_cand_cnt.p, c->d_candbuf.p, c->d_rowbuf.p,
+                              c->d_accmask.p, c->d_lut, fp, st);
         if (nwork)
             launch_match_dot4(c->d_imgs.p, c->d_pairs.p, c->d_work.p, (uint32_t)nwork,
                               c->d_rowbuf.p, c->d_colbuf.p, st);
         (void)hipEventRecord(c->ev[3], st);
         kernel_launches += (nord ? 1 : 0) + (nwork ? 1 : 0);
         if (nord)  // tile -> exact index for the accepted rows
-            launch_resolve_index(0, c->d_imgs.p, c->d_pairs.p, (uint32_t)nb, c->d_rowbuf.p, c->d_lut,
+            launch_resolve_index(0, c->d_imgs.p, c->d_pairs.p, (uint32_t)nb, c->d_rowbuf.p, c->d_accmask.p, c->d_lut,
                                  fp, c->d_cand_cnt.p, c->d_candbuf.p, c->d_scalars + 3, st);
         if (nord && o.cross_check) {
             // lazy cross check: reverse scan only for the columns accepted rows point at
-            launch_select_candidates(c->d_imgs.p, c->d_pairs.p, (uint32_t)nb, c->d_rowbuf.p,
+            launch_select_candidates(c->d_imgs.p, c->d_pairs.p, (uint32_t)nb, c->d_rowbuf.p, c->d_accmask.p,
                                      c->d_lut, fp, c->d_cand_cnt.p, c->d_candbuf.p, st);
             // streamed image is image 1 now: a second queue order, sorted by it
             if (!hc(c->h_order2.ensure(nord), "pinned order2") || !hc(c->d_order2.ensure(nord), "dev order2"))
@@ -509,13 +514,14 @@ int amc_match_pairs(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, si
                                    hipMemcpyHostToDevice, st), "H2D order2"))
                 break;
             launch_match_mfma(1, c->d_imgs.p, c->d_pairs.p, d_order2, (uint32_t)nord,
-                              c->d_scalars + 1, c->d_cand_cnt.p, c->d_candbuf.p, c->d_colbuf.p, st);
-            launch_resolve_index(1, c->d_imgs.p, c->d_pairs.p, (uint32_t)nb, c->d_colbuf.p, c->d_lut,
+                              c->d_scalars + 1, c->d_cand_cnt.p, c->d_candbuf.p, c->d_colbuf.p,
+                              c->d_accmask.p, c->d_lut, fp, st);
+            launch_resolve_index(1, c->d_imgs.p, c->d_pairs.p, (uint32_t)nb, c->d_colbuf.p, c->d_accmask.p, c->d_lut,
                                  fp, c->d_cand_cnt.p, c->d_candbuf.p, c->d_scalars + 3, st);
         }
         (void)hipEventRecord(c->ev[4], st);
         launch_finalize(c->d_imgs.p, c->d_pairs.p, (uint32_t)nb, c->d_rowbuf.p, c->d_colbuf.p,
-                        c->d_lut, fp, c->d_scalars, (uint32_t)std::min(cap, (size_t)0xFFFFFFFFu),
+                        c->d_accmask.p, c->d_lut, fp, c->d_scalars, (uint32_t)std::min(cap, (size_t)0xFFFFFFFFu),
                         c->d_pair_off.p, c->d_pair_cnt.p, c->d_matches.p, st);
         if (!hc(hipGetLastError(), "kernel launch")) break;
         if (!hc(hipMemcpyAsync(c->h_scalars.p, c->d_scalars, 4 * sizeof(uint32_t),

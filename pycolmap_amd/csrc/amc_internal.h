@@ -75,25 +75,44 @@ void launch_match_dot4(const ImageDev* imgs, const PairDev* pairs, const Dot4Wor
 // streamed image for L2 reuse).  mode 0: rows of image 1 vs image 2 -> rowbuf + row_off.
 // mode 1: candidate rows of image 2 (candbuf + col_off, cand_cnt[pair] of them) vs image 1 ->
 // colbuf + col_off (scattered by row index).
+// COLMAP's per-row acceptance tests (FindBestMatchesOneWayBruteForce) on a (best,
+// second) pair.  acos thresholds: lut[d] = acosf(min(d/512^2, 1)) built on the HOST with the host
+// libm; (float)d * 2^-18 is exact for d < 2^24, so indexing by min(d, 262144) reproduces COLMAP's
+// float expression bit-for-bit without depending on the device's acosf.
+__device__ __forceinline__ bool one_way_accepts(const Top2 t, const float* __restrict__ lut,
+                                                float max_ratio, float max_distance) {
+    if (t.best_v == 0u) return false;  // best_i2 == -1: nothing > 0
+    const float a_best = lut[min(t.best_v, 262144u)];
+    if (a_best > max_distance) return false;
+    const float a_second = lut[min(t.second_v, 262144u)];
+    // single IEEE multiply, nothing to contract with
+    if (a_best >= max_ratio * a_second) return false;
+    return true;
+}
+
+// accmask: one bit per row of the mfma pairs' row tables (bit r of word (row_off + r) / 32): set
+// by the scan for rows that pass the acceptance tests with the preliminary second value, narrowed
+// by resolve_index (side 0) to the rows that pass with the exact one.  The later kernels walk the
+// bits instead of re-reading and re-testing every row.
 void launch_match_mfma(int mode, const ImageDev* imgs, const PairDev* pairs,
                        const uint32_t* order, uint32_t nitems, uint32_t* queue_head,
                        const uint32_t* cand_cnt, const uint32_t* candbuf, Top2* outbuf,
-                       hipStream_t s);
+                       uint32_t* accmask, const float* acos_lut, FinalizeParams fp, hipStream_t s);
 
 void launch_resolve_index(int side, const ImageDev* imgs, const PairDev* pairs, uint32_t npairs,
-                          Top2* table, const float* acos_lut, FinalizeParams fp,
+                          Top2* table, uint32_t* accmask, const float* acos_lut, FinalizeParams fp,
                           const uint32_t* cand_cnt, const uint32_t* candbuf, uint32_t* err_count,
                           hipStream_t s);
 constexpr uint32_t kSelectMaxCols = 32768;  // select_candidates' LDS bitmap (4 KiB)
 
 void launch_select_candidates(const ImageDev* imgs, const PairDev* pairs, uint32_t npairs,
-                              const Top2* rowbuf, const float* acos_lut, FinalizeParams fp,
-                              uint32_t* cand_cnt, uint32_t* candbuf, hipStream_t s);
+                              const Top2* rowbuf, const uint32_t* accmask, const float* acos_lut,
+                              FinalizeParams fp, uint32_t* cand_cnt, uint32_t* candbuf, hipStream_t s);
 
 void launch_finalize(const ImageDev* imgs, const PairDev* pairs, uint32_t npairs,
-                     const Top2* rowbuf, const Top2* colbuf, const float* acos_lut,
-                     FinalizeParams fp, uint32_t* cursor, uint32_t capacity, uint32_t* pair_off,
-                     uint32_t* pair_cnt, uint32_t* matches, hipStream_t s);
+                     const Top2* rowbuf, const Top2* colbuf, const uint32_t* accmask,
+                     const float* acos_lut, FinalizeParams fp, uint32_t* cursor, uint32_t capacity,
+                     uint32_t* pair_off, uint32_t* pair_cnt, uint32_t* matches, hipStream_t s);
 
 // ----- two-view verification (tvg.hip) ------------------------------------------------------
 struct CameraDev {

@@ -62,21 +62,11 @@ void launch_prep(const uint8_t* raw, uint8_t* prep, int32_t* rs128, uint32_t row
 // (float)d * 2^-18 is exact for d < 2^24, so indexing by min(d, 262144) reproduces COLMAP's
 // float expression bit-for-bit without depending on the device's acosf.
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ bool one_way_accepts(const Top2 t, const float* __restrict__ lut,
-                                                float max_ratio, float max_distance) {
-    if (t.best_v == 0u) return false;  // best_i2 == -1: nothing > 0
-    const float a_best = lut[min(t.best_v, 262144u)];
-    if (a_best > max_distance) return false;
-    const float a_second = lut[min(t.second_v, 262144u)];
-    // single IEEE multiply, nothing to contract with
-    if (a_best >= max_ratio * a_second) return false;
-    return true;
-}
-
 __global__ __launch_bounds__(256) void finalize_kernel(
     const ImageDev* __restrict__ imgs, const PairDev* __restrict__ pairs,
     const Top2* __restrict__ rowbuf, const Top2* __restrict__ colbuf,
-    const float* __restrict__ lut, FinalizeParams fp, uint32_t* __restrict__ cursor,
+    const uint32_t* __restrict__ accmask, const float* __restrict__ lut, FinalizeParams fp,
+    uint32_t* __restrict__ cursor,
     uint32_t capacity, uint32_t* __restrict__ pair_off, uint32_t* __restrict__ pair_cnt,
     uint32_t* __restrict__ matches) {
     __shared__ uint32_t wave_cnt[4];
@@ -85,12 +75,19 @@ __global__ __launch_bounds__(256) void finalize_kernel(
     const uint32_t n1 = imgs[p.slot1].rows, n2 = imgs[p.slot2].rows;
     const Top2* rows = rowbuf + p.row_off;
     const Top2* cols = colbuf + p.col_off;
+    const uint32_t* mask = accmask + (p.row_off >> 5);
     const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
 
     auto is_match = [&](uint32_t i, uint32_t& j_out) -> bool {
         if (i >= n1 || n2 == 0) return false;
-        const Top2 t = rows[i];
-        if (!one_way_accepts(t, lut, fp.max_ratio, fp.max_distance)) return false;
+        Top2 t;
+        if (p.mode) {  // mfma pair: the accept bits are final after resolve_index
+            if (!((mask[i >> 5] >> (i & 31)) & 1u)) return false;
+            t = rows[i];
+        } else {
+            t = rows[i];
+            if (!one_way_accepts(t, lut, fp.max_ratio, fp.max_distance)) return false;
+        }
         const uint32_t j = t.best_idx;
         j_out = j;
         if (j >= n2) return false;  // unresolved (counted as an internal error upstream)
@@ -157,8 +154,8 @@ __global__ __launch_bounds__(256) void finalize_kernel(
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void resolve_index_kernel(
     int side, const ImageDev* __restrict__ imgs, const PairDev* __restrict__ pairs,
-    Top2* __restrict__ table, const float* __restrict__ lut, FinalizeParams fp,
-    const uint32_t* __restrict__ cand_cnt, const uint32_t* __restrict__ candbuf,
+    Top2* __restrict__ table, uint32_t* __restrict__ accmask, const float* __restrict__ lut,
+    FinalizeParams fp, const uint32_t* __restrict__ cand_cnt, const uint32_t* __restrict__ candbuf,
     uint32_t* __restrict__ err_count) {
     const PairDev p = pairs[blockIdx.x];
     if (p.mode == 0) return;  // dot4 pairs carry exact indices already
@@ -167,6 +164,7 @@ __global__ __launch_bounds__(256) void resolve_index_kernel(
     const uint32_t n = side == 0 ? X.rows : cand_cnt[blockIdx.x];
     if (n == 0 || Y.rows == 0) return;
     Top2* tab = table + (side == 0 ? p.row_off : p.col_off);
+    uint32_t* amask = accmask + (p.row_off >> 5);
     const uint32_t* list = candbuf + p.col_off;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const uint32_t l31 = lane & 31, half = lane >> 5;
@@ -177,8 +175,13 @@ __global__ __launch_bounds__(256) void resolve_index_kernel(
         bool acc = false;
         if (e < n) {
             row = side == 0 ? e : list[e];
-            t = tab[row];
-            acc = one_way_accepts(t, lut, fp.max_ratio, fp.max_distance);
+            if (side == 0) {  // the scan left one accept bit per row: only those rows are read
+                acc = (amask[e >> 5] >> (e & 31)) & 1u;
+                if (acc) t = tab[row];
+            } else {
+                t = tab[row];
+                acc = one_way_accepts(t, lut, fp.max_ratio, fp.max_distance);
+            }
         }
         uint32_t resolved = 0xFFFFFFFFu;
         uint32_t second = t.second_v;  // so far: the largest value outside the best's scan unit
@@ -219,20 +222,26 @@ __global__ __launch_bounds__(256) void resolve_index_kernel(
                 if (!m) atomicAdd(err_count, 1u);  // scan and recomputation disagree: a bug
             }
         }
-        if (e < n) {  // rows rejected above: index never used, second only ever grows
+        if (acc) {  // rows rejected above: index never used, second only ever grows
             tab[row].best_idx = resolved;
             tab[row].second_v = second;
+        }
+        if (side == 0) {  // narrow the accept bits to the rows that pass with the exact second
+            t.second_v = second;
+            const bool keep = acc && one_way_accepts(t, lut, fp.max_ratio, fp.max_distance);
+            const unsigned long long kb = __ballot(keep);
+            if ((lane & 31) == 0 && e < ((n + 31) & ~31u)) amask[e >> 5] = (uint32_t)(kb >> (lane & 32));
         }
     }
 }
 
 void launch_resolve_index(int side, const ImageDev* imgs, const PairDev* pairs, uint32_t npairs,
-                          Top2* table, const float* acos_lut, FinalizeParams fp,
+                          Top2* table, uint32_t* accmask, const float* acos_lut, FinalizeParams fp,
                           const uint32_t* cand_cnt, const uint32_t* candbuf, uint32_t* err_count,
                           hipStream_t s) {
     if (npairs == 0) return;
     hipLaunchKernelGGL(resolve_index_kernel, dim3(npairs), dim3(256), 0, s, side, imgs, pairs,
-                       table, acos_lut, fp, cand_cnt, candbuf, err_count);
+                       table, accmask, acos_lut, fp, cand_cnt, candbuf, err_count);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -243,8 +252,9 @@ void launch_resolve_index(int side, const ImageDev* imgs, const PairDev* pairs, 
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void select_candidates_kernel(
     const ImageDev* __restrict__ imgs, const PairDev* __restrict__ pairs,
-    const Top2* __restrict__ rowbuf, const float* __restrict__ lut, FinalizeParams fp,
-    uint32_t* __restrict__ cand_cnt, uint32_t* __restrict__ candbuf) {
+    const Top2* __restrict__ rowbuf, const uint32_t* __restrict__ accmask,
+    const float* __restrict__ lut, FinalizeParams fp, uint32_t* __restrict__ cand_cnt,
+    uint32_t* __restrict__ candbuf) {
     constexpr uint32_t kWords = kSelectMaxCols / 32;  // bitmap words
     constexpr uint32_t kPer = kWords / 256;           // consecutive words per thread
     __shared__ uint32_t bits[kWords];
@@ -260,10 +270,11 @@ __global__ __launch_bounds__(256) void select_candidates_kernel(
     for (uint32_t k = tid; k < kWords; k += 256) bits[k] = 0;
     __syncthreads();
     if (n2 != 0) {
+        const uint32_t* mask = accmask + (p.row_off >> 5);  // final accept bits (resolve_index)
         for (uint32_t i = tid; i < n1; i += 256) {
-            const Top2 t = rows[i];
-            if (one_way_accepts(t, lut, fp.max_ratio, fp.max_distance) && t.best_idx < n2)
-                atomicOr(&bits[t.best_idx >> 5], 1u << (t.best_idx & 31));
+            if (!((mask[i >> 5] >> (i & 31)) & 1u)) continue;
+            const uint32_t j = rows[i].best_idx;
+            if (j < n2) atomicOr(&bits[j >> 5], 1u << (j & 31));
         }
     }
     __syncthreads();
@@ -300,20 +311,20 @@ __global__ __launch_bounds__(256) void select_candidates_kernel(
 }
 
 void launch_select_candidates(const ImageDev* imgs, const PairDev* pairs, uint32_t npairs,
-                              const Top2* rowbuf, const float* acos_lut, FinalizeParams fp,
-                              uint32_t* cand_cnt, uint32_t* candbuf, hipStream_t s) {
+                              const Top2* rowbuf, const uint32_t* accmask, const float* acos_lut,
+                              FinalizeParams fp, uint32_t* cand_cnt, uint32_t* candbuf, hipStream_t s) {
     if (npairs == 0) return;
     hipLaunchKernelGGL(select_candidates_kernel, dim3(npairs), dim3(256), 0, s, imgs, pairs,
-                       rowbuf, acos_lut, fp, cand_cnt, candbuf);
+                       rowbuf, accmask, acos_lut, fp, cand_cnt, candbuf);
 }
 
 void launch_finalize(const ImageDev* imgs, const PairDev* pairs, uint32_t npairs,
-                     const Top2* rowbuf, const Top2* colbuf, const float* acos_lut,
-                     FinalizeParams fp, uint32_t* cursor, uint32_t capacity, uint32_t* pair_off,
-                     uint32_t* pair_cnt, uint32_t* matches, hipStream_t s) {
+                     const Top2* rowbuf, const Top2* colbuf, const uint32_t* accmask,
+                     const float* acos_lut, FinalizeParams fp, uint32_t* cursor, uint32_t capacity,
+                     uint32_t* pair_off, uint32_t* pair_cnt, uint32_t* matches, hipStream_t s) {
     if (npairs == 0) return;
     hipLaunchKernelGGL(finalize_kernel, dim3(npairs), dim3(256), 0, s, imgs, pairs, rowbuf,
-                       colbuf, acos_lut, fp, cursor, capacity, pair_off, pair_cnt, matches);
+                       colbuf, accmask, acos_lut, fp, cursor, capacity, pair_off, pair_cnt, matches);
 }
 
 }  // namespace amc

@@ -100,7 +100,8 @@ __global__ __launch_bounds__(512) void match_mfma_kernel(
     const ImageDev* __restrict__ imgs, const PairDev* __restrict__ pairs,
     const uint32_t* __restrict__ order, uint32_t nitems, uint32_t* __restrict__ queue_head,
     const uint32_t* __restrict__ cand_cnt, const uint32_t* __restrict__ candbuf,
-    Top2* __restrict__ outbuf) {
+    Top2* __restrict__ outbuf, uint32_t* __restrict__ accmask, const float* __restrict__ lut,
+    FinalizeParams fp) {
     __shared__ __attribute__((aligned(16))) char smem[kLdsBytes];
 
     const int tid = threadIdx.x;
@@ -316,6 +317,7 @@ __global__ __launch_bounds__(512) void match_mfma_kernel(
                     t = ow ? ot : t;
                     b = ow ? ob : b;
                     const int k = rowbase + xt * 32 + l31;
+                    bool acc = false;
                     if (lh == 0 && k < nrows) {
                         const int row = MODE == 0 ? k : (int)list[k];
                         Top2 o;
@@ -324,6 +326,12 @@ __global__ __launch_bounds__(512) void match_mfma_kernel(
                         o.second_v = (uint32_t)(s + xterm[xt]);
                         o.pad = 0;
                         out[row] = o;
+                        // a larger second only ever rejects: rows failing now can be forgotten
+                        if (MODE == 0) acc = one_way_accepts(o, lut, fp.max_ratio, fp.max_distance);
+                    }
+                    if (MODE == 0) {  // accept bits of rows rowbase + xt*32 .. +31 (lanes 0..31)
+                        const uint32_t bits = (uint32_t)__ballot(acc);
+                        if (lane == 0) accmask[(p.row_off + (uint64_t)(rowbase + xt * 32)) >> 5] = bits;
                     }
                 }
             }
@@ -334,7 +342,7 @@ __global__ __launch_bounds__(512) void match_mfma_kernel(
 void launch_match_mfma(int mode, const ImageDev* imgs, const PairDev* pairs,
                        const uint32_t* order, uint32_t nitems, uint32_t* queue_head,
                        const uint32_t* cand_cnt, const uint32_t* candbuf, Top2* outbuf,
-                       hipStream_t s) {
+                       uint32_t* accmask, const float* acos_lut, FinalizeParams fp, hipStream_t s) {
     if (nitems == 0) return;
     int dev = 0, cus = 256;
     (void)hipGetDevice(&dev);
@@ -343,10 +351,10 @@ void launch_match_mfma(int mode, const ImageDev* imgs, const PairDev* pairs,
     (void)hipMemsetAsync(queue_head, 0, sizeof(uint32_t), s);
     if (mode == 0)
         hipLaunchKernelGGL((match_mfma_kernel<0>), dim3(grid), dim3(512), 0, s, imgs, pairs,
-                           order, nitems, queue_head, cand_cnt, candbuf, outbuf);
+                           order, nitems, queue_head, cand_cnt, candbuf, outbuf, accmask, acos_lut, fp);
     else
         hipLaunchKernelGGL((match_mfma_kernel<1>), dim3(grid), dim3(512), 0, s, imgs, pairs,
-                           order, nitems, queue_head, cand_cnt, candbuf, outbuf);
+                           order, nitems, queue_head, cand_cnt, candbuf, outbuf, accmask, acos_lut, fp);
 }
 
 }  // namespace amc
