@@ -317,8 +317,9 @@ int ceil_log2(uint32_t x) {
 }
 
 // limits for one batch (bytes of device scratch)
-constexpr size_t kMaxTop2Entries = (size_t)48 << 20;   // 48 Mi entries x 16 B = 768 MiB per side
-constexpr size_t kMaxMatchCap = (size_t)48 << 20;      // 48 Mi matches x 8 B = 384 MiB
+// sized for 288 GB of HBM: few, large batches (each batch ends in a host synchronisation)
+constexpr size_t kMaxTop2Entries = (size_t)256 << 20;  // 256 Mi entries x 16 B = 4 GiB per side
+constexpr size_t kMaxMatchCap = (size_t)256 << 20;     // worst-case matches of a batch: x 8 B = 2 GiB (device)
 
 }  // namespace
 
@@ -393,7 +394,7 @@ int amc_match_pairs(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, si
             !hc(c->d_accmask.ensure(top_rows / 32 + 8), "accept mask") ||
             !hc(c->d_pair_off.ensure(nb), "pair_off") || !hc(c->d_pair_cnt.ensure(nb), "pair_cnt") ||
             !hc(c->h_pair_off.ensure(nb), "pinned pair_off") || !hc(c->h_pair_cnt.ensure(nb), "pinned pair_cnt") ||
-            !hc(c->d_matches.ensure(2 * cap), "dev matches") || !hc(c->h_matches.ensure(2 * cap), "pinned matches") ||
+            !hc(c->d_matches.ensure(2 * cap), "dev matches") ||
             !hc(c->d_cand_cnt.ensure(nb), "cand_cnt") || !hc(c->d_candbuf.ensure(top_cols), "candbuf"))
             break;
 
@@ -543,8 +544,10 @@ int amc_match_pairs(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, si
                       total, cap);
             break;
         }
+        // the pinned staging buffer follows the ACTUAL number of matches, not the worst case
         if (total &&
-            (!hc(hipMemcpyAsync(c->h_matches.p, c->d_matches.p, (size_t)total * 2 * sizeof(uint32_t),
+            (!hc(c->h_matches.ensure(2 * (size_t)total), "pinned matches") ||
+             !hc(hipMemcpyAsync(c->h_matches.p, c->d_matches.p, (size_t)total * 2 * sizeof(uint32_t),
                                 hipMemcpyDeviceToHost, st), "D2H matches") ||
              !hc(hipStreamSynchronize(st), "sync after D2H")))
             break;
