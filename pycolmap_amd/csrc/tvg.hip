@@ -588,6 +588,85 @@ __device__ void smallest_eigvec9_wave(const lds_f64* A, const lds_f64* V, double
     for (int i = 0; i < 9; ++i) x[i] = V[i * 9 + best];
 }
 
+// ---- real roots of ONE polynomial by the whole wave (local optimisation's 5-point solve) ----------
+// tvg_math.h's RootChain walks the chain of derivatives and, per level, bisects the sign-change
+// brackets one after the other.  The brackets of a level are independent, so here lane i takes
+// bracket i (same arithmetic per bracket, hence the same roots bit for bit) and the level costs one
+// bisection instead of up to R of them; the ordered, de-duplicated root list is then assembled
+// exactly as roots_between_t does it.
+template <int DEG, int R>
+struct WaveRootChain {
+    static __device__ __forceinline__ int run(const double (&c)[DEG + 1], double* roots, lds_f64* tmp, int lane) {
+        double crit[R];
+        const int nc = WaveRootChain<DEG, R - 1>::run(c, crit, tmp, lane);
+        double d[R + 1];
+        poly_derivative_t<DEG, DEG - R>(c, d);
+        double bound = 0.0;
+#pragma unroll
+        for (int i = 0; i < R; ++i) bound = dmax(bound, dabs(d[i] / d[R]));
+        bound = 1.0 + bound;
+        int ne = 0;
+        tmp[ne++] = -bound;
+        for (int i = 0; i < nc; ++i)
+            if (crit[i] > -bound && crit[i] < bound) tmp[ne++] = crit[i];
+        tmp[ne++] = bound;
+        wave_lds_sync();
+        // one bracket per lane: 0 nothing, 1 exact root at the lower edge, 2 bracketed root
+        int kind = 0;
+        double val = 0.0;
+        if (lane + 1 < ne) {
+            double lo = tmp[lane], hi = tmp[lane + 1];
+            double flo = poly_eval_t<R>(d, lo);
+            const double fhi = poly_eval_t<R>(d, hi);
+            if (flo == 0.0) {
+                kind = 1;
+                val = lo;
+            } else if (fhi != 0.0 && (flo < 0.0) != (fhi < 0.0)) {
+                for (int it = 0; it < 200; ++it) {
+                    const double mid = 0.5 * (lo + hi);
+                    if (mid == lo || mid == hi) break;
+                    const double fm = poly_eval_t<R>(d, mid);
+                    if (fm == 0.0) { lo = mid; hi = mid; break; }
+                    if ((fm < 0.0) == (flo < 0.0)) { lo = mid; flo = fm; } else { hi = mid; }
+                }
+                kind = 2;
+                val = 0.5 * (lo + hi);
+            }
+        }
+        const double last = tmp[ne - 1];
+        wave_lds_sync();  // tmp is rewritten by the next level
+        int nr = 0;
+        for (int i = 0; i + 1 < ne; ++i) {
+            const int k = __builtin_amdgcn_readlane(kind, i);
+            const double r = readlane_f64(val, i);
+            if (k == 1) {
+                if (nr == 0 || roots[nr - 1] != r) roots[nr++] = r;
+            } else if (k == 2) {
+                roots[nr++] = r;
+            }
+        }
+        if (poly_eval_t<R>(d, last) == 0.0 && (nr == 0 || roots[nr - 1] != last)) roots[nr++] = last;
+        return nr;
+    }
+};
+template <int DEG>
+struct WaveRootChain<DEG, 1> {
+    static __device__ __forceinline__ int run(const double (&c)[DEG + 1], double* roots, lds_f64*, int) {
+        double d[2];
+        poly_derivative_t<DEG, DEG - 1>(c, d);
+        roots[0] = -d[0] / d[1];
+        return 1;
+    }
+};
+// all real roots of a degree-10 polynomial (wave-uniform input), ascending; = real_roots_t<10>
+__device__ __noinline__ int real_roots10_wave(const double* c_in, double* roots, lds_f64* tmp, int lane) {
+    double c[11];
+#pragma unroll
+    for (int i = 0; i <= 10; ++i) c[i] = c_in[i];
+    if (c[10] == 0.0) return real_roots_t<10>(c, roots);  // degenerate leading coefficient: plain path
+    return WaveRootChain<10, 10>::run(c, roots, tmp, lane);
+}
+
 // local estimator on the K listed inlier correspondences -> models (uniform), count
 template <bool L>
 __device__ __forceinline__ int local_estimate_impl(const LoCtx& w, int kind, const Pts& P, int K, double* models) {
@@ -616,7 +695,13 @@ __device__ __forceinline__ int local_estimate_impl(const LoCtx& w, int kind, con
         jacobi_eigen_wave(9, w.jacA, w.jacV, lane);
         double nsp[4 * 9];
         e5_nullspace_from_eig(w.jacA, w.jacV, nsp);
-        return e5_from_nullspace(nsp, models);
+        wave_lds_sync();  // jacA doubles as the root finder's scratch from here on
+        E5Polys polys;
+        e5_build(nsp, polys);
+        double roots[10];
+        const int nr = real_roots10_wave(polys.det, roots, w.jacA, lane);
+        e5_models(nsp, polys, roots, nr, models);
+        return nr;
     }
     if (kind == K_H && K == 4) {
         double a[4], b[4], c[4], d[4];

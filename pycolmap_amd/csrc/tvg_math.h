@@ -573,8 +573,17 @@ AMC_HD void e5_pmul(const double (&a)[DA + 1], const double (&b)[DB + 1], double
         for (int j = 0; j <= DB; ++j) r[i + j] += a[i] * b[j];
 }
 
-// nsp: 4 x 9 basis (rows: x, y, z, 1 directions).  Returns #models (<= 10), row-major.
-AMC_HD int e5_from_nullspace(const double* nsp, double* models /* 10 x 9 */) {
+// The 5-point solver in three steps, so that the root finding in the middle can be swapped for a
+// wave-cooperative version where one problem is solved by a whole wave (tvg.hip, local optimisation):
+//   e5_build:   nsp (4 x 9 basis; rows: x, y, z, 1 directions) -> B(z) (3 x 3 polynomial matrix) and
+//               det B(z), degree 10
+//   real roots of det B
+//   e5_models:  roots -> essential matrices (row-major), in root order
+struct E5Polys {
+    double B[3][3][5];  // B[k][0..1]: degree 3, B[k][2]: degree 4 (low -> high)
+    double det[11];
+};
+AMC_HD void e5_build(const double* nsp, E5Polys& P) {
     double e[9][4];
 #pragma unroll
     for (int k = 0; k < 9; ++k)
@@ -654,7 +663,7 @@ AMC_HD int e5_from_nullspace(const double* nsp, double* models /* 10 x 9 */) {
             for (int c = 0; c < 20; ++c) G[r][c] = G[r][c] - f * G[col][c];
         }
     }
-    double B[3][3][5];  // B[k][0..1]: degree 3, B[k][2]: degree 4 (low -> high)
+    double (&B)[3][3][5] = P.B;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         const double (&hi)[20] = G[4 + 2 * k];
@@ -675,7 +684,7 @@ AMC_HD int e5_from_nullspace(const double* nsp, double* models /* 10 x 9 */) {
     }
     // det B(z) with the oracle's accumulation order: pz_mul (i outer, j inner), sub, add.  B[k][0]
     // and B[k][1] are cubics stored in 5 slots: the products below use their 4 coefficients.
-    double det[11];
+    double (&det)[11] = P.det;
     {
         double b00[4], b01[4], b10[4], b11[4], b20[4], b21[4];
 #pragma unroll
@@ -700,8 +709,9 @@ AMC_HD int e5_from_nullspace(const double* nsp, double* models /* 10 x 9 */) {
 #pragma unroll
         for (int i = 0; i <= 10; ++i) det[i] = (q0[i] - q1[i]) + q2[i];
     }
-    double roots[10];
-    const int nr = real_roots_t<10>(det, roots);
+}
+AMC_HD void e5_models(const double* nsp, const E5Polys& P, const double* roots, int nr, double* models) {
+    const double (&B)[3][3][5] = P.B;
     for (int i = 0; i < nr; ++i) {
         const double z = roots[i];
         const double a0 = poly_eval(B[0][0], 3, z), b0 = poly_eval(B[0][1], 3, z), c0 = poly_eval(B[0][2], 4, z);
@@ -712,6 +722,14 @@ AMC_HD int e5_from_nullspace(const double* nsp, double* models /* 10 x 9 */) {
         double* E = models + 9 * i;
         for (int k = 0; k < 9; ++k) E[k] = x * nsp[k] + y * nsp[9 + k] + z * nsp[18 + k] + nsp[27 + k];
     }
+}
+// nsp -> #models (<= 10), row-major
+AMC_HD int e5_from_nullspace(const double* nsp, double* models /* 10 x 9 */) {
+    E5Polys P;
+    e5_build(nsp, P);
+    double roots[10];
+    const int nr = real_roots_t<10>(P.det, roots);
+    e5_models(nsp, P, roots, nr, models);
     return nr;
 }
 
