@@ -58,6 +58,9 @@ uint32_t MatchController::SlotOf(image_t id) const {
 // FeatureMatcherCache::Setup + the GPU matcher's descriptor upload.  The LRU cache over SQLite is
 // replaced by a device-resident arena holding every image.
 void MatchController::Setup() {
+    if (sift_.guided_matching)
+        throw std::invalid_argument("SiftMatchingOptions.guided_matching is not implemented on the accelerated path "
+                                    "yet (SURVEY.md section 8f, rank 2); set guided_matching=False");
     db_ = std::make_unique<Database>(path_);
     images_ = db_->ReadAllImages();
     const std::vector<CameraRow> cams = db_->ReadAllCameras();

@@ -360,6 +360,9 @@ PYBIND11_MODULE(_pycolmap, m) {
         "match_sequential",
         [run_pipeline](const py::object& database_path, const SiftMatchingOptions& sift,
                        const SequentialMatchingOptions& mo, const TwoViewGeometryOptions& tvg, Device device) {
+            if (mo.loop_detection)  // pre-flight, before any device work (RunSequential checks again)
+                throw py::value_error("loop_detection needs a vocabulary tree (FLANN) and is not implemented "
+                                      "(SURVEY.md section 8f, rank 1)");
             run_pipeline(database_path, sift, tvg, device, [&](MatchController& c) { RunSequential(c, mo); });
         },
         "database_path"_a, "sift_options"_a = SiftMatchingOptions(),
