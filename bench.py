@@ -168,6 +168,8 @@ def main():
                     help="pairs in the verification leg (0 = skip); reported under \"verify\"")
     ap.add_argument("--no-cross-check", action="store_true",
                     help="diagnostic: one-way matching only (NOT the BASELINE workload)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="diagnostic: run the multi-GPU exchange path (process group + all-gather) even with 1 rank")
     args = ap.parse_args()
 
     import torch
@@ -183,9 +185,12 @@ def main():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the measured path")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=device)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", device_id=device, rank=rank, world_size=world)
 
     # ---- workload ------------------------------------------------------------------------
     num_images = args.images if world == 1 else int(round(args.images * math.sqrt(world)))
@@ -206,7 +211,7 @@ def main():
     def step():
         off, m, st = ctx.match_pairs(s1, s2, kernel=args.kernel, cross_check=not args.no_cross_check)
         gathered = None
-        if world > 1:
+        if use_dist:
             # the exchange step: RCCL all-gather of the match tables (sizes, then padded tables);
             # afterwards every rank holds the whole match graph (rank 0 would feed the SQLite writer)
             gathered = D.all_gather_match_tables(mine, off, m, device=device, as_numpy=False)
@@ -214,7 +219,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -230,7 +235,7 @@ def main():
         ndist_local = last[2]["num_distances"]
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -308,10 +313,21 @@ def main():
             out["verify"] = verify_leg(lambda: _capi.Context(local_rank), local_rank, args.verify_pairs,
                                        max(1, args.steps), min(1, args.warmup),
                                        0 if args.no_cpu_baseline else 16)
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        final_line = json.dumps(out)
+    else:
+        final_line = None
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    if final_line is not None:
+        # RCCL writes a version banner to the C stdout buffer, which would otherwise be flushed at
+        # exit AFTER this line: drain it first so that the JSON line is the last thing on stdout
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        print(final_line, flush=True)
 
 
 if __name__ == "__main__":
