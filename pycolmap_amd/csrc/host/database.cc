@@ -11,13 +11,19 @@ namespace {
 [[noreturn]] void Fail(sqlite3* db, const std::string& what) {
     throw std::runtime_error("SQLite error (" + what + "): " + (db ? sqlite3_errmsg(db) : "no db"));
 }
+// A prepared statement borrowed from the connection's cache for one use: the per-pair statements
+// (existence checks, match / two-view-geometry inserts) run hundreds of thousands of times per job,
+// so they are compiled once and reset + re-bound afterwards.
 struct Stmt {
     sqlite3_stmt* s = nullptr;
     sqlite3* db;
-    Stmt(sqlite3* d, const char* sql) : db(d) {
-        if (sqlite3_prepare_v2(d, sql, -1, &s, nullptr) != SQLITE_OK) Fail(d, sql);
+    Stmt(sqlite3* d, sqlite3_stmt* cached) : s(cached), db(d) {}
+    ~Stmt() {
+        sqlite3_reset(s);
+        sqlite3_clear_bindings(s);
     }
-    ~Stmt() { sqlite3_finalize(s); }
+    Stmt(const Stmt&) = delete;
+    Stmt& operator=(const Stmt&) = delete;
     bool Step() {
         const int rc = sqlite3_step(s);
         if (rc == SQLITE_ROW) return true;
@@ -61,7 +67,16 @@ Database::Database(const std::string& path) {
     Exec("PRAGMA foreign_keys=ON");
 }
 Database::~Database() {
+    for (auto& kv : stmts_) sqlite3_finalize(kv.second);
     if (db_) sqlite3_close(db_);
+}
+sqlite3_stmt* Database::Prepared(const std::string& sql) const {
+    auto it = stmts_.find(sql);
+    if (it != stmts_.end()) return it->second;
+    sqlite3_stmt* st = nullptr;
+    if (sqlite3_prepare_v2(db_, sql.c_str(), -1, &st, nullptr) != SQLITE_OK) Fail(db_, sql);
+    stmts_.emplace(sql, st);
+    return st;
 }
 void Database::Exec(const char* sql) const {
     char* err = nullptr;
@@ -85,19 +100,19 @@ void Database::PairIdToImagePair(image_pair_t pair_id, image_t* id1, image_t* id
 }
 
 size_t Database::Count(const char* table) const {
-    Stmt st(db_, (std::string("SELECT COUNT(*) FROM ") + table).c_str());
+    Stmt st(db_, Prepared((std::string("SELECT COUNT(*) FROM ") + table)));
     st.Step();
     return static_cast<size_t>(sqlite3_column_int64(st.s, 0));
 }
 size_t Database::SumRows(const char* table) const {
-    Stmt st(db_, (std::string("SELECT SUM(rows) FROM ") + table).c_str());
+    Stmt st(db_, Prepared((std::string("SELECT SUM(rows) FROM ") + table)));
     st.Step();
     return static_cast<size_t>(sqlite3_column_int64(st.s, 0));
 }
 
 std::vector<CameraRow> Database::ReadAllCameras() const {
     std::vector<CameraRow> out;
-    Stmt st(db_, "SELECT camera_id, model, width, height, params, prior_focal_length FROM cameras ORDER BY camera_id");
+    Stmt st(db_, Prepared("SELECT camera_id, model, width, height, params, prior_focal_length FROM cameras ORDER BY camera_id"));
     while (st.Step()) {
         CameraRow c;
         c.camera_id = static_cast<camera_t>(sqlite3_column_int64(st.s, 0));
@@ -114,7 +129,7 @@ std::vector<CameraRow> Database::ReadAllCameras() const {
 }
 std::vector<ImageRow> Database::ReadAllImages() const {
     std::vector<ImageRow> out;
-    Stmt st(db_, "SELECT image_id, name, camera_id FROM images ORDER BY image_id");
+    Stmt st(db_, Prepared("SELECT image_id, name, camera_id FROM images ORDER BY image_id"));
     while (st.Step()) {
         ImageRow r;
         r.image_id = static_cast<image_t>(sqlite3_column_int64(st.s, 0));
@@ -126,7 +141,7 @@ std::vector<ImageRow> Database::ReadAllImages() const {
 }
 std::vector<float> Database::ReadKeypointsXY(image_t image_id, uint32_t* rows) const {
     *rows = 0;
-    Stmt st(db_, "SELECT rows, cols, data FROM keypoints WHERE image_id = ?");
+    Stmt st(db_, Prepared("SELECT rows, cols, data FROM keypoints WHERE image_id = ?"));
     sqlite3_bind_int64(st.s, 1, image_id);
     std::vector<float> out;
     if (!st.Step()) return out;
@@ -147,7 +162,7 @@ std::vector<float> Database::ReadKeypointsXY(image_t image_id, uint32_t* rows) c
 }
 std::vector<uint8_t> Database::ReadDescriptors(image_t image_id, uint32_t* rows) const {
     *rows = 0;
-    Stmt st(db_, "SELECT rows, cols, data FROM descriptors WHERE image_id = ?");
+    Stmt st(db_, Prepared("SELECT rows, cols, data FROM descriptors WHERE image_id = ?"));
     sqlite3_bind_int64(st.s, 1, image_id);
     std::vector<uint8_t> out;
     if (!st.Step()) return out;
@@ -164,7 +179,7 @@ std::vector<uint8_t> Database::ReadDescriptors(image_t image_id, uint32_t* rows)
 }
 
 bool Database::ExistsPair(const char* table, image_pair_t pair_id) const {
-    Stmt st(db_, (std::string("SELECT 1 FROM ") + table + " WHERE pair_id = ?").c_str());
+    Stmt st(db_, Prepared((std::string("SELECT 1 FROM ") + table + " WHERE pair_id = ?")));
     sqlite3_bind_int64(st.s, 1, static_cast<sqlite3_int64>(pair_id));
     return st.Step();
 }
@@ -186,14 +201,14 @@ static std::vector<uint32_t> BlobToMatches(sqlite3_stmt* s, int col_rows, int co
     return m;
 }
 std::vector<uint32_t> Database::ReadMatches(image_t id1, image_t id2) const {
-    Stmt st(db_, "SELECT rows, cols, data FROM matches WHERE pair_id = ?");
+    Stmt st(db_, Prepared("SELECT rows, cols, data FROM matches WHERE pair_id = ?"));
     sqlite3_bind_int64(st.s, 1, static_cast<sqlite3_int64>(ImagePairToPairId(id1, id2)));
     if (!st.Step()) return {};
     return BlobToMatches(st.s, 0, 2, SwapImagePair(id1, id2));
 }
 TwoViewGeometryRow Database::ReadTwoViewGeometry(image_t id1, image_t id2) const {
     TwoViewGeometryRow t;
-    Stmt st(db_, "SELECT rows, cols, data, config, F, E, H, qvec, tvec FROM two_view_geometries WHERE pair_id = ?");
+    Stmt st(db_, Prepared("SELECT rows, cols, data, config, F, E, H, qvec, tvec FROM two_view_geometries WHERE pair_id = ?"));
     sqlite3_bind_int64(st.s, 1, static_cast<sqlite3_int64>(ImagePairToPairId(id1, id2)));
     if (!st.Step()) return t;
     t.inlier_matches = BlobToMatches(st.s, 0, 2, false);
@@ -212,33 +227,44 @@ TwoViewGeometryRow Database::ReadTwoViewGeometry(image_t id1, image_t id2) const
 }
 
 void Database::WriteMatches(image_t id1, image_t id2, const std::vector<uint32_t>& matches) {
-    std::vector<uint32_t> m = matches;
-    if (SwapImagePair(id1, id2))
-        for (size_t i = 0; i + 1 < m.size(); i += 2) std::swap(m[i], m[i + 1]);
-    Stmt st(db_, "INSERT INTO matches(pair_id, rows, cols, data) VALUES(?, ?, ?, ?)");
+    // the blob is bound in place (SQLITE_STATIC: it outlives the step); a swapped copy is made only
+    // for pairs given in descending id order
+    std::vector<uint32_t> swapped;
+    const std::vector<uint32_t>* m = &matches;
+    if (SwapImagePair(id1, id2)) {
+        swapped = matches;
+        for (size_t i = 0; i + 1 < swapped.size(); i += 2) std::swap(swapped[i], swapped[i + 1]);
+        m = &swapped;
+    }
+    Stmt st(db_, Prepared("INSERT INTO matches(pair_id, rows, cols, data) VALUES(?, ?, ?, ?)"));
     sqlite3_bind_int64(st.s, 1, static_cast<sqlite3_int64>(ImagePairToPairId(id1, id2)));
-    sqlite3_bind_int64(st.s, 2, static_cast<sqlite3_int64>(m.size() / 2));
+    sqlite3_bind_int64(st.s, 2, static_cast<sqlite3_int64>(m->size() / 2));
     sqlite3_bind_int64(st.s, 3, 2);
-    sqlite3_bind_blob(st.s, 4, m.empty() ? "" : reinterpret_cast<const char*>(m.data()),
-                      static_cast<int>(m.size() * sizeof(uint32_t)), SQLITE_TRANSIENT);
+    sqlite3_bind_blob(st.s, 4, m->empty() ? "" : reinterpret_cast<const char*>(m->data()),
+                      static_cast<int>(m->size() * sizeof(uint32_t)), SQLITE_STATIC);
     st.Step();
 }
 void Database::WriteTwoViewGeometry(image_t id1, image_t id2, const TwoViewGeometryRow& in) {
-    TwoViewGeometryRow t = in;
-    if (SwapImagePair(id1, id2)) t.Invert();
-    Stmt st(db_, "INSERT INTO two_view_geometries(pair_id, rows, cols, data, config, F, E, H, qvec, tvec) "
-                 "VALUES(?, ?, ?, ?, ?, ?, ?, ?, ?, ?)");
+    TwoViewGeometryRow inverted;
+    const bool swap = SwapImagePair(id1, id2);
+    if (swap) {
+        inverted = in;
+        inverted.Invert();
+    }
+    const TwoViewGeometryRow& t = swap ? inverted : in;
+    Stmt st(db_, Prepared("INSERT INTO two_view_geometries(pair_id, rows, cols, data, config, F, E, H, qvec, tvec) "
+                 "VALUES(?, ?, ?, ?, ?, ?, ?, ?, ?, ?)"));
     sqlite3_bind_int64(st.s, 1, static_cast<sqlite3_int64>(ImagePairToPairId(id1, id2)));
     sqlite3_bind_int64(st.s, 2, static_cast<sqlite3_int64>(t.inlier_matches.size() / 2));
     sqlite3_bind_int64(st.s, 3, 2);
     sqlite3_bind_blob(st.s, 4, t.inlier_matches.empty() ? "" : reinterpret_cast<const char*>(t.inlier_matches.data()),
-                      static_cast<int>(t.inlier_matches.size() * sizeof(uint32_t)), SQLITE_TRANSIENT);
+                      static_cast<int>(t.inlier_matches.size() * sizeof(uint32_t)), SQLITE_STATIC);
     sqlite3_bind_int64(st.s, 5, t.config);
     // COLMAP stores the matrices only when there are inlier matches, empty blobs otherwise
     const bool has = !t.inlier_matches.empty();
     auto wr = [&](int col, const double* src, int n) {
         sqlite3_bind_blob(st.s, col, has ? reinterpret_cast<const char*>(src) : "", has ? static_cast<int>(n * sizeof(double)) : 0,
-                          SQLITE_TRANSIENT);
+                          SQLITE_STATIC);
     };
     wr(6, t.F.data(), 9);
     wr(7, t.E.data(), 9);
@@ -248,12 +274,12 @@ void Database::WriteTwoViewGeometry(image_t id1, image_t id2, const TwoViewGeome
     st.Step();
 }
 void Database::DeleteMatches(image_t id1, image_t id2) {
-    Stmt st(db_, "DELETE FROM matches WHERE pair_id = ?");
+    Stmt st(db_, Prepared("DELETE FROM matches WHERE pair_id = ?"));
     sqlite3_bind_int64(st.s, 1, static_cast<sqlite3_int64>(ImagePairToPairId(id1, id2)));
     st.Step();
 }
 void Database::DeleteInlierMatches(image_t id1, image_t id2) {
-    Stmt st(db_, "DELETE FROM two_view_geometries WHERE pair_id = ?");
+    Stmt st(db_, Prepared("DELETE FROM two_view_geometries WHERE pair_id = ?"));
     sqlite3_bind_int64(st.s, 1, static_cast<sqlite3_int64>(ImagePairToPairId(id1, id2)));
     st.Step();
 }

@@ -8,6 +8,7 @@
 #include <cstdint>
 #include <stdexcept>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 struct sqlite3;
@@ -87,7 +88,9 @@ class Database {
     size_t SumRows(const char* table) const;
     bool ExistsPair(const char* table, image_pair_t pair_id) const;
     void Exec(const char* sql) const;
+    sqlite3_stmt* Prepared(const std::string& sql) const;  // prepared once per connection, then reused
     sqlite3* db_ = nullptr;
+    mutable std::unordered_map<std::string, sqlite3_stmt*> stmts_;
 };
 
 class DatabaseTransaction {
