@@ -162,7 +162,8 @@ def main():
     ap.add_argument("--images", type=int, default=500, help="images at N=1 (BASELINE configs[1])")
     ap.add_argument("--feats", type=int, default=4096)
     ap.add_argument("--kernel", default="auto", choices=["auto", "mfma", "dot4"])
-    ap.add_argument("--cpu-sample-pairs", type=int, default=32)
+    ap.add_argument("--cpu-sample-pairs", type=int, default=0,
+                    help="pairs timed on the host by the oracle (0 = one per host core, so every core is busy)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verify-pairs", type=int, default=4096,
                     help="pairs in the verification leg (0 = skip); reported under \"verify\"")
@@ -295,7 +296,9 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             cores = os.cpu_count() or 1
             arena_cpu = arena.cpu().numpy()
-            v, npairs, dt, (idx, coff, cm) = cpu_baseline(arena_cpu, s1, s2, args.cpu_sample_pairs, cores)
+            sample = args.cpu_sample_pairs if args.cpu_sample_pairs > 0 else cores
+            v, npairs, dt, (idx, coff, cm) = cpu_baseline(arena_cpu, s1, s2, sample, cores)
+            cores = min(cores, npairs)  # the oracle runs one pair per thread
             # the sample doubles as a full-size parity spot check of the timed GPU result
             mism = 0
             for k, p in enumerate(idx):
