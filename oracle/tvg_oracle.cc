@@ -1231,6 +1231,26 @@ int oracle_estimate_two_view_geometry(const oracle_camera* cam1, const double* p
     return 0;
 }
 
+// The same for a batch of pairs, one pair per OpenMP thread at a time (used to time the oracle on
+// all host cores).  Pair p: cameras cams1[p] / cams2[p], keypoints pts1[p] (n1[p] x 2) / pts2[p],
+// matches[p] (M[p] x 2), mask written at inlier_masks + mask_off[p].  Returns the number of pairs
+// with unsupported input.
+int oracle_estimate_two_view_geometry_batch(size_t npairs, const oracle_camera* cams1, const double* const* pts1,
+                                            const size_t* n1, const oracle_camera* cams2,
+                                            const double* const* pts2, const size_t* n2,
+                                            const uint32_t* const* matches, const size_t* M,
+                                            const size_t* mask_off, const oracle_tvg_options* opts,
+                                            uint32_t seed, oracle_tvg_result* out, char* inlier_masks,
+                                            int num_threads) {
+    int bad = 0;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(num_threads > 0 ? num_threads : 1) reduction(+ : bad)
+    for (long p = 0; p < static_cast<long>(npairs); ++p)
+        if (oracle_estimate_two_view_geometry(&cams1[p], pts1[p], n1[p], &cams2[p], pts2[p], n2[p], matches[p],
+                                              M[p], opts, seed, &out[p], inlier_masks + mask_off[p]) != 0)
+            ++bad;
+    return bad;
+}
+
 // Single-model LO-RANSAC with a fresh PRNG(seed): the semantics of pycolmap's
 // fundamental_matrix_estimation / homography_matrix_estimation / essential_matrix_estimation
 // (/root/reference/pycolmap/estimators/fundamental_matrix.h:17-39).  kind: 0 = F (7pt/8pt),

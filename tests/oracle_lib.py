@@ -167,6 +167,43 @@ def estimate_two_view_geometry(cam1, pts1, cam2, pts2, matches, opts=None, seed=
                 trials=list(res.trials), inl=list(res.inl), inlier_mask=mask[:len(m)].astype(bool))
 
 
+def estimate_two_view_geometry_batch(cams1, pts1, cams2, pts2, matches, opts=None, seed=0, threads=1):
+    """Batched oracle_estimate_two_view_geometry on `threads` OpenMP threads (one pair per thread at a
+    time).  Lists of per-pair inputs; returns a list of result dicts like estimate_two_view_geometry."""
+    lib = load()
+    opts = opts or tvg_default_options()
+    n = len(pts1)
+    p1 = [_d(x).reshape(-1, 2) for x in pts1]
+    p2 = [_d(x).reshape(-1, 2) for x in pts2]
+    mm = [np.ascontiguousarray(m, dtype=np.uint32).reshape(-1, 2) for m in matches]
+    C1 = (OCamera * n)(*cams1)
+    C2 = (OCamera * n)(*cams2)
+    P1 = (C.c_void_p * n)(*[a.ctypes.data for a in p1])
+    P2 = (C.c_void_p * n)(*[a.ctypes.data for a in p2])
+    MM = (C.c_void_p * n)(*[a.ctypes.data for a in mm])
+    N1 = (C.c_size_t * n)(*[len(a) for a in p1])
+    N2 = (C.c_size_t * n)(*[len(a) for a in p2])
+    M = (C.c_size_t * n)(*[len(a) for a in mm])
+    moff = np.zeros(n + 1, dtype=np.uint64)
+    moff[1:] = np.cumsum([max(1, len(a)) for a in mm])
+    MO = (C.c_size_t * n)(*[int(x) for x in moff[:-1]])
+    res = (TvgResult * n)()
+    masks = np.zeros(int(moff[-1]), dtype=np.uint8)
+    lib.oracle_estimate_two_view_geometry_batch.restype = C.c_int
+    bad = lib.oracle_estimate_two_view_geometry_batch(
+        C.c_size_t(n), C1, P1, N1, C2, P2, N2, MM, M, MO, C.byref(opts), C.c_uint32(seed), res, _p(masks),
+        C.c_int(threads))
+    assert bad == 0, "oracle: unsupported input"
+    out = []
+    for p in range(n):
+        r = res[p]
+        out.append(dict(config=int(r.config), config_name=CONFIG_NAMES[r.config], num_inliers=int(r.num_inliers),
+                        E=np.array(r.E).reshape(3, 3), F=np.array(r.F).reshape(3, 3), H=np.array(r.H).reshape(3, 3),
+                        trials=list(r.trials), inl=list(r.inl),
+                        inlier_mask=masks[int(moff[p]):int(moff[p]) + len(mm[p])].astype(bool)))
+    return out
+
+
 def ransac_estimate(kind, p1, p2, opts=None, seed=0):
     """kind: 'F' | 'H' | 'E'. Mirrors pycolmap's *_matrix_estimation (seed 0 per call)."""
     lib = load()
