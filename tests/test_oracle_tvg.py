@@ -288,3 +288,21 @@ def test_watermark_detection():
     assert r["config_name"] == "WATERMARK" and 1 <= r["trials"][3] <= 18
     r = o.estimate_two_view_geometry(cam, p1, cam, p2, matches, o.tvg_default_options(detect_watermark=0))
     assert r["config_name"] != "WATERMARK" and r["trials"][3] == 0
+
+
+def test_batch_entry_point_equals_single_calls():
+    """oracle_estimate_two_view_geometry_batch (OpenMP, used by bench.py's CPU baseline) returns exactly
+    what the per-pair entry point returns, whatever the thread count."""
+    rng = np.random.default_rng(42)
+    scenes = [synth.two_view_scene(rng, num_inliers=int(rng.integers(20, 200)), num_outliers=int(rng.integers(0, 80)),
+                                   planar=bool(i % 3 == 0)) for i in range(9)]
+    cams = [o.make_camera("PINHOLE", 1600, 1200, (1200.0, 1200.0, 800.0, 600.0), prior=bool(i % 2)) for i in range(9)]
+    for threads in (1, 4):
+        got = o.estimate_two_view_geometry_batch(cams, [s["pts1"] for s in scenes], cams, [s["pts2"] for s in scenes],
+                                                 [s["matches"] for s in scenes], threads=threads)
+        for cam, sc, g in zip(cams, scenes, got):
+            w = o.estimate_two_view_geometry(cam, sc["pts1"], cam, sc["pts2"], sc["matches"])
+            assert g["config"] == w["config"] and g["trials"] == w["trials"] and g["inl"] == w["inl"]
+            np.testing.assert_array_equal(g["inlier_mask"], w["inlier_mask"])
+            for k in "EFH":
+                np.testing.assert_array_equal(g[k], w[k])
