@@ -98,6 +98,22 @@ def test_mixed_batch_sizes_and_edge_cases(amc_ctx):
     assert _capi.CONFIG_NAMES[tvg["config"][1]] == "DEGENERATE"      # 14 matches < min_num_inliers
 
 
+def test_tiny_match_counts(amc_ctx):
+    """0 .. 9 correspondences with min_num_inliers = 0: every RANSAC sees fewer points than, exactly
+    as many as, or barely more than its minimal sample."""
+    rng = np.random.default_rng(31)
+    base = synth.two_view_scene(rng, num_inliers=40, num_outliers=0)
+    scenes = []
+    for m in (0, 1, 3, 4, 5, 6, 7, 8, 9):
+        sc = dict(base)
+        sc["matches"] = base["matches"][:m].copy()
+        scenes.append(sc)
+    for prior in (False, True):
+        tvg, mask, off, want = run_both(amc_ctx, scenes, [prior] * len(scenes), dict(min_num_inliers=0))
+        for p in range(len(scenes)):
+            assert_pair_equal(p, tvg, mask, off, want)
+
+
 def test_large_match_counts(amc_ctx):
     """Pairs whose correspondences do not fit a wave's LDS share (points stay in HBM), and pairs
     whose index arrays need a whole workgroup's LDS (one wave per workgroup), mixed with small ones."""
