@@ -227,6 +227,21 @@ int amc_verify_pairs(amc_ctx* ctx, const uint32_t* slot1, const uint32_t* slot2,
                      const amc_tvg_opts* opts, uint32_t seed, amc_verify_result* out);
 void amc_verify_result_free(amc_verify_result* r);
 
+/* ---- guided matching (SiftMatchingOptions.guided_matching, /root/reference/pycolmap/pipeline/
+ * match_features.h:95-98) ------------------------------------------------------------------------
+ * COLMAP 3.9.1 FeatureMatcher::MatchGuided(max_error, keypoints1, keypoints2, descriptors1,
+ * descriptors2, TwoViewGeometry*): after a successful verification the pair is matched again with
+ * a float32 geometric filter on the distance matrix - squared Sampson error under F for
+ * CALIBRATED / UNCALIBRATED, forward transfer error under H for PLANAR / PANORAMIC /
+ * PLANAR_OR_PANORAMIC, rejected pairings score 0 - and the result replaces the geometry's
+ * inlier_matches.  geoms[p] supplies config, F and H of pair p (any other configuration is
+ * AMC_E_INVALID: COLMAP leaves those pairs alone); max_error is
+ * TwoViewGeometryOptions.ransac_options.max_error.  Both images need their float32 keypoints
+ * (amc_upload_keypoints), one per descriptor.  Same result layout as amc_match_pairs. */
+int amc_match_guided_pairs(amc_ctx* ctx, const uint32_t* slot1, const uint32_t* slot2, size_t npairs,
+                           const amc_tvg* geoms, double max_error, const amc_match_opts* opts,
+                           amc_match_result* out);
+
 /* ---- single LO-RANSAC per pair: the pycolmap estimator bindings ---------------------------------
  * AMC_RANSAC_F  LORANSAC<FundamentalMatrixSevenPointEstimator, FundamentalMatrixEightPointEstimator>
  *               (/root/reference/pycolmap/estimators/fundamental_matrix.h:17-39)

@@ -103,6 +103,89 @@ int oracle_match(const uint8_t* d1, int n1, const uint8_t* d2, int n2, double ma
     return num;
 }
 
+/* ---- guided matching (SiftMatchingOptions.guided_matching) ------------------------------------
+ * COLMAP 3.9.1 colmap/feature/sift.cc, SiftCPUFeatureMatcher::MatchGuided: after a successful
+ * verification the pair is matched again with a geometric filter on the distance matrix
+ * (ComputeSiftDistanceMatrix(kp1, kp2, d1, d2, guided_filter): an entry the filter rejects gets
+ * distance 0, everything else the plain dot product), then FindBestMatchesBruteForce as usual; the
+ * result replaces the two-view geometry's inlier_matches.  The filter works in float32 on the
+ * float32 keypoint coordinates with the model cast to float (F.cast<float>() / H.cast<float>()):
+ *   CALIBRATED, UNCALIBRATED:             squared Sampson error of (p1, p2) under F  >  max_error^2
+ *   PLANAR, PANORAMIC, PLANAR_OR_PANORAMIC: |hnormalized(H p1) - p2|^2              >  max_error^2
+ *   any other configuration: no guided matching (the caller keeps the inlier matches it has).
+ * Parity unpinned like the rest of this file; additionally (deviation D5) Eigen's
+ * evaluation order inside the 3x3 float products is not recoverable here: every 3-term sum below
+ * is evaluated left to right with separate multiplies and adds (no FMA contraction). */
+enum { ORACLE_GUIDED_NONE = 0, ORACLE_GUIDED_F = 1, ORACLE_GUIDED_H = 2 };
+
+int oracle_guided_kind(int tvg_config) {
+    /* TwoViewGeometry::ConfigurationType: 2 CALIBRATED, 3 UNCALIBRATED, 4 PLANAR, 5 PANORAMIC,
+     * 6 PLANAR_OR_PANORAMIC (/root/reference/pycolmap/estimators/two_view_geometry.h:67-77) */
+    if (tvg_config == 2 || tvg_config == 3) return ORACLE_GUIDED_F;
+    if (tvg_config == 4 || tvg_config == 5 || tvg_config == 6) return ORACLE_GUIDED_H;
+    return ORACLE_GUIDED_NONE;
+}
+
+/* true = the filter rejects the pairing (its distance is forced to 0) */
+int oracle_guided_filter(int kind, const float* m /* 9, row-major */, float max_residual, float x1, float y1,
+                         float x2, float y2) {
+    if (kind == ORACLE_GUIDED_F) {
+        const float Fx1_0 = m[0] * x1 + m[1] * y1 + m[2] * 1.0f;
+        const float Fx1_1 = m[3] * x1 + m[4] * y1 + m[5] * 1.0f;
+        const float Fx1_2 = m[6] * x1 + m[7] * y1 + m[8] * 1.0f;
+        const float Ftx2_0 = m[0] * x2 + m[3] * y2 + m[6] * 1.0f;
+        const float Ftx2_1 = m[1] * x2 + m[4] * y2 + m[7] * 1.0f;
+        const float x2tFx1 = x2 * Fx1_0 + y2 * Fx1_1 + 1.0f * Fx1_2;
+        return x2tFx1 * x2tFx1 / (Fx1_0 * Fx1_0 + Fx1_1 * Fx1_1 + Ftx2_0 * Ftx2_0 + Ftx2_1 * Ftx2_1) > max_residual;
+    }
+    const float Hp_0 = m[0] * x1 + m[1] * y1 + m[2] * 1.0f;
+    const float Hp_1 = m[3] * x1 + m[4] * y1 + m[5] * 1.0f;
+    const float Hp_2 = m[6] * x1 + m[7] * y1 + m[8] * 1.0f;
+    const float e0 = Hp_0 / Hp_2 - x2;
+    const float e1 = Hp_1 / Hp_2 - y2;
+    return e0 * e0 + e1 * e1 > max_residual;
+}
+
+/* MatchGuided for one pair.  kp: n x 2 float32 (x, y); model: the two-view geometry's F (kind F) or
+ * H (kind H) as 9 doubles, row-major; max_error: TwoViewGeometryOptions.ransac_options.max_error.
+ * Returns #matches like oracle_match, -1 on allocation failure, -2 if the configuration has no
+ * guided matching. */
+int oracle_match_guided(const uint8_t* d1, const float* kp1, int n1, const uint8_t* d2, const float* kp2, int n2,
+                        int tvg_config, const double* F9, const double* H9, double max_error, double max_ratio,
+                        double max_distance, int cross_check, uint32_t* out_matches) {
+    const int kind = oracle_guided_kind(tvg_config);
+    if (kind == ORACLE_GUIDED_NONE) return -2;
+    if (n1 <= 0 || n2 <= 0) return 0;
+    float m[9];
+    for (int i = 0; i < 9; ++i) m[i] = (float)(kind == ORACLE_GUIDED_F ? F9[i] : H9[i]);
+    const float max_residual = (float)(max_error * max_error);
+    int32_t* dists = (int32_t*)malloc((size_t)n1 * n2 * sizeof(int32_t));
+    int32_t* m12 = (int32_t*)malloc((size_t)n1 * sizeof(int32_t));
+    int32_t* m21 = (int32_t*)malloc((size_t)n2 * sizeof(int32_t));
+    if (!dists || !m12 || !m21) {
+        free(dists); free(m12); free(m21);
+        return -1;
+    }
+    oracle_sift_distance_matrix(d1, n1, d2, n2, dists);
+    for (int i1 = 0; i1 < n1; ++i1)
+        for (int i2 = 0; i2 < n2; ++i2)
+            if (oracle_guided_filter(kind, m, max_residual, kp1[2 * i1], kp1[2 * i1 + 1], kp2[2 * i2], kp2[2 * i2 + 1]))
+                dists[(size_t)i1 * n2 + i2] = 0;
+    const float r = (float)max_ratio, t = (float)max_distance;
+    one_way(dists, n1, n2, (size_t)n2, 1, r, t, m12);
+    if (cross_check) one_way(dists, n2, n1, 1, (size_t)n2, r, t, m21);
+    int num = 0;
+    for (int i1 = 0; i1 < n1; ++i1) {
+        if (m12[i1] == -1) continue;
+        if (cross_check && m21[m12[i1]] != i1) continue;
+        out_matches[2 * num] = (uint32_t)i1;
+        out_matches[2 * num + 1] = (uint32_t)m12[i1];
+        ++num;
+    }
+    free(dists); free(m12); free(m21);
+    return num;
+}
+
 /* Batched driver used by tests and by bench.py's cpu_baseline leg: descriptors of image s
  * start at arena + row_offset[s]*128 and have rows[s] rows.  One pair per OpenMP thread
  * ("one image pair per thread").  Results: counts[p] and matches at

@@ -27,7 +27,7 @@ EXPORTED_SYMBOLS = [
     "amc_match_opts_default", "amc_get_acos_lut",
     "amc_tvg_opts_default", "amc_upload_keypoints", "amc_upload_camera", "amc_verify_pairs",
     "amc_verify_result_free", "amc_upload_points_f64", "amc_ransac_pairs", "amc_ransac_result_free",
-    "amc_squared_sampson_error",
+    "amc_squared_sampson_error", "amc_match_guided_pairs",
 ]
 RANSAC_F, RANSAC_H, RANSAC_E = 0, 1, 2
 RANSAC_KINDS = {"F": RANSAC_F, "H": RANSAC_H, "E": RANSAC_E}
@@ -140,6 +140,8 @@ def load() -> C.CDLL:
                                      C.c_void_p, C.POINTER(TvgOpts), C.c_uint32, C.POINTER(VerifyResult)]
     lib.amc_verify_result_free.argtypes = [C.POINTER(VerifyResult)]
     lib.amc_verify_result_free.restype = None
+    lib.amc_match_guided_pairs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_double,
+                                           C.POINTER(MatchOpts), C.POINTER(MatchResult)]
     lib.amc_upload_points_f64.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
     lib.amc_ransac_pairs.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
                                      C.c_void_p, C.POINTER(RansacOpts), C.c_uint32, C.POINTER(RansacResult)]
@@ -247,6 +249,34 @@ class Context:
                          match_kernel_ms=float(res.match_kernel_ms),
                          cross_kernel_ms=float(res.cross_kernel_ms),
                          match_kernel_launches=int(res.match_kernel_launches))
+        finally:
+            self._lib.amc_match_result_free(C.byref(res))
+        return offsets, matches, stats
+
+    def match_guided_pairs(self, slot1, slot2, tvg, max_error: float, max_ratio: float = 0.8,
+                           max_distance: float = 0.7, cross_check: bool = True):
+        """FeatureMatcher::MatchGuided per pair: `tvg` is a TVG_DTYPE array (config, F, H used), e.g.
+        the output of verify_pairs.  Returns (offsets, matches, stats) like match_pairs."""
+        s1 = np.ascontiguousarray(slot1, dtype=np.uint32)
+        s2 = np.ascontiguousarray(slot2, dtype=np.uint32)
+        g = np.ascontiguousarray(tvg, dtype=TVG_DTYPE)
+        if s1.shape != s2.shape or s1.ndim != 1 or g.shape != s1.shape:
+            raise ValueError("slot1/slot2/tvg must be equal-length 1-D arrays")
+        assert C.sizeof(Tvg) == TVG_DTYPE.itemsize
+        opts = MatchOpts(max_ratio, max_distance, 1 if cross_check else 0, KERNEL_AUTO)
+        res = MatchResult()
+        _check(self._lib.amc_match_guided_pairs(self._h, s1.ctypes.data_as(C.c_void_p),
+                                                s2.ctypes.data_as(C.c_void_p), s1.size,
+                                                g.ctypes.data_as(C.c_void_p), float(max_error), C.byref(opts),
+                                                C.byref(res)))
+        try:
+            n = int(res.npairs)
+            offsets = np.ctypeslib.as_array(res.offsets, shape=(n + 1,)).copy()
+            total = int(offsets[-1])
+            matches = (np.ctypeslib.as_array(res.matches, shape=(total, 2)).copy() if total
+                       else np.zeros((0, 2), dtype=np.uint32))
+            stats = dict(num_distances=int(res.num_distances), pairs_dot4=int(res.pairs_dot4),
+                         device_ms=float(res.device_ms))
         finally:
             self._lib.amc_match_result_free(C.byref(res))
         return offsets, matches, stats

@@ -111,6 +111,7 @@ struct amc_ctx {
     DevBuf<uint32_t> d_order, d_order2;
     DevBuf<Top2> d_rowbuf, d_colbuf;
     DevBuf<uint32_t> d_accmask;  // one accept bit per row-table entry (mfma pairs)
+    DevBuf<GuidedDev> d_guided;  // guided matching: one filter model per pair of the batch
     DevBuf<uint32_t> d_pair_off, d_pair_cnt, d_matches, d_cand_cnt, d_candbuf;
     PinBuf<PairDev> h_pairs;
     PinBuf<Dot4Work> h_work;
@@ -207,7 +208,7 @@ void amc_ctx_destroy(amc_ctx* c) {
     if (c->d_lut) (void)hipFree(c->d_lut);
     if (c->d_scalars) (void)hipFree(c->d_scalars);
     c->d_pairs.release(); c->d_work.release(); c->d_order.release(); c->d_order2.release();
-    c->d_rowbuf.release(); c->d_colbuf.release(); c->d_accmask.release();
+    c->d_rowbuf.release(); c->d_colbuf.release(); c->d_accmask.release(); c->d_guided.release();
     c->d_pair_off.release(); c->d_pair_cnt.release(); c->d_matches.release();
     c->d_cand_cnt.release(); c->d_candbuf.release();
     c->h_pairs.release(); c->h_work.release(); c->h_order.release(); c->h_order2.release();
@@ -323,8 +324,11 @@ constexpr size_t kMaxMatchCap = (size_t)256 << 20;     // worst-case matches of 
 
 }  // namespace
 
-int amc_match_pairs(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, size_t npairs,
-                    const amc_match_opts* opts_in, amc_match_result* out) {
+// amc_match_pairs, and with `geoms` != nullptr guided matching (every pair then runs the dot4
+// kernel with the pair's float32 filter; geoms[p] must have a configuration COLMAP guides on)
+static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, size_t npairs,
+                      const amc_match_opts* opts_in, const amc_tvg* geoms, double max_error,
+                      amc_match_result* out) {
     if (!c || !out) return fail(AMC_E_INVALID, "amc_match_pairs: NULL ctx/out");
     std::memset(out, 0, sizeof *out);
     if (npairs > 0 && (!slot1 || !slot2))
@@ -339,6 +343,29 @@ int amc_match_pairs(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, si
         if (!c->slots[slot1[i]].valid || !c->slots[slot2[i]].valid)
             return fail(AMC_E_STATE, "amc_match_pairs: pair %zu references a slot with no "
                         "descriptors uploaded", i);
+    }
+    std::vector<GuidedDev> h_guided;
+    if (geoms) {
+        h_guided.resize(npairs);
+        for (size_t i = 0; i < npairs; ++i) {
+            const int cfg = geoms[i].config;
+            GuidedDev& g = h_guided[i];
+            g.kind = (cfg == AMC_TVG_CALIBRATED || cfg == AMC_TVG_UNCALIBRATED) ? kGuidedF
+                     : (cfg == AMC_TVG_PLANAR || cfg == AMC_TVG_PANORAMIC || cfg == AMC_TVG_PLANAR_OR_PANORAMIC)
+                         ? kGuidedH : kGuidedNone;
+            if (g.kind == kGuidedNone)
+                return fail(AMC_E_INVALID, "amc_match_guided_pairs: pair %zu: configuration %d has no guided "
+                            "matching (COLMAP keeps the inlier matches it has)", i, cfg);
+            const double* m = g.kind == kGuidedF ? geoms[i].F : geoms[i].H;
+            for (int k = 0; k < 9; ++k) g.m[k] = (float)m[k];
+            g.max_residual = (float)(max_error * max_error);
+            g.pad_ = 0.f;
+            const Slot& a = c->slots[slot1[i]];
+            const Slot& b = c->slots[slot2[i]];
+            if (!a.kp || !b.kp || a.kp_rows < a.dev.rows || b.kp_rows < b.dev.rows)
+                return fail(AMC_E_STATE, "amc_match_guided_pairs: pair %zu: float32 keypoints (one per descriptor) "
+                            "must be uploaded for both images", i);
+        }
     }
     HIPCHK(hipSetDevice(c->device));
     hipStream_t st = c->stream;
@@ -406,7 +433,7 @@ int amc_match_pairs(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, si
             const Slot& a = c->slots[slot1[begin + i]];
             const Slot& b = c->slots[slot2[begin + i]];
             const bool nonempty = a.dev.rows > 0 && b.dev.rows > 0;
-            want_mfma[i] = nonempty && o.kernel != AMC_KERNEL_DOT4 &&
+            want_mfma[i] = nonempty && o.kernel != AMC_KERNEL_DOT4 && !geoms &&
                            (!o.cross_check || b.dev.rows_pad <= mfma_max_cols);
         }
         size_t row_off = 0, col_off = 0, nwork = 0, nord = 0;
@@ -478,6 +505,10 @@ int amc_match_pairs(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, si
         if (okq && nwork)
             okq = hc(hipMemcpyAsync(c->d_work.p, c->h_work.p, nwork * sizeof(Dot4Work),
                                     hipMemcpyHostToDevice, st), "H2D work");
+        if (okq && geoms)  // this batch's slice of the filter models (pageable source: the copy is staged)
+            okq = hc(c->d_guided.ensure(nb), "dev guided") &&
+                  hc(hipMemcpyAsync(c->d_guided.p, h_guided.data() + begin, nb * sizeof(GuidedDev),
+                                    hipMemcpyHostToDevice, st), "H2D guided");
         if (!okq) break;
         FinalizeParams fp;
         fp.max_ratio = max_ratio_f;
@@ -491,7 +522,7 @@ int amc_match_pairs(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, si
                               c->d_accmask.p, c->d_lut, fp, st);
         if (nwork)
             launch_match_dot4(c->d_imgs.p, c->d_pairs.p, c->d_work.p, (uint32_t)nwork,
-                              c->d_rowbuf.p, c->d_colbuf.p, st);
+                              c->d_rowbuf.p, c->d_colbuf.p, geoms ? c->d_guided.p : nullptr, st);
         (void)hipEventRecord(c->ev[3], st);
         kernel_launches += (nord ? 1 : 0) + (nwork ? 1 : 0);
         if (nord)  // tile -> exact index for the accepted rows
@@ -588,6 +619,26 @@ int amc_match_pairs(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, si
     return AMC_OK;
 }
 
+int amc_match_pairs(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, size_t npairs,
+                    const amc_match_opts* opts_in, amc_match_result* out) {
+    return match_impl(c, slot1, slot2, npairs, opts_in, nullptr, 0.0, out);
+}
+
+int amc_match_guided_pairs(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, size_t npairs,
+                           const amc_tvg* geoms, double max_error, const amc_match_opts* opts_in,
+                           amc_match_result* out) {
+    if (npairs > 0 && !geoms) {
+        if (out) std::memset(out, 0, sizeof *out);
+        return fail(AMC_E_INVALID, "amc_match_guided_pairs: NULL geometries");
+    }
+    if (!(max_error >= 0.0)) {
+        if (out) std::memset(out, 0, sizeof *out);
+        return fail(AMC_E_INVALID, "amc_match_guided_pairs: max_error must be >= 0");
+    }
+    static const amc_tvg kNone{};
+    return match_impl(c, slot1, slot2, npairs, opts_in, npairs ? geoms : &kNone, max_error, out);
+}
+
 void amc_match_result_free(amc_match_result* r) {
     if (!r) return;
     delete static_cast<ResultPriv*>(r->_priv);
@@ -632,6 +683,9 @@ int amc_upload_keypoints(amc_ctx* c, uint32_t slot, const float* xy, uint32_t ro
         if (s.kp64) (void)hipFree(s.kp64);
         s.kp = nullptr;
         s.kp64 = nullptr;
+        s.dev.kp = nullptr;
+        s.dev.kp_rows = 0;
+        c->table_dirty = true;
     }
     s.kp_rows = rows;
     s.has_kp = true;
@@ -647,6 +701,9 @@ int amc_upload_keypoints(amc_ctx* c, uint32_t slot, const float* xy, uint32_t ro
         return fail(AMC_E_NOMEM, "amc_upload_keypoints: hipMalloc: %s", hipGetErrorString(e));
     }
     HIPCHK(hipMemcpy(s.kp, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
+    s.dev.kp = s.kp;  // guided matching reads the float32 keypoints from the image table
+    s.dev.kp_rows = rows;
+    c->table_dirty = true;
     return AMC_OK;
 }
 
@@ -663,6 +720,9 @@ int amc_upload_points_f64(amc_ctx* c, uint32_t slot, const double* xy, uint32_t 
         if (s.kp64) (void)hipFree(s.kp64);
         s.kp = nullptr;
         s.kp64 = nullptr;
+        s.dev.kp = nullptr;
+        s.dev.kp_rows = 0;
+        c->table_dirty = true;
     }
     s.kp_rows = rows;
     s.has_kp = true;

@@ -24,8 +24,20 @@ struct ImageDev {
     const uint8_t* prep;   // rows_pad x 128, bytes ^0x80 (= u8-128 as i8), 16-B slots of row r
                            // stored at slot (q ^ ((r>>1)&7)) (LDS-bank swizzle), zero rows = 0x80
     const int32_t* rs128;  // rows_pad: 128 * sum_k raw[r][k]
+    const float* kp;       // kp_rows x 2 float32 keypoints (x, y), or nullptr (guided matching only)
     uint32_t rows;
     uint32_t rows_pad;
+    uint32_t kp_rows;
+    uint32_t pad_;
+};
+
+// Guided matching (SiftCPUFeatureMatcher::MatchGuided): the pair's float32 filter model.
+enum : int { kGuidedNone = 0, kGuidedF = 1, kGuidedH = 2 };
+struct GuidedDev {
+    int32_t kind;         // kGuidedF: Sampson error under F; kGuidedH: forward transfer error under H
+    float max_residual;   // (float)(max_error * max_error)
+    float m[9];           // F or H cast to float, row-major
+    float pad_;
 };
 
 // One-way top-2 record, the common intermediate of both match kernels (16 B).
@@ -68,8 +80,9 @@ struct FinalizeParams {
 void launch_prep(const uint8_t* raw, uint8_t* prep, int32_t* rs128, uint32_t rows_pad,
                  uint32_t* maxsq_out, hipStream_t s);
 
+// guided: nullptr, or one GuidedDev per PairDev of the batch (entries the filter rejects score 0)
 void launch_match_dot4(const ImageDev* imgs, const PairDev* pairs, const Dot4Work* work,
-                       uint32_t nwork, Top2* rowbuf, Top2* colbuf, hipStream_t s);
+                       uint32_t nwork, Top2* rowbuf, Top2* colbuf, const GuidedDev* guided, hipStream_t s);
 
 // mfma: one workgroup per work item, dynamic queue over `order` (pair indices, sorted by the
 // streamed image for L2 reuse).  mode 0: rows of image 1 vs image 2 -> rowbuf + row_off.

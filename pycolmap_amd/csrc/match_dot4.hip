@@ -45,11 +45,35 @@ __device__ __forceinline__ void merge_state(RowState& a, const RowState b) {
     a.sv = max(win_sv, loser_bv);
 }
 
+// Guided matching's float32 filter (SiftCPUFeatureMatcher::MatchGuided; oracle_guided_filter in
+// oracle/match_oracle.c spells out the operation order): true = this (image-1 point, image-2 point)
+// pairing is rejected and its distance is forced to 0.
+__device__ __forceinline__ bool guided_rejects(const GuidedDev& g, float x1, float y1, float x2, float y2) {
+    const float* m = g.m;
+    if (g.kind == kGuidedF) {
+        const float Fx1_0 = m[0] * x1 + m[1] * y1 + m[2] * 1.0f;
+        const float Fx1_1 = m[3] * x1 + m[4] * y1 + m[5] * 1.0f;
+        const float Fx1_2 = m[6] * x1 + m[7] * y1 + m[8] * 1.0f;
+        const float Ftx2_0 = m[0] * x2 + m[3] * y2 + m[6] * 1.0f;
+        const float Ftx2_1 = m[1] * x2 + m[4] * y2 + m[7] * 1.0f;
+        const float x2tFx1 = x2 * Fx1_0 + y2 * Fx1_1 + 1.0f * Fx1_2;
+        return x2tFx1 * x2tFx1 / (Fx1_0 * Fx1_0 + Fx1_1 * Fx1_1 + Ftx2_0 * Ftx2_0 + Ftx2_1 * Ftx2_1) > g.max_residual;
+    }
+    const float Hp_0 = m[0] * x1 + m[1] * y1 + m[2] * 1.0f;
+    const float Hp_1 = m[3] * x1 + m[4] * y1 + m[5] * 1.0f;
+    const float Hp_2 = m[6] * x1 + m[7] * y1 + m[8] * 1.0f;
+    const float e0 = Hp_0 / Hp_2 - x2;
+    const float e1 = Hp_1 / Hp_2 - y2;
+    return e0 * e0 + e1 * e1 > g.max_residual;
+}
+
+template <bool GUIDED>
 __global__ __launch_bounds__(256) void match_dot4_kernel(const ImageDev* __restrict__ imgs,
                                                          const PairDev* __restrict__ pairs,
                                                          const Dot4Work* __restrict__ work,
                                                          Top2* __restrict__ rowbuf,
-                                                         Top2* __restrict__ colbuf) {
+                                                         Top2* __restrict__ colbuf,
+                                                         const GuidedDev* __restrict__ guided) {
     __shared__ __attribute__((aligned(16))) uint32_t Ak[32][64];
     __shared__ __attribute__((aligned(16))) uint32_t Bk[32][64];
 
@@ -81,6 +105,19 @@ __global__ __launch_bounds__(256) void match_dot4_kernel(const ImageDev* __restr
     RowState st[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) st[r] = RowState{0u, 0xFFFFFFFFu, 0u};
+
+    // guided matching: this thread's 4 X keypoints (rows past the end are never stored)
+    GuidedDev gd;
+    float xk[4][2];
+    if (GUIDED) {
+        gd = guided[w.pair];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const uint32_t i = min(w.rb * 64 + ty * 4 + r, X.kp_rows - 1);
+            xk[r][0] = X.kp[2 * (size_t)i];
+            xk[r][1] = X.kp[2 * (size_t)i + 1];
+        }
+    }
 
     const uint32_t ntiles = (Y.rows + 63) / 64;
     for (uint32_t ct = 0; ct < ntiles; ++ct) {
@@ -119,6 +156,20 @@ __global__ __launch_bounds__(256) void match_dot4_kernel(const ImageDev* __restr
         }
 
         const uint32_t j0 = ct * 64 + tx * 4;
+        if (GUIDED) {
+            // the filter always sees (image-1 point, image-2 point), whichever image is being scanned
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const uint32_t j = min(j0 + c, Y.kp_rows - 1);
+                const float yx = Y.kp[2 * (size_t)j], yy = Y.kp[2 * (size_t)j + 1];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool rej = w.dir == 0 ? guided_rejects(gd, xk[r][0], xk[r][1], yx, yy)
+                                                : guided_rejects(gd, yx, yy, xk[r][0], xk[r][1]);
+                    if (rej) acc[r][c] = 0;
+                }
+            }
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -148,10 +199,14 @@ __global__ __launch_bounds__(256) void match_dot4_kernel(const ImageDev* __restr
 }
 
 void launch_match_dot4(const ImageDev* imgs, const PairDev* pairs, const Dot4Work* work,
-                       uint32_t nwork, Top2* rowbuf, Top2* colbuf, hipStream_t s) {
+                       uint32_t nwork, Top2* rowbuf, Top2* colbuf, const GuidedDev* guided, hipStream_t s) {
     if (nwork == 0) return;
-    hipLaunchKernelGGL(match_dot4_kernel, dim3(nwork), dim3(256), 0, s, imgs, pairs, work,
-                       rowbuf, colbuf);
+    if (guided)
+        hipLaunchKernelGGL((match_dot4_kernel<true>), dim3(nwork), dim3(256), 0, s, imgs, pairs, work,
+                           rowbuf, colbuf, guided);
+    else
+        hipLaunchKernelGGL((match_dot4_kernel<false>), dim3(nwork), dim3(256), 0, s, imgs, pairs, work,
+                           rowbuf, colbuf, guided);
 }
 
 }  // namespace amc

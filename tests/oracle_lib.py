@@ -82,6 +82,27 @@ def match_pairs(images, slot1, slot2, max_ratio=0.8, max_distance=0.7, cross_che
     return offsets, matches
 
 
+def match_guided(d1, kp1, d2, kp2, config, F, H, max_error, max_ratio=0.8, max_distance=0.7, cross_check=True):
+    """oracle_match_guided for one pair. kp: [n, >=2] float32. Returns [M,2] uint32, or None when the
+    configuration has no guided matching."""
+    a = np.ascontiguousarray(d1, dtype=np.uint8).reshape(-1, 128)
+    b = np.ascontiguousarray(d2, dtype=np.uint8).reshape(-1, 128)
+    k1 = np.ascontiguousarray(np.asarray(kp1, dtype=np.float32)[:, :2]) if len(a) else np.zeros((1, 2), np.float32)
+    k2 = np.ascontiguousarray(np.asarray(kp2, dtype=np.float32)[:, :2]) if len(b) else np.zeros((1, 2), np.float32)
+    out = np.zeros((max(1, len(a)), 2), dtype=np.uint32)
+    lib = load()
+    lib.oracle_match_guided.restype = C.c_int
+    n = lib.oracle_match_guided(_p(a if len(a) else np.zeros((1, 128), np.uint8)), _p(k1), C.c_int(len(a)),
+                                _p(b if len(b) else np.zeros((1, 128), np.uint8)), _p(k2), C.c_int(len(b)),
+                                C.c_int(int(config)), _p(_d(F).reshape(9)), _p(_d(H).reshape(9)),
+                                C.c_double(max_error), C.c_double(max_ratio), C.c_double(max_distance),
+                                C.c_int(int(cross_check)), _p(out))
+    if n == -2:
+        return None
+    assert n >= 0
+    return out[:n].copy()
+
+
 def acos_lut():
     out = np.empty(262145, dtype=np.float32)
     load().oracle_acos_lut(_p(out))

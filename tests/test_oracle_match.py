@@ -160,3 +160,98 @@ def test_golden_fixtures():
         off, m = oracle_lib.match_pairs(imgs, g["slot1"], g["slot2"], float(r), float(d), bool(cc), threads=2)
         np.testing.assert_array_equal(off, g[f"{name}_offsets"])
         np.testing.assert_array_equal(m, g[f"{name}_matches"])
+
+
+# ---- guided matching (SiftCPUFeatureMatcher::MatchGuided restatement) -------------------------------
+def _guided_filter_np(kind, M, max_error, p1, p2):
+    """Independent float32 numpy restatement of the filter: [n1, n2] bool, True = rejected."""
+    f = np.float32
+    m = np.asarray(M, dtype=np.float64).astype(f).reshape(9)
+    x1, y1 = p1[:, 0].astype(f)[:, None], p1[:, 1].astype(f)[:, None]
+    x2, y2 = p2[:, 0].astype(f)[None, :], p2[:, 1].astype(f)[None, :]
+    mr = f(np.float64(max_error) * np.float64(max_error))
+    with np.errstate(all="ignore"):
+        if kind == "F":
+            a0 = (m[0] * x1 + m[1] * y1) + m[2]
+            a1 = (m[3] * x1 + m[4] * y1) + m[5]
+            a2 = (m[6] * x1 + m[7] * y1) + m[8]
+            b0 = (m[0] * x2 + m[3] * y2) + m[6]
+            b1 = (m[1] * x2 + m[4] * y2) + m[7]
+            num = (x2 * a0 + y2 * a1) + a2
+            den = ((a0 * a0 + a1 * a1) + b0 * b0) + b1 * b1
+            return (num * num) / den > mr
+        h0 = (m[0] * x1 + m[1] * y1) + m[2]
+        h1 = (m[3] * x1 + m[4] * y1) + m[5]
+        h2 = (m[6] * x1 + m[7] * y1) + m[8]
+        e0 = h0 / h2 - x2
+        e1 = h1 / h2 - y2
+        return e0 * e0 + e1 * e1 > mr
+
+
+def match_from_dists_numpy(D, max_ratio, max_distance, cross_check):
+    """FindBestMatchesBruteForce on a given int distance matrix with numpy primitives; the float32
+    acos values come from the host-libm table (exact: (float)d * 2^-18 has no rounding)."""
+    lut = oracle_lib.acos_lut()
+    r, t = np.float32(max_ratio), np.float32(max_distance)
+
+    def one_way(M):
+        R, Cn = M.shape
+        best_idx = M.argmax(axis=1)                       # first maximum = lowest index among ties
+        best = M[np.arange(R), best_idx]
+        second = np.partition(M, Cn - 2, axis=1)[:, Cn - 2] if Cn > 1 else np.zeros(R, M.dtype)
+        second = np.maximum(second, 0)
+        a_b = lut[np.minimum(best, 262144)]
+        a_s = lut[np.minimum(second, 262144)]
+        ok = (best > 0) & ~(a_b > t) & ~(a_b >= r * a_s)
+        return np.where(ok, best_idx, -1)
+
+    if D.shape[0] == 0 or D.shape[1] == 0:
+        return np.zeros((0, 2), np.uint32)
+    m12 = one_way(D)
+    m21 = one_way(D.T)
+    out = [(i, j) for i, j in enumerate(m12) if j >= 0 and (not cross_check or m21[j] == i)]
+    return np.array(out, dtype=np.uint32).reshape(-1, 2)
+
+
+def _guided_np(d1, kp1, d2, kp2, kind, M, max_error, max_ratio=0.8, max_distance=0.7, cross_check=True):
+    dists = d1.astype(np.int64) @ d2.astype(np.int64).T
+    dists[_guided_filter_np(kind, M, max_error, kp1, kp2)] = 0
+    return match_from_dists_numpy(dists, max_ratio, max_distance, cross_check)
+
+
+def test_guided_matching_oracle_against_numpy_restatement():
+    from pycolmap_amd import synth
+    rng = np.random.default_rng(77)
+    imgs = synth.multiview_scene(rng, num_images=3, n_feats=300, num_landmarks=400)
+    for a, b in ((0, 1), (0, 2), (2, 1)):
+        sc_a, sc_b = imgs[a], imgs[b]
+        kp1, kp2 = sc_a["keypoints"][:, :2], sc_b["keypoints"][:, :2]
+        F = rng.normal(size=(3, 3)) * 1e-3
+        H = np.eye(3) + rng.normal(size=(3, 3)) * 1e-3
+        for cfg, kind, M in ((2, "F", F), (3, "F", F), (4, "H", H), (5, "H", H), (6, "H", H)):
+            for err in (0.5, 4.0, 50.0):
+                got = oracle_lib.match_guided(sc_a["descriptors"], kp1, sc_b["descriptors"], kp2, cfg, F, H, err)
+                want = _guided_np(sc_a["descriptors"], kp1, sc_b["descriptors"], kp2, kind, M, err)
+                np.testing.assert_array_equal(got, want)
+        for cfg in (0, 1, 7, 8):   # UNDEFINED, DEGENERATE, WATERMARK, MULTIPLE: no guided matching
+            assert oracle_lib.match_guided(sc_a["descriptors"], kp1, sc_b["descriptors"], kp2, cfg, F, H, 4.0) is None
+
+
+def test_guided_matching_limits():
+    """A filter that accepts everything reproduces plain matching; one that rejects everything leaves
+    an all-zero distance matrix, i.e. no matches; points exactly on the epipolar line pass."""
+    from pycolmap_amd import synth
+    rng = np.random.default_rng(78)
+    imgs = synth.multiview_scene(rng, num_images=2, n_feats=256, num_landmarks=300)
+    d1, d2 = imgs[0]["descriptors"], imgs[1]["descriptors"]
+    kp1, kp2 = imgs[0]["keypoints"][:, :2], imgs[1]["keypoints"][:, :2]
+    F = np.array([[0, -1e-3, 0.2], [1e-3, 0, -0.3], [-0.2, 0.3, 0.0]])
+    H = np.eye(3)
+    plain = oracle_lib.match(d1, d2)
+    np.testing.assert_array_equal(oracle_lib.match_guided(d1, kp1, d2, kp2, 3, F, H, 1e9), plain)
+    np.testing.assert_array_equal(oracle_lib.match_guided(d1, kp1, d2, kp2, 4, F, H, 1e9), plain)
+    assert len(oracle_lib.match_guided(d1, kp1, d2, kp2, 4, F, np.eye(3) * 0 + [[0, 0, 1e6]] * 3, 1e-3)) == 0
+    # H = identity, max_error 1: only pairings closer than 1 px survive the filter
+    kp2_near = (kp1 + 0.25).astype(np.float32)
+    got = oracle_lib.match_guided(d1, kp1, d1, kp2_near, 6, F, np.eye(3), 1.0, max_ratio=1.0, max_distance=10.0)
+    assert len(got) > 0 and np.all(got[:, 0] == got[:, 1])
