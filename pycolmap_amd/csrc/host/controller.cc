@@ -58,9 +58,6 @@ uint32_t MatchController::SlotOf(image_t id) const {
 // FeatureMatcherCache::Setup + the GPU matcher's descriptor upload.  The LRU cache over SQLite is
 // replaced by a device-resident arena holding every image.
 void MatchController::Setup() {
-    if (sift_.guided_matching)
-        throw std::invalid_argument("SiftMatchingOptions.guided_matching is not implemented on the accelerated path "
-                                    "yet (SURVEY.md section 8f, rank 2); set guided_matching=False");
     db_ = std::make_unique<Database>(path_);
     images_ = db_->ReadAllImages();
     const std::vector<CameraRow> cams = db_->ReadAllCameras();
@@ -191,6 +188,45 @@ void MatchController::Match(const ImagePairs& image_pairs) {
         }
         stats.verify_device_ms += vr.device_ms;
         stats.pairs_verified += vwhich.size();
+
+        // ---- guided matching (FeatureMatcherWorker with a verified geometry): pairs that kept at
+        //      least min_num_inliers inliers and whose configuration COLMAP guides on are matched
+        //      again under the geometric filter; the result REPLACES the inlier matches, the raw
+        //      matches and the models stay as they are.
+        if (sift_.guided_matching) {
+            std::vector<uint32_t> g1, g2;
+            std::vector<amc_tvg> geoms;
+            std::vector<size_t> gwhich;
+            for (size_t p = 0; p < vwhich.size(); ++p) {
+                const Job& j = jobs[vwhich[p]];
+                const int cfg = vr.tvg[p].config;
+                const bool guides = cfg == AMC_TVG_CALIBRATED || cfg == AMC_TVG_UNCALIBRATED ||
+                                    cfg == AMC_TVG_PLANAR || cfg == AMC_TVG_PANORAMIC ||
+                                    cfg == AMC_TVG_PLANAR_OR_PANORAMIC;
+                if (!guides || j.tvg.inlier_matches.size() / 2 < min_inl) continue;
+                g1.push_back(v1[p]);
+                g2.push_back(v2[p]);
+                geoms.push_back(vr.tvg[p]);
+                gwhich.push_back(vwhich[p]);
+            }
+            if (!gwhich.empty()) {
+                amc_match_opts mo;
+                amc_match_opts_default(&mo);
+                mo.max_ratio = sift_.max_ratio;
+                mo.max_distance = sift_.max_distance;
+                mo.cross_check = sift_.cross_check;
+                amc_match_result gr;
+                Check(amc_match_guided_pairs(ctx_, g1.data(), g2.data(), gwhich.size(), geoms.data(),
+                                             tvg_.ransac_options.max_error, &mo, &gr),
+                      "amc_match_guided_pairs");
+                for (size_t q = 0; q < gwhich.size(); ++q)
+                    jobs[gwhich[q]].tvg.inlier_matches.assign(gr.matches + 2 * gr.offsets[q],
+                                                              gr.matches + 2 * gr.offsets[q + 1]);
+                stats.guided_device_ms += gr.device_ms;
+                stats.pairs_guided += gwhich.size();
+                amc_match_result_free(&gr);
+            }
+        }
         amc_verify_result_free(&vr);
     }
 

@@ -73,8 +73,8 @@ struct AmcFailure : std::runtime_error {
 };
 
 struct MatchStats {
-    size_t pairs_matched = 0, pairs_verified = 0, pairs_skipped = 0;
-    double match_device_ms = 0, verify_device_ms = 0, db_ms = 0;
+    size_t pairs_matched = 0, pairs_verified = 0, pairs_skipped = 0, pairs_guided = 0;
+    double match_device_ms = 0, verify_device_ms = 0, guided_device_ms = 0, db_ms = 0;
     uint64_t num_distances = 0;
 };
 

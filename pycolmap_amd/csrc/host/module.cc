@@ -168,7 +168,8 @@ py::dict StatsDict(const MatchStats& s) {
     return py::dict("pairs_matched"_a = s.pairs_matched, "pairs_verified"_a = s.pairs_verified,
                     "pairs_skipped"_a = s.pairs_skipped, "match_device_ms"_a = s.match_device_ms,
                     "verify_device_ms"_a = s.verify_device_ms, "db_ms"_a = s.db_ms,
-                    "num_distances"_a = s.num_distances);
+                    "num_distances"_a = s.num_distances, "pairs_guided"_a = s.pairs_guided,
+                    "guided_device_ms"_a = s.guided_device_ms);
 }
 
 }  // namespace

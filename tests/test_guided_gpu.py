@@ -97,3 +97,27 @@ def test_guided_argument_errors(ctx):
         ctx.match_guided_pairs([0], [1], tvg, 4.0)
     off, m, _ = ctx.match_guided_pairs([], [], np.zeros(0, dtype=_capi.TVG_DTYPE), 4.0)
     assert off.tolist() == [0] and m.shape == (0, 2)
+
+
+def test_guided_resolves_repeated_structures(ctx):
+    """Every feature of image 1 has its true partner AND a decoy with the identical descriptor in image
+    2: plain matching rejects all of them on the ratio test (best == second), the homography filter
+    removes the decoys and guided matching recovers every correspondence."""
+    rng = np.random.default_rng(12)
+    n = 100
+    desc = synth.quantize_descriptors(rng.gamma(0.7, 1.0, size=(n, 128)))
+    kp1 = rng.uniform(50, 900, size=(n, 2)).astype(np.float32)
+    shift = np.array([5.0, -3.0], np.float32)
+    kp2 = np.concatenate([kp1 + shift, kp1 + np.array([400.0, 350.0], np.float32)]).astype(np.float32)
+    imgs = [dict(descriptors=desc, keypoints=kp1, width=1600, height=1200, params=(1200.0, 1200.0, 800.0, 600.0)),
+            dict(descriptors=np.concatenate([desc, desc]), keypoints=kp2, width=1600, height=1200,
+                 params=(1200.0, 1200.0, 800.0, 600.0))]
+    upload_scene(ctx, imgs, False)
+    off, m, _ = ctx.match_pairs([0], [1])
+    assert len(m) == 0 and len(o.match(imgs[0]["descriptors"], imgs[1]["descriptors"])) == 0
+    tvg = np.zeros(1, dtype=_capi.TVG_DTYPE)
+    tvg["config"] = 4
+    tvg["H"][0] = [[1, 0, 5], [0, 1, -3], [0, 0, 1]]
+    assert check_guided(ctx, imgs, [0], [1], tvg, 4.0) == n
+    off, m, _ = ctx.match_guided_pairs([0], [1], tvg, 4.0)
+    np.testing.assert_array_equal(m, np.stack([np.arange(n)] * 2, axis=1))

@@ -71,8 +71,6 @@ def test_device_enum_and_error_conventions(tmp_path):
     with pytest.raises(ValueError):
         pycolmap.match_vocabtree(db)
     # options the accelerated path does not implement fail loudly instead of being ignored
-    with pytest.raises(ValueError, match="guided_matching"):
-        pycolmap.match_exhaustive(db, sift_options=dict(guided_matching=True))
     with pytest.raises(ValueError, match="loop_detection"):
         pycolmap.match_sequential(db, matching_options=dict(loop_detection=True))
     assert pycolmap.has_cuda is True

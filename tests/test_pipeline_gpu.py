@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 MIN_INL = 15
 
 
-def expected_rows(images, ids, blocks, sift=(0.8, 0.7, True), prior=False, tvg_kw=None):
+def expected_rows(images, ids, blocks, sift=(0.8, 0.7, True), prior=False, tvg_kw=None, guided=False):
     """What COLMAP's controller would store for the given pair blocks (oracle matcher + oracle TVG)."""
     by_id = {i: im for i, im in zip(ids, images)}
     exp_m, exp_t, seen = {}, {}, set()
@@ -35,6 +35,11 @@ def expected_rows(images, ids, blocks, sift=(0.8, 0.7, True), prior=False, tvg_k
                                                  b["keypoints"][:, :2].astype(np.float64), m,
                                                  o.tvg_default_options(**(tvg_kw or {})))
                 inl = m[r["inlier_mask"]]
+                if guided and len(inl) >= MIN_INL and r["config"] in (2, 3, 4, 5, 6):
+                    # MatchGuided replaces the inlier matches; raw matches and models stay
+                    max_error = (tvg_kw or {}).get("max_error", 4.0)
+                    inl = o.match_guided(a["descriptors"], a["keypoints"], b["descriptors"], b["keypoints"],
+                                         r["config"], r["F"], r["H"], max_error, *sift)
                 if len(inl) >= MIN_INL:
                     tv = dict(config=r["config"], F=r["F"], E=r["E"], H=r["H"], inl=inl)
             else:
@@ -131,3 +136,21 @@ def test_verify_matches_reads_stored_matches(tmp_path):
     assert st["pairs_matched"] == 0 and st["pairs_verified"] >= 2
     exp_m, exp_t = expected_rows(images, ids, [pairs])
     compare(db, exp_m, exp_t)
+
+
+@pytest.mark.parametrize("prior", [False, True])
+def test_match_exhaustive_with_guided_matching(tmp_path, prior):
+    """SiftMatchingOptions.guided_matching: verified pairs are matched again under the geometric filter
+    and the guided matches become the stored inlier matches."""
+    rng = np.random.default_rng(40 + int(prior))
+    images = synth.multiview_scene(rng, num_images=5, n_feats=500, num_landmarks=700)
+    for im in images:
+        im["prior"] = prior
+    db = tmp_path / "guided.db"
+    ids = colmap_db.create(db, images)
+    pycolmap.match_exhaustive(db, sift_options=dict(guided_matching=True))
+    stats = pycolmap.last_run_stats()
+    assert stats["pairs_guided"] > 0
+    blocks = pycolmap._pycolmap._exhaustive_blocks(ids, 50)
+    exp_m, exp_t = expected_rows(images, ids, blocks, prior=prior, guided=True)
+    assert compare(db, exp_m, exp_t) >= 5
