@@ -109,6 +109,8 @@ int amc_ctx_set_stream(amc_ctx* ctx, void* hip_stream);
 /* Size the image-slot table. Slots are dense ids 0..num_slots-1 chosen by the caller (the host
  * layer maps COLMAP image_ids to slots). Discards previously uploaded data. */
 int amc_ctx_reserve_slots(amc_ctx* ctx, uint32_t num_slots);
+/* Append empty slots up to num_slots (>= the current count), keeping every uploaded image. */
+int amc_ctx_grow_slots(amc_ctx* ctx, uint32_t num_slots);
 
 /* Upload an image's descriptors: rows x 128 uint8 row-major (COLMAP FeatureDescriptors /
  * the `descriptors` blob).  rows may be 0.  The library copies. */

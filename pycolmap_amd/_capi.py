@@ -27,7 +27,7 @@ EXPORTED_SYMBOLS = [
     "amc_match_opts_default", "amc_get_acos_lut",
     "amc_tvg_opts_default", "amc_upload_keypoints", "amc_upload_camera", "amc_verify_pairs",
     "amc_verify_result_free", "amc_upload_points_f64", "amc_ransac_pairs", "amc_ransac_result_free",
-    "amc_squared_sampson_error", "amc_match_guided_pairs",
+    "amc_squared_sampson_error", "amc_match_guided_pairs", "amc_ctx_grow_slots",
 ]
 RANSAC_F, RANSAC_H, RANSAC_E = 0, 1, 2
 RANSAC_KINDS = {"F": RANSAC_F, "H": RANSAC_H, "E": RANSAC_E}
@@ -122,6 +122,7 @@ def load() -> C.CDLL:
     lib.amc_ctx_destroy.restype = None
     lib.amc_ctx_set_stream.argtypes = [C.c_void_p, C.c_void_p]
     lib.amc_ctx_reserve_slots.argtypes = [C.c_void_p, C.c_uint32]
+    lib.amc_ctx_grow_slots.argtypes = [C.c_void_p, C.c_uint32]
     lib.amc_upload_descriptors.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
     lib.amc_upload_descriptors_device.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
     lib.amc_match_pairs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
@@ -213,6 +214,10 @@ class Context:
 
     def reserve_slots(self, n: int) -> None:
         _check(self._lib.amc_ctx_reserve_slots(self._h, n))
+
+    def grow_slots(self, n: int) -> None:
+        """Append empty slots up to n, keeping every uploaded image."""
+        _check(self._lib.amc_ctx_grow_slots(self._h, n))
 
     def upload_descriptors(self, slot: int, desc: np.ndarray) -> None:
         d = np.ascontiguousarray(desc, dtype=np.uint8)

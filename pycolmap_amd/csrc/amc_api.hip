@@ -239,6 +239,16 @@ int amc_ctx_reserve_slots(amc_ctx* c, uint32_t num_slots) {
     return AMC_OK;
 }
 
+int amc_ctx_grow_slots(amc_ctx* c, uint32_t num_slots) {
+    if (!c) return fail(AMC_E_INVALID, "amc_ctx_grow_slots: ctx is NULL");
+    if (num_slots < c->slots.size())
+        return fail(AMC_E_INVALID, "amc_ctx_grow_slots: %u < current %zu slots (use amc_ctx_reserve_slots to reset)",
+                    num_slots, c->slots.size());
+    c->slots.resize(num_slots);
+    c->table_dirty = true;
+    return AMC_OK;
+}
+
 static int upload_common(amc_ctx* c, uint32_t slot, const void* src, uint32_t rows,
                          hipMemcpyKind kind) {
     if (!c) return fail(AMC_E_INVALID, "upload_descriptors: ctx is NULL");

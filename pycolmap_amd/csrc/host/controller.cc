@@ -241,6 +241,68 @@ void MatchController::Match(const ImagePairs& image_pairs) {
     stats.db_ms += NowMs() - t_db1;
 }
 
+// ---- loop detection -------------------------------------------------------------------------
+// COLMAP's SequentialFeatureMatcher::RunLoopDetection asks a FLANN vocabulary tree (a file the
+// user has to supply) for the images most similar to every loop_detection_period-th image and
+// matches those pairs.  There is no FLANN here and an approximate index is not a parity target;
+// the retrieval is replaced by exact FEATURE VOTING with the kernels that already exist: every
+// image keeps a copy of its first `max_features` descriptors, the query's copy is matched against
+// every candidate's copy with the regular matcher (ratio test + cross check), and the candidates
+// are ranked by the number of matches.  It is deterministic, needs no training data, and costs
+// N x max_features^2 distances per query (6.7e8 at N = 10,000, 256 features: well under a ms of
+// the scan kernel).  tests/test_pipeline_gpu.py restates it with the CPU oracle.
+void MatchController::SetupLoopIndex(int max_features) {
+    if (loop_index_features_ == max_features) return;
+    const uint32_t n = static_cast<uint32_t>(images_.size());
+    Check(amc_ctx_grow_slots(ctx_, 2 * n), "amc_ctx_grow_slots");
+    for (uint32_t s = 0; s < n; ++s) {
+        uint32_t drows = 0;
+        const std::vector<uint8_t> desc = db_->ReadDescriptors(images_[s].image_id, &drows);
+        const uint32_t use = std::min<uint32_t>({drows, static_cast<uint32_t>(max_features),
+                                                 static_cast<uint32_t>(std::max(sift_.max_num_matches, 0))});
+        Check(amc_upload_descriptors(ctx_, n + s, desc.data(), use), "amc_upload_descriptors (loop index)");
+    }
+    loop_index_features_ = max_features;
+}
+
+std::vector<image_t> MatchController::RetrieveLoopCandidates(image_t query, const std::vector<image_t>& candidates,
+                                                             int num_images, int max_features) {
+    if (num_images <= 0 || candidates.empty()) return {};
+    SetupLoopIndex(max_features > 0 ? max_features : kLoopIndexDefaultFeatures);
+    const uint32_t n = static_cast<uint32_t>(images_.size());
+    std::vector<uint32_t> s1, s2;
+    std::vector<image_t> who;
+    for (image_t c : candidates) {
+        if (c == query) continue;
+        s1.push_back(n + SlotOf(query));
+        s2.push_back(n + SlotOf(c));
+        who.push_back(c);
+    }
+    if (who.empty()) return {};
+    amc_match_opts mo;
+    amc_match_opts_default(&mo);
+    mo.max_ratio = sift_.max_ratio;
+    mo.max_distance = sift_.max_distance;
+    mo.cross_check = sift_.cross_check;
+    amc_match_result r;
+    Check(amc_match_pairs(ctx_, s1.data(), s2.data(), who.size(), &mo, &r), "amc_match_pairs (loop index)");
+    std::vector<size_t> order(who.size());
+    std::vector<uint64_t> votes(who.size());
+    for (size_t i = 0; i < who.size(); ++i) {
+        order[i] = i;
+        votes[i] = r.offsets[i + 1] - r.offsets[i];
+    }
+    stats.loop_device_ms += r.device_ms;
+    stats.loop_pairs_scored += who.size();
+    ++stats.loop_queries;
+    amc_match_result_free(&r);
+    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return votes[a] > votes[b]; });
+    std::vector<image_t> out;
+    for (size_t k = 0; k < order.size() && out.size() < static_cast<size_t>(num_images); ++k)
+        if (votes[order[k]] > 0) out.push_back(who[order[k]]);  // an image without a single vote is no candidate
+    return out;
+}
+
 // ExhaustiveFeatureMatcher::Run: block pairs, one transaction + Match() each
 std::vector<ImagePairs> ExhaustiveBlocks(const std::vector<image_t>& ids, int block_size) {
     if (block_size <= 1) throw std::invalid_argument("block_size must be > 1");
@@ -262,18 +324,35 @@ std::vector<ImagePairs> ExhaustiveBlocks(const std::vector<image_t>& ids, int bl
     }
     return out;
 }
+// COLMAP runs one Match() + one transaction per generated block and keeps the device busy with a
+// pool of worker threads.  Here the device is kept busy by batching instead: consecutive blocks are
+// merged until a device call has kGroupPairs pairs (a sequential block is ~17 pairs, far too few for
+// 1024 resident waves), then matched, verified and written in one transaction.  What ends up in the
+// database is the same; only the granularity of a resumed, interrupted run changes.
+constexpr size_t kGroupPairs = 8192;
+static void RunGrouped(MatchController& c, const std::vector<ImagePairs>& blocks) {
+    ImagePairs group;
+    auto flush = [&] {
+        if (group.empty()) return;
+        DatabaseTransaction tx(&c.Db());
+        c.Match(group);
+        group.clear();
+    };
+    for (const ImagePairs& pairs : blocks) {
+        if (c.StopRequested()) break;
+        group.insert(group.end(), pairs.begin(), pairs.end());
+        if (group.size() >= kGroupPairs) flush();
+    }
+    if (!c.StopRequested()) flush();
+}
+
 void RunExhaustive(MatchController& c, const ExhaustiveMatchingOptions& o) {
     std::vector<image_t> ids;
     for (const auto& im : c.Images()) ids.push_back(im.image_id);
-    for (const ImagePairs& pairs : ExhaustiveBlocks(ids, o.block_size)) {
-        if (c.StopRequested()) break;
-        DatabaseTransaction tx(&c.Db());
-        c.Match(pairs);
-    }
+    RunGrouped(c, ExhaustiveBlocks(ids, o.block_size));
 }
 
-// SequentialFeatureMatcher::Run without loop detection (needs a FLANN vocabulary tree file:
-// SURVEY.md 8f rank 1)
+// SequentialFeatureMatcher::RunSequentialMatching
 std::vector<ImagePairs> SequentialBlocks(const std::vector<image_t>& ids, int overlap, bool quadratic_overlap) {
     if (overlap <= 0) throw std::invalid_argument("overlap must be > 0");
     std::vector<ImagePairs> out;
@@ -293,16 +372,23 @@ std::vector<ImagePairs> SequentialBlocks(const std::vector<image_t>& ids, int ov
     return out;
 }
 void RunSequential(MatchController& c, const SequentialMatchingOptions& o) {
-    if (o.loop_detection)
-        throw std::invalid_argument("loop_detection needs a vocabulary tree (FLANN) and is not implemented");
     std::vector<ImageRow> ordered = c.Images();  // GetOrderedImageIds: by name
     std::sort(ordered.begin(), ordered.end(), [](const ImageRow& a, const ImageRow& b) { return a.name < b.name; });
     std::vector<image_t> ids;
     for (const auto& im : ordered) ids.push_back(im.image_id);
-    for (const ImagePairs& pairs : SequentialBlocks(ids, o.overlap, o.quadratic_overlap)) {
-        if (c.StopRequested()) break;
-        DatabaseTransaction tx(&c.Db());
-        c.Match(pairs);
+    RunGrouped(c, SequentialBlocks(ids, o.overlap, o.quadratic_overlap));
+    // SequentialFeatureMatcher::RunLoopDetection: every loop_detection_period-th image (in name
+    // order) is matched against its loop_detection_num_images retrieved images
+    if (o.loop_detection) {
+        std::vector<ImagePairs> loop_blocks;
+        for (size_t i = 0; i < ids.size() && !c.StopRequested(); i += kLoopDetectionPeriod) {
+            const std::vector<image_t> found =
+                c.RetrieveLoopCandidates(ids[i], ids, o.loop_detection_num_images, o.loop_detection_max_num_features);
+            ImagePairs pairs;
+            for (image_t j : found) pairs.emplace_back(ids[i], j);
+            loop_blocks.push_back(std::move(pairs));
+        }
+        RunGrouped(c, loop_blocks);
     }
 }
 
@@ -328,11 +414,10 @@ void RunImagePairs(MatchController& c, const std::string& pairs_path, int block_
         all.emplace_back(i1->second, i2->second);
     }
     const size_t B = static_cast<size_t>(std::max(block_size, 1));
-    for (size_t s = 0; s < all.size() && !c.StopRequested(); s += B) {
-        ImagePairs block(all.begin() + s, all.begin() + std::min(all.size(), s + B));
-        DatabaseTransaction tx(&c.Db());
-        c.Match(block);
-    }
+    std::vector<ImagePairs> blocks;
+    for (size_t s = 0; s < all.size(); s += B)
+        blocks.emplace_back(all.begin() + s, all.begin() + std::min(all.size(), s + B));
+    RunGrouped(c, blocks);
 }
 
 }  // namespace amchost

@@ -73,8 +73,9 @@ struct AmcFailure : std::runtime_error {
 };
 
 struct MatchStats {
-    size_t pairs_matched = 0, pairs_verified = 0, pairs_skipped = 0, pairs_guided = 0;
-    double match_device_ms = 0, verify_device_ms = 0, guided_device_ms = 0, db_ms = 0;
+    size_t pairs_matched = 0, pairs_verified = 0, pairs_skipped = 0, pairs_guided = 0, loop_queries = 0,
+           loop_pairs_scored = 0;
+    double match_device_ms = 0, verify_device_ms = 0, guided_device_ms = 0, loop_device_ms = 0, db_ms = 0;
     uint64_t num_distances = 0;
 };
 
@@ -86,6 +87,12 @@ class MatchController {
     void Setup();  // read cameras/images/keypoints/descriptors, fill the GPU arena
     // FeatureMatcherController::Match: filter, match, verify, write
     void Match(const ImagePairs& pairs);
+    // Loop-closure candidates of `query` among `candidates` (SequentialFeatureMatcher::RunLoopDetection
+    // with the vocabulary-tree query replaced by feature voting, see controller.cc): the up to
+    // num_images images with the most cross-checked matches between the first max_features
+    // descriptors of both images, most first, ties in `candidates` order.
+    std::vector<image_t> RetrieveLoopCandidates(image_t query, const std::vector<image_t>& candidates,
+                                                int num_images, int max_features);
     const std::vector<ImageRow>& Images() const { return images_; }
     Database& Db() { return *db_; }
     void RequestStop() { stop_.store(true); }
@@ -103,7 +110,12 @@ class MatchController {
     amc_ctx* ctx_ = nullptr;
     std::atomic<bool> stop_{false};
     uint32_t SlotOf(image_t id) const;
+    int loop_index_features_ = 0;  // > 0 once the truncated copies (slots N .. 2N-1) are uploaded
+    void SetupLoopIndex(int max_features);
 };
+
+constexpr int kLoopDetectionPeriod = 10;      // SequentialMatchingOptions::loop_detection_period (not bound by pycolmap)
+constexpr int kLoopIndexDefaultFeatures = 512;  // features per image used for voting when max_num_features <= 0
 
 // pair generators as pure functions: one entry per Match() call / DB transaction
 std::vector<ImagePairs> ExhaustiveBlocks(const std::vector<image_t>& ids, int block_size);

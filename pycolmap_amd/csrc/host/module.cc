@@ -169,7 +169,8 @@ py::dict StatsDict(const MatchStats& s) {
                     "pairs_skipped"_a = s.pairs_skipped, "match_device_ms"_a = s.match_device_ms,
                     "verify_device_ms"_a = s.verify_device_ms, "db_ms"_a = s.db_ms,
                     "num_distances"_a = s.num_distances, "pairs_guided"_a = s.pairs_guided,
-                    "guided_device_ms"_a = s.guided_device_ms);
+                    "guided_device_ms"_a = s.guided_device_ms, "loop_queries"_a = s.loop_queries,
+                    "loop_pairs_scored"_a = s.loop_pairs_scored, "loop_device_ms"_a = s.loop_device_ms);
 }
 
 }  // namespace
@@ -361,9 +362,6 @@ PYBIND11_MODULE(_pycolmap, m) {
         "match_sequential",
         [run_pipeline](const py::object& database_path, const SiftMatchingOptions& sift,
                        const SequentialMatchingOptions& mo, const TwoViewGeometryOptions& tvg, Device device) {
-            if (mo.loop_detection)  // pre-flight, before any device work (RunSequential checks again)
-                throw py::value_error("loop_detection needs a vocabulary tree (FLANN) and is not implemented "
-                                      "(SURVEY.md section 8f, rank 1)");
             run_pipeline(database_path, sift, tvg, device, [&](MatchController& c) { RunSequential(c, mo); });
         },
         "database_path"_a, "sift_options"_a = SiftMatchingOptions(),

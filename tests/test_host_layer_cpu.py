@@ -70,9 +70,6 @@ def test_device_enum_and_error_conventions(tmp_path):
         pycolmap.match_exhaustive(str(db), sift_options={"bogus": 1})
     with pytest.raises(ValueError):
         pycolmap.match_vocabtree(db)
-    # options the accelerated path does not implement fail loudly instead of being ignored
-    with pytest.raises(ValueError, match="loop_detection"):
-        pycolmap.match_sequential(db, matching_options=dict(loop_detection=True))
     assert pycolmap.has_cuda is True
 
 

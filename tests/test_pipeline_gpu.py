@@ -154,3 +154,33 @@ def test_match_exhaustive_with_guided_matching(tmp_path, prior):
     blocks = pycolmap._pycolmap._exhaustive_blocks(ids, 50)
     exp_m, exp_t = expected_rows(images, ids, blocks, prior=prior, guided=True)
     assert compare(db, exp_m, exp_t) >= 5
+
+
+def test_match_sequential_loop_detection(tmp_path):
+    """loop_detection=True: after the sequential pairs, every 10th image (in name order) is matched
+    against the loop_detection_num_images images that share the most matches with it on the first
+    loop_detection_max_num_features descriptors (feature voting)."""
+    rng = np.random.default_rng(50)
+    images = synth.multiview_scene(rng, num_images=21, n_feats=300, num_landmarks=420)
+    db = tmp_path / "loop.db"
+    ids = colmap_db.create(db, images)
+    L, K = 96, 3
+    pycolmap.match_sequential(db, matching_options=dict(overlap=2, quadratic_overlap=False, loop_detection=True,
+                                                        loop_detection_num_images=K,
+                                                        loop_detection_max_num_features=L))
+    st = pycolmap.last_run_stats()
+    assert st["loop_queries"] == 3 and st["loop_pairs_scored"] == 3 * 20
+    blocks = pycolmap._pycolmap._sequential_blocks(ids, 2, False)
+    # the voting, restated with the CPU oracle matcher
+    loop_blocks = []
+    for qi in range(0, len(ids), 10):
+        votes = [(len(o.match(images[qi]["descriptors"][:L], images[j]["descriptors"][:L])), j)
+                 for j in range(len(ids)) if j != qi]
+        ranked = sorted(votes, key=lambda v: -v[0])           # stable: ties keep the candidate order
+        loop_blocks.append([(ids[qi], ids[j]) for n, j in ranked[:K] if n > 0])
+    assert sum(len(b) for b in loop_blocks) >= 6
+    exp_m, exp_t = expected_rows(images, ids, list(blocks) + loop_blocks)
+    assert compare(db, exp_m, exp_t) >= 10
+    # the loop pairs are pairs the sequential pass did not cover
+    seq_pairs = {colmap_db.pair_id(a, b) for blk in blocks for a, b in blk if a != b}
+    assert any(colmap_db.pair_id(a, b) not in seq_pairs for blk in loop_blocks for a, b in blk)
