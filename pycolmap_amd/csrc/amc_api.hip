@@ -921,7 +921,7 @@ static int verify_impl(amc_ctx* c, int mode, const uint32_t* slot1, const uint32
     std::vector<size_t> cls[2];
     for (size_t p = 0; p < npairs; ++p) {
         const uint32_t mc = std::max<uint32_t>(64, round_up(tp[p].M, 64));
-        if (tvg_lds_bytes(mc, 0, 1) + 64 <= 160 * 1024 / 4) cls[0].push_back(p);
+        if (tvg_lds_bytes(mc, 0, 1) + 64 <= 160 * 1024 / (4 * kTvgWavesPerSimd)) cls[0].push_back(p);
         else if (tvg_lds_bytes(mc, 0, 1) + 64 <= 160 * 1024) cls[1].push_back(p);
         else {
             delete priv;
@@ -960,9 +960,9 @@ static int verify_impl(amc_ctx* c, int mode, const uint32_t* slot1, const uint32
         }
         const uint32_t mcap = std::max<uint32_t>(64, round_up(cm, 64));
         const size_t lds_block = tvg_lds_bytes(mcap, tvg_pts_cap(mcap, wpb), wpb);
-        // one wave per SIMD (the kernel's register budget): at most 4 waves per CU
-        const uint32_t blocks_per_cu =
-            (uint32_t)std::max<size_t>(1, std::min<size_t>(4 / wpb, (160 * 1024) / std::max<size_t>(lds_block, 1)));
+        // kTvgWavesPerSimd waves per SIMD (the kernel's register budget): 4 * that many waves per CU
+        const uint32_t blocks_per_cu = (uint32_t)std::max<size_t>(
+            1, std::min<size_t>(4 * kTvgWavesPerSimd / wpb, (160 * 1024) / std::max<size_t>(lds_block, 1)));
         uint32_t num_waves = (uint32_t)std::min<size_t>(idx.size(), (size_t)cus * blocks_per_cu * wpb);
         num_waves = std::max<uint32_t>(wpb, (num_waves + wpb - 1) / wpb * wpb);
         HIPCHK(c->d_tpairs.ensure(idx.size()));

@@ -39,11 +39,12 @@ constexpr int kMaxModels = 10;
 constexpr int kModelDoubles = 64 * kMaxModels * 9;
 
 __host__ __device__ inline size_t tvg_ws_doubles(uint32_t mcap) {
-    return (size_t)W_NUM_ARRAYS * mcap + kModelDoubles;
+    return (size_t)W_NUM_ARRAYS * mcap + kModelDoubles + 312;  // + 624-word generator snapshot
 }
-// LDS bytes of one wave: jacA + jacV | points | mt, snap, rawcnt | sidx | perm | inl
+// LDS bytes of one wave: jacA + jacV | points | mt, rawcnt | sidx | perm | inl
+// (the generator snapshot of a chunk, read back only on an abort, lives in the global workspace)
 __host__ __device__ inline size_t tvg_lds_per_wave(uint32_t mcap, uint32_t pts_cap) {
-    const size_t per = (size_t)162 * 8 + (size_t)4 * pts_cap * 8 + (size_t)(624 + 624 + 64) * 4 + 64 * 8 * 2 +
+    const size_t per = (size_t)162 * 8 + (size_t)4 * pts_cap * 8 + (size_t)(624 + 64) * 4 + 64 * 8 * 2 +
                        (size_t)((mcap + 7) / 8 * 8) * 2 * 2;
     return (per + 15) / 16 * 16;
 }
@@ -62,7 +63,7 @@ struct Wave {
     unsigned long long prof[8];
     // LDS
     lds_u32* mt;      // 624
-    lds_u32* snap;    // 624
+    uint32_t* snap;   // 624, global workspace: written once per chunk, read on abort / sampler fallback
     lds_u16* sidx;    // 64 x 8
     lds_u32* rawcnt;  // 64
     lds_u16* perm;    // mcap
@@ -145,7 +146,7 @@ struct SamplerState {
 __device__ __forceinline__ uint32_t sgpr(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
 template <int kMin>
-__device__ __forceinline__ SamplerState sample_chunk_t(lds_u32* mt, const lds_u32* snap, lds_u16* perm, lds_u16* sidx,
+__device__ __forceinline__ SamplerState sample_chunk_t(lds_u32* mt, const uint32_t* snap, lds_u16* perm, lds_u16* sidx,
                                                        lds_u32* rawcnt, SamplerState st, int M, int nT, int lane,
                                                        int force_slow) {
     const int snap_mti = st.mti;
@@ -286,12 +287,12 @@ __device__ __forceinline__ SamplerState sample_chunk_t(lds_u32* mt, const lds_u3
     return st;
 }
 
-__device__ __noinline__ SamplerState sample_chunk(lds_u32* mt_, const lds_u32* snap_, lds_u16* perm_, lds_u16* sidx_,
+__device__ __noinline__ SamplerState sample_chunk(lds_u32* mt_, const uint32_t* snap_, lds_u16* perm_, lds_u16* sidx_,
                                                   lds_u32* rawcnt_, SamplerState st, int M_, int kMin_, int nT_,
                                                   int lane, int force_slow_) {
     // everything but `lane` is wave-uniform: move it to scalar registers
     lds_u32* mt = (lds_u32*)(uintptr_t)sgpr((uint32_t)(uintptr_t)mt_);
-    const lds_u32* snap = (const lds_u32*)(uintptr_t)sgpr((uint32_t)(uintptr_t)snap_);
+    const uint32_t* snap = snap_;
     lds_u16* perm = (lds_u16*)(uintptr_t)sgpr((uint32_t)(uintptr_t)perm_);
     lds_u16* sidx = (lds_u16*)(uintptr_t)sgpr((uint32_t)(uintptr_t)sidx_);
     lds_u32* rawcnt = (lds_u32*)(uintptr_t)sgpr((uint32_t)(uintptr_t)rawcnt_);
@@ -966,6 +967,7 @@ __device__ Report lo_ransac(Wave& w_io, const RansacCfg& cfg, const double* gx, 
         // ---- snapshot the generator, draw the chunk's samples (wave-uniform, sequential) ----
         for (int i = lane; i < 624; i += 64) w.snap[i] = w.mt[i];
         const int snap_mti = w.mti;
+        wave_mem_sync();  // the snapshot is read back by other lanes (fallback sampler, rollback)
         wave_lds_sync();
         unsigned long long tp0 = __builtin_readcyclecounter();
         ss.mti = w.mti;
@@ -1332,14 +1334,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(kTvgWavesPe
     w.lpts = w.jacA + 162;
     w.pts_cap = pts_cap;
     w.mt = reinterpret_cast<lds_u32*>(base + (162 + (size_t)4 * pts_cap) * 8);
-    w.snap = w.mt + 624;
-    w.rawcnt = w.snap + 624;
+    w.rawcnt = w.mt + 624;
     w.sidx = reinterpret_cast<lds_u16*>(w.rawcnt + 64);
     w.perm = w.sidx + 64 * 8;
     w.inl = w.perm + (mcap + 7) / 8 * 8;
     w.mcap = mcap;
     const size_t gw = (size_t)blockIdx.x * (blockDim.x >> 6) + wid;
     w.ws = ws_all + gw * tvg_ws_doubles(mcap);
+    w.snap = reinterpret_cast<uint32_t*>(w.ws + (size_t)W_NUM_ARRAYS * mcap + kModelDoubles);
     w.masks = mask_ws_all + gw * tvg_ws_bytes_extra(mcap);
 
     for (;;) {
@@ -1362,7 +1364,7 @@ uint32_t tvg_pts_cap(uint32_t mcap, int waves_per_block) {
     const size_t budget = 160 * 1024 / ((size_t)waves_per_block * kTvgWavesPerSimd);
     const size_t other = tvg_lds_bytes(mcap, 0, 1) + 64;
     if (other >= budget) return 0;
-    const size_t cap = (budget - other) / 32 / 64 * 64;
+    const size_t cap = (budget - other) / 32 / 2 * 2;  // 4 arrays of doubles, kept 16-byte aligned
     return (uint32_t)(cap < mcap ? cap : mcap);
 }
 
