@@ -3,20 +3,25 @@
 // and the watermark test.
 //
 // Mapping.  A persistent grid of wavefronts pulls image pairs from a queue; ONE WAVE owns one
-// pair at a time (no workgroup barriers anywhere), and inside the wave the 64 lanes are
+// pair at a time (no workgroup barriers anywhere; 2 waves per SIMD), and inside the wave the 64
+// lanes are
 //   * 64 RANSAC trials for the minimal solvers (one trial per lane, tvg_math.h),
-//   * 64 strided correspondences for residual scoring, support counting, normalisation sums and
+//   * 64 strided correspondences for inlier counting, residual scoring, normalisation sums and
 //     A^T A accumulation (the fixed 64-way strided + butterfly order of the oracle's det_sum64,
 //     which is exactly what a wave computes with __shfl_xor),
-//   * one redundant copy of the small dense solves of the local-optimisation step (all lanes
-//     run the same Jacobi on the same wave-uniform A^T A: no divergence, no broadcast).
+//   * cooperating workers on the single dense problems of the local-optimisation step: the
+//     disjoint rotations of a Jacobi round, the sign-change brackets of a root-finding level.
 // RANSAC is sequential by definition (the adaptive trial count depends on the best model so
-// far); what is data-INdependent is the sample stream, so per 64-trial chunk the wave first draws
-// the 64 samples (mt19937 + libstdc++'s Lemire uniform_int + the persistent partial Fisher-Yates
-// permutation, replayed exactly), solves the 64 minimal problems in parallel, then replays
-// acceptance / local optimisation / early exit in trial order.  If a RANSAC stops inside a
-// chunk, the PRNG is rolled back to the position the sequential algorithm would have left it in
-// (snapshot + recorded draw counts), because the next RANSAC of the pair continues the stream.
+// far); what is data-INdependent is the sample stream.  So per 64-trial chunk the wave draws the
+// 64 samples (mt19937 + libstdc++'s Lemire uniform_int + the persistent partial Fisher-Yates
+// permutation, reproduced exactly; sample_chunk), solves the 64 minimal problems in parallel
+// (solve_chunk), counts the inliers of every resulting model (count_chunk), and then replays only
+// the trials that can matter - a model whose count reaches the best so far, or the first trial at
+// the adaptive limit - in trial order, re-scoring them in full (lo_ransac).  If a RANSAC stops
+// inside a chunk, the PRNG is rolled back to the position the sequential algorithm would have left
+// it in (snapshot + recorded draw counts), because the next RANSAC of the pair continues the stream.
+// Every phase is its own __noinline__ function with by-value, scalarised arguments: they are
+// register-allocated separately, so the 128-VGPR budget spills only inside the lane-local solvers.
 //
 // FP64 everywhere, -ffp-contract=off, IEEE divide/sqrt: results are bit-identical to
 // oracle/tvg_oracle.cc (inlier masks, configs, model bit patterns).
