@@ -23,7 +23,7 @@
 // outputs of a unit to their maximum (8 x v_max3/v_max) and keeps the top two of those maxima
 // plus the tile of the best, 13 VALU per 16 outputs = 0.8/output, which leaves the matrix pipe as
 // the limiter.  The row's exact second-largest value is completed by resolve_index_kernel from
-// the winning tile (see valu16).  Everything else is moved off the VALU:
+// the winning tile (see `phase` below).  Everything else is moved off the VALU:
 //   * zero point: the matrix core is signed, the arena holds a' = a - 128 (bytes ^ 0x80) and
 //         sum a*b = sum a'*b' + 128*SX_i + 128*SY_j - 2^21        (SX, SY = byte sums, int32 exact)
 //     The MFMA's A operand is the streamed Y tile and its B operand the resident X tile, so a
@@ -40,8 +40,8 @@
 // B-operand tiles resident in registers) = a 1024-row block of X; Y streams through LDS in
 // 256-row chunks by direct-to-LDS DMA, double buffered, one barrier per chunk; the prepared
 // arena is pre-swizzled so the linear DMA image is bank-conflict-free for ds_read_b128.
-// Each wave software-pipelines: the 4 MFMAs of unit u+1 are issued in front of the 24 VALU of
-// unit u (unit = 32 Y rows x 32 X rows), two accumulator sets.
+// Each wave software-pipelines: the 4 MFMAs of unit u+1 are interleaved with the 13 VALU of unit u
+// (unit = 32 Y rows x 32 X rows), two accumulator sets.
 #include <climits>
 
 #include "amc_internal.h"

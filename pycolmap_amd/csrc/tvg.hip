@@ -57,7 +57,7 @@ __host__ __device__ inline size_t tvg_ws_bytes_extra(uint32_t mcap) { return (si
 
 // LDS objects are addressed through address-space-3 pointers so that every access is a ds_*
 // instruction (a generic pointer makes the compiler emit flat_* loads, which take the
-// vector-memory path and cost several hundred cycles each at one wave per SIMD).
+// vector-memory path and cost several hundred cycles each at this occupancy).
 #define AMC_LDS __attribute__((address_space(3)))
 typedef AMC_LDS double lds_f64;
 typedef AMC_LDS uint32_t lds_u32;
@@ -756,7 +756,7 @@ __device__ __forceinline__ double residual_t(const double (&m)[9], double a, dou
     return KIND == K_H ? h_residual(m, a, b, c, d) : (KIND == K_T ? t_residual(m, a, b, c, d) : sampson(m, a, b, c, d));
 }
 // inliers of U consecutive full 64-point batches starting at k0: U independent residual chains in
-// flight (at one wave per SIMD nothing else hides the FP64 and LDS latencies)
+// flight (at two waves per SIMD little else hides the FP64 and LDS latencies)
 template <bool L, int KIND, int U>
 __device__ __forceinline__ int count_batches(const double (&m)[9], const Pts& P, int k0, double max_res, int lane) {
     double a[U], b[U], c[U], d[U];
