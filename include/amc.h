@@ -157,7 +157,7 @@ typedef struct amc_tvg_opts {
     int32_t multiple_ignore_watermark;
     int32_t force_H_use;
     int32_t compute_relative_pose; /* must be 0 (next) */
-    int32_t multiple_models;       /* must be 0 (next) */
+    int32_t multiple_models;       /* EstimateMultipleTwoViewGeometries: see amc_verify_result.inlier_mask */
     double min_E_F_inlier_ratio;
     double max_H_inlier_ratio;
     double watermark_min_inlier_ratio;
@@ -191,8 +191,11 @@ typedef struct amc_tvg {
 typedef struct amc_verify_result {
     size_t npairs;
     amc_tvg* tvg;          /* npairs */
-    uint8_t* inlier_mask;  /* one byte per input match, same CSR offsets as the input;
-                              inlier_matches = matches[mask] (ExtractInlierMatches) */
+    uint8_t* inlier_mask;  /* one byte per input match, same CSR offsets as the input: 0 = outlier,
+                              g + 1 = inlier of the g-th estimated geometry (always 1 unless
+                              multiple_models).  inlier_matches = the matches with a non-zero byte,
+                              ordered by (byte, position): ExtractInlierMatches, and for a MULTIPLE
+                              geometry the per-geometry lists one after the other */
     double device_ms;      /* first launch -> results on host */
     double kernel_ms;      /* verification kernel launches, HIP events on the stream */
     uint32_t kernel_launches;

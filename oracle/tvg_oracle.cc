@@ -1122,6 +1122,64 @@ std::vector<Mat3> estimate_e5(const std::vector<Pt>& p1, const std::vector<Pt>& 
 // ----------------------------------------------------------------------------------------------
 // C API (ctypes) for tests and the CPU baseline
 // ----------------------------------------------------------------------------------------------
+// EstimateMultipleTwoViewGeometries (colmap/estimators/two_view_geometry.cc), the multiple_models
+// path: estimate, set the inliers aside, estimate again on what remains, until a round comes back
+// DEGENERATE.  WATERMARK rounds are dropped (their inliers still leave the pool) when
+// multiple_ignore_watermark is set.  No geometry -> DEGENERATE; one -> that geometry; several ->
+// config MULTIPLE whose inlier matches are the geometries' inlier matches one after the other (the
+// models of a MULTIPLE geometry stay default-constructed).  Every round reseeds like any other
+// EstimateTwoViewGeometry call here (D4).  inlier_mask[i] = 1 + index of the geometry match i belongs
+// to (0: none), which also encodes COLMAP's concatenation order.
+Tvg estimate_multiple_two_view_geometries(const Camera& c1, const std::vector<Pt>& pts1, const Camera& c2,
+                                          const std::vector<Pt>& pts2, const uint32_t* matches, size_t M,
+                                          const TvgOptions& o, uint32_t seed) {
+    TvgOptions single = o;
+    single.multiple_models = 0;
+    std::vector<size_t> remaining(M);
+    for (size_t i = 0; i < M; ++i) remaining[i] = i;
+    std::vector<Tvg> geometries;
+    std::vector<char> label(M, 0);
+    for (int round = 0; round < 254; ++round) {
+        std::vector<uint32_t> rm(2 * remaining.size());
+        for (size_t k = 0; k < remaining.size(); ++k) {
+            rm[2 * k] = matches[2 * remaining[k]];
+            rm[2 * k + 1] = matches[2 * remaining[k] + 1];
+        }
+        Tvg g = estimate_two_view_geometry(c1, pts1, c2, pts2, rm.data(), remaining.size(), single, seed);
+        if (g.config == DEGENERATE) break;
+        const bool keep = !(o.multiple_ignore_watermark && g.config == WATERMARK);
+        if (keep) geometries.push_back(g);
+        std::vector<size_t> next;
+        for (size_t k = 0; k < remaining.size(); ++k) {
+            const bool in = k < g.inlier_mask.size() && g.inlier_mask[k];
+            if (in) {
+                if (keep) label[remaining[k]] = static_cast<char>(geometries.size());
+            } else {
+                next.push_back(remaining[k]);
+            }
+        }
+        if (next.size() == remaining.size()) break;  // nothing left the pool: COLMAP would spin here
+        remaining.swap(next);
+    }
+    Tvg out;
+    out.inlier_mask = label;
+    if (geometries.empty()) {
+        out.config = DEGENERATE;
+        std::fill(out.inlier_mask.begin(), out.inlier_mask.end(), 0);
+    } else if (geometries.size() == 1) {
+        const Tvg& g = geometries[0];
+        out.config = g.config;
+        out.E = g.E; out.F = g.F; out.H = g.H;
+        out.num_inliers = g.num_inliers;
+        for (int i = 0; i < 4; ++i) out.trials[i] = g.trials[i];
+        for (int i = 0; i < 3; ++i) out.inl[i] = g.inl[i];
+    } else {
+        out.config = MULTIPLE;
+        for (const Tvg& g : geometries) out.num_inliers += g.num_inliers;
+    }
+    return out;
+}
+
 extern "C" {
 
 struct oracle_tvg_options {
@@ -1213,13 +1271,15 @@ int oracle_estimate_two_view_geometry(const oracle_camera* cam1, const double* p
                                       oracle_tvg_result* out, char* inlier_mask) {
     const Camera c1 = to_cam(cam1), c2 = to_cam(cam2);
     if (!camera_supported(c1) || !camera_supported(c2)) return -1;
-    if (opts->multiple_models || opts->compute_relative_pose) return -1;
+    if (opts->compute_relative_pose) return -1;
     for (size_t i = 0; i < M; ++i)
         if (matches[2 * i] >= n1 || matches[2 * i + 1] >= n2) return -1;
     std::vector<Pt> a(n1), b(n2);
     for (size_t i = 0; i < n1; ++i) a[i] = Pt{pts1[2 * i], pts1[2 * i + 1]};
     for (size_t i = 0; i < n2; ++i) b[i] = Pt{pts2[2 * i], pts2[2 * i + 1]};
-    const Tvg g = estimate_two_view_geometry(c1, a, c2, b, matches, M, to_opts(opts), seed);
+    const Tvg g = opts->multiple_models
+                      ? estimate_multiple_two_view_geometries(c1, a, c2, b, matches, M, to_opts(opts), seed)
+                      : estimate_two_view_geometry(c1, a, c2, b, matches, M, to_opts(opts), seed);
     out->config = g.config;
     out->num_inliers = static_cast<int32_t>(g.num_inliers);
     std::memcpy(out->E, g.E.m, sizeof out->E);

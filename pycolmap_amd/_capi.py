@@ -380,9 +380,11 @@ class Context:
             else:
                 tvg = np.zeros(0, dtype=TVG_DTYPE)
             total = m.shape[0]
-            mask = (np.ctypeslib.as_array(res.inlier_mask, shape=(total,)).astype(bool) if total
-                    else np.zeros(0, dtype=bool))
-            stats = dict(device_ms=float(res.device_ms), kernel_ms=float(res.kernel_ms))
+            labels = (np.ctypeslib.as_array(res.inlier_mask, shape=(total,)).copy() if total
+                      else np.zeros(0, dtype=np.uint8))
+            mask = labels.astype(bool)
+            # inlier_labels: 1 + index of the geometry a match belongs to (multiple_models), else 0 / 1
+            stats = dict(device_ms=float(res.device_ms), kernel_ms=float(res.kernel_ms), inlier_labels=labels)
         finally:
             self._lib.amc_verify_result_free(C.byref(res))
         return tvg, mask, stats

@@ -802,9 +802,11 @@ static int verify_impl(amc_ctx* c, int mode, const uint32_t* slot1, const uint32
         return fail(AMC_E_INVALID, "amc_verify_pairs: NULL pair arrays");
     amc_tvg_opts o;
     if (opts_in) o = *opts_in; else amc_tvg_opts_default(&o);
-    if (o.compute_relative_pose || o.multiple_models)
-        return fail(AMC_E_INVALID, "amc_verify_pairs: compute_relative_pose / multiple_models are not "
-                    "implemented (SURVEY.md 8f rank 4)");
+    if (o.compute_relative_pose)
+        return fail(AMC_E_INVALID, "amc_verify_pairs: compute_relative_pose is not implemented "
+                    "(SURVEY.md 8f rank 4)");
+    if (o.multiple_models)
+        return fail(AMC_E_INVALID, "amc_verify_pairs: internal: multiple_models reaches verify_impl");
     if (o.ransac.max_num_trials < 0 || o.ransac.min_num_trials < 0 || o.ransac.max_num_trials > (1 << 30))
         return fail(AMC_E_INVALID, "amc_verify_pairs: bad trial limits");
     const uint64_t total = npairs ? match_offsets[npairs] : 0;
@@ -1012,9 +1014,114 @@ static int verify_impl(amc_ctx* c, int mode, const uint32_t* slot1, const uint32
     return AMC_OK;
 }
 
+// EstimateMultipleTwoViewGeometries (TwoViewGeometryOptions.multiple_models): rounds of
+// EstimateTwoViewGeometry over all still-active pairs at once, each on the matches its earlier
+// rounds left over, until a pair's round comes back DEGENERATE.  All estimation runs in the kernel;
+// the host only shrinks the match lists between rounds.
+static int verify_multiple(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, size_t npairs,
+                           const uint64_t* match_offsets, const uint32_t* matches, const amc_tvg_opts& o,
+                           uint32_t seed, amc_verify_result* out) {
+    std::memset(out, 0, sizeof *out);
+    if (npairs > 0 && (!slot1 || !slot2 || !match_offsets))
+        return fail(AMC_E_INVALID, "amc_verify_pairs: NULL pair arrays");
+    const uint64_t total = npairs ? match_offsets[npairs] : 0;
+    if (total > 0 && !matches) return fail(AMC_E_INVALID, "amc_verify_pairs: NULL matches");
+    for (size_t p = 0; p < npairs; ++p)
+        if (match_offsets[p + 1] < match_offsets[p])
+            return fail(AMC_E_INVALID, "amc_verify_pairs: match_offsets not monotone at %zu", p);
+    amc_tvg_opts single = o;
+    single.multiple_models = 0;
+    VerifyPriv* priv = new (std::nothrow) VerifyPriv();
+    if (!priv) return fail(AMC_E_NOMEM, "amc_verify_pairs: out of host memory");
+    priv->tvg.resize(npairs);
+    priv->mask.assign(total, 0);
+    std::vector<std::vector<uint32_t>> remaining(npairs);  // indices into the pair's original matches
+    std::vector<std::vector<amc_tvg>> kept(npairs);
+    std::vector<size_t> active;
+    for (size_t p = 0; p < npairs; ++p) {
+        const size_t M = (size_t)(match_offsets[p + 1] - match_offsets[p]);
+        remaining[p].resize(M);
+        for (size_t i = 0; i < M; ++i) remaining[p][i] = (uint32_t)i;
+        active.push_back(p);
+    }
+    double device_ms = 0.0, kernel_ms = 0.0;
+    uint32_t launches = 0;
+    int rc = AMC_OK;
+    for (int round = 0; round < 254 && !active.empty() && rc == AMC_OK; ++round) {
+        std::vector<uint32_t> s1(active.size()), s2(active.size()), rm;
+        std::vector<uint64_t> off(active.size() + 1, 0);
+        for (size_t a = 0; a < active.size(); ++a) {
+            const size_t p = active[a];
+            s1[a] = slot1[p];
+            s2[a] = slot2[p];
+            const uint32_t* mm = matches + 2 * match_offsets[p];
+            for (uint32_t i : remaining[p]) {
+                rm.push_back(mm[2 * (size_t)i]);
+                rm.push_back(mm[2 * (size_t)i + 1]);
+            }
+            off[a + 1] = off[a] + remaining[p].size();
+        }
+        amc_verify_result r;
+        rc = verify_impl(c, 0, s1.data(), s2.data(), active.size(), off.data(), rm.data(), &single, seed, &r);
+        if (rc != AMC_OK) break;
+        device_ms += r.device_ms;
+        kernel_ms += r.kernel_ms;
+        launches += r.kernel_launches;
+        std::vector<size_t> still;
+        for (size_t a = 0; a < active.size(); ++a) {
+            const size_t p = active[a];
+            const amc_tvg& g = r.tvg[a];
+            if (g.config == AMC_TVG_DEGENERATE) continue;  // this pair is finished
+            const bool keep = !(o.multiple_ignore_watermark && g.config == AMC_TVG_WATERMARK);
+            if (keep) kept[p].push_back(g);
+            const uint8_t* mask = r.inlier_mask + off[a];
+            std::vector<uint32_t> next;
+            for (size_t k = 0; k < remaining[p].size(); ++k) {
+                if (mask[k]) {
+                    if (keep) priv->mask[match_offsets[p] + remaining[p][k]] = (uint8_t)kept[p].size();
+                } else {
+                    next.push_back(remaining[p][k]);
+                }
+            }
+            if (next.size() == remaining[p].size()) continue;  // nothing left the pool: stop, do not spin
+            remaining[p].swap(next);
+            still.push_back(p);
+        }
+        amc_verify_result_free(&r);
+        active.swap(still);
+    }
+    if (rc != AMC_OK) {
+        delete priv;
+        return rc;
+    }
+    for (size_t p = 0; p < npairs; ++p) {
+        amc_tvg& t = priv->tvg[p];
+        std::memset(&t, 0, sizeof t);
+        if (kept[p].empty()) {
+            t.config = AMC_TVG_DEGENERATE;
+            std::fill(priv->mask.begin() + match_offsets[p], priv->mask.begin() + match_offsets[p + 1], 0);
+        } else if (kept[p].size() == 1) {
+            t = kept[p][0];
+        } else {
+            t.config = AMC_TVG_MULTIPLE;  // the models of a MULTIPLE geometry stay default (zero)
+            for (const amc_tvg& g : kept[p]) t.num_inliers += g.num_inliers;
+        }
+    }
+    out->npairs = npairs;
+    out->_priv = priv;
+    out->tvg = priv->tvg.data();
+    out->inlier_mask = priv->mask.data();
+    out->device_ms = device_ms;
+    out->kernel_ms = kernel_ms;
+    out->kernel_launches = launches;
+    return AMC_OK;
+}
+
 int amc_verify_pairs(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, size_t npairs,
                      const uint64_t* match_offsets, const uint32_t* matches,
                      const amc_tvg_opts* opts_in, uint32_t seed, amc_verify_result* out) {
+    if (c && out && opts_in && opts_in->multiple_models)
+        return verify_multiple(c, slot1, slot2, npairs, match_offsets, matches, *opts_in, seed, out);
     return verify_impl(c, 0, slot1, slot2, npairs, match_offsets, matches, opts_in, seed, out);
 }
 

@@ -19,6 +19,19 @@ double NowMs() {
 }
 }  // namespace
 
+// ExtractInlierMatches; for a MULTIPLE geometry (mask byte = 1 + geometry index) the per-geometry
+// lists follow one another, as EstimateMultipleTwoViewGeometries concatenates them
+void AppendInlierMatches(const uint8_t* mask, const uint32_t* matches, size_t m, std::vector<uint32_t>* out) {
+    uint8_t top = 0;
+    for (size_t i = 0; i < m; ++i) top = std::max(top, mask[i]);
+    for (uint8_t g = 1; g <= top; ++g)
+        for (size_t i = 0; i < m; ++i)
+            if (mask[i] == g) {
+                out->push_back(matches[2 * i]);
+                out->push_back(matches[2 * i + 1]);
+            }
+}
+
 amc_tvg_opts ToAmc(const TwoViewGeometryOptions& o) {
     amc_tvg_opts t;
     amc_tvg_opts_default(&t);
@@ -180,11 +193,7 @@ void MatchController::Match(const ImagePairs& image_pairs) {
             std::memcpy(j.tvg.H.data(), g.H, sizeof g.H);
             const uint8_t* mask = vr.inlier_mask + voff[p];
             const size_t m = j.matches.size() / 2;
-            for (size_t i = 0; i < m; ++i)  // ExtractInlierMatches
-                if (mask[i]) {
-                    j.tvg.inlier_matches.push_back(j.matches[2 * i]);
-                    j.tvg.inlier_matches.push_back(j.matches[2 * i + 1]);
-                }
+            AppendInlierMatches(mask, j.matches.data(), m, &j.tvg.inlier_matches);
         }
         stats.verify_device_ms += vr.device_ms;
         stats.pairs_verified += vwhich.size();

@@ -63,6 +63,7 @@ struct TwoViewGeometryOptions {
     RANSACOptions ransac_options;
 };
 amc_tvg_opts ToAmc(const TwoViewGeometryOptions& o);
+void AppendInlierMatches(const uint8_t* mask, const uint32_t* matches, size_t m, std::vector<uint32_t>* out);
 
 using ImagePairs = std::vector<std::pair<image_t, image_t>>;
 

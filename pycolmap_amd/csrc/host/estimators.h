@@ -354,11 +354,7 @@ inline PyTwoViewGeometry EstimateTvg(const PyCamera& cam1, const PointsArray& p1
     std::memcpy(g.E.data(), t.E, sizeof t.E);
     std::memcpy(g.F.data(), t.F, sizeof t.F);
     std::memcpy(g.H.data(), t.H, sizeof t.H);
-    for (size_t i = 0; i < M; ++i)
-        if (mask[i]) {
-            g.inlier_matches.push_back(matches[2 * i]);
-            g.inlier_matches.push_back(matches[2 * i + 1]);
-        }
+    AppendInlierMatches(mask.data(), matches.data(), M, &g.inlier_matches);
     return g;
 }
 

@@ -185,7 +185,8 @@ def estimate_two_view_geometry(cam1, pts1, cam2, pts2, matches, opts=None, seed=
     return dict(config=int(res.config), config_name=CONFIG_NAMES[res.config],
                 num_inliers=int(res.num_inliers), E=np.array(res.E).reshape(3, 3),
                 F=np.array(res.F).reshape(3, 3), H=np.array(res.H).reshape(3, 3),
-                trials=list(res.trials), inl=list(res.inl), inlier_mask=mask[:len(m)].astype(bool))
+                trials=list(res.trials), inl=list(res.inl), inlier_mask=mask[:len(m)].astype(bool),
+                inlier_label=mask[:len(m)].copy())  # 1 + geometry index (multiple_models), else 0/1
 
 
 def estimate_two_view_geometry_batch(cams1, pts1, cams2, pts2, matches, opts=None, seed=0, threads=1):
@@ -221,7 +222,8 @@ def estimate_two_view_geometry_batch(cams1, pts1, cams2, pts2, matches, opts=Non
         out.append(dict(config=int(r.config), config_name=CONFIG_NAMES[r.config], num_inliers=int(r.num_inliers),
                         E=np.array(r.E).reshape(3, 3), F=np.array(r.F).reshape(3, 3), H=np.array(r.H).reshape(3, 3),
                         trials=list(r.trials), inl=list(r.inl),
-                        inlier_mask=masks[int(moff[p]):int(moff[p]) + len(mm[p])].astype(bool)))
+                        inlier_mask=masks[int(moff[p]):int(moff[p]) + len(mm[p])].astype(bool),
+                        inlier_label=masks[int(moff[p]):int(moff[p]) + len(mm[p])].copy()))
     return out
 
 

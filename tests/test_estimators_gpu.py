@@ -229,3 +229,24 @@ def test_python_estimator_api_matches_oracle():
     wc = o.estimate_two_view_geometry(ocam_p, p1, ocam_p, p2, ident, o.tvg_default_options())
     assert gc.config.name == wc["config_name"]
     np.testing.assert_array_equal(bits(gc.E), bits(wc["E"]))
+
+
+def test_multiple_models_through_the_python_api():
+    """options.multiple_models: config MULTIPLE, inlier matches = the geometries' lists one after the other."""
+    import pycolmap_amd as pc
+    rng = np.random.default_rng(17)
+    a = synth.two_view_scene(rng, num_inliers=160, num_outliers=30, extra_keypoints=5)
+    b = synth.two_view_scene(rng, num_inliers=120, num_outliers=0, extra_keypoints=5)
+    pts1 = np.concatenate([a["pts1"], b["pts1"]])
+    pts2 = np.concatenate([a["pts2"], b["pts2"]])
+    matches = np.concatenate([a["matches"].astype(np.int64),
+                              b["matches"].astype(np.int64) + [len(a["pts1"]), len(a["pts2"])]]).astype(np.uint32)
+    cam = pc.Camera(model="PINHOLE", width=a["width"], height=a["height"],
+                    params=[a["f"], a["f"], a["width"] / 2.0, a["height"] / 2.0])
+    g = pc.estimate_two_view_geometry(cam, pts1, cam, pts2, matches, dict(multiple_models=True))
+    ocam = o.make_camera("PINHOLE", a["width"], a["height"], (a["f"], a["f"], a["width"] / 2.0, a["height"] / 2.0))
+    w = o.estimate_two_view_geometry(ocam, pts1, ocam, pts2, matches, o.tvg_default_options(multiple_models=1))
+    assert g.config.name == w["config_name"] == "MULTIPLE"
+    want = np.concatenate([matches[w["inlier_label"] == k] for k in range(1, int(w["inlier_label"].max()) + 1)])
+    np.testing.assert_array_equal(g.inlier_matches, want)
+    assert len(want) >= 250

@@ -178,6 +178,60 @@ def test_invalid_inputs_raise(amc_ctx):
         amc_ctx.verify_pairs([0], [1], [0, len(bad)], bad)
     assert e.value.code == _capi.AMC_E_INVALID
     with pytest.raises(_capi.AmcError):
-        amc_ctx.verify_pairs([0], [1], [0, len(bad)], sc["matches"], _capi.tvg_options(multiple_models=1))
+        amc_ctx.verify_pairs([0], [1], [0, len(bad)], sc["matches"], _capi.tvg_options(compute_relative_pose=1))
     tvg, mask, _ = amc_ctx.verify_pairs([], [], [0], np.zeros((0, 2), np.uint32))
     assert len(tvg) == 0 and len(mask) == 0
+
+
+def two_motion_scene(rng, n_a, n_b, n_out):
+    """Matches that follow two different rigid motions (plus outliers): keypoints of two scenes glued."""
+    a = synth.two_view_scene(rng, num_inliers=n_a, num_outliers=n_out, extra_keypoints=5)
+    b = synth.two_view_scene(rng, num_inliers=n_b, num_outliers=0, extra_keypoints=5)
+    off1, off2 = len(a["pts1"]), len(a["pts2"])
+    sc = dict(a)
+    sc["pts1"] = np.concatenate([a["pts1"], b["pts1"]])
+    sc["pts2"] = np.concatenate([a["pts2"], b["pts2"]])
+    mb = b["matches"].astype(np.int64) + [off1, off2]
+    m = np.concatenate([a["matches"].astype(np.int64), mb])
+    sc["matches"] = m[rng.permutation(len(m))].astype(np.uint32)
+    return sc
+
+
+def test_multiple_models(amc_ctx):
+    """TwoViewGeometryOptions.multiple_models = EstimateMultipleTwoViewGeometries: rounds on the matches
+    the previous rounds left over.  The mask byte is 1 + the index of the geometry a match belongs to."""
+    rng = np.random.default_rng(61)
+    scenes = [two_motion_scene(rng, 200, 120, 40), two_motion_scene(rng, 150, 150, 0),
+              synth.two_view_scene(rng, num_inliers=180, num_outliers=60),            # one model only
+              synth.two_view_scene(rng, num_inliers=10, num_outliers=100),            # nothing: DEGENERATE
+              two_motion_scene(rng, 90, 60, 200)]
+    for priors, kw in (([False] * 5, dict(multiple_models=1)),
+                       ([True, False, True, False, True], dict(multiple_models=1, multiple_ignore_watermark=0)),
+                       ([False] * 5, dict(multiple_models=1, min_num_inliers=40))):
+        slots, cams = build_batch(scenes, priors)
+        amc_ctx.reserve_slots(len(slots))
+        for i, (kp, cam) in enumerate(zip(slots, cams)):
+            amc_ctx.upload_keypoints(i, kp.astype(np.float32))
+            amc_ctx.upload_camera(i, cam["model"], cam["width"], cam["height"], cam["params"], cam["prior"])
+        s1 = np.arange(0, len(slots), 2, dtype=np.uint32)
+        off = np.zeros(len(scenes) + 1, dtype=np.uint64)
+        off[1:] = np.cumsum([len(sc["matches"]) for sc in scenes])
+        matches = np.concatenate([sc["matches"] for sc in scenes])
+        tvg, mask, st = amc_ctx.verify_pairs(s1, s1 + 1, off, matches, _capi.tvg_options(**kw), seed=0)
+        names = []
+        for p, (sc, prior) in enumerate(zip(scenes, priors)):
+            cam = o.make_camera("PINHOLE", sc["width"], sc["height"],
+                                (sc["f"], sc["f"], sc["width"] / 2.0, sc["height"] / 2.0), prior=prior)
+            w = o.estimate_two_view_geometry(cam, sc["pts1"], cam, sc["pts2"], sc["matches"],
+                                             o.tvg_default_options(**kw), seed=0)
+            g = tvg[p]
+            names.append(_capi.CONFIG_NAMES[g["config"]])
+            assert names[-1] == w["config_name"], p
+            assert g["num_inliers"] == w["num_inliers"], p
+            np.testing.assert_array_equal(st["inlier_labels"][int(off[p]):int(off[p + 1])], w["inlier_label"], err_msg=str(p))
+            for k in "EFH":
+                np.testing.assert_array_equal(bits(g[k]), bits(w[k]), err_msg=f"{p} {k}")
+            if names[-1] != "MULTIPLE":
+                assert g["num_trials"].tolist() == w["trials"], p
+        assert "MULTIPLE" in names and "DEGENERATE" in names
+        assert any(n not in ("MULTIPLE", "DEGENERATE") for n in names)
