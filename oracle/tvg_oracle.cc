@@ -765,6 +765,17 @@ double cam_from_img_threshold(const Camera& c, double threshold) {
 // ----------------------------------------------------------------------------------------------
 // two_view_geometry.cc
 // ----------------------------------------------------------------------------------------------
+struct V3 { double v[3]; };
+// cam2_from_cam1 of EstimateTwoViewGeometryPose (filled when TwoViewGeometryOptions.compute_relative_pose)
+struct RelPose {
+    bool ok = false;
+    int config = UNDEFINED;       // PLANAR_OR_PANORAMIC resolved
+    Mat3 R{{1, 0, 0, 0, 1, 0, 0, 0, 1}};
+    V3 t{{0, 0, 0}};
+    double qvec[4] = {1, 0, 0, 0};
+    double tri_angle = 0.0;
+    size_t num_points3D = 0;
+};
 struct Tvg {
     int config = UNDEFINED;
     Mat3 E{}, F{}, H{};
@@ -772,7 +783,10 @@ struct Tvg {
     size_t num_inliers = 0;
     size_t trials[4] = {0, 0, 0, 0};   // E, F, H, watermark
     size_t inl[3] = {0, 0, 0};         // E, F, H support
+    RelPose pose;
 };
+RelPose estimate_relative_pose(const Camera& c1, const std::vector<Pt>& pts1, const Camera& c2,
+                               const std::vector<Pt>& pts2, const uint32_t* matches, size_t M, const Tvg& g);
 
 bool in_bbox(const Pt& p, double minx, double maxx, double miny, double maxy) {
     return p.x >= minx && p.x <= maxx && p.y >= miny && p.y <= maxy;
@@ -929,6 +943,10 @@ Tvg estimate_two_view_geometry(const Camera& c1, const std::vector<Pt>& pts1, co
     if (o.detect_watermark && best_mask != nullptr && !best_mask->empty() &&
         detect_watermark(c1, mp1, c2, mp2, num_inliers, *best_mask, o, prng, &g.trials[3]))
         g.config = WATERMARK;
+    if (o.compute_relative_pose) {
+        g.pose = estimate_relative_pose(c1, pts1, c2, pts2, matches, M, g);
+        if (g.pose.ok) g.config = g.pose.config;
+    }
     return g;
 }
 
@@ -1117,6 +1135,328 @@ std::vector<Mat3> estimate_e5(const std::vector<Pt>& p1, const std::vector<Pt>& 
     return models;
 }
 
+// ----------------------------------------------------------------------------------------------
+// Relative pose of a verified pair (colmap/estimators/two_view_geometry.cc
+// EstimateTwoViewGeometryPose; colmap/geometry/{essential_matrix,homography_matrix,triangulation,
+// pose}.cc), restated without Eigen (D1: the 3x3 / 4x4 SVDs are taken from the Jacobi
+// eigen-decomposition of A^T A; the rotations and translations they lead to do not depend on the
+// SVD's sign and ordering conventions, only the order in which the four candidate poses are tried
+// does, and that only matters when two candidates tie in the cheirality count).
+//   CALIBRATED / UNCALIBRATED:        PoseFromEssentialMatrix(E, ...)
+//   PLANAR / PANORAMIC / PLANAR_OR_..: PoseFromHomographyMatrix(H, K1, K2, ...)
+// then tri_angle = median triangulation angle of the points in front of both cameras, and
+// PLANAR_OR_PANORAMIC resolves to PANORAMIC (zero translation) or PLANAR.
+// ----------------------------------------------------------------------------------------------
+V3 v3_cross(const V3& a, const V3& b) {
+    return V3{{a.v[1] * b.v[2] - a.v[2] * b.v[1], a.v[2] * b.v[0] - a.v[0] * b.v[2], a.v[0] * b.v[1] - a.v[1] * b.v[0]}};
+}
+double v3_dot(const V3& a, const V3& b) { return a.v[0] * b.v[0] + a.v[1] * b.v[1] + a.v[2] * b.v[2]; }
+double v3_norm(const V3& a) { return std::sqrt(v3_dot(a, a)); }
+V3 v3_scale(const V3& a, double s) { return V3{{a.v[0] * s, a.v[1] * s, a.v[2] * s}}; }
+V3 v3_normalized(const V3& a) {
+    const double n = v3_norm(a);
+    return V3{{a.v[0] / n, a.v[1] / n, a.v[2] / n}};
+}
+V3 mat3_vec(const Mat3& a, const V3& x) {
+    V3 r;
+    for (int i = 0; i < 3; ++i) r.v[i] = a.m[3 * i] * x.v[0] + a.m[3 * i + 1] * x.v[1] + a.m[3 * i + 2] * x.v[2];
+    return r;
+}
+double mat3_det(const Mat3& a) {
+    const double* m = a.m;
+    return m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6]);
+}
+Mat3 mat3_inv(const Mat3& a) {
+    const double* m = a.m;
+    const double d = mat3_det(a);
+    Mat3 r;
+    r.m[0] = (m[4] * m[8] - m[5] * m[7]) / d; r.m[1] = (m[2] * m[7] - m[1] * m[8]) / d; r.m[2] = (m[1] * m[5] - m[2] * m[4]) / d;
+    r.m[3] = (m[5] * m[6] - m[3] * m[8]) / d; r.m[4] = (m[0] * m[8] - m[2] * m[6]) / d; r.m[5] = (m[2] * m[3] - m[0] * m[5]) / d;
+    r.m[6] = (m[3] * m[7] - m[4] * m[6]) / d; r.m[7] = (m[1] * m[6] - m[0] * m[7]) / d; r.m[8] = (m[0] * m[4] - m[1] * m[3]) / d;
+    return r;
+}
+Mat3 calibration_matrix(const Camera& c) {
+    Mat3 k{};
+    if (c.model_id == 0) { k.m[0] = c.params[0]; k.m[4] = c.params[0]; k.m[2] = c.params[1]; k.m[5] = c.params[2]; }
+    else { k.m[0] = c.params[0]; k.m[4] = c.params[1]; k.m[2] = c.params[2]; k.m[5] = c.params[3]; }
+    k.m[8] = 1.0;
+    return k;
+}
+
+// A = U diag(S) V^T, S descending, from the eigen-decomposition of A^T A.  u_k = A v_k / s_k for the two
+// largest singular values, u_2 = u_0 x u_1 (so det U = +1 and a vanishing third singular value is fine).
+void svd3(const Mat3& A, Mat3* U, double S[3], Mat3* V) {
+    double ata[9], ev[9];
+    const Mat3 At = mat3_t(A);
+    const Mat3 P = mat3_mul(At, A);
+    std::memcpy(ata, P.m, sizeof ata);
+    jacobi_eigen(3, ata, ev);
+    int ord[3] = {0, 1, 2};
+    for (int i = 0; i < 3; ++i)
+        for (int j = i + 1; j < 3; ++j)
+            if (ata[4 * ord[j]] > ata[4 * ord[i]]) std::swap(ord[i], ord[j]);
+    V3 vcol[3], ucol[3];
+    for (int k = 0; k < 3; ++k) {
+        S[k] = std::sqrt(std::max(ata[4 * ord[k]], 0.0));
+        vcol[k] = V3{{ev[0 * 3 + ord[k]], ev[1 * 3 + ord[k]], ev[2 * 3 + ord[k]]}};
+    }
+    for (int k = 0; k < 2; ++k) {
+        if (S[k] == 0.0) {  // rank-deficient input (the all-zero E): fall back to the unit vector, U = I
+            ucol[k] = V3{{k == 0 ? 1.0 : 0.0, k == 1 ? 1.0 : 0.0, 0.0}};
+            continue;
+        }
+        const double inv = 1.0 / S[k];
+        ucol[k] = v3_scale(mat3_vec(A, vcol[k]), inv);
+    }
+    ucol[2] = v3_cross(ucol[0], ucol[1]);
+    for (int i = 0; i < 3; ++i)
+        for (int k = 0; k < 3; ++k) { U->m[3 * i + k] = ucol[k].v[i]; V->m[3 * i + k] = vcol[k].v[i]; }
+}
+
+// DecomposeEssentialMatrix
+void decompose_essential(const Mat3& E, Mat3* R1, Mat3* R2, V3* t) {
+    Mat3 U, V;
+    double S[3];
+    svd3(E, &U, S, &V);
+    Mat3 Vt = mat3_t(V);
+    if (mat3_det(U) < 0) for (double& x : U.m) x = -x;
+    if (mat3_det(Vt) < 0) for (double& x : Vt.m) x = -x;
+    const Mat3 W{{0, 1, 0, -1, 0, 0, 0, 0, 1}};
+    *R1 = mat3_mul(mat3_mul(U, W), Vt);
+    *R2 = mat3_mul(mat3_mul(U, mat3_t(W)), Vt);
+    *t = v3_normalized(V3{{U.m[2], U.m[5], U.m[8]}});
+}
+
+// TriangulatePoint: DLT, the right singular vector of the smallest singular value of the 4 x 4 system,
+// dehomogenised.  P1 = [I | 0], P2 = [R | t].
+V3 triangulate_point(const Mat3& R, const V3& t, const Pt& x1, const Pt& x2) {
+    double A[4][4];
+    const double P1[3][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}};
+    double P2[3][4];
+    for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) P2[i][j] = R.m[3 * i + j]; P2[i][3] = t.v[i]; }
+    for (int j = 0; j < 4; ++j) {
+        A[0][j] = x1.x * P1[2][j] - P1[0][j];
+        A[1][j] = x1.y * P1[2][j] - P1[1][j];
+        A[2][j] = x2.x * P2[2][j] - P2[0][j];
+        A[3][j] = x2.y * P2[2][j] - P2[1][j];
+    }
+    double ata[16], ev[16];
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            double sum = 0.0;
+            for (int k = 0; k < 4; ++k) sum += A[k][i] * A[k][j];
+            ata[4 * i + j] = sum;
+        }
+    jacobi_eigen(4, ata, ev);
+    int best = 0;
+    for (int i = 1; i < 4; ++i)
+        if (ata[5 * i] < ata[5 * best]) best = i;
+    const double w = ev[3 * 4 + best];
+    return V3{{ev[0 * 4 + best] / w, ev[1 * 4 + best] / w, ev[2 * 4 + best] / w}};
+}
+
+// CheckCheirality: the triangulated points in front of both cameras (and not absurdly far)
+void check_cheirality(const Mat3& R, const V3& t, const std::vector<Pt>& p1, const std::vector<Pt>& p2,
+                      std::vector<V3>* points3D) {
+    const double kMinDepth = std::numeric_limits<double>::epsilon();
+    const double max_depth = 1000.0 * v3_norm(mat3_vec(mat3_t(R), t));
+    const double n2 = std::sqrt(R.m[2] * R.m[2] + R.m[5] * R.m[5] + R.m[8] * R.m[8]);  // |P2.col(2)|
+    points3D->clear();
+    for (size_t i = 0; i < p1.size(); ++i) {
+        const V3 X = triangulate_point(R, t, p1[i], p2[i]);
+        const double depth1 = (0.0 * X.v[0] + 0.0 * X.v[1] + 1.0 * X.v[2] + 0.0 * 1.0) * 1.0;
+        if (depth1 > kMinDepth && depth1 < max_depth) {
+            const double depth2 = (R.m[6] * X.v[0] + R.m[7] * X.v[1] + R.m[8] * X.v[2] + t.v[2] * 1.0) * n2;
+            if (depth2 > kMinDepth && depth2 < max_depth) points3D->push_back(X);
+        }
+    }
+}
+
+struct PoseCandidates { std::vector<Mat3> R; std::vector<V3> t; };
+
+// the candidate (later ones win ties) with the most points in front of both cameras
+void best_candidate(const PoseCandidates& c, const std::vector<Pt>& p1, const std::vector<Pt>& p2, Mat3* R, V3* t,
+                    std::vector<V3>* points3D) {
+    points3D->clear();
+    for (size_t i = 0; i < c.R.size(); ++i) {
+        std::vector<V3> cand;
+        check_cheirality(c.R[i], c.t[i], p1, p2, &cand);
+        if (cand.size() >= points3D->size()) { *R = c.R[i]; *t = c.t[i]; *points3D = cand; }
+    }
+}
+
+// PoseFromEssentialMatrix
+void pose_from_essential(const Mat3& E, const std::vector<Pt>& p1, const std::vector<Pt>& p2, Mat3* R, V3* t,
+                         std::vector<V3>* points3D) {
+    Mat3 R1, R2;
+    V3 tt;
+    decompose_essential(E, &R1, &R2, &tt);
+    PoseCandidates c;
+    c.R = {R1, R2, R1, R2};
+    c.t = {tt, tt, v3_scale(tt, -1.0), v3_scale(tt, -1.0)};
+    best_candidate(c, p1, p2, R, t, points3D);
+}
+
+int sign_of(double x) { return (0.0 < x) - (x < 0.0); }
+double opposite_of_minor(const Mat3& S, int row, int col) {
+    const int col1 = col == 0 ? 1 : 0, col2 = col == 2 ? 1 : 2;
+    const int row1 = row == 0 ? 1 : 0, row2 = row == 2 ? 1 : 2;
+    return S.m[3 * row1 + col2] * S.m[3 * row2 + col1] - S.m[3 * row1 + col1] * S.m[3 * row2 + col2];
+}
+Mat3 homography_rotation(const Mat3& Hn, const V3& tstar, const V3& n, double v) {
+    Mat3 M;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) M.m[3 * i + j] = (i == j ? 1.0 : 0.0) - (2.0 / v) * tstar.v[i] * n.v[j];
+    return mat3_mul(Hn, M);
+}
+// DecomposeHomographyMatrix (Malis & Vargas, "Deeper understanding of the homography decomposition
+// for vision-based control", analytical method)
+void decompose_homography(const Mat3& H, const Mat3& K1, const Mat3& K2, PoseCandidates* out) {
+    Mat3 Hn = mat3_mul(mat3_mul(mat3_inv(K2), H), K1);
+    {
+        Mat3 U, V;
+        double S[3];
+        svd3(Hn, &U, S, &V);
+        for (double& x : Hn.m) x /= S[1];
+    }
+    if (mat3_det(Hn) < 0) for (double& x : Hn.m) x *= -1.0;
+    Mat3 S = mat3_mul(mat3_t(Hn), Hn);
+    S.m[0] -= 1.0; S.m[4] -= 1.0; S.m[8] -= 1.0;
+    double inf_norm = 0.0;  // lpNorm<Infinity> of a matrix expression: largest absolute coefficient
+    for (double x : S.m) inf_norm = std::max(inf_norm, std::fabs(x));
+    out->R.clear(); out->t.clear();
+    if (inf_norm < 1e-3) {  // H is a rotation
+        out->R = {Hn};
+        out->t = {V3{{0, 0, 0}}};
+        return;
+    }
+    const double M00 = opposite_of_minor(S, 0, 0), M11 = opposite_of_minor(S, 1, 1), M22 = opposite_of_minor(S, 2, 2);
+    const double rtM00 = std::sqrt(M00), rtM11 = std::sqrt(M11), rtM22 = std::sqrt(M22);
+    const double M01 = opposite_of_minor(S, 0, 1), M12 = opposite_of_minor(S, 1, 2), M02 = opposite_of_minor(S, 0, 2);
+    const int e12 = sign_of(M12), e02 = sign_of(M02), e01 = sign_of(M01);
+    const double nS[3] = {std::fabs(S.m[0]), std::fabs(S.m[4]), std::fabs(S.m[8])};
+    int idx = 0;  // std::max_element: first maximum
+    for (int i = 1; i < 3; ++i)
+        if (nS[i] > nS[idx]) idx = i;
+    V3 np1, np2;
+    if (idx == 0) {
+        np1 = V3{{S.m[0], S.m[1] + rtM22, S.m[2] + e12 * rtM11}};
+        np2 = V3{{S.m[0], S.m[1] - rtM22, S.m[2] - e12 * rtM11}};
+    } else if (idx == 1) {
+        np1 = V3{{S.m[1] + rtM22, S.m[4], S.m[5] - e02 * rtM00}};
+        np2 = V3{{S.m[1] - rtM22, S.m[4], S.m[5] + e02 * rtM00}};
+    } else {
+        np1 = V3{{S.m[2] + e01 * rtM11, S.m[5] + rtM00, S.m[8]}};
+        np2 = V3{{S.m[2] - e01 * rtM11, S.m[5] - rtM00, S.m[8]}};
+    }
+    const double traceS = S.m[0] + S.m[4] + S.m[8];
+    const double v = 2.0 * std::sqrt(1.0 + traceS - M00 - M11 - M22);
+    const double ESii = sign_of(S.m[4 * idx]);
+    const double r_2 = 2 + traceS + v, nt_2 = 2 + traceS - v;
+    const double r = std::sqrt(r_2), n_t = std::sqrt(nt_2);
+    const V3 n1 = v3_normalized(np1), n2 = v3_normalized(np2);
+    const double half_nt = 0.5 * n_t, esii_t_r = ESii * r;
+    V3 t1s, t2s;
+    for (int i = 0; i < 3; ++i) {
+        t1s.v[i] = half_nt * (esii_t_r * n2.v[i] - n_t * n1.v[i]);
+        t2s.v[i] = half_nt * (esii_t_r * n1.v[i] - n_t * n2.v[i]);
+    }
+    const Mat3 R1 = homography_rotation(Hn, t1s, n1, v);
+    const V3 t1 = mat3_vec(R1, t1s);
+    const Mat3 R2 = homography_rotation(Hn, t2s, n2, v);
+    const V3 t2 = mat3_vec(R2, t2s);
+    out->R = {R1, R1, R2, R2};
+    out->t = {t1, v3_scale(t1, -1.0), t2, v3_scale(t2, -1.0)};
+}
+
+// Eigen::Quaterniond(rotation matrix) -> (w, x, y, z)
+void rotation_to_quaternion(const Mat3& R, double q[4]) {
+    const double* m = R.m;
+    double t = m[0] + m[4] + m[8];
+    if (t > 0.0) {
+        t = std::sqrt(t + 1.0);
+        q[0] = 0.5 * t;
+        t = 0.5 / t;
+        q[1] = (m[7] - m[5]) * t;
+        q[2] = (m[2] - m[6]) * t;
+        q[3] = (m[3] - m[1]) * t;
+    } else {
+        int i = 0;
+        if (m[4] > m[0]) i = 1;
+        if (m[8] > m[4 * i]) i = 2;
+        const int j = (i + 1) % 3, k = (j + 1) % 3;
+        t = std::sqrt(m[4 * i] - m[4 * j] - m[4 * k] + 1.0);
+        q[1 + i] = 0.5 * t;
+        t = 0.5 / t;
+        q[0] = (m[3 * k + j] - m[3 * j + k]) * t;
+        q[1 + j] = (m[3 * j + i] + m[3 * i + j]) * t;
+        q[1 + k] = (m[3 * k + i] + m[3 * i + k]) * t;
+    }
+}
+
+// CalculateTriangulationAngles + Median
+double median_tri_angle(const V3& c1, const V3& c2, const std::vector<V3>& X) {
+    const double baseline2 = (c1.v[0] - c2.v[0]) * (c1.v[0] - c2.v[0]) + (c1.v[1] - c2.v[1]) * (c1.v[1] - c2.v[1]) +
+                             (c1.v[2] - c2.v[2]) * (c1.v[2] - c2.v[2]);
+    std::vector<double> ang(X.size());
+    for (size_t i = 0; i < X.size(); ++i) {
+        double r1 = 0.0, r2 = 0.0;
+        for (int k = 0; k < 3; ++k) {
+            r1 += (X[i].v[k] - c1.v[k]) * (X[i].v[k] - c1.v[k]);
+            r2 += (X[i].v[k] - c2.v[k]) * (X[i].v[k] - c2.v[k]);
+        }
+        const double den = 2.0 * std::sqrt(r1 * r2);
+        if (den == 0.0) { ang[i] = 0.0; continue; }
+        const double nom = r1 + r2 - baseline2;
+        const double a = std::fabs(std::acos(nom / den));
+        ang[i] = std::min(a, M_PI - a);
+    }
+    std::sort(ang.begin(), ang.end());
+    const size_t mid = ang.size() / 2;
+    if (ang.size() % 2 == 0) return 0.5 * ang[mid] + 0.5 * ang[mid - 1];
+    return ang[mid];
+}
+
+// EstimateTwoViewGeometryPose.  pts: keypoints; matches/inlier_mask as produced by the estimation.
+RelPose estimate_relative_pose(const Camera& c1, const std::vector<Pt>& pts1, const Camera& c2,
+                               const std::vector<Pt>& pts2, const uint32_t* matches, size_t M, const Tvg& g) {
+    RelPose out;
+    out.config = g.config;
+    if (g.config != CALIBRATED && g.config != UNCALIBRATED && g.config != PLANAR && g.config != PANORAMIC &&
+        g.config != PLANAR_OR_PANORAMIC)
+        return out;
+    std::vector<Pt> n1, n2;
+    for (size_t i = 0; i < M; ++i)
+        if (i < g.inlier_mask.size() && g.inlier_mask[i]) {
+            n1.push_back(cam_from_img(c1, pts1[matches[2 * i]]));
+            n2.push_back(cam_from_img(c2, pts2[matches[2 * i + 1]]));
+        }
+    std::vector<V3> X;
+    if (g.config == CALIBRATED || g.config == UNCALIBRATED) {
+        // g.E also for UNCALIBRATED ("most likely leads to an ill-defined reconstruction", upstream): the E
+        // model of the calibrated path, or the default all-zero E of the uncalibrated path
+        pose_from_essential(g.E, n1, n2, &out.R, &out.t, &X);
+    } else {
+        PoseCandidates c;
+        decompose_homography(g.H, calibration_matrix(c1), calibration_matrix(c2), &c);
+        best_candidate(c, n1, n2, &out.R, &out.t, &X);
+    }
+    out.ok = true;
+    rotation_to_quaternion(out.R, out.qvec);
+    out.num_points3D = X.size();
+    if (X.empty()) {
+        out.tri_angle = 0.0;
+    } else {
+        const V3 c2c = v3_scale(mat3_vec(mat3_t(out.R), out.t), -1.0);
+        out.tri_angle = median_tri_angle(V3{{0, 0, 0}}, c2c, X);
+    }
+    if (g.config == PLANAR_OR_PANORAMIC) {
+        if (v3_norm(out.t) == 0.0) { out.config = PANORAMIC; out.tri_angle = 0.0; }
+        else out.config = PLANAR;
+    }
+    return out;
+}
+
 }  // namespace
 
 // ----------------------------------------------------------------------------------------------
@@ -1214,7 +1554,21 @@ struct oracle_tvg_result {
     double E[9], F[9], H[9];
     int64_t trials[4];
     int64_t inl[3];
+    // EstimateTwoViewGeometryPose (compute_relative_pose); pose_ok = 0 leaves the defaults (identity, 0)
+    int32_t pose_ok;
+    int32_t num_points3D;
+    double qvec[4], tvec[3], R[9];
+    double tri_angle;
 };
+
+static void put_pose(const RelPose& p, oracle_tvg_result* out) {
+    out->pose_ok = p.ok ? 1 : 0;
+    out->num_points3D = static_cast<int32_t>(p.num_points3D);
+    std::memcpy(out->qvec, p.qvec, sizeof out->qvec);
+    std::memcpy(out->tvec, p.t.v, sizeof out->tvec);
+    std::memcpy(out->R, p.R.m, sizeof out->R);
+    out->tri_angle = p.tri_angle;
+}
 
 static TvgOptions to_opts(const oracle_tvg_options* o) {
     TvgOptions t;
@@ -1271,7 +1625,6 @@ int oracle_estimate_two_view_geometry(const oracle_camera* cam1, const double* p
                                       oracle_tvg_result* out, char* inlier_mask) {
     const Camera c1 = to_cam(cam1), c2 = to_cam(cam2);
     if (!camera_supported(c1) || !camera_supported(c2)) return -1;
-    if (opts->compute_relative_pose) return -1;
     for (size_t i = 0; i < M; ++i)
         if (matches[2 * i] >= n1 || matches[2 * i + 1] >= n2) return -1;
     std::vector<Pt> a(n1), b(n2);
@@ -1288,6 +1641,34 @@ int oracle_estimate_two_view_geometry(const oracle_camera* cam1, const double* p
     for (int i = 0; i < 4; ++i) out->trials[i] = static_cast<int64_t>(g.trials[i]);
     for (int i = 0; i < 3; ++i) out->inl[i] = static_cast<int64_t>(g.inl[i]);
     for (size_t i = 0; i < M; ++i) inlier_mask[i] = i < g.inlier_mask.size() ? g.inlier_mask[i] : 0;
+    put_pose(g.pose, out);
+    return 0;
+}
+
+// EstimateTwoViewGeometryPose on a given geometry: config, E, H and the inlier matches (Mi x 2).
+// out->config is the config after the call; out->pose_ok its return value.
+int oracle_estimate_two_view_geometry_pose(const oracle_camera* cam1, const double* pts1, size_t n1,
+                                           const oracle_camera* cam2, const double* pts2, size_t n2,
+                                           const uint32_t* inlier_matches, size_t Mi, int32_t config,
+                                           const double* E9, const double* H9, oracle_tvg_result* out) {
+    const Camera c1 = to_cam(cam1), c2 = to_cam(cam2);
+    if (!camera_supported(c1) || !camera_supported(c2)) return -1;
+    for (size_t i = 0; i < Mi; ++i)
+        if (inlier_matches[2 * i] >= n1 || inlier_matches[2 * i + 1] >= n2) return -1;
+    std::vector<Pt> a(n1), b(n2);
+    for (size_t i = 0; i < n1; ++i) a[i] = Pt{pts1[2 * i], pts1[2 * i + 1]};
+    for (size_t i = 0; i < n2; ++i) b[i] = Pt{pts2[2 * i], pts2[2 * i + 1]};
+    Tvg g;
+    g.config = config;
+    std::memcpy(g.E.m, E9, sizeof g.E.m);
+    std::memcpy(g.H.m, H9, sizeof g.H.m);
+    g.inlier_mask.assign(Mi, 1);
+    g.num_inliers = Mi;
+    const RelPose p = estimate_relative_pose(c1, a, c2, b, inlier_matches, Mi, g);
+    std::memset(out, 0, sizeof *out);
+    out->config = p.ok ? p.config : config;
+    out->num_inliers = static_cast<int32_t>(Mi);
+    put_pose(p, out);
     return 0;
 }
 

@@ -131,7 +131,14 @@ class OCamera(C.Structure):
 class TvgResult(C.Structure):
     _fields_ = [("config", C.c_int32), ("num_inliers", C.c_int32), ("E", C.c_double * 9),
                 ("F", C.c_double * 9), ("H", C.c_double * 9), ("trials", C.c_int64 * 4),
-                ("inl", C.c_int64 * 3)]
+                ("inl", C.c_int64 * 3), ("pose_ok", C.c_int32), ("num_points3D", C.c_int32),
+                ("qvec", C.c_double * 4), ("tvec", C.c_double * 3), ("R", C.c_double * 9),
+                ("tri_angle", C.c_double)]
+
+
+def _pose_fields(r) -> dict:
+    return dict(pose_ok=bool(r.pose_ok), num_points3D=int(r.num_points3D), qvec=np.array(r.qvec),
+                tvec=np.array(r.tvec), R=np.array(r.R).reshape(3, 3), tri_angle=float(r.tri_angle))
 
 
 CONFIG_NAMES = ["UNDEFINED", "DEGENERATE", "CALIBRATED", "UNCALIBRATED", "PLANAR", "PANORAMIC",
@@ -186,7 +193,24 @@ def estimate_two_view_geometry(cam1, pts1, cam2, pts2, matches, opts=None, seed=
                 num_inliers=int(res.num_inliers), E=np.array(res.E).reshape(3, 3),
                 F=np.array(res.F).reshape(3, 3), H=np.array(res.H).reshape(3, 3),
                 trials=list(res.trials), inl=list(res.inl), inlier_mask=mask[:len(m)].astype(bool),
-                inlier_label=mask[:len(m)].copy())  # 1 + geometry index (multiple_models), else 0/1
+                inlier_label=mask[:len(m)].copy(),  # 1 + geometry index (multiple_models), else 0/1
+                **_pose_fields(res))
+
+
+def estimate_two_view_geometry_pose(cam1, pts1, cam2, pts2, inlier_matches, config, E=None, H=None):
+    """EstimateTwoViewGeometryPose on a given geometry (config, E, H, inlier matches)."""
+    lib = load()
+    p1, p2 = _d(pts1).reshape(-1, 2), _d(pts2).reshape(-1, 2)
+    m = np.ascontiguousarray(inlier_matches, dtype=np.uint32).reshape(-1, 2)
+    E = _d(np.zeros((3, 3)) if E is None else E).reshape(9)
+    H = _d(np.zeros((3, 3)) if H is None else H).reshape(9)
+    res = TvgResult()
+    lib.oracle_estimate_two_view_geometry_pose.restype = C.c_int
+    rc = lib.oracle_estimate_two_view_geometry_pose(
+        C.byref(cam1), _p(p1), C.c_size_t(len(p1)), C.byref(cam2), _p(p2), C.c_size_t(len(p2)),
+        _p(m), C.c_size_t(len(m)), C.c_int32(int(config)), _p(E), _p(H), C.byref(res))
+    assert rc == 0, "oracle: unsupported input"
+    return dict(config=int(res.config), config_name=CONFIG_NAMES[res.config], **_pose_fields(res))
 
 
 def estimate_two_view_geometry_batch(cams1, pts1, cams2, pts2, matches, opts=None, seed=0, threads=1):
@@ -223,7 +247,7 @@ def estimate_two_view_geometry_batch(cams1, pts1, cams2, pts2, matches, opts=Non
                         E=np.array(r.E).reshape(3, 3), F=np.array(r.F).reshape(3, 3), H=np.array(r.H).reshape(3, 3),
                         trials=list(r.trials), inl=list(r.inl),
                         inlier_mask=masks[int(moff[p]):int(moff[p]) + len(mm[p])].astype(bool),
-                        inlier_label=masks[int(moff[p]):int(moff[p]) + len(mm[p])].copy()))
+                        inlier_label=masks[int(moff[p]):int(moff[p]) + len(mm[p])].copy(), **_pose_fields(r)))
     return out
 
 

@@ -306,3 +306,96 @@ def test_batch_entry_point_equals_single_calls():
             np.testing.assert_array_equal(g["inlier_mask"], w["inlier_mask"])
             for k in "EFH":
                 np.testing.assert_array_equal(g[k], w[k])
+
+
+# ------------------------------------------------------- relative pose ----
+def _rot_angle_deg(Ra, Rb):
+    c = (np.trace(Ra.T @ Rb) - 1.0) / 2.0
+    return np.degrees(np.arccos(np.clip(c, -1.0, 1.0)))
+
+
+def _quat_to_rot(q):
+    w, x, y, z = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                     [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                     [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+
+
+def _tri_angles_numpy(R, t, K, p1, p2):
+    """Independent float64 restatement: midpoint-free angle between the two viewing rays of each
+    correspondence (the triangulation angle of a noise-free point equals the angle between its rays)."""
+    Kinv = np.linalg.inv(K)
+    r1 = (Kinv @ np.c_[p1, np.ones(len(p1))].T).T
+    r2 = (Kinv @ np.c_[p2, np.ones(len(p2))].T).T
+    r2w = (R.T @ r2.T).T                       # second ray in the first camera's frame
+    c = np.sum(r1 * r2w, axis=1) / np.linalg.norm(r1, axis=1) / np.linalg.norm(r2w, axis=1)
+    a = np.arccos(np.clip(c, -1, 1))
+    return np.minimum(a, np.pi - a)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_relative_pose_recovers_planted_motion(seed):
+    """compute_relative_pose on a calibrated general scene: rotation, translation direction and
+    the median triangulation angle of the planted motion; quaternion consistent with R."""
+    rng = np.random.default_rng(100 + seed)
+    sc = synth.two_view_scene(rng, num_inliers=250, num_outliers=80, noise=0.3)
+    cam = o.make_camera(prior=True)
+    r = o.estimate_two_view_geometry(cam, sc["pts1"], cam, sc["pts2"], sc["matches"],
+                                     o.tvg_default_options(compute_relative_pose=1))
+    assert r["config_name"] == "CALIBRATED" and r["pose_ok"]
+    assert abs(np.linalg.det(r["R"]) - 1.0) < 1e-9 and np.allclose(r["R"] @ r["R"].T, np.eye(3), atol=1e-9)
+    assert _rot_angle_deg(r["R"], sc["R"]) < 0.5
+    tdir = sc["t"] / np.linalg.norm(sc["t"])
+    assert abs(np.linalg.norm(r["tvec"]) - 1.0) < 1e-9 and float(tdir @ r["tvec"]) > 0.999
+    assert np.allclose(_quat_to_rot(r["qvec"]), r["R"], atol=1e-9) and abs(np.linalg.norm(r["qvec"]) - 1) < 1e-9
+    assert r["num_points3D"] >= 0.97 * r["num_inliers"]          # nearly all inliers in front of both cameras
+    m = sc["matches"][r["inlier_mask"]]
+    ang = _tri_angles_numpy(sc["R"], sc["t"], sc["K"], sc["pts1"][m[:, 0]], sc["pts2"][m[:, 1]])
+    assert abs(r["tri_angle"] - np.median(ang)) < 0.05 * np.median(ang)
+    # the same geometry through the stand-alone entry point (estimate_two_view_geometry_pose)
+    p = o.estimate_two_view_geometry_pose(cam, sc["pts1"], cam, sc["pts2"], m, r["config"], E=r["E"], H=r["H"])
+    assert p["pose_ok"] and np.array_equal(p["R"], r["R"]) and np.array_equal(p["tvec"], r["tvec"])
+    assert p["tri_angle"] == r["tri_angle"] and p["num_points3D"] == r["num_points3D"]
+
+
+def test_relative_pose_planar_and_panoramic():
+    rng = np.random.default_rng(77)
+    cam = o.make_camera(prior=True)
+    opts = o.tvg_default_options(compute_relative_pose=1)
+    pl = synth.two_view_scene(rng, num_inliers=300, num_outliers=60, noise=0.2, planar=True)
+    r = o.estimate_two_view_geometry(cam, pl["pts1"], cam, pl["pts2"], pl["matches"], opts)
+    assert r["config_name"] == "PLANAR" and r["pose_ok"]     # PLANAR_OR_PANORAMIC resolved by the pose
+    assert _rot_angle_deg(r["R"], pl["R"]) < 1.0
+    # homography translation is in units of the plane distance: t_true / d
+    tt = pl["t"] / synth.PLANE_D
+    assert np.linalg.norm(r["tvec"] - tt) < 0.05 * np.linalg.norm(tt)
+    assert r["tri_angle"] > 0 and r["num_points3D"] >= 0.95 * r["num_inliers"]
+    pr = synth.two_view_scene(rng, num_inliers=300, num_outliers=60, noise=0.05, pure_rotation=True)
+    r = o.estimate_two_view_geometry(cam, pr["pts1"], cam, pr["pts2"], pr["matches"], opts)
+    assert r["pose_ok"] and r["config_name"] in ("PANORAMIC", "PLANAR")
+    assert _rot_angle_deg(r["R"], pr["R"]) < 0.5
+    if r["config_name"] == "PANORAMIC":
+        assert r["tri_angle"] == 0.0 and np.all(r["tvec"] == 0)
+    # an exact rotation homography is PANORAMIC by construction
+    K = pr["K"]
+    m = pr["matches"][pr["inlier"]]
+    p = o.estimate_two_view_geometry_pose(cam, pr["pts1"], cam, pr["pts2"], m, 6, H=K @ pr["R"] @ np.linalg.inv(K))
+    assert p["pose_ok"] and p["config_name"] == "PANORAMIC" and p["tri_angle"] == 0.0
+    assert _rot_angle_deg(p["R"], pr["R"]) < 1e-6
+
+
+def test_relative_pose_skips_configs_without_geometry():
+    rng = np.random.default_rng(5)
+    cam = o.make_camera(prior=True)
+    sc = synth.two_view_scene(rng, num_inliers=100, num_outliers=10)
+    m = sc["matches"][sc["inlier"]]
+    for cfg in (0, 1, 7, 8):   # UNDEFINED, DEGENERATE, WATERMARK, MULTIPLE
+        p = o.estimate_two_view_geometry_pose(cam, sc["pts1"], cam, sc["pts2"], m, cfg, E=sc["E_true"])
+        assert not p["pose_ok"] and p["config"] == cfg and p["tri_angle"] == 0.0
+        assert np.array_equal(p["qvec"], [1, 0, 0, 0]) and np.array_equal(p["tvec"], [0, 0, 0])
+    # UNCALIBRATED with the default (all-zero) E of the uncalibrated path: defined, finite output
+    p = o.estimate_two_view_geometry_pose(cam, sc["pts1"], cam, sc["pts2"], m, 3)
+    assert p["pose_ok"] and np.all(np.isfinite(p["R"])) and np.all(np.isfinite(p["tvec"]))
+    # no inlier matches at all
+    p = o.estimate_two_view_geometry_pose(cam, sc["pts1"], cam, sc["pts2"], m[:0], 2, E=sc["E_true"])
+    assert p["pose_ok"] and p["num_points3D"] == 0 and p["tri_angle"] == 0.0
