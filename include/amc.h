@@ -156,7 +156,7 @@ typedef struct amc_tvg_opts {
     int32_t detect_watermark;
     int32_t multiple_ignore_watermark;
     int32_t force_H_use;
-    int32_t compute_relative_pose; /* must be 0 (next) */
+    int32_t compute_relative_pose; /* EstimateTwoViewGeometryPose after the estimation: amc_verify_result.pose */
     int32_t multiple_models;       /* EstimateMultipleTwoViewGeometries: see amc_verify_result.inlier_mask */
     double min_E_F_inlier_ratio;
     double max_H_inlier_ratio;
@@ -188,6 +188,24 @@ typedef struct amc_tvg {
     int64_t model_inliers[3];
 } amc_tvg;
 
+/* cam2_from_cam1 and tri_angle of a TwoViewGeometry (/root/reference/pycolmap/estimators/
+ * two_view_geometry.h:85-92), as COLMAP 3.9.1 EstimateTwoViewGeometryPose leaves them: for CALIBRATED /
+ * UNCALIBRATED the pose from E (DecomposeEssentialMatrix, cheirality of the inlier matches), for
+ * PLANAR / PANORAMIC / PLANAR_OR_PANORAMIC the pose from H (DecomposeHomographyMatrix with both
+ * calibration matrices), tri_angle = median triangulation angle of the points in front of both
+ * cameras, and PLANAR_OR_PANORAMIC resolved to PANORAMIC (zero translation) or PLANAR.  Any other
+ * config: ok = 0, identity rotation, zero translation, tri_angle 0 (the struct's defaults). */
+typedef struct amc_pose {
+    int32_t ok;            /* EstimateTwoViewGeometryPose's return value */
+    int32_t config;        /* the geometry's config afterwards */
+    double qvec[4];        /* cam2_from_cam1.rotation as (w, x, y, z): the `qvec` column of two_view_geometries */
+    double tvec[3];        /* cam2_from_cam1.translation */
+    double R[9];           /* the rotation matrix, row-major */
+    double tri_angle;      /* radians */
+    uint32_t num_points3D; /* inlier matches triangulated in front of both cameras */
+    uint32_t pad_;
+} amc_pose;
+
 typedef struct amc_verify_result {
     size_t npairs;
     amc_tvg* tvg;          /* npairs */
@@ -199,6 +217,8 @@ typedef struct amc_verify_result {
     double device_ms;      /* first launch -> results on host */
     double kernel_ms;      /* verification kernel launches, HIP events on the stream */
     uint32_t kernel_launches;
+    amc_pose* pose;        /* npairs when opts.compute_relative_pose (then tvg[p].config == pose[p].config),
+                              else NULL */
     void* _priv;
 } amc_verify_result;
 
@@ -231,6 +251,16 @@ int amc_verify_pairs(amc_ctx* ctx, const uint32_t* slot1, const uint32_t* slot2,
                      const uint64_t* match_offsets, const uint32_t* matches,
                      const amc_tvg_opts* opts, uint32_t seed, amc_verify_result* out);
 void amc_verify_result_free(amc_verify_result* r);
+
+/* EstimateTwoViewGeometryPose (/root/reference/pycolmap/estimators/two_view_geometry.h:153-159) on given
+ * geometries: geoms[p] supplies config, E and H; inlier_matches (CSR, as amc_verify_pairs' matches)
+ * are the geometry's inlier_matches.  Both images need points and a SIMPLE_PINHOLE / PINHOLE camera.
+ * out: npairs records.  Also the cam2_from_cam1 of essential_matrix_estimation
+ * (/root/reference/pycolmap/estimators/essential_matrix.h:63-83): config = AMC_TVG_CALIBRATED, E = the
+ * report's model, inlier_matches = its inliers. */
+int amc_pose_pairs(amc_ctx* ctx, const uint32_t* slot1, const uint32_t* slot2, size_t npairs,
+                   const uint64_t* match_offsets, const uint32_t* inlier_matches, const amc_tvg* geoms,
+                   amc_pose* out);
 
 /* ---- guided matching (SiftMatchingOptions.guided_matching, /root/reference/pycolmap/pipeline/
  * match_features.h:95-98) ------------------------------------------------------------------------

@@ -1197,7 +1197,8 @@ void svd3(const Mat3& A, Mat3* U, double S[3], Mat3* V) {
             if (ata[4 * ord[j]] > ata[4 * ord[i]]) std::swap(ord[i], ord[j]);
     V3 vcol[3], ucol[3];
     for (int k = 0; k < 3; ++k) {
-        S[k] = std::sqrt(std::max(ata[4 * ord[k]], 0.0));
+        const double lam = ata[4 * ord[k]];
+        S[k] = std::sqrt(lam < 0.0 ? 0.0 : lam);
         vcol[k] = V3{{ev[0 * 3 + ord[k]], ev[1 * 3 + ord[k]], ev[2 * 3 + ord[k]]}};
     }
     for (int k = 0; k < 2; ++k) {
@@ -1513,6 +1514,7 @@ Tvg estimate_multiple_two_view_geometries(const Camera& c1, const std::vector<Pt
         out.num_inliers = g.num_inliers;
         for (int i = 0; i < 4; ++i) out.trials[i] = g.trials[i];
         for (int i = 0; i < 3; ++i) out.inl[i] = g.inl[i];
+        out.pose = g.pose;
     } else {
         out.config = MULTIPLE;
         for (const Tvg& g : geometries) out.num_inliers += g.num_inliers;

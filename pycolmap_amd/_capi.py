@@ -27,7 +27,7 @@ EXPORTED_SYMBOLS = [
     "amc_match_opts_default", "amc_get_acos_lut",
     "amc_tvg_opts_default", "amc_upload_keypoints", "amc_upload_camera", "amc_verify_pairs",
     "amc_verify_result_free", "amc_upload_points_f64", "amc_ransac_pairs", "amc_ransac_result_free",
-    "amc_squared_sampson_error", "amc_match_guided_pairs", "amc_ctx_grow_slots",
+    "amc_squared_sampson_error", "amc_match_guided_pairs", "amc_ctx_grow_slots", "amc_pose_pairs",
 ]
 RANSAC_F, RANSAC_H, RANSAC_E = 0, 1, 2
 RANSAC_KINDS = {"F": RANSAC_F, "H": RANSAC_H, "E": RANSAC_E}
@@ -74,10 +74,16 @@ class Tvg(C.Structure):
                 ("model_inliers", C.c_int64 * 3)]
 
 
+class Pose(C.Structure):
+    _fields_ = [("ok", C.c_int32), ("config", C.c_int32), ("qvec", C.c_double * 4), ("tvec", C.c_double * 3),
+                ("R", C.c_double * 9), ("tri_angle", C.c_double), ("num_points3D", C.c_uint32),
+                ("pad_", C.c_uint32)]
+
+
 class VerifyResult(C.Structure):
     _fields_ = [("npairs", C.c_size_t), ("tvg", C.POINTER(Tvg)), ("inlier_mask", C.POINTER(C.c_uint8)),
                 ("device_ms", C.c_double), ("kernel_ms", C.c_double), ("kernel_launches", C.c_uint32),
-                ("_priv", C.c_void_p)]
+                ("pose", C.POINTER(Pose)), ("_priv", C.c_void_p)]
 
 
 class RansacReport(C.Structure):
@@ -92,6 +98,9 @@ class RansacResult(C.Structure):
 
 RANSAC_DTYPE = np.dtype([("success", np.int32), ("num_inliers", np.int32), ("num_trials", np.int64),
                          ("model", np.float64, (3, 3))])
+POSE_DTYPE = np.dtype([("ok", np.int32), ("config", np.int32), ("qvec", np.float64, (4,)),
+                       ("tvec", np.float64, (3,)), ("R", np.float64, (3, 3)), ("tri_angle", np.float64),
+                       ("num_points3D", np.uint32), ("pad_", np.uint32)])
 TVG_DTYPE = np.dtype([("config", np.int32), ("num_inliers", np.int32), ("E", np.float64, (3, 3)),
                       ("F", np.float64, (3, 3)), ("H", np.float64, (3, 3)),
                       ("num_trials", np.int64, (4,)), ("model_inliers", np.int64, (3,))])
@@ -150,6 +159,8 @@ def load() -> C.CDLL:
     lib.amc_ransac_result_free.restype = None
     lib.amc_squared_sampson_error.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
                                               C.c_void_p]
+    lib.amc_pose_pairs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_void_p]
     _lib = lib
     return lib
 
@@ -385,9 +396,39 @@ class Context:
             mask = labels.astype(bool)
             # inlier_labels: 1 + index of the geometry a match belongs to (multiple_models), else 0 / 1
             stats = dict(device_ms=float(res.device_ms), kernel_ms=float(res.kernel_ms), inlier_labels=labels)
+            if res.pose:  # compute_relative_pose: one amc_pose per pair
+                assert C.sizeof(Pose) == POSE_DTYPE.itemsize
+                stats["pose"] = (np.frombuffer(C.string_at(res.pose, n * C.sizeof(Pose)), dtype=POSE_DTYPE).copy()
+                                 if n else np.zeros(0, dtype=POSE_DTYPE))
         finally:
             self._lib.amc_verify_result_free(C.byref(res))
         return tvg, mask, stats
+
+    def pose_pairs(self, slot1, slot2, match_offsets, inlier_matches, config, E=None, H=None) -> np.ndarray:
+        """EstimateTwoViewGeometryPose for given geometries: config [npairs], E / H [npairs, 3, 3].
+        Returns a POSE_DTYPE array [npairs]."""
+        s1 = np.ascontiguousarray(slot1, dtype=np.uint32)
+        s2 = np.ascontiguousarray(slot2, dtype=np.uint32)
+        off = np.ascontiguousarray(match_offsets, dtype=np.uint64)
+        m = np.ascontiguousarray(inlier_matches, dtype=np.uint32).reshape(-1, 2)
+        if off.shape != (s1.size + 1,) or s1.shape != s2.shape:
+            raise ValueError("match_offsets must have npairs + 1 entries")
+        if int(off[-1]) != m.shape[0]:
+            raise ValueError("match_offsets[-1] must equal the number of matches")
+        n = s1.size
+        geoms = np.zeros(n, dtype=TVG_DTYPE)
+        geoms["config"] = np.asarray(config, dtype=np.int32).reshape(n)
+        if E is not None:
+            geoms["E"] = np.asarray(E, dtype=np.float64).reshape(n, 3, 3)
+        if H is not None:
+            geoms["H"] = np.asarray(H, dtype=np.float64).reshape(n, 3, 3)
+        out = np.zeros(n, dtype=POSE_DTYPE)
+        assert C.sizeof(Pose) == POSE_DTYPE.itemsize and C.sizeof(Tvg) == TVG_DTYPE.itemsize
+        _check(self._lib.amc_pose_pairs(self._h, s1.ctypes.data_as(C.c_void_p), s2.ctypes.data_as(C.c_void_p),
+                                        C.c_size_t(n), off.ctypes.data_as(C.c_void_p),
+                                        m.ctypes.data_as(C.c_void_p), geoms.ctypes.data_as(C.c_void_p),
+                                        out.ctypes.data_as(C.c_void_p)))
+        return out
 
     def acos_lut(self) -> np.ndarray:
         out = np.empty(262145, dtype=np.float32)

@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "amc_internal.h"
+#include "pose_math.h"  // median_angle_host
 
 using namespace amc;
 
@@ -124,6 +125,11 @@ struct amc_ctx {
     DevBuf<double> d_tws;
     DevBuf<uint8_t> d_tmaskws, d_toutmask;
     DevBuf<TvgOut> d_tout;
+    // relative-pose scratch
+    DevBuf<PosePair> d_ppairs;
+    DevBuf<uint32_t> d_pmatches;
+    DevBuf<double> d_pcos;
+    DevBuf<PoseOut> d_pout;
 };
 
 extern "C" {
@@ -217,6 +223,7 @@ void amc_ctx_destroy(amc_ctx* c) {
     c->d_timgs.release(); c->d_tpairs.release(); c->d_tmatches.release(); c->d_ttabs.release();
     c->d_mtinit.release(); c->d_tws.release(); c->d_tmaskws.release(); c->d_toutmask.release();
     c->d_tout.release();
+    c->d_ppairs.release(); c->d_pmatches.release(); c->d_pcos.release(); c->d_pout.release();
     for (auto& ev : c->ev)
         if (ev) (void)hipEventDestroy(ev);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -787,9 +794,115 @@ size_t ransac_max_trials_host(const amc_ransac_opts& o, double min_inlier_ratio,
 struct VerifyPriv {
     std::vector<amc_tvg> tvg;
     std::vector<uint8_t> mask;
+    std::vector<amc_pose> pose;
 };
 
+void pose_default(amc_pose* q, int32_t config) {
+    std::memset(q, 0, sizeof *q);
+    q->config = config;
+    q->qvec[0] = 1.0;
+    q->R[0] = q->R[4] = q->R[8] = 1.0;
+}
+
 }  // namespace
+
+// EstimateTwoViewGeometryPose for every listed pair (pose.hip); `inlier_matches` in CSR layout.
+// kernel_ms (optional): the pose kernel's duration.
+static int pose_impl(amc_ctx* c, const char* who, const uint32_t* slot1, const uint32_t* slot2, size_t npairs,
+                     const uint64_t* match_offsets, const uint32_t* inlier_matches, const amc_tvg* geoms,
+                     amc_pose* out, double* kernel_ms) {
+    if (kernel_ms) *kernel_ms = 0.0;
+    if (!c) return fail(AMC_E_INVALID, "%s: NULL ctx", who);
+    if (npairs == 0) return AMC_OK;
+    if (!slot1 || !slot2 || !match_offsets || !geoms || !out)
+        return fail(AMC_E_INVALID, "%s: NULL pair arrays", who);
+    const uint64_t total = match_offsets[npairs];
+    if (total > 0 && !inlier_matches) return fail(AMC_E_INVALID, "%s: NULL matches", who);
+    if (npairs > 0xFFFFFFFFull) return fail(AMC_E_INVALID, "%s: too many pairs", who);
+    std::vector<PosePair> pp(npairs);
+    for (size_t p = 0; p < npairs; ++p) {
+        if (slot1[p] >= c->slots.size() || slot2[p] >= c->slots.size())
+            return fail(AMC_E_INVALID, "%s: pair %zu references slot out of range", who, p);
+        const Slot& a = c->slots[slot1[p]];
+        const Slot& b = c->slots[slot2[p]];
+        if (!a.has_kp || !b.has_kp || !a.has_cam || !b.has_cam)
+            return fail(AMC_E_STATE, "%s: pair %zu: keypoints/camera not uploaded", who, p);
+        if (match_offsets[p + 1] < match_offsets[p])
+            return fail(AMC_E_INVALID, "%s: match_offsets not monotone at %zu", who, p);
+        const uint64_t M = match_offsets[p + 1] - match_offsets[p];
+        if (M > 0xFFFFFFFFull) return fail(AMC_E_INVALID, "%s: pair %zu has too many matches", who, p);
+        const int32_t cfg = geoms[p].config;
+        const bool has_geometry = cfg == AMC_TVG_CALIBRATED || cfg == AMC_TVG_UNCALIBRATED || cfg == AMC_TVG_PLANAR ||
+                                  cfg == AMC_TVG_PANORAMIC || cfg == AMC_TVG_PLANAR_OR_PANORAMIC;
+        if (has_geometry &&
+            ((a.cam.model_id != AMC_CAM_SIMPLE_PINHOLE && a.cam.model_id != AMC_CAM_PINHOLE) ||
+             (b.cam.model_id != AMC_CAM_SIMPLE_PINHOLE && b.cam.model_id != AMC_CAM_PINHOLE)))
+            return fail(AMC_E_INVALID, "%s: pair %zu: the relative pose supports SIMPLE_PINHOLE / PINHOLE "
+                        "cameras only", who, p);
+        for (uint64_t k = match_offsets[p]; k < match_offsets[p + 1]; ++k)
+            if (inlier_matches[2 * k] >= a.kp_rows || inlier_matches[2 * k + 1] >= b.kp_rows)
+                return fail(AMC_E_INVALID, "%s: pair %zu match %llu indexes past the keypoints", who, p,
+                            (unsigned long long)(k - match_offsets[p]));
+        pp[p].slot1 = slot1[p];
+        pp[p].slot2 = slot2[p];
+        pp[p].match_off = match_offsets[p];
+        pp[p].M = (uint32_t)M;
+        pp[p].config = cfg;
+        std::memcpy(pp[p].E, geoms[p].E, sizeof pp[p].E);
+        std::memcpy(pp[p].H, geoms[p].H, sizeof pp[p].H);
+    }
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    std::vector<TvgImage> timgs(c->slots.size());
+    for (size_t i = 0; i < timgs.size(); ++i) {
+        timgs[i].kp = c->slots[i].kp;
+        timgs[i].kp64 = c->slots[i].kp64;
+        timgs[i].rows = c->slots[i].kp_rows;
+        timgs[i].pad = 0;
+        timgs[i].cam = c->slots[i].cam;
+    }
+    HIPCHK(c->d_timgs.ensure(timgs.size()));
+    HIPCHK(c->d_ppairs.ensure(npairs));
+    HIPCHK(c->d_pmatches.ensure(std::max<size_t>(2 * total, 2)));
+    HIPCHK(c->d_pcos.ensure(std::max<size_t>(total, 1)));
+    HIPCHK(c->d_pout.ensure(npairs));
+    HIPCHK(hipMemcpyAsync(c->d_timgs.p, timgs.data(), timgs.size() * sizeof(TvgImage), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(c->d_ppairs.p, pp.data(), npairs * sizeof(PosePair), hipMemcpyHostToDevice, st));
+    if (total)
+        HIPCHK(hipMemcpyAsync(c->d_pmatches.p, inlier_matches, 2 * total * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    HIPCHK(hipEventRecord(c->ev[4], st));
+    HIPCHK(launch_pose(c->d_timgs.p, c->d_ppairs.p, (uint32_t)npairs, c->d_pmatches.p, c->d_pcos.p, c->d_pout.p, st));
+    HIPCHK(hipEventRecord(c->ev[5], st));
+    std::vector<PoseOut> h(npairs);
+    HIPCHK(hipMemcpyAsync(h.data(), c->d_pout.p, npairs * sizeof(PoseOut), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (kernel_ms) {
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, c->ev[4], c->ev[5]);
+        *kernel_ms = ms;
+    }
+    for (size_t p = 0; p < npairs; ++p) {
+        amc_pose& q = out[p];
+        pose_default(&q, geoms[p].config);
+        if (!h[p].ok) continue;
+        q.ok = 1;
+        std::memcpy(q.R, h[p].R, sizeof q.R);
+        std::memcpy(q.tvec, h[p].t, sizeof q.tvec);
+        std::memcpy(q.qvec, h[p].q, sizeof q.qvec);
+        q.num_points3D = h[p].num_points3D;
+        // Median(CalculateTriangulationAngles(...)): libm acos of the selected cosine(s)
+        q.tri_angle = amc::tvg::median_angle_host(h[p].num_points3D, h[p].cmed);
+        if (q.config == AMC_TVG_PLANAR_OR_PANORAMIC) {
+            if (h[p].t_is_zero) {
+                q.config = AMC_TVG_PANORAMIC;
+                q.tri_angle = 0.0;
+            } else {
+                q.config = AMC_TVG_PLANAR;
+            }
+        }
+    }
+    return AMC_OK;
+}
 
 // mode 0: EstimateTwoViewGeometry; 1 / 2 / 3: a single F / H / E LO-RANSAC per pair, reported
 // through the same record (config = success, num_inliers, the model, its trial count, the mask)
@@ -802,9 +915,8 @@ static int verify_impl(amc_ctx* c, int mode, const uint32_t* slot1, const uint32
         return fail(AMC_E_INVALID, "amc_verify_pairs: NULL pair arrays");
     amc_tvg_opts o;
     if (opts_in) o = *opts_in; else amc_tvg_opts_default(&o);
-    if (o.compute_relative_pose)
-        return fail(AMC_E_INVALID, "amc_verify_pairs: compute_relative_pose is not implemented "
-                    "(SURVEY.md 8f rank 4)");
+    if (o.compute_relative_pose && mode != 0)
+        return fail(AMC_E_INVALID, "amc_verify_pairs: internal: compute_relative_pose outside mode 0");
     if (o.multiple_models)
         return fail(AMC_E_INVALID, "amc_verify_pairs: internal: multiple_models reaches verify_impl");
     if (o.ransac.max_num_trials < 0 || o.ransac.min_num_trials < 0 || o.ransac.max_num_trials > (1 << 30))
@@ -1011,6 +1123,37 @@ static int verify_impl(amc_ctx* c, int mode, const uint32_t* slot1, const uint32
     out->device_ms = ms;
     out->kernel_ms = kernel_ms;
     out->kernel_launches = launches;
+    if (o.compute_relative_pose) {
+        // EstimateTwoViewGeometryPose on the selected inlier matches (mask order = match order)
+        std::vector<uint64_t> ioff(npairs + 1, 0);
+        std::vector<uint32_t> im;
+        im.reserve(2 * total);
+        for (size_t p = 0; p < npairs; ++p) {
+            const uint8_t* mk = priv->mask.data() + match_offsets[p];
+            const uint32_t* mm = matches + 2 * match_offsets[p];
+            const size_t M = (size_t)(match_offsets[p + 1] - match_offsets[p]);
+            for (size_t k = 0; k < M; ++k)
+                if (mk[k]) {
+                    im.push_back(mm[2 * k]);
+                    im.push_back(mm[2 * k + 1]);
+                }
+            ioff[p + 1] = im.size() / 2;
+        }
+        priv->pose.resize(npairs);
+        double pose_ms = 0.0;
+        const int rc = pose_impl(c, "amc_verify_pairs", slot1, slot2, npairs, ioff.data(), im.data(), priv->tvg.data(),
+                                 priv->pose.data(), &pose_ms);
+        if (rc != AMC_OK) {
+            delete priv;
+            std::memset(out, 0, sizeof *out);
+            return rc;
+        }
+        for (size_t p = 0; p < npairs; ++p) priv->tvg[p].config = priv->pose[p].config;
+        out->pose = priv->pose.data();
+        out->device_ms += pose_ms;
+        out->kernel_ms += pose_ms;
+        out->kernel_launches += 1;
+    }
     return AMC_OK;
 }
 
@@ -1037,6 +1180,8 @@ static int verify_multiple(amc_ctx* c, const uint32_t* slot1, const uint32_t* sl
     priv->mask.assign(total, 0);
     std::vector<std::vector<uint32_t>> remaining(npairs);  // indices into the pair's original matches
     std::vector<std::vector<amc_tvg>> kept(npairs);
+    std::vector<amc_pose> first_pose(npairs);  // pose of a pair's first kept geometry
+    for (size_t p = 0; p < npairs; ++p) pose_default(&first_pose[p], AMC_TVG_UNDEFINED);
     std::vector<size_t> active;
     for (size_t p = 0; p < npairs; ++p) {
         const size_t M = (size_t)(match_offsets[p + 1] - match_offsets[p]);
@@ -1073,7 +1218,10 @@ static int verify_multiple(amc_ctx* c, const uint32_t* slot1, const uint32_t* sl
             const amc_tvg& g = r.tvg[a];
             if (g.config == AMC_TVG_DEGENERATE) continue;  // this pair is finished
             const bool keep = !(o.multiple_ignore_watermark && g.config == AMC_TVG_WATERMARK);
-            if (keep) kept[p].push_back(g);
+            if (keep) {
+                kept[p].push_back(g);
+                if (kept[p].size() == 1 && r.pose) first_pose[p] = r.pose[a];
+            }
             const uint8_t* mask = r.inlier_mask + off[a];
             std::vector<uint32_t> next;
             for (size_t k = 0; k < remaining[p].size(); ++k) {
@@ -1094,23 +1242,28 @@ static int verify_multiple(amc_ctx* c, const uint32_t* slot1, const uint32_t* sl
         delete priv;
         return rc;
     }
+    if (o.compute_relative_pose) priv->pose.resize(npairs);
     for (size_t p = 0; p < npairs; ++p) {
         amc_tvg& t = priv->tvg[p];
         std::memset(&t, 0, sizeof t);
+        if (o.compute_relative_pose) pose_default(&priv->pose[p], AMC_TVG_UNDEFINED);
         if (kept[p].empty()) {
             t.config = AMC_TVG_DEGENERATE;
             std::fill(priv->mask.begin() + match_offsets[p], priv->mask.begin() + match_offsets[p + 1], 0);
         } else if (kept[p].size() == 1) {
             t = kept[p][0];
+            if (o.compute_relative_pose) priv->pose[p] = first_pose[p];
         } else {
             t.config = AMC_TVG_MULTIPLE;  // the models of a MULTIPLE geometry stay default (zero)
             for (const amc_tvg& g : kept[p]) t.num_inliers += g.num_inliers;
         }
+        if (o.compute_relative_pose) priv->pose[p].config = t.config;
     }
     out->npairs = npairs;
     out->_priv = priv;
     out->tvg = priv->tvg.data();
     out->inlier_mask = priv->mask.data();
+    out->pose = o.compute_relative_pose ? priv->pose.data() : nullptr;
     out->device_ms = device_ms;
     out->kernel_ms = kernel_ms;
     out->kernel_launches = launches;
@@ -1123,6 +1276,12 @@ int amc_verify_pairs(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, s
     if (c && out && opts_in && opts_in->multiple_models)
         return verify_multiple(c, slot1, slot2, npairs, match_offsets, matches, *opts_in, seed, out);
     return verify_impl(c, 0, slot1, slot2, npairs, match_offsets, matches, opts_in, seed, out);
+}
+
+int amc_pose_pairs(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, size_t npairs,
+                   const uint64_t* match_offsets, const uint32_t* inlier_matches, const amc_tvg* geoms,
+                   amc_pose* out) {
+    return pose_impl(c, "amc_pose_pairs", slot1, slot2, npairs, match_offsets, inlier_matches, geoms, out, nullptr);
 }
 
 namespace {

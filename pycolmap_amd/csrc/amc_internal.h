@@ -150,6 +150,28 @@ struct TvgPair {
     uint32_t M;
     uint32_t tab_off[3];  // dyn_max_num_trials tables for the E (k=5), F (k=7), H (k=4) RANSACs
 };
+// ----- relative pose of verified pairs (pose.hip) ----------------------------------------------
+// One pair of EstimateTwoViewGeometryPose: the geometry's config / E / H and its inlier matches
+// (rows match_off .. match_off + M of the batch's inlier-match array).
+struct PosePair {
+    uint32_t slot1, slot2;
+    uint64_t match_off;
+    uint32_t M;
+    int32_t config;
+    double E[9], H[9];
+};
+// R, t of the winning candidate, its quaternion, the number of points in front of both cameras and
+// the one or two cosines the median triangulation angle is the acos of (host libm; pose_math.h)
+struct alignas(128) PoseOut {
+    int32_t ok;
+    int32_t t_is_zero;   // ||t|| == 0 (PLANAR_OR_PANORAMIC -> PANORAMIC)
+    uint32_t num_points3D;
+    uint32_t pad;
+    double R[9], t[3], q[4], cmed[2];
+};
+hipError_t launch_pose(const TvgImage* imgs, const PosePair* pairs, uint32_t npairs, const uint32_t* matches,
+                       double* cosine_ws, PoseOut* out, hipStream_t s);
+
 // device-side result record: amc_tvg padded to its own cache lines (same reason)
 struct alignas(128) TvgOut {
     amc_tvg g;

@@ -1,0 +1,213 @@
+// pose.hip — relative pose of verified image pairs: COLMAP 3.9.1 EstimateTwoViewGeometryPose
+// (TwoViewGeometryOptions.compute_relative_pose, /root/reference/pycolmap/estimators/
+// two_view_geometry.h:59-62; estimate_two_view_geometry_pose, :153-159; the cam2_from_cam1 of
+// essential_matrix_estimation, /root/reference/pycolmap/estimators/essential_matrix.h:63-83).
+//
+// One wave per pair.
+//   1. lane 0 decomposes the model into its candidate poses (E: 2 rotations x 2 translation signs;
+//      H: Malis-Vargas, 1 or 4 candidates) and parks them in LDS;
+//   2. per candidate the wave triangulates the inlier correspondences, one per lane (4 x 4 DLT,
+//      Jacobi eigen-decomposition in registers), and counts the points in front of both cameras
+//      with a ballot; the last candidate with the largest count wins (COLMAP's >=);
+//   3. the winner's points are triangulated once more and the cosine of each triangulation angle is
+//      written to the pair's slice of a global workspace;
+//   4. the median angle belongs to the middle element(s) of the cosines ordered by |c|: a 63-step
+//      bitwise search on the keys, counting with ballots.  The host takes acos of the one or two
+//      selected cosines (libm, as the acos table of the matcher: pose_math.h).
+// FP64 throughout, no contraction; bit-exact with oracle/tvg_oracle.cc (tests/test_pose_gpu.py).
+// Bytes per pair are tiny (16 B per inlier match + 2 x 16 B keypoints, read five times from L2):
+// the kernel is bound by the FP64 Jacobi sweeps, ~5 triangulations per inlier.
+#include <hip/hip_runtime.h>
+
+#include "amc_internal.h"
+#include "pose_math.h"
+
+namespace amc {
+namespace {
+
+using namespace tvg;
+
+__device__ __forceinline__ void wave_mem_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+
+struct Corr { double x1, y1, x2, y2; };
+
+// k-th correspondence of the pair in camera coordinates (Camera::CamFromImg of both cameras)
+__device__ __forceinline__ Corr load_corr(const TvgImage& im1, const TvgImage& im2, const uint32_t* mm, int k) {
+    const uint32_t i1 = mm[2 * (size_t)k], i2 = mm[2 * (size_t)k + 1];
+    const double X1 = im1.kp64 ? im1.kp64[2 * (size_t)i1] : (double)im1.kp[2 * (size_t)i1];
+    const double Y1 = im1.kp64 ? im1.kp64[2 * (size_t)i1 + 1] : (double)im1.kp[2 * (size_t)i1 + 1];
+    const double X2 = im2.kp64 ? im2.kp64[2 * (size_t)i2] : (double)im2.kp[2 * (size_t)i2];
+    const double Y2 = im2.kp64 ? im2.kp64[2 * (size_t)i2 + 1] : (double)im2.kp[2 * (size_t)i2 + 1];
+    Corr c;
+    if (im1.cam.model_id == AMC_CAM_SIMPLE_PINHOLE) {
+        c.x1 = (X1 - im1.cam.params[1]) / im1.cam.params[0];
+        c.y1 = (Y1 - im1.cam.params[2]) / im1.cam.params[0];
+    } else {
+        c.x1 = (X1 - im1.cam.params[2]) / im1.cam.params[0];
+        c.y1 = (Y1 - im1.cam.params[3]) / im1.cam.params[1];
+    }
+    if (im2.cam.model_id == AMC_CAM_SIMPLE_PINHOLE) {
+        c.x2 = (X2 - im2.cam.params[1]) / im2.cam.params[0];
+        c.y2 = (Y2 - im2.cam.params[2]) / im2.cam.params[0];
+    } else {
+        c.x2 = (X2 - im2.cam.params[2]) / im2.cam.params[0];
+        c.y2 = (Y2 - im2.cam.params[3]) / im2.cam.params[1];
+    }
+    return c;
+}
+
+// the cosine with rank `rank` (0-based) among n cosines ordered by |c|, largest first
+__device__ double select_cosine(const double* cs, uint32_t n, uint32_t rank, int lane) {
+    uint64_t K = 0;
+    for (int bit = 62; bit >= 0; --bit) {
+        const uint64_t T = K | (1ull << bit);
+        uint32_t cnt = 0;
+        for (uint32_t base = 0; base < n; base += 64) {
+            const uint32_t i = base + lane;
+            const bool ge = i < n && cosine_key(cs[i]) >= T;
+            cnt += (uint32_t)__popcll(__ballot(ge));
+        }
+        if (cnt >= rank + 1) K = T;
+    }
+    for (uint32_t base = 0; base < n; base += 64) {
+        const uint32_t i = base + lane;
+        const double c = i < n ? cs[i] : 0.0;
+        const unsigned long long hit = __ballot(i < n && cosine_key(c) == K);
+        if (hit) {
+            const int src = __builtin_ctzll(hit);
+            union { double d; int w[2]; } b;
+            b.d = c;
+            b.w[0] = __builtin_amdgcn_readlane(b.w[0], src);
+            b.w[1] = __builtin_amdgcn_readlane(b.w[1], src);
+            return b.d;
+        }
+    }
+    return 0.0;
+}
+
+__global__ __launch_bounds__(64) void pose_kernel(const TvgImage* __restrict__ imgs, const PosePair* __restrict__ pairs,
+                                                  uint32_t npairs, const uint32_t* __restrict__ matches,
+                                                  double* __restrict__ cosine_ws, PoseOut* __restrict__ out) {
+    __shared__ PoseCands cands;
+    const uint32_t p = blockIdx.x;
+    if (p >= npairs) return;
+    const int lane = threadIdx.x;
+    const PosePair& pr = pairs[p];
+    const int config = pr.config;
+    PoseOut* o = out + p;
+    const bool has_geometry = config == AMC_TVG_CALIBRATED || config == AMC_TVG_UNCALIBRATED ||
+                              config == AMC_TVG_PLANAR || config == AMC_TVG_PANORAMIC ||
+                              config == AMC_TVG_PLANAR_OR_PANORAMIC;
+    if (!has_geometry) {  // EstimateTwoViewGeometryPose returns false: the geometry keeps its defaults
+        if (lane == 0) {
+            o->ok = 0; o->t_is_zero = 1; o->num_points3D = 0; o->pad = 0;
+            for (int i = 0; i < 9; ++i) o->R[i] = (i % 4 == 0) ? 1.0 : 0.0;
+            for (int i = 0; i < 3; ++i) o->t[i] = 0.0;
+            o->q[0] = 1.0; o->q[1] = 0.0; o->q[2] = 0.0; o->q[3] = 0.0;
+            o->cmed[0] = 1.0; o->cmed[1] = 1.0;
+        }
+        return;
+    }
+    const TvgImage im1 = imgs[pr.slot1], im2 = imgs[pr.slot2];
+    const uint32_t* mm = matches + 2 * pr.match_off;
+    const int M = (int)pr.M;
+    if (lane == 0) {
+        PoseCands c;
+        double m9[9];
+        if (config == AMC_TVG_CALIBRATED || config == AMC_TVG_UNCALIBRATED) {
+            for (int i = 0; i < 9; ++i) m9[i] = pr.E[i];
+            pose_candidates_E(m9, c);
+        } else {
+            double K1[9], K2[9];
+            for (int i = 0; i < 9; ++i) m9[i] = pr.H[i];
+            calibration_matrix(im1.cam.model_id, im1.cam.params, K1);
+            calibration_matrix(im2.cam.model_id, im2.cam.params, K2);
+            pose_candidates_H(m9, K1, K2, c);
+        }
+        cands = c;
+    }
+    __syncthreads();
+    const int ncand = cands.n;
+    int best = 0;
+    uint32_t best_count = 0;
+    for (int k = 0; k < ncand; ++k) {
+        double R[9], t[3];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) R[i] = cands.R[k][i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) t[i] = cands.t[k][i];
+        const CheiralityBounds b = cheirality_bounds(R, t);
+        uint32_t cnt = 0;
+        for (int base = 0; base < M; base += 64) {
+            const int i = base + lane;
+            bool ok = false;
+            if (i < M) {
+                const Corr c = load_corr(im1, im2, mm, i);
+                double X[3];
+                ok = cheirality_point(R, t, b, c.x1, c.y1, c.x2, c.y2, X);
+            }
+            cnt += (uint32_t)__popcll(__ballot(ok));
+        }
+        if (cnt >= best_count) { best = k; best_count = cnt; }
+    }
+    double R[9], t[3];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) R[i] = cands.R[best][i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) t[i] = cands.t[best][i];
+    const CheiralityBounds b = cheirality_bounds(R, t);
+    double c2[3], baseline2;
+    second_centre(R, t, c2, &baseline2);
+    double* cs = cosine_ws + pr.match_off;
+    uint32_t n = 0;
+    for (int base = 0; base < M; base += 64) {
+        const int i = base + lane;
+        bool ok = false;
+        double cosine = 0.0;
+        if (i < M) {
+            const Corr c = load_corr(im1, im2, mm, i);
+            double X[3];
+            ok = cheirality_point(R, t, b, c.x1, c.y1, c.x2, c.y2, X);
+            if (ok) cosine = triangulation_cosine(c2, baseline2, X);
+        }
+        const unsigned long long bal = __ballot(ok);
+        if (ok) cs[n + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = cosine;
+        n += (uint32_t)__popcll(bal);
+    }
+    wave_mem_sync();
+    double cmed0 = 1.0, cmed1 = 1.0;
+    if (n > 0) {
+        cmed0 = select_cosine(cs, n, n / 2, lane);
+        if (n % 2 == 0) cmed1 = select_cosine(cs, n, n / 2 - 1, lane);
+    }
+    if (lane == 0) {
+        o->ok = 1;
+        o->t_is_zero = vec3_norm(t) == 0.0 ? 1 : 0;
+        o->num_points3D = n;
+        o->pad = 0;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) o->R[i] = R[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) o->t[i] = t[i];
+        double q[4];
+        rotation_to_quaternion(R, q);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o->q[i] = q[i];
+        o->cmed[0] = cmed0;
+        o->cmed[1] = cmed1;
+    }
+}
+
+}  // namespace
+
+hipError_t launch_pose(const TvgImage* imgs, const PosePair* pairs, uint32_t npairs, const uint32_t* matches,
+                       double* cosine_ws, PoseOut* out, hipStream_t s) {
+    if (npairs == 0) return hipSuccess;
+    hipLaunchKernelGGL(pose_kernel, dim3(npairs), dim3(64), 0, s, imgs, pairs, npairs, matches, cosine_ws, out);
+    return hipGetLastError();
+}
+
+}  // namespace amc

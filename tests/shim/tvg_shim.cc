@@ -1,6 +1,8 @@
 // Test-only host build of pycolmap_amd/csrc/tvg_math.h (the lane-local device numerics), so the
 // CPU suite can compare them bit-for-bit with the oracle without a GPU.
 #include "../../pycolmap_amd/csrc/tvg_math.h"
+#include "../../pycolmap_amd/csrc/pose_math.h"
+#include <vector>
 using namespace amc::tvg;
 extern "C" {
 int shim_estimate_f7(const double* p1, const double* p2, double* models) {
@@ -28,4 +30,80 @@ void shim_residuals(int kind, const double* m, const double* p1, const double* p
                            : h_residual(m, p1[2 * i], p1[2 * i + 1], p2[2 * i], p2[2 * i + 1]);
 }
 unsigned shim_temper(unsigned y) { return mt_temper(y); }
+
+// The relative-pose kernel's per-pair algorithm (csrc/pose.hip) run serially with the same
+// lane-local functions: cameras (model id + params), n inlier correspondences in image
+// coordinates, the geometry's config / E / H.  out: ok, config, num_points3D, then
+// R[9] t[3] q[4] tri_angle as doubles.
+static void shim_norm(int model, const double* prm, double x, double y, double* nx, double* ny) {
+    if (model == 0) { *nx = (x - prm[1]) / prm[0]; *ny = (y - prm[2]) / prm[0]; }
+    else { *nx = (x - prm[2]) / prm[0]; *ny = (y - prm[3]) / prm[1]; }
+}
+static double shim_select(const std::vector<double>& c, size_t rank) {
+    uint64_t K = 0;
+    for (int bit = 62; bit >= 0; --bit) {
+        const uint64_t T = K | (1ull << bit);
+        size_t cnt = 0;
+        for (double x : c) cnt += cosine_key(x) >= T;
+        if (cnt >= rank + 1) K = T;
+    }
+    for (double x : c)
+        if (cosine_key(x) == K) return x;
+    return 0.0;
+}
+void shim_pose(int model1, const double* prm1, int model2, const double* prm2, const double* p1, const double* p2,
+               int n, int config, const double* E, const double* H, int* iout, double* dout) {
+    iout[0] = 0; iout[1] = config; iout[2] = 0;
+    const double ident[17] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0, 0};
+    for (int i = 0; i < 17; ++i) dout[i] = ident[i];
+    if (config != 2 && config != 3 && config != 4 && config != 5 && config != 6) return;
+    std::vector<double> x1(n), y1(n), x2(n), y2(n);
+    for (int i = 0; i < n; ++i) {
+        shim_norm(model1, prm1, p1[2 * i], p1[2 * i + 1], &x1[i], &y1[i]);
+        shim_norm(model2, prm2, p2[2 * i], p2[2 * i + 1], &x2[i], &y2[i]);
+    }
+    PoseCands c;
+    if (config == 2 || config == 3) {
+        pose_candidates_E(E, c);
+    } else {
+        double K1[9], K2[9];
+        calibration_matrix(model1, prm1, K1);
+        calibration_matrix(model2, prm2, K2);
+        pose_candidates_H(H, K1, K2, c);
+    }
+    int best = 0;
+    size_t best_count = 0;
+    for (int k = 0; k < c.n; ++k) {
+        const CheiralityBounds b = cheirality_bounds(c.R[k], c.t[k]);
+        size_t cnt = 0;
+        double X[3];
+        for (int i = 0; i < n; ++i) cnt += cheirality_point(c.R[k], c.t[k], b, x1[i], y1[i], x2[i], y2[i], X);
+        if (cnt >= best_count) { best = k; best_count = cnt; }
+    }
+    const double* R = c.R[best];
+    const double* t = c.t[best];
+    const CheiralityBounds b = cheirality_bounds(R, t);
+    double c2[3], baseline2;
+    second_centre(R, t, c2, &baseline2);
+    std::vector<double> cs;
+    for (int i = 0; i < n; ++i) {
+        double X[3];
+        if (cheirality_point(R, t, b, x1[i], y1[i], x2[i], y2[i], X)) cs.push_back(triangulation_cosine(c2, baseline2, X));
+    }
+    double cmed[2] = {1.0, 1.0};
+    if (!cs.empty()) {
+        cmed[0] = shim_select(cs, cs.size() / 2);
+        if (cs.size() % 2 == 0) cmed[1] = shim_select(cs, cs.size() / 2 - 1);
+    }
+    double tri = median_angle_host((uint32_t)cs.size(), cmed);
+    if (config == 6) {
+        if (vec3_norm(t) == 0.0) { config = 5; tri = 0.0; }
+        else config = 4;
+    }
+    iout[0] = 1; iout[1] = config; iout[2] = (int)cs.size();
+    for (int i = 0; i < 9; ++i) dout[i] = R[i];
+    for (int i = 0; i < 3; ++i) dout[9 + i] = t[i];
+    rotation_to_quaternion(R, dout + 12);
+    dout[16] = tri;
+}
 }

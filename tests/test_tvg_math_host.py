@@ -19,8 +19,8 @@ SHIM = ROOT / "tests" / "shim" / "_build" / "libtvgshim.so"
 def shim():
     SHIM.parent.mkdir(exist_ok=True)
     src = ROOT / "tests" / "shim" / "tvg_shim.cc"
-    hdr = ROOT / "pycolmap_amd" / "csrc" / "tvg_math.h"
-    if not SHIM.exists() or SHIM.stat().st_mtime < max(src.stat().st_mtime, hdr.stat().st_mtime):
+    hdrs = [ROOT / "pycolmap_amd" / "csrc" / "tvg_math.h", ROOT / "pycolmap_amd" / "csrc" / "pose_math.h"]
+    if not SHIM.exists() or SHIM.stat().st_mtime < max(f.stat().st_mtime for f in [src] + hdrs):
         subprocess.run(["g++", "-O2", "-ffp-contract=off", "-fno-fast-math", "-std=c++17", "-shared",
                         "-fPIC", str(src), "-o", str(SHIM)], check=True)
     return C.CDLL(str(SHIM))
@@ -94,3 +94,74 @@ def test_roots_jacobi_residuals_temper_bit_exact(shim):
     # here: the known first output of mt19937(5489) state word tempering
     shim.shim_temper.restype = C.c_uint
     assert shim.shim_temper(0) == 0
+
+
+# ------------------------------------------------------------------ relative pose (pose_math.h) ----
+def _shim_pose(shim, cam1, cam2, p1, p2, config, E, H):
+    iout = np.zeros(3, dtype=np.int32)
+    dout = np.zeros(17)
+    prm1 = np.array(list(cam1.params)[:4], dtype=np.float64)
+    prm2 = np.array(list(cam2.params)[:4], dtype=np.float64)
+    a, b = np.ascontiguousarray(p1, dtype=np.float64), np.ascontiguousarray(p2, dtype=np.float64)
+    E = np.ascontiguousarray(E, dtype=np.float64).reshape(9)
+    H = np.ascontiguousarray(H, dtype=np.float64).reshape(9)
+    shim.shim_pose(C.c_int(cam1.model_id), _p(prm1), C.c_int(cam2.model_id), _p(prm2), _p(a), _p(b),
+                   C.c_int(len(a)), C.c_int(int(config)), _p(E), _p(H), _p(iout), _p(dout))
+    return dict(pose_ok=bool(iout[0]), config=int(iout[1]), num_points3D=int(iout[2]), R=dout[:9].reshape(3, 3),
+                tvec=dout[9:12].copy(), qvec=dout[12:16].copy(), tri_angle=float(dout[16]))
+
+
+def _same_pose(got, want):
+    assert got["pose_ok"] == want["pose_ok"] and got["config"] == want["config"]
+    assert got["num_points3D"] == want["num_points3D"]
+    for k in ("R", "tvec", "qvec"):
+        np.testing.assert_array_equal(bits(got[k]), bits(want[k]), err_msg=k)
+    assert bits(got["tri_angle"]) == bits(want["tri_angle"])
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_relative_pose_bit_exact(shim, seed):
+    """The kernel's per-pair pose algorithm (lane-local functions, selection-based median) equals the
+    oracle's EstimateTwoViewGeometryPose bit for bit: calibrated, uncalibrated (E of the calibrated
+    path), planar, panoramic, and a mixed SIMPLE_PINHOLE / PINHOLE camera pair."""
+    rng = np.random.default_rng(500 + seed)
+    kinds = [dict(), dict(planar=True), dict(pure_rotation=True, noise=0.05)]
+    sc = synth.two_view_scene(rng, num_inliers=int(rng.integers(20, 300)), num_outliers=int(rng.integers(0, 60)),
+                              **kinds[seed % 3])
+    cam1 = o.make_camera("PINHOLE", 1600, 1200, (1200.0, 1190.0, 800.0, 600.0), prior=True)
+    cam2 = o.make_camera("SIMPLE_PINHOLE", 1600, 1200, (1210.0, 801.0, 599.0), prior=True) if seed % 2 else cam1
+    r = o.estimate_two_view_geometry(cam1, sc["pts1"], cam2, sc["pts2"], sc["matches"])
+    assert r["config"] in (2, 3, 6)
+    m = sc["matches"][r["inlier_mask"]]
+    p1, p2 = sc["pts1"][m[:, 0]], sc["pts2"][m[:, 1]]
+    ident = np.c_[np.arange(len(m)), np.arange(len(m))].astype(np.uint32)
+    for cfg in {r["config"], 2, 3, 4, 5, 6}:
+        want = o.estimate_two_view_geometry_pose(cam1, p1, cam2, p2, ident, cfg, E=r["E"], H=r["H"])
+        got = _shim_pose(shim, cam1, cam2, p1, p2, cfg, r["E"], r["H"])
+        _same_pose(got, want)
+    # subsets: odd / even / tiny / empty correspondence lists (median of one, of two, of none)
+    for n in (0, 1, 2, 3, 8):
+        want = o.estimate_two_view_geometry_pose(cam1, p1[:n], cam2, p2[:n], ident[:n], 2, E=r["E"], H=r["H"])
+        _same_pose(_shim_pose(shim, cam1, cam2, p1[:n], p2[:n], 2, r["E"], r["H"]), want)
+
+
+def test_relative_pose_bit_exact_odd_inputs(shim):
+    """Configurations without a pose, the all-zero E of the uncalibrated path, an exact rotation
+    homography and correspondences behind the cameras."""
+    rng = np.random.default_rng(9)
+    sc = synth.two_view_scene(rng, num_inliers=60, num_outliers=0, noise=0.2)
+    cam = o.make_camera(prior=True)
+    m = sc["matches"]
+    p1, p2 = sc["pts1"][m[:, 0]], sc["pts2"][m[:, 1]]
+    ident = np.c_[np.arange(len(m)), np.arange(len(m))].astype(np.uint32)
+    Z = np.zeros((3, 3))
+    K = sc["K"]
+    Hrot = K @ sc["R"] @ np.linalg.inv(K)
+    cases = [(0, Z, Z), (1, Z, Z), (7, sc["E_true"], Z), (8, Z, Z), (3, Z, Z), (2, -sc["E_true"], Z),
+             (6, Z, Hrot), (5, Z, Hrot), (4, Z, -Hrot), (2, sc["E_true"].T, Z)]
+    for cfg, E, H in cases:
+        want = o.estimate_two_view_geometry_pose(cam, p1, cam, p2, ident, cfg, E=E, H=H)
+        _same_pose(_shim_pose(shim, cam, cam, p1, p2, cfg, E, H), want)
+    # swapped images: most triangulated points fall behind a camera for the planted E
+    want = o.estimate_two_view_geometry_pose(cam, p2, cam, p1, ident, 2, E=sc["E_true"], H=Z)
+    _same_pose(_shim_pose(shim, cam, cam, p2, p1, 2, sc["E_true"], Z), want)
