@@ -15,7 +15,8 @@ __version__ = "0.1.0"
 
 try:  # the compiled host layer; absent only before `python -m pycolmap_amd.build`
     from ._pycolmap import (  # noqa: F401
-        COLMAP_version, Camera, CameraModelId, Database, Device, ExhaustiveMatchingOptions, RANSACOptions,
+        COLMAP_version, Camera, CameraModelId, Database, Device, ExhaustiveMatchingOptions, RANSACOptions, Rigid3d,
+        Rotation3d,
         SequentialMatchingOptions, SiftMatchingOptions, TwoViewGeometry, TwoViewGeometryConfiguration,
         TwoViewGeometryOptions, essential_matrix_estimation, estimate_calibrated_two_view_geometry,
         estimate_two_view_geometry, estimate_two_view_geometry_pose, fundamental_matrix_estimation, has_cuda,

@@ -191,6 +191,10 @@ void MatchController::Match(const ImagePairs& image_pairs) {
             std::memcpy(j.tvg.E.data(), g.E, sizeof g.E);
             std::memcpy(j.tvg.F.data(), g.F, sizeof g.F);
             std::memcpy(j.tvg.H.data(), g.H, sizeof g.H);
+            if (vr.pose) {  // compute_relative_pose: cam2_from_cam1 goes to the qvec / tvec columns
+                std::memcpy(j.tvg.qvec.data(), vr.pose[p].qvec, sizeof vr.pose[p].qvec);
+                std::memcpy(j.tvg.tvec.data(), vr.pose[p].tvec, sizeof vr.pose[p].tvec);
+            }
             const uint8_t* mask = vr.inlier_mask + voff[p];
             const size_t m = j.matches.size() / 2;
             AppendInlierMatches(mask, j.matches.data(), m, &j.tvg.inlier_matches);

@@ -34,7 +34,8 @@ struct Stmt {
 }  // namespace
 
 // TwoViewGeometry::Invert (colmap/scene/two_view_geometry.cc): F <- F^T, E <- E^T, H <- H^-1,
-// swap the match columns.  (Relative pose is not computed on this path; identity stays identity.)
+// swap the match columns, cam2_from_cam1 <- Inverse(cam2_from_cam1) (colmap/geometry/rigid3.h: the
+// inverse quaternion, then the rotated negated translation, both as Eigen evaluates them).
 void TwoViewGeometryRow::Invert() {
     auto transpose = [](std::array<double, 9>& m) {
         std::swap(m[1], m[3]);
@@ -53,6 +54,22 @@ void TwoViewGeometryRow::Invert() {
         H[6] = c02 * inv; H[7] = (h[1] * h[6] - h[0] * h[7]) * inv; H[8] = (h[0] * h[4] - h[1] * h[3]) * inv;
     }
     for (size_t i = 0; i + 1 < inlier_matches.size(); i += 2) std::swap(inlier_matches[i], inlier_matches[i + 1]);
+    {
+        // Eigen::Quaterniond::inverse(): conjugate / squaredNorm (qvec is stored w, x, y, z)
+        const double x = qvec[1], y = qvec[2], z = qvec[3], w = qvec[0];
+        const double n2 = x * x + y * y + z * z + w * w;
+        double iw = 0.0, ix = 0.0, iy = 0.0, iz = 0.0;
+        if (n2 > 0.0) { ix = -x / n2; iy = -y / n2; iz = -z / n2; iw = w / n2; }
+        // Eigen's quaternion * vector: v + w * (2 q x v) + q x (2 q x v), v = -t
+        const double v0 = -tvec[0], v1 = -tvec[1], v2 = -tvec[2];
+        double u0 = iy * v2 - iz * v1, u1 = iz * v0 - ix * v2, u2 = ix * v1 - iy * v0;
+        u0 += u0; u1 += u1; u2 += u2;
+        const double r0 = v0 + iw * u0 + (iy * u2 - iz * u1);
+        const double r1 = v1 + iw * u1 + (iz * u0 - ix * u2);
+        const double r2 = v2 + iw * u2 + (ix * u1 - iy * u0);
+        qvec = {{iw, ix, iy, iz}};
+        tvec = {{r0, r1, r2}};
+    }
 }
 
 Database::Database(const std::string& path) {

@@ -11,8 +11,7 @@
 //
 // Differences, all documented in DESIGN.md section 7: results are deterministic (seed 0 per call,
 // also for estimate_two_view_geometry, which in the reference inherits the calling thread's PRNG
-// state); the relative pose (cam2_from_cam1, tri_angle) is not computed, so
-// essential_matrix_estimation returns cam2_from_cam1 = None.
+// state); the relative pose (cam2_from_cam1, tri_angle) comes from the pose kernel (amc_pose_pairs).
 #pragma once
 #include <pybind11/numpy.h>
 #include <pybind11/pybind11.h>
@@ -265,6 +264,13 @@ inline RANSACOptions PyRansacDefaults() {  // /root/reference/pycolmap/optim/bin
     return o;
 }
 
+inline PyRigid3d RigidFromPose(const amc_pose& q) {
+    PyRigid3d r;
+    r.rotation.xyzw = {{q.qvec[1], q.qvec[2], q.qvec[3], q.qvec[0]}};
+    r.translation = {{q.tvec[0], q.tvec[1], q.tvec[2]}};
+    return r;
+}
+
 // LORANSAC<...>::Estimate(points1, points2) through amc_ransac_pairs -> dict or None
 inline py::object RansacEstimate(int kind, const char* key, const PointsArray& p1, const PointsArray& p2,
                                  const PyCamera* cam1, const PyCamera* cam2, const RANSACOptions& opts) {
@@ -272,6 +278,7 @@ inline py::object RansacEstimate(int kind, const char* key, const PointsArray& p
     CheckSameSize(n1, n2, "points2D1.size() == points2D2.size()");
     amc_ransac_report rep{};
     std::vector<uint8_t> mask(n1, 0);
+    amc_pose pose{};
     {
         py::gil_scoped_release release;
         EstimatorCtx& E = TheEstimatorCtx();
@@ -294,6 +301,21 @@ inline py::object RansacEstimate(int kind, const char* key, const PointsArray& p
         rep = res.reports[0];
         if (n1) std::memcpy(mask.data(), res.inlier_mask, n1);
         amc_ransac_result_free(&res);
+        if (kind == AMC_RANSAC_E && rep.success) {
+            // PoseFromEssentialMatrix on the inlier correspondences
+            // (/root/reference/pycolmap/estimators/essential_matrix.h:63-83)
+            std::vector<uint32_t> inl;
+            for (size_t i = 0; i < n1; ++i)
+                if (mask[i]) {
+                    inl.push_back(static_cast<uint32_t>(i));
+                    inl.push_back(static_cast<uint32_t>(i));
+                }
+            amc_tvg g{};
+            g.config = AMC_TVG_CALIBRATED;
+            std::memcpy(g.E, rep.model, sizeof g.E);
+            const uint64_t ioff[2] = {0, inl.size() / 2};
+            EstCheck(amc_pose_pairs(ctx, &s1, &s2, 1, ioff, inl.data(), &g, &pose), "amc_pose_pairs");
+        }
     }
     if (!rep.success) return py::none();
     std::array<double, 9> model;
@@ -302,7 +324,7 @@ inline py::object RansacEstimate(int kind, const char* key, const PointsArray& p
     for (size_t i = 0; i < n1; ++i) inliers.append(py::bool_(mask[i] != 0));
     py::dict d;
     d[py::str(key)] = Mat3(model);
-    if (kind == AMC_RANSAC_E) d["cam2_from_cam1"] = py::none();  // relative pose: SURVEY.md 8f rank 4
+    if (kind == AMC_RANSAC_E) d["cam2_from_cam1"] = RigidFromPose(pose);
     d["num_inliers"] = static_cast<size_t>(rep.num_inliers);
     d["inliers"] = inliers;
     return std::move(d);
@@ -332,6 +354,8 @@ inline PyTwoViewGeometry EstimateTvg(const PyCamera& cam1, const PointsArray& p1
     const size_t M = matches.size() / 2;
     std::vector<uint8_t> mask(M, 0);
     amc_tvg t{};
+    amc_pose pose{};
+    bool have_pose = false;
     {
         py::gil_scoped_release release;
         EstimatorCtx& E = TheEstimatorCtx();
@@ -348,7 +372,15 @@ inline PyTwoViewGeometry EstimateTvg(const PyCamera& cam1, const PointsArray& p1
         EstCheck(amc_verify_pairs(ctx, &s1, &s2, 1, off, matches.data(), &to, /*seed=*/0, &vr), "amc_verify_pairs");
         t = vr.tvg[0];
         if (M) std::memcpy(mask.data(), vr.inlier_mask, M);
+        if (vr.pose) {
+            pose = vr.pose[0];
+            have_pose = true;
+        }
         amc_verify_result_free(&vr);
+    }
+    if (have_pose) {
+        g.cam2_from_cam1 = RigidFromPose(pose);
+        g.tri_angle = pose.tri_angle;
     }
     g.config = t.config;
     std::memcpy(g.E.data(), t.E, sizeof t.E);
@@ -401,6 +433,40 @@ inline void BindEstimators(py::module_& m) {
         "camera1"_a, "points1"_a, "camera2"_a, "points2"_a, "matches"_a = py::none(),
         "options"_a = TwoViewGeometryOptions());
     m.def(
+        "estimate_two_view_geometry_pose",
+        [](const PyCamera& c1, const PointsArray& p1, const PyCamera& c2, const PointsArray& p2,
+           PyTwoViewGeometry& g) {
+            // /root/reference/pycolmap/estimators/two_view_geometry.h:153-159; updates `geometry` in place
+            const size_t n1 = CheckPoints(p1, "points1"), n2 = CheckPoints(p2, "points2");
+            if (!c1.IsPinhole() || !c2.IsPinhole())
+                throw py::value_error("estimate_two_view_geometry_pose: only SIMPLE_PINHOLE / PINHOLE cameras are "
+                                      "supported on the accelerated path");
+            amc_pose pose{};
+            {
+                py::gil_scoped_release release;
+                EstimatorCtx& E = TheEstimatorCtx();
+                std::lock_guard<std::mutex> lock(E.mu);
+                amc_ctx* ctx = E.Get();
+                EstCheck(amc_upload_points_f64(ctx, 0, p1.data(), static_cast<uint32_t>(n1)), "amc_upload_points_f64");
+                EstCheck(amc_upload_points_f64(ctx, 1, p2.data(), static_cast<uint32_t>(n2)), "amc_upload_points_f64");
+                UploadCamera(ctx, 0, c1, false);
+                UploadCamera(ctx, 1, c2, false);
+                amc_tvg t{};
+                t.config = g.config;
+                std::memcpy(t.E, g.E.data(), sizeof t.E);
+                std::memcpy(t.H, g.H.data(), sizeof t.H);
+                const uint32_t s1 = 0, s2 = 1;
+                const uint64_t off[2] = {0, g.inlier_matches.size() / 2};
+                EstCheck(amc_pose_pairs(ctx, &s1, &s2, 1, off, g.inlier_matches.data(), &t, &pose), "amc_pose_pairs");
+            }
+            if (!pose.ok) return false;
+            g.config = pose.config;
+            g.cam2_from_cam1 = RigidFromPose(pose);
+            g.tri_angle = pose.tri_angle;
+            return true;
+        },
+        "camera1"_a, "points1"_a, "camera2"_a, "points2"_a, "geometry"_a);
+    m.def(
         "squared_sampson_error",
         [](const PointsArray& p1, const PointsArray& p2, const PointsArray& E) {
             const size_t n1 = CheckPoints(p1, "points2D1"), n2 = CheckPoints(p2, "points2D2");
@@ -418,10 +484,6 @@ inline void BindEstimators(py::module_& m) {
         },
         "points2D1"_a, "points2D2"_a, "E"_a,
         "Calculate the squared Sampson error for a given essential or fundamental matrix.");
-    m.def("estimate_two_view_geometry_pose", [](const py::args&, const py::kwargs&) {
-        throw py::value_error("estimate_two_view_geometry_pose (relative pose from E) is not part of the accelerated "
-                              "match + verify path yet (SURVEY.md section 8f, rank 4).");
-    });
 }
 
 }  // namespace amchost

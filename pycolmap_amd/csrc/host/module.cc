@@ -270,6 +270,71 @@ PYBIND11_MODULE(_pycolmap, m) {
                            "multiple_ignore_watermark", "force_H_use", "compute_relative_pose",
                            "multiple_models", "ransac"});
 
+    // Rotation3d / Rigid3d: value types of cam2_from_cam1 (/root/reference/pycolmap/geometry/bindings.h:24-104)
+    py::class_<PyRotation3d>(m, "Rotation3d")
+        .def(py::init<>())
+        .def(py::init([](const std::array<double, 4>& xyzw) {
+                 PyRotation3d r;
+                 r.xyzw = xyzw;
+                 return r;
+             }),
+             "xyzw"_a, "Quaternion in [x,y,z,w] format.")
+        .def_property(
+            "quat",
+            [](const PyRotation3d& r) {
+                py::array_t<double> a(4);
+                std::memcpy(a.mutable_data(), r.xyzw.data(), sizeof(double) * 4);
+                return a;
+            },
+            [](PyRotation3d& r, const std::array<double, 4>& q) { r.xyzw = q; }, "Quaternion in [x,y,z,w] format.")
+        .def("matrix", [](const PyRotation3d& r) { return Mat3(r.Matrix()); })
+        .def("norm",
+             [](const PyRotation3d& r) {
+                 return std::sqrt(r.xyzw[0] * r.xyzw[0] + r.xyzw[1] * r.xyzw[1] + r.xyzw[2] * r.xyzw[2] +
+                                  r.xyzw[3] * r.xyzw[3]);
+             })
+        .def("__repr__", [](const PyRotation3d& r) {
+            std::ostringstream ss;
+            ss << "Rotation3d(quat_xyzw=[" << r.xyzw[0] << ", " << r.xyzw[1] << ", " << r.xyzw[2] << ", " << r.xyzw[3]
+               << "])";
+            return ss.str();
+        });
+    py::class_<PyRigid3d>(m, "Rigid3d")
+        .def(py::init<>())
+        .def(py::init([](const PyRotation3d& r, const std::array<double, 3>& t) {
+            PyRigid3d x;
+            x.rotation = r;
+            x.translation = t;
+            return x;
+        }))
+        .def_readwrite("rotation", &PyRigid3d::rotation)
+        .def_property(
+            "translation",
+            [](const PyRigid3d& r) {
+                py::array_t<double> a(3);
+                std::memcpy(a.mutable_data(), r.translation.data(), sizeof(double) * 3);
+                return a;
+            },
+            [](PyRigid3d& r, const std::array<double, 3>& t) { r.translation = t; })
+        .def("matrix",
+             [](const PyRigid3d& r) {  // Rigid3d::ToMatrix: [R | t], 3 x 4
+                 const std::array<double, 9> R = r.rotation.Matrix();
+                 py::array_t<double> a({3, 4});
+                 double* d = a.mutable_data();
+                 for (int i = 0; i < 3; ++i) {
+                     for (int j = 0; j < 3; ++j) d[4 * i + j] = R[3 * i + j];
+                     d[4 * i + 3] = r.translation[i];
+                 }
+                 return a;
+             })
+        .def("__repr__", [](const PyRigid3d& r) {
+            std::ostringstream ss;
+            ss << "Rigid3d(quat_xyzw=[" << r.rotation.xyzw[0] << ", " << r.rotation.xyzw[1] << ", " << r.rotation.xyzw[2]
+               << ", " << r.rotation.xyzw[3] << "], t=[" << r.translation[0] << ", " << r.translation[1] << ", "
+               << r.translation[2] << "])";
+            return ss.str();
+        });
+
     py::class_<PyTwoViewGeometry> PyTvg(m, "TwoViewGeometry");
     py::object cfg_enum = py::module_::import("enum").attr("IntEnum")(
         "TwoViewGeometryConfiguration",
@@ -281,7 +346,7 @@ PYBIND11_MODULE(_pycolmap, m) {
         .def_property_readonly("E", [](const PyTwoViewGeometry& s) { return Mat3(s.E); })
         .def_property_readonly("F", [](const PyTwoViewGeometry& s) { return Mat3(s.F); })
         .def_property_readonly("H", [](const PyTwoViewGeometry& s) { return Mat3(s.H); })
-        .def_property_readonly("cam2_from_cam1", [](const PyTwoViewGeometry&) { return py::none(); })
+        .def_readonly("cam2_from_cam1", &PyTwoViewGeometry::cam2_from_cam1)
         .def_property_readonly("inlier_matches",
                                [](const PyTwoViewGeometry& s) { return MatchesArray(s.inlier_matches); })
         .def_readonly("tri_angle", &PyTwoViewGeometry::tri_angle);
@@ -324,6 +389,8 @@ PYBIND11_MODULE(_pycolmap, m) {
                  g.F = r.F;
                  g.H = r.H;
                  g.inlier_matches = r.inlier_matches;
+                 g.cam2_from_cam1.rotation.xyzw = {{r.qvec[1], r.qvec[2], r.qvec[3], r.qvec[0]}};
+                 g.cam2_from_cam1.translation = r.tvec;
                  return g;
              },
              "image_id1"_a, "image_id2"_a);

@@ -10,11 +10,33 @@
 namespace amchost {
 namespace py = pybind11;
 
+// Rotation3d / Rigid3d value types (/root/reference/pycolmap/geometry/bindings.h:24-104): only what a
+// TwoViewGeometry's cam2_from_cam1 needs - the quaternion in Eigen's (x, y, z, w) coefficient order,
+// the translation, and the matrix forms.
+struct PyRotation3d {
+    std::array<double, 4> xyzw{{0, 0, 0, 1}};
+    // Eigen::Quaterniond::toRotationMatrix
+    std::array<double, 9> Matrix() const {
+        const double x = xyzw[0], y = xyzw[1], z = xyzw[2], w = xyzw[3];
+        const double tx = 2.0 * x, ty = 2.0 * y, tz = 2.0 * z;
+        const double twx = tx * w, twy = ty * w, twz = tz * w;
+        const double txx = tx * x, txy = ty * x, txz = tz * x;
+        const double tyy = ty * y, tyz = tz * y, tzz = tz * z;
+        return {{1.0 - (tyy + tzz), txy - twz, txz + twy, txy + twz, 1.0 - (txx + tzz), tyz - twx, txz - twy,
+                 tyz + twx, 1.0 - (txx + tyy)}};
+    }
+};
+struct PyRigid3d {
+    PyRotation3d rotation;
+    std::array<double, 3> translation{{0, 0, 0}};
+};
+
 // TwoViewGeometry as pycolmap exposes it (/root/reference/pycolmap/estimators/two_view_geometry.h:79-93)
 struct PyTwoViewGeometry {
     int config = 0;
     std::array<double, 9> E{}, F{}, H{};
     std::vector<uint32_t> inlier_matches;
+    PyRigid3d cam2_from_cam1;
     double tri_angle = 0.0;
 };
 inline py::array_t<double> Mat3(const std::array<double, 9>& m) {

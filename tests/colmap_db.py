@@ -77,6 +77,8 @@ def read_all(path):
         def mat(b):
             return np.frombuffer(b, np.float64).reshape(3, 3).copy() if b else None
         tvgs[pid] = dict(inlier_matches=np.frombuffer(data or b"", np.uint32).reshape(rows, 2).copy(),
-                         config=config, F=mat(F), E=mat(E), H=mat(H))
+                         config=config, F=mat(F), E=mat(E), H=mat(H),
+                         qvec=np.frombuffer(q, np.float64).copy() if q else None,
+                         tvec=np.frombuffer(t, np.float64).copy() if t else None)
     con.close()
     return matches, tvgs

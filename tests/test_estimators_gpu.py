@@ -200,7 +200,14 @@ def test_python_estimator_api_matches_oracle():
     assert gotE is not None and wantE["success"]
     np.testing.assert_array_equal(bits(gotE["E"]), bits(wantE["model"]))
     np.testing.assert_array_equal(np.array(gotE["inliers"]), wantE["inliers"])
-    assert gotE["cam2_from_cam1"] is None
+    # cam2_from_cam1: PoseFromEssentialMatrix on the inlier correspondences
+    ocamE = o.make_camera("PINHOLE", sc["width"], sc["height"], (sc["f"], sc["f"], sc["width"] / 2.0, sc["height"] / 2.0))
+    inl = np.flatnonzero(wantE["inliers"]).astype(np.uint32)
+    wp = o.estimate_two_view_geometry_pose(ocamE, p1, ocamE, p2, np.c_[inl, inl], 2, E=wantE["model"])
+    rig = gotE["cam2_from_cam1"]
+    np.testing.assert_array_equal(bits(rig.rotation.quat), bits(wp["qvec"][[1, 2, 3, 0]]))   # Eigen order x, y, z, w
+    np.testing.assert_array_equal(bits(rig.translation), bits(wp["tvec"]))
+    assert np.allclose(rig.rotation.matrix(), wp["R"], atol=1e-12) and np.allclose(rig.matrix()[:, 3], wp["tvec"])
 
     res = pc.squared_sampson_error(n1, n2, gotE["E"])
     np.testing.assert_array_equal(bits(np.array(res)), bits(o.sampson_error(n1, n2, gotE["E"])))
@@ -210,6 +217,22 @@ def test_python_estimator_api_matches_oracle():
         cam.has_prior_focal_length = prior
         ocam = o.make_camera("PINHOLE", sc["width"], sc["height"],
                              (sc["f"], sc["f"], sc["width"] / 2.0, sc["height"] / 2.0), prior=prior)
+        # compute_relative_pose, and the same pose through estimate_two_view_geometry_pose afterwards
+        gp = pc.estimate_two_view_geometry(cam, sc["pts1"], cam, sc["pts2"], sc["matches"],
+                                           pc.TwoViewGeometryOptions(compute_relative_pose=True))
+        wpp = o.estimate_two_view_geometry(ocam, sc["pts1"], ocam, sc["pts2"], sc["matches"],
+                                           o.tvg_default_options(compute_relative_pose=1))
+        assert gp.config.name == wpp["config_name"] and wpp["pose_ok"]
+        np.testing.assert_array_equal(bits(gp.cam2_from_cam1.rotation.quat), bits(wpp["qvec"][[1, 2, 3, 0]]))
+        np.testing.assert_array_equal(bits(gp.cam2_from_cam1.translation), bits(wpp["tvec"]))
+        assert bits(gp.tri_angle) == bits(wpp["tri_angle"]) and gp.tri_angle > 0
+        g = pc.estimate_two_view_geometry(cam, sc["pts1"], cam, sc["pts2"], sc["matches"])
+        assert g.tri_angle == 0.0 and np.array_equal(g.cam2_from_cam1.rotation.quat, [0, 0, 0, 1])
+        assert pc.estimate_two_view_geometry_pose(cam, sc["pts1"], cam, sc["pts2"], g) is True
+        np.testing.assert_array_equal(bits(g.cam2_from_cam1.rotation.quat), bits(wpp["qvec"][[1, 2, 3, 0]]))
+        np.testing.assert_array_equal(bits(g.cam2_from_cam1.translation), bits(wpp["tvec"]))
+        assert bits(g.tri_angle) == bits(wpp["tri_angle"]) and g.config.name == wpp["config_name"]
+        assert pc.estimate_two_view_geometry_pose(cam, sc["pts1"], cam, sc["pts2"], pc.TwoViewGeometry()) is False
         g = pc.estimate_two_view_geometry(cam, sc["pts1"], cam, sc["pts2"], sc["matches"])
         w = o.estimate_two_view_geometry(ocam, sc["pts1"], ocam, sc["pts2"], sc["matches"], o.tvg_default_options())
         assert g.config.name == w["config_name"]

@@ -167,8 +167,18 @@ def test_estimator_bindings_argument_checks():
         pc.squared_sampson_error(a, b, np.eye(3))
     with pytest.raises(ValueError):
         pc.squared_sampson_error(a, a, np.eye(2))
-    with pytest.raises(ValueError):
-        pc.estimate_two_view_geometry_pose()
+    with pytest.raises(TypeError):
+        pc.estimate_two_view_geometry_pose()                    # five positional arguments, like the reference
+    with pytest.raises(ValueError, match="PINHOLE"):
+        pc.estimate_two_view_geometry_pose(pc.Camera.create(1, "OPENCV", 1000.0, 1600, 1200), a, cam, a,
+                                           pc.TwoViewGeometry())
+    g = pc.TwoViewGeometry()                                    # defaults of cam2_from_cam1 / tri_angle
+    assert g.tri_angle == 0.0 and np.array_equal(g.cam2_from_cam1.rotation.quat, [0, 0, 0, 1])
+    assert np.array_equal(g.cam2_from_cam1.translation, [0, 0, 0])
+    assert np.array_equal(g.cam2_from_cam1.matrix(), np.c_[np.eye(3), np.zeros(3)])
+    r = pc.Rotation3d([0.0, 0.0, np.sin(0.25), np.cos(0.25)])   # 0.5 rad about z
+    assert np.allclose(r.matrix(), [[np.cos(0.5), -np.sin(0.5), 0], [np.sin(0.5), np.cos(0.5), 0], [0, 0, 1]])
+    assert abs(r.norm() - 1.0) < 1e-15 and "Rotation3d" in repr(r) and "Rigid3d" in repr(pc.Rigid3d(r, [1, 2, 3]))
     import torch
     if not torch.cuda.is_available():
         with pytest.raises(RuntimeError, match="amc_ctx_create"):

@@ -41,7 +41,7 @@ def expected_rows(images, ids, blocks, sift=(0.8, 0.7, True), prior=False, tvg_k
                     inl = o.match_guided(a["descriptors"], a["keypoints"], b["descriptors"], b["keypoints"],
                                          r["config"], r["F"], r["H"], max_error, *sift)
                 if len(inl) >= MIN_INL:
-                    tv = dict(config=r["config"], F=r["F"], E=r["E"], H=r["H"], inl=inl)
+                    tv = dict(config=r["config"], F=r["F"], E=r["E"], H=r["H"], inl=inl, qvec=r["qvec"], tvec=r["tvec"])
             else:
                 m = np.zeros((0, 2), np.uint32)
             swap = id1 > id2
@@ -49,8 +49,13 @@ def expected_rows(images, ids, blocks, sift=(0.8, 0.7, True), prior=False, tvg_k
             if tv is None:
                 exp_t[pid] = dict(config=0, inl=np.zeros((0, 2), np.uint32), F=None, E=None, H=None)
             elif swap:
+                w, x, y, z = tv["qvec"]                       # Inverse(cam2_from_cam1): R^T, -R^T t
+                R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                              [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                              [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
                 exp_t[pid] = dict(config=tv["config"], inl=np.ascontiguousarray(tv["inl"][:, ::-1]), F=tv["F"].T,
-                                  E=tv["E"].T, H=np.linalg.inv(tv["H"]), H_approx=True)
+                                  E=tv["E"].T, H=np.linalg.inv(tv["H"]), H_approx=True,
+                                  qvec=np.array([w, -x, -y, -z]), tvec=-R.T @ tv["tvec"])
             else:
                 exp_t[pid] = tv
     return exp_m, exp_t
@@ -71,10 +76,14 @@ def compare(db_path, exp_m, exp_t):
         nver += 1
         for k in "FE":
             np.testing.assert_array_equal(g[k].view(np.uint64), np.ascontiguousarray(e[k]).view(np.uint64))
-        if e.get("H_approx"):
+        if e.get("H_approx"):     # stored inverted (id1 > id2): H^-1 and the inverse pose up to rounding
             np.testing.assert_allclose(g["H"], e["H"], rtol=1e-9, atol=1e-12)
+            np.testing.assert_allclose(g["qvec"], e["qvec"], rtol=0, atol=1e-12)
+            np.testing.assert_allclose(g["tvec"], e["tvec"], rtol=0, atol=1e-12)
         else:
             np.testing.assert_array_equal(g["H"].view(np.uint64), e["H"].view(np.uint64))
+            np.testing.assert_array_equal(g["qvec"].view(np.uint64), e["qvec"].view(np.uint64))
+            np.testing.assert_array_equal(g["tvec"].view(np.uint64), e["tvec"].view(np.uint64))
     return nver
 
 
@@ -136,6 +145,32 @@ def test_verify_matches_reads_stored_matches(tmp_path):
     assert st["pairs_matched"] == 0 and st["pairs_verified"] >= 2
     exp_m, exp_t = expected_rows(images, ids, [pairs])
     compare(db, exp_m, exp_t)
+
+
+def test_match_exhaustive_with_relative_pose(tmp_path):
+    """TwoViewGeometryOptions.compute_relative_pose: cam2_from_cam1 lands in the qvec / tvec columns (inverted
+    for pairs stored in swapped order), PLANAR_OR_PANORAMIC is resolved, and read_two_view_geometry returns it."""
+    rng = np.random.default_rng(77)
+    images = synth.multiview_scene(rng, num_images=6, n_feats=512)
+    for im in images:
+        im["prior"] = True
+    db = tmp_path / "pose.db"
+    ids = colmap_db.create(db, images)
+    pycolmap.match_exhaustive(db, matching_options={"block_size": 2},
+                              verification_options={"compute_relative_pose": True})
+    blocks = pycolmap._pycolmap._exhaustive_blocks(ids, 2)
+    exp_m, exp_t = expected_rows(images, ids, blocks, prior=True, tvg_kw=dict(compute_relative_pose=1))
+    assert compare(db, exp_m, exp_t) >= 5
+    moved = [e for e in exp_t.values() if len(e["inl"]) and not np.array_equal(e["qvec"], [1, 0, 0, 0])]
+    assert len(moved) >= 5 and any(e.get("H_approx") for e in moved)
+    d = pycolmap.Database(db)
+    pid, e = next((p, e) for p, e in exp_t.items() if len(e["inl"]) and not e.get("H_approx"))
+    id1, id2 = pycolmap.Database.pair_id_to_image_pair(pid)
+    g = d.read_two_view_geometry(id1, id2)
+    np.testing.assert_array_equal(g.cam2_from_cam1.rotation.quat, e["qvec"][[1, 2, 3, 0]])
+    np.testing.assert_array_equal(g.cam2_from_cam1.translation, e["tvec"])
+    gi = d.read_two_view_geometry(id2, id1)                     # asked in the other order: inverted on the way out
+    np.testing.assert_allclose(gi.cam2_from_cam1.rotation.quat, e["qvec"][[1, 2, 3, 0]] * [-1, -1, -1, 1], atol=1e-12)
 
 
 @pytest.mark.parametrize("prior", [False, True])

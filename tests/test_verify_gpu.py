@@ -181,8 +181,6 @@ def test_invalid_inputs_raise(amc_ctx):
     with pytest.raises(_capi.AmcError) as e:
         amc_ctx.verify_pairs([0], [1], [0, len(bad)], bad)
     assert e.value.code == _capi.AMC_E_INVALID
-    with pytest.raises(_capi.AmcError):
-        amc_ctx.verify_pairs([0], [1], [0, len(bad)], sc["matches"], _capi.tvg_options(compute_relative_pose=1))
     tvg, mask, _ = amc_ctx.verify_pairs([], [], [0], np.zeros((0, 2), np.uint32))
     assert len(tvg) == 0 and len(mask) == 0
 
