@@ -149,6 +149,19 @@ def verify_leg(ctx_factory, device_index: int, npairs: int, steps: int, warmup: 
         "configs": {_capi.CONFIG_NAMES[c]: int(n) for c, n in zip(*np.unique(tvg["config"], return_counts=True))},
         "mean_trials_E_F_H": [float(x) for x in tvg["num_trials"][:, :3].mean(axis=0)],
     }
+    # the same workload with TwoViewGeometryOptions.compute_relative_pose (pose.hip on the selected
+    # inliers after the estimation): reported beside the metric, not as the metric
+    popts = _capi.tvg_options(compute_relative_pose=1)
+    ctx.verify_pairs(s1, s2, off, matches, popts)
+    t0 = time.perf_counter()
+    ptvg, pmask, pst = ctx.verify_pairs(s1, s2, off, matches, popts)
+    pdt = time.perf_counter() - t0
+    out["with_relative_pose"] = {
+        "value": npairs / pdt, "unit": "pairs/s", "ms_per_step": 1e3 * pdt,
+        "pose_kernel_ms_per_step": pst["kernel_ms"] - kms / steps,
+        "mean_points3D_per_pair": float(pst["pose"]["num_points3D"].mean()),
+        "configs": {_capi.CONFIG_NAMES[c]: int(n) for c, n in zip(*np.unique(ptvg["config"], return_counts=True))},
+    }
     if cpu_sample > 0:
         # the oracle on every host core (OpenMP inside the oracle library, one pair per thread at a
         # time), `cpu_sample` pairs per core; every result is also compared with the GPU's
