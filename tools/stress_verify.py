@@ -20,6 +20,13 @@ def bits(a):
     return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
 
 
+def nbits(a):
+    """bit patterns with every NaN canonical (x86 / gfx950 default NaNs differ in sign)"""
+    a = np.ascontiguousarray(a, dtype=np.float64).reshape(-1).copy()
+    a[np.isnan(a)] = np.nan
+    return a.view(np.uint64)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rounds", type=int, default=10)
@@ -43,7 +50,8 @@ def main():
             ransac["min_num_trials"] = ransac["max_num_trials"]
         kw = dict(min_num_inliers=int(rng.choice([8, 15, 30])), detect_watermark=int(rng.integers(0, 2)),
                   force_H_use=int(rng.random() < 0.15), max_H_inlier_ratio=float(rng.choice([0.5, 0.8, 0.95])),
-                  min_E_F_inlier_ratio=float(rng.choice([0.8, 0.95])), ransac=ransac)
+                  min_E_F_inlier_ratio=float(rng.choice([0.8, 0.95])), compute_relative_pose=int(rng.integers(0, 2)),
+                  ransac=ransac)
         seed = int(rng.integers(0, 2 ** 31))
         scenes, priors = [], []
         for _ in range(args.pairs):
@@ -64,7 +72,7 @@ def main():
         off[1:] = np.cumsum([len(sc["matches"]) for sc in scenes])
         matches = np.concatenate([sc["matches"] for sc in scenes])
         try:
-            tvg, mask, _ = ctx.verify_pairs(s1, s1 + 1, off, matches, _capi.tvg_options(**kw), seed=seed)
+            tvg, mask, vst = ctx.verify_pairs(s1, s1 + 1, off, matches, _capi.tvg_options(**kw), seed=seed)
         except _capi.AmcError as e:
             print(f"round {rnd}: rejected option set ({e}); skipped")
             continue
@@ -85,6 +93,14 @@ def main():
                   g["model_inliers"].tolist() == w["inl"] and g["num_inliers"] == w["num_inliers"] and
                   np.array_equal(mask[int(off[p]):int(off[p + 1])], w["inlier_mask"]) and
                   all(np.array_equal(bits(g[k]), bits(w[k])) for k in "EFH"))
+            if ok and kw["compute_relative_pose"]:
+                q = vst["pose"][p]
+                ok = (bool(q["ok"]) == w["pose_ok"] and int(q["num_points3D"]) == w["num_points3D"] and
+                      np.array_equal(nbits(q["qvec"]), nbits(w["qvec"])) and np.array_equal(nbits(q["tvec"]), nbits(w["tvec"])) and
+                      np.array_equal(nbits(q["R"]), nbits(w["R"])) and np.array_equal(nbits(q["tri_angle"]), nbits(w["tri_angle"])))
+                if not ok:
+                    print(f"POSE MISMATCH pair {p}: gpu q={q['qvec']} t={q['tvec']} tri={q['tri_angle']} n={q['num_points3D']} "
+                          f"vs oracle q={w['qvec']} t={w['tvec']} tri={w['tri_angle']} n={w['num_points3D']}")
             total += 1
             if not ok:
                 bad += 1
