@@ -326,12 +326,25 @@ def main():
                 "peak": INT8_DENSE_PEAK_OPS / 1e12,
                 "unit": "TOP/s (int8; 256 ops per descriptor-pair distance)",
                 "frac": achieved / INT8_DENSE_PEAK_OPS,
-                "traffic": None,
+                "traffic": None,  # filled below from the committed PMC pass when the launch shape is the same
                 "kernel": "match_mfma_kernel" if st["pairs_mfma"] else "match_dot4_kernel",
                 "avg_kernel_ms": avg_kernel_s * 1e3,
                 "launches_per_step": launches_per_step,
             },
         }
+        # HBM bytes per launch of the dominant kernel: PMC counters cannot be collected inside this process,
+        # so the number comes from the committed rocprofv3 --pmc pass of this same command
+        # (profiles/r01/pmc_hbm_v6.*), and only when this run launches the same shape.
+        try:
+            pmc = json.loads((ROOT / "profiles" / "r01" / "pmc_hbm_v6.json").read_text())
+            per_launch = int(len(s1)) // launches_per_step
+            if st["pairs_mfma"] and args.feats == 4096 and abs(per_launch - pmc["pairs_per_launch"]) <= 1:
+                out["roofline"]["traffic"] = pmc["fetch_bytes_per_launch_corrected"]
+                out["roofline"]["traffic_unit"] = "bytes read from HBM per launch (FETCH_SIZE x 1024 x 2, gfx950 correction)"
+                out["roofline"]["traffic_source"] = "profiles/r01/pmc_hbm_v6.txt"
+                out["roofline"]["algorithmic_bytes"] = float(per_launch) * 2 * args.feats * 128
+        except (OSError, KeyError, ValueError):
+            pass
         if world == 1 and not args.no_cpu_baseline:
             cores = host_cores()
             arena_cpu = arena.cpu().numpy()
