@@ -399,3 +399,27 @@ def test_relative_pose_skips_configs_without_geometry():
     # no inlier matches at all
     p = o.estimate_two_view_geometry_pose(cam, sc["pts1"], cam, sc["pts2"], m[:0], 2, E=sc["E_true"])
     assert p["pose_ok"] and p["num_points3D"] == 0 and p["tri_angle"] == 0.0
+
+
+# ------------------------------------------------------------------------- golden fixture ----
+def test_golden_fixture_pins_the_oracle():
+    """tests/golden/tvg_golden_v1.npz: the oracle still produces what it produced when the fixture was
+    committed (configs, masks, trial counts, model / pose bit patterns), with and without the pose."""
+    import tvg_golden
+    n = 0
+    for c in tvg_golden.cases():
+        for pose in (0, 1):
+            cam1 = o.make_camera(c["cam1"][0], 1600, 1200, c["cam1"][1], prior=c["prior"])
+            cam2 = o.make_camera(c["cam2"][0], 1600, 1200, c["cam2"][1], prior=c["prior"])
+            r = o.estimate_two_view_geometry(cam1, c["pts1"], cam2, c["pts2"], c["matches"],
+                                             o.tvg_default_options(compute_relative_pose=pose, **c["opts"]), seed=0)
+            w = c["want"][pose]
+            tag = f"case {c['index']} pose {pose}"
+            assert r["config"] == w["config"] and r["trials"] == w["trials"] and r["inl"] == w["inl"], tag
+            np.testing.assert_array_equal(r["inlier_mask"], w["mask"], err_msg=tag)
+            assert r["num_points3D"] == w["points3D"], tag
+            assert tvg_golden.bits(r["tri_angle"])[0] == w["tri_angle"][0], tag
+            for f in tvg_golden.FIELDS:
+                np.testing.assert_array_equal(tvg_golden.bits(r[f]), w[f], err_msg=f"{tag} {f}")
+            n += 1
+    assert n == 24

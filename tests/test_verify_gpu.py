@@ -267,3 +267,39 @@ def test_non_finite_and_degenerate_inputs(amc_ctx):
         tvg, mask, off, want = run_both(amc_ctx, scenes, [prior] * len(scenes))
         for p in range(len(scenes)):
             assert_pair_equal(p, tvg, mask, off, want)
+
+
+def test_golden_fixture(amc_ctx):
+    """The HIP path against the committed fixture (tests/golden/tvg_golden_v1.npz): every case, with and
+    without compute_relative_pose, option overrides included.  No oracle call in this test."""
+    import tvg_golden
+    cases = list(tvg_golden.cases())
+    amc_ctx.reserve_slots(2 * len(cases))
+    for i, c in enumerate(cases):
+        amc_ctx.upload_points_f64(2 * i, c["pts1"])
+        amc_ctx.upload_points_f64(2 * i + 1, c["pts2"])
+        amc_ctx.upload_camera(2 * i, c["cam1"][0], 1600, 1200, c["cam1"][1], c["prior"])
+        amc_ctx.upload_camera(2 * i + 1, c["cam2"][0], 1600, 1200, c["cam2"][1], c["prior"])
+    ransac_keys = {"max_error", "min_inlier_ratio", "confidence", "dyn_num_trials_multiplier", "min_num_trials",
+                   "max_num_trials"}
+    for i, c in enumerate(cases):
+        for pose in (0, 1):
+            kw = {k: v for k, v in c["opts"].items() if k not in ransac_keys}
+            kw["ransac"] = {k: v for k, v in c["opts"].items() if k in ransac_keys}
+            kw["compute_relative_pose"] = pose
+            off = np.array([0, len(c["matches"])], dtype=np.uint64)
+            tvg, mask, st = amc_ctx.verify_pairs([2 * i], [2 * i + 1], off, c["matches"], _capi.tvg_options(**kw), seed=0)
+            w = c["want"][pose]
+            tag = f"case {i} pose {pose}"
+            g = tvg[0]
+            assert int(g["config"]) == w["config"], tag
+            assert g["num_trials"].tolist() == w["trials"] and g["model_inliers"].tolist() == w["inl"], tag
+            np.testing.assert_array_equal(mask, w["mask"], err_msg=tag)
+            for f in "EFH":
+                np.testing.assert_array_equal(tvg_golden.bits(g[f]), w[f], err_msg=f"{tag} {f}")
+            if pose:
+                q = st["pose"][0]
+                assert int(q["num_points3D"]) == w["points3D"], tag
+                assert tvg_golden.bits(q["tri_angle"])[0] == w["tri_angle"][0], tag
+                for f in ("qvec", "tvec", "R"):
+                    np.testing.assert_array_equal(tvg_golden.bits(q[f]), w[f], err_msg=f"{tag} {f}")
