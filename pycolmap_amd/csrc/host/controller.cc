@@ -71,6 +71,10 @@ uint32_t MatchController::SlotOf(image_t id) const {
 // FeatureMatcherCache::Setup + the GPU matcher's descriptor upload.  The LRU cache over SQLite is
 // replaced by a device-resident arena holding every image.
 void MatchController::Setup() {
+    struct SetupTimer {
+        double t0, *acc;
+        ~SetupTimer() { *acc += NowMs() - t0; }
+    } setup_timer{NowMs(), &stats.setup_ms};
     db_ = std::make_unique<Database>(path_);
     images_ = db_->ReadAllImages();
     const std::vector<CameraRow> cams = db_->ReadAllCameras();
@@ -104,6 +108,10 @@ void MatchController::Setup() {
 // FeatureMatcherController::Match (colmap/controllers/feature_matching_utils.cc), batched
 void MatchController::Match(const ImagePairs& image_pairs) {
     if (image_pairs.empty()) return;
+    struct TotalTimer {
+        double t0, *acc;
+        ~TotalTimer() { *acc += NowMs() - t0; }
+    } total_timer{NowMs(), &stats.match_total_ms};
     struct Job {
         image_t id1, id2;
         bool have_matches;
@@ -152,7 +160,9 @@ void MatchController::Match(const ImagePairs& image_pairs) {
         mo.max_distance = sift_.max_distance;
         mo.cross_check = sift_.cross_check;
         amc_match_result r;
+        const double t_call = NowMs();
         Check(amc_match_pairs(ctx_, s1.data(), s2.data(), which.size(), &mo, &r), "amc_match_pairs");
+        stats.match_call_ms += NowMs() - t_call;
         for (size_t p = 0; p < which.size(); ++p) {
             Job& j = jobs[which[p]];
             j.matches.assign(r.matches + 2 * r.offsets[p], r.matches + 2 * r.offsets[p + 1]);
@@ -181,9 +191,11 @@ void MatchController::Match(const ImagePairs& image_pairs) {
     if (!vwhich.empty()) {
         const amc_tvg_opts to = ToAmc(tvg_);
         amc_verify_result vr;
+        const double t_call = NowMs();
         Check(amc_verify_pairs(ctx_, v1.data(), v2.data(), vwhich.size(), voff.data(), vmatches.data(), &to,
                                /*seed=*/0, &vr),
               "amc_verify_pairs");
+        stats.verify_call_ms += NowMs() - t_call;
         for (size_t p = 0; p < vwhich.size(); ++p) {
             Job& j = jobs[vwhich[p]];
             const amc_tvg& g = vr.tvg[p];

@@ -77,6 +77,8 @@ struct MatchStats {
     size_t pairs_matched = 0, pairs_verified = 0, pairs_skipped = 0, pairs_guided = 0, loop_queries = 0,
            loop_pairs_scored = 0;
     double match_device_ms = 0, verify_device_ms = 0, guided_device_ms = 0, loop_device_ms = 0, db_ms = 0;
+    // wall time of the library calls (device time + the library's host side) and of Match() as a whole
+    double match_call_ms = 0, verify_call_ms = 0, match_total_ms = 0, setup_ms = 0;
     uint64_t num_distances = 0;
 };
 

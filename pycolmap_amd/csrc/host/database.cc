@@ -195,6 +195,53 @@ std::vector<uint8_t> Database::ReadDescriptors(image_t image_id, uint32_t* rows)
     return out;
 }
 
+std::vector<float> Database::ReadKeypoints(image_t image_id, uint32_t* rows, uint32_t* cols) const {
+    *rows = 0;
+    *cols = 0;
+    Stmt st(db_, Prepared("SELECT rows, cols, data FROM keypoints WHERE image_id = ?"));
+    sqlite3_bind_int64(st.s, 1, image_id);
+    std::vector<float> out;
+    if (!st.Step()) return out;
+    const uint32_t r = static_cast<uint32_t>(sqlite3_column_int64(st.s, 0));
+    const uint32_t c = static_cast<uint32_t>(sqlite3_column_int64(st.s, 1));
+    const int nbytes = sqlite3_column_bytes(st.s, 2);
+    if (static_cast<size_t>(nbytes) != static_cast<size_t>(r) * c * sizeof(float))
+        throw std::runtime_error("keypoints blob of image " + std::to_string(image_id) + " has inconsistent shape");
+    out.resize(static_cast<size_t>(r) * c);
+    if (nbytes) std::memcpy(out.data(), sqlite3_column_blob(st.s, 2), static_cast<size_t>(nbytes));
+    *rows = r;
+    *cols = c;
+    return out;
+}
+bool Database::ExistsKeypoints(image_t image_id) const {
+    Stmt st(db_, Prepared("SELECT 1 FROM keypoints WHERE image_id = ?"));
+    sqlite3_bind_int64(st.s, 1, image_id);
+    return st.Step();
+}
+bool Database::ExistsDescriptors(image_t image_id) const {
+    Stmt st(db_, Prepared("SELECT 1 FROM descriptors WHERE image_id = ?"));
+    sqlite3_bind_int64(st.s, 1, image_id);
+    return st.Step();
+}
+void Database::WriteKeypoints(image_t image_id, const float* data, uint32_t rows, uint32_t cols) {
+    Stmt st(db_, Prepared("INSERT INTO keypoints(image_id, rows, cols, data) VALUES(?, ?, ?, ?)"));
+    sqlite3_bind_int64(st.s, 1, image_id);
+    sqlite3_bind_int64(st.s, 2, rows);
+    sqlite3_bind_int64(st.s, 3, cols);
+    const size_t nbytes = static_cast<size_t>(rows) * cols * sizeof(float);
+    sqlite3_bind_blob64(st.s, 4, nbytes ? reinterpret_cast<const char*>(data) : "", nbytes, SQLITE_STATIC);
+    st.Step();
+}
+void Database::WriteDescriptors(image_t image_id, const uint8_t* data, uint32_t rows) {
+    Stmt st(db_, Prepared("INSERT INTO descriptors(image_id, rows, cols, data) VALUES(?, ?, ?, ?)"));
+    sqlite3_bind_int64(st.s, 1, image_id);
+    sqlite3_bind_int64(st.s, 2, rows);
+    sqlite3_bind_int64(st.s, 3, 128);
+    const size_t nbytes = static_cast<size_t>(rows) * 128;
+    sqlite3_bind_blob64(st.s, 4, nbytes ? reinterpret_cast<const char*>(data) : "", nbytes, SQLITE_STATIC);
+    st.Step();
+}
+
 bool Database::ExistsPair(const char* table, image_pair_t pair_id) const {
     Stmt st(db_, Prepared((std::string("SELECT 1 FROM ") + table + " WHERE pair_id = ?")));
     sqlite3_bind_int64(st.s, 1, static_cast<sqlite3_int64>(pair_id));

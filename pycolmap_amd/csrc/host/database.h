@@ -69,6 +69,13 @@ class Database {
     // keypoints blob: rows x cols float32; returns x,y only (rows x 2)
     std::vector<float> ReadKeypointsXY(image_t image_id, uint32_t* rows) const;
     std::vector<uint8_t> ReadDescriptors(image_t image_id, uint32_t* rows) const;
+    // the whole keypoints blob (rows x cols float32, cols = 2, 4 or 6)
+    std::vector<float> ReadKeypoints(image_t image_id, uint32_t* rows, uint32_t* cols) const;
+    // Database::WriteKeypoints / WriteDescriptors: one row per image, an existing row is an error
+    void WriteKeypoints(image_t image_id, const float* data, uint32_t rows, uint32_t cols);
+    void WriteDescriptors(image_t image_id, const uint8_t* data, uint32_t rows);
+    bool ExistsKeypoints(image_t image_id) const;
+    bool ExistsDescriptors(image_t image_id) const;
 
     bool ExistsMatches(image_t id1, image_t id2) const;
     bool ExistsInlierMatches(image_t id1, image_t id2) const;

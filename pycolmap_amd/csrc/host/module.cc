@@ -168,6 +168,8 @@ py::dict StatsDict(const MatchStats& s) {
     return py::dict("pairs_matched"_a = s.pairs_matched, "pairs_verified"_a = s.pairs_verified,
                     "pairs_skipped"_a = s.pairs_skipped, "match_device_ms"_a = s.match_device_ms,
                     "verify_device_ms"_a = s.verify_device_ms, "db_ms"_a = s.db_ms,
+                    "match_call_ms"_a = s.match_call_ms, "verify_call_ms"_a = s.verify_call_ms,
+                    "match_total_ms"_a = s.match_total_ms, "setup_ms"_a = s.setup_ms,
                     "num_distances"_a = s.num_distances, "pairs_guided"_a = s.pairs_guided,
                     "guided_device_ms"_a = s.guided_device_ms, "loop_queries"_a = s.loop_queries,
                     "loop_pairs_scored"_a = s.loop_pairs_scored, "loop_device_ms"_a = s.loop_device_ms);
@@ -380,6 +382,52 @@ PYBIND11_MODULE(_pycolmap, m) {
         .def("read_matches",
              [](const Database& db, image_t a, image_t b) { return MatchesArray(db.ReadMatches(a, b)); },
              "image_id1"_a, "image_id2"_a)
+        // keypoints / descriptors / matches accessors: the reference leaves them unbound
+        // (/root/reference/pycolmap/scene/database.h:35-41); names follow COLMAP's Database methods
+        .def("exists_keypoints", &Database::ExistsKeypoints, "image_id"_a)
+        .def("exists_descriptors", &Database::ExistsDescriptors, "image_id"_a)
+        .def("read_keypoints",
+             [](const Database& db, image_t id) {
+                 uint32_t rows = 0, cols = 0;
+                 const std::vector<float> v = db.ReadKeypoints(id, &rows, &cols);
+                 py::array_t<float> a({static_cast<py::ssize_t>(rows), static_cast<py::ssize_t>(cols)});
+                 if (!v.empty()) std::memcpy(a.mutable_data(), v.data(), v.size() * sizeof(float));
+                 return a;
+             },
+             "image_id"_a, "rows x cols float32 (cols = 2, 4 or 6: x, y[, scale, orientation | a11, a12, a21, a22])")
+        .def("read_descriptors",
+             [](const Database& db, image_t id) {
+                 uint32_t rows = 0;
+                 const std::vector<uint8_t> v = db.ReadDescriptors(id, &rows);
+                 py::array_t<uint8_t> a({static_cast<py::ssize_t>(rows), static_cast<py::ssize_t>(128)});
+                 if (!v.empty()) std::memcpy(a.mutable_data(), v.data(), v.size());
+                 return a;
+             },
+             "image_id"_a, "rows x 128 uint8")
+        .def("write_keypoints",
+             [](Database& db, image_t id, const py::array_t<float, py::array::c_style | py::array::forcecast>& kp) {
+                 if (kp.ndim() != 2 || (kp.shape(1) != 2 && kp.shape(1) != 4 && kp.shape(1) != 6))
+                     throw py::value_error("keypoints must be an N x 2, N x 4 or N x 6 float32 array");
+                 db.WriteKeypoints(id, kp.data(), static_cast<uint32_t>(kp.shape(0)), static_cast<uint32_t>(kp.shape(1)));
+             },
+             "image_id"_a, "keypoints"_a)
+        .def("write_descriptors",
+             [](Database& db, image_t id, const py::array_t<uint8_t, py::array::c_style>& d) {
+                 if (d.ndim() != 2 || d.shape(1) != 128)
+                     throw py::value_error("descriptors must be an N x 128 uint8 array");
+                 db.WriteDescriptors(id, d.data(), static_cast<uint32_t>(d.shape(0)));
+             },
+             "image_id"_a, "descriptors"_a)
+        .def("write_matches",
+             [](Database& db, image_t a, image_t b,
+                const py::array_t<uint32_t, py::array::c_style | py::array::forcecast>& m) {
+                 if (m.size() != 0 && (m.ndim() != 2 || m.shape(1) != 2))
+                     throw py::value_error("matches must be an M x 2 unsigned integer array");
+                 db.WriteMatches(a, b, std::vector<uint32_t>(m.data(), m.data() + m.size()));
+             },
+             "image_id1"_a, "image_id2"_a, "matches"_a)
+        .def("delete_matches", &Database::DeleteMatches, "image_id1"_a, "image_id2"_a)
+        .def("delete_inlier_matches", &Database::DeleteInlierMatches, "image_id1"_a, "image_id2"_a)
         .def("read_two_view_geometry",
              [](const Database& db, image_t a, image_t b) {
                  const TwoViewGeometryRow r = db.ReadTwoViewGeometry(a, b);

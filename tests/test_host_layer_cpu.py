@@ -119,6 +119,36 @@ def test_database_binding_reads_colmap_schema(tmp_path):
     assert g.config == pycolmap.TwoViewGeometryConfiguration.UNDEFINED and g.inlier_matches.shape == (0, 2)
     with pytest.raises(ValueError):
         pycolmap.Database(tmp_path / "nope.db")
+    # keypoints / descriptors / matches accessors (unbound in the reference)
+    np.testing.assert_array_equal(db.read_keypoints(ids[1]), np.ascontiguousarray(imgs[1]["keypoints"], np.float32))
+    np.testing.assert_array_equal(db.read_descriptors(ids[2]), imgs[2]["descriptors"])
+    assert db.read_keypoints(999).shape == (0, 0) and db.read_descriptors(999).shape == (0, 128)
+    assert db.exists_keypoints(ids[0]) and not db.exists_keypoints(999) and db.exists_descriptors(ids[0])
+    db.write_matches(ids[2], ids[1], m)                          # descending ids: stored swapped, read back as given
+    np.testing.assert_array_equal(db.read_matches(ids[2], ids[1]), m)
+    np.testing.assert_array_equal(db.read_matches(ids[1], ids[2]), m[:, ::-1])
+    assert db.num_matched_image_pairs == 3
+    db.delete_matches(ids[1], ids[2])
+    assert not db.exists_matches(ids[2], ids[1]) and db.num_matched_image_pairs == 2
+    with pytest.raises(ValueError):
+        db.write_matches(ids[0], ids[1], np.zeros((3, 3), np.uint32))
+    with pytest.raises(RuntimeError):
+        db.write_keypoints(ids[0], np.zeros((4, 2), np.float32))     # the row exists: UNIQUE constraint, like COLMAP's CHECK
+    with pytest.raises(ValueError):
+        db.write_descriptors(ids[0], np.zeros((4, 64), np.uint8))
+    import sqlite3
+    con = sqlite3.connect(db_path)
+    con.execute("INSERT INTO images(name, camera_id) VALUES ('extra.jpg', 1)")
+    new_id = con.execute("SELECT image_id FROM images WHERE name = 'extra.jpg'").fetchone()[0]
+    con.commit()
+    con.close()
+    kp = rng.uniform(0, 100, size=(7, 4)).astype(np.float32)
+    de = rng.integers(0, 256, size=(7, 128), dtype=np.uint8)
+    db.write_keypoints(new_id, kp)
+    db.write_descriptors(new_id, de)
+    np.testing.assert_array_equal(db.read_keypoints(new_id), kp)
+    np.testing.assert_array_equal(db.read_descriptors(new_id), de)
+    assert db.num_keypoints == 127 and db.num_descriptors == 127
 
 
 # ---- Camera + single-pair estimator bindings (surface only: no GPU here) --------------------------
