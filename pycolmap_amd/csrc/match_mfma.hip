@@ -226,6 +226,15 @@ __global__ __launch_bounds__(512) void match_mfma_kernel(
             auto phase = [&](i32x16& an, const YFrag& y, int xtn, const i32x16& ac, int xtc, int tile) {
                 an = __builtin_amdgcn_mfma_i32_32x32x32_i8(y.f[0], xf[xtn][0], y.ci, 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
+#if defined(AMC_DIAG) && (AMC_DIAG & 2)
+                an = __builtin_amdgcn_mfma_i32_32x32x32_i8(y.f[1], xf[xtn][1], an, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                an = __builtin_amdgcn_mfma_i32_32x32x32_i8(y.f[2], xf[xtn][2], an, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                pm = smax2(pm, ac[0]);  // timing diagnostic: one VALU per unit keeps the accumulators live
+                ptile = tile;
+                (void)insert;
+#else
                 insert((xtc + 3) & 3, pm, ptile);
                 __builtin_amdgcn_sched_barrier(0);
                 an = __builtin_amdgcn_mfma_i32_32x32x32_i8(y.f[1], xf[xtn][1], an, 0, 0, 0);
@@ -243,6 +252,7 @@ __global__ __launch_bounds__(512) void match_mfma_kernel(
                 m3 = smax3(m3, m4, ac[15]);
                 pm = smax2(m0, m3);
                 ptile = tile;
+#endif
                 __builtin_amdgcn_sched_barrier(0);
                 an = __builtin_amdgcn_mfma_i32_32x32x32_i8(y.f[3], xf[xtn][3], an, 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
@@ -266,6 +276,16 @@ __global__ __launch_bounds__(512) void match_mfma_kernel(
             // that completed it - the matrix pipe runs MFMAs in order, 32 clk each, so the value
             // has been written back for well over the 11 wait states an 8-pass MFMA needs.
 #define AMC_PHASE(accn, yfr, xtn, accc, xtc) phase(accn, yfr, xtn, accc, xtc, tile);
+#if defined(AMC_DIAG) && (AMC_DIAG & 4)
+#define AMC_DIAG_SYNC
+#else
+#define AMC_DIAG_SYNC asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads();
+#endif
+#if defined(AMC_DIAG) && (AMC_DIAG & 8)
+#define AMC_DIAG_STAGE(c__)
+#else
+#define AMC_DIAG_STAGE(c__) if ((c__) + 2 < nchunks) stage((c__) + 2, (c__) & 1);
+#endif
             // one step = one Y tile held in `yc`; prefetches the next tile into `yn`
 #define AMC_STEP(yc, yn, c_, yt_)                                                              \
     {                                                                                          \
@@ -273,9 +293,8 @@ __global__ __launch_bounds__(512) void match_mfma_kernel(
         const bool lastt = (yt__ == kYT - 1);                                                  \
         const bool cross = lastt && (c__ + 1 < nchunks);                                       \
         if (cross) {                                                                           \
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                   \
-            __syncthreads();                                                                   \
-            if (c__ + 2 < nchunks) stage(c__ + 2, c__ & 1);                                    \
+            AMC_DIAG_SYNC                                                                      \
+            AMC_DIAG_STAGE(c__)                                                                \
         }                                                                                      \
         if (active) {                                                                          \
             /* very last tile: re-read itself (result unused) to stay branch-free */          \
@@ -298,6 +317,8 @@ __global__ __launch_bounds__(512) void match_mfma_kernel(
             }
 #undef AMC_STEP
 #undef AMC_PHASE
+#undef AMC_DIAG_SYNC
+#undef AMC_DIAG_STAGE
             if (active) insert(3, pm, ptile);  // the last unit's maximum is still pending
             __syncthreads();  // everyone is done with both LDS chunk buffers
             // restart the stream for the next row block now: the copy runs under this block's
@@ -321,6 +342,11 @@ __global__ __launch_bounds__(512) void match_mfma_kernel(
                     if (lh == 0 && k < nrows) {
                         const int row = MODE == 0 ? k : (int)list[k];
                         Top2 o;
+#if defined(AMC_DIAG) && (AMC_DIAG & 1)
+                        // timing diagnostic: every row "has no match" (the scan state only feeds the pad word)
+                        o.best_v = 0; o.best_idx = 0xFFFFFFFFu; o.second_v = 0; o.pad = (uint32_t)(b ^ s ^ t) & 0u;
+                        out[row] = o;
+#else
                         o.best_v = (uint32_t)(b + xterm[xt]);
                         o.best_idx = o.best_v ? (uint32_t)t : 0xFFFFFFFFu;  // TILE of the best
                         o.second_v = (uint32_t)(s + xterm[xt]);
@@ -328,6 +354,7 @@ __global__ __launch_bounds__(512) void match_mfma_kernel(
                         out[row] = o;
                         // a larger second only ever rejects: rows failing now can be forgotten
                         if (MODE == 0) acc = one_way_accepts(o, lut, fp.max_ratio, fp.max_distance);
+#endif
                     }
                     if (MODE == 0) {  // accept bits of rows rowbase + xt*32 .. +31 (lanes 0..31)
                         const uint32_t bits = (uint32_t)__ballot(acc);
