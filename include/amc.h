@@ -219,6 +219,7 @@ typedef struct amc_verify_result {
     uint32_t kernel_launches;
     amc_pose* pose;        /* npairs when opts.compute_relative_pose (then tvg[p].config == pose[p].config),
                               else NULL */
+    double pose_kernel_ms; /* the pose kernel's share of kernel_ms */
     void* _priv;
 } amc_verify_result;
 

@@ -83,7 +83,7 @@ class Pose(C.Structure):
 class VerifyResult(C.Structure):
     _fields_ = [("npairs", C.c_size_t), ("tvg", C.POINTER(Tvg)), ("inlier_mask", C.POINTER(C.c_uint8)),
                 ("device_ms", C.c_double), ("kernel_ms", C.c_double), ("kernel_launches", C.c_uint32),
-                ("pose", C.POINTER(Pose)), ("_priv", C.c_void_p)]
+                ("pose", C.POINTER(Pose)), ("pose_kernel_ms", C.c_double), ("_priv", C.c_void_p)]
 
 
 class RansacReport(C.Structure):
@@ -396,6 +396,7 @@ class Context:
             mask = labels.astype(bool)
             # inlier_labels: 1 + index of the geometry a match belongs to (multiple_models), else 0 / 1
             stats = dict(device_ms=float(res.device_ms), kernel_ms=float(res.kernel_ms), inlier_labels=labels)
+            stats["pose_kernel_ms"] = float(res.pose_kernel_ms)
             if res.pose:  # compute_relative_pose: one amc_pose per pair
                 assert C.sizeof(Pose) == POSE_DTYPE.itemsize
                 stats["pose"] = (np.frombuffer(C.string_at(res.pose, n * C.sizeof(Pose)), dtype=POSE_DTYPE).copy()

@@ -1152,6 +1152,7 @@ static int verify_impl(amc_ctx* c, int mode, const uint32_t* slot1, const uint32
         out->pose = priv->pose.data();
         out->device_ms += pose_ms;
         out->kernel_ms += pose_ms;
+        out->pose_kernel_ms = pose_ms;
         out->kernel_launches += 1;
     }
     return AMC_OK;
@@ -1189,7 +1190,7 @@ static int verify_multiple(amc_ctx* c, const uint32_t* slot1, const uint32_t* sl
         for (size_t i = 0; i < M; ++i) remaining[p][i] = (uint32_t)i;
         active.push_back(p);
     }
-    double device_ms = 0.0, kernel_ms = 0.0;
+    double device_ms = 0.0, kernel_ms = 0.0, pose_ms = 0.0;
     uint32_t launches = 0;
     int rc = AMC_OK;
     for (int round = 0; round < 254 && !active.empty() && rc == AMC_OK; ++round) {
@@ -1211,6 +1212,7 @@ static int verify_multiple(amc_ctx* c, const uint32_t* slot1, const uint32_t* sl
         if (rc != AMC_OK) break;
         device_ms += r.device_ms;
         kernel_ms += r.kernel_ms;
+        pose_ms += r.pose_kernel_ms;
         launches += r.kernel_launches;
         std::vector<size_t> still;
         for (size_t a = 0; a < active.size(); ++a) {
@@ -1264,6 +1266,7 @@ static int verify_multiple(amc_ctx* c, const uint32_t* slot1, const uint32_t* sl
     out->tvg = priv->tvg.data();
     out->inlier_mask = priv->mask.data();
     out->pose = o.compute_relative_pose ? priv->pose.data() : nullptr;
+    out->pose_kernel_ms = pose_ms;
     out->device_ms = device_ms;
     out->kernel_ms = kernel_ms;
     out->kernel_launches = launches;
