@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <map>
 #include <new>
 #include <string>
 #include <vector>
@@ -94,6 +95,18 @@ struct PinBuf {
     }
 };
 
+// key of a cached dyn_max_num_trials table
+struct TrialTabKey {
+    uint32_t M;
+    double confidence, multiplier;
+    bool operator<(const TrialTabKey& o) const {
+        if (M != o.M) return M < o.M;
+        if (confidence != o.confidence) return confidence < o.confidence;
+        return multiplier < o.multiplier;
+    }
+};
+constexpr size_t kTrialTabCacheWords = size_t(64) << 20;  // 256 MB of uint32
+
 }  // namespace
 
 struct amc_ctx {
@@ -125,6 +138,9 @@ struct amc_ctx {
     DevBuf<double> d_tws;
     DevBuf<uint8_t> d_tmaskws, d_toutmask;
     DevBuf<TvgOut> d_tout;
+    // dyn_max_num_trials tables by (match count, confidence, multiplier), see verify_impl
+    std::map<TrialTabKey, std::vector<uint32_t>> trial_tabs;
+    size_t trial_tab_words = 0;
     // relative-pose scratch
     DevBuf<PosePair> d_ppairs;
     DevBuf<uint32_t> d_pmatches;
@@ -810,7 +826,7 @@ void pose_default(amc_pose* q, int32_t config) {
 // kernel_ms (optional): the pose kernel's duration.
 static int pose_impl(amc_ctx* c, const char* who, const uint32_t* slot1, const uint32_t* slot2, size_t npairs,
                      const uint64_t* match_offsets, const uint32_t* inlier_matches, const amc_tvg* geoms,
-                     amc_pose* out, double* kernel_ms) {
+                     amc_pose* out, double* kernel_ms, bool indices_checked = false) {
     if (kernel_ms) *kernel_ms = 0.0;
     if (!c) return fail(AMC_E_INVALID, "%s: NULL ctx", who);
     if (npairs == 0) return AMC_OK;
@@ -839,10 +855,11 @@ static int pose_impl(amc_ctx* c, const char* who, const uint32_t* slot1, const u
              (b.cam.model_id != AMC_CAM_SIMPLE_PINHOLE && b.cam.model_id != AMC_CAM_PINHOLE)))
             return fail(AMC_E_INVALID, "%s: pair %zu: the relative pose supports SIMPLE_PINHOLE / PINHOLE "
                         "cameras only", who, p);
-        for (uint64_t k = match_offsets[p]; k < match_offsets[p + 1]; ++k)
-            if (inlier_matches[2 * k] >= a.kp_rows || inlier_matches[2 * k + 1] >= b.kp_rows)
-                return fail(AMC_E_INVALID, "%s: pair %zu match %llu indexes past the keypoints", who, p,
-                            (unsigned long long)(k - match_offsets[p]));
+        if (!indices_checked)  // (amc_verify_pairs passes a subset of matches it has checked already)
+            for (uint64_t k = match_offsets[p]; k < match_offsets[p + 1]; ++k)
+                if (inlier_matches[2 * k] >= a.kp_rows || inlier_matches[2 * k + 1] >= b.kp_rows)
+                    return fail(AMC_E_INVALID, "%s: pair %zu match %llu indexes past the keypoints", who, p,
+                                (unsigned long long)(k - match_offsets[p]));
         pp[p].slot1 = slot1[p];
         pp[p].slot2 = slot2[p];
         pp[p].match_off = match_offsets[p];
@@ -938,10 +955,21 @@ static int verify_impl(amc_ctx* c, int mode, const uint32_t* slot1, const uint32
         if (M > 65535) return fail(AMC_E_INVALID, "amc_verify_pairs: pair %zu has %llu matches (> 65535)", p,
                                    (unsigned long long)M);
         maxM = std::max<uint32_t>(maxM, (uint32_t)M);
-        for (uint64_t k = match_offsets[p]; k < match_offsets[p + 1]; ++k)
-            if (matches[2 * k] >= a.kp_rows || matches[2 * k + 1] >= b.kp_rows)
-                return fail(AMC_E_INVALID, "amc_verify_pairs: pair %zu match %llu indexes past the keypoints",
-                            p, (unsigned long long)(k - match_offsets[p]));
+        {
+            // largest index per column first (a loop the compiler vectorises); the offending match is only
+            // looked for when there is one
+            uint32_t mx1 = 0, mx2 = 0;
+            const uint32_t* mm = matches + 2 * match_offsets[p];
+            for (uint64_t k = 0; k < M; ++k) {
+                mx1 = std::max(mx1, mm[2 * k]);
+                mx2 = std::max(mx2, mm[2 * k + 1]);
+            }
+            if (M && (mx1 >= a.kp_rows || mx2 >= b.kp_rows))
+                for (uint64_t k = 0; k < M; ++k)
+                    if (mm[2 * k] >= a.kp_rows || mm[2 * k + 1] >= b.kp_rows)
+                        return fail(AMC_E_INVALID, "amc_verify_pairs: pair %zu match %llu indexes past the keypoints",
+                                    p, (unsigned long long)k);
+        }
         const bool uses_E = mode == 0 ? (!o.force_H_use && a.cam.has_prior && b.cam.has_prior) : mode == 3;
         if (uses_E &&
             ((a.cam.model_id != AMC_CAM_SIMPLE_PINHOLE && a.cam.model_id != AMC_CAM_PINHOLE) ||
@@ -1004,13 +1032,34 @@ static int verify_impl(amc_ctx* c, int mode, const uint32_t* slot1, const uint32
         const uint32_t M = (uint32_t)(match_offsets[p + 1] - match_offsets[p]);
         if (tab_of_M[M] < 0) {
             tab_of_M[M] = (int64_t)tabs.size();
-            for (int t = 0; t < 3; ++t)
-                for (uint32_t i = 0; i <= M; ++i) {
-                    const size_t v = M ? compute_num_trials_host(i, M, o.ransac.confidence,
-                                                                 o.ransac.dyn_num_trials_multiplier, kmins[t])
-                                       : 0;
-                    tabs.push_back(v > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)v);
+            // the table of one match count depends on (M, confidence, multiplier) only: kept across calls
+            // (a pow and two logs per entry; a pipeline sees the same few hundred counts again and again)
+            const TrialTabKey key{M, o.ransac.confidence, o.ransac.dyn_num_trials_multiplier};
+            // (NaN options would break the map's ordering: those tables are rebuilt every time)
+            const bool cacheable = key.confidence == key.confidence && key.multiplier == key.multiplier;
+            auto it = cacheable ? c->trial_tabs.find(key) : c->trial_tabs.end();
+            if (it == c->trial_tabs.end()) {
+                std::vector<uint32_t> t3;
+                t3.reserve(3 * ((size_t)M + 1));
+                for (int t = 0; t < 3; ++t)
+                    for (uint32_t i = 0; i <= M; ++i) {
+                        const size_t v = M ? compute_num_trials_host(i, M, o.ransac.confidence,
+                                                                     o.ransac.dyn_num_trials_multiplier, kmins[t])
+                                           : 0;
+                        t3.push_back(v > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)v);
+                    }
+                if (!cacheable) {
+                    tabs.insert(tabs.end(), t3.begin(), t3.end());
+                } else {
+                    if (c->trial_tab_words + t3.size() > kTrialTabCacheWords) {  // bounded: start over
+                        c->trial_tabs.clear();
+                        c->trial_tab_words = 0;
+                    }
+                    c->trial_tab_words += t3.size();
+                    it = c->trial_tabs.emplace(key, std::move(t3)).first;
                 }
+            }
+            if (it != c->trial_tabs.end()) tabs.insert(tabs.end(), it->second.begin(), it->second.end());
         }
         tp[p].slot1 = slot1[p];
         tp[p].slot2 = slot2[p];
@@ -1142,7 +1191,7 @@ static int verify_impl(amc_ctx* c, int mode, const uint32_t* slot1, const uint32
         priv->pose.resize(npairs);
         double pose_ms = 0.0;
         const int rc = pose_impl(c, "amc_verify_pairs", slot1, slot2, npairs, ioff.data(), im.data(), priv->tvg.data(),
-                                 priv->pose.data(), &pose_ms);
+                                 priv->pose.data(), &pose_ms, /*indices_checked=*/true);
         if (rc != AMC_OK) {
             delete priv;
             std::memset(out, 0, sizeof *out);
