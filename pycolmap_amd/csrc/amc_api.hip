@@ -127,10 +127,15 @@ struct amc_ctx {
     DevBuf<uint32_t> d_accmask;  // one accept bit per row-table entry (mfma pairs)
     DevBuf<GuidedDev> d_guided;  // guided matching: one filter model per pair of the batch
     DevBuf<uint32_t> d_pair_off, d_pair_cnt, d_matches, d_cand_cnt, d_candbuf;
-    PinBuf<PairDev> h_pairs;
-    PinBuf<Dot4Work> h_work;
-    PinBuf<uint32_t> h_order, h_order2, h_pair_off, h_pair_cnt, h_matches, h_scalars;
+    // host staging of a match batch, two sets: batch k+1 is prepared and enqueued while the results of
+    // batch k are still being copied out and scattered (match_impl)
+    PinBuf<PairDev> h_pairs[2];
+    PinBuf<Dot4Work> h_work[2];
+    PinBuf<uint32_t> h_order[2], h_order2[2], h_pair_off[2], h_pair_cnt[2], h_matches[2], h_bscalars[2];
+    PinBuf<uint32_t> h_scalars;
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t bev[2][5] = {{nullptr, nullptr, nullptr, nullptr, nullptr},
+                            {nullptr, nullptr, nullptr, nullptr, nullptr}};  // scan start/end, cross end, small D2H, matches
     // verification scratch
     DevBuf<TvgImage> d_timgs;
     DevBuf<TvgPair> d_tpairs;
@@ -195,6 +200,8 @@ int amc_ctx_create(int device_id, amc_ctx** out) {
     }
     c->stream = c->own_stream;
     for (auto& ev : c->ev) (void)hipEventCreate(&ev);
+    for (auto& set : c->bev)
+        for (auto& ev : set) (void)hipEventCreate(&ev);
     // acos table with the HOST libm (the same one COLMAP's CPU path and the oracle call)
     c->h_lut.resize(kAcosLutSize);
     const float kDistNorm = 1.0f / (512.0f * 512.0f);
@@ -233,8 +240,11 @@ void amc_ctx_destroy(amc_ctx* c) {
     c->d_rowbuf.release(); c->d_colbuf.release(); c->d_accmask.release(); c->d_guided.release();
     c->d_pair_off.release(); c->d_pair_cnt.release(); c->d_matches.release();
     c->d_cand_cnt.release(); c->d_candbuf.release();
-    c->h_pairs.release(); c->h_work.release(); c->h_order.release(); c->h_order2.release();
-    c->h_pair_off.release(); c->h_pair_cnt.release(); c->h_matches.release();
+    for (int k = 0; k < 2; ++k) {
+        c->h_pairs[k].release(); c->h_work[k].release(); c->h_order[k].release(); c->h_order2[k].release();
+        c->h_pair_off[k].release(); c->h_pair_cnt[k].release(); c->h_matches[k].release();
+        c->h_bscalars[k].release();
+    }
     c->h_scalars.release();
     c->d_timgs.release(); c->d_tpairs.release(); c->d_tmatches.release(); c->d_ttabs.release();
     c->d_mtinit.release(); c->d_tws.release(); c->d_tmaskws.release(); c->d_toutmask.release();
@@ -242,6 +252,9 @@ void amc_ctx_destroy(amc_ctx* c) {
     c->d_ppairs.release(); c->d_pmatches.release(); c->d_pcos.release(); c->d_pout.release();
     for (auto& ev : c->ev)
         if (ev) (void)hipEventDestroy(ev);
+    for (auto& set : c->bev)
+        for (auto& ev : set)
+            if (ev) (void)hipEventDestroy(ev);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -425,130 +438,179 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
     uint32_t kernel_launches = 0;
     HIPCHK(hipEventRecord(c->ev[0], st));
 
-    size_t begin = 0;
     int rc = AMC_OK;
-    while (begin < npairs && rc == AMC_OK) {
-        // ---- carve a batch ---------------------------------------------------------------
-        size_t end = begin, top_rows = 0, top_cols = 0, cap = 0;
-        while (end < npairs) {
-            const Slot& a = c->slots[slot1[end]];
-            const Slot& b = c->slots[slot2[end]];
-            const size_t nr = a.dev.rows_pad, nc = b.dev.rows_pad;
+    auto hc = [&](hipError_t e, const char* what) {
+        if (e != hipSuccess && rc == AMC_OK)
+            rc = fail(AMC_E_HIP, "amc_match_pairs: %s: %s", what, hipGetErrorString(e));
+        return e == hipSuccess;
+    };
+    // test hook: a smaller per-batch budget, so that small inputs exercise the multi-batch pipeline
+    size_t max_entries = kMaxTop2Entries;
+    if (const char* e = std::getenv("AMC_MATCH_BATCH_ENTRIES")) {
+        const long long v = std::atoll(e);
+        if (v > 0) max_entries = std::min<size_t>(kMaxTop2Entries, (size_t)v);
+    }
+    FinalizeParams fp;
+    fp.max_ratio = max_ratio_f;
+    fp.max_distance = (float)o.max_distance;
+    fp.cross_check = o.cross_check ? 1 : 0;
+    fp.reserved = 0;
+
+    // A batch goes through four steps.  Steps of consecutive batches are interleaved so that the device
+    // never waits for the host between them:
+    //   prepare(k+1)   host only: route pairs to kernels, queue orders, staging set (k+1)&1   } while the device
+    //   collect(k)     wait for batch k's counters, enqueue the copy of its matches            } runs batch k
+    //   enqueue(k+1)   H2D + all kernels + the counters' D2H, behind that copy in stream order
+    //   scatter(k)     wait for the matches, append them to the result                         (device runs k+1)
+    struct Batch {
+        size_t begin = 0, end = 0, nb = 0, top_rows = 0, top_cols = 0, cap = 0;
+        size_t row_off = 0, nwork = 0, nord = 0;
+        int set = 0;
+        uint32_t total = 0;
+    };
+    auto carve = [&](size_t begin, int set) {
+        Batch b;
+        b.begin = b.end = begin;
+        b.set = set;
+        while (b.end < npairs) {
+            const Slot& x = c->slots[slot1[b.end]];
+            const Slot& y = c->slots[slot2[b.end]];
+            const size_t nr = x.dev.rows_pad, nc = y.dev.rows_pad;
             // cross-checked matches are one-to-one; without the cross check every row of image 1
             // may match (several rows may share a column)
-            const size_t mc = o.cross_check ? std::min(a.dev.rows, b.dev.rows) : a.dev.rows;
-            if (end > begin && (top_rows + nr > kMaxTop2Entries || top_cols + nc > kMaxTop2Entries ||
-                                cap + mc > kMaxMatchCap || end - begin >= (1u << 24)))
+            const size_t mc = o.cross_check ? std::min(x.dev.rows, y.dev.rows) : x.dev.rows;
+            if (b.end > b.begin && (b.top_rows + nr > max_entries || b.top_cols + nc > max_entries ||
+                                    b.cap + mc > kMaxMatchCap || b.end - b.begin >= (1u << 24)))
                 break;
-            top_rows += nr; top_cols += nc; cap += mc; ++end;
+            b.top_rows += nr; b.top_cols += nc; b.cap += mc; ++b.end;
         }
-        const size_t nb = end - begin;
-        auto hc = [&](hipError_t e, const char* what) {
-            if (e != hipSuccess && rc == AMC_OK)
-                rc = fail(AMC_E_HIP, "amc_match_pairs: %s: %s", what, hipGetErrorString(e));
-            return e == hipSuccess;
-        };
-        if (!hc(c->h_pairs.ensure(nb), "pinned pairs") || !hc(c->d_pairs.ensure(nb), "dev pairs") ||
-            !hc(c->h_order.ensure(nb), "pinned order") || !hc(c->d_order.ensure(nb), "dev order") ||
-            !hc(c->d_rowbuf.ensure(top_rows), "row top2") || !hc(c->d_colbuf.ensure(top_cols), "col top2") ||
-            !hc(c->d_accmask.ensure(top_rows / 32 + 8), "accept mask") ||
-            !hc(c->d_pair_off.ensure(nb), "pair_off") || !hc(c->d_pair_cnt.ensure(nb), "pair_cnt") ||
-            !hc(c->h_pair_off.ensure(nb), "pinned pair_off") || !hc(c->h_pair_cnt.ensure(nb), "pinned pair_cnt") ||
-            !hc(c->d_matches.ensure(2 * cap), "dev matches") ||
-            !hc(c->d_cand_cnt.ensure(nb), "cand_cnt") || !hc(c->d_candbuf.ensure(top_cols), "candbuf"))
-            break;
-
-        // ---- route each pair to a kernel -------------------------------------------------
+        b.nb = b.end - b.begin;
+        return b;
+    };
+    // host side of a batch: which kernel takes each pair, the work queues (mfma: one item per pair, in
+    // an order that keeps co-resident workgroups on the same streamed image; dot4: one item per 64 rows)
+    auto prepare = [&](Batch& b) {
+        const int k = b.set;
+        const size_t nb = b.nb, begin = b.begin;
+        if (!hc(c->h_pairs[k].ensure(nb), "pinned pairs") || !hc(c->h_order[k].ensure(nb), "pinned order") ||
+            !hc(c->h_order2[k].ensure(nb), "pinned order2") || !hc(c->h_pair_off[k].ensure(nb), "pinned pair_off") ||
+            !hc(c->h_pair_cnt[k].ensure(nb), "pinned pair_cnt") || !hc(c->h_bscalars[k].ensure(16), "pinned scalars"))
+            return false;
         // mfma: exact for any u8 values and sizes; the lazy cross check's candidate bitmap
         // (select_candidates_kernel) holds kSelectMaxCols image-2 rows, larger images take the dot4 path.
         std::vector<uint8_t> want_mfma(nb, 0);
         for (size_t i = 0; i < nb; ++i) {
-            const Slot& a = c->slots[slot1[begin + i]];
-            const Slot& b = c->slots[slot2[begin + i]];
-            const bool nonempty = a.dev.rows > 0 && b.dev.rows > 0;
+            const Slot& x = c->slots[slot1[begin + i]];
+            const Slot& y = c->slots[slot2[begin + i]];
+            const bool nonempty = x.dev.rows > 0 && y.dev.rows > 0;
             want_mfma[i] = nonempty && o.kernel != AMC_KERNEL_DOT4 && !geoms &&
-                           (!o.cross_check || b.dev.rows_pad <= mfma_max_cols);
+                           (!o.cross_check || y.dev.rows_pad <= mfma_max_cols);
         }
+        PairDev* hp = c->h_pairs[k].p;
         size_t row_off = 0, col_off = 0, nwork = 0, nord = 0;
         for (size_t i = 0; i < nb; ++i) {
-            const Slot& a = c->slots[slot1[begin + i]];
-            const Slot& b = c->slots[slot2[begin + i]];
-            const bool nonempty = a.dev.rows > 0 && b.dev.rows > 0;
+            const Slot& x = c->slots[slot1[begin + i]];
+            const Slot& y = c->slots[slot2[begin + i]];
+            const bool nonempty = x.dev.rows > 0 && y.dev.rows > 0;
             if (o.kernel == AMC_KERNEL_MFMA && nonempty && !want_mfma[i]) {
                 rc = fail(AMC_E_INVALID,
                           "amc_match_pairs: kernel=MFMA forced but pair %zu is not eligible "
-                          "(rows_pad=%u, cols_pad=%u > %zu)", begin + i, a.dev.rows_pad,
-                          b.dev.rows_pad, mfma_max_cols);
-                break;
+                          "(rows_pad=%u, cols_pad=%u > %zu)", begin + i, x.dev.rows_pad,
+                          y.dev.rows_pad, mfma_max_cols);
+                return false;
             }
-            PairDev& pd = c->h_pairs.p[i];
+            PairDev& pd = hp[i];
             pd.slot1 = slot1[begin + i];
             pd.slot2 = slot2[begin + i];
             pd.mode = want_mfma[i] ? 1u : 0u;
             pd.pad = 0;
             pd.row_off = row_off;
             pd.col_off = col_off;
-            row_off += a.dev.rows_pad;
-            col_off += b.dev.rows_pad;
-            num_dist += (uint64_t)a.dev.rows * b.dev.rows;
+            row_off += x.dev.rows_pad;
+            col_off += y.dev.rows_pad;
+            num_dist += (uint64_t)x.dev.rows * y.dev.rows;
             if (!nonempty) continue;
             if (want_mfma[i]) {
-                c->h_order.p[nord++] = (uint32_t)i;
+                c->h_order[k].p[nord++] = (uint32_t)i;
                 ++n_mfma;
             } else {
-                nwork += (a.dev.rows + 63) / 64;
-                if (o.cross_check) nwork += (b.dev.rows + 63) / 64;
+                nwork += (x.dev.rows + 63) / 64;
+                if (o.cross_check) nwork += (y.dev.rows + 63) / 64;
                 ++n_dot4;
             }
         }
-        if (rc != AMC_OK) break;
         // mfma queue order: group by image 2 so co-resident workgroups stream the same B
-        std::stable_sort(c->h_order.p, c->h_order.p + nord, [&](uint32_t x, uint32_t y) {
-            const PairDev& px = c->h_pairs.p[x];
-            const PairDev& py = c->h_pairs.p[y];
+        std::stable_sort(c->h_order[k].p, c->h_order[k].p + nord, [&](uint32_t x, uint32_t y) {
+            const PairDev& px = hp[x];
+            const PairDev& py = hp[y];
             return px.slot2 != py.slot2 ? px.slot2 < py.slot2 : px.slot1 < py.slot1;
         });
+        if (nord && o.cross_check) {
+            // the reverse scan streams image 1: a second queue order, sorted by it
+            std::copy(c->h_order[k].p, c->h_order[k].p + nord, c->h_order2[k].p);
+            std::stable_sort(c->h_order2[k].p, c->h_order2[k].p + nord, [&](uint32_t x, uint32_t y) {
+                const PairDev& px = hp[x];
+                const PairDev& py = hp[y];
+                return px.slot1 != py.slot1 ? px.slot1 < py.slot1 : px.slot2 < py.slot2;
+            });
+        }
         if (nwork) {
-            if (!hc(c->h_work.ensure(nwork), "pinned work") || !hc(c->d_work.ensure(nwork), "dev work"))
-                break;
+            if (!hc(c->h_work[k].ensure(nwork), "pinned work")) return false;
             size_t w = 0;
             for (size_t i = 0; i < nb; ++i) {
-                if (c->h_pairs.p[i].mode) continue;
-                const Slot& a = c->slots[slot1[begin + i]];
-                const Slot& b = c->slots[slot2[begin + i]];
-                if (a.dev.rows == 0 || b.dev.rows == 0) continue;
-                for (uint32_t rb = 0; rb < (a.dev.rows + 63) / 64; ++rb)
-                    c->h_work.p[w++] = Dot4Work{(uint32_t)i, 0u, rb};
+                if (hp[i].mode) continue;
+                const Slot& x = c->slots[slot1[begin + i]];
+                const Slot& y = c->slots[slot2[begin + i]];
+                if (x.dev.rows == 0 || y.dev.rows == 0) continue;
+                for (uint32_t rb = 0; rb < (x.dev.rows + 63) / 64; ++rb)
+                    c->h_work[k].p[w++] = Dot4Work{(uint32_t)i, 0u, rb};
                 if (o.cross_check)
-                    for (uint32_t rb = 0; rb < (b.dev.rows + 63) / 64; ++rb)
-                        c->h_work.p[w++] = Dot4Work{(uint32_t)i, 1u, rb};
+                    for (uint32_t rb = 0; rb < (y.dev.rows + 63) / 64; ++rb)
+                        c->h_work[k].p[w++] = Dot4Work{(uint32_t)i, 1u, rb};
             }
         }
-
-        // ---- enqueue ------------------------------------------------------------------
-        bool okq = hc(hipMemcpyAsync(c->d_pairs.p, c->h_pairs.p, nb * sizeof(PairDev),
+        b.row_off = row_off;
+        b.nwork = nwork;
+        b.nord = nord;
+        return true;
+    };
+    // device side of a batch, all on the stream: H2D of the queues, the kernels, D2H of the counters
+    auto enqueue = [&](Batch& b) {
+        const int k = b.set;
+        const size_t nb = b.nb, nord = b.nord, nwork = b.nwork;
+        // device scratch only ever grows; growing frees the old allocation, so drain the stream first
+        const bool grow = c->d_pairs.cap < nb || c->d_order.cap < nb || c->d_order2.cap < nb ||
+                          c->d_rowbuf.cap < b.top_rows || c->d_colbuf.cap < b.top_cols ||
+                          c->d_accmask.cap < b.top_rows / 32 + 8 || c->d_pair_off.cap < nb || c->d_pair_cnt.cap < nb ||
+                          c->d_matches.cap < 2 * b.cap || c->d_cand_cnt.cap < nb || c->d_candbuf.cap < b.top_cols ||
+                          c->d_work.cap < nwork || (geoms && c->d_guided.cap < nb);
+        if (grow && !hc(hipStreamSynchronize(st), "sync before growing device scratch")) return false;
+        if (!hc(c->d_pairs.ensure(nb), "dev pairs") || !hc(c->d_order.ensure(nb), "dev order") ||
+            !hc(c->d_order2.ensure(nb), "dev order2") ||
+            !hc(c->d_rowbuf.ensure(b.top_rows), "row top2") || !hc(c->d_colbuf.ensure(b.top_cols), "col top2") ||
+            !hc(c->d_accmask.ensure(b.top_rows / 32 + 8), "accept mask") ||
+            !hc(c->d_pair_off.ensure(nb), "pair_off") || !hc(c->d_pair_cnt.ensure(nb), "pair_cnt") ||
+            !hc(c->d_matches.ensure(2 * b.cap), "dev matches") ||
+            !hc(c->d_cand_cnt.ensure(nb), "cand_cnt") || !hc(c->d_candbuf.ensure(b.top_cols), "candbuf") ||
+            (nwork && !hc(c->d_work.ensure(nwork), "dev work")) || (geoms && !hc(c->d_guided.ensure(nb), "dev guided")))
+            return false;
+        bool okq = hc(hipMemcpyAsync(c->d_pairs.p, c->h_pairs[k].p, nb * sizeof(PairDev),
                                      hipMemcpyHostToDevice, st), "H2D pairs") &&
                    hc(hipMemsetAsync(c->d_scalars, 0, 2 * sizeof(uint32_t), st), "memset cursor") &&
                    hc(hipMemsetAsync(c->d_scalars + 3, 0, sizeof(uint32_t), st), "memset errcount");
         if (okq && nord)
-            okq = hc(hipMemcpyAsync(c->d_order.p, c->h_order.p, nord * sizeof(uint32_t),
+            okq = hc(hipMemcpyAsync(c->d_order.p, c->h_order[k].p, nord * sizeof(uint32_t),
                                     hipMemcpyHostToDevice, st), "H2D order") &&
                   // row blocks no wave owns (beyond an image's last row) never write their words
-                  hc(hipMemsetAsync(c->d_accmask.p, 0, (row_off / 32 + 8) * sizeof(uint32_t), st), "memset accmask");
+                  hc(hipMemsetAsync(c->d_accmask.p, 0, (b.row_off / 32 + 8) * sizeof(uint32_t), st), "memset accmask");
         if (okq && nwork)
-            okq = hc(hipMemcpyAsync(c->d_work.p, c->h_work.p, nwork * sizeof(Dot4Work),
+            okq = hc(hipMemcpyAsync(c->d_work.p, c->h_work[k].p, nwork * sizeof(Dot4Work),
                                     hipMemcpyHostToDevice, st), "H2D work");
         if (okq && geoms)  // this batch's slice of the filter models (pageable source: the copy is staged)
-            okq = hc(c->d_guided.ensure(nb), "dev guided") &&
-                  hc(hipMemcpyAsync(c->d_guided.p, h_guided.data() + begin, nb * sizeof(GuidedDev),
+            okq = hc(hipMemcpyAsync(c->d_guided.p, h_guided.data() + b.begin, nb * sizeof(GuidedDev),
                                     hipMemcpyHostToDevice, st), "H2D guided");
-        if (!okq) break;
-        FinalizeParams fp;
-        fp.max_ratio = max_ratio_f;
-        fp.max_distance = (float)o.max_distance;
-        fp.cross_check = o.cross_check ? 1 : 0;
-        fp.reserved = 0;
-        (void)hipEventRecord(c->ev[2], st);
+        if (!okq) return false;
+        (void)hipEventRecord(c->bev[k][0], st);
         if (nord)
             launch_match_mfma(0, c->d_imgs.p, c->d_pairs.p, c->d_order.p, (uint32_t)nord,
                               c->d_scalars + 1, c->d_cand_cnt.p, c->d_candbuf.p, c->d_rowbuf.p,
@@ -556,7 +618,7 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
         if (nwork)
             launch_match_dot4(c->d_imgs.p, c->d_pairs.p, c->d_work.p, (uint32_t)nwork,
                               c->d_rowbuf.p, c->d_colbuf.p, geoms ? c->d_guided.p : nullptr, st);
-        (void)hipEventRecord(c->ev[3], st);
+        (void)hipEventRecord(c->bev[k][1], st);
         kernel_launches += (nord ? 1 : 0) + (nwork ? 1 : 0);
         if (nord)  // tile -> exact index for the accepted rows
             launch_resolve_index(0, c->d_imgs.p, c->d_pairs.p, (uint32_t)nb, c->d_rowbuf.p, c->d_accmask.p, c->d_lut,
@@ -565,69 +627,87 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
             // lazy cross check: reverse scan only for the columns accepted rows point at
             launch_select_candidates(c->d_imgs.p, c->d_pairs.p, (uint32_t)nb, c->d_rowbuf.p, c->d_accmask.p,
                                      c->d_lut, fp, c->d_cand_cnt.p, c->d_candbuf.p, st);
-            // streamed image is image 1 now: a second queue order, sorted by it
-            if (!hc(c->h_order2.ensure(nord), "pinned order2") || !hc(c->d_order2.ensure(nord), "dev order2"))
-                break;
-            std::copy(c->h_order.p, c->h_order.p + nord, c->h_order2.p);
-            std::stable_sort(c->h_order2.p, c->h_order2.p + nord, [&](uint32_t x, uint32_t y) {
-                const PairDev& px = c->h_pairs.p[x];
-                const PairDev& py = c->h_pairs.p[y];
-                return px.slot1 != py.slot1 ? px.slot1 < py.slot1 : px.slot2 < py.slot2;
-            });
-            uint32_t* d_order2 = c->d_order2.p;
-            if (!hc(hipMemcpyAsync(d_order2, c->h_order2.p, nord * sizeof(uint32_t),
+            if (!hc(hipMemcpyAsync(c->d_order2.p, c->h_order2[k].p, nord * sizeof(uint32_t),
                                    hipMemcpyHostToDevice, st), "H2D order2"))
-                break;
-            launch_match_mfma(1, c->d_imgs.p, c->d_pairs.p, d_order2, (uint32_t)nord,
+                return false;
+            launch_match_mfma(1, c->d_imgs.p, c->d_pairs.p, c->d_order2.p, (uint32_t)nord,
                               c->d_scalars + 1, c->d_cand_cnt.p, c->d_candbuf.p, c->d_colbuf.p,
                               c->d_accmask.p, c->d_lut, fp, st);
             launch_resolve_index(1, c->d_imgs.p, c->d_pairs.p, (uint32_t)nb, c->d_colbuf.p, c->d_accmask.p, c->d_lut,
                                  fp, c->d_cand_cnt.p, c->d_candbuf.p, c->d_scalars + 3, st);
         }
-        (void)hipEventRecord(c->ev[4], st);
+        (void)hipEventRecord(c->bev[k][2], st);
         launch_finalize(c->d_imgs.p, c->d_pairs.p, (uint32_t)nb, c->d_rowbuf.p, c->d_colbuf.p,
-                        c->d_accmask.p, c->d_lut, fp, c->d_scalars, (uint32_t)std::min(cap, (size_t)0xFFFFFFFFu),
+                        c->d_accmask.p, c->d_lut, fp, c->d_scalars, (uint32_t)std::min(b.cap, (size_t)0xFFFFFFFFu),
                         c->d_pair_off.p, c->d_pair_cnt.p, c->d_matches.p, st);
-        if (!hc(hipGetLastError(), "kernel launch")) break;
-        if (!hc(hipMemcpyAsync(c->h_scalars.p, c->d_scalars, 4 * sizeof(uint32_t),
-                               hipMemcpyDeviceToHost, st), "D2H cursor") ||
-            !hc(hipMemcpyAsync(c->h_pair_off.p, c->d_pair_off.p, nb * sizeof(uint32_t),
-                               hipMemcpyDeviceToHost, st), "D2H pair_off") ||
-            !hc(hipMemcpyAsync(c->h_pair_cnt.p, c->d_pair_cnt.p, nb * sizeof(uint32_t),
-                               hipMemcpyDeviceToHost, st), "D2H pair_cnt") ||
-            !hc(hipStreamSynchronize(st), "sync after batch kernels"))
-            break;
-        const uint32_t total = c->h_scalars.p[0];
-        if (c->h_scalars.p[3] != 0) {
+        if (!hc(hipGetLastError(), "kernel launch")) return false;
+        return hc(hipMemcpyAsync(c->h_bscalars[k].p, c->d_scalars, 4 * sizeof(uint32_t),
+                                 hipMemcpyDeviceToHost, st), "D2H cursor") &&
+               hc(hipMemcpyAsync(c->h_pair_off[k].p, c->d_pair_off.p, nb * sizeof(uint32_t),
+                                 hipMemcpyDeviceToHost, st), "D2H pair_off") &&
+               hc(hipMemcpyAsync(c->h_pair_cnt[k].p, c->d_pair_cnt.p, nb * sizeof(uint32_t),
+                                 hipMemcpyDeviceToHost, st), "D2H pair_cnt") &&
+               hc(hipEventRecord(c->bev[k][3], st), "event record");
+    };
+    // the batch's counters are on the host: check them, enqueue the copy of exactly `total` matches
+    auto collect = [&](Batch& b) {
+        const int k = b.set;
+        if (!hc(hipEventSynchronize(c->bev[k][3]), "wait for the batch")) return false;
+        b.total = c->h_bscalars[k].p[0];
+        if (c->h_bscalars[k].p[3] != 0) {
             rc = fail(AMC_E_HIP, "amc_match_pairs: internal: %u accepted rows could not be resolved "
-                      "to an index (scan/recompute mismatch)", c->h_scalars.p[3]);
-            break;
+                      "to an index (scan/recompute mismatch)", c->h_bscalars[k].p[3]);
+            return false;
         }
-        if (total > cap) {
-            rc = fail(AMC_E_HIP, "amc_match_pairs: internal: %u matches exceed capacity %zu",
-                      total, cap);
-            break;
+        if (b.total > b.cap) {
+            rc = fail(AMC_E_HIP, "amc_match_pairs: internal: %u matches exceed capacity %zu", b.total, b.cap);
+            return false;
         }
         // the pinned staging buffer follows the ACTUAL number of matches, not the worst case
-        if (total &&
-            (!hc(c->h_matches.ensure(2 * (size_t)total), "pinned matches") ||
-             !hc(hipMemcpyAsync(c->h_matches.p, c->d_matches.p, (size_t)total * 2 * sizeof(uint32_t),
-                                hipMemcpyDeviceToHost, st), "D2H matches") ||
-             !hc(hipStreamSynchronize(st), "sync after D2H")))
-            break;
+        if (b.total &&
+            (!hc(c->h_matches[k].ensure(2 * (size_t)b.total), "pinned matches") ||
+             !hc(hipMemcpyAsync(c->h_matches[k].p, c->d_matches.p, (size_t)b.total * 2 * sizeof(uint32_t),
+                                hipMemcpyDeviceToHost, st), "D2H matches")))
+            return false;
+        return hc(hipEventRecord(c->bev[k][4], st), "event record");
+    };
+    // append the batch's matches to the result CSR (pairs keep the caller's order)
+    auto scatter = [&](Batch& b) {
+        const int k = b.set;
+        if (!hc(hipEventSynchronize(c->bev[k][4]), "wait for the matches")) return false;
         float ms = 0.f;
-        if (hipEventElapsedTime(&ms, c->ev[2], c->ev[3]) == hipSuccess) kernel_ms += ms;
-        if (hipEventElapsedTime(&ms, c->ev[3], c->ev[4]) == hipSuccess) cross_ms += ms;
-        // ---- scatter into the CSR (pairs keep the caller's order) --------------------------
-        for (size_t i = 0; i < nb; ++i) {
-            const uint32_t cnt = c->h_pair_cnt.p[i];
-            const uint32_t off = c->h_pair_off.p[i];
-            priv->offsets[begin + i + 1] = priv->offsets[begin + i] + cnt;
+        if (hipEventElapsedTime(&ms, c->bev[k][0], c->bev[k][1]) == hipSuccess) kernel_ms += ms;
+        if (hipEventElapsedTime(&ms, c->bev[k][1], c->bev[k][2]) == hipSuccess) cross_ms += ms;
+        priv->matches.reserve(priv->matches.size() + 2 * (size_t)b.total);
+        for (size_t i = 0; i < b.nb; ++i) {
+            const uint32_t cnt = c->h_pair_cnt[k].p[i];
+            const uint32_t off = c->h_pair_off[k].p[i];
+            priv->offsets[b.begin + i + 1] = priv->offsets[b.begin + i] + cnt;
             if (cnt)
-                priv->matches.insert(priv->matches.end(), c->h_matches.p + 2ull * off,
-                                     c->h_matches.p + 2ull * (off + cnt));
+                priv->matches.insert(priv->matches.end(), c->h_matches[k].p + 2ull * off,
+                                     c->h_matches[k].p + 2ull * (off + cnt));
         }
-        begin = end;
+        return true;
+    };
+
+    if (npairs > 0) {
+        Batch cur = carve(0, 0);
+        bool ok = prepare(cur) && enqueue(cur);
+        while (ok) {
+            Batch next;
+            const bool have_next = cur.end < npairs;
+            if (have_next) {
+                next = carve(cur.end, cur.set ^ 1);
+                ok = prepare(next);
+            }
+            ok = ok && collect(cur);
+            if (ok && have_next) ok = enqueue(next);
+            ok = ok && scatter(cur);
+            if (!have_next) break;
+            cur = next;
+        }
+        if (!ok && rc == AMC_OK) rc = fail(AMC_E_HIP, "amc_match_pairs: batch failed");
+        if (rc != AMC_OK) (void)hipStreamSynchronize(st);  // nothing of this call stays in flight
     }
     if (rc != AMC_OK) {
         delete priv;

@@ -215,3 +215,30 @@ def test_more_than_8192_rows_matches_oracle(amc_ctx):
     assert st_n["pairs_mfma"] == 3
     for p, (a, b) in enumerate(zip(s1, s2)):
         np.testing.assert_array_equal(m_n[off_n[p]:off_n[p + 1]], oracle_lib.match(imgs[a], imgs[b], cross_check=False))
+
+
+@pytest.mark.parametrize("kernel", ["auto", "dot4"])
+@pytest.mark.parametrize("entries", [1, 1500, 4000])
+def test_many_batches_pipeline(amc_ctx, monkeypatch, kernel, entries):
+    """A call is cut into batches by device-scratch budget and the batches are software-pipelined
+    (batch k+1 prepared and enqueued while batch k's matches are copied out).  AMC_MATCH_BATCH_ENTRIES
+    shrinks the budget so that a small input runs as many ragged batches - one pair each for 1 - and the
+    result must not depend on where the cuts fall; empty images and empty results included."""
+    rng = np.random.default_rng(11)
+    imgs = synth.scene_images(rng, 6, 400, num_landmarks=700, visible_frac=0.5)
+    imgs += [synth.random_descriptors(rng, 130), np.zeros((0, 128), np.uint8), synth.random_descriptors(rng, 600)]
+    upload(amc_ctx, imgs)
+    s1, s2 = synth.exhaustive_pairs(len(imgs))
+    ref = amc_ctx.match_pairs(s1, s2, kernel=kernel)
+    monkeypatch.setenv("AMC_MATCH_BATCH_ENTRIES", str(entries))
+    for opts in ((0.8, 0.7, True), (0.9, 1.0, False)):
+        off, m, st = assert_same(amc_ctx, imgs, s1, s2, kernel, opts)
+    off, m, st = amc_ctx.match_pairs(s1, s2, kernel=kernel)
+    np.testing.assert_array_equal(off, ref[0])
+    np.testing.assert_array_equal(m, ref[1])
+    assert st["match_kernel_launches"] > ref[2]["match_kernel_launches"]      # it really ran as several batches
+    # reversed pair order, and only pairs with an empty image: batches with no work at all
+    off, m, _ = assert_same(amc_ctx, imgs, s2[::-1].copy(), s1[::-1].copy(), kernel)
+    e = np.full(5, 7, dtype=np.uint32)
+    off, m, _ = amc_ctx.match_pairs(e, np.arange(5, dtype=np.uint32), kernel=kernel)
+    assert off.tolist() == [0] * 6 and len(m) == 0
