@@ -1,11 +1,19 @@
-# A/B timing of the match kernel inside ONE gpurun call (box-to-box clock spread is ~3 %):
-# builds match_mfma.hip as of git revision $1 into pycolmap_amd/csrc/_obj/libamc_prev.so.
+# A/B timing inside ONE gpurun call (box-to-box clock spread is ~3 %): builds one source file of
+# pycolmap_amd/csrc as of git revision $1 and links it with the current objects into
+# pycolmap_amd/csrc/_obj/libamc_prev.so (select it with AMC_LIB_PATH; tools/diag_run.sh prev base ...).
+#   bash tools/ab_build.sh <rev> [file.hip]      default file: match_mfma.hip
 set -e
 cd "$(dirname "$0")/.."
 REV=${1:-HEAD}
-git show $REV:pycolmap_amd/csrc/match_mfma.hip > pycolmap_amd/csrc/_obj/match_mfma_prev.hip
+F=${2:-match_mfma.hip}
+STEM=${F%.hip}
+git show $REV:pycolmap_amd/csrc/$F > pycolmap_amd/csrc/_obj/${STEM}_prev.hip
 cd pycolmap_amd/csrc
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -I../../include -I."
-/opt/rocm/bin/hipcc $FLAGS -c _obj/match_mfma_prev.hip -o _obj/match_mfma_prev.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o _obj/libamc_prev.so _obj/amc_api.o _obj/match_common.o _obj/match_dot4.o _obj/match_mfma_prev.o _obj/tvg.o _obj/pose.o
+/opt/rocm/bin/hipcc $FLAGS -c _obj/${STEM}_prev.hip -o _obj/${STEM}_prev.o
+OBJS=""
+for o in amc_api match_common match_dot4 match_mfma tvg pose; do
+  if [ $o = $STEM ]; then OBJS="$OBJS _obj/${o}_prev.o"; else OBJS="$OBJS _obj/$o.o"; fi
+done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o _obj/libamc_prev.so $OBJS
 ls -la _obj/libamc_prev.so
