@@ -351,7 +351,34 @@ PYBIND11_MODULE(_pycolmap, m) {
         .def_readonly("cam2_from_cam1", &PyTwoViewGeometry::cam2_from_cam1)
         .def_property_readonly("inlier_matches",
                                [](const PyTwoViewGeometry& s) { return MatchesArray(s.inlier_matches); })
-        .def_readonly("tri_angle", &PyTwoViewGeometry::tri_angle);
+        .def_readonly("tri_angle", &PyTwoViewGeometry::tri_angle)
+        .def("invert",
+             [](PyTwoViewGeometry& g) {  // TwoViewGeometry::Invert: the geometry as seen from image 2
+                 TwoViewGeometryRow r;
+                 r.config = g.config;
+                 r.E = g.E;
+                 r.F = g.F;
+                 r.H = g.H;
+                 r.inlier_matches = std::move(g.inlier_matches);
+                 r.qvec = {{g.cam2_from_cam1.rotation.xyzw[3], g.cam2_from_cam1.rotation.xyzw[0],
+                            g.cam2_from_cam1.rotation.xyzw[1], g.cam2_from_cam1.rotation.xyzw[2]}};
+                 r.tvec = g.cam2_from_cam1.translation;
+                 r.Invert();
+                 g.E = r.E;
+                 g.F = r.F;
+                 g.H = r.H;
+                 g.inlier_matches = std::move(r.inlier_matches);
+                 g.cam2_from_cam1.rotation.xyzw = {{r.qvec[1], r.qvec[2], r.qvec[3], r.qvec[0]}};
+                 g.cam2_from_cam1.translation = r.tvec;
+             })
+        .def("todict",
+             [cfg_enum](const PyTwoViewGeometry& s) {
+                 return py::dict("config"_a = cfg_enum(s.config), "E"_a = Mat3(s.E), "F"_a = Mat3(s.F), "H"_a = Mat3(s.H),
+                                 "cam2_from_cam1"_a = s.cam2_from_cam1, "inlier_matches"_a = MatchesArray(s.inlier_matches),
+                                 "tri_angle"_a = s.tri_angle);
+             })
+        .def("__copy__", [](const PyTwoViewGeometry& s) { return PyTwoViewGeometry(s); })
+        .def("__deepcopy__", [](const PyTwoViewGeometry& s, const py::dict&) { return PyTwoViewGeometry(s); });
 
     // ---- Database ---------------------------------------------------------------------------
     py::class_<Database>(m, "Database")

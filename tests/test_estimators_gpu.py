@@ -233,6 +233,19 @@ def test_python_estimator_api_matches_oracle():
         np.testing.assert_array_equal(bits(g.cam2_from_cam1.translation), bits(wpp["tvec"]))
         assert bits(g.tri_angle) == bits(wpp["tri_angle"]) and g.config.name == wpp["config_name"]
         assert pc.estimate_two_view_geometry_pose(cam, sc["pts1"], cam, sc["pts2"], pc.TwoViewGeometry()) is False
+        # invert(): E^T, F^T, H^-1, swapped match columns, inverse pose; twice = back (up to rounding in H / pose)
+        import copy
+        gi = copy.deepcopy(g)
+        gi.invert()
+        np.testing.assert_array_equal(gi.E, g.E.T)
+        np.testing.assert_array_equal(gi.F, g.F.T)
+        np.testing.assert_array_equal(gi.inlier_matches, g.inlier_matches[:, ::-1])
+        assert np.allclose(gi.H @ g.H / (gi.H @ g.H)[2, 2], np.eye(3), atol=1e-9)
+        T, Ti = np.vstack([g.cam2_from_cam1.matrix(), [0, 0, 0, 1]]), np.vstack([gi.cam2_from_cam1.matrix(), [0, 0, 0, 1]])
+        assert np.allclose(T @ Ti, np.eye(4), atol=1e-12)
+        gi.invert()
+        np.testing.assert_array_equal(gi.inlier_matches, g.inlier_matches)
+        assert np.allclose(gi.cam2_from_cam1.matrix(), g.cam2_from_cam1.matrix(), atol=1e-12)
         g = pc.estimate_two_view_geometry(cam, sc["pts1"], cam, sc["pts2"], sc["matches"])
         w = o.estimate_two_view_geometry(ocam, sc["pts1"], ocam, sc["pts2"], sc["matches"], o.tvg_default_options())
         assert g.config.name == w["config_name"]

@@ -206,6 +206,9 @@ def test_estimator_bindings_argument_checks():
     assert g.tri_angle == 0.0 and np.array_equal(g.cam2_from_cam1.rotation.quat, [0, 0, 0, 1])
     assert np.array_equal(g.cam2_from_cam1.translation, [0, 0, 0])
     assert np.array_equal(g.cam2_from_cam1.matrix(), np.c_[np.eye(3), np.zeros(3)])
+    g.invert()                                                  # Invert() of the default geometry: still the identity pose
+    assert np.allclose(g.cam2_from_cam1.matrix(), np.c_[np.eye(3), np.zeros(3)]) and g.inlier_matches.shape == (0, 2)
+    assert set(g.todict()) == {"config", "E", "F", "H", "cam2_from_cam1", "inlier_matches", "tri_angle"}
     r = pc.Rotation3d([0.0, 0.0, np.sin(0.25), np.cos(0.25)])   # 0.5 rad about z
     assert np.allclose(r.matrix(), [[np.cos(0.5), -np.sin(0.5), 0], [np.sin(0.5), np.cos(0.5), 0], [0, 0, 1]])
     assert abs(r.norm() - 1.0) < 1e-15 and "Rotation3d" in repr(r) and "Rigid3d" in repr(pc.Rigid3d(r, [1, 2, 3]))
