@@ -190,7 +190,10 @@ struct TvgParams {
 size_t tvg_ws_doubles_host(uint32_t mcap);
 size_t tvg_ws_mask_bytes_host(uint32_t mcap);
 // target occupancy of the verification kernel (waves per SIMD): sets its VGPR budget and LDS share
-constexpr int kTvgWavesPerSimd = 2;
+#ifndef AMC_TVG_WAVES
+#define AMC_TVG_WAVES 2
+#endif
+constexpr int kTvgWavesPerSimd = AMC_TVG_WAVES;
 size_t tvg_lds_bytes(uint32_t mcap, uint32_t pts_cap, int waves);
 uint32_t tvg_pts_cap(uint32_t mcap, int waves_per_block);
 hipError_t launch_sampson(const double* p1, const double* p2, size_t n, const double* E9, double* out,
