@@ -1192,10 +1192,14 @@ static int verify_impl(amc_ctx* c, int mode, const uint32_t* slot1, const uint32
     double kernel_ms = 0.0;
     uint32_t launches = 0;
     for (int k = 0; k < 2; ++k) {
-        const std::vector<size_t>& idx = cls[k];
-        if (idx.empty()) continue;
+        if (cls[k].empty()) continue;
         const int wpb = k == 0 ? 4 : 1;
         uint32_t cm = 0;
+        // The waves pull pairs from a queue in this order.  A pair's cost grows with its match count (every
+        // trial scores all matches), so the largest go first: what is left for the tail of the launch, when
+        // most waves have run dry, are the cheap ones.  Results are stored by pair, the order is free.
+        std::vector<size_t> idx = cls[k];
+        std::stable_sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return tp[a].M > tp[b].M; });
         std::vector<TvgPair> sub(idx.size());
         for (size_t i = 0; i < idx.size(); ++i) {
             sub[i] = tp[idx[i]];
