@@ -906,14 +906,18 @@ void pose_default(amc_pose* q, int32_t config) {
 // kernel_ms (optional): the pose kernel's duration.
 static int pose_impl(amc_ctx* c, const char* who, const uint32_t* slot1, const uint32_t* slot2, size_t npairs,
                      const uint64_t* match_offsets, const uint32_t* inlier_matches, const amc_tvg* geoms,
-                     amc_pose* out, double* kernel_ms, bool indices_checked = false) {
+                     amc_pose* out, double* kernel_ms, const uint64_t* resident_mask_off = nullptr) {
+    // resident_mask_off != nullptr (amc_verify_pairs): the matches of this call are still in d_tmatches
+    // (same offsets) and pair p's inlier bytes at d_toutmask + resident_mask_off[p]; nothing is uploaded
+    // again and the kernel takes the rows whose byte is set.  Their indices have been checked.
+    const bool resident = resident_mask_off != nullptr;
     if (kernel_ms) *kernel_ms = 0.0;
     if (!c) return fail(AMC_E_INVALID, "%s: NULL ctx", who);
     if (npairs == 0) return AMC_OK;
     if (!slot1 || !slot2 || !match_offsets || !geoms || !out)
         return fail(AMC_E_INVALID, "%s: NULL pair arrays", who);
     const uint64_t total = match_offsets[npairs];
-    if (total > 0 && !inlier_matches) return fail(AMC_E_INVALID, "%s: NULL matches", who);
+    if (total > 0 && !inlier_matches && !resident) return fail(AMC_E_INVALID, "%s: NULL matches", who);
     if (npairs > 0xFFFFFFFFull) return fail(AMC_E_INVALID, "%s: too many pairs", who);
     std::vector<PosePair> pp(npairs);
     for (size_t p = 0; p < npairs; ++p) {
@@ -935,7 +939,7 @@ static int pose_impl(amc_ctx* c, const char* who, const uint32_t* slot1, const u
              (b.cam.model_id != AMC_CAM_SIMPLE_PINHOLE && b.cam.model_id != AMC_CAM_PINHOLE)))
             return fail(AMC_E_INVALID, "%s: pair %zu: the relative pose supports SIMPLE_PINHOLE / PINHOLE "
                         "cameras only", who, p);
-        if (!indices_checked)  // (amc_verify_pairs passes a subset of matches it has checked already)
+        if (!resident)
             for (uint64_t k = match_offsets[p]; k < match_offsets[p + 1]; ++k)
                 if (inlier_matches[2 * k] >= a.kp_rows || inlier_matches[2 * k + 1] >= b.kp_rows)
                     return fail(AMC_E_INVALID, "%s: pair %zu match %llu indexes past the keypoints", who, p,
@@ -943,6 +947,7 @@ static int pose_impl(amc_ctx* c, const char* who, const uint32_t* slot1, const u
         pp[p].slot1 = slot1[p];
         pp[p].slot2 = slot2[p];
         pp[p].match_off = match_offsets[p];
+        pp[p].mask_off = resident ? resident_mask_off[p] : 0;
         pp[p].M = (uint32_t)M;
         pp[p].config = cfg;
         std::memcpy(pp[p].E, geoms[p].E, sizeof pp[p].E);
@@ -960,15 +965,16 @@ static int pose_impl(amc_ctx* c, const char* who, const uint32_t* slot1, const u
     }
     HIPCHK(c->d_timgs.ensure(timgs.size()));
     HIPCHK(c->d_ppairs.ensure(npairs));
-    HIPCHK(c->d_pmatches.ensure(std::max<size_t>(2 * total, 2)));
+    if (!resident) HIPCHK(c->d_pmatches.ensure(std::max<size_t>(2 * total, 2)));
     HIPCHK(c->d_pcos.ensure(std::max<size_t>(total, 1)));
     HIPCHK(c->d_pout.ensure(npairs));
     HIPCHK(hipMemcpyAsync(c->d_timgs.p, timgs.data(), timgs.size() * sizeof(TvgImage), hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(c->d_ppairs.p, pp.data(), npairs * sizeof(PosePair), hipMemcpyHostToDevice, st));
-    if (total)
+    if (total && !resident)
         HIPCHK(hipMemcpyAsync(c->d_pmatches.p, inlier_matches, 2 * total * sizeof(uint32_t), hipMemcpyHostToDevice, st));
     HIPCHK(hipEventRecord(c->ev[4], st));
-    HIPCHK(launch_pose(c->d_timgs.p, c->d_ppairs.p, (uint32_t)npairs, c->d_pmatches.p, c->d_pcos.p, c->d_pout.p, st));
+    HIPCHK(launch_pose(c->d_timgs.p, c->d_ppairs.p, (uint32_t)npairs, resident ? c->d_tmatches.p : c->d_pmatches.p,
+                       resident ? c->d_toutmask.p : nullptr, c->d_pcos.p, c->d_pout.p, st));
     HIPCHK(hipEventRecord(c->ev[5], st));
     std::vector<PoseOut> h(npairs);
     HIPCHK(hipMemcpyAsync(h.data(), c->d_pout.p, npairs * sizeof(PoseOut), hipMemcpyDeviceToHost, st));
@@ -1257,25 +1263,14 @@ static int verify_impl(amc_ctx* c, int mode, const uint32_t* slot1, const uint32
     out->kernel_ms = kernel_ms;
     out->kernel_launches = launches;
     if (o.compute_relative_pose) {
-        // EstimateTwoViewGeometryPose on the selected inlier matches (mask order = match order)
-        std::vector<uint64_t> ioff(npairs + 1, 0);
-        std::vector<uint32_t> im;
-        im.reserve(2 * total);
-        for (size_t p = 0; p < npairs; ++p) {
-            const uint8_t* mk = priv->mask.data() + match_offsets[p];
-            const uint32_t* mm = matches + 2 * match_offsets[p];
-            const size_t M = (size_t)(match_offsets[p + 1] - match_offsets[p]);
-            for (size_t k = 0; k < M; ++k)
-                if (mk[k]) {
-                    im.push_back(mm[2 * k]);
-                    im.push_back(mm[2 * k + 1]);
-                }
-            ioff[p + 1] = im.size() / 2;
-        }
+        // EstimateTwoViewGeometryPose on the selected inlier matches (mask order = match order): the matches
+        // and the masks of this call are still on the device
+        std::vector<uint64_t> moff(npairs);
+        for (size_t p = 0; p < npairs; ++p) moff[p] = tp[p].mask_off;
         priv->pose.resize(npairs);
         double pose_ms = 0.0;
-        const int rc = pose_impl(c, "amc_verify_pairs", slot1, slot2, npairs, ioff.data(), im.data(), priv->tvg.data(),
-                                 priv->pose.data(), &pose_ms, /*indices_checked=*/true);
+        const int rc = pose_impl(c, "amc_verify_pairs", slot1, slot2, npairs, match_offsets, matches, priv->tvg.data(),
+                                 priv->pose.data(), &pose_ms, moff.data());
         if (rc != AMC_OK) {
             delete priv;
             std::memset(out, 0, sizeof *out);

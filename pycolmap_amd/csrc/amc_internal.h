@@ -156,6 +156,7 @@ struct TvgPair {
 struct PosePair {
     uint32_t slot1, slot2;
     uint64_t match_off;
+    uint64_t mask_off;   // with a mask: the pair's inlier bytes (amc_verify_pairs' device mask), row k counts if non-zero
     uint32_t M;
     int32_t config;
     double E[9], H[9];
@@ -169,8 +170,9 @@ struct alignas(128) PoseOut {
     uint32_t pad;
     double R[9], t[3], q[4], cmed[2];
 };
+// mask == nullptr: every listed match is an inlier match
 hipError_t launch_pose(const TvgImage* imgs, const PosePair* pairs, uint32_t npairs, const uint32_t* matches,
-                       double* cosine_ws, PoseOut* out, hipStream_t s);
+                       const uint8_t* mask, double* cosine_ws, PoseOut* out, hipStream_t s);
 
 // device-side result record: amc_tvg padded to its own cache lines (same reason)
 struct alignas(128) TvgOut {

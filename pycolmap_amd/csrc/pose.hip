@@ -90,6 +90,7 @@ __device__ double select_cosine(const double* cs, uint32_t n, uint32_t rank, int
 
 __global__ __launch_bounds__(64) void pose_kernel(const TvgImage* __restrict__ imgs, const PosePair* __restrict__ pairs,
                                                   uint32_t npairs, const uint32_t* __restrict__ matches,
+                                                  const uint8_t* __restrict__ mask_all,
                                                   double* __restrict__ cosine_ws, PoseOut* __restrict__ out) {
     __shared__ PoseCands cands;
     const uint32_t p = blockIdx.x;
@@ -113,6 +114,8 @@ __global__ __launch_bounds__(64) void pose_kernel(const TvgImage* __restrict__ i
     }
     const TvgImage im1 = imgs[pr.slot1], im2 = imgs[pr.slot2];
     const uint32_t* mm = matches + 2 * pr.match_off;
+    // inlier matches: all M rows, or (behind amc_verify_pairs) the rows of the pair's mask that are set
+    const uint8_t* mask = mask_all ? mask_all + pr.mask_off : nullptr;
     const int M = (int)pr.M;
     if (lane == 0) {
         PoseCands c;
@@ -144,7 +147,7 @@ __global__ __launch_bounds__(64) void pose_kernel(const TvgImage* __restrict__ i
         for (int base = 0; base < M; base += 64) {
             const int i = base + lane;
             bool ok = false;
-            if (i < M) {
+            if (i < M && (!mask || mask[i])) {
                 const Corr c = load_corr(im1, im2, mm, i);
                 double X[3];
                 ok = cheirality_point(R, t, b, c.x1, c.y1, c.x2, c.y2, X);
@@ -167,7 +170,7 @@ __global__ __launch_bounds__(64) void pose_kernel(const TvgImage* __restrict__ i
         const int i = base + lane;
         bool ok = false;
         double cosine = 0.0;
-        if (i < M) {
+        if (i < M && (!mask || mask[i])) {
             const Corr c = load_corr(im1, im2, mm, i);
             double X[3];
             ok = cheirality_point(R, t, b, c.x1, c.y1, c.x2, c.y2, X);
@@ -204,9 +207,9 @@ __global__ __launch_bounds__(64) void pose_kernel(const TvgImage* __restrict__ i
 }  // namespace
 
 hipError_t launch_pose(const TvgImage* imgs, const PosePair* pairs, uint32_t npairs, const uint32_t* matches,
-                       double* cosine_ws, PoseOut* out, hipStream_t s) {
+                       const uint8_t* mask, double* cosine_ws, PoseOut* out, hipStream_t s) {
     if (npairs == 0) return hipSuccess;
-    hipLaunchKernelGGL(pose_kernel, dim3(npairs), dim3(64), 0, s, imgs, pairs, npairs, matches, cosine_ws, out);
+    hipLaunchKernelGGL(pose_kernel, dim3(npairs), dim3(64), 0, s, imgs, pairs, npairs, matches, mask, cosine_ws, out);
     return hipGetLastError();
 }
 
