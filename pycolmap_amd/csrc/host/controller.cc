@@ -76,6 +76,7 @@ void MatchController::Setup() {
         ~SetupTimer() { *acc += NowMs() - t0; }
     } setup_timer{NowMs(), &stats.setup_ms};
     db_ = std::make_unique<Database>(path_);
+    db_->SetBulkWriteMode(true);  // rollback journal while this controller appends; WAL again on close
     images_ = db_->ReadAllImages();
     const std::vector<CameraRow> cams = db_->ReadAllCameras();
     std::unordered_map<camera_t, const CameraRow*> cam_by_id;

@@ -84,8 +84,28 @@ Database::Database(const std::string& path) {
     Exec("PRAGMA foreign_keys=ON");
 }
 Database::~Database() {
+    if (db_ && bulk_mode_) {
+        try {
+            SetBulkWriteMode(false);
+        } catch (...) {
+        }
+    }
     for (auto& kv : stmts_) sqlite3_finalize(kv.second);
     if (db_) sqlite3_close(db_);
+}
+std::string Database::SetBulkWriteMode(bool on) {
+    // cached statements hold the schema; a journal-mode switch needs no statement in progress (all are reset)
+    sqlite3_stmt* st = nullptr;
+    const char* sql = on ? "PRAGMA journal_mode=TRUNCATE" : "PRAGMA journal_mode=WAL";
+    if (sqlite3_prepare_v2(db_, sql, -1, &st, nullptr) != SQLITE_OK) Fail(db_, sql);
+    std::string mode;
+    if (sqlite3_step(st) == SQLITE_ROW) {
+        const unsigned char* t = sqlite3_column_text(st, 0);
+        if (t) mode = reinterpret_cast<const char*>(t);
+    }
+    sqlite3_finalize(st);
+    bulk_mode_ = on && mode == "truncate";
+    return mode;
 }
 sqlite3_stmt* Database::Prepared(const std::string& sql) const {
     auto it = stmts_.find(sql);

@@ -89,6 +89,14 @@ class Database {
 
     void BeginTransaction();
     void EndTransaction();
+    // Bulk-write mode of the matching controllers.  COLMAP opens its databases with journal_mode=WAL
+    // (kept: it is what a reader of the file finds afterwards), but under WAL every page of the
+    // gigabytes of match blobs a run appends is written twice (log, then checkpoint).  While a
+    // controller owns the connection the journal is a rollback journal (TRUNCATE: appended pages are
+    // written once, only overwritten pages are journalled); WAL is restored when the mode is switched
+    // off or the database is closed.  If another connection holds the file SQLite refuses the switch
+    // and the run simply stays in WAL.  Returns the journal mode in effect.
+    std::string SetBulkWriteMode(bool on);
 
   private:
     size_t Count(const char* table) const;
@@ -97,6 +105,7 @@ class Database {
     void Exec(const char* sql) const;
     sqlite3_stmt* Prepared(const std::string& sql) const;  // prepared once per connection, then reused
     sqlite3* db_ = nullptr;
+    bool bulk_mode_ = false;
     mutable std::unordered_map<std::string, sqlite3_stmt*> stmts_;
 };
 

@@ -411,6 +411,9 @@ PYBIND11_MODULE(_pycolmap, m) {
              "image_id1"_a, "image_id2"_a)
         // keypoints / descriptors / matches accessors: the reference leaves them unbound
         // (/root/reference/pycolmap/scene/database.h:35-41); names follow COLMAP's Database methods
+        .def("set_bulk_write_mode", &Database::SetBulkWriteMode, "on"_a,
+             "Rollback journal instead of WAL while appending many blobs; returns the journal mode in effect. "
+             "WAL (COLMAP's mode) is restored when switched off or on close.")
         .def("exists_keypoints", &Database::ExistsKeypoints, "image_id"_a)
         .def("exists_descriptors", &Database::ExistsDescriptors, "image_id"_a)
         .def("read_keypoints",

@@ -149,6 +149,20 @@ def test_database_binding_reads_colmap_schema(tmp_path):
     np.testing.assert_array_equal(db.read_keypoints(new_id), kp)
     np.testing.assert_array_equal(db.read_descriptors(new_id), de)
     assert db.num_keypoints == 127 and db.num_descriptors == 127
+    # bulk-write mode: rollback journal while a controller appends, WAL (COLMAP's mode) again afterwards
+    assert db.set_bulk_write_mode(True) == "truncate"
+    db.write_matches(ids[1], ids[2], m)
+    assert db.set_bulk_write_mode(False) == "wal"
+    np.testing.assert_array_equal(db.read_matches(ids[1], ids[2]), m)
+    db2 = pycolmap.Database(db_path)
+    db2.set_bulk_write_mode(True)
+    db2.write_matches(ids[0], ids[2], m) if not db2.exists_matches(ids[0], ids[2]) else None
+    del db2                                                     # closing restores WAL
+    import gc
+    gc.collect()
+    con = sqlite3.connect(db_path)
+    assert con.execute("PRAGMA journal_mode").fetchone()[0] == "wal"
+    con.close()
 
 
 # ---- Camera + single-pair estimator bindings (surface only: no GPU here) --------------------------
