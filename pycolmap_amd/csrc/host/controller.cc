@@ -4,6 +4,8 @@
 #include <chrono>
 #include <cstring>
 #include <fstream>
+#include <future>
+#include <memory>
 #include <sstream>
 #include <unordered_map>
 #include <unordered_set>
@@ -108,18 +110,17 @@ void MatchController::Setup() {
 
 // FeatureMatcherController::Match (colmap/controllers/feature_matching_utils.cc), batched
 void MatchController::Match(const ImagePairs& image_pairs) {
-    if (image_pairs.empty()) return;
+    std::vector<Job> jobs = Compute(image_pairs);
+    Write(jobs);
+}
+
+std::vector<MatchController::Job> MatchController::Compute(const ImagePairs& image_pairs) {
+    std::vector<Job> jobs;
+    if (image_pairs.empty()) return jobs;
     struct TotalTimer {
         double t0, *acc;
         ~TotalTimer() { *acc += NowMs() - t0; }
     } total_timer{NowMs(), &stats.match_total_ms};
-    struct Job {
-        image_t id1, id2;
-        bool have_matches;
-        std::vector<uint32_t> matches;
-        TwoViewGeometryRow tvg;
-    };
-    std::vector<Job> jobs;
     std::unordered_set<image_pair_t> seen;
     seen.reserve(image_pairs.size());
     const double t_db0 = NowMs();
@@ -127,6 +128,7 @@ void MatchController::Match(const ImagePairs& image_pairs) {
         if (pr.first == pr.second) continue;  // avoid self-matches
         const image_pair_t pid = Database::ImagePairToPairId(pr.first, pr.second);
         if (!seen.insert(pid).second) continue;  // avoid duplicate image pairs
+        if (computed_.count(pid)) { ++stats.pairs_skipped; continue; }  // done earlier in this run (rows may be in flight)
         const bool exists_matches = db_->ExistsMatches(pr.first, pr.second);
         const bool exists_inlier = db_->ExistsInlierMatches(pr.first, pr.second);
         if (exists_matches && exists_inlier) { ++stats.pairs_skipped; continue; }  // resume
@@ -143,7 +145,8 @@ void MatchController::Match(const ImagePairs& image_pairs) {
         jobs.push_back(std::move(j));
     }
     stats.db_ms += NowMs() - t_db0;
-    if (jobs.empty()) return;
+    if (jobs.empty()) return jobs;
+    for (const Job& j : jobs) computed_.insert(Database::ImagePairToPairId(j.id1, j.id2));
 
     // ---- FeatureMatcherWorker: descriptor matching for the pairs without stored matches ----
     std::vector<uint32_t> s1, s2;
@@ -256,7 +259,12 @@ void MatchController::Match(const ImagePairs& image_pairs) {
         amc_verify_result_free(&vr);
     }
 
-    // ---- controller thread: drop results below min_num_inliers, write both tables ----------
+    return jobs;
+}
+
+// ---- controller thread: drop results below min_num_inliers, write both tables ----------
+void MatchController::Write(std::vector<Job>& jobs) {
+    const size_t min_inl = static_cast<size_t>(std::max(tvg_.min_num_inliers, 0));
     const double t_db1 = NowMs();
     for (Job& j : jobs) {
         if (j.matches.size() / 2 < min_inl) j.matches.clear();
@@ -264,7 +272,7 @@ void MatchController::Match(const ImagePairs& image_pairs) {
         db_->WriteMatches(j.id1, j.id2, j.matches);
         db_->WriteTwoViewGeometry(j.id1, j.id2, j.tvg);
     }
-    stats.db_ms += NowMs() - t_db1;
+    stats.write_ms += NowMs() - t_db1;
 }
 
 // ---- loop detection -------------------------------------------------------------------------
@@ -357,12 +365,26 @@ std::vector<ImagePairs> ExhaustiveBlocks(const std::vector<image_t>& ids, int bl
 // database is the same; only the granularity of a resumed, interrupted run changes.
 constexpr size_t kGroupPairs = 32768;  // the verification kernel's launch tail: 64 k pairs/s at 4 k pairs, 95 k at 64 k
 static void RunGrouped(MatchController& c, const std::vector<ImagePairs>& blocks) {
+    // One group's rows are written by a worker thread (one transaction per group) while the device
+    // matches and verifies the next group: SQLite's share of a run hides behind the kernels.
     ImagePairs group;
+    std::future<void> writer;
+    struct Drain {  // whatever happens, no writer outlives this call
+        std::future<void>& f;
+        ~Drain() {
+            if (f.valid()) f.wait();
+        }
+    } drain{writer};
     auto flush = [&] {
         if (group.empty()) return;
-        DatabaseTransaction tx(&c.Db());
-        c.Match(group);
+        auto jobs = std::make_shared<std::vector<MatchController::Job>>(c.Compute(group));
         group.clear();
+        if (writer.valid()) writer.get();  // one writer at a time; rethrows what it threw
+        if (jobs->empty()) return;
+        writer = std::async(std::launch::async, [&c, jobs] {
+            DatabaseTransaction tx(&c.Db());
+            c.Write(*jobs);
+        });
     };
     for (const ImagePairs& pairs : blocks) {
         if (c.StopRequested()) break;
@@ -370,6 +392,7 @@ static void RunGrouped(MatchController& c, const std::vector<ImagePairs>& blocks
         if (group.size() >= kGroupPairs) flush();
     }
     if (!c.StopRequested()) flush();
+    if (writer.valid()) writer.get();
 }
 
 void RunExhaustive(MatchController& c, const ExhaustiveMatchingOptions& o) {

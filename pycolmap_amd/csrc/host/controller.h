@@ -8,6 +8,7 @@
 #include <memory>
 #include <string>
 #include <utility>
+#include <unordered_set>
 #include <vector>
 
 #include "../../../include/amc.h"
@@ -79,6 +80,7 @@ struct MatchStats {
     double match_device_ms = 0, verify_device_ms = 0, guided_device_ms = 0, loop_device_ms = 0, db_ms = 0;
     // wall time of the library calls (device time + the library's host side) and of Match() as a whole
     double match_call_ms = 0, verify_call_ms = 0, match_total_ms = 0, setup_ms = 0;
+    double write_ms = 0;  // writing both tables (a worker thread: overlaps the next group's device work)
     uint64_t num_distances = 0;
 };
 
@@ -88,8 +90,18 @@ class MatchController {
                     const TwoViewGeometryOptions& tvg, int device_id);
     ~MatchController();
     void Setup();  // read cameras/images/keypoints/descriptors, fill the GPU arena
-    // FeatureMatcherController::Match: filter, match, verify, write
+    // FeatureMatcherController::Match: filter, match, verify, write.  Match() = Compute() + Write();
+    // the grouped runners call the halves themselves so that one group's rows are written (a worker
+    // thread) while the device already works on the next group.
+    struct Job {
+        image_t id1, id2;
+        bool have_matches;
+        std::vector<uint32_t> matches;
+        TwoViewGeometryRow tvg;
+    };
     void Match(const ImagePairs& pairs);
+    std::vector<Job> Compute(const ImagePairs& pairs);  // filter against the DB, match, verify
+    void Write(std::vector<Job>& jobs);                  // drop what is below min_num_inliers, write both tables
     // Loop-closure candidates of `query` among `candidates` (SequentialFeatureMatcher::RunLoopDetection
     // with the vocabulary-tree query replaced by feature voting, see controller.cc): the up to
     // num_images images with the most cross-checked matches between the first max_features
@@ -113,6 +125,8 @@ class MatchController {
     amc_ctx* ctx_ = nullptr;
     std::atomic<bool> stop_{false};
     uint32_t SlotOf(image_t id) const;
+    // pairs this run has computed already: their rows may still be on their way to the database
+    std::unordered_set<image_pair_t> computed_;
     int loop_index_features_ = 0;  // > 0 once the truncated copies (slots N .. 2N-1) are uploaded
     void SetupLoopIndex(int max_features);
 };

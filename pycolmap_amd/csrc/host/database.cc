@@ -94,6 +94,7 @@ Database::~Database() {
     if (db_) sqlite3_close(db_);
 }
 std::string Database::SetBulkWriteMode(bool on) {
+    std::lock_guard<std::recursive_mutex> lock(mu_);
     // cached statements hold the schema; a journal-mode switch needs no statement in progress (all are reset)
     sqlite3_stmt* st = nullptr;
     const char* sql = on ? "PRAGMA journal_mode=TRUNCATE" : "PRAGMA journal_mode=WAL";
@@ -108,6 +109,7 @@ std::string Database::SetBulkWriteMode(bool on) {
     return mode;
 }
 sqlite3_stmt* Database::Prepared(const std::string& sql) const {
+    std::lock_guard<std::recursive_mutex> lock(mu_);
     auto it = stmts_.find(sql);
     if (it != stmts_.end()) return it->second;
     sqlite3_stmt* st = nullptr;
@@ -116,6 +118,7 @@ sqlite3_stmt* Database::Prepared(const std::string& sql) const {
     return st;
 }
 void Database::Exec(const char* sql) const {
+    std::lock_guard<std::recursive_mutex> lock(mu_);
     char* err = nullptr;
     if (sqlite3_exec(db_, sql, nullptr, nullptr, &err) != SQLITE_OK) {
         const std::string msg = err ? err : "?";
@@ -123,8 +126,14 @@ void Database::Exec(const char* sql) const {
         throw std::runtime_error(std::string("SQLite exec failed: ") + sql + ": " + msg);
     }
 }
-void Database::BeginTransaction() { Exec("BEGIN TRANSACTION"); }
-void Database::EndTransaction() { Exec("END TRANSACTION"); }
+void Database::BeginTransaction() {
+    std::lock_guard<std::recursive_mutex> lock(mu_);
+    Exec("BEGIN TRANSACTION");
+}
+void Database::EndTransaction() {
+    std::lock_guard<std::recursive_mutex> lock(mu_);
+    Exec("END TRANSACTION");
+}
 
 image_pair_t Database::ImagePairToPairId(image_t id1, image_t id2) {
     if (id1 >= kMaxNumImages || id2 >= kMaxNumImages) throw std::invalid_argument("image_id out of range");
@@ -137,17 +146,20 @@ void Database::PairIdToImagePair(image_pair_t pair_id, image_t* id1, image_t* id
 }
 
 size_t Database::Count(const char* table) const {
+    std::lock_guard<std::recursive_mutex> lock(mu_);
     Stmt st(db_, Prepared((std::string("SELECT COUNT(*) FROM ") + table)));
     st.Step();
     return static_cast<size_t>(sqlite3_column_int64(st.s, 0));
 }
 size_t Database::SumRows(const char* table) const {
+    std::lock_guard<std::recursive_mutex> lock(mu_);
     Stmt st(db_, Prepared((std::string("SELECT SUM(rows) FROM ") + table)));
     st.Step();
     return static_cast<size_t>(sqlite3_column_int64(st.s, 0));
 }
 
 std::vector<CameraRow> Database::ReadAllCameras() const {
+    std::lock_guard<std::recursive_mutex> lock(mu_);
     std::vector<CameraRow> out;
     Stmt st(db_, Prepared("SELECT camera_id, model, width, height, params, prior_focal_length FROM cameras ORDER BY camera_id"));
     while (st.Step()) {
@@ -165,6 +177,7 @@ std::vector<CameraRow> Database::ReadAllCameras() const {
     return out;
 }
 std::vector<ImageRow> Database::ReadAllImages() const {
+    std::lock_guard<std::recursive_mutex> lock(mu_);
     std::vector<ImageRow> out;
     Stmt st(db_, Prepared("SELECT image_id, name, camera_id FROM images ORDER BY image_id"));
     while (st.Step()) {
@@ -177,6 +190,7 @@ std::vector<ImageRow> Database::ReadAllImages() const {
     return out;
 }
 std::vector<float> Database::ReadKeypointsXY(image_t image_id, uint32_t* rows) const {
+    std::lock_guard<std::recursive_mutex> lock(mu_);
     *rows = 0;
     Stmt st(db_, Prepared("SELECT rows, cols, data FROM keypoints WHERE image_id = ?"));
     sqlite3_bind_int64(st.s, 1, image_id);
@@ -198,6 +212,7 @@ std::vector<float> Database::ReadKeypointsXY(image_t image_id, uint32_t* rows) c
     return out;
 }
 std::vector<uint8_t> Database::ReadDescriptors(image_t image_id, uint32_t* rows) const {
+    std::lock_guard<std::recursive_mutex> lock(mu_);
     *rows = 0;
     Stmt st(db_, Prepared("SELECT rows, cols, data FROM descriptors WHERE image_id = ?"));
     sqlite3_bind_int64(st.s, 1, image_id);
@@ -216,6 +231,7 @@ std::vector<uint8_t> Database::ReadDescriptors(image_t image_id, uint32_t* rows)
 }
 
 std::vector<float> Database::ReadKeypoints(image_t image_id, uint32_t* rows, uint32_t* cols) const {
+    std::lock_guard<std::recursive_mutex> lock(mu_);
     *rows = 0;
     *cols = 0;
     Stmt st(db_, Prepared("SELECT rows, cols, data FROM keypoints WHERE image_id = ?"));
@@ -234,16 +250,19 @@ std::vector<float> Database::ReadKeypoints(image_t image_id, uint32_t* rows, uin
     return out;
 }
 bool Database::ExistsKeypoints(image_t image_id) const {
+    std::lock_guard<std::recursive_mutex> lock(mu_);
     Stmt st(db_, Prepared("SELECT 1 FROM keypoints WHERE image_id = ?"));
     sqlite3_bind_int64(st.s, 1, image_id);
     return st.Step();
 }
 bool Database::ExistsDescriptors(image_t image_id) const {
+    std::lock_guard<std::recursive_mutex> lock(mu_);
     Stmt st(db_, Prepared("SELECT 1 FROM descriptors WHERE image_id = ?"));
     sqlite3_bind_int64(st.s, 1, image_id);
     return st.Step();
 }
 void Database::WriteKeypoints(image_t image_id, const float* data, uint32_t rows, uint32_t cols) {
+    std::lock_guard<std::recursive_mutex> lock(mu_);
     Stmt st(db_, Prepared("INSERT INTO keypoints(image_id, rows, cols, data) VALUES(?, ?, ?, ?)"));
     sqlite3_bind_int64(st.s, 1, image_id);
     sqlite3_bind_int64(st.s, 2, rows);
@@ -253,6 +272,7 @@ void Database::WriteKeypoints(image_t image_id, const float* data, uint32_t rows
     st.Step();
 }
 void Database::WriteDescriptors(image_t image_id, const uint8_t* data, uint32_t rows) {
+    std::lock_guard<std::recursive_mutex> lock(mu_);
     Stmt st(db_, Prepared("INSERT INTO descriptors(image_id, rows, cols, data) VALUES(?, ?, ?, ?)"));
     sqlite3_bind_int64(st.s, 1, image_id);
     sqlite3_bind_int64(st.s, 2, rows);
@@ -263,12 +283,17 @@ void Database::WriteDescriptors(image_t image_id, const uint8_t* data, uint32_t 
 }
 
 bool Database::ExistsPair(const char* table, image_pair_t pair_id) const {
+    std::lock_guard<std::recursive_mutex> lock(mu_);
     Stmt st(db_, Prepared((std::string("SELECT 1 FROM ") + table + " WHERE pair_id = ?")));
     sqlite3_bind_int64(st.s, 1, static_cast<sqlite3_int64>(pair_id));
     return st.Step();
 }
-bool Database::ExistsMatches(image_t id1, image_t id2) const { return ExistsPair("matches", ImagePairToPairId(id1, id2)); }
+bool Database::ExistsMatches(image_t id1, image_t id2) const {
+    std::lock_guard<std::recursive_mutex> lock(mu_);
+    return ExistsPair("matches", ImagePairToPairId(id1, id2));
+}
 bool Database::ExistsInlierMatches(image_t id1, image_t id2) const {
+    std::lock_guard<std::recursive_mutex> lock(mu_);
     return ExistsPair("two_view_geometries", ImagePairToPairId(id1, id2));
 }
 
@@ -285,12 +310,14 @@ static std::vector<uint32_t> BlobToMatches(sqlite3_stmt* s, int col_rows, int co
     return m;
 }
 std::vector<uint32_t> Database::ReadMatches(image_t id1, image_t id2) const {
+    std::lock_guard<std::recursive_mutex> lock(mu_);
     Stmt st(db_, Prepared("SELECT rows, cols, data FROM matches WHERE pair_id = ?"));
     sqlite3_bind_int64(st.s, 1, static_cast<sqlite3_int64>(ImagePairToPairId(id1, id2)));
     if (!st.Step()) return {};
     return BlobToMatches(st.s, 0, 2, SwapImagePair(id1, id2));
 }
 TwoViewGeometryRow Database::ReadTwoViewGeometry(image_t id1, image_t id2) const {
+    std::lock_guard<std::recursive_mutex> lock(mu_);
     TwoViewGeometryRow t;
     Stmt st(db_, Prepared("SELECT rows, cols, data, config, F, E, H, qvec, tvec FROM two_view_geometries WHERE pair_id = ?"));
     sqlite3_bind_int64(st.s, 1, static_cast<sqlite3_int64>(ImagePairToPairId(id1, id2)));
@@ -311,6 +338,7 @@ TwoViewGeometryRow Database::ReadTwoViewGeometry(image_t id1, image_t id2) const
 }
 
 void Database::WriteMatches(image_t id1, image_t id2, const std::vector<uint32_t>& matches) {
+    std::lock_guard<std::recursive_mutex> lock(mu_);
     // the blob is bound in place (SQLITE_STATIC: it outlives the step); a swapped copy is made only
     // for pairs given in descending id order
     std::vector<uint32_t> swapped;
@@ -329,6 +357,7 @@ void Database::WriteMatches(image_t id1, image_t id2, const std::vector<uint32_t
     st.Step();
 }
 void Database::WriteTwoViewGeometry(image_t id1, image_t id2, const TwoViewGeometryRow& in) {
+    std::lock_guard<std::recursive_mutex> lock(mu_);
     TwoViewGeometryRow inverted;
     const bool swap = SwapImagePair(id1, id2);
     if (swap) {
@@ -358,11 +387,13 @@ void Database::WriteTwoViewGeometry(image_t id1, image_t id2, const TwoViewGeome
     st.Step();
 }
 void Database::DeleteMatches(image_t id1, image_t id2) {
+    std::lock_guard<std::recursive_mutex> lock(mu_);
     Stmt st(db_, Prepared("DELETE FROM matches WHERE pair_id = ?"));
     sqlite3_bind_int64(st.s, 1, static_cast<sqlite3_int64>(ImagePairToPairId(id1, id2)));
     st.Step();
 }
 void Database::DeleteInlierMatches(image_t id1, image_t id2) {
+    std::lock_guard<std::recursive_mutex> lock(mu_);
     Stmt st(db_, Prepared("DELETE FROM two_view_geometries WHERE pair_id = ?"));
     sqlite3_bind_int64(st.s, 1, static_cast<sqlite3_int64>(ImagePairToPairId(id1, id2)));
     st.Step();

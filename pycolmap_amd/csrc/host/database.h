@@ -7,6 +7,7 @@
 #include <array>
 #include <cstdint>
 #include <stdexcept>
+#include <mutex>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -106,6 +107,9 @@ class Database {
     sqlite3_stmt* Prepared(const std::string& sql) const;  // prepared once per connection, then reused
     sqlite3* db_ = nullptr;
     bool bulk_mode_ = false;
+    // every public call holds this: the matching controllers write one group from a worker thread
+    // while the main thread already filters the next group against the same connection
+    mutable std::recursive_mutex mu_;
     mutable std::unordered_map<std::string, sqlite3_stmt*> stmts_;
 };
 

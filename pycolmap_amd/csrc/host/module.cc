@@ -169,7 +169,7 @@ py::dict StatsDict(const MatchStats& s) {
                     "pairs_skipped"_a = s.pairs_skipped, "match_device_ms"_a = s.match_device_ms,
                     "verify_device_ms"_a = s.verify_device_ms, "db_ms"_a = s.db_ms,
                     "match_call_ms"_a = s.match_call_ms, "verify_call_ms"_a = s.verify_call_ms,
-                    "match_total_ms"_a = s.match_total_ms, "setup_ms"_a = s.setup_ms,
+                    "match_total_ms"_a = s.match_total_ms, "setup_ms"_a = s.setup_ms, "write_ms"_a = s.write_ms,
                     "num_distances"_a = s.num_distances, "pairs_guided"_a = s.pairs_guided,
                     "guided_device_ms"_a = s.guided_device_ms, "loop_queries"_a = s.loop_queries,
                     "loop_pairs_scored"_a = s.loop_pairs_scored, "loop_device_ms"_a = s.loop_device_ms);
