@@ -79,6 +79,11 @@ void MatchController::Setup() {
     } setup_timer{NowMs(), &stats.setup_ms};
     db_ = std::make_unique<Database>(path_);
     db_->SetBulkWriteMode(true);  // rollback journal while this controller appends; WAL again on close
+    {
+        const std::vector<image_pair_t> m = db_->ReadMatchedPairIds(), t = db_->ReadVerifiedPairIds();
+        had_matches_.insert(m.begin(), m.end());
+        had_tvg_.insert(t.begin(), t.end());
+    }
     images_ = db_->ReadAllImages();
     const std::vector<CameraRow> cams = db_->ReadAllCameras();
     std::unordered_map<camera_t, const CameraRow*> cam_by_id;
@@ -129,8 +134,8 @@ std::vector<MatchController::Job> MatchController::Compute(const ImagePairs& ima
         const image_pair_t pid = Database::ImagePairToPairId(pr.first, pr.second);
         if (!seen.insert(pid).second) continue;  // avoid duplicate image pairs
         if (computed_.count(pid)) { ++stats.pairs_skipped; continue; }  // done earlier in this run (rows may be in flight)
-        const bool exists_matches = db_->ExistsMatches(pr.first, pr.second);
-        const bool exists_inlier = db_->ExistsInlierMatches(pr.first, pr.second);
+        const bool exists_matches = had_matches_.count(pid) != 0;
+        const bool exists_inlier = had_tvg_.count(pid) != 0;
         if (exists_matches && exists_inlier) { ++stats.pairs_skipped; continue; }  // resume
         // one of the two rows missing: recompute from scratch, delete what exists first
         if (exists_inlier) db_->DeleteInlierMatches(pr.first, pr.second);

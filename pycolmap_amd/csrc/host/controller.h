@@ -127,6 +127,9 @@ class MatchController {
     uint32_t SlotOf(image_t id) const;
     // pairs this run has computed already: their rows may still be on their way to the database
     std::unordered_set<image_pair_t> computed_;
+    // pair ids with a row in matches / two_view_geometries when the run started (read once in Setup: the
+    // resume filter then needs no query per pair and does not contend with the writer thread)
+    std::unordered_set<image_pair_t> had_matches_, had_tvg_;
     int loop_index_features_ = 0;  // > 0 once the truncated copies (slots N .. 2N-1) are uploaded
     void SetupLoopIndex(int max_features);
 };

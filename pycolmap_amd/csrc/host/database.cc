@@ -282,6 +282,27 @@ void Database::WriteDescriptors(image_t image_id, const uint8_t* data, uint32_t 
     st.Step();
 }
 
+static std::vector<image_pair_t> PairIdsOf(sqlite3* db, sqlite3_stmt* s) {
+    std::vector<image_pair_t> ids;
+    for (;;) {
+        const int rc = sqlite3_step(s);
+        if (rc == SQLITE_ROW) {
+            ids.push_back(static_cast<image_pair_t>(sqlite3_column_int64(s, 0)));
+            continue;
+        }
+        sqlite3_reset(s);
+        if (rc != SQLITE_DONE) throw std::runtime_error(std::string("SQLite step failed: ") + sqlite3_errmsg(db));
+        return ids;
+    }
+}
+std::vector<image_pair_t> Database::ReadMatchedPairIds() const {
+    std::lock_guard<std::recursive_mutex> lock(mu_);
+    return PairIdsOf(db_, Prepared("SELECT pair_id FROM matches"));
+}
+std::vector<image_pair_t> Database::ReadVerifiedPairIds() const {
+    std::lock_guard<std::recursive_mutex> lock(mu_);
+    return PairIdsOf(db_, Prepared("SELECT pair_id FROM two_view_geometries"));
+}
 bool Database::ExistsPair(const char* table, image_pair_t pair_id) const {
     std::lock_guard<std::recursive_mutex> lock(mu_);
     Stmt st(db_, Prepared((std::string("SELECT 1 FROM ") + table + " WHERE pair_id = ?")));

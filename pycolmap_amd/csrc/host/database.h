@@ -78,6 +78,10 @@ class Database {
     bool ExistsKeypoints(image_t image_id) const;
     bool ExistsDescriptors(image_t image_id) const;
 
+    // all pair ids that have a row in `matches` / `two_view_geometries` (one scan instead of two point
+    // queries per candidate pair)
+    std::vector<image_pair_t> ReadMatchedPairIds() const;
+    std::vector<image_pair_t> ReadVerifiedPairIds() const;
     bool ExistsMatches(image_t id1, image_t id2) const;
     bool ExistsInlierMatches(image_t id1, image_t id2) const;
     // matches as stored for the ordered pair (id1, id2): columns swapped back if id1 > id2
