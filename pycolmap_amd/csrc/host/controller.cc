@@ -25,12 +25,27 @@ double NowMs() {
 // lists follow one another, as EstimateMultipleTwoViewGeometries concatenates them
 void AppendInlierMatches(const uint8_t* mask, const uint32_t* matches, size_t m, std::vector<uint32_t>* out) {
     uint8_t top = 0;
-    for (size_t i = 0; i < m; ++i) top = std::max(top, mask[i]);
+    size_t n = 0;
+    for (size_t i = 0; i < m; ++i) {
+        top = std::max(top, mask[i]);
+        n += mask[i] != 0;
+    }
+    const size_t base = out->size();
+    out->resize(base + 2 * n);
+    uint32_t* dst = out->data() + base;
+    if (top <= 1) {  // the usual single geometry: one pass, no per-element capacity checks
+        for (size_t i = 0; i < m; ++i)
+            if (mask[i]) {
+                *dst++ = matches[2 * i];
+                *dst++ = matches[2 * i + 1];
+            }
+        return;
+    }
     for (uint8_t g = 1; g <= top; ++g)
         for (size_t i = 0; i < m; ++i)
             if (mask[i] == g) {
-                out->push_back(matches[2 * i]);
-                out->push_back(matches[2 * i + 1]);
+                *dst++ = matches[2 * i];
+                *dst++ = matches[2 * i + 1];
             }
 }
 
@@ -187,6 +202,12 @@ std::vector<MatchController::Job> MatchController::Compute(const ImagePairs& ima
     std::vector<uint32_t> v1, v2, vmatches;
     std::vector<uint64_t> voff{0};
     std::vector<size_t> vwhich;
+    {
+        size_t total = 0;
+        for (const Job& j : jobs)
+            if (j.matches.size() / 2 >= min_inl) total += j.matches.size();
+        vmatches.reserve(total);
+    }
     for (size_t k = 0; k < jobs.size(); ++k) {
         const size_t m = jobs[k].matches.size() / 2;
         if (m >= min_inl) {
