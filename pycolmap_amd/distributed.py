@@ -82,3 +82,55 @@ def all_gather_match_tables(pair_index: np.ndarray, offsets: np.ndarray, matches
     if not as_numpy:
         return g_off, g_matches
     return g_off.cpu().numpy().astype(np.uint64), g_matches.cpu().numpy().view(np.uint32)
+
+
+def all_gather_pair_records(pair_index: np.ndarray, records: np.ndarray, total_pairs: int, device=None, group=None):
+    """All-gather of one fixed-size record per pair (e.g. the TwoViewGeometry of a verified pair: config, E, F, H,
+    pose).  `records` is a 1-D structured / plain array with one element per local pair, `pair_index` their global
+    positions; returns the array of all `total_pairs` records in global order (pairs nobody owns stay zero).  One
+    size exchange + one padded byte all-gather, reassembled with a single indexed copy on `device`."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    dev = device if device is not None else torch.device("cpu")
+    rec = np.ascontiguousarray(records)
+    width = rec.dtype.itemsize
+    n = len(pair_index)
+    if len(rec) != n:
+        raise ValueError("one record per local pair")
+    sizes = torch.tensor([n], dtype=torch.int64, device=dev)
+    all_sizes = torch.empty(world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(all_sizes, sizes, group=group)
+    max_n = max(int(all_sizes.max()), 1)
+    idx = torch.full((max_n,), -1, dtype=torch.int64, device=dev)
+    body = torch.zeros(max_n, width, dtype=torch.uint8, device=dev)
+    if n:
+        idx[:n] = torch.from_numpy(np.asarray(pair_index, dtype=np.int64)).to(dev)
+        body[:n] = torch.from_numpy(rec.view(np.uint8).reshape(n, width)).to(dev)
+    all_idx = torch.empty(world * max_n, dtype=torch.int64, device=dev)
+    all_body = torch.empty(world * max_n, width, dtype=torch.uint8, device=dev)
+    dist.all_gather_into_tensor(all_idx, idx, group=group)
+    dist.all_gather_into_tensor(all_body, body, group=group)
+    valid = all_idx >= 0
+    out = torch.zeros(total_pairs, width, dtype=torch.uint8, device=dev)
+    out[all_idx[valid]] = all_body[valid]
+    return out.cpu().numpy().reshape(-1).view(rec.dtype).copy()
+
+
+def all_gather_verification(pair_index: np.ndarray, tvg: np.ndarray, match_offsets: np.ndarray, matches: np.ndarray,
+                            inlier_mask: np.ndarray, total_pairs: int, device=None, group=None):
+    """The exchange step of a sharded match + verify run: every rank passes the two-view geometries of its pairs (the
+    structured array `Context.verify_pairs` returns), their matches (CSR) and inlier mask; every rank gets back, in the
+    global pair order, (tvg records, match offsets, matches, inlier-match offsets, inlier matches) - what rank 0 needs
+    to write COLMAP's `matches` and `two_view_geometries` tables."""
+    off = np.asarray(match_offsets, dtype=np.int64)
+    m = np.ascontiguousarray(matches, dtype=np.uint32).reshape(-1, 2)
+    mask = np.asarray(inlier_mask).astype(bool)
+    csum = np.zeros(len(mask) + 1, dtype=np.int64)
+    csum[1:] = np.cumsum(mask)
+    inl_off = csum[off]            # inlier matches before each pair's first match: the CSR of the inlier lists
+    g_tvg = all_gather_pair_records(pair_index, tvg, total_pairs, device=device, group=group)
+    g_off, g_m = all_gather_match_tables(pair_index, off, m, device=device, group=group)
+    g_ioff, g_im = all_gather_match_tables(pair_index, inl_off, m[mask], device=device, group=group)
+    return g_tvg, g_off, g_m, g_ioff, g_im

@@ -78,3 +78,71 @@ def test_shard_pairs_groups_by_streamed_image():
         assert np.all(np.diff(b.astype(np.int64)) >= 0)          # sorted by image 2 within a shard
         np.testing.assert_array_equal(s1[idx], a)
     assert D.shard_pairs(s1[:0], s2[:0], 0, 2)[0].size == 0
+
+
+# ---- the verify half: geometries + inlier matches of sharded pairs ---------------------------------
+TVG_DT = np.dtype([("config", np.int32), ("num_inliers", np.int32), ("E", np.float64, (3, 3)),
+                   ("F", np.float64, (3, 3)), ("H", np.float64, (3, 3))])
+
+
+def _verify_scenes():
+    from pycolmap_amd import synth
+    rng = np.random.default_rng(5)
+    return [synth.two_view_scene(rng, num_inliers=int(rng.integers(0, 120)), num_outliers=int(rng.integers(5, 60)),
+                                 planar=bool(k % 3 == 0)) for k in range(11)]
+
+
+def _oracle_verify(scenes, which):
+    import oracle_lib as o
+    cam = o.make_camera(prior=True)
+    tvg = np.zeros(len(which), dtype=TVG_DT)
+    masks, mm, off = [], [], [0]
+    for i, k in enumerate(which):
+        sc = scenes[int(k)]
+        r = o.estimate_two_view_geometry(cam, sc["pts1"], cam, sc["pts2"], sc["matches"])
+        tvg[i] = (r["config"], r["num_inliers"], r["E"], r["F"], r["H"])
+        masks.append(r["inlier_mask"])
+        mm.append(sc["matches"])
+        off.append(off[-1] + len(sc["matches"]))
+    cat = np.concatenate(mm) if mm else np.zeros((0, 2), np.uint32)
+    return tvg, np.array(off), cat, (np.concatenate(masks) if masks else np.zeros(0, bool))
+
+
+def _verify_worker(rank, world, port, out_dir):
+    sys.path.insert(0, str(ROOT))
+    sys.path.insert(0, str(ROOT / "tests"))
+    import torch.distributed as dist
+
+    from pycolmap_amd import distributed as D
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    scenes = _verify_scenes()
+    n = len(scenes)
+    per = (n + world - 1) // world
+    mine = np.arange(n)[rank * per:(rank + 1) * per]
+    tvg, off, m, mask = _oracle_verify(scenes, mine)
+    g = D.all_gather_verification(mine, tvg, off, m, mask, n)
+    np.savez(Path(out_dir) / f"v{rank}.npz", tvg=g[0], off=g[1], m=g[2], ioff=g[3], im=g[4])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_verification_equals_single_process(tmp_path, world):
+    """Geometries, matches and inlier matches of pairs verified on different ranks, gathered: every rank ends up with
+    what one process computes for all pairs (ragged shards; with 4 ranks and 11 pairs the last shard is short)."""
+    import torch.multiprocessing as mp
+    mp.spawn(_verify_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    sys.path.insert(0, str(ROOT / "tests"))
+    scenes = _verify_scenes()
+    tvg, off, m, mask = _oracle_verify(scenes, np.arange(len(scenes)))
+    assert len(set(tvg["config"].tolist())) >= 3
+    inl_counts = np.array([mask[off[k]:off[k + 1]].sum() for k in range(len(scenes))])
+    for r in range(world):
+        z = np.load(tmp_path / f"v{r}.npz")
+        assert z["tvg"].tobytes() == tvg.tobytes()
+        np.testing.assert_array_equal(z["off"], off)
+        np.testing.assert_array_equal(z["m"], m)
+        np.testing.assert_array_equal(np.diff(z["ioff"]), inl_counts)
+        np.testing.assert_array_equal(z["im"], m[mask])
