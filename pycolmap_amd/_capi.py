@@ -270,7 +270,7 @@ class Context:
         return offsets, matches, stats
 
     def match_guided_pairs(self, slot1, slot2, tvg, max_error: float, max_ratio: float = 0.8,
-                           max_distance: float = 0.7, cross_check: bool = True, kernel: str = "auto"):
+                           max_distance: float = 0.7, cross_check: bool = True):
         """FeatureMatcher::MatchGuided per pair: `tvg` is a TVG_DTYPE array (config, F, H used), e.g.
         the output of verify_pairs.  Returns (offsets, matches, stats) like match_pairs."""
         s1 = np.ascontiguousarray(slot1, dtype=np.uint32)
@@ -279,7 +279,7 @@ class Context:
         if s1.shape != s2.shape or s1.ndim != 1 or g.shape != s1.shape:
             raise ValueError("slot1/slot2/tvg must be equal-length 1-D arrays")
         assert C.sizeof(Tvg) == TVG_DTYPE.itemsize
-        opts = MatchOpts(max_ratio, max_distance, 1 if cross_check else 0, KERNELS[kernel])
+        opts = MatchOpts(max_ratio, max_distance, 1 if cross_check else 0, KERNEL_AUTO)
         res = MatchResult()
         _check(self._lib.amc_match_guided_pairs(self._h, s1.ctypes.data_as(C.c_void_p),
                                                 s2.ctypes.data_as(C.c_void_p), s1.size,
@@ -292,7 +292,7 @@ class Context:
             matches = (np.ctypeslib.as_array(res.matches, shape=(total, 2)).copy() if total
                        else np.zeros((0, 2), dtype=np.uint32))
             stats = dict(num_distances=int(res.num_distances), pairs_dot4=int(res.pairs_dot4),
-                         pairs_mfma=int(res.pairs_mfma), device_ms=float(res.device_ms))
+                         device_ms=float(res.device_ms))
         finally:
             self._lib.amc_match_result_free(C.byref(res))
         return offsets, matches, stats

@@ -503,8 +503,7 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
             const Slot& x = c->slots[slot1[begin + i]];
             const Slot& y = c->slots[slot2[begin + i]];
             const bool nonempty = x.dev.rows > 0 && y.dev.rows > 0;
-            // (guided matching has its own mfma scan: match_mfma_guided.hip)
-            want_mfma[i] = nonempty && o.kernel != AMC_KERNEL_DOT4 &&
+            want_mfma[i] = nonempty && o.kernel != AMC_KERNEL_DOT4 && !geoms &&
                            (!o.cross_check || y.dev.rows_pad <= mfma_max_cols);
         }
         PairDev* hp = c->h_pairs[k].p;
@@ -612,12 +611,7 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
                                     hipMemcpyHostToDevice, st), "H2D guided");
         if (!okq) return false;
         (void)hipEventRecord(c->bev[k][0], st);
-        const GuidedDev* gdev = geoms ? c->d_guided.p : nullptr;
-        if (nord && gdev)
-            launch_match_mfma_guided(0, c->d_imgs.p, c->d_pairs.p, c->d_order.p, (uint32_t)nord,
-                                     c->d_scalars + 1, c->d_cand_cnt.p, c->d_candbuf.p, c->d_rowbuf.p,
-                                     c->d_accmask.p, c->d_lut, fp, gdev, st);
-        else if (nord)
+        if (nord)
             launch_match_mfma(0, c->d_imgs.p, c->d_pairs.p, c->d_order.p, (uint32_t)nord,
                               c->d_scalars + 1, c->d_cand_cnt.p, c->d_candbuf.p, c->d_rowbuf.p,
                               c->d_accmask.p, c->d_lut, fp, st);
@@ -628,7 +622,7 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
         kernel_launches += (nord ? 1 : 0) + (nwork ? 1 : 0);
         if (nord)  // tile -> exact index for the accepted rows
             launch_resolve_index(0, c->d_imgs.p, c->d_pairs.p, (uint32_t)nb, c->d_rowbuf.p, c->d_accmask.p, c->d_lut,
-                                 fp, c->d_cand_cnt.p, c->d_candbuf.p, c->d_scalars + 3, gdev, st);
+                                 fp, c->d_cand_cnt.p, c->d_candbuf.p, c->d_scalars + 3, st);
         if (nord && o.cross_check) {
             // lazy cross check: reverse scan only for the columns accepted rows point at
             launch_select_candidates(c->d_imgs.p, c->d_pairs.p, (uint32_t)nb, c->d_rowbuf.p, c->d_accmask.p,
@@ -636,16 +630,11 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
             if (!hc(hipMemcpyAsync(c->d_order2.p, c->h_order2[k].p, nord * sizeof(uint32_t),
                                    hipMemcpyHostToDevice, st), "H2D order2"))
                 return false;
-            if (gdev)
-                launch_match_mfma_guided(1, c->d_imgs.p, c->d_pairs.p, c->d_order2.p, (uint32_t)nord,
-                                         c->d_scalars + 1, c->d_cand_cnt.p, c->d_candbuf.p, c->d_colbuf.p,
-                                         c->d_accmask.p, c->d_lut, fp, gdev, st);
-            else
-                launch_match_mfma(1, c->d_imgs.p, c->d_pairs.p, c->d_order2.p, (uint32_t)nord,
-                                  c->d_scalars + 1, c->d_cand_cnt.p, c->d_candbuf.p, c->d_colbuf.p,
-                                  c->d_accmask.p, c->d_lut, fp, st);
+            launch_match_mfma(1, c->d_imgs.p, c->d_pairs.p, c->d_order2.p, (uint32_t)nord,
+                              c->d_scalars + 1, c->d_cand_cnt.p, c->d_candbuf.p, c->d_colbuf.p,
+                              c->d_accmask.p, c->d_lut, fp, st);
             launch_resolve_index(1, c->d_imgs.p, c->d_pairs.p, (uint32_t)nb, c->d_colbuf.p, c->d_accmask.p, c->d_lut,
-                                 fp, c->d_cand_cnt.p, c->d_candbuf.p, c->d_scalars + 3, gdev, st);
+                                 fp, c->d_cand_cnt.p, c->d_candbuf.p, c->d_scalars + 3, st);
         }
         (void)hipEventRecord(c->bev[k][2], st);
         launch_finalize(c->d_imgs.p, c->d_pairs.p, (uint32_t)nb, c->d_rowbuf.p, c->d_colbuf.p,
@@ -814,8 +803,7 @@ int amc_upload_keypoints(amc_ctx* c, uint32_t slot, const float* xy, uint32_t ro
     s.kp_rows = rows;
     s.has_kp = true;
     if (rows == 0) return AMC_OK;
-    // zero-padded to whole kRowPad-row chunks: the guided mfma scan DMAs a chunk's keypoints into LDS
-    std::vector<float> packed((size_t)round_up(rows, (uint32_t)kRowPad) * 2, 0.0f);
+    std::vector<float> packed((size_t)rows * 2);
     for (uint32_t i = 0; i < rows; ++i) {
         packed[2 * (size_t)i] = xy[(size_t)i * stride_floats];
         packed[2 * (size_t)i + 1] = xy[(size_t)i * stride_floats + 1];

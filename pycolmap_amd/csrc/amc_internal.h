@@ -80,30 +80,6 @@ struct FinalizeParams {
 void launch_prep(const uint8_t* raw, uint8_t* prep, int32_t* rs128, uint32_t rows_pad,
                  uint32_t* maxsq_out, hipStream_t s);
 
-#if defined(__HIPCC__)
-// Guided matching's float32 filter (SiftCPUFeatureMatcher::MatchGuided; oracle_guided_filter in
-// oracle/match_oracle.c spells out the operation order): true = this (image-1 point, image-2 point)
-// pairing is rejected and its distance is forced to 0.
-__device__ __forceinline__ bool guided_rejects(const GuidedDev& g, float x1, float y1, float x2, float y2) {
-    const float* m = g.m;
-    if (g.kind == kGuidedF) {
-        const float Fx1_0 = m[0] * x1 + m[1] * y1 + m[2] * 1.0f;
-        const float Fx1_1 = m[3] * x1 + m[4] * y1 + m[5] * 1.0f;
-        const float Fx1_2 = m[6] * x1 + m[7] * y1 + m[8] * 1.0f;
-        const float Ftx2_0 = m[0] * x2 + m[3] * y2 + m[6] * 1.0f;
-        const float Ftx2_1 = m[1] * x2 + m[4] * y2 + m[7] * 1.0f;
-        const float x2tFx1 = x2 * Fx1_0 + y2 * Fx1_1 + 1.0f * Fx1_2;
-        return x2tFx1 * x2tFx1 / (Fx1_0 * Fx1_0 + Fx1_1 * Fx1_1 + Ftx2_0 * Ftx2_0 + Ftx2_1 * Ftx2_1) > g.max_residual;
-    }
-    const float Hp_0 = m[0] * x1 + m[1] * y1 + m[2] * 1.0f;
-    const float Hp_1 = m[3] * x1 + m[4] * y1 + m[5] * 1.0f;
-    const float Hp_2 = m[6] * x1 + m[7] * y1 + m[8] * 1.0f;
-    const float e0 = Hp_0 / Hp_2 - x2;
-    const float e1 = Hp_1 / Hp_2 - y2;
-    return e0 * e0 + e1 * e1 > g.max_residual;
-}
-#endif
-
 // guided: nullptr, or one GuidedDev per PairDev of the batch (entries the filter rejects score 0)
 void launch_match_dot4(const ImageDev* imgs, const PairDev* pairs, const Dot4Work* work,
                        uint32_t nwork, Top2* rowbuf, Top2* colbuf, const GuidedDev* guided, hipStream_t s);
@@ -136,17 +112,10 @@ void launch_match_mfma(int mode, const ImageDev* imgs, const PairDev* pairs,
                        const uint32_t* cand_cnt, const uint32_t* candbuf, Top2* outbuf,
                        uint32_t* accmask, const float* acos_lut, FinalizeParams fp, hipStream_t s);
 
-// the guided scan (match_mfma_guided.hip): same outputs as launch_match_mfma on the filtered distance matrix
-void launch_match_mfma_guided(int mode, const ImageDev* imgs, const PairDev* pairs,
-                              const uint32_t* order, uint32_t nitems, uint32_t* queue_head,
-                              const uint32_t* cand_cnt, const uint32_t* candbuf, Top2* outbuf,
-                              uint32_t* accmask, const float* acos_lut, FinalizeParams fp,
-                              const GuidedDev* guided, hipStream_t s);
-// guided: nullptr, or the batch's filter models (the recomputed values go through the same filter)
 void launch_resolve_index(int side, const ImageDev* imgs, const PairDev* pairs, uint32_t npairs,
                           Top2* table, uint32_t* accmask, const float* acos_lut, FinalizeParams fp,
                           const uint32_t* cand_cnt, const uint32_t* candbuf, uint32_t* err_count,
-                          const GuidedDev* guided, hipStream_t s);
+                          hipStream_t s);
 constexpr uint32_t kSelectMaxCols = 32768;  // select_candidates' LDS bitmap (4 KiB)
 
 void launch_select_candidates(const ImageDev* imgs, const PairDev* pairs, uint32_t npairs,

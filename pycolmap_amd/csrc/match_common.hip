@@ -156,11 +156,9 @@ __global__ __launch_bounds__(256) void resolve_index_kernel(
     int side, const ImageDev* __restrict__ imgs, const PairDev* __restrict__ pairs,
     Top2* __restrict__ table, uint32_t* __restrict__ accmask, const float* __restrict__ lut,
     FinalizeParams fp, const uint32_t* __restrict__ cand_cnt, const uint32_t* __restrict__ candbuf,
-    uint32_t* __restrict__ err_count, const GuidedDev* __restrict__ guided) {
+    uint32_t* __restrict__ err_count) {
     const PairDev p = pairs[blockIdx.x];
     if (p.mode == 0) return;  // dot4 pairs carry exact indices already
-    GuidedDev gd{};
-    if (guided) gd = guided[blockIdx.x];
     const ImageDev X = imgs[side == 0 ? p.slot1 : p.slot2];
     const ImageDev Y = imgs[side == 0 ? p.slot2 : p.slot1];
     const uint32_t n = side == 0 ? X.rows : cand_cnt[blockIdx.x];
@@ -209,15 +207,6 @@ __global__ __launch_bounds__(256) void resolve_index_kernel(
                 }
             }
             sum += __shfl_xor(sum, 32);
-            if (guided && jj < Y.rows) {
-                // guided matching: the recomputed entry goes through the pair's filter like every entry of
-                // the scan did (image-1 point first, whichever image is being scanned)
-                const uint32_t xr = min(xrow, X.kp_rows - 1), yr = min(jj, Y.kp_rows - 1);
-                const float xx = X.kp[2 * (size_t)xr], xy = X.kp[2 * (size_t)xr + 1];
-                const float yx = Y.kp[2 * (size_t)yr], yy = Y.kp[2 * (size_t)yr + 1];
-                const bool rej = side == 0 ? guided_rejects(gd, xx, xy, yx, yy) : guided_rejects(gd, yx, yy, xx, xy);
-                if (rej) sum = 0;
-            }
             const bool eq = (sum == val) && (jj < Y.rows);
             const uint32_t m = (uint32_t)(__ballot(eq) & 0xFFFFFFFFull);
             const uint32_t first = m ? (uint32_t)(__ffs(m) - 1) : 0xFFFFFFFFu;
@@ -249,10 +238,10 @@ __global__ __launch_bounds__(256) void resolve_index_kernel(
 void launch_resolve_index(int side, const ImageDev* imgs, const PairDev* pairs, uint32_t npairs,
                           Top2* table, uint32_t* accmask, const float* acos_lut, FinalizeParams fp,
                           const uint32_t* cand_cnt, const uint32_t* candbuf, uint32_t* err_count,
-                          const GuidedDev* guided, hipStream_t s) {
+                          hipStream_t s) {
     if (npairs == 0) return;
     hipLaunchKernelGGL(resolve_index_kernel, dim3(npairs), dim3(256), 0, s, side, imgs, pairs,
-                       table, accmask, acos_lut, fp, cand_cnt, candbuf, err_count, guided);
+                       table, accmask, acos_lut, fp, cand_cnt, candbuf, err_count);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -25,23 +25,15 @@ def upload_scene(ctx, imgs, prior):
 
 
 def check_guided(ctx, imgs, s1, s2, tvg, max_error, **kw):
-    """Both device paths - the dot4 kernel that filters every entry and the mfma scan that consults the
-    filter only where it can matter (match_mfma_guided.hip) - against the oracle."""
+    off, m, st = ctx.match_guided_pairs(s1, s2, tvg, max_error, **kw)
+    assert st["pairs_dot4"] == len(s1)
     total = 0
-    nonempty = sum(1 for a, b in zip(s1, s2) if len(imgs[a]["descriptors"]) and len(imgs[b]["descriptors"]))
-    for kernel in ("dot4", "auto"):
-        off, m, st = ctx.match_guided_pairs(s1, s2, tvg, max_error, kernel=kernel, **kw)
-        if kernel == "dot4":
-            assert st["pairs_dot4"] == nonempty and st["pairs_mfma"] == 0
-        else:
-            assert st["pairs_mfma"] == nonempty and st["pairs_dot4"] == 0
-        total = 0
-        for p, (a, b) in enumerate(zip(s1, s2)):
-            want = o.match_guided(imgs[a]["descriptors"], imgs[a]["keypoints"], imgs[b]["descriptors"],
-                                  imgs[b]["keypoints"], tvg[p]["config"], tvg[p]["F"], tvg[p]["H"], max_error, **kw)
-            assert want is not None
-            np.testing.assert_array_equal(m[int(off[p]):int(off[p + 1])], want, err_msg=f"{kernel} pair {p} ({a},{b})")
-            total += len(want)
+    for p, (a, b) in enumerate(zip(s1, s2)):
+        want = o.match_guided(imgs[a]["descriptors"], imgs[a]["keypoints"], imgs[b]["descriptors"],
+                              imgs[b]["keypoints"], tvg[p]["config"], tvg[p]["F"], tvg[p]["H"], max_error, **kw)
+        assert want is not None
+        np.testing.assert_array_equal(m[int(off[p]):int(off[p + 1])], want, err_msg=f"pair {p} ({a},{b})")
+        total += len(want)
     return total
 
 
