@@ -1041,20 +1041,14 @@ static int verify_impl(amc_ctx* c, int mode, const uint32_t* slot1, const uint32
         if (M > 65535) return fail(AMC_E_INVALID, "amc_verify_pairs: pair %zu has %llu matches (> 65535)", p,
                                    (unsigned long long)M);
         maxM = std::max<uint32_t>(maxM, (uint32_t)M);
-        {
-            // largest index per column first (a loop the compiler vectorises); the offending match is only
-            // looked for when there is one
-            uint32_t mx1 = 0, mx2 = 0;
+        // Match indices are checked by the kernel where it gathers the points (bad_index_count below); only
+        // the pairs it returns from before that - fewer matches than min_num_inliers - are checked here.
+        if (mode == 0 && M < (uint64_t)std::max(o.min_num_inliers, 0)) {
             const uint32_t* mm = matches + 2 * match_offsets[p];
-            for (uint64_t k = 0; k < M; ++k) {
-                mx1 = std::max(mx1, mm[2 * k]);
-                mx2 = std::max(mx2, mm[2 * k + 1]);
-            }
-            if (M && (mx1 >= a.kp_rows || mx2 >= b.kp_rows))
-                for (uint64_t k = 0; k < M; ++k)
-                    if (mm[2 * k] >= a.kp_rows || mm[2 * k + 1] >= b.kp_rows)
-                        return fail(AMC_E_INVALID, "amc_verify_pairs: pair %zu match %llu indexes past the keypoints",
-                                    p, (unsigned long long)k);
+            for (uint64_t k = 0; k < M; ++k)
+                if (mm[2 * k] >= a.kp_rows || mm[2 * k + 1] >= b.kp_rows)
+                    return fail(AMC_E_INVALID, "amc_verify_pairs: pair %zu match %llu indexes past the keypoints",
+                                p, (unsigned long long)k);
         }
         const bool uses_E = mode == 0 ? (!o.force_H_use && a.cam.has_prior && b.cam.has_prior) : mode == 3;
         if (uses_E &&
@@ -1081,6 +1075,7 @@ static int verify_impl(amc_ctx* c, int mode, const uint32_t* slot1, const uint32
         const char* e = std::getenv("AMC_TVG_SLOW_SAMPLER");
         P.force_slow_sampler = (e && e[0] == '1') ? 1 : 0;
         P.mode = mode;
+        P.bad_index_count = c->d_scalars + 2;
     }
     if (mode == 0 && o.detect_watermark && P.max_trials[3] > P.min_num_trials)
         return fail(AMC_E_INVALID, "amc_verify_pairs: unsupported option combination: the watermark RANSAC "
@@ -1191,6 +1186,7 @@ static int verify_impl(amc_ctx* c, int mode, const uint32_t* slot1, const uint32
     if (!tabs.empty())
         HIPCHK(hipMemcpyAsync(c->d_ttabs.p, tabs.data(), tabs.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(c->d_mtinit.p, mt0, sizeof mt0, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemsetAsync(c->d_scalars + 2, 0, sizeof(uint32_t), st));
     HIPCHK(hipStreamSynchronize(st));
 
     std::vector<TvgOut> h_out(npairs);
@@ -1240,8 +1236,23 @@ static int verify_impl(amc_ctx* c, int mode, const uint32_t* slot1, const uint32
     }
     if (mask_bytes)
         HIPCHK(hipMemcpyAsync(h_mask.data(), c->d_toutmask.p, mask_bytes, hipMemcpyDeviceToHost, st));
+    uint32_t bad_pairs = 0;
+    HIPCHK(hipMemcpyAsync(&bad_pairs, c->d_scalars + 2, sizeof bad_pairs, hipMemcpyDeviceToHost, st));
     HIPCHK(hipEventRecord(c->ev[1], st));
     HIPCHK(hipEventSynchronize(c->ev[1]));
+    if (bad_pairs) {  // the kernel met an index past an image's keypoints: find it for the message
+        delete priv;
+        std::memset(out, 0, sizeof *out);
+        for (size_t p = 0; p < npairs; ++p) {
+            const Slot& a = c->slots[slot1[p]];
+            const Slot& b = c->slots[slot2[p]];
+            for (uint64_t k = match_offsets[p]; k < match_offsets[p + 1]; ++k)
+                if (matches[2 * k] >= a.kp_rows || matches[2 * k + 1] >= b.kp_rows)
+                    return fail(AMC_E_INVALID, "amc_verify_pairs: pair %zu match %llu indexes past the keypoints", p,
+                                (unsigned long long)(k - match_offsets[p]));
+        }
+        return fail(AMC_E_INVALID, "amc_verify_pairs: %u pairs index past the keypoints", bad_pairs);
+    }
     if (std::getenv("AMC_TVG_PROFILE")) {
         unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         for (size_t p = 0; p < npairs; ++p)

@@ -188,6 +188,7 @@ struct TvgParams {
         watermark_border_size, max_error;
     int32_t force_slow_sampler;  // test hook (AMC_TVG_SLOW_SAMPLER=1): draw-by-draw sampler path only
     int32_t mode;                // 0: EstimateTwoViewGeometry; 1 / 2 / 3: a single F / H / E LO-RANSAC
+    uint32_t* bad_index_count;   // += 1 per pair whose matches index past an image's keypoints (the pair is skipped)
 };
 size_t tvg_ws_doubles_host(uint32_t mcap);
 size_t tvg_ws_mask_bytes_host(uint32_t mcap);

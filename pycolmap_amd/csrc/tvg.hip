@@ -1128,12 +1128,28 @@ __device__ __noinline__ void process_pair(Wave& w, uint32_t q, const TvgImage* _
     // ---- matched points (FeatureKeypointsToPointsVector: float -> double) ------------------
     double *X1 = w.arr(W_X1), *Y1 = w.arr(W_Y1), *X2 = w.arr(W_X2), *Y2 = w.arr(W_Y2);
     const uint32_t* mm = matches + 2 * pr.match_off;
+    // The indices are checked here, where they are read anyway (the host only checks the pairs that
+    // return above): a pair with a match past an image's keypoints is counted and not estimated - the
+    // host then fails the whole call with AMC_E_INVALID, naming the match.
+    bool bad = false;
     for (int k = lane; k < M; k += 64) {
         const uint32_t i1 = mm[2 * k], i2 = mm[2 * k + 1];
+        if (i1 >= im1.rows || i2 >= im2.rows) {
+            bad = true;
+            continue;
+        }
         X1[k] = im1.kp64 ? im1.kp64[2 * (size_t)i1] : (double)im1.kp[2 * (size_t)i1];
         Y1[k] = im1.kp64 ? im1.kp64[2 * (size_t)i1 + 1] : (double)im1.kp[2 * (size_t)i1 + 1];
         X2[k] = im2.kp64 ? im2.kp64[2 * (size_t)i2] : (double)im2.kp[2 * (size_t)i2];
         Y2[k] = im2.kp64 ? im2.kp64[2 * (size_t)i2 + 1] : (double)im2.kp[2 * (size_t)i2 + 1];
+    }
+    if (__any(bad)) {
+        g.config = AMC_TVG_UNDEFINED;
+        if (lane == 0) {
+            atomicAdd(P.bad_index_count, 1u);
+            out[q].g = g;
+        }
+        return;
     }
     // ---- SetPRNGSeed(seed): generator state as std::mt19937(seed) leaves it ---------------
     for (int i = lane; i < 624; i += 64) w.mt[i] = mt_init[i];
