@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""One-rank RCCL run of the sharded match + verify exchange on a GPU (the N > 1 logic is covered by the gloo
+tests; this checks the same functions on device tensors over the nccl backend):
+    MASTER_ADDR=127.0.0.1 MASTER_PORT=29533 RANK=0 WORLD_SIZE=1 python tools/dist_smoke.py"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+from pycolmap_amd import _capi, synth  # noqa: E402
+from pycolmap_amd import distributed as D  # noqa: E402
+
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+os.environ.setdefault("MASTER_PORT", "29533")
+rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)))
+dist.init_process_group("nccl", rank=rank, world_size=world)
+dev = torch.device("cuda", torch.cuda.current_device())
+rng = np.random.default_rng(0)
+imgs = synth.multiview_scene(rng, num_images=6, n_feats=600, num_landmarks=800)
+ctx = _capi.Context(torch.cuda.current_device())
+ctx.reserve_slots(len(imgs))
+for k, im in enumerate(imgs):
+    ctx.upload_descriptors(k, im["descriptors"])
+    ctx.upload_keypoints(k, im["keypoints"])
+    ctx.upload_camera(k, "PINHOLE", im["width"], im["height"], im["params"], True)
+s1_all, s2_all = synth.exhaustive_pairs(len(imgs))
+s1, s2, mine = D.shard_pairs(s1_all, s2_all, rank, world)
+off, m, _ = ctx.match_pairs(s1, s2)
+tvg, mask, _ = ctx.verify_pairs(s1, s2, off, m, _capi.tvg_options(compute_relative_pose=1))
+g_tvg, g_off, g_m, g_ioff, g_im = D.all_gather_verification(mine, tvg, off, m, mask, len(s1_all), device=dev)
+# single-process reference on the same device
+woff, wm, _ = ctx.match_pairs(s1_all, s2_all)
+wtvg, wmask, _ = ctx.verify_pairs(s1_all, s2_all, woff, wm, _capi.tvg_options(compute_relative_pose=1))
+assert np.array_equal(g_off, woff) and np.array_equal(g_m, wm)
+assert g_tvg.tobytes() == wtvg.tobytes()
+assert np.array_equal(g_im, wm[wmask]) and int(g_ioff[-1]) == int(wmask.sum())
+dist.barrier()
+dist.destroy_process_group()
+if rank == 0:
+    print(f"dist smoke ok: {len(s1_all)} pairs, {len(wm)} matches, {int(wmask.sum())} inlier matches, world {world}")
