@@ -173,8 +173,23 @@ enum {
     AMC_TVG_MULTIPLE = 8
 };
 
-/* Camera models accepted by the E path (ids as in COLMAP). */
-enum { AMC_CAM_SIMPLE_PINHOLE = 0, AMC_CAM_PINHOLE = 1 };
+/* Camera models (ids and parameter vectors as in COLMAP 3.9.1 colmap/sensor/models.h, SURVEY.md A.1;
+ * pycolmap.CameraModelId, /root/reference/pycolmap/scene/camera.h:40-49).  The calibrated path lifts
+ * keypoints with Camera::CamFromImg of the image's model
+ * (/root/reference/pycolmap/estimators/essential_matrix.h:33-46): all eleven are supported. */
+enum {
+    AMC_CAM_SIMPLE_PINHOLE = 0,        /* f, cx, cy */
+    AMC_CAM_PINHOLE = 1,               /* fx, fy, cx, cy */
+    AMC_CAM_SIMPLE_RADIAL = 2,         /* f, cx, cy, k */
+    AMC_CAM_RADIAL = 3,                /* f, cx, cy, k1, k2 */
+    AMC_CAM_OPENCV = 4,                /* fx, fy, cx, cy, k1, k2, p1, p2 */
+    AMC_CAM_OPENCV_FISHEYE = 5,        /* fx, fy, cx, cy, k1, k2, k3, k4 */
+    AMC_CAM_FULL_OPENCV = 6,           /* fx, fy, cx, cy, k1, k2, p1, p2, k3, k4, k5, k6 */
+    AMC_CAM_FOV = 7,                   /* fx, fy, cx, cy, omega */
+    AMC_CAM_SIMPLE_RADIAL_FISHEYE = 8, /* f, cx, cy, k */
+    AMC_CAM_RADIAL_FISHEYE = 9,        /* f, cx, cy, k1, k2 */
+    AMC_CAM_THIN_PRISM_FISHEYE = 10    /* fx, fy, cx, cy, k1, k2, p1, p2, k3, k4, sx1, sy1 */
+};
 
 /* One pair's TwoViewGeometry (/root/reference/pycolmap/estimators/two_view_geometry.h:79-93):
  * config, E/F/H row-major (the three RANSAC report models, as COLMAP stores them), the size of
@@ -238,10 +253,18 @@ int amc_upload_keypoints(amc_ctx* ctx, uint32_t slot, const float* xy, uint32_t 
  * estimators work on them unchanged; this replaces the slot's float32 keypoints. */
 int amc_upload_points_f64(amc_ctx* ctx, uint32_t slot, const double* xy, uint32_t rows);
 
-/* Camera of an image (COLMAP Camera: model id, size, params, has_prior_focal_length). */
+/* Camera of an image (COLMAP Camera: model id, size, params, has_prior_focal_length).  num_params must be the
+ * model's parameter count (Camera::VerifyParams), else AMC_E_INVALID. */
 int amc_upload_camera(amc_ctx* ctx, uint32_t slot, int32_t model_id, uint64_t width,
                       uint64_t height, const double* params, int32_t num_params,
                       int32_t has_prior_focal_length);
+
+/* Camera::CamFromImg for n image points (/root/reference/pycolmap/scene/camera.h:136-150: cam_from_img on an
+ * N x 2 array): xy n x 2 pixels -> uv n x 2 normalised image-plane coordinates.  The same code that lifts an
+ * image's keypoints for the calibrated path (device kernel for the pinhole and polynomial-distortion models; the
+ * host libm for the fisheye family and FOV, whose distortion calls atan / tan / sin / cos). */
+int amc_cam_from_img(amc_ctx* ctx, int32_t model_id, const double* params, int32_t num_params,
+                     const double* xy, size_t n, double* uv);
 
 /* EstimateTwoViewGeometry for every listed pair.  matches of pair p: uint32 (idx1, idx2) rows
  * matches[2*match_offsets[p] .. 2*match_offsets[p+1]).  The PRNG is re-seeded with `seed` at the
@@ -255,7 +278,7 @@ void amc_verify_result_free(amc_verify_result* r);
 
 /* EstimateTwoViewGeometryPose (/root/reference/pycolmap/estimators/two_view_geometry.h:153-159) on given
  * geometries: geoms[p] supplies config, E and H; inlier_matches (CSR, as amc_verify_pairs' matches)
- * are the geometry's inlier_matches.  Both images need points and a SIMPLE_PINHOLE / PINHOLE camera.
+ * are the geometry's inlier_matches.  Both images need points and a camera.
  * out: npairs records.  Also the cam2_from_cam1 of essential_matrix_estimation
  * (/root/reference/pycolmap/estimators/essential_matrix.h:63-83): config = AMC_TVG_CALIBRATED, E = the
  * report's model, inlier_matches = its inliers. */
@@ -285,8 +308,7 @@ int amc_match_guided_pairs(amc_ctx* ctx, const uint32_t* slot1, const uint32_t* 
  *               (/root/reference/pycolmap/estimators/homography_matrix.h:16-37)
  * AMC_RANSAC_E  LORANSAC<EssentialMatrixFivePointEstimator, ...> on CamFromImg-normalised points
  *               with max_error = 0.5 * (e / f1 + e / f2)
- *               (/root/reference/pycolmap/estimators/essential_matrix.h:19-52); needs both cameras
- *               (SIMPLE_PINHOLE / PINHOLE).
+ *               (/root/reference/pycolmap/estimators/essential_matrix.h:19-52); needs both cameras.
  * The correspondences of pair p are rows match_offsets[p] .. match_offsets[p+1] of `matches`
  * (indices into the two slots' points).  The PRNG is seeded with `seed` per pair (the bindings
  * call SetPRNGSeed(0)). */

@@ -78,7 +78,7 @@ struct TvgOptions {
 };
 
 struct Camera {
-    int32_t model_id;  // 0 SIMPLE_PINHOLE (f,cx,cy), 1 PINHOLE (fx,fy,cx,cy)
+    int32_t model_id;  // COLMAP camera model id, 0..10 (kModels below)
     int32_t has_prior_focal_length;
     uint64_t width, height;
     double params[12];
@@ -750,16 +750,205 @@ Report lo_ransac(EstKind est, EstKind local_est, const RansacOptions& opt_in, Pr
 }
 
 // ----------------------------------------------------------------------------------------------
-// cameras (subset): SIMPLE_PINHOLE, PINHOLE
+// cameras: colmap/sensor/models.h (3.9.1), the eleven models, as Camera::CamFromImg /
+// CamFromImgThreshold / CalibrationMatrix use them.  Called per matched point by
+// EstimateCalibratedTwoViewGeometry (reference side: /root/reference/pycolmap/estimators/
+// essential_matrix.h:33-46, /root/reference/pycolmap/scene/camera.h:136-165).  Restated from the
+// upstream templates with T = double (confidence: high for the pinhole / radial / OpenCV models and
+// IterativeUndistortion, medium for the FOV closed form and the thin-prism fisheye tail).
 // ----------------------------------------------------------------------------------------------
-bool camera_supported(const Camera& c) { return c.model_id == 0 || c.model_id == 1; }
+struct ModelInfo { int num_params; int num_focal; };  // focal idxs 0..num_focal-1, principal point next
+const ModelInfo kModels[11] = {
+    {3, 1},   // 0 SIMPLE_PINHOLE        f, cx, cy
+    {4, 2},   // 1 PINHOLE               fx, fy, cx, cy
+    {4, 1},   // 2 SIMPLE_RADIAL         f, cx, cy, k
+    {5, 1},   // 3 RADIAL                f, cx, cy, k1, k2
+    {8, 2},   // 4 OPENCV                fx, fy, cx, cy, k1, k2, p1, p2
+    {8, 2},   // 5 OPENCV_FISHEYE        fx, fy, cx, cy, k1, k2, k3, k4
+    {12, 2},  // 6 FULL_OPENCV           fx, fy, cx, cy, k1, k2, p1, p2, k3, k4, k5, k6
+    {5, 2},   // 7 FOV                   fx, fy, cx, cy, omega
+    {4, 1},   // 8 SIMPLE_RADIAL_FISHEYE f, cx, cy, k
+    {5, 1},   // 9 RADIAL_FISHEYE        f, cx, cy, k1, k2
+    {12, 2},  // 10 THIN_PRISM_FISHEYE   fx, fy, cx, cy, k1, k2, p1, p2, k3, k4, sx1, sy1
+};
+bool camera_supported(const Camera& c) { return c.model_id >= 0 && c.model_id <= 10; }
+
+// <Model>::Distortion(extra_params, u, v, &du, &dv)
+void model_distortion(int model, const double* extra, double u, double v, double* du, double* dv) {
+    const double kEps = std::numeric_limits<double>::epsilon();
+    switch (model) {
+        case 2: {  // SimpleRadialCameraModel
+            const double k = extra[0];
+            const double u2 = u * u;
+            const double v2 = v * v;
+            const double r2 = u2 + v2;
+            const double radial = k * r2;
+            *du = u * radial;
+            *dv = v * radial;
+            return;
+        }
+        case 3: {  // RadialCameraModel
+            const double k1 = extra[0];
+            const double k2 = extra[1];
+            const double u2 = u * u;
+            const double v2 = v * v;
+            const double r2 = u2 + v2;
+            const double radial = k1 * r2 + k2 * r2 * r2;
+            *du = u * radial;
+            *dv = v * radial;
+            return;
+        }
+        case 4: {  // OpenCVCameraModel
+            const double k1 = extra[0];
+            const double k2 = extra[1];
+            const double p1 = extra[2];
+            const double p2 = extra[3];
+            const double u2 = u * u;
+            const double uv = u * v;
+            const double v2 = v * v;
+            const double r2 = u2 + v2;
+            const double radial = k1 * r2 + k2 * r2 * r2;
+            *du = u * radial + 2.0 * p1 * uv + p2 * (r2 + 2.0 * u2);
+            *dv = v * radial + 2.0 * p2 * uv + p1 * (r2 + 2.0 * v2);
+            return;
+        }
+        case 6: {  // FullOpenCVCameraModel
+            const double k1 = extra[0], k2 = extra[1], p1 = extra[2], p2 = extra[3];
+            const double k3 = extra[4], k4 = extra[5], k5 = extra[6], k6 = extra[7];
+            const double u2 = u * u;
+            const double uv = u * v;
+            const double v2 = v * v;
+            const double r2 = u2 + v2;
+            const double r4 = r2 * r2;
+            const double r6 = r4 * r2;
+            const double radial = (1.0 + k1 * r2 + k2 * r4 + k3 * r6) / (1.0 + k4 * r2 + k5 * r4 + k6 * r6);
+            *du = u * radial + 2.0 * p1 * uv + p2 * (r2 + 2.0 * u2) - u;
+            *dv = v * radial + 2.0 * p2 * uv + p1 * (r2 + 2.0 * v2) - v;
+            return;
+        }
+        case 5: case 8: case 9: {  // OpenCVFisheye / SimpleRadialFisheye / RadialFisheye
+            const double r = std::sqrt(u * u + v * v);
+            if (r > kEps) {
+                const double theta = std::atan(r);
+                const double theta2 = theta * theta;
+                double thetad;
+                if (model == 8) {
+                    thetad = theta * (1.0 + extra[0] * theta2);
+                } else if (model == 9) {
+                    const double theta4 = theta2 * theta2;
+                    thetad = theta * (1.0 + extra[0] * theta2 + extra[1] * theta4);
+                } else {
+                    const double theta4 = theta2 * theta2;
+                    const double theta6 = theta4 * theta2;
+                    const double theta8 = theta4 * theta4;
+                    thetad = theta * (1.0 + extra[0] * theta2 + extra[1] * theta4 + extra[2] * theta6 +
+                                      extra[3] * theta8);
+                }
+                *du = u * thetad / r - u;
+                *dv = v * thetad / r - v;
+            } else {
+                *du = 0.0;
+                *dv = 0.0;
+            }
+            return;
+        }
+        case 10: {  // ThinPrismFisheyeCameraModel
+            const double k1 = extra[0], k2 = extra[1], p1 = extra[2], p2 = extra[3];
+            const double k3 = extra[4], k4 = extra[5], sx1 = extra[6], sy1 = extra[7];
+            const double u2 = u * u;
+            const double uv = u * v;
+            const double v2 = v * v;
+            const double r2 = u2 + v2;
+            const double r4 = r2 * r2;
+            const double r6 = r4 * r2;
+            const double r8 = r6 * r2;
+            const double radial = k1 * r2 + k2 * r4 + k3 * r6 + k4 * r8;
+            *du = u * radial + 2.0 * p1 * uv + p2 * (r2 + 2.0 * u2) + sx1 * r2;
+            *dv = v * radial + 2.0 * p2 * uv + p1 * (r2 + 2.0 * v2) + sy1 * r2;
+            return;
+        }
+    }
+    *du = 0.0;
+    *dv = 0.0;
+}
+
+// BaseCameraModel<CameraModel>::IterativeUndistortion: Newton iteration with a numerical
+// (central difference) Jacobian; Eigen's fixed-size 2 x 2 inverse is adjugate / determinant.
+void iterative_undistortion(int model, const double* extra, double* u, double* v) {
+    const size_t kNumIterations = 100;
+    const double kMaxStepNorm = 1e-10;
+    const double kRelStepSize = 1e-6;
+    const double x0[2] = {*u, *v};
+    double x[2] = {*u, *v};
+    for (size_t i = 0; i < kNumIterations; ++i) {
+        const double step0 = std::max(std::numeric_limits<double>::epsilon(), std::abs(kRelStepSize * x[0]));
+        const double step1 = std::max(std::numeric_limits<double>::epsilon(), std::abs(kRelStepSize * x[1]));
+        double dx[2], dx_0b[2], dx_0f[2], dx_1b[2], dx_1f[2];
+        model_distortion(model, extra, x[0], x[1], &dx[0], &dx[1]);
+        model_distortion(model, extra, x[0] - step0, x[1], &dx_0b[0], &dx_0b[1]);
+        model_distortion(model, extra, x[0] + step0, x[1], &dx_0f[0], &dx_0f[1]);
+        model_distortion(model, extra, x[0], x[1] - step1, &dx_1b[0], &dx_1b[1]);
+        model_distortion(model, extra, x[0], x[1] + step1, &dx_1f[0], &dx_1f[1]);
+        double J[2][2];
+        J[0][0] = 1 + (dx_0f[0] - dx_0b[0]) / (2 * step0);
+        J[0][1] = (dx_1f[0] - dx_1b[0]) / (2 * step1);
+        J[1][0] = (dx_0f[1] - dx_0b[1]) / (2 * step0);
+        J[1][1] = 1 + (dx_1f[1] - dx_1b[1]) / (2 * step1);
+        const double invdet = 1.0 / (J[0][0] * J[1][1] - J[1][0] * J[0][1]);
+        const double Ji[2][2] = {{J[1][1] * invdet, -J[0][1] * invdet}, {-J[1][0] * invdet, J[0][0] * invdet}};
+        const double rhs[2] = {x[0] + dx[0] - x0[0], x[1] + dx[1] - x0[1]};
+        const double step_x[2] = {Ji[0][0] * rhs[0] + Ji[0][1] * rhs[1], Ji[1][0] * rhs[0] + Ji[1][1] * rhs[1]};
+        x[0] -= step_x[0];
+        x[1] -= step_x[1];
+        if (step_x[0] * step_x[0] + step_x[1] * step_x[1] < kMaxStepNorm) break;
+    }
+    *u = x[0];
+    *v = x[1];
+}
+
 Pt cam_from_img(const Camera& c, const Pt& p) {
-    if (c.model_id == 0) return Pt{(p.x - c.params[1]) / c.params[0], (p.y - c.params[2]) / c.params[0]};
-    return Pt{(p.x - c.params[2]) / c.params[0], (p.y - c.params[3]) / c.params[1]};
+    const ModelInfo& mi = kModels[c.model_id];
+    const double f1 = c.params[0], f2 = c.params[mi.num_focal - 1];
+    const double c1 = c.params[mi.num_focal], c2 = c.params[mi.num_focal + 1];
+    const double* extra = c.params + mi.num_focal + 2;
+    double u = (p.x - c1) / f1;
+    double v = (p.y - c2) / f2;
+    if (c.model_id <= 1) return Pt{u, v};
+    if (c.model_id == 7) {  // FOVCameraModel::Undistortion, closed form
+        const double omega = extra[0];
+        const double kEpsilon = 1e-4;
+        const double radius2 = u * u + v * v;
+        const double omega2 = omega * omega;
+        double factor;
+        if (omega2 < kEpsilon) {
+            factor = (omega2 * radius2) / 3.0 - omega2 / 12.0 + 1.0;
+        } else if (radius2 < kEpsilon) {
+            factor = (omega * (omega * omega * radius2 + 3.0)) / (6.0 * std::tan(omega / 2.0));
+        } else {
+            const double radius = std::sqrt(radius2);
+            const double numerator = std::tan(radius * omega);
+            factor = numerator / (radius * 2.0 * std::tan(omega / 2.0));
+        }
+        return Pt{u * factor, v * factor};
+    }
+    iterative_undistortion(c.model_id, extra, &u, &v);
+    if (c.model_id == 10) {  // thin-prism fisheye: back from the equidistant angle to the plane
+        const double theta = std::sqrt(u * u + v * v);
+        const double theta_cos_theta = theta * std::cos(theta);
+        if (theta_cos_theta > std::numeric_limits<double>::epsilon()) {
+            const double scale = std::sin(theta) / theta_cos_theta;
+            u *= scale;
+            v *= scale;
+        }
+    }
+    return Pt{u, v};
 }
 double cam_from_img_threshold(const Camera& c, double threshold) {
-    const double mean_f = c.model_id == 0 ? c.params[0] : (c.params[0] + c.params[1]) / 2.0;
-    return threshold / mean_f;
+    const ModelInfo& mi = kModels[c.model_id];
+    double mean_focal_length = 0;
+    for (int i = 0; i < mi.num_focal; ++i) mean_focal_length += c.params[i];
+    mean_focal_length /= mi.num_focal;
+    return threshold / mean_focal_length;
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -1128,8 +1317,16 @@ std::vector<Mat3> estimate_e5(const std::vector<Pt>& p1, const std::vector<Pt>& 
         const double dd = a0 * b1 - a1 * b0;
         const double x = (b0 * c1 - b1 * c0) / dd;
         const double y = (a1 * c0 - a0 * c1) / dd;
+        // upstream takes (x, y, 1) from the unit null vector X of B(z) as X(0)/X(2), X(1)/X(2) and skips
+        // the root when |X(2)| < 1e-10, i.e. when |(x, y, 1)| > 1e10 (also drops a singular 2 x 2 system)
+        if (!(x * x + y * y + 1.0 < 1e20)) continue;
         Mat3 E;
         for (int k = 0; k < 9; ++k) E.m[k] = x * nsp[k] + y * nsp[9 + k] + z * nsp[18 + k] + nsp[27 + k];
+        // essential_vec /= essential_vec.norm()
+        double n2 = 0.0;
+        for (int k = 0; k < 9; ++k) n2 += E.m[k] * E.m[k];
+        const double nrm = std::sqrt(n2);
+        for (int k = 0; k < 9; ++k) E.m[k] = E.m[k] / nrm;
         models.push_back(E);
     }
     return models;
@@ -1175,10 +1372,13 @@ Mat3 mat3_inv(const Mat3& a) {
     r.m[6] = (m[3] * m[7] - m[4] * m[6]) / d; r.m[7] = (m[1] * m[6] - m[0] * m[7]) / d; r.m[8] = (m[0] * m[4] - m[1] * m[3]) / d;
     return r;
 }
-Mat3 calibration_matrix(const Camera& c) {
+Mat3 calibration_matrix(const Camera& c) {  // Camera::CalibrationMatrix
     Mat3 k{};
-    if (c.model_id == 0) { k.m[0] = c.params[0]; k.m[4] = c.params[0]; k.m[2] = c.params[1]; k.m[5] = c.params[2]; }
-    else { k.m[0] = c.params[0]; k.m[4] = c.params[1]; k.m[2] = c.params[2]; k.m[5] = c.params[3]; }
+    const int nf = kModels[c.model_id].num_focal;
+    k.m[0] = c.params[0];
+    k.m[4] = c.params[nf - 1];
+    k.m[2] = c.params[nf];
+    k.m[5] = c.params[nf + 1];
     k.m[8] = 1.0;
     return k;
 }
@@ -1717,6 +1917,24 @@ int oracle_ransac_estimate(int kind, const double* p1, const double* p2, size_t 
 }
 
 // unit-test hooks ------------------------------------------------------------------------------
+// Camera::CamFromImg of n image points; returns -1 for an unknown model
+int oracle_cam_from_img(const oracle_camera* cam, const double* xy, size_t n, double* uv) {
+    const Camera c = to_cam(cam);
+    if (!camera_supported(c)) return -1;
+    for (size_t i = 0; i < n; ++i) {
+        const Pt q = cam_from_img(c, Pt{xy[2 * i], xy[2 * i + 1]});
+        uv[2 * i] = q.x;
+        uv[2 * i + 1] = q.y;
+    }
+    return 0;
+}
+double oracle_cam_from_img_threshold(const oracle_camera* cam, double threshold) {
+    return cam_from_img_threshold(to_cam(cam), threshold);
+}
+void oracle_calibration_matrix(const oracle_camera* cam, double* K9) {
+    const Mat3 k = calibration_matrix(to_cam(cam));
+    std::memcpy(K9, k.m, sizeof k.m);
+}
 void oracle_sampson_error(const double* p1, const double* p2, size_t n, const double* E9, double* out) {
     Mat3 E;
     std::memcpy(E.m, E9, sizeof E.m);

@@ -28,6 +28,7 @@ EXPORTED_SYMBOLS = [
     "amc_tvg_opts_default", "amc_upload_keypoints", "amc_upload_camera", "amc_verify_pairs",
     "amc_verify_result_free", "amc_upload_points_f64", "amc_ransac_pairs", "amc_ransac_result_free",
     "amc_squared_sampson_error", "amc_match_guided_pairs", "amc_ctx_grow_slots", "amc_pose_pairs",
+    "amc_cam_from_img",
 ]
 RANSAC_F, RANSAC_H, RANSAC_E = 0, 1, 2
 RANSAC_KINDS = {"F": RANSAC_F, "H": RANSAC_H, "E": RANSAC_E}
@@ -104,7 +105,9 @@ POSE_DTYPE = np.dtype([("ok", np.int32), ("config", np.int32), ("qvec", np.float
 TVG_DTYPE = np.dtype([("config", np.int32), ("num_inliers", np.int32), ("E", np.float64, (3, 3)),
                       ("F", np.float64, (3, 3)), ("H", np.float64, (3, 3)),
                       ("num_trials", np.int64, (4,)), ("model_inliers", np.int64, (3,))])
-CAMERA_MODELS = {"SIMPLE_PINHOLE": 0, "PINHOLE": 1}
+CAMERA_MODELS = {"SIMPLE_PINHOLE": 0, "PINHOLE": 1, "SIMPLE_RADIAL": 2, "RADIAL": 3, "OPENCV": 4, "OPENCV_FISHEYE": 5,
+                 "FULL_OPENCV": 6, "FOV": 7, "SIMPLE_RADIAL_FISHEYE": 8, "RADIAL_FISHEYE": 9,
+                 "THIN_PRISM_FISHEYE": 10}
 CONFIG_NAMES = ["UNDEFINED", "DEGENERATE", "CALIBRATED", "UNCALIBRATED", "PLANAR", "PANORAMIC",
                 "PLANAR_OR_PANORAMIC", "WATERMARK", "MULTIPLE"]
 
@@ -157,6 +160,7 @@ def load() -> C.CDLL:
                                      C.c_void_p, C.POINTER(RansacOpts), C.c_uint32, C.POINTER(RansacResult)]
     lib.amc_ransac_result_free.argtypes = [C.POINTER(RansacResult)]
     lib.amc_ransac_result_free.restype = None
+    lib.amc_cam_from_img.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p]
     lib.amc_squared_sampson_error.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
                                               C.c_void_p]
     lib.amc_pose_pairs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
@@ -356,6 +360,16 @@ class Context:
         _check(self._lib.amc_squared_sampson_error(self._h, p1.ctypes.data_as(C.c_void_p),
                                                    p2.ctypes.data_as(C.c_void_p), p1.shape[0],
                                                    e.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def cam_from_img(self, model: str | int, params, points) -> np.ndarray:
+        """Camera::CamFromImg of an N x 2 array of image points."""
+        p = np.ascontiguousarray(params, dtype=np.float64)
+        xy = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 2)
+        mid = CAMERA_MODELS[model] if isinstance(model, str) else int(model)
+        out = np.empty_like(xy)
+        _check(self._lib.amc_cam_from_img(self._h, mid, p.ctypes.data_as(C.c_void_p), p.size,
+                                          xy.ctypes.data_as(C.c_void_p), xy.shape[0], out.ctypes.data_as(C.c_void_p)))
         return out
 
     def upload_camera(self, slot: int, model: str | int, width: int, height: int, params,

@@ -10,9 +10,11 @@
 #include <map>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "amc_internal.h"
+#include "camera_math.h"
 #include "pose_math.h"  // median_angle_host
 
 using namespace amc;
@@ -48,6 +50,8 @@ struct Slot {
     bool valid = false;
     float* kp = nullptr;   // rows x 2 float32 keypoints (x, y)
     double* kp64 = nullptr;  // or rows x 2 float64 points (amc_upload_points_f64)
+    double* kpn = nullptr;   // rows x 2 float64 CamFromImg of the points (cameras with distortion), see ensure_normalized
+    bool kpn_valid = false;  // kpn matches the current points and camera
     uint32_t kp_rows = 0;
     bool has_kp = false, has_cam = false;
     CameraDev cam{};
@@ -140,6 +144,7 @@ struct amc_ctx {
     DevBuf<TvgImage> d_timgs;
     DevBuf<TvgPair> d_tpairs;
     DevBuf<uint32_t> d_tmatches, d_ttabs, d_mtinit;
+    DevBuf<double> d_wmcut;
     DevBuf<double> d_tws;
     DevBuf<uint8_t> d_tmaskws, d_toutmask;
     DevBuf<TvgOut> d_tout;
@@ -225,6 +230,7 @@ static void free_slot(Slot& s) {
     if (s.base) (void)hipFree(s.base);
     if (s.kp) (void)hipFree(s.kp);
     if (s.kp64) (void)hipFree(s.kp64);
+    if (s.kpn) (void)hipFree(s.kpn);
     s = Slot();
 }
 
@@ -247,7 +253,7 @@ void amc_ctx_destroy(amc_ctx* c) {
     }
     c->h_scalars.release();
     c->d_timgs.release(); c->d_tpairs.release(); c->d_tmatches.release(); c->d_ttabs.release();
-    c->d_mtinit.release(); c->d_tws.release(); c->d_tmaskws.release(); c->d_toutmask.release();
+    c->d_mtinit.release(); c->d_wmcut.release(); c->d_tws.release(); c->d_tmaskws.release(); c->d_toutmask.release();
     c->d_tout.release();
     c->d_ppairs.release(); c->d_pmatches.release(); c->d_pcos.release(); c->d_pout.release();
     for (auto& ev : c->ev)
@@ -790,12 +796,15 @@ int amc_upload_keypoints(amc_ctx* c, uint32_t slot, const float* xy, uint32_t ro
         return fail(AMC_E_INVALID, "amc_upload_keypoints: need x,y columns (stride %u) and data", stride_floats);
     HIPCHK(hipSetDevice(c->device));
     Slot& s = c->slots[slot];
-    if (s.kp || s.kp64) {
+    if (s.kp || s.kp64 || s.kpn) {
         HIPCHK(hipStreamSynchronize(c->stream));
         if (s.kp) (void)hipFree(s.kp);
         if (s.kp64) (void)hipFree(s.kp64);
+        if (s.kpn) (void)hipFree(s.kpn);
         s.kp = nullptr;
         s.kp64 = nullptr;
+        s.kpn = nullptr;
+        s.kpn_valid = false;
         s.dev.kp = nullptr;
         s.dev.kp_rows = 0;
         c->table_dirty = true;
@@ -827,12 +836,15 @@ int amc_upload_points_f64(amc_ctx* c, uint32_t slot, const double* xy, uint32_t 
     if (rows > 0 && !xy) return fail(AMC_E_INVALID, "amc_upload_points_f64: NULL data");
     HIPCHK(hipSetDevice(c->device));
     Slot& s = c->slots[slot];
-    if (s.kp || s.kp64) {
+    if (s.kp || s.kp64 || s.kpn) {
         HIPCHK(hipStreamSynchronize(c->stream));
         if (s.kp) (void)hipFree(s.kp);
         if (s.kp64) (void)hipFree(s.kp64);
+        if (s.kpn) (void)hipFree(s.kpn);
         s.kp = nullptr;
         s.kp64 = nullptr;
+        s.kpn = nullptr;
+        s.kpn_valid = false;
         s.dev.kp = nullptr;
         s.dev.kp_rows = 0;
         c->table_dirty = true;
@@ -856,15 +868,122 @@ int amc_upload_camera(amc_ctx* c, uint32_t slot, int32_t model_id, uint64_t widt
         return fail(AMC_E_INVALID, "amc_upload_camera: slot %u >= reserved %zu", slot, c->slots.size());
     if (num_params < 0 || (num_params > 0 && !params))
         return fail(AMC_E_INVALID, "amc_upload_camera: bad params");
+    // Camera::VerifyParams: the parameter vector must have the model's length
+    if (cam::num_params(model_id) < 0)
+        return fail(AMC_E_INVALID, "amc_upload_camera: unknown camera model id %d", model_id);
+    if (num_params != cam::num_params(model_id))
+        return fail(AMC_E_INVALID, "amc_upload_camera: camera model %d takes %d parameters, got %d", model_id,
+                    cam::num_params(model_id), num_params);
     Slot& s = c->slots[slot];
     s.cam = CameraDev{};
     s.cam.model_id = model_id;
     s.cam.has_prior = has_prior ? 1 : 0;
     s.cam.width = width;
     s.cam.height = height;
-    for (int i = 0; i < num_params && i < 4; ++i) s.cam.params[i] = params[i];
+    for (int i = 0; i < num_params; ++i) s.cam.params[i] = params[i];
     s.has_cam = true;
+    s.kpn_valid = false;  // the lifted keypoints belong to the previous camera
     return AMC_OK;
+}
+
+// Camera::CamFromImg of all keypoints of a slot, once per (points, camera): COLMAP lifts every matched point of
+// every pair (EstimateCalibratedTwoViewGeometry, EstimateTwoViewGeometryPose); the lift depends on the keypoint
+// only, so it is taken here per image and kept in HBM.  Pinhole cameras need nothing (two divisions, done where
+// the points are gathered).  Polynomial distortion models run on the device (camera.hip); the fisheye family and
+// FOV call atan / tan / sin / cos and are lifted with the host libm (camera_math.h).
+static int ensure_normalized(amc_ctx* c, uint32_t slot) {
+    Slot& s = c->slots[slot];
+    if (!s.has_cam || !s.has_kp || cam::is_pinhole(s.cam.model_id) || s.kpn_valid) return AMC_OK;
+    const uint32_t rows = s.kp_rows;
+    if (rows == 0) {
+        s.kpn_valid = true;
+        return AMC_OK;
+    }
+    if (!s.kpn) {
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&s.kpn), (size_t)rows * 2 * sizeof(double));
+        if (e != hipSuccess) return fail(AMC_E_NOMEM, "CamFromImg buffer: hipMalloc: %s", hipGetErrorString(e));
+    }
+    if (!cam::needs_libm(s.cam.model_id)) {
+        HIPCHK(launch_undistort(s.kp, s.kp64, rows, s.cam, s.kpn, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+    } else {
+        std::vector<double> xy((size_t)rows * 2), uv((size_t)rows * 2);
+        if (s.kp64) {
+            HIPCHK(hipMemcpy(xy.data(), s.kp64, xy.size() * sizeof(double), hipMemcpyDeviceToHost));
+        } else {
+            std::vector<float> f((size_t)rows * 2);
+            HIPCHK(hipMemcpy(f.data(), s.kp, f.size() * sizeof(float), hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < f.size(); ++i) xy[i] = (double)f[i];
+        }
+        const CameraDev camd = s.cam;
+        auto work = [&](uint32_t lo, uint32_t hi) {
+            for (uint32_t i = lo; i < hi; ++i)
+                cam::cam_from_img(camd.model_id, camd.params, xy[2 * (size_t)i], xy[2 * (size_t)i + 1], uv[2 * (size_t)i],
+                                  uv[2 * (size_t)i + 1]);
+        };
+        const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+        const unsigned nth = rows >= 2048 ? hw : 1;
+        if (nth == 1) {
+            work(0, rows);
+        } else {
+            std::vector<std::thread> th;
+            const uint32_t per = (rows + nth - 1) / nth;
+            for (unsigned t = 0; t < nth; ++t) {
+                const uint32_t lo = std::min(rows, t * per), hi = std::min(rows, lo + per);
+                if (lo < hi) th.emplace_back(work, lo, hi);
+            }
+            for (auto& t : th) t.join();
+        }
+        HIPCHK(hipMemcpy(s.kpn, uv.data(), uv.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+    s.kpn_valid = true;
+    return AMC_OK;
+}
+
+int amc_cam_from_img(amc_ctx* c, int32_t model_id, const double* params, int32_t num_params, const double* xy,
+                     size_t n, double* uv) {
+    if (!c) return fail(AMC_E_INVALID, "amc_cam_from_img: ctx is NULL");
+    if (cam::num_params(model_id) < 0) return fail(AMC_E_INVALID, "amc_cam_from_img: unknown camera model id %d", model_id);
+    if (num_params != cam::num_params(model_id) || !params)
+        return fail(AMC_E_INVALID, "amc_cam_from_img: camera model %d takes %d parameters, got %d", model_id,
+                    cam::num_params(model_id), num_params);
+    if (n == 0) return AMC_OK;
+    if (!xy || !uv) return fail(AMC_E_INVALID, "amc_cam_from_img: NULL points");
+    if (n > 0x7FFFFFFFull) return fail(AMC_E_INVALID, "amc_cam_from_img: too many points");
+    if (cam::needs_libm(model_id)) {
+        for (size_t i = 0; i < n; ++i) cam::cam_from_img(model_id, params, xy[2 * i], xy[2 * i + 1], uv[2 * i], uv[2 * i + 1]);
+        return AMC_OK;
+    }
+    HIPCHK(hipSetDevice(c->device));
+    CameraDev cd{};
+    cd.model_id = model_id;
+    for (int i = 0; i < num_params; ++i) cd.params[i] = params[i];
+    DevBuf<double> buf;
+    HIPCHK(buf.ensure(4 * n));
+    hipStream_t st = c->stream;
+    int rc = AMC_OK;
+    auto chk = [&](hipError_t e, const char* what) {
+        if (e != hipSuccess && rc == AMC_OK) rc = fail(AMC_E_HIP, "amc_cam_from_img: %s: %s", what, hipGetErrorString(e));
+    };
+    chk(hipMemcpyAsync(buf.p, xy, 2 * n * sizeof(double), hipMemcpyHostToDevice, st), "copy in");
+    if (rc == AMC_OK) chk(launch_undistort(nullptr, buf.p, (uint32_t)n, cd, buf.p + 2 * n, st), "launch");
+    if (rc == AMC_OK) chk(hipMemcpyAsync(uv, buf.p + 2 * n, 2 * n * sizeof(double), hipMemcpyDeviceToHost, st), "copy out");
+    chk(hipStreamSynchronize(st), "sync");
+    buf.release();
+    return rc;
+}
+
+static void fill_tvg_images(const amc_ctx* c, std::vector<TvgImage>& timgs) {
+    timgs.resize(c->slots.size());
+    for (size_t i = 0; i < timgs.size(); ++i) {
+        const Slot& s = c->slots[i];
+        timgs[i].kp = s.kp;
+        timgs[i].kp64 = s.kp64;
+        timgs[i].kpn = (s.kpn_valid && !cam::is_pinhole(s.cam.model_id)) ? s.kpn : nullptr;
+        timgs[i].rows = s.kp_rows;
+        timgs[i].pad = 0;
+        timgs[i].cam = s.cam;
+    }
 }
 
 namespace {
@@ -920,6 +1039,7 @@ static int pose_impl(amc_ctx* c, const char* who, const uint32_t* slot1, const u
     if (total > 0 && !inlier_matches && !resident) return fail(AMC_E_INVALID, "%s: NULL matches", who);
     if (npairs > 0xFFFFFFFFull) return fail(AMC_E_INVALID, "%s: too many pairs", who);
     std::vector<PosePair> pp(npairs);
+    std::vector<uint8_t> need_lift(c->slots.size(), 0);
     for (size_t p = 0; p < npairs; ++p) {
         if (slot1[p] >= c->slots.size() || slot2[p] >= c->slots.size())
             return fail(AMC_E_INVALID, "%s: pair %zu references slot out of range", who, p);
@@ -934,11 +1054,7 @@ static int pose_impl(amc_ctx* c, const char* who, const uint32_t* slot1, const u
         const int32_t cfg = geoms[p].config;
         const bool has_geometry = cfg == AMC_TVG_CALIBRATED || cfg == AMC_TVG_UNCALIBRATED || cfg == AMC_TVG_PLANAR ||
                                   cfg == AMC_TVG_PANORAMIC || cfg == AMC_TVG_PLANAR_OR_PANORAMIC;
-        if (has_geometry &&
-            ((a.cam.model_id != AMC_CAM_SIMPLE_PINHOLE && a.cam.model_id != AMC_CAM_PINHOLE) ||
-             (b.cam.model_id != AMC_CAM_SIMPLE_PINHOLE && b.cam.model_id != AMC_CAM_PINHOLE)))
-            return fail(AMC_E_INVALID, "%s: pair %zu: the relative pose supports SIMPLE_PINHOLE / PINHOLE "
-                        "cameras only", who, p);
+        if (has_geometry) need_lift[slot1[p]] = need_lift[slot2[p]] = 1;
         if (!resident)
             for (uint64_t k = match_offsets[p]; k < match_offsets[p + 1]; ++k)
                 if (inlier_matches[2 * k] >= a.kp_rows || inlier_matches[2 * k + 1] >= b.kp_rows)
@@ -955,14 +1071,13 @@ static int pose_impl(amc_ctx* c, const char* who, const uint32_t* slot1, const u
     }
     HIPCHK(hipSetDevice(c->device));
     hipStream_t st = c->stream;
-    std::vector<TvgImage> timgs(c->slots.size());
-    for (size_t i = 0; i < timgs.size(); ++i) {
-        timgs[i].kp = c->slots[i].kp;
-        timgs[i].kp64 = c->slots[i].kp64;
-        timgs[i].rows = c->slots[i].kp_rows;
-        timgs[i].pad = 0;
-        timgs[i].cam = c->slots[i].cam;
-    }
+    for (size_t i = 0; i < need_lift.size(); ++i)
+        if (need_lift[i]) {
+            const int rc = ensure_normalized(c, (uint32_t)i);
+            if (rc != AMC_OK) return rc;
+        }
+    std::vector<TvgImage> timgs;
+    fill_tvg_images(c, timgs);
     HIPCHK(c->d_timgs.ensure(timgs.size()));
     HIPCHK(c->d_ppairs.ensure(npairs));
     if (!resident) HIPCHK(c->d_pmatches.ensure(std::max<size_t>(2 * total, 2)));
@@ -1027,6 +1142,7 @@ static int verify_impl(amc_ctx* c, int mode, const uint32_t* slot1, const uint32
     const uint64_t total = npairs ? match_offsets[npairs] : 0;
     if (total > 0 && !matches) return fail(AMC_E_INVALID, "amc_verify_pairs: NULL matches");
     uint32_t maxM = 0;
+    std::vector<uint8_t> need_lift(c->slots.size(), 0);
     for (size_t p = 0; p < npairs; ++p) {
         if (slot1[p] >= c->slots.size() || slot2[p] >= c->slots.size())
             return fail(AMC_E_INVALID, "amc_verify_pairs: pair %zu references slot out of range", p);
@@ -1051,11 +1167,7 @@ static int verify_impl(amc_ctx* c, int mode, const uint32_t* slot1, const uint32
                                 p, (unsigned long long)k);
         }
         const bool uses_E = mode == 0 ? (!o.force_H_use && a.cam.has_prior && b.cam.has_prior) : mode == 3;
-        if (uses_E &&
-            ((a.cam.model_id != AMC_CAM_SIMPLE_PINHOLE && a.cam.model_id != AMC_CAM_PINHOLE) ||
-             (b.cam.model_id != AMC_CAM_SIMPLE_PINHOLE && b.cam.model_id != AMC_CAM_PINHOLE)))
-            return fail(AMC_E_INVALID, "amc_verify_pairs: pair %zu: calibrated path supports SIMPLE_PINHOLE / "
-                        "PINHOLE cameras only", p);
+        if (uses_E) need_lift[slot1[p]] = need_lift[slot2[p]] = 1;
     }
     TvgParams P{};
     P.min_num_inliers = o.min_num_inliers;
@@ -1077,10 +1189,33 @@ static int verify_impl(amc_ctx* c, int mode, const uint32_t* slot1, const uint32
         P.mode = mode;
         P.bad_index_count = c->d_scalars + 2;
     }
-    if (mode == 0 && o.detect_watermark && P.max_trials[3] > P.min_num_trials)
-        return fail(AMC_E_INVALID, "amc_verify_pairs: unsupported option combination: the watermark RANSAC "
-                    "may run %d trials > min_num_trials %d (its dynamic trial count is not tabulated)",
-                    P.max_trials[3], P.min_num_trials);
+    // inlier-ratio cut-offs of the watermark RANSAC's dynamic trial count (TvgParams::wm_cut)
+    std::vector<double> wm_cut;
+    if (mode == 0 && o.detect_watermark) {
+        auto dyn_of_ratio = [&](double r) -> size_t {  // ComputeNumTrials with inlier_ratio = r, kMinNumSamples = 1
+            const double nom = 1 - o.ransac.confidence;
+            if (nom <= 0) return std::numeric_limits<size_t>::max();
+            const double denom = 1 - std::pow(r, 1);
+            if (denom <= 0) return 1;
+            if (denom == 1.0) return std::numeric_limits<size_t>::max();
+            return static_cast<size_t>(std::ceil(std::log(nom) / std::log(denom) * o.ransac.dyn_num_trials_multiplier));
+        };
+        const int nT = std::max(P.max_trials[3], 0);
+        wm_cut.assign((size_t)nT + 1, 2.0);
+        for (int T = 0; T <= nT; ++T) {
+            if (dyn_of_ratio(1.0) > (size_t)T) continue;  // not even r = 1 gets there: stays 2.0
+            // doubles in [0, 1] order like their bit patterns: bisect the smallest r with dyn(r) <= T
+            uint64_t lo = 0, hi = 0x3FF0000000000000ull;  // dyn(lo) > T (or lo is the answer at 0), dyn(hi) <= T
+            if (dyn_of_ratio(0.0) <= (size_t)T) { wm_cut[T] = 0.0; continue; }
+            while (hi - lo > 1) {
+                const uint64_t mid = lo + (hi - lo) / 2;
+                double r;
+                std::memcpy(&r, &mid, sizeof r);
+                if (dyn_of_ratio(r) <= (size_t)T) hi = mid; else lo = mid;
+            }
+            std::memcpy(&wm_cut[T], &hi, sizeof(double));
+        }
+    }
 
     HIPCHK(hipSetDevice(c->device));
     hipStream_t st = c->stream;
@@ -1094,15 +1229,18 @@ static int verify_impl(amc_ctx* c, int mode, const uint32_t* slot1, const uint32
     out->inlier_mask = priv->mask.data();
     if (npairs == 0) return AMC_OK;
 
-    // image table
-    std::vector<TvgImage> timgs(c->slots.size());
-    for (size_t i = 0; i < timgs.size(); ++i) {
-        timgs[i].kp = c->slots[i].kp;
-        timgs[i].kp64 = c->slots[i].kp64;
-        timgs[i].rows = c->slots[i].kp_rows;
-        timgs[i].pad = 0;
-        timgs[i].cam = c->slots[i].cam;
-    }
+    // image table (cameras with distortion parameters: CamFromImg of their keypoints first)
+    for (size_t i = 0; i < need_lift.size(); ++i)
+        if (need_lift[i]) {
+            const int rc = ensure_normalized(c, (uint32_t)i);
+            if (rc != AMC_OK) {
+                delete priv;
+                std::memset(out, 0, sizeof *out);
+                return rc;
+            }
+        }
+    std::vector<TvgImage> timgs;
+    fill_tvg_images(c, timgs);
     // dyn_max_num_trials tables, one set per distinct match count
     std::vector<uint32_t> tabs;
     std::vector<int64_t> tab_of_M((size_t)maxM + 1, -1);
@@ -1186,6 +1324,12 @@ static int verify_impl(amc_ctx* c, int mode, const uint32_t* slot1, const uint32
     if (!tabs.empty())
         HIPCHK(hipMemcpyAsync(c->d_ttabs.p, tabs.data(), tabs.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(c->d_mtinit.p, mt0, sizeof mt0, hipMemcpyHostToDevice, st));
+    P.wm_cut = nullptr;
+    if (!wm_cut.empty()) {
+        HIPCHK(c->d_wmcut.ensure(wm_cut.size()));
+        HIPCHK(hipMemcpyAsync(c->d_wmcut.p, wm_cut.data(), wm_cut.size() * sizeof(double), hipMemcpyHostToDevice, st));
+        P.wm_cut = c->d_wmcut.p;
+    }
     HIPCHK(hipMemsetAsync(c->d_scalars + 2, 0, sizeof(uint32_t), st));
     HIPCHK(hipStreamSynchronize(st));
 

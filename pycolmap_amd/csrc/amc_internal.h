@@ -129,18 +129,24 @@ void launch_finalize(const ImageDev* imgs, const PairDev* pairs, uint32_t npairs
 
 // ----- two-view verification (tvg.hip) ------------------------------------------------------
 struct CameraDev {
-    int32_t model_id;
+    int32_t model_id;    // COLMAP camera model id 0..10 (camera_math.h)
     int32_t has_prior;
     uint64_t width, height;
-    double params[4];
+    double params[12];
 };
 struct TvgImage {
     const float* kp;     // rows x 2 float32 (x, y), or
     const double* kp64;  // rows x 2 float64 when the points were uploaded in double precision
+    const double* kpn;   // rows x 2 float64: Camera::CamFromImg of every keypoint, for cameras with distortion
+                         // parameters (lifted once per image, camera.hip / amc_api.hip ensure_normalized);
+                         // nullptr for SIMPLE_PINHOLE / PINHOLE, whose lift is two divisions done in place
     uint32_t rows;
     uint32_t pad;
     CameraDev cam;
 };
+// Camera::CamFromImg of every keypoint of one image (polynomial distortion models only; camera.hip)
+hipError_t launch_undistort(const float* kp, const double* kp64, uint32_t rows, const CameraDev& cam, double* kpn,
+                            hipStream_t s);
 struct TvgPair {
     uint32_t slot1, slot2;
     uint64_t match_off;   // into the batch's match array (in matches, not uint32s)
@@ -189,6 +195,13 @@ struct TvgParams {
     int32_t force_slow_sampler;  // test hook (AMC_TVG_SLOW_SAMPLER=1): draw-by-draw sampler path only
     int32_t mode;                // 0: EstimateTwoViewGeometry; 1 / 2 / 3: a single F / H / E LO-RANSAC
     uint32_t* bad_index_count;   // += 1 per pair whose matches index past an image's keypoints (the pair is skipped)
+    // dyn_max_num_trials of the watermark (translation, 1-point) RANSAC.  Its sample count is the pair's inlier
+    // count, known only on the device, so a table by match count cannot be laid out ahead; but
+    // ComputeNumTrials depends on (num_inliers, num_samples) only through r = num_inliers / num_samples and is
+    // non-increasing in r, so the host (host libm, like every other trial table) bisects, for every trial
+    // count T in [0, max_trials[3]], the smallest double r with ComputeNumTrials(r) <= T: wm_cut[T] (2.0 when
+    // there is none).  The kernel then has dyn_max = the first T with r >= wm_cut[T].
+    const double* wm_cut;
 };
 size_t tvg_ws_doubles_host(uint32_t mcap);
 size_t tvg_ws_mask_bytes_host(uint32_t mcap);

@@ -131,7 +131,9 @@ void MatchController::Setup() {
 // FeatureMatcherController::Match (colmap/controllers/feature_matching_utils.cc), batched
 void MatchController::Match(const ImagePairs& image_pairs) {
     std::vector<Job> jobs = Compute(image_pairs);
+    DatabaseTransaction tx(db_.get());
     Write(jobs);
+    tx.Commit();
 }
 
 std::vector<MatchController::Job> MatchController::Compute(const ImagePairs& image_pairs) {
@@ -152,21 +154,20 @@ std::vector<MatchController::Job> MatchController::Compute(const ImagePairs& ima
         const bool exists_matches = had_matches_.count(pid) != 0;
         const bool exists_inlier = had_tvg_.count(pid) != 0;
         if (exists_matches && exists_inlier) { ++stats.pairs_skipped; continue; }  // resume
-        // one of the two rows missing: recompute from scratch, delete what exists first
-        if (exists_inlier) db_->DeleteInlierMatches(pr.first, pr.second);
+        // One of the two rows missing: recompute from scratch.  COLMAP deletes what exists right here; the
+        // deletes are deferred to Write(), into the transaction that inserts the replacement rows, so that a
+        // call that fails on the way (a stored match indexing past the keypoints, an option the device
+        // rejects) leaves the database as it found it.
         Job j;
         j.id1 = pr.first;
         j.id2 = pr.second;
         j.have_matches = exists_matches;
-        if (exists_matches) {
-            j.matches = db_->ReadMatches(pr.first, pr.second);
-            db_->DeleteMatches(pr.first, pr.second);
-        }
+        j.had_tvg_row = exists_inlier;
+        if (exists_matches) j.matches = db_->ReadMatches(pr.first, pr.second);
         jobs.push_back(std::move(j));
     }
     stats.db_ms += NowMs() - t_db0;
     if (jobs.empty()) return jobs;
-    for (const Job& j : jobs) computed_.insert(Database::ImagePairToPairId(j.id1, j.id2));
 
     // ---- FeatureMatcherWorker: descriptor matching for the pairs without stored matches ----
     std::vector<uint32_t> s1, s2;
@@ -285,6 +286,8 @@ std::vector<MatchController::Job> MatchController::Compute(const ImagePairs& ima
         amc_verify_result_free(&vr);
     }
 
+    // only now: a failed call above must leave these pairs eligible for the next attempt
+    for (const Job& j : jobs) computed_.insert(Database::ImagePairToPairId(j.id1, j.id2));
     return jobs;
 }
 
@@ -295,6 +298,8 @@ void MatchController::Write(std::vector<Job>& jobs) {
     for (Job& j : jobs) {
         if (j.matches.size() / 2 < min_inl) j.matches.clear();
         if (j.tvg.inlier_matches.size() / 2 < min_inl) j.tvg = TwoViewGeometryRow();
+        if (j.had_tvg_row) db_->DeleteInlierMatches(j.id1, j.id2);
+        if (j.have_matches) db_->DeleteMatches(j.id1, j.id2);
         db_->WriteMatches(j.id1, j.id2, j.matches);
         db_->WriteTwoViewGeometry(j.id1, j.id2, j.tvg);
     }
@@ -410,6 +415,7 @@ static void RunGrouped(MatchController& c, const std::vector<ImagePairs>& blocks
         writer = std::async(std::launch::async, [&c, jobs] {
             DatabaseTransaction tx(&c.Db());
             c.Write(*jobs);
+            tx.Commit();
         });
     };
     for (const ImagePairs& pairs : blocks) {

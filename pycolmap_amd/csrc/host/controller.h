@@ -95,7 +95,8 @@ class MatchController {
     // thread) while the device already works on the next group.
     struct Job {
         image_t id1, id2;
-        bool have_matches;
+        bool have_matches;         // the matches row existed (its matches are verified, not recomputed)
+        bool had_tvg_row = false;  // a two_view_geometries row existed (without a matches row): replaced in Write()
         std::vector<uint32_t> matches;
         TwoViewGeometryRow tvg;
     };

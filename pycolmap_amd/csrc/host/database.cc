@@ -47,7 +47,7 @@ void TwoViewGeometryRow::Invert() {
     const std::array<double, 9> h = H;
     const double c00 = h[4] * h[8] - h[5] * h[7], c01 = h[5] * h[6] - h[3] * h[8], c02 = h[3] * h[7] - h[4] * h[6];
     const double det = h[0] * c00 + h[1] * c01 + h[2] * c02;
-    if (det != 0.0 && std::isfinite(det)) {
+    {   // Eigen's 3 x 3 inverse: cofactors / determinant; a singular H gives inf / NaN entries there too
         const double inv = 1.0 / det;
         H[0] = c00 * inv; H[1] = (h[2] * h[7] - h[1] * h[8]) * inv; H[2] = (h[1] * h[5] - h[2] * h[4]) * inv;
         H[3] = c01 * inv; H[4] = (h[0] * h[8] - h[2] * h[6]) * inv; H[5] = (h[2] * h[3] - h[0] * h[5]) * inv;
@@ -73,7 +73,8 @@ void TwoViewGeometryRow::Invert() {
 }
 
 Database::Database(const std::string& path) {
-    if (sqlite3_open_v2(path.c_str(), &db_, SQLITE_OPEN_READWRITE, nullptr) != SQLITE_OK) {
+    // Database::Open: the file and COLMAP's tables are created when missing
+    if (sqlite3_open_v2(path.c_str(), &db_, SQLITE_OPEN_READWRITE | SQLITE_OPEN_CREATE, nullptr) != SQLITE_OK) {
         const std::string msg = db_ ? sqlite3_errmsg(db_) : "out of memory";
         sqlite3_close(db_);
         db_ = nullptr;
@@ -82,6 +83,27 @@ Database::Database(const std::string& path) {
     Exec("PRAGMA synchronous=OFF");       // as COLMAP's Database::Open
     Exec("PRAGMA journal_mode=WAL");
     Exec("PRAGMA foreign_keys=ON");
+    CreateTables();
+}
+// Database::CreateTables (colmap/scene/database.cc): CREATE TABLE IF NOT EXISTS for every table of the schema
+void Database::CreateTables() const {
+    Exec("CREATE TABLE IF NOT EXISTS cameras (camera_id INTEGER PRIMARY KEY AUTOINCREMENT NOT NULL, "
+         "model INTEGER NOT NULL, width INTEGER NOT NULL, height INTEGER NOT NULL, params BLOB, "
+         "prior_focal_length INTEGER NOT NULL);");
+    Exec("CREATE TABLE IF NOT EXISTS images (image_id INTEGER PRIMARY KEY AUTOINCREMENT NOT NULL, "
+         "name TEXT NOT NULL UNIQUE, camera_id INTEGER NOT NULL, prior_qw REAL, prior_qx REAL, prior_qy REAL, "
+         "prior_qz REAL, prior_tx REAL, prior_ty REAL, prior_tz REAL, "
+         "CONSTRAINT image_id_check CHECK(image_id >= 0 and image_id < 2147483647), "
+         "FOREIGN KEY(camera_id) REFERENCES cameras(camera_id));");
+    Exec("CREATE UNIQUE INDEX IF NOT EXISTS index_name ON images(name);");
+    Exec("CREATE TABLE IF NOT EXISTS keypoints (image_id INTEGER PRIMARY KEY NOT NULL, rows INTEGER NOT NULL, "
+         "cols INTEGER NOT NULL, data BLOB, FOREIGN KEY(image_id) REFERENCES images(image_id) ON DELETE CASCADE);");
+    Exec("CREATE TABLE IF NOT EXISTS descriptors (image_id INTEGER PRIMARY KEY NOT NULL, rows INTEGER NOT NULL, "
+         "cols INTEGER NOT NULL, data BLOB, FOREIGN KEY(image_id) REFERENCES images(image_id) ON DELETE CASCADE);");
+    Exec("CREATE TABLE IF NOT EXISTS matches (pair_id INTEGER PRIMARY KEY NOT NULL, rows INTEGER NOT NULL, "
+         "cols INTEGER NOT NULL, data BLOB);");
+    Exec("CREATE TABLE IF NOT EXISTS two_view_geometries (pair_id INTEGER PRIMARY KEY NOT NULL, rows INTEGER NOT NULL, "
+         "cols INTEGER NOT NULL, data BLOB, config INTEGER NOT NULL, F BLOB, E BLOB, H BLOB, qvec BLOB, tvec BLOB);");
 }
 Database::~Database() {
     if (db_ && bulk_mode_) {
@@ -133,6 +155,14 @@ void Database::BeginTransaction() {
 void Database::EndTransaction() {
     std::lock_guard<std::recursive_mutex> lock(mu_);
     Exec("END TRANSACTION");
+}
+void Database::RollbackTransaction() noexcept {
+    try {
+        std::lock_guard<std::recursive_mutex> lock(mu_);
+        for (auto& kv : stmts_) sqlite3_reset(kv.second);  // a statement left mid-step would block the rollback
+        Exec("ROLLBACK TRANSACTION");
+    } catch (...) {
+    }
 }
 
 image_pair_t Database::ImagePairToPairId(image_t id1, image_t id2) {
@@ -268,7 +298,7 @@ void Database::WriteKeypoints(image_t image_id, const float* data, uint32_t rows
     sqlite3_bind_int64(st.s, 2, rows);
     sqlite3_bind_int64(st.s, 3, cols);
     const size_t nbytes = static_cast<size_t>(rows) * cols * sizeof(float);
-    sqlite3_bind_blob64(st.s, 4, nbytes ? reinterpret_cast<const char*>(data) : "", nbytes, SQLITE_STATIC);
+    sqlite3_bind_blob64(st.s, 4, nbytes ? reinterpret_cast<const char*>(data) : nullptr, nbytes, SQLITE_STATIC);
     st.Step();
 }
 void Database::WriteDescriptors(image_t image_id, const uint8_t* data, uint32_t rows) {
@@ -278,7 +308,7 @@ void Database::WriteDescriptors(image_t image_id, const uint8_t* data, uint32_t 
     sqlite3_bind_int64(st.s, 2, rows);
     sqlite3_bind_int64(st.s, 3, 128);
     const size_t nbytes = static_cast<size_t>(rows) * 128;
-    sqlite3_bind_blob64(st.s, 4, nbytes ? reinterpret_cast<const char*>(data) : "", nbytes, SQLITE_STATIC);
+    sqlite3_bind_blob64(st.s, 4, nbytes ? reinterpret_cast<const char*>(data) : nullptr, nbytes, SQLITE_STATIC);
     st.Step();
 }
 
@@ -373,7 +403,7 @@ void Database::WriteMatches(image_t id1, image_t id2, const std::vector<uint32_t
     sqlite3_bind_int64(st.s, 1, static_cast<sqlite3_int64>(ImagePairToPairId(id1, id2)));
     sqlite3_bind_int64(st.s, 2, static_cast<sqlite3_int64>(m->size() / 2));
     sqlite3_bind_int64(st.s, 3, 2);
-    sqlite3_bind_blob(st.s, 4, m->empty() ? "" : reinterpret_cast<const char*>(m->data()),
+    sqlite3_bind_blob(st.s, 4, m->empty() ? nullptr : reinterpret_cast<const char*>(m->data()),
                       static_cast<int>(m->size() * sizeof(uint32_t)), SQLITE_STATIC);
     st.Step();
 }
@@ -391,13 +421,13 @@ void Database::WriteTwoViewGeometry(image_t id1, image_t id2, const TwoViewGeome
     sqlite3_bind_int64(st.s, 1, static_cast<sqlite3_int64>(ImagePairToPairId(id1, id2)));
     sqlite3_bind_int64(st.s, 2, static_cast<sqlite3_int64>(t.inlier_matches.size() / 2));
     sqlite3_bind_int64(st.s, 3, 2);
-    sqlite3_bind_blob(st.s, 4, t.inlier_matches.empty() ? "" : reinterpret_cast<const char*>(t.inlier_matches.data()),
+    sqlite3_bind_blob(st.s, 4, t.inlier_matches.empty() ? nullptr : reinterpret_cast<const char*>(t.inlier_matches.data()),
                       static_cast<int>(t.inlier_matches.size() * sizeof(uint32_t)), SQLITE_STATIC);
     sqlite3_bind_int64(st.s, 5, t.config);
     // COLMAP stores the matrices only when there are inlier matches, empty blobs otherwise
     const bool has = !t.inlier_matches.empty();
     auto wr = [&](int col, const double* src, int n) {
-        sqlite3_bind_blob(st.s, col, has ? reinterpret_cast<const char*>(src) : "", has ? static_cast<int>(n * sizeof(double)) : 0,
+        sqlite3_bind_blob(st.s, col, has ? reinterpret_cast<const char*>(src) : nullptr, has ? static_cast<int>(n * sizeof(double)) : 0,
                           SQLITE_STATIC);
     };
     wr(6, t.F.data(), 9);

@@ -94,6 +94,7 @@ class Database {
 
     void BeginTransaction();
     void EndTransaction();
+    void RollbackTransaction() noexcept;
     // Bulk-write mode of the matching controllers.  COLMAP opens its databases with journal_mode=WAL
     // (kept: it is what a reader of the file finds afterwards), but under WAL every page of the
     // gigabytes of match blobs a run appends is written twice (log, then checkpoint).  While a
@@ -104,6 +105,7 @@ class Database {
     std::string SetBulkWriteMode(bool on);
 
   private:
+    void CreateTables() const;
     size_t Count(const char* table) const;
     size_t SumRows(const char* table) const;
     bool ExistsPair(const char* table, image_pair_t pair_id) const;
@@ -117,12 +119,23 @@ class Database {
     mutable std::unordered_map<std::string, sqlite3_stmt*> stmts_;
 };
 
+// BEGIN on construction; Commit() ends the transaction, and a scope left without it (an exception on the
+// way) rolls back: a group whose write failed half way leaves no partial rows, and the destructor never throws.
 class DatabaseTransaction {
   public:
     explicit DatabaseTransaction(Database* db) : db_(db) { db_->BeginTransaction(); }
-    ~DatabaseTransaction() { db_->EndTransaction(); }
+    void Commit() {
+        done_ = true;
+        db_->EndTransaction();
+    }
+    ~DatabaseTransaction() {
+        if (!done_) db_->RollbackTransaction();
+    }
+    DatabaseTransaction(const DatabaseTransaction&) = delete;
+    DatabaseTransaction& operator=(const DatabaseTransaction&) = delete;
   private:
     Database* db_;
+    bool done_ = false;
 };
 
 }  // namespace amchost

@@ -345,9 +345,6 @@ inline PyTwoViewGeometry EstimateTvg(const PyCamera& cam1, const PointsArray& p1
             throw py::value_error("matches must be an M x 2 unsigned integer array");
         matches.assign(arr.data(), arr.data() + arr.size());
     }
-    if (calibrated_entry && (!cam1.IsPinhole() || !cam2.IsPinhole()))
-        throw py::value_error("estimate_calibrated_two_view_geometry: only SIMPLE_PINHOLE / PINHOLE cameras are "
-                              "supported on the accelerated path");
     TwoViewGeometryOptions opt = options;
     if (calibrated_entry) opt.force_H_use = false;  // EstimateCalibratedTwoViewGeometry is called directly
     PyTwoViewGeometry g;
@@ -409,9 +406,6 @@ inline void BindEstimators(py::module_& m) {
         "essential_matrix_estimation",
         [](const PointsArray& p1, const PointsArray& p2, const PyCamera& c1, const PyCamera& c2,
            const RANSACOptions& o) {
-            if (!c1.IsPinhole() || !c2.IsPinhole())
-                throw py::value_error("essential_matrix_estimation: only SIMPLE_PINHOLE / PINHOLE cameras are "
-                                      "supported on the accelerated path");
             return RansacEstimate(AMC_RANSAC_E, "E", p1, p2, &c1, &c2, o);
         },
         "points2D1"_a, "points2D2"_a, "camera1"_a, "camera2"_a, "estimation_options"_a = est_options,
@@ -438,9 +432,6 @@ inline void BindEstimators(py::module_& m) {
            PyTwoViewGeometry& g) {
             // /root/reference/pycolmap/estimators/two_view_geometry.h:153-159; updates `geometry` in place
             const size_t n1 = CheckPoints(p1, "points1"), n2 = CheckPoints(p2, "points2");
-            if (!c1.IsPinhole() || !c2.IsPinhole())
-                throw py::value_error("estimate_two_view_geometry_pose: only SIMPLE_PINHOLE / PINHOLE cameras are "
-                                      "supported on the accelerated path");
             amc_pose pose{};
             {
                 py::gil_scoped_release release;

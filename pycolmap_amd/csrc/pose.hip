@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 
 #include "amc_internal.h"
+#include "camera_math.h"
 #include "pose_math.h"
 
 namespace amc {
@@ -34,28 +35,37 @@ __device__ __forceinline__ void wave_mem_sync() {
 
 struct Corr { double x1, y1, x2, y2; };
 
+// What load_corr needs of one image, read once per pair (wave-uniform)
+struct LiftSrc {
+    const float* kp;
+    const double* kp64;
+    const double* kpn;   // lifted keypoints of a camera with distortion parameters, else nullptr
+    double fx, fy, cx, cy;
+};
+__device__ __forceinline__ LiftSrc lift_src(const TvgImage* im) {
+    LiftSrc s;
+    s.kp = im->kp; s.kp64 = im->kp64; s.kpn = im->kpn;
+    const int nf = cam::num_focal(im->cam.model_id);
+    s.fx = im->cam.params[0]; s.fy = im->cam.params[nf - 1];
+    s.cx = im->cam.params[nf]; s.cy = im->cam.params[nf + 1];
+    return s;
+}
+__device__ __forceinline__ void lift_point(const LiftSrc& s, uint32_t i, double& u, double& v) {
+    if (s.kpn) {
+        u = s.kpn[2 * (size_t)i];
+        v = s.kpn[2 * (size_t)i + 1];
+        return;
+    }
+    const double X = s.kp64 ? s.kp64[2 * (size_t)i] : (double)s.kp[2 * (size_t)i];
+    const double Y = s.kp64 ? s.kp64[2 * (size_t)i + 1] : (double)s.kp[2 * (size_t)i + 1];
+    u = (X - s.cx) / s.fx;
+    v = (Y - s.cy) / s.fy;
+}
 // k-th correspondence of the pair in camera coordinates (Camera::CamFromImg of both cameras)
-__device__ __forceinline__ Corr load_corr(const TvgImage& im1, const TvgImage& im2, const uint32_t* mm, int k) {
-    const uint32_t i1 = mm[2 * (size_t)k], i2 = mm[2 * (size_t)k + 1];
-    const double X1 = im1.kp64 ? im1.kp64[2 * (size_t)i1] : (double)im1.kp[2 * (size_t)i1];
-    const double Y1 = im1.kp64 ? im1.kp64[2 * (size_t)i1 + 1] : (double)im1.kp[2 * (size_t)i1 + 1];
-    const double X2 = im2.kp64 ? im2.kp64[2 * (size_t)i2] : (double)im2.kp[2 * (size_t)i2];
-    const double Y2 = im2.kp64 ? im2.kp64[2 * (size_t)i2 + 1] : (double)im2.kp[2 * (size_t)i2 + 1];
+__device__ __forceinline__ Corr load_corr(const LiftSrc& im1, const LiftSrc& im2, const uint32_t* mm, int k) {
     Corr c;
-    if (im1.cam.model_id == AMC_CAM_SIMPLE_PINHOLE) {
-        c.x1 = (X1 - im1.cam.params[1]) / im1.cam.params[0];
-        c.y1 = (Y1 - im1.cam.params[2]) / im1.cam.params[0];
-    } else {
-        c.x1 = (X1 - im1.cam.params[2]) / im1.cam.params[0];
-        c.y1 = (Y1 - im1.cam.params[3]) / im1.cam.params[1];
-    }
-    if (im2.cam.model_id == AMC_CAM_SIMPLE_PINHOLE) {
-        c.x2 = (X2 - im2.cam.params[1]) / im2.cam.params[0];
-        c.y2 = (Y2 - im2.cam.params[2]) / im2.cam.params[0];
-    } else {
-        c.x2 = (X2 - im2.cam.params[2]) / im2.cam.params[0];
-        c.y2 = (Y2 - im2.cam.params[3]) / im2.cam.params[1];
-    }
+    lift_point(im1, mm[2 * (size_t)k], c.x1, c.y1);
+    lift_point(im2, mm[2 * (size_t)k + 1], c.x2, c.y2);
     return c;
 }
 
@@ -112,7 +122,7 @@ __global__ __launch_bounds__(64) void pose_kernel(const TvgImage* __restrict__ i
         }
         return;
     }
-    const TvgImage im1 = imgs[pr.slot1], im2 = imgs[pr.slot2];
+    const LiftSrc im1 = lift_src(imgs + pr.slot1), im2 = lift_src(imgs + pr.slot2);
     const uint32_t* mm = matches + 2 * pr.match_off;
     // inlier matches: all M rows, or (behind amc_verify_pairs) the rows of the pair's mask that are set
     const uint8_t* mask = mask_all ? mask_all + pr.mask_off : nullptr;
@@ -126,8 +136,8 @@ __global__ __launch_bounds__(64) void pose_kernel(const TvgImage* __restrict__ i
         } else {
             double K1[9], K2[9];
             for (int i = 0; i < 9; ++i) m9[i] = pr.H[i];
-            calibration_matrix(im1.cam.model_id, im1.cam.params, K1);
-            calibration_matrix(im2.cam.model_id, im2.cam.params, K2);
+            cam::calibration_matrix(imgs[pr.slot1].cam.model_id, imgs[pr.slot1].cam.params, K1);
+            cam::calibration_matrix(imgs[pr.slot2].cam.model_id, imgs[pr.slot2].cam.params, K2);
             pose_candidates_H(m9, K1, K2, c);
         }
         cands = c;

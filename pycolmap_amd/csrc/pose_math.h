@@ -98,15 +98,6 @@ AMC_HD void vec3_normalize(const double* a, double* r) {
     r[0] = a[0] / n; r[1] = a[1] / n; r[2] = a[2] / n;
 }
 
-// CalibrationMatrix of a SIMPLE_PINHOLE / PINHOLE camera
-AMC_HD void calibration_matrix(int model_id, const double* params, double* K) {
-#pragma unroll
-    for (int i = 0; i < 9; ++i) K[i] = 0.0;
-    if (model_id == 0) { K[0] = params[0]; K[4] = params[0]; K[2] = params[1]; K[5] = params[2]; }
-    else { K[0] = params[0]; K[4] = params[1]; K[2] = params[2]; K[5] = params[3]; }
-    K[8] = 1.0;
-}
-
 // A = U diag(S) V^T, S descending.  u_k = A v_k / s_k for the two largest singular values (the unit
 // vector e_k when s_k is zero: U = I for the all-zero matrix, as Eigen returns), u_2 = u_0 x u_1.
 AMC_HD void svd3(const double* A, double* U, double* S, double* V) {

@@ -28,6 +28,7 @@
 #include <algorithm>
 
 #include "amc_internal.h"
+#include "camera_math.h"
 #include "tvg_math.h"
 
 namespace amc {
@@ -706,8 +707,7 @@ __device__ __forceinline__ int local_estimate_impl(const LoCtx& w, int kind, con
         e5_build(nsp, polys);
         double roots[10];
         const int nr = real_roots10_wave(polys.det, roots, w.jacA, lane);
-        e5_models(nsp, polys, roots, nr, models);
-        return nr;
+        return e5_models(nsp, polys, roots, nr, models);
     }
     if (kind == K_H && K == 4) {
         double a[4], b[4], c[4], d[4];
@@ -917,6 +917,7 @@ struct RansacCfg {
     int max_trials;          // already clamped as the RANSAC constructor does
     int min_trials;
     const uint32_t* dyn_tab; // dyn_max_num_trials by num_inliers (host libm), or nullptr
+    const double* wm_cut;    // K_T only: inlier-ratio cut-offs by trial count (TvgParams::wm_cut), max_trials + 1 entries
     int force_slow_sampler;  // test hook: always take the draw-by-draw sampler path
 };
 
@@ -1045,7 +1046,20 @@ __device__ Report lo_ransac(Wave& w_io, const RansacCfg& cfg, const double* gx, 
                             for (int i = 0; i < 9; ++i) cur.v[i] = best_model[i];
                         }
                     }
-                    dyn_max = cfg.dyn_tab ? cfg.dyn_tab[best.cnt] : 0xFFFFFFFFu;
+                    if (cfg.dyn_tab) {
+                        dyn_max = cfg.dyn_tab[best.cnt];
+                    } else if (cfg.wm_cut) {
+                        // first T in [0, max_trials] with r >= wm_cut[T] (the cut-offs do not increase with T)
+                        const double r = (double)best.cnt / (double)M;
+                        int lo_t = 0, hi_t = cfg.max_trials + 1;  // answer in [lo_t, hi_t]; hi_t = none
+                        while (lo_t < hi_t) {
+                            const int mid = (lo_t + hi_t) >> 1;
+                            if (r >= cfg.wm_cut[mid]) hi_t = mid; else lo_t = mid + 1;
+                        }
+                        dyn_max = lo_t <= cfg.max_trials ? (uint32_t)lo_t : 0xFFFFFFFFu;
+                    } else {
+                        dyn_max = 0xFFFFFFFFu;
+                    }
                     w.prof[3] += __builtin_readcyclecounter() - tl0;
                 }
                 if ((uint32_t)trial >= dyn_max && trial >= cfg.min_trials) {
@@ -1109,7 +1123,10 @@ __device__ __noinline__ void process_pair(Wave& w, uint32_t q, const TvgImage* _
     for (int i = 0; i < 8; ++i) w.prof[i] = 0;
     const unsigned long long tstart = __builtin_readcyclecounter();
     const TvgPair pr = pairs[q];
-    const TvgImage im1 = imgs[pr.slot1], im2 = imgs[pr.slot2];
+    // the image records are read field by field where they are needed (wave-uniform scalar loads): a by-value
+    // copy of both would hold 2 x 38 dwords of camera parameters in scalar registers for the whole pair
+    const TvgImage* __restrict__ pim1 = imgs + pr.slot1;
+    const TvgImage* __restrict__ pim2 = imgs + pr.slot2;
     const int M = (int)pr.M;
     amc_tvg g;
     g.config = AMC_TVG_UNDEFINED;
@@ -1132,16 +1149,23 @@ __device__ __noinline__ void process_pair(Wave& w, uint32_t q, const TvgImage* _
     // return above): a pair with a match past an image's keypoints is counted and not estimated - the
     // host then fails the whole call with AMC_E_INVALID, naming the match.
     bool bad = false;
-    for (int k = lane; k < M; k += 64) {
-        const uint32_t i1 = mm[2 * k], i2 = mm[2 * k + 1];
-        if (i1 >= im1.rows || i2 >= im2.rows) {
-            bad = true;
-            continue;
+    {
+        const float* __restrict__ kp1 = pim1->kp;
+        const float* __restrict__ kp2 = pim2->kp;
+        const double* __restrict__ kd1 = pim1->kp64;
+        const double* __restrict__ kd2 = pim2->kp64;
+        const uint32_t rows1 = pim1->rows, rows2 = pim2->rows;
+        for (int k = lane; k < M; k += 64) {
+            const uint32_t i1 = mm[2 * k], i2 = mm[2 * k + 1];
+            if (i1 >= rows1 || i2 >= rows2) {
+                bad = true;
+                continue;
+            }
+            X1[k] = kd1 ? kd1[2 * (size_t)i1] : (double)kp1[2 * (size_t)i1];
+            Y1[k] = kd1 ? kd1[2 * (size_t)i1 + 1] : (double)kp1[2 * (size_t)i1 + 1];
+            X2[k] = kd2 ? kd2[2 * (size_t)i2] : (double)kp2[2 * (size_t)i2];
+            Y2[k] = kd2 ? kd2[2 * (size_t)i2 + 1] : (double)kp2[2 * (size_t)i2 + 1];
         }
-        X1[k] = im1.kp64 ? im1.kp64[2 * (size_t)i1] : (double)im1.kp[2 * (size_t)i1];
-        Y1[k] = im1.kp64 ? im1.kp64[2 * (size_t)i1 + 1] : (double)im1.kp[2 * (size_t)i1 + 1];
-        X2[k] = im2.kp64 ? im2.kp64[2 * (size_t)i2] : (double)im2.kp[2 * (size_t)i2];
-        Y2[k] = im2.kp64 ? im2.kp64[2 * (size_t)i2 + 1] : (double)im2.kp[2 * (size_t)i2 + 1];
     }
     if (__any(bad)) {
         g.config = AMC_TVG_UNDEFINED;
@@ -1157,7 +1181,7 @@ __device__ __noinline__ void process_pair(Wave& w, uint32_t q, const TvgImage* _
     wave_mem_sync();
 
     // mode 0: the EstimateTwoViewGeometry dispatch; modes 1 / 2 / 3: exactly one of F / H / E
-    const bool calibrated = P.mode == 0 ? (!P.force_H_use && im1.cam.has_prior && im2.cam.has_prior) : P.mode == 3;
+    const bool calibrated = P.mode == 0 ? (!P.force_H_use && pim1->cam.has_prior && pim2->cam.has_prior) : P.mode == 3;
     const bool run_F = P.mode == 0 ? !P.force_H_use : P.mode == 1;
     const bool run_H = P.mode == 0 || P.mode == 2;
     uint8_t *maskE = w.masks, *maskF = w.masks + mcap, *maskH = w.masks + 2 * (size_t)mcap;
@@ -1168,31 +1192,45 @@ __device__ __noinline__ void process_pair(Wave& w, uint32_t q, const TvgImage* _
     for (int i = 0; i < 9; ++i) { E_rep.model[i] = 0; F_rep.model[i] = 0; }
 
     RansacCfg cfg;
+    cfg.wm_cut = nullptr;
     cfg.min_trials = P.min_num_trials;
     cfg.force_slow_sampler = P.force_slow_sampler;
     if (calibrated) {
         double *N1x = w.arr(W_NX1), *N1y = w.arr(W_NY1), *N2x = w.arr(W_NX2), *N2y = w.arr(W_NY2);
-        const CameraDev c1 = im1.cam, c2 = im2.cam;
-        for (int k = lane; k < M; k += 64) {
-            if (c1.model_id == AMC_CAM_SIMPLE_PINHOLE) {
-                N1x[k] = (X1[k] - c1.params[1]) / c1.params[0];
-                N1y[k] = (Y1[k] - c1.params[2]) / c1.params[0];
-            } else {
-                N1x[k] = (X1[k] - c1.params[2]) / c1.params[0];
-                N1y[k] = (Y1[k] - c1.params[3]) / c1.params[1];
-            }
-            if (c2.model_id == AMC_CAM_SIMPLE_PINHOLE) {
-                N2x[k] = (X2[k] - c2.params[1]) / c2.params[0];
-                N2y[k] = (Y2[k] - c2.params[2]) / c2.params[0];
-            } else {
-                N2x[k] = (X2[k] - c2.params[2]) / c2.params[0];
-                N2y[k] = (Y2[k] - c2.params[3]) / c2.params[1];
+        // Camera::CamFromImg of the matched points.  SIMPLE_PINHOLE / PINHOLE: (x - c) / f in place.  Cameras
+        // with distortion parameters: the keypoints were lifted once per image (kpn), gather from there.
+        {
+            const int model1 = pim1->cam.model_id, model2 = pim2->cam.model_id;
+            const double* __restrict__ kn1 = pim1->kpn;
+            const double* __restrict__ kn2 = pim2->kpn;
+            const int nf1 = cam::num_focal(model1), nf2 = cam::num_focal(model2);
+            const double f1x = pim1->cam.params[0], f1y = pim1->cam.params[nf1 - 1];
+            const double c1x = pim1->cam.params[nf1], c1y = pim1->cam.params[nf1 + 1];
+            const double f2x = pim2->cam.params[0], f2y = pim2->cam.params[nf2 - 1];
+            const double c2x = pim2->cam.params[nf2], c2y = pim2->cam.params[nf2 + 1];
+            for (int k = lane; k < M; k += 64) {
+                if (kn1) {
+                    const uint32_t i1 = mm[2 * k];
+                    N1x[k] = kn1[2 * (size_t)i1];
+                    N1y[k] = kn1[2 * (size_t)i1 + 1];
+                } else {
+                    N1x[k] = (X1[k] - c1x) / f1x;
+                    N1y[k] = (Y1[k] - c1y) / f1y;
+                }
+                if (kn2) {
+                    const uint32_t i2 = mm[2 * k + 1];
+                    N2x[k] = kn2[2 * (size_t)i2];
+                    N2y[k] = kn2[2 * (size_t)i2 + 1];
+                } else {
+                    N2x[k] = (X2[k] - c2x) / f2x;
+                    N2y[k] = (Y2[k] - c2y) / f2y;
+                }
             }
         }
         wave_mem_sync();
-        const double f1 = c1.model_id == AMC_CAM_SIMPLE_PINHOLE ? c1.params[0] : (c1.params[0] + c1.params[1]) / 2.0;
-        const double f2 = c2.model_id == AMC_CAM_SIMPLE_PINHOLE ? c2.params[0] : (c2.params[0] + c2.params[1]) / 2.0;
-        const double e_err = (P.max_error / f1 + P.max_error / f2) / 2;
+        // E threshold: (cam1.CamFromImgThreshold(e) + cam2.CamFromImgThreshold(e)) / 2
+        const double e_err = (cam::cam_from_img_threshold(pim1->cam.model_id, pim1->cam.params, P.max_error) +
+                              cam::cam_from_img_threshold(pim2->cam.model_id, pim2->cam.params, P.max_error)) / 2;
         cfg.est = K_E5; cfg.local_est = K_E5;
         cfg.max_res = e_err * e_err;
         cfg.max_trials = P.max_trials[0];
@@ -1293,13 +1331,13 @@ __device__ __noinline__ void process_pair(Wave& w, uint32_t q, const TvgImage* _
         }
         // ---- DetectWatermark -----------------------------------------------------------------
         if (P.detect_watermark && best_ok) {
-            const CameraDev c1 = im1.cam, c2 = im2.cam;
-            const double diagonal1 = dsqrt((double)(c1.width * c1.width + c1.height * c1.height));
-            const double diagonal2 = dsqrt((double)(c2.width * c2.width + c2.height * c2.height));
+            const uint64_t w1 = pim1->cam.width, h1 = pim1->cam.height, w2 = pim2->cam.width, h2 = pim2->cam.height;
+            const double diagonal1 = dsqrt((double)(w1 * w1 + h1 * h1));
+            const double diagonal2 = dsqrt((double)(w2 * w2 + h2 * h2));
             const double minx1 = P.watermark_border_size * diagonal1, miny1 = minx1;
-            const double maxx1 = (double)c1.width - minx1, maxy1 = (double)c1.height - miny1;
+            const double maxx1 = (double)w1 - minx1, maxy1 = (double)h1 - miny1;
             const double minx2 = P.watermark_border_size * diagonal2, miny2 = minx2;
-            const double maxx2 = (double)c2.width - minx2, maxy2 = (double)c2.height - miny2;
+            const double maxx2 = (double)w2 - minx2, maxy2 = (double)h2 - miny2;
             double *ix1 = w.arr(W_NX1), *iy1 = w.arr(W_NY1), *ix2 = w.arr(W_NX2), *iy2 = w.arr(W_NY2);
             int basep = 0, border = 0;
             for (int k0 = 0; k0 < M; k0 += 64) {
@@ -1322,7 +1360,8 @@ __device__ __noinline__ void process_pair(Wave& w, uint32_t q, const TvgImage* _
                 cfg.est = K_T; cfg.local_est = K_T;
                 cfg.max_res = P.max_error * P.max_error;
                 cfg.max_trials = P.max_trials[3];
-                cfg.dyn_tab = nullptr;  // never consulted: max_trials[3] <= min_num_trials (host check)
+                cfg.dyn_tab = nullptr;
+                cfg.wm_cut = P.wm_cut;
                 const Report T_rep = lo_ransac(w, cfg, ix1, mcap, num_inliers, w.masks + 3 * (size_t)mcap);
                 g.num_trials[3] = T_rep.num_trials;
                 const double inlier_ratio = (double)T_rep.support.cnt / (double)num_inliers;

@@ -710,8 +710,11 @@ AMC_HD void e5_build(const double* nsp, E5Polys& P) {
         for (int i = 0; i <= 10; ++i) det[i] = (q0[i] - q1[i]) + q2[i];
     }
 }
-AMC_HD void e5_models(const double* nsp, const E5Polys& P, const double* roots, int nr, double* models) {
+// returns the number of models written (a root whose (x, y) blows up is skipped, as upstream skips
+// |X(2)| < 1e-10 of the unit null vector of B(z)); every E is scaled to unit Frobenius norm
+AMC_HD int e5_models(const double* nsp, const E5Polys& P, const double* roots, int nr, double* models) {
     const double (&B)[3][3][5] = P.B;
+    int nm = 0;
     for (int i = 0; i < nr; ++i) {
         const double z = roots[i];
         const double a0 = poly_eval(B[0][0], 3, z), b0 = poly_eval(B[0][1], 3, z), c0 = poly_eval(B[0][2], 4, z);
@@ -719,9 +722,16 @@ AMC_HD void e5_models(const double* nsp, const E5Polys& P, const double* roots, 
         const double dd = a0 * b1 - a1 * b0;
         const double x = (b0 * c1 - b1 * c0) / dd;
         const double y = (a1 * c0 - a0 * c1) / dd;
-        double* E = models + 9 * i;
+        if (!(x * x + y * y + 1.0 < 1e20)) continue;
+        double* E = models + 9 * nm;
         for (int k = 0; k < 9; ++k) E[k] = x * nsp[k] + y * nsp[9 + k] + z * nsp[18 + k] + nsp[27 + k];
+        double n2 = 0.0;
+        for (int k = 0; k < 9; ++k) n2 += E[k] * E[k];
+        const double nrm = dsqrt(n2);
+        for (int k = 0; k < 9; ++k) E[k] = E[k] / nrm;
+        ++nm;
     }
+    return nm;
 }
 // nsp -> #models (<= 10), row-major
 AMC_HD int e5_from_nullspace(const double* nsp, double* models /* 10 x 9 */) {
@@ -729,8 +739,7 @@ AMC_HD int e5_from_nullspace(const double* nsp, double* models /* 10 x 9 */) {
     e5_build(nsp, P);
     double roots[10];
     const int nr = real_roots_t<10>(P.det, roots);
-    e5_models(nsp, P, roots, nr, models);
-    return nr;
+    return e5_models(nsp, P, roots, nr, models);
 }
 
 // minimal 5-point

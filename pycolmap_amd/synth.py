@@ -131,13 +131,14 @@ def two_view_scene(rng, num_inliers=300, num_outliers=100, noise=0.5, planar=Fal
 
 
 def multiview_scene(rng, num_images=6, n_feats=600, num_landmarks=900, f=1200.0, width=1600, height=1200,
-                    sigma_px=0.5, sigma_d=0.06):
+                    sigma_px=0.5, sigma_d=0.06, camera=None):
     """Images of one 3-D scene with geometrically consistent keypoints AND matching descriptors:
     the input of the whole match + verify pipeline.  Cameras sit on an arc and
     look at the landmark cloud; each image keeps up to 70 % landmark features (projection + pixel
     noise, descriptor = noisy landmark prototype) and is padded with pure-noise features.
     Returns a list of dict(name, keypoints [n,4] float32 (x, y, scale, orientation), descriptors
-    [n,128] uint8, model=1 (PINHOLE), width, height, params)."""
+    [n,128] uint8, model=1 (PINHOLE), width, height, params).  camera = (model name, params): every image
+    is taken with that camera instead (keypoints projected with img_from_cam below; model = its id)."""
     X = rng.uniform([-4, -2.5, -2], [4, 2.5, 2], size=(num_landmarks, 3))
     proto = rng.gamma(0.7, 1.0, size=(num_landmarks, 128))
     proto /= np.linalg.norm(proto, axis=1, keepdims=True)
@@ -152,8 +153,12 @@ def multiview_scene(rng, num_images=6, n_feats=600, num_landmarks=900, f=1200.0,
         y = np.cross(z, x)
         R = np.stack([x, y, z])
         Xc = (X - C) @ R.T
-        uv = (Xc @ K.T)
-        uv = uv[:, :2] / uv[:, 2:]
+        if camera is None:
+            uv = (Xc @ K.T)
+            uv = uv[:, :2] / uv[:, 2:]
+        else:
+            zc = np.where(Xc[:, 2] > 1, Xc[:, 2], 1.0)
+            uv = img_from_cam(camera[0], camera[1], Xc[:, :2] / zc[:, None])
         vis = np.where((Xc[:, 2] > 1) & (uv[:, 0] > 8) & (uv[:, 0] < width - 8) & (uv[:, 1] > 8) & (uv[:, 1] < height - 8))[0]
         vis = rng.permutation(vis)[:int(0.7 * n_feats)]
         kp = uv[vis] + rng.normal(0, sigma_px, size=(len(vis), 2))
@@ -164,5 +169,99 @@ def multiview_scene(rng, num_images=6, n_feats=600, num_landmarks=900, f=1200.0,
         perm = rng.permutation(n_feats)
         kp4 = np.c_[kp[perm], rng.uniform(1, 4, n_feats), rng.uniform(-3.1, 3.1, n_feats)].astype(np.float32)
         images.append(dict(name=f"img_{i:04d}.jpg", keypoints=kp4, descriptors=quantize_descriptors(d[perm]),
-                           model=1, width=width, height=height, params=(f, f, width / 2.0, height / 2.0)))
+                           model=1 if camera is None else CAMERA_MODEL_IDS[camera[0]], width=width, height=height,
+                           params=(f, f, width / 2.0, height / 2.0) if camera is None else tuple(camera[1])))
     return images
+
+
+# ------------------------------------------------------------------------------------------------
+# camera models (COLMAP 3.9.1 colmap/sensor/models.h): forward projection for generating inputs
+# ------------------------------------------------------------------------------------------------
+CAMERA_MODEL_IDS = {"SIMPLE_PINHOLE": 0, "PINHOLE": 1, "SIMPLE_RADIAL": 2, "RADIAL": 3, "OPENCV": 4,
+                    "OPENCV_FISHEYE": 5, "FULL_OPENCV": 6, "FOV": 7, "SIMPLE_RADIAL_FISHEYE": 8,
+                    "RADIAL_FISHEYE": 9, "THIN_PRISM_FISHEYE": 10}
+_NUM_FOCAL = {0: 1, 1: 2, 2: 1, 3: 1, 4: 2, 5: 2, 6: 2, 7: 2, 8: 1, 9: 1, 10: 2}
+
+# plausible parameter vectors of a 1600 x 1200 sensor, one per model (tests, golden fixtures, benches)
+EXAMPLE_CAMERAS = {
+    "SIMPLE_PINHOLE": (1150.0, 805.0, 598.0),
+    "PINHOLE": (1200.0, 1190.0, 800.0, 600.0),
+    "SIMPLE_RADIAL": (1180.0, 802.0, 597.0, -0.06),
+    "RADIAL": (1180.0, 802.0, 597.0, -0.07, 0.02),
+    "OPENCV": (1210.0, 1195.0, 795.0, 605.0, -0.08, 0.03, 0.001, -0.0015),
+    "OPENCV_FISHEYE": (900.0, 905.0, 800.0, 600.0, -0.03, 0.01, -0.002, 0.0005),
+    "FULL_OPENCV": (1210.0, 1195.0, 795.0, 605.0, -0.08, 0.03, 0.001, -0.0015, 0.004, 0.01, -0.005, 0.001),
+    "FOV": (1100.0, 1105.0, 800.0, 600.0, 0.6),
+    "SIMPLE_RADIAL_FISHEYE": (900.0, 800.0, 600.0, -0.02),
+    "RADIAL_FISHEYE": (900.0, 800.0, 600.0, -0.03, 0.008),
+    "THIN_PRISM_FISHEYE": (900.0, 905.0, 800.0, 600.0, -0.03, 0.01, 0.0005, -0.0008, -0.002, 0.0004, 0.001, -0.0012),
+}
+
+
+def img_from_cam(model, params, uv: np.ndarray) -> np.ndarray:
+    """Camera::ImgFromCam for an N x 2 array of normalised image-plane points (float64 numpy; used to
+    synthesise keypoints of distorted cameras, not a parity path)."""
+    mid = CAMERA_MODEL_IDS[model] if isinstance(model, str) else int(model)
+    p = np.asarray(params, dtype=np.float64)
+    nf = _NUM_FOCAL[mid]
+    f1, f2, c1, c2 = p[0], p[nf - 1], p[nf], p[nf + 1]
+    e = p[nf + 2:]
+    u, v = np.asarray(uv, dtype=np.float64).reshape(-1, 2).T
+    if mid == 10:  # equidistant projection first
+        r = np.sqrt(u * u + v * v)
+        th = np.arctan(r)
+        s = np.where(r > 1e-15, th / np.where(r > 1e-15, r, 1.0), 1.0)
+        u, v = u * s, v * s
+    u2, v2, uv_ = u * u, v * v, u * v
+    r2 = u2 + v2
+    if mid in (0, 1):
+        du = dv = 0.0
+    elif mid == 2:
+        du, dv = u * (e[0] * r2), v * (e[0] * r2)
+    elif mid == 3:
+        rad = e[0] * r2 + e[1] * r2 * r2
+        du, dv = u * rad, v * rad
+    elif mid == 4:
+        rad = e[0] * r2 + e[1] * r2 * r2
+        du = u * rad + 2 * e[2] * uv_ + e[3] * (r2 + 2 * u2)
+        dv = v * rad + 2 * e[3] * uv_ + e[2] * (r2 + 2 * v2)
+    elif mid == 6:
+        r4, r6 = r2 * r2, r2 * r2 * r2
+        rad = (1 + e[0] * r2 + e[1] * r4 + e[4] * r6) / (1 + e[5] * r2 + e[6] * r4 + e[7] * r6)
+        du = u * rad + 2 * e[2] * uv_ + e[3] * (r2 + 2 * u2) - u
+        dv = v * rad + 2 * e[3] * uv_ + e[2] * (r2 + 2 * v2) - v
+    elif mid in (5, 8, 9):
+        r = np.sqrt(r2)
+        th = np.arctan(r)
+        th2 = th * th
+        k = list(e) + [0.0] * (4 - len(e))
+        thd = th * (1 + k[0] * th2 + k[1] * th2 ** 2 + k[2] * th2 ** 3 + k[3] * th2 ** 4)
+        s = np.where(r > 1e-15, thd / np.where(r > 1e-15, r, 1.0), 1.0)
+        du, dv = u * s - u, v * s - v
+    elif mid == 7:
+        om = e[0]
+        r = np.sqrt(r2)
+        fac = np.arctan(r * 2 * np.tan(om / 2)) / np.where(r > 1e-9, r * om, 1.0)
+        fac = np.where(r > 1e-9, fac, 2 * np.tan(om / 2) / om)
+        du, dv = u * fac - u, v * fac - v
+    elif mid == 10:
+        r4, r6, r8 = r2 * r2, r2 ** 3, r2 ** 4
+        rad = e[0] * r2 + e[1] * r4 + e[4] * r6 + e[5] * r8
+        du = u * rad + 2 * e[2] * uv_ + e[3] * (r2 + 2 * u2) + e[6] * r2
+        dv = v * rad + 2 * e[3] * uv_ + e[2] * (r2 + 2 * v2) + e[7] * r2
+    else:
+        raise ValueError(f"unknown camera model {model}")
+    return np.stack([f1 * (u + du) + c1, f2 * (v + dv) + c2], axis=1)
+
+
+def recamera_scene(sc: dict, model1, params1, model2, params2) -> dict:
+    """The two-view scene `sc` (pinhole views, focal sc['f'], principal point at the centre) seen
+    through two other cameras: every keypoint is taken back to the normalised plane and projected
+    with the given model; float32-rounded like the `keypoints` blob.  Geometry (R, t, inlier set)
+    is unchanged, so E stays recoverable on the calibrated path."""
+    out = dict(sc)
+    cx, cy, f = sc["width"] / 2.0, sc["height"] / 2.0, sc["f"]
+    for key, (m, p) in (("pts1", (model1, params1)), ("pts2", (model2, params2))):
+        uv = (sc[key] - np.array([cx, cy])) / f
+        out[key] = img_from_cam(m, p, uv).astype(np.float32).astype(np.float64)
+    return out

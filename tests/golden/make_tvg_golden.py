@@ -1,4 +1,4 @@
-"""Generates tests/golden/tvg_golden_v1.npz: seeded two-view scenes with the oracle's
+"""Generates tests/golden/tvg_golden_v2.npz: seeded two-view scenes with the oracle's
 EstimateTwoViewGeometry (+ EstimateTwoViewGeometryPose) results.
 
 As for the match fixture, the reference holds no golden vectors for this path (SURVEY.md section
@@ -22,7 +22,13 @@ sys.path.insert(0, str(ROOT / "tests"))
 import oracle_lib as o  # noqa: E402
 from pycolmap_amd import synth  # noqa: E402
 
-CAMS = [("PINHOLE", (1200.0, 1200.0, 800.0, 600.0)), ("SIMPLE_PINHOLE", (1150.0, 805.0, 598.0))]
+# indices 0 / 1: the two pinhole cameras of the v1 fixture; 2..: one camera per distortion model
+# (synth.EXAMPLE_CAMERAS); a case using one of those sees its scene through that camera
+# (synth.recamera_scene) so that the calibrated path has real geometry to find
+CAMS = [("PINHOLE", (1200.0, 1200.0, 800.0, 600.0)), ("SIMPLE_PINHOLE", (1150.0, 805.0, 598.0))] + \
+       [(m, synth.EXAMPLE_CAMERAS[m]) for m in ("SIMPLE_RADIAL", "RADIAL", "OPENCV", "OPENCV_FISHEYE", "FULL_OPENCV",
+                                                "FOV", "SIMPLE_RADIAL_FISHEYE", "RADIAL_FISHEYE",
+                                                "THIN_PRISM_FISHEYE")]
 # (scene kwargs, prior focal length, camera index image 1 / image 2, option overrides)
 CASES = [
     (dict(num_inliers=300, num_outliers=100), False, 0, 0, {}),
@@ -38,6 +44,15 @@ CASES = [
                                                              max_num_trials=2000, min_inlier_ratio=0.1)),
     (dict(num_inliers=180, num_outliers=90, planar=True), False, 0, 0, dict(detect_watermark=0, max_H_inlier_ratio=0.5)),
     (dict(num_inliers=400, num_outliers=300, noise=0.3), True, 0, 0, dict(min_E_F_inlier_ratio=0.8)),
+    # cameras with distortion parameters (Camera::CamFromImg = IterativeUndistortion / closed forms)
+    (dict(num_inliers=260, num_outliers=90), True, 2, 2, {}),                    # SIMPLE_RADIAL: extract_features' default
+    (dict(num_inliers=220, num_outliers=120), True, 3, 4, {}),                   # RADIAL x OPENCV
+    (dict(num_inliers=200, num_outliers=80, planar=True), True, 4, 0, {}),       # OPENCV x PINHOLE, planar
+    (dict(num_inliers=240, num_outliers=100), True, 5, 6, {}),                   # OPENCV_FISHEYE x FULL_OPENCV
+    (dict(num_inliers=240, num_outliers=100), True, 7, 8, {}),                   # FOV x SIMPLE_RADIAL_FISHEYE
+    (dict(num_inliers=240, num_outliers=100), True, 9, 10, {}),                  # RADIAL_FISHEYE x THIN_PRISM_FISHEYE
+    (dict(num_inliers=150, num_outliers=60), False, 2, 4, {}),                   # no prior focal length: F + H only
+    (dict(num_inliers=250, num_outliers=50, pure_rotation=True, noise=0.05), True, 2, 3, {}),
 ]
 FIELDS = ("E", "F", "H", "qvec", "tvec", "R")
 
@@ -47,6 +62,8 @@ def main():
     out = {"num_cases": np.int64(len(CASES))}
     for k, (kw, prior, c1, c2, okw) in enumerate(CASES):
         sc = synth.two_view_scene(rng, **kw)
+        if c1 >= 2 or c2 >= 2:
+            sc = synth.recamera_scene(sc, CAMS[c1][0], CAMS[c1][1], CAMS[c2][0], CAMS[c2][1])
         out[f"pts1_{k}"] = sc["pts1"]
         out[f"pts2_{k}"] = sc["pts2"]
         out[f"matches_{k}"] = sc["matches"]
@@ -69,7 +86,7 @@ def main():
             for f in FIELDS:
                 out[f"{f}_{tag}"] = np.ascontiguousarray(r[f], dtype=np.float64).reshape(-1).view(np.uint64)
             print(k, pose, r["config_name"], r["num_inliers"], r["trials"], round(r["tri_angle"], 5))
-    np.savez_compressed(Path(__file__).with_name("tvg_golden_v1.npz"), **out)
+    np.savez_compressed(Path(__file__).with_name("tvg_golden_v2.npz"), **out)
 
 
 if __name__ == "__main__":

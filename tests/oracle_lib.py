@@ -162,10 +162,15 @@ def ransac_options(max_error=4.0, min_inlier_ratio=0.01, confidence=0.9999,
                                min_num_trials=min_num_trials, max_num_trials=max_num_trials)
 
 
+CAMERA_MODELS = {"SIMPLE_PINHOLE": 0, "PINHOLE": 1, "SIMPLE_RADIAL": 2, "RADIAL": 3, "OPENCV": 4, "OPENCV_FISHEYE": 5,
+                 "FULL_OPENCV": 6, "FOV": 7, "SIMPLE_RADIAL_FISHEYE": 8, "RADIAL_FISHEYE": 9,
+                 "THIN_PRISM_FISHEYE": 10}
+
+
 def make_camera(model="PINHOLE", width=1600, height=1200, params=(1200.0, 1200.0, 800.0, 600.0),
                 prior=False) -> OCamera:
     c = OCamera()
-    c.model_id = {"SIMPLE_PINHOLE": 0, "PINHOLE": 1}[model]
+    c.model_id = CAMERA_MODELS[model] if isinstance(model, str) else int(model)
     c.has_prior_focal_length = int(prior)
     c.width, c.height = width, height
     for i, v in enumerate(params):
@@ -175,6 +180,29 @@ def make_camera(model="PINHOLE", width=1600, height=1200, params=(1200.0, 1200.0
 
 def _d(a):
     return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def cam_from_img(cam: OCamera, points) -> np.ndarray:
+    """Camera::CamFromImg of an N x 2 array of image points."""
+    xy = _d(points).reshape(-1, 2)
+    out = np.empty_like(xy)
+    lib = load()
+    lib.oracle_cam_from_img.restype = C.c_int
+    rc = lib.oracle_cam_from_img(C.byref(cam), _p(xy), C.c_size_t(len(xy)), _p(out))
+    assert rc == 0, "oracle: unknown camera model"
+    return out
+
+
+def cam_from_img_threshold(cam: OCamera, threshold: float) -> float:
+    lib = load()
+    lib.oracle_cam_from_img_threshold.restype = C.c_double
+    return float(lib.oracle_cam_from_img_threshold(C.byref(cam), C.c_double(threshold)))
+
+
+def calibration_matrix(cam: OCamera) -> np.ndarray:
+    out = np.empty(9)
+    load().oracle_calibration_matrix(C.byref(cam), _p(out))
+    return out.reshape(3, 3)
 
 
 def estimate_two_view_geometry(cam1, pts1, cam2, pts2, matches, opts=None, seed=0):

@@ -2,6 +2,7 @@
 // CPU suite can compare them bit-for-bit with the oracle without a GPU.
 #include "../../pycolmap_amd/csrc/tvg_math.h"
 #include "../../pycolmap_amd/csrc/pose_math.h"
+#include "../../pycolmap_amd/csrc/camera_math.h"
 #include <vector>
 using namespace amc::tvg;
 extern "C" {
@@ -36,8 +37,14 @@ unsigned shim_temper(unsigned y) { return mt_temper(y); }
 // coordinates, the geometry's config / E / H.  out: ok, config, num_points3D, then
 // R[9] t[3] q[4] tri_angle as doubles.
 static void shim_norm(int model, const double* prm, double x, double y, double* nx, double* ny) {
-    if (model == 0) { *nx = (x - prm[1]) / prm[0]; *ny = (y - prm[2]) / prm[0]; }
-    else { *nx = (x - prm[2]) / prm[0]; *ny = (y - prm[3]) / prm[1]; }
+    amc::cam::cam_from_img(model, prm, x, y, *nx, *ny);
+}
+// Camera::CamFromImg / CamFromImgThreshold / CalibrationMatrix of camera_math.h (host build)
+void shim_cam_from_img(int model, const double* prm, const double* xy, int n, double* uv) {
+    for (int i = 0; i < n; ++i) amc::cam::cam_from_img(model, prm, xy[2 * i], xy[2 * i + 1], uv[2 * i], uv[2 * i + 1]);
+}
+double shim_cam_from_img_threshold(int model, const double* prm, double t) {
+    return amc::cam::cam_from_img_threshold(model, prm, t);
 }
 static double shim_select(const std::vector<double>& c, size_t rank) {
     uint64_t K = 0;
@@ -67,8 +74,8 @@ void shim_pose(int model1, const double* prm1, int model2, const double* prm2, c
         pose_candidates_E(E, c);
     } else {
         double K1[9], K2[9];
-        calibration_matrix(model1, prm1, K1);
-        calibration_matrix(model2, prm2, K2);
+        amc::cam::calibration_matrix(model1, prm1, K1);
+        amc::cam::calibration_matrix(model2, prm2, K2);
         pose_candidates_H(H, K1, K2, c);
     }
     int best = 0;

@@ -1,0 +1,160 @@
+"""GPU parity tests of the calibrated path with COLMAP's distortion camera models: Camera::CamFromImg of every
+keypoint (camera.hip on the device for the polynomial models, host libm for the fisheye family / FOV), then
+E + F + H LO-RANSAC, model selection and the relative pose - bit for bit against the oracle, which lifts per
+matched point like upstream (/root/reference/pycolmap/estimators/essential_matrix.h:33-46)."""
+import numpy as np
+import pytest
+
+import colmap_db
+import oracle_lib as o
+from pycolmap_amd import _capi, synth
+from test_pose_gpu import assert_pose_equal
+from test_verify_gpu import assert_pair_equal
+
+pytestmark = pytest.mark.gpu
+MODELS = list(synth.EXAMPLE_CAMERAS)
+
+
+@pytest.mark.parametrize("model", MODELS)
+def test_cam_from_img_bit_exact(amc_ctx, model):
+    rng = np.random.default_rng(5)
+    prm = synth.EXAMPLE_CAMERAS[model]
+    xy = rng.uniform([0, 0], [1600, 1200], size=(5000, 2)).astype(np.float32).astype(np.float64)
+    got = amc_ctx.cam_from_img(model, prm, xy)
+    want = o.cam_from_img(o.make_camera(model, 1600, 1200, prm), xy)
+    np.testing.assert_array_equal(got.view(np.uint64), want.view(np.uint64))
+    assert len(amc_ctx.cam_from_img(model, prm, np.zeros((0, 2)))) == 0
+
+
+def test_cam_from_img_rejects_bad_parameter_vectors(amc_ctx):
+    with pytest.raises(_capi.AmcError):
+        amc_ctx.cam_from_img("OPENCV", (1000.0, 1000.0, 800.0, 600.0), np.zeros((1, 2)))     # 4 of 8 parameters
+    with pytest.raises(_capi.AmcError):
+        amc_ctx.cam_from_img(11, (1.0,), np.zeros((1, 2)))                                   # no such model
+    amc_ctx.reserve_slots(1)
+    with pytest.raises(_capi.AmcError):
+        amc_ctx.upload_camera(0, "SIMPLE_RADIAL", 1600, 1200, (1000.0, 800.0, 600.0), True)  # 3 of 4
+
+
+def _run(ctx, scenes, cams, priors, opts_kw=None, f64=False):
+    """scenes[i] seen through cams[i] = ((model1, params1), (model2, params2)); returns GPU + oracle results."""
+    opts_kw = opts_kw or {}
+    ctx.reserve_slots(2 * len(scenes))
+    for i, (sc, (c1, c2), prior) in enumerate(zip(scenes, cams, priors)):
+        for s, pts, c in ((2 * i, sc["pts1"], c1), (2 * i + 1, sc["pts2"], c2)):
+            if f64:
+                ctx.upload_points_f64(s, pts)
+            else:
+                ctx.upload_keypoints(s, pts.astype(np.float32))
+            ctx.upload_camera(s, c[0], sc["width"], sc["height"], c[1], prior)
+    s1 = np.arange(0, 2 * len(scenes), 2, dtype=np.uint32)
+    off = np.zeros(len(scenes) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(sc["matches"]) for sc in scenes])
+    matches = np.concatenate([sc["matches"] for sc in scenes])
+    tvg, mask, st = ctx.verify_pairs(s1, s1 + 1, off, matches, _capi.tvg_options(**opts_kw), seed=0)
+    want = []
+    for sc, (c1, c2), prior in zip(scenes, cams, priors):
+        want.append(o.estimate_two_view_geometry(
+            o.make_camera(c1[0], sc["width"], sc["height"], c1[1], prior=prior), sc["pts1"],
+            o.make_camera(c2[0], sc["width"], sc["height"], c2[1], prior=prior), sc["pts2"], sc["matches"],
+            o.tvg_default_options(**opts_kw), seed=0))
+    return tvg, mask, off, st, want
+
+
+@pytest.mark.parametrize("model", MODELS[2:])
+def test_calibrated_verification_per_model(amc_ctx, model):
+    rng = np.random.default_rng(100 + MODELS.index(model))
+    cam = (model, synth.EXAMPLE_CAMERAS[model])
+    pin = ("PINHOLE", synth.EXAMPLE_CAMERAS["PINHOLE"])
+    base = [synth.two_view_scene(rng, num_inliers=260, num_outliers=90),
+            synth.two_view_scene(rng, num_inliers=180, num_outliers=120, planar=True),
+            synth.two_view_scene(rng, num_inliers=90, num_outliers=110, noise=1.0),
+            synth.two_view_scene(rng, num_inliers=200, num_outliers=50)]
+    cams = [(cam, cam), (cam, pin), (pin, cam), (cam, cam)]
+    scenes = [synth.recamera_scene(sc, c1[0], c1[1], c2[0], c2[1]) for sc, (c1, c2) in zip(base, cams)]
+    priors = [True, True, True, False]    # the last pair runs F + H only (no prior focal length)
+    tvg, mask, off, st, want = _run(amc_ctx, scenes, cams, priors, dict(compute_relative_pose=1))
+    for p in range(len(scenes)):
+        assert_pair_equal(p, tvg, mask, off, want)
+        assert_pose_equal(st["pose"][p], want[p], f"{model} pair {p}")
+    assert _capi.CONFIG_NAMES[tvg["config"][0]] == "CALIBRATED" and tvg["num_trials"][0][0] > 0
+    assert tvg["num_trials"][3][0] == 0
+
+
+def test_recalibration_and_reupload_invalidate_the_lift(amc_ctx):
+    """The lifted keypoints are cached per slot: a new camera or new keypoints must replace them."""
+    rng = np.random.default_rng(9)
+    base = synth.two_view_scene(rng, num_inliers=200, num_outliers=60)
+    camA = ("SIMPLE_RADIAL", synth.EXAMPLE_CAMERAS["SIMPLE_RADIAL"])
+    camB = ("OPENCV", synth.EXAMPLE_CAMERAS["OPENCV"])
+    for cam in (camA, camB, camA):
+        sc = synth.recamera_scene(base, cam[0], cam[1], cam[0], cam[1])
+        for f64 in (False, True):
+            tvg, mask, off, st, want = _run(amc_ctx, [sc], [(cam, cam)], [True], f64=f64)
+            assert_pair_equal(0, tvg, mask, off, want)
+    # same slots, only the camera changes (keypoints stay): verify twice without reserve_slots
+    sc = synth.recamera_scene(base, camA[0], camA[1], camA[0], camA[1])
+    amc_ctx.reserve_slots(2)
+    amc_ctx.upload_keypoints(0, sc["pts1"].astype(np.float32))
+    amc_ctx.upload_keypoints(1, sc["pts2"].astype(np.float32))
+    off = np.array([0, len(sc["matches"])], dtype=np.uint64)
+    for cam in (camA, camB):
+        for s in (0, 1):
+            amc_ctx.upload_camera(s, cam[0], 1600, 1200, cam[1], True)
+        tvg, mask, _ = amc_ctx.verify_pairs([0], [1], off, sc["matches"], _capi.tvg_options(), seed=0)
+        oc = o.make_camera(cam[0], 1600, 1200, cam[1], prior=True)
+        w = o.estimate_two_view_geometry(oc, sc["pts1"], oc, sc["pts2"], sc["matches"], o.tvg_default_options(), seed=0)
+        assert_pair_equal(0, tvg, mask, off, [w])
+
+
+def test_single_pair_estimators_with_distorted_cameras(amc_ctx):
+    """amc_ransac_pairs(E) and amc_pose_pairs: essential_matrix_estimation's two halves
+    (/root/reference/pycolmap/estimators/essential_matrix.h:19-83) with an OPENCV and a fisheye camera."""
+    rng = np.random.default_rng(21)
+    c1 = ("OPENCV", synth.EXAMPLE_CAMERAS["OPENCV"])
+    c2 = ("RADIAL_FISHEYE", synth.EXAMPLE_CAMERAS["RADIAL_FISHEYE"])
+    sc = synth.recamera_scene(synth.two_view_scene(rng, num_inliers=220, num_outliers=70), c1[0], c1[1], c2[0], c2[1])
+    n = len(sc["matches"])
+    p1, p2 = sc["pts1"][sc["matches"][:, 0]], sc["pts2"][sc["matches"][:, 1]]
+    amc_ctx.reserve_slots(2)
+    amc_ctx.upload_points_f64(0, p1)
+    amc_ctx.upload_points_f64(1, p2)
+    amc_ctx.upload_camera(0, c1[0], 1600, 1200, c1[1], True)
+    amc_ctx.upload_camera(1, c2[0], 1600, 1200, c2[1], True)
+    ident = np.stack([np.arange(n), np.arange(n)], axis=1).astype(np.uint32)
+    off = np.array([0, n], dtype=np.uint64)
+    kw = dict(max_error=4.0, min_inlier_ratio=0.01, confidence=0.9999, min_num_trials=1000, max_num_trials=100000)
+    rep, mask = amc_ctx.ransac_pairs("E", [0], [1], off, ident, ransac=kw, seed=0)
+    oc1, oc2 = o.make_camera(c1[0], 1600, 1200, c1[1], prior=True), o.make_camera(c2[0], 1600, 1200, c2[1], prior=True)
+    n1, n2 = o.cam_from_img(oc1, p1), o.cam_from_img(oc2, p2)
+    kw["max_error"] = (o.cam_from_img_threshold(oc1, 4.0) + o.cam_from_img_threshold(oc2, 4.0)) / 2
+    w = o.ransac_estimate("E", n1, n2, o.ransac_options(**kw), seed=0)
+    assert bool(rep[0]["success"]) == w["success"] and int(rep[0]["num_inliers"]) == w["num_inliers"]
+    assert int(rep[0]["num_trials"]) == w["num_trials"] and w["num_inliers"] > 150
+    np.testing.assert_array_equal(rep[0]["model"].reshape(-1).view(np.uint64), w["model"].reshape(-1).view(np.uint64))
+    np.testing.assert_array_equal(mask.astype(bool), w["inliers"])
+    inl = ident[mask.astype(bool)]
+    got = amc_ctx.pose_pairs([0], [1], np.array([0, len(inl)], np.uint64), inl, [2], [rep[0]["model"]])
+    wp = o.estimate_two_view_geometry_pose(oc1, p1, oc2, p2, inl, 2, E=rep[0]["model"])
+    assert_pose_equal(got[0], wp, "E pose")
+
+
+def test_pipeline_with_simple_radial_database(tmp_path):
+    """match_exhaustive + verify_matches on a database whose cameras are SIMPLE_RADIAL with a prior focal length -
+    what extract_features writes by default with EXIF (/root/reference/pycolmap/pipeline/extract_features.h:149)."""
+    import pycolmap_amd as pycolmap
+    from test_pipeline_gpu import compare, expected_rows
+    rng = np.random.default_rng(4)
+    cam = ("SIMPLE_RADIAL", synth.EXAMPLE_CAMERAS["SIMPLE_RADIAL"])
+    images = synth.multiview_scene(rng, num_images=6, n_feats=512, camera=cam)
+    for im in images:
+        im["prior"] = True
+    db = tmp_path / "db.db"
+    ids = colmap_db.create(db, images)
+    pycolmap.match_exhaustive(db, matching_options={"block_size": 4},
+                              verification_options={"compute_relative_pose": True})
+    blocks = pycolmap._pycolmap._exhaustive_blocks(ids, 4)
+    exp_m, exp_t = expected_rows(images, ids, blocks, prior=True, tvg_kw=dict(compute_relative_pose=1))
+    assert compare(db, exp_m, exp_t) >= 5
+    got_m, got_t = colmap_db.read_all(db)
+    assert sum(t["config"] == 2 for t in got_t.values()) >= 5      # CALIBRATED through the distorted cameras

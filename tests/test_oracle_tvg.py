@@ -403,7 +403,7 @@ def test_relative_pose_skips_configs_without_geometry():
 
 # ------------------------------------------------------------------------- golden fixture ----
 def test_golden_fixture_pins_the_oracle():
-    """tests/golden/tvg_golden_v1.npz: the oracle still produces what it produced when the fixture was
+    """tests/golden/tvg_golden_v2.npz: the oracle still produces what it produced when the fixture was
     committed (configs, masks, trial counts, model / pose bit patterns), with and without the pose."""
     import tvg_golden
     n = 0
@@ -422,4 +422,4 @@ def test_golden_fixture_pins_the_oracle():
             for f in tvg_golden.FIELDS:
                 np.testing.assert_array_equal(tvg_golden.bits(r[f]), w[f], err_msg=f"{tag} {f}")
             n += 1
-    assert n == 24
+    assert n == 40

@@ -29,8 +29,8 @@ def expected_rows(images, ids, blocks, sift=(0.8, 0.7, True), prior=False, tvg_k
             m = o.match(a["descriptors"], b["descriptors"], *sift)
             tv = None
             if len(m) >= MIN_INL:
-                cam1 = o.make_camera("PINHOLE", a["width"], a["height"], a["params"], prior=prior)
-                cam2 = o.make_camera("PINHOLE", b["width"], b["height"], b["params"], prior=prior)
+                cam1 = o.make_camera(a.get("model", 1), a["width"], a["height"], a["params"], prior=prior)
+                cam2 = o.make_camera(b.get("model", 1), b["width"], b["height"], b["params"], prior=prior)
                 r = o.estimate_two_view_geometry(cam1, a["keypoints"][:, :2].astype(np.float64), cam2,
                                                  b["keypoints"][:, :2].astype(np.float64), m,
                                                  o.tvg_default_options(**(tvg_kw or {})))
@@ -145,6 +145,39 @@ def test_verify_matches_reads_stored_matches(tmp_path):
     assert st["pairs_matched"] == 0 and st["pairs_verified"] >= 2
     exp_m, exp_t = expected_rows(images, ids, [pairs])
     compare(db, exp_m, exp_t)
+
+
+def test_failed_call_leaves_stored_rows_alone(tmp_path):
+    """Imported matches (hloc style) with one index past the keypoints: verify_matches must raise and the database
+    must still hold every stored row - the deletes of a recomputed pair happen in the transaction that writes
+    its replacement rows, never before the device calls have succeeded."""
+    rng = np.random.default_rng(5)
+    images = synth.multiview_scene(rng, num_images=4, n_feats=512)
+    db = tmp_path / "db.db"
+    ids = colmap_db.create(db, images)
+    pairs = [(ids[0], ids[1]), (ids[1], ids[2]), (ids[2], ids[3])]
+    for k, (a, b) in enumerate(pairs):
+        m = o.match(images[ids.index(a)]["descriptors"], images[ids.index(b)]["descriptors"]).copy()
+        assert len(m) >= MIN_INL
+        if k == 1:
+            m[3, 1] = 100000            # past image b's 512 keypoints
+        colmap_db.write_matches(db, a, b, m)
+    before_m, before_t = colmap_db.read_all(db)
+    pairs_txt = tmp_path / "pairs.txt"
+    pairs_txt.write_text("\n".join(f"{images[ids.index(a)]['name']} {images[ids.index(b)]['name']}" for a, b in pairs))
+    with pytest.raises(ValueError, match="keypoints"):
+        pycolmap.verify_matches(db, pairs_txt)
+    after_m, after_t = colmap_db.read_all(db)
+    assert set(after_m) == set(before_m) and after_t == before_t == {}
+    for pid in before_m:
+        np.testing.assert_array_equal(after_m[pid], before_m[pid])
+    # with the bad pair left out the same call goes through and replaces nothing it should not
+    pairs_txt.write_text("\n".join(f"{images[ids.index(a)]['name']} {images[ids.index(b)]['name']}"
+                                   for a, b in (pairs[0], pairs[2])))
+    pycolmap.verify_matches(db, pairs_txt)
+    final_m, final_t = colmap_db.read_all(db)
+    assert set(final_m) == set(before_m) and len(final_t) == 2
+    np.testing.assert_array_equal(final_m[colmap_db.pair_id(*pairs[1])], before_m[colmap_db.pair_id(*pairs[1])])
 
 
 def test_match_exhaustive_with_relative_pose(tmp_path):

@@ -152,6 +152,33 @@ def test_watermark_and_option_variants(amc_ctx):
         assert_pair_equal(1, tvg, mask, off, want)
 
 
+def test_watermark_ransac_below_its_trial_cap(amc_ctx):
+    """min_num_trials below the watermark RANSAC's trial cap (18 at the default ratios; the C++ RANSACOptions
+    default is 0): its adaptive trial count decides when it stops.  Watermark-like scenes with a varying share
+    of translated points, so that the count lands on different sides of the cut-offs."""
+    rng = np.random.default_rng(17)
+    w, h = 1600, 1200
+    scenes = []
+    for n, frac in ((80, 1.0), (120, 0.9), (200, 0.75), (64, 0.72), (150, 0.6), (90, 0.95)):
+        x = np.r_[rng.uniform(5, 150, n // 2), rng.uniform(w - 150, w - 5, n - n // 2)]
+        y = rng.uniform(5, 150, n)
+        p1 = np.c_[x, y]
+        shift = np.where((rng.uniform(size=n) < frac)[:, None], np.array([3.0, -2.0]), rng.uniform(-60, 60, size=(n, 2)))
+        p2 = p1 + shift + rng.normal(0, 0.05, size=(n, 2))
+        scenes.append(dict(pts1=p1.astype(np.float32).astype(np.float64), pts2=p2.astype(np.float32).astype(np.float64),
+                           matches=np.c_[np.arange(n), np.arange(n)].astype(np.uint32), width=w, height=h, f=1200.0))
+    seen = set()
+    for mt in (0, 1, 2, 5, 17):
+        for kw in (dict(ransac=dict(min_num_trials=mt)),
+                   dict(ransac=dict(min_num_trials=mt, confidence=0.9, dyn_num_trials_multiplier=1.0)),
+                   dict(ransac=dict(min_num_trials=mt), watermark_min_inlier_ratio=0.5)):
+            tvg, mask, off, want = run_both(amc_ctx, scenes, [False] * len(scenes), kw)
+            for p in range(len(scenes)):
+                assert_pair_equal(p, tvg, mask, off, want)
+                seen.add((_capi.CONFIG_NAMES[tvg["config"][p]], int(tvg["num_trials"][p][3])))
+    assert any(c == "WATERMARK" for c, _ in seen) and len({t for _, t in seen}) >= 3
+
+
 def test_seed_changes_the_stream_and_is_reproducible(amc_ctx):
     rng = np.random.default_rng(3)
     sc = [synth.two_view_scene(rng, num_inliers=120, num_outliers=120)]
@@ -270,7 +297,7 @@ def test_non_finite_and_degenerate_inputs(amc_ctx):
 
 
 def test_golden_fixture(amc_ctx):
-    """The HIP path against the committed fixture (tests/golden/tvg_golden_v1.npz): every case, with and
+    """The HIP path against the committed fixture (tests/golden/tvg_golden_v2.npz): every case, with and
     without compute_relative_pose, option overrides included.  No oracle call in this test."""
     import tvg_golden
     cases = list(tvg_golden.cases())

@@ -1,10 +1,17 @@
-"""Loader of tests/golden/tvg_golden_v1.npz (made by tests/golden/make_tvg_golden.py)."""
+"""Loader of tests/golden/tvg_golden_v2.npz (made by tests/golden/make_tvg_golden.py)."""
 from pathlib import Path
 
 import numpy as np
 
-PATH = Path(__file__).parent / "golden" / "tvg_golden_v1.npz"
-CAMS = [("PINHOLE", (1200.0, 1200.0, 800.0, 600.0)), ("SIMPLE_PINHOLE", (1150.0, 805.0, 598.0))]
+PATH = Path(__file__).parent / "golden" / "tvg_golden_v2.npz"
+import sys
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+from pycolmap_amd import synth  # noqa: E402  (EXAMPLE_CAMERAS only: pure numpy)
+
+CAMS = [("PINHOLE", (1200.0, 1200.0, 800.0, 600.0)), ("SIMPLE_PINHOLE", (1150.0, 805.0, 598.0))] + \
+       [(m, synth.EXAMPLE_CAMERAS[m]) for m in ("SIMPLE_RADIAL", "RADIAL", "OPENCV", "OPENCV_FISHEYE", "FULL_OPENCV",
+                                                "FOV", "SIMPLE_RADIAL_FISHEYE", "RADIAL_FISHEYE",
+                                                "THIN_PRISM_FISHEYE")]
 FIELDS = ("E", "F", "H", "qvec", "tvec", "R")
 INT_OPTS = {"force_H_use", "detect_watermark", "min_num_trials", "max_num_trials", "min_num_inliers",
             "multiple_models", "compute_relative_pose"}
