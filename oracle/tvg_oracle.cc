@@ -934,9 +934,13 @@ Pt cam_from_img(const Camera& c, const Pt& p) {
     iterative_undistortion(c.model_id, extra, &u, &v);
     if (c.model_id == 10) {  // thin-prism fisheye: back from the equidistant angle to the plane
         const double theta = std::sqrt(u * u + v * v);
-        const double theta_cos_theta = theta * std::cos(theta);
+        // upstream: theta * ceres::cos(theta), ceres::sin(theta); GCC at -O2 turns the pair into one sincos
+        // call (cexpi) - made explicit so that it does not depend on the optimiser
+        double sin_theta, cos_theta;
+        ::sincos(theta, &sin_theta, &cos_theta);
+        const double theta_cos_theta = theta * cos_theta;
         if (theta_cos_theta > std::numeric_limits<double>::epsilon()) {
-            const double scale = std::sin(theta) / theta_cos_theta;
+            const double scale = sin_theta / theta_cos_theta;
             u *= scale;
             v *= scale;
         }

@@ -257,9 +257,14 @@ AMC_HD void cam_from_img(int model, const double* p, double x, double y, double&
 #if !defined(__HIP_DEVICE_COMPILE__)
     if (model == THIN_PRISM_FISHEYE) {
         const double theta = std::sqrt(u * u + v * v);
-        const double theta_cos_theta = theta * std::cos(theta);
+        // sin and cos of one argument: GCC (-O2, what COLMAP and the oracle are built with) merges the two
+        // calls into glibc's sincos, clang (this file's host pass) does not, and the two entry points are not
+        // bit-identical in the last ulp - call sincos outright on both sides
+        double sin_theta, cos_theta;
+        ::sincos(theta, &sin_theta, &cos_theta);
+        const double theta_cos_theta = theta * cos_theta;
         if (theta_cos_theta > 2.220446049250313e-16) {
-            const double scale = std::sin(theta) / theta_cos_theta;
+            const double scale = sin_theta / theta_cos_theta;
             u *= scale;
             v *= scale;
         }
