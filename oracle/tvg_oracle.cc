@@ -40,6 +40,18 @@
  *       (COLMAP's pipeline carries a thread_local PRNG across pairs and is therefore not
  *       reproducible run-to-run).
  * Compile with -ffp-contract=off (oracle/Makefile): no FMA contraction, IEEE double throughout.
+ *
+ * DEVIATION TOGGLES (oracle/Makefile builds one extra library per flag; tests/ref2 measures what each
+ * deviation does to configs / masks / trial counts):
+ *   -DORACLE_SEQ_SUMS         D3 off: every det_sum64 becomes the sequential sum COLMAP writes
+ *   -DORACLE_LAPACK_SVD       D1 off: null spaces, least-squares null vectors, the rank-2 projection and the
+ *                             pose SVDs come from LAPACK dgesvd (an actual SVD of the design matrix, as
+ *                             Eigen::JacobiSVD is) instead of Gauss-Jordan / Jacobi on A^T A
+ *   -DORACLE_COMPANION_ROOTS  D2 off: polynomial roots are the eigenvalues of the companion matrix (LAPACK
+ *                             dgeev), |imag| <= 1e-10 kept, in the solver's order - COLMAP's
+ *                             FindPolynomialRootsCompanionMatrix
+ * LAPACK is the LAPACKE interface of the OpenBLAS that scipy bundles, loaded at run time from the path in the
+ * environment variable ORACLE_LAPACK_LIB (tests/ref2/variants.py sets it).  The default build uses none of it.
  */
 #include <algorithm>
 #include <cmath>
@@ -47,9 +59,55 @@
 #include <cstring>
 #include <limits>
 #include <random>
+#include <string>
 #include <vector>
 
+#if defined(ORACLE_LAPACK_SVD) || defined(ORACLE_COMPANION_ROOTS)
+#include <dlfcn.h>
+
+#include <cstdio>
+#include <cstdlib>
+#define ORACLE_USES_LAPACK 1
+#endif
+
 namespace {
+
+#ifdef ORACLE_USES_LAPACK
+// LAPACKE (row-major layout = 101) entry points of scipy's OpenBLAS
+struct Lapack {
+    int (*dgesvd)(int, char, char, int, int, double*, int, double*, double*, int, double*, int, double*) = nullptr;
+    int (*dgeev)(int, char, char, int, double*, int, double*, double*, double*, int, double*, int) = nullptr;
+};
+Lapack& lapack() {
+    static Lapack L = [] {
+        Lapack l;
+        const char* path = std::getenv("ORACLE_LAPACK_LIB");
+        void* h = path ? dlopen(path, RTLD_NOW | RTLD_LOCAL) : nullptr;
+        if (!h) {
+            std::fprintf(stderr, "oracle: ORACLE_LAPACK_LIB not set or not loadable (%s)\n", path ? dlerror() : "unset");
+            std::abort();
+        }
+        for (const char* prefix : {"scipy_", ""}) {
+            if (!l.dgesvd) l.dgesvd = reinterpret_cast<decltype(l.dgesvd)>(dlsym(h, (std::string(prefix) + "LAPACKE_dgesvd").c_str()));
+            if (!l.dgeev) l.dgeev = reinterpret_cast<decltype(l.dgeev)>(dlsym(h, (std::string(prefix) + "LAPACKE_dgeev").c_str()));
+        }
+        if (!l.dgesvd || !l.dgeev) {
+            std::fprintf(stderr, "oracle: LAPACKE_dgesvd / LAPACKE_dgeev not found in %s\n", path);
+            std::abort();
+        }
+        return l;
+    }();
+    return L;
+}
+// A (m x n, row-major, preserved) = U diag(S) V^T, S descending; Vt n x n row-major (row k = k-th right singular
+// vector), U m x m row-major when asked for
+void lapack_svd(int m, int n, const double* A, double* S, double* U, double* Vt) {
+    std::vector<double> a(A, A + static_cast<size_t>(m) * n), superb(std::max(1, std::min(m, n))), udummy(1);
+    const int info = lapack().dgesvd(101, U ? 'A' : 'N', 'A', m, n, a.data(), n, S, U ? U : udummy.data(), U ? m : 1, Vt, n,
+                                     superb.data());
+    if (info != 0) std::fprintf(stderr, "oracle: dgesvd info %d\n", info);
+}
+#endif
 
 // ----------------------------------------------------------------------------------------------
 // options / types (mirrors of COLMAP structs; field names as pycolmap exposes them)
@@ -109,6 +167,11 @@ struct Report {
 // ----------------------------------------------------------------------------------------------
 template <typename F>
 double det_sum64(size_t n, F term) {
+#ifdef ORACLE_SEQ_SUMS
+    double acc = 0.0;  // D3 off: COLMAP's plain loop
+    for (size_t k = 0; k < n; ++k) acc += term(k);
+    return acc;
+#endif
     double p[64];
     for (int l = 0; l < 64; ++l) p[l] = 0.0;
     for (size_t k = 0; k < n; ++k) p[k & 63] += term(k);
@@ -299,6 +362,15 @@ void smallest_eigvec9(double* ata, double* x) {
 // null space of an R x 9 matrix (R <= 8) by Gauss-Jordan elimination with full pivoting.
 // Writes 9-R basis vectors into ns (row k = k-th basis vector).  a is destroyed.
 void nullspace9(int R, double* a /* R x 9 */, double* ns /* (9-R) x 9 */) {
+#ifdef ORACLE_LAPACK_SVD
+    {   // D1 off: the right singular vectors of the 9 - R smallest singular values, V.col(R + k) -> ns row k
+        double S[9], Vt[81];
+        lapack_svd(R, 9, a, S, nullptr, Vt);
+        for (int k = 0; k < 9 - R; ++k)
+            for (int j = 0; j < 9; ++j) ns[k * 9 + j] = Vt[(R + k) * 9 + j];
+        return;
+    }
+#endif
     int perm[9];
     for (int j = 0; j < 9; ++j) perm[j] = j;
     for (int r = 0; r < R; ++r) {
@@ -382,6 +454,45 @@ int roots_between(const double* c, int deg, const double* crit, int nc, double* 
 // all real roots of a polynomial of degree <= 10, ascending (D2): bottom-up over the chain of
 // derivatives (degree 1 first), each level bracketed by the roots of the level below.
 int real_roots(const double* c_in, int deg_in, double* roots) {
+#ifdef ORACLE_COMPANION_ROOTS
+    {   // D2 off: FindPolynomialRootsCompanionMatrix (colmap/math/polynomial.cc); c_in is low -> high here
+        int hi = deg_in;
+        while (hi > 0 && c_in[hi] == 0.0) --hi;  // RemoveLeadingZeros
+        const int degree = hi;
+        if (degree <= 0) return 0;
+        if (degree == 1) {  // FindLinearPolynomialRoots
+            roots[0] = -c_in[0] / c_in[1];
+            return 1;
+        }
+        if (degree == 2) {  // FindQuadraticPolynomialRoots
+            const double a = c_in[2], b = c_in[1], c = c_in[0];
+            const double b2 = b * b, d = b2 - 4 * a * c;
+            if (d >= 0) {
+                const double sqrt_d = std::sqrt(d);
+                const double a2 = 2 * a;
+                if (b >= 0) { roots[0] = (-b - sqrt_d) / a2; roots[1] = (2 * c) / (-b - sqrt_d); }
+                else { roots[0] = (2 * c) / (-b + sqrt_d); roots[1] = (-b + sqrt_d) / a2; }
+                return 2;
+            }
+            return 0;  // a complex pair
+        }
+        int lo = 0;
+        while (lo < hi && c_in[lo] == 0.0) ++lo;  // RemoveTrailingZeros: zero is a root
+        const int n = hi - lo;                     // size of the companion matrix
+        int nr = 0;
+        if (n >= 1) {
+            std::vector<double> C(static_cast<size_t>(n) * n, 0.0), wr(n), wi(n), dummy(1);
+            for (int i = 1; i < n; ++i) C[static_cast<size_t>(i) * n + (i - 1)] = 1.0;
+            for (int j = 0; j < n; ++j) C[j] = -c_in[hi - 1 - j] / c_in[hi];  // row 0 = -coeffs.tail / coeffs(0)
+            const int info = lapack().dgeev(101, 'N', 'N', n, C.data(), n, wr.data(), wi.data(), dummy.data(), 1, dummy.data(), 1);
+            if (info != 0) return 0;
+            for (int i = 0; i < n; ++i)
+                if (std::fabs(wi[i]) <= 1e-10) roots[nr++] = wr[i];  // kMaxRootImag at the call sites
+        }
+        if (lo > 0) roots[nr++] = 0.0;
+        return nr;
+    }
+#endif
     int deg = deg_in;
     while (deg > 0 && c_in[deg] == 0.0) --deg;
     if (deg == 0) return 0;
@@ -543,22 +654,54 @@ void accumulate_ata(size_t K, RowFn row, double* ata /* 81 */) {
         }
 }
 
+#ifdef ORACLE_LAPACK_SVD
+// D1 off: the `count` right singular vectors of the smallest singular values of the K x 9 design matrix,
+// out row k = V.col(9 - count + k) (Eigen's / LAPACK's descending order)
+template <typename RowFn>
+void lapack_null_vectors(size_t K, RowFn row, int count, double* out) {
+    std::vector<double> A(std::max<size_t>(K, 9) * 9, 0.0);  // padded with zero rows up to 9 x 9: full V either way
+    for (size_t k = 0; k < K; ++k) row(k, A.data() + k * 9);
+    const int m = static_cast<int>(std::max<size_t>(K, 9));
+    std::vector<double> S(9);
+    double Vt[81];
+    lapack_svd(m, 9, A.data(), S.data(), nullptr, Vt);
+    for (int k = 0; k < count; ++k)
+        for (int j = 0; j < 9; ++j) out[k * 9 + j] = Vt[(9 - count + k) * 9 + j];
+}
+#endif
+
 // FundamentalMatrixEightPointEstimator::Estimate
 std::vector<Mat3> estimate_f8(const std::vector<Pt>& p1, const std::vector<Pt>& p2) {
     std::vector<Pt> n1, n2;
     Mat3 T1, T2;
     center_and_normalize(p1, &n1, &T1);
     center_and_normalize(p2, &n2, &T2);
-    double ata[81];
-    accumulate_ata(p1.size(), [&](size_t k, double* r) {
+    auto f8_row = [&](size_t k, double* r) {
         r[0] = n1[k].x * n2[k].x; r[1] = n1[k].y * n2[k].x; r[2] = n2[k].x;
         r[3] = n1[k].x * n2[k].y; r[4] = n1[k].y * n2[k].y; r[5] = n2[k].y;
         r[6] = n1[k].x; r[7] = n1[k].y; r[8] = 1.0;
-    }, ata);
+    };
     double f[9];
+#ifdef ORACLE_LAPACK_SVD
+    lapack_null_vectors(p1.size(), f8_row, 1, f);
+#else
+    double ata[81];
+    accumulate_ata(p1.size(), f8_row, ata);
     smallest_eigvec9(ata, f);
+#endif
     Mat3 Fh;
     for (int k = 0; k < 9; ++k) Fh.m[k] = f[k];
+#ifdef ORACLE_LAPACK_SVD
+    {   // rank 2 as upstream: F = U diag(s0, s1, 0) V^T of the 3 x 3 SVD
+        double S3[3], U3[9], Vt3[9];
+        lapack_svd(3, 3, Fh.m, S3, U3, Vt3);
+        Mat3 Fr;
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j)
+                Fr.m[3 * i + j] = U3[3 * i] * S3[0] * Vt3[j] + U3[3 * i + 1] * S3[1] * Vt3[3 + j];
+        return {mat3_mul(mat3_mul(mat3_t(T2), Fr), T1)};
+    }
+#endif
     // rank 2: remove the component along the smallest right singular vector v3 of Fh
     // (= smallest eigenvector of Fh^T Fh):  F' = Fh - (Fh v3) v3^T
     double ftf[9], v[9];
@@ -601,10 +744,15 @@ std::vector<Mat3> estimate_h(const std::vector<Pt>& p1, const std::vector<Pt>& p
         for (size_t i = 0; i < 4; ++i) { row_a(i, A + i * 9); row_b(i, A + (4 + i) * 9); }
         nullspace9(8, A, h);
     } else {
-        double ata[81];
         // rows 0..N-1 are the "a" rows, N..2N-1 the "b" rows (COLMAP's i / j = N + i layout)
-        accumulate_ata(2 * N, [&](size_t k, double* r) { if (k < N) row_a(k, r); else row_b(k - N, r); }, ata);
+        auto h_row = [&](size_t k, double* r) { if (k < N) row_a(k, r); else row_b(k - N, r); };
+#ifdef ORACLE_LAPACK_SVD
+        lapack_null_vectors(2 * N, h_row, 1, h);
+#else
+        double ata[81];
+        accumulate_ata(2 * N, h_row, ata);
         smallest_eigvec9(ata, h);
+#endif
     }
     Mat3 Hh;
     for (int k = 0; k < 9; ++k) Hh.m[k] = h[k];
@@ -1234,6 +1382,9 @@ std::vector<Mat3> estimate_e5(const std::vector<Pt>& p1, const std::vector<Pt>& 
         for (size_t i = 0; i < 5; ++i) fill_row(i, A + i * 9);
         nullspace9(5, A, nsp);
     } else {
+#ifdef ORACLE_LAPACK_SVD
+        lapack_null_vectors(N, fill_row, 4, nsp);  // E = svd.matrixV().block<9, 4>(0, 5)
+#else
         double ata[81], v[81];
         accumulate_ata(N, fill_row, ata);
         jacobi_eigen(9, ata, v);
@@ -1244,6 +1395,7 @@ std::vector<Mat3> estimate_e5(const std::vector<Pt>& p1, const std::vector<Pt>& 
                 if (ata[order[j] * 9 + order[j]] < ata[order[i] * 9 + order[i]]) std::swap(order[i], order[j]);
         for (int k = 0; k < 4; ++k)
             for (int i = 0; i < 9; ++i) nsp[k * 9 + i] = v[i * 9 + order[3 - k]];
+#endif
     }
     // E(x,y,z) entries as linear forms: x*nsp[0] + y*nsp[1] + z*nsp[2] + nsp[3]
     P1 e[9];
@@ -1315,15 +1467,30 @@ std::vector<Mat3> estimate_e5(const std::vector<Pt>& p1, const std::vector<Pt>& 
     std::vector<Mat3> models;
     for (int i = 0; i < nr; ++i) {
         const double z = roots[i];
-        // solve the 2x2 system from rows 0,1 of B(z): [a0 b0; a1 b1] [x y]^T = -[c0 c1]^T
-        const double a0 = poly_eval(B[0][0].c, 3, z), b0 = poly_eval(B[0][1].c, 3, z), c0 = poly_eval(B[0][2].c, 4, z);
-        const double a1 = poly_eval(B[1][0].c, 3, z), b1 = poly_eval(B[1][1].c, 3, z), c1 = poly_eval(B[1][2].c, 4, z);
-        const double dd = a0 * b1 - a1 * b0;
-        const double x = (b0 * c1 - b1 * c0) / dd;
-        const double y = (a1 * c0 - a0 * c1) / dd;
-        // upstream takes (x, y, 1) from the unit null vector X of B(z) as X(0)/X(2), X(1)/X(2) and skips
-        // the root when |X(2)| < 1e-10, i.e. when |(x, y, 1)| > 1e10 (also drops a singular 2 x 2 system)
-        if (!(x * x + y * y + 1.0 < 1e20)) continue;
+        // (x, y, 1) spans the null space of B(z).  Upstream takes the last right singular vector X of the 3 x 3
+        // matrix (JacobiSVD), skips the root when |X(2)| < 1e-10 and uses X(0) / X(2), X(1) / X(2).  Here (D1) the
+        // null vector is the cross product of the two rows that give the longest one - the same direction, from
+        // all three rows like the SVD, without the SVD.
+        double Bz[3][3];
+        for (int k = 0; k < 3; ++k) {
+            Bz[k][0] = poly_eval(B[k][0].c, 3, z);
+            Bz[k][1] = poly_eval(B[k][1].c, 3, z);
+            Bz[k][2] = poly_eval(B[k][2].c, 4, z);
+        }
+        double X[3] = {0, 0, 0}, best_n2 = -1.0;
+        const int pairs[3][2] = {{0, 1}, {0, 2}, {1, 2}};
+        for (const auto& pr : pairs) {
+            const double* u = Bz[pr[0]];
+            const double* w = Bz[pr[1]];
+            const double c0 = u[1] * w[2] - u[2] * w[1], c1 = u[2] * w[0] - u[0] * w[2], c2 = u[0] * w[1] - u[1] * w[0];
+            const double n2 = c0 * c0 + c1 * c1 + c2 * c2;
+            if (n2 > best_n2) { best_n2 = n2; X[0] = c0; X[1] = c1; X[2] = c2; }
+        }
+        const double nn = std::sqrt(best_n2);
+        for (double& v : X) v = v / nn;
+        if (!(std::fabs(X[2]) >= 1e-10)) continue;  // also drops NaN
+        const double x = X[0] / X[2];
+        const double y = X[1] / X[2];
         Mat3 E;
         for (int k = 0; k < 9; ++k) E.m[k] = x * nsp[k] + y * nsp[9 + k] + z * nsp[18 + k] + nsp[27 + k];
         // essential_vec /= essential_vec.norm()
@@ -1390,6 +1557,15 @@ Mat3 calibration_matrix(const Camera& c) {  // Camera::CalibrationMatrix
 // A = U diag(S) V^T, S descending, from the eigen-decomposition of A^T A.  u_k = A v_k / s_k for the two
 // largest singular values, u_2 = u_0 x u_1 (so det U = +1 and a vanishing third singular value is fine).
 void svd3(const Mat3& A, Mat3* U, double S[3], Mat3* V) {
+#ifdef ORACLE_LAPACK_SVD
+    {
+        double Vt[9];
+        lapack_svd(3, 3, A.m, S, U->m, Vt);
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) V->m[3 * i + j] = Vt[3 * j + i];
+        return;
+    }
+#endif
     double ata[9], ev[9];
     const Mat3 At = mat3_t(A);
     const Mat3 P = mat3_mul(At, A);
@@ -1445,6 +1621,16 @@ V3 triangulate_point(const Mat3& R, const V3& t, const Pt& x1, const Pt& x2) {
         A[2][j] = x2.x * P2[2][j] - P2[0][j];
         A[3][j] = x2.y * P2[2][j] - P2[1][j];
     }
+#ifdef ORACLE_LAPACK_SVD
+    {
+        double S4[4], Vt4[16], Af[16];
+        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 4; ++j) Af[4 * i + j] = A[i][j];
+        lapack_svd(4, 4, Af, S4, nullptr, Vt4);
+        const double w4 = Vt4[12 + 3];
+        return V3{{Vt4[12] / w4, Vt4[13] / w4, Vt4[14] / w4}};
+    }
+#endif
     double ata[16], ev[16];
     for (int i = 0; i < 4; ++i)
         for (int j = 0; j < 4; ++j) {

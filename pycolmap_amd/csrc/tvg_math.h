@@ -717,12 +717,30 @@ AMC_HD int e5_models(const double* nsp, const E5Polys& P, const double* roots, i
     int nm = 0;
     for (int i = 0; i < nr; ++i) {
         const double z = roots[i];
-        const double a0 = poly_eval(B[0][0], 3, z), b0 = poly_eval(B[0][1], 3, z), c0 = poly_eval(B[0][2], 4, z);
-        const double a1 = poly_eval(B[1][0], 3, z), b1 = poly_eval(B[1][1], 3, z), c1 = poly_eval(B[1][2], 4, z);
-        const double dd = a0 * b1 - a1 * b0;
-        const double x = (b0 * c1 - b1 * c0) / dd;
-        const double y = (a1 * c0 - a0 * c1) / dd;
-        if (!(x * x + y * y + 1.0 < 1e20)) continue;
+        // null vector of B(z) = the longest cross product of two of its rows (the oracle's statement of
+        // upstream's JacobiSVD null vector X, skipped when |X(2)| < 1e-10)
+        double Bz[3][3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            Bz[k][0] = poly_eval(B[k][0], 3, z);
+            Bz[k][1] = poly_eval(B[k][1], 3, z);
+            Bz[k][2] = poly_eval(B[k][2], 4, z);
+        }
+        double X0 = 0.0, X1 = 0.0, X2 = 0.0, best_n2 = -1.0;
+#pragma unroll
+        for (int pr = 0; pr < 3; ++pr) {
+            const int iu = pr == 2 ? 1 : 0, iw = pr == 0 ? 1 : 2;
+            const double c0 = Bz[iu][1] * Bz[iw][2] - Bz[iu][2] * Bz[iw][1];
+            const double c1 = Bz[iu][2] * Bz[iw][0] - Bz[iu][0] * Bz[iw][2];
+            const double c2 = Bz[iu][0] * Bz[iw][1] - Bz[iu][1] * Bz[iw][0];
+            const double n2 = c0 * c0 + c1 * c1 + c2 * c2;
+            if (n2 > best_n2) { best_n2 = n2; X0 = c0; X1 = c1; X2 = c2; }
+        }
+        const double nn = dsqrt(best_n2);
+        X0 = X0 / nn; X1 = X1 / nn; X2 = X2 / nn;
+        if (!(dabs(X2) >= 1e-10)) continue;
+        const double x = X0 / X2;
+        const double y = X1 / X2;
         double* E = models + 9 * nm;
         for (int k = 0; k < 9; ++k) E[k] = x * nsp[k] + y * nsp[9 + k] + z * nsp[18 + k] + nsp[27 + k];
         double n2 = 0.0;

@@ -70,6 +70,36 @@ def test_oracle_vs_numpy_restatement(seed, opts):
     assert len(got) > 10  # the synthetic scene really produces matches
 
 
+def test_oracle_vs_numpy_at_full_size_4096():
+    """BASELINE's image size: 4096 x 4096, scene-like descriptors (hundreds of true matches, ties from
+    quantisation).  numpy side: exact Gram matrix through float64 BLAS (every partial sum < 2^53),
+    argmax = first maximum, second = second-largest with multiplicity, acos / ratio in float32 exactly as
+    A.2 writes them (no ambiguity margin: the comparison is bit for bit)."""
+    rng = np.random.default_rng(4096)
+    d1, d2 = synth.scene_images(rng, 2, 4096, num_landmarks=6000, visible_frac=0.4)
+    D = (d1.astype(np.float64) @ d2.astype(np.float64).T).astype(np.int32)
+
+    def one_way(M):
+        R, Cn = M.shape
+        best_idx = M.argmax(axis=1)
+        best = M[np.arange(R), best_idx]
+        second = np.maximum(np.partition(M, Cn - 2, axis=1)[:, Cn - 2], 0)
+        k = np.float32(1.0) / (np.float32(512.0) * np.float32(512.0))
+        a_b = np.arccos(np.minimum(k * best.astype(np.float32), np.float32(1.0)))
+        a_s = np.arccos(np.minimum(k * second.astype(np.float32), np.float32(1.0)))
+        assert a_b.dtype == np.float32
+        ok = (best > 0) & ~(a_b > np.float32(0.7)) & ~(a_b >= np.float32(0.8) * a_s)
+        return np.where(ok, best_idx, -1)
+
+    m12, m21 = one_way(D), one_way(D.T)
+    want = np.array([(i, j) for i, j in enumerate(m12) if j >= 0 and m21[j] == i], dtype=np.uint32).reshape(-1, 2)
+    got = oracle_lib.match(d1, d2)
+    assert len(want) > 300
+    # numpy's float32 arccos is not glibc's acosf bit for bit: rows whose test flips within one float32 ulp of a
+    # threshold may differ.  Count them instead of hiding them: there must be none here (seeded inputs).
+    np.testing.assert_array_equal(got, want)
+
+
 def _unit(k):
     v = np.zeros(128, np.uint8)
     v[k] = 255
