@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define AMC_ABI_VERSION 1
+#define AMC_ABI_VERSION 2
 #define AMC_DESC_DIM 128 /* SIFT descriptor bytes; /root/reference/pycolmap/feature/sift.h:76-77 */
 
 enum {
@@ -235,6 +235,14 @@ typedef struct amc_verify_result {
     amc_pose* pose;        /* npairs when opts.compute_relative_pose (then tvg[p].config == pose[p].config),
                               else NULL */
     double pose_kernel_ms; /* the pose kernel's share of kernel_ms */
+    /* Algorithmic work of the call, summed over its pairs and counted as COLMAP's sequential loops do it (every
+     * model of every trial up to the stopping trial x all correspondences, ...), for the FP64 roofline of the
+     * verification kernel (bench.py):
+     *   [0] Sampson residuals  [1] homography transfer residuals  [2] translation residuals
+     *   [3] 5-point minimal solves  [4] 7-point solves  [5] 4-point DLT solves
+     *   [6] local 5-point solves  [7] local 8-point solves  [8] local DLT solves
+     *   [9] inlier points summed over by the local solves  [10] 1-point (watermark) trials  [11] unused */
+    uint64_t work[12];
     void* _priv;
 } amc_verify_result;
 
@@ -275,6 +283,17 @@ int amc_verify_pairs(amc_ctx* ctx, const uint32_t* slot1, const uint32_t* slot2,
                      const uint64_t* match_offsets, const uint32_t* matches,
                      const amc_tvg_opts* opts, uint32_t seed, amc_verify_result* out);
 void amc_verify_result_free(amc_verify_result* r);
+
+/* FeatureMatcherWorker + VerifierWorker for one list of pairs (COLMAP's FeatureMatcherController::Match hands every
+ * matched pair on to the verifier, /root/reference/pycolmap/pipeline/match_features.h:45-47): amc_match_pairs, then
+ * amc_verify_pairs on every pair's matches - read by the verification kernel where the matcher left them in HBM,
+ * without the host round trip of calling the two entry points one after the other.  Results are those of the two
+ * calls: match_out as amc_match_pairs fills it; verify_out->tvg[p] / inlier_mask follow match_out->offsets (a pair
+ * with fewer than min_num_inliers matches comes back DEGENERATE, as EstimateTwoViewGeometry returns it).  Both
+ * images of every pair need descriptors, keypoints and a camera.  Free both results. */
+int amc_match_verify_pairs(amc_ctx* ctx, const uint32_t* slot1, const uint32_t* slot2, size_t npairs,
+                           const amc_match_opts* match_opts, const amc_tvg_opts* tvg_opts, uint32_t seed,
+                           amc_match_result* match_out, amc_verify_result* verify_out);
 
 /* EstimateTwoViewGeometryPose (/root/reference/pycolmap/estimators/two_view_geometry.h:153-159) on given
  * geometries: geoms[p] supplies config, E and H; inlier_matches (CSR, as amc_verify_pairs' matches)

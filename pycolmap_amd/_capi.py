@@ -28,7 +28,7 @@ EXPORTED_SYMBOLS = [
     "amc_tvg_opts_default", "amc_upload_keypoints", "amc_upload_camera", "amc_verify_pairs",
     "amc_verify_result_free", "amc_upload_points_f64", "amc_ransac_pairs", "amc_ransac_result_free",
     "amc_squared_sampson_error", "amc_match_guided_pairs", "amc_ctx_grow_slots", "amc_pose_pairs",
-    "amc_cam_from_img",
+    "amc_cam_from_img", "amc_match_verify_pairs",
 ]
 RANSAC_F, RANSAC_H, RANSAC_E = 0, 1, 2
 RANSAC_KINDS = {"F": RANSAC_F, "H": RANSAC_H, "E": RANSAC_E}
@@ -84,7 +84,8 @@ class Pose(C.Structure):
 class VerifyResult(C.Structure):
     _fields_ = [("npairs", C.c_size_t), ("tvg", C.POINTER(Tvg)), ("inlier_mask", C.POINTER(C.c_uint8)),
                 ("device_ms", C.c_double), ("kernel_ms", C.c_double), ("kernel_launches", C.c_uint32),
-                ("pose", C.POINTER(Pose)), ("pose_kernel_ms", C.c_double), ("_priv", C.c_void_p)]
+                ("pose", C.POINTER(Pose)), ("pose_kernel_ms", C.c_double), ("work", C.c_uint64 * 12),
+                ("_priv", C.c_void_p)]
 
 
 class RansacReport(C.Structure):
@@ -257,21 +258,66 @@ class Context:
                                          s2.ctypes.data_as(C.c_void_p), s1.size, C.byref(opts),
                                          C.byref(res)))
         try:
-            n = int(res.npairs)
-            offsets = np.ctypeslib.as_array(res.offsets, shape=(n + 1,)).copy()
-            total = int(offsets[-1])
-            if total:
-                matches = np.ctypeslib.as_array(res.matches, shape=(total, 2)).copy()
-            else:
-                matches = np.zeros((0, 2), dtype=np.uint32)
-            stats = dict(num_distances=int(res.num_distances), pairs_mfma=int(res.pairs_mfma),
-                         pairs_dot4=int(res.pairs_dot4), device_ms=float(res.device_ms),
-                         match_kernel_ms=float(res.match_kernel_ms),
-                         cross_kernel_ms=float(res.cross_kernel_ms),
-                         match_kernel_launches=int(res.match_kernel_launches))
+            offsets, matches, stats = self._unpack_match(res)
         finally:
             self._lib.amc_match_result_free(C.byref(res))
         return offsets, matches, stats
+
+    @staticmethod
+    def _unpack_match(res):
+        n = int(res.npairs)
+        offsets = np.ctypeslib.as_array(res.offsets, shape=(n + 1,)).copy()
+        total = int(offsets[-1])
+        if total:
+            matches = np.ctypeslib.as_array(res.matches, shape=(total, 2)).copy()
+        else:
+            matches = np.zeros((0, 2), dtype=np.uint32)
+        stats = dict(num_distances=int(res.num_distances), pairs_mfma=int(res.pairs_mfma),
+                     pairs_dot4=int(res.pairs_dot4), device_ms=float(res.device_ms),
+                     match_kernel_ms=float(res.match_kernel_ms),
+                     cross_kernel_ms=float(res.cross_kernel_ms),
+                     match_kernel_launches=int(res.match_kernel_launches))
+        return offsets, matches, stats
+
+    @staticmethod
+    def _unpack_verify(res, total):
+        n = int(res.npairs)
+        assert C.sizeof(Tvg) == TVG_DTYPE.itemsize
+        tvg = (np.frombuffer(C.string_at(res.tvg, n * C.sizeof(Tvg)), dtype=TVG_DTYPE).copy() if n
+               else np.zeros(0, dtype=TVG_DTYPE))
+        labels = (np.ctypeslib.as_array(res.inlier_mask, shape=(total,)).copy() if total
+                  else np.zeros(0, dtype=np.uint8))
+        mask = labels.astype(bool)
+        # inlier_labels: 1 + index of the geometry a match belongs to (multiple_models), else 0 / 1
+        stats = dict(device_ms=float(res.device_ms), kernel_ms=float(res.kernel_ms), inlier_labels=labels,
+                     kernel_launches=int(res.kernel_launches), work=[int(x) for x in res.work])
+        stats["pose_kernel_ms"] = float(res.pose_kernel_ms)
+        if res.pose:  # compute_relative_pose: one amc_pose per pair
+            assert C.sizeof(Pose) == POSE_DTYPE.itemsize
+            stats["pose"] = (np.frombuffer(C.string_at(res.pose, n * C.sizeof(Pose)), dtype=POSE_DTYPE).copy()
+                             if n else np.zeros(0, dtype=POSE_DTYPE))
+        return tvg, mask, stats
+
+    def match_verify_pairs(self, slot1, slot2, opts: TvgOpts | None = None, seed: int = 0, max_ratio: float = 0.8,
+                           max_distance: float = 0.7, cross_check: bool = True, kernel: str = "auto"):
+        """amc_match_verify_pairs: match every pair, then EstimateTwoViewGeometry on its matches where the matcher
+        left them in HBM.  Returns (offsets, matches, match stats, tvg, inlier_mask, verify stats)."""
+        s1 = np.ascontiguousarray(slot1, dtype=np.uint32)
+        s2 = np.ascontiguousarray(slot2, dtype=np.uint32)
+        if s1.shape != s2.shape or s1.ndim != 1:
+            raise ValueError("slot1/slot2 must be equal-length 1-D arrays")
+        mo = MatchOpts(max_ratio, max_distance, 1 if cross_check else 0, KERNELS[kernel])
+        o = opts or tvg_options()
+        mres, vres = MatchResult(), VerifyResult()
+        _check(self._lib.amc_match_verify_pairs(self._h, s1.ctypes.data_as(C.c_void_p), s2.ctypes.data_as(C.c_void_p),
+                                                s1.size, C.byref(mo), C.byref(o), seed, C.byref(mres), C.byref(vres)))
+        try:
+            offsets, matches, mstats = self._unpack_match(mres)
+            tvg, mask, vstats = self._unpack_verify(vres, matches.shape[0])
+        finally:
+            self._lib.amc_match_result_free(C.byref(mres))
+            self._lib.amc_verify_result_free(C.byref(vres))
+        return offsets, matches, mstats, tvg, mask, vstats
 
     def match_guided_pairs(self, slot1, slot2, tvg, max_error: float, max_ratio: float = 0.8,
                            max_distance: float = 0.7, cross_check: bool = True):
@@ -397,24 +443,7 @@ class Context:
                                           s1.size, off.ctypes.data_as(C.c_void_p), m.ctypes.data_as(C.c_void_p),
                                           C.byref(o), seed, C.byref(res)))
         try:
-            n = int(res.npairs)
-            assert C.sizeof(Tvg) == TVG_DTYPE.itemsize
-            if n:
-                buf = C.string_at(res.tvg, n * C.sizeof(Tvg))
-                tvg = np.frombuffer(buf, dtype=TVG_DTYPE).copy()
-            else:
-                tvg = np.zeros(0, dtype=TVG_DTYPE)
-            total = m.shape[0]
-            labels = (np.ctypeslib.as_array(res.inlier_mask, shape=(total,)).copy() if total
-                      else np.zeros(0, dtype=np.uint8))
-            mask = labels.astype(bool)
-            # inlier_labels: 1 + index of the geometry a match belongs to (multiple_models), else 0 / 1
-            stats = dict(device_ms=float(res.device_ms), kernel_ms=float(res.kernel_ms), inlier_labels=labels)
-            stats["pose_kernel_ms"] = float(res.pose_kernel_ms)
-            if res.pose:  # compute_relative_pose: one amc_pose per pair
-                assert C.sizeof(Pose) == POSE_DTYPE.itemsize
-                stats["pose"] = (np.frombuffer(C.string_at(res.pose, n * C.sizeof(Pose)), dtype=POSE_DTYPE).copy()
-                                 if n else np.zeros(0, dtype=POSE_DTYPE))
+            tvg, mask, stats = self._unpack_verify(res, m.shape[0])
         finally:
             self._lib.amc_verify_result_free(C.byref(res))
         return tvg, mask, stats

@@ -131,6 +131,9 @@ struct amc_ctx {
     DevBuf<uint32_t> d_accmask;  // one accept bit per row-table entry (mfma pairs)
     DevBuf<GuidedDev> d_guided;  // guided matching: one filter model per pair of the batch
     DevBuf<uint32_t> d_pair_off, d_pair_cnt, d_matches, d_cand_cnt, d_candbuf;
+    // amc_match_verify_pairs: the matches of every batch of the call stay here (appended batch after batch), so
+    // that the verification kernel reads them where the matcher left them instead of from a host round trip
+    DevBuf<uint32_t> d_keep;
     // host staging of a match batch, two sets: batch k+1 is prepared and enqueued while the results of
     // batch k are still being copied out and scattered (match_impl)
     PinBuf<PairDev> h_pairs[2];
@@ -245,7 +248,7 @@ void amc_ctx_destroy(amc_ctx* c) {
     c->d_pairs.release(); c->d_work.release(); c->d_order.release(); c->d_order2.release();
     c->d_rowbuf.release(); c->d_colbuf.release(); c->d_accmask.release(); c->d_guided.release();
     c->d_pair_off.release(); c->d_pair_cnt.release(); c->d_matches.release();
-    c->d_cand_cnt.release(); c->d_candbuf.release();
+    c->d_cand_cnt.release(); c->d_candbuf.release(); c->d_keep.release();
     for (int k = 0; k < 2; ++k) {
         c->h_pairs[k].release(); c->h_work[k].release(); c->h_order[k].release(); c->h_order2[k].release();
         c->h_pair_off[k].release(); c->h_pair_cnt[k].release(); c->h_matches[k].release();
@@ -378,9 +381,11 @@ constexpr size_t kMaxMatchCap = (size_t)256 << 20;     // worst-case matches of 
 
 // amc_match_pairs, and with `geoms` != nullptr guided matching (every pair then runs the dot4
 // kernel with the pair's float32 filter; geoms[p] must have a configuration COLMAP guides on)
+// keep_off != nullptr: the matches also stay on the device (c->d_keep) and keep_off[p] receives the position
+// (in matches) of pair p's list there.
 static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, size_t npairs,
                       const amc_match_opts* opts_in, const amc_tvg* geoms, double max_error,
-                      amc_match_result* out) {
+                      amc_match_result* out, std::vector<uint64_t>* keep_off = nullptr) {
     if (!c || !out) return fail(AMC_E_INVALID, "amc_match_pairs: NULL ctx/out");
     std::memset(out, 0, sizeof *out);
     if (npairs > 0 && (!slot1 || !slot2))
@@ -435,6 +440,8 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
     ResultPriv* priv = new (std::nothrow) ResultPriv();
     if (!priv) return fail(AMC_E_NOMEM, "amc_match_pairs: out of host memory");
     priv->offsets.assign(npairs + 1, 0);
+    size_t keep_used = 0;  // matches appended to c->d_keep so far
+    if (keep_off) keep_off->assign(npairs, 0);
 
     const float max_ratio_f = (float)o.max_ratio;
     const size_t mfma_max_cols = kSelectMaxCols;  // cross-check candidate bitmap (image 2 rows)
@@ -675,6 +682,27 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
              !hc(hipMemcpyAsync(c->h_matches[k].p, c->d_matches.p, (size_t)b.total * 2 * sizeof(uint32_t),
                                 hipMemcpyDeviceToHost, st), "D2H matches")))
             return false;
+        if (keep_off) {
+            // append the batch to the resident table (in stream order, before the next batch reuses d_matches)
+            const size_t need = 2 * (keep_used + (size_t)b.total);
+            if (need > c->d_keep.cap) {
+                DevBuf<uint32_t> bigger;
+                if (!hc(bigger.ensure(std::max(need, 2 * c->d_keep.cap)), "resident match table")) return false;
+                if (keep_used &&
+                    !hc(hipMemcpyAsync(bigger.p, c->d_keep.p, 2 * keep_used * sizeof(uint32_t), hipMemcpyDeviceToDevice, st),
+                        "move resident match table"))
+                    return false;
+                if (!hc(hipStreamSynchronize(st), "sync before freeing the old resident table")) return false;
+                c->d_keep.release();
+                c->d_keep = bigger;
+            }
+            if (b.total &&
+                !hc(hipMemcpyAsync(c->d_keep.p + 2 * keep_used, c->d_matches.p, (size_t)b.total * 2 * sizeof(uint32_t),
+                                   hipMemcpyDeviceToDevice, st), "D2D matches"))
+                return false;
+            for (size_t i = 0; i < b.nb; ++i) (*keep_off)[b.begin + i] = keep_used + c->h_pair_off[k].p[i];
+            keep_used += b.total;
+        }
         return hc(hipEventRecord(c->bev[k][4], st), "event record");
     };
     // append the batch's matches to the result CSR (pairs keep the caller's order)
@@ -1025,10 +1053,12 @@ void pose_default(amc_pose* q, int32_t config) {
 // kernel_ms (optional): the pose kernel's duration.
 static int pose_impl(amc_ctx* c, const char* who, const uint32_t* slot1, const uint32_t* slot2, size_t npairs,
                      const uint64_t* match_offsets, const uint32_t* inlier_matches, const amc_tvg* geoms,
-                     amc_pose* out, double* kernel_ms, const uint64_t* resident_mask_off = nullptr) {
-    // resident_mask_off != nullptr (amc_verify_pairs): the matches of this call are still in d_tmatches
-    // (same offsets) and pair p's inlier bytes at d_toutmask + resident_mask_off[p]; nothing is uploaded
-    // again and the kernel takes the rows whose byte is set.  Their indices have been checked.
+                     amc_pose* out, double* kernel_ms, const uint64_t* resident_mask_off = nullptr,
+                     const uint32_t* resident_matches = nullptr, const uint64_t* resident_match_off = nullptr) {
+    // resident_mask_off != nullptr (amc_verify_pairs): the matches of this call are still on the device - at
+    // resident_matches, pair p's list at resident_match_off[p] (default: d_tmatches, the call's CSR offsets) - and
+    // pair p's inlier bytes at d_toutmask + resident_mask_off[p]; nothing is uploaded again and the kernel takes the
+    // rows whose byte is set.  Their indices have been checked.
     const bool resident = resident_mask_off != nullptr;
     if (kernel_ms) *kernel_ms = 0.0;
     if (!c) return fail(AMC_E_INVALID, "%s: NULL ctx", who);
@@ -1062,7 +1092,8 @@ static int pose_impl(amc_ctx* c, const char* who, const uint32_t* slot1, const u
                                 (unsigned long long)(k - match_offsets[p]));
         pp[p].slot1 = slot1[p];
         pp[p].slot2 = slot2[p];
-        pp[p].match_off = match_offsets[p];
+        pp[p].match_off = (resident && resident_match_off) ? resident_match_off[p] : match_offsets[p];
+        pp[p].ws_off = match_offsets[p];
         pp[p].mask_off = resident ? resident_mask_off[p] : 0;
         pp[p].M = (uint32_t)M;
         pp[p].config = cfg;
@@ -1088,7 +1119,8 @@ static int pose_impl(amc_ctx* c, const char* who, const uint32_t* slot1, const u
     if (total && !resident)
         HIPCHK(hipMemcpyAsync(c->d_pmatches.p, inlier_matches, 2 * total * sizeof(uint32_t), hipMemcpyHostToDevice, st));
     HIPCHK(hipEventRecord(c->ev[4], st));
-    HIPCHK(launch_pose(c->d_timgs.p, c->d_ppairs.p, (uint32_t)npairs, resident ? c->d_tmatches.p : c->d_pmatches.p,
+    HIPCHK(launch_pose(c->d_timgs.p, c->d_ppairs.p, (uint32_t)npairs,
+                       resident ? (resident_matches ? resident_matches : c->d_tmatches.p) : c->d_pmatches.p,
                        resident ? c->d_toutmask.p : nullptr, c->d_pcos.p, c->d_pout.p, st));
     HIPCHK(hipEventRecord(c->ev[5], st));
     std::vector<PoseOut> h(npairs);
@@ -1124,9 +1156,12 @@ static int pose_impl(amc_ctx* c, const char* who, const uint32_t* slot1, const u
 
 // mode 0: EstimateTwoViewGeometry; 1 / 2 / 3: a single F / H / E LO-RANSAC per pair, reported
 // through the same record (config = success, num_inliers, the model, its trial count, the mask)
+// dev_matches != nullptr (amc_match_verify_pairs): the matches are already on this device - pair p's list starts at
+// dev_matches + 2 * dev_off[p] and has match_offsets[p + 1] - match_offsets[p] rows; `matches` is not read.
 static int verify_impl(amc_ctx* c, int mode, const uint32_t* slot1, const uint32_t* slot2, size_t npairs,
                        const uint64_t* match_offsets, const uint32_t* matches,
-                       const amc_tvg_opts* opts_in, uint32_t seed, amc_verify_result* out) {
+                       const amc_tvg_opts* opts_in, uint32_t seed, amc_verify_result* out,
+                       const uint32_t* dev_matches = nullptr, const uint64_t* dev_off = nullptr) {
     if (!c || !out) return fail(AMC_E_INVALID, "amc_verify_pairs: NULL ctx/out");
     std::memset(out, 0, sizeof *out);
     if (npairs > 0 && (!slot1 || !slot2 || !match_offsets))
@@ -1140,7 +1175,7 @@ static int verify_impl(amc_ctx* c, int mode, const uint32_t* slot1, const uint32
     if (o.ransac.max_num_trials < 0 || o.ransac.min_num_trials < 0 || o.ransac.max_num_trials > (1 << 30))
         return fail(AMC_E_INVALID, "amc_verify_pairs: bad trial limits");
     const uint64_t total = npairs ? match_offsets[npairs] : 0;
-    if (total > 0 && !matches) return fail(AMC_E_INVALID, "amc_verify_pairs: NULL matches");
+    if (total > 0 && !matches && !dev_matches) return fail(AMC_E_INVALID, "amc_verify_pairs: NULL matches");
     uint32_t maxM = 0;
     std::vector<uint8_t> need_lift(c->slots.size(), 0);
     for (size_t p = 0; p < npairs; ++p) {
@@ -1159,7 +1194,7 @@ static int verify_impl(amc_ctx* c, int mode, const uint32_t* slot1, const uint32
         maxM = std::max<uint32_t>(maxM, (uint32_t)M);
         // Match indices are checked by the kernel where it gathers the points (bad_index_count below); only
         // the pairs it returns from before that - fewer matches than min_num_inliers - are checked here.
-        if (mode == 0 && M < (uint64_t)std::max(o.min_num_inliers, 0)) {
+        if (mode == 0 && !dev_matches && M < (uint64_t)std::max(o.min_num_inliers, 0)) {
             const uint32_t* mm = matches + 2 * match_offsets[p];
             for (uint64_t k = 0; k < M; ++k)
                 if (mm[2 * k] >= a.kp_rows || mm[2 * k + 1] >= b.kp_rows)
@@ -1282,7 +1317,7 @@ static int verify_impl(amc_ctx* c, int mode, const uint32_t* slot1, const uint32
         }
         tp[p].slot1 = slot1[p];
         tp[p].slot2 = slot2[p];
-        tp[p].match_off = match_offsets[p];
+        tp[p].match_off = dev_matches ? dev_off[p] : match_offsets[p];
         tp[p].mask_off = mask_bytes;
         mask_bytes += ((uint64_t)M + 127) / 128 * 128;
         tp[p].M = M;
@@ -1313,14 +1348,15 @@ static int verify_impl(amc_ctx* c, int mode, const uint32_t* slot1, const uint32
         }
     }
     HIPCHK(c->d_timgs.ensure(timgs.size()));
-    HIPCHK(c->d_tmatches.ensure(std::max<size_t>(2 * total, 2)));
+    if (!dev_matches) HIPCHK(c->d_tmatches.ensure(std::max<size_t>(2 * total, 2)));
     HIPCHK(c->d_ttabs.ensure(std::max<size_t>(tabs.size(), 1)));
     HIPCHK(c->d_mtinit.ensure(624));
     HIPCHK(c->d_toutmask.ensure(std::max<size_t>(mask_bytes, 128)));
     HIPCHK(hipEventRecord(c->ev[0], st));
     HIPCHK(hipMemcpyAsync(c->d_timgs.p, timgs.data(), timgs.size() * sizeof(TvgImage), hipMemcpyHostToDevice, st));
-    if (total)
+    if (total && !dev_matches)
         HIPCHK(hipMemcpyAsync(c->d_tmatches.p, matches, 2 * total * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    const uint32_t* kernel_matches = dev_matches ? dev_matches : c->d_tmatches.p;
     if (!tabs.empty())
         HIPCHK(hipMemcpyAsync(c->d_ttabs.p, tabs.data(), tabs.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(c->d_mtinit.p, mt0, sizeof mt0, hipMemcpyHostToDevice, st));
@@ -1365,7 +1401,7 @@ static int verify_impl(amc_ctx* c, int mode, const uint32_t* slot1, const uint32
         HIPCHK(hipMemcpyAsync(c->d_tpairs.p, sub.data(), sub.size() * sizeof(TvgPair), hipMemcpyHostToDevice, st));
         HIPCHK(hipStreamSynchronize(st));  // `sub` goes out of scope at the end of the iteration
         HIPCHK(hipEventRecord(c->ev[2], st));
-        HIPCHK(launch_tvg(c->d_timgs.p, c->d_tpairs.p, (uint32_t)idx.size(), c->d_tmatches.p, c->d_ttabs.p,
+        HIPCHK(launch_tvg(c->d_timgs.p, c->d_tpairs.p, (uint32_t)idx.size(), kernel_matches, c->d_ttabs.p,
                           c->d_mtinit.p, P, c->d_tws.p, c->d_tmaskws.p, mcap, num_waves, wpb, c->d_scalars + 1,
                           c->d_tout.p, c->d_toutmask.p, st));
         HIPCHK(hipEventRecord(c->ev[3], st));
@@ -1387,7 +1423,7 @@ static int verify_impl(amc_ctx* c, int mode, const uint32_t* slot1, const uint32
     if (bad_pairs) {  // the kernel met an index past an image's keypoints: find it for the message
         delete priv;
         std::memset(out, 0, sizeof *out);
-        for (size_t p = 0; p < npairs; ++p) {
+        for (size_t p = 0; p < npairs && matches; ++p) {
             const Slot& a = c->slots[slot1[p]];
             const Slot& b = c->slots[slot2[p]];
             for (uint64_t k = match_offsets[p]; k < match_offsets[p + 1]; ++k)
@@ -1417,6 +1453,8 @@ static int verify_impl(amc_ctx* c, int mode, const uint32_t* slot1, const uint32
     out->device_ms = ms;
     out->kernel_ms = kernel_ms;
     out->kernel_launches = launches;
+    for (size_t p = 0; p < npairs; ++p)
+        for (int i = 0; i < 12; ++i) out->work[i] += h_out[p].work[i];
     if (o.compute_relative_pose) {
         // EstimateTwoViewGeometryPose on the selected inlier matches (mask order = match order): the matches
         // and the masks of this call are still on the device
@@ -1425,7 +1463,7 @@ static int verify_impl(amc_ctx* c, int mode, const uint32_t* slot1, const uint32
         priv->pose.resize(npairs);
         double pose_ms = 0.0;
         const int rc = pose_impl(c, "amc_verify_pairs", slot1, slot2, npairs, match_offsets, matches, priv->tvg.data(),
-                                 priv->pose.data(), &pose_ms, moff.data());
+                                 priv->pose.data(), &pose_ms, moff.data(), dev_matches, dev_off);
         if (rc != AMC_OK) {
             delete priv;
             std::memset(out, 0, sizeof *out);
@@ -1474,6 +1512,7 @@ static int verify_multiple(amc_ctx* c, const uint32_t* slot1, const uint32_t* sl
         active.push_back(p);
     }
     double device_ms = 0.0, kernel_ms = 0.0, pose_ms = 0.0;
+    uint64_t work[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t launches = 0;
     int rc = AMC_OK;
     for (int round = 0; round < 254 && !active.empty() && rc == AMC_OK; ++round) {
@@ -1495,6 +1534,7 @@ static int verify_multiple(amc_ctx* c, const uint32_t* slot1, const uint32_t* sl
         if (rc != AMC_OK) break;
         device_ms += r.device_ms;
         kernel_ms += r.kernel_ms;
+        for (int i = 0; i < 12; ++i) work[i] += r.work[i];
         pose_ms += r.pose_kernel_ms;
         launches += r.kernel_launches;
         std::vector<size_t> still;
@@ -1553,6 +1593,7 @@ static int verify_multiple(amc_ctx* c, const uint32_t* slot1, const uint32_t* sl
     out->device_ms = device_ms;
     out->kernel_ms = kernel_ms;
     out->kernel_launches = launches;
+    for (int i = 0; i < 12; ++i) out->work[i] = work[i];
     return AMC_OK;
 }
 
@@ -1562,6 +1603,28 @@ int amc_verify_pairs(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, s
     if (c && out && opts_in && opts_in->multiple_models)
         return verify_multiple(c, slot1, slot2, npairs, match_offsets, matches, *opts_in, seed, out);
     return verify_impl(c, 0, slot1, slot2, npairs, match_offsets, matches, opts_in, seed, out);
+}
+
+int amc_match_verify_pairs(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, size_t npairs,
+                           const amc_match_opts* match_opts, const amc_tvg_opts* tvg_opts, uint32_t seed,
+                           amc_match_result* match_out, amc_verify_result* verify_out) {
+    if (!c || !match_out || !verify_out) return fail(AMC_E_INVALID, "amc_match_verify_pairs: NULL ctx/out");
+    std::memset(verify_out, 0, sizeof *verify_out);
+    if (tvg_opts && tvg_opts->multiple_models) {
+        // EstimateMultipleTwoViewGeometries shrinks the match lists on the host between rounds: no resident path
+        int rc = match_impl(c, slot1, slot2, npairs, match_opts, nullptr, 0.0, match_out);
+        if (rc != AMC_OK) return rc;
+        rc = amc_verify_pairs(c, slot1, slot2, npairs, match_out->offsets, match_out->matches, tvg_opts, seed, verify_out);
+        if (rc != AMC_OK) amc_match_result_free(match_out);
+        return rc;
+    }
+    std::vector<uint64_t> keep_off;
+    int rc = match_impl(c, slot1, slot2, npairs, match_opts, nullptr, 0.0, match_out, &keep_off);
+    if (rc != AMC_OK) return rc;
+    rc = verify_impl(c, 0, slot1, slot2, npairs, match_out->offsets, match_out->matches, tvg_opts, seed, verify_out,
+                     c->d_keep.p ? c->d_keep.p : reinterpret_cast<const uint32_t*>(c->d_scalars), keep_off.data());
+    if (rc != AMC_OK) amc_match_result_free(match_out);
+    return rc;
 }
 
 int amc_pose_pairs(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, size_t npairs,

@@ -163,6 +163,7 @@ struct PosePair {
     uint32_t slot1, slot2;
     uint64_t match_off;
     uint64_t mask_off;   // with a mask: the pair's inlier bytes (amc_verify_pairs' device mask), row k counts if non-zero
+    uint64_t ws_off;     // the pair's M doubles of the cosine workspace
     uint32_t M;
     int32_t config;
     double E[9], H[9];
@@ -186,6 +187,10 @@ struct alignas(128) TvgOut {
     // shader-clock cycles spent per phase (diagnostics; printed with AMC_TVG_PROFILE=1):
     // 0 sampling, 1 minimal solvers, 2 scoring of sample models, 3 local optimisation, 4 total
     unsigned long long prof[8];
+    // algorithmic work of the pair (tvg.hip WK_*): residual evaluations by kind (Sampson, homography transfer,
+    // translation), minimal solves (5-point, 7-point, 4-point), local solves (5-point, 8-point, DLT), the inlier
+    // points those local solves summed over, 1-point trials - the inputs of bench.py's FP64 roofline
+    unsigned long long work[12];
 };
 struct TvgParams {
     int32_t min_num_inliers, detect_watermark, force_H_use, min_num_trials;

@@ -178,16 +178,24 @@ std::vector<MatchController::Job> MatchController::Compute(const ImagePairs& ima
             s2.push_back(SlotOf(jobs[k].id2));
             which.push_back(k);
         }
-    if (!which.empty()) {
-        amc_match_opts mo;
-        amc_match_opts_default(&mo);
-        mo.max_ratio = sift_.max_ratio;
-        mo.max_distance = sift_.max_distance;
-        mo.cross_check = sift_.cross_check;
-        amc_match_result r;
-        const double t_call = NowMs();
-        Check(amc_match_pairs(ctx_, s1.data(), s2.data(), which.size(), &mo, &r), "amc_match_pairs");
-        stats.match_call_ms += NowMs() - t_call;
+    amc_match_opts mo;
+    amc_match_opts_default(&mo);
+    mo.max_ratio = sift_.max_ratio;
+    mo.max_distance = sift_.max_distance;
+    mo.cross_check = sift_.cross_check;
+    const amc_tvg_opts to = ToAmc(tvg_);
+    const size_t min_inl = static_cast<size_t>(std::max(tvg_.min_num_inliers, 0));
+    // Nothing stored for any pair of the group (the usual match_* run): one fused call, the verification kernel
+    // reads every pair's matches where the matcher left them in HBM (no packing of a second match list on the
+    // host, no upload of it).  Pairs below min_num_inliers come back DEGENERATE and are dropped in Write().
+    const bool fused = which.size() == jobs.size() && !tvg_.multiple_models;
+    amc_verify_result vr;
+    std::memset(&vr, 0, sizeof vr);
+    std::vector<uint32_t> v1, v2, vmatches;
+    std::vector<uint64_t> voff{0};
+    std::vector<size_t> vwhich;
+    bool have_vr = false;
+    auto take_matches = [&](const amc_match_result& r) {
         for (size_t p = 0; p < which.size(); ++p) {
             Job& j = jobs[which[p]];
             j.matches.assign(r.matches + 2 * r.offsets[p], r.matches + 2 * r.offsets[p + 1]);
@@ -195,40 +203,60 @@ std::vector<MatchController::Job> MatchController::Compute(const ImagePairs& ima
         stats.match_device_ms += r.device_ms;
         stats.num_distances += r.num_distances;
         stats.pairs_matched += which.size();
+    };
+    if (fused) {
+        amc_match_result r;
+        const double t_call = NowMs();
+        Check(amc_match_verify_pairs(ctx_, s1.data(), s2.data(), which.size(), &mo, &to, /*seed=*/0, &r, &vr),
+              "amc_match_verify_pairs");
+        stats.match_call_ms += NowMs() - t_call;  // both stages: the device times below split it
+        take_matches(r);
+        v1 = s1;
+        v2 = s2;
+        vwhich = which;
+        voff.assign(r.offsets, r.offsets + which.size() + 1);
+        amc_match_result_free(&r);
+        have_vr = true;
+        for (const Job& j : jobs) stats.pairs_verified += j.matches.size() / 2 >= min_inl;
+    } else if (!which.empty()) {
+        amc_match_result r;
+        const double t_call = NowMs();
+        Check(amc_match_pairs(ctx_, s1.data(), s2.data(), which.size(), &mo, &r), "amc_match_pairs");
+        stats.match_call_ms += NowMs() - t_call;
+        take_matches(r);
         amc_match_result_free(&r);
     }
 
     // ---- VerifierWorker: only pairs with >= min_num_inliers matches are estimated ----------
-    const size_t min_inl = static_cast<size_t>(std::max(tvg_.min_num_inliers, 0));
-    std::vector<uint32_t> v1, v2, vmatches;
-    std::vector<uint64_t> voff{0};
-    std::vector<size_t> vwhich;
-    {
+    if (!fused) {
         size_t total = 0;
         for (const Job& j : jobs)
             if (j.matches.size() / 2 >= min_inl) total += j.matches.size();
         vmatches.reserve(total);
-    }
-    for (size_t k = 0; k < jobs.size(); ++k) {
-        const size_t m = jobs[k].matches.size() / 2;
-        if (m >= min_inl) {
-            v1.push_back(SlotOf(jobs[k].id1));
-            v2.push_back(SlotOf(jobs[k].id2));
-            vmatches.insert(vmatches.end(), jobs[k].matches.begin(), jobs[k].matches.end());
-            voff.push_back(voff.back() + m);
-            vwhich.push_back(k);
+        for (size_t k = 0; k < jobs.size(); ++k) {
+            const size_t m = jobs[k].matches.size() / 2;
+            if (m >= min_inl) {
+                v1.push_back(SlotOf(jobs[k].id1));
+                v2.push_back(SlotOf(jobs[k].id2));
+                vmatches.insert(vmatches.end(), jobs[k].matches.begin(), jobs[k].matches.end());
+                voff.push_back(voff.back() + m);
+                vwhich.push_back(k);
+            }
+        }
+        if (!vwhich.empty()) {
+            const double t_call = NowMs();
+            Check(amc_verify_pairs(ctx_, v1.data(), v2.data(), vwhich.size(), voff.data(), vmatches.data(), &to,
+                                   /*seed=*/0, &vr),
+                  "amc_verify_pairs");
+            stats.verify_call_ms += NowMs() - t_call;
+            have_vr = true;
+            stats.pairs_verified += vwhich.size();
         }
     }
-    if (!vwhich.empty()) {
-        const amc_tvg_opts to = ToAmc(tvg_);
-        amc_verify_result vr;
-        const double t_call = NowMs();
-        Check(amc_verify_pairs(ctx_, v1.data(), v2.data(), vwhich.size(), voff.data(), vmatches.data(), &to,
-                               /*seed=*/0, &vr),
-              "amc_verify_pairs");
-        stats.verify_call_ms += NowMs() - t_call;
+    if (have_vr) {
         for (size_t p = 0; p < vwhich.size(); ++p) {
             Job& j = jobs[vwhich[p]];
+            if (j.matches.size() / 2 < min_inl) continue;  // fused call: not a pair COLMAP's verifier estimates
             const amc_tvg& g = vr.tvg[p];
             j.tvg.config = g.config;
             std::memcpy(j.tvg.E.data(), g.E, sizeof g.E);
@@ -243,7 +271,6 @@ std::vector<MatchController::Job> MatchController::Compute(const ImagePairs& ima
             AppendInlierMatches(mask, j.matches.data(), m, &j.tvg.inlier_matches);
         }
         stats.verify_device_ms += vr.device_ms;
-        stats.pairs_verified += vwhich.size();
 
         // ---- guided matching (FeatureMatcherWorker with a verified geometry): pairs that kept at
         //      least min_num_inliers inliers and whose configuration COLMAP guides on are matched
@@ -266,11 +293,6 @@ std::vector<MatchController::Job> MatchController::Compute(const ImagePairs& ima
                 gwhich.push_back(vwhich[p]);
             }
             if (!gwhich.empty()) {
-                amc_match_opts mo;
-                amc_match_opts_default(&mo);
-                mo.max_ratio = sift_.max_ratio;
-                mo.max_distance = sift_.max_distance;
-                mo.cross_check = sift_.cross_check;
                 amc_match_result gr;
                 Check(amc_match_guided_pairs(ctx_, g1.data(), g2.data(), gwhich.size(), geoms.data(),
                                              tvg_.ransac_options.max_error, &mo, &gr),

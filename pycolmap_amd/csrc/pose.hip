@@ -174,7 +174,7 @@ __global__ __launch_bounds__(64) void pose_kernel(const TvgImage* __restrict__ i
     const CheiralityBounds b = cheirality_bounds(R, t);
     double c2[3], baseline2;
     second_centre(R, t, c2, &baseline2);
-    double* cs = cosine_ws + pr.match_off;
+    double* cs = cosine_ws + pr.ws_off;
     uint32_t n = 0;
     for (int base = 0; base < M; base += 64) {
         const int i = base + lane;

@@ -64,9 +64,17 @@ typedef AMC_LDS double lds_f64;
 typedef AMC_LDS uint32_t lds_u32;
 typedef AMC_LDS uint16_t lds_u16;
 
+// Algorithmic work of a pair, counted as the sequential algorithm does it (TvgOut::work): what COLMAP's loops
+// evaluate - every model of every trial up to the stopping trial against all M correspondences, every local model
+// against all M, one final residual pass per successful RANSAC - not what this kernel skips by early exit.
+enum : int { WK_SAMPSON = 0, WK_HRES, WK_TRES, WK_E5MIN, WK_F7MIN, WK_H4MIN, WK_LO_E5, WK_LO_F8, WK_LO_H, WK_LO_POINTS,
+              WK_TRIALS, WK_COUNT };
+__device__ __forceinline__ int wk_residual_slot(int kind) { return kind == K_H ? WK_HRES : (kind == K_T ? WK_TRES : WK_SAMPSON); }
+
 struct Wave {
     int lane;
     unsigned long long prof[8];
+    unsigned long long* work;  // the pair's TvgOut::work (global memory, lane 0 adds to it: a few times per 64 trials)
     // LDS
     lds_u32* mt;      // 624
     uint32_t* snap;   // 624, global workspace: written once per chunk, read on abort / sampler fallback
@@ -1028,6 +1036,13 @@ __device__ Report lo_ransac(Wave& w_io, const RansacCfg& cfg, const double* gx, 
                             double lm[kMaxModels * 9];
                             const unsigned long long tle = __builtin_readcyclecounter();
                             const int nl = local_estimate(lo, cfg.local_est, P, K, lm);
+                            if (lane == 0) {
+                                w.work[wk_residual_slot(cfg.local_est)] += (unsigned long long)nl * (unsigned long long)M;
+                                if (cfg.local_est == K_E5) w.work[WK_LO_E5] += 1;
+                                else if (cfg.local_est == K_F8) w.work[WK_LO_F8] += 1;
+                                else if (cfg.local_est == K_H) w.work[WK_LO_H] += 1;
+                                w.work[WK_LO_POINTS] += (unsigned long long)K;
+                            }
                             if (cfg.local_est == K_E5) w.prof[6] += __builtin_readcyclecounter() - tle;
                             else if (cfg.local_est == K_F8) w.prof[7] += __builtin_readcyclecounter() - tle;
                             const int prev = best.cnt;
@@ -1072,6 +1087,15 @@ __device__ Report lo_ransac(Wave& w_io, const RansacCfg& cfg, const double* gx, 
         }
         w.prof[2] += cm.cyc_count;
         { const unsigned long long tp1 = __builtin_readcyclecounter(); w.prof[2] += tp1 - tp0; }
+        {   // algorithmic work of the chunk: the trials the sequential loop ran, their models x M residuals
+            const int upto = aborted ? abort_trial - chunk : nT - 1;
+            const int nmodels = wave_sum_int(lane <= upto ? cm.nmod : 0);
+            if (lane == 0) {
+                w.work[wk_residual_slot(cfg.est)] += (unsigned long long)nmodels * (unsigned long long)M;
+                w.work[cfg.est == K_E5 ? WK_E5MIN : (cfg.est == K_F7 ? WK_F7MIN : (cfg.est == K_H ? WK_H4MIN : WK_TRIALS))] +=
+                    (unsigned long long)(upto + 1);
+            }
+        }
         if (aborted) {
             // roll the generator back to where the sequential algorithm stopped drawing
             wave_lds_sync();
@@ -1094,6 +1118,8 @@ __device__ Report lo_ransac(Wave& w_io, const RansacCfg& cfg, const double* gx, 
     for (int i = 0; i < 9; ++i) rep.model[i] = best_model[i];
     w_io.mti = w.mti;
     for (int i = 0; i < 8; ++i) w_io.prof[i] = w.prof[i];
+    if (best.cnt >= kMin && lane == 0)
+        w.work[wk_residual_slot(best_is_local ? cfg.local_est : cfg.est)] += (unsigned long long)M;
     if (best.cnt < kMin) return rep;
     rep.success = true;
     const int fk = best_is_local ? cfg.local_est : cfg.est;
@@ -1121,6 +1147,9 @@ __device__ __noinline__ void process_pair(Wave& w, uint32_t q, const TvgImage* _
     const int lane = w.lane;
     const uint32_t mcap = w.mcap;
     for (int i = 0; i < 8; ++i) w.prof[i] = 0;
+    w.work = out[q].work;
+    if (lane == 0)
+        for (int i = 0; i < 12; ++i) w.work[i] = 0;
     const unsigned long long tstart = __builtin_readcyclecounter();
     const TvgPair pr = pairs[q];
     // the image records are read field by field where they are needed (wave-uniform scalar loads): a by-value

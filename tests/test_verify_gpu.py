@@ -330,3 +330,45 @@ def test_golden_fixture(amc_ctx):
                 assert tvg_golden.bits(q["tri_angle"])[0] == w["tri_angle"][0], tag
                 for f in ("qvec", "tvec", "R"):
                     np.testing.assert_array_equal(tvg_golden.bits(q[f]), w[f], err_msg=f"{tag} {f}")
+
+
+@pytest.mark.parametrize("pose", [0, 1])
+def test_fused_match_verify_equals_the_two_calls(amc_ctx, monkeypatch, pose):
+    """amc_match_verify_pairs (the verification kernel reads the matches where the matcher left them in HBM) against
+    amc_match_pairs followed by amc_verify_pairs, on a scene whose pairs range from no overlap to dense overlap;
+    also with the matcher forced into many small batches (the resident table is appended batch after batch)."""
+    rng = np.random.default_rng(77)
+    cam = ("SIMPLE_RADIAL", synth.EXAMPLE_CAMERAS["SIMPLE_RADIAL"])
+    images = synth.multiview_scene(rng, num_images=9, n_feats=640, camera=cam if pose else None)
+    amc_ctx.reserve_slots(len(images))
+    for k, im in enumerate(images):
+        amc_ctx.upload_descriptors(k, im["descriptors"])
+        amc_ctx.upload_keypoints(k, im["keypoints"])
+        amc_ctx.upload_camera(k, im["model"], im["width"], im["height"], im["params"], True)
+    s1, s2 = synth.exhaustive_pairs(len(images))
+    s1, s2 = np.r_[s1, s2[:5]], np.r_[s2, s1[:5]]          # a few pairs in swapped order as well
+    opts = _capi.tvg_options(compute_relative_pose=pose)
+    off, m, _ = amc_ctx.match_pairs(s1, s2)
+    tvg, mask, st = amc_ctx.verify_pairs(s1, s2, off, m, opts, seed=0)
+    assert (tvg["config"] == 1).any() and (tvg["config"] >= 2).sum() >= 6     # DEGENERATE (too few matches) and real ones
+    for batch_entries in (None, "4096"):
+        if batch_entries:
+            monkeypatch.setenv("AMC_MATCH_BATCH_ENTRIES", batch_entries)
+        foff, fm, fmst, ftvg, fmask, fst = amc_ctx.match_verify_pairs(s1, s2, opts, seed=0)
+        np.testing.assert_array_equal(foff, off)
+        np.testing.assert_array_equal(fm, m)
+        np.testing.assert_array_equal(fmask, mask)
+        for f in ("config", "num_inliers", "num_trials", "model_inliers"):
+            np.testing.assert_array_equal(ftvg[f], tvg[f], err_msg=f)
+        for f in "EFH":
+            np.testing.assert_array_equal(bits(ftvg[f]), bits(tvg[f]), err_msg=f)
+        assert fst["work"] == st["work"] and sum(st["work"]) > 0
+        if pose:
+            for f in ("ok", "config", "num_points3D"):
+                np.testing.assert_array_equal(fst["pose"][f], st["pose"][f])
+            for f in ("qvec", "tvec", "R", "tri_angle"):
+                np.testing.assert_array_equal(bits(fst["pose"][f]), bits(st["pose"][f]), err_msg=f)
+    # empty list
+    z = np.zeros(0, np.uint32)
+    foff, fm, _, ftvg, fmask, _ = amc_ctx.match_verify_pairs(z, z, opts)
+    assert len(foff) == 1 and len(fm) == 0 and len(ftvg) == 0
