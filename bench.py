@@ -9,12 +9,20 @@ descriptors already resident in HBM when the timed region starts.
 
     python bench.py --gpus 1 --steps 3 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+        --master-port P bench.py --gpus N --steps K --warmup W [--config 3|4]
 
-N=1 workload = BASELINE.json configs[1] (500 x 4096, 124,750 pairs, 2.09e12 distances).
-N>1: weak scaling — the image set grows as 500*sqrt(N) so every rank matches ~124,750 pairs of
-one replicated descriptor arena; ranks exchange their match tables with one RCCL all-gather at
-the end of each step (the exchange step north_star names).
+--config 1 (default): N=1 workload = BASELINE.json configs[1] (500 x 4096, 124,750 pairs, 2.09e12
+  distances); N>1: weak scaling - the image set grows as 500*sqrt(N) so every rank matches ~124,750
+  pairs of one replicated descriptor arena.  At N=1 the JSON line also carries
+    "verify"   BASELINE's second metric, verified image-pairs/s, with its own FP64 roofline and CPU baseline,
+    "pipeline" configs[2] as stated: match + F/E/H verification of the same image set, chained on the device
+               (amc_match_verify_pairs) on a scene with real geometry,
+    "dense"    the same match on a set where EVERY pair overlaps (reverse scan and D2H no longer negligible).
+--config 3: BASELINE configs[3], 2000 x 8192, the FIXED pair set sharded over the ranks (strong scaling).
+--config 4: BASELINE configs[4], 10000 x 4096, sequential (overlap 50, quadratic) + loop-closure pairs
+            (feature voting on the first 512 descriptors, then the match of the retrieved pairs), sharded.
+In every multi-GPU mode ranks exchange their match tables with one RCCL all-gather at the end of each
+step (the exchange step north_star names), inside the timed region.
 
 Prints ONE JSON line (rank 0).
 """
@@ -35,10 +43,46 @@ sys.path.insert(0, str(ROOT))
 
 INT8_DENSE_PEAK_OPS = 5.0e15  # gfx950 dense int8 MFMA: 2x the 2.5 PF bf16 dense peak
                               # (/opt/skills/guides/MI355X_MICROARCH.md: "I8 ... ~2x bf16 rate")
+INT8_MEASURED_CEILING_OPS = 3.944e15  # the guide's measured I8 MFMA microbenchmark ceiling
 OPS_PER_DISTANCE = 256        # 128 int8 MACs
+# FP64 vector peak of MI355X: half the 157.3 TFLOP/s FP32 vector peak the guide lists, an FMA counted as 2 flop.
+# The verification kernels are built with -ffp-contract=off (every multiply and add rounds separately, as COLMAP's
+# x86 build does): no FMA is ever issued, which halves the reachable ceiling.
+FP64_VECTOR_PEAK = 78.6e12
+FP64_NO_FMA_CEILING = 39.3e12
+# Algorithmic FP64 work of the verification path.  Residuals are exact counts of the
+# arithmetic COLMAP's residual loops perform per correspondence; the solver figures are operation counts of the
+# solvers as written in tvg_math.h (elimination, polynomial set-up, an average bisection schedule).
+FLOP_SAMPSON, FLOP_HRES, FLOP_TRES = 33, 20, 7
+FLOP_E5_MIN, FLOP_F7_MIN, FLOP_H4_MIN = 30000, 2900, 1300
+FLOP_LO_E5, FLOP_LO_F8, FLOP_LO_H = 72000, 44000, 44000      # 9 x 9 Jacobi (+ 5-point set-up / roots)
+FLOP_LO_POINT = 200                                           # normalisation + design row + 45 MACs per inlier
 
 
-def make_arena_torch(num_images: int, feats: int, seed: int, device):
+def verify_flops(work):
+    """FP64 flop of a verification call from amc_verify_result.work (include/amc.h): (scoring, solvers)."""
+    scoring = FLOP_SAMPSON * work[0] + FLOP_HRES * work[1] + FLOP_TRES * work[2]
+    solvers = (FLOP_E5_MIN * work[3] + FLOP_F7_MIN * work[4] + FLOP_H4_MIN * work[5] + FLOP_LO_E5 * work[6] +
+               FLOP_LO_F8 * work[7] + FLOP_LO_H * work[8] + FLOP_LO_POINT * work[9])
+    return float(scoring), float(solvers)
+
+
+def fp64_roofline(work, kernel_s, launches):
+    scoring, solvers = verify_flops(work)
+    total = scoring + solvers
+    ach = total / kernel_s if kernel_s > 0 else 0.0
+    return {"bound": "fp64 vector (VALU); no MFMA, bytes negligible (points live in LDS)",
+            "achieved": ach / 1e12, "peak": FP64_VECTOR_PEAK / 1e12, "unit": "TFLOP/s (FP64)",
+            "frac": ach / FP64_VECTOR_PEAK, "frac_of_no_fma_ceiling": ach / FP64_NO_FMA_CEILING,
+            "no_fma_ceiling": FP64_NO_FMA_CEILING / 1e12,
+            "flop_per_launch": total / max(launches, 1), "flop_scoring_share": scoring / total if total else 0.0,
+            "kernel": "tvg_kernel", "avg_kernel_ms": 1e3 * kernel_s / max(launches, 1), "launches": launches,
+            "traffic": None,
+            "note": "algorithmic flop as COLMAP's loops count them (every model of every trial x all matches); the "
+                    "kernel skips part of that work by early exit, so this is useful work per second, not issue rate"}
+
+
+def make_arena_torch(num_images: int, feats: int, seed: int, device, overlap: str = "ring"):
     """Seeded SIFT-like descriptors generated on the GPU (SURVEY.md section 8d recipe).
 
     Landmarks sit on a ring; image i views a window of the ring that overlaps its ~8 nearest
@@ -53,6 +97,8 @@ def make_arena_torch(num_images: int, feats: int, seed: int, device):
     k = int(0.6 * feats)            # landmark features per image
     W = 2 * k                       # window of the ring an image can see
     stride = max(1, W // 8)         # neighbours up to 8 apart share landmarks
+    if overlap == "all":            # every image looks at the same window: every pair overlaps
+        stride = 0
     L = max(W, num_images * stride)
     proto = torch.randn(L, 128, generator=g, device=device).abs().pow(3.0)
     proto = proto / proto.norm(dim=1, keepdim=True)
@@ -136,10 +182,11 @@ def verify_leg(ctx_factory, device_index: int, npairs: int, steps: int, warmup: 
     for _ in range(warmup):
         ctx.verify_pairs(s1, s2, off, matches, opts)
     t0 = time.perf_counter()
-    kms = 0.0
+    kms, launches = 0.0, 0
     for _ in range(steps):
         tvg, mask, st = ctx.verify_pairs(s1, s2, off, matches, opts)
         kms += st["kernel_ms"]
+        launches += st["kernel_launches"]
     dt = time.perf_counter() - t0
     out = {
         "metric": "verified image-pairs/sec (E+F+H LO-RANSAC, model selection, watermark test)",
@@ -148,6 +195,7 @@ def verify_leg(ctx_factory, device_index: int, npairs: int, steps: int, warmup: 
         "mean_matches_per_pair": float(counts.mean()), "dtype": "f64",
         "configs": {_capi.CONFIG_NAMES[c]: int(n) for c, n in zip(*np.unique(tvg["config"], return_counts=True))},
         "mean_trials_E_F_H": [float(x) for x in tvg["num_trials"][:, :3].mean(axis=0)],
+        "roofline": fp64_roofline([w * steps for w in st["work"]], kms * 1e-3, launches),
     }
     # the same workload with TwoViewGeometryOptions.compute_relative_pose (pose.hip on the selected
     # inliers after the estimation): reported beside the metric, not as the metric
@@ -193,6 +241,294 @@ def verify_leg(ctx_factory, device_index: int, npairs: int, steps: int, warmup: 
     return out
 
 
+def pipeline_leg(ctx_factory, steps: int, warmup: int, cpu_pairs: int, num_images: int, feats: int):
+    """BASELINE.json configs[2] as it is stated: exhaustive match of the image set + F/E/H RANSAC verification of
+    every pair with >= 15 matches, on ONE scene with real geometry (synth.tower_scene: an orbit capture, sparse
+    overlap), the two stages chained on the device: amc_match_verify_pairs - the verification kernel reads the
+    matches where the matcher left them in HBM."""
+    from pycolmap_amd import _capi, synth
+    rng = np.random.default_rng(11)
+    t0 = time.perf_counter()
+    images = synth.tower_scene(rng, num_images=num_images, n_feats=feats)
+    gen_s = time.perf_counter() - t0
+    ctx = ctx_factory()
+    ctx.reserve_slots(num_images)
+    for k, im in enumerate(images):
+        ctx.upload_descriptors(k, im["descriptors"])
+        ctx.upload_keypoints(k, im["keypoints"])
+        ctx.upload_camera(k, im["model"], im["width"], im["height"], im["params"], True)
+    s1, s2 = synth.exhaustive_pairs(num_images)
+    opts = _capi.tvg_options()
+    for _ in range(warmup):
+        ctx.match_verify_pairs(s1, s2, opts)
+    t0 = time.perf_counter()
+    acc = dict(match_ms=0.0, scan_ms=0.0, cross_ms=0.0, verify_ms=0.0, verify_kernel_ms=0.0, launches=0)
+    for _ in range(steps):
+        off, m, mst, tvg, mask, vst = ctx.match_verify_pairs(s1, s2, opts)
+        acc["match_ms"] += mst["device_ms"]; acc["scan_ms"] += mst["match_kernel_ms"]; acc["cross_ms"] += mst["cross_kernel_ms"]
+        acc["verify_ms"] += vst["device_ms"]; acc["verify_kernel_ms"] += vst["kernel_ms"]; acc["launches"] += vst["kernel_launches"]
+    dt = time.perf_counter() - t0
+    counts = np.diff(off.astype(np.int64))
+    ver = counts >= 15
+    nver = int(ver.sum())
+    out = {
+        "metric": "verified image-pairs/sec, BASELINE configs[2]: exhaustive match + F/E/H verification chained on the device",
+        "value": nver * steps / dt, "unit": "verified pairs/s",
+        "workload": f"{num_images} images x {feats} features of one synthetic orbit scene (synth.tower_scene, PINHOLE "
+                    f"cameras with prior focal length: E, F and H run), all {len(s1)} pairs matched, the {nver} pairs "
+                    f"with >= 15 matches verified",
+        "pairs_total": int(len(s1)), "pairs_verified": nver, "steps": steps, "ms_per_step": 1e3 * dt / steps,
+        "distances_per_s_whole_pipeline": float(mst["num_distances"]) * steps / dt,
+        "stage_ms_per_step": {k: v / steps for k, v in acc.items() if k != "launches"},
+        "matches_per_verified_pair": {"mean": float(counts[ver].mean()) if nver else 0.0,
+                                      "max": int(counts.max()) if len(counts) else 0},
+        "mean_inliers_per_verified_pair": float(tvg["num_inliers"][ver].mean()) if nver else 0.0,
+        "configs": {_capi.CONFIG_NAMES[c]: int(n) for c, n in zip(*np.unique(tvg["config"][ver], return_counts=True))},
+        "mean_trials_E_F_H": [float(x) for x in tvg["num_trials"][ver][:, :3].mean(axis=0)] if nver else [0, 0, 0],
+        "roofline": fp64_roofline([w * steps for w in vst["work"]], acc["verify_kernel_ms"] * 1e-3, acc["launches"]),
+        "scene_generation_s": gen_s, "dtype": "u8 -> int8 MFMA / int32 (match), f64 (verification)",
+    }
+    if cpu_pairs > 0:
+        # the CPU oracles on the same pairs: a seeded sample of ALL pairs for the rate (most do not overlap, as in
+        # the job itself), plus verified pairs only for the parity of the chained result
+        sys.path.insert(0, str(ROOT / "tests"))
+        import oracle_lib as o
+        cores = host_cores()
+        rs = np.random.default_rng(5)
+        idx = np.sort(rs.choice(len(s1), size=min(cpu_pairs, len(s1)), replace=False))
+        vidx = np.flatnonzero(ver)
+        vidx = np.sort(rs.choice(vidx, size=min(len(vidx), max(cpu_pairs // 4, 1)), replace=False)) if len(vidx) else vidx
+        cam = o.make_camera("PINHOLE", images[0]["width"], images[0]["height"], images[0]["params"], prior=True)
+        kps = [im["keypoints"][:, :2].astype(np.float64) for im in images]
+        t0 = time.perf_counter()
+        imgs = [im["descriptors"] for im in images]
+        coff, cm = o.match_pairs(imgs, s1[idx], s2[idx], threads=cores)
+        mm = [cm[int(coff[k]):int(coff[k + 1])] for k in range(len(idx))]
+        todo = [k for k in range(len(idx)) if len(mm[k]) >= 15]
+        want = o.estimate_two_view_geometry_batch([cam] * len(todo), [kps[int(s1[idx[k]])] for k in todo], [cam] * len(todo),
+                                                  [kps[int(s2[idx[k]])] for k in todo], [mm[k] for k in todo], threads=cores)
+        cdt = time.perf_counter() - t0
+        mism = 0
+        for k, p in enumerate(idx):
+            if not np.array_equal(m[int(off[p]):int(off[p + 1])], mm[k]):
+                mism += 1
+        for k, w in zip(todo, want):
+            p = idx[k]
+            if tvg["config"][p] != w["config"] or not np.array_equal(mask[int(off[p]):int(off[p + 1])], w["inlier_mask"]):
+                mism += 1
+        # parity on verified pairs (their matches come from the GPU result just compared pair by pair above)
+        vw = o.estimate_two_view_geometry_batch([cam] * len(vidx), [kps[int(s1[p])] for p in vidx], [cam] * len(vidx),
+                                                [kps[int(s2[p])] for p in vidx],
+                                                [m[int(off[p]):int(off[p + 1])] for p in vidx], threads=cores)
+        vmis = sum(1 for p, w in zip(vidx, vw)
+                   if tvg["config"][p] != w["config"] or not np.array_equal(mask[int(off[p]):int(off[p + 1])], w["inlier_mask"])
+                   or not np.array_equal(tvg["F"][p].view(np.uint64), w["F"].view(np.uint64)))
+        out["cpu_baseline"] = {"value": len(idx) / cdt, "unit": "pairs/s (matched, and verified when >= 15 matches)",
+                               "cores": min(cores, len(idx)), "kind": "port",
+                               "sample": f"{len(idx)} seeded pairs of the same set ({len(todo)} of them verified), oracle/match_oracle.c "
+                                         f"+ oracle/tvg_oracle.cc, OpenMP one pair per thread, {cdt:.1f} s",
+                               "gpu_pairs_per_s_same_unit": len(s1) * steps / dt,
+                               "gpu_vs_oracle_mismatching_pairs": mism,
+                               "verified_pairs_checked": int(len(vidx)), "verified_pairs_mismatching": int(vmis)}
+    ctx.close()
+    return out
+
+
+def dense_leg(ctx_factory, device, steps: int, warmup: int, num_images: int, feats: int, kernel: str):
+    """configs[1] on a set where EVERY pair overlaps (all images look at the same landmarks): the share of accepted
+    rows is ~100x that of the sparse set, so the reverse scan of the candidate columns and the D2H of the match
+    table stop being negligible.  Reported beside the headline, same unit."""
+    import torch
+    arena = make_arena_torch(num_images, feats, seed=1, device=device, overlap="all")
+    ctx = ctx_factory()
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.reserve_slots(num_images)
+    for i in range(num_images):
+        ctx.upload_descriptors_device(i, arena[i].data_ptr(), feats)
+    torch.cuda.synchronize()
+    from pycolmap_amd import synth
+    s1, s2 = synth.exhaustive_pairs(num_images)
+    for _ in range(warmup):
+        ctx.match_pairs(s1, s2, kernel=kernel)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    scan = cross = dev = 0.0
+    for _ in range(steps):
+        off, m, st = ctx.match_pairs(s1, s2, kernel=kernel)
+        scan += st["match_kernel_ms"]; cross += st["cross_kernel_ms"]; dev += st["device_ms"]
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ctx.close()
+    nm = int(m.shape[0])
+    return {"metric": "descriptor-pair distances/sec, every pair overlapping", "value": float(st["num_distances"]) * steps / dt,
+            "unit": "distances/s", "workload": f"{num_images} images x {feats} descriptors, all images share their landmarks",
+            "steps": steps, "ms_per_step": 1e3 * dt / steps, "matches_per_pair": nm / max(len(s1), 1),
+            "match_table_bytes": nm * 8,
+            "stage_ms_per_step": {"scan_kernel": scan / steps, "resolve_select_reverse_scan": cross / steps,
+                                  "device_total_incl_d2h": dev / steps,
+                                  "host_side_of_the_call": 1e3 * dt / steps - dev / steps}}
+
+
+def run_config34(args):
+    """BASELINE configs[3] (2000 x 8192 exhaustive) and configs[4] (10000 x 4096 sequential + loop): a FIXED
+    workload whose pairs are sharded over the ranks by work (sum of n1 * n2), the descriptor arena replicated on
+    every GPU, one RCCL all-gather of the match tables at the end of every step (inside the timed region)."""
+    import torch
+    import torch.distributed as dist
+    from pycolmap_amd import _capi, synth
+    from pycolmap_amd import distributed as D
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the measured path")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", device_id=device, rank=rank, world_size=world)
+
+    if args.config == 3:
+        num_images = 2000 if args.images == 500 else args.images
+        feats = 8192 if args.feats == 4096 else args.feats
+    else:
+        num_images = 10000 if args.images == 500 else args.images
+        feats = args.feats
+    arena = make_arena_torch(num_images, feats, seed=0, device=device)
+    ctx = _capi.Context(local_rank)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    loop_feats = 512
+    ctx.reserve_slots(num_images * (2 if args.config == 4 else 1))
+    for i in range(num_images):
+        ctx.upload_descriptors_device(i, arena[i].data_ptr(), feats)
+        if args.config == 4:   # the loop index: every image's first 512 descriptors (controller.cc SetupLoopIndex)
+            ctx.upload_descriptors_device(num_images + i, arena[i].data_ptr(), loop_feats)
+    torch.cuda.synchronize()
+    rows = np.full(num_images, feats)
+
+    if args.config == 3:
+        a_all, b_all = synth.exhaustive_pairs(num_images)
+    else:
+        # SequentialFeatureMatcher: offsets 1..49 and 2^k (quadratic overlap), self pairs and duplicates dropped
+        import pycolmap_amd as pc
+        blocks = pc._pycolmap._sequential_blocks(list(range(1, num_images + 1)), 50, True)
+        seen, aa, bb = set(), [], []
+        for blk in blocks:
+            for i1, i2 in blk:
+                if i1 == i2 or (i1, i2) in seen:
+                    continue
+                seen.add((i1, i2))
+                aa.append(i1 - 1)
+                bb.append(i2 - 1)
+        a_all, b_all = np.array(aa, np.uint32), np.array(bb, np.uint32)
+        del seen
+    s1, s2, mine = D.shard_pairs(a_all, b_all, rank, world, rows=rows)
+    queries = np.arange(0, num_images, 10)[rank::world] if args.config == 4 else np.zeros(0, np.int64)
+    loop_num_images = 50
+
+    def step():
+        off, m, st = ctx.match_pairs(s1, s2, kernel=args.kernel)
+        nd = st["num_distances"]
+        kms, kl = st["match_kernel_ms"], st["match_kernel_launches"]
+        parts = [(mine, off, m)]
+        extra = {}
+        if args.config == 4 and len(queries):
+            # loop closure (SequentialFeatureMatcher::RunLoopDetection with the vocabulary tree replaced by exact
+            # feature voting, DESIGN.md section 7): every 10th image against every other image on the first 512
+            # descriptors, the 50 best-voted candidates are then matched at full size
+            cand = np.arange(num_images, dtype=np.uint32)
+            q1 = np.repeat(queries.astype(np.uint32), num_images - 1)
+            q2 = np.concatenate([cand[cand != q] for q in queries])
+            voff, _, vst = ctx.match_pairs(num_images + q1, num_images + q2, kernel=args.kernel)
+            votes = np.diff(voff.astype(np.int64)).reshape(len(queries), num_images - 1)
+            order = np.argsort(-votes, axis=1, kind="stable")[:, :loop_num_images]
+            keep = np.take_along_axis(votes, order, axis=1) > 0
+            l1 = np.repeat(queries.astype(np.uint32), loop_num_images).reshape(len(queries), -1)[keep]
+            l2 = q2.reshape(len(queries), num_images - 1)[np.arange(len(queries))[:, None], order][keep]
+            loff, lm, lst = ctx.match_pairs(l1, l2, kernel=args.kernel)
+            nd += vst["num_distances"] + lst["num_distances"]
+            kms += vst["match_kernel_ms"] + lst["match_kernel_ms"]
+            kl += vst["match_kernel_launches"] + lst["match_kernel_launches"]
+            extra = dict(loop_queries=int(len(queries)), loop_scoring_pairs=int(len(q1)), loop_pairs=int(len(l1)),
+                         loop_scoring_distances=int(vst["num_distances"]), loop_match_distances=int(lst["num_distances"]))
+            parts.append((None, loff, lm))
+        gathered = None
+        if use_dist:
+            # the exchange step: sequential pairs have global positions; the loop pairs of a rank are numbered after
+            # those of the ranks before it (one small all-gather of the counts)
+            gathered = [D.all_gather_match_tables(mine, off, m, device=device, as_numpy=False)]
+            if args.config == 4:
+                lo_, lm_ = (parts[1][1], parts[1][2]) if len(parts) > 1 else (np.zeros(1, np.uint64), np.zeros((0, 2), np.uint32))
+                gathered.append(D.all_gather_appended_tables(lo_, lm_, device=device, as_numpy=False))
+        return nd, kms, kl, int(sum(p[2].shape[0] for p in parts)), extra, gathered
+
+    def fence():
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    nd = kms = kl = nm = 0
+    extra = {}
+    for _ in range(args.steps):
+        d_, k_, l_, nm, extra, _ = step()
+        nd += d_; kms += k_; kl += l_
+    fence()
+    elapsed = time.perf_counter() - t0
+    nd_rank = nd
+    if use_dist:
+        t = torch.tensor([elapsed, float(nd)], device=device, dtype=torch.float64)
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        elapsed, nd = float(tmax[0].item()), float(t[1].item())
+    final_line = None
+    if rank == 0:
+        avg_kernel_s = (kms / max(kl, 1)) * 1e-3
+        ach = (nd_rank * OPS_PER_DISTANCE / max(kl, 1)) / avg_kernel_s if avg_kernel_s > 0 else 0.0
+        name = ("2000 images x 8192 descriptors, exhaustive match, pairs sharded across the GPUs (BASELINE.json configs[3])"
+                if args.config == 3 else
+                "10000 images x 4096 descriptors, sequential (overlap 50, quadratic) + loop matching (BASELINE.json configs[4])")
+        if (args.config == 3 and (num_images, feats) != (2000, 8192)) or (args.config == 4 and (num_images, feats) != (10000, 4096)):
+            name = f"REDUCED {num_images} x {feats} variant of: " + name
+        out = {
+            "metric": "descriptor-pair distances/sec (exhaustive SIFT match: dot + top-2 + ratio + cross-check)",
+            "value": nd / elapsed, "unit": "distances/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "u8 descriptors, int8 MFMA / int32 accumulate", "data": "synthetic",
+            "config": {"workload": name, "pairs_total": int(len(a_all)), "pairs_rank0": int(len(s1)),
+                       "distances_per_step_all_ranks": nd / args.steps, "matches_rank0": nm, "rccl_ranks": world if use_dist else 0,
+                       "sharding": "pairs sorted by image 2, contiguous slices of equal sum(n1*n2), arena replicated; "
+                                   "one all-gather of the match tables per step", **extra},
+            "roofline": {"bound": "mfma", "achieved": ach / 1e12, "peak": INT8_DENSE_PEAK_OPS / 1e12,
+                         "unit": "TOP/s (int8; 256 ops per descriptor-pair distance)", "frac": ach / INT8_DENSE_PEAK_OPS,
+                         "frac_of_measured_i8_ceiling": ach / INT8_MEASURED_CEILING_OPS, "traffic": None,
+                         "kernel": "match_mfma_kernel", "avg_kernel_ms": avg_kernel_s * 1e3,
+                         "launches_per_step": kl // max(args.steps, 1)},
+        }
+        final_line = json.dumps(out)
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+    if final_line is not None:
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        print(final_line, flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -212,7 +548,15 @@ def main():
                     help="diagnostic: one-way matching only (NOT the BASELINE workload)")
     ap.add_argument("--force-dist", action="store_true",
                     help="diagnostic: run the multi-GPU exchange path (process group + all-gather) even with 1 rank")
+    ap.add_argument("--config", type=int, default=1, choices=[1, 3, 4],
+                    help="1: BASELINE configs[1] (+ verify / pipeline / dense legs at N=1; weak scaling at N>1); "
+                         "3: configs[3], 2000 x 8192 fixed pair set sharded over the ranks (strong scaling); "
+                         "4: configs[4], 10000 x 4096 sequential + loop matching, sharded")
+    ap.add_argument("--no-pipeline", action="store_true", help="skip the chained configs[2] leg")
+    ap.add_argument("--no-dense", action="store_true", help="skip the dense-overlap match leg")
     args = ap.parse_args()
+    if args.config in (3, 4):
+        return run_config34(args)
 
     import torch
     import torch.distributed as dist
@@ -240,7 +584,7 @@ def main():
     s1_all, s2_all = synth.exhaustive_pairs(num_images)
     # shard: order by image 2 (the kernel's L2-friendly order), deal contiguous slices to ranks
     from pycolmap_amd import distributed as D
-    s1, s2, mine = D.shard_pairs(s1_all, s2_all, rank, world)
+    s1, s2, mine = D.shard_pairs(s1_all, s2_all, rank, world, rows=np.full(num_images, args.feats))
 
     ctx = _capi.Context(local_rank)
     stream = torch.cuda.current_stream()
@@ -328,6 +672,8 @@ def main():
                 "peak": INT8_DENSE_PEAK_OPS / 1e12,
                 "unit": "TOP/s (int8; 256 ops per descriptor-pair distance)",
                 "frac": achieved / INT8_DENSE_PEAK_OPS,
+                "frac_of_measured_i8_ceiling": achieved / INT8_MEASURED_CEILING_OPS,
+                "measured_i8_ceiling": INT8_MEASURED_CEILING_OPS / 1e12,
                 "traffic": None,  # filled below from the committed PMC pass when the launch shape is the same
                 "kernel": "match_mfma_kernel" if st["pairs_mfma"] else "match_dot4_kernel",
                 "avg_kernel_ms": avg_kernel_s * 1e3,
@@ -370,6 +716,15 @@ def main():
             out["verify"] = verify_leg(lambda: _capi.Context(local_rank), local_rank, args.verify_pairs,
                                        max(1, args.steps), min(1, args.warmup),
                                        0 if args.no_cpu_baseline else 256)
+        if world == 1 and not args.no_pipeline:
+            ctx.close()          # the legs below bring their own contexts and arenas
+            del arena
+            torch.cuda.empty_cache()
+            out["pipeline"] = pipeline_leg(lambda: _capi.Context(local_rank), max(1, min(args.steps, 2)), min(1, args.warmup),
+                                           0 if args.no_cpu_baseline else 4 * host_cores(), args.images, args.feats)
+        if world == 1 and not args.no_dense:
+            out["dense"] = dense_leg(lambda: _capi.Context(local_rank), device, max(1, min(args.steps, 2)),
+                                     min(1, args.warmup), args.images, args.feats, args.kernel)
         final_line = json.dumps(out)
     else:
         final_line = None

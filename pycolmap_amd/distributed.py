@@ -13,15 +13,29 @@ from __future__ import annotations
 import numpy as np
 
 
-def shard_pairs(slot1: np.ndarray, slot2: np.ndarray, rank: int, world: int):
+def shard_pairs(slot1: np.ndarray, slot2: np.ndarray, rank: int, world: int, rows: np.ndarray | None = None):
     """Contiguous slice of the pair list, after ordering by image 2 (then image 1) so that pairs
-    sharing the streamed image stay on one GPU and in one L2.  Returns (slot1, slot2, index) where
-    `index` maps the shard back to positions in the caller's list."""
+    sharing the streamed image stay on one GPU and in one L2.  With `rows` (descriptors per slot) the cuts
+    sit at equal shares of the WORK, sum of n1 * n2 (ragged image sizes would otherwise
+    leave ranks with very different scan times); without it, at equal pair counts.  Returns (slot1, slot2, index)
+    where `index` maps the shard back to positions in the caller's list."""
     s1 = np.asarray(slot1, dtype=np.uint32)
     s2 = np.asarray(slot2, dtype=np.uint32)
     order = np.lexsort((s1, s2))
-    per = (len(order) + world - 1) // world
-    mine = order[rank * per:(rank + 1) * per]
+    if rows is None or len(order) == 0:
+        per = (len(order) + world - 1) // world
+        mine = order[rank * per:(rank + 1) * per]
+        return s1[mine], s2[mine], mine
+    r = np.asarray(rows, dtype=np.float64)
+    work = np.cumsum(r[s1[order]] * r[s2[order]])
+    total = work[-1]
+    if total <= 0:                                       # nothing to weigh: fall back to counts
+        return shard_pairs(s1, s2, rank, world)
+    # pair k goes to the rank whose share of the cumulative work its midpoint falls into
+    mid = work - 0.5 * r[s1[order]] * r[s2[order]]
+    owner = np.minimum((mid * world / total).astype(np.int64), world - 1)
+    lo, hi = np.searchsorted(owner, [rank, rank + 1])
+    mine = order[lo:hi]
     return s1[mine], s2[mine], mine
 
 
@@ -82,6 +96,26 @@ def all_gather_match_tables(pair_index: np.ndarray, offsets: np.ndarray, matches
     if not as_numpy:
         return g_off, g_matches
     return g_off.cpu().numpy().astype(np.uint64), g_matches.cpu().numpy().view(np.uint32)
+
+
+def all_gather_appended_tables(offsets: np.ndarray, matches: np.ndarray, device=None, group=None, as_numpy: bool = True):
+    """all_gather_match_tables for pair lists that have no global numbering yet - e.g. the loop-closure pairs every
+    rank retrieves for its own query images (BASELINE configs[4]): the lists are appended in rank order.  One more
+    tiny all-gather (the per-rank pair counts) gives every rank its base position; returns what
+    all_gather_match_tables returns plus this rank's base."""
+    import torch
+    import torch.distributed as dist
+
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    dev = device if device is not None else torch.device("cpu")
+    n = len(offsets) - 1
+    cnt = torch.tensor([n], dtype=torch.int64, device=dev)
+    allc = torch.empty(world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(allc, cnt, group=group)
+    base = int(allc[:rank].sum().item())
+    g_off, g_m = all_gather_match_tables(base + np.arange(n, dtype=np.int64), offsets, matches, device=device, group=group,
+                                         as_numpy=as_numpy)
+    return g_off, g_m, base
 
 
 def all_gather_pair_records(pair_index: np.ndarray, records: np.ndarray, total_pairs: int, device=None, group=None):

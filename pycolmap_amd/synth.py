@@ -265,3 +265,63 @@ def recamera_scene(sc: dict, model1, params1, model2, params2) -> dict:
         uv = (sc[key] - np.array([cx, cy])) / f
         out[key] = img_from_cam(m, p, uv).astype(np.float32).astype(np.float64)
     return out
+
+
+def tower_scene(rng, num_images=500, n_feats=4096, f=1200.0, width=1600, height=1200, sigma_px=0.5, sigma_d=0.06,
+                images_per_turn=48, landmark_frac=0.65, camera=None):
+    """An orbit capture with real geometry AND the sparse overlap of a real exhaustive-matching job (BASELINE.json
+    configs[2]): the cameras climb a helix inside a cylindrical wall of landmarks and look outward, `images_per_turn`
+    images per revolution, 0.8 vertical fields of view per revolution.  An image overlaps its ~8 neighbours on either
+    side (and a few images one turn below / above); most of the N(N-1)/2 pairs see disjoint parts of the wall.
+    Per image: up to landmark_frac * n_feats projected landmarks (pixel noise sigma_px, descriptor = noisy landmark
+    prototype), padded with noise features to exactly n_feats.  Returns the list of image dicts multiview_scene
+    returns (name, keypoints [n,4] float32, descriptors [n,128] uint8, model, width, height, params)."""
+    Rc, Rw = 1.0, 6.0                                    # camera helix radius, wall radius
+    dphi = 2.0 * np.pi / images_per_turn
+    vis_h = 2.0 * (Rw - Rc) * (height / 2.0) / f          # wall height one image sees
+    dz = 0.8 * vis_h / images_per_turn              # consecutive turns share a fifth of their height
+    turns = num_images / images_per_turn
+    want = int(landmark_frac * n_feats)
+    # landmark density: `want` of them inside one view (window ~ 2 atan(w / 2f) of the wall, vis_h tall)
+    win = 2.0 * np.arctan(width / 2.0 / f) * 0.95
+    total_h = turns * 0.8 * vis_h + vis_h
+    L = int(want * 1.25 * (2.0 * np.pi / win) * (total_h / vis_h))
+    th = rng.uniform(0, 2 * np.pi, L)
+    zz = rng.uniform(-vis_h / 2, total_h - vis_h / 2, L)
+    rr = Rw + rng.uniform(-0.6, 0.6, L)                   # a rough wall: real depth variation, no plane
+    X = np.stack([rr * np.cos(th), rr * np.sin(th), zz], axis=1)
+    proto = rng.gamma(0.7, 1.0, size=(L, 128)).astype(np.float32)
+    proto /= np.linalg.norm(proto, axis=1, keepdims=True)
+    order = np.argsort(zz)                                # visibility test on a z-window only
+    Xs, zs = X[order], zz[order]
+    K = np.array([[f, 0, width / 2.0], [0, f, height / 2.0], [0, 0, 1.0]])
+    images = []
+    for i in range(num_images):
+        phi, zc = i * dphi, i * dz
+        C = np.array([Rc * np.cos(phi), Rc * np.sin(phi), zc])
+        zax = np.array([np.cos(phi), np.sin(phi), 0.0])   # looking outward
+        xax = np.array([-np.sin(phi), np.cos(phi), 0.0])
+        yax = np.cross(zax, xax)
+        R = np.stack([xax, yax, zax])
+        lo, hi = np.searchsorted(zs, [zc - vis_h, zc + vis_h])
+        Xc = (Xs[lo:hi] - C) @ R.T
+        front = Xc[:, 2] > 1.0
+        zc_ = np.where(front, Xc[:, 2], 1.0)
+        if camera is None:
+            uv = Xc[:, :2] / zc_[:, None] * f + np.array([width / 2.0, height / 2.0])
+        else:
+            uv = img_from_cam(camera[0], camera[1], Xc[:, :2] / zc_[:, None])
+        vis = np.where(front & (uv[:, 0] > 8) & (uv[:, 0] < width - 8) & (uv[:, 1] > 8) & (uv[:, 1] < height - 8))[0]
+        vis = rng.permutation(vis)[:want]
+        gid = order[lo:hi][vis]
+        kp = uv[vis] + rng.normal(0, sigma_px, size=(len(vis), 2))
+        d = proto[gid] + rng.normal(0, sigma_d, size=(len(vis), 128)).astype(np.float32) * proto[gid].mean()
+        nn = n_feats - len(vis)
+        kp = np.concatenate([kp, rng.uniform([8, 8], [width - 8, height - 8], size=(nn, 2))])
+        d = np.concatenate([d, rng.gamma(0.7, 1.0, size=(nn, 128)).astype(np.float32) * 0.1])
+        perm = rng.permutation(n_feats)
+        kp4 = np.c_[kp[perm], rng.uniform(1, 4, n_feats), rng.uniform(-3.1, 3.1, n_feats)].astype(np.float32)
+        images.append(dict(name=f"img_{i:05d}.jpg", keypoints=kp4, descriptors=quantize_descriptors(d[perm]),
+                           model=1 if camera is None else CAMERA_MODEL_IDS[camera[0]], width=width, height=height,
+                           params=(f, f, width / 2.0, height / 2.0) if camera is None else tuple(camera[1])))
+    return images

@@ -146,3 +146,82 @@ def test_sharded_verification_equals_single_process(tmp_path, world):
         np.testing.assert_array_equal(z["m"], m)
         np.testing.assert_array_equal(np.diff(z["ioff"]), inl_counts)
         np.testing.assert_array_equal(z["im"], m[mask])
+
+
+def test_shard_pairs_balances_work_for_ragged_images():
+    """shards are cut at equal sum(n1 * n2), not at equal pair counts."""
+    from pycolmap_amd import distributed as D
+    from pycolmap_amd import synth
+    rng = np.random.default_rng(3)
+    rows = rng.integers(50, 4000, size=60)
+    rows[:5] = 0                                                   # images without descriptors cost nothing
+    s1, s2 = synth.exhaustive_pairs(60)
+    for world in (2, 3, 8):
+        parts = [D.shard_pairs(s1, s2, r, world, rows=rows) for r in range(world)]
+        idx = np.concatenate([p[2] for p in parts])
+        assert sorted(idx.tolist()) == list(range(len(s1)))
+        work = np.array([(rows[a].astype(np.int64) * rows[b]).sum() for a, b, _ in parts], dtype=np.float64)
+        assert work.max() <= 1.15 * work.mean(), (world, work)
+        by_count = np.array([(rows[a].astype(np.int64) * rows[b]).sum() for a, b, _ in
+                             [D.shard_pairs(s1, s2, r, world) for r in range(world)]], dtype=np.float64)
+        assert work.max() <= by_count.max()                        # never worse than dealing equal counts
+        for a, b, _ in parts:
+            assert np.all(np.diff(b.astype(np.int64)) >= 0)
+
+
+def _worker_config4(rank, world, port, out_dir):
+    """bench.py --config 4's exchange with the CPU oracle as the matcher: sequential pairs sharded by work, every
+    rank's own loop-closure pairs (queries dealt round-robin) appended in rank order."""
+    sys.path.insert(0, str(ROOT))
+    sys.path.insert(0, str(ROOT / "tests"))
+    import torch.distributed as dist
+
+    import oracle_lib
+    from pycolmap_amd import distributed as D
+    from pycolmap_amd import synth
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(1)
+    imgs = synth.scene_images(rng, 12, 64, num_landmarks=120, visible_frac=0.5)
+    n = len(imgs)
+    seq = [(i, j) for i in range(n) for j in (i + 1, i + 2, i + 4) if j < n]
+    a_all = np.array([p[0] for p in seq], np.uint32)
+    b_all = np.array([p[1] for p in seq], np.uint32)
+    s1, s2, mine = D.shard_pairs(a_all, b_all, rank, world, rows=np.full(n, 64))
+    off, m = oracle_lib.match_pairs(imgs, s1, s2, threads=1)
+    g_off, g_m = D.all_gather_match_tables(mine, off, m)
+    queries = np.arange(0, n, 3)[rank::world]
+    l1 = np.repeat(queries.astype(np.uint32), 2)
+    l2 = ((l1 + np.tile([5, 7], len(queries))) % n).astype(np.uint32)
+    loff, lm = oracle_lib.match_pairs(imgs, l1, l2, threads=1) if len(l1) else (np.zeros(1, np.uint64), np.zeros((0, 2), np.uint32))
+    a_off, a_m, base = D.all_gather_appended_tables(loff, lm)
+    np.savez(Path(out_dir) / f"c4_rank{rank}.npz", g_off=g_off, g_m=g_m, a_off=a_off, a_m=a_m, base=base, l1=l1, l2=l2)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_config4_exchange_dry_run(tmp_path, world):
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_worker_config4, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    sys.path.insert(0, str(ROOT / "tests"))
+    import oracle_lib
+    from pycolmap_amd import synth
+    rng = np.random.default_rng(1)
+    imgs = synth.scene_images(rng, 12, 64, num_landmarks=120, visible_frac=0.5)
+    n = len(imgs)
+    seq = [(i, j) for i in range(n) for j in (i + 1, i + 2, i + 4) if j < n]
+    want_off, want_m = oracle_lib.match_pairs(imgs, np.array([p[0] for p in seq], np.uint32),
+                                              np.array([p[1] for p in seq], np.uint32), threads=2)
+    z = [np.load(tmp_path / f"c4_rank{r}.npz") for r in range(world)]
+    l1 = np.concatenate([x["l1"] for x in z])                      # rank order = the order of the appended table
+    l2 = np.concatenate([x["l2"] for x in z])
+    lw_off, lw_m = oracle_lib.match_pairs(imgs, l1, l2, threads=2)
+    assert [int(x["base"]) for x in z] == np.cumsum([0] + [len(x["l1"]) for x in z[:-1]]).tolist()
+    for x in z:
+        np.testing.assert_array_equal(x["g_off"], want_off)
+        np.testing.assert_array_equal(x["g_m"], want_m)
+        np.testing.assert_array_equal(x["a_off"], lw_off)
+        np.testing.assert_array_equal(x["a_m"], lw_m)
