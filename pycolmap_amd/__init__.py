@@ -15,12 +15,12 @@ __version__ = "0.1.0"
 
 try:  # the compiled host layer; absent only before `python -m pycolmap_amd.build`
     from ._pycolmap import (  # noqa: F401
-        COLMAP_version, Camera, CameraModelId, Database, Device, ExhaustiveMatchingOptions, RANSACOptions, Rigid3d,
+        COLMAP_build, COLMAP_version, Camera, CameraModelId, Database, Device, ExhaustiveMatchingOptions, RANSACOptions, Rigid3d,
         Rotation3d,
         SequentialMatchingOptions, SiftMatchingOptions, TwoViewGeometry, TwoViewGeometryConfiguration,
         TwoViewGeometryOptions, essential_matrix_estimation, estimate_calibrated_two_view_geometry,
         estimate_two_view_geometry, estimate_two_view_geometry_pose, fundamental_matrix_estimation, has_cuda,
-        has_hip, homography_matrix_estimation, last_run_stats, match_exhaustive, match_sequential,
+        has_hip, homography_matrix_estimation, last_run_stats, logging, match_exhaustive, match_sequential,
         match_spatial, match_vocabtree, squared_sampson_error, verify_matches,
     )
     _HOST_LAYER_ERROR = None

@@ -72,11 +72,14 @@ amc_tvg_opts ToAmc(const TwoViewGeometryOptions& o) {
 }
 
 MatchController::MatchController(const std::string& database_path, const SiftMatchingOptions& sift,
-                                 const TwoViewGeometryOptions& tvg, int device_id)
-    : path_(database_path), sift_(sift), tvg_(tvg), device_id_(device_id) {}
+                                 const TwoViewGeometryOptions& tvg, std::vector<int> device_ids)
+    : path_(database_path), sift_(sift), tvg_(tvg), device_ids_(std::move(device_ids)) {
+    if (device_ids_.empty()) device_ids_.push_back(0);
+}
 
 MatchController::~MatchController() {
-    if (ctx_) amc_ctx_destroy(ctx_);
+    for (amc_ctx* c : ctxs_)
+        if (c) amc_ctx_destroy(c);
 }
 
 uint32_t MatchController::SlotOf(image_t id) const {
@@ -103,28 +106,62 @@ void MatchController::Setup() {
     const std::vector<CameraRow> cams = db_->ReadAllCameras();
     std::unordered_map<camera_t, const CameraRow*> cam_by_id;
     for (const auto& c : cams) cam_by_id[c.camera_id] = &c;
-    Check(amc_ctx_create(device_id_, &ctx_), "amc_ctx_create");
-    Check(amc_ctx_reserve_slots(ctx_, static_cast<uint32_t>(images_.size())), "amc_ctx_reserve_slots");
+    for (int dev : device_ids_) {
+        amc_ctx* c = nullptr;
+        Check(amc_ctx_create(dev, &c), "amc_ctx_create");
+        ctxs_.push_back(c);
+        Check(amc_ctx_reserve_slots(c, static_cast<uint32_t>(images_.size())), "amc_ctx_reserve_slots");
+    }
+    ctx_ = ctxs_[0];
     image_t max_id = 0;
     for (const auto& im : images_) max_id = std::max(max_id, im.image_id);
     slot_of_image_.assign(static_cast<size_t>(max_id) + 1, 0xFFFFFFFFu);
-    for (uint32_t s = 0; s < images_.size(); ++s) {
-        const ImageRow& im = images_[s];
-        slot_of_image_[im.image_id] = s;
-        uint32_t drows = 0, krows = 0;
-        const std::vector<uint8_t> desc = db_->ReadDescriptors(im.image_id, &drows);
-        const std::vector<float> kp = db_->ReadKeypointsXY(im.image_id, &krows);
-        // COLMAP's GPU matcher clamps to the first max_num_matches features
-        // (WarnIfMaxNumMatchesReachedGPU; SiftMatchingOptions.max_num_matches)
-        const uint32_t use = std::min<uint32_t>(drows, static_cast<uint32_t>(std::max(sift_.max_num_matches, 0)));
-        Check(amc_upload_descriptors(ctx_, s, desc.data(), use), "amc_upload_descriptors");
-        Check(amc_upload_keypoints(ctx_, s, kp.data(), krows, 2), "amc_upload_keypoints");
-        auto it = cam_by_id.find(im.camera_id);
-        if (it == cam_by_id.end()) throw std::runtime_error("image " + im.name + " references a missing camera");
-        const CameraRow& c = *it->second;
-        Check(amc_upload_camera(ctx_, s, c.model_id, c.width, c.height, c.params.data(),
-                                static_cast<int32_t>(c.params.size()), c.has_prior_focal_length),
+    desc_rows_.assign(images_.size(), 0);
+    // The arena (descriptors, keypoints, camera of every image) is replicated on every context: 0.26 - 5.2 GB for
+    // BASELINE's configs against 288 GB of HBM per GPU.  One reader (SQLite), one uploader
+    // thread per context working through the same rows.
+    struct Row {
+        std::vector<uint8_t> desc;
+        std::vector<float> kp;
+        uint32_t use = 0, krows = 0;
+        const CameraRow* cam = nullptr;
+    };
+    auto upload = [&](amc_ctx* c, uint32_t s, const Row& r) {
+        Check(amc_upload_descriptors(c, s, r.desc.data(), r.use), "amc_upload_descriptors");
+        Check(amc_upload_keypoints(c, s, r.kp.data(), r.krows, 2), "amc_upload_keypoints");
+        Check(amc_upload_camera(c, s, r.cam->model_id, r.cam->width, r.cam->height, r.cam->params.data(),
+                                static_cast<int32_t>(r.cam->params.size()), r.cam->has_prior_focal_length),
               "amc_upload_camera");
+    };
+    constexpr uint32_t kChunk = 64;  // images read from SQLite per round of parallel uploads
+    for (uint32_t s0 = 0; s0 < images_.size(); s0 += kChunk) {
+        const uint32_t s1 = std::min<uint32_t>(s0 + kChunk, static_cast<uint32_t>(images_.size()));
+        std::vector<Row> rows(s1 - s0);
+        for (uint32_t s = s0; s < s1; ++s) {
+            const ImageRow& im = images_[s];
+            slot_of_image_[im.image_id] = s;
+            Row& r = rows[s - s0];
+            uint32_t drows = 0;
+            r.desc = db_->ReadDescriptors(im.image_id, &drows);
+            r.kp = db_->ReadKeypointsXY(im.image_id, &r.krows);
+            // COLMAP's GPU matcher clamps to the first max_num_matches features
+            // (WarnIfMaxNumMatchesReachedGPU; SiftMatchingOptions.max_num_matches)
+            r.use = std::min<uint32_t>(drows, static_cast<uint32_t>(std::max(sift_.max_num_matches, 0)));
+            desc_rows_[s] = r.use;
+            auto it = cam_by_id.find(im.camera_id);
+            if (it == cam_by_id.end()) throw std::runtime_error("image " + im.name + " references a missing camera");
+            r.cam = it->second;
+        }
+        if (ctxs_.size() == 1) {
+            for (uint32_t s = s0; s < s1; ++s) upload(ctx_, s, rows[s - s0]);
+        } else {
+            std::vector<std::future<void>> up;
+            for (amc_ctx* c : ctxs_)
+                up.push_back(std::async(std::launch::async, [&, c] {
+                    for (uint32_t s = s0; s < s1; ++s) upload(c, s, rows[s - s0]);
+                }));
+            for (auto& f : up) f.get();
+        }
     }
 }
 
@@ -169,6 +206,58 @@ std::vector<MatchController::Job> MatchController::Compute(const ImagePairs& ima
     stats.db_ms += NowMs() - t_db0;
     if (jobs.empty()) return jobs;
 
+    // ---- the group's pairs are dealt to the contexts in contiguous ranges of equal matching work (sum of n1 * n2;
+    //      pairs with stored matches cost only their verification and weigh 0 here).  Pairs are independent and
+    //      every pair re-seeds its generator, so what a range computes does not depend on which context took it or
+    //      on how many there are: the rows written are the same for any gpu_index.
+    const size_t D = std::min(ctxs_.size(), jobs.size());
+    if (D <= 1) {
+        ComputeOn(ctx_, jobs, 0, jobs.size());
+    } else {
+        std::vector<double> cum(jobs.size() + 1, 0.0);
+        for (size_t k = 0; k < jobs.size(); ++k) {
+            double w = 1.0;  // never 0: a group of stored-match pairs still splits evenly
+            if (!jobs[k].have_matches)
+                w += static_cast<double>(desc_rows_[SlotOf(jobs[k].id1)]) * static_cast<double>(desc_rows_[SlotOf(jobs[k].id2)]);
+            cum[k + 1] = cum[k] + w;
+        }
+        std::vector<size_t> cut(D + 1, jobs.size());
+        cut[0] = 0;
+        for (size_t d = 1; d < D; ++d)
+            cut[d] = static_cast<size_t>(std::lower_bound(cum.begin(), cum.end(), cum.back() * d / D) - cum.begin());
+        for (size_t d = 1; d <= D; ++d) cut[d] = std::max(cut[d], cut[d - 1]);
+        std::vector<std::future<void>> work;
+        for (size_t d = 0; d < D; ++d)
+            if (cut[d] < cut[d + 1])
+                work.push_back(std::async(std::launch::async, [this, &jobs, &cut, d] { ComputeOn(ctxs_[d], jobs, cut[d], cut[d + 1]); }));
+        std::exception_ptr first;
+        for (auto& f : work) {
+            try {
+                f.get();
+            } catch (...) {
+                if (!first) first = std::current_exception();
+            }
+        }
+        if (first) std::rethrow_exception(first);
+    }
+
+    // only now: a failed call above must leave these pairs eligible for the next attempt
+    for (const Job& j : jobs) computed_.insert(Database::ImagePairToPairId(j.id1, j.id2));
+    return jobs;
+}
+
+// FeatureMatcherWorker + VerifierWorker for jobs[begin, end) on one context
+void MatchController::ComputeOn(amc_ctx* ctx, std::vector<Job>& all_jobs, size_t begin, size_t end) {
+    struct Range {  // the code below indexes jobs[0 .. size())
+        std::vector<Job>& v;
+        size_t b, e;
+        size_t size() const { return e - b; }
+        Job& operator[](size_t k) const { return v[b + k]; }
+        Job* begin() const { return v.data() + b; }
+        Job* end() const { return v.data() + e; }
+    } jobs{all_jobs, begin, end};
+    MatchStats stats;  // this range's share; merged under the lock at the end
+    amc_ctx* const ctx_ = ctx;
     // ---- FeatureMatcherWorker: descriptor matching for the pairs without stored matches ----
     std::vector<uint32_t> s1, s2;
     std::vector<size_t> which;
@@ -308,9 +397,14 @@ std::vector<MatchController::Job> MatchController::Compute(const ImagePairs& ima
         amc_verify_result_free(&vr);
     }
 
-    // only now: a failed call above must leave these pairs eligible for the next attempt
-    for (const Job& j : jobs) computed_.insert(Database::ImagePairToPairId(j.id1, j.id2));
-    return jobs;
+    {
+        std::lock_guard<std::mutex> lock(stats_mu_);
+        MatchStats& t = this->stats;
+        t.pairs_matched += stats.pairs_matched; t.pairs_verified += stats.pairs_verified; t.pairs_guided += stats.pairs_guided;
+        t.match_device_ms += stats.match_device_ms; t.verify_device_ms += stats.verify_device_ms;
+        t.guided_device_ms += stats.guided_device_ms; t.match_call_ms += stats.match_call_ms;
+        t.verify_call_ms += stats.verify_call_ms; t.num_distances += stats.num_distances;
+    }
 }
 
 // ---- controller thread: drop results below min_num_inliers, write both tables ----------

@@ -6,6 +6,7 @@
 #include <atomic>
 #include <functional>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <utility>
 #include <unordered_set>
@@ -86,8 +87,12 @@ struct MatchStats {
 
 class MatchController {
   public:
+    // device_ids: one amc_ctx (with the whole descriptor arena) and one host thread per entry.
+    // SiftMatchingOptions.gpu_index "0,1,2,3" / "-1" = all (/root/reference/pycolmap/pipeline/match_features.h:76-81,
+    // where COLMAP starts one SiftGPU matcher thread per listed index); an index may be listed twice (two
+    // contexts on one device), which is how the single-GPU tests cover the multi-context path.
     MatchController(const std::string& database_path, const SiftMatchingOptions& sift,
-                    const TwoViewGeometryOptions& tvg, int device_id);
+                    const TwoViewGeometryOptions& tvg, std::vector<int> device_ids);
     ~MatchController();
     void Setup();  // read cameras/images/keypoints/descriptors, fill the GPU arena
     // FeatureMatcherController::Match: filter, match, verify, write.  Match() = Compute() + Write();
@@ -101,7 +106,7 @@ class MatchController {
         TwoViewGeometryRow tvg;
     };
     void Match(const ImagePairs& pairs);
-    std::vector<Job> Compute(const ImagePairs& pairs);  // filter against the DB, match, verify
+    std::vector<Job> Compute(const ImagePairs& pairs);  // filter against the DB, match, verify (all devices)
     void Write(std::vector<Job>& jobs);                  // drop what is below min_num_inliers, write both tables
     // Loop-closure candidates of `query` among `candidates` (SequentialFeatureMatcher::RunLoopDetection
     // with the vocabulary-tree query replaced by feature voting, see controller.cc): the up to
@@ -119,12 +124,17 @@ class MatchController {
     std::string path_;
     SiftMatchingOptions sift_;
     TwoViewGeometryOptions tvg_;
-    int device_id_;
+    std::vector<int> device_ids_;
     std::unique_ptr<Database> db_;
     std::vector<ImageRow> images_;
     std::vector<uint32_t> slot_of_image_;  // image_id -> slot (dense table)
-    amc_ctx* ctx_ = nullptr;
+    std::vector<uint32_t> desc_rows_;      // descriptors uploaded per slot (the weights of the work split)
+    std::vector<amc_ctx*> ctxs_;           // one per entry of device_ids_; ctxs_[0] also serves the loop index
+    amc_ctx* ctx_ = nullptr;               // = ctxs_[0]
+    std::mutex stats_mu_;                  // the device threads add their shares to `stats`
     std::atomic<bool> stop_{false};
+    // match + verify (+ guided matching) of jobs[begin, end) on one context; called concurrently for disjoint ranges
+    void ComputeOn(amc_ctx* ctx, std::vector<Job>& jobs, size_t begin, size_t end);
     uint32_t SlotOf(image_t id) const;
     // pairs this run has computed already: their rows may still be on their way to the database
     std::unordered_set<image_pair_t> computed_;

@@ -101,6 +101,8 @@ inline int ParseCameraModel(const py::object& o) {
     return o.cast<int>();
 }
 
+py::object CamFromImgPoints(const PyCamera& c, const py::object& points);  // below (uses the estimator context)
+
 inline void BindCamera(py::module_& m) {
     py::dict members("INVALID"_a = -1);
     for (const auto& cm : CameraModels()) members[py::str(cm.name)] = cm.id;
@@ -183,6 +185,8 @@ inline void BindCamera(py::module_& m) {
         .def("cam_from_img_threshold",
              [](const PyCamera& c, double threshold) { return threshold / c.MeanFocalLength(); },
              "Convert pixel threshold in image plane to world space.")
+        .def("cam_from_img", &CamFromImgPoints, "image_points"_a,
+             "Project point(s) in image plane to world / infinity: one point (2,) or an N x 2 array.")
         .def("verify_params",
              [](const PyCamera& c) {
                  const CameraModelInfo* mi = FindCameraModel(c.model);
@@ -232,10 +236,34 @@ inline size_t CheckPoints(const PointsArray& a, const char* name) {
     }
     return static_cast<size_t>(a.shape(0));
 }
-inline void CheckSameSize(size_t a, size_t b, const char* what) {
+// THROW_CHECK_EQ(points2D1.size(), points2D2.size()) (/root/reference/pycolmap/estimators/fundamental_matrix.h:22):
+// ValueError "[file:line] Check Failed: a == b (x vs. y)"
+#define CheckSameSize(a, b, what) CheckSameSizeAt(__FILE__, __LINE__, (a), (b), (what))
+inline void CheckSameSizeAt(const char* file, int line, size_t a, size_t b, const char* what) {
     if (a != b)
-        throw py::value_error(std::string("[pycolmap_amd] Check Failed: ") + what + " (" + std::to_string(a) + " vs. " +
-                              std::to_string(b) + ")");
+        throw py::value_error(CheckMessage(file, line, std::string(what) + " (" + std::to_string(a) + " vs. " +
+                                                             std::to_string(b) + ")"));
+}
+// Camera.cam_from_img (/root/reference/pycolmap/scene/camera.h:136-150) through amc_cam_from_img
+inline py::object CamFromImgPoints(const PyCamera& c, const py::object& points) {
+    c.CheckParams();
+    auto arr = py::array_t<double, py::array::c_style | py::array::forcecast>::ensure(points);
+    if (!arr) throw py::value_error("cam_from_img: points must be convertible to a float64 array");
+    const bool single = arr.ndim() == 1 && arr.shape(0) == 2;
+    if (!single && !(arr.ndim() == 2 && arr.shape(1) == 2) && arr.size() != 0)
+        throw py::value_error("cam_from_img: expected one point (2,) or an N x 2 array");
+    const size_t n = single ? 1 : static_cast<size_t>(arr.size() / 2);
+    py::array_t<double> out({static_cast<py::ssize_t>(n), static_cast<py::ssize_t>(2)});
+    {
+        py::gil_scoped_release release;
+        EstimatorCtx& E = TheEstimatorCtx();
+        std::lock_guard<std::mutex> lock(E.mu);
+        EstCheck(amc_cam_from_img(E.Get(), c.model, c.params.data(), static_cast<int32_t>(c.params.size()), arr.data(), n,
+                                  out.mutable_data()),
+                 "amc_cam_from_img");
+    }
+    if (single) return out.attr("reshape")(2);
+    return std::move(out);
 }
 inline amc_ransac_opts ToAmcRansac(const RANSACOptions& o) {
     amc_ransac_opts r;

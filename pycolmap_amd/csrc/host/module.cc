@@ -14,9 +14,15 @@
 //   Database                                                /root/reference/pycolmap/scene/database.h:9-46
 //   Camera, *_matrix_estimation, estimate_two_view_geometry, squared_sampson_error -> estimators.h
 #include <pybind11/numpy.h>
+#include <cctype>
+
 #include <pybind11/pybind11.h>
 #include <pybind11/stl.h>
 
+#include <iostream>
+#include <ctime>
+#include <cstdio>
+#include <mutex>
 #include <atomic>
 #include <chrono>
 #include <exception>
@@ -39,10 +45,15 @@ enum class Device { AUTO = -1, CPU = 0, CUDA = 1 };
 std::string PathToString(const py::object& p) {
     return py::module_::import("os").attr("fspath")(p).cast<std::string>();
 }
-void CheckFileExists(const std::string& path) {
-    std::ifstream f(path);
-    if (!f.good()) throw py::value_error("[pycolmap_amd] Check Failed: file " + path + " does not exist.");
-}
+// THROW_CHECK_FILE_EXISTS (/root/reference/pycolmap/log_exceptions.h:54-76, 123-125): ValueError,
+// "[file:line] Check Failed: ExistsFile(path) : File <path> does not exist."
+#define AMC_THROW_CHECK_FILE_EXISTS(path)                                                                        \
+    do {                                                                                                         \
+        std::ifstream f_(path);                                                                                  \
+        if (!f_.good())                                                                                          \
+            throw py::value_error(CheckMessage(__FILE__, __LINE__, "ExistsFile(" #path ")",                      \
+                                               std::string("File ") + (path) + " does not exist."));             \
+    } while (0)
 // VerifyGPUParams analogue.  This package is the accelerator path only.
 void RequireAccelerator(Device d) {
     if (d == Device::CPU)
@@ -71,26 +82,61 @@ void MergeDict(py::object self, const py::dict& d, const std::vector<std::string
         }
     }
 }
-py::dict ToDict(const py::object& self, const std::vector<std::string>& fields) {
+py::dict ToDict(const py::object& self, const std::vector<std::string>& fields, bool recursive = true) {
     py::dict d;
     for (const auto& f : fields) {
         py::object v = self.attr(f.c_str());
-        d[py::str(f)] = py::hasattr(v, "todict") ? v.attr("todict")() : v;
+        d[py::str(f)] = (recursive && py::hasattr(v, "todict")) ? v.attr("todict")() : v;
     }
     return d;
 }
-std::string Summary(const py::object& self, const std::vector<std::string>& fields, int indent) {
+// CreateSummary (/root/reference/pycolmap/helpers.h:159-214): "Name:" then one line per attribute,
+// "    attr = value" ("    attr: type = value" with write_type), nested option objects as "    attr: <their summary>"
+// indented by four more spaces; long sequences abbreviated like the reference does.
+std::string Summary(const py::object& self, const std::vector<std::string>& fields, bool write_type) {
     std::ostringstream ss;
+    const std::string prefix = "    ";
     ss << py::str(self.attr("__class__").attr("__name__")).cast<std::string>() << ":";
     for (const auto& f : fields) {
         py::object v = self.attr(f.c_str());
-        ss << "\n" << std::string(indent + 4, ' ') << f << " = ";
-        if (py::hasattr(v, "summary"))
-            ss << v.attr("summary")(indent + 4).cast<std::string>();
-        else
-            ss << py::repr(v).cast<std::string>();
+        ss << "\n" << prefix << f;
+        if (py::hasattr(v, "summary")) {
+            std::string sub = v.attr("summary")(write_type).cast<std::string>();
+            std::string ind;
+            for (char ch : sub) {
+                ind.push_back(ch);
+                if (ch == '\n') ind += prefix;
+            }
+            ss << ": " << ind;
+        } else {
+            if (write_type) ss << ": " << py::str(py::type::of(v).attr("__name__")).cast<std::string>();
+            std::string value = py::str(v).cast<std::string>();
+            if (value.size() > 80 && py::hasattr(v, "__len__")) {
+                const int n = v.attr("__len__")().cast<int>();
+                value = std::string(1, value.front()) + " ... " + std::to_string(n) + " elements ... " + std::string(1, value.back());
+            }
+            ss << " = " << value;
+        }
     }
     return ss.str();
+}
+// AddDefaultsToDocstrings (/root/reference/pycolmap/helpers.h:217-240): every option's docstring ends in
+// "(type, default: value)", taken from a default-constructed instance
+void AddDefaultsToDocstrings(const py::object& cls, const std::vector<std::string>& fields) {
+    py::object obj = cls();
+    for (const auto& f : fields) {
+        py::object member = obj.attr(f.c_str());
+        py::object prop = cls.attr(f.c_str());
+        const std::string doc = py::str(prop.attr("__doc__")).cast<std::string>();
+        const std::string type_name = py::str(py::type::of(member).attr("__name__")).cast<std::string>();
+        std::string def = py::str(member).cast<std::string>();
+        if (py::hasattr(member, "summary")) def = py::str(member.attr("__class__").attr("__name__")).cast<std::string>() + "()";
+        try {
+            prop.attr("__doc__") = py::str((doc == "None" ? std::string() : doc + " ") + "(" + type_name + ", default: " + def + ")");
+        } catch (const py::error_already_set&) {
+            PyErr_Clear();  // a read-only docstring: leave it
+        }
+    }
 }
 
 template <typename T>
@@ -110,14 +156,17 @@ void MakeDataclass(py::class_<T>& cls, const std::vector<std::string>& fields) {
         return self.cast<T>();
     }));
     py::implicitly_convertible<py::dict, T>();
+    py::implicitly_convertible<py::kwargs, T>();
+    AddDefaultsToDocstrings(cls_obj, fields);
     cls.def("mergedict", [fields](py::object self, const py::dict& d) { MergeDict(self, d, fields); });
-    cls.def("todict", [fields](py::object self) { return ToDict(self, fields); });
-    cls.def("summary", [fields](py::object self, int indent) { return Summary(self, fields, indent); },
-            "indent"_a = 0);
-    cls.def("__repr__", [fields](py::object self) { return Summary(self, fields, 0); });
+    cls.def("todict", [fields](py::object self, bool recursive) { return ToDict(self, fields, recursive); },
+            "recursive"_a = true);
+    cls.def("summary", [fields](py::object self, bool write_type) { return Summary(self, fields, write_type); },
+            "write_type"_a = false);
+    cls.def("__repr__", [fields](py::object self) { return Summary(self, fields, false); });
     cls.def("__copy__", [](const T& self) { return T(self); });
     cls.def("__deepcopy__", [](const T& self, const py::dict&) { return T(self); });
-    cls.def(py::pickle([fields](py::object self) { return ToDict(self, fields); },
+    cls.def(py::pickle([fields](py::object self) { return ToDict(self, fields, /*recursive=*/false); },
                        [fields, cls_obj](const py::dict& d) {
                            py::object self = cls_obj();
                            MergeDict(self, d, fields);
@@ -177,11 +226,129 @@ py::dict StatsDict(const MatchStats& s) {
 
 }  // namespace
 
+// SiftMatchingOptions.gpu_index (/root/reference/pycolmap/pipeline/match_features.h:76-81; COLMAP:
+// "Index of the GPU used for feature matching. For multi-GPU matching, you should separate multiple GPU indices
+// by comma, e.g., '0,1,2,3'", "-1" = every device): the list of devices the controller opens a context on.
+// An index may repeat.  Anything that is not a list of device numbers raises instead of being ignored.
+static std::vector<int> ParseGpuIndex(const std::string& gpu_index) {
+    std::vector<int> out;
+    std::string tok;
+    auto flush = [&] {
+        size_t a = 0, b = tok.size();
+        while (a < b && std::isspace(static_cast<unsigned char>(tok[a]))) ++a;
+        while (b > a && std::isspace(static_cast<unsigned char>(tok[b - 1]))) --b;
+        const std::string t = tok.substr(a, b - a);
+        tok.clear();
+        if (t.empty()) throw py::value_error("gpu_index: empty entry in '" + gpu_index + "'");
+        size_t pos = 0;
+        int v = 0;
+        try {
+            v = std::stoi(t, &pos);
+        } catch (const std::exception&) {
+            pos = 0;
+        }
+        if (pos != t.size()) throw py::value_error("gpu_index: '" + t + "' is not a device number (in '" + gpu_index + "')");
+        out.push_back(v);
+    };
+    for (char ch : gpu_index) {
+        if (ch == ',') flush();
+        else tok.push_back(ch);
+    }
+    flush();
+    if (out.size() == 1 && out[0] == -1) {  // all devices
+        const int n = amc_device_count();
+        if (n <= 0) throw std::runtime_error(std::string("gpu_index -1: no MI355X device visible: ") + (n < 0 ? amc_last_error() : ""));
+        out.clear();
+        for (int i = 0; i < n; ++i) out.push_back(i);
+        return out;
+    }
+    for (int v : out)
+        if (v < 0) throw py::value_error("gpu_index: negative device number in '" + gpu_index + "' (-1 alone means all devices)");
+    return out;
+}
+
+// ---- pycolmap.logging (/root/reference/pycolmap/main.cc:39-89): the glog front end the reference exposes -
+// flags, per-severity destinations, info / warning / error / fatal stamped with the Python call site.  There is no
+// glog here; the few lines it amounts to for this surface are written out: glog's line format, severity filtering
+// by minloglevel / stderrthreshold, optional files.  fatal raises (glog aborts the process).
+struct Logging {
+    enum Level { INFO = 0, WARNING = 1, ERROR = 2, FATAL = 3 };
+    static int minloglevel, stderrthreshold;
+    static std::string log_dir;
+    static bool logtostderr, alsologtostderr;
+    static std::string destination[4];
+    static std::mutex mu;
+    static void Write(Level lv, const std::string& where, int line, const std::string& msg) {
+        if (static_cast<int>(lv) < minloglevel) return;
+        const auto now = std::chrono::system_clock::now();
+        const std::time_t t = std::chrono::system_clock::to_time_t(now);
+        const long us = static_cast<long>(std::chrono::duration_cast<std::chrono::microseconds>(now.time_since_epoch()).count() % 1000000);
+        std::tm tmv;
+        localtime_r(&t, &tmv);
+        char head[64];
+        std::snprintf(head, sizeof head, "%c%04d%02d%02d %02d:%02d:%02d.%06ld", "IWEF"[lv], tmv.tm_year + 1900, tmv.tm_mon + 1,
+                      tmv.tm_mday, tmv.tm_hour, tmv.tm_min, tmv.tm_sec, us);
+        std::ostringstream ln;
+        ln << head << " " << std::this_thread::get_id() << " " << where << ":" << line << "] " << msg << "\n";
+        std::lock_guard<std::mutex> lock(mu);
+        if (logtostderr || alsologtostderr || static_cast<int>(lv) >= stderrthreshold) std::cerr << ln.str() << std::flush;
+        if (!logtostderr)
+            for (int k = 0; k <= static_cast<int>(lv); ++k) {  // glog: a message goes to its severity's file and all lower ones
+                std::string path = destination[k];
+                if (path.empty() && !log_dir.empty()) path = log_dir + "/pycolmap_amd." + "IWEF"[k] + ".log";
+                if (path.empty()) continue;
+                std::ofstream f(path, std::ios::app);
+                f << ln.str();
+            }
+    }
+};
+int Logging::minloglevel = 0;
+int Logging::stderrthreshold = 2;
+std::string Logging::log_dir;
+bool Logging::logtostderr = false;
+bool Logging::alsologtostderr = true;   // the reference sets FLAGS_alsologtostderr = true at import
+std::string Logging::destination[4];
+std::mutex Logging::mu;
+
+static std::pair<std::string, int> PythonCallFrame() {
+    const py::object frame = py::module_::import("sys").attr("_getframe")(0);
+    const std::string file = py::str(frame.attr("f_code").attr("co_filename"));
+    const std::string function = py::str(frame.attr("f_code").attr("co_name"));
+    return {file + ":" + function, py::int_(frame.attr("f_lineno"))};
+}
+
+static void BindLogging(py::module_& m) {
+    py::class_<Logging> PyLogging(m, "logging");
+    PyLogging.def_readwrite_static("minloglevel", &Logging::minloglevel)
+        .def_readwrite_static("stderrthreshold", &Logging::stderrthreshold)
+        .def_readwrite_static("log_dir", &Logging::log_dir)
+        .def_readwrite_static("logtostderr", &Logging::logtostderr)
+        .def_readwrite_static("alsologtostderr", &Logging::alsologtostderr)
+        .def_static("set_log_destination",
+                    [](Logging::Level severity, const std::string& path) { Logging::destination[severity] = path; })
+        .def_static("info", [](const std::string& msg) { auto f = PythonCallFrame(); Logging::Write(Logging::INFO, f.first, f.second, msg); })
+        .def_static("warning", [](const std::string& msg) { auto f = PythonCallFrame(); Logging::Write(Logging::WARNING, f.first, f.second, msg); })
+        .def_static("error", [](const std::string& msg) { auto f = PythonCallFrame(); Logging::Write(Logging::ERROR, f.first, f.second, msg); })
+        .def_static("fatal", [](const std::string& msg) {
+            auto f = PythonCallFrame();
+            Logging::Write(Logging::FATAL, f.first, f.second, msg);
+            throw std::runtime_error("pycolmap.logging.fatal: " + msg);
+        });
+    py::enum_<Logging::Level>(PyLogging, "Level")
+        .value("INFO", Logging::INFO)
+        .value("WARNING", Logging::WARNING)
+        .value("ERROR", Logging::ERROR)
+        .value("FATAL", Logging::FATAL)
+        .export_values();
+}
+
 PYBIND11_MODULE(_pycolmap, m) {
     m.doc() = "MI355X-native match + verify path behind the pycolmap API (pycolmap_amd)";
     m.attr("has_cuda") = true;  // drop-in: "an accelerator is available" (it is an MI355X)
     m.attr("has_hip") = true;
     m.attr("COLMAP_version") = "3.9.1-semantics";
+    m.attr("COLMAP_build") = "pycolmap_amd (libamc.so, gfx950)";
+    BindLogging(m);
 
     py::enum_<Device> PyDevice(m, "Device");
     PyDevice.value("auto", Device::AUTO).value("cpu", Device::CPU).value("cuda", Device::CUDA);
@@ -383,9 +550,8 @@ PYBIND11_MODULE(_pycolmap, m) {
     // ---- Database ---------------------------------------------------------------------------
     py::class_<Database>(m, "Database")
         .def(py::init([](const py::object& path) {
-                 const std::string p = PathToString(path);
-                 CheckFileExists(p);
-                 return std::make_unique<Database>(p);
+                 // Database::Open: creates the file and COLMAP's tables when they are missing
+                 return std::make_unique<Database>(PathToString(path));
              }),
              "path"_a)
         .def_property_readonly("num_cameras", &Database::NumCameras)
@@ -478,15 +644,14 @@ PYBIND11_MODULE(_pycolmap, m) {
     BindEstimators(m);
 
     // ---- pipeline entry points ----------------------------------------------------------------
+    m.def("_parse_gpu_index", &ParseGpuIndex, "gpu_index"_a, "SiftMatchingOptions.gpu_index -> device list (test hook)");
     auto run_pipeline = [](const py::object& database_path, const SiftMatchingOptions& sift,
                            const TwoViewGeometryOptions& tvg, Device device,
                            const std::function<void(MatchController&)>& body) {
         const std::string db_path = PathToString(database_path);
-        CheckFileExists(db_path);
+        AMC_THROW_CHECK_FILE_EXISTS(db_path);
         RequireAccelerator(device);
-        int dev = 0;  // gpu_index "-1" = default device; "k[,..]" = first listed device
-        if (!sift.gpu_index.empty() && sift.gpu_index != "-1") dev = std::stoi(sift.gpu_index);
-        MatchController ctrl(db_path, sift, tvg, dev);
+        MatchController ctrl(db_path, sift, tvg, ParseGpuIndex(sift.gpu_index));
         RunInterruptible(ctrl, [&] {
             ctrl.Setup();
             body(ctrl);
@@ -517,8 +682,9 @@ PYBIND11_MODULE(_pycolmap, m) {
         [run_pipeline](const py::object& database_path, const py::object& pairs_path,
                        const TwoViewGeometryOptions& tvg) {
             const std::string pp = PathToString(pairs_path);
-            CheckFileExists(PathToString(database_path));
-            CheckFileExists(pp);
+            const std::string dbp = PathToString(database_path);
+            AMC_THROW_CHECK_FILE_EXISTS(dbp);
+            AMC_THROW_CHECK_FILE_EXISTS(pp);
             run_pipeline(database_path, SiftMatchingOptions(), tvg, Device::AUTO,
                          [&](MatchController& c) { RunImagePairs(c, pp); });
         },

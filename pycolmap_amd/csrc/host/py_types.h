@@ -5,10 +5,20 @@
 
 #include <array>
 #include <cstring>
+#include <string>
 #include <vector>
 
 namespace amchost {
 namespace py = pybind11;
+
+// The reference's exception text (/root/reference/pycolmap/log_exceptions.h:29-76): "[file:line] Check Failed: expr"
+// or "... expr : message"; file is the base name of the throwing source file.
+inline std::string CheckMessage(const char* file, int line, const std::string& expr, const std::string& msg = std::string()) {
+    const char* base = std::strrchr(file, '/');
+    std::string out = std::string("[") + (base ? base + 1 : file) + ":" + std::to_string(line) + "] Check Failed: " + expr;
+    if (!msg.empty()) out += " : " + msg;
+    return out;
+}
 
 // Rotation3d / Rigid3d value types (/root/reference/pycolmap/geometry/bindings.h:24-104): only what a
 // TwoViewGeometry's cam2_from_cam1 needs - the quaternion in Eigen's (x, y, z, w) coefficient order,

@@ -117,8 +117,13 @@ def test_database_binding_reads_colmap_schema(tmp_path):
     assert db.exists_matches(ids[0], ids[2]) and not db.exists_inlier_matches(ids[0], ids[1])
     g = db.read_two_view_geometry(ids[0], ids[1])
     assert g.config == pycolmap.TwoViewGeometryConfiguration.UNDEFINED and g.inlier_matches.shape == (0, 2)
-    with pytest.raises(ValueError):
-        pycolmap.Database(tmp_path / "nope.db")
+    # Database::Open creates a missing file with COLMAP's empty tables (like the reference's Database(path))
+    fresh = pycolmap.Database(tmp_path / "fresh.db")
+    assert fresh.num_images == 0 and fresh.num_matches == 0 and fresh.num_cameras == 0
+    del fresh
+    import sqlite3
+    tables = {r[0] for r in sqlite3.connect(tmp_path / "fresh.db").execute("SELECT name FROM sqlite_master WHERE type='table'")}
+    assert {"cameras", "images", "keypoints", "descriptors", "matches", "two_view_geometries"} <= tables
     # keypoints / descriptors / matches accessors (unbound in the reference)
     np.testing.assert_array_equal(db.read_keypoints(ids[1]), np.ascontiguousarray(imgs[1]["keypoints"], np.float32))
     np.testing.assert_array_equal(db.read_descriptors(ids[2]), imgs[2]["descriptors"])
@@ -225,3 +230,69 @@ def test_estimator_bindings_argument_checks():
     if not torch.cuda.is_available():
         with pytest.raises(RuntimeError, match="amc_ctx_create"):
             pc.fundamental_matrix_estimation(np.zeros((8, 2)), np.zeros((8, 2)))
+
+
+def test_gpu_index_parsing():
+    """SiftMatchingOptions.gpu_index (/root/reference/pycolmap/pipeline/match_features.h:76-81): a comma-separated
+    device list, one context per entry; anything else raises instead of being silently ignored."""
+    import pycolmap_amd as pc
+    parse = pc._pycolmap._parse_gpu_index
+    assert parse("0") == [0] and parse("0,1,2,3") == [0, 1, 2, 3] and parse(" 1 , 1 ") == [1, 1]
+    for bad in ("", "x", "0,,1", "0,", "-2", "0,-1", "1.5", "0 1"):
+        with pytest.raises(ValueError):
+            parse(bad)
+    with pytest.raises(RuntimeError):      # "-1" = all devices: there is none in the CPU container
+        parse("-1")
+
+
+def test_option_protocol_matches_the_reference_helpers():
+    """/root/reference/pycolmap/helpers.h:159-283: summary(write_type), todict(recursive), defaults in docstrings,
+    dict / kwargs construction and implicit conversion, copy and pickle."""
+    import copy
+    import pickle
+
+    import pycolmap_amd as pc
+    o = pc.TwoViewGeometryOptions(min_num_inliers=20, ransac=dict(max_error=2.0))
+    lines = o.summary().splitlines()
+    assert lines[0] == "TwoViewGeometryOptions:" and "    min_num_inliers = 20" in lines
+    assert "    ransac: RANSACOptions:" in lines and "        max_error = 2.0" in lines           # nested, four deeper
+    typed = o.summary(write_type=True).splitlines()
+    assert "    min_num_inliers: int = 20" in typed and "        max_error: float = 2.0" in typed
+    assert isinstance(o.todict()["ransac"], dict) and o.todict(recursive=True)["ransac"]["max_error"] == 2.0
+    assert isinstance(o.todict(recursive=False)["ransac"], pc.RANSACOptions)
+    assert "(int, default: 15)" in pc.TwoViewGeometryOptions.min_num_inliers.__doc__
+    assert "(float, default: 0.8)" in pc.SiftMatchingOptions.max_ratio.__doc__
+    assert pc.SiftMatchingOptions.max_ratio.__doc__.startswith("Maximum distance ratio")
+    assert "(str, default: -1)" in pc.SiftMatchingOptions.gpu_index.__doc__
+    for c in (copy.copy(o), copy.deepcopy(o), pickle.loads(pickle.dumps(o)), pc.TwoViewGeometryOptions(o.todict())):
+        assert c.todict() == o.todict()
+    with pytest.raises(ValueError, match=r"^\[module\.cc:\d+\] Check Failed: ExistsFile\(db_path\) : File .* does not exist\.$"):
+        pc.match_exhaustive("/nonexistent/database.db")
+    with pytest.raises(ValueError, match=r"^\[estimators\.h:\d+\] Check Failed: .*\(5 vs\. 6\)$"):
+        pc.fundamental_matrix_estimation(np.zeros((5, 2)), np.zeros((6, 2)))
+
+
+def test_logging_surface_and_pycolmap_alias(tmp_path, capfd):
+    """/root/reference/pycolmap/main.cc:39-89 (logging) and :91-118 (the module is called pycolmap)."""
+    import pycolmap
+    import pycolmap_amd as pc
+    assert pycolmap.match_exhaustive is pc.match_exhaustive and pycolmap.TwoViewGeometryOptions is pc.TwoViewGeometryOptions
+    assert pycolmap.has_cuda and isinstance(pycolmap.COLMAP_version, str) and isinstance(pycolmap.COLMAP_build, str)
+    with pytest.raises(AttributeError, match="outside pycolmap_amd's scope"):
+        pycolmap.incremental_mapping
+    lg = pycolmap.logging
+    assert lg.Level.INFO == lg.INFO and int(lg.WARNING) == 1 and int(lg.FATAL) == 3
+    lg.set_log_destination(lg.INFO, str(tmp_path / "info.log"))
+    lg.info("hello from the test")
+    lg.warning("careful")
+    err = capfd.readouterr().err
+    assert "hello from the test" in err and err.lstrip().startswith("I") and "test_logging_surface_and_pycolmap_alias" in err
+    text = (tmp_path / "info.log").read_text()
+    assert "hello from the test" in text and "careful" in text
+    lg.minloglevel = 2
+    lg.info("suppressed")
+    assert "suppressed" not in capfd.readouterr().err
+    lg.minloglevel = 0
+    with pytest.raises(RuntimeError):
+        lg.fatal("stop")
+    lg.set_log_destination(lg.INFO, "")

@@ -252,3 +252,54 @@ def test_match_sequential_loop_detection(tmp_path):
     # the loop pairs are pairs the sequential pass did not cover
     seq_pairs = {colmap_db.pair_id(a, b) for blk in blocks for a, b in blk if a != b}
     assert any(colmap_db.pair_id(a, b) not in seq_pairs for blk in loop_blocks for a, b in blk)
+
+
+def _dump_tables(db_path):
+    import sqlite3
+    con = sqlite3.connect(db_path)
+    out = [list(con.execute(f"SELECT * FROM {t} ORDER BY pair_id")) for t in ("matches", "two_view_geometries")]
+    con.close()
+    return out
+
+
+@pytest.mark.parametrize("gpu_index", ["0,0", "0,0,0", "-1"])
+def test_multi_context_run_writes_the_same_database(tmp_path, gpu_index):
+    """SiftMatchingOptions.gpu_index = "0,1,.." / "-1": one context + one host thread per entry, the group's pairs
+    dealt to them by work.  Two (three) contexts on the one device of the test box must leave exactly the rows the
+    single-context run leaves - every column of both tables, byte for byte, rows in the same order."""
+    rng = np.random.default_rng(8)
+    images = synth.multiview_scene(rng, num_images=5, n_feats=384) + synth.multiview_scene(rng, num_images=4, n_feats=700)
+    for k, im in enumerate(images):
+        im["name"] = f"im{k:03d}.jpg"
+        im["prior"] = k % 2 == 0
+    dumps = {}
+    for tag, idx in (("single", "0"), ("multi", gpu_index)):
+        db = tmp_path / f"{tag}.db"
+        colmap_db.create(db, images)
+        pycolmap.match_exhaustive(db, sift_options={"gpu_index": idx, "guided_matching": True},
+                                  matching_options={"block_size": 4}, verification_options={"compute_relative_pose": True})
+        dumps[tag] = _dump_tables(db)
+        assert pycolmap.last_run_stats()["pairs_matched"] == 36
+    assert dumps["single"] == dumps["multi"]
+    assert len(dumps["single"][0]) == 36 and sum(r[4] >= 2 for r in dumps["single"][1]) >= 10
+    # stored matches + verify_matches through several contexts
+    db = tmp_path / "stored.db"
+    ids = colmap_db.create(db, images)
+    for a, b in ((0, 1), (1, 2), (5, 6), (7, 8), (0, 8)):
+        colmap_db.write_matches(db, ids[a], ids[b], o.match(images[a]["descriptors"], images[b]["descriptors"]))
+    pairs_txt = tmp_path / "pairs.txt"
+    pairs_txt.write_text("\n".join(f"{images[a]['name']} {images[b]['name']}" for a, b in ((0, 1), (1, 2), (5, 6), (7, 8), (0, 8))))
+    pycolmap.verify_matches(db, pairs_txt)
+    assert pycolmap.last_run_stats()["pairs_verified"] >= 4
+
+
+def test_bad_gpu_index_raises(tmp_path):
+    rng = np.random.default_rng(9)
+    images = synth.multiview_scene(rng, num_images=3, n_feats=128)
+    db = tmp_path / "db.db"
+    colmap_db.create(db, images)
+    with pytest.raises(ValueError):
+        pycolmap.match_exhaustive(db, sift_options={"gpu_index": "0,gpu1"})
+    with pytest.raises(ValueError):
+        pycolmap.match_exhaustive(db, sift_options={"gpu_index": "0,99"})      # no such device
+    assert colmap_db.read_all(db) == ({}, {})

@@ -339,7 +339,9 @@ def test_fused_match_verify_equals_the_two_calls(amc_ctx, monkeypatch, pose):
     also with the matcher forced into many small batches (the resident table is appended batch after batch)."""
     rng = np.random.default_rng(77)
     cam = ("SIMPLE_RADIAL", synth.EXAMPLE_CAMERAS["SIMPLE_RADIAL"])
-    images = synth.multiview_scene(rng, num_images=9, n_feats=640, camera=cam if pose else None)
+    # two unrelated scenes: pairs across them share nothing (a handful of chance matches: DEGENERATE)
+    images = synth.multiview_scene(rng, num_images=5, n_feats=640, camera=cam if pose else None) + \
+        synth.multiview_scene(rng, num_images=4, n_feats=640, camera=cam if pose else None)
     amc_ctx.reserve_slots(len(images))
     for k, im in enumerate(images):
         amc_ctx.upload_descriptors(k, im["descriptors"])
