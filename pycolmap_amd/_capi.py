@@ -34,6 +34,32 @@ RANSAC_F, RANSAC_H, RANSAC_E = 0, 1, 2
 RANSAC_KINDS = {"F": RANSAC_F, "H": RANSAC_H, "E": RANSAC_E}
 
 
+class _MatchLease:
+    """Owns one amc_match_result; frees it when the arrays viewing it are gone."""
+
+    def __init__(self, lib, res):
+        self._lib, self._res = lib, res
+
+    def __del__(self):
+        try:
+            self._lib.amc_match_result_free(C.byref(self._res))
+        except Exception:  # interpreter shutdown
+            pass
+
+
+class _LeasedArray(np.ndarray):
+    """ndarray view that keeps its lease alive (numpy views of it inherit the reference through .base)."""
+
+    @staticmethod
+    def wrap(arr, lease):
+        out = arr.view(_LeasedArray)
+        out._lease = lease
+        return out
+
+    def __array_finalize__(self, obj):
+        self._lease = getattr(obj, "_lease", None)
+
+
 class AmcError(RuntimeError):
     def __init__(self, code: int, msg: str):
         super().__init__(f"amc error {code}: {msg}")
@@ -246,8 +272,9 @@ class Context:
         _check(self._lib.amc_upload_descriptors_device(self._h, slot, C.c_void_p(dev_ptr), rows))
 
     def match_pairs(self, slot1, slot2, max_ratio: float = 0.8, max_distance: float = 0.7,
-                    cross_check: bool = True, kernel: str = "auto"):
-        """Returns (offsets uint64[npairs+1], matches uint32[M,2], stats dict)."""
+                    cross_check: bool = True, kernel: str = "auto", copy: bool = True):
+        """Returns (offsets uint64[npairs+1], matches uint32[M,2], stats dict).  copy=False: the arrays are views of
+        the library's pinned result buffer (freed when they are collected) instead of private copies."""
         s1 = np.ascontiguousarray(slot1, dtype=np.uint32)
         s2 = np.ascontiguousarray(slot2, dtype=np.uint32)
         if s1.shape != s2.shape or s1.ndim != 1:

@@ -8,6 +8,8 @@
 #include <cstring>
 #include <limits>
 #include <map>
+#include <memory>
+#include <mutex>
 #include <new>
 #include <string>
 #include <thread>
@@ -99,6 +101,40 @@ struct PinBuf {
     }
 };
 
+// Pinned host buffers behind amc_match_result.matches.  A result leases one (the D2H copies of a call land in it
+// directly); amc_match_result_free returns it for the next call, so a pipeline allocates pinned memory once.  The
+// pool is shared-owned: results may outlive their context.
+struct PinnedPool {
+    std::mutex mu;
+    std::vector<PinBuf<uint32_t>> idle;
+    PinBuf<uint32_t> acquire() {
+        std::lock_guard<std::mutex> lock(mu);
+        if (idle.empty()) return PinBuf<uint32_t>();
+        size_t best = 0;
+        for (size_t i = 1; i < idle.size(); ++i)
+            if (idle[i].cap > idle[best].cap) best = i;
+        PinBuf<uint32_t> b = idle[best];
+        idle.erase(idle.begin() + best);
+        return b;
+    }
+    void give_back(PinBuf<uint32_t> b) {
+        if (!b.p) return;
+        std::lock_guard<std::mutex> lock(mu);
+        if (idle.size() >= 3) {  // keep the three largest
+            size_t small = 0;
+            for (size_t i = 1; i < idle.size(); ++i)
+                if (idle[i].cap < idle[small].cap) small = i;
+            if (idle[small].cap < b.cap) std::swap(idle[small], b);
+            b.release();
+            return;
+        }
+        idle.push_back(b);
+    }
+    ~PinnedPool() {
+        for (auto& b : idle) b.release();
+    }
+};
+
 // key of a cached dyn_max_num_trials table
 struct TrialTabKey {
     uint32_t M;
@@ -134,6 +170,9 @@ struct amc_ctx {
     // amc_match_verify_pairs: the matches of every batch of the call stay here (appended batch after batch), so
     // that the verification kernel reads them where the matcher left them instead of from a host round trip
     DevBuf<uint32_t> d_keep;
+    DevBuf<uint64_t> d_csr;                 // per batch: where each pair's matches go in d_keep (pair order)
+    PinBuf<uint64_t> h_csr[2];
+    std::shared_ptr<PinnedPool> result_pool = std::make_shared<PinnedPool>();
     // host staging of a match batch, two sets: batch k+1 is prepared and enqueued while the results of
     // batch k are still being copied out and scattered (match_impl)
     PinBuf<PairDev> h_pairs[2];
@@ -248,7 +287,8 @@ void amc_ctx_destroy(amc_ctx* c) {
     c->d_pairs.release(); c->d_work.release(); c->d_order.release(); c->d_order2.release();
     c->d_rowbuf.release(); c->d_colbuf.release(); c->d_accmask.release(); c->d_guided.release();
     c->d_pair_off.release(); c->d_pair_cnt.release(); c->d_matches.release();
-    c->d_cand_cnt.release(); c->d_candbuf.release(); c->d_keep.release();
+    c->d_cand_cnt.release(); c->d_candbuf.release(); c->d_keep.release(); c->d_csr.release();
+    c->h_csr[0].release(); c->h_csr[1].release();
     for (int k = 0; k < 2; ++k) {
         c->h_pairs[k].release(); c->h_work[k].release(); c->h_order[k].release(); c->h_order2[k].release();
         c->h_pair_off[k].release(); c->h_pair_cnt[k].release(); c->h_matches[k].release();
@@ -363,7 +403,12 @@ namespace {
 
 struct ResultPriv {
     std::vector<uint64_t> offsets;
-    std::vector<uint32_t> matches;
+    PinBuf<uint32_t> matches;               // leased from the context's pool, returned by amc_match_result_free
+    std::shared_ptr<PinnedPool> pool;
+    ~ResultPriv() {
+        if (pool) pool->give_back(matches);
+        else matches.release();
+    }
 };
 
 int ceil_log2(uint32_t x) {
@@ -440,7 +485,9 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
     ResultPriv* priv = new (std::nothrow) ResultPriv();
     if (!priv) return fail(AMC_E_NOMEM, "amc_match_pairs: out of host memory");
     priv->offsets.assign(npairs + 1, 0);
-    size_t keep_used = 0;  // matches appended to c->d_keep so far
+    priv->pool = c->result_pool;
+    priv->matches = c->result_pool->acquire();
+    size_t keep_used = 0;  // matches of this call in c->d_keep so far (pair order: the result's CSR layout)
     if (keep_off) keep_off->assign(npairs, 0);
 
     const float max_ratio_f = (float)o.max_ratio;
@@ -676,14 +723,23 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
             rc = fail(AMC_E_HIP, "amc_match_pairs: internal: %u matches exceed capacity %zu", b.total, b.cap);
             return false;
         }
-        // the pinned staging buffer follows the ACTUAL number of matches, not the worst case
-        if (b.total &&
-            (!hc(c->h_matches[k].ensure(2 * (size_t)b.total), "pinned matches") ||
-             !hc(hipMemcpyAsync(c->h_matches[k].p, c->d_matches.p, (size_t)b.total * 2 * sizeof(uint32_t),
-                                hipMemcpyDeviceToHost, st), "D2H matches")))
+        // The batch's matches lie in d_matches in the order the workgroups claimed space (atomic cursor).  Put them
+        // in pair order behind the batches before it in d_keep - the CSR layout of the result - and copy that
+        // straight into the result's pinned buffer: no per-pair scatter on the host, and amc_match_verify_pairs
+        // reads the same table.
+        if (!hc(c->h_csr[k].ensure(b.nb), "pinned csr")) return false;
+        uint64_t run = keep_used;
+        for (size_t i = 0; i < b.nb; ++i) {
+            c->h_csr[k].p[i] = run;
+            if (keep_off) (*keep_off)[b.begin + i] = run;
+            run += c->h_pair_cnt[k].p[i];
+        }
+        if (run - keep_used != b.total) {
+            rc = fail(AMC_E_HIP, "amc_match_pairs: internal: pair counts (%llu) disagree with the cursor (%u)",
+                      (unsigned long long)(run - keep_used), b.total);
             return false;
-        if (keep_off) {
-            // append the batch to the resident table (in stream order, before the next batch reuses d_matches)
+        }
+        if (b.total) {
             const size_t need = 2 * (keep_used + (size_t)b.total);
             if (need > c->d_keep.cap) {
                 DevBuf<uint32_t> bigger;
@@ -696,13 +752,24 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
                 c->d_keep.release();
                 c->d_keep = bigger;
             }
-            if (b.total &&
-                !hc(hipMemcpyAsync(c->d_keep.p + 2 * keep_used, c->d_matches.p, (size_t)b.total * 2 * sizeof(uint32_t),
-                                   hipMemcpyDeviceToDevice, st), "D2D matches"))
+            if (need > priv->matches.cap) {  // grow the result buffer (first calls only: the pool keeps it)
+                if (!hc(hipStreamSynchronize(st), "sync before growing the result buffer")) return false;
+                PinBuf<uint32_t> bigger;
+                if (!hc(bigger.ensure(std::max(need, 2 * priv->matches.cap)), "pinned result")) return false;
+                if (keep_used) std::memcpy(bigger.p, priv->matches.p, 2 * keep_used * sizeof(uint32_t));
+                priv->matches.release();
+                priv->matches = bigger;
+            }
+            if (!hc(c->d_csr.ensure(b.nb), "dev csr") ||
+                !hc(hipMemcpyAsync(c->d_csr.p, c->h_csr[k].p, b.nb * sizeof(uint64_t), hipMemcpyHostToDevice, st), "H2D csr"))
                 return false;
-            for (size_t i = 0; i < b.nb; ++i) (*keep_off)[b.begin + i] = keep_used + c->h_pair_off[k].p[i];
-            keep_used += b.total;
+            launch_reorder_matches(c->d_pair_off.p, c->d_pair_cnt.p, c->d_csr.p, (uint32_t)b.nb, c->d_matches.p, c->d_keep.p, st);
+            if (!hc(hipGetLastError(), "reorder launch") ||
+                !hc(hipMemcpyAsync(priv->matches.p + 2 * keep_used, c->d_keep.p + 2 * keep_used,
+                                   (size_t)b.total * 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st), "D2H matches"))
+                return false;
         }
+        keep_used += b.total;
         return hc(hipEventRecord(c->bev[k][4], st), "event record");
     };
     // append the batch's matches to the result CSR (pairs keep the caller's order)
@@ -712,15 +779,8 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, c->bev[k][0], c->bev[k][1]) == hipSuccess) kernel_ms += ms;
         if (hipEventElapsedTime(&ms, c->bev[k][1], c->bev[k][2]) == hipSuccess) cross_ms += ms;
-        priv->matches.reserve(priv->matches.size() + 2 * (size_t)b.total);
-        for (size_t i = 0; i < b.nb; ++i) {
-            const uint32_t cnt = c->h_pair_cnt[k].p[i];
-            const uint32_t off = c->h_pair_off[k].p[i];
-            priv->offsets[b.begin + i + 1] = priv->offsets[b.begin + i] + cnt;
-            if (cnt)
-                priv->matches.insert(priv->matches.end(), c->h_matches[k].p + 2ull * off,
-                                     c->h_matches[k].p + 2ull * (off + cnt));
-        }
+        for (size_t i = 0; i < b.nb; ++i)
+            priv->offsets[b.begin + i + 1] = priv->offsets[b.begin + i] + c->h_pair_cnt[k].p[i];
         return true;
     };
 
@@ -754,7 +814,7 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
 
     out->npairs = npairs;
     out->offsets = priv->offsets.data();
-    out->matches = priv->matches.empty() ? nullptr : priv->matches.data();
+    out->matches = priv->offsets[npairs] ? priv->matches.p : nullptr;
     out->num_distances = num_dist;
     out->pairs_mfma = n_mfma;
     out->pairs_dot4 = n_dot4;

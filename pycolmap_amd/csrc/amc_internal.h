@@ -127,6 +127,9 @@ void launch_finalize(const ImageDev* imgs, const PairDev* pairs, uint32_t npairs
                      const float* acos_lut, FinalizeParams fp, uint32_t* cursor, uint32_t capacity,
                      uint32_t* pair_off, uint32_t* pair_cnt, uint32_t* matches, hipStream_t s);
 
+void launch_reorder_matches(const uint32_t* src_off, const uint32_t* cnt, const uint64_t* dst_off, uint32_t npairs,
+                            const uint32_t* src, uint32_t* dst, hipStream_t s);
+
 // ----- two-view verification (tvg.hip) ------------------------------------------------------
 struct CameraDev {
     int32_t model_id;    // COLMAP camera model id 0..10 (camera_math.h)

@@ -318,6 +318,28 @@ void launch_select_candidates(const ImageDev* imgs, const PairDev* pairs, uint32
                        rowbuf, accmask, acos_lut, fp, cand_cnt, candbuf);
 }
 
+// Pair p's matches sit at src + 2 * src_off[p] (finalize_kernel's atomic-cursor order); move them to
+// dst + 2 * dst_off[p]: the batch in pair order, i.e. the CSR layout of the result, so that one D2H copy lands them
+// where the caller reads them (no per-pair scatter on the host) and the verification kernel can index them by pair.
+// One wave per pair, 8-byte elements, consecutive lanes on consecutive matches.
+__global__ __launch_bounds__(256) void reorder_matches_kernel(const uint32_t* __restrict__ src_off,
+                                                              const uint32_t* __restrict__ cnt,
+                                                              const uint64_t* __restrict__ dst_off, uint32_t npairs,
+                                                              const uint2* __restrict__ src, uint2* __restrict__ dst) {
+    const uint32_t p = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (p >= npairs) return;
+    const uint32_t n = cnt[p];
+    const uint2* s = src + src_off[p];
+    uint2* d = dst + dst_off[p];
+    for (uint32_t i = threadIdx.x & 63; i < n; i += 64) d[i] = s[i];
+}
+void launch_reorder_matches(const uint32_t* src_off, const uint32_t* cnt, const uint64_t* dst_off, uint32_t npairs,
+                            const uint32_t* src, uint32_t* dst, hipStream_t s) {
+    if (npairs == 0) return;
+    hipLaunchKernelGGL(reorder_matches_kernel, dim3((npairs + 3) / 4), dim3(256), 0, s, src_off, cnt, dst_off, npairs,
+                       reinterpret_cast<const uint2*>(src), reinterpret_cast<uint2*>(dst));
+}
+
 void launch_finalize(const ImageDev* imgs, const PairDev* pairs, uint32_t npairs,
                      const Top2* rowbuf, const Top2* colbuf, const uint32_t* accmask,
                      const float* acos_lut, FinalizeParams fp, uint32_t* cursor, uint32_t capacity,
