@@ -1,6 +1,7 @@
 // amc_api.hip — host side of libamc.so: implements include/amc.h on top of the HIP kernels.
 // No CPU fallback: every entry point that computes needs a gfx950 device.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -435,6 +436,13 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
     std::memset(out, 0, sizeof *out);
     if (npairs > 0 && (!slot1 || !slot2))
         return fail(AMC_E_INVALID, "amc_match_pairs: NULL pair arrays");
+    // AMC_MATCH_PROFILE=1: wall-clock of the call's host phases on stderr
+    const bool prof = std::getenv("AMC_MATCH_PROFILE") != nullptr;
+    const auto wall0 = std::chrono::steady_clock::now();
+    double t_prepare = 0.0, t_collect = 0.0, t_enqueue = 0.0, t_scatter = 0.0;
+    auto since = [](std::chrono::steady_clock::time_point t) {
+        return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count();
+    };
     amc_match_opts o;
     if (opts_in) o = *opts_in; else amc_match_opts_default(&o);
     if (o.kernel != AMC_KERNEL_AUTO && o.kernel != AMC_KERNEL_MFMA && o.kernel != AMC_KERNEL_DOT4)
@@ -527,6 +535,7 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
         size_t row_off = 0, nwork = 0, nord = 0;
         int set = 0;
         uint32_t total = 0;
+        bool grouped_resolve = true;
     };
     auto carve = [&](size_t begin, int set) {
         Batch b;
@@ -568,6 +577,7 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
         }
         PairDev* hp = c->h_pairs[k].p;
         size_t row_off = 0, col_off = 0, nwork = 0, nord = 0;
+        b.grouped_resolve = std::getenv("AMC_RESOLVE_UNGROUPED") == nullptr;  // (test hook: the per-row kernel)
         for (size_t i = 0; i < nb; ++i) {
             const Slot& x = c->slots[slot1[begin + i]];
             const Slot& y = c->slots[slot2[begin + i]];
@@ -593,6 +603,8 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
             if (want_mfma[i]) {
                 c->h_order[k].p[nord++] = (uint32_t)i;
                 ++n_mfma;
+                // the tile-grouped resolve needs both images' tiles to fit its LDS histogram
+                if (std::max(x.dev.rows_pad, y.dev.rows_pad) > resolve_grouped_max_rows()) b.grouped_resolve = false;
             } else {
                 nwork += (x.dev.rows + 63) / 64;
                 if (o.cross_check) nwork += (y.dev.rows + 63) / 64;
@@ -682,7 +694,7 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
         kernel_launches += (nord ? 1 : 0) + (nwork ? 1 : 0);
         if (nord)  // tile -> exact index for the accepted rows
             launch_resolve_index(0, c->d_imgs.p, c->d_pairs.p, (uint32_t)nb, c->d_rowbuf.p, c->d_accmask.p, c->d_lut,
-                                 fp, c->d_cand_cnt.p, c->d_candbuf.p, c->d_scalars + 3, st);
+                                 fp, c->d_cand_cnt.p, c->d_candbuf.p, c->d_scalars + 3, b.grouped_resolve, st);
         if (nord && o.cross_check) {
             // lazy cross check: reverse scan only for the columns accepted rows point at
             launch_select_candidates(c->d_imgs.p, c->d_pairs.p, (uint32_t)nb, c->d_rowbuf.p, c->d_accmask.p,
@@ -694,7 +706,7 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
                               c->d_scalars + 1, c->d_cand_cnt.p, c->d_candbuf.p, c->d_colbuf.p,
                               c->d_accmask.p, c->d_lut, fp, st);
             launch_resolve_index(1, c->d_imgs.p, c->d_pairs.p, (uint32_t)nb, c->d_colbuf.p, c->d_accmask.p, c->d_lut,
-                                 fp, c->d_cand_cnt.p, c->d_candbuf.p, c->d_scalars + 3, st);
+                                 fp, c->d_cand_cnt.p, c->d_candbuf.p, c->d_scalars + 3, b.grouped_resolve, st);
         }
         (void)hipEventRecord(c->bev[k][2], st);
         launch_finalize(c->d_imgs.p, c->d_pairs.p, (uint32_t)nb, c->d_rowbuf.p, c->d_colbuf.p,
@@ -786,17 +798,30 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
 
     if (npairs > 0) {
         Batch cur = carve(0, 0);
-        bool ok = prepare(cur) && enqueue(cur);
+        auto tp = std::chrono::steady_clock::now();
+        bool ok = prepare(cur);
+        t_prepare += since(tp);
+        tp = std::chrono::steady_clock::now();
+        ok = ok && enqueue(cur);
+        t_enqueue += since(tp);
         while (ok) {
             Batch next;
             const bool have_next = cur.end < npairs;
             if (have_next) {
+                tp = std::chrono::steady_clock::now();
                 next = carve(cur.end, cur.set ^ 1);
                 ok = prepare(next);
+                t_prepare += since(tp);
             }
+            tp = std::chrono::steady_clock::now();
             ok = ok && collect(cur);
+            t_collect += since(tp);
+            tp = std::chrono::steady_clock::now();
             if (ok && have_next) ok = enqueue(next);
+            t_enqueue += since(tp);
+            tp = std::chrono::steady_clock::now();
             ok = ok && scatter(cur);
+            t_scatter += since(tp);
             if (!have_next) break;
             cur = next;
         }
@@ -823,6 +848,10 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
     out->match_kernel_launches = kernel_launches;
     out->cross_kernel_ms = cross_ms;
     out->_priv = priv;
+    if (prof)
+        std::fprintf(stderr, "[amc match profile] pairs=%zu wall=%.1f ms: prepare %.1f, enqueue %.1f, collect(wait+reorder+D2H enqueue) %.1f, "
+                     "scatter(wait) %.1f; device events %.1f ms (scan %.1f, cross %.1f)\n", npairs, since(wall0), t_prepare, t_enqueue,
+                     t_collect, t_scatter, (double)total_ms, kernel_ms, cross_ms);
     return AMC_OK;
 }
 

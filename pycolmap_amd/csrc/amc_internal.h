@@ -115,7 +115,9 @@ void launch_match_mfma(int mode, const ImageDev* imgs, const PairDev* pairs,
 void launch_resolve_index(int side, const ImageDev* imgs, const PairDev* pairs, uint32_t npairs,
                           Top2* table, uint32_t* accmask, const float* acos_lut, FinalizeParams fp,
                           const uint32_t* cand_cnt, const uint32_t* candbuf, uint32_t* err_count,
-                          hipStream_t s);
+                          bool grouped, hipStream_t s);
+// largest image (padded rows) the tile-grouped variant of resolve_index handles (its LDS histogram)
+uint32_t resolve_grouped_max_rows();
 constexpr uint32_t kSelectMaxCols = 32768;  // select_candidates' LDS bitmap (4 KiB)
 
 void launch_select_candidates(const ImageDev* imgs, const PairDev* pairs, uint32_t npairs,

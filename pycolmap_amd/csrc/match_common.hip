@@ -235,14 +235,155 @@ __global__ __launch_bounds__(256) void resolve_index_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// resolve_index, grouped by tile.  The kernel above reads the 4 KB Y tile of every accepted row from L2 - fine
+// when a pair has a dozen accepted rows, but on overlapping image pairs a third of the rows are accepted (1,300 of
+// 4,096) and the launch becomes L2-bandwidth bound (340 GB per 62 k pairs, 9 TB/s, as long as the reverse scan
+// itself).  Here the accepted rows of a pair are bucketed by their best tile first (counting sort in LDS, chunks
+// of 4,096 rows), each wave then walks a contiguous range of the sorted list and keeps the current tile's 32 Y
+// rows in registers (lane = (Y row, half), 64 bytes each) across all the X rows that point into it: per accepted
+// row only its own 128 bytes are fetched.  Same arithmetic per row as above, so the same results; rows are
+// independent, their order is free.  Used when the Y image has at most kResolveMaxTiles tiles.
+// ---------------------------------------------------------------------------------------
+constexpr uint32_t kResolveChunk = 4096, kResolveMaxTiles = 2048;
+__global__ __launch_bounds__(256) void resolve_index_grouped_kernel(
+    int side, const ImageDev* __restrict__ imgs, const PairDev* __restrict__ pairs,
+    Top2* __restrict__ table, uint32_t* __restrict__ accmask, const float* __restrict__ lut,
+    FinalizeParams fp, const uint32_t* __restrict__ cand_cnt, const uint32_t* __restrict__ candbuf,
+    uint32_t* __restrict__ err_count) {
+    __shared__ uint32_t s_list[kResolveChunk];    // (tile << 12) | position in the chunk
+    __shared__ uint32_t s_sorted[kResolveChunk];
+    __shared__ uint32_t s_hist[kResolveMaxTiles];
+    __shared__ uint32_t s_wsum[4];
+    __shared__ uint32_t s_count;
+    const PairDev p = pairs[blockIdx.x];
+    if (p.mode == 0) return;  // dot4 pairs carry exact indices already
+    const ImageDev X = imgs[side == 0 ? p.slot1 : p.slot2];
+    const ImageDev Y = imgs[side == 0 ? p.slot2 : p.slot1];
+    const uint32_t n = side == 0 ? X.rows : cand_cnt[blockIdx.x];
+    if (n == 0 || Y.rows == 0) return;
+    Top2* tab = table + (side == 0 ? p.row_off : p.col_off);
+    uint32_t* amask = accmask + (p.row_off >> 5);
+    const uint32_t* list = candbuf + p.col_off;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const uint32_t l31 = lane & 31, half = lane >> 5;
+    const uint32_t ntiles = Y.rows_pad / 32;
+    constexpr uint32_t kPer = kResolveMaxTiles / 256;  // histogram bins per thread in the scan
+    for (uint32_t chunk0 = 0; chunk0 < n; chunk0 += kResolveChunk) {
+        const uint32_t chunk_end = min(n, chunk0 + kResolveChunk);
+        if (tid == 0) s_count = 0;
+        for (uint32_t k = tid; k < kResolveMaxTiles; k += 256) s_hist[k] = 0;
+        __syncthreads();
+        // ---- accepted rows of the chunk and the histogram of their tiles
+        for (uint32_t e = chunk0 + tid; e < chunk_end; e += 256) {
+            bool acc;
+            uint32_t tile;
+            if (side == 0) {
+                acc = (amask[e >> 5] >> (e & 31)) & 1u;
+                tile = acc ? tab[e].best_idx : 0u;
+            } else {
+                const Top2 t = tab[list[e]];
+                acc = one_way_accepts(t, lut, fp.max_ratio, fp.max_distance);
+                tile = t.best_idx;
+            }
+            if (acc) {
+                if (tile >= ntiles) {  // cannot happen (the scan only reports tiles it visited): counted, row left unresolved
+                    atomicAdd(err_count, 1u);
+                    continue;
+                }
+                const uint32_t pos = atomicAdd(&s_count, 1u);
+                s_list[pos] = (tile << 12) | (e - chunk0);
+                atomicAdd(&s_hist[tile], 1u);
+            }
+        }
+        __syncthreads();
+        const uint32_t cnt = s_count;
+        if (cnt == 0) { __syncthreads(); continue; }
+        // ---- exclusive scan of the histogram (thread t owns bins [t * kPer, (t + 1) * kPer))
+        uint32_t h[kPer], c = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < kPer; ++k) { h[k] = s_hist[tid * kPer + k]; c += h[k]; }
+        uint32_t inc = c;
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) {
+            const uint32_t o = __shfl_up(inc, m);
+            if (lane >= (uint32_t)m) inc += o;
+        }
+        if (lane == 63) s_wsum[wid] = inc;
+        __syncthreads();
+        uint32_t start = inc - c;
+        for (uint32_t k = 0; k < wid; ++k) start += s_wsum[k];
+#pragma unroll
+        for (uint32_t k = 0; k < kPer; ++k) { s_hist[tid * kPer + k] = start; start += h[k]; }
+        __syncthreads();
+        for (uint32_t k = tid; k < cnt; k += 256) {
+            const uint32_t v = s_list[k];
+            s_sorted[atomicAdd(&s_hist[v >> 12], 1u)] = v;
+        }
+        __syncthreads();
+        // ---- each wave walks a contiguous quarter of the sorted list, the tile's Y rows stay in registers
+        const uint32_t kb = (uint32_t)(((uint64_t)cnt * wid) / 4), ke = (uint32_t)(((uint64_t)cnt * (wid + 1)) / 4);
+        uint32_t cur_tile = 0xFFFFFFFFu;
+        uint4 yv[4] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
+        uint32_t jj = 0;
+        for (uint32_t k = kb; k < ke; ++k) {
+            const uint32_t v = s_sorted[k];
+            const uint32_t tile = v >> 12, e = chunk0 + (v & 4095u);
+            if (tile != cur_tile) {
+                cur_tile = tile;
+                jj = tile * 32 + l31;
+                const uint4* yp = reinterpret_cast<const uint4*>(Y.raw + (size_t)jj * kDim + half * 64);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) yv[q] = yp[q];  // jj < rows_pad: padding rows are zero
+            }
+            const uint32_t row = side == 0 ? e : list[e];
+            const Top2 t = tab[row];
+            const uint4* xp = reinterpret_cast<const uint4*>(X.raw + (size_t)row * kDim + half * 64);
+            uint32_t sum = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint4 a = xp[q], cc = yv[q];
+                sum = __builtin_amdgcn_udot4(a.x, cc.x, sum, false);
+                sum = __builtin_amdgcn_udot4(a.y, cc.y, sum, false);
+                sum = __builtin_amdgcn_udot4(a.z, cc.z, sum, false);
+                sum = __builtin_amdgcn_udot4(a.w, cc.w, sum, false);
+            }
+            sum += __shfl_xor(sum, 32);
+            const bool eq = (sum == t.best_v) && (jj < Y.rows);
+            const uint32_t m = (uint32_t)(__ballot(eq) & 0xFFFFFFFFull);
+            const uint32_t first = m ? (uint32_t)(__ffs(m) - 1) : 0xFFFFFFFFu;
+            uint32_t sw = (jj < Y.rows && l31 != first) ? sum : 0u;
+#pragma unroll
+            for (int d = 16; d >= 1; d >>= 1) sw = max(sw, (uint32_t)__shfl_xor(sw, d));
+            if (lane == 0) {
+                Top2 u = t;
+                u.best_idx = m ? tile * 32 + first : 0xFFFFFFFFu;
+                u.second_v = max(t.second_v, sw);
+                tab[row].best_idx = u.best_idx;
+                tab[row].second_v = u.second_v;
+                if (!m) atomicAdd(err_count, 1u);  // scan and recomputation disagree: a bug
+                // side 0: narrow the accept bits to the rows that pass with the exact second
+                if (side == 0 && !one_way_accepts(u, lut, fp.max_ratio, fp.max_distance))
+                    atomicAnd(&amask[e >> 5], ~(1u << (e & 31)));
+            }
+        }
+        __syncthreads();
+    }
+}
+
 void launch_resolve_index(int side, const ImageDev* imgs, const PairDev* pairs, uint32_t npairs,
                           Top2* table, uint32_t* accmask, const float* acos_lut, FinalizeParams fp,
                           const uint32_t* cand_cnt, const uint32_t* candbuf, uint32_t* err_count,
-                          hipStream_t s) {
+                          bool grouped, hipStream_t s) {
     if (npairs == 0) return;
-    hipLaunchKernelGGL(resolve_index_kernel, dim3(npairs), dim3(256), 0, s, side, imgs, pairs,
-                       table, accmask, acos_lut, fp, cand_cnt, candbuf, err_count);
+    if (grouped)
+        hipLaunchKernelGGL(resolve_index_grouped_kernel, dim3(npairs), dim3(256), 0, s, side, imgs, pairs,
+                           table, accmask, acos_lut, fp, cand_cnt, candbuf, err_count);
+    else
+        hipLaunchKernelGGL(resolve_index_kernel, dim3(npairs), dim3(256), 0, s, side, imgs, pairs,
+                           table, accmask, acos_lut, fp, cand_cnt, candbuf, err_count);
 }
+uint32_t resolve_grouped_max_rows() { return kResolveMaxTiles * 32; }
 
 // ---------------------------------------------------------------------------------------
 // select_candidates: which rows of image 2 ("columns") does the cross check need?  Exactly

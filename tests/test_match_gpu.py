@@ -242,3 +242,33 @@ def test_many_batches_pipeline(amc_ctx, monkeypatch, kernel, entries):
     e = np.full(5, 7, dtype=np.uint32)
     off, m, _ = amc_ctx.match_pairs(e, np.arange(5, dtype=np.uint32), kernel=kernel)
     assert off.tolist() == [0] * 6 and len(m) == 0
+
+
+@pytest.mark.parametrize("cross_check", [True, False])
+def test_dense_overlap_and_both_resolve_kernels(amc_ctx, monkeypatch, cross_check):
+    """Every pair overlapping (a third of the rows accepted, many accepted rows per Y tile): the tile-grouped
+    resolve_index kernel, the per-row one (AMC_RESOLVE_UNGROUPED=1) and the oracle agree; ragged sizes, an image
+    above 4096 rows (two chunks of the grouped kernel's row list), the zero-copy result view."""
+    rng = np.random.default_rng(42)
+    sizes = [700, 1300, 4096, 5000, 64, 1]
+    L = 9000
+    proto = rng.gamma(0.7, 1.0, size=(L, 128))
+    proto /= np.linalg.norm(proto, axis=1, keepdims=True)
+    imgs = []
+    for n in sizes:
+        vis = rng.choice(L, size=n, replace=False)
+        imgs.append(synth.quantize_descriptors(proto[vis] + rng.normal(0, 0.05, size=(n, 128)) * proto[vis].mean()))
+    upload(amc_ctx, imgs)
+    s1 = np.array([0, 1, 2, 3, 2, 3, 4, 5, 0, 3], dtype=np.uint32)
+    s2 = np.array([1, 2, 3, 2, 0, 0, 2, 3, 4, 3], dtype=np.uint32)
+    opts = (0.8, 0.7, cross_check)
+    off, m, st = assert_same(amc_ctx, imgs, s1, s2, "mfma", opts, expect_kernel="mfma")
+    assert int(off[3] - off[2]) > 300                       # 4096 x 5000 with hundreds of mutual matches
+    voff, vm, _ = amc_ctx.match_pairs(s1, s2, *opts, kernel="mfma", copy=False)
+    np.testing.assert_array_equal(np.asarray(voff), off)
+    np.testing.assert_array_equal(np.asarray(vm), m)
+    del voff, vm
+    monkeypatch.setenv("AMC_RESOLVE_UNGROUPED", "1")
+    off2, m2, _ = amc_ctx.match_pairs(s1, s2, *opts, kernel="mfma")
+    np.testing.assert_array_equal(off2, off)
+    np.testing.assert_array_equal(m2, m)
