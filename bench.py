@@ -353,9 +353,14 @@ def dense_leg(ctx_factory, device, steps: int, warmup: int, num_images: int, fea
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     scan = cross = dev = 0.0
+    t_free = t_call = 0.0
     for _ in range(steps):
+        ta = time.perf_counter()
         off = m = None                       # give the previous result's pinned buffer back to the pool first
+        tb = time.perf_counter()
         off, m, st = ctx.match_pairs(s1, s2, kernel=kernel, copy=False)   # views of the result, as a C++ caller reads it
+        tc = time.perf_counter()
+        t_free += tb - ta; t_call += tc - tb
         scan += st["match_kernel_ms"]; cross += st["cross_kernel_ms"]; dev += st["device_ms"]
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
@@ -367,7 +372,8 @@ def dense_leg(ctx_factory, device, steps: int, warmup: int, num_images: int, fea
             "match_table_bytes": nm * 8,
             "stage_ms_per_step": {"scan_kernel": scan / steps, "resolve_select_reverse_scan": cross / steps,
                                   "device_total_incl_d2h": dev / steps,
-                                  "host_side_of_the_call": 1e3 * dt / steps - dev / steps}}
+                                  "host_side_of_the_call": 1e3 * dt / steps - dev / steps,
+                                  "python_free_previous_result": 1e3 * t_free / steps, "python_call": 1e3 * t_call / steps}}
 
 
 def run_config34(args):

@@ -284,6 +284,10 @@ class Context:
         _check(self._lib.amc_match_pairs(self._h, s1.ctypes.data_as(C.c_void_p),
                                          s2.ctypes.data_as(C.c_void_p), s1.size, C.byref(opts),
                                          C.byref(res)))
+        if not copy:
+            # zero-copy views of the library's pinned result buffer (what a C++ caller reads): the arrays keep the
+            # result alive and amc_match_result_free runs when the last of them is collected
+            return self._unpack_match(res, _MatchLease(self._lib, res))
         try:
             offsets, matches, stats = self._unpack_match(res)
         finally:
@@ -291,12 +295,19 @@ class Context:
         return offsets, matches, stats
 
     @staticmethod
-    def _unpack_match(res):
+    def _unpack_match(res, lease=None):
         n = int(res.npairs)
-        offsets = np.ctypeslib.as_array(res.offsets, shape=(n + 1,)).copy()
+
+        def view(ptr, count, dtype):   # a buffer over the address: no per-call ctypes array types, no element walk
+            nbytes = count * np.dtype(dtype).itemsize
+            return np.frombuffer((C.c_char * nbytes).from_address(C.addressof(ptr.contents)), dtype=dtype)
+
+        offsets = view(res.offsets, n + 1, np.uint64)
         total = int(offsets[-1])
+        offsets = offsets.copy() if lease is None else _LeasedArray.wrap(offsets, lease)
         if total:
-            matches = np.ctypeslib.as_array(res.matches, shape=(total, 2)).copy()
+            matches = view(res.matches, 2 * total, np.uint32).reshape(total, 2)
+            matches = matches.copy() if lease is None else _LeasedArray.wrap(matches, lease)
         else:
             matches = np.zeros((0, 2), dtype=np.uint32)
         stats = dict(num_distances=int(res.num_distances), pairs_mfma=int(res.pairs_mfma),

@@ -326,45 +326,67 @@ __global__ __launch_bounds__(256) void resolve_index_grouped_kernel(
         uint32_t cur_tile = 0xFFFFFFFFu;
         uint4 yv[4] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
         uint32_t jj = 0;
-        for (uint32_t k = kb; k < ke; ++k) {
-            const uint32_t v = s_sorted[k];
-            const uint32_t tile = v >> 12, e = chunk0 + (v & 4095u);
-            if (tile != cur_tile) {
-                cur_tile = tile;
-                jj = tile * 32 + l31;
-                const uint4* yp = reinterpret_cast<const uint4*>(Y.raw + (size_t)jj * kDim + half * 64);
+        // kU rows in flight: a row's table entry and its X bytes are two dependent trips to L2 / HBM, and with one row
+        // at a time the wave just waits for them (the first version of this kernel was latency bound, no faster
+        // than the per-row kernel)
+        constexpr int kU = 4;
+        for (uint32_t k0 = kb; k0 < ke; k0 += kU) {
+            uint32_t vv[kU], rr[kU];
+            Top2 tt[kU];
+            uint4 xa[kU][4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) yv[q] = yp[q];  // jj < rows_pad: padding rows are zero
+            for (int u = 0; u < kU; ++u) {
+                const uint32_t k = min(k0 + (uint32_t)u, ke - 1);  // the tail repeats its last row (never processed twice)
+                vv[u] = s_sorted[k];
+                const uint32_t e = chunk0 + (vv[u] & 4095u);
+                rr[u] = side == 0 ? e : list[e];
             }
-            const uint32_t row = side == 0 ? e : list[e];
-            const Top2 t = tab[row];
-            const uint4* xp = reinterpret_cast<const uint4*>(X.raw + (size_t)row * kDim + half * 64);
-            uint32_t sum = 0;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const uint4 a = xp[q], cc = yv[q];
-                sum = __builtin_amdgcn_udot4(a.x, cc.x, sum, false);
-                sum = __builtin_amdgcn_udot4(a.y, cc.y, sum, false);
-                sum = __builtin_amdgcn_udot4(a.z, cc.z, sum, false);
-                sum = __builtin_amdgcn_udot4(a.w, cc.w, sum, false);
+            for (int u = 0; u < kU; ++u) {
+                tt[u] = tab[rr[u]];
+                const uint4* xp = reinterpret_cast<const uint4*>(X.raw + (size_t)rr[u] * kDim + half * 64);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) xa[u][q] = xp[q];
             }
-            sum += __shfl_xor(sum, 32);
-            const bool eq = (sum == t.best_v) && (jj < Y.rows);
-            const uint32_t m = (uint32_t)(__ballot(eq) & 0xFFFFFFFFull);
-            const uint32_t first = m ? (uint32_t)(__ffs(m) - 1) : 0xFFFFFFFFu;
-            uint32_t sw = (jj < Y.rows && l31 != first) ? sum : 0u;
 #pragma unroll
-            for (int d = 16; d >= 1; d >>= 1) sw = max(sw, (uint32_t)__shfl_xor(sw, d));
-            if (lane == 0) {
-                Top2 u = t;
-                u.best_idx = m ? tile * 32 + first : 0xFFFFFFFFu;
-                u.second_v = max(t.second_v, sw);
-                tab[row].best_idx = u.best_idx;
-                tab[row].second_v = u.second_v;
-                if (!m) atomicAdd(err_count, 1u);  // scan and recomputation disagree: a bug
-                // side 0: narrow the accept bits to the rows that pass with the exact second
-                if (side == 0 && !one_way_accepts(u, lut, fp.max_ratio, fp.max_distance))
-                    atomicAnd(&amask[e >> 5], ~(1u << (e & 31)));
+            for (int u = 0; u < kU; ++u) {
+                if (k0 + (uint32_t)u >= ke) break;
+                const uint32_t tile = vv[u] >> 12, e = chunk0 + (vv[u] & 4095u), row = rr[u];
+                const Top2 t = tt[u];
+                if (tile != cur_tile) {
+                    cur_tile = tile;
+                    jj = tile * 32 + l31;
+                    const uint4* yp = reinterpret_cast<const uint4*>(Y.raw + (size_t)jj * kDim + half * 64);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) yv[q] = yp[q];  // jj < rows_pad: padding rows are zero
+                }
+                uint32_t sum = 0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const uint4 a = xa[u][q], cc = yv[q];
+                    sum = __builtin_amdgcn_udot4(a.x, cc.x, sum, false);
+                    sum = __builtin_amdgcn_udot4(a.y, cc.y, sum, false);
+                    sum = __builtin_amdgcn_udot4(a.z, cc.z, sum, false);
+                    sum = __builtin_amdgcn_udot4(a.w, cc.w, sum, false);
+                }
+                sum += __shfl_xor(sum, 32);
+                const bool eq = (sum == t.best_v) && (jj < Y.rows);
+                const uint32_t m = (uint32_t)(__ballot(eq) & 0xFFFFFFFFull);
+                const uint32_t first = m ? (uint32_t)(__ffs(m) - 1) : 0xFFFFFFFFu;
+                uint32_t sw = (jj < Y.rows && l31 != first) ? sum : 0u;
+#pragma unroll
+                for (int d = 16; d >= 1; d >>= 1) sw = max(sw, (uint32_t)__shfl_xor(sw, d));
+                if (lane == 0) {
+                    Top2 w2 = t;
+                    w2.best_idx = m ? tile * 32 + first : 0xFFFFFFFFu;
+                    w2.second_v = max(t.second_v, sw);
+                    tab[row].best_idx = w2.best_idx;
+                    tab[row].second_v = w2.second_v;
+                    if (!m) atomicAdd(err_count, 1u);  // scan and recomputation disagree: a bug
+                    // side 0: narrow the accept bits to the rows that pass with the exact second
+                    if (side == 0 && !one_way_accepts(w2, lut, fp.max_ratio, fp.max_distance))
+                        atomicAnd(&amask[e >> 5], ~(1u << (e & 31)));
+                }
             }
         }
         __syncthreads();
