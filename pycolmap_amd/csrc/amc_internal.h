@@ -203,6 +203,7 @@ struct TvgParams {
     double min_E_F_inlier_ratio, max_H_inlier_ratio, watermark_min_inlier_ratio,
         watermark_border_size, max_error;
     int32_t force_slow_sampler;  // test hook (AMC_TVG_SLOW_SAMPLER=1): draw-by-draw sampler path only
+    int32_t no_fast_count;       // test hook (AMC_TVG_EXACT_COUNT=1): no division-free test in the counting loop
     int32_t mode;                // 0: EstimateTwoViewGeometry; 1 / 2 / 3: a single F / H / E LO-RANSAC
     uint32_t* bad_index_count;   // += 1 per pair whose matches index past an image's keypoints (the pair is skipped)
     // dyn_max_num_trials of the watermark (translation, 1-point) RANSAC.  Its sample count is the pair's inlier

@@ -763,14 +763,67 @@ template <int KIND>
 __device__ __forceinline__ double residual_t(const double (&m)[9], double a, double b, double c, double d) {
     return KIND == K_H ? h_residual(m, a, b, c, d) : (KIND == K_T ? t_residual(m, a, b, c, d) : sampson(m, a, b, c, d));
 }
+// ---- division-free inlier tests for the counting loop ----------------------------------------------
+// Counting only needs the DECISION residual <= max_res, and for both residuals that is a polynomial inequality:
+//   homography  (d0 - pd0/pd2)^2 + (d1 - pd1/pd2)^2 <= T   <=>   (d0 pd2 - pd0)^2 + (d1 pd2 - pd1)^2 <= T pd2^2
+//   Sampson     c^2 / den <= T                              <=>   c^2 <= T den               (den > 0)
+// evaluated here with fused multiply-adds (no division: a third of the instructions of the reference expression
+// and no rcp -> Newton -> fixup dependency chain).  The two sides are NOT the reference's roundings, so the test
+// is only trusted away from the boundary: with L and R the two sides, `in` when L <= R (1 - 1e-8), `out` when
+// L >= R (1 + 1e-8), and the (practically never taken) band in between - or an R that is not a normal positive
+// number - sends the whole 64-point batch through the exact residual.  Why the band suffices: both this
+// expression and the reference one are backward-stable evaluations of the same real quantity whose relative error
+// at the boundary is <= ~10 eps x (largest coordinate / max_error) - the cancellation in d - p and in x2^T E x1;
+// lo_ransac switches the fast test off unless that ratio is below 1e5 (RansacCfg::fast_count), which bounds both
+// errors by ~1e-10, a hundredth of the band.  The counts are therefore exactly the reference's counts.
+constexpr double kFastLo = 1.0 - 1e-8, kFastHi = 1.0 + 1e-8;
+template <int KIND>
+__device__ __forceinline__ void fast_inlier(const double (&m)[9], double a, double b, double c, double d, double T,
+                                            bool& in, bool& amb) {
+    double Lq, R;
+    if (KIND == K_H) {
+        const double pd0 = __fma_rn(m[0], a, __fma_rn(m[1], b, m[2]));
+        const double pd1 = __fma_rn(m[3], a, __fma_rn(m[4], b, m[5]));
+        const double pd2 = __fma_rn(m[6], a, __fma_rn(m[7], b, m[8]));
+        const double u = __fma_rn(c, pd2, -pd0), v = __fma_rn(d, pd2, -pd1);
+        Lq = __fma_rn(u, u, v * v);
+        R = T * (pd2 * pd2);
+    } else {
+        const double Ex1_0 = __fma_rn(m[0], a, __fma_rn(m[1], b, m[2]));
+        const double Ex1_1 = __fma_rn(m[3], a, __fma_rn(m[4], b, m[5]));
+        const double Ex1_2 = __fma_rn(m[6], a, __fma_rn(m[7], b, m[8]));
+        const double Etx2_0 = __fma_rn(m[0], c, __fma_rn(m[3], d, m[6]));
+        const double Etx2_1 = __fma_rn(m[1], c, __fma_rn(m[4], d, m[7]));
+        const double x2tEx1 = __fma_rn(c, Ex1_0, __fma_rn(d, Ex1_1, Ex1_2));
+        Lq = x2tEx1 * x2tEx1;
+        R = T * __fma_rn(Ex1_0, Ex1_0, __fma_rn(Ex1_1, Ex1_1, __fma_rn(Etx2_0, Etx2_0, Etx2_1 * Etx2_1)));
+    }
+    const bool sane = R > 1e-200 && R < 1e200;  // false for 0, denormal-ish, huge, inf and NaN
+    in = sane && Lq <= R * kFastLo;
+    amb = !sane || (Lq > R * kFastLo && Lq < R * kFastHi);
+}
 // inliers of U consecutive full 64-point batches starting at k0: U independent residual chains in
 // flight (at two waves per SIMD little else hides the FP64 and LDS latencies)
-template <bool L, int KIND, int U>
+template <bool L, int KIND, int U, bool FAST>
 __device__ __forceinline__ int count_batches(const double (&m)[9], const Pts& P, int k0, double max_res, int lane) {
     double a[U], b[U], c[U], d[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) load_pt<L>(P, k0 + 64 * u + lane, a[u], b[u], c[u], d[u]);
     int cnt = 0;
+    if (FAST && KIND != K_T) {
+        bool in[U], amb = false;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            bool am;
+            fast_inlier<KIND>(m, a[u], b[u], c[u], d[u], max_res, in[u], am);
+            amb |= am;
+        }
+        if (__builtin_expect(__ballot(amb) == 0ull, 1)) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) cnt += __popcll(__ballot(in[u]));
+            return cnt;
+        }
+    }
 #pragma unroll
     for (int u = 0; u < U; ++u) cnt += __popcll(__ballot(residual_t<KIND>(m, a[u], b[u], c[u], d[u]) <= max_res));
     return cnt;
@@ -779,22 +832,22 @@ __device__ __forceinline__ int count_batches(const double (&m)[9], const Pts& P,
 // inlier could not reach `thr` - an upper bound below `thr`.  thr is the best count when the chunk
 // started: the best only grows, so such a model can never become a candidate and its exact count
 // is irrelevant (see the replay in lo_ransac).
-template <bool L, int KIND>
+template <bool L, int KIND, bool FAST>
 __device__ __forceinline__ int count_model(const double (&m)[9], const Pts& P, int M, double max_res, int lane,
                                            int thr) {
     int cnt = 0;
     int k0 = 0;
     for (; k0 + 256 <= M; k0 += 256) {
-        cnt += count_batches<L, KIND, 4>(m, P, k0, max_res, lane);
+        cnt += count_batches<L, KIND, 4, FAST>(m, P, k0, max_res, lane);
         if (cnt + (M - (k0 + 256)) < thr) return cnt + (M - (k0 + 256));
     }
     if (k0 + 128 <= M) {
-        cnt += count_batches<L, KIND, 2>(m, P, k0, max_res, lane);
+        cnt += count_batches<L, KIND, 2, FAST>(m, P, k0, max_res, lane);
         k0 += 128;
         if (cnt + (M - k0) < thr) return cnt + (M - k0);
     }
     if (k0 + 64 <= M) {
-        cnt += count_batches<L, KIND, 1>(m, P, k0, max_res, lane);
+        cnt += count_batches<L, KIND, 1, FAST>(m, P, k0, max_res, lane);
         k0 += 64;
     }
     if (k0 < M) {  // ragged tail
@@ -809,7 +862,7 @@ __device__ __forceinline__ int count_model(const double (&m)[9], const Pts& P, i
     }
     return cnt;
 }
-template <bool L, int KIND, int NM>
+template <bool L, int KIND, int NM, bool FAST>
 __device__ __forceinline__ int count_lane_models(const double (&mym)[27], int nmod, const Pts& P, int M,
                                                  double max_res, int nT, int lane, int thr) {
     int maxcnt = -1;
@@ -821,14 +874,14 @@ __device__ __forceinline__ int count_lane_models(const double (&mym)[27], int nm
                 double sm[9];
 #pragma unroll
                 for (int i = 0; i < 9; ++i) sm[i] = readlane_f64(mym[9 * m + i], t);
-                const int c = count_model<L, KIND>(sm, P, M, max_res, lane, thr);
+                const int c = count_model<L, KIND, FAST>(sm, P, M, max_res, lane, thr);
                 if (lane == t) maxcnt = max(maxcnt, c);
             }
         }
     }
     return maxcnt;
 }
-template <bool L>
+template <bool L, bool FAST>
 __device__ __forceinline__ int count_global_models(const double* models, int nmod, const Pts& P, int M,
                                                    double max_res, int nT, int lane, int thr) {
     int maxcnt = -1;
@@ -839,7 +892,7 @@ __device__ __forceinline__ int count_global_models(const double* models, int nmo
             double sm[9];
 #pragma unroll
             for (int i = 0; i < 9; ++i) sm[i] = readlane_f64(src[i], 0);
-            const int c = count_model<L, K_F7>(sm, P, M, max_res, lane, thr);
+            const int c = count_model<L, K_F7, FAST>(sm, P, M, max_res, lane, thr);
             if (lane == t) maxcnt = max(maxcnt, c);
         }
     }
@@ -886,9 +939,10 @@ __device__ __noinline__ void solve_chunk(ChunkModels* out, int est, const Pts P,
 }
 
 __device__ __noinline__ void count_chunk(ChunkModels* io, int est_, const Pts P_, int M_, double max_res_, int nT_,
-                                         int lane, const double* models_, int thr_) {
+                                         int lane, const double* models_, int thr_, int fast_) {
     const unsigned long long c1 = __builtin_readcyclecounter();
     const int est = uni(est_), M = uni(M_), nT = uni(nT_), thr = uni(thr_);
+    const bool fast = uni(fast_) != 0;
     const double max_res = uni(max_res_);
     const Pts P = uni(P_);
     const double* models = uni_ptr(models_);
@@ -897,16 +951,22 @@ __device__ __noinline__ void count_chunk(ChunkModels* io, int est_, const Pts P_
     for (int i = 0; i < 27; ++i) mym[i] = io->mym[i];
     const int nmod = io->nmod;
     int maxcnt;
-    if (P.lds) {
-        if (est == K_F7) maxcnt = count_lane_models<true, K_F7, 3>(mym, nmod, P, M, max_res, nT, lane, thr);
-        else if (est == K_H) maxcnt = count_lane_models<true, K_H, 1>(mym, nmod, P, M, max_res, nT, lane, thr);
-        else if (est == K_T) maxcnt = count_lane_models<true, K_T, 1>(mym, nmod, P, M, max_res, nT, lane, thr);
-        else maxcnt = count_global_models<true>(models, nmod, P, M, max_res, nT, lane, thr);
+    // the points of nearly every pair fit the LDS share; the global-memory path keeps the exact test only
+    if (P.lds && fast) {
+        if (est == K_F7) maxcnt = count_lane_models<true, K_F7, 3, true>(mym, nmod, P, M, max_res, nT, lane, thr);
+        else if (est == K_H) maxcnt = count_lane_models<true, K_H, 1, true>(mym, nmod, P, M, max_res, nT, lane, thr);
+        else if (est == K_T) maxcnt = count_lane_models<true, K_T, 1, false>(mym, nmod, P, M, max_res, nT, lane, thr);
+        else maxcnt = count_global_models<true, true>(models, nmod, P, M, max_res, nT, lane, thr);
+    } else if (P.lds) {
+        if (est == K_F7) maxcnt = count_lane_models<true, K_F7, 3, false>(mym, nmod, P, M, max_res, nT, lane, thr);
+        else if (est == K_H) maxcnt = count_lane_models<true, K_H, 1, false>(mym, nmod, P, M, max_res, nT, lane, thr);
+        else if (est == K_T) maxcnt = count_lane_models<true, K_T, 1, false>(mym, nmod, P, M, max_res, nT, lane, thr);
+        else maxcnt = count_global_models<true, false>(models, nmod, P, M, max_res, nT, lane, thr);
     } else {
-        if (est == K_F7) maxcnt = count_lane_models<false, K_F7, 3>(mym, nmod, P, M, max_res, nT, lane, thr);
-        else if (est == K_H) maxcnt = count_lane_models<false, K_H, 1>(mym, nmod, P, M, max_res, nT, lane, thr);
-        else if (est == K_T) maxcnt = count_lane_models<false, K_T, 1>(mym, nmod, P, M, max_res, nT, lane, thr);
-        else maxcnt = count_global_models<false>(models, nmod, P, M, max_res, nT, lane, thr);
+        if (est == K_F7) maxcnt = count_lane_models<false, K_F7, 3, false>(mym, nmod, P, M, max_res, nT, lane, thr);
+        else if (est == K_H) maxcnt = count_lane_models<false, K_H, 1, false>(mym, nmod, P, M, max_res, nT, lane, thr);
+        else if (est == K_T) maxcnt = count_lane_models<false, K_T, 1, false>(mym, nmod, P, M, max_res, nT, lane, thr);
+        else maxcnt = count_global_models<false, false>(models, nmod, P, M, max_res, nT, lane, thr);
     }
     io->maxcnt = maxcnt;
     io->cyc_count = __builtin_readcyclecounter() - c1;
@@ -927,6 +987,7 @@ struct RansacCfg {
     const uint32_t* dyn_tab; // dyn_max_num_trials by num_inliers (host libm), or nullptr
     const double* wm_cut;    // K_T only: inlier-ratio cut-offs by trial count (TvgParams::wm_cut), max_trials + 1 entries
     int force_slow_sampler;  // test hook: always take the draw-by-draw sampler path
+    int no_fast_count;       // test hook (AMC_TVG_EXACT_COUNT=1): the counting loop evaluates the reference residual only
 };
 
 // LORANSAC<est, local_est>::Estimate over the M correspondences in the four arrays at gx (x1 | y1
@@ -956,13 +1017,22 @@ __device__ Report lo_ransac(Wave& w_io, const RansacCfg& cfg, const double* gx, 
     Pts P;
     P.g = gx; P.gs = gstride; P.l = w.lpts; P.ls = w.pts_cap;
     P.lds = (uint32_t)M <= w.pts_cap;
+    int fast_count = 0;
     if (P.lds) {
+        double amax = 0.0;
         for (int k = lane; k < M; k += 64) {
-            w.lpts[k] = gx[k];
-            w.lpts[w.pts_cap + k] = gx[gstride + k];
-            w.lpts[2 * w.pts_cap + k] = gx[2 * (size_t)gstride + k];
-            w.lpts[3 * w.pts_cap + k] = gx[3 * (size_t)gstride + k];
+            const double p0 = gx[k], p1 = gx[gstride + k], p2 = gx[2 * (size_t)gstride + k], p3 = gx[3 * (size_t)gstride + k];
+            w.lpts[k] = p0;
+            w.lpts[w.pts_cap + k] = p1;
+            w.lpts[2 * w.pts_cap + k] = p2;
+            w.lpts[3 * w.pts_cap + k] = p3;
+            amax = dmax(dmax(amax, dmax(dabs(p0), dabs(p1))), dmax(dabs(p2), dabs(p3)));
         }
+#pragma unroll
+        for (int sh = 32; sh >= 1; sh >>= 1) amax = dmax(amax, __shfl_xor(amax, sh));
+        // the division-free counting test is trusted only while (largest coordinate / max_error) <= 1e5 (see
+        // fast_inlier); a NaN coordinate leaves amax as it was or NaN - either way the comparison below decides
+        fast_count = (cfg.no_fast_count == 0 && amax * amax <= 1e10 * cfg.max_res) ? 1 : 0;
     }
 
     // sampler.Initialize(M).  The first kMin entries of the persistent permutation are touched by
@@ -991,7 +1061,7 @@ __device__ Report lo_ransac(Wave& w_io, const RansacCfg& cfg, const double* gx, 
         // ---- 64 minimal problems + the inlier count of every model (solve_count_chunk) ---------
         ChunkModels cm;
         solve_chunk(&cm, cfg.est, P, w.sidx, nT, lane, models);
-        count_chunk(&cm, cfg.est, P, M, cfg.max_res, nT, lane, models, best.cnt);
+        count_chunk(&cm, cfg.est, P, M, cfg.max_res, nT, lane, models, best.cnt, fast_count);
         w.prof[1] += cm.cyc_solve;
         if (cfg.est == K_E5) w.prof[5] += cm.cyc_solve;
         tp0 = __builtin_readcyclecounter();
@@ -1224,6 +1294,7 @@ __device__ __noinline__ void process_pair(Wave& w, uint32_t q, const TvgImage* _
     cfg.wm_cut = nullptr;
     cfg.min_trials = P.min_num_trials;
     cfg.force_slow_sampler = P.force_slow_sampler;
+    cfg.no_fast_count = P.no_fast_count;
     if (calibrated) {
         double *N1x = w.arr(W_NX1), *N1y = w.arr(W_NY1), *N2x = w.arr(W_NX2), *N2y = w.arr(W_NY2);
         // Camera::CamFromImg of the matched points.  SIMPLE_PINHOLE / PINHOLE: (x - c) / f in place.  Cameras
