@@ -1525,13 +1525,14 @@ static int verify_impl(amc_ctx* c, int mode, const uint32_t* slot1, const uint32
         return fail(AMC_E_INVALID, "amc_verify_pairs: %u pairs index past the keypoints", bad_pairs);
     }
     if (std::getenv("AMC_TVG_PROFILE")) {
+        tvg_diag_report();
         unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         for (size_t p = 0; p < npairs; ++p)
             for (int i = 0; i < 8; ++i) acc[i] += h_out[p].prof[i];
         std::fprintf(stderr, "[amc tvg profile] pairs=%zu cycles/pair: sampling=%.0f minimal=%.0f replay+score=%.0f "
                      "(of which LO=%.0f) total=%.0f\n", npairs, (double)acc[0] / npairs, (double)acc[1] / npairs,
                      (double)acc[2] / npairs, (double)acc[3] / npairs, (double)acc[4] / npairs);
-        std::fprintf(stderr, "[amc tvg profile] per pair: minimal(E5)=%.0f local_estimate(E5)=%.0f local_estimate(F8)=%.0f\n",
+        std::fprintf(stderr, "[amc tvg profile] per pair: counting loop=%.0f local_estimate(E5)=%.0f local_estimate(F8)=%.0f\n",
                      (double)acc[5] / npairs, (double)acc[6] / npairs, (double)acc[7] / npairs);
     }
     for (size_t p = 0; p < npairs; ++p) {

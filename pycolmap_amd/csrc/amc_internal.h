@@ -214,6 +214,7 @@ struct TvgParams {
     // there is none).  The kernel then has dyn_max = the first T with r >= wm_cut[T].
     const double* wm_cut;
 };
+void tvg_diag_report();  // diagnostic builds (-DAMC_TVG_DIAG=2): cycle split of the counting loop, on stderr
 size_t tvg_ws_doubles_host(uint32_t mcap);
 size_t tvg_ws_mask_bytes_host(uint32_t mcap);
 // target occupancy of the verification kernel (waves per SIMD): sets its VGPR budget and LDS share

@@ -26,6 +26,7 @@
 // FP64 everywhere, -ffp-contract=off, IEEE divide/sqrt: results are bit-identical to
 // oracle/tvg_oracle.cc (inlier masks, configs, model bit patterns).
 #include <algorithm>
+#include <cstdio>
 
 #include "amc_internal.h"
 #include "camera_math.h"
@@ -777,6 +778,15 @@ __device__ __forceinline__ double residual_t(const double (&m)[9], double a, dou
 // lo_ransac switches the fast test off unless that ratio is below 1e5 (RansacCfg::fast_count), which bounds both
 // errors by ~1e-10, a hundredth of the band.  The counts are therefore exactly the reference's counts.
 constexpr double kFastLo = 1.0 - 1e-8, kFastHi = 1.0 + 1e-8;
+#if defined(AMC_TVG_DIAG) && (AMC_TVG_DIAG & 2)
+// diagnostic build: shader-clock cycles of the parts of the counting loop, summed over all waves (lane 0 adds)
+__device__ unsigned long long g_tvg_diag[8];
+#define DIAG_T0() const unsigned long long dt0_ = __builtin_readcyclecounter()
+#define DIAG_ADD(slot) do { if (lane == 0) atomicAdd(&g_tvg_diag[slot], __builtin_readcyclecounter() - dt0_); } while (0)
+#else
+#define DIAG_T0() do {} while (0)
+#define DIAG_ADD(slot) do {} while (0)
+#endif
 template <int KIND>
 __device__ __forceinline__ void fast_inlier(const double (&m)[9], double a, double b, double c, double d, double T,
                                             bool& in, bool& amb) {
@@ -824,6 +834,9 @@ __device__ __forceinline__ int count_batches(const double (&m)[9], const Pts& P,
             return cnt;
         }
     }
+#if defined(AMC_TVG_DIAG) && (AMC_TVG_DIAG & 1)
+    if (FAST && KIND != K_T) return 0;  // diagnostic build: a taken fallback corrupts the counts (parity tests then fail)
+#endif
 #pragma unroll
     for (int u = 0; u < U; ++u) cnt += __popcll(__ballot(residual_t<KIND>(m, a[u], b[u], c[u], d[u]) <= max_res));
     return cnt;
@@ -838,9 +851,13 @@ __device__ __forceinline__ int count_model(const double (&m)[9], const Pts& P, i
     int cnt = 0;
     int k0 = 0;
     for (; k0 + 256 <= M; k0 += 256) {
+        DIAG_T0();
         cnt += count_batches<L, KIND, 4, FAST>(m, P, k0, max_res, lane);
+        DIAG_ADD(0);
+        if (lane == 0) { DIAG_T0(); DIAG_ADD(3); }  // slot 3: the cost of one timer pair itself
         if (cnt + (M - (k0 + 256)) < thr) return cnt + (M - (k0 + 256));
     }
+    DIAG_T0();
     if (k0 + 128 <= M) {
         cnt += count_batches<L, KIND, 2, FAST>(m, P, k0, max_res, lane);
         k0 += 128;
@@ -860,6 +877,7 @@ __device__ __forceinline__ int count_model(const double (&m)[9], const Pts& P, i
         }
         cnt += __popcll(__ballot(in));
     }
+    DIAG_ADD(1);
     return cnt;
 }
 template <bool L, int KIND, int NM, bool FAST>
@@ -871,11 +889,16 @@ __device__ __forceinline__ int count_lane_models(const double (&mym)[27], int nm
 #pragma unroll
         for (int m = 0; m < NM; ++m) {
             if (m < n) {
+                DIAG_T0();
                 double sm[9];
 #pragma unroll
                 for (int i = 0; i < 9; ++i) sm[i] = readlane_f64(mym[9 * m + i], t);
+                DIAG_ADD(2);
                 const int c = count_model<L, KIND, FAST>(sm, P, M, max_res, lane, thr);
                 if (lane == t) maxcnt = max(maxcnt, c);
+#if defined(AMC_TVG_DIAG) && (AMC_TVG_DIAG & 2)
+                if (lane == 0) atomicAdd(&g_tvg_diag[4], 1ull);
+#endif
             }
         }
     }
@@ -898,6 +921,93 @@ __device__ __forceinline__ int count_global_models(const double* models, int nmo
     }
     return maxcnt;
 }
+
+// ---- counting with the correspondences held in registers --------------------------------------------
+// count_model above reads the points of every batch from LDS again for every model: per model a broadcast, an LDS
+// round trip, the arithmetic, then the ragged tail with another round trip - at two waves per SIMD those latencies
+// are what the loop costs (measured: ~2,100 cycles per model of 300 points whether the residual takes 34 or 20
+// FP64 instructions).  Here the loop is turned inside out: the wave loads all M <= 64 * NB correspondences once
+// per chunk (NB batches of 64, 8 VGPRs each), and every model of the chunk's 64 trials is then counted against the
+// registers - the inner loop is a broadcast plus straight FP64 arithmetic on independent batches.  Lanes past M in
+// the last batch hold a copy of point 0 and are masked out of the ballots.  The division-free test (fast_inlier)
+// decides; a model with an ambiguous point is recounted with the exact residual, from the same registers.
+template <int KIND, int NB>
+__device__ __forceinline__ int count_regs(const double (&sm)[9], const double (&a)[NB], const double (&b)[NB],
+                                          const double (&c)[NB], const double (&d)[NB], unsigned long long last_valid,
+                                          int M, double max_res, int thr) {
+    int cnt = 0;
+    bool amb = false;
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+        bool in, am;
+        fast_inlier<KIND>(sm, a[u], b[u], c[u], d[u], max_res, in, am);
+        amb |= am;
+        unsigned long long bal = __ballot(in);
+        if (u == NB - 1) bal &= last_valid;
+        cnt += __popcll(bal);
+        // as in count_model: a model that cannot reach the best count even if every remaining point were an inlier
+        if ((u & 1) == 1 && u + 1 < NB) {
+            const int rest = M - 64 * (u + 1);
+            if (cnt + rest < thr && __ballot(amb) == 0ull) return cnt + rest;
+        }
+    }
+    if (__builtin_expect(__ballot(amb) == 0ull, 1)) return cnt;
+    cnt = 0;  // some point sat in the band around the threshold: the reference residual decides, for the whole model
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+        unsigned long long bal = __ballot(residual_t<KIND>(sm, a[u], b[u], c[u], d[u]) <= max_res);
+        if (u == NB - 1) bal &= last_valid;
+        cnt += __popcll(bal);
+    }
+    return cnt;
+}
+// KIND K_F7 / K_H: the models are in the solving lanes' registers (mym, NM per trial); KIND K_E5: in global memory
+template <int KIND, int NM, int NB>
+__device__ __forceinline__ int count_chunk_regs(const double (&mym)[27], const double* models, int nmod, const Pts& P,
+                                                int M, double max_res, int nT, int lane, int thr) {
+    double a[NB], b[NB], c[NB], d[NB];
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+        const int k = 64 * u + lane;
+        load_pt<true>(P, k < M ? k : 0, a[u], b[u], c[u], d[u]);
+    }
+    const int tail = M - 64 * (NB - 1);  // 1 .. 64 valid lanes in the last batch
+    const unsigned long long last_valid = tail >= 64 ? ~0ull : ((1ull << tail) - 1ull);
+    int maxcnt = -1;
+    for (int t = 0; t < nT; ++t) {
+        const int n = __builtin_amdgcn_readlane(nmod, t);
+        for (int m = 0; m < (KIND == K_E5 ? n : NM); ++m) {
+            if (m >= n) break;
+            double sm[9];
+            if (KIND == K_E5) {
+                const double* src = models + ((size_t)t * kMaxModels + m) * 9;
+#pragma unroll
+                for (int i = 0; i < 9; ++i) sm[i] = readlane_f64(src[i], 0);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 9; ++i) sm[i] = readlane_f64(mym[9 * (NM == 1 ? 0 : m) + i], t);
+            }
+            const int cc = count_regs<(KIND == K_E5 ? K_F7 : KIND), NB>(sm, a, b, c, d, last_valid, M, max_res, thr);
+            if (lane == t) maxcnt = max(maxcnt, cc);
+        }
+    }
+    return maxcnt;
+}
+template <int KIND, int NM>
+__device__ __forceinline__ int count_chunk_regs_nb(const double (&mym)[27], const double* models, int nmod, const Pts& P,
+                                                   int M, double max_res, int nT, int lane, int thr) {
+    switch ((M + 63) / 64) {
+        case 1: return count_chunk_regs<KIND, NM, 1>(mym, models, nmod, P, M, max_res, nT, lane, thr);
+        case 2: return count_chunk_regs<KIND, NM, 2>(mym, models, nmod, P, M, max_res, nT, lane, thr);
+        case 3: return count_chunk_regs<KIND, NM, 3>(mym, models, nmod, P, M, max_res, nT, lane, thr);
+        case 4: return count_chunk_regs<KIND, NM, 4>(mym, models, nmod, P, M, max_res, nT, lane, thr);
+        case 5: return count_chunk_regs<KIND, NM, 5>(mym, models, nmod, P, M, max_res, nT, lane, thr);
+        case 6: return count_chunk_regs<KIND, NM, 6>(mym, models, nmod, P, M, max_res, nT, lane, thr);
+        case 7: return count_chunk_regs<KIND, NM, 7>(mym, models, nmod, P, M, max_res, nT, lane, thr);
+        default: return count_chunk_regs<KIND, NM, 8>(mym, models, nmod, P, M, max_res, nT, lane, thr);
+    }
+}
+constexpr int kRegCountMaxM = 512;  // 8 batches of 64: 64 VGPRs of points
 
 __device__ __noinline__ void solve_chunk(ChunkModels* out, int est, const Pts P, const lds_u16* sidx, int nT,
                                          int lane, double* models) {
@@ -952,7 +1062,11 @@ __device__ __noinline__ void count_chunk(ChunkModels* io, int est_, const Pts P_
     const int nmod = io->nmod;
     int maxcnt;
     // the points of nearly every pair fit the LDS share; the global-memory path keeps the exact test only
-    if (P.lds && fast) {
+    if (P.lds && fast && M <= kRegCountMaxM && M >= 1 && est != K_T) {
+        if (est == K_F7) maxcnt = count_chunk_regs_nb<K_F7, 3>(mym, models, nmod, P, M, max_res, nT, lane, thr);
+        else if (est == K_H) maxcnt = count_chunk_regs_nb<K_H, 1>(mym, models, nmod, P, M, max_res, nT, lane, thr);
+        else maxcnt = count_chunk_regs_nb<K_E5, 1>(mym, models, nmod, P, M, max_res, nT, lane, thr);
+    } else if (P.lds && fast) {
         if (est == K_F7) maxcnt = count_lane_models<true, K_F7, 3, true>(mym, nmod, P, M, max_res, nT, lane, thr);
         else if (est == K_H) maxcnt = count_lane_models<true, K_H, 1, true>(mym, nmod, P, M, max_res, nT, lane, thr);
         else if (est == K_T) maxcnt = count_lane_models<true, K_T, 1, false>(mym, nmod, P, M, max_res, nT, lane, thr);
@@ -1063,7 +1177,7 @@ __device__ Report lo_ransac(Wave& w_io, const RansacCfg& cfg, const double* gx, 
         solve_chunk(&cm, cfg.est, P, w.sidx, nT, lane, models);
         count_chunk(&cm, cfg.est, P, M, cfg.max_res, nT, lane, models, best.cnt, fast_count);
         w.prof[1] += cm.cyc_solve;
-        if (cfg.est == K_E5) w.prof[5] += cm.cyc_solve;
+        w.prof[5] += cm.cyc_count;  // the counting loop alone (also part of prof[2])
         tp0 = __builtin_readcyclecounter();
         // ---- replay in trial order.  Only two kinds of trial can change anything: one holding a
         //      model whose count reaches the best so far (candidate: re-scored in full, exactly as
@@ -1513,6 +1627,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(kTvgWavesPe
     }
 }
 
+#if defined(AMC_TVG_DIAG) && (AMC_TVG_DIAG & 2)
+void tvg_diag_report() {
+    unsigned long long h[8];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_tvg_diag), sizeof h) != hipSuccess) return;
+    std::fprintf(stderr, "[amc tvg diag] models counted %llu; cycles per model: 256-point groups %.0f, rest of count_model %.0f, "
+                 "model broadcast %.0f, (timer pair %.0f)\n", h[4], (double)h[0] / h[4], (double)h[1] / h[4], (double)h[2] / h[4],
+                 (double)h[3] / (h[4] ? h[4] : 1));
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tvg_diag), z, sizeof z);
+}
+#else
+void tvg_diag_report() {}
+#endif
 size_t tvg_ws_doubles_host(uint32_t mcap) { return tvg_ws_doubles(mcap); }
 size_t tvg_ws_mask_bytes_host(uint32_t mcap) { return tvg_ws_bytes_extra(mcap); }
 
