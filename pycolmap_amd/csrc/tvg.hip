@@ -965,11 +965,13 @@ __device__ __forceinline__ int count_regs(const double (&sm)[9], const double (&
 template <int KIND, int NM, int NB>
 __device__ __forceinline__ int count_chunk_regs(const double (&mym)[27], const double* models, int nmod, const Pts& P,
                                                 int M, double max_res, int nT, int lane, int thr) {
+    // one load per chunk of 64 trials: from LDS, or - pairs whose points do not fit the wave's LDS share - straight
+    // from the global arrays (the latency is paid once per chunk, not once per model)
     double a[NB], b[NB], c[NB], d[NB];
 #pragma unroll
     for (int u = 0; u < NB; ++u) {
         const int k = 64 * u + lane;
-        load_pt<true>(P, k < M ? k : 0, a[u], b[u], c[u], d[u]);
+        load_pt_any(P, k < M ? k : 0, a[u], b[u], c[u], d[u]);
     }
     const int tail = M - 64 * (NB - 1);  // 1 .. 64 valid lanes in the last batch
     const unsigned long long last_valid = tail >= 64 ? ~0ull : ((1ull << tail) - 1ull);
@@ -1004,10 +1006,14 @@ __device__ __forceinline__ int count_chunk_regs_nb(const double (&mym)[27], cons
         case 5: return count_chunk_regs<KIND, NM, 5>(mym, models, nmod, P, M, max_res, nT, lane, thr);
         case 6: return count_chunk_regs<KIND, NM, 6>(mym, models, nmod, P, M, max_res, nT, lane, thr);
         case 7: return count_chunk_regs<KIND, NM, 7>(mym, models, nmod, P, M, max_res, nT, lane, thr);
-        default: return count_chunk_regs<KIND, NM, 8>(mym, models, nmod, P, M, max_res, nT, lane, thr);
+        case 8: return count_chunk_regs<KIND, NM, 8>(mym, models, nmod, P, M, max_res, nT, lane, thr);
+        case 9: return count_chunk_regs<KIND, NM, 9>(mym, models, nmod, P, M, max_res, nT, lane, thr);
+        case 10: return count_chunk_regs<KIND, NM, 10>(mym, models, nmod, P, M, max_res, nT, lane, thr);
+        case 11: return count_chunk_regs<KIND, NM, 11>(mym, models, nmod, P, M, max_res, nT, lane, thr);
+        default: return count_chunk_regs<KIND, NM, 12>(mym, models, nmod, P, M, max_res, nT, lane, thr);
     }
 }
-constexpr int kRegCountMaxM = 512;  // 8 batches of 64: 64 VGPRs of points
+constexpr int kRegCountMaxM = 768;  // 12 batches of 64: 96 VGPRs of points (the phase has 256 to itself)
 
 __device__ __noinline__ void solve_chunk(ChunkModels* out, int est, const Pts P, const lds_u16* sidx, int nT,
                                          int lane, double* models) {
@@ -1062,7 +1068,7 @@ __device__ __noinline__ void count_chunk(ChunkModels* io, int est_, const Pts P_
     const int nmod = io->nmod;
     int maxcnt;
     // the points of nearly every pair fit the LDS share; the global-memory path keeps the exact test only
-    if (P.lds && fast && M <= kRegCountMaxM && M >= 1 && est != K_T) {
+    if (fast && M <= kRegCountMaxM && M >= 1 && est != K_T) {
         if (est == K_F7) maxcnt = count_chunk_regs_nb<K_F7, 3>(mym, models, nmod, P, M, max_res, nT, lane, thr);
         else if (est == K_H) maxcnt = count_chunk_regs_nb<K_H, 1>(mym, models, nmod, P, M, max_res, nT, lane, thr);
         else maxcnt = count_chunk_regs_nb<K_E5, 1>(mym, models, nmod, P, M, max_res, nT, lane, thr);
@@ -1132,14 +1138,16 @@ __device__ Report lo_ransac(Wave& w_io, const RansacCfg& cfg, const double* gx, 
     P.g = gx; P.gs = gstride; P.l = w.lpts; P.ls = w.pts_cap;
     P.lds = (uint32_t)M <= w.pts_cap;
     int fast_count = 0;
-    if (P.lds) {
+    {
         double amax = 0.0;
         for (int k = lane; k < M; k += 64) {
             const double p0 = gx[k], p1 = gx[gstride + k], p2 = gx[2 * (size_t)gstride + k], p3 = gx[3 * (size_t)gstride + k];
-            w.lpts[k] = p0;
-            w.lpts[w.pts_cap + k] = p1;
-            w.lpts[2 * w.pts_cap + k] = p2;
-            w.lpts[3 * w.pts_cap + k] = p3;
+            if (P.lds) {
+                w.lpts[k] = p0;
+                w.lpts[w.pts_cap + k] = p1;
+                w.lpts[2 * w.pts_cap + k] = p2;
+                w.lpts[3 * w.pts_cap + k] = p3;
+            }
             amax = dmax(dmax(amax, dmax(dabs(p0), dabs(p1))), dmax(dabs(p2), dabs(p3)));
         }
 #pragma unroll
