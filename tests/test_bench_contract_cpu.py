@@ -33,6 +33,37 @@ def test_committed_bench_line_has_the_contract_keys():
     v = d.get("verify")
     if v:
         assert v["unit"] == "pairs/s" and v["value"] > 0 and v["cpu_baseline"]["gpu_vs_oracle_mismatching_pairs"] == 0
+        vr = v["roofline"]                                     # the second metric's own roofline (FP64 vector)
+        assert abs(vr["frac"] - vr["achieved"] / vr["peak"]) < 1e-9 and 0 < vr["frac"] < 1
+        assert abs(vr["frac_of_no_fma_ceiling"] - 2 * vr["frac"]) < 1e-6 and vr["kernel"] == "tvg_kernel"
+    pl = d.get("pipeline")
+    if pl:                                                     # configs[2] chained on the device
+        assert pl["unit"] == "verified pairs/s" and pl["pairs_verified"] > 1000 and pl["pairs_total"] == 124750
+        assert abs(pl["value"] - pl["pairs_verified"] / (pl["ms_per_step"] * 1e-3)) < 1e-6 * pl["value"]
+        assert pl["cpu_baseline"]["gpu_vs_oracle_mismatching_pairs"] == 0
+        assert pl["cpu_baseline"]["verified_pairs_mismatching"] == 0 and pl["cpu_baseline"]["verified_pairs_checked"] > 0
+        assert 0 < pl["roofline"]["frac"] < 1
+    dn = d.get("dense")
+    if dn:
+        assert dn["unit"] == "distances/s" and dn["matches_per_pair"] > 500
+        assert abs(dn["value"] - d["config"]["distances_total"] / (dn["ms_per_step"] * 1e-3)) < 1e-6 * dn["value"]
+
+
+def test_committed_scaled_config_lines():
+    """bench.py --config 3 / 4 at N=1 (profiles/r02): the contract keys, strong scaling, the stated workloads."""
+    for name, pairs in (("bench_config3_n1_v1.json", 1999000), ("bench_config4_n1_v1.json", None)):
+        path = ROOT / "profiles" / "r02" / name
+        d = json.loads(path.read_text().strip().splitlines()[-1])
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                  "vs_baseline", "dtype", "data", "config", "roofline"):
+            assert k in d, f"{name}: missing {k}"
+        assert d["scaling"] == "strong" and d["n_gpus"] == 1 and d["unit"] == "distances/s" and d["value"] > 5e9
+        assert "REDUCED" not in d["config"]["workload"]
+        if pairs:
+            assert d["config"]["pairs_total"] == pairs
+        else:
+            assert d["config"]["loop_queries"] == 1000 and d["config"]["pairs_total"] > 500000
+        assert abs(d["value"] - d["config"]["distances_per_step_all_ranks"] / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
 
 
 def test_host_cores_reads_the_cgroup_quota():
