@@ -672,6 +672,17 @@ PYBIND11_MODULE(_pycolmap, m) {
         "match_sequential",
         [run_pipeline](const py::object& database_path, const SiftMatchingOptions& sift,
                        const SequentialMatchingOptions& mo, const TwoViewGeometryOptions& tvg, Device device) {
+            // options of COLMAP's vocabulary-tree retrieval that have no counterpart in the feature-voting retrieval
+            // used here (controller.cc): accepted for drop-in compatibility, and said out loud when they are set
+            const SequentialMatchingOptions def;
+            if (mo.loop_detection && (!mo.vocab_tree_path.empty() ||
+                                      mo.loop_detection_num_nearest_neighbors != def.loop_detection_num_nearest_neighbors ||
+                                      mo.loop_detection_num_checks != def.loop_detection_num_checks ||
+                                      mo.loop_detection_num_images_after_verification != def.loop_detection_num_images_after_verification))
+                Logging::Write(Logging::WARNING, "match_sequential", 0,
+                               "vocab_tree_path / loop_detection_num_nearest_neighbors / _num_checks / "
+                               "_num_images_after_verification are ignored: loop closure candidates come from exact feature "
+                               "voting on the first loop_detection_max_num_features descriptors, not from a vocabulary tree");
             run_pipeline(database_path, sift, tvg, device, [&](MatchController& c) { RunSequential(c, mo); });
         },
         "database_path"_a, "sift_options"_a = SiftMatchingOptions(),

@@ -3,7 +3,9 @@
 No GPU compute here (the drop-in boundary)."""
 import copy
 import itertools
+import os
 import pickle
+from pathlib import Path
 
 import numpy as np
 import pytest
@@ -11,6 +13,8 @@ import pytest
 import colmap_db
 import pycolmap_amd as pycolmap
 from pycolmap_amd import synth
+
+ROOT = Path(__file__).resolve().parent.parent
 
 
 def test_option_defaults_match_the_reference():
@@ -296,3 +300,26 @@ def test_logging_surface_and_pycolmap_alias(tmp_path, capfd):
     with pytest.raises(RuntimeError):
         lg.fatal("stop")
     lg.set_log_destination(lg.INFO, "")
+
+
+@pytest.mark.parametrize("sanitizer", ["thread", "address,undefined"])
+def test_concurrent_database_use_under_sanitizers(tmp_path, sanitizer):
+    """The writer-thread / reader overlap of the grouped runners (controller.cc RunGrouped) and the rollback of an
+    abandoned transaction, compiled with TSan and with ASan + UBSan (tests/shim/db_threads.cc); any report fails."""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    inc = next((p for p in ("/usr/include", "/opt/conda/include") if (Path(p) / "sqlite3.h").exists()), None)
+    if inc is None:
+        pytest.skip("no sqlite3.h")
+    exe = tmp_path / "db_threads"
+    cmd = ["g++", "-O1", "-g", "-std=c++17", f"-fsanitize={sanitizer}", f"-I{inc}", str(ROOT / "tests" / "shim" / "db_threads.cc"),
+           str(ROOT / "pycolmap_amd" / "csrc" / "host" / "database.cc"), "-l:libsqlite3.so.0", "-lpthread", "-o", str(exe)]
+    b = subprocess.run(cmd, capture_output=True, text=True)
+    if b.returncode != 0 and ("cannot find" in b.stderr or "unrecognized" in b.stderr):
+        pytest.skip("sanitizer runtime not installed: " + b.stderr[-200:])
+    assert b.returncode == 0, b.stderr[-2000:]
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1 exitcode=66", ASAN_OPTIONS="detect_leaks=1", UBSAN_OPTIONS="halt_on_error=1")
+    r = subprocess.run([str(exe), str(tmp_path / "san.db")], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0 and r.stdout.startswith("ok rows="), (r.returncode, r.stdout[-500:], r.stderr[-3000:])
