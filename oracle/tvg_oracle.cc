@@ -720,8 +720,39 @@ std::vector<Mat3> estimate_f8(const std::vector<Pt>& p1, const std::vector<Pt>& 
     return {mat3_mul(mat3_mul(mat3_t(T2), Fr), T1)};
 }
 
-// HomographyMatrixEstimator::Estimate (normalised DLT); minimal case (N == 4) through the
-// 8 x 9 null space, over-determined through A^T A (D1)
+// The homography through exactly four correspondences, in closed form (part of D1: COLMAP takes the
+// null vector of the 8 x 9 DLT matrix from a Jacobi SVD; the matrix has an exact one-dimensional null
+// space for four points in general position, and this is that vector written out).  With
+// S = [s0 s1 s2] and D = [d0 d1 d2] (homogeneous columns), adj(S) has rows s1 x s2, s2 x s0, s0 x s1 and
+//   Hhat = D * diag(mu_k / lam_k) * adj(S),   lam = adj(S) s3,   mu = adj(D) d3
+// maps s_k -> d_k for k = 0..3 (a change of projective basis).  Scaled to unit Frobenius norm like the
+// singular vector it replaces.  Three collinear (or repeated) points give 0/0 -> NaN -> no inliers.
+void h4_closed_form(const Pt* s, const Pt* d, double* h) {
+    double a[3][3], b[3][3], c[3][3];
+    for (int k = 0; k < 3; ++k) {
+        const int p = (k + 1) % 3, q = (k + 2) % 3;
+        a[k][0] = s[p].y - s[q].y; a[k][1] = s[q].x - s[p].x; a[k][2] = s[p].x * s[q].y - s[p].y * s[q].x;
+        b[k][0] = d[p].y - d[q].y; b[k][1] = d[q].x - d[p].x; b[k][2] = d[p].x * d[q].y - d[p].y * d[q].x;
+    }
+    for (int k = 0; k < 3; ++k) {
+        const double lam = (a[k][0] * s[3].x + a[k][1] * s[3].y) + a[k][2];
+        const double mu = (b[k][0] * d[3].x + b[k][1] * d[3].y) + b[k][2];
+        const double r = mu / lam;
+        c[k][0] = r * a[k][0]; c[k][1] = r * a[k][1]; c[k][2] = r * a[k][2];
+    }
+    for (int j = 0; j < 3; ++j) {
+        h[j] = (d[0].x * c[0][j] + d[1].x * c[1][j]) + d[2].x * c[2][j];
+        h[3 + j] = (d[0].y * c[0][j] + d[1].y * c[1][j]) + d[2].y * c[2][j];
+        h[6 + j] = (c[0][j] + c[1][j]) + c[2][j];
+    }
+    double n2 = 0.0;
+    for (int j = 0; j < 9; ++j) n2 = n2 + h[j] * h[j];
+    const double inv = 1.0 / std::sqrt(n2);
+    for (int j = 0; j < 9; ++j) h[j] = h[j] * inv;
+}
+
+// HomographyMatrixEstimator::Estimate (normalised DLT); minimal case (N == 4) in closed form,
+// over-determined through A^T A (D1)
 std::vector<Mat3> estimate_h(const std::vector<Pt>& p1, const std::vector<Pt>& p2) {
     const size_t N = p1.size();
     std::vector<Pt> n1, n2;
@@ -740,9 +771,13 @@ std::vector<Mat3> estimate_h(const std::vector<Pt>& p1, const std::vector<Pt>& p
     };
     double h[9];
     if (N == 4) {
+#ifdef ORACLE_LAPACK_SVD
         double A[8 * 9];
         for (size_t i = 0; i < 4; ++i) { row_a(i, A + i * 9); row_b(i, A + (4 + i) * 9); }
         nullspace9(8, A, h);
+#else
+        h4_closed_form(n1.data(), n2.data(), h);
+#endif
     } else {
         // rows 0..N-1 are the "a" rows, N..2N-1 the "b" rows (COLMAP's i / j = N + i layout)
         auto h_row = [&](size_t k, double* r) { if (k < N) row_a(k, r); else row_b(k - N, r); };

@@ -318,22 +318,29 @@ class Context:
         return offsets, matches, stats
 
     @staticmethod
-    def _unpack_verify(res, total):
+    def _unpack_verify(res, total, labelled=False):
+        """Copies the result out (one copy per array).  `labelled`: the mask holds geometry labels (multiple_models)
+        rather than 0 / 1."""
         n = int(res.npairs)
         assert C.sizeof(Tvg) == TVG_DTYPE.itemsize
-        tvg = (np.frombuffer(C.string_at(res.tvg, n * C.sizeof(Tvg)), dtype=TVG_DTYPE).copy() if n
-               else np.zeros(0, dtype=TVG_DTYPE))
-        labels = (np.ctypeslib.as_array(res.inlier_mask, shape=(total,)).copy() if total
-                  else np.zeros(0, dtype=np.uint8))
-        mask = labels.astype(bool)
+
+        def copy_of(ptr, count, dtype):
+            nbytes = count * np.dtype(dtype).itemsize
+            if not nbytes:
+                return np.zeros(0, dtype=dtype)
+            addr = C.cast(ptr, C.c_void_p).value
+            return np.frombuffer((C.c_char * nbytes).from_address(addr), dtype=dtype).copy()
+
+        tvg = copy_of(res.tvg, n, TVG_DTYPE)
+        labels = copy_of(res.inlier_mask, total, np.uint8)
+        mask = labels.astype(bool) if labelled else labels.view(np.bool_)   # 0 / 1 bytes are numpy bools as they are
         # inlier_labels: 1 + index of the geometry a match belongs to (multiple_models), else 0 / 1
         stats = dict(device_ms=float(res.device_ms), kernel_ms=float(res.kernel_ms), inlier_labels=labels,
                      kernel_launches=int(res.kernel_launches), work=[int(x) for x in res.work])
         stats["pose_kernel_ms"] = float(res.pose_kernel_ms)
         if res.pose:  # compute_relative_pose: one amc_pose per pair
             assert C.sizeof(Pose) == POSE_DTYPE.itemsize
-            stats["pose"] = (np.frombuffer(C.string_at(res.pose, n * C.sizeof(Pose)), dtype=POSE_DTYPE).copy()
-                             if n else np.zeros(0, dtype=POSE_DTYPE))
+            stats["pose"] = copy_of(res.pose, n, POSE_DTYPE)
         return tvg, mask, stats
 
     def match_verify_pairs(self, slot1, slot2, opts: TvgOpts | None = None, seed: int = 0, max_ratio: float = 0.8,
@@ -351,7 +358,7 @@ class Context:
                                                 s1.size, C.byref(mo), C.byref(o), seed, C.byref(mres), C.byref(vres)))
         try:
             offsets, matches, mstats = self._unpack_match(mres)
-            tvg, mask, vstats = self._unpack_verify(vres, matches.shape[0])
+            tvg, mask, vstats = self._unpack_verify(vres, matches.shape[0], bool(o.multiple_models))
         finally:
             self._lib.amc_match_result_free(C.byref(mres))
             self._lib.amc_verify_result_free(C.byref(vres))
@@ -481,7 +488,7 @@ class Context:
                                           s1.size, off.ctypes.data_as(C.c_void_p), m.ctypes.data_as(C.c_void_p),
                                           C.byref(o), seed, C.byref(res)))
         try:
-            tvg, mask, stats = self._unpack_verify(res, m.shape[0])
+            tvg, mask, stats = self._unpack_verify(res, m.shape[0], bool(o.multiple_models))
         finally:
             self._lib.amc_verify_result_free(C.byref(res))
         return tvg, mask, stats

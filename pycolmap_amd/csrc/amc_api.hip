@@ -191,6 +191,8 @@ struct amc_ctx {
     DevBuf<double> d_tws;
     DevBuf<uint8_t> d_tmaskws, d_toutmask;
     DevBuf<TvgOut> d_tout;
+    PinBuf<TvgOut> h_tout;    // where the records and masks of a verification call land (copied out before return)
+    PinBuf<uint8_t> h_tmask;
     // dyn_max_num_trials tables by (match count, confidence, multiplier), see verify_impl
     std::map<TrialTabKey, std::vector<uint32_t>> trial_tabs;
     size_t trial_tab_words = 0;
@@ -290,6 +292,7 @@ void amc_ctx_destroy(amc_ctx* c) {
     c->d_pair_off.release(); c->d_pair_cnt.release(); c->d_matches.release();
     c->d_cand_cnt.release(); c->d_candbuf.release(); c->d_keep.release(); c->d_csr.release();
     c->h_csr[0].release(); c->h_csr[1].release();
+    c->h_tout.release(); c->h_tmask.release();
     for (int k = 0; k < 2; ++k) {
         c->h_pairs[k].release(); c->h_work[k].release(); c->h_order[k].release(); c->h_order2[k].release();
         c->h_pair_off[k].release(); c->h_pair_cnt[k].release(); c->h_matches[k].release();
@@ -1127,6 +1130,10 @@ struct VerifyPriv {
     std::vector<amc_tvg> tvg;
     std::vector<uint8_t> mask;
     std::vector<amc_pose> pose;
+    // single-geometry calls: plain storage, every element written from the device results (a vector would
+    // zero tens of megabytes first)
+    std::unique_ptr<amc_tvg[]> tvg_raw;
+    std::unique_ptr<uint8_t[]> mask_raw;
 };
 
 void pose_default(amc_pose* q, int32_t config) {
@@ -1255,6 +1262,15 @@ static int verify_impl(amc_ctx* c, int mode, const uint32_t* slot1, const uint32
     std::memset(out, 0, sizeof *out);
     if (npairs > 0 && (!slot1 || !slot2 || !match_offsets))
         return fail(AMC_E_INVALID, "amc_verify_pairs: NULL pair arrays");
+    // AMC_VERIFY_PROFILE=1: wall-clock of the call's host phases on stderr
+    const bool hprof = std::getenv("AMC_VERIFY_PROFILE") != nullptr;
+    auto wall = std::chrono::steady_clock::now();
+    double t_phase[6] = {0, 0, 0, 0, 0, 0};
+    auto lap = [&](int k) {
+        const auto now = std::chrono::steady_clock::now();
+        t_phase[k] += std::chrono::duration<double, std::milli>(now - wall).count();
+        wall = now;
+    };
     amc_tvg_opts o;
     if (opts_in) o = *opts_in; else amc_tvg_opts_default(&o);
     if (o.compute_relative_pose && mode != 0)
@@ -1345,14 +1361,19 @@ static int verify_impl(amc_ctx* c, int mode, const uint32_t* slot1, const uint32
 
     HIPCHK(hipSetDevice(c->device));
     hipStream_t st = c->stream;
+    lap(0);
     VerifyPriv* priv = new (std::nothrow) VerifyPriv();
     if (!priv) return fail(AMC_E_NOMEM, "amc_verify_pairs: out of host memory");
-    priv->tvg.resize(npairs);
-    priv->mask.assign(total, 0);
+    priv->tvg_raw.reset(new (std::nothrow) amc_tvg[std::max<size_t>(npairs, 1)]);
+    priv->mask_raw.reset(new (std::nothrow) uint8_t[std::max<uint64_t>(total, 1)]);
+    if (!priv->tvg_raw || !priv->mask_raw) {
+        delete priv;
+        return fail(AMC_E_NOMEM, "amc_verify_pairs: out of host memory");
+    }
     out->npairs = npairs;
     out->_priv = priv;
-    out->tvg = priv->tvg.data();
-    out->inlier_mask = priv->mask.data();
+    out->tvg = priv->tvg_raw.get();
+    out->inlier_mask = priv->mask_raw.get();
     if (npairs == 0) return AMC_OK;
 
     // image table (cameras with distortion parameters: CamFromImg of their keypoints first)
@@ -1412,6 +1433,7 @@ static int verify_impl(amc_ctx* c, int mode, const uint32_t* slot1, const uint32
         tp[p].mask_off = mask_bytes;
         mask_bytes += ((uint64_t)M + 127) / 128 * 128;
         tp[p].M = M;
+        tp[p].orig = (uint32_t)p;
         for (int t = 0; t < 3; ++t) tp[p].tab_off[t] = (uint32_t)(tab_of_M[M] + (int64_t)t * (M + 1));
     }
     // std::mt19937(seed) initial state
@@ -1438,6 +1460,7 @@ static int verify_impl(amc_ctx* c, int mode, const uint32_t* slot1, const uint32
                         "kernel's per-pair state can index in LDS (limit ~38000)", p, tp[p].M);
         }
     }
+    lap(1);
     HIPCHK(c->d_timgs.ensure(timgs.size()));
     if (!dev_matches) HIPCHK(c->d_tmatches.ensure(std::max<size_t>(2 * total, 2)));
     HIPCHK(c->d_ttabs.ensure(std::max<size_t>(tabs.size(), 1)));
@@ -1459,9 +1482,13 @@ static int verify_impl(amc_ctx* c, int mode, const uint32_t* slot1, const uint32
     }
     HIPCHK(hipMemsetAsync(c->d_scalars + 2, 0, sizeof(uint32_t), st));
     HIPCHK(hipStreamSynchronize(st));
+    lap(2);
 
-    std::vector<TvgOut> h_out(npairs);
-    std::vector<uint8_t> h_mask(std::max<size_t>(mask_bytes, 1));
+    HIPCHK(c->h_tout.ensure(npairs));
+    HIPCHK(c->h_tmask.ensure(std::max<size_t>(mask_bytes, 1)));
+    HIPCHK(c->d_tout.ensure(npairs));
+    const TvgOut* h_out = c->h_tout.p;
+    const uint8_t* h_mask = c->h_tmask.p;
     double kernel_ms = 0.0;
     uint32_t launches = 0;
     for (int k = 0; k < 2; ++k) {
@@ -1488,7 +1515,6 @@ static int verify_impl(amc_ctx* c, int mode, const uint32_t* slot1, const uint32
         HIPCHK(c->d_tpairs.ensure(idx.size()));
         HIPCHK(c->d_tws.ensure((size_t)num_waves * tvg_ws_doubles_host(mcap)));
         HIPCHK(c->d_tmaskws.ensure((size_t)num_waves * tvg_ws_mask_bytes_host(mcap)));
-        HIPCHK(c->d_tout.ensure(idx.size()));
         HIPCHK(hipMemcpyAsync(c->d_tpairs.p, sub.data(), sub.size() * sizeof(TvgPair), hipMemcpyHostToDevice, st));
         HIPCHK(hipStreamSynchronize(st));  // `sub` goes out of scope at the end of the iteration
         HIPCHK(hipEventRecord(c->ev[2], st));
@@ -1496,21 +1522,21 @@ static int verify_impl(amc_ctx* c, int mode, const uint32_t* slot1, const uint32
                           c->d_mtinit.p, P, c->d_tws.p, c->d_tmaskws.p, mcap, num_waves, wpb, c->d_scalars + 1,
                           c->d_tout.p, c->d_toutmask.p, st));
         HIPCHK(hipEventRecord(c->ev[3], st));
-        std::vector<TvgOut> sub_out(idx.size());
-        HIPCHK(hipMemcpyAsync(sub_out.data(), c->d_tout.p, idx.size() * sizeof(TvgOut), hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
-        for (size_t i = 0; i < idx.size(); ++i) h_out[idx[i]] = sub_out[i];
+        HIPCHK(hipStreamSynchronize(st));  // d_tpairs is rewritten by the next class
         float kms = 0.f;
         (void)hipEventElapsedTime(&kms, c->ev[2], c->ev[3]);
         kernel_ms += kms;
         ++launches;
     }
+    // the kernel stores a pair's record at the caller's pair index (TvgPair::orig)
+    HIPCHK(hipMemcpyAsync(c->h_tout.p, c->d_tout.p, npairs * sizeof(TvgOut), hipMemcpyDeviceToHost, st));
     if (mask_bytes)
-        HIPCHK(hipMemcpyAsync(h_mask.data(), c->d_toutmask.p, mask_bytes, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(c->h_tmask.p, c->d_toutmask.p, mask_bytes, hipMemcpyDeviceToHost, st));
     uint32_t bad_pairs = 0;
     HIPCHK(hipMemcpyAsync(&bad_pairs, c->d_scalars + 2, sizeof bad_pairs, hipMemcpyDeviceToHost, st));
     HIPCHK(hipEventRecord(c->ev[1], st));
     HIPCHK(hipEventSynchronize(c->ev[1]));
+    lap(3);
     if (bad_pairs) {  // the kernel met an index past an image's keypoints: find it for the message
         delete priv;
         std::memset(out, 0, sizeof *out);
@@ -1536,9 +1562,9 @@ static int verify_impl(amc_ctx* c, int mode, const uint32_t* slot1, const uint32
                      (double)acc[5] / npairs, (double)acc[6] / npairs, (double)acc[7] / npairs);
     }
     for (size_t p = 0; p < npairs; ++p) {
-        priv->tvg[p] = h_out[p].g;
+        priv->tvg_raw[p] = h_out[p].g;
         if (tp[p].M)
-            std::memcpy(priv->mask.data() + match_offsets[p], h_mask.data() + tp[p].mask_off, tp[p].M);
+            std::memcpy(priv->mask_raw.get() + match_offsets[p], h_mask + tp[p].mask_off, tp[p].M);
     }
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[1]);
@@ -1547,6 +1573,11 @@ static int verify_impl(amc_ctx* c, int mode, const uint32_t* slot1, const uint32
     out->kernel_launches = launches;
     for (size_t p = 0; p < npairs; ++p)
         for (int i = 0; i < 12; ++i) out->work[i] += h_out[p].work[i];
+    lap(4);
+    if (hprof)
+        std::fprintf(stderr, "[amc verify profile] pairs=%zu checks %.1f ms, tables %.1f, upload %.1f, kernels+download %.1f "
+                     "(kernels %.1f), unpack %.1f\n", npairs, t_phase[0], t_phase[1], t_phase[2], t_phase[3], kernel_ms,
+                     t_phase[4]);
     if (o.compute_relative_pose) {
         // EstimateTwoViewGeometryPose on the selected inlier matches (mask order = match order): the matches
         // and the masks of this call are still on the device
@@ -1554,14 +1585,14 @@ static int verify_impl(amc_ctx* c, int mode, const uint32_t* slot1, const uint32
         for (size_t p = 0; p < npairs; ++p) moff[p] = tp[p].mask_off;
         priv->pose.resize(npairs);
         double pose_ms = 0.0;
-        const int rc = pose_impl(c, "amc_verify_pairs", slot1, slot2, npairs, match_offsets, matches, priv->tvg.data(),
+        const int rc = pose_impl(c, "amc_verify_pairs", slot1, slot2, npairs, match_offsets, matches, priv->tvg_raw.get(),
                                  priv->pose.data(), &pose_ms, moff.data(), dev_matches, dev_off);
         if (rc != AMC_OK) {
             delete priv;
             std::memset(out, 0, sizeof *out);
             return rc;
         }
-        for (size_t p = 0; p < npairs; ++p) priv->tvg[p].config = priv->pose[p].config;
+        for (size_t p = 0; p < npairs; ++p) priv->tvg_raw[p].config = priv->pose[p].config;
         out->pose = priv->pose.data();
         out->device_ms += pose_ms;
         out->kernel_ms += pose_ms;

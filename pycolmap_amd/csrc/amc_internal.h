@@ -160,6 +160,7 @@ struct TvgPair {
                           // write bytes of the same cache line
     uint32_t M;
     uint32_t tab_off[3];  // dyn_max_num_trials tables for the E (k=5), F (k=7), H (k=4) RANSACs
+    uint32_t orig;        // index of the pair's TvgOut record (the caller's pair index)
 };
 // ----- relative pose of verified pairs (pose.hip) ----------------------------------------------
 // One pair of EstimateTwoViewGeometryPose: the geometry's config / E / H and its inlier matches

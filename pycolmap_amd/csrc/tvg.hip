@@ -194,57 +194,122 @@ __device__ __forceinline__ SamplerState sample_chunk_t(lds_u32* mt, const uint32
     }
     wave_lds_sync();
     if (__ballot(slowflag) == 0ull) {
-        // ---- sequential swaps, wave-uniform ----
-        uint32_t jrow = lane < 8 ? (uint32_t)sidx[lane] : 0u;
-        for (int t = 0; t < nT; ++t) {
-            const uint32_t jcur = jrow;
-            if (t + 1 < nT) jrow = lane < 8 ? (uint32_t)sidx[(t + 1) * 8 + lane] : 0u;  // prefetch
-            uint32_t j[7];
-            bool head = false;  // some j falls into the register-resident head of the permutation
+        // ---- sequential swaps ----
+        // Lane i < kMin owns slot i of the permutation's head (prv); one trial is, per slot, v = perm[j],
+        // perm[j] = prv, prv = v - independent across slots as long as the trial's j are distinct and
+        // none falls into the head.  Those trials (classified up front, lane t looks at trial t) take
+        // one LDS read + two writes per lane, and the only dependence from trial to trial is the read
+        // of t feeding the write of t + 1, so consecutive trials overlap in the in-order LDS queue.
+        // The others (a few per cent) run the scalar, slot-by-slot code on the gathered head.
+        // Lane t keeps trial t's draws in registers (jj); the loop below fetches them with readlane, so the
+        // LDS queue only carries the permutation traffic and the wait before a trial's write is for the read
+        // issued one trial earlier (sidx of trial t is stored during trial t + 1 for the same reason).
+        unsigned long long slowmask;
+        uint32_t jj[7];
+        {
+            bool odd = false;
+#pragma unroll
+            for (int i = 0; i < 7; ++i)
+                jj[i] = (i < kMin && lane < nT) ? (uint32_t)sidx[lane * 8 + i] : 0xFFFF0000u + (uint32_t)i;
 #pragma unroll
             for (int i = 0; i < 7; ++i) {
-                j[i] = i < kMin ? (uint32_t)__builtin_amdgcn_readlane((int)jcur, i) : 0xFFFFu;
-                head |= j[i] < (uint32_t)kMin;
+                odd |= jj[i] < (uint32_t)kMin;
+#pragma unroll
+                for (int q = i + 1; q < 7; ++q) odd |= jj[i] == jj[q];
             }
-
-            if (!head) {
-                // in-order LDS queue: read_i, write_i pairs of one trial are all in flight together
-                uint32_t v[7];
+            if (lane < nT) rawcnt[lane] = (uint32_t)((lane + 1) * kMin);
+            slowmask = __ballot(odd && lane < nT);
+        }
+        wave_lds_sync();  // every lane has its draws before the rows are overwritten with the samples
+        uint32_t prv = 0;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) prv = lane == i ? st.pr[i] : prv;
+        const bool slot = lane < kMin;
+        int t = 0;
+        while (t < nT) {
+            const unsigned long long rest = slowmask >> t;
+            int run = rest ? (int)__builtin_ctzll(rest) : 64;
+            run = min(run, nT - t);
+            // two trials per round on alternating registers: the value read by one trial is stored by the
+            // next, and nothing in between needs it (no copy, so no wait on the read just issued).  `pend` is
+            // the trial whose samples (the value about to be stored) are not in sidx yet; at the start of a
+            // run that store repeats what trial t - 1 already wrote (row 0 when there is none: rewritten below).
+            int pend = max(t - 1, 0);
+            uint32_t a = prv;
+            const int e = t + run;
+            while (t + 1 < e) {
+                uint32_t j0 = 0, j1 = 0;
 #pragma unroll
                 for (int i = 0; i < 7; ++i)
                     if (i < kMin) {
-                        v[i] = perm[j[i]];
-                        perm[j[i]] = (uint16_t)st.pr[i];
+                        const uint32_t x0 = (uint32_t)__builtin_amdgcn_readlane((int)jj[i], t);
+                        const uint32_t x1 = (uint32_t)__builtin_amdgcn_readlane((int)jj[i], t + 1);
+                        j0 = lane == i ? x0 : j0;
+                        j1 = lane == i ? x1 : j1;
                     }
+                if (slot) {
+                    const uint32_t b = perm[j0];
+                    perm[j0] = (uint16_t)a;
+                    sidx[pend * 8 + lane] = (uint16_t)a;
+                    a = perm[j1];
+                    perm[j1] = (uint16_t)b;
+                    sidx[t * 8 + lane] = (uint16_t)b;
+                }
+                pend = t + 1;
+                t += 2;
+            }
+            if (t < e) {
+                uint32_t j0 = 0;
 #pragma unroll
                 for (int i = 0; i < 7; ++i)
-                    if (i < kMin) st.pr[i] = sgpr(v[i]);
-            } else {
-#pragma unroll
-                for (int i = 0; i < 7; ++i) {
                     if (i < kMin) {
-                        if (j[i] < (uint32_t)kMin) {
-                            uint32_t vj = st.pr[0];
+                        const uint32_t x0 = (uint32_t)__builtin_amdgcn_readlane((int)jj[i], t);
+                        j0 = lane == i ? x0 : j0;
+                    }
+                if (slot) {
+                    const uint32_t b = perm[j0];
+                    perm[j0] = (uint16_t)a;
+                    sidx[pend * 8 + lane] = (uint16_t)a;
+                    a = b;
+                }
+                pend = t;
+                ++t;
+            }
+            if (run > 0 && slot) sidx[pend * 8 + lane] = (uint16_t)a;
+            prv = a;
+            if (t >= nT) break;
+            // trial t touches the head or draws an index twice: slot by slot on the gathered head
+            uint32_t j[7], pr[7];
 #pragma unroll
-                            for (int q = 1; q < 7; ++q) vj = (j[i] == (uint32_t)q) ? st.pr[q] : vj;
-                            const uint32_t vi = st.pr[i];
+            for (int i = 0; i < 7; ++i) {
+                j[i] = i < kMin ? (uint32_t)__builtin_amdgcn_readlane((int)jj[i], t) : 0xFFFFu;
+                pr[i] = i < kMin ? (uint32_t)__builtin_amdgcn_readlane((int)prv, i) : 0u;
+            }
 #pragma unroll
-                            for (int q = 0; q < 7; ++q) st.pr[q] = (j[i] == (uint32_t)q) ? vi : st.pr[q];
-                            st.pr[i] = vj;
-                        } else {
-                            const uint32_t vj = sgpr(perm[j[i]]);
-                            perm[j[i]] = (uint16_t)st.pr[i];
-                            st.pr[i] = vj;
-                        }
+            for (int i = 0; i < 7; ++i) {
+                if (i < kMin) {
+                    if (j[i] < (uint32_t)kMin) {
+                        uint32_t vj = pr[0];
+#pragma unroll
+                        for (int q = 1; q < 7; ++q) vj = (j[i] == (uint32_t)q) ? pr[q] : vj;
+                        const uint32_t vi = pr[i];
+#pragma unroll
+                        for (int q = 0; q < 7; ++q) pr[q] = (j[i] == (uint32_t)q) ? vi : pr[q];
+                        pr[i] = vj;
+                    } else {
+                        const uint32_t vj = sgpr(perm[j[i]]);
+                        perm[j[i]] = (uint16_t)pr[i];
+                        pr[i] = vj;
                     }
                 }
             }
-            if (lane == 0) {
 #pragma unroll
-                for (int i = 0; i < 7; ++i) sidx[t * 8 + i] = (uint16_t)st.pr[i];
-                rawcnt[t] = (uint32_t)((t + 1) * kMin);
-            }
+            for (int i = 0; i < 7; ++i) prv = (i < kMin && lane == i) ? pr[i] : prv;
+            if (slot) sidx[t * 8 + lane] = (uint16_t)prv;
+            ++t;
         }
+#pragma unroll
+        for (int i = 0; i < 7; ++i) st.pr[i] = i < kMin ? (uint32_t)__builtin_amdgcn_readlane((int)prv, i) : st.pr[i];
         wave_lds_sync();
         return st;
     }
@@ -1339,11 +1404,12 @@ __device__ __noinline__ void process_pair(Wave& w, uint32_t q, const TvgImage* _
     const int lane = w.lane;
     const uint32_t mcap = w.mcap;
     for (int i = 0; i < 8; ++i) w.prof[i] = 0;
-    w.work = out[q].work;
+    const TvgPair pr = pairs[q];
+    const uint32_t oq = pr.orig;  // results are stored by the caller's pair index, whatever the queue order
+    w.work = out[oq].work;
     if (lane == 0)
         for (int i = 0; i < 12; ++i) w.work[i] = 0;
     const unsigned long long tstart = __builtin_readcyclecounter();
-    const TvgPair pr = pairs[q];
     // the image records are read field by field where they are needed (wave-uniform scalar loads): a by-value
     // copy of both would hold 2 x 38 dwords of camera parameters in scalar registers for the whole pair
     const TvgImage* __restrict__ pim1 = imgs + pr.slot1;
@@ -1360,7 +1426,7 @@ __device__ __noinline__ void process_pair(Wave& w, uint32_t q, const TvgImage* _
 
     if (P.mode == 0 && M < P.min_num_inliers) {
         g.config = AMC_TVG_DEGENERATE;
-        if (lane == 0) out[q].g = g;
+        if (lane == 0) out[oq].g = g;
         return;
     }
     // ---- matched points (FeatureKeypointsToPointsVector: float -> double) ------------------
@@ -1392,7 +1458,7 @@ __device__ __noinline__ void process_pair(Wave& w, uint32_t q, const TvgImage* _
         g.config = AMC_TVG_UNDEFINED;
         if (lane == 0) {
             atomicAdd(P.bad_index_count, 1u);
-            out[q].g = g;
+            out[oq].g = g;
         }
         return;
     }
@@ -1493,9 +1559,9 @@ __device__ __noinline__ void process_pair(Wave& w, uint32_t q, const TvgImage* _
         if (r.success)
             for (int k = lane; k < M; k += 64) omask[k] = rm[k];
         if (lane == 0) {
-            out[q].g = g;
+            out[oq].g = g;
             w.prof[4] = __builtin_readcyclecounter() - tstart;
-            for (int i = 0; i < 8; ++i) out[q].prof[i] = w.prof[i];
+            for (int i = 0; i < 8; ++i) out[oq].prof[i] = w.prof[i];
         }
         return;
     }
@@ -1592,9 +1658,9 @@ __device__ __noinline__ void process_pair(Wave& w, uint32_t q, const TvgImage* _
         }
     }
     if (lane == 0) {
-        out[q].g = g;
+        out[oq].g = g;
         w.prof[4] = __builtin_readcyclecounter() - tstart;
-        for (int i = 0; i < 8; ++i) out[q].prof[i] = w.prof[i];
+        for (int i = 0; i < 8; ++i) out[oq].prof[i] = w.prof[i];
     }
 }
 

@@ -507,23 +507,47 @@ AMC_HD void normalize4(const double* x, const double* y, double* nx, double* ny,
     }
 }
 
-// minimal 4-point homography
+// minimal 4-point homography in closed form (same operation order as the oracle's h4_closed_form): with
+// S = [s0 s1 s2], D = [d0 d1 d2] (homogeneous columns), adj(S) has rows s1 x s2, s2 x s0, s0 x s1, and
+//   Hhat = D * diag(mu_k / lam_k) * adj(S),   lam = adj(S) s3,  mu = adj(D) d3
+// maps s_k -> d_k for all four points (projective basis change); scaled to unit Frobenius norm.
+AMC_HD void h4_closed_form(const double* sx, const double* sy, const double* dx, const double* dy, double* h) {
+    double a[3][3], b[3][3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int p = (k + 1) % 3, q = (k + 2) % 3;
+        a[k][0] = sy[p] - sy[q]; a[k][1] = sx[q] - sx[p]; a[k][2] = sx[p] * sy[q] - sy[p] * sx[q];
+        b[k][0] = dy[p] - dy[q]; b[k][1] = dx[q] - dx[p]; b[k][2] = dx[p] * dy[q] - dy[p] * dx[q];
+    }
+    double c[3][3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const double lam = (a[k][0] * sx[3] + a[k][1] * sy[3]) + a[k][2];
+        const double mu = (b[k][0] * dx[3] + b[k][1] * dy[3]) + b[k][2];
+        const double r = mu / lam;
+        c[k][0] = r * a[k][0]; c[k][1] = r * a[k][1]; c[k][2] = r * a[k][2];
+    }
+    double n2 = 0.0;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        h[j] = (dx[0] * c[0][j] + dx[1] * c[1][j]) + dx[2] * c[2][j];
+        h[3 + j] = (dy[0] * c[0][j] + dy[1] * c[1][j]) + dy[2] * c[2][j];
+        h[6 + j] = (c[0][j] + c[1][j]) + c[2][j];
+    }
+#pragma unroll
+    for (int j = 0; j < 9; ++j) n2 = n2 + h[j] * h[j];
+    const double inv = 1.0 / dsqrt(n2);
+#pragma unroll
+    for (int j = 0; j < 9; ++j) h[j] = h[j] * inv;
+}
+
 AMC_HD void estimate_h4(const double* x1, const double* y1, const double* x2, const double* y2, double* H) {
     double n1x[4], n1y[4], n2x[4], n2y[4], T1[9], T2[9];
     normalize4(x1, y1, n1x, n1y, T1);
     normalize4(x2, y2, n2x, n2y, T2);
-    double A[8][9];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const double s_0 = n1x[i], s_1 = n1y[i], d_0 = n2x[i], d_1 = n2y[i];
-        A[i][0] = -s_0; A[i][1] = -s_1; A[i][2] = -1; A[i][3] = 0; A[i][4] = 0; A[i][5] = 0;
-        A[i][6] = s_0 * d_0; A[i][7] = s_1 * d_0; A[i][8] = d_0;
-        A[4 + i][0] = 0; A[4 + i][1] = 0; A[4 + i][2] = 0; A[4 + i][3] = -s_0; A[4 + i][4] = -s_1; A[4 + i][5] = -1;
-        A[4 + i][6] = s_0 * d_1; A[4 + i][7] = s_1 * d_1; A[4 + i][8] = d_1;
-    }
-    double h[1][9];
-    nullspace_reg<8>(A, h);
-    h_denormalize(h[0], T1, T2, H);
+    double h[9];
+    h4_closed_form(n1x, n1y, n2x, n2y, h);
+    h_denormalize(h, T1, T2, H);
 }
 
 // ---- 5-point essential matrix -------------------------------------------------------------------

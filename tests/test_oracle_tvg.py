@@ -403,7 +403,7 @@ def test_relative_pose_skips_configs_without_geometry():
 
 # ------------------------------------------------------------------------- golden fixture ----
 def test_golden_fixture_pins_the_oracle():
-    """tests/golden/tvg_golden_v2.npz: the oracle still produces what it produced when the fixture was
+    """tests/golden/tvg_golden_v3.npz: the oracle still produces what it produced when the fixture was
     committed (configs, masks, trial counts, model / pose bit patterns), with and without the pose."""
     import tvg_golden
     n = 0

@@ -297,7 +297,7 @@ def test_non_finite_and_degenerate_inputs(amc_ctx):
 
 
 def test_golden_fixture(amc_ctx):
-    """The HIP path against the committed fixture (tests/golden/tvg_golden_v2.npz): every case, with and
+    """The HIP path against the committed fixture (tests/golden/tvg_golden_v3.npz): every case, with and
     without compute_relative_pose, option overrides included.  No oracle call in this test."""
     import tvg_golden
     cases = list(tvg_golden.cases())
