@@ -84,7 +84,8 @@ typedef struct amc_match_result {
     uint32_t* matches;   /* 2 * offsets[npairs] */
     uint64_t num_distances;   /* sum over pairs of n1*n2 (the BASELINE.json metric's unit) */
     uint64_t pairs_mfma;      /* pairs routed to the int8-MFMA kernel */
-    uint64_t pairs_dot4;      /* pairs routed to the u8 dot4 kernel */
+    uint64_t pairs_dot4;      /* pairs routed to the u8 dot4 kernel (guided: the dense filtered scan) */
+    uint64_t pairs_guided_grid; /* guided pairs matched by candidate generation instead (match_guided.hip) */
     double device_ms;         /* first kernel launch -> last result byte on host, HIP events */
     double match_kernel_ms;   /* sum of one-way match-kernel launch durations (image 1 -> image 2
                                  scan), HIP events on the stream */

@@ -74,7 +74,7 @@ class MatchOpts(C.Structure):
 class MatchResult(C.Structure):
     _fields_ = [("npairs", C.c_size_t), ("offsets", C.POINTER(C.c_uint64)),
                 ("matches", C.POINTER(C.c_uint32)), ("num_distances", C.c_uint64),
-                ("pairs_mfma", C.c_uint64), ("pairs_dot4", C.c_uint64),
+                ("pairs_mfma", C.c_uint64), ("pairs_dot4", C.c_uint64), ("pairs_guided_grid", C.c_uint64),
                 ("device_ms", C.c_double), ("match_kernel_ms", C.c_double),
                 ("cross_kernel_ms", C.c_double),
                 ("match_kernel_launches", C.c_uint32), ("_priv", C.c_void_p)]
@@ -387,6 +387,7 @@ class Context:
             matches = (np.ctypeslib.as_array(res.matches, shape=(total, 2)).copy() if total
                        else np.zeros((0, 2), dtype=np.uint32))
             stats = dict(num_distances=int(res.num_distances), pairs_dot4=int(res.pairs_dot4),
+                         pairs_guided_grid=int(res.pairs_guided_grid),
                          device_ms=float(res.device_ms))
         finally:
             self._lib.amc_match_result_free(C.byref(res))

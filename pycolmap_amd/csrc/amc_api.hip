@@ -58,6 +58,8 @@ struct Slot {
     uint32_t kp_rows = 0;
     bool has_kp = false, has_cam = false;
     CameraDev cam{};
+    void* grid_base = nullptr;  // guided matching's keypoint grid: sxy | sidx | cell_start (one allocation)
+    GridDev grid{};             // n == 0: none (no float32 keypoints, or non-finite coordinates)
 };
 
 // grow-only device / pinned-host scratch
@@ -157,6 +159,7 @@ struct amc_ctx {
     std::vector<Slot> slots;
     bool table_dirty = true;
     DevBuf<ImageDev> d_imgs;
+    DevBuf<GridDev> d_grids;   // guided matching's keypoint grids, by slot (uploaded with d_imgs)
     float* d_lut = nullptr;
     std::vector<float> h_lut;
     uint32_t* d_scalars = nullptr;  // [0] cursor, [1] queue head, [2] maxsq scratch
@@ -276,6 +279,7 @@ static void free_slot(Slot& s) {
     if (s.kp) (void)hipFree(s.kp);
     if (s.kp64) (void)hipFree(s.kp64);
     if (s.kpn) (void)hipFree(s.kpn);
+    if (s.grid_base) (void)hipFree(s.grid_base);
     s = Slot();
 }
 
@@ -285,6 +289,7 @@ void amc_ctx_destroy(amc_ctx* c) {
     (void)hipDeviceSynchronize();
     for (auto& s : c->slots) free_slot(s);
     c->d_imgs.release();
+    c->d_grids.release();
     if (c->d_lut) (void)hipFree(c->d_lut);
     if (c->d_scalars) (void)hipFree(c->d_scalars);
     c->d_pairs.release(); c->d_work.release(); c->d_order.release(); c->d_order2.release();
@@ -428,6 +433,65 @@ constexpr size_t kMaxMatchCap = (size_t)256 << 20;     // worst-case matches of 
 
 }  // namespace
 
+// Whether a guided pair may take the candidate-generation kernel (match_guided.hip), and what that kernel needs
+// beyond the float model: it is exact as long as the float32 filter cannot return NaN (NaN > t is false = "not
+// rejected" for EVERY pairing, which no geometric candidate set contains) and its conservative regions hold -
+// finite, sanely scaled models and keypoints.  Anything else keeps the dense kernel, which evaluates the filter
+// on all n1 x n2 pairings.
+static void guided_grid_setup(GuidedDev& g, const GridDev& g1, const GridDev& g2, bool dense_only) {
+    g.grid_ok = 0;
+    g.bound[0] = g.bound[1] = 0.0;
+    for (int k = 0; k < 9; ++k) g.minv[k] = 0.0;
+    if (dense_only || g1.n == 0 || g2.n == 0) return;
+    double m[9], mx = 0.0;
+    for (int k = 0; k < 9; ++k) {
+        m[k] = (double)g.m[k];
+        if (!std::isfinite(m[k])) return;
+        mx = std::max(mx, std::fabs(m[k]));
+    }
+    if (!(mx > 1e-12) || !(mx < 1e12) || !std::isfinite(g.max_residual) || !(g.max_residual >= 0.f)) return;
+    const double c1[4][2] = {{g1.x0, g1.y0}, {g1.bx1, g1.y0}, {g1.x0, g1.by1}, {g1.bx1, g1.by1}};
+    const double c2[4][2] = {{g2.x0, g2.y0}, {g2.bx1, g2.y0}, {g2.x0, g2.by1}, {g2.bx1, g2.by1}};
+    for (int k = 0; k < 4; ++k)
+        if (std::fabs(c1[k][0]) > 1e7 || std::fabs(c1[k][1]) > 1e7 || std::fabs(c2[k][0]) > 1e7 || std::fabs(c2[k][1]) > 1e7) return;
+    if (g.kind == kGuidedF) {
+        // |F^T x2|_12^2 and |F x1|_12^2 are convex in the point: their maxima over a box are at its corners
+        for (int k = 0; k < 4; ++k) {
+            const double u0 = m[0] * c2[k][0] + m[3] * c2[k][1] + m[6], u1 = m[1] * c2[k][0] + m[4] * c2[k][1] + m[7];
+            const double v0 = m[0] * c1[k][0] + m[1] * c1[k][1] + m[2], v1 = m[3] * c1[k][0] + m[4] * c1[k][1] + m[5];
+            g.bound[0] = std::max(g.bound[0], u0 * u0 + u1 * u1);
+            g.bound[1] = std::max(g.bound[1], v0 * v0 + v1 * v1);
+        }
+        // a little room for the filter's float32 rounding of these terms
+        g.bound[0] *= 1.001;
+        g.bound[1] *= 1.001;
+        if (!(g.bound[0] < 1e30) || !(g.bound[1] < 1e30)) return;
+        g.grid_ok = 1;
+        return;
+    }
+    // H: the projective division must keep one sign, well away from zero, over image 1's keypoint box (then the
+    // filter never divides by zero and the points H maps into a box are the H^-1 image of that box)
+    bool pos = false, neg = false;
+    for (int k = 0; k < 4; ++k) {
+        const double w = m[6] * c1[k][0] + m[7] * c1[k][1] + m[8];
+        const double wmag = std::fabs(m[6] * c1[k][0]) + std::fabs(m[7] * c1[k][1]) + std::fabs(m[8]);
+        if (!(std::fabs(w) > 1e-3 * wmag) || !(wmag > 1e-30)) return;
+        pos |= w > 0.0;
+        neg |= w < 0.0;
+    }
+    if (pos && neg) return;
+    const double det = m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6]);
+    if (!(std::fabs(det) > 1e-9 * mx * mx * mx)) return;
+    const double adj[9] = {m[4] * m[8] - m[5] * m[7], m[2] * m[7] - m[1] * m[8], m[1] * m[5] - m[2] * m[4],
+                           m[5] * m[6] - m[3] * m[8], m[0] * m[8] - m[2] * m[6], m[2] * m[3] - m[0] * m[5],
+                           m[3] * m[7] - m[4] * m[6], m[1] * m[6] - m[0] * m[7], m[0] * m[4] - m[1] * m[3]};
+    for (int k = 0; k < 9; ++k) {
+        g.minv[k] = adj[k] / det;
+        if (!std::isfinite(g.minv[k])) return;
+    }
+    g.grid_ok = 1;
+}
+
 // amc_match_pairs, and with `geoms` != nullptr guided matching (every pair then runs the dot4
 // kernel with the pair's float32 filter; geoms[p] must have a configuration COLMAP guides on)
 // keep_off != nullptr: the matches also stay on the device (c->d_keep) and keep_off[p] receives the position
@@ -458,6 +522,7 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
                         "descriptors uploaded", i);
     }
     std::vector<GuidedDev> h_guided;
+    const bool guided_dense_only = std::getenv("AMC_GUIDED_DENSE") != nullptr;  // (test hook: the dense kernel for every pair)
     if (geoms) {
         h_guided.resize(npairs);
         for (size_t i = 0; i < npairs; ++i) {
@@ -472,12 +537,12 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
             const double* m = g.kind == kGuidedF ? geoms[i].F : geoms[i].H;
             for (int k = 0; k < 9; ++k) g.m[k] = (float)m[k];
             g.max_residual = (float)(max_error * max_error);
-            g.pad_ = 0.f;
             const Slot& a = c->slots[slot1[i]];
             const Slot& b = c->slots[slot2[i]];
             if (!a.kp || !b.kp || a.kp_rows < a.dev.rows || b.kp_rows < b.dev.rows)
                 return fail(AMC_E_STATE, "amc_match_guided_pairs: pair %zu: float32 keypoints (one per descriptor) "
                             "must be uploaded for both images", i);
+            guided_grid_setup(g, a.grid, b.grid, guided_dense_only);
         }
     }
     HIPCHK(hipSetDevice(c->device));
@@ -490,6 +555,11 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
         if (!t.empty())
             HIPCHK(hipMemcpy(c->d_imgs.p, t.data(), t.size() * sizeof(ImageDev),
                              hipMemcpyHostToDevice));
+        HIPCHK(c->d_grids.ensure(c->slots.size()));
+        std::vector<GridDev> gt(c->slots.size());
+        for (size_t i = 0; i < gt.size(); ++i) gt[i] = c->slots[i].grid;
+        if (!gt.empty())
+            HIPCHK(hipMemcpy(c->d_grids.p, gt.data(), gt.size() * sizeof(GridDev), hipMemcpyHostToDevice));
         c->table_dirty = false;
     }
 
@@ -504,7 +574,7 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
     const float max_ratio_f = (float)o.max_ratio;
     const size_t mfma_max_cols = kSelectMaxCols;  // cross-check candidate bitmap (image 2 rows)
 
-    uint64_t num_dist = 0, n_mfma = 0, n_dot4 = 0;
+    uint64_t num_dist = 0, n_mfma = 0, n_dot4 = 0, n_grid = 0;
     double kernel_ms = 0.0, cross_ms = 0.0;
     uint32_t kernel_launches = 0;
     HIPCHK(hipEventRecord(c->ev[0], st));
@@ -535,7 +605,7 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
     //   scatter(k)     wait for the matches, append them to the result                         (device runs k+1)
     struct Batch {
         size_t begin = 0, end = 0, nb = 0, top_rows = 0, top_cols = 0, cap = 0;
-        size_t row_off = 0, nwork = 0, nord = 0;
+        size_t row_off = 0, nwork = 0, nord = 0, nwork_grid = 0;
         int set = 0;
         uint32_t total = 0;
         bool grouped_resolve = true;
@@ -611,7 +681,7 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
             } else {
                 nwork += (x.dev.rows + 63) / 64;
                 if (o.cross_check) nwork += (y.dev.rows + 63) / 64;
-                ++n_dot4;
+                if (geoms && h_guided[begin + i].grid_ok) ++n_grid; else ++n_dot4;
             }
         }
         // mfma queue order: group by image 2 so co-resident workgroups stream the same B
@@ -629,19 +699,25 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
                 return px.slot1 != py.slot1 ? px.slot1 < py.slot1 : px.slot2 < py.slot2;
             });
         }
+        b.nwork_grid = 0;
         if (nwork) {
             if (!hc(c->h_work[k].ensure(nwork), "pinned work")) return false;
             size_t w = 0;
-            for (size_t i = 0; i < nb; ++i) {
-                if (hp[i].mode) continue;
-                const Slot& x = c->slots[slot1[begin + i]];
-                const Slot& y = c->slots[slot2[begin + i]];
-                if (x.dev.rows == 0 || y.dev.rows == 0) continue;
-                for (uint32_t rb = 0; rb < (x.dev.rows + 63) / 64; ++rb)
-                    c->h_work[k].p[w++] = Dot4Work{(uint32_t)i, 0u, rb};
-                if (o.cross_check)
-                    for (uint32_t rb = 0; rb < (y.dev.rows + 63) / 64; ++rb)
-                        c->h_work[k].p[w++] = Dot4Work{(uint32_t)i, 1u, rb};
+            // guided pairs the candidate-generation kernel takes come first: one launch per kernel over its part
+            for (int pass = geoms ? 0 : 1; pass < 2; ++pass) {
+                for (size_t i = 0; i < nb; ++i) {
+                    if (hp[i].mode) continue;
+                    if (geoms && (h_guided[begin + i].grid_ok != 0) != (pass == 0)) continue;
+                    const Slot& x = c->slots[slot1[begin + i]];
+                    const Slot& y = c->slots[slot2[begin + i]];
+                    if (x.dev.rows == 0 || y.dev.rows == 0) continue;
+                    for (uint32_t rb = 0; rb < (x.dev.rows + 63) / 64; ++rb)
+                        c->h_work[k].p[w++] = Dot4Work{(uint32_t)i, 0u, rb};
+                    if (o.cross_check)
+                        for (uint32_t rb = 0; rb < (y.dev.rows + 63) / 64; ++rb)
+                            c->h_work[k].p[w++] = Dot4Work{(uint32_t)i, 1u, rb};
+                }
+                if (pass == 0) b.nwork_grid = w;
             }
         }
         b.row_off = row_off;
@@ -690,11 +766,14 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
             launch_match_mfma(0, c->d_imgs.p, c->d_pairs.p, c->d_order.p, (uint32_t)nord,
                               c->d_scalars + 1, c->d_cand_cnt.p, c->d_candbuf.p, c->d_rowbuf.p,
                               c->d_accmask.p, c->d_lut, fp, st);
-        if (nwork)
-            launch_match_dot4(c->d_imgs.p, c->d_pairs.p, c->d_work.p, (uint32_t)nwork,
+        if (b.nwork_grid)
+            launch_match_guided_grid(c->d_imgs.p, c->d_grids.p, c->d_pairs.p, c->d_work.p, (uint32_t)b.nwork_grid,
+                                     c->d_rowbuf.p, c->d_colbuf.p, c->d_guided.p, st);
+        if (nwork > b.nwork_grid)
+            launch_match_dot4(c->d_imgs.p, c->d_pairs.p, c->d_work.p + b.nwork_grid, (uint32_t)(nwork - b.nwork_grid),
                               c->d_rowbuf.p, c->d_colbuf.p, geoms ? c->d_guided.p : nullptr, st);
         (void)hipEventRecord(c->bev[k][1], st);
-        kernel_launches += (nord ? 1 : 0) + (nwork ? 1 : 0);
+        kernel_launches += (nord ? 1 : 0) + (b.nwork_grid ? 1 : 0) + (nwork > b.nwork_grid ? 1 : 0);
         if (nord)  // tile -> exact index for the accepted rows
             launch_resolve_index(0, c->d_imgs.p, c->d_pairs.p, (uint32_t)nb, c->d_rowbuf.p, c->d_accmask.p, c->d_lut,
                                  fp, c->d_cand_cnt.p, c->d_candbuf.p, c->d_scalars + 3, b.grouped_resolve, st);
@@ -846,6 +925,7 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
     out->num_distances = num_dist;
     out->pairs_mfma = n_mfma;
     out->pairs_dot4 = n_dot4;
+    out->pairs_guided_grid = n_grid;
     out->device_ms = total_ms;
     out->match_kernel_ms = kernel_ms;
     out->match_kernel_launches = kernel_launches;
@@ -907,6 +987,56 @@ void amc_tvg_opts_default(amc_tvg_opts* o) {
     o->ransac.max_num_trials = 10000;
 }
 
+// Guided matching's candidate generation (match_guided.hip): bucket the image's keypoints on a kGridDim^2 grid
+// over their bounding box.  No grid (grid.n = 0) when a coordinate is not finite: such pairs take the dense kernel.
+static int build_keypoint_grid(Slot& s, const float* xy, uint32_t rows) {
+    float x0 = xy[0], y0 = xy[1], x1 = xy[0], y1 = xy[1];
+    for (uint32_t i = 0; i < rows; ++i) {
+        const float x = xy[2 * (size_t)i], y = xy[2 * (size_t)i + 1];
+        if (!std::isfinite(x) || !std::isfinite(y)) return AMC_OK;
+        x0 = std::min(x0, x); x1 = std::max(x1, x);
+        y0 = std::min(y0, y); y1 = std::max(y1, y);
+    }
+    GridDev g{};
+    g.x0 = x0;
+    g.y0 = y0;
+    g.cw = std::max((x1 - x0) / (float)kGridDim, 1e-3f);
+    g.ch = std::max((y1 - y0) / (float)kGridDim, 1e-3f);
+    if (!std::isfinite(g.cw) || !std::isfinite(g.ch)) return AMC_OK;  // (extent overflows float)
+    g.inv_cw = 1.0f / g.cw;
+    g.inv_ch = 1.0f / g.ch;
+    g.bx1 = x1;
+    g.by1 = y1;
+    g.n = rows;
+    const size_t ncell = (size_t)kGridDim * kGridDim;
+    std::vector<uint32_t> cell(rows), start(ncell + 1, 0), sidx(rows);
+    for (uint32_t i = 0; i < rows; ++i) {
+        const int gx = grid_cell(xy[2 * (size_t)i], g.x0, g.inv_cw), gy = grid_cell(xy[2 * (size_t)i + 1], g.y0, g.inv_ch);
+        cell[i] = (uint32_t)(gy * kGridDim + gx);
+        ++start[cell[i] + 1];
+    }
+    for (size_t k = 0; k < ncell; ++k) start[k + 1] += start[k];
+    std::vector<uint32_t> cur(start.begin(), start.end() - 1);
+    for (uint32_t i = 0; i < rows; ++i) sidx[cur[cell[i]]++] = i;
+    std::vector<float> sxy((size_t)rows * 2);
+    for (uint32_t k = 0; k < rows; ++k) {
+        sxy[2 * (size_t)k] = xy[2 * (size_t)sidx[k]];
+        sxy[2 * (size_t)k + 1] = xy[2 * (size_t)sidx[k] + 1];
+    }
+    const size_t b_xy = sxy.size() * sizeof(float), b_idx = sidx.size() * sizeof(uint32_t), b_st = start.size() * sizeof(uint32_t);
+    hipError_t e = hipMalloc(&s.grid_base, b_xy + b_idx + b_st);
+    if (e != hipSuccess) return fail(AMC_E_NOMEM, "amc_upload_keypoints: hipMalloc (grid): %s", hipGetErrorString(e));
+    char* base = static_cast<char*>(s.grid_base);
+    HIPCHK(hipMemcpy(base, sxy.data(), b_xy, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(base + b_xy, sidx.data(), b_idx, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(base + b_xy + b_idx, start.data(), b_st, hipMemcpyHostToDevice));
+    g.sxy = reinterpret_cast<const float*>(base);
+    g.sidx = reinterpret_cast<const uint32_t*>(base + b_xy);
+    g.cell_start = reinterpret_cast<const uint32_t*>(base + b_xy + b_idx);
+    s.grid = g;
+    return AMC_OK;
+}
+
 int amc_upload_keypoints(amc_ctx* c, uint32_t slot, const float* xy, uint32_t rows,
                          uint32_t stride_floats) {
     if (!c) return fail(AMC_E_INVALID, "amc_upload_keypoints: ctx is NULL");
@@ -916,11 +1046,14 @@ int amc_upload_keypoints(amc_ctx* c, uint32_t slot, const float* xy, uint32_t ro
         return fail(AMC_E_INVALID, "amc_upload_keypoints: need x,y columns (stride %u) and data", stride_floats);
     HIPCHK(hipSetDevice(c->device));
     Slot& s = c->slots[slot];
-    if (s.kp || s.kp64 || s.kpn) {
+    if (s.kp || s.kp64 || s.kpn || s.grid_base) {
         HIPCHK(hipStreamSynchronize(c->stream));
         if (s.kp) (void)hipFree(s.kp);
         if (s.kp64) (void)hipFree(s.kp64);
         if (s.kpn) (void)hipFree(s.kpn);
+        if (s.grid_base) (void)hipFree(s.grid_base);
+        s.grid_base = nullptr;
+        s.grid = GridDev{};
         s.kp = nullptr;
         s.kp64 = nullptr;
         s.kpn = nullptr;
@@ -946,7 +1079,7 @@ int amc_upload_keypoints(amc_ctx* c, uint32_t slot, const float* xy, uint32_t ro
     s.dev.kp = s.kp;  // guided matching reads the float32 keypoints from the image table
     s.dev.kp_rows = rows;
     c->table_dirty = true;
-    return AMC_OK;
+    return build_keypoint_grid(s, packed.data(), rows);
 }
 
 int amc_upload_points_f64(amc_ctx* c, uint32_t slot, const double* xy, uint32_t rows) {
@@ -956,11 +1089,14 @@ int amc_upload_points_f64(amc_ctx* c, uint32_t slot, const double* xy, uint32_t 
     if (rows > 0 && !xy) return fail(AMC_E_INVALID, "amc_upload_points_f64: NULL data");
     HIPCHK(hipSetDevice(c->device));
     Slot& s = c->slots[slot];
-    if (s.kp || s.kp64 || s.kpn) {
+    if (s.kp || s.kp64 || s.kpn || s.grid_base) {
         HIPCHK(hipStreamSynchronize(c->stream));
         if (s.kp) (void)hipFree(s.kp);
         if (s.kp64) (void)hipFree(s.kp64);
         if (s.kpn) (void)hipFree(s.kpn);
+        if (s.grid_base) (void)hipFree(s.grid_base);
+        s.grid_base = nullptr;
+        s.grid = GridDev{};
         s.kp = nullptr;
         s.kp64 = nullptr;
         s.kpn = nullptr;

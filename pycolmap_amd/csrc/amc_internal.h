@@ -37,8 +37,57 @@ struct GuidedDev {
     int32_t kind;         // kGuidedF: Sampson error under F; kGuidedH: forward transfer error under H
     float max_residual;   // (float)(max_error * max_error)
     float m[9];           // F or H cast to float, row-major
-    float pad_;
+    int32_t grid_ok;      // the candidate-generation kernel may run this pair (match_guided.hip), else the dense one
+    // candidate generation only (doubles of the float model above):
+    double bound[2];      // F: [0] max |F^T x2|_12^2 over image 2's keypoint box, [1] max |F x1|_12^2 over image 1's
+    double minv[9];       // H: inverse of the float model, row-major
 };
+
+// Guided matching by candidate generation: an image's float32 keypoints bucketed on a kGridDim x kGridDim grid
+// over their bounding box (built once per upload, amc_upload_keypoints).  Cell (gx, gy) has id gy * kGridDim + gx;
+// cell_start is the CSR of the keypoints sorted by cell id, so the keypoints of cells gx0..gx1 of one grid row
+// are one contiguous range of sxy / sidx.
+constexpr int kGridDim = 64;
+struct GridDev {
+    const float* sxy;            // n x 2: keypoints in cell order
+    const uint32_t* sidx;        // n: their original indices
+    const uint32_t* cell_start;  // kGridDim^2 + 1
+    float x0, y0, inv_cw, inv_ch;    // cell of (x, y) = clamp(floor((x - x0) * inv_cw)), clamp(floor((y - y0) * inv_ch))
+    float cw, ch;
+    float bx1, by1;              // bounding box is [x0, bx1] x [y0, by1]
+    uint32_t n;                  // keypoints on the grid (0: no grid - non-finite coordinates or no keypoints)
+    uint32_t pad_;
+};
+// the cell coordinate of v along one axis: the same float operations on the host (grid build) and in the kernel
+// (range lookup), monotone in v, so a coordinate interval maps to the cell interval of its end points
+__host__ __device__ inline int grid_cell(float v, float v0, float inv) {
+    const float t = floorf((v - v0) * inv);
+    return t < 0.f ? 0 : (t > (float)(kGridDim - 1) ? kGridDim - 1 : (int)t);
+}
+
+#if defined(__HIPCC__)
+// Guided matching's float32 filter (SiftCPUFeatureMatcher::MatchGuided; oracle_guided_filter in
+// oracle/match_oracle.c spells out the operation order): true = this (image-1 point, image-2 point)
+// pairing is rejected and its distance is forced to 0.
+__device__ __forceinline__ bool guided_rejects(const GuidedDev& g, float x1, float y1, float x2, float y2) {
+    const float* m = g.m;
+    if (g.kind == kGuidedF) {
+        const float Fx1_0 = m[0] * x1 + m[1] * y1 + m[2] * 1.0f;
+        const float Fx1_1 = m[3] * x1 + m[4] * y1 + m[5] * 1.0f;
+        const float Fx1_2 = m[6] * x1 + m[7] * y1 + m[8] * 1.0f;
+        const float Ftx2_0 = m[0] * x2 + m[3] * y2 + m[6] * 1.0f;
+        const float Ftx2_1 = m[1] * x2 + m[4] * y2 + m[7] * 1.0f;
+        const float x2tFx1 = x2 * Fx1_0 + y2 * Fx1_1 + 1.0f * Fx1_2;
+        return x2tFx1 * x2tFx1 / (Fx1_0 * Fx1_0 + Fx1_1 * Fx1_1 + Ftx2_0 * Ftx2_0 + Ftx2_1 * Ftx2_1) > g.max_residual;
+    }
+    const float Hp_0 = m[0] * x1 + m[1] * y1 + m[2] * 1.0f;
+    const float Hp_1 = m[3] * x1 + m[4] * y1 + m[5] * 1.0f;
+    const float Hp_2 = m[6] * x1 + m[7] * y1 + m[8] * 1.0f;
+    const float e0 = Hp_0 / Hp_2 - x2;
+    const float e1 = Hp_1 / Hp_2 - y2;
+    return e0 * e0 + e1 * e1 > g.max_residual;
+}
+#endif
 
 // One-way top-2 record, the common intermediate of both match kernels (16 B).
 //   best_v   : best dot product (true value), 0 if none > 0
@@ -83,6 +132,9 @@ void launch_prep(const uint8_t* raw, uint8_t* prep, int32_t* rs128, uint32_t row
 // guided: nullptr, or one GuidedDev per PairDev of the batch (entries the filter rejects score 0)
 void launch_match_dot4(const ImageDev* imgs, const PairDev* pairs, const Dot4Work* work,
                        uint32_t nwork, Top2* rowbuf, Top2* colbuf, const GuidedDev* guided, hipStream_t s);
+// guided matching by candidate generation (match_guided.hip): same work items and Top2 output as the dot4 kernel
+void launch_match_guided_grid(const ImageDev* imgs, const GridDev* grids, const PairDev* pairs, const Dot4Work* work,
+                              uint32_t nwork, Top2* rowbuf, Top2* colbuf, const GuidedDev* guided, hipStream_t s);
 
 // mfma: one workgroup per work item, dynamic queue over `order` (pair indices, sorted by the
 // streamed image for L2 reuse).  mode 0: rows of image 1 vs image 2 -> rowbuf + row_off.

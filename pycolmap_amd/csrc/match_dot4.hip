@@ -45,28 +45,6 @@ __device__ __forceinline__ void merge_state(RowState& a, const RowState b) {
     a.sv = max(win_sv, loser_bv);
 }
 
-// Guided matching's float32 filter (SiftCPUFeatureMatcher::MatchGuided; oracle_guided_filter in
-// oracle/match_oracle.c spells out the operation order): true = this (image-1 point, image-2 point)
-// pairing is rejected and its distance is forced to 0.
-__device__ __forceinline__ bool guided_rejects(const GuidedDev& g, float x1, float y1, float x2, float y2) {
-    const float* m = g.m;
-    if (g.kind == kGuidedF) {
-        const float Fx1_0 = m[0] * x1 + m[1] * y1 + m[2] * 1.0f;
-        const float Fx1_1 = m[3] * x1 + m[4] * y1 + m[5] * 1.0f;
-        const float Fx1_2 = m[6] * x1 + m[7] * y1 + m[8] * 1.0f;
-        const float Ftx2_0 = m[0] * x2 + m[3] * y2 + m[6] * 1.0f;
-        const float Ftx2_1 = m[1] * x2 + m[4] * y2 + m[7] * 1.0f;
-        const float x2tFx1 = x2 * Fx1_0 + y2 * Fx1_1 + 1.0f * Fx1_2;
-        return x2tFx1 * x2tFx1 / (Fx1_0 * Fx1_0 + Fx1_1 * Fx1_1 + Ftx2_0 * Ftx2_0 + Ftx2_1 * Ftx2_1) > g.max_residual;
-    }
-    const float Hp_0 = m[0] * x1 + m[1] * y1 + m[2] * 1.0f;
-    const float Hp_1 = m[3] * x1 + m[4] * y1 + m[5] * 1.0f;
-    const float Hp_2 = m[6] * x1 + m[7] * y1 + m[8] * 1.0f;
-    const float e0 = Hp_0 / Hp_2 - x2;
-    const float e1 = Hp_1 / Hp_2 - y2;
-    return e0 * e0 + e1 * e1 > g.max_residual;
-}
-
 template <bool GUIDED>
 __global__ __launch_bounds__(256) void match_dot4_kernel(const ImageDev* __restrict__ imgs,
                                                          const PairDev* __restrict__ pairs,

@@ -40,4 +40,4 @@ def test_no_gpu_means_loud_failure_not_fallback():
 def test_struct_layout_matches_header():
     # amc_match_opts: 2 doubles + 2 int32 = 24 bytes; amc_match_result ends with a pointer
     assert ctypes.sizeof(_capi.MatchOpts) == 24
-    assert ctypes.sizeof(_capi.MatchResult) == 8 * 3 + 8 * 3 + 8 * 3 + 8 + 8
+    assert ctypes.sizeof(_capi.MatchResult) == 8 * 3 + 8 * 4 + 8 * 3 + 8 + 8
