@@ -49,6 +49,9 @@ __device__ __forceinline__ void lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 __device__ __forceinline__ bool finite_d(double v) { return v - v == 0.0; }
+// hardware approximations (relative error ~1e-8): the regions below carry 2 % and a pixel of slack
+__device__ __forceinline__ double arcp(double v) { return __builtin_amdgcn_rcp(v); }
+__device__ __forceinline__ double asqrt(double v) { return __builtin_amdgcn_sqrt(v); }
 
 }  // namespace
 
@@ -67,7 +70,19 @@ __global__ __launch_bounds__(256) void match_guided_grid_kernel(const ImageDev* 
     const ImageDev X = imgs[dir == 0 ? p.slot1 : p.slot2];
     const ImageDev Y = imgs[dir == 0 ? p.slot2 : p.slot1];
     const GridDev G = grids[dir == 0 ? p.slot2 : p.slot1];
-    const GuidedDev gd = guided[w.pair];
+    // the pair's model, field by field with constant indices (a run-time index into the struct would park all of
+    // it - and the filter's nine coefficients with it - in scratch memory)
+    GuidedDev gd;
+    {
+        const GuidedDev* __restrict__ gp = guided + w.pair;
+        gd.kind = gp->kind;
+        gd.max_residual = gp->max_residual;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) gd.m[k] = gp->m[k];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) gd.minv[k] = gp->minv[k];
+    }
+    const double bound = w.dir == 0 ? guided[w.pair].bound[0] : guided[w.pair].bound[1];
     Top2* out = (dir == 0 ? rowbuf + p.row_off : colbuf + p.col_off) + (size_t)w.rb * 64;
 
     const int lane = threadIdx.x & 63;
@@ -119,22 +134,25 @@ __global__ __launch_bounds__(256) void match_guided_grid_kernel(const ImageDev* 
             }
             const double L2 = a * a + b * b;
             // Sampson <= T  =>  (l . q)^2 <= T (|l|^2 + |other|^2) <= T (L2 + bound); one pixel on top
-            const double W = sqrt(T * (L2 + gd.bound[dir])) * 1.02 + sqrt(L2);
+            const double W = asqrt(T * (L2 + bound)) * 1.02 + asqrt(L2);
             if (!(L2 > 1e-30) || !(L2 < 1e30) || !(W < 1e300)) {
                 full = true;
             } else {
                 const double t0 = -(b * ylo + c), t1 = -(b * yhi + c);  // a x in [t - W, t + W]
                 const double lo = fmin(t0, t1) - W, hi = fmax(t0, t1) + W;
-                if (a > 0.0) { xa = lo / a; xb = hi / a; }
-                else if (a < 0.0) { xa = hi / a; xb = lo / a; }
+                const double ia = arcp(a);  // (+-inf for a = +-0; not used then)
+                if (a > 0.0) { xa = lo * ia; xb = hi * ia; }
+                else if (a < 0.0) { xa = hi * ia; xb = lo * ia; }
                 else if (!(lo <= 0.0 && hi >= 0.0)) none = true;
+                if (xa != xa || xb != xb) { xa = -kInf; xb = kInf; }  // 0 * inf of a denormal a: every cell of the row
             }
         } else if (dir == 0) {  // box around hnormalized(H p)
             const double wq = m[6] * px + m[7] * py + m[8];
             const double wmag = fabs(m[6] * px) + fabs(m[7] * py) + fabs(m[8]);
-            const double cx = (m[0] * px + m[1] * py + m[2]) / wq;
-            const double cy = (m[3] * px + m[4] * py + m[5]) / wq;
-            const double r = sqrt(T) * 1.02 + 1.0;
+            const double iw = arcp(wq);
+            const double cx = (m[0] * px + m[1] * py + m[2]) * iw;
+            const double cy = (m[3] * px + m[4] * py + m[5]) * iw;
+            const double r = asqrt(T) * 1.02 + 1.0;
             if (!(fabs(wq) > 1e-4 * wmag) || !(wmag > 1e-30) || !finite_d(cx) || !finite_d(cy) || !(r < 1e300)) {
                 full = true;
             } else if (yhi < cy - r || ylo > cy + r) {
@@ -144,7 +162,7 @@ __global__ __launch_bounds__(256) void match_guided_grid_kernel(const ImageDev* 
                 xb = cx + r;
             }
         } else {  // p is an image-2 point: candidates are the image-1 points H maps into the box around p
-            const double r = sqrt(T) * 1.02 + 1.0;
+            const double r = asqrt(T) * 1.02 + 1.0;
             double xmin = kInf, xmax = -kInf, ymin = kInf, ymax = -kInf;
             bool pos = false, neg = false, bad = !(r < 1e300);
 #pragma unroll
@@ -152,8 +170,9 @@ __global__ __launch_bounds__(256) void match_guided_grid_kernel(const ImageDev* 
                 const double qx = px + ((k & 1) ? r : -r), qy = py + ((k & 2) ? r : -r);
                 const double wk = gd.minv[6] * qx + gd.minv[7] * qy + gd.minv[8];
                 const double wmag = fabs(gd.minv[6] * qx) + fabs(gd.minv[7] * qy) + fabs(gd.minv[8]);
-                const double ux = (gd.minv[0] * qx + gd.minv[1] * qy + gd.minv[2]) / wk;
-                const double uy = (gd.minv[3] * qx + gd.minv[4] * qy + gd.minv[5]) / wk;
+                const double iw = arcp(wk);
+                const double ux = (gd.minv[0] * qx + gd.minv[1] * qy + gd.minv[2]) * iw;
+                const double uy = (gd.minv[3] * qx + gd.minv[4] * qy + gd.minv[5]) * iw;
                 pos |= wk > 0.0;
                 neg |= wk < 0.0;
                 bad |= !(fabs(wk) > 1e-4 * wmag) || !finite_d(ux) || !finite_d(uy);
