@@ -288,6 +288,39 @@ def pipeline_leg(ctx_factory, steps: int, warmup: int, cpu_pairs: int, num_image
         "roofline": fp64_roofline([w * steps for w in vst["work"]], acc["verify_kernel_ms"] * 1e-3, acc["launches"]),
         "scene_generation_s": gen_s, "dtype": "u8 -> int8 MFMA / int32 (match), f64 (verification)",
     }
+    # guided matching (SiftMatchingOptions.guided_matching) of the verified pairs with the models just estimated:
+    # the third stage of the same pipeline when the option is on, by the candidate-generation kernel
+    gi = np.flatnonzero(ver & np.isin(tvg["config"], [2, 3, 4, 5, 6]))
+    if len(gi):
+        g1, g2, gt = s1[gi], s2[gi], tvg[gi]
+        max_error = float(opts.ransac.max_error)
+        ctx.match_guided_pairs(g1, g2, gt, max_error)
+        tg = time.perf_counter()
+        for _ in range(steps):
+            goff, gm, gst = ctx.match_guided_pairs(g1, g2, gt, max_error)
+        gdt = (time.perf_counter() - tg) / steps
+        entries = 2.0 * float(gst["num_distances"])          # both directions of the cross check
+        out["guided"] = {"metric": "guided-matching matrix entries/sec (MatchGuided: geometric filter + top-2 + ratio + cross check)",
+                         "value": entries / gdt, "unit": "entries/s", "pairs": int(len(gi)), "ms_per_step": 1e3 * gdt,
+                         "pairs_by_kernel": {"candidate_generation": gst["pairs_guided_grid"], "dense_filtered_scan": gst["pairs_dot4"]},
+                         "matches_per_pair": float(len(gm)) / len(gi),
+                         "note": "entries = 2 n1 n2 per pair, the size of the matrix MatchGuided scores; the candidate kernel "
+                                 "evaluates the filter on ~4 % and the dot product on ~1 % of them"}
+        if cpu_pairs > 0:
+            sys.path.insert(0, str(ROOT / "tests"))
+            import oracle_lib as o
+            rs = np.random.default_rng(6)
+            pick = np.sort(rs.choice(len(gi), size=min(len(gi), max(cpu_pairs // 8, 2)), replace=False))
+            tg = time.perf_counter()
+            gmis = 0
+            for k in pick:
+                a, b = int(g1[k]), int(g2[k])
+                want = o.match_guided(images[a]["descriptors"], images[a]["keypoints"], images[b]["descriptors"],
+                                      images[b]["keypoints"], gt[k]["config"], gt[k]["F"], gt[k]["H"], max_error)
+                gmis += int(not np.array_equal(gm[int(goff[k]):int(goff[k + 1])], want))
+            out["guided"]["cpu_baseline"] = {"value": 2.0 * feats * feats * len(pick) / (time.perf_counter() - tg), "unit": "entries/s",
+                                             "cores": 1, "kind": "port", "sample": f"{len(pick)} seeded pairs, oracle_match_guided",
+                                             "gpu_vs_oracle_mismatching_pairs": gmis}
     if cpu_pairs > 0:
         # the CPU oracles on the same pairs: a seeded sample of ALL pairs for the rate (most do not overlap, as in
         # the job itself), plus verified pairs only for the parity of the chained result

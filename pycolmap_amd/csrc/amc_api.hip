@@ -156,6 +156,8 @@ struct amc_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
+    hipStream_t copy_stream = nullptr;  // D2H of a batch's matches, beside the next batch's kernels
+    hipEvent_t cev[2] = {nullptr, nullptr};  // batch k's matches are in place in d_keep
     std::vector<Slot> slots;
     bool table_dirty = true;
     DevBuf<ImageDev> d_imgs;
@@ -252,6 +254,13 @@ int amc_ctx_create(int device_id, amc_ctx** out) {
         return fail(AMC_E_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
     }
     c->stream = c->own_stream;
+    e = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        (void)hipStreamDestroy(c->own_stream);
+        delete c;
+        return fail(AMC_E_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
+    }
+    for (auto& ev : c->cev) (void)hipEventCreateWithFlags(&ev, hipEventDisableTiming);
     for (auto& ev : c->ev) (void)hipEventCreate(&ev);
     for (auto& set : c->bev)
         for (auto& ev : set) (void)hipEventCreate(&ev);
@@ -313,6 +322,9 @@ void amc_ctx_destroy(amc_ctx* c) {
     for (auto& set : c->bev)
         for (auto& ev : set)
             if (ev) (void)hipEventDestroy(ev);
+    for (auto& ev : c->cev)
+        if (ev) (void)hipEventDestroy(ev);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -842,12 +854,16 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
                     !hc(hipMemcpyAsync(bigger.p, c->d_keep.p, 2 * keep_used * sizeof(uint32_t), hipMemcpyDeviceToDevice, st),
                         "move resident match table"))
                     return false;
-                if (!hc(hipStreamSynchronize(st), "sync before freeing the old resident table")) return false;
+                if (!hc(hipStreamSynchronize(st), "sync before freeing the old resident table") ||
+                    !hc(hipStreamSynchronize(c->copy_stream), "sync before freeing the old resident table"))
+                    return false;
                 c->d_keep.release();
                 c->d_keep = bigger;
             }
             if (need > priv->matches.cap) {  // grow the result buffer (first calls only: the pool keeps it)
-                if (!hc(hipStreamSynchronize(st), "sync before growing the result buffer")) return false;
+                if (!hc(hipStreamSynchronize(st), "sync before growing the result buffer") ||
+                    !hc(hipStreamSynchronize(c->copy_stream), "sync before growing the result buffer"))
+                    return false;
                 PinBuf<uint32_t> bigger;
                 if (!hc(bigger.ensure(std::max(need, 2 * priv->matches.cap)), "pinned result")) return false;
                 if (keep_used) std::memcpy(bigger.p, priv->matches.p, 2 * keep_used * sizeof(uint32_t));
@@ -858,12 +874,16 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
                 !hc(hipMemcpyAsync(c->d_csr.p, c->h_csr[k].p, b.nb * sizeof(uint64_t), hipMemcpyHostToDevice, st), "H2D csr"))
                 return false;
             launch_reorder_matches(c->d_pair_off.p, c->d_pair_cnt.p, c->d_csr.p, (uint32_t)b.nb, c->d_matches.p, c->d_keep.p, st);
-            if (!hc(hipGetLastError(), "reorder launch") ||
+            // the copy to the host runs on its own stream, beside the next batch's kernels (which write d_matches
+            // and, later, d_keep beyond this batch - never what is being copied)
+            if (!hc(hipGetLastError(), "reorder launch") || !hc(hipEventRecord(c->cev[k], st), "event record") ||
+                !hc(hipStreamWaitEvent(c->copy_stream, c->cev[k], 0), "stream wait") ||
                 !hc(hipMemcpyAsync(priv->matches.p + 2 * keep_used, c->d_keep.p + 2 * keep_used,
-                                   (size_t)b.total * 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st), "D2H matches"))
+                                   (size_t)b.total * 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->copy_stream), "D2H matches"))
                 return false;
+            keep_used += b.total;
+            return hc(hipEventRecord(c->bev[k][4], c->copy_stream), "event record");
         }
-        keep_used += b.total;
         return hc(hipEventRecord(c->bev[k][4], st), "event record");
     };
     // append the batch's matches to the result CSR (pairs keep the caller's order)
@@ -908,11 +928,19 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
             cur = next;
         }
         if (!ok && rc == AMC_OK) rc = fail(AMC_E_HIP, "amc_match_pairs: batch failed");
-        if (rc != AMC_OK) (void)hipStreamSynchronize(st);  // nothing of this call stays in flight
+        if (rc != AMC_OK) {  // nothing of this call stays in flight
+            (void)hipStreamSynchronize(st);
+            (void)hipStreamSynchronize(c->copy_stream);
+        }
     }
     if (rc != AMC_OK) {
         delete priv;
         return rc;
+    }
+    // device_ms ends with the last result byte on the host: the stream joins the copy stream first
+    if (npairs > 0) {
+        HIPCHK(hipEventRecord(c->cev[0], c->copy_stream));
+        HIPCHK(hipStreamWaitEvent(st, c->cev[0], 0));
     }
     HIPCHK(hipEventRecord(c->ev[1], st));
     HIPCHK(hipEventSynchronize(c->ev[1]));

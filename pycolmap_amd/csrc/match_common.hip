@@ -256,6 +256,8 @@ __global__ __launch_bounds__(256) void resolve_index_grouped_kernel(
     __shared__ uint32_t s_hist[kResolveMaxTiles];
     __shared__ uint32_t s_wsum[4];
     __shared__ uint32_t s_count;
+    __shared__ uint32_t s_brow[4][32], s_btile[4][32];  // the batch's rows and tiles, by wave
+    __shared__ uint4 s_x[4][256];                       // and their X rows (32 x 128 bytes)
     const PairDev p = pairs[blockIdx.x];
     if (p.mode == 0) return;  // dot4 pairs carry exact indices already
     const ImageDev X = imgs[side == 0 ? p.slot1 : p.slot2];
@@ -274,26 +276,49 @@ __global__ __launch_bounds__(256) void resolve_index_grouped_kernel(
         if (tid == 0) s_count = 0;
         for (uint32_t k = tid; k < kResolveMaxTiles; k += 256) s_hist[k] = 0;
         __syncthreads();
-        // ---- accepted rows of the chunk and the histogram of their tiles
-        for (uint32_t e = chunk0 + tid; e < chunk_end; e += 256) {
-            bool acc;
-            uint32_t tile;
+        // ---- accepted rows of the chunk and the histogram of their tiles (four rows per thread and round: their table
+        // reads are independent and in flight together)
+        for (uint32_t e0 = chunk0 + tid; e0 < chunk_end; e0 += 4 * 256) {
+            bool acc[4];
+            uint32_t tile[4];
             if (side == 0) {
-                acc = (amask[e >> 5] >> (e & 31)) & 1u;
-                tile = acc ? tab[e].best_idx : 0u;
+                uint32_t aw[4], bi[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t e = min(e0 + (uint32_t)u * 256, chunk_end - 1);
+                    aw[u] = amask[e >> 5];
+                    bi[u] = tab[e].best_idx;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t e = e0 + (uint32_t)u * 256;
+                    acc[u] = e < chunk_end && ((aw[u] >> (e & 31)) & 1u);
+                    tile[u] = bi[u];
+                }
             } else {
-                const Top2 t = tab[list[e]];
-                acc = one_way_accepts(t, lut, fp.max_ratio, fp.max_distance);
-                tile = t.best_idx;
+                uint32_t le[4];
+                Top2 tt[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) le[u] = list[min(e0 + (uint32_t)u * 256, chunk_end - 1)];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) tt[u] = tab[le[u]];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    acc[u] = e0 + (uint32_t)u * 256 < chunk_end && one_way_accepts(tt[u], lut, fp.max_ratio, fp.max_distance);
+                    tile[u] = tt[u].best_idx;
+                }
             }
-            if (acc) {
-                if (tile >= ntiles) {  // cannot happen (the scan only reports tiles it visited): counted, row left unresolved
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (!acc[u]) continue;
+                const uint32_t e = e0 + (uint32_t)u * 256;
+                if (tile[u] >= ntiles) {  // cannot happen (the scan only reports tiles it visited): counted, row left unresolved
                     atomicAdd(err_count, 1u);
                     continue;
                 }
                 const uint32_t pos = atomicAdd(&s_count, 1u);
-                s_list[pos] = (tile << 12) | (e - chunk0);
-                atomicAdd(&s_hist[tile], 1u);
+                s_list[pos] = (tile[u] << 12) | (e - chunk0);
+                atomicAdd(&s_hist[tile[u]], 1u);
             }
         }
         __syncthreads();
@@ -321,73 +346,122 @@ __global__ __launch_bounds__(256) void resolve_index_grouped_kernel(
             s_sorted[atomicAdd(&s_hist[v >> 12], 1u)] = v;
         }
         __syncthreads();
-        // ---- each wave walks a contiguous quarter of the sorted list, the tile's Y rows stay in registers
+        // ---- each wave walks a contiguous quarter of the sorted list in batches of 32 rows.  Lane (j, h) keeps Y row j
+        // of ITS half's current tile in registers (all 128 bytes); half h handles rows h*16 .. h*16+15 of the batch, one
+        // per step, every lane of the half loading the same X row (one request).  A step is 8 loads + 32 dot4 + one
+        // LDS store of the lane's dot product; everything that needs the 32 values of a row together - first index
+        // equal to the best, largest of the others, the acceptance test with its LUT read, the table update - is done
+        // after the batch by the row's owner lane, 32 rows in parallel.  (The first grouped version did that per row:
+        // a 32-lane reduction through seven LDS permutes and a lane-0 tail with three dependent memory round trips,
+        // ~3,600 cycles per row.)
+        uint32_t* part = s_list + wid * 1024;  // [32 rows][32], row r rotated by r: free of bank conflicts both ways
+        uint4* xs = s_x[wid];
         const uint32_t kb = (uint32_t)(((uint64_t)cnt * wid) / 4), ke = (uint32_t)(((uint64_t)cnt * (wid + 1)) / 4);
         uint32_t cur_tile = 0xFFFFFFFFu;
-        uint4 yv[4] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
-        uint32_t jj = 0;
-        // kU rows in flight: a row's table entry and its X bytes are two dependent trips to L2 / HBM, and with one row
-        // at a time the wave just waits for them (the first version of this kernel was latency bound, no faster
-        // than the per-row kernel)
-        constexpr int kU = 4;
-        for (uint32_t k0 = kb; k0 < ke; k0 += kU) {
-            uint32_t vv[kU], rr[kU];
-            Top2 tt[kU];
-            uint4 xa[kU][4];
+        uint4 yv[8];
 #pragma unroll
-            for (int u = 0; u < kU; ++u) {
-                const uint32_t k = min(k0 + (uint32_t)u, ke - 1);  // the tail repeats its last row (never processed twice)
-                vv[u] = s_sorted[k];
-                const uint32_t e = chunk0 + (vv[u] & 4095u);
-                rr[u] = side == 0 ? e : list[e];
+        for (int q = 0; q < 8; ++q) yv[q] = make_uint4(0, 0, 0, 0);
+        for (uint32_t b0 = kb; b0 < ke; b0 += 32) {
+            const uint32_t nb = min(32u, ke - b0);
+            uint32_t my_row = 0, my_e = 0, my_tile = 0;
+            Top2 my_t{0u, 0u, 0u, 0u};
+            if (lane < nb) {
+                const uint32_t v = s_sorted[b0 + lane];
+                my_tile = v >> 12;
+                my_e = chunk0 + (v & 4095u);
+                my_row = side == 0 ? my_e : list[my_e];
+                my_t = tab[my_row];
+                s_brow[wid][lane] = my_row;
+                s_btile[wid][lane] = my_tile;
             }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // the batch's X rows -> LDS with one round of independent loads (lane = 16-byte piece; 4 KB per wave)
+            {
+                uint4 piece[4];
 #pragma unroll
-            for (int u = 0; u < kU; ++u) {
-                tt[u] = tab[rr[u]];
-                const uint4* xp = reinterpret_cast<const uint4*>(X.raw + (size_t)rr[u] * kDim + half * 64);
+                for (int q = 0; q < 4; ++q) {
+                    const uint32_t idx = (uint32_t)q * 64 + lane, r = idx >> 3;
+                    const uint32_t rowq = s_brow[wid][r < nb ? r : 0];
+                    piece[q] = *reinterpret_cast<const uint4*>(X.raw + (size_t)rowq * kDim + (idx & 7u) * 16);
+                }
 #pragma unroll
-                for (int q = 0; q < 4; ++q) xa[u][q] = xp[q];
+                for (int q = 0; q < 4; ++q) xs[(uint32_t)q * 64 + lane] = piece[q];
             }
-#pragma unroll
-            for (int u = 0; u < kU; ++u) {
-                if (k0 + (uint32_t)u >= ke) break;
-                const uint32_t tile = vv[u] >> 12, e = chunk0 + (vv[u] & 4095u), row = rr[u];
-                const Top2 t = tt[u];
-                if (tile != cur_tile) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            {   // first step's Y tile
+                const uint32_t r = half * 16;
+                const uint32_t tile = s_btile[wid][r < nb ? r : 0];
+                if (r < nb && tile != cur_tile) {
                     cur_tile = tile;
-                    jj = tile * 32 + l31;
-                    const uint4* yp = reinterpret_cast<const uint4*>(Y.raw + (size_t)jj * kDim + half * 64);
+                    const uint4* yp = reinterpret_cast<const uint4*>(Y.raw + (size_t)(tile * 32 + l31) * kDim);
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) yv[q] = yp[q];  // jj < rows_pad: padding rows are zero
+                    for (int q = 0; q < 8; ++q) yv[q] = yp[q];  // tile * 32 + l31 < rows_pad: padding rows are zero
+                }
+            }
+            for (uint32_t st = 0; st < 16; ++st) {
+                const uint32_t r = half * 16 + st;
+                const bool live = r < nb;
+                // the next step's Y tile, if it is another one, while this step is multiplied
+                const uint32_t rn = r + 1;
+                const bool live_n = st + 1 < 16 && rn < nb;
+                const uint32_t tile_n = s_btile[wid][live_n ? rn : 0];
+                const bool change = live_n && tile_n != cur_tile;
+                uint4 yn[8];
+                if (change) {
+                    const uint4* yp = reinterpret_cast<const uint4*>(Y.raw + (size_t)(tile_n * 32 + l31) * kDim);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) yn[q] = yp[q];
                 }
                 uint32_t sum = 0;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const uint4 a = xa[u][q], cc = yv[q];
-                    sum = __builtin_amdgcn_udot4(a.x, cc.x, sum, false);
-                    sum = __builtin_amdgcn_udot4(a.y, cc.y, sum, false);
-                    sum = __builtin_amdgcn_udot4(a.z, cc.z, sum, false);
-                    sum = __builtin_amdgcn_udot4(a.w, cc.w, sum, false);
+                for (int q = 0; q < 8; ++q) {
+                    const uint4 xa = xs[(live ? r : 0u) * 8 + (uint32_t)q];
+                    sum = __builtin_amdgcn_udot4(xa.x, yv[q].x, sum, false);
+                    sum = __builtin_amdgcn_udot4(xa.y, yv[q].y, sum, false);
+                    sum = __builtin_amdgcn_udot4(xa.z, yv[q].z, sum, false);
+                    sum = __builtin_amdgcn_udot4(xa.w, yv[q].w, sum, false);
                 }
-                sum += __shfl_xor(sum, 32);
-                const bool eq = (sum == t.best_v) && (jj < Y.rows);
-                const uint32_t m = (uint32_t)(__ballot(eq) & 0xFFFFFFFFull);
-                const uint32_t first = m ? (uint32_t)(__ffs(m) - 1) : 0xFFFFFFFFu;
-                uint32_t sw = (jj < Y.rows && l31 != first) ? sum : 0u;
+                if (live) part[r * 32 + ((l31 + r) & 31u)] = sum;
+                if (change) {
+                    cur_tile = tile_n;
 #pragma unroll
-                for (int d = 16; d >= 1; d >>= 1) sw = max(sw, (uint32_t)__shfl_xor(sw, d));
-                if (lane == 0) {
-                    Top2 w2 = t;
-                    w2.best_idx = m ? tile * 32 + first : 0xFFFFFFFFu;
-                    w2.second_v = max(t.second_v, sw);
-                    tab[row].best_idx = w2.best_idx;
-                    tab[row].second_v = w2.second_v;
-                    if (!m) atomicAdd(err_count, 1u);  // scan and recomputation disagree: a bug
-                    // side 0: narrow the accept bits to the rows that pass with the exact second
-                    if (side == 0 && !one_way_accepts(w2, lut, fp.max_ratio, fp.max_distance))
-                        atomicAnd(&amask[e >> 5], ~(1u << (e & 31)));
+                    for (int q = 0; q < 8; ++q) yv[q] = yn[q];
                 }
             }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (lane < nb) {
+                bool found = false;
+                uint32_t first = 0, sw = 0;
+#pragma unroll 8
+                for (uint32_t jx = 0; jx < 32; ++jx) {
+                    const uint32_t sv = part[lane * 32 + ((jx + lane) & 31u)];
+                    const bool valid = my_tile * 32 + jx < Y.rows;
+                    if (valid && !found && sv == my_t.best_v) {
+                        found = true;
+                        first = jx;
+                    } else if (valid) {
+                        sw = max(sw, sv);
+                    }
+                }
+                Top2 w2 = my_t;
+                w2.best_idx = found ? my_tile * 32 + first : 0xFFFFFFFFu;
+                w2.second_v = max(my_t.second_v, sw);
+                tab[my_row].best_idx = w2.best_idx;
+                tab[my_row].second_v = w2.second_v;
+                if (!found) atomicAdd(err_count, 1u);  // scan and recomputation disagree: a bug
+                // side 0: narrow the accept bits to the rows that pass with the exact second
+                if (side == 0 && !one_way_accepts(w2, lut, fp.max_ratio, fp.max_distance))
+                    atomicAnd(&amask[my_e >> 5], ~(1u << (my_e & 31)));
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
         __syncthreads();
     }
