@@ -748,6 +748,152 @@ __device__ __noinline__ int real_roots10_wave(const double* c_in, double* roots,
     return WaveRootChain<10, 10>::run(c, roots, tmp, lane);
 }
 
+// ---- the 5-point solve of ONE problem by the whole wave (local optimisation) -----------------------
+// e5_build keeps the 10 x 20 constraint matrix of a solve in one lane: 200 live doubles, most of them in scratch
+// memory, and with one problem per wave every lane did the same elimination.  Here the rows are still computed by
+// every lane (same expressions, row by row, so that only one row is live), but lane c < 20 keeps just column c,
+// and the Gauss-Jordan elimination runs on those 20 columns in parallel: per pivot the pivot column is broadcast
+// (ten readlanes), every lane searches the pivot and applies the row swap to its own column, and one multiply and
+// nine multiply-subtracts finish the step.  Every element goes through the operations e5_build applies to it, in
+// the same order: the same bits.  E E^T and its trace sit in `sc` (>= 100 doubles of LDS) between the two passes.
+__device__ __noinline__ void e5_build_wave(const double* nsp, E5Polys& P, lds_f64* sc, int lane) {
+    double e[9][4];
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int d = 0; d < 4; ++d) e[k][d] = nsp[d * 9 + k];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            double a[10], b[10], c[10];
+            e5_mul11(e[3 * i], e[3 * j], a);
+            e5_mul11(e[3 * i + 1], e[3 * j + 1], b);
+            e5_mul11(e[3 * i + 2], e[3 * j + 2], c);
+            if (lane == 0) {
+#pragma unroll
+                for (int t = 0; t < 10; ++t) sc[(3 * i + j) * 10 + t] = (a[t] + b[t]) + c[t];
+            }
+        }
+    wave_lds_sync();
+    if (lane == 0) {
+#pragma unroll
+        for (int t = 0; t < 10; ++t) sc[90 + t] = (sc[t] + sc[40 + t]) + sc[80 + t];
+    }
+    wave_lds_sync();
+    double g[10];  // this lane's column of G
+    auto keep = [&](double& dst, const double (&row)[20]) {
+        double x = row[19];
+#pragma unroll
+        for (int c = 18; c >= 0; --c) x = lane == c ? row[c] : x;
+        dst = x;
+    };
+    {   // det(E) -> row 0
+        double a[10], b[10], d[10], t0[20], t1[20], t2[20], row[20];
+        e5_mul11(e[4], e[8], a); e5_mul11(e[5], e[7], b);
+#pragma unroll
+        for (int i = 0; i < 10; ++i) d[i] = a[i] - b[i];
+        e5_mul21(d, e[0], t0);
+        e5_mul11(e[3], e[8], a); e5_mul11(e[5], e[6], b);
+#pragma unroll
+        for (int i = 0; i < 10; ++i) d[i] = a[i] - b[i];
+        e5_mul21(d, e[1], t1);
+        e5_mul11(e[3], e[7], a); e5_mul11(e[4], e[6], b);
+#pragma unroll
+        for (int i = 0; i < 10; ++i) d[i] = a[i] - b[i];
+        e5_mul21(d, e[2], t2);
+#pragma unroll
+        for (int i = 0; i < 20; ++i) row[i] = (t0[i] - t1[i]) + t2[i];
+        keep(g[0], row);
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            double q[10], acc[20], tmp[20], row[20];
+#pragma unroll
+            for (int t = 0; t < 10; ++t) q[t] = sc[(3 * i) * 10 + t];
+            e5_mul21(q, e[j], acc);
+#pragma unroll
+            for (int t = 0; t < 10; ++t) q[t] = sc[(3 * i + 1) * 10 + t];
+            e5_mul21(q, e[3 + j], tmp);
+#pragma unroll
+            for (int t = 0; t < 20; ++t) acc[t] = acc[t] + tmp[t];
+#pragma unroll
+            for (int t = 0; t < 10; ++t) q[t] = sc[(3 * i + 2) * 10 + t];
+            e5_mul21(q, e[6 + j], tmp);
+#pragma unroll
+            for (int t = 0; t < 20; ++t) acc[t] = acc[t] + tmp[t];
+#pragma unroll
+            for (int t = 0; t < 10; ++t) q[t] = sc[90 + t];
+            e5_mul21(q, e[3 * i + j], tmp);
+#pragma unroll
+            for (int t = 0; t < 20; ++t) row[t] = acc[t] * 2.0 - tmp[t];
+            keep(g[1 + 3 * i + j], row);
+        }
+    // Gauss-Jordan with partial pivoting on the left 10 x 10 block, one column per lane
+#pragma unroll
+    for (int col = 0; col < 10; ++col) {
+        double bc[10];  // column `col` as it stands, wave-uniform
+#pragma unroll
+        for (int r = 0; r < 10; ++r) bc[r] = readlane_f64(g[r], col);
+        int piv = col;
+        double pv = dabs(bc[col]);
+#pragma unroll
+        for (int r = col + 1; r < 10; ++r)
+            if (dabs(bc[r]) > pv) { pv = dabs(bc[r]); piv = r; }
+#pragma unroll
+        for (int r = col + 1; r < 10; ++r) {
+            const bool sw = piv == r;
+            const double t = g[col], u = bc[col];
+            g[col] = sw ? g[r] : g[col];
+            g[r] = sw ? t : g[r];
+            bc[col] = sw ? bc[r] : bc[col];
+            bc[r] = sw ? u : bc[r];
+        }
+        const double inv = 1.0 / bc[col];
+        g[col] = g[col] * inv;
+#pragma unroll
+        for (int r = 0; r < 10; ++r) {
+            if (r == col) continue;
+            g[r] = g[r] - bc[r] * g[col];
+        }
+    }
+    // rows 4..9 of columns 10..19 -> every lane
+    wave_lds_sync();
+    if (lane >= 10 && lane < 20) {
+#pragma unroll
+        for (int r = 0; r < 6; ++r) sc[r * 10 + (lane - 10)] = g[4 + r];
+    }
+    wave_lds_sync();
+    double hl[6][10];
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int c = 0; c < 10; ++c) hl[r][c] = sc[r * 10 + c];
+    wave_lds_sync();  // sc is the root finder's scratch next
+    e5_finish(hl, P);
+}
+// e5_models with root i on lane i; the models come back wave-uniform, in root order
+__device__ __noinline__ int e5_models_wave(const double* nsp, const E5Polys& P, const double* roots, int nr, double* models,
+                                           int lane) {
+    double z = roots[0];
+#pragma unroll
+    for (int i = 1; i < 10; ++i) z = lane == i ? roots[i] : z;
+    double E[9];
+    const bool ok = e5_model_from_root(nsp, P, z, E) && lane < nr;
+    unsigned long long mask = __ballot(ok);
+    int nm = 0;
+    while (mask) {
+        const int src = (int)__builtin_ctzll(mask);
+        mask &= mask - 1;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) models[9 * nm + i] = readlane_f64(E[i], src);
+        ++nm;
+    }
+    return nm;
+}
+
 // local estimator on the K listed inlier correspondences -> models (uniform), count
 template <bool L>
 __device__ __forceinline__ int local_estimate_impl(const LoCtx& w, int kind, const Pts& P, int K, double* models) {
@@ -778,10 +924,10 @@ __device__ __forceinline__ int local_estimate_impl(const LoCtx& w, int kind, con
         e5_nullspace_from_eig(w.jacA, w.jacV, nsp);
         wave_lds_sync();  // jacA doubles as the root finder's scratch from here on
         E5Polys polys;
-        e5_build(nsp, polys);
+        e5_build_wave(nsp, polys, w.jacA, lane);
         double roots[10];
         const int nr = real_roots10_wave(polys.det, roots, w.jacA, lane);
-        return e5_models(nsp, polys, roots, nr, models);
+        return e5_models_wave(nsp, polys, roots, nr, models, lane);
     }
     if (kind == K_H && K == 4) {
         double a[4], b[4], c[4], d[4];

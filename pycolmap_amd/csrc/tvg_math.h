@@ -607,6 +607,55 @@ struct E5Polys {
     double B[3][3][5];  // B[k][0..1]: degree 3, B[k][2]: degree 4 (low -> high)
     double det[11];
 };
+// rows 4..9, columns 10..19 of the eliminated constraint matrix -> B(z) and det B(z)
+AMC_HD void e5_finish(const double (&hl)[6][10], E5Polys& P) {
+    double (&B)[3][3][5] = P.B;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const double (&hi)[10] = hl[2 * k];
+        const double (&lo)[10] = hl[2 * k + 1];
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int d = 0; d < 5; ++d) B[k][t][d] = 0.0;
+        double (&a)[5] = B[k][0];
+        double (&b)[5] = B[k][1];
+        double (&c)[5] = B[k][2];
+        a[2] += hi[0]; a[1] += hi[1]; a[0] += hi[2];
+        b[2] += hi[3]; b[1] += hi[4]; b[0] += hi[5];
+        c[3] += hi[6]; c[2] += hi[7]; c[1] += hi[8]; c[0] += hi[9];
+        a[3] -= lo[0]; a[2] -= lo[1]; a[1] -= lo[2];
+        b[3] -= lo[3]; b[2] -= lo[4]; b[1] -= lo[5];
+        c[4] -= lo[6]; c[3] -= lo[7]; c[2] -= lo[8]; c[1] -= lo[9];
+    }
+    // det B(z) with the oracle's accumulation order: pz_mul (i outer, j inner), sub, add.  B[k][0]
+    // and B[k][1] are cubics stored in 5 slots: the products below use their 4 coefficients.
+    double (&det)[11] = P.det;
+    {
+        double b00[4], b01[4], b10[4], b11[4], b20[4], b21[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            b00[i] = B[0][0][i]; b01[i] = B[0][1][i]; b10[i] = B[1][0][i];
+            b11[i] = B[1][1][i]; b20[i] = B[2][0][i]; b21[i] = B[2][1][i];
+        }
+        double u8[8], w8[8], u7[7], w7[7], m0[8], m1[8], m2[7];
+        e5_pmul<3, 4>(b11, B[2][2], u8); e5_pmul<4, 3>(B[1][2], b21, w8);
+#pragma unroll
+        for (int i = 0; i <= 7; ++i) m0[i] = u8[i] - w8[i];
+        e5_pmul<3, 4>(b10, B[2][2], u8); e5_pmul<4, 3>(B[1][2], b20, w8);
+#pragma unroll
+        for (int i = 0; i <= 7; ++i) m1[i] = u8[i] - w8[i];
+        e5_pmul<3, 3>(b10, b21, u7); e5_pmul<3, 3>(b11, b20, w7);
+#pragma unroll
+        for (int i = 0; i <= 6; ++i) m2[i] = u7[i] - w7[i];
+        double q0[11], q1[11], q2[11];
+        e5_pmul<3, 7>(b00, m0, q0);
+        e5_pmul<3, 7>(b01, m1, q1);
+        e5_pmul<4, 6>(B[0][2], m2, q2);
+#pragma unroll
+        for (int i = 0; i <= 10; ++i) det[i] = (q0[i] - q1[i]) + q2[i];
+    }
+}
 AMC_HD void e5_build(const double* nsp, E5Polys& P) {
     double e[9][4];
 #pragma unroll
@@ -687,92 +736,53 @@ AMC_HD void e5_build(const double* nsp, E5Polys& P) {
             for (int c = 0; c < 20; ++c) G[r][c] = G[r][c] - f * G[col][c];
         }
     }
-    double (&B)[3][3][5] = P.B;
+    double hl[6][10];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const double (&hi)[20] = G[4 + 2 * k];
-        const double (&lo)[20] = G[5 + 2 * k];
+    for (int r = 0; r < 6; ++r)
 #pragma unroll
-        for (int t = 0; t < 3; ++t)
-#pragma unroll
-            for (int d = 0; d < 5; ++d) B[k][t][d] = 0.0;
-        double (&a)[5] = B[k][0];
-        double (&b)[5] = B[k][1];
-        double (&c)[5] = B[k][2];
-        a[2] += hi[10]; a[1] += hi[11]; a[0] += hi[12];
-        b[2] += hi[13]; b[1] += hi[14]; b[0] += hi[15];
-        c[3] += hi[16]; c[2] += hi[17]; c[1] += hi[18]; c[0] += hi[19];
-        a[3] -= lo[10]; a[2] -= lo[11]; a[1] -= lo[12];
-        b[3] -= lo[13]; b[2] -= lo[14]; b[1] -= lo[15];
-        c[4] -= lo[16]; c[3] -= lo[17]; c[2] -= lo[18]; c[1] -= lo[19];
-    }
-    // det B(z) with the oracle's accumulation order: pz_mul (i outer, j inner), sub, add.  B[k][0]
-    // and B[k][1] are cubics stored in 5 slots: the products below use their 4 coefficients.
-    double (&det)[11] = P.det;
-    {
-        double b00[4], b01[4], b10[4], b11[4], b20[4], b21[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            b00[i] = B[0][0][i]; b01[i] = B[0][1][i]; b10[i] = B[1][0][i];
-            b11[i] = B[1][1][i]; b20[i] = B[2][0][i]; b21[i] = B[2][1][i];
-        }
-        double u8[8], w8[8], u7[7], w7[7], m0[8], m1[8], m2[7];
-        e5_pmul<3, 4>(b11, B[2][2], u8); e5_pmul<4, 3>(B[1][2], b21, w8);
-#pragma unroll
-        for (int i = 0; i <= 7; ++i) m0[i] = u8[i] - w8[i];
-        e5_pmul<3, 4>(b10, B[2][2], u8); e5_pmul<4, 3>(B[1][2], b20, w8);
-#pragma unroll
-        for (int i = 0; i <= 7; ++i) m1[i] = u8[i] - w8[i];
-        e5_pmul<3, 3>(b10, b21, u7); e5_pmul<3, 3>(b11, b20, w7);
-#pragma unroll
-        for (int i = 0; i <= 6; ++i) m2[i] = u7[i] - w7[i];
-        double q0[11], q1[11], q2[11];
-        e5_pmul<3, 7>(b00, m0, q0);
-        e5_pmul<3, 7>(b01, m1, q1);
-        e5_pmul<4, 6>(B[0][2], m2, q2);
-#pragma unroll
-        for (int i = 0; i <= 10; ++i) det[i] = (q0[i] - q1[i]) + q2[i];
-    }
+        for (int c = 0; c < 10; ++c) hl[r][c] = G[4 + r][10 + c];
+    e5_finish(hl, P);
 }
 // returns the number of models written (a root whose (x, y) blows up is skipped, as upstream skips
 // |X(2)| < 1e-10 of the unit null vector of B(z)); every E is scaled to unit Frobenius norm
-AMC_HD int e5_models(const double* nsp, const E5Polys& P, const double* roots, int nr, double* models) {
+// one root z of det B -> its essential matrix (false: skipped)
+AMC_HD bool e5_model_from_root(const double* nsp, const E5Polys& P, double z, double* E) {
     const double (&B)[3][3][5] = P.B;
-    int nm = 0;
-    for (int i = 0; i < nr; ++i) {
-        const double z = roots[i];
-        // null vector of B(z) = the longest cross product of two of its rows (the oracle's statement of
-        // upstream's JacobiSVD null vector X, skipped when |X(2)| < 1e-10)
-        double Bz[3][3];
+    // null vector of B(z) = the longest cross product of two of its rows (the oracle's statement of
+    // upstream's JacobiSVD null vector X, skipped when |X(2)| < 1e-10)
+    double Bz[3][3];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            Bz[k][0] = poly_eval(B[k][0], 3, z);
-            Bz[k][1] = poly_eval(B[k][1], 3, z);
-            Bz[k][2] = poly_eval(B[k][2], 4, z);
-        }
-        double X0 = 0.0, X1 = 0.0, X2 = 0.0, best_n2 = -1.0;
-#pragma unroll
-        for (int pr = 0; pr < 3; ++pr) {
-            const int iu = pr == 2 ? 1 : 0, iw = pr == 0 ? 1 : 2;
-            const double c0 = Bz[iu][1] * Bz[iw][2] - Bz[iu][2] * Bz[iw][1];
-            const double c1 = Bz[iu][2] * Bz[iw][0] - Bz[iu][0] * Bz[iw][2];
-            const double c2 = Bz[iu][0] * Bz[iw][1] - Bz[iu][1] * Bz[iw][0];
-            const double n2 = c0 * c0 + c1 * c1 + c2 * c2;
-            if (n2 > best_n2) { best_n2 = n2; X0 = c0; X1 = c1; X2 = c2; }
-        }
-        const double nn = dsqrt(best_n2);
-        X0 = X0 / nn; X1 = X1 / nn; X2 = X2 / nn;
-        if (!(dabs(X2) >= 1e-10)) continue;
-        const double x = X0 / X2;
-        const double y = X1 / X2;
-        double* E = models + 9 * nm;
-        for (int k = 0; k < 9; ++k) E[k] = x * nsp[k] + y * nsp[9 + k] + z * nsp[18 + k] + nsp[27 + k];
-        double n2 = 0.0;
-        for (int k = 0; k < 9; ++k) n2 += E[k] * E[k];
-        const double nrm = dsqrt(n2);
-        for (int k = 0; k < 9; ++k) E[k] = E[k] / nrm;
-        ++nm;
+    for (int k = 0; k < 3; ++k) {
+        Bz[k][0] = poly_eval(B[k][0], 3, z);
+        Bz[k][1] = poly_eval(B[k][1], 3, z);
+        Bz[k][2] = poly_eval(B[k][2], 4, z);
     }
+    double X0 = 0.0, X1 = 0.0, X2 = 0.0, best_n2 = -1.0;
+#pragma unroll
+    for (int pr = 0; pr < 3; ++pr) {
+        const int iu = pr == 2 ? 1 : 0, iw = pr == 0 ? 1 : 2;
+        const double c0 = Bz[iu][1] * Bz[iw][2] - Bz[iu][2] * Bz[iw][1];
+        const double c1 = Bz[iu][2] * Bz[iw][0] - Bz[iu][0] * Bz[iw][2];
+        const double c2 = Bz[iu][0] * Bz[iw][1] - Bz[iu][1] * Bz[iw][0];
+        const double n2 = c0 * c0 + c1 * c1 + c2 * c2;
+        if (n2 > best_n2) { best_n2 = n2; X0 = c0; X1 = c1; X2 = c2; }
+    }
+    const double nn = dsqrt(best_n2);
+    X0 = X0 / nn; X1 = X1 / nn; X2 = X2 / nn;
+    if (!(dabs(X2) >= 1e-10)) return false;
+    const double x = X0 / X2;
+    const double y = X1 / X2;
+    for (int k = 0; k < 9; ++k) E[k] = x * nsp[k] + y * nsp[9 + k] + z * nsp[18 + k] + nsp[27 + k];
+    double n2 = 0.0;
+    for (int k = 0; k < 9; ++k) n2 += E[k] * E[k];
+    const double nrm = dsqrt(n2);
+    for (int k = 0; k < 9; ++k) E[k] = E[k] / nrm;
+    return true;
+}
+AMC_HD int e5_models(const double* nsp, const E5Polys& P, const double* roots, int nr, double* models) {
+    int nm = 0;
+    for (int i = 0; i < nr; ++i)
+        if (e5_model_from_root(nsp, P, roots[i], models + 9 * nm)) ++nm;
     return nm;
 }
 // nsp -> #models (<= 10), row-major
