@@ -616,17 +616,28 @@ __device__ __forceinline__ void ata_impl(const LoCtx& w, const Pts& P, int K, co
 // k of rows p_e, q_e of A.  Every element sees exactly the arithmetic of the scalar version, so the
 // results are bit-identical; the pairs of a round being disjoint, no two lanes touch one entry
 // within a phase.
-__device__ __noinline__ void jacobi_eigen_wave(int n, lds_f64* A, lds_f64* V, int lane) {
+// jacobi_pair(9, r, e, p, q) without the run-time modulo (m = 9 rounds, 4 pairs per round)
+__device__ __forceinline__ void jacobi_pair9(int r, int e, int& p, int& q) {
+    int x = r + e + 1, y = r - (e + 1);
+    x = x >= 9 ? x - 9 : x;
+    y = y < 0 ? y + 9 : y;
+    p = x < y ? x : y;
+    q = x < y ? y : x;
+}
+__device__ __noinline__ void jacobi_eigen_wave(int n_, lds_f64* A, lds_f64* V, int lane) {
+    constexpr int n = 9, rounds = 9, np = 4;  // the only size the kernel decomposes as a wave
+    (void)n_;
     for (int i = lane; i < n * n; i += 64) V[i] = ((i / n) == (i % n)) ? 1.0 : 0.0;
     wave_lds_sync();
     double total = 0.0;
     for (int i = 0; i < n * n; ++i) total += A[i] * A[i];
     const double tol = total * 1e-32;
-    const int rounds = jacobi_num_rounds(n), np = jacobi_pairs_per_round(n);
     const int e_of = lane / n, k_of = lane - e_of * n;  // this lane's (pair, entry) in the update phases
     for (int sweep = 0; sweep < 40; ++sweep) {
         double off = 0.0;
+#pragma unroll
         for (int p = 0; p < n - 1; ++p)
+#pragma unroll
             for (int q = p + 1; q < n; ++q) off += A[p * n + q] * A[p * n + q];
         if (!(off > tol)) break;
         for (int r = 0; r < rounds; ++r) {
@@ -635,13 +646,13 @@ __device__ __noinline__ void jacobi_eigen_wave(int n, lds_f64* A, lds_f64* V, in
             bool act = false;
             if (lane < np) {
                 int p, q;
-                jacobi_pair(n, r, lane, p, q);
+                jacobi_pair9(r, lane, p, q);
                 act = jacobi_rotation(A[p * n + p], A[q * n + q], A[p * n + q], c, s);
             }
             const double ce = __shfl(c, e_of), se = __shfl(s, e_of);
             const bool acte = __shfl((int)act, e_of) != 0 && e_of < np;
             int p = 0, q = 0;
-            if (e_of < np) jacobi_pair(n, r, e_of, p, q);
+            if (e_of < np) jacobi_pair9(r, e_of, p, q);
             wave_lds_sync();
             if (acte) {  // columns p, q of A and V, entry k
                 const double akp = A[k_of * n + p], akq = A[k_of * n + q];
