@@ -722,14 +722,15 @@ def main():
         }
         # HBM bytes per launch of the dominant kernel: PMC counters cannot be collected inside this process,
         # so the number comes from the committed rocprofv3 --pmc pass of this same command
-        # (profiles/r01/pmc_hbm_v6.*), and only when this run launches the same shape.
+        # (profiles/r02/pmc_hbm_r02.*), and only when this run launches the same shape.
         try:
-            pmc = json.loads((ROOT / "profiles" / "r01" / "pmc_hbm_v6.json").read_text())
+            pmc = json.loads((ROOT / "profiles" / "r02" / "pmc_hbm_r02.json").read_text())
             per_launch = int(len(s1)) // launches_per_step
             if st["pairs_mfma"] and args.feats == 4096 and abs(per_launch - pmc["pairs_per_launch"]) <= 1:
                 out["roofline"]["traffic"] = pmc["fetch_bytes_per_launch_corrected"]
                 out["roofline"]["traffic_unit"] = "bytes read from HBM per launch (FETCH_SIZE x 1024 x 2, gfx950 correction)"
-                out["roofline"]["traffic_source"] = "profiles/r01/pmc_hbm_v6.txt"
+                out["roofline"]["traffic_source"] = "profiles/r02/pmc_hbm_r02_v2.txt"
+                out["roofline"]["traffic_written"] = pmc.get("write_bytes_per_launch")
                 out["roofline"]["algorithmic_bytes"] = float(per_launch) * 2 * args.feats * 128
         except (OSError, KeyError, ValueError):
             pass
