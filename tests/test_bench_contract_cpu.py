@@ -43,6 +43,11 @@ def test_committed_bench_line_has_the_contract_keys():
         assert pl["cpu_baseline"]["gpu_vs_oracle_mismatching_pairs"] == 0
         assert pl["cpu_baseline"]["verified_pairs_mismatching"] == 0 and pl["cpu_baseline"]["verified_pairs_checked"] > 0
         assert 0 < pl["roofline"]["frac"] < 1
+        g = pl.get("guided")
+        if g:                                                  # the guided re-match of the verified pairs
+            assert g["unit"] == "entries/s" and g["value"] > 1.6e12            # >= 3 x 5.3e11
+            assert g["pairs"] == sum(g["pairs_by_kernel"].values()) and g["pairs_by_kernel"]["candidate_generation"] > 0
+            assert g["cpu_baseline"]["gpu_vs_oracle_mismatching_pairs"] == 0
     dn = d.get("dense")
     if dn:
         assert dn["unit"] == "distances/s" and dn["matches_per_pair"] > 500
