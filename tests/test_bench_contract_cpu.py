@@ -56,7 +56,7 @@ def test_committed_bench_line_has_the_contract_keys():
 
 def test_committed_scaled_config_lines():
     """bench.py --config 3 / 4 at N=1 (profiles/r02): the contract keys, strong scaling, the stated workloads."""
-    for name, pairs in (("bench_config3_n1_v1.json", 1999000), ("bench_config4_n1_v1.json", None)):
+    for name, pairs in (("bench_config3_n1_v2.json", 1999000), ("bench_config4_n1_v2.json", None)):
         path = ROOT / "profiles" / "r02" / name
         d = json.loads(path.read_text().strip().splitlines()[-1])
         for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
