@@ -246,18 +246,22 @@ __global__ __launch_bounds__(256) void resolve_index_kernel(
 // independent, their order is free.  Used when the Y image has at most kResolveMaxTiles tiles.
 // ---------------------------------------------------------------------------------------
 constexpr uint32_t kResolveChunk = 4096, kResolveMaxTiles = 2048;
-__global__ __launch_bounds__(256) void resolve_index_grouped_kernel(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void resolve_index_grouped_kernel(
     int side, const ImageDev* __restrict__ imgs, const PairDev* __restrict__ pairs,
     Top2* __restrict__ table, uint32_t* __restrict__ accmask, const float* __restrict__ lut,
     FinalizeParams fp, const uint32_t* __restrict__ cand_cnt, const uint32_t* __restrict__ candbuf,
     uint32_t* __restrict__ err_count) {
-    __shared__ uint32_t s_list[kResolveChunk];    // (tile << 12) | position in the chunk
-    __shared__ uint32_t s_sorted[kResolveChunk];
-    __shared__ uint32_t s_hist[kResolveMaxTiles];
+    // 48 KB, three workgroups per CU.  While sorting: s_list | s_sorted | s_hist; while walking the rows the first
+    // third holds the rows' dot products (`part`) and the last third the batch's X rows (over s_hist and beyond).
+    __shared__ __attribute__((aligned(16))) uint32_t s_pool[3 * kResolveChunk];
+    uint32_t* const s_list = s_pool;                        // (tile << 12) | position in the chunk
+    uint32_t* const s_sorted = s_pool + kResolveChunk;
+    uint32_t* const s_hist = s_pool + 2 * kResolveChunk;    // kResolveMaxTiles entries
+    uint4* const s_xall = reinterpret_cast<uint4*>(s_pool + 2 * kResolveChunk);  // 4 waves x 256 x 16 B
+    static_assert(kResolveMaxTiles <= kResolveChunk && 4 * 256 * 4 <= kResolveChunk, "the last third holds either");
     __shared__ uint32_t s_wsum[4];
     __shared__ uint32_t s_count;
     __shared__ uint32_t s_brow[4][32], s_btile[4][32];  // the batch's rows and tiles, by wave
-    __shared__ uint4 s_x[4][256];                       // and their X rows (32 x 128 bytes)
     const PairDev p = pairs[blockIdx.x];
     if (p.mode == 0) return;  // dot4 pairs carry exact indices already
     const ImageDev X = imgs[side == 0 ? p.slot1 : p.slot2];
@@ -355,7 +359,7 @@ __global__ __launch_bounds__(256) void resolve_index_grouped_kernel(
         // a 32-lane reduction through seven LDS permutes and a lane-0 tail with three dependent memory round trips,
         // ~3,600 cycles per row.)
         uint32_t* part = s_list + wid * 1024;  // [32 rows][32], row r rotated by r: free of bank conflicts both ways
-        uint4* xs = s_x[wid];
+        uint4* xs = s_xall + wid * 256;
         const uint32_t kb = (uint32_t)(((uint64_t)cnt * wid) / 4), ke = (uint32_t)(((uint64_t)cnt * (wid + 1)) / 4);
         uint32_t cur_tile = 0xFFFFFFFFu;
         uint4 yv[8];
