@@ -200,7 +200,7 @@ def test_guided_grid_random_models_and_layouts(ctx):
     upload_scene(ctx, layouts, False)
     s1, s2 = synth.exhaustive_pairs(n_img)
     s1, s2 = np.concatenate([s1, s2]), np.concatenate([s2, s1])
-    total_grid = 0
+    total_grid = total_matches = 0
     for rep in range(6):
         tvg = np.zeros(len(s1), dtype=_capi.TVG_DTYPE)
         for p in range(len(s1)):
@@ -237,9 +237,14 @@ def test_guided_grid_random_models_and_layouts(ctx):
                 H = np.diag([rng.uniform(0.2, 5), rng.uniform(0.2, 5), 1.0])
             tvg["H"][p] = H * 10.0 ** rng.uniform(-3, 3)
         max_error = [0.0, 0.7, 4.0, 25.0, 400.0, 1e6][rep]
-        _, _, ngrid = both_kernels(ctx, s1, s2, tvg, max_error, cross_check=bool(rep % 2 == 0))
+        # random descriptors never pass the default ratio test: accept every row that has a candidate at all, so that
+        # the matches depend on every row's best index (and on the cross check)
+        _, mg, ngrid = both_kernels(ctx, s1, s2, tvg, max_error, cross_check=bool(rep % 2 == 0), max_ratio=1.0,
+                                    max_distance=2.0)
         total_grid += ngrid
+        total_matches += len(mg)
     assert total_grid > len(s1)          # the routing does send plenty of these to the grid kernel
+    assert total_matches > 1000
     # and against the oracle, one round
     check_guided(ctx, layouts, s1[:20], s2[:20], tvg[:20], 4.0)
 

@@ -60,9 +60,12 @@ for rd in range(rounds):
         tvg["H"][p] = H * 10.0 ** rng.uniform(-4, 4)
     max_error = float(rng.choice([0.0, 0.3, 1.0, 4.0, 4.0, 16.0, 100.0, 1e4]))
     cc = bool(rng.integers(0, 2))
-    off_g, m_g, st_g = ctx.match_guided_pairs(s1, s2, tvg, max_error, cross_check=cc)
+    # random descriptors never pass the default ratio test: most rounds accept every row that has a candidate at all,
+    # so that the matches depend on every row's best index and on the cross check
+    kw = dict(cross_check=cc) if rd % 4 == 3 else dict(cross_check=cc, max_ratio=1.0, max_distance=2.0)
+    off_g, m_g, st_g = ctx.match_guided_pairs(s1, s2, tvg, max_error, **kw)
     os.environ["AMC_GUIDED_DENSE"] = "1"
-    off_d, m_d, _ = ctx.match_guided_pairs(s1, s2, tvg, max_error, cross_check=cc)
+    off_d, m_d, _ = ctx.match_guided_pairs(s1, s2, tvg, max_error, **kw)
     del os.environ["AMC_GUIDED_DENSE"]
     for p in range(len(s1)):
         a = m_g[int(off_g[p]):int(off_g[p + 1])]
