@@ -1034,24 +1034,6 @@ __device__ __forceinline__ void fast_inlier(const double (&m)[9], double a, doub
     in = sane && Lq <= R * kFastLo;
     amb = !sane || (Lq > R * kFastLo && Lq < R * kFastHi);
 }
-// The homography test with the threshold folded into the operands (register counting loop): with s = 1 / sqrt(T),
-// rows 0 and 1 of the model and the image-2 coordinates are pre-multiplied by s (the rows once per 64-trial chunk by
-// the lanes that solved them, the coordinates once per chunk), so that the inequality is u'^2 + v'^2 <= w^2 with
-// u' = c' w - p0', v' = d' w - p1': 14 arithmetic instructions and 4 comparisons instead of 16 + 5.  The scaling
-// adds a rounding of relative size 1e-16, the decision keeps its 1e-8 band (see fast_inlier).
-__device__ __forceinline__ void fast_inlier_hs(const double (&m)[9], double a, double b, double cs, double ds, bool& in,
-                                               bool& amb) {
-    const double p0 = __fma_rn(m[0], a, __fma_rn(m[1], b, m[2]));
-    const double p1 = __fma_rn(m[3], a, __fma_rn(m[4], b, m[5]));
-    const double w = __fma_rn(m[6], a, __fma_rn(m[7], b, m[8]));
-    const double u = __fma_rn(cs, w, -p0), v = __fma_rn(ds, w, -p1);
-    const double R = w * w;
-    const double t = __fma_rn(u, u, v * v) - R;
-    const double band = R * 1e-8;
-    const bool sane = R > 1e-200 && R < 1e200;  // false for 0, denormal-ish, huge, inf and NaN
-    in = sane && t <= -band;
-    amb = !sane || !(dabs(t) >= band);
-}
 // inliers of U consecutive full 64-point batches starting at k0: U independent residual chains in
 // flight (at two waves per SIMD little else hides the FP64 and LDS latencies)
 template <bool L, int KIND, int U, bool FAST>
@@ -1171,19 +1153,16 @@ __device__ __forceinline__ int count_global_models(const double* models, int nmo
 // registers - the inner loop is a broadcast plus straight FP64 arithmetic on independent batches.  Lanes past M in
 // the last batch hold a copy of point 0 and are masked out of the ballots.  The division-free test (fast_inlier)
 // decides; a model with an ambiguous point is recounted with the exact residual, from the same registers.
-// HS: sm holds rows 0, 1 scaled by 1 / sqrt(max_res) and cs, ds the scaled image-2 coordinates (K_H only)
-template <int KIND, int NB, bool HS>
+template <int KIND, int NB>
 __device__ __forceinline__ int count_regs(const double (&sm)[9], const double (&a)[NB], const double (&b)[NB],
-                                          const double (&c)[NB], const double (&d)[NB], const double (&cs)[NB],
-                                          const double (&ds)[NB], unsigned long long last_valid, int M, double max_res,
-                                          int thr, const double (&mym)[27], int src_lane) {
+                                          const double (&c)[NB], const double (&d)[NB], unsigned long long last_valid,
+                                          int M, double max_res, int thr) {
     int cnt = 0;
     bool amb = false;
 #pragma unroll
     for (int u = 0; u < NB; ++u) {
         bool in, am;
-        if (HS) fast_inlier_hs(sm, a[u], b[u], cs[u], ds[u], in, am);
-        else fast_inlier<KIND>(sm, a[u], b[u], c[u], d[u], max_res, in, am);
+        fast_inlier<KIND>(sm, a[u], b[u], c[u], d[u], max_res, in, am);
         amb |= am;
         unsigned long long bal = __ballot(in);
         if (u == NB - 1) bal &= last_valid;
@@ -1196,12 +1175,9 @@ __device__ __forceinline__ int count_regs(const double (&sm)[9], const double (&
     }
     if (__builtin_expect(__ballot(amb) == 0ull, 1)) return cnt;
     cnt = 0;  // some point sat in the band around the threshold: the reference residual decides, for the whole model
-    double em[9];  // HS: the reference residual takes the solver's own model, not the scaled copy
-#pragma unroll
-    for (int i = 0; i < 9; ++i) em[i] = HS ? readlane_f64(mym[i], src_lane) : sm[i];
 #pragma unroll
     for (int u = 0; u < NB; ++u) {
-        unsigned long long bal = __ballot(residual_t<KIND>(em, a[u], b[u], c[u], d[u]) <= max_res);
+        unsigned long long bal = __ballot(residual_t<KIND>(sm, a[u], b[u], c[u], d[u]) <= max_res);
         if (u == NB - 1) bal &= last_valid;
         cnt += __popcll(bal);
     }
@@ -1221,17 +1197,6 @@ __device__ __forceinline__ int count_chunk_regs(const double (&mym)[27], const d
     }
     const int tail = M - 64 * (NB - 1);  // 1 .. 64 valid lanes in the last batch
     const unsigned long long last_valid = tail >= 64 ? ~0ull : ((1ull << tail) - 1ull);
-    // homography: the threshold folded into the operands (fast_inlier_hs) - scaled image-2 coordinates, and rows 0 / 1
-    // of every lane's model scaled before they are broadcast
-    constexpr bool HS = KIND == K_H;
-    double cs[NB], ds[NB], msc[9];
-    if (HS) {
-        const double s = 1.0 / dsqrt(max_res);
-#pragma unroll
-        for (int u = 0; u < NB; ++u) { cs[u] = c[u] * s; ds[u] = d[u] * s; }
-#pragma unroll
-        for (int i = 0; i < 9; ++i) msc[i] = i < 6 ? mym[i] * s : mym[i];
-    }
     int maxcnt = -1;
     for (int t = 0; t < nT; ++t) {
         const int n = __builtin_amdgcn_readlane(nmod, t);
@@ -1242,15 +1207,11 @@ __device__ __forceinline__ int count_chunk_regs(const double (&mym)[27], const d
                 const double* src = models + ((size_t)t * kMaxModels + m) * 9;
 #pragma unroll
                 for (int i = 0; i < 9; ++i) sm[i] = readlane_f64(src[i], 0);
-            } else if (HS) {
-#pragma unroll
-                for (int i = 0; i < 9; ++i) sm[i] = readlane_f64(msc[i], t);
             } else {
 #pragma unroll
                 for (int i = 0; i < 9; ++i) sm[i] = readlane_f64(mym[9 * (NM == 1 ? 0 : m) + i], t);
             }
-            const int cc = count_regs<(KIND == K_E5 ? K_F7 : KIND), NB, HS>(sm, a, b, c, d, HS ? cs : c, HS ? ds : d, last_valid,
-                                                                          M, max_res, thr, mym, t);
+            const int cc = count_regs<(KIND == K_E5 ? K_F7 : KIND), NB>(sm, a, b, c, d, last_valid, M, max_res, thr);
             if (lane == t) maxcnt = max(maxcnt, cc);
         }
     }
