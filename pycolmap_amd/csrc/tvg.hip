@@ -1183,10 +1183,107 @@ __device__ __forceinline__ int count_regs(const double (&sm)[9], const double (&
     }
     return cnt;
 }
+// ---- homography counting: packed-FP32 pre-filter ------------------------------------------------------
+// The homography RANSAC of a non-planar pair runs to its trial cap and nearly all of its models count nearly all
+// matches as outliers by a wide margin; the decision u'^2 + v'^2 <= w^2 (u' = c' w - p0', v' = d' w - p1', the
+// threshold folded into rows 0 / 1 of the model and the image-2 coordinates by s = 1 / sqrt(T)) does not need 53
+// bits there.  It is first evaluated in FP32 on two 64-point batches at a time (v_pk_fma_f32: two batches per
+// instruction), TOGETHER WITH A BOUND ON ITS OWN ERROR; a point is decided in FP32 only if |t32| exceeds that bound,
+// and a model with any undecided point is recounted by the FP64 path (count_regs: division-free test, then the
+// reference residual inside its band).
+//
+// The bound (u = 2^-24, every FP32 operation below is a single rounding; C = largest |coordinate| of the pair,
+// Cs = C s; m = the scaled model as the lane computed it in FP64; A0 = (|m0| + |m1|) C + |m2|, A1, Aw likewise):
+//   p0, p1, w:   |p32 - p| <= 5u A            (coefficient and coordinate conversions + two FMAs)
+//   u', v':      |u32 - u'| <= E0 + u |u32|,  E0 = 5u max(A0, A1) + 6u Cs Aw
+//   L = u'^2 + v'^2, R = w^2, t = L - R:
+//   |t32 - t| <= 6u |t32| + 6u R32 + 2 E0 (|u32| + |v32|) + 2 Ew |w32| + 2 E0^2 + Ew^2,   Ew = 5u Aw
+// and the FP64 test is itself only trusted outside |t| <= 2e-8 R, so a point is decided here iff
+//   |t32| > 4.2e-7 R32 + kE (|u32| + |v32|) + kW |w32| + K0,   kE = 2.05 E0, kW = 2.05 Ew, K0 = 2.05 (2 E0^2 + Ew^2)
+// (the constants carry > 2 % of slack for the FP32 rounding of the bound itself and the 6u |t32| term; NaN / inf
+// compare false = undecided).  For 1600 x 1200 images and a 4 px threshold the band is ~1e-3 of R: a point is
+// undecided only within ~1e-3 px of the threshold circle.  (Replacing |u| + |v| and |w| by AM-GM bounds in L and R
+// saves the absolute values but leaves 29 % of the models undecided instead of 4 %: the sampled homographies of a
+// non-planar scene are wild, many points have |w| far below the model's typical value.)
+// Checked by a diagnostic build that counts every model both ways (tools/diag_build_tvg.sh 8): 80 million models of
+// the bench's verify leg, 3.9 % undecided, no decided model with a count different from the FP64 path's.
+typedef float v2f __attribute__((ext_vector_type(2)));
+struct H32Lane {
+    float m[9];
+    float kE, kW, K0;
+};
+__device__ __forceinline__ float f32_up(double v) {  // a float >= v (v >= 0)
+    return (float)(v * (1.0 + 1e-6));
+}
+__device__ __forceinline__ H32Lane h32_prepare(const double (&mym)[27], double s, double C) {
+    constexpr double U = 5.9604644775390625e-08;  // 2^-24
+    double msc[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) msc[i] = i < 6 ? mym[i] * s : mym[i];
+    const double A0 = (dabs(msc[0]) + dabs(msc[1])) * C + dabs(msc[2]);
+    const double A1 = (dabs(msc[3]) + dabs(msc[4])) * C + dabs(msc[5]);
+    const double Aw = (dabs(msc[6]) + dabs(msc[7])) * C + dabs(msc[8]);
+    const double E0 = 5.0 * U * dmax(A0, A1) + 6.0 * U * (C * s) * Aw;
+    const double Ew = 5.0 * U * Aw;
+    H32Lane h;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) h.m[i] = (float)msc[i];
+    h.kE = f32_up(2.05 * E0);
+    h.kW = f32_up(2.05 * Ew);
+    h.K0 = f32_up(2.05 * (2.0 * E0 * E0 + Ew * Ew) + 1e-30);
+    return h;
+}
+__device__ __forceinline__ float readlane_f32(float v, int src) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
+}
+__device__ __forceinline__ v2f splat(float x) { return (v2f){x, x}; }
+__device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+// count of one model over NP pairs of batches held as packed floats
+template <int NP>
+__device__ __forceinline__ int count_h32(const float (&m)[9], float kE, float kW, float K0, const v2f (&A)[NP],
+                                         const v2f (&B)[NP], const v2f (&Cs)[NP], const v2f (&Ds)[NP],
+                                         unsigned long long valid_lo_last, unsigned long long valid_hi_last, int M, int thr,
+                                         bool& undecided) {
+    int cnt = 0;
+    bool und = false;
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+        const v2f p0 = pk_fma(splat(m[0]), A[q], pk_fma(splat(m[1]), B[q], splat(m[2])));
+        const v2f p1 = pk_fma(splat(m[3]), A[q], pk_fma(splat(m[4]), B[q], splat(m[5])));
+        const v2f w = pk_fma(splat(m[6]), A[q], pk_fma(splat(m[7]), B[q], splat(m[8])));
+        const v2f u = pk_fma(Cs[q], w, -p0), v = pk_fma(Ds[q], w, -p1);
+        const v2f R = w * w;
+        const v2f t = pk_fma(u, u, v * v) - R;
+        const v2f auv = __builtin_elementwise_abs(u) + __builtin_elementwise_abs(v);
+        const v2f band = pk_fma(splat(4.2e-7f), R, pk_fma(splat(kE), auv, pk_fma(splat(kW), __builtin_elementwise_abs(w), splat(K0))));
+        const bool dec0 = fabsf(t.x) > band.x, dec1 = fabsf(t.y) > band.y;
+        unsigned long long in0 = __ballot(t.x < 0.0f), in1 = __ballot(t.y < 0.0f);
+        unsigned long long un0 = __ballot(!dec0), un1 = __ballot(!dec1);
+        if (q == NP - 1) {
+            in0 &= valid_lo_last; un0 &= valid_lo_last;
+            in1 &= valid_hi_last; un1 &= valid_hi_last;
+        }
+        cnt += __popcll(in0) + __popcll(in1);
+        und |= (un0 | un1) != 0ull;
+        if (q + 1 < NP) {  // a model that cannot reach the best count even if every remaining point were an inlier
+            const int rest = M - 128 * (q + 1);
+            if (!und && cnt + rest < thr) {
+                undecided = false;
+                return cnt + rest;
+            }
+        }
+    }
+    undecided = und;
+    return cnt;
+}
+#if defined(AMC_TVG_DIAG) && (AMC_TVG_DIAG & 8)
+__device__ unsigned long long g_h32_diag[4];  // models, undecided models, decided models whose count differs from FP64
+#endif
+
 // KIND K_F7 / K_H: the models are in the solving lanes' registers (mym, NM per trial); KIND K_E5: in global memory
 template <int KIND, int NM, int NB>
 __device__ __forceinline__ int count_chunk_regs(const double (&mym)[27], const double* models, int nmod, const Pts& P,
-                                                int M, double max_res, int nT, int lane, int thr) {
+                                                int M, double max_res, int nT, int lane, int thr, double cmax) {
     // one load per chunk of 64 trials: from LDS, or - pairs whose points do not fit the wave's LDS share - straight
     // from the global arrays (the latency is paid once per chunk, not once per model)
     double a[NB], b[NB], c[NB], d[NB];
@@ -1198,6 +1295,57 @@ __device__ __forceinline__ int count_chunk_regs(const double (&mym)[27], const d
     const int tail = M - 64 * (NB - 1);  // 1 .. 64 valid lanes in the last batch
     const unsigned long long last_valid = tail >= 64 ? ~0ull : ((1ull << tail) - 1ull);
     int maxcnt = -1;
+    if (KIND == K_H) {
+        // packed-FP32 pre-filter (above): pairs of batches as float2, the lanes' models scaled and rounded once
+        constexpr int NP = (NB + 1) / 2;
+        const double s = 1.0 / dsqrt(max_res);
+        v2f A2[NP], B2[NP], C2[NP], D2[NP];
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            const int u0 = 2 * q, u1 = (2 * q + 1 < NB) ? 2 * q + 1 : 2 * q;
+            A2[q] = (v2f){(float)a[u0], (float)a[u1]};
+            B2[q] = (v2f){(float)b[u0], (float)b[u1]};
+            C2[q] = (v2f){(float)(c[u0] * s), (float)(c[u1] * s)};
+            D2[q] = (v2f){(float)(d[u0] * s), (float)(d[u1] * s)};
+        }
+        // the last pair's halves: batch 2 (NP - 1) is full unless it is the last batch; batch 2 NP - 1 may not exist
+        // (odd NB: that half holds a copy of the other batch and counts nothing)
+        const unsigned long long v_lo = (2 * (NP - 1) == NB - 1) ? last_valid : ~0ull;
+        const unsigned long long v_hi = (2 * NP - 1 <= NB - 1) ? ((2 * NP - 1 == NB - 1) ? last_valid : ~0ull) : 0ull;
+        const H32Lane hl = h32_prepare(mym, s, cmax);
+        for (int t = 0; t < nT; ++t) {
+            if (__builtin_amdgcn_readlane(nmod, t) < 1) continue;
+            float m32[9];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) m32[i] = readlane_f32(hl.m[i], t);
+            const float kE = readlane_f32(hl.kE, t), kW = readlane_f32(hl.kW, t), K0 = readlane_f32(hl.K0, t);
+            bool und;
+            int cc = count_h32<NP>(m32, kE, kW, K0, A2, B2, C2, D2, v_lo, v_hi, M, thr, und);
+#if defined(AMC_TVG_DIAG) && (AMC_TVG_DIAG & 8)
+            {
+                double sm[9];
+#pragma unroll
+                for (int i = 0; i < 9; ++i) sm[i] = readlane_f64(mym[i], t);
+                const int c64 = count_regs<K_H, NB>(sm, a, b, c, d, last_valid, M, max_res, 0);
+                bool und2;
+                const int c32 = count_h32<NP>(m32, kE, kW, K0, A2, B2, C2, D2, v_lo, v_hi, M, 0, und2);
+                if (lane == 0) {
+                    atomicAdd(&g_h32_diag[0], 1ull);
+                    if (und2) atomicAdd(&g_h32_diag[1], 1ull);
+                    else if (c32 != c64) atomicAdd(&g_h32_diag[2], 1ull);
+                }
+            }
+#endif
+            if (und) {
+                double sm[9];
+#pragma unroll
+                for (int i = 0; i < 9; ++i) sm[i] = readlane_f64(mym[i], t);
+                cc = count_regs<K_H, NB>(sm, a, b, c, d, last_valid, M, max_res, thr);
+            }
+            if (lane == t) maxcnt = max(maxcnt, cc);
+        }
+        return maxcnt;
+    }
     for (int t = 0; t < nT; ++t) {
         const int n = __builtin_amdgcn_readlane(nmod, t);
         for (int m = 0; m < (KIND == K_E5 ? n : NM); ++m) {
@@ -1219,20 +1367,20 @@ __device__ __forceinline__ int count_chunk_regs(const double (&mym)[27], const d
 }
 template <int KIND, int NM>
 __device__ __forceinline__ int count_chunk_regs_nb(const double (&mym)[27], const double* models, int nmod, const Pts& P,
-                                                   int M, double max_res, int nT, int lane, int thr) {
+                                                   int M, double max_res, int nT, int lane, int thr, double cmax) {
     switch ((M + 63) / 64) {
-        case 1: return count_chunk_regs<KIND, NM, 1>(mym, models, nmod, P, M, max_res, nT, lane, thr);
-        case 2: return count_chunk_regs<KIND, NM, 2>(mym, models, nmod, P, M, max_res, nT, lane, thr);
-        case 3: return count_chunk_regs<KIND, NM, 3>(mym, models, nmod, P, M, max_res, nT, lane, thr);
-        case 4: return count_chunk_regs<KIND, NM, 4>(mym, models, nmod, P, M, max_res, nT, lane, thr);
-        case 5: return count_chunk_regs<KIND, NM, 5>(mym, models, nmod, P, M, max_res, nT, lane, thr);
-        case 6: return count_chunk_regs<KIND, NM, 6>(mym, models, nmod, P, M, max_res, nT, lane, thr);
-        case 7: return count_chunk_regs<KIND, NM, 7>(mym, models, nmod, P, M, max_res, nT, lane, thr);
-        case 8: return count_chunk_regs<KIND, NM, 8>(mym, models, nmod, P, M, max_res, nT, lane, thr);
-        case 9: return count_chunk_regs<KIND, NM, 9>(mym, models, nmod, P, M, max_res, nT, lane, thr);
-        case 10: return count_chunk_regs<KIND, NM, 10>(mym, models, nmod, P, M, max_res, nT, lane, thr);
-        case 11: return count_chunk_regs<KIND, NM, 11>(mym, models, nmod, P, M, max_res, nT, lane, thr);
-        default: return count_chunk_regs<KIND, NM, 12>(mym, models, nmod, P, M, max_res, nT, lane, thr);
+        case 1: return count_chunk_regs<KIND, NM, 1>(mym, models, nmod, P, M, max_res, nT, lane, thr, cmax);
+        case 2: return count_chunk_regs<KIND, NM, 2>(mym, models, nmod, P, M, max_res, nT, lane, thr, cmax);
+        case 3: return count_chunk_regs<KIND, NM, 3>(mym, models, nmod, P, M, max_res, nT, lane, thr, cmax);
+        case 4: return count_chunk_regs<KIND, NM, 4>(mym, models, nmod, P, M, max_res, nT, lane, thr, cmax);
+        case 5: return count_chunk_regs<KIND, NM, 5>(mym, models, nmod, P, M, max_res, nT, lane, thr, cmax);
+        case 6: return count_chunk_regs<KIND, NM, 6>(mym, models, nmod, P, M, max_res, nT, lane, thr, cmax);
+        case 7: return count_chunk_regs<KIND, NM, 7>(mym, models, nmod, P, M, max_res, nT, lane, thr, cmax);
+        case 8: return count_chunk_regs<KIND, NM, 8>(mym, models, nmod, P, M, max_res, nT, lane, thr, cmax);
+        case 9: return count_chunk_regs<KIND, NM, 9>(mym, models, nmod, P, M, max_res, nT, lane, thr, cmax);
+        case 10: return count_chunk_regs<KIND, NM, 10>(mym, models, nmod, P, M, max_res, nT, lane, thr, cmax);
+        case 11: return count_chunk_regs<KIND, NM, 11>(mym, models, nmod, P, M, max_res, nT, lane, thr, cmax);
+        default: return count_chunk_regs<KIND, NM, 12>(mym, models, nmod, P, M, max_res, nT, lane, thr, cmax);
     }
 }
 constexpr int kRegCountMaxM = 768;  // 12 batches of 64: 96 VGPRs of points (the phase has 256 to itself)
@@ -1277,11 +1425,11 @@ __device__ __noinline__ void solve_chunk(ChunkModels* out, int est, const Pts P,
 }
 
 __device__ __noinline__ void count_chunk(ChunkModels* io, int est_, const Pts P_, int M_, double max_res_, int nT_,
-                                         int lane, const double* models_, int thr_, int fast_) {
+                                         int lane, const double* models_, int thr_, int fast_, double cmax_) {
     const unsigned long long c1 = __builtin_readcyclecounter();
     const int est = uni(est_), M = uni(M_), nT = uni(nT_), thr = uni(thr_);
     const bool fast = uni(fast_) != 0;
-    const double max_res = uni(max_res_);
+    const double max_res = uni(max_res_), cmax = uni(cmax_);
     const Pts P = uni(P_);
     const double* models = uni_ptr(models_);
     double mym[27];
@@ -1291,9 +1439,9 @@ __device__ __noinline__ void count_chunk(ChunkModels* io, int est_, const Pts P_
     int maxcnt;
     // the points of nearly every pair fit the LDS share; the global-memory path keeps the exact test only
     if (fast && M <= kRegCountMaxM && M >= 1 && est != K_T) {
-        if (est == K_F7) maxcnt = count_chunk_regs_nb<K_F7, 3>(mym, models, nmod, P, M, max_res, nT, lane, thr);
-        else if (est == K_H) maxcnt = count_chunk_regs_nb<K_H, 1>(mym, models, nmod, P, M, max_res, nT, lane, thr);
-        else maxcnt = count_chunk_regs_nb<K_E5, 1>(mym, models, nmod, P, M, max_res, nT, lane, thr);
+        if (est == K_F7) maxcnt = count_chunk_regs_nb<K_F7, 3>(mym, models, nmod, P, M, max_res, nT, lane, thr, cmax);
+        else if (est == K_H) maxcnt = count_chunk_regs_nb<K_H, 1>(mym, models, nmod, P, M, max_res, nT, lane, thr, cmax);
+        else maxcnt = count_chunk_regs_nb<K_E5, 1>(mym, models, nmod, P, M, max_res, nT, lane, thr, cmax);
     } else if (P.lds && fast) {
         if (est == K_F7) maxcnt = count_lane_models<true, K_F7, 3, true>(mym, nmod, P, M, max_res, nT, lane, thr);
         else if (est == K_H) maxcnt = count_lane_models<true, K_H, 1, true>(mym, nmod, P, M, max_res, nT, lane, thr);
@@ -1360,6 +1508,7 @@ __device__ Report lo_ransac(Wave& w_io, const RansacCfg& cfg, const double* gx, 
     P.g = gx; P.gs = gstride; P.l = w.lpts; P.ls = w.pts_cap;
     P.lds = (uint32_t)M <= w.pts_cap;
     int fast_count = 0;
+    double cmax = 0.0;  // largest |coordinate| of the pair's correspondences
     {
         double amax = 0.0;
         for (int k = lane; k < M; k += 64) {
@@ -1377,6 +1526,7 @@ __device__ Report lo_ransac(Wave& w_io, const RansacCfg& cfg, const double* gx, 
         // the division-free counting test is trusted only while (largest coordinate / max_error) <= 1e5 (see
         // fast_inlier); a NaN coordinate leaves amax as it was or NaN - either way the comparison below decides
         fast_count = (cfg.no_fast_count == 0 && amax * amax <= 1e10 * cfg.max_res) ? 1 : 0;
+        cmax = amax;
     }
 
     // sampler.Initialize(M).  The first kMin entries of the persistent permutation are touched by
@@ -1405,7 +1555,7 @@ __device__ Report lo_ransac(Wave& w_io, const RansacCfg& cfg, const double* gx, 
         // ---- 64 minimal problems + the inlier count of every model (solve_count_chunk) ---------
         ChunkModels cm;
         solve_chunk(&cm, cfg.est, P, w.sidx, nT, lane, models);
-        count_chunk(&cm, cfg.est, P, M, cfg.max_res, nT, lane, models, best.cnt, fast_count);
+        count_chunk(&cm, cfg.est, P, M, cfg.max_res, nT, lane, models, best.cnt, fast_count, cmax);
         w.prof[1] += cm.cyc_solve;
         w.prof[5] += cm.cyc_count;  // the counting loop alone (also part of prof[2])
         tp0 = __builtin_readcyclecounter();
@@ -1867,6 +2017,16 @@ void tvg_diag_report() {
                  (double)h[3] / (h[4] ? h[4] : 1));
     unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tvg_diag), z, sizeof z);
+}
+#elif defined(AMC_TVG_DIAG) && (AMC_TVG_DIAG & 8)
+// diagnostic build 8: every homography model is counted by the FP32 pre-filter AND by the FP64 path
+void tvg_diag_report() {
+    unsigned long long h[4];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_h32_diag), sizeof h) != hipSuccess) return;
+    std::fprintf(stderr, "[amc tvg diag] homography models through the FP32 pre-filter %llu: undecided %llu (%.4f %%), decided "
+                 "with a count different from the FP64 path: %llu\n", h[0], h[1], h[0] ? 100.0 * (double)h[1] / (double)h[0] : 0.0, h[2]);
+    unsigned long long z[4] = {0, 0, 0, 0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_h32_diag), z, sizeof z);
 }
 #else
 void tvg_diag_report() {}
