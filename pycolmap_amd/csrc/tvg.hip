@@ -1281,20 +1281,25 @@ __device__ unsigned long long g_h32_diag[4];  // models, undecided models, decid
 #endif
 
 // KIND K_F7 / K_H: the models are in the solving lanes' registers (mym, NM per trial); KIND K_E5: in global memory
+// One block of up to 768 correspondences [off, off + Mb) against every model of the chunk; `acc` (lane t: the running
+// counts of trial t's models) carries the counts from block to block - pairs with more matches than the registers
+// hold are counted 768 at a time.  A model that cannot reach `thr` even if every remaining match (of this block and
+// of the `rest_after` ones behind it) were an inlier is not evaluated: its count is only ever compared with `thr`.
 template <int KIND, int NM, int NB>
-__device__ __forceinline__ int count_chunk_regs(const double (&mym)[27], const double* models, int nmod, const Pts& P,
-                                                int M, double max_res, int nT, int lane, int thr, double cmax) {
+__device__ __forceinline__ void count_block_regs(const double (&mym)[27], const double* models, int nmod, const Pts& P,
+                                                 int off, int Mb, int rest_after, double max_res, int nT, int lane, int thr,
+                                                 double cmax, int (&acc)[(KIND == K_E5 ? kMaxModels : NM)]) {
+    constexpr int NMX = KIND == K_E5 ? kMaxModels : NM;
     // one load per chunk of 64 trials: from LDS, or - pairs whose points do not fit the wave's LDS share - straight
     // from the global arrays (the latency is paid once per chunk, not once per model)
     double a[NB], b[NB], c[NB], d[NB];
 #pragma unroll
     for (int u = 0; u < NB; ++u) {
         const int k = 64 * u + lane;
-        load_pt_any(P, k < M ? k : 0, a[u], b[u], c[u], d[u]);
+        load_pt_any(P, off + (k < Mb ? k : 0), a[u], b[u], c[u], d[u]);
     }
-    const int tail = M - 64 * (NB - 1);  // 1 .. 64 valid lanes in the last batch
+    const int tail = Mb - 64 * (NB - 1);  // 1 .. 64 valid lanes in the last batch
     const unsigned long long last_valid = tail >= 64 ? ~0ull : ((1ull << tail) - 1ull);
-    int maxcnt = -1;
     if (KIND == K_H) {
         // packed-FP32 pre-filter (above): pairs of batches as float2, the lanes' models scaled and rounded once
         constexpr int NP = (NB + 1) / 2;
@@ -1315,75 +1320,96 @@ __device__ __forceinline__ int count_chunk_regs(const double (&mym)[27], const d
         const H32Lane hl = h32_prepare(mym, s, cmax);
         for (int t = 0; t < nT; ++t) {
             if (__builtin_amdgcn_readlane(nmod, t) < 1) continue;
-            float m32[9];
+            const int prev = __builtin_amdgcn_readlane(acc[0], t);
+            int cc = Mb;
+            if (prev + Mb + rest_after >= thr) {
+                const int thr_b = thr - prev - rest_after;  // what this block has to contribute for the model to matter
+                float m32[9];
 #pragma unroll
-            for (int i = 0; i < 9; ++i) m32[i] = readlane_f32(hl.m[i], t);
-            const float kE = readlane_f32(hl.kE, t), kW = readlane_f32(hl.kW, t), K0 = readlane_f32(hl.K0, t);
-            bool und;
-            int cc = count_h32<NP>(m32, kE, kW, K0, A2, B2, C2, D2, v_lo, v_hi, M, thr, und);
+                for (int i = 0; i < 9; ++i) m32[i] = readlane_f32(hl.m[i], t);
+                const float kE = readlane_f32(hl.kE, t), kW = readlane_f32(hl.kW, t), K0 = readlane_f32(hl.K0, t);
+                bool und;
+                cc = count_h32<NP>(m32, kE, kW, K0, A2, B2, C2, D2, v_lo, v_hi, Mb, thr_b, und);
 #if defined(AMC_TVG_DIAG) && (AMC_TVG_DIAG & 8)
-            {
-                double sm[9];
+                {
+                    double sm[9];
 #pragma unroll
-                for (int i = 0; i < 9; ++i) sm[i] = readlane_f64(mym[i], t);
-                const int c64 = count_regs<K_H, NB>(sm, a, b, c, d, last_valid, M, max_res, 0);
-                bool und2;
-                const int c32 = count_h32<NP>(m32, kE, kW, K0, A2, B2, C2, D2, v_lo, v_hi, M, 0, und2);
-                if (lane == 0) {
-                    atomicAdd(&g_h32_diag[0], 1ull);
-                    if (und2) atomicAdd(&g_h32_diag[1], 1ull);
-                    else if (c32 != c64) atomicAdd(&g_h32_diag[2], 1ull);
+                    for (int i = 0; i < 9; ++i) sm[i] = readlane_f64(mym[i], t);
+                    const int c64 = count_regs<K_H, NB>(sm, a, b, c, d, last_valid, Mb, max_res, 0);
+                    bool und2;
+                    const int c32 = count_h32<NP>(m32, kE, kW, K0, A2, B2, C2, D2, v_lo, v_hi, Mb, 0, und2);
+                    if (lane == 0) {
+                        atomicAdd(&g_h32_diag[0], 1ull);
+                        if (und2) atomicAdd(&g_h32_diag[1], 1ull);
+                        else if (c32 != c64) atomicAdd(&g_h32_diag[2], 1ull);
+                    }
+                }
+#endif
+                if (und) {
+                    double sm[9];
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) sm[i] = readlane_f64(mym[i], t);
+                    cc = count_regs<K_H, NB>(sm, a, b, c, d, last_valid, Mb, max_res, thr_b);
                 }
             }
-#endif
-            if (und) {
-                double sm[9];
-#pragma unroll
-                for (int i = 0; i < 9; ++i) sm[i] = readlane_f64(mym[i], t);
-                cc = count_regs<K_H, NB>(sm, a, b, c, d, last_valid, M, max_res, thr);
-            }
-            if (lane == t) maxcnt = max(maxcnt, cc);
+            if (lane == t) acc[0] += cc;
         }
-        return maxcnt;
+        return;
     }
     for (int t = 0; t < nT; ++t) {
         const int n = __builtin_amdgcn_readlane(nmod, t);
-        for (int m = 0; m < (KIND == K_E5 ? n : NM); ++m) {
-            if (m >= n) break;
-            double sm[9];
-            if (KIND == K_E5) {
-                const double* src = models + ((size_t)t * kMaxModels + m) * 9;
 #pragma unroll
-                for (int i = 0; i < 9; ++i) sm[i] = readlane_f64(src[i], 0);
-            } else {
+        for (int m = 0; m < NMX; ++m) {
+            if (m >= n) continue;  // (uniform; `break` would keep the loop from unrolling and acc[m] from registers)
+            const int prev = __builtin_amdgcn_readlane(acc[m], t);
+            int cc = Mb;
+            if (prev + Mb + rest_after >= thr) {
+                double sm[9];
+                if (KIND == K_E5) {
+                    const double* src = models + ((size_t)t * kMaxModels + m) * 9;
 #pragma unroll
-                for (int i = 0; i < 9; ++i) sm[i] = readlane_f64(mym[9 * (NM == 1 ? 0 : m) + i], t);
+                    for (int i = 0; i < 9; ++i) sm[i] = readlane_f64(src[i], 0);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) sm[i] = readlane_f64(mym[9 * (NM == 1 ? 0 : m) + i], t);
+                }
+                cc = count_regs<(KIND == K_E5 ? K_F7 : KIND), NB>(sm, a, b, c, d, last_valid, Mb, max_res, thr - prev - rest_after);
             }
-            const int cc = count_regs<(KIND == K_E5 ? K_F7 : KIND), NB>(sm, a, b, c, d, last_valid, M, max_res, thr);
-            if (lane == t) maxcnt = max(maxcnt, cc);
+            if (lane == t) acc[m] += cc;
         }
     }
-    return maxcnt;
 }
+template <int KIND, int NM>
+__device__ __forceinline__ void count_block_regs_nb(const double (&mym)[27], const double* models, int nmod, const Pts& P,
+                                                    int off, int Mb, int rest_after, double max_res, int nT, int lane, int thr,
+                                                    double cmax, int (&acc)[(KIND == K_E5 ? kMaxModels : NM)]) {
+#define AMC_CB(NB_) case NB_: count_block_regs<KIND, NM, NB_>(mym, models, nmod, P, off, Mb, rest_after, max_res, nT, lane, thr, cmax, acc); break;
+    switch ((Mb + 63) / 64) {
+        AMC_CB(1) AMC_CB(2) AMC_CB(3) AMC_CB(4) AMC_CB(5) AMC_CB(6) AMC_CB(7) AMC_CB(8) AMC_CB(9) AMC_CB(10) AMC_CB(11)
+        default: count_block_regs<KIND, NM, 12>(mym, models, nmod, P, off, Mb, rest_after, max_res, nT, lane, thr, cmax, acc); break;
+    }
+#undef AMC_CB
+}
+constexpr int kRegBlock = 768;  // 12 batches of 64: 96 VGPRs of points (the phase has 256 to itself)
+// all M correspondences, kRegBlock at a time; returns (lane t) the largest count among trial t's models, each either
+// exact or an upper bound below `thr`
 template <int KIND, int NM>
 __device__ __forceinline__ int count_chunk_regs_nb(const double (&mym)[27], const double* models, int nmod, const Pts& P,
                                                    int M, double max_res, int nT, int lane, int thr, double cmax) {
-    switch ((M + 63) / 64) {
-        case 1: return count_chunk_regs<KIND, NM, 1>(mym, models, nmod, P, M, max_res, nT, lane, thr, cmax);
-        case 2: return count_chunk_regs<KIND, NM, 2>(mym, models, nmod, P, M, max_res, nT, lane, thr, cmax);
-        case 3: return count_chunk_regs<KIND, NM, 3>(mym, models, nmod, P, M, max_res, nT, lane, thr, cmax);
-        case 4: return count_chunk_regs<KIND, NM, 4>(mym, models, nmod, P, M, max_res, nT, lane, thr, cmax);
-        case 5: return count_chunk_regs<KIND, NM, 5>(mym, models, nmod, P, M, max_res, nT, lane, thr, cmax);
-        case 6: return count_chunk_regs<KIND, NM, 6>(mym, models, nmod, P, M, max_res, nT, lane, thr, cmax);
-        case 7: return count_chunk_regs<KIND, NM, 7>(mym, models, nmod, P, M, max_res, nT, lane, thr, cmax);
-        case 8: return count_chunk_regs<KIND, NM, 8>(mym, models, nmod, P, M, max_res, nT, lane, thr, cmax);
-        case 9: return count_chunk_regs<KIND, NM, 9>(mym, models, nmod, P, M, max_res, nT, lane, thr, cmax);
-        case 10: return count_chunk_regs<KIND, NM, 10>(mym, models, nmod, P, M, max_res, nT, lane, thr, cmax);
-        case 11: return count_chunk_regs<KIND, NM, 11>(mym, models, nmod, P, M, max_res, nT, lane, thr, cmax);
-        default: return count_chunk_regs<KIND, NM, 12>(mym, models, nmod, P, M, max_res, nT, lane, thr, cmax);
+    constexpr int NMX = KIND == K_E5 ? kMaxModels : NM;
+    int acc[NMX];
+#pragma unroll
+    for (int m = 0; m < NMX; ++m) acc[m] = 0;
+    for (int off = 0; off < M; off += kRegBlock) {
+        const int Mb = min(kRegBlock, M - off);
+        count_block_regs_nb<KIND, NM>(mym, models, nmod, P, off, Mb, M - off - Mb, max_res, nT, lane, thr, cmax, acc);
     }
+    int maxcnt = -1;
+#pragma unroll
+    for (int m = 0; m < NMX; ++m)
+        if (m < nmod) maxcnt = max(maxcnt, acc[m]);
+    return maxcnt;
 }
-constexpr int kRegCountMaxM = 768;  // 12 batches of 64: 96 VGPRs of points (the phase has 256 to itself)
 
 __device__ __noinline__ void solve_chunk(ChunkModels* out, int est, const Pts P, const lds_u16* sidx, int nT,
                                          int lane, double* models) {
@@ -1438,7 +1464,7 @@ __device__ __noinline__ void count_chunk(ChunkModels* io, int est_, const Pts P_
     const int nmod = io->nmod;
     int maxcnt;
     // the points of nearly every pair fit the LDS share; the global-memory path keeps the exact test only
-    if (fast && M <= kRegCountMaxM && M >= 1 && est != K_T) {
+    if (fast && M >= 1 && est != K_T) {
         if (est == K_F7) maxcnt = count_chunk_regs_nb<K_F7, 3>(mym, models, nmod, P, M, max_res, nT, lane, thr, cmax);
         else if (est == K_H) maxcnt = count_chunk_regs_nb<K_H, 1>(mym, models, nmod, P, M, max_res, nT, lane, thr, cmax);
         else maxcnt = count_chunk_regs_nb<K_E5, 1>(mym, models, nmod, P, M, max_res, nT, lane, thr, cmax);
