@@ -28,6 +28,11 @@ except ImportError as _e:  # pragma: no cover - exercised only on an unbuilt tre
     _HOST_LAYER_ERROR = _e
 
     def __getattr__(name):
+        # submodules (`from pycolmap_amd import build`, `_capi`, `synth`, ...) must stay importable on an unbuilt tree:
+        # the import machinery asks the package for the attribute first and imports the submodule on AttributeError
+        import importlib.util
+        if name.startswith("__") or importlib.util.find_spec(f"{__name__}.{name}") is not None:
+            raise AttributeError(name)
         raise ImportError(
             f"pycolmap_amd.{name}: the compiled host layer is missing ({_HOST_LAYER_ERROR}); run "
             "`python -m pycolmap_amd.build` (needs hipcc + g++). pycolmap_amd has no Python/CPU fallback.")

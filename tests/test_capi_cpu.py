@@ -41,3 +41,23 @@ def test_struct_layout_matches_header():
     # amc_match_opts: 2 doubles + 2 int32 = 24 bytes; amc_match_result ends with a pointer
     assert ctypes.sizeof(_capi.MatchOpts) == 24
     assert ctypes.sizeof(_capi.MatchResult) == 8 * 3 + 8 * 4 + 8 * 3 + 8 + 8
+
+
+def test_submodules_import_on_an_unbuilt_tree(tmp_path):
+    """A fresh checkout has no compiled host layer: `from pycolmap_amd import build` (what __graft_entry__.build() does
+    first) must still work, and asking for an API name must say what is missing."""
+    import shutil
+    import subprocess
+    import sys
+    pkg = tmp_path / "pycolmap_amd"
+    pkg.mkdir()
+    src = Path(__file__).resolve().parent.parent / "pycolmap_amd"
+    for f in src.glob("*.py"):
+        shutil.copy(f, pkg / f.name)
+    code = ("from pycolmap_amd import build, synth\n"
+            "import pycolmap_amd\n"
+            "try:\n    pycolmap_amd.match_exhaustive\nexcept ImportError as e:\n    assert 'pycolmap_amd.build' in str(e)\n"
+            "else:\n    raise SystemExit('no error for a missing host layer')\n"
+            "print('ok')\n")
+    r = subprocess.run([sys.executable, "-c", code], cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.strip() == "ok", r.stderr
