@@ -17,7 +17,8 @@ try:  # the compiled host layer; absent only before `python -m pycolmap_amd.buil
     from ._pycolmap import (  # noqa: F401
         COLMAP_build, COLMAP_version, Camera, CameraModelId, Database, Device, ExhaustiveMatchingOptions, RANSACOptions, Rigid3d,
         Rotation3d,
-        SequentialMatchingOptions, SiftMatchingOptions, TwoViewGeometry, TwoViewGeometryConfiguration,
+        SequentialMatchingOptions, SiftMatchingOptions, SpatialMatchingOptions, TwoViewGeometry, TwoViewGeometryConfiguration,
+        VocabTreeMatchingOptions,
         TwoViewGeometryOptions, essential_matrix_estimation, estimate_calibrated_two_view_geometry,
         estimate_two_view_geometry, estimate_two_view_geometry_pose, fundamental_matrix_estimation, has_cuda,
         has_hip, homography_matrix_estimation, last_run_stats, logging, match_exhaustive, match_sequential,

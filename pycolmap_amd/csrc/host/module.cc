@@ -421,6 +421,38 @@ PYBIND11_MODULE(_pycolmap, m) {
                           "loop_detection_num_images_after_verification", "loop_detection_max_num_features",
                           "vocab_tree_path"});
 
+    // match_spatial / match_vocabtree are outside this library's scope, but their option classes
+    // exist so that a script written for the reference constructs them without error and fails at the call, with
+    // the reason (/root/reference/pycolmap/pipeline/match_features.h:154-214; defaults of COLMAP 3.9.1)
+    struct SpatialMatchingOptions {
+        bool is_gps = true, ignore_z = true;
+        int max_num_neighbors = 50;
+        double max_distance = 100.0;
+    };
+    struct VocabTreeMatchingOptions {
+        int num_images = 100, num_nearest_neighbors = 5, num_checks = 256, num_images_after_verification = 0;
+        int max_num_features = -1;
+        std::string vocab_tree_path, match_list_path;
+    };
+    py::class_<SpatialMatchingOptions> PySp(m, "SpatialMatchingOptions");
+    PySp.def(py::init<>())
+        .def_readwrite("is_gps", &SpatialMatchingOptions::is_gps)
+        .def_readwrite("ignore_z", &SpatialMatchingOptions::ignore_z)
+        .def_readwrite("max_num_neighbors", &SpatialMatchingOptions::max_num_neighbors)
+        .def_readwrite("max_distance", &SpatialMatchingOptions::max_distance);
+    MakeDataclass(PySp, {"is_gps", "ignore_z", "max_num_neighbors", "max_distance"});
+    py::class_<VocabTreeMatchingOptions> PyVt(m, "VocabTreeMatchingOptions");
+    PyVt.def(py::init<>())
+        .def_readwrite("num_images", &VocabTreeMatchingOptions::num_images)
+        .def_readwrite("num_nearest_neighbors", &VocabTreeMatchingOptions::num_nearest_neighbors)
+        .def_readwrite("num_checks", &VocabTreeMatchingOptions::num_checks)
+        .def_readwrite("num_images_after_verification", &VocabTreeMatchingOptions::num_images_after_verification)
+        .def_readwrite("max_num_features", &VocabTreeMatchingOptions::max_num_features)
+        .def_readwrite("vocab_tree_path", &VocabTreeMatchingOptions::vocab_tree_path)
+        .def_readwrite("match_list_path", &VocabTreeMatchingOptions::match_list_path);
+    MakeDataclass(PyVt, {"num_images", "num_nearest_neighbors", "num_checks", "num_images_after_verification",
+                         "max_num_features", "vocab_tree_path", "match_list_path"});
+
     py::class_<TwoViewGeometryOptions> PyTvgO(m, "TwoViewGeometryOptions");
     PyTvgO.def(py::init<>())  // C++ defaults, incl. the C++ RANSAC defaults
         .def_readwrite("min_num_inliers", &TwoViewGeometryOptions::min_num_inliers)
