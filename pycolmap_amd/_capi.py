@@ -47,6 +47,19 @@ class _MatchLease:
             pass
 
 
+class _VerifyLease:
+    """Owns one amc_verify_result; frees it when the arrays viewing it are gone."""
+
+    def __init__(self, lib, res):
+        self._lib, self._res = lib, res
+
+    def __del__(self):
+        try:
+            self._lib.amc_verify_result_free(C.byref(self._res))
+        except Exception:  # interpreter shutdown
+            pass
+
+
 class _LeasedArray(np.ndarray):
     """ndarray view that keeps its lease alive (numpy views of it inherit the reference through .base)."""
 
@@ -318,21 +331,23 @@ class Context:
         return offsets, matches, stats
 
     @staticmethod
-    def _unpack_verify(res, total, labelled=False):
-        """Copies the result out (one copy per array).  `labelled`: the mask holds geometry labels (multiple_models)
-        rather than 0 / 1."""
+    def _unpack_verify(res, total, labelled=False, lease=None):
+        """The result as numpy arrays: copies (one per array), or - with a lease, which then owns the C result -
+        views of the library's own buffers.  `labelled`: the mask holds geometry labels (multiple_models) rather
+        than 0 / 1."""
         n = int(res.npairs)
         assert C.sizeof(Tvg) == TVG_DTYPE.itemsize
 
-        def copy_of(ptr, count, dtype):
+        def take(ptr, count, dtype):
             nbytes = count * np.dtype(dtype).itemsize
             if not nbytes:
                 return np.zeros(0, dtype=dtype)
             addr = C.cast(ptr, C.c_void_p).value
-            return np.frombuffer((C.c_char * nbytes).from_address(addr), dtype=dtype).copy()
+            a = np.frombuffer((C.c_char * nbytes).from_address(addr), dtype=dtype)
+            return a.copy() if lease is None else _LeasedArray.wrap(a, lease)
 
-        tvg = copy_of(res.tvg, n, TVG_DTYPE)
-        labels = copy_of(res.inlier_mask, total, np.uint8)
+        tvg = take(res.tvg, n, TVG_DTYPE)
+        labels = take(res.inlier_mask, total, np.uint8)
         mask = labels.astype(bool) if labelled else labels.view(np.bool_)   # 0 / 1 bytes are numpy bools as they are
         # inlier_labels: 1 + index of the geometry a match belongs to (multiple_models), else 0 / 1
         stats = dict(device_ms=float(res.device_ms), kernel_ms=float(res.kernel_ms), inlier_labels=labels,
@@ -340,7 +355,7 @@ class Context:
         stats["pose_kernel_ms"] = float(res.pose_kernel_ms)
         if res.pose:  # compute_relative_pose: one amc_pose per pair
             assert C.sizeof(Pose) == POSE_DTYPE.itemsize
-            stats["pose"] = copy_of(res.pose, n, POSE_DTYPE)
+            stats["pose"] = take(res.pose, n, POSE_DTYPE)
         return tvg, mask, stats
 
     def match_verify_pairs(self, slot1, slot2, opts: TvgOpts | None = None, seed: int = 0, max_ratio: float = 0.8,
@@ -472,9 +487,11 @@ class Context:
                                            p.ctypes.data_as(C.c_void_p), p.size,
                                            int(has_prior_focal_length)))
 
-    def verify_pairs(self, slot1, slot2, match_offsets, matches, opts: TvgOpts | None = None, seed: int = 0):
+    def verify_pairs(self, slot1, slot2, match_offsets, matches, opts: TvgOpts | None = None, seed: int = 0,
+                     copy: bool = True):
         """EstimateTwoViewGeometry per pair. Returns (tvg structured array [npairs], inlier_mask
-        bool [total matches], stats)."""
+        bool [total matches], stats).  copy=False: the arrays are views of the library's result buffers (as a C++
+        caller reads them), released when the last of them is garbage collected."""
         s1 = np.ascontiguousarray(slot1, dtype=np.uint32)
         s2 = np.ascontiguousarray(slot2, dtype=np.uint32)
         off = np.ascontiguousarray(match_offsets, dtype=np.uint64)
@@ -488,6 +505,8 @@ class Context:
         _check(self._lib.amc_verify_pairs(self._h, s1.ctypes.data_as(C.c_void_p), s2.ctypes.data_as(C.c_void_p),
                                           s1.size, off.ctypes.data_as(C.c_void_p), m.ctypes.data_as(C.c_void_p),
                                           C.byref(o), seed, C.byref(res)))
+        if not copy:
+            return self._unpack_verify(res, m.shape[0], bool(o.multiple_models), _VerifyLease(self._lib, res))
         try:
             tvg, mask, stats = self._unpack_verify(res, m.shape[0], bool(o.multiple_models))
         finally:

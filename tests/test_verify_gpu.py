@@ -374,3 +374,23 @@ def test_fused_match_verify_equals_the_two_calls(amc_ctx, monkeypatch, pose):
     z = np.zeros(0, np.uint32)
     foff, fm, _, ftvg, fmask, _ = amc_ctx.match_verify_pairs(z, z, opts)
     assert len(foff) == 1 and len(fm) == 0 and len(ftvg) == 0
+
+
+def test_result_views_equal_copies_and_outlive_the_call(amc_ctx):
+    """verify_pairs(copy=False): the arrays are views of the library's result, released with the last of them."""
+    import gc
+    rng = np.random.default_rng(77)
+    sc = synth.two_view_scene(rng, num_inliers=120, num_outliers=50)
+    amc_ctx.reserve_slots(2)
+    for j, pts in enumerate((sc["pts1"], sc["pts2"])):
+        amc_ctx.upload_keypoints(j, pts.astype(np.float32))
+        amc_ctx.upload_camera(j, "PINHOLE", sc["width"], sc["height"], (sc["f"], sc["f"], sc["width"] / 2.0, sc["height"] / 2.0), True)
+    off = np.array([0, len(sc["matches"])], np.uint64)
+    a = amc_ctx.verify_pairs([0], [1], off, sc["matches"], _capi.tvg_options())
+    b = amc_ctx.verify_pairs([0], [1], off, sc["matches"], _capi.tvg_options(), copy=False)
+    assert a[0].tobytes() == b[0].tobytes() and np.array_equal(a[1], b[1]) and a[1].dtype == b[1].dtype == np.bool_
+    part = b[1][3:40]
+    want = a[1][3:40].copy()
+    del b
+    gc.collect()
+    np.testing.assert_array_equal(part, want)      # the slice keeps the result alive
