@@ -446,62 +446,15 @@ constexpr size_t kMaxMatchCap = (size_t)256 << 20;     // worst-case matches of 
 }  // namespace
 
 // Whether a guided pair may take the candidate-generation kernel (match_guided.hip), and what that kernel needs
-// beyond the float model: it is exact as long as the float32 filter cannot return NaN (NaN > t is false = "not
-// rejected" for EVERY pairing, which no geometric candidate set contains) and its conservative regions hold -
-// finite, sanely scaled models and keypoints.  Anything else keeps the dense kernel, which evaluates the filter
-// on all n1 x n2 pairings.
+// beyond the float model: guided_region.h's guided_pair_setup on the two images' keypoint boxes.  Anything it turns
+// down keeps the dense kernel, which evaluates the filter on all n1 x n2 pairings.
 static void guided_grid_setup(GuidedDev& g, const GridDev& g1, const GridDev& g2, bool dense_only) {
     g.grid_ok = 0;
     g.bound[0] = g.bound[1] = 0.0;
     for (int k = 0; k < 9; ++k) g.minv[k] = 0.0;
     if (dense_only || g1.n == 0 || g2.n == 0) return;
-    double m[9], mx = 0.0;
-    for (int k = 0; k < 9; ++k) {
-        m[k] = (double)g.m[k];
-        if (!std::isfinite(m[k])) return;
-        mx = std::max(mx, std::fabs(m[k]));
-    }
-    if (!(mx > 1e-12) || !(mx < 1e12) || !std::isfinite(g.max_residual) || !(g.max_residual >= 0.f)) return;
-    const double c1[4][2] = {{g1.x0, g1.y0}, {g1.bx1, g1.y0}, {g1.x0, g1.by1}, {g1.bx1, g1.by1}};
-    const double c2[4][2] = {{g2.x0, g2.y0}, {g2.bx1, g2.y0}, {g2.x0, g2.by1}, {g2.bx1, g2.by1}};
-    for (int k = 0; k < 4; ++k)
-        if (std::fabs(c1[k][0]) > 1e7 || std::fabs(c1[k][1]) > 1e7 || std::fabs(c2[k][0]) > 1e7 || std::fabs(c2[k][1]) > 1e7) return;
-    if (g.kind == kGuidedF) {
-        // |F^T x2|_12^2 and |F x1|_12^2 are convex in the point: their maxima over a box are at its corners
-        for (int k = 0; k < 4; ++k) {
-            const double u0 = m[0] * c2[k][0] + m[3] * c2[k][1] + m[6], u1 = m[1] * c2[k][0] + m[4] * c2[k][1] + m[7];
-            const double v0 = m[0] * c1[k][0] + m[1] * c1[k][1] + m[2], v1 = m[3] * c1[k][0] + m[4] * c1[k][1] + m[5];
-            g.bound[0] = std::max(g.bound[0], u0 * u0 + u1 * u1);
-            g.bound[1] = std::max(g.bound[1], v0 * v0 + v1 * v1);
-        }
-        // a little room for the filter's float32 rounding of these terms
-        g.bound[0] *= 1.001;
-        g.bound[1] *= 1.001;
-        if (!(g.bound[0] < 1e30) || !(g.bound[1] < 1e30)) return;
-        g.grid_ok = 1;
-        return;
-    }
-    // H: the projective division must keep one sign, well away from zero, over image 1's keypoint box (then the
-    // filter never divides by zero and the points H maps into a box are the H^-1 image of that box)
-    bool pos = false, neg = false;
-    for (int k = 0; k < 4; ++k) {
-        const double w = m[6] * c1[k][0] + m[7] * c1[k][1] + m[8];
-        const double wmag = std::fabs(m[6] * c1[k][0]) + std::fabs(m[7] * c1[k][1]) + std::fabs(m[8]);
-        if (!(std::fabs(w) > 1e-3 * wmag) || !(wmag > 1e-30)) return;
-        pos |= w > 0.0;
-        neg |= w < 0.0;
-    }
-    if (pos && neg) return;
-    const double det = m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6]);
-    if (!(std::fabs(det) > 1e-9 * mx * mx * mx)) return;
-    const double adj[9] = {m[4] * m[8] - m[5] * m[7], m[2] * m[7] - m[1] * m[8], m[1] * m[5] - m[2] * m[4],
-                           m[5] * m[6] - m[3] * m[8], m[0] * m[8] - m[2] * m[6], m[2] * m[3] - m[0] * m[5],
-                           m[3] * m[7] - m[4] * m[6], m[1] * m[6] - m[0] * m[7], m[0] * m[4] - m[1] * m[3]};
-    for (int k = 0; k < 9; ++k) {
-        g.minv[k] = adj[k] / det;
-        if (!std::isfinite(g.minv[k])) return;
-    }
-    g.grid_ok = 1;
+    const float box1[4] = {g1.x0, g1.y0, g1.bx1, g1.by1}, box2[4] = {g2.x0, g2.y0, g2.bx1, g2.by1};
+    g.grid_ok = guided::guided_pair_setup(g.kind, g.m, g.max_residual, box1, box2, g.bound, g.minv) ? 1 : 0;
 }
 
 // amc_match_pairs, and with `geoms` != nullptr guided matching (every pair then runs the dot4
@@ -1018,34 +971,13 @@ void amc_tvg_opts_default(amc_tvg_opts* o) {
 // Guided matching's candidate generation (match_guided.hip): bucket the image's keypoints on a kGridDim^2 grid
 // over their bounding box.  No grid (grid.n = 0) when a coordinate is not finite: such pairs take the dense kernel.
 static int build_keypoint_grid(Slot& s, const float* xy, uint32_t rows) {
-    float x0 = xy[0], y0 = xy[1], x1 = xy[0], y1 = xy[1];
-    for (uint32_t i = 0; i < rows; ++i) {
-        const float x = xy[2 * (size_t)i], y = xy[2 * (size_t)i + 1];
-        if (!std::isfinite(x) || !std::isfinite(y)) return AMC_OK;
-        x0 = std::min(x0, x); x1 = std::max(x1, x);
-        y0 = std::min(y0, y); y1 = std::max(y1, y);
-    }
+    guided::GridGeom gg;
+    std::vector<uint32_t> sidx, start;
+    if (!guided::build_grid(xy, rows, gg, sidx, start)) return AMC_OK;
     GridDev g{};
-    g.x0 = x0;
-    g.y0 = y0;
-    g.cw = std::max((x1 - x0) / (float)kGridDim, 1e-3f);
-    g.ch = std::max((y1 - y0) / (float)kGridDim, 1e-3f);
-    if (!std::isfinite(g.cw) || !std::isfinite(g.ch)) return AMC_OK;  // (extent overflows float)
-    g.inv_cw = 1.0f / g.cw;
-    g.inv_ch = 1.0f / g.ch;
-    g.bx1 = x1;
-    g.by1 = y1;
+    g.x0 = gg.x0; g.y0 = gg.y0; g.cw = gg.cw; g.ch = gg.ch; g.inv_cw = gg.inv_cw; g.inv_ch = gg.inv_ch;
+    g.bx1 = gg.bx1; g.by1 = gg.by1;
     g.n = rows;
-    const size_t ncell = (size_t)kGridDim * kGridDim;
-    std::vector<uint32_t> cell(rows), start(ncell + 1, 0), sidx(rows);
-    for (uint32_t i = 0; i < rows; ++i) {
-        const int gx = grid_cell(xy[2 * (size_t)i], g.x0, g.inv_cw), gy = grid_cell(xy[2 * (size_t)i + 1], g.y0, g.inv_ch);
-        cell[i] = (uint32_t)(gy * kGridDim + gx);
-        ++start[cell[i] + 1];
-    }
-    for (size_t k = 0; k < ncell; ++k) start[k + 1] += start[k];
-    std::vector<uint32_t> cur(start.begin(), start.end() - 1);
-    for (uint32_t i = 0; i < rows; ++i) sidx[cur[cell[i]]++] = i;
     std::vector<float> sxy((size_t)rows * 2);
     for (uint32_t k = 0; k < rows; ++k) {
         sxy[2 * (size_t)k] = xy[2 * (size_t)sidx[k]];

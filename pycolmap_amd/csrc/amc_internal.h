@@ -6,6 +6,7 @@
 #include <stdint.h>
 
 #include "../../include/amc.h"
+#include "guided_region.h"
 
 namespace amc {
 
@@ -47,7 +48,7 @@ struct GuidedDev {
 // over their bounding box (built once per upload, amc_upload_keypoints).  Cell (gx, gy) has id gy * kGridDim + gx;
 // cell_start is the CSR of the keypoints sorted by cell id, so the keypoints of cells gx0..gx1 of one grid row
 // are one contiguous range of sxy / sidx.
-constexpr int kGridDim = 64;
+using guided::kGridDim;
 struct GridDev {
     const float* sxy;            // n x 2: keypoints in cell order
     const uint32_t* sidx;        // n: their original indices
@@ -58,13 +59,7 @@ struct GridDev {
     uint32_t n;                  // keypoints on the grid (0: no grid - non-finite coordinates or no keypoints)
     uint32_t pad_;
 };
-// the cell coordinate of v along one axis: the same float operations on the host (grid build) and in the kernel
-// (range lookup), monotone in v, so a coordinate interval maps to the cell interval of its end points
-__host__ __device__ inline int grid_cell(float v, float v0, float inv) {
-    const float t = floorf((v - v0) * inv);
-    return t < 0.f ? 0 : (t > (float)(kGridDim - 1) ? kGridDim - 1 : (int)t);
-}
-
+using guided::grid_cell;
 #if defined(__HIPCC__)
 // Guided matching's float32 filter (SiftCPUFeatureMatcher::MatchGuided; oracle_guided_filter in
 // oracle/match_oracle.c spells out the operation order): true = this (image-1 point, image-2 point)

@@ -48,10 +48,6 @@ __device__ __forceinline__ void lds_sync() {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-__device__ __forceinline__ bool finite_d(double v) { return v - v == 0.0; }
-// hardware approximations (relative error ~1e-8): the regions below carry 2 % and a pixel of slack
-__device__ __forceinline__ double arcp(double v) { return __builtin_amdgcn_rcp(v); }
-__device__ __forceinline__ double asqrt(double v) { return __builtin_amdgcn_sqrt(v); }
 
 }  // namespace
 
@@ -96,10 +92,8 @@ __global__ __launch_bounds__(256) void match_guided_grid_kernel(const ImageDev* 
     const double T = (double)gd.max_residual;
     // lane = grid row: the y interval its keypoints lie in (1 % of a cell on either side covers the float
     // rounding of grid_cell)
-    const double ylo = (double)G.y0 + ((double)lane - 0.01) * (double)G.ch;
-    const double yhi = (double)G.y0 + ((double)lane + 1.01) * (double)G.ch;
-    const double gx_lo = (double)G.x0 - 1.0, gx_hi = (double)G.bx1 + 1.0;
-    const double kInf = __longlong_as_double(0x7FF0000000000000ll);
+    double ylo, yhi;
+    guided::grid_row_interval(G.y0, G.ch, lane, ylo, yhi);
 
     for (int rr = 0; rr < 16; ++rr) {
         const uint32_t row = w.rb * 64 + (uint32_t)wid * 16 + (uint32_t)rr;  // wave-uniform
@@ -118,85 +112,13 @@ __global__ __launch_bounds__(256) void match_guided_grid_kernel(const ImageDev* 
             for (int i = 0; i < 32; ++i) xd[i] = (uint32_t)__builtin_amdgcn_readlane((int)v, i);
         }
 
-        // ---- the acceptance region's cells in this lane's grid row: [xa, xb], or nothing ----
-        bool full = false, none = false;
-        double xa = -kInf, xb = kInf;
-        if (gd.kind == kGuidedF) {
-            double a, b, c;
-            if (dir == 0) {  // l = F p: the line of p in image 2
-                a = m[0] * px + m[1] * py + m[2];
-                b = m[3] * px + m[4] * py + m[5];
-                c = m[6] * px + m[7] * py + m[8];
-            } else {         // l = F^T p: the line of p in image 1
-                a = m[0] * px + m[3] * py + m[6];
-                b = m[1] * px + m[4] * py + m[7];
-                c = m[2] * px + m[5] * py + m[8];
-            }
-            const double L2 = a * a + b * b;
-            // Sampson <= T  =>  (l . q)^2 <= T (|l|^2 + |other|^2) <= T (L2 + bound); one pixel on top
-            const double W = asqrt(T * (L2 + bound)) * 1.02 + asqrt(L2);
-            if (!(L2 > 1e-30) || !(L2 < 1e30) || !(W < 1e300)) {
-                full = true;
-            } else {
-                const double t0 = -(b * ylo + c), t1 = -(b * yhi + c);  // a x in [t - W, t + W]
-                const double lo = fmin(t0, t1) - W, hi = fmax(t0, t1) + W;
-                const double ia = arcp(a);  // (+-inf for a = +-0; not used then)
-                if (a > 0.0) { xa = lo * ia; xb = hi * ia; }
-                else if (a < 0.0) { xa = hi * ia; xb = lo * ia; }
-                else if (!(lo <= 0.0 && hi >= 0.0)) none = true;
-                if (xa != xa || xb != xb) { xa = -kInf; xb = kInf; }  // 0 * inf of a denormal a: every cell of the row
-            }
-        } else if (dir == 0) {  // box around hnormalized(H p)
-            const double wq = m[6] * px + m[7] * py + m[8];
-            const double wmag = fabs(m[6] * px) + fabs(m[7] * py) + fabs(m[8]);
-            const double iw = arcp(wq);
-            const double cx = (m[0] * px + m[1] * py + m[2]) * iw;
-            const double cy = (m[3] * px + m[4] * py + m[5]) * iw;
-            const double r = asqrt(T) * 1.02 + 1.0;
-            if (!(fabs(wq) > 1e-4 * wmag) || !(wmag > 1e-30) || !finite_d(cx) || !finite_d(cy) || !(r < 1e300)) {
-                full = true;
-            } else if (yhi < cy - r || ylo > cy + r) {
-                none = true;
-            } else {
-                xa = cx - r;
-                xb = cx + r;
-            }
-        } else {  // p is an image-2 point: candidates are the image-1 points H maps into the box around p
-            const double r = asqrt(T) * 1.02 + 1.0;
-            double xmin = kInf, xmax = -kInf, ymin = kInf, ymax = -kInf;
-            bool pos = false, neg = false, bad = !(r < 1e300);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const double qx = px + ((k & 1) ? r : -r), qy = py + ((k & 2) ? r : -r);
-                const double wk = gd.minv[6] * qx + gd.minv[7] * qy + gd.minv[8];
-                const double wmag = fabs(gd.minv[6] * qx) + fabs(gd.minv[7] * qy) + fabs(gd.minv[8]);
-                const double iw = arcp(wk);
-                const double ux = (gd.minv[0] * qx + gd.minv[1] * qy + gd.minv[2]) * iw;
-                const double uy = (gd.minv[3] * qx + gd.minv[4] * qy + gd.minv[5]) * iw;
-                pos |= wk > 0.0;
-                neg |= wk < 0.0;
-                bad |= !(fabs(wk) > 1e-4 * wmag) || !finite_d(ux) || !finite_d(uy);
-                xmin = fmin(xmin, ux); xmax = fmax(xmax, ux);
-                ymin = fmin(ymin, uy); ymax = fmax(ymax, uy);
-            }
-            if (bad || (pos && neg)) {
-                full = true;
-            } else {
-                const double sl = 1e-3 * ((double)G.cw + (double)G.ch);
-                if (yhi < ymin - sl || ylo > ymax + sl) none = true;
-                xa = xmin - sl;
-                xb = xmax + sl;
-            }
-        }
-        if (full) {
-            none = false;
-            xa = -kInf;
-            xb = kInf;
-        }
+        // ---- the acceptance region's cells in this lane's grid row: [xa, xb], or nothing (guided_region.h) ----
+        double xa, xb;
+        const bool none = !guided::guided_row_region(gd.kind, (int)dir, m, gd.minv, T, bound, px, py, ylo, yhi,
+                                                     (double)G.cw + (double)G.ch, xa, xb);
         uint32_t s0 = 0, len = 0;
-        if (!none && xb >= gx_lo && xa <= gx_hi) {
-            const int gx0 = grid_cell((float)fmax(xa, gx_lo), G.x0, G.inv_cw);
-            const int gx1 = grid_cell((float)fmin(xb, gx_hi), G.x0, G.inv_cw);
+        int gx0, gx1;
+        if (!none && guided::grid_cells_of(xa, xb, G.x0, G.bx1, G.inv_cw, gx0, gx1)) {
             s0 = G.cell_start[lane * kGridDim + gx0];
             len = G.cell_start[lane * kGridDim + gx1 + 1] - s0;
         }
