@@ -1208,31 +1208,7 @@ __device__ __forceinline__ int count_regs(const double (&sm)[9], const double (&
 // Checked by a diagnostic build that counts every model both ways (tools/diag_build_tvg.sh 8): 80 million models of
 // the bench's verify leg, 3.9 % undecided, no decided model with a count different from the FP64 path's.
 typedef float v2f __attribute__((ext_vector_type(2)));
-struct H32Lane {
-    float m[9];
-    float kE, kW, K0;
-};
-__device__ __forceinline__ float f32_up(double v) {  // a float >= v (v >= 0)
-    return (float)(v * (1.0 + 1e-6));
-}
-__device__ __forceinline__ H32Lane h32_prepare(const double (&mym)[27], double s, double C) {
-    constexpr double U = 5.9604644775390625e-08;  // 2^-24
-    double msc[9];
-#pragma unroll
-    for (int i = 0; i < 9; ++i) msc[i] = i < 6 ? mym[i] * s : mym[i];
-    const double A0 = (dabs(msc[0]) + dabs(msc[1])) * C + dabs(msc[2]);
-    const double A1 = (dabs(msc[3]) + dabs(msc[4])) * C + dabs(msc[5]);
-    const double Aw = (dabs(msc[6]) + dabs(msc[7])) * C + dabs(msc[8]);
-    const double E0 = 5.0 * U * dmax(A0, A1) + 6.0 * U * (C * s) * Aw;
-    const double Ew = 5.0 * U * Aw;
-    H32Lane h;
-#pragma unroll
-    for (int i = 0; i < 9; ++i) h.m[i] = (float)msc[i];
-    h.kE = f32_up(2.05 * E0);
-    h.kW = f32_up(2.05 * Ew);
-    h.K0 = f32_up(2.05 * (2.0 * E0 * E0 + Ew * Ew) + 1e-30);
-    return h;
-}
+typedef H32Model H32Lane;  // tvg_math.h: the scaled float model and the constants of its error bound (h32_prepare)
 __device__ __forceinline__ float readlane_f32(float v, int src) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
 }
@@ -1317,7 +1293,7 @@ __device__ __forceinline__ void count_block_regs(const double (&mym)[27], const 
         // (odd NB: that half holds a copy of the other batch and counts nothing)
         const unsigned long long v_lo = (2 * (NP - 1) == NB - 1) ? last_valid : ~0ull;
         const unsigned long long v_hi = (2 * NP - 1 <= NB - 1) ? ((2 * NP - 1 == NB - 1) ? last_valid : ~0ull) : 0ull;
-        const H32Lane hl = h32_prepare(mym, s, cmax);
+        const H32Lane hl = h32_prepare(&mym[0], s, cmax);
         for (int t = 0; t < nT; ++t) {
             if (__builtin_amdgcn_readlane(nmod, t) < 1) continue;
             const int prev = __builtin_amdgcn_readlane(acc[0], t);

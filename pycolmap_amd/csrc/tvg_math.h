@@ -833,6 +833,54 @@ AMC_HD int e5_from_ata(double* ata, double* models) {
     return e5_from_nullspace(nsp, models);
 }
 
+// ---- homography inlier decisions in FP32, with a bound on their own error -------------------------
+// The counting loop's pre-filter (tvg.hip: count_h32 evaluates exactly this, two points per packed instruction).
+// With s = 1 / sqrt(T) folded into rows 0 / 1 of the model and into the image-2 coordinates, a point is an inlier
+// iff t = u'^2 + v'^2 - w^2 <= 0 (u' = c' w - p0', v' = d' w - p1').  Every operation below is one FP32 rounding
+// (u = 2^-24); C = largest |coordinate| of the pair; A0 = (|m0| + |m1|) C + |m2|, A1, Aw likewise (m = scaled model):
+//   |p32 - p| <= 5u A,   |u32 - u'| <= E0 + u |u32| with E0 = 5u max(A0, A1) + 6u (C s) Aw,   Ew = 5u Aw
+//   |t32 - t| <= 6u |t32| + 6u R32 + 2 E0 (|u32| + |v32|) + 2 Ew |w32| + 2 E0^2 + Ew^2
+// The FP64 test is itself only trusted outside |t| <= 2e-8 R, so a point is decided iff
+//   |t32| > 4.2e-7 R32 + kE (|u32| + |v32|) + kW |w32| + K0,   kE = 2.05 E0, kW = 2.05 Ew, K0 = 2.05 (2 E0^2 + Ew^2)
+// (> 2 % of slack for the rounding of the bound itself and the 6u |t32| term; NaN / inf compare false = undecided).
+struct H32Model {
+    float m[9];
+    float kE, kW, K0;
+};
+AMC_HD float f32_up(double v) {  // a float >= v (v >= 0)
+    return (float)(v * (1.0 + 1e-6));
+}
+AMC_HD H32Model h32_prepare(const double* model, double s, double C) {
+    const double U = 5.9604644775390625e-08;  // 2^-24
+    double msc[9];
+    for (int i = 0; i < 9; ++i) msc[i] = i < 6 ? model[i] * s : model[i];
+    const double A0 = (dabs(msc[0]) + dabs(msc[1])) * C + dabs(msc[2]);
+    const double A1 = (dabs(msc[3]) + dabs(msc[4])) * C + dabs(msc[5]);
+    const double Aw = (dabs(msc[6]) + dabs(msc[7])) * C + dabs(msc[8]);
+    const double E0 = 5.0 * U * dmax(A0, A1) + 6.0 * U * (C * s) * Aw;
+    const double Ew = 5.0 * U * Aw;
+    H32Model h;
+    for (int i = 0; i < 9; ++i) h.m[i] = (float)msc[i];
+    h.kE = f32_up(2.05 * E0);
+    h.kW = f32_up(2.05 * Ew);
+    h.K0 = f32_up(2.05 * (2.0 * E0 * E0 + Ew * Ew) + 1e-30);
+    return h;
+}
+// one point (a, b: image-1 coordinates; cs, ds: image-2 coordinates times s, all rounded to float):
+// 1 inlier, 0 outlier, -1 undecided
+AMC_HD int h32_point(const H32Model& h, float a, float b, float cs, float ds) {
+    const float p0 = fmaf(h.m[0], a, fmaf(h.m[1], b, h.m[2]));
+    const float p1 = fmaf(h.m[3], a, fmaf(h.m[4], b, h.m[5]));
+    const float w = fmaf(h.m[6], a, fmaf(h.m[7], b, h.m[8]));
+    const float u = fmaf(cs, w, -p0), v = fmaf(ds, w, -p1);
+    const float R = w * w;
+    const float t = fmaf(u, u, v * v) - R;
+    const float auv = fabsf(u) + fabsf(v);
+    const float band = fmaf(4.2e-7f, R, fmaf(h.kE, auv, fmaf(h.kW, fabsf(w), h.K0)));
+    if (!(fabsf(t) > band)) return -1;
+    return t < 0.0f ? 1 : 0;
+}
+
 // ---- mt19937 tempering + libstdc++ uniform_int_distribution<uint32_t> (Lemire) ------------------
 AMC_HD uint32_t mt_temper(uint32_t y) {
     y ^= (y >> 11);

@@ -31,6 +31,20 @@ void shim_residuals(int kind, const double* m, const double* p1, const double* p
                            : h_residual(m, p1[2 * i], p1[2 * i + 1], p2[2 * i], p2[2 * i + 1]);
 }
 unsigned shim_temper(unsigned y) { return mt_temper(y); }
+// The counting loop's FP32 pre-filter for homographies (tvg_math.h h32_prepare / h32_point): per point 1 inlier,
+// 0 outlier, -1 undecided, with the operands prepared as the kernel prepares them (coordinates and scaled
+// coordinates rounded to float; C = largest |coordinate| of the set).
+void shim_h32_decisions(const double* model, double max_res, const double* p1, const double* p2, int n, signed char* out) {
+    double C = 0.0;
+    for (int i = 0; i < n; ++i) {
+        C = dmax(C, dmax(dabs(p1[2 * i]), dabs(p1[2 * i + 1])));
+        C = dmax(C, dmax(dabs(p2[2 * i]), dabs(p2[2 * i + 1])));
+    }
+    const double s = 1.0 / dsqrt(max_res);
+    const H32Model h = h32_prepare(model, s, C);
+    for (int i = 0; i < n; ++i)
+        out[i] = (signed char)h32_point(h, (float)p1[2 * i], (float)p1[2 * i + 1], (float)(p2[2 * i] * s), (float)(p2[2 * i + 1] * s));
+}
 
 // The relative-pose kernel's per-pair algorithm (csrc/pose.hip) run serially with the same
 // lane-local functions: cameras (model id + params), n inlier correspondences in image

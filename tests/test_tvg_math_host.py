@@ -165,3 +165,61 @@ def test_relative_pose_bit_exact_odd_inputs(shim):
     # swapped images: most triangulated points fall behind a camera for the planted E
     want = o.estimate_two_view_geometry_pose(cam, p2, cam, p1, ident, 2, E=sc["E_true"], H=Z)
     _same_pose(_shim_pose(shim, cam, cam, p2, p1, 2, sc["E_true"], Z), want)
+
+
+def test_fp32_homography_prefilter_never_contradicts_the_reference(shim):
+    """tvg_math.h h32_point: the counting loop decides a homography inlier in FP32 only when |t32| exceeds its own
+    error bound.  Whatever it decides must be the reference decision h_residual <= max_error^2 - for fitted and for
+    wild homographies, points far from and within 1e-6 px of the threshold circle, thresholds 0.25 .. 400 px^2 -
+    and it must decide nearly everything that is not on the circle."""
+    rng = np.random.default_rng(17)
+    decided = undecided = 0
+    for trial in range(400):
+        n = 256
+        style = trial % 5
+        p1 = rng.uniform([0, 0], [1600, 1200], size=(n, 2))
+        if style == 0:      # a real homography, points scattered around their images
+            H = np.eye(3) + rng.normal(size=(3, 3)) * [[0.1, 0.1, 60], [0.1, 0.1, 60], [1e-4, 1e-4, 0.05]]
+        elif style == 1:    # from four random correspondences: the minimal models of a non-planar scene
+            src = rng.uniform([0, 0], [1600, 1200], size=(4, 2))
+            dst = rng.uniform([0, 0], [1600, 1200], size=(4, 2))
+            out = np.zeros(9)
+            shim.shim_estimate_h4(_p(np.ascontiguousarray(src)), _p(np.ascontiguousarray(dst)), _p(out))
+            H = out.reshape(3, 3)
+        elif style == 2:    # strongly projective
+            H = np.array([[1, 0, 0], [0, 1, 0], [rng.uniform(-2e-3, 2e-3), rng.uniform(-2e-3, 2e-3), 1.0]])
+        elif style == 3:
+            H = rng.normal(size=(3, 3)) * 10.0 ** rng.uniform(-6, 6)
+        else:
+            H = np.diag([rng.uniform(0.2, 5), rng.uniform(0.2, 5), 1.0]) * 10.0 ** rng.uniform(-3, 3)
+        if not np.all(np.isfinite(H)):
+            continue
+        max_res = float(rng.choice([0.25, 1.0, 16.0, 16.0, 100.0, 400.0]))
+        q = np.concatenate([p1, np.ones((n, 1))], axis=1) @ H.T
+        with np.errstate(all="ignore"):
+            proj = q[:, :2] / q[:, 2:3]
+        # image-2 points: a third random, a third on the threshold circle +- up to 1e-6 px, a third well inside
+        ang = rng.uniform(0, 2 * np.pi, size=n)
+        rad = np.where(np.arange(n) % 3 == 1, np.sqrt(max_res) * (1 + rng.uniform(-1, 1, size=n) * 10.0 ** rng.uniform(-9, -3, size=n)),
+                       np.sqrt(max_res) * rng.uniform(0, 0.9, size=n))
+        p2 = proj + np.stack([np.cos(ang), np.sin(ang)], axis=1) * rad[:, None]
+        far = np.arange(n) % 3 == 0
+        p2[far] = rng.uniform([0, 0], [1600, 1200], size=(int(far.sum()), 2))
+        p2 = np.where(np.isfinite(p2), p2, 0.0)
+        p1c, p2c = np.ascontiguousarray(p1.astype(np.float32).astype(np.float64)), np.ascontiguousarray(p2.astype(np.float32).astype(np.float64))
+        Hc = np.ascontiguousarray(H.reshape(9))
+        res = np.zeros(n)
+        shim.shim_residuals(1, _p(Hc), _p(p1c), _p(p2c), n, _p(res))
+        want = res <= max_res
+        got = np.zeros(n, dtype=np.int8)
+        shim.shim_h32_decisions(_p(Hc), C.c_double(max_res), _p(p1c), _p(p2c), n, _p(got))
+        dec = got >= 0
+        wrong = dec & ((got == 1) != want)
+        assert not wrong.any(), f"trial {trial} style {style}: FP32 decided {got[wrong][:4]} against residuals {res[wrong][:4]} (max {max_res})"
+        off_circle = np.abs(np.sqrt(np.maximum(res, 0)) - np.sqrt(max_res)) > 0.05 * np.sqrt(max_res)
+        if style in (0, 4) and abs(np.log10(np.abs(H).max())) < 2:
+            # tame models: everything 5 % away from the circle is decided
+            assert dec[off_circle & np.isfinite(res)].mean() > 0.98
+        decided += int(dec.sum())
+        undecided += int((~dec).sum())
+    assert decided > undecided               # (a third of the points sit on the circle by construction)
