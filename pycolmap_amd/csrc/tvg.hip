@@ -1212,11 +1212,14 @@ typedef H32Model H32Lane;  // tvg_math.h: the scaled float model and the constan
 __device__ __forceinline__ float readlane_f32(float v, int src) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
 }
-__device__ __forceinline__ v2f splat(float x) { return (v2f){x, x}; }
-__device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+struct H32PkOps {  // h32_eval on two points per instruction
+    static __device__ __forceinline__ v2f fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+    static __device__ __forceinline__ v2f abs(v2f a) { return __builtin_elementwise_abs(a); }
+    static __device__ __forceinline__ v2f splat(float x) { return (v2f){x, x}; }
+};
 // count of one model over NP pairs of batches held as packed floats
 template <int NP>
-__device__ __forceinline__ int count_h32(const float (&m)[9], float kE, float kW, float K0, const v2f (&A)[NP],
+__device__ __forceinline__ int count_h32(const H32Model& hm, const v2f (&A)[NP],
                                          const v2f (&B)[NP], const v2f (&Cs)[NP], const v2f (&Ds)[NP],
                                          unsigned long long valid_lo_last, unsigned long long valid_hi_last, int M, int thr,
                                          bool& undecided) {
@@ -1224,14 +1227,8 @@ __device__ __forceinline__ int count_h32(const float (&m)[9], float kE, float kW
     bool und = false;
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
-        const v2f p0 = pk_fma(splat(m[0]), A[q], pk_fma(splat(m[1]), B[q], splat(m[2])));
-        const v2f p1 = pk_fma(splat(m[3]), A[q], pk_fma(splat(m[4]), B[q], splat(m[5])));
-        const v2f w = pk_fma(splat(m[6]), A[q], pk_fma(splat(m[7]), B[q], splat(m[8])));
-        const v2f u = pk_fma(Cs[q], w, -p0), v = pk_fma(Ds[q], w, -p1);
-        const v2f R = w * w;
-        const v2f t = pk_fma(u, u, v * v) - R;
-        const v2f auv = __builtin_elementwise_abs(u) + __builtin_elementwise_abs(v);
-        const v2f band = pk_fma(splat(4.2e-7f), R, pk_fma(splat(kE), auv, pk_fma(splat(kW), __builtin_elementwise_abs(w), splat(K0))));
+        v2f t, band;
+        h32_eval<v2f, H32PkOps>(hm, A[q], B[q], Cs[q], Ds[q], t, band);
         const bool dec0 = fabsf(t.x) > band.x, dec1 = fabsf(t.y) > band.y;
         unsigned long long in0 = __ballot(t.x < 0.0f), in1 = __ballot(t.y < 0.0f);
         unsigned long long un0 = __ballot(!dec0), un1 = __ballot(!dec1);
@@ -1300,12 +1297,14 @@ __device__ __forceinline__ void count_block_regs(const double (&mym)[27], const 
             int cc = Mb;
             if (prev + Mb + rest_after >= thr) {
                 const int thr_b = thr - prev - rest_after;  // what this block has to contribute for the model to matter
-                float m32[9];
+                H32Model hm;  // trial t's scaled model and bound constants, wave-uniform
 #pragma unroll
-                for (int i = 0; i < 9; ++i) m32[i] = readlane_f32(hl.m[i], t);
-                const float kE = readlane_f32(hl.kE, t), kW = readlane_f32(hl.kW, t), K0 = readlane_f32(hl.K0, t);
+                for (int i = 0; i < 9; ++i) hm.m[i] = readlane_f32(hl.m[i], t);
+                hm.kE = readlane_f32(hl.kE, t);
+                hm.kW = readlane_f32(hl.kW, t);
+                hm.K0 = readlane_f32(hl.K0, t);
                 bool und;
-                cc = count_h32<NP>(m32, kE, kW, K0, A2, B2, C2, D2, v_lo, v_hi, Mb, thr_b, und);
+                cc = count_h32<NP>(hm, A2, B2, C2, D2, v_lo, v_hi, Mb, thr_b, und);
 #if defined(AMC_TVG_DIAG) && (AMC_TVG_DIAG & 8)
                 {
                     double sm[9];
@@ -1313,7 +1312,7 @@ __device__ __forceinline__ void count_block_regs(const double (&mym)[27], const 
                     for (int i = 0; i < 9; ++i) sm[i] = readlane_f64(mym[i], t);
                     const int c64 = count_regs<K_H, NB>(sm, a, b, c, d, last_valid, Mb, max_res, 0);
                     bool und2;
-                    const int c32 = count_h32<NP>(m32, kE, kW, K0, A2, B2, C2, D2, v_lo, v_hi, Mb, 0, und2);
+                    const int c32 = count_h32<NP>(hm, A2, B2, C2, D2, v_lo, v_hi, Mb, 0, und2);
                     if (lane == 0) {
                         atomicAdd(&g_h32_diag[0], 1ull);
                         if (und2) atomicAdd(&g_h32_diag[1], 1ull);

@@ -866,17 +866,29 @@ AMC_HD H32Model h32_prepare(const double* model, double s, double C) {
     h.K0 = f32_up(2.05 * (2.0 * E0 * E0 + Ew * Ew) + 1e-30);
     return h;
 }
+// t = u'^2 + v'^2 - w^2 and the bound on its error, for one point (V = float) or for two at once (V = a two-float
+// vector: the kernel's v_pk_fma_f32 form) - the same expression either way
+struct H32Ops {
+    static AMC_HD float fma(float a, float b, float c) { return fmaf(a, b, c); }
+    static AMC_HD float abs(float a) { return fabsf(a); }
+    static AMC_HD float splat(float a) { return a; }
+};
+template <class V, class Ops>
+AMC_HD void h32_eval(const H32Model& h, V a, V b, V cs, V ds, V& t, V& band) {
+    const V p0 = Ops::fma(Ops::splat(h.m[0]), a, Ops::fma(Ops::splat(h.m[1]), b, Ops::splat(h.m[2])));
+    const V p1 = Ops::fma(Ops::splat(h.m[3]), a, Ops::fma(Ops::splat(h.m[4]), b, Ops::splat(h.m[5])));
+    const V w = Ops::fma(Ops::splat(h.m[6]), a, Ops::fma(Ops::splat(h.m[7]), b, Ops::splat(h.m[8])));
+    const V u = Ops::fma(cs, w, -p0), v = Ops::fma(ds, w, -p1);
+    const V R = w * w;
+    t = Ops::fma(u, u, v * v) - R;
+    const V auv = Ops::abs(u) + Ops::abs(v);
+    band = Ops::fma(Ops::splat(4.2e-7f), R, Ops::fma(Ops::splat(h.kE), auv, Ops::fma(Ops::splat(h.kW), Ops::abs(w), Ops::splat(h.K0))));
+}
 // one point (a, b: image-1 coordinates; cs, ds: image-2 coordinates times s, all rounded to float):
 // 1 inlier, 0 outlier, -1 undecided
 AMC_HD int h32_point(const H32Model& h, float a, float b, float cs, float ds) {
-    const float p0 = fmaf(h.m[0], a, fmaf(h.m[1], b, h.m[2]));
-    const float p1 = fmaf(h.m[3], a, fmaf(h.m[4], b, h.m[5]));
-    const float w = fmaf(h.m[6], a, fmaf(h.m[7], b, h.m[8]));
-    const float u = fmaf(cs, w, -p0), v = fmaf(ds, w, -p1);
-    const float R = w * w;
-    const float t = fmaf(u, u, v * v) - R;
-    const float auv = fabsf(u) + fabsf(v);
-    const float band = fmaf(4.2e-7f, R, fmaf(h.kE, auv, fmaf(h.kW, fabsf(w), h.K0)));
+    float t, band;
+    h32_eval<float, H32Ops>(h, a, b, cs, ds, t, band);
     if (!(fabsf(t) > band)) return -1;
     return t < 0.0f ? 1 : 0;
 }
