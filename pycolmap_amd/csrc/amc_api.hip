@@ -1,6 +1,7 @@
 // amc_api.hip — host side of libamc.so: implements include/amc.h on top of the HIP kernels.
 // No CPU fallback: every entry point that computes needs a gfx950 device.
 #include <algorithm>
+#include <array>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -1657,18 +1658,31 @@ static int verify_impl(amc_ctx* c, int mode, const uint32_t* slot1, const uint32
         std::fprintf(stderr, "[amc tvg profile] per pair: counting loop=%.0f local_estimate(E5)=%.0f local_estimate(F8)=%.0f\n",
                      (double)acc[5] / npairs, (double)acc[6] / npairs, (double)acc[7] / npairs);
     }
-    for (size_t p = 0; p < npairs; ++p) {
-        priv->tvg_raw[p] = h_out[p].g;
-        if (tp[p].M)
-            std::memcpy(priv->mask_raw.get() + match_offsets[p], h_mask + tp[p].mask_off, tp[p].M);
+    {   // records and masks into the result's arrays (disjoint ranges of pairs: a few host threads for large calls)
+        const unsigned nth = npairs >= 16384 ? std::min(4u, std::max(1u, std::thread::hardware_concurrency())) : 1u;
+        std::vector<std::array<uint64_t, 12>> wsum(nth);
+        auto part = [&](unsigned k) {
+            std::array<uint64_t, 12> w{};
+            for (size_t p = npairs * k / nth; p < npairs * (k + 1) / nth; ++p) {
+                priv->tvg_raw[p] = h_out[p].g;
+                if (tp[p].M)
+                    std::memcpy(priv->mask_raw.get() + match_offsets[p], h_mask + tp[p].mask_off, tp[p].M);
+                for (int i = 0; i < 12; ++i) w[i] += h_out[p].work[i];
+            }
+            wsum[k] = w;
+        };
+        std::vector<std::thread> th;
+        for (unsigned k = 1; k < nth; ++k) th.emplace_back(part, k);
+        part(0);
+        for (auto& t : th) t.join();
+        for (unsigned k = 0; k < nth; ++k)
+            for (int i = 0; i < 12; ++i) out->work[i] += wsum[k][i];
     }
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[1]);
     out->device_ms = ms;
     out->kernel_ms = kernel_ms;
     out->kernel_launches = launches;
-    for (size_t p = 0; p < npairs; ++p)
-        for (int i = 0; i < 12; ++i) out->work[i] += h_out[p].work[i];
     lap(4);
     if (hprof)
         std::fprintf(stderr, "[amc verify profile] pairs=%zu checks %.1f ms, tables %.1f, upload %.1f, kernels+download %.1f "
