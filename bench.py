@@ -8,21 +8,27 @@ through libamc.so's amc_match_pairs (match kernel -> finalize -> match tables on
 descriptors already resident in HBM when the timed region starts.
 
     python bench.py --gpus 1 --steps 3 --warmup 1
+    python bench.py --gpus N --steps K --warmup W            # N > 1: launches itself under torch.distributed.run
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W [--config 3|4]
+        --master-port P bench.py --gpus N --steps K --warmup W [--config 3|4 | --weak]
 
---config 1 (default): N=1 workload = BASELINE.json configs[1] (500 x 4096, 124,750 pairs, 2.09e12
-  distances); N>1: weak scaling - the image set grows as 500*sqrt(N) so every rank matches ~124,750
+--config 1 (default at N=1): BASELINE.json configs[1] (500 x 4096, 124,750 pairs, 2.09e12 distances).  With N>1 it
+  is only run on request (--weak): weak scaling - the image set grows as 500*sqrt(N) so every rank matches ~124,750
   pairs of one replicated descriptor arena.  At N=1 the JSON line also carries
     "verify"   BASELINE's second metric, verified image-pairs/s, with its own FP64 roofline and CPU baseline,
     "pipeline" configs[2] as stated: match + F/E/H verification of the same image set, chained on the device
                (amc_match_verify_pairs) on a scene with real geometry,
     "dense"    the same match on a set where EVERY pair overlaps (reverse scan and D2H no longer negligible).
---config 3: BASELINE configs[3], 2000 x 8192, the FIXED pair set sharded over the ranks (strong scaling).
+--config 3 (default at N>1): BASELINE configs[3], 2000 x 8192, the FIXED pair set sharded over the ranks (strong
+            scaling) - the workload north_star states its ">= 7x at 8 GPUs" on.
 --config 4: BASELINE configs[4], 10000 x 4096, sequential (overlap 50, quadratic) + loop-closure pairs
             (feature voting on the first 512 descriptors, then the match of the retrieved pairs), sharded.
 In every multi-GPU mode ranks exchange their match tables with one RCCL all-gather at the end of each
-step (the exchange step north_star names), inside the timed region.
+step (the exchange step north_star names), inside the timed region; the line reports it separately
+(config.exchange_ms_per_step) beside every rank's kernel time (config.kernel_ms_per_step_by_rank).
+--cpu-dry-run (with --backend gloo): the same entry without a GPU - sharding, exchange, reductions and the JSON
+line run for real over gloo on tiny sizes, the kernels are replaced by the CPU oracle.  A plumbing check for
+tests/ (value is null: nothing it prints is a measurement).
 
 Prints ONE JSON line (rank 0).
 """
@@ -76,7 +82,7 @@ def fp64_roofline(work, kernel_s, launches):
             "frac": ach / FP64_VECTOR_PEAK, "frac_of_no_fma_ceiling": ach / FP64_NO_FMA_CEILING,
             "no_fma_ceiling": FP64_NO_FMA_CEILING / 1e12,
             "flop_per_launch": total / max(launches, 1), "flop_scoring_share": scoring / total if total else 0.0,
-            "kernel": "tvg_kernel", "avg_kernel_ms": 1e3 * kernel_s / max(launches, 1), "launches": launches,
+            "kernel": "tvg_e_kernel + tvg_fh_kernel", "avg_kernel_ms": 1e3 * kernel_s / max(launches, 1), "launches": launches,
             "traffic": None,
             "note": "algorithmic flop as COLMAP's loops count them (every model of every trial x all matches); the "
                     "kernel skips part of that work by early exit, so this is useful work per second, not issue rate"}
@@ -410,6 +416,95 @@ def dense_leg(ctx_factory, device, steps: int, warmup: int, num_images: int, fea
                                   "python_free_previous_result": 1e3 * t_free / steps, "python_call": 1e3 * t_call / steps}}
 
 
+class _DryRunContext:
+    """--cpu-dry-run only: stands where _capi.Context stands so that the multi-rank entry (sharding, exchange,
+    reductions, the JSON line) can be exercised without a GPU.  The match kernels are replaced by the CPU oracle
+    (tests/oracle_lib.py, test infrastructure): nothing measured through this class is reported as a value."""
+
+    def __init__(self):
+        self.imgs = {}
+
+    def set_stream(self, stream):
+        pass
+
+    def reserve_slots(self, n):
+        self.imgs = {}
+
+    def upload_descriptors(self, slot, desc):
+        self.imgs[int(slot)] = np.ascontiguousarray(desc, dtype=np.uint8)
+
+    def match_pairs(self, s1, s2, kernel="auto", cross_check=True, copy=True):
+        sys.path.insert(0, str(ROOT / "tests"))
+        import oracle_lib
+        used = np.unique(np.concatenate([np.asarray(s1, np.int64), np.asarray(s2, np.int64)])) if len(s1) else np.zeros(0, np.int64)
+        remap = {int(u): k for k, u in enumerate(used)}
+        imgs = [self.imgs[int(u)] for u in used]
+        a = np.array([remap[int(x)] for x in s1], np.uint32)
+        b = np.array([remap[int(x)] for x in s2], np.uint32)
+        t0 = time.perf_counter()
+        off, m = oracle_lib.match_pairs(imgs, a, b, threads=1) if len(a) else (np.zeros(1, np.uint64), np.zeros((0, 2), np.uint32))
+        ms = 1e3 * (time.perf_counter() - t0)
+        nd = int(sum(len(imgs[int(x)]) * len(imgs[int(y)]) for x, y in zip(a, b)))
+        return off, m, {"num_distances": nd, "match_kernel_ms": ms, "match_kernel_launches": 1, "cross_kernel_ms": 0.0,
+                        "device_ms": ms, "pairs_mfma": 0, "pairs_dot4": 0}
+
+    def close(self):
+        pass
+
+
+def _free_port() -> int:
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks ourselves, exactly as the
+    driver's command line would (one process per GPU, rendezvous on 127.0.0.1)."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(Path(__file__).resolve()), *sys.argv[1:]]
+    return subprocess.call(cmd, env=env)
+
+
+def dist_setup(args):
+    """(world, rank, local_rank, device, use_dist) for this process; initialises the process group when there is more
+    than one rank (RCCL on the GPUs; gloo on the CPU under --cpu-dry-run)."""
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.cpu_dry_run:
+        device = torch.device("cpu")
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the measured path")
+        torch.cuda.set_device(local_rank)
+        device = torch.device("cuda", local_rank)
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        if args.cpu_dry_run:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group(args.backend, device_id=device, rank=rank, world_size=world)
+    return world, rank, local_rank, device, use_dist
+
+
+def device_sync(args):
+    if not args.cpu_dry_run:
+        import torch
+        torch.cuda.synchronize()
+
+
 def run_config34(args):
     """BASELINE configs[3] (2000 x 8192 exhaustive) and configs[4] (10000 x 4096 sequential + loop): a FIXED
     workload whose pairs are sharded over the ranks by work (sum of n1 * n2), the descriptor arena replicated on
@@ -419,21 +514,8 @@ def run_config34(args):
     from pycolmap_amd import _capi, synth
     from pycolmap_amd import distributed as D
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the measured path")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    use_dist = world > 1 or args.force_dist
-    if use_dist:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", device_id=device, rank=rank, world_size=world)
+    world, rank, local_rank, device, use_dist = dist_setup(args)
+    dry = args.cpu_dry_run
 
     if args.config == 3:
         num_images = 2000 if args.images == 500 else args.images
@@ -442,15 +524,23 @@ def run_config34(args):
         num_images = 10000 if args.images == 500 else args.images
         feats = args.feats
     arena = make_arena_torch(num_images, feats, seed=0, device=device)
-    ctx = _capi.Context(local_rank)
-    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-    loop_feats = 512
-    ctx.reserve_slots(num_images * (2 if args.config == 4 else 1))
-    for i in range(num_images):
-        ctx.upload_descriptors_device(i, arena[i].data_ptr(), feats)
-        if args.config == 4:   # the loop index: every image's first 512 descriptors (controller.cc SetupLoopIndex)
-            ctx.upload_descriptors_device(num_images + i, arena[i].data_ptr(), loop_feats)
-    torch.cuda.synchronize()
+    loop_feats = min(512, feats)
+    if dry:
+        ctx = _DryRunContext()
+        ctx.reserve_slots(num_images * 2)
+        for i in range(num_images):
+            ctx.upload_descriptors(i, arena[i].numpy())
+            if args.config == 4:
+                ctx.upload_descriptors(num_images + i, arena[i, :loop_feats].numpy())
+    else:
+        ctx = _capi.Context(local_rank)
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        ctx.reserve_slots(num_images * (2 if args.config == 4 else 1))
+        for i in range(num_images):
+            ctx.upload_descriptors_device(i, arena[i].data_ptr(), feats)
+            if args.config == 4:   # the loop index: every image's first 512 descriptors (controller.cc SetupLoopIndex)
+                ctx.upload_descriptors_device(num_images + i, arena[i].data_ptr(), loop_feats)
+    device_sync(args)
     rows = np.full(num_images, feats)
 
     if args.config == 3:
@@ -471,7 +561,8 @@ def run_config34(args):
         del seen
     s1, s2, mine = D.shard_pairs(a_all, b_all, rank, world, rows=rows)
     queries = np.arange(0, num_images, 10)[rank::world] if args.config == 4 else np.zeros(0, np.int64)
-    loop_num_images = 50
+    loop_num_images = min(50, num_images - 1)
+    exch = {"ms": 0.0}
 
     def step():
         off, m, st = ctx.match_pairs(s1, s2, kernel=args.kernel, copy=False)
@@ -502,22 +593,29 @@ def run_config34(args):
         gathered = None
         if use_dist:
             # the exchange step: sequential pairs have global positions; the loop pairs of a rank are numbered after
-            # those of the ranks before it (one small all-gather of the counts)
+            # those of the ranks before it (one small all-gather of the counts).  Timed on its own (host clock
+            # between device synchronisations): it waits for the slowest rank's kernels, so it holds the load
+            # imbalance as well as the transfer.
+            device_sync(args)
+            te = time.perf_counter()
             gathered = [D.all_gather_match_tables(mine, off, m, device=device, as_numpy=False)]
             if args.config == 4:
                 lo_, lm_ = (parts[1][1], parts[1][2]) if len(parts) > 1 else (np.zeros(1, np.uint64), np.zeros((0, 2), np.uint32))
                 gathered.append(D.all_gather_appended_tables(lo_, lm_, device=device, as_numpy=False))
+            device_sync(args)
+            exch["ms"] += 1e3 * (time.perf_counter() - te)
         return nd, kms, kl, int(sum(p[2].shape[0] for p in parts)), extra, gathered
 
     def fence():
-        torch.cuda.synchronize()
+        device_sync(args)
         if use_dist:
             dist.barrier()
-            torch.cuda.synchronize()
+            device_sync(args)
 
     for _ in range(args.warmup):
         step()
     fence()
+    exch["ms"] = 0.0
     t0 = time.perf_counter()
     nd = kms = kl = nm = 0
     extra = {}
@@ -527,12 +625,20 @@ def run_config34(args):
     fence()
     elapsed = time.perf_counter() - t0
     nd_rank = nd
+    kernel_ms_by_rank = [kms / max(args.steps, 1)]
+    exch_ms_by_rank = [exch["ms"] / max(args.steps, 1)]
     if use_dist:
         t = torch.tensor([elapsed, float(nd)], device=device, dtype=torch.float64)
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         elapsed, nd = float(tmax[0].item()), float(t[1].item())
+        per = torch.tensor([kernel_ms_by_rank[0], exch_ms_by_rank[0]], device=device, dtype=torch.float64)
+        allper = torch.empty(2 * world, device=device, dtype=torch.float64)
+        dist.all_gather_into_tensor(allper, per)
+        allper = allper.cpu().view(world, 2)
+        kernel_ms_by_rank = [float(x) for x in allper[:, 0]]
+        exch_ms_by_rank = [float(x) for x in allper[:, 1]]
     final_line = None
     if rank == 0:
         avg_kernel_s = (kms / max(kl, 1)) * 1e-3
@@ -544,11 +650,14 @@ def run_config34(args):
             name = f"REDUCED {num_images} x {feats} variant of: " + name
         out = {
             "metric": "descriptor-pair distances/sec (exhaustive SIFT match: dot + top-2 + ratio + cross-check)",
-            "value": nd / elapsed, "unit": "distances/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": None if dry else nd / elapsed, "unit": "distances/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "u8 descriptors, int8 MFMA / int32 accumulate", "data": "synthetic",
             "config": {"workload": name, "pairs_total": int(len(a_all)), "pairs_rank0": int(len(s1)),
-                       "distances_per_step_all_ranks": nd / args.steps, "matches_rank0": nm, "rccl_ranks": world if use_dist else 0,
+                       "distances_per_step_all_ranks": nd / args.steps, "matches_rank0": nm,
+                       "rccl_ranks": world if (use_dist and not dry) else 0, "backend": ("gloo" if dry else args.backend) if use_dist else None,
+                       "kernel_ms_per_step_by_rank": kernel_ms_by_rank,
+                       "exchange_ms_per_step": max(exch_ms_by_rank), "exchange_ms_per_step_by_rank": exch_ms_by_rank,
                        "sharding": "pairs sorted by image 2, contiguous slices of equal sum(n1*n2), arena replicated; "
                                    "one all-gather of the match tables per step", **extra},
             "roofline": {"bound": "mfma", "achieved": ach / 1e12, "peak": INT8_DENSE_PEAK_OPS / 1e12,
@@ -557,6 +666,11 @@ def run_config34(args):
                          "kernel": "match_mfma_kernel", "avg_kernel_ms": avg_kernel_s * 1e3,
                          "launches_per_step": kl // max(args.steps, 1)},
         }
+        if dry:
+            out["dry_run"] = True
+            out["metric"] = "DRY RUN (CPU oracle in place of the kernels, gloo in place of RCCL): NOT a measurement - " + out["metric"]
+            out["data"] = "synthetic (cpu dry run)"
+            out["roofline"] = None
         final_line = json.dumps(out)
     if use_dist:
         dist.barrier()
@@ -589,13 +703,32 @@ def main():
                     help="diagnostic: one-way matching only (NOT the BASELINE workload)")
     ap.add_argument("--force-dist", action="store_true",
                     help="diagnostic: run the multi-GPU exchange path (process group + all-gather) even with 1 rank")
-    ap.add_argument("--config", type=int, default=1, choices=[1, 3, 4],
-                    help="1: BASELINE configs[1] (+ verify / pipeline / dense legs at N=1; weak scaling at N>1); "
-                         "3: configs[3], 2000 x 8192 fixed pair set sharded over the ranks (strong scaling); "
-                         "4: configs[4], 10000 x 4096 sequential + loop matching, sharded")
+    ap.add_argument("--config", type=int, default=None, choices=[1, 3, 4],
+                    help="1: BASELINE configs[1] (+ verify / pipeline / dense legs; the default at N=1); "
+                         "3: configs[3], 2000 x 8192 fixed pair set sharded over the ranks (strong scaling; the default "
+                         "at N>1); 4: configs[4], 10000 x 4096 sequential + loop matching, sharded")
+    ap.add_argument("--weak", action="store_true",
+                    help="N>1: weak scaling of configs[1] (the image set grows as 500*sqrt(N)) instead of configs[3]")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend of the exchange step (nccl = RCCL; gloo only with --cpu-dry-run)")
+    ap.add_argument("--cpu-dry-run", action="store_true",
+                    help="no GPU: run the multi-rank plumbing (sharding, exchange, reductions, JSON line) over gloo with the "
+                         "CPU oracle in place of the kernels; prints value = null.  For tests/, with tiny --images/--feats")
     ap.add_argument("--no-pipeline", action="store_true", help="skip the chained configs[2] leg")
     ap.add_argument("--no-dense", action="store_true", help="skip the dense-overlap match leg")
     args = ap.parse_args()
+    if args.config is None:
+        args.config = 1 if (args.gpus == 1 or args.weak) else 3
+    if args.weak and args.config != 1:
+        raise SystemExit("--weak is the N>1 variant of --config 1")
+    if args.cpu_dry_run:
+        args.backend = "gloo"
+        if args.config == 1:
+            raise SystemExit("--cpu-dry-run covers the sharded configurations (--config 3 | 4)")
+    elif args.backend != "nccl":
+        raise SystemExit("--backend gloo is for --cpu-dry-run: the measured path exchanges over RCCL")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))
     if args.config in (3, 4):
         return run_config34(args)
 
@@ -603,21 +736,7 @@ def main():
     import torch.distributed as dist
     from pycolmap_amd import _capi, synth
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the measured path")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    use_dist = world > 1 or args.force_dist
-    if use_dist:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", device_id=device, rank=rank, world_size=world)
+    world, rank, local_rank, device, use_dist = dist_setup(args)
 
     # ---- workload ------------------------------------------------------------------------
     num_images = args.images if world == 1 else int(round(args.images * math.sqrt(world)))

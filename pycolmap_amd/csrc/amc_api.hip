@@ -1,6 +1,7 @@
 // amc_api.hip — host side of libamc.so: implements include/amc.h on top of the HIP kernels.
 // No CPU fallback: every entry point that computes needs a gfx950 device.
 #include <algorithm>
+#include <random>
 #include <array>
 #include <chrono>
 #include <cmath>
@@ -192,7 +193,14 @@ struct amc_ctx {
     // verification scratch
     DevBuf<TvgImage> d_timgs;
     DevBuf<TvgPair> d_tpairs;
-    DevBuf<uint32_t> d_tmatches, d_ttabs, d_mtinit;
+    DevBuf<uint32_t> d_tmatches, d_ttabs;
+    DevBuf<TvgPair> d_tpairs_e;       // the calibrated pairs of a launch, in the essential-matrix kernel's queue order
+    DevBuf<TvgEState> d_estate;       // essential-matrix kernel -> F/H kernel hand-off, by pair
+    DevBuf<uint8_t> d_emask;          // ... and the E RANSAC's inlier masks (same layout as d_toutmask)
+    // tempered words of std::mt19937(seed): the sample stream every pair consumes (TvgParams::stream)
+    DevBuf<uint32_t> d_stream;
+    uint32_t stream_seed = 0;
+    size_t stream_len = 0;
     DevBuf<double> d_wmcut;
     DevBuf<double> d_tws;
     DevBuf<uint8_t> d_tmaskws, d_toutmask;
@@ -315,7 +323,7 @@ void amc_ctx_destroy(amc_ctx* c) {
     }
     c->h_scalars.release();
     c->d_timgs.release(); c->d_tpairs.release(); c->d_tmatches.release(); c->d_ttabs.release();
-    c->d_mtinit.release(); c->d_wmcut.release(); c->d_tws.release(); c->d_tmaskws.release(); c->d_toutmask.release();
+    c->d_tpairs_e.release(); c->d_estate.release(); c->d_emask.release(); c->d_stream.release(); c->d_wmcut.release(); c->d_tws.release(); c->d_tmaskws.release(); c->d_toutmask.release();
     c->d_tout.release();
     c->d_ppairs.release(); c->d_pmatches.release(); c->d_pcos.release(); c->d_pout.release();
     for (auto& ev : c->ev)
@@ -1472,16 +1480,23 @@ static int verify_impl(amc_ctx* c, int mode, const uint32_t* slot1, const uint32
     out->tvg = priv->tvg_raw.get();
     out->inlier_mask = priv->mask_raw.get();
     if (npairs == 0) return AMC_OK;
+    // every failure below (HIPCHK returns included) frees the result's storage and hands back a zeroed struct
+    struct Guard {
+        VerifyPriv* p;
+        amc_verify_result* o;
+        ~Guard() {
+            if (p) {
+                delete p;
+                std::memset(o, 0, sizeof *o);
+            }
+        }
+    } guard{priv, out};
 
     // image table (cameras with distortion parameters: CamFromImg of their keypoints first)
     for (size_t i = 0; i < need_lift.size(); ++i)
         if (need_lift[i]) {
             const int rc = ensure_normalized(c, (uint32_t)i);
-            if (rc != AMC_OK) {
-                delete priv;
-                std::memset(out, 0, sizeof *out);
-                return rc;
-            }
+            if (rc != AMC_OK) return rc;
         }
     std::vector<TvgImage> timgs;
     fill_tvg_images(c, timgs);
@@ -1533,36 +1548,63 @@ static int verify_impl(amc_ctx* c, int mode, const uint32_t* slot1, const uint32
         tp[p].orig = (uint32_t)p;
         for (int t = 0; t < 3; ++t) tp[p].tab_off[t] = (uint32_t)(tab_of_M[M] + (int64_t)t * (M + 1));
     }
-    // std::mt19937(seed) initial state
-    uint32_t mt0[624];
-    mt0[0] = seed;
-    for (int i = 1; i < 624; ++i) mt0[i] = 1812433253u * (mt0[i - 1] ^ (mt0[i - 1] >> 30)) + (uint32_t)i;
-
     int cus = 256;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device);
 
-    // Size classes.  A wave's LDS share holds, besides the generator state, two uint16 index
-    // arrays of mcap entries (the sampler's permutation and the inlier list).  Normal pairs run 4
-    // waves per workgroup (40 KB each); pairs too large for that run one wave per workgroup with up
-    // to the whole 160 KB (M <= ~38 k: covers max_num_matches = 32768); their points stay in HBM.
-    std::vector<size_t> cls[2];
+    // Size classes.  A wave's LDS share holds, besides a few KB of fixed state, two uint16 index arrays of mcap
+    // entries (the sampler's permutation and the inlier list); everything else of a pair lives in the wave's global
+    // workspace.  Pairs up to ~1,500 matches run at the F/H kernel's full occupancy, 4 waves per workgroup; larger
+    // ones in launches of their own with fewer resident waves; the largest (M <= ~38 k: covers
+    // max_num_matches = 32768) one wave per workgroup with up to the whole 160 KB.
+    std::vector<size_t> cls[3];
     for (size_t p = 0; p < npairs; ++p) {
         const uint32_t mc = std::max<uint32_t>(64, round_up(tp[p].M, 64));
-        if (tvg_lds_bytes(mc, 0, 1) + 64 <= 160 * 1024 / (4 * kTvgWavesPerSimd)) cls[0].push_back(p);
-        else if (tvg_lds_bytes(mc, 0, 1) + 64 <= 160 * 1024) cls[1].push_back(p);
-        else {
-            delete priv;
-            std::memset(out, 0, sizeof *out);
+        const size_t lds = tvg_lds_bytes(mc, 1) + 64;
+        if (lds <= 160 * 1024 / (4 * (size_t)kTvgFhWavesPerSimd)) cls[0].push_back(p);
+        else if (lds <= 160 * 1024 / 4) cls[1].push_back(p);
+        else if (lds <= 160 * 1024) cls[2].push_back(p);
+        else
             return fail(AMC_E_INVALID, "amc_verify_pairs: pair %zu has %u matches: more than the verification "
                         "kernel's per-pair state can index in LDS (limit ~38000)", p, tp[p].M);
-        }
     }
+    // which pairs run the essential-matrix RANSAC first (tvg_e_kernel), exactly as the F/H kernel decides it
+    auto uses_E = [&](size_t p) {
+        if (mode == 3) return true;
+        if (mode != 0 || o.force_H_use) return false;
+        if (tp[p].M < (uint32_t)std::max(o.min_num_inliers, 0)) return false;
+        return c->slots[slot1[p]].cam.has_prior != 0 && c->slots[slot2[p]].cam.has_prior != 0;
+    };
     lap(1);
+    // The sample stream: std::mt19937(seed)'s output words (operator() tempers them).  Every pair re-seeds (D4), so
+    // they all read the same table; its length covers every RANSAC of a pair running to its trial cap, plus the
+    // words a chunk draws ahead and a margin for Lemire rejections.  Kept across calls with the same seed.
+    size_t stream_need = (size_t)5 * P.max_trials[0] + (size_t)7 * P.max_trials[1] + (size_t)4 * P.max_trials[2] +
+                         (size_t)P.max_trials[3] + 4 * 64 * 7 + 4096;
+    constexpr size_t kMaxStreamWords = (size_t)1 << 28;  // 1 GiB of words: max_num_trials ~ 1.6e7 at the default ratio
+    if (stream_need > kMaxStreamWords)
+        return fail(AMC_E_INVALID, "amc_verify_pairs: ransac.max_num_trials / min_inlier_ratio allow %zu draws per pair: "
+                    "more than the sample-stream table holds (%zu)", stream_need, kMaxStreamWords);
+    auto ensure_stream = [&](size_t need) -> hipError_t {
+        if (c->d_stream.p && c->stream_seed == seed && c->stream_len >= need) return hipSuccess;
+        std::vector<uint32_t> words(need);
+        std::mt19937 gen(seed);
+        for (size_t i = 0; i < need; ++i) words[i] = (uint32_t)gen();
+        hipError_t e = c->d_stream.ensure(need);
+        if (e != hipSuccess) return e;
+        e = hipMemcpyAsync(c->d_stream.p, words.data(), need * sizeof(uint32_t), hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) return e;
+        e = hipStreamSynchronize(st);  // `words` goes out of scope
+        c->stream_seed = seed;
+        c->stream_len = e == hipSuccess ? need : 0;
+        return e;
+    };
+    HIPCHK(ensure_stream(stream_need));
     HIPCHK(c->d_timgs.ensure(timgs.size()));
     if (!dev_matches) HIPCHK(c->d_tmatches.ensure(std::max<size_t>(2 * total, 2)));
     HIPCHK(c->d_ttabs.ensure(std::max<size_t>(tabs.size(), 1)));
-    HIPCHK(c->d_mtinit.ensure(624));
     HIPCHK(c->d_toutmask.ensure(std::max<size_t>(mask_bytes, 128)));
+    HIPCHK(c->d_emask.ensure(std::max<size_t>(mask_bytes, 128)));
+    HIPCHK(c->d_estate.ensure(npairs));
     HIPCHK(hipEventRecord(c->ev[0], st));
     HIPCHK(hipMemcpyAsync(c->d_timgs.p, timgs.data(), timgs.size() * sizeof(TvgImage), hipMemcpyHostToDevice, st));
     if (total && !dev_matches)
@@ -1570,14 +1612,12 @@ static int verify_impl(amc_ctx* c, int mode, const uint32_t* slot1, const uint32
     const uint32_t* kernel_matches = dev_matches ? dev_matches : c->d_tmatches.p;
     if (!tabs.empty())
         HIPCHK(hipMemcpyAsync(c->d_ttabs.p, tabs.data(), tabs.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(c->d_mtinit.p, mt0, sizeof mt0, hipMemcpyHostToDevice, st));
     P.wm_cut = nullptr;
     if (!wm_cut.empty()) {
         HIPCHK(c->d_wmcut.ensure(wm_cut.size()));
         HIPCHK(hipMemcpyAsync(c->d_wmcut.p, wm_cut.data(), wm_cut.size() * sizeof(double), hipMemcpyHostToDevice, st));
         P.wm_cut = c->d_wmcut.p;
     }
-    HIPCHK(hipMemsetAsync(c->d_scalars + 2, 0, sizeof(uint32_t), st));
     HIPCHK(hipStreamSynchronize(st));
     lap(2);
 
@@ -1588,42 +1628,77 @@ static int verify_impl(amc_ctx* c, int mode, const uint32_t* slot1, const uint32
     const uint8_t* h_mask = c->h_tmask.p;
     double kernel_ms = 0.0;
     uint32_t launches = 0;
-    for (int k = 0; k < 2; ++k) {
-        if (cls[k].empty()) continue;
-        const int wpb = k == 0 ? 4 : 1;
-        uint32_t cm = 0;
-        // The waves pull pairs from a queue in this order.  A pair's cost grows with its match count (every
-        // trial scores all matches), so the largest go first: what is left for the tail of the launch, when
-        // most waves have run dry, are the cheap ones.  Results are stored by pair, the order is free.
-        std::vector<size_t> idx = cls[k];
-        std::stable_sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return tp[a].M > tp[b].M; });
-        std::vector<TvgPair> sub(idx.size());
-        for (size_t i = 0; i < idx.size(); ++i) {
-            sub[i] = tp[idx[i]];
-            cm = std::max(cm, sub[i].M);
+    for (int attempt = 0;; ++attempt) {
+        P.stream = c->d_stream.p;
+        P.stream_len = (uint32_t)std::min<size_t>(c->stream_len, 0xFFFFFFFFu);
+        P.stream_err = c->d_scalars + 4;
+        // [2] pairs with a bad match index, [4] waves that ran off the stream table; the records' profile and work
+        // counters are accumulated by both kernels
+        HIPCHK(hipMemsetAsync(c->d_scalars + 2, 0, 3 * sizeof(uint32_t), st));
+        HIPCHK(hipMemsetAsync(c->d_tout.p, 0, npairs * sizeof(TvgOut), st));
+        kernel_ms = 0.0;
+        launches = 0;
+        for (int k = 0; k < 3; ++k) {
+            if (cls[k].empty()) continue;
+            const int wpb = k == 2 ? 1 : 4;
+            uint32_t cm = 0;
+            // The waves pull pairs from a queue in this order.  A pair's cost grows with its match count (every
+            // trial scores all matches), so the largest go first: what is left for the tail of the launch, when
+            // most waves have run dry, are the cheap ones.  Results are stored by pair, the order is free.
+            std::vector<size_t> idx = cls[k];
+            std::stable_sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return tp[a].M > tp[b].M; });
+            std::vector<TvgPair> sub(idx.size()), sub_e;
+            for (size_t i = 0; i < idx.size(); ++i) {
+                sub[i] = tp[idx[i]];
+                cm = std::max(cm, sub[i].M);
+                if (uses_E(idx[i])) sub_e.push_back(sub[i]);
+            }
+            const uint32_t mcap = std::max<uint32_t>(64, round_up(cm, 64));
+            const size_t lds_block = tvg_lds_bytes(mcap, wpb);
+            auto waves_for = [&](size_t n, int waves_per_simd) {
+                const uint32_t blocks_per_cu = (uint32_t)std::max<size_t>(
+                    1, std::min<size_t>(4 * (size_t)waves_per_simd / wpb, (160 * 1024) / std::max<size_t>(lds_block, 1)));
+                uint32_t nw = (uint32_t)std::min<size_t>(n, (size_t)cus * blocks_per_cu * wpb);
+                return std::max<uint32_t>(wpb, (nw + wpb - 1) / wpb * wpb);
+            };
+            const bool run_fh = mode != 3;
+            const uint32_t waves_e = sub_e.empty() ? 0 : waves_for(sub_e.size(), kTvgEWavesPerSimd);
+            const uint32_t waves_fh = run_fh ? waves_for(idx.size(), kTvgFhWavesPerSimd) : 0;
+            HIPCHK(c->d_tpairs.ensure(idx.size()));
+            HIPCHK(c->d_tpairs_e.ensure(std::max<size_t>(sub_e.size(), 1)));
+            HIPCHK(c->d_tws.ensure((size_t)std::max(waves_e, waves_fh) * tvg_ws_doubles_host(mcap)));
+            HIPCHK(c->d_tmaskws.ensure((size_t)std::max<uint32_t>(waves_fh, 1) * tvg_ws_mask_bytes_host(mcap)));
+            HIPCHK(hipMemcpyAsync(c->d_tpairs.p, sub.data(), sub.size() * sizeof(TvgPair), hipMemcpyHostToDevice, st));
+            if (!sub_e.empty())
+                HIPCHK(hipMemcpyAsync(c->d_tpairs_e.p, sub_e.data(), sub_e.size() * sizeof(TvgPair), hipMemcpyHostToDevice, st));
+            HIPCHK(hipStreamSynchronize(st));  // `sub` / `sub_e` go out of scope at the end of the iteration
+            HIPCHK(hipEventRecord(c->ev[2], st));
+            if (!sub_e.empty()) {
+                HIPCHK(launch_tvg_e(c->d_timgs.p, c->d_tpairs_e.p, (uint32_t)sub_e.size(), kernel_matches, c->d_ttabs.p, P,
+                                    c->d_tws.p, mcap, waves_e, wpb, c->d_scalars + 1, c->d_estate.p, c->d_emask.p,
+                                    c->d_tout.p, c->d_toutmask.p, st));
+                ++launches;
+            }
+            if (run_fh) {
+                HIPCHK(launch_tvg_fh(c->d_timgs.p, c->d_tpairs.p, (uint32_t)idx.size(), kernel_matches, c->d_ttabs.p, P,
+                                     c->d_tws.p, c->d_tmaskws.p, mcap, waves_fh, wpb, c->d_scalars + 1, c->d_estate.p,
+                                     c->d_emask.p, c->d_tout.p, c->d_toutmask.p, st));
+                ++launches;
+            }
+            HIPCHK(hipEventRecord(c->ev[3], st));
+            HIPCHK(hipStreamSynchronize(st));  // d_tpairs is rewritten by the next class
+            float kms = 0.f;
+            (void)hipEventElapsedTime(&kms, c->ev[2], c->ev[3]);
+            kernel_ms += kms;
         }
-        const uint32_t mcap = std::max<uint32_t>(64, round_up(cm, 64));
-        const size_t lds_block = tvg_lds_bytes(mcap, tvg_pts_cap(mcap, wpb), wpb);
-        // kTvgWavesPerSimd waves per SIMD (the kernel's register budget): 4 * that many waves per CU
-        const uint32_t blocks_per_cu = (uint32_t)std::max<size_t>(
-            1, std::min<size_t>(4 * kTvgWavesPerSimd / wpb, (160 * 1024) / std::max<size_t>(lds_block, 1)));
-        uint32_t num_waves = (uint32_t)std::min<size_t>(idx.size(), (size_t)cus * blocks_per_cu * wpb);
-        num_waves = std::max<uint32_t>(wpb, (num_waves + wpb - 1) / wpb * wpb);
-        HIPCHK(c->d_tpairs.ensure(idx.size()));
-        HIPCHK(c->d_tws.ensure((size_t)num_waves * tvg_ws_doubles_host(mcap)));
-        HIPCHK(c->d_tmaskws.ensure((size_t)num_waves * tvg_ws_mask_bytes_host(mcap)));
-        HIPCHK(hipMemcpyAsync(c->d_tpairs.p, sub.data(), sub.size() * sizeof(TvgPair), hipMemcpyHostToDevice, st));
-        HIPCHK(hipStreamSynchronize(st));  // `sub` goes out of scope at the end of the iteration
-        HIPCHK(hipEventRecord(c->ev[2], st));
-        HIPCHK(launch_tvg(c->d_timgs.p, c->d_tpairs.p, (uint32_t)idx.size(), kernel_matches, c->d_ttabs.p,
-                          c->d_mtinit.p, P, c->d_tws.p, c->d_tmaskws.p, mcap, num_waves, wpb, c->d_scalars + 1,
-                          c->d_tout.p, c->d_toutmask.p, st));
-        HIPCHK(hipEventRecord(c->ev[3], st));
-        HIPCHK(hipStreamSynchronize(st));  // d_tpairs is rewritten by the next class
-        float kms = 0.f;
-        (void)hipEventElapsedTime(&kms, c->ev[2], c->ev[3]);
-        kernel_ms += kms;
-        ++launches;
+        uint32_t stream_over = 0;
+        HIPCHK(hipMemcpyAsync(&stream_over, c->d_scalars + 4, sizeof stream_over, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (!stream_over) break;
+        // a Lemire rejection loop ran past the table (probability ~1e-6 per 4096 spare words): lay out more, redo
+        if (attempt >= 4 || c->stream_len * 2 > kMaxStreamWords)
+            return fail(AMC_E_HIP, "amc_verify_pairs: the sample stream table was exhausted %d times", attempt + 1);
+        HIPCHK(ensure_stream(c->stream_len * 2));
     }
     // the kernel stores a pair's record at the caller's pair index (TvgPair::orig)
     HIPCHK(hipMemcpyAsync(c->h_tout.p, c->d_tout.p, npairs * sizeof(TvgOut), hipMemcpyDeviceToHost, st));
@@ -1635,8 +1710,6 @@ static int verify_impl(amc_ctx* c, int mode, const uint32_t* slot1, const uint32
     HIPCHK(hipEventSynchronize(c->ev[1]));
     lap(3);
     if (bad_pairs) {  // the kernel met an index past an image's keypoints: find it for the message
-        delete priv;
-        std::memset(out, 0, sizeof *out);
         for (size_t p = 0; p < npairs && matches; ++p) {
             const Slot& a = c->slots[slot1[p]];
             const Slot& b = c->slots[slot2[p]];
@@ -1697,11 +1770,7 @@ static int verify_impl(amc_ctx* c, int mode, const uint32_t* slot1, const uint32
         double pose_ms = 0.0;
         const int rc = pose_impl(c, "amc_verify_pairs", slot1, slot2, npairs, match_offsets, matches, priv->tvg_raw.get(),
                                  priv->pose.data(), &pose_ms, moff.data(), dev_matches, dev_off);
-        if (rc != AMC_OK) {
-            delete priv;
-            std::memset(out, 0, sizeof *out);
-            return rc;
-        }
+        if (rc != AMC_OK) return rc;
         for (size_t p = 0; p < npairs; ++p) priv->tvg_raw[p].config = priv->pose[p].config;
         out->pose = priv->pose.data();
         out->device_ms += pose_ms;
@@ -1709,6 +1778,7 @@ static int verify_impl(amc_ctx* c, int mode, const uint32_t* slot1, const uint32
         out->pose_kernel_ms = pose_ms;
         out->kernel_launches += 1;
     }
+    guard.p = nullptr;
     return AMC_OK;
 }
 

@@ -261,23 +261,49 @@ struct TvgParams {
     // count T in [0, max_trials[3]], the smallest double r with ComputeNumTrials(r) <= T: wm_cut[T] (2.0 when
     // there is none).  The kernel then has dyn_max = the first T with r >= wm_cut[T].
     const double* wm_cut;
+    // The sample stream: std::mt19937(seed) is re-seeded for every pair (D4), so every pair consumes the SAME
+    // sequence - laid out once by the host as tempered 32-bit words.  A RANSAC's generator state is then a position
+    // in this table (no twist, no snapshot, no roll-back of a 624-word state; the position travels from the E kernel
+    // to the F/H kernel in TvgEState).  stream_len covers every RANSAC running to its trial cap; a wave that would
+    // read past it (only through Lemire's rejection loop) counts in *stream_err and the host retries with more.
+    const uint32_t* stream;
+    uint32_t stream_len;
+    uint32_t* stream_err;
 };
-void tvg_diag_report();  // diagnostic builds (-DAMC_TVG_DIAG=2): cycle split of the counting loop, on stderr
+// What the essential-matrix kernel hands to the F/H kernel for one pair: the RANSAC report (the mask goes to the
+// pair's region of a second mask buffer) and the stream position it stopped at.
+struct alignas(64) TvgEState {
+    double model[9];
+    double sum;
+    int32_t cnt, success, num_trials;
+    uint32_t soff;
+};
+void tvg_diag_report();  // (diagnostic builds of earlier rounds; kept for the profile printout's call site)
 size_t tvg_ws_doubles_host(uint32_t mcap);
 size_t tvg_ws_mask_bytes_host(uint32_t mcap);
-// target occupancy of the verification kernel (waves per SIMD): sets its VGPR budget and LDS share
-#ifndef AMC_TVG_WAVES
-#define AMC_TVG_WAVES 2
+// Target occupancy (waves per SIMD) of the two verification kernels: sets their VGPR budgets and LDS shares.
+// tvg_e_kernel holds the 5-point solver (~200 live doubles per lane): 2.  tvg_fh_kernel (7-point / 4-point solvers,
+// counting loops with lane-resident models) runs more waves to hide its LDS / scalar-load / FP64 latencies.
+#ifndef AMC_E_WAVES
+#define AMC_E_WAVES 2
 #endif
-constexpr int kTvgWavesPerSimd = AMC_TVG_WAVES;
-size_t tvg_lds_bytes(uint32_t mcap, uint32_t pts_cap, int waves);
-uint32_t tvg_pts_cap(uint32_t mcap, int waves_per_block);
+#ifndef AMC_FH_WAVES
+#define AMC_FH_WAVES 4
+#endif
+constexpr int kTvgEWavesPerSimd = AMC_E_WAVES;
+constexpr int kTvgFhWavesPerSimd = AMC_FH_WAVES;
+size_t tvg_lds_bytes(uint32_t mcap, int waves);
 hipError_t launch_sampson(const double* p1, const double* p2, size_t n, const double* E9, double* out,
                           hipStream_t s);
-hipError_t launch_tvg(const TvgImage* imgs, const TvgPair* pairs, uint32_t npairs,
-                      const uint32_t* matches, const uint32_t* trial_tabs, const uint32_t* mt_init,
-                      const TvgParams& P, double* ws, uint8_t* mask_ws, uint32_t mcap,
-                      uint32_t num_waves, int waves_per_block, uint32_t* queue_head, TvgOut* out,
-                      uint8_t* out_mask, hipStream_t s);
+// the essential-matrix RANSAC of the listed (calibrated) pairs -> estate[pair.orig], emask + pair.mask_off
+hipError_t launch_tvg_e(const TvgImage* imgs, const TvgPair* pairs, uint32_t npairs, const uint32_t* matches,
+                        const uint32_t* trial_tabs, const TvgParams& P, double* ws, uint32_t mcap, uint32_t num_waves,
+                        int waves_per_block, uint32_t* queue_head, TvgEState* estate, uint8_t* emask, TvgOut* out,
+                        uint8_t* out_mask, hipStream_t s);
+// F and H RANSACs, model selection, watermark test of the listed pairs (after launch_tvg_e on the same stream)
+hipError_t launch_tvg_fh(const TvgImage* imgs, const TvgPair* pairs, uint32_t npairs, const uint32_t* matches,
+                         const uint32_t* trial_tabs, const TvgParams& P, double* ws, uint8_t* mask_ws, uint32_t mcap,
+                         uint32_t num_waves, int waves_per_block, uint32_t* queue_head, const TvgEState* estate,
+                         const uint8_t* emask, TvgOut* out, uint8_t* out_mask, hipStream_t s);
 
 }  // namespace amc

@@ -1,0 +1,1643 @@
+// tvg_core.h — device code of the batched two-view geometric verification (COLMAP EstimateTwoViewGeometry,
+// SURVEY.md A.3) on gfx950: one LO-RANSAC (LORANSAC<Est, LocalEst>::Estimate) by one wavefront.  Included by the two
+// kernels that run it, each with its own register budget and occupancy:
+//   tvg_e.hip   the essential-matrix RANSAC (5-point solver: 200 live doubles per lane, 2 waves per SIMD)
+//   tvg_fh.hip  the fundamental-matrix and homography RANSACs, model selection, watermark test (AMC_FH_WAVES per SIMD)
+// (one translation unit each: a device function shared by kernels with different occupancy attributes is compiled
+// for the loosest of them).
+//
+// Mapping.  A persistent grid of wavefronts pulls image pairs from a queue; ONE WAVE owns one pair at a time (no
+// workgroup barriers anywhere), and inside the wave the 64 lanes are
+//   * 64 RANSAC trials for the minimal solvers (one trial per lane, tvg_math.h),
+//   * 64 MODELS for inlier counting: every lane keeps one model of the chunk in registers and the correspondences
+//     stream past through the scalar unit (s_load from a per-wave table -> SGPR operands of the vector FMAs): no
+//     ballots, no broadcasts, no cross-lane traffic in the inner loop,
+//   * 64 strided correspondences for exact residual scoring, normalisation sums and A^T A accumulation (the fixed
+//     64-way strided + butterfly order of the oracle's det_sum64, which is exactly what a wave computes with
+//     __shfl_xor),
+//   * cooperating workers on the single dense problems of the local-optimisation step: the disjoint rotations of a
+//     Jacobi round, the sign-change brackets of a root-finding level.
+// RANSAC is sequential by definition (the adaptive trial count depends on the best model so far); what is
+// data-INdependent is the sample stream.  std::mt19937(seed) is the same sequence for every pair, so the host lays
+// out its tempered words once (TvgParams::stream) and a RANSAC's generator state is just a position in that table:
+// per 64-trial chunk the wave turns 64 x kMin words into the 64 samples (libstdc++'s Lemire uniform_int + the
+// persistent partial Fisher-Yates permutation, reproduced exactly; sample_chunk), solves the 64 minimal problems in
+// parallel (solve_chunk), counts the inliers of every resulting model (count_chunk), and then replays only the trials
+// that can matter - a model whose count reaches the best so far, or the first trial at the adaptive limit - in trial
+// order, re-scoring them in full (lo_ransac).  If a RANSAC stops inside a chunk, the position is set back to where
+// the sequential algorithm would have stopped drawing, because the next RANSAC of the pair continues the stream.
+//
+// FP64 everywhere a decision is final, -ffp-contract=off, IEEE divide/sqrt: results are bit-identical to
+// oracle/tvg_oracle.cc (inlier masks, configs, model bit patterns).
+#pragma once
+#include <algorithm>
+#include <cstdio>
+
+#include "amc_internal.h"
+#include "camera_math.h"
+#include "tvg_math.h"
+
+namespace amc {
+namespace {
+using namespace tvg;
+
+enum : int { K_F7 = 0, K_F8 = 1, K_H = 2, K_T = 3, K_E5 = 4 };
+__device__ __forceinline__ constexpr int kmin_of(int kind) {
+    return kind == K_F7 ? 7 : kind == K_F8 ? 8 : kind == K_H ? 4 : kind == K_T ? 1 : 5;
+}
+
+constexpr int kMaxModels = 10;
+constexpr int kModelDoubles = 64 * kMaxModels * 9;
+
+// LDS objects are addressed through address-space-3 pointers so that every access is a ds_* instruction (a generic
+// pointer makes the compiler emit flat_* loads, which take the vector-memory path and cost several hundred cycles).
+#define AMC_LDS __attribute__((address_space(3)))
+typedef AMC_LDS double lds_f64;
+typedef AMC_LDS uint32_t lds_u32;
+typedef AMC_LDS int32_t lds_i32;
+typedef AMC_LDS uint16_t lds_u16;
+// Wave-uniform reads of global tables through the scalar data cache (s_load_*): the table is either never written by
+// the kernel (the sample stream) or written by this wave, drained and followed by s_dcache_inv (scalar_table_sync).
+#define AMC_CONST __attribute__((address_space(4)))
+
+// Algorithmic work of a pair, counted as the sequential algorithm does it (TvgOut::work): what COLMAP's loops
+// evaluate - every model of every trial up to the stopping trial against all M correspondences, every local model
+// against all M, one final residual pass per successful RANSAC - not what this kernel skips.
+enum : int { WK_SAMPSON = 0, WK_HRES, WK_TRES, WK_E5MIN, WK_F7MIN, WK_H4MIN, WK_LO_E5, WK_LO_F8, WK_LO_H, WK_LO_POINTS,
+              WK_TRIALS, WK_COUNT };
+__device__ __forceinline__ constexpr int wk_residual_slot(int kind) { return kind == K_H ? WK_HRES : (kind == K_T ? WK_TRES : WK_SAMPSON); }
+
+struct Wave {
+    int lane;
+    unsigned long long prof[8];
+    unsigned long long* work;  // the pair's TvgOut::work (global memory, lane 0 adds to it: a few times per 64 trials)
+    // LDS
+    lds_u16* sidx;    // 64 x 8: the chunk's samples
+    lds_u32* rawcnt;  // 64: raw words consumed up to and including trial t of the chunk
+    lds_i32* tmax;    // 64: largest count among trial t's models (count_models)
+    lds_u16* mlist;   // 64 x kMaxModels: the chunk's models in (trial, root) order (count_models)
+    lds_u16* perm;    // mcap: the sampler's persistent permutation
+    lds_u16* inl;     // mcap: ordered inlier index list of the local-optimisation step
+    lds_f64* jacA;    // 81: A^T A / eigenvalues (and scratch of the wave-wide 5-point solve)
+    lds_f64* jacV;    // 81: eigenvectors
+    // the sample stream: tempered words of std::mt19937(seed), soff = words consumed so far (wave-uniform)
+    const uint32_t* stream;
+    uint32_t stream_len;
+    uint32_t soff;
+    uint32_t* err;    // [0] += 1 when a RANSAC ran past the end of the stream table (the host retries with a longer one)
+    // global workspace
+    double* ws;        // W_NUM_ARRAYS x mcap point arrays | AoS table | models
+    uint8_t* masks;    // 4 x mcap
+    uint32_t mcap;
+};
+// per-wave global workspace: SoA point arrays (doubles, mcap each) ...
+enum : int { W_X1 = 0, W_Y1, W_X2, W_Y2, W_AX1, W_AY1, W_AX2, W_AY2, W_NUM_ARRAYS };
+// ... then the tables the counting loops read through the scalar cache: (x1, y1, x2, y2) as doubles, one 32-byte
+// record per correspondence, and the packed-FP32 table of the homography pre-filter (16 bytes per correspondence,
+// two correspondences interleaved: a0 a1 b0 b1 c0' c1' d0' d1'), then the chunk's models (E / F: kMaxModels per trial)
+__host__ __device__ inline size_t tvg_ws_doubles(uint32_t mcap) {
+    return (size_t)W_NUM_ARRAYS * mcap + (size_t)4 * mcap + (size_t)2 * mcap + kModelDoubles;
+}
+__device__ __forceinline__ double* ws_arr(const Wave& w, int a) { return w.ws + (size_t)a * w.mcap; }
+__device__ __forceinline__ double* ws_p64(const Wave& w) { return w.ws + (size_t)W_NUM_ARRAYS * w.mcap; }
+__device__ __forceinline__ float* ws_p32(const Wave& w) { return reinterpret_cast<float*>(w.ws + (size_t)(W_NUM_ARRAYS + 4) * w.mcap); }
+__device__ __forceinline__ double* ws_models(const Wave& w) { return w.ws + (size_t)(W_NUM_ARRAYS + 6) * w.mcap; }
+// LDS bytes of one wave: jacA + jacV | sidx | rawcnt | tmax | mlist | perm | inl
+__host__ __device__ inline size_t tvg_lds_per_wave(uint32_t mcap) {
+    const size_t per = (size_t)162 * 8 + 64 * 8 * 2 + 64 * 4 + 64 * 4 + 64 * kMaxModels * 2 + (size_t)((mcap + 7) / 8 * 8) * 2 * 2;
+    return (per + 15) / 16 * 16;
+}
+__host__ __device__ inline size_t tvg_ws_bytes_extra(uint32_t mcap) { return (size_t)4 * mcap; }  // 4 masks
+
+__device__ __forceinline__ void wave_carve(Wave& w, AMC_LDS char* base, uint32_t mcap) {
+    w.jacA = reinterpret_cast<lds_f64*>(base);
+    w.jacV = w.jacA + 81;
+    w.sidx = reinterpret_cast<lds_u16*>(base + 162 * 8);
+    w.rawcnt = reinterpret_cast<lds_u32*>(w.sidx + 64 * 8);
+    w.tmax = reinterpret_cast<lds_i32*>(w.rawcnt + 64);
+    w.mlist = reinterpret_cast<lds_u16*>(w.tmax + 64);
+    w.perm = w.mlist + 64 * kMaxModels;
+    w.inl = w.perm + (mcap + 7) / 8 * 8;
+    w.mcap = mcap;
+}
+
+// Global-memory hand-off between lanes of ONE wave (a lane reads what another lane of the same
+// wave stored): drain this wave's stores, then keep the compiler from moving accesses across.
+__device__ __forceinline__ void wave_mem_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+// ... and when the reader is the scalar unit (AMC_CONST loads): the stores are drained to L2 (the vector L1 is
+// write-through), then the scalar data cache - which does not snoop vector stores, and may hold lines of the previous
+// pair's table at the same addresses - is invalidated
+__device__ __forceinline__ void scalar_table_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+    __builtin_amdgcn_s_dcache_inv();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the invalidation has completed before the next s_load issues
+    __builtin_amdgcn_wave_barrier();
+}
+// LDS hand-off inside the wave: LDS operations of a wave complete in order, the barrier only
+// stops the compiler from reordering across it
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// broadcast lane `src`'s double to the whole wave through the scalar unit (src is wave-uniform)
+__device__ __forceinline__ double readlane_f64(double v, int src) {
+    const unsigned long long u = __double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, src);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), src);
+    return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+}
+
+// ---- wave reductions in the oracle's det_sum64 order ---------------------------------------------
+__device__ __forceinline__ double butterfly(double v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = v + __shfl_xor(v, m);
+    return v;
+}
+__device__ __forceinline__ int wave_sum_int(int v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+__device__ __forceinline__ uint32_t sgpr(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+// wave-uniform values that arrive in vector registers (function arguments) -> scalar registers
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ double uni(double v) { return readlane_f64(v, 0); }
+template <class T>
+__device__ __forceinline__ T* uni_ptr(T* p) {
+    const unsigned long long u = (unsigned long long)p;
+    const unsigned lo = uni((uint32_t)u), hi = uni((uint32_t)(u >> 32));
+    return (T*)(((unsigned long long)hi << 32) | lo);
+}
+template <class T>
+__device__ __forceinline__ AMC_LDS T* uni_lds(AMC_LDS T* p) {
+    return (AMC_LDS T*)(uintptr_t)uni((uint32_t)(uintptr_t)p);
+}
+template <class T>
+__device__ __forceinline__ const AMC_CONST T* as_const_table(const T* p) {  // p wave-uniform
+    return (const AMC_CONST T*)(unsigned long long)uni_ptr(p);
+}
+
+// ---- RandomSampler::Sample for a chunk of nT consecutive trials -----------------------------------
+// The sample stream does not depend on the data, so a chunk's draws are produced ahead of the trials that use them.
+// Per draw the sequential algorithm does j = uniform_int(i, M-1) and swap(perm[i], perm[j]).  Fast path: all
+// nT*kMin words are turned into j by the lanes in parallel (Lemire's multiply-shift on the tempered word; the
+// rejection branch `low < range` has probability range / 2^32 per draw); only the swaps stay sequential.  If any
+// draw of the chunk needs the rejection branch the chunk is redone draw by draw from the same position, exactly as
+// libstdc++ does it.  perm[0..kMin) lives in registers (pr), the rest in LDS.
+struct SamplerState {
+    uint32_t off;   // stream position
+    uint32_t pr[7];
+};
+__device__ __forceinline__ uint32_t stream_word(const AMC_CONST uint32_t* stream, uint32_t len, uint32_t pos, bool& over) {
+    over |= pos >= len;
+    return stream[pos < len ? pos : len - 1];
+}
+
+template <int kMin>
+__device__ __forceinline__ SamplerState sample_chunk_t(const uint32_t* stream, uint32_t slen, lds_u16* perm, lds_u16* sidx,
+                                                       lds_u32* rawcnt, SamplerState st, int M, int nT, int lane,
+                                                       int force_slow, uint32_t* err) {
+    const int need = nT * kMin;
+    // ---- parallel: tempered word -> j, for the whole chunk ----
+    bool slowflag = force_slow != 0;
+    const bool fits = st.off + (uint32_t)need <= slen;
+    if (fits) {
+        for (int n0 = 0; n0 < need; n0 += 64) {
+            const int n = n0 + lane;
+            if (n < need) {
+                const int t = n / kMin, i = n - t * kMin;
+                const uint32_t range = (uint32_t)(M - i);
+                const uint64_t product = (uint64_t)stream[st.off + (uint32_t)n] * (uint64_t)range;
+                if ((uint32_t)product < range) slowflag = true;
+                sidx[t * 8 + i] = (uint16_t)((uint32_t)i + (uint32_t)(product >> 32));
+            }
+        }
+    } else {
+        slowflag = true;  // the table ends inside this chunk: the draw-by-draw path checks every word
+    }
+    wave_lds_sync();
+    if (__ballot(slowflag) == 0ull) {
+        // ---- sequential swaps ----
+        // Lane i < kMin owns slot i of the permutation's head (prv); one trial is, per slot, v = perm[j],
+        // perm[j] = prv, prv = v - independent across slots as long as the trial's j are distinct and
+        // none falls into the head.  Those trials (classified up front, lane t looks at trial t) take
+        // one LDS read + two writes per lane, and the only dependence from trial to trial is the read
+        // of t feeding the write of t + 1, so consecutive trials overlap in the in-order LDS queue.
+        // The others (a few per cent) run the scalar, slot-by-slot code on the gathered head.
+        // Lane t keeps trial t's draws in registers (jj); the loop below fetches them with readlane, so the
+        // LDS queue only carries the permutation traffic and the wait before a trial's write is for the read
+        // issued one trial earlier (sidx of trial t is stored during trial t + 1 for the same reason).
+        unsigned long long slowmask;
+        uint32_t jj[7];
+        {
+            bool odd = false;
+#pragma unroll
+            for (int i = 0; i < 7; ++i)
+                jj[i] = (i < kMin && lane < nT) ? (uint32_t)sidx[lane * 8 + i] : 0xFFFF0000u + (uint32_t)i;
+#pragma unroll
+            for (int i = 0; i < 7; ++i) {
+                odd |= jj[i] < (uint32_t)kMin;
+#pragma unroll
+                for (int q = i + 1; q < 7; ++q) odd |= jj[i] == jj[q];
+            }
+            if (lane < nT) rawcnt[lane] = (uint32_t)((lane + 1) * kMin);
+            slowmask = __ballot(odd && lane < nT);
+        }
+        wave_lds_sync();  // every lane has its draws before the rows are overwritten with the samples
+        uint32_t prv = 0;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) prv = lane == i ? st.pr[i] : prv;
+        const bool slot = lane < kMin;
+        int t = 0;
+        while (t < nT) {
+            const unsigned long long rest = slowmask >> t;
+            int run = rest ? (int)__builtin_ctzll(rest) : 64;
+            run = min(run, nT - t);
+            // two trials per round on alternating registers: the value read by one trial is stored by the
+            // next, and nothing in between needs it (no copy, so no wait on the read just issued).  `pend` is
+            // the trial whose samples (the value about to be stored) are not in sidx yet; at the start of a
+            // run that store repeats what trial t - 1 already wrote (row 0 when there is none: rewritten below).
+            int pend = max(t - 1, 0);
+            uint32_t a = prv;
+            const int e = t + run;
+            while (t + 1 < e) {
+                uint32_t j0 = 0, j1 = 0;
+#pragma unroll
+                for (int i = 0; i < 7; ++i)
+                    if (i < kMin) {
+                        const uint32_t x0 = (uint32_t)__builtin_amdgcn_readlane((int)jj[i], t);
+                        const uint32_t x1 = (uint32_t)__builtin_amdgcn_readlane((int)jj[i], t + 1);
+                        j0 = lane == i ? x0 : j0;
+                        j1 = lane == i ? x1 : j1;
+                    }
+                if (slot) {
+                    const uint32_t b = perm[j0];
+                    perm[j0] = (uint16_t)a;
+                    sidx[pend * 8 + lane] = (uint16_t)a;
+                    a = perm[j1];
+                    perm[j1] = (uint16_t)b;
+                    sidx[t * 8 + lane] = (uint16_t)b;
+                }
+                pend = t + 1;
+                t += 2;
+            }
+            if (t < e) {
+                uint32_t j0 = 0;
+#pragma unroll
+                for (int i = 0; i < 7; ++i)
+                    if (i < kMin) {
+                        const uint32_t x0 = (uint32_t)__builtin_amdgcn_readlane((int)jj[i], t);
+                        j0 = lane == i ? x0 : j0;
+                    }
+                if (slot) {
+                    const uint32_t b = perm[j0];
+                    perm[j0] = (uint16_t)a;
+                    sidx[pend * 8 + lane] = (uint16_t)a;
+                    a = b;
+                }
+                pend = t;
+                ++t;
+            }
+            if (run > 0 && slot) sidx[pend * 8 + lane] = (uint16_t)a;
+            prv = a;
+            if (t >= nT) break;
+            // trial t touches the head or draws an index twice: slot by slot on the gathered head
+            uint32_t j[7], pr[7];
+#pragma unroll
+            for (int i = 0; i < 7; ++i) {
+                j[i] = i < kMin ? (uint32_t)__builtin_amdgcn_readlane((int)jj[i], t) : 0xFFFFu;
+                pr[i] = i < kMin ? (uint32_t)__builtin_amdgcn_readlane((int)prv, i) : 0u;
+            }
+#pragma unroll
+            for (int i = 0; i < 7; ++i) {
+                if (i < kMin) {
+                    if (j[i] < (uint32_t)kMin) {
+                        uint32_t vj = pr[0];
+#pragma unroll
+                        for (int q = 1; q < 7; ++q) vj = (j[i] == (uint32_t)q) ? pr[q] : vj;
+                        const uint32_t vi = pr[i];
+#pragma unroll
+                        for (int q = 0; q < 7; ++q) pr[q] = (j[i] == (uint32_t)q) ? vi : pr[q];
+                        pr[i] = vj;
+                    } else {
+                        const uint32_t vj = sgpr(perm[j[i]]);
+                        perm[j[i]] = (uint16_t)pr[i];
+                        pr[i] = vj;
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 7; ++i) prv = (i < kMin && lane == i) ? pr[i] : prv;
+            if (slot) sidx[t * 8 + lane] = (uint16_t)prv;
+            ++t;
+        }
+#pragma unroll
+        for (int i = 0; i < 7; ++i) st.pr[i] = i < kMin ? (uint32_t)__builtin_amdgcn_readlane((int)prv, i) : st.pr[i];
+        st.off += (uint32_t)need;
+        wave_lds_sync();
+        return st;
+    }
+    // ---- a draw hit the rejection branch (or the table is about to end): the chunk draw by draw ----
+    const AMC_CONST uint32_t* cs = as_const_table(stream);
+    uint32_t pos = st.off;
+    uint32_t nraw = 0;
+    bool over = false;
+    for (int t = 0; t < nT; ++t) {
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            if (i < kMin) {
+                const uint32_t range = (uint32_t)(M - i);
+                uint64_t product;
+                uint32_t low;
+                {
+                    ++nraw;
+                    product = (uint64_t)stream_word(cs, slen, pos++, over) * (uint64_t)range;
+                    low = (uint32_t)product;
+                }
+                if (low < range) {
+                    const uint32_t threshold = (0u - range) % range;
+                    while (low < threshold && !over) {
+                        ++nraw;
+                        product = (uint64_t)stream_word(cs, slen, pos++, over) * (uint64_t)range;
+                        low = (uint32_t)product;
+                    }
+                }
+                const uint32_t jj = (uint32_t)(product >> 32) + (uint32_t)i;
+                if (jj < (uint32_t)kMin) {
+                    uint32_t vj = st.pr[0];
+#pragma unroll
+                    for (int q = 1; q < 7; ++q) vj = (jj == (uint32_t)q) ? st.pr[q] : vj;
+                    const uint32_t vi = st.pr[i];
+#pragma unroll
+                    for (int q = 0; q < 7; ++q) st.pr[q] = (jj == (uint32_t)q) ? vi : st.pr[q];
+                    st.pr[i] = vj;
+                } else {
+                    const uint32_t vj = sgpr(perm[jj]);
+                    perm[jj] = (uint16_t)st.pr[i];
+                    st.pr[i] = vj;
+                }
+            }
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < 7; ++i) sidx[t * 8 + i] = (uint16_t)st.pr[i];
+            rawcnt[t] = nraw;
+        }
+    }
+    if (over && lane == 0) atomicAdd(err, 1u);
+    st.off = pos;
+    wave_lds_sync();
+    return st;
+}
+
+template <int kMin>
+__device__ __noinline__ SamplerState sample_chunk(const uint32_t* stream_, uint32_t slen_, lds_u16* perm_, lds_u16* sidx_,
+                                                  lds_u32* rawcnt_, SamplerState st, int M_, int nT_, int lane,
+                                                  int force_slow_, uint32_t* err_) {
+    // everything but `lane` is wave-uniform: move it to scalar registers
+    const uint32_t* stream = uni_ptr(stream_);
+    uint32_t* err = uni_ptr(err_);
+    lds_u16* perm = uni_lds(perm_);
+    lds_u16* sidx = uni_lds(sidx_);
+    lds_u32* rawcnt = uni_lds(rawcnt_);
+    const int M = uni(M_), nT = uni(nT_), force_slow = uni(force_slow_);
+    const uint32_t slen = uni(slen_);
+    st.off = uni(st.off);
+#pragma unroll
+    for (int i = 0; i < 7; ++i) st.pr[i] = sgpr(st.pr[i]);
+    return sample_chunk_t<kMin>(stream, slen, perm, sidx, rawcnt, st, M, nT, lane, force_slow, err);
+}
+
+// ---- the active RANSAC's correspondences: four arrays in the wave's global workspace -----------------
+struct Pts {
+    const double* g;   // x1 | y1 | x2 | y2, each `gs` long
+    uint32_t gs;
+};
+__device__ __forceinline__ Pts uni(Pts P) {
+    Pts Q;
+    Q.g = uni_ptr(P.g);
+    Q.gs = uni(P.gs);
+    return Q;
+}
+__device__ __forceinline__ void load_pt(const Pts& P, int k, double& a, double& b, double& c, double& d) {
+    a = P.g[k]; b = P.g[P.gs + k]; c = P.g[2 * (size_t)P.gs + k]; d = P.g[3 * (size_t)P.gs + k];
+}
+
+template <int KIND>
+__device__ __forceinline__ double residual_t(const double* m, double a, double b, double c, double d) {
+    return KIND == K_H ? h_residual(m, a, b, c, d) : (KIND == K_T ? t_residual(m, a, b, c, d) : sampson(m, a, b, c, d));
+}
+__device__ __forceinline__ double residual_of(int kind, const double* m, double a, double b, double c, double d) {
+    if (kind == K_H) return h_residual(m, a, b, c, d);
+    if (kind == K_T) return t_residual(m, a, b, c, d);
+    return sampson(m, a, b, c, d);
+}
+
+struct Model9 {
+    double v[9];
+};
+struct Support {
+    int cnt;
+    double sum;
+};
+__device__ __forceinline__ bool better(const Support a, const Support b) {
+    if (a.cnt > b.cnt) return true;
+    return a.cnt == b.cnt && a.sum < b.sum;
+}
+// InlierSupportMeasurer::Evaluate.  The count comes from ballots (wave-uniform by construction);
+// the residual sum is only ever consulted when the count ties or beats the best so far
+// (Compare()), so its 64-way butterfly is skipped otherwise (`need_sum_from` = that count).
+template <int KIND>
+__device__ __noinline__ Support score(const Model9 mv, const Pts P_, int M_, double max_res_, int lane, int need_sum_from) {
+    double m[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) m[i] = uni(mv.v[i]);
+    const Pts P = uni(P_);
+    const int M = uni(M_);
+    const double max_res = uni(max_res_);
+    double acc = 0.0;
+    int cnt = 0;
+    for (int k0 = 0; k0 < M; k0 += 64) {
+        const int k = k0 + lane;
+        bool in = false;
+        if (k < M) {
+            double a, b, c, d;
+            load_pt(P, k, a, b, c, d);
+            const double r = residual_t<KIND>(m, a, b, c, d);
+            in = r <= max_res;
+            if (in) acc += r;
+        }
+        cnt += __popcll(__ballot(in));
+    }
+    Support s;
+    s.cnt = cnt;
+    s.sum = cnt >= need_sum_from ? butterfly(acc) : 1.7976931348623157e308;
+    return s;
+}
+
+// ---- local optimisation over the ordered inlier list w.inl[0..K) ---------------------------------
+// ordered compaction of the inlier indices of `model` (kind); returns K
+__device__ __noinline__ int extract_inliers(lds_u16* inl, int lane, int kind, const Model9 mv, const Pts P, int M,
+                                            double max_res) {
+    const double* model = mv.v;
+    int base = 0;
+    for (int k0 = 0; k0 < M; k0 += 64) {
+        const int k = k0 + lane;
+        bool in = false;
+        if (k < M) {
+            double a, b, c, d;
+            load_pt(P, k, a, b, c, d);
+            in = residual_of(kind, model, a, b, c, d) <= max_res;
+        }
+        const unsigned long long bal = __ballot(in);
+        if (in) inl[base + __popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)k;
+        base += __popcll(bal);
+    }
+    wave_lds_sync();
+    return base;
+}
+
+// CenterAndNormalizeImagePoints over the K listed points of image `img` (0: x1,y1; 1: x2,y2):
+// only the transform T is produced; the normalised coordinates are recomputed where they are
+// consumed (apply_T), with the operations of the reference loop, instead of being stored.
+struct LoCtx {  // what the local estimators need of the wave, passed by value (registers)
+    lds_u16* inl;
+    lds_f64* jacA;
+    lds_f64* jacV;
+    int lane;
+};
+__device__ __forceinline__ void center_T(const LoCtx& w, const Pts& P, int img, int K, double* T) {
+    const int lane = w.lane;
+    double ax = 0.0, ay = 0.0;
+    for (int k = lane; k < K; k += 64) {
+        double p[4];
+        load_pt(P, w.inl[k], p[0], p[1], p[2], p[3]);
+        ax += p[2 * img]; ay += p[2 * img + 1];
+    }
+    const double cx = butterfly(ax) / (double)K;
+    const double cy = butterfly(ay) / (double)K;
+    double ar = 0.0;
+    for (int k = lane; k < K; k += 64) {
+        double p[4];
+        load_pt(P, w.inl[k], p[0], p[1], p[2], p[3]);
+        const double ddx = p[2 * img] - cx, ddy = p[2 * img + 1] - cy;
+        ar += ddx * ddx + ddy * ddy;
+    }
+    double rms = butterfly(ar);
+    rms = dsqrt(rms / (double)K);
+    const double nf = dsqrt(2.0) / rms;
+    T[0] = nf; T[1] = 0; T[2] = -nf * cx;
+    T[3] = 0; T[4] = nf; T[5] = -nf * cy;
+    T[6] = 0; T[7] = 0; T[8] = 1;
+}
+__device__ __forceinline__ void apply_T(const double* T, double p0, double p1, double& o0, double& o1) {
+    const double np0 = T[0] * p0 + T[1] * p1 + T[2];
+    const double np1 = T[3] * p0 + T[4] * p1 + T[5];
+    const double np2 = T[6] * p0 + T[7] * p1 + T[8];
+    const double inv = 1.0 / np2;
+    o0 = np0 * inv;
+    o1 = np1 * inv;
+}
+
+// A^T A (9 x 9, symmetric) over the design rows of the listed correspondences, every entry in
+// det_sum64 order: each lane keeps the partial sums of its strided rows, then one butterfly per entry.
+//   MODE 0: epipolar row [x1 x2, y1 x2, x2, x1 y2, y1 y2, y2, x1, y1, 1]      (F8 / E5), K rows
+//   MODE 1: homography rows; r < K -> "a" row of point r, r >= K -> "b" row of point r-K, 2K rows
+// NORM: correspondences are normalised by T1 / T2 first.
+// The 45 entries are accumulated in two passes over the rows (rows 0..3 of the triangle: 30 entries, rows 4..8: 15)
+// so that the accumulators of a pass fit the register budget of a 4-waves-per-SIMD kernel; an entry's sum sees the
+// same addends in the same order either way.
+template <int MODE, bool NORM, int I0, int I1>
+__device__ __forceinline__ void ata_pass(const LoCtx& w, const Pts& P, int K, const double* T1, const double* T2) {
+    constexpr int NE = (9 - I0) * (9 - I0 + 1) / 2 - (9 - I1) * (9 - I1 + 1) / 2;  // entries (i, j >= i) with I0 <= i < I1
+    const int lane = w.lane;
+    const int rows = MODE == 1 ? 2 * K : K;
+    double acc[NE];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) acc[e] = 0.0;
+    for (int r0 = lane; r0 < rows; r0 += 64) {
+        const int k = (MODE == 1 && r0 >= K) ? r0 - K : r0;
+        double x1, y1, x2, y2;
+        load_pt(P, w.inl[k], x1, y1, x2, y2);
+        if (NORM) {
+            apply_T(T1, x1, y1, x1, y1);
+            apply_T(T2, x2, y2, x2, y2);
+        }
+        double r[9];
+        if (MODE == 0) {
+            r[0] = x1 * x2; r[1] = y1 * x2; r[2] = x2;
+            r[3] = x1 * y2; r[4] = y1 * y2; r[5] = y2;
+            r[6] = x1; r[7] = y1; r[8] = 1.0;
+        } else if (r0 < K) {
+            r[0] = -x1; r[1] = -y1; r[2] = -1; r[3] = 0; r[4] = 0; r[5] = 0;
+            r[6] = x1 * x2; r[7] = y1 * x2; r[8] = x2;
+        } else {
+            r[0] = 0; r[1] = 0; r[2] = 0; r[3] = -x1; r[4] = -y1; r[5] = -1;
+            r[6] = x1 * y2; r[7] = y1 * y2; r[8] = y2;
+        }
+        int e = 0;
+#pragma unroll
+        for (int i = I0; i < I1; ++i)
+#pragma unroll
+            for (int j = i; j < 9; ++j) acc[e++] += r[i] * r[j];
+    }
+    int e = 0;
+#pragma unroll
+    for (int i = I0; i < I1; ++i)
+#pragma unroll
+        for (int j = i; j < 9; ++j) {
+            const double sres = butterfly(acc[e++]);
+            if (lane == 0) {
+                w.jacA[i * 9 + j] = sres;
+                w.jacA[j * 9 + i] = sres;
+            }
+        }
+}
+template <int MODE, bool NORM>
+__device__ __forceinline__ void ata_impl(const LoCtx& w, const Pts& P, int K, const double* T1, const double* T2) {
+    ata_pass<MODE, NORM, 0, 4>(w, P, K, T1, T2);
+    ata_pass<MODE, NORM, 4, 9>(w, P, K, T1, T2);
+    wave_lds_sync();
+}
+
+// Round-robin Jacobi (tvg_math.h jacobi_eigen) on a symmetric n x n matrix held in LDS, the whole
+// wave cooperating.  Per round: lane e < n/2 computes the rotation of the round's e-th pair; lane
+// (e, k) = e * n + k then updates entry k of columns p_e, q_e of A and V, and after a barrier entry
+// k of rows p_e, q_e of A.  Every element sees exactly the arithmetic of the scalar version, so the
+// results are bit-identical; the pairs of a round being disjoint, no two lanes touch one entry
+// within a phase.
+// jacobi_pair(9, r, e, p, q) without the run-time modulo (m = 9 rounds, 4 pairs per round)
+__device__ __forceinline__ void jacobi_pair9(int r, int e, int& p, int& q) {
+    int x = r + e + 1, y = r - (e + 1);
+    x = x >= 9 ? x - 9 : x;
+    y = y < 0 ? y + 9 : y;
+    p = x < y ? x : y;
+    q = x < y ? y : x;
+}
+__device__ __noinline__ void jacobi_eigen_wave(lds_f64* A, lds_f64* V, int lane) {
+    constexpr int n = 9, rounds = 9, np = 4;  // the only size the kernel decomposes as a wave
+    for (int i = lane; i < n * n; i += 64) V[i] = ((i / n) == (i % n)) ? 1.0 : 0.0;
+    wave_lds_sync();
+    double total = 0.0;
+    for (int i = 0; i < n * n; ++i) total += A[i] * A[i];
+    const double tol = total * 1e-32;
+    const int e_of = lane / n, k_of = lane - e_of * n;  // this lane's (pair, entry) in the update phases
+    for (int sweep = 0; sweep < 40; ++sweep) {
+        double off = 0.0;
+#pragma unroll
+        for (int p = 0; p < n - 1; ++p)
+#pragma unroll
+            for (int q = p + 1; q < n; ++q) off += A[p * n + q] * A[p * n + q];
+        if (!(off > tol)) break;
+        for (int r = 0; r < rounds; ++r) {
+            // rotation parameters: lane e computes pair e
+            double c = 1.0, s = 0.0;
+            bool act = false;
+            if (lane < np) {
+                int p, q;
+                jacobi_pair9(r, lane, p, q);
+                act = jacobi_rotation(A[p * n + p], A[q * n + q], A[p * n + q], c, s);
+            }
+            const double ce = __shfl(c, e_of), se = __shfl(s, e_of);
+            const bool acte = __shfl((int)act, e_of) != 0 && e_of < np;
+            int p = 0, q = 0;
+            if (e_of < np) jacobi_pair9(r, e_of, p, q);
+            wave_lds_sync();
+            if (acte) {  // columns p, q of A and V, entry k
+                const double akp = A[k_of * n + p], akq = A[k_of * n + q];
+                const double vkp = V[k_of * n + p], vkq = V[k_of * n + q];
+                A[k_of * n + p] = ce * akp - se * akq;
+                A[k_of * n + q] = se * akp + ce * akq;
+                V[k_of * n + p] = ce * vkp - se * vkq;
+                V[k_of * n + q] = se * vkp + ce * vkq;
+            }
+            wave_lds_sync();
+            if (acte) {  // rows p, q of A, entry k
+                const double apk = A[p * n + k_of], aqk = A[q * n + k_of];
+                A[p * n + k_of] = ce * apk - se * aqk;
+                A[q * n + k_of] = se * apk + ce * aqk;
+            }
+            wave_lds_sync();
+        }
+    }
+}
+// eigenvector of the smallest eigenvalue after jacobi_eigen_wave (first minimum, like the oracle)
+__device__ __forceinline__ void smallest_eigvec9_wave(const lds_f64* A, const lds_f64* V, double* x) {
+    int best = 0;
+    for (int i = 1; i < 9; ++i)
+        if (A[i * 9 + i] < A[best * 9 + best]) best = i;
+    for (int i = 0; i < 9; ++i) x[i] = V[i * 9 + best];
+}
+// ---- real roots of ONE polynomial by the whole wave (local optimisation's 5-point solve) ----------
+// tvg_math.h's RootChain walks the chain of derivatives and, per level, bisects the sign-change
+// brackets one after the other.  The brackets of a level are independent, so here lane i takes
+// bracket i (same arithmetic per bracket, hence the same roots bit for bit) and the level costs one
+// bisection instead of up to R of them; the ordered, de-duplicated root list is then assembled
+// exactly as roots_between_t does it.
+template <int DEG, int R>
+struct WaveRootChain {
+    static __device__ __forceinline__ int run(const double (&c)[DEG + 1], double* roots, lds_f64* tmp, int lane) {
+        double crit[R];
+        const int nc = WaveRootChain<DEG, R - 1>::run(c, crit, tmp, lane);
+        double d[R + 1];
+        poly_derivative_t<DEG, DEG - R>(c, d);
+        double bound = 0.0;
+#pragma unroll
+        for (int i = 0; i < R; ++i) bound = dmax(bound, dabs(d[i] / d[R]));
+        bound = 1.0 + bound;
+        int ne = 0;
+        tmp[ne++] = -bound;
+        for (int i = 0; i < nc; ++i)
+            if (crit[i] > -bound && crit[i] < bound) tmp[ne++] = crit[i];
+        tmp[ne++] = bound;
+        wave_lds_sync();
+        // one bracket per lane: 0 nothing, 1 exact root at the lower edge, 2 bracketed root
+        int kind = 0;
+        double val = 0.0;
+        if (lane + 1 < ne) {
+            double lo = tmp[lane], hi = tmp[lane + 1];
+            double flo = poly_eval_t<R>(d, lo);
+            const double fhi = poly_eval_t<R>(d, hi);
+            if (flo == 0.0) {
+                kind = 1;
+                val = lo;
+            } else if (fhi != 0.0 && (flo < 0.0) != (fhi < 0.0)) {
+                for (int it = 0; it < 200; ++it) {
+                    const double mid = 0.5 * (lo + hi);
+                    if (mid == lo || mid == hi) break;
+                    const double fm = poly_eval_t<R>(d, mid);
+                    if (fm == 0.0) { lo = mid; hi = mid; break; }
+                    if ((fm < 0.0) == (flo < 0.0)) { lo = mid; flo = fm; } else { hi = mid; }
+                }
+                kind = 2;
+                val = 0.5 * (lo + hi);
+            }
+        }
+        const double last = tmp[ne - 1];
+        wave_lds_sync();  // tmp is rewritten by the next level
+        int nr = 0;
+        for (int i = 0; i + 1 < ne; ++i) {
+            const int k = __builtin_amdgcn_readlane(kind, i);
+            const double r = readlane_f64(val, i);
+            if (k == 1) {
+                if (nr == 0 || roots[nr - 1] != r) roots[nr++] = r;
+            } else if (k == 2) {
+                roots[nr++] = r;
+            }
+        }
+        if (poly_eval_t<R>(d, last) == 0.0 && (nr == 0 || roots[nr - 1] != last)) roots[nr++] = last;
+        return nr;
+    }
+};
+template <int DEG>
+struct WaveRootChain<DEG, 1> {
+    static __device__ __forceinline__ int run(const double (&c)[DEG + 1], double* roots, lds_f64*, int) {
+        double d[2];
+        poly_derivative_t<DEG, DEG - 1>(c, d);
+        roots[0] = -d[0] / d[1];
+        return 1;
+    }
+};
+// all real roots of a degree-10 polynomial (wave-uniform input), ascending; = real_roots_t<10>
+__device__ __noinline__ int real_roots10_wave(const double* c_in, double* roots, lds_f64* tmp, int lane) {
+    double c[11];
+#pragma unroll
+    for (int i = 0; i <= 10; ++i) c[i] = c_in[i];
+    if (c[10] == 0.0) return real_roots_t<10>(c, roots);  // degenerate leading coefficient: plain path
+    return WaveRootChain<10, 10>::run(c, roots, tmp, lane);
+}
+
+// ---- the 5-point solve of ONE problem by the whole wave (local optimisation) -----------------------
+// e5_build keeps the 10 x 20 constraint matrix of a solve in one lane: 200 live doubles, most of them in scratch
+// memory, and with one problem per wave every lane did the same elimination.  Here the rows are still computed by
+// every lane (same expressions, row by row, so that only one row is live), but lane c < 20 keeps just column c,
+// and the Gauss-Jordan elimination runs on those 20 columns in parallel: per pivot the pivot column is broadcast
+// (ten readlanes), every lane searches the pivot and applies the row swap to its own column, and one multiply and
+// nine multiply-subtracts finish the step.  Every element goes through the operations e5_build applies to it, in
+// the same order: the same bits.  E E^T and its trace sit in `sc` (>= 100 doubles of LDS) between the two passes.
+__device__ __noinline__ void e5_build_wave(const double* nsp, E5Polys& P, lds_f64* sc, int lane) {
+    double e[9][4];
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int d = 0; d < 4; ++d) e[k][d] = nsp[d * 9 + k];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            double a[10], b[10], c[10];
+            e5_mul11(e[3 * i], e[3 * j], a);
+            e5_mul11(e[3 * i + 1], e[3 * j + 1], b);
+            e5_mul11(e[3 * i + 2], e[3 * j + 2], c);
+            if (lane == 0) {
+#pragma unroll
+                for (int t = 0; t < 10; ++t) sc[(3 * i + j) * 10 + t] = (a[t] + b[t]) + c[t];
+            }
+        }
+    wave_lds_sync();
+    if (lane == 0) {
+#pragma unroll
+        for (int t = 0; t < 10; ++t) sc[90 + t] = (sc[t] + sc[40 + t]) + sc[80 + t];
+    }
+    wave_lds_sync();
+    double g[10];  // this lane's column of G
+    auto keep = [&](double& dst, const double (&row)[20]) {
+        double x = row[19];
+#pragma unroll
+        for (int c = 18; c >= 0; --c) x = lane == c ? row[c] : x;
+        dst = x;
+    };
+    {   // det(E) -> row 0
+        double a[10], b[10], d[10], t0[20], t1[20], t2[20], row[20];
+        e5_mul11(e[4], e[8], a); e5_mul11(e[5], e[7], b);
+#pragma unroll
+        for (int i = 0; i < 10; ++i) d[i] = a[i] - b[i];
+        e5_mul21(d, e[0], t0);
+        e5_mul11(e[3], e[8], a); e5_mul11(e[5], e[6], b);
+#pragma unroll
+        for (int i = 0; i < 10; ++i) d[i] = a[i] - b[i];
+        e5_mul21(d, e[1], t1);
+        e5_mul11(e[3], e[7], a); e5_mul11(e[4], e[6], b);
+#pragma unroll
+        for (int i = 0; i < 10; ++i) d[i] = a[i] - b[i];
+        e5_mul21(d, e[2], t2);
+#pragma unroll
+        for (int i = 0; i < 20; ++i) row[i] = (t0[i] - t1[i]) + t2[i];
+        keep(g[0], row);
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            double q[10], acc[20], tmp[20], row[20];
+#pragma unroll
+            for (int t = 0; t < 10; ++t) q[t] = sc[(3 * i) * 10 + t];
+            e5_mul21(q, e[j], acc);
+#pragma unroll
+            for (int t = 0; t < 10; ++t) q[t] = sc[(3 * i + 1) * 10 + t];
+            e5_mul21(q, e[3 + j], tmp);
+#pragma unroll
+            for (int t = 0; t < 20; ++t) acc[t] = acc[t] + tmp[t];
+#pragma unroll
+            for (int t = 0; t < 10; ++t) q[t] = sc[(3 * i + 2) * 10 + t];
+            e5_mul21(q, e[6 + j], tmp);
+#pragma unroll
+            for (int t = 0; t < 20; ++t) acc[t] = acc[t] + tmp[t];
+#pragma unroll
+            for (int t = 0; t < 10; ++t) q[t] = sc[90 + t];
+            e5_mul21(q, e[3 * i + j], tmp);
+#pragma unroll
+            for (int t = 0; t < 20; ++t) row[t] = acc[t] * 2.0 - tmp[t];
+            keep(g[1 + 3 * i + j], row);
+        }
+    // Gauss-Jordan with partial pivoting on the left 10 x 10 block, one column per lane
+#pragma unroll
+    for (int col = 0; col < 10; ++col) {
+        double bc[10];  // column `col` as it stands, wave-uniform
+#pragma unroll
+        for (int r = 0; r < 10; ++r) bc[r] = readlane_f64(g[r], col);
+        int piv = col;
+        double pv = dabs(bc[col]);
+#pragma unroll
+        for (int r = col + 1; r < 10; ++r)
+            if (dabs(bc[r]) > pv) { pv = dabs(bc[r]); piv = r; }
+#pragma unroll
+        for (int r = col + 1; r < 10; ++r) {
+            const bool sw = piv == r;
+            const double t = g[col], u = bc[col];
+            g[col] = sw ? g[r] : g[col];
+            g[r] = sw ? t : g[r];
+            bc[col] = sw ? bc[r] : bc[col];
+            bc[r] = sw ? u : bc[r];
+        }
+        const double inv = 1.0 / bc[col];
+        g[col] = g[col] * inv;
+#pragma unroll
+        for (int r = 0; r < 10; ++r) {
+            if (r == col) continue;
+            g[r] = g[r] - bc[r] * g[col];
+        }
+    }
+    // rows 4..9 of columns 10..19 -> every lane
+    wave_lds_sync();
+    if (lane >= 10 && lane < 20) {
+#pragma unroll
+        for (int r = 0; r < 6; ++r) sc[r * 10 + (lane - 10)] = g[4 + r];
+    }
+    wave_lds_sync();
+    double hl[6][10];
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int c = 0; c < 10; ++c) hl[r][c] = sc[r * 10 + c];
+    wave_lds_sync();  // sc is the root finder's scratch next
+    e5_finish(hl, P);
+}
+// e5_models with root i on lane i; the models come back wave-uniform, in root order
+__device__ __noinline__ int e5_models_wave(const double* nsp, const E5Polys& P, const double* roots, int nr, double* models,
+                                           int lane) {
+    double z = roots[0];
+#pragma unroll
+    for (int i = 1; i < 10; ++i) z = lane == i ? roots[i] : z;
+    double E[9];
+    const bool ok = e5_model_from_root(nsp, P, z, E) && lane < nr;
+    unsigned long long mask = __ballot(ok);
+    int nm = 0;
+    while (mask) {
+        const int src = (int)__builtin_ctzll(mask);
+        mask &= mask - 1;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) models[9 * nm + i] = readlane_f64(E[i], src);
+        ++nm;
+    }
+    return nm;
+}
+
+// local estimator on the K listed inlier correspondences -> models (uniform), count
+template <int LOCAL>
+__device__ __noinline__ int local_estimate(const LoCtx w, const Pts P, int K, double* models) {
+    const int lane = w.lane;
+    if (LOCAL == K_T) {
+        double a = 0, b = 0, c = 0, d = 0;
+        for (int k = lane; k < K; k += 64) {
+            double p0, p1, p2, p3;
+            load_pt(P, w.inl[k], p0, p1, p2, p3);
+            a += p0; b += p1; c += p2; d += p3;
+        }
+        const double sx = butterfly(a) / (double)K, sy = butterfly(b) / (double)K;
+        const double dx = butterfly(c) / (double)K, dy = butterfly(d) / (double)K;
+        for (int i = 0; i < 9; ++i) models[i] = 0.0;
+        models[0] = dx - sx;
+        models[1] = dy - sy;
+        return 1;
+    }
+    if (LOCAL == K_E5) {
+        if (K == 5) {
+            double a[5], b[5], c[5], d[5];
+            for (int i = 0; i < 5; ++i) load_pt(P, w.inl[i], a[i], b[i], c[i], d[i]);
+            return estimate_e5_minimal(a, b, c, d, models);
+        }
+        ata_impl<0, false>(w, P, K, nullptr, nullptr);
+        jacobi_eigen_wave(w.jacA, w.jacV, lane);
+        double nsp[4 * 9];
+        e5_nullspace_from_eig(w.jacA, w.jacV, nsp);
+        wave_lds_sync();  // jacA doubles as the root finder's scratch from here on
+        E5Polys polys;
+        e5_build_wave(nsp, polys, w.jacA, lane);
+        double roots[10];
+        const int nr = real_roots10_wave(polys.det, roots, w.jacA, lane);
+        return e5_models_wave(nsp, polys, roots, nr, models, lane);
+    }
+    if (LOCAL == K_H && K == 4) {
+        double a[4], b[4], c[4], d[4];
+        for (int i = 0; i < 4; ++i) load_pt(P, w.inl[i], a[i], b[i], c[i], d[i]);
+        estimate_h4(a, b, c, d, models);
+        return 1;
+    }
+    double T1[9], T2[9];
+    center_T(w, P, 0, K, T1);
+    center_T(w, P, 1, K, T2);
+    if (LOCAL == K_F8) {
+        ata_impl<0, true>(w, P, K, T1, T2);
+        jacobi_eigen_wave(w.jacA, w.jacV, lane);
+        double f[9];
+        smallest_eigvec9_wave(w.jacA, w.jacV, f);
+        f8_from_vec(f, T1, T2, models);
+    } else {
+        ata_impl<1, true>(w, P, K, T1, T2);
+        jacobi_eigen_wave(w.jacA, w.jacV, lane);
+        double h[9];
+        smallest_eigvec9_wave(w.jacA, w.jacV, h);
+        h_denormalize(h, T1, T2, models);
+    }
+    return 1;
+}
+
+// ---- a chunk's minimal problems and the inlier count of every resulting model --------------------
+// One minimal problem per lane.  H / T models stay with the solving lane (mym); F and E models - up to 3 / 10 per
+// trial - go to the wave's global model table.  Then every model of the chunk is counted (count_chunk).  A model can
+// only change the course of the sequential algorithm if its count reaches the best count so far, so all the replay
+// needs per trial is the largest count among its models (exact, or an upper bound below that threshold); the few
+// trials that qualify are re-scored in full there.
+struct ChunkModels {
+    double mym[9];
+    int nmod;    // models of this lane's trial
+    int maxcnt;  // max inlier count over them (-1: none)
+    unsigned long long cyc_solve, cyc_count;
+};
+
+// ---- division-free inlier tests for the counting loop ----------------------------------------------
+// Counting only needs the DECISION residual <= max_res, and for both residuals that is a polynomial inequality:
+//   homography  (d0 - pd0/pd2)^2 + (d1 - pd1/pd2)^2 <= T   <=>   (d0 pd2 - pd0)^2 + (d1 pd2 - pd1)^2 <= T pd2^2
+//   Sampson     c^2 / den <= T                              <=>   c^2 <= T den               (den > 0)
+// evaluated here with fused multiply-adds (no division: a third of the instructions of the reference expression
+// and no rcp -> Newton -> fixup dependency chain).  The two sides are NOT the reference's roundings, so the test
+// is only trusted away from the boundary: with L and R the two sides, `in` when L <= R (1 - 1e-8), `out` when
+// L >= R (1 + 1e-8), and the (practically never taken) band in between - or an R that is not a normal positive
+// number - leaves the point undecided (`amb`).  Why the band suffices: both this
+// expression and the reference one are backward-stable evaluations of the same real quantity whose relative error
+// at the boundary is <= ~10 eps x (largest coordinate / max_error) - the cancellation in d - p and in x2^T E x1;
+// lo_ransac switches the fast test off unless that ratio is below 1e5 (fast_count), which bounds both
+// errors by ~1e-10, a hundredth of the band.  A decided point is therefore decided as the reference decides it.
+constexpr double kFastLo = 1.0 - 1e-8, kFastHi = 1.0 + 1e-8;
+template <int KIND>
+__device__ __forceinline__ void fast_inlier(const double (&m)[9], double a, double b, double c, double d, double T,
+                                            bool& in, bool& amb) {
+    double Lq, R;
+    if (KIND == K_H) {
+        const double pd0 = __fma_rn(m[0], a, __fma_rn(m[1], b, m[2]));
+        const double pd1 = __fma_rn(m[3], a, __fma_rn(m[4], b, m[5]));
+        const double pd2 = __fma_rn(m[6], a, __fma_rn(m[7], b, m[8]));
+        const double u = __fma_rn(c, pd2, -pd0), v = __fma_rn(d, pd2, -pd1);
+        Lq = __fma_rn(u, u, v * v);
+        R = T * (pd2 * pd2);
+    } else {
+        const double Ex1_0 = __fma_rn(m[0], a, __fma_rn(m[1], b, m[2]));
+        const double Ex1_1 = __fma_rn(m[3], a, __fma_rn(m[4], b, m[5]));
+        const double Ex1_2 = __fma_rn(m[6], a, __fma_rn(m[7], b, m[8]));
+        const double Etx2_0 = __fma_rn(m[0], c, __fma_rn(m[3], d, m[6]));
+        const double Etx2_1 = __fma_rn(m[1], c, __fma_rn(m[4], d, m[7]));
+        const double x2tEx1 = __fma_rn(c, Ex1_0, __fma_rn(d, Ex1_1, Ex1_2));
+        Lq = x2tEx1 * x2tEx1;
+        R = T * __fma_rn(Ex1_0, Ex1_0, __fma_rn(Ex1_1, Ex1_1, __fma_rn(Etx2_0, Etx2_0, Etx2_1 * Etx2_1)));
+    }
+    // "R is a positive number of ordinary magnitude" (2^-664 <= R < 2^664): one integer range check on its exponent
+    // field - false for 0, denormals, huge values, inf, NaN and anything negative
+    const bool sane = ((uint32_t)((unsigned long long)__double_as_longlong(R) >> 32) - 0x16700000u) < 0x53000000u;
+    const bool c1 = Lq <= R * kFastLo, c2 = Lq < R * kFastHi;  // c1 implies c2; a NaN Lq fails both: an outlier, as
+                                                                // the reference's NaN <= max_res says
+    in = sane && c1;
+    amb = !sane || (c2 && !c1);
+}
+
+// ---- counting, one model at a time, lanes = correspondences (the exact path) -------------------------
+// Inlier count of ONE wave-uniform model over the M correspondences by the reference residual (ballot + popcount),
+// or - as soon as even counting every remaining correspondence as an inlier could not reach `thr` - an upper bound
+// below `thr`.  This is what every count was before the lanes-as-models loops below; it remains for the models those
+// cannot decide (a point inside a fast test's band, for a model near the threshold), for the one-point translation
+// RANSAC of the watermark test and for the AMC_TVG_EXACT_COUNT=1 test hook.
+template <int KIND>
+__device__ __forceinline__ int count_model_exact(const double (&m)[9], const Pts& P, int M, double max_res, int lane, int thr) {
+    int cnt = 0;
+    for (int k0 = 0; k0 < M; k0 += 256) {
+        double a[4], b[4], c[4], d[4];
+        bool val[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = k0 + 64 * u + lane;
+            val[u] = k < M;
+            load_pt(P, val[u] ? k : 0, a[u], b[u], c[u], d[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            cnt += __popcll(__ballot(val[u] && residual_t<KIND>(m, a[u], b[u], c[u], d[u]) <= max_res));
+        const int rest = M - (k0 + 256);
+        if (rest > 0 && cnt + rest < thr) return cnt + rest;
+    }
+    return cnt;
+}
+// all models of the chunk that way: H / T models from the solving lanes' registers ...
+template <int KIND>
+__device__ __forceinline__ int count_lane_models_exact(const double (&mym)[9], int nmod, const Pts& P, int M,
+                                                       double max_res, int nT, int lane, int thr) {
+    int maxcnt = -1;
+    for (int t = 0; t < nT; ++t) {
+        if (__builtin_amdgcn_readlane(nmod, t) < 1) continue;
+        double sm[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) sm[i] = readlane_f64(mym[i], t);
+        const int c = count_model_exact<KIND>(sm, P, M, max_res, lane, thr);
+        if (lane == t) maxcnt = max(maxcnt, c);
+    }
+    return maxcnt;
+}
+// ... F / E models from the wave's global model table
+__device__ __forceinline__ int count_global_models_exact(const double* models, int nmod, const Pts& P, int M,
+                                                         double max_res, int nT, int lane, int thr) {
+    int maxcnt = -1;
+    for (int t = 0; t < nT; ++t) {
+        const int n = __builtin_amdgcn_readlane(nmod, t);
+        for (int m = 0; m < n; ++m) {
+            const double* src = models + ((size_t)t * kMaxModels + m) * 9;
+            double sm[9];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) sm[i] = readlane_f64(src[i], 0);
+            const int c = count_model_exact<K_F7>(sm, P, M, max_res, lane, thr);
+            if (lane == t) maxcnt = max(maxcnt, c);
+        }
+    }
+    return maxcnt;
+}
+
+// ---- counting with the lanes as MODELS ------------------------------------------------------------------
+// The chunk's models are lane-resident (one per lane) and the correspondences are wave-uniform: they are read from
+// the per-wave tables in global memory by the scalar unit (s_load_dwordx8 through the scalar data cache) and enter the
+// vector FMAs as SGPR operands.  Per correspondence the loop is straight arithmetic plus two compare / add-with-carry
+// pairs - no popcounts, no readlane broadcasts, no dependence on a scalar result - and every lane counts
+//   ub  the points NOT decided outliers = decided inliers + the points its fast test left undecided (its band, or a
+//       degenerate right-hand side),
+// while a wave-wide mask (scalar registers: SALU ORs of the compare results) remembers which lanes had an undecided
+// point at all.  A model with undecided points whose ub reaches thr is recounted by the exact path above; for every
+// other model ub is its exact count (nothing undecided) or an upper bound below thr - all the replay compares with.
+
+// Sampson test in FP64 (fundamental / essential models): table = (x1, y1, x2, y2) doubles per correspondence.
+// ub = correspondences NOT decided outliers (decided inliers + undecided); the lane's bit of the returned mask is set
+// when it left a correspondence undecided.  The next record is requested before the current one is used, so the
+// scalar-cache latency overlaps the arithmetic.
+struct F64Rec {
+    double a, b, c, d;
+};
+__device__ __forceinline__ F64Rec f64_rec(const AMC_CONST double* tab, int k) {
+    F64Rec r;
+    r.a = tab[4 * k]; r.b = tab[4 * k + 1]; r.c = tab[4 * k + 2]; r.d = tab[4 * k + 3];
+    return r;
+}
+__device__ __forceinline__ void f64_count1(const double (&m)[9], const F64Rec& r, double T, int& ub, unsigned long long& undmask) {
+    bool in, amb;
+    fast_inlier<K_F7>(m, r.a, r.b, r.c, r.d, T, in, amb);
+    ub += (int)(in || amb);
+    undmask |= __ballot(amb);
+}
+// correspondences [k0, k1) against the lane's model; ub / undmask are carried from segment to segment
+__device__ __forceinline__ void count_lanes_f64(const double (&m)[9], const AMC_CONST double* tab, int k0, int k1, double T,
+                                                int& ub, unsigned long long& undmask) {
+    F64Rec ra = f64_rec(tab, k0);
+    int k = k0;
+    for (; k + 2 <= k1; k += 2) {
+        const F64Rec rb = f64_rec(tab, k + 1);
+        f64_count1(m, ra, T, ub, undmask);
+        ra = f64_rec(tab, k + 2 < k1 ? k + 2 : k1 - 1);
+        f64_count1(m, rb, T, ub, undmask);
+    }
+    if (k < k1) f64_count1(m, ra, T, ub, undmask);
+}
+// exact inlier count of one wave-uniform model over the correspondences [k0, M), lanes = correspondences
+template <int KIND>
+__device__ __forceinline__ int count_range_exact(const double (&m)[9], const Pts& P, int k0, int M, double max_res, int lane) {
+    int cnt = 0;
+    for (int kb = k0; kb < M; kb += 128) {
+        double a[2], b[2], c[2], d[2];
+        bool val[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int k = kb + 64 * u + lane;
+            val[u] = k < M;
+            load_pt(P, val[u] ? k : 0, a[u], b[u], c[u], d[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+            cnt += __popcll(__ballot(val[u] && residual_t<KIND>(m, a[u], b[u], c[u], d[u]) <= max_res));
+    }
+    return cnt;
+}
+
+// Homography transfer test in packed FP32 with a bound on its own error (tvg_math.h h32_eval: the threshold folded
+// into rows 0 / 1 of the model and into the image-2 coordinates, t = u'^2 + v'^2 - w^2, a point is decided only if
+// |t32| exceeds the bound on |t32 - t| plus the band inside which the FP64 test itself defers to the reference
+// residual; derivation there).  Two correspondences per instruction (v_pk_fma_f32): the table interleaves them
+// (a0 a1 | b0 b1 | c0' c1' | d0' d1').  The homography RANSAC of a non-planar pair runs to its trial cap and nearly
+// all of its models count nearly all matches as outliers by a wide margin: this loop is where the time of such a
+// pair goes.  A diagnostic build of round 2 counted 500 million models both ways (profiles/r02/h32_diag.txt): no
+// decided point disagreed with the FP64 count.
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef H32Model H32Lane;  // tvg_math.h: the scaled float model and the constants of its error bound (h32_prepare)
+__device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+// packed FP32 instructions have no |x| source modifier (the compiler spends a v_and per component on it): the two
+// places the error bound takes absolute values are single instructions on the plain FP32 pipe instead
+__device__ __forceinline__ float abs_add_f32(float a, float b) {  // |a| + |b|
+    float r;
+    asm("v_add_f32 %0, |%1|, |%2|" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float fma_abs_f32(float a, float b, float c) {  // fma(a, |b|, c)
+    float r;
+    asm("v_fma_f32 %0, %1, |%2|, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+struct H32Splat {  // the lane's model with every coefficient in both halves of a register pair
+    v2f m[9], kE, c42;
+    float kW, K0;
+};
+__device__ __forceinline__ H32Splat h32_splat(const H32Lane& h) {
+    H32Splat s;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) s.m[i] = (v2f){h.m[i], h.m[i]};
+    s.kE = (v2f){h.kE, h.kE};
+    s.c42 = (v2f){4.2e-7f, 4.2e-7f};
+    s.kW = h.kW;
+    s.K0 = h.K0;
+    return s;
+}
+// h32_eval (tvg_math.h) on two correspondences: the same operations in the same order, so t and band are the
+// values that function returns for each of them
+__device__ __forceinline__ void h32_eval_pk(const H32Splat& h, v2f a, v2f b, v2f cs, v2f ds, v2f& t, v2f& band) {
+    const v2f p0 = pk_fma(h.m[0], a, pk_fma(h.m[1], b, h.m[2]));
+    const v2f p1 = pk_fma(h.m[3], a, pk_fma(h.m[4], b, h.m[5]));
+    const v2f w = pk_fma(h.m[6], a, pk_fma(h.m[7], b, h.m[8]));
+    const v2f u = pk_fma(cs, w, -p0), v = pk_fma(ds, w, -p1);
+    const v2f R = w * w;
+    t = pk_fma(u, u, v * v) - R;
+    const v2f auv = (v2f){abs_add_f32(u.x, v.x), abs_add_f32(u.y, v.y)};
+    const v2f kw = (v2f){fma_abs_f32(h.kW, w.x, h.K0), fma_abs_f32(h.kW, w.y, h.K0)};
+    band = pk_fma(h.c42, R, pk_fma(h.kE, auv, kw));
+}
+struct H32Rec {  // two correspondences of the pre-filter table
+    v2f a, b, cs, ds;
+};
+__device__ __forceinline__ H32Rec h32_rec(const AMC_CONST v2f* tab, int k) {
+    H32Rec r;
+    r.a = tab[4 * k]; r.b = tab[4 * k + 1]; r.cs = tab[4 * k + 2]; r.ds = tab[4 * k + 3];
+    return r;
+}
+__device__ __forceinline__ void h32_count2(const H32Splat& h, const H32Rec& r, bool both, int& ub, unsigned long long& undmask) {
+    v2f t, band;
+    h32_eval_pk(h, r.a, r.b, r.cs, r.ds, t, band);
+    const bool d0 = __builtin_fabsf(t.x) > band.x, d1 = __builtin_fabsf(t.y) > band.y;
+    if (both) {
+        ub += (int)!(d0 && !(t.x < 0.0f)) + (int)!(d1 && !(t.y < 0.0f));
+        undmask |= __ballot(!d0) | __ballot(!d1);
+    } else {
+        ub += (int)!(d0 && !(t.x < 0.0f));
+        undmask |= __ballot(!d0);
+    }
+}
+__device__ __forceinline__ unsigned long long count_lanes_h32(const H32Lane& hl, const AMC_CONST v2f* tab, int M, int& ub_out) {
+    const H32Splat h = h32_splat(hl);
+    int ub = 0;
+    unsigned long long undmask = 0ull;
+    const int np = M >> 1, last = ((M + 1) >> 1) - 1;  // full pairs; index of the table's last record
+    // two records in flight on alternating scalar registers: the one after next is requested before the current
+    // one is used, so the scalar-cache latency overlaps the arithmetic
+    H32Rec ra = h32_rec(tab, 0);
+    int k = 0;
+    for (; k + 2 <= np; k += 2) {
+        const H32Rec rb = h32_rec(tab, k + 1);
+        h32_count2(h, ra, true, ub, undmask);
+        ra = h32_rec(tab, k + 2 <= last ? k + 2 : last);
+        h32_count2(h, rb, true, ub, undmask);
+    }
+    if (k < np) {
+        h32_count2(h, ra, true, ub, undmask);
+        ++k;
+        if (M & 1) ra = h32_rec(tab, last);
+    }
+    if (M & 1) h32_count2(h, ra, false, ub, undmask);  // the last, unpaired correspondence (second half: a copy, not counted)
+    ub_out = ub;
+    return undmask;
+}
+
+// the models of an F / E chunk (global table, nmod per trial) by the lanes-as-models loop: the valid models are listed
+// in (trial, root) order, 64 of them are counted at a time, and the largest count of a trial's models is collected in
+// LDS (tmax).  Returns lane t's maxcnt.
+__device__ __forceinline__ int count_models_f64(const double* models, int nmod, const double* p64, const Pts& P, int M,
+                                                double max_res, int nT, int lane, int thr, lds_u16* mlist, lds_i32* tmax) {
+    // exclusive prefix of nmod over the lanes
+    int incl = nmod;
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) {
+        const int o = __shfl_up(incl, s);
+        if (lane >= s) incl += o;
+    }
+    const int total = __builtin_amdgcn_readlane(incl, 63);
+    const int base = incl - nmod;
+    for (int m = 0; m < nmod; ++m) mlist[base + m] = (uint16_t)(lane * 16 + m);
+    tmax[lane] = -1;
+    wave_lds_sync();
+    const AMC_CONST double* tab = as_const_table(p64);
+    for (int g0 = 0; g0 < total; g0 += 64) {
+        const int idx = g0 + lane;
+        const bool valid = idx < total;
+        const int e = (int)mlist[valid ? idx : 0];
+        const int t = e >> 4, mi = e & 15;
+        const double* src = models + ((size_t)t * kMaxModels + mi) * 9;
+        double mm[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) mm[i] = src[i];
+        // 64 correspondences at a time.  After each segment the models that can still reach thr - even if every
+        // correspondence to come were an inlier - are counted: the RANSACs this path serves (E, F) have a high best
+        // count, most sampled models are far below it, and once only a handful of the group's models are alive the
+        // rest of their correspondences is cheaper to score one model at a time across the wave (exact residual)
+        // than to keep 64 lanes streaming for them.  A model that dropped out reports ub + (all it has not seen),
+        // an upper bound below thr.
+        int ub = 0;
+        unsigned long long und = 0ull;
+        constexpr int kSeg = 64, kFewAlive = 6;
+        for (int k0 = 0; k0 < M; k0 += kSeg) {
+            const int k1 = min(k0 + kSeg, M);
+            count_lanes_f64(mm, tab, k0, k1, max_res, ub, und);
+            if (k1 < M) {
+                unsigned long long alive = __ballot(valid && ub + (M - k1) >= thr);
+                if (__popcll(alive) <= kFewAlive) {
+                    const bool mine = (alive >> lane) & 1ull;
+                    while (alive) {
+                        const int src_lane = (int)__builtin_ctzll(alive);
+                        alive &= alive - 1;
+                        double sm[9];
+#pragma unroll
+                        for (int i = 0; i < 9; ++i) sm[i] = readlane_f64(mm[i], src_lane);
+                        const int c = count_range_exact<K_F7>(sm, P, k1, M, max_res, lane);
+                        if (lane == src_lane) ub += c;
+                    }
+                    if (!mine) ub += M - k1;
+                    break;
+                }
+            }
+        }
+        unsigned long long redo = __ballot(valid && ub >= thr) & und;
+        while (redo) {  // practically never: a point of a near-threshold model inside the fast test's band
+            const int src_lane = (int)__builtin_ctzll(redo);
+            redo &= redo - 1;
+            double sm[9];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) sm[i] = readlane_f64(mm[i], src_lane);
+            const int c = count_model_exact<K_F7>(sm, P, M, max_res, lane, thr);
+            if (lane == src_lane) ub = c;
+        }
+        if (valid) __hip_atomic_fetch_max(&tmax[t], ub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    }
+    wave_lds_sync();
+    const int r = tmax[lane];
+    wave_lds_sync();
+    (void)nT;
+    return nmod > 0 ? r : -1;
+}
+
+template <int EST>
+__device__ __noinline__ void solve_chunk(ChunkModels* out, const Pts P_, const lds_u16* sidx_, int nT_, int lane,
+                                         double* models_) {
+    const unsigned long long c0 = __builtin_readcyclecounter();
+    const Pts P = uni(P_);
+    const lds_u16* sidx = uni_lds(sidx_);
+    const int nT = uni(nT_);
+    double* models = uni_ptr(models_);
+    int nmod = 0;
+    double mym[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) mym[i] = 0.0;
+    if (lane < nT) {
+        if (EST == K_F7) {
+            double sx1[7], sy1[7], sx2[7], sy2[7];
+#pragma unroll
+            for (int i = 0; i < 7; ++i) load_pt(P, sidx[lane * 8 + i], sx1[i], sy1[i], sx2[i], sy2[i]);
+            double fm[27];
+#pragma unroll
+            for (int i = 0; i < 27; ++i) fm[i] = 0.0;
+            nmod = estimate_f7(sx1, sy1, sx2, sy2, fm);
+            double* dst = models + (size_t)lane * kMaxModels * 9;
+#pragma unroll
+            for (int i = 0; i < 27; ++i) dst[i] = fm[i];
+        } else if (EST == K_H) {
+            double sx1[4], sy1[4], sx2[4], sy2[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) load_pt(P, sidx[lane * 8 + i], sx1[i], sy1[i], sx2[i], sy2[i]);
+            estimate_h4(sx1, sy1, sx2, sy2, mym);
+            nmod = 1;
+        } else if (EST == K_E5) {
+            double sx1[5], sy1[5], sx2[5], sy2[5];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) load_pt(P, sidx[lane * 8 + i], sx1[i], sy1[i], sx2[i], sy2[i]);
+            nmod = estimate_e5_minimal(sx1, sy1, sx2, sy2, models + (size_t)lane * kMaxModels * 9);
+        } else {  // K_T: model = dst - src of the single sample
+            double a, b, c, d;
+            load_pt(P, sidx[lane * 8], a, b, c, d);
+            mym[0] = c - a;
+            mym[1] = d - b;
+            nmod = 1;
+        }
+    }
+    wave_mem_sync();
+#pragma unroll
+    for (int i = 0; i < 9; ++i) out->mym[i] = mym[i];
+    out->nmod = nmod;
+    out->cyc_solve = __builtin_readcyclecounter() - c0;
+}
+
+struct CountCtx {  // wave-uniform inputs of count_chunk
+    Pts P;
+    const double* p64;   // AoS doubles (scalar_table_sync'ed)
+    const float* p32;    // packed-FP32 homography table
+    const double* models;
+    lds_u16* mlist;
+    lds_i32* tmax;
+    int M, nT, thr, fast;
+    double max_res, cmax;
+};
+template <int EST>
+__device__ __noinline__ void count_chunk(ChunkModels* io, const CountCtx cc_, int lane) {
+    const unsigned long long c1 = __builtin_readcyclecounter();
+    const Pts P = uni(cc_.P);
+    const int M = uni(cc_.M), nT = uni(cc_.nT), thr = uni(cc_.thr);
+    const bool fast = uni(cc_.fast) != 0;
+    const double max_res = uni(cc_.max_res), cmax = uni(cc_.cmax);
+    const double* models = uni_ptr(cc_.models);
+    double mym[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) mym[i] = io->mym[i];
+    const int nmod = io->nmod;
+    int maxcnt;
+    if (EST == K_T) {
+        maxcnt = count_lane_models_exact<K_T>(mym, nmod, P, M, max_res, nT, lane, thr);
+    } else if (!fast) {
+        if (EST == K_H) maxcnt = count_lane_models_exact<K_H>(mym, nmod, P, M, max_res, nT, lane, thr);
+        else maxcnt = count_global_models_exact(models, nmod, P, M, max_res, nT, lane, thr);
+    } else if (EST == K_H) {
+        const double s = 1.0 / dsqrt(max_res);
+        const H32Lane hl = h32_prepare(mym, s, cmax);
+        int ub;
+        const unsigned long long und = count_lanes_h32(hl, as_const_table(reinterpret_cast<const v2f*>(uni_ptr(cc_.p32))), M, ub);
+        unsigned long long redo = __ballot(nmod > 0 && ub >= thr) & und;
+        while (redo) {  // a model near the best count with points the FP32 test could not decide: FP64, exactly
+            const int src_lane = (int)__builtin_ctzll(redo);
+            redo &= redo - 1;
+            double sm[9];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) sm[i] = readlane_f64(mym[i], src_lane);
+            const int c = count_model_exact<K_H>(sm, P, M, max_res, lane, thr);
+            if (lane == src_lane) ub = c;
+        }
+        maxcnt = nmod > 0 ? ub : -1;
+    } else {
+        maxcnt = count_models_f64(models, nmod, uni_ptr(cc_.p64), P, M, max_res, nT, lane, thr, uni_lds(cc_.mlist),
+                                  uni_lds(cc_.tmax));
+    }
+    io->maxcnt = maxcnt;
+    io->cyc_count = __builtin_readcyclecounter() - c1;
+}
+
+struct Report {
+    bool success;
+    int num_trials;
+    Support support;
+    double model[9];
+};
+
+struct RansacCfg {
+    double max_res;          // max_error^2
+    int max_trials;          // already clamped as the RANSAC constructor does
+    int min_trials;
+    const uint32_t* dyn_tab; // dyn_max_num_trials by num_inliers (host libm), or nullptr
+    const double* wm_cut;    // K_T only: inlier-ratio cut-offs by trial count (TvgParams::wm_cut), max_trials + 1 entries
+    int force_slow_sampler;  // test hook: always take the draw-by-draw sampler path
+    int no_fast_count;       // test hook (AMC_TVG_EXACT_COUNT=1): the counting loops evaluate the reference residual only
+};
+
+// LORANSAC<EST, LOCAL>::Estimate over the M correspondences in the four arrays at gx (x1 | y1 | x2 | y2, each gstride
+// long); mask: M bytes.  The generator position w.soff is advanced exactly as the sequential algorithm would.
+template <int EST, int LOCAL>
+__device__ Report lo_ransac(Wave& w_io, const RansacCfg& cfg, const double* gx, uint32_t gstride, int M, uint8_t* mask) {
+    Wave w = w_io;  // by-value copy: the fields live in registers, not behind a pointer
+    const int lane = w.lane;
+    constexpr int kMin = kmin_of(EST), kLocalMin = kmin_of(LOCAL);
+    LoCtx lo;
+    lo.inl = w.inl; lo.jacA = w.jacA; lo.jacV = w.jacV; lo.lane = lane;
+    Report rep;
+    rep.success = false;
+    rep.num_trials = 0;
+    rep.support.cnt = 0;
+    rep.support.sum = 1.7976931348623157e308;  // numeric_limits<double>::max()
+    for (int i = 0; i < 9; ++i) rep.model[i] = 0.0;
+    if (M < kMin) return rep;
+
+    Support best = rep.support;
+    double best_model[9];
+    for (int i = 0; i < 9; ++i) best_model[i] = 0.0;
+    bool best_is_local = false;
+    uint32_t dyn_max = (uint32_t)cfg.max_trials;
+
+    Pts P;
+    P.g = gx; P.gs = gstride;
+    // the tables of the counting loops (read back through the scalar cache), and the pair's largest |coordinate|
+    int fast_count = 0;
+    double cmax = 0.0;
+    double* p64 = ws_p64(w);
+    float* p32 = ws_p32(w);
+    {
+        const double s = 1.0 / dsqrt(cfg.max_res);
+        double amax = 0.0;
+        for (int k = lane; k < M + (M & 1); k += 64) {
+            const int kk = k < M ? k : M - 1;  // odd M: the pre-filter table's last pair repeats the last point
+            const double p0 = gx[kk], p1 = gx[gstride + kk], p2 = gx[2 * (size_t)gstride + kk], p3 = gx[3 * (size_t)gstride + kk];
+            if (EST == K_H) {
+                float* q = p32 + 8 * (size_t)(k >> 1) + (k & 1);
+                q[0] = (float)p0; q[2] = (float)p1; q[4] = (float)(p2 * s); q[6] = (float)(p3 * s);
+            } else if (EST != K_T && k < M) {
+                double* q = p64 + 4 * (size_t)k;
+                q[0] = p0; q[1] = p1; q[2] = p2; q[3] = p3;
+            }
+            amax = dmax(dmax(amax, dmax(dabs(p0), dabs(p1))), dmax(dabs(p2), dabs(p3)));
+        }
+#pragma unroll
+        for (int sh = 32; sh >= 1; sh >>= 1) amax = dmax(amax, __shfl_xor(amax, sh));
+        // the division-free counting test is trusted only while (largest coordinate / max_error) <= 1e5 (see
+        // fast_inlier); a NaN coordinate leaves amax as it was or NaN - either way the comparison below decides
+        fast_count = (cfg.no_fast_count == 0 && amax * amax <= 1e10 * cfg.max_res) ? 1 : 0;
+        cmax = amax;
+        if (EST != K_T) scalar_table_sync();
+    }
+
+    // sampler.Initialize(M).  The first kMin entries of the persistent permutation are touched by
+    // every draw: they live in (wave-uniform) registers, the rest in LDS.
+    for (int k = lane; k < M; k += 64) w.perm[k] = (uint16_t)k;
+    SamplerState ss;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) ss.pr[i] = (uint32_t)i;
+    wave_lds_sync();
+
+    double* models = ws_models(w);
+    bool aborted = false;
+    int abort_trial = -1;
+    for (int chunk = 0; chunk < cfg.max_trials && !aborted; chunk += 64) {
+        const int nT = min(64, cfg.max_trials - chunk);
+        // ---- draw the chunk's samples ----
+        const uint32_t chunk_off = w.soff;
+        unsigned long long tp0 = __builtin_readcyclecounter();
+        ss.off = w.soff;
+        ss = sample_chunk<kMin>(w.stream, w.stream_len, w.perm, w.sidx, w.rawcnt, ss, M, nT, lane, cfg.force_slow_sampler, w.err);
+        w.soff = ss.off;
+        { const unsigned long long tp1 = __builtin_readcyclecounter(); w.prof[0] += tp1 - tp0; tp0 = tp1; }
+        // ---- 64 minimal problems + the inlier count of every model ---------
+        ChunkModels cm;
+        solve_chunk<EST>(&cm, P, w.sidx, nT, lane, models);
+        CountCtx cc;
+        cc.P = P; cc.p64 = p64; cc.p32 = p32; cc.models = models; cc.mlist = w.mlist; cc.tmax = w.tmax;
+        cc.M = M; cc.nT = nT; cc.thr = best.cnt; cc.fast = fast_count; cc.max_res = cfg.max_res; cc.cmax = cmax;
+        count_chunk<EST>(&cm, cc, lane);
+        w.prof[1] += cm.cyc_solve;
+        w.prof[5] += cm.cyc_count;  // the counting loop alone (also part of prof[2])
+        tp0 = __builtin_readcyclecounter();
+        // ---- replay in trial order.  Only two kinds of trial can change anything: one holding a
+        //      model whose count reaches the best so far (candidate: re-scored in full, exactly as
+        //      the sequential loop would), and the first trial with a model at or beyond the
+        //      adaptive trial limit (abort).  Everything in between is skipped.
+        const unsigned long long live = nT == 64 ? ~0ull : ((1ull << nT) - 1ull);
+        int t = 0;
+        while (!aborted) {
+            const long long lim = (long long)(dyn_max > (uint32_t)cfg.min_trials ? dyn_max : (uint32_t)cfg.min_trials) - chunk;
+            const unsigned long long cand = __ballot(cm.nmod > 0 && cm.maxcnt >= best.cnt);
+            const unsigned long long stop = __ballot(cm.nmod > 0 && (long long)lane >= lim);
+            const unsigned long long ev = (cand | stop) & live & (t >= 64 ? 0ull : (~0ull << t));
+            if (ev == 0ull) break;
+            t = (int)__builtin_ctzll(ev);
+            const int trial = chunk + t;
+            const int n = __builtin_amdgcn_readlane(cm.nmod, t);
+            for (int m = 0; m < n; ++m) {
+                Model9 smv;
+                double* sm = smv.v;
+                if (EST == K_E5 || EST == K_F7) {
+                    const double* src = models + ((size_t)t * kMaxModels + m) * 9;
+                    for (int i = 0; i < 9; ++i) sm[i] = src[i];
+                } else {
+                    for (int i = 0; i < 9; ++i) sm[i] = readlane_f64(cm.mym[i], t);
+                }
+                const Support sup = score<(EST == K_E5 ? K_F7 : EST)>(smv, P, M, cfg.max_res, lane, best.cnt);
+                if (better(sup, best)) {
+                    const unsigned long long tl0 = __builtin_readcyclecounter();
+                    best = sup;
+                    for (int i = 0; i < 9; ++i) best_model[i] = sm[i];
+                    best_is_local = false;
+                    if (sup.cnt > kMin && sup.cnt >= kLocalMin) {
+                        // recursive local optimisation: inliers of the sample model first, then of
+                        // the improved local model (COLMAP swaps residual vectors to the same effect)
+                        int cur_kind = EST;
+                        Model9 cur;
+                        for (int i = 0; i < 9; ++i) cur.v[i] = sm[i];
+                        for (int lt = 0; lt < 10; ++lt) {
+                            const int K = extract_inliers(w.inl, lane, cur_kind, cur, P, M, cfg.max_res);
+                            double lm[(LOCAL == K_E5 ? kMaxModels : 1) * 9];
+                            const unsigned long long tle = __builtin_readcyclecounter();
+                            const int nl = local_estimate<LOCAL>(lo, P, K, lm);
+                            if (lane == 0) {
+                                w.work[wk_residual_slot(LOCAL)] += (unsigned long long)nl * (unsigned long long)M;
+                                if (LOCAL == K_E5) w.work[WK_LO_E5] += 1;
+                                else if (LOCAL == K_F8) w.work[WK_LO_F8] += 1;
+                                else if (LOCAL == K_H) w.work[WK_LO_H] += 1;
+                                w.work[WK_LO_POINTS] += (unsigned long long)K;
+                            }
+                            if (LOCAL == K_E5) w.prof[6] += __builtin_readcyclecounter() - tle;
+                            else if (LOCAL == K_F8) w.prof[7] += __builtin_readcyclecounter() - tle;
+                            const int prev = best.cnt;
+                            for (int q = 0; q < nl; ++q) {
+                                Model9 lmv;
+                                for (int i = 0; i < 9; ++i) lmv.v[i] = lm[9 * q + i];
+                                const Support ls = score<(LOCAL == K_E5 || LOCAL == K_F8 ? K_F7 : LOCAL)>(lmv, P, M, cfg.max_res, lane, best.cnt);
+                                if (better(ls, best)) {
+                                    best = ls;
+                                    for (int i = 0; i < 9; ++i) best_model[i] = lm[9 * q + i];
+                                    best_is_local = true;
+                                }
+                            }
+                            if (best.cnt <= prev) break;
+                            cur_kind = LOCAL;
+                            for (int i = 0; i < 9; ++i) cur.v[i] = best_model[i];
+                        }
+                    }
+                    if (cfg.dyn_tab) {
+                        dyn_max = cfg.dyn_tab[best.cnt];
+                    } else if (cfg.wm_cut) {
+                        // first T in [0, max_trials] with r >= wm_cut[T] (the cut-offs do not increase with T)
+                        const double r = (double)best.cnt / (double)M;
+                        int lo_t = 0, hi_t = cfg.max_trials + 1;  // answer in [lo_t, hi_t]; hi_t = none
+                        while (lo_t < hi_t) {
+                            const int mid = (lo_t + hi_t) >> 1;
+                            if (r >= cfg.wm_cut[mid]) hi_t = mid; else lo_t = mid + 1;
+                        }
+                        dyn_max = lo_t <= cfg.max_trials ? (uint32_t)lo_t : 0xFFFFFFFFu;
+                    } else {
+                        dyn_max = 0xFFFFFFFFu;
+                    }
+                    w.prof[3] += __builtin_readcyclecounter() - tl0;
+                }
+                if ((uint32_t)trial >= dyn_max && trial >= cfg.min_trials) {
+                    aborted = true;
+                    abort_trial = trial;
+                    break;
+                }
+            }
+            ++t;
+        }
+        w.prof[2] += cm.cyc_count;
+        { const unsigned long long tp1 = __builtin_readcyclecounter(); w.prof[2] += tp1 - tp0; }
+        {   // algorithmic work of the chunk: the trials the sequential loop ran, their models x M residuals
+            const int upto = aborted ? abort_trial - chunk : nT - 1;
+            const int nmodels = wave_sum_int(lane <= upto ? cm.nmod : 0);
+            if (lane == 0) {
+                w.work[wk_residual_slot(EST)] += (unsigned long long)nmodels * (unsigned long long)M;
+                w.work[EST == K_E5 ? WK_E5MIN : (EST == K_F7 ? WK_F7MIN : (EST == K_H ? WK_H4MIN : WK_TRIALS))] +=
+                    (unsigned long long)(upto + 1);
+            }
+        }
+        if (aborted) {
+            // back to where the sequential algorithm stopped drawing
+            wave_lds_sync();
+            w.soff = chunk_off + sgpr(w.rawcnt[abort_trial - chunk]);
+        }
+    }
+    // report.num_trials exactly as the for/abort dance of loransac.h leaves it
+    rep.num_trials = aborted ? ((abort_trial + 1 < cfg.max_trials) ? abort_trial + 2 : abort_trial + 1)
+                             : cfg.max_trials;
+    rep.support = best;
+    for (int i = 0; i < 9; ++i) rep.model[i] = best_model[i];
+    w_io.soff = w.soff;
+    for (int i = 0; i < 8; ++i) w_io.prof[i] = w.prof[i];
+    if (best.cnt >= kMin && lane == 0)
+        w.work[wk_residual_slot(best_is_local ? LOCAL : EST)] += (unsigned long long)M;
+    if (best.cnt < kMin) return rep;
+    rep.success = true;
+    const int fk = best_is_local ? LOCAL : EST;
+    for (int k = lane; k < M; k += 64) {
+        double a, b, c, d;
+        load_pt(P, k, a, b, c, d);
+        mask[k] = residual_of(fk, rep.model, a, b, c, d) <= cfg.max_res ? 1 : 0;
+    }
+    wave_mem_sync();
+    return rep;
+}
+
+}  // namespace
+}  // namespace amc

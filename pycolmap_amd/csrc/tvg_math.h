@@ -276,41 +276,121 @@ AMC_HD double poly_eval(const double* c, int deg, double x) {
     return v;
 }
 // real roots of c (degree DEG >= 2, c[DEG] != 0) given the real roots `crit` of its derivative:
-// one sign-change bisection per monotone interval, ascending
+// one sign-change bisection per monotone interval, ascending.
+// Written for a SIMT lane: every array is indexed with compile-time indices (slots are filled by predicated
+// selects), so nothing lives in scratch memory, and the intervals are first classified and the bisections then run
+// over the lane's OWN sign-change intervals only - a wave's lanes solve different polynomials, and a loop over all
+// DEG + 1 intervals would make every lane wait for a bisection whenever any lane has a sign change in that slot.
+// Per interval the arithmetic is that of the plain loop (for each interval: f(lo) == 0 -> root lo unless it repeats
+// the previous root; f(hi) == 0 or equal signs -> nothing; else bisect until the midpoint hits an end): same roots,
+// same bits, same order.
 template <int DEG>
-AMC_HD int roots_between_t(const double (&c)[DEG + 1], const double* crit, int nc, double* roots) {
+AMC_HD int roots_between_t(const double (&c)[DEG + 1], const double (&crit)[DEG - 1], int nc, double (&roots)[DEG]) {
     double bound = 0.0;
 #pragma unroll
     for (int i = 0; i < DEG; ++i) bound = dmax(bound, dabs(c[i] / c[DEG]));
     bound = 1.0 + bound;
+    // edges: -bound, the critical points inside (-bound, bound), bound
     double edges[DEG + 1];
-    int ne = 0;
-    edges[ne++] = -bound;
-    for (int i = 0; i < nc; ++i)
-        if (crit[i] > -bound && crit[i] < bound) edges[ne++] = crit[i];
-    edges[ne++] = bound;
-    int nr = 0;
-    for (int i = 0; i + 1 < ne; ++i) {
-        double lo = edges[i], hi = edges[i + 1];
-        double flo = poly_eval_t<DEG>(c, lo);
-        const double fhi = poly_eval_t<DEG>(c, hi);
-        if (flo == 0.0) {
-            if (nr == 0 || roots[nr - 1] != lo) roots[nr++] = lo;
-            continue;
-        }
-        if (fhi == 0.0) continue;
-        if ((flo < 0.0) == (fhi < 0.0)) continue;
-        for (int it = 0; it < 200; ++it) {
-            const double mid = 0.5 * (lo + hi);
-            if (mid == lo || mid == hi) break;
-            const double fm = poly_eval_t<DEG>(c, mid);
-            if (fm == 0.0) { lo = mid; hi = mid; break; }
-            if ((fm < 0.0) == (flo < 0.0)) { lo = mid; flo = fm; } else { hi = mid; }
-        }
-        roots[nr++] = 0.5 * (lo + hi);
+#pragma unroll
+    for (int s = 0; s <= DEG; ++s) edges[s] = 0.0;
+    edges[0] = -bound;
+    int ne = 1;
+#pragma unroll
+    for (int j = 0; j < DEG - 1; ++j) {
+        const bool put = j < nc && crit[j] > -bound && crit[j] < bound;
+#pragma unroll
+        for (int s = 1; s < DEG; ++s) edges[s] = (put && ne == s) ? crit[j] : edges[s];
+        ne += put ? 1 : 0;
     }
-    if (poly_eval_t<DEG>(c, edges[ne - 1]) == 0.0 && (nr == 0 || roots[nr - 1] != edges[ne - 1]))
-        roots[nr++] = edges[ne - 1];
+#pragma unroll
+    for (int s = 1; s <= DEG; ++s) edges[s] = (ne == s) ? bound : edges[s];
+    ne += 1;
+    double f[DEG + 1];
+#pragma unroll
+    for (int s = 0; s <= DEG; ++s) f[s] = poly_eval_t<DEG>(c, edges[s]);
+    // interval i = [edges[i], edges[i + 1]]: 1 exact root at the lower edge, 2 sign change, 0 nothing
+    int kind[DEG];
+    unsigned todo = 0u;
+#pragma unroll
+    for (int i = 0; i < DEG; ++i) {
+        const bool valid = i + 1 < ne;
+        const bool zlo = f[i] == 0.0;
+        const bool chg = !zlo && f[i + 1] != 0.0 && ((f[i] < 0.0) != (f[i + 1] < 0.0));
+        kind[i] = valid ? (zlo ? 1 : (chg ? 2 : 0)) : 0;
+        todo |= (valid && chg) ? (1u << i) : 0u;
+    }
+    double val[DEG];
+#pragma unroll
+    for (int i = 0; i < DEG; ++i) val[i] = 0.0;
+    // two of the lane's brackets at a time: the bisection is a chain of dependent operations (Horner steps), and two
+    // independent chains interleaved cost hardly more than one at the occupancy these solvers run at.  Each bracket
+    // sees exactly the plain loop's arithmetic and its own 200-iteration cap.
+    while (todo) {
+        const int cur0 = __builtin_ctz(todo);
+        todo &= todo - 1u;
+        const bool two = todo != 0u;
+        const int cur1 = two ? __builtin_ctz(todo) : cur0;
+        todo = two ? (todo & (todo - 1u)) : todo;
+        double lo0 = edges[0], hi0 = edges[1], flo0 = f[0];
+        double lo1 = edges[0], hi1 = edges[1], flo1 = f[0];
+#pragma unroll
+        for (int i = 1; i < DEG; ++i) {
+            const bool me0 = cur0 == i, me1 = cur1 == i;
+            lo0 = me0 ? edges[i] : lo0;
+            hi0 = me0 ? edges[i + 1] : hi0;
+            flo0 = me0 ? f[i] : flo0;
+            lo1 = me1 ? edges[i] : lo1;
+            hi1 = me1 ? edges[i + 1] : hi1;
+            flo1 = me1 ? f[i] : flo1;
+        }
+        bool act0 = true, act1 = two;
+        for (int it = 0; it < 200 && (act0 || act1); ++it) {
+            const double mid0 = 0.5 * (lo0 + hi0), mid1 = 0.5 * (lo1 + hi1);
+            act0 = act0 && !(mid0 == lo0 || mid0 == hi0);
+            act1 = act1 && !(mid1 == lo1 || mid1 == hi1);
+            const double fm0 = poly_eval_t<DEG>(c, mid0), fm1 = poly_eval_t<DEG>(c, mid1);
+            if (act0) {
+                if (fm0 == 0.0) { lo0 = mid0; hi0 = mid0; act0 = false; }
+                else if ((fm0 < 0.0) == (flo0 < 0.0)) { lo0 = mid0; flo0 = fm0; }
+                else { hi0 = mid0; }
+            }
+            if (act1) {
+                if (fm1 == 0.0) { lo1 = mid1; hi1 = mid1; act1 = false; }
+                else if ((fm1 < 0.0) == (flo1 < 0.0)) { lo1 = mid1; flo1 = fm1; }
+                else { hi1 = mid1; }
+            }
+        }
+        const double r0 = 0.5 * (lo0 + hi0), r1 = 0.5 * (lo1 + hi1);
+#pragma unroll
+        for (int i = 0; i < DEG; ++i) val[i] = (cur0 == i) ? r0 : ((two && cur1 == i) ? r1 : val[i]);
+    }
+    // the ordered root list
+    int nr = 0;
+    double last = 0.0;
+#pragma unroll
+    for (int s = 0; s < DEG; ++s) roots[s] = 0.0;
+#pragma unroll
+    for (int i = 0; i < DEG; ++i) {
+        const bool push = (kind[i] == 1 && (nr == 0 || last != edges[i])) || kind[i] == 2;
+        const double v = kind[i] == 1 ? edges[i] : val[i];
+#pragma unroll
+        for (int s = 0; s < DEG; ++s) roots[s] = (push && nr == s) ? v : roots[s];
+        last = push ? v : last;
+        nr += push ? 1 : 0;
+    }
+    {   // the upper end itself
+        double fe = f[1], ee = edges[1];
+#pragma unroll
+        for (int s = 2; s <= DEG; ++s) {
+            fe = (ne - 1 == s) ? f[s] : fe;
+            ee = (ne - 1 == s) ? edges[s] : ee;
+        }
+        const bool push = fe == 0.0 && (nr == 0 || last != ee);
+#pragma unroll
+        for (int s = 0; s < DEG; ++s) roots[s] = (push && nr == s) ? ee : roots[s];
+        nr += push ? 1 : 0;
+    }
     return nr;
 }
 // J-th derivative of c (degree DEG), coefficient by coefficient as the chain of successive
@@ -329,8 +409,8 @@ AMC_HD void poly_derivative_t(const double (&c)[DEG + 1], double (&d)[DEG - J + 
 // the next one; the linear one is solved directly
 template <int DEG, int R>
 struct RootChain {
-    static AMC_HD int run(const double (&c)[DEG + 1], double* roots) {
-        double crit[R];
+    static AMC_HD int run(const double (&c)[DEG + 1], double (&roots)[R]) {
+        double crit[R - 1];
         const int nc = RootChain<DEG, R - 1>::run(c, crit);
         double d[R + 1];
         poly_derivative_t<DEG, DEG - R>(c, d);
@@ -339,7 +419,7 @@ struct RootChain {
 };
 template <int DEG>
 struct RootChain<DEG, 1> {
-    static AMC_HD int run(const double (&c)[DEG + 1], double* roots) {
+    static AMC_HD int run(const double (&c)[DEG + 1], double (&roots)[1]) {
         double d[2];
         poly_derivative_t<DEG, DEG - 1>(c, d);
         roots[0] = -d[0] / d[1];
@@ -357,7 +437,11 @@ struct RealRoots {
             for (int i = 0; i < DEG; ++i) lower[i] = c[i];
             return RealRoots<DEG - 1>::run(lower, roots);
         }
-        return RootChain<DEG, DEG>::run(c, roots);
+        double r[DEG];
+        const int nr = RootChain<DEG, DEG>::run(c, r);
+#pragma unroll
+        for (int i = 0; i < DEG; ++i) roots[i] = r[i];
+        return nr;
     }
 };
 template <>

@@ -35,7 +35,7 @@ def test_committed_bench_line_has_the_contract_keys():
         assert v["unit"] == "pairs/s" and v["value"] > 0 and v["cpu_baseline"]["gpu_vs_oracle_mismatching_pairs"] == 0
         vr = v["roofline"]                                     # the second metric's own roofline (FP64 vector)
         assert abs(vr["frac"] - vr["achieved"] / vr["peak"]) < 1e-9 and 0 < vr["frac"] < 1
-        assert abs(vr["frac_of_no_fma_ceiling"] - 2 * vr["frac"]) < 1e-6 and vr["kernel"] == "tvg_kernel"
+        assert abs(vr["frac_of_no_fma_ceiling"] - 2 * vr["frac"]) < 1e-6 and vr["kernel"] in ("tvg_kernel", "tvg_e_kernel + tvg_fh_kernel")
     pl = d.get("pipeline")
     if pl:                                                     # configs[2] chained on the device
         assert pl["unit"] == "verified pairs/s" and pl["pairs_verified"] > 1000 and pl["pairs_total"] == 124750
@@ -78,3 +78,52 @@ def test_host_cores_reads_the_cgroup_quota():
     n = bench.host_cores()
     import os
     assert 1 <= n <= (os.cpu_count() or 1)
+
+
+def _run_bench(*argv, timeout=600):
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)          # the entry must find out by itself that it has to launch its ranks
+    env.pop("RANK", None)
+    env.pop("LOCAL_RANK", None)
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), *argv], capture_output=True, text=True, timeout=timeout,
+                       env=env, cwd=str(ROOT))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]     # ONE JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+def test_multi_rank_entry_launches_itself_and_defaults_to_configs3():
+    """`python bench.py --gpus 2` (no launcher around it, no --config): the entry starts its two ranks under
+    torch.distributed.run, picks BASELINE configs[3] (fixed pair set, strong scaling), shards the pairs, exchanges the
+    match tables and prints one line with the per-rank kernel times and the exchange time.  Run here without a GPU
+    (--cpu-dry-run: gloo, CPU oracle in place of the kernels, tiny sizes): a plumbing check, value is null."""
+    d = _run_bench("--gpus", "2", "--cpu-dry-run", "--images", "9", "--feats", "64", "--steps", "1", "--warmup", "1")
+    assert d["dry_run"] is True and d["value"] is None and d["metric"].startswith("DRY RUN")
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["higher_is_better"] is True
+    c = d["config"]
+    assert "configs[3]" in c["workload"] and c["workload"].startswith("REDUCED 9 x 64")
+    assert c["pairs_total"] == 36 and 0 < c["pairs_rank0"] < 36
+    assert c["distances_per_step_all_ranks"] == 36 * 64 * 64      # every pair matched exactly once over the two ranks
+    assert c["backend"] == "gloo" and c["rccl_ranks"] == 0
+    assert len(c["kernel_ms_per_step_by_rank"]) == 2 and len(c["exchange_ms_per_step_by_rank"]) == 2
+    assert c["exchange_ms_per_step"] == max(c["exchange_ms_per_step_by_rank"]) > 0
+
+
+def test_multi_rank_entry_configs4_dry_run():
+    d = _run_bench("--gpus", "2", "--cpu-dry-run", "--config", "4", "--images", "24", "--feats", "64", "--steps", "1",
+                   "--warmup", "0")
+    c = d["config"]
+    assert d["dry_run"] and "configs[4]" in c["workload"] and c["loop_queries"] >= 1 and c["loop_pairs"] > 0
+    assert c["pairs_total"] == 24 * 23 // 2          # overlap 50 >= 24 images: every pair is a sequential pair
+
+
+def test_bench_refuses_gloo_for_a_measurement():
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "1", "--backend", "gloo"], capture_output=True,
+                       text=True, timeout=120, cwd=str(ROOT))
+    assert r.returncode != 0 and "cpu-dry-run" in (r.stdout + r.stderr)
