@@ -66,26 +66,55 @@ FLOP_LO_POINT = 200                                           # normalisation + 
 
 
 def verify_flops(work):
-    """FP64 flop of a verification call from amc_verify_result.work (include/amc.h): (scoring, solvers)."""
-    scoring = FLOP_SAMPSON * work[0] + FLOP_HRES * work[1] + FLOP_TRES * work[2]
+    """Algorithmic flop of a verification call from amc_verify_result.work (include/amc.h):
+    (FP64 scoring, solvers, homography scoring).  The homography RANSAC's inlier counts are decided by the packed-FP32
+    pre-filter, so their flop are NOT FP64 work and are kept out of the FP64 numerator."""
+    scoring64 = FLOP_SAMPSON * work[0] + FLOP_TRES * work[2]
+    scoring_h = FLOP_HRES * work[1]
     solvers = (FLOP_E5_MIN * work[3] + FLOP_F7_MIN * work[4] + FLOP_H4_MIN * work[5] + FLOP_LO_E5 * work[6] +
                FLOP_LO_F8 * work[7] + FLOP_LO_H * work[8] + FLOP_LO_POINT * work[9])
-    return float(scoring), float(solvers)
+    return float(scoring64), float(solvers), float(scoring_h)
 
 
-def fp64_roofline(work, kernel_s, launches):
-    scoring, solvers = verify_flops(work)
+def executed_valu(kernel_s_per_pair):
+    """Executed vector instructions of the verification kernels from the committed SQ counter pass
+    (profiles/r03/pmc_tvg_r03.json, tools/pmc_tvg_r03.sh), valid only while the kernels' sources hash to what they were
+    when the counters were taken: wave instructions x 64 lanes per pair, as a share of the FP64 issue rate."""
+    try:
+        import hashlib
+        pmc = json.loads((ROOT / "profiles" / "r03" / "pmc_tvg_r03.json").read_text())
+        if not all(hashlib.sha256((ROOT / f).read_bytes()).hexdigest() == h for f, h in pmc["kernel_source_sha256"].items()):
+            return None
+        lane_ops_per_pair = pmc["valu_wave_instructions_per_pair"] * 64.0
+        return {"valu_lane_ops_per_pair": lane_ops_per_pair, "source": "profiles/r03/pmc_tvg_r03.json",
+                "valu_lane_ops_per_s": lane_ops_per_pair / kernel_s_per_pair if kernel_s_per_pair > 0 else 0.0,
+                "frac_of_valu_issue_peak": (lane_ops_per_pair / kernel_s_per_pair) / FP64_NO_FMA_CEILING if kernel_s_per_pair > 0 else 0.0,
+                "note": "ALL vector instructions the two kernels executed (FP64, packed FP32, integer, moves), one lane-op per "
+                        "lane and instruction, against the 39.3 T lane-op/s the vector ALU issues at FP64 rate; the counters "
+                        "were taken on the workload named in the file, the rate uses this run's kernel time"}
+    except (OSError, KeyError, ValueError):
+        return None
+
+
+def fp64_roofline(work, kernel_s, launches, pairs=0):
+    scoring, solvers, scoring_h = verify_flops(work)
     total = scoring + solvers
     ach = total / kernel_s if kernel_s > 0 else 0.0
-    return {"bound": "fp64 vector (VALU); no MFMA, bytes negligible (points live in LDS)",
-            "achieved": ach / 1e12, "peak": FP64_VECTOR_PEAK / 1e12, "unit": "TFLOP/s (FP64)",
-            "frac": ach / FP64_VECTOR_PEAK, "frac_of_no_fma_ceiling": ach / FP64_NO_FMA_CEILING,
-            "no_fma_ceiling": FP64_NO_FMA_CEILING / 1e12,
-            "flop_per_launch": total / max(launches, 1), "flop_scoring_share": scoring / total if total else 0.0,
-            "kernel": "tvg_e_kernel + tvg_fh_kernel", "avg_kernel_ms": 1e3 * kernel_s / max(launches, 1), "launches": launches,
-            "traffic": None,
-            "note": "algorithmic flop as COLMAP's loops count them (every model of every trial x all matches); the "
-                    "kernel skips part of that work by early exit, so this is useful work per second, not issue rate"}
+    out = {"bound": "fp64 vector (VALU); no MFMA, bytes negligible (correspondences stream through the scalar cache)",
+           "achieved": ach / 1e12, "peak": FP64_VECTOR_PEAK / 1e12, "unit": "TFLOP/s (FP64)",
+           "frac": ach / FP64_VECTOR_PEAK, "frac_of_no_fma_ceiling": ach / FP64_NO_FMA_CEILING,
+           "no_fma_ceiling": FP64_NO_FMA_CEILING / 1e12,
+           "flop_per_launch": total / max(launches, 1), "flop_scoring_share": scoring / total if total else 0.0,
+           "fp32_prefilter_flop_not_counted": scoring_h,
+           "achieved_if_homography_scoring_were_counted_as_fp64": (total + scoring_h) / kernel_s / 1e12 if kernel_s > 0 else 0.0,
+           "kernel": "tvg_e_kernel + tvg_fh_kernel", "avg_kernel_ms": 1e3 * kernel_s / max(launches, 1), "launches": launches,
+           "traffic": None,
+           "note": "algorithmic FP64 flop as COLMAP's loops count them (every Sampson / translation residual of every model of "
+                   "every trial x all matches, the solvers); the homography transfer residuals are decided in packed FP32 and "
+                   "are reported separately, not in the numerator.  Useful work per second, not issue rate"}
+    if pairs:
+        out["executed"] = executed_valu(kernel_s / pairs)
+    return out
 
 
 def make_arena_torch(num_images: int, feats: int, seed: int, device, overlap: str = "ring"):
@@ -156,20 +185,33 @@ def cpu_baseline(arena_cpu: np.ndarray, s1: np.ndarray, s2: np.ndarray, sample_p
     off, m = oracle_lib.match_pairs(imgs, a, b, threads=threads)
     dt = time.perf_counter() - t0
     ndist = float(sum(len(imgs[int(x)]) * len(imgs[int(y)]) for x, y in zip(a, b)))
-    return ndist / dt, len(idx), dt, (idx, off, m)
+    # the same pairs by the AVX-512 VNNI variant of the matcher (oracle/match_vnni.c: vpdpbusd with the zero-point
+    # identity, vectorised top-2): what the host's cores can do, beside what the literal restatement costs
+    opt = None
+    if oracle_lib.vnni_available():
+        t1 = time.perf_counter()
+        voff, vm = oracle_lib.match_pairs(imgs, a, b, threads=threads, variant="vnni")
+        vdt = time.perf_counter() - t1
+        opt = {"value": ndist / vdt, "unit": "distances/s", "cores": min(threads, len(idx)), "kind": "optimised",
+               "sample": f"the same {len(idx)} pairs, oracle/match_vnni.c (AVX-512 VNNI vpdpbusd, -O3, OpenMP, one pair per "
+                         f"thread), {vdt:.2f} s", "identical_to_port": bool(np.array_equal(voff, off) and np.array_equal(vm, m))}
+    return ndist / dt, len(idx), dt, (idx, off, m), opt
 
 
-def verify_leg(ctx_factory, device_index: int, npairs: int, steps: int, warmup: int, cpu_sample: int):
+def verify_leg(ctx_factory, device_index: int, npairs: int, steps: int, warmup: int, cpu_sample: int, distinct: int = 4096):
     """BASELINE's second metric: verified image-pairs/s.  Workload (configs[2] style): `npairs`
     synthetic calibrated two-view scenes (PINHOLE, prior focal length => E, F and H LO-RANSACs +
     model selection + watermark test all run), ~300 planted inliers + ~100 outliers each, a
-    quarter of the scenes planar.  64 distinct seeded scenes are reused round-robin."""
+    quarter of the scenes planar.  `distinct` seeded scenes (default 4096: different trial counts, branches and
+    correspondences from pair to pair), reused round-robin to fill the 124,750 pairs."""
     from pycolmap_amd import _capi, synth
     rng = np.random.default_rng(7)
-    distinct = 64
+    distinct = max(1, min(distinct, npairs))
+    t_gen = time.perf_counter()
     scenes = [synth.two_view_scene(rng, num_inliers=int(rng.integers(150, 450)),
                                    num_outliers=int(rng.integers(50, 200)), planar=(k % 4 == 3))
               for k in range(distinct)]
+    t_gen = time.perf_counter() - t_gen
     ctx = ctx_factory()
     ctx.reserve_slots(2 * distinct)
     for k, sc in enumerate(scenes):
@@ -199,10 +241,11 @@ def verify_leg(ctx_factory, device_index: int, npairs: int, steps: int, warmup: 
         "metric": "verified image-pairs/sec (E+F+H LO-RANSAC, model selection, watermark test)",
         "value": npairs * steps / dt, "unit": "pairs/s", "pairs": npairs, "steps": steps,
         "ms_per_step": 1e3 * dt / steps, "kernel_ms_per_step": kms / steps,
-        "mean_matches_per_pair": float(counts.mean()), "dtype": "f64",
+        "mean_matches_per_pair": float(counts.mean()), "dtype": "f64", "distinct_scenes": distinct,
+        "scene_generation_s": t_gen,
         "configs": {_capi.CONFIG_NAMES[c]: int(n) for c, n in zip(*np.unique(tvg["config"], return_counts=True))},
         "mean_trials_E_F_H": [float(x) for x in tvg["num_trials"][:, :3].mean(axis=0)],
-        "roofline": fp64_roofline([w * steps for w in st["work"]], kms * 1e-3, launches),
+        "roofline": fp64_roofline([w * steps for w in st["work"]], kms * 1e-3, launches, pairs=npairs * steps),
     }
     # the same workload with TwoViewGeometryOptions.compute_relative_pose (pose.hip on the selected
     # inliers after the estimation): reported beside the metric, not as the metric
@@ -564,12 +607,31 @@ def run_config34(args):
     loop_num_images = min(50, num_images - 1)
     exch = {"ms": 0.0}
 
+    def exchange(fn):
+        # the exchange step, timed on its own (host clock between device synchronisations): it waits for the slowest
+        # rank's kernels, so it holds the load imbalance as well as the transfer
+        device_sync(args)
+        te = time.perf_counter()
+        r = fn()
+        device_sync(args)
+        exch["ms"] += 1e3 * (time.perf_counter() - te)
+        return r
+
+    def resident():
+        # the match table where the kernels left it in HBM (no host round trip before the collective)
+        return None if dry else ctx.resident_matches_tensor(local_rank)
+
     def step():
         off, m, st = ctx.match_pairs(s1, s2, kernel=args.kernel, copy=False)
         nd = st["num_distances"]
         kms, kl = st["match_kernel_ms"], st["match_kernel_launches"]
         parts = [(mine, off, m)]
         extra = {}
+        gathered = None
+        if use_dist:
+            # sequential / exhaustive pairs have global positions: one all-gather of the tables, fed from device memory
+            gathered = [exchange(lambda: D.all_gather_match_tables(mine, off, m, device=device, as_numpy=False,
+                                                                   device_matches=resident()))]
         if args.config == 4 and len(queries):
             # loop closure (SequentialFeatureMatcher::RunLoopDetection with the vocabulary tree replaced by exact
             # feature voting): every 10th image against every other image on the first 512
@@ -590,20 +652,12 @@ def run_config34(args):
             extra = dict(loop_queries=int(len(queries)), loop_scoring_pairs=int(len(q1)), loop_pairs=int(len(l1)),
                          loop_scoring_distances=int(vst["num_distances"]), loop_match_distances=int(lst["num_distances"]))
             parts.append((None, loff, lm))
-        gathered = None
-        if use_dist:
-            # the exchange step: sequential pairs have global positions; the loop pairs of a rank are numbered after
-            # those of the ranks before it (one small all-gather of the counts).  Timed on its own (host clock
-            # between device synchronisations): it waits for the slowest rank's kernels, so it holds the load
-            # imbalance as well as the transfer.
-            device_sync(args)
-            te = time.perf_counter()
-            gathered = [D.all_gather_match_tables(mine, off, m, device=device, as_numpy=False)]
-            if args.config == 4:
-                lo_, lm_ = (parts[1][1], parts[1][2]) if len(parts) > 1 else (np.zeros(1, np.uint64), np.zeros((0, 2), np.uint32))
-                gathered.append(D.all_gather_appended_tables(lo_, lm_, device=device, as_numpy=False))
-            device_sync(args)
-            exch["ms"] += 1e3 * (time.perf_counter() - te)
+        if use_dist and args.config == 4:
+            # the loop pairs of a rank are numbered after those of the ranks before it (one small all-gather of the counts)
+            have = len(parts) > 1
+            lo_, lm_ = (parts[1][1], parts[1][2]) if have else (np.zeros(1, np.uint64), np.zeros((0, 2), np.uint32))
+            gathered.append(exchange(lambda: D.all_gather_appended_tables(lo_, lm_, device=device, as_numpy=False,
+                                                                          device_matches=resident() if have else None)))
         return nd, kms, kl, int(sum(p[2].shape[0] for p in parts)), extra, gathered
 
     def fence():
@@ -699,6 +753,7 @@ def main():
                     help="pairs in the verification leg (0 = skip); reported under \"verify\".  Default: every pair "
                          "of the 500-image set, BASELINE.json configs[2] (the kernel keeps 2048 waves busy from a "
                          "queue, so a 4096-pair call spends a quarter of its time in the tail: 64 k vs 92-99 k pairs/s)")
+    ap.add_argument("--verify-scenes", type=int, default=4096, help="distinct seeded scenes in the verification leg")
     ap.add_argument("--no-cross-check", action="store_true",
                     help="diagnostic: one-way matching only (NOT the BASELINE workload)")
     ap.add_argument("--force-dist", action="store_true",
@@ -760,7 +815,8 @@ def main():
         if use_dist:
             # the exchange step: RCCL all-gather of the match tables (sizes, then padded tables);
             # afterwards every rank holds the whole match graph (rank 0 would feed the SQLite writer)
-            gathered = D.all_gather_match_tables(mine, off, m, device=device, as_numpy=False)
+            gathered = D.all_gather_match_tables(mine, off, m, device=device, as_numpy=False,
+                                                 device_matches=ctx.resident_matches_tensor(local_rank))
         return off, m, st, gathered
 
     def fence():
@@ -840,25 +896,32 @@ def main():
                 "launches_per_step": launches_per_step,
             },
         }
-        # HBM bytes per launch of the dominant kernel: PMC counters cannot be collected inside this process,
-        # so the number comes from the committed rocprofv3 --pmc pass of this same command
-        # (profiles/r02/pmc_hbm_r02.*), and only when this run launches the same shape.
+        # HBM bytes per launch of the dominant kernel: PMC counters cannot be collected inside this process, so the
+        # number comes from the committed rocprofv3 --pmc pass of this same command (profiles/*/pmc_hbm_*.json) - and
+        # only while (i) this run launches the same shape and (ii) the kernel's source still hashes to what it was when
+        # the counters were taken (roofline.traffic_source_sha); otherwise the field stays null.
         try:
-            pmc = json.loads((ROOT / "profiles" / "r02" / "pmc_hbm_r02.json").read_text())
+            import hashlib
+            pmc_path = sorted((ROOT / "profiles").glob("r*/pmc_hbm_r*.json"))[-1]
+            pmc = json.loads(pmc_path.read_text())
             per_launch = int(len(s1)) // launches_per_step
-            if st["pairs_mfma"] and args.feats == 4096 and abs(per_launch - pmc["pairs_per_launch"]) <= 1:
+            shas = pmc.get("kernel_source_sha256", {})
+            same_source = bool(shas) and all(hashlib.sha256((ROOT / f).read_bytes()).hexdigest() == h for f, h in shas.items())
+            out["roofline"]["traffic_source"] = str(pmc_path.relative_to(ROOT))
+            out["roofline"]["traffic_source_sha"] = shas
+            out["roofline"]["traffic_source_current"] = same_source
+            if same_source and st["pairs_mfma"] and args.feats == 4096 and abs(per_launch - pmc["pairs_per_launch"]) <= 1:
                 out["roofline"]["traffic"] = pmc["fetch_bytes_per_launch_corrected"]
                 out["roofline"]["traffic_unit"] = "bytes read from HBM per launch (FETCH_SIZE x 1024 x 2, gfx950 correction)"
-                out["roofline"]["traffic_source"] = "profiles/r02/pmc_hbm_r02_v2.txt"
                 out["roofline"]["traffic_written"] = pmc.get("write_bytes_per_launch")
                 out["roofline"]["algorithmic_bytes"] = float(per_launch) * 2 * args.feats * 128
-        except (OSError, KeyError, ValueError):
+        except (OSError, KeyError, ValueError, IndexError):
             pass
         if world == 1 and not args.no_cpu_baseline:
             cores = host_cores()
             arena_cpu = arena.cpu().numpy()
             sample = args.cpu_sample_pairs if args.cpu_sample_pairs > 0 else 8 * cores
-            v, npairs, dt, (idx, coff, cm) = cpu_baseline(arena_cpu, s1, s2, sample, cores)
+            v, npairs, dt, (idx, coff, cm), cpu_opt = cpu_baseline(arena_cpu, s1, s2, sample, cores)
             cores = min(cores, npairs)  # the oracle runs one pair per thread
             # the sample doubles as a full-size parity spot check of the timed GPU result
             mism = 0
@@ -872,11 +935,12 @@ def main():
                 "sample": f"{npairs} seeded pairs of the same {num_images}x{args.feats} workload, "
                           f"oracle/match_oracle.c (-O2, OpenMP, one pair per thread), {dt:.1f} s",
                 "gpu_vs_oracle_mismatching_pairs": mism,
+                "optimised": cpu_opt,   # None on a host without AVX-512 VNNI
             }
         if args.verify_pairs > 0 and world == 1:
             out["verify"] = verify_leg(lambda: _capi.Context(local_rank), local_rank, args.verify_pairs,
                                        max(1, args.steps), min(1, args.warmup),
-                                       0 if args.no_cpu_baseline else 256)
+                                       0 if args.no_cpu_baseline else 256, distinct=args.verify_scenes)
         if world == 1 and not args.no_pipeline:
             ctx.close()          # the legs below bring their own contexts and arenas
             del arena

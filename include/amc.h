@@ -107,6 +107,21 @@ void amc_ctx_destroy(amc_ctx* ctx);
  * stream; pass NULL to restore.  Lets a host that owns streams (e.g. torch) order/time us. */
 int amc_ctx_set_stream(amc_ctx* ctx, void* hip_stream);
 
+/* Release what the ctx keeps between calls for reuse and can re-allocate on demand: per-call device scratch (top-2
+ * tables, the device-resident match table, verification workspaces), the pinned staging buffers and the pool of idle
+ * result buffers (bounded on its own: three buffers, 1.5 GiB).  Uploaded images stay.  A host that runs one large job
+ * per ctx (COLMAP's FeatureMatcherController::Match, /root/reference/pycolmap/pipeline/match_features.h:45-47) calls
+ * this when the job is done; with gpu_index "-1" there is one ctx per device. */
+int amc_ctx_trim(amc_ctx* ctx);
+
+/* The match table of the LAST amc_match_pairs / amc_match_guided_pairs / amc_match_verify_pairs call on this ctx, where
+ * the kernels left it in device memory: 2 * num_matches uint32 in the result's CSR order (amc_match_result.offsets
+ * index it).  For a host that hands the table to a device-side consumer without a host round trip - the multi-GPU
+ * exchange step (RCCL all-gather of the match tables, pycolmap_amd/distributed.py; the reference's multi-GPU surface is
+ * SiftMatchingOptions.gpu_index, /root/reference/pycolmap/pipeline/match_features.h:76-81).  The pointer stays valid
+ * until the next match call, amc_ctx_trim or amc_ctx_destroy on this ctx; NULL when the table is empty. */
+int amc_ctx_resident_matches(amc_ctx* ctx, const uint32_t** dev_matches, uint64_t* num_matches);
+
 /* Size the image-slot table. Slots are dense ids 0..num_slots-1 chosen by the caller (the host
  * layer maps COLMAP image_ids to slots). Discards previously uploaded data. */
 int amc_ctx_reserve_slots(amc_ctx* ctx, uint32_t num_slots);

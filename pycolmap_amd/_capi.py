@@ -28,7 +28,7 @@ EXPORTED_SYMBOLS = [
     "amc_tvg_opts_default", "amc_upload_keypoints", "amc_upload_camera", "amc_verify_pairs",
     "amc_verify_result_free", "amc_upload_points_f64", "amc_ransac_pairs", "amc_ransac_result_free",
     "amc_squared_sampson_error", "amc_match_guided_pairs", "amc_ctx_grow_slots", "amc_pose_pairs",
-    "amc_cam_from_img", "amc_match_verify_pairs",
+    "amc_cam_from_img", "amc_match_verify_pairs", "amc_ctx_trim", "amc_ctx_resident_matches",
 ]
 RANSAC_F, RANSAC_H, RANSAC_E = 0, 1, 2
 RANSAC_KINDS = {"F": RANSAC_F, "H": RANSAC_H, "E": RANSAC_E}
@@ -173,6 +173,10 @@ def load() -> C.CDLL:
     lib.amc_ctx_destroy.argtypes = [C.c_void_p]
     lib.amc_ctx_destroy.restype = None
     lib.amc_ctx_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+    lib.amc_ctx_trim.argtypes = [C.c_void_p]
+    lib.amc_ctx_trim.restype = C.c_int
+    lib.amc_ctx_resident_matches.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.amc_ctx_resident_matches.restype = C.c_int
     lib.amc_ctx_reserve_slots.argtypes = [C.c_void_p, C.c_uint32]
     lib.amc_ctx_grow_slots.argtypes = [C.c_void_p, C.c_uint32]
     lib.amc_upload_descriptors.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
@@ -266,6 +270,29 @@ class Context:
 
     def set_stream(self, hip_stream: int | None) -> None:
         _check(self._lib.amc_ctx_set_stream(self._h, C.c_void_p(hip_stream or 0)))
+
+    def resident_matches(self):
+        """(device pointer, number of matches) of the last match call's table in device memory (amc_ctx_resident_matches):
+        CSR order of that call's result, valid until the next match call / trim / close."""
+        ptr, n = C.c_void_p(), C.c_uint64()
+        _check(self._lib.amc_ctx_resident_matches(self._h, C.byref(ptr), C.byref(n)))
+        return int(ptr.value or 0), int(n.value)
+
+    def resident_matches_tensor(self, device_index: int = 0):
+        """The same table as a torch int32 [n, 2] tensor that ALIASES the library's device memory (no copy): what the
+        exchange step hands to RCCL.  Same lifetime as resident_matches()."""
+        import torch
+        ptr, n = self.resident_matches()
+        if n == 0:
+            return torch.zeros((0, 2), dtype=torch.int32, device=torch.device("cuda", device_index))
+
+        class _View:   # numpy-style CUDA array interface over the raw pointer (uint32 bit patterns viewed as int32)
+            __cuda_array_interface__ = {"shape": (n, 2), "typestr": "<i4", "data": (ptr, True), "version": 3, "strides": None}
+        return torch.as_tensor(_View(), device=torch.device("cuda", device_index))
+
+    def trim(self) -> None:
+        """Release per-call scratch, staging buffers and idle result buffers (amc_ctx_trim); uploaded images stay."""
+        _check(self._lib.amc_ctx_trim(self._h))
 
     def reserve_slots(self, n: int) -> None:
         _check(self._lib.amc_ctx_reserve_slots(self._h, n))

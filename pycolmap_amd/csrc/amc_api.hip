@@ -110,6 +110,10 @@ struct PinBuf {
 // directly); amc_match_result_free returns it for the next call, so a pipeline allocates pinned memory once.  The
 // pool is shared-owned: results may outlive their context.
 struct PinnedPool {
+    // Idle buffers are kept for the next call, but not without bound: at most three, and at most kMaxIdleBytes in
+    // total (a dense 500 x 4096 call returns a 1 GiB table: one such buffer stays, a second one does not).  With one
+    // context per device (gpu_index "-1") the bound holds per device.  amc_ctx_trim empties the pool.
+    static constexpr size_t kMaxIdleBytes = (size_t)3 << 29;  // 1.5 GiB
     std::mutex mu;
     std::vector<PinBuf<uint32_t>> idle;
     PinBuf<uint32_t> acquire() {
@@ -125,15 +129,26 @@ struct PinnedPool {
     void give_back(PinBuf<uint32_t> b) {
         if (!b.p) return;
         std::lock_guard<std::mutex> lock(mu);
-        if (idle.size() >= 3) {  // keep the three largest
+        idle.push_back(b);
+        auto total = [&] {
+            size_t t = 0;
+            for (auto& x : idle) t += x.cap * sizeof(uint32_t);
+            return t;
+        };
+        // drop the smallest until the bounds hold (the largest is the one the next call of a pipeline wants); a single
+        // buffer above the byte bound is dropped as well
+        while (!idle.empty() && (idle.size() > 3 || total() > kMaxIdleBytes)) {
             size_t small = 0;
             for (size_t i = 1; i < idle.size(); ++i)
                 if (idle[i].cap < idle[small].cap) small = i;
-            if (idle[small].cap < b.cap) std::swap(idle[small], b);
-            b.release();
-            return;
+            idle[small].release();
+            idle.erase(idle.begin() + small);
         }
-        idle.push_back(b);
+    }
+    void trim() {
+        std::lock_guard<std::mutex> lock(mu);
+        for (auto& b : idle) b.release();
+        idle.clear();
     }
     ~PinnedPool() {
         for (auto& b : idle) b.release();
@@ -179,6 +194,7 @@ struct amc_ctx {
     // that the verification kernel reads them where the matcher left them instead of from a host round trip
     DevBuf<uint32_t> d_keep;
     DevBuf<uint64_t> d_csr;                 // per batch: where each pair's matches go in d_keep (pair order)
+    uint64_t resident_matches = 0;          // matches of the LAST match call, in its result's CSR order, at d_keep (amc_ctx_resident_matches)
     PinBuf<uint64_t> h_csr[2];
     std::shared_ptr<PinnedPool> result_pool = std::make_shared<PinnedPool>();
     // host staging of a match batch, two sets: batch k+1 is prepared and enqueued while the results of
@@ -341,6 +357,34 @@ void amc_ctx_destroy(amc_ctx* c) {
 int amc_ctx_set_stream(amc_ctx* c, void* hip_stream) {
     if (!c) return fail(AMC_E_INVALID, "amc_ctx_set_stream: ctx is NULL");
     c->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : c->own_stream;
+    return AMC_OK;
+}
+
+int amc_ctx_trim(amc_ctx* c) {
+    if (!c) return fail(AMC_E_INVALID, "amc_ctx_trim: NULL ctx");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->copy_stream) HIPCHK(hipStreamSynchronize(c->copy_stream));
+    // per-call scratch and result staging: everything a later call re-allocates on demand (uploaded images, the acos
+    // table, the sample stream and the trial tables stay)
+    c->result_pool->trim();
+    c->d_keep.release(); c->d_csr.release();
+    c->resident_matches = 0;
+    c->d_rowbuf.release(); c->d_colbuf.release(); c->d_accmask.release(); c->d_matches.release(); c->d_candbuf.release();
+    c->d_tws.release(); c->d_tmaskws.release(); c->d_toutmask.release(); c->d_emask.release(); c->d_estate.release();
+    c->d_tout.release(); c->d_tmatches.release(); c->d_pmatches.release(); c->d_pcos.release();
+    c->h_tout.release(); c->h_tmask.release();
+    for (int k = 0; k < 2; ++k) {
+        c->h_matches[k].release();
+        c->h_csr[k].release();
+    }
+    return AMC_OK;
+}
+
+int amc_ctx_resident_matches(amc_ctx* c, const uint32_t** dev_matches, uint64_t* num_matches) {
+    if (!c || !dev_matches || !num_matches) return fail(AMC_E_INVALID, "amc_ctx_resident_matches: NULL argument");
+    *dev_matches = c->resident_matches ? c->d_keep.p : nullptr;
+    *num_matches = c->resident_matches;
     return AMC_OK;
 }
 
@@ -543,6 +587,7 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
     priv->pool = c->result_pool;
     priv->matches = c->result_pool->acquire();
     size_t keep_used = 0;  // matches of this call in c->d_keep so far (pair order: the result's CSR layout)
+    c->resident_matches = 0;
     if (keep_off) keep_off->assign(npairs, 0);
 
     const float max_ratio_f = (float)o.max_ratio;
@@ -910,6 +955,7 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
     (void)hipEventElapsedTime(&total_ms, c->ev[0], c->ev[1]);
 
     out->npairs = npairs;
+    c->resident_matches = keep_used;
     out->offsets = priv->offsets.data();
     out->matches = priv->offsets[npairs] ? priv->matches.p : nullptr;
     out->num_distances = num_dist;

@@ -3,8 +3,9 @@
 Image pairs are independent units, so the path shards embarrassingly: one process per GPU
 (`torch.distributed`, backend "nccl" = RCCL over xGMI on MI355X, "gloo" on CPU for tests), the
 descriptor arena replicated on every GPU, the pair list dealt in contiguous slices, and ONE exchange
-step at the end: an all-gather of the per-rank match tables (counts first, then padded tables) so
-that every rank — in particular the rank that owns the SQLite writer — holds the whole match graph.
+step at the end: an all-gather of the per-rank match tables (sizes first, then the tables themselves: uneven
+all-gathers of 32-bit payloads, fed from the device memory the match kernels wrote) so that every rank — in particular
+the rank that owns the SQLite writer — holds the whole match graph.
 The functions here are pure tensor plumbing and work unchanged on CPU tensors (gloo) and GPU
 tensors (RCCL).
 """
@@ -39,50 +40,73 @@ def shard_pairs(slot1: np.ndarray, slot2: np.ndarray, rank: int, world: int, row
     return s1[mine], s2[mine], mine
 
 
+def _gather_rows(t, sizes, group=None):
+    """All-gather of per-rank tensors with DIFFERENT numbers of rows: returns the list of every rank's rows.
+    RCCL (backend "nccl"): one uneven all_gather - each rank sends exactly its rows, nothing is padded.  gloo (CPU
+    tests) only gathers equal sizes: pad to the largest rank there."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    sizes = [int(x) for x in sizes]
+    t = t.contiguous()
+    tail = tuple(t.shape[1:])
+    if dist.get_backend(group) == "nccl" and min(sizes) > 0:
+        outs = [torch.empty((n,) + tail, dtype=t.dtype, device=t.device) for n in sizes]
+        dist.all_gather(outs, t, group=group)
+        return outs
+    mx = max(max(sizes), 1)
+    pad = torch.zeros((mx,) + tail, dtype=t.dtype, device=t.device)
+    if t.shape[0]:
+        pad[:t.shape[0]] = t
+    allp = torch.empty((world * mx,) + tail, dtype=t.dtype, device=t.device)
+    dist.all_gather_into_tensor(allp, pad, group=group)
+    return [allp[r * mx:r * mx + sizes[r]] for r in range(world)]
+
+
 def all_gather_match_tables(pair_index: np.ndarray, offsets: np.ndarray, matches: np.ndarray, device=None,
-                            group=None, as_numpy: bool = True):
+                            group=None, as_numpy: bool = True, device_matches=None, download_rank=None):
     """Exchange per-rank CSR match tables.  Every rank passes the global indices of its pairs, its
     CSR offsets and its (M, 2) uint32 matches; every rank gets back the table for ALL pairs as
     (global_offsets, global_matches) in the global pair order.
 
-    Collectives: an all-gather of the (npairs, nmatches) sizes, then two padded all-gathers (per-pair
-    (index, count) and the match rows) - few and large, which is what xGMI's point-to-point rings
-    want.  The reassembly into the global CSR is a handful of tensor ops on `device` (scatter of the
-    counts, one cumulative sum, one indexed copy of the rows): no per-pair host work."""
+    `device_matches`: the rank's match rows as an int32 [M, 2] tensor already on `device` - the table where the match
+    kernels left it (Context.resident_matches_tensor(): no host round trip, no copy); `matches` is then not read.
+    Collectives: an all-gather of the (npairs, nmatches) sizes, then two uneven all-gathers (per-pair (index, count)
+    and the match rows, 32-bit payloads, each rank sends exactly what it has) - few and large, which is what xGMI's
+    point-to-point links want.  The reassembly into the global CSR is a handful of tensor ops on `device` (scatter of
+    the counts, one cumulative sum, one indexed copy of the rows): no per-pair host work.
+    as_numpy=False: device tensors are returned.  download_rank=r: only rank r copies the result to the host (the
+    rank that owns the SQLite writer), the others return (None, None)."""
     import torch
     import torch.distributed as dist
 
     world = dist.get_world_size(group)
     dev = device if device is not None else torch.device("cpu")
     counts = np.diff(np.asarray(offsets, dtype=np.int64))
-    npairs, nm = len(pair_index), int(matches.shape[0])
+    npairs = len(pair_index)
+    nm = int(device_matches.shape[0]) if device_matches is not None else int(matches.shape[0])
+    if int(counts.sum()) != nm:
+        raise ValueError("offsets and matches disagree")
     sizes = torch.tensor([npairs, nm], dtype=torch.int64, device=dev)
     all_sizes = torch.empty(world * 2, dtype=torch.int64, device=dev)
     dist.all_gather_into_tensor(all_sizes, sizes, group=group)
     all_sizes = all_sizes.view(world, 2).cpu()
-    max_p, max_m = max(int(all_sizes[:, 0].max()), 1), max(int(all_sizes[:, 1].max()), 1)
 
-    meta = torch.zeros(max_p, 2, dtype=torch.int64, device=dev)   # (global index, count)
-    if npairs:
-        meta[:npairs, 0] = torch.from_numpy(np.asarray(pair_index, dtype=np.int64)).to(dev)
-        meta[:npairs, 1] = torch.from_numpy(counts).to(dev)
-    all_meta = torch.empty(world * max_p, 2, dtype=torch.int64, device=dev)
-    dist.all_gather_into_tensor(all_meta, meta, group=group)
-
-    rows = torch.zeros(max_m, 2, dtype=torch.int32, device=dev)
-    if nm:
-        rows[:nm] = torch.from_numpy(np.ascontiguousarray(matches, dtype=np.uint32).view(np.int32)).to(dev)
-    all_rows = torch.empty(world * max_m, 2, dtype=torch.int32, device=dev)
-    dist.all_gather_into_tensor(all_rows, rows, group=group)
+    meta_h = np.empty((npairs, 2), dtype=np.int32)          # (global index, count): 8 bytes per pair, the only H2D
+    meta_h[:, 0] = np.asarray(pair_index, dtype=np.int64)
+    meta_h[:, 1] = counts
+    meta = torch.from_numpy(meta_h).to(dev)
+    if device_matches is not None:
+        rows = device_matches.view(torch.int32).reshape(-1, 2)
+    else:
+        rows = torch.from_numpy(np.ascontiguousarray(matches, dtype=np.uint32).view(np.int32).reshape(-1, 2)).to(dev)
+    all_meta = torch.cat(_gather_rows(meta, all_sizes[:, 0].tolist(), group), 0)
+    rows_cat = torch.cat(_gather_rows(rows, all_sizes[:, 1].tolist(), group), 0)   # rank-major, like all_meta
 
     # ---- global CSR, on `dev` ----
-    np_r = all_sizes[:, 0].to(dev)
-    nm_r = all_sizes[:, 1].to(dev)
-    valid_p = (torch.arange(max_p, device=dev)[None, :] < np_r[:, None]).reshape(-1)
-    valid_m = (torch.arange(max_m, device=dev)[None, :] < nm_r[:, None]).reshape(-1)
-    idx = all_meta[valid_p, 0]          # rank-major concatenation of every rank's pairs ...
-    cnt = all_meta[valid_p, 1]
-    rows_cat = all_rows[valid_m]        # ... and of their rows, in the same order
+    idx = all_meta[:, 0].to(torch.int64)
+    cnt = all_meta[:, 1].to(torch.int64)
     total_pairs = int(idx.numel())
     g_counts = torch.zeros(total_pairs, dtype=torch.int64, device=dev)
     g_counts[idx] = cnt
@@ -95,10 +119,13 @@ def all_gather_match_tables(pair_index: np.ndarray, offsets: np.ndarray, matches
         g_matches[torch.arange(rows_cat.shape[0], device=dev) + shift] = rows_cat
     if not as_numpy:
         return g_off, g_matches
+    if download_rank is not None and dist.get_rank(group) != download_rank:
+        return None, None
     return g_off.cpu().numpy().astype(np.uint64), g_matches.cpu().numpy().view(np.uint32)
 
 
-def all_gather_appended_tables(offsets: np.ndarray, matches: np.ndarray, device=None, group=None, as_numpy: bool = True):
+def all_gather_appended_tables(offsets: np.ndarray, matches: np.ndarray, device=None, group=None, as_numpy: bool = True,
+                               device_matches=None):
     """all_gather_match_tables for pair lists that have no global numbering yet - e.g. the loop-closure pairs every
     rank retrieves for its own query images (BASELINE configs[4]): the lists are appended in rank order.  One more
     tiny all-gather (the per-rank pair counts) gives every rank its base position; returns what
@@ -114,7 +141,7 @@ def all_gather_appended_tables(offsets: np.ndarray, matches: np.ndarray, device=
     dist.all_gather_into_tensor(allc, cnt, group=group)
     base = int(allc[:rank].sum().item())
     g_off, g_m = all_gather_match_tables(base + np.arange(n, dtype=np.int64), offsets, matches, device=device, group=group,
-                                         as_numpy=as_numpy)
+                                         as_numpy=as_numpy, device_matches=device_matches)
     return g_off, g_m, base
 
 

@@ -1,0 +1,161 @@
+#!/usr/bin/env python3
+"""Reference pin kit: run the REAL pycolmap (0.6.x on COLMAP 3.9.1) on this repo's seeded scenes and store what it
+returns, so that the oracle and the HIP path can be compared with the reference itself instead of with each other.
+
+The reference holds no golden vectors for the matching / verification path and cannot be built in the development
+container, so the parity of this repo is "unpinned": bit-exact to oracle/tvg_oracle.cc, which is a
+restatement.  This script is the route to a real pin.  On any machine with pycolmap installed:
+
+    pip install pycolmap==0.6.1            # wheels bundle COLMAP 3.9.1
+    python tests/golden/make_reference_golden.py          # -> tests/golden/reference_v1.npz
+    python -m pytest tests/test_reference_golden.py -q    # CPU: the oracle against the file;  -m gpu: the HIP path
+
+It needs numpy, the module under test and pycolmap_amd/synth.py (pure numpy, loaded by path through scenes.py) - nothing
+of this repo has to be built.  `--module pycolmap_amd` runs the same calls against this repo's API-compatible module
+(a dry run that proves the script and the consuming tests execute; its output is NOT a reference and is never committed
+as reference_v1.npz).
+
+What is recorded per scene (floating-point results as raw uint64 bit patterns):
+  * fundamental_matrix_estimation, homography_matrix_estimation on the matched points
+    (/root/reference/pycolmap/estimators/fundamental_matrix.h:17-39, homography_matrix.h:16-37: SetPRNGSeed(0), one
+    LO-RANSAC), essential_matrix_estimation (essential_matrix.h:19-83) - with TwoViewGeometryOptions().ransac's values
+    and with pycolmap's own RANSACOptions() defaults;
+  * estimate_two_view_geometry and estimate_calibrated_two_view_geometry (two_view_geometry.h:95-151) with the scene's
+    options.  These bindings do NOT reseed COLMAP's thread-local generator, so each call is preceded by a
+    fundamental_matrix_estimation on a single point: SetPRNGSeed(0) runs, LORANSAC::Estimate returns before drawing;
+  * squared_sampson_error (two_view_geometry.h:161-175) of the matched points under the estimated F.
+"""
+import argparse
+import importlib
+import sys
+from pathlib import Path
+
+import numpy as np
+
+HERE = Path(__file__).resolve().parent
+sys.path.insert(0, str(HERE))
+import scenes  # noqa: E402
+
+TVG_RANSAC = dict(max_error=4.0, min_inlier_ratio=0.25, confidence=0.999, dyn_num_trials_multiplier=3.0,
+                  min_num_trials=100, max_num_trials=10000)      # TwoViewGeometryOptions().ransac (C++ defaults)
+PY_RANSAC = dict(max_error=4.0, min_inlier_ratio=0.01, confidence=0.9999, dyn_num_trials_multiplier=3.0,
+                 min_num_trials=1000, max_num_trials=100000)     # pycolmap.RANSACOptions() (optim/bindings.h:10-18)
+TVG_OPTION_KEYS = ("min_num_inliers", "min_E_F_inlier_ratio", "max_H_inlier_ratio", "watermark_min_inlier_ratio",
+                   "watermark_border_size", "detect_watermark", "multiple_ignore_watermark", "force_H_use",
+                   "compute_relative_pose", "multiple_models")
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).reshape(-1).view(np.uint64).copy()
+
+
+def make_camera(pc, cam, width, height, prior):
+    model, params = cam
+    c = pc.Camera(model=model, width=int(width), height=int(height), params=[float(x) for x in params])
+    c.has_prior_focal_length = bool(prior)
+    return c
+
+
+def ransac_options(pc, kw):
+    o = pc.RANSACOptions()
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
+def tvg_options(pc, scene_opts, **extra):
+    o = pc.TwoViewGeometryOptions()
+    for k, v in TVG_RANSAC.items():
+        setattr(o.ransac, k, v)
+    for k, v in {**scene_opts, **extra}.items():
+        if k in scenes.RANSAC_OPTION_KEYS:
+            setattr(o.ransac, k, type(getattr(o.ransac, k))(v))
+        else:
+            setattr(o, k, type(getattr(o, k))(v))
+    return o
+
+
+def reseed(pc):
+    """SetPRNGSeed(0) without consuming a draw: one correspondence is fewer than any minimal sample."""
+    assert pc.fundamental_matrix_estimation(np.zeros((1, 2)), np.ones((1, 2))) is None
+
+
+def record_ransac(out, tag, res, key, n):
+    out[f"{tag}_success"] = np.int64(res is not None)
+    out[f"{tag}_model"] = bits(res[key]) if res is not None else np.zeros(9, np.uint64)
+    out[f"{tag}_num_inliers"] = np.int64(res["num_inliers"] if res is not None else 0)
+    out[f"{tag}_mask"] = np.asarray(res["inliers"], dtype=bool) if res is not None else np.zeros(n, bool)
+
+
+def record_tvg(out, tag, g):
+    out[f"{tag}_config"] = np.int64(int(g.config))
+    for k in "EFH":
+        out[f"{tag}_{k}"] = bits(getattr(g, k))
+    out[f"{tag}_inlier_matches"] = np.ascontiguousarray(g.inlier_matches, dtype=np.uint32).reshape(-1, 2)
+    out[f"{tag}_tri_angle"] = bits([g.tri_angle])
+    out[f"{tag}_quat_xyzw"] = bits(g.cam2_from_cam1.rotation.quat)
+    out[f"{tag}_tvec"] = bits(g.cam2_from_cam1.translation)
+
+
+def record_all(pc, module_name, limit=0, verbose=True):
+    """Every call of the kit against module `pc`; returns the dict that main() stores."""
+    is_reference = module_name == "pycolmap" and not hasattr(pc, "has_hip")
+    out = {"module": np.array(module_name), "is_reference": np.int64(is_reference),
+           "module_version": np.array(str(getattr(pc, "__version__", "?"))),
+           "colmap_version": np.array(str(getattr(pc, "COLMAP_version", "?")))}
+    names = []
+    for n, sc in enumerate(scenes.all_scenes()):
+        if limit and n >= limit:
+            break
+        name = sc["name"]
+        names.append(name)
+        m = sc["matches"]
+        p1, p2 = sc["pts1"][m[:, 0]], sc["pts2"][m[:, 1]]
+        cam1 = make_camera(pc, sc["cam1"], sc["width"], sc["height"], sc["prior"])
+        cam2 = make_camera(pc, sc["cam2"], sc["width"], sc["height"], sc["prior"])
+        for oname, okw in (("tvgopts", TVG_RANSAC), ("pyopts", PY_RANSAC)):
+            if oname == "pyopts" and not name.startswith("golden"):
+                continue                      # the 100,000-trial defaults on the golden scenes only (minutes on a CPU)
+            ro = ransac_options(pc, okw)
+            record_ransac(out, f"{name}_F_{oname}", pc.fundamental_matrix_estimation(p1, p2, ro), "F", len(m))
+            record_ransac(out, f"{name}_H_{oname}", pc.homography_matrix_estimation(p1, p2, ro), "H", len(m))
+            if len(m):
+                rE = pc.essential_matrix_estimation(p1, p2, cam1, cam2, ro)
+                record_ransac(out, f"{name}_E_{oname}", rE, "E", len(m))
+                if rE is not None:
+                    out[f"{name}_E_{oname}_quat_xyzw"] = bits(rE["cam2_from_cam1"].rotation.quat)
+                    out[f"{name}_E_{oname}_tvec"] = bits(rE["cam2_from_cam1"].translation)
+        for pose in (0, 1):
+            reseed(pc)
+            g = pc.estimate_two_view_geometry(cam1, sc["pts1"], cam2, sc["pts2"], m,
+                                              tvg_options(pc, sc["opts"], compute_relative_pose=bool(pose)))
+            record_tvg(out, f"{name}_tvg_p{pose}", g)
+        reseed(pc)
+        gc = pc.estimate_calibrated_two_view_geometry(cam1, sc["pts1"], cam2, sc["pts2"], m, tvg_options(pc, sc["opts"]))
+        record_tvg(out, f"{name}_ctvg", gc)
+        Fm = np.frombuffer(out[f"{name}_F_tvgopts_model"].tobytes(), dtype=np.float64).reshape(3, 3)
+        out[f"{name}_sampson"] = bits(pc.squared_sampson_error(p1, p2, Fm)) if len(m) else np.zeros(0, np.uint64)
+        if verbose:
+            print(name, len(m), "matches: tvg config", int(g.config), "inlier matches", len(g.inlier_matches), flush=True)
+    out["names"] = np.array(names)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--module", default="pycolmap", help="module to record (the real pycolmap; pycolmap_amd for a dry run)")
+    ap.add_argument("--out", default=str(HERE / "reference_v1.npz"))
+    ap.add_argument("--limit", type=int, default=0, help="only the first N scenes (dry runs)")
+    args = ap.parse_args()
+    if args.module == "pycolmap_amd":
+        sys.path.insert(0, str(scenes.ROOT))
+    pc = importlib.import_module(args.module)
+    out = record_all(pc, args.module, args.limit)
+    if not int(out["is_reference"]) and Path(args.out).name == "reference_v1.npz":
+        raise SystemExit("refusing to write reference_v1.npz from a module that is not the real pycolmap: pass --out")
+    np.savez_compressed(args.out, **out)
+    print("wrote", args.out, "from", args.module, "(reference)" if int(out["is_reference"]) else "(NOT a reference: dry run)")
+
+
+if __name__ == "__main__":
+    main()

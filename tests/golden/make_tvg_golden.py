@@ -22,43 +22,14 @@ sys.path.insert(0, str(ROOT / "tests"))
 import oracle_lib as o  # noqa: E402
 from pycolmap_amd import synth  # noqa: E402
 
-# indices 0 / 1: the two pinhole cameras of the v1 fixture; 2..: one camera per distortion model
-# (synth.EXAMPLE_CAMERAS); a case using one of those sees its scene through that camera
-# (synth.recamera_scene) so that the calibrated path has real geometry to find
-CAMS = [("PINHOLE", (1200.0, 1200.0, 800.0, 600.0)), ("SIMPLE_PINHOLE", (1150.0, 805.0, 598.0))] + \
-       [(m, synth.EXAMPLE_CAMERAS[m]) for m in ("SIMPLE_RADIAL", "RADIAL", "OPENCV", "OPENCV_FISHEYE", "FULL_OPENCV",
-                                                "FOV", "SIMPLE_RADIAL_FISHEYE", "RADIAL_FISHEYE",
-                                                "THIN_PRISM_FISHEYE")]
-# (scene kwargs, prior focal length, camera index image 1 / image 2, option overrides)
-CASES = [
-    (dict(num_inliers=300, num_outliers=100), False, 0, 0, {}),
-    (dict(num_inliers=300, num_outliers=100), True, 0, 0, {}),
-    (dict(num_inliers=200, num_outliers=150, planar=True), False, 0, 0, {}),
-    (dict(num_inliers=200, num_outliers=150, planar=True), True, 0, 1, {}),
-    (dict(num_inliers=250, num_outliers=50, pure_rotation=True, noise=0.05), True, 0, 0, {}),
-    (dict(num_inliers=60, num_outliers=40, noise=1.0), True, 1, 0, {}),
-    (dict(num_inliers=0, num_outliers=40), False, 0, 0, {}),
-    (dict(num_inliers=12, num_outliers=0), True, 0, 0, {}),                      # fewer than min_num_inliers
-    (dict(num_inliers=150, num_outliers=60), True, 0, 0, dict(force_H_use=1)),
-    (dict(num_inliers=150, num_outliers=60), True, 1, 1, dict(max_error=2.0, confidence=0.99, min_num_trials=50,
-                                                             max_num_trials=2000, min_inlier_ratio=0.1)),
-    (dict(num_inliers=180, num_outliers=90, planar=True), False, 0, 0, dict(detect_watermark=0, max_H_inlier_ratio=0.5)),
-    (dict(num_inliers=400, num_outliers=300, noise=0.3), True, 0, 0, dict(min_E_F_inlier_ratio=0.8)),
-    # cameras with distortion parameters (Camera::CamFromImg = IterativeUndistortion / closed forms)
-    (dict(num_inliers=260, num_outliers=90), True, 2, 2, {}),                    # SIMPLE_RADIAL: extract_features' default
-    (dict(num_inliers=220, num_outliers=120), True, 3, 4, {}),                   # RADIAL x OPENCV
-    (dict(num_inliers=200, num_outliers=80, planar=True), True, 4, 0, {}),       # OPENCV x PINHOLE, planar
-    (dict(num_inliers=240, num_outliers=100), True, 5, 6, {}),                   # OPENCV_FISHEYE x FULL_OPENCV
-    (dict(num_inliers=240, num_outliers=100), True, 7, 8, {}),                   # FOV x SIMPLE_RADIAL_FISHEYE
-    (dict(num_inliers=240, num_outliers=100), True, 9, 10, {}),                  # RADIAL_FISHEYE x THIN_PRISM_FISHEYE
-    (dict(num_inliers=150, num_outliers=60), False, 2, 4, {}),                   # no prior focal length: F + H only
-    (dict(num_inliers=250, num_outliers=50, pure_rotation=True, noise=0.05), True, 2, 3, {}),
-]
+sys.path.insert(0, str(Path(__file__).resolve().parent))
+from scenes import CAMS, CASES, GOLDEN_SEED  # noqa: E402  (shared with make_reference_golden.py)
+
 FIELDS = ("E", "F", "H", "qvec", "tvec", "R")
 
 
 def main():
-    rng = np.random.default_rng(20260924)
+    rng = np.random.default_rng(GOLDEN_SEED)
     out = {"num_cases": np.int64(len(CASES))}
     for k, (kw, prior, c1, c2, okw) in enumerate(CASES):
         sc = synth.two_view_scene(rng, **kw)

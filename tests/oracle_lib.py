@@ -28,6 +28,11 @@ def load() -> C.CDLL:
                                            C.c_void_p, C.c_size_t, C.c_double, C.c_double, C.c_int,
                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         lib.oracle_match_pairs.restype = C.c_int
+        lib.oracle_match_pairs_vnni.argtypes = lib.oracle_match_pairs.argtypes
+        lib.oracle_match_pairs_vnni.restype = C.c_int
+        lib.oracle_match_vnni.argtypes = lib.oracle_match.argtypes
+        lib.oracle_match_vnni.restype = C.c_int
+        lib.oracle_vnni_available.restype = C.c_int
         lib.oracle_acos_lut.argtypes = [C.c_void_p]
         lib.oracle_acos_lut.restype = None
         _lib = lib
@@ -56,8 +61,23 @@ def distance_matrix(d1, d2):
     return out
 
 
-def match_pairs(images, slot1, slot2, max_ratio=0.8, max_distance=0.7, cross_check=True, threads=8):
-    """Batched oracle over a list of uint8 [n_i,128] images. Returns (offsets, matches)."""
+def vnni_available() -> bool:
+    """The AVX-512 VNNI variant of the matcher (oracle/match_vnni.c) can run on this host."""
+    return bool(load().oracle_vnni_available())
+
+
+def match_vnni(d1: np.ndarray, d2: np.ndarray, max_ratio=0.8, max_distance=0.7, cross_check=True):
+    d1 = np.ascontiguousarray(d1, dtype=np.uint8).reshape(-1, 128)
+    d2 = np.ascontiguousarray(d2, dtype=np.uint8).reshape(-1, 128)
+    out = np.zeros((max(1, len(d1)), 2), dtype=np.uint32)
+    n = load().oracle_match_vnni(_p(d1), len(d1), _p(d2), len(d2), max_ratio, max_distance, int(cross_check), _p(out))
+    assert n >= 0
+    return out[:n].copy()
+
+
+def match_pairs(images, slot1, slot2, max_ratio=0.8, max_distance=0.7, cross_check=True, threads=8, variant="literal"):
+    """Batched oracle over a list of uint8 [n_i,128] images. Returns (offsets, matches).
+    variant "literal": oracle/match_oracle.c (the restatement); "vnni": oracle/match_vnni.c (same results, AVX-512 VNNI)."""
     rows = np.array([len(im) for im in images], dtype=np.uint32)
     row_off = np.zeros(len(images), dtype=np.uint64)
     row_off[1:] = np.cumsum(rows[:-1], dtype=np.uint64)
@@ -71,9 +91,10 @@ def match_pairs(images, slot1, slot2, max_ratio=0.8, max_distance=0.7, cross_che
     out_off[1:] = np.cumsum(cap)
     counts = np.zeros(len(s1), dtype=np.uint32)
     out = np.zeros((max(1, int(out_off[-1])), 2), dtype=np.uint32)
-    rc = load().oracle_match_pairs(_p(arena), _p(row_off), _p(rows), _p(s1), _p(s2), len(s1),
-                                   max_ratio, max_distance, int(cross_check), _p(out_off),
-                                   _p(counts), _p(out), threads)
+    fn = load().oracle_match_pairs if variant == "literal" else load().oracle_match_pairs_vnni
+    rc = fn(_p(arena), _p(row_off), _p(rows), _p(s1), _p(s2), len(s1),
+            max_ratio, max_distance, int(cross_check), _p(out_off),
+            _p(counts), _p(out), threads)
     assert rc == 0
     offsets = np.zeros(len(s1) + 1, dtype=np.uint64)
     offsets[1:] = np.cumsum(counts)

@@ -193,6 +193,10 @@ def test_8192_rows(amc_ctx):
     off_d, m_d, _ = amc_ctx.match_pairs([0], [1], kernel="dot4")
     np.testing.assert_array_equal(m, m_d)
     assert len(m) > 500
+    # BASELINE configs[3]'s image size against the oracle itself (the vectorised variant where the host has AVX-512
+    # VNNI - checked against the literal one in tests/test_oracle_match.py - else the literal one: ~10 s)
+    want = oracle_lib.match_vnni(imgs[0], imgs[1]) if oracle_lib.vnni_available() else oracle_lib.match(imgs[0], imgs[1])
+    np.testing.assert_array_equal(m, want)
 
 
 def test_more_than_8192_rows_matches_oracle(amc_ctx):
@@ -272,3 +276,20 @@ def test_dense_overlap_and_both_resolve_kernels(amc_ctx, monkeypatch, cross_chec
     off2, m2, _ = amc_ctx.match_pairs(s1, s2, *opts, kernel="mfma")
     np.testing.assert_array_equal(off2, off)
     np.testing.assert_array_equal(m2, m)
+
+
+def test_trim_releases_scratch_and_the_context_keeps_working(amc_ctx):
+    """amc_ctx_trim: per-call scratch, staging and idle result buffers go, uploaded images stay - the next call
+    re-allocates what it needs and returns the same result."""
+    rng = np.random.default_rng(23)
+    imgs = synth.scene_images(rng, 4, 500, num_landmarks=700, visible_frac=0.5)
+    upload(amc_ctx, imgs)
+    s1, s2 = synth.exhaustive_pairs(len(imgs))
+    off, m, _ = amc_ctx.match_pairs(s1, s2)
+    amc_ctx.trim()
+    amc_ctx.trim()
+    off2, m2, _ = amc_ctx.match_pairs(s1, s2)
+    np.testing.assert_array_equal(off, off2)
+    np.testing.assert_array_equal(m, m2)
+    woff, wm = oracle_lib.match_pairs(imgs, s1, s2)
+    np.testing.assert_array_equal(m2, wm)

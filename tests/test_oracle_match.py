@@ -285,3 +285,36 @@ def test_guided_matching_limits():
     kp2_near = (kp1 + 0.25).astype(np.float32)
     got = oracle_lib.match_guided(d1, kp1, d1, kp2_near, 6, F, np.eye(3), 1.0, max_ratio=1.0, max_distance=10.0)
     assert len(got) > 0 and np.all(got[:, 0] == got[:, 1])
+
+
+# ---- the AVX-512 VNNI variant (oracle/match_vnni.c): bench.py's "optimised" CPU baseline ---------------------
+def _vnni_or_skip():
+    if not oracle_lib.vnni_available():
+        pytest.skip("host without AVX-512 VNNI")
+
+
+def test_vnni_variant_equals_the_literal_oracle():
+    """Same matches as match_oracle.c on scene-like, ragged, tie-heavy, all-zero, saturated and duplicated inputs, with
+    and without the cross check, at thresholds other than the defaults tooracle_lib."""
+    _vnni_or_skip()
+    rng = np.random.default_rng(42)
+    imgs = synth.scene_images(rng, 5, 600, num_landmarks=800, visible_frac=0.5)
+    imgs += [np.zeros((37, 128), np.uint8), rng.integers(0, 3, (129, 128)).astype(np.uint8), np.full((5, 128), 255, np.uint8),
+             np.repeat(imgs[0][:40], 3, axis=0), imgs[1][:1], imgs[2][:17], rng.integers(0, 256, (33, 128)).astype(np.uint8)]
+    for a in range(len(imgs)):
+        for b in range(len(imgs)):
+            for kw in (dict(), dict(cross_check=False), dict(max_ratio=0.95, max_distance=1.2)):
+                np.testing.assert_array_equal(oracle_lib.match_vnni(imgs[a], imgs[b], **kw), oracle_lib.match(imgs[a], imgs[b], **kw),
+                                              err_msg=f"{a} {b} {kw}")
+    assert len(oracle_lib.match_vnni(np.zeros((0, 128), np.uint8), imgs[0])) == 0
+
+
+def test_vnni_batched_entry_point_equals_the_literal_one():
+    _vnni_or_skip()
+    rng = np.random.default_rng(43)
+    imgs = synth.scene_images(rng, 6, 300, num_landmarks=500, visible_frac=0.5) + [np.zeros((0, 128), np.uint8)]
+    s1, s2 = np.array([0, 1, 2, 3, 6, 5, 0], np.uint32), np.array([1, 2, 3, 4, 0, 6, 5], np.uint32)
+    off, m = oracle_lib.match_pairs(imgs, s1, s2, threads=3)
+    voff, vm = oracle_lib.match_pairs(imgs, s1, s2, threads=3, variant="vnni")
+    np.testing.assert_array_equal(off, voff)
+    np.testing.assert_array_equal(m, vm)

@@ -1,0 +1,109 @@
+"""Consumes the reference pin (tests/golden/reference_v1.npz, written by tests/golden/make_reference_golden.py from the
+REAL pycolmap 0.6.x / COLMAP 3.9.1 - see that script) when it is present, and skips when it is not: the file cannot be
+produced in the development container (no pycolmap, no network).
+
+Both tests run the kit's own calls - the CPU oracle behind tests/oracle_pycolmap.py, the HIP path behind pycolmap_amd - and
+compare call by call with the recorded reference, reporting identical-success / identical-config / identical-mask
+fractions and Hamming distances in the style of tests/ref2/deviation_budget.json.  What must hold against a real
+reference: squared_sampson_error bit for bit (the operation order is specified), configurations and masks within the
+documented deviation budget (D1 eigen-solver / D2 root finder - a diverging RANSAC path changes a
+mask, never by much).  Against a dry-run file (recorded from this repo's own module: AMC_REFERENCE_GOLDEN=<file>)
+everything must be identical - that is how the plumbing of kit + tests is proven here.
+"""
+import json
+import os
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT / "tests" / "golden"))
+PATH = Path(os.environ.get("AMC_REFERENCE_GOLDEN", ROOT / "tests" / "golden" / "reference_v1.npz"))
+
+pytestmark = pytest.mark.skipif(not PATH.exists(), reason=f"no reference pin at {PATH} (see tests/golden/make_reference_golden.py)")
+
+
+def compare(ref, cand):
+    """Call-by-call comparison of two record dicts of make_reference_golden.record_all."""
+    names = [str(n) for n in ref["names"]]
+    st = {"scenes": len(names), "ransac_calls": 0, "ransac_same_success": 0, "ransac_same_mask": 0, "ransac_same_model_bits": 0,
+          "ransac_hamming": [], "tvg_calls": 0, "tvg_same_config": 0, "tvg_same_inlier_matches": 0, "tvg_same_models_bits": 0,
+          "tvg_same_pose_bits": 0, "tvg_inlier_symdiff": [], "sampson_points": 0, "sampson_bit_exact_points": 0,
+          "differing": []}
+    for name in names:
+        for key in [k for k in ref.files if k.startswith(name + "_") and k.endswith("_success")]:
+            tag = key[:-len("_success")]
+            st["ransac_calls"] += 1
+            same_s = int(ref[key]) == int(cand[key])
+            st["ransac_same_success"] += same_s
+            ham = int(np.count_nonzero(ref[tag + "_mask"] != cand[tag + "_mask"]))
+            st["ransac_same_mask"] += ham == 0
+            st["ransac_hamming"].append(ham)
+            st["ransac_same_model_bits"] += bool(np.array_equal(ref[tag + "_model"], cand[tag + "_model"]))
+            if not same_s or ham:
+                st["differing"].append(f"{tag}: success {int(ref[key])}/{int(cand[key])}, Hamming {ham}")
+        for key in [k for k in ref.files if k.startswith(name + "_") and k.endswith("_config")]:
+            tag = key[:-len("_config")]
+            st["tvg_calls"] += 1
+            same_c = int(ref[key]) == int(cand[key])
+            st["tvg_same_config"] += same_c
+            a = {tuple(r) for r in ref[tag + "_inlier_matches"].tolist()}
+            b = {tuple(r) for r in cand[tag + "_inlier_matches"].tolist()}
+            same_m = np.array_equal(ref[tag + "_inlier_matches"], cand[tag + "_inlier_matches"])
+            st["tvg_same_inlier_matches"] += bool(same_m)
+            st["tvg_inlier_symdiff"].append(len(a ^ b))
+            st["tvg_same_models_bits"] += all(np.array_equal(ref[f"{tag}_{k}"], cand[f"{tag}_{k}"]) for k in "EFH")
+            st["tvg_same_pose_bits"] += all(np.array_equal(ref[f"{tag}_{k}"], cand[f"{tag}_{k}"])
+                                            for k in ("tri_angle", "quat_xyzw", "tvec"))
+            if not same_c or not same_m:
+                st["differing"].append(f"{tag}: config {int(ref[key])}/{int(cand[key])}, inlier matches differ by {len(a ^ b)}")
+        sa, sb = ref[name + "_sampson"], cand[name + "_sampson"]
+        st["sampson_points"] += len(sa)
+        # the residuals are taken under each side's own F: comparable only where the two F agree bit for bit
+        if np.array_equal(ref[name + "_F_tvgopts_model"], cand[name + "_F_tvgopts_model"]):
+            st["sampson_bit_exact_points"] += int(np.count_nonzero(sa == sb))
+        else:
+            st["sampson_points"] -= len(sa)
+    st["ransac_mean_hamming"] = float(np.mean(st["ransac_hamming"])) if st["ransac_hamming"] else 0.0
+    st["ransac_max_hamming"] = int(max(st["ransac_hamming"], default=0))
+    st["tvg_max_inlier_symdiff"] = int(max(st["tvg_inlier_symdiff"], default=0))
+    del st["ransac_hamming"], st["tvg_inlier_symdiff"]
+    return st
+
+
+def check(ref, st, who):
+    print(json.dumps({"against": str(PATH.name), "candidate": who, **{k: v for k, v in st.items() if k != "differing"},
+                      "differing_first_10": st["differing"][:10]}, indent=1))
+    if not int(ref["is_reference"]):
+        # a dry-run file recorded from this repo's own module: the oracle and the HIP path reproduce it exactly
+        assert st["ransac_same_mask"] == st["ransac_calls"] == st["ransac_same_model_bits"], st["differing"][:5]
+        assert st["tvg_same_inlier_matches"] == st["tvg_calls"] == st["tvg_same_models_bits"] == st["tvg_same_pose_bits"]
+        assert st["sampson_bit_exact_points"] == st["sampson_points"]
+        return
+    # a real reference.  Hard: the Sampson residual (specified operation order) wherever both sides evaluated the same F.
+    assert st["sampson_bit_exact_points"] == st["sampson_points"]
+    # Budgeted (tests/ref2/deviation_budget.json measured 93.5 % identical masks between the oracle and an
+    # "upstream-like" restatement; a diverged RANSAC path moves a few matches, never the configuration class en masse)
+    assert st["ransac_same_success"] >= 0.97 * st["ransac_calls"]
+    assert st["tvg_same_config"] >= 0.95 * st["tvg_calls"]
+    assert st["ransac_same_mask"] >= 0.85 * st["ransac_calls"]
+    assert st["tvg_same_inlier_matches"] >= 0.85 * st["tvg_calls"]
+
+
+def test_oracle_against_the_reference_pin():
+    import make_reference_golden as kit
+    import oracle_pycolmap
+    ref = np.load(PATH)
+    cand = kit.record_all(oracle_pycolmap, "oracle_pycolmap", limit=len(ref["names"]), verbose=False)
+    check(ref, compare(ref, cand), "oracle/tvg_oracle.cc (tests/oracle_pycolmap.py)")
+
+
+@pytest.mark.gpu
+def test_hip_path_against_the_reference_pin():
+    import make_reference_golden as kit
+    import pycolmap_amd
+    ref = np.load(PATH)
+    cand = kit.record_all(pycolmap_amd, "pycolmap_amd", limit=len(ref["names"]), verbose=False)
+    check(ref, compare(ref, cand), "pycolmap_amd (HIP path)")

@@ -223,3 +223,54 @@ def test_fp32_homography_prefilter_never_contradicts_the_reference(shim):
         decided += int(dec.sum())
         undecided += int((~dec).sum())
     assert decided > undecided               # (a third of the points sit on the circle by construction)
+
+
+def test_closed_form_h4_on_degenerate_samples_against_the_svd_dlt(shim):
+    """The minimal 4-point homography is a closed form (change of projective basis) where upstream solves the 8 x 9 DLT by
+    SVD (tests/ref2/tvg_ref2.py estimate_h restates that).  On a proper sample the two give the same H up to scale; on a
+    degenerate one - three collinear points - the SVD still returns a (singular) null vector while the closed form
+    divides by zero.  What has to hold for the RANSAC built on it: the degenerate model must never out-score anything,
+    i.e. it must not count inliers beyond what the SVD model counts, and near-degenerate samples must give the same
+    inlier DECISIONS as the SVD model on points away from the threshold."""
+    from ref2 import tvg_ref2 as r2
+    rng = np.random.default_rng(5)
+    sc, p1, p2 = scene_points(3, num_inliers=200, num_outliers=60, planar=True, noise=0.3)
+    max_res = 16.0
+
+    def decisions(H):
+        out = np.zeros(len(p1))
+        shim.shim_residuals(1, _p(np.ascontiguousarray(H.reshape(9))), _p(p1), _p(p2), len(p1), _p(out))
+        return out
+
+    checked_near = 0
+    for trial in range(60):
+        a = rng.uniform(100, 1500, (4, 2))
+        b = rng.uniform(100, 1100, (4, 2))
+        eps = 0.0 if trial < 20 else 10.0 ** rng.uniform(-9, -2)        # exactly / nearly collinear in image 1
+        t = rng.uniform(0.2, 0.8)
+        a[2] = a[0] + t * (a[1] - a[0]) + eps * np.array([-(a[1] - a[0])[1], (a[1] - a[0])[0]])
+        if trial % 3 == 0:
+            a, b = b.copy(), a.copy()                                   # ... or in image 2
+        a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
+        got = np.zeros((1, 9))
+        shim.shim_estimate_h4(_p(a), _p(b), _p(got))
+        # bit-exact with the oracle's closed form whatever the sample (NaNs compared as NaNs)
+        want = o.estimate_models("H", a, b).reshape(1, 9)
+        np.testing.assert_array_equal(np.isnan(got), np.isnan(want))
+        np.testing.assert_array_equal(bits(np.nan_to_num(got)), bits(np.nan_to_num(want)))
+        r_cf = decisions(got)
+        H_svd = r2.estimate_h(a, b)[0]
+        r_svd = decisions(H_svd)
+        in_cf, in_svd = r_cf <= max_res, r_svd <= max_res                # NaN / inf residuals compare false: outliers
+        if eps == 0.0:
+            # exactly degenerate: the closed form's model is non-finite or wild; it must not collect support the SVD
+            # model does not have (so it can never become a best model the reference would not also have found)
+            assert in_cf.sum() <= max(in_svd.sum(), 4), (trial, int(in_cf.sum()), int(in_svd.sum()))
+        else:
+            # nearly degenerate: four points in general position determine H exactly; both solvers see the same model up
+            # to conditioning, so the decisions agree wherever the SVD residual is not within 5 % of the threshold
+            clear = np.abs(r_svd - max_res) > 0.05 * max_res
+            if np.all(np.isfinite(got)) and np.all(np.isfinite(H_svd)) and eps > 1e-6:
+                np.testing.assert_array_equal(in_cf[clear], in_svd[clear], err_msg=f"trial {trial} eps {eps}")
+                checked_near += 1
+    assert checked_near >= 10
