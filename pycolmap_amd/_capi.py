@@ -287,7 +287,7 @@ class Context:
             return torch.zeros((0, 2), dtype=torch.int32, device=torch.device("cuda", device_index))
 
         class _View:   # numpy-style CUDA array interface over the raw pointer (uint32 bit patterns viewed as int32)
-            __cuda_array_interface__ = {"shape": (n, 2), "typestr": "<i4", "data": (ptr, True), "version": 3, "strides": None}
+            __cuda_array_interface__ = {"shape": (n, 2), "typestr": "<i4", "data": (ptr, False), "version": 3, "strides": None}
         return torch.as_tensor(_View(), device=torch.device("cuda", device_index))
 
     def trim(self) -> None:

@@ -1768,6 +1768,7 @@ static int verify_impl(amc_ctx* c, int mode, const uint32_t* slot1, const uint32
     }
     if (std::getenv("AMC_TVG_PROFILE")) {
         tvg_diag_report();
+        tvg_diag_report_e();
         unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         for (size_t p = 0; p < npairs; ++p)
             for (int i = 0; i < 8; ++i) acc[i] += h_out[p].prof[i];

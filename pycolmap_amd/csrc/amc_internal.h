@@ -278,7 +278,8 @@ struct alignas(64) TvgEState {
     int32_t cnt, success, num_trials;
     uint32_t soff;
 };
-void tvg_diag_report();  // (diagnostic builds of earlier rounds; kept for the profile printout's call site)
+void tvg_diag_report();    // diagnostic builds (-DAMC_TVG_LODIAG): stage cycles of the local estimators, on stderr
+void tvg_diag_report_e();  // ... of the essential-matrix kernel
 size_t tvg_ws_doubles_host(uint32_t mcap);
 size_t tvg_ws_mask_bytes_host(uint32_t mcap);
 // Target occupancy (waves per SIMD) of the two verification kernels: sets their VGPR budgets and LDS shares.

@@ -899,6 +899,20 @@ __device__ __noinline__ int e5_models_wave(const double* nsp, const E5Polys& P, 
     return nm;
 }
 
+// Diagnostic build (-DAMC_TVG_LODIAG, tools/variant_build_tvg.sh): shader-clock cycles of the stages of the local
+// estimators, summed over all waves (lane 0 adds); printed by the host with AMC_TVG_PROFILE=1.
+#if defined(AMC_TVG_LODIAG)
+__device__ unsigned long long g_lo_diag[16];
+#define LODIAG_T0() unsigned long long lodiag_t_ = __builtin_readcyclecounter()
+#define LODIAG_LAP(slot) do { const unsigned long long n_ = __builtin_readcyclecounter(); \
+                              if (lane == 0) atomicAdd(&g_lo_diag[slot], n_ - lodiag_t_); lodiag_t_ = n_; } while (0)
+#define LODIAG_COUNT(slot) do { if (lane == 0) atomicAdd(&g_lo_diag[slot], 1ull); } while (0)
+#else
+#define LODIAG_T0() do {} while (0)
+#define LODIAG_LAP(slot) do {} while (0)
+#define LODIAG_COUNT(slot) do {} while (0)
+#endif
+
 // local estimator on the K listed inlier correspondences -> models (uniform), count
 template <int LOCAL>
 __device__ __noinline__ int local_estimate(const LoCtx w, const Pts P, int K, double* models) {
@@ -923,16 +937,24 @@ __device__ __noinline__ int local_estimate(const LoCtx w, const Pts P, int K, do
             for (int i = 0; i < 5; ++i) load_pt(P, w.inl[i], a[i], b[i], c[i], d[i]);
             return estimate_e5_minimal(a, b, c, d, models);
         }
+        LODIAG_T0();
+        LODIAG_COUNT(0);
         ata_impl<0, false>(w, P, K, nullptr, nullptr);
+        LODIAG_LAP(1);
         jacobi_eigen_wave(w.jacA, w.jacV, lane);
+        LODIAG_LAP(2);
         double nsp[4 * 9];
         e5_nullspace_from_eig(w.jacA, w.jacV, nsp);
         wave_lds_sync();  // jacA doubles as the root finder's scratch from here on
         E5Polys polys;
         e5_build_wave(nsp, polys, w.jacA, lane);
+        LODIAG_LAP(3);
         double roots[10];
         const int nr = real_roots10_wave(polys.det, roots, w.jacA, lane);
-        return e5_models_wave(nsp, polys, roots, nr, models, lane);
+        LODIAG_LAP(4);
+        const int nm = e5_models_wave(nsp, polys, roots, nr, models, lane);
+        LODIAG_LAP(5);
+        return nm;
     }
     if (LOCAL == K_H && K == 4) {
         double a[4], b[4], c[4], d[4];
@@ -943,18 +965,26 @@ __device__ __noinline__ int local_estimate(const LoCtx w, const Pts P, int K, do
     double T1[9], T2[9];
     center_T(w, P, 0, K, T1);
     center_T(w, P, 1, K, T2);
+    LODIAG_T0();
+    LODIAG_COUNT(LOCAL == K_F8 ? 8 : 12);
     if (LOCAL == K_F8) {
         ata_impl<0, true>(w, P, K, T1, T2);
+        LODIAG_LAP(9);
         jacobi_eigen_wave(w.jacA, w.jacV, lane);
+        LODIAG_LAP(10);
         double f[9];
         smallest_eigvec9_wave(w.jacA, w.jacV, f);
         f8_from_vec(f, T1, T2, models);
+        LODIAG_LAP(11);
     } else {
         ata_impl<1, true>(w, P, K, T1, T2);
+        LODIAG_LAP(13);
         jacobi_eigen_wave(w.jacA, w.jacV, lane);
+        LODIAG_LAP(14);
         double h[9];
         smallest_eigvec9_wave(w.jacA, w.jacV, h);
         h_denormalize(h, T1, T2, models);
+        LODIAG_LAP(15);
     }
     return 1;
 }

@@ -158,6 +158,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(kTvgEWavesP
     }
 }
 
+
+#if defined(AMC_TVG_LODIAG)
+void tvg_diag_report_e() {
+    unsigned long long h[16];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_lo_diag), sizeof h) != hipSuccess) return;
+    std::fprintf(stderr, "[amc tvg lodiag tvg_diag_report_e] local 5-point solves %llu: cycles per solve ata %.0f jacobi %.0f build %.0f roots %.0f models %.0f | "
+                 "8-point solves %llu: ata %.0f jacobi %.0f finish %.0f | DLT solves %llu: ata %.0f jacobi %.0f finish %.0f\n",
+                 h[0], (double)h[1] / (h[0] ? h[0] : 1), (double)h[2] / (h[0] ? h[0] : 1), (double)h[3] / (h[0] ? h[0] : 1),
+                 (double)h[4] / (h[0] ? h[0] : 1), (double)h[5] / (h[0] ? h[0] : 1), h[8], (double)h[9] / (h[8] ? h[8] : 1),
+                 (double)h[10] / (h[8] ? h[8] : 1), (double)h[11] / (h[8] ? h[8] : 1), h[12], (double)h[13] / (h[12] ? h[12] : 1),
+                 (double)h[14] / (h[12] ? h[12] : 1), (double)h[15] / (h[12] ? h[12] : 1));
+    unsigned long long z[16] = {};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lo_diag), z, sizeof z);
+}
+#else
+void tvg_diag_report_e() {}
+#endif
+
 hipError_t launch_tvg_e(const TvgImage* imgs, const TvgPair* pairs, uint32_t npairs, const uint32_t* matches,
                         const uint32_t* trial_tabs, const TvgParams& P, double* ws, uint32_t mcap, uint32_t num_waves,
                         int waves_per_block, uint32_t* queue_head, TvgEState* estate, uint8_t* emask, TvgOut* out,

@@ -276,7 +276,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(kTvgFhWaves
 size_t tvg_ws_doubles_host(uint32_t mcap) { return tvg_ws_doubles(mcap); }
 size_t tvg_ws_mask_bytes_host(uint32_t mcap) { return tvg_ws_bytes_extra(mcap); }
 size_t tvg_lds_bytes(uint32_t mcap, int waves) { return (size_t)waves * tvg_lds_per_wave(mcap); }
+
+#if defined(AMC_TVG_LODIAG)
+void tvg_diag_report() {
+    unsigned long long h[16];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_lo_diag), sizeof h) != hipSuccess) return;
+    std::fprintf(stderr, "[amc tvg lodiag tvg_diag_report] local 5-point solves %llu: cycles per solve ata %.0f jacobi %.0f build %.0f roots %.0f models %.0f | "
+                 "8-point solves %llu: ata %.0f jacobi %.0f finish %.0f | DLT solves %llu: ata %.0f jacobi %.0f finish %.0f\n",
+                 h[0], (double)h[1] / (h[0] ? h[0] : 1), (double)h[2] / (h[0] ? h[0] : 1), (double)h[3] / (h[0] ? h[0] : 1),
+                 (double)h[4] / (h[0] ? h[0] : 1), (double)h[5] / (h[0] ? h[0] : 1), h[8], (double)h[9] / (h[8] ? h[8] : 1),
+                 (double)h[10] / (h[8] ? h[8] : 1), (double)h[11] / (h[8] ? h[8] : 1), h[12], (double)h[13] / (h[12] ? h[12] : 1),
+                 (double)h[14] / (h[12] ? h[12] : 1), (double)h[15] / (h[12] ? h[12] : 1));
+    unsigned long long z[16] = {};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lo_diag), z, sizeof z);
+}
+#else
 void tvg_diag_report() {}
+#endif
 
 // ComputeSquaredSampsonError over n correspondences (points n x 2, E row-major)
 __global__ __launch_bounds__(256) void sampson_kernel(const double* __restrict__ p1, const double* __restrict__ p2,

@@ -104,7 +104,12 @@ def estimate_two_view_geometry(camera1, points1, camera2, points2, matches=None,
 
 
 def estimate_calibrated_two_view_geometry(camera1, points1, camera2, points2, matches=None, options=None):
-    return _tvg(camera1, points1, camera2, points2, matches, options, True)
+    # EstimateCalibratedTwoViewGeometry is entered directly: the dispatch of EstimateTwoViewGeometry (multiple_models,
+    # force_H_use, the prior-focal-length test) is not in its way
+    import copy
+    opts = copy.deepcopy(options or TwoViewGeometryOptions())
+    opts.force_H_use, opts.multiple_models = False, False
+    return _tvg(camera1, points1, camera2, points2, matches, opts, True)
 
 
 def squared_sampson_error(points2D1, points2D2, E):
