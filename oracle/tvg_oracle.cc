@@ -31,8 +31,10 @@
  *   D1  Null spaces come from Gauss-Jordan elimination with full pivoting (minimal solvers) or
  *       the smallest eigenvector of A^T A by round-robin Jacobi (least-squares solvers) instead of
  *       Eigen::JacobiSVD; rank-2 enforcement projects out the smallest right singular vector.
- *   D2  Polynomial roots by bracketing + bisection on the real line instead of companion-matrix
- *       eigenvalues; models are tried in ascending root order.
+ *   D2  Polynomial roots on the real line instead of companion-matrix eigenvalues: every monotone stretch (between
+ *       the roots of the derivative, found the same way one degree down) with a sign change is bisected to 2^-26 of
+ *       its position and finished with three bracketed Newton steps (round 3; rounds 1-2 bisected to the last ulp);
+ *       models are tried in ascending root order.
  *   D3  Sums over correspondences (centroids, A^T A, inlier residual sums) use a fixed 64-way
  *       strided + butterfly order (det_sum64) so that a 64-lane wavefront reproduces them
  *       bit-for-bit; COLMAP sums sequentially.  Same values up to rounding.
@@ -409,10 +411,44 @@ double poly_eval(const double* c, int deg, double x) {  // c[0] + c[1] x + ...
     return v;
 }
 
+// The root inside a sign-change bracket [lo, hi] (flo = p(lo), non-zero; p(hi) has the other sign): bisection until
+// the bracket is narrower than 2^-26 of where it sits (or cannot be split any more, or 200 steps), then three Newton
+// steps from its midpoint, each accepted only if it lands strictly inside the bracket.  (Rounds 1-2 bisected down to
+// adjacent doubles, ~75 polynomial evaluations per root; the bracket pins the root and the monotone stretch, Newton
+// finishes in the 3 evaluations of p and p' it is good at.  dc = the coefficients of p', degree deg - 1.)
+constexpr double kRootRelWidth = 1.4901161193847656e-08;  // 2^-26
+#ifdef ORACLE_ROOT_STATS
+long g_root_iter_hist[201];
+#endif
+double bracket_root(const double* c, const double* dc, int deg, double lo, double hi, double flo) {
+#ifdef ORACLE_ROOT_STATS
+    struct Tally { int n = 0; ~Tally() { ++g_root_iter_hist[n]; } } tally;
+#define ORACLE_ROOT_TICK ++tally.n
+#else
+#define ORACLE_ROOT_TICK (void)0
+#endif
+    for (int it = 0; it < 200; ++it) {
+        ORACLE_ROOT_TICK;
+        const double mid = 0.5 * (lo + hi);
+        if (mid == lo || mid == hi) break;
+        const double fm = poly_eval(c, deg, mid);
+        if (fm == 0.0) return mid;
+        if ((fm < 0.0) == (flo < 0.0)) { lo = mid; flo = fm; } else { hi = mid; }
+        if (hi - lo <= kRootRelWidth * (std::fabs(lo) + std::fabs(hi))) break;
+    }
+    double r = 0.5 * (lo + hi);
+    for (int n = 0; n < 3; ++n) {
+        const double f = poly_eval(c, deg, r), d = poly_eval(dc, deg - 1, r);
+        const double rn = r - f / d;
+        if (rn > lo && rn < hi) r = rn;  // (a NaN or infinite step fails both comparisons)
+    }
+    return r;
+}
+
 // real roots of one polynomial whose derivative's real roots (`crit`, ascending) are known:
 // between consecutive critical points the polynomial is monotone, so each sign change brackets
-// exactly one root; fixed-length bisection (runs until the interval cannot be split further).
-int roots_between(const double* c, int deg, const double* crit, int nc, double* roots) {
+// exactly one root (bracket_root).  dc: the derivative's coefficients.
+int roots_between(const double* c, const double* dc, int deg, const double* crit, int nc, double* roots) {
     if (deg == 1) {
         roots[0] = -c[0] / c[1];
         return 1;
@@ -428,8 +464,8 @@ int roots_between(const double* c, int deg, const double* crit, int nc, double* 
     edges[ne++] = bound;
     int nr = 0;
     for (int i = 0; i + 1 < ne; ++i) {
-        double lo = edges[i], hi = edges[i + 1];
-        double flo = poly_eval(c, deg, lo);
+        const double lo = edges[i], hi = edges[i + 1];
+        const double flo = poly_eval(c, deg, lo);
         const double fhi = poly_eval(c, deg, hi);
         if (flo == 0.0) {
             if (nr == 0 || roots[nr - 1] != lo) roots[nr++] = lo;
@@ -437,14 +473,7 @@ int roots_between(const double* c, int deg, const double* crit, int nc, double* 
         }
         if (fhi == 0.0) continue;  // picked up as lo of the next interval (or below)
         if ((flo < 0.0) == (fhi < 0.0)) continue;
-        for (int it = 0; it < 200; ++it) {
-            const double mid = 0.5 * (lo + hi);
-            if (mid == lo || mid == hi) break;
-            const double fm = poly_eval(c, deg, mid);
-            if (fm == 0.0) { lo = mid; hi = mid; break; }
-            if ((fm < 0.0) == (flo < 0.0)) { lo = mid; flo = fm; } else { hi = mid; }
-        }
-        roots[nr++] = 0.5 * (lo + hi);
+        roots[nr++] = bracket_root(c, dc, deg, lo, hi, flo);
     }
     if (poly_eval(c, deg, edges[ne - 1]) == 0.0 && (nr == 0 || roots[nr - 1] != edges[ne - 1]))
         roots[nr++] = edges[ne - 1];
@@ -503,7 +532,7 @@ int real_roots(const double* c_in, int deg_in, double* roots) {
     double crit[10], cur[10];
     int nc = 0;
     for (int j = deg - 1; j >= 0; --j) {
-        const int n = roots_between(chain[j], deg - j, crit, nc, cur);
+        const int n = roots_between(chain[j], j + 1 < deg ? chain[j + 1] : nullptr, deg - j, crit, nc, cur);
         nc = n;
         for (int i = 0; i < n; ++i) crit[i] = cur[i];
     }
@@ -2202,6 +2231,9 @@ int64_t oracle_compute_num_trials(int64_t num_inliers, int64_t num_samples, doub
                                                                          : static_cast<int64_t>(v);
 }
 int oracle_real_roots(const double* coeffs, int deg, double* roots) { return real_roots(coeffs, deg, roots); }
+#ifdef ORACLE_ROOT_STATS
+void oracle_root_iter_hist(long* out) { for (int i = 0; i <= 200; ++i) { out[i] = g_root_iter_hist[i]; g_root_iter_hist[i] = 0; } }
+#endif
 void oracle_jacobi_eigen(int n, double* a, double* v) { jacobi_eigen(n, a, v); }
 double oracle_det_sum64(const double* x, size_t n) { return det_sum64(n, [&](size_t k) { return x[k]; }); }
 

@@ -3,6 +3,7 @@
 #include <sqlite3.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 namespace amchost {
@@ -128,6 +129,31 @@ std::string Database::SetBulkWriteMode(bool on) {
     }
     sqlite3_finalize(st);
     bulk_mode_ = on && mode == "truncate";
+    // connection-level settings for the append phase (they do not change a byte of the file): by default none;
+    // AMC_DB_BULK_PRAGMAS="mmap_size=17179869184;locking_mode=EXCLUSIVE" (semicolon-separated, without the PRAGMA
+    // keyword) tries others - tools/pipeline_bench.py is how they are measured.  Switched back when the mode ends.
+    if (const char* e = std::getenv("AMC_DB_BULK_PRAGMAS")) {
+        const std::string list(e);
+        size_t p0 = 0;
+        while (p0 < list.size()) {
+            size_t q = list.find(';', p0);
+            if (q == std::string::npos) q = list.size();
+            std::string one = list.substr(p0, q - p0);
+            p0 = q + 1;
+            if (one.empty()) continue;
+            if (!on) {  // back to SQLite's defaults for the settings that stick to the connection
+                const std::string key = one.substr(0, one.find('='));
+                if (key == "locking_mode") one = "locking_mode=NORMAL";
+                else if (key == "mmap_size") one = "mmap_size=0";
+                else if (key == "cache_size") one = "cache_size=-2000";
+                else continue;
+            }
+            try {
+                Exec(("PRAGMA " + one).c_str());
+            } catch (...) {
+            }
+        }
+    }
     return mode;
 }
 sqlite3_stmt* Database::Prepared(const std::string& sql) const {

@@ -675,18 +675,19 @@ __device__ __forceinline__ void smallest_eigvec9_wave(const lds_f64* A, const ld
     for (int i = 0; i < 9; ++i) x[i] = V[i * 9 + best];
 }
 // ---- real roots of ONE polynomial by the whole wave (local optimisation's 5-point solve) ----------
-// tvg_math.h's RootChain walks the chain of derivatives and, per level, bisects the sign-change
-// brackets one after the other.  The brackets of a level are independent, so here lane i takes
+// tvg_math.h's RootChain walks the chain of derivatives and, per level, solves the sign-change
+// brackets two at a time.  The brackets of a level are independent, so here lane i takes
 // bracket i (same arithmetic per bracket, hence the same roots bit for bit) and the level costs one
-// bisection instead of up to R of them; the ordered, de-duplicated root list is then assembled
+// bracket solve instead of up to R of them; the ordered, de-duplicated root list is then assembled
 // exactly as roots_between_t does it.
 template <int DEG, int R>
 struct WaveRootChain {
     static __device__ __forceinline__ int run(const double (&c)[DEG + 1], double* roots, lds_f64* tmp, int lane) {
         double crit[R];
         const int nc = WaveRootChain<DEG, R - 1>::run(c, crit, tmp, lane);
-        double d[R + 1];
+        double d[R + 1], dd[R];
         poly_derivative_t<DEG, DEG - R>(c, d);
+        poly_derivative_t<DEG, DEG - R + 1>(c, dd);  // the derivative of d
         double bound = 0.0;
 #pragma unroll
         for (int i = 0; i < R; ++i) bound = dmax(bound, dabs(d[i] / d[R]));
@@ -708,15 +709,25 @@ struct WaveRootChain {
                 kind = 1;
                 val = lo;
             } else if (fhi != 0.0 && (flo < 0.0) != (fhi < 0.0)) {
+                // bracket_root: bisection to 2^-26 of the bracket's position, then three bracketed Newton steps
+                bool zero = false;
                 for (int it = 0; it < 200; ++it) {
                     const double mid = 0.5 * (lo + hi);
                     if (mid == lo || mid == hi) break;
                     const double fm = poly_eval_t<R>(d, mid);
-                    if (fm == 0.0) { lo = mid; hi = mid; break; }
+                    if (fm == 0.0) { lo = mid; hi = mid; zero = true; break; }
                     if ((fm < 0.0) == (flo < 0.0)) { lo = mid; flo = fm; } else { hi = mid; }
+                    if (hi - lo <= kRootRelWidth * (dabs(lo) + dabs(hi))) break;
+                }
+                double r = 0.5 * (lo + hi);
+#pragma unroll
+                for (int n = 0; n < 3; ++n) {
+                    const double fr = poly_eval_t<R>(d, r), dr = poly_eval_t<R - 1>(dd, r);
+                    const double rn = r - fr / dr;
+                    r = (!zero && rn > lo && rn < hi) ? rn : r;
                 }
                 kind = 2;
-                val = 0.5 * (lo + hi);
+                val = r;
             }
         }
         const double last = tmp[ne - 1];

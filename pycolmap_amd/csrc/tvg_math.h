@@ -275,17 +275,20 @@ AMC_HD double poly_eval(const double* c, int deg, double x) {
     for (int i = deg - 1; i >= 0; --i) v = v * x + c[i];
     return v;
 }
-// real roots of c (degree DEG >= 2, c[DEG] != 0) given the real roots `crit` of its derivative:
-// one sign-change bisection per monotone interval, ascending.
+// real roots of c (degree DEG >= 2, c[DEG] != 0) given the real roots `crit` of its derivative (coefficients dc):
+// every monotone interval with a sign change holds one root - bisected until the bracket is narrower than 2^-26 of
+// where it sits, then three Newton steps accepted only strictly inside the bracket (oracle: bracket_root) - ascending.
 // Written for a SIMT lane: every array is indexed with compile-time indices (slots are filled by predicated
-// selects), so nothing lives in scratch memory, and the intervals are first classified and the bisections then run
-// over the lane's OWN sign-change intervals only - a wave's lanes solve different polynomials, and a loop over all
-// DEG + 1 intervals would make every lane wait for a bisection whenever any lane has a sign change in that slot.
-// Per interval the arithmetic is that of the plain loop (for each interval: f(lo) == 0 -> root lo unless it repeats
-// the previous root; f(hi) == 0 or equal signs -> nothing; else bisect until the midpoint hits an end): same roots,
-// same bits, same order.
+// selects), so nothing lives in scratch memory, and the intervals are first classified and the brackets then
+// solved over the lane's OWN sign-change intervals only, two at a time on independent dependency chains - a wave's
+// lanes solve different polynomials, and a loop over all DEG + 1 intervals would make every lane wait for a bracket
+// whenever any lane has a sign change in that slot.  Per interval the arithmetic is that of the plain loop (for each
+// interval: f(lo) == 0 -> root lo unless it repeats the previous root; f(hi) == 0 or equal signs -> nothing; else
+// bracket_root): same roots, same bits, same order.
+constexpr double kRootRelWidth = 1.4901161193847656e-08;  // 2^-26
 template <int DEG>
-AMC_HD int roots_between_t(const double (&c)[DEG + 1], const double (&crit)[DEG - 1], int nc, double (&roots)[DEG]) {
+AMC_HD int roots_between_t(const double (&c)[DEG + 1], const double (&dc)[DEG], const double (&crit)[DEG - 1], int nc,
+                           double (&roots)[DEG]) {
     double bound = 0.0;
 #pragma unroll
     for (int i = 0; i < DEG; ++i) bound = dmax(bound, dabs(c[i] / c[DEG]));
@@ -323,9 +326,6 @@ AMC_HD int roots_between_t(const double (&c)[DEG + 1], const double (&crit)[DEG 
     double val[DEG];
 #pragma unroll
     for (int i = 0; i < DEG; ++i) val[i] = 0.0;
-    // two of the lane's brackets at a time: the bisection is a chain of dependent operations (Horner steps), and two
-    // independent chains interleaved cost hardly more than one at the occupancy these solvers run at.  Each bracket
-    // sees exactly the plain loop's arithmetic and its own 200-iteration cap.
     while (todo) {
         const int cur0 = __builtin_ctz(todo);
         todo &= todo - 1u;
@@ -344,24 +344,38 @@ AMC_HD int roots_between_t(const double (&c)[DEG + 1], const double (&crit)[DEG 
             hi1 = me1 ? edges[i + 1] : hi1;
             flo1 = me1 ? f[i] : flo1;
         }
-        bool act0 = true, act1 = two;
+        // bisection phase of both brackets (act: still bisecting; zero: the midpoint was an exact root)
+        bool act0 = true, act1 = two, zero0 = false, zero1 = false;
         for (int it = 0; it < 200 && (act0 || act1); ++it) {
             const double mid0 = 0.5 * (lo0 + hi0), mid1 = 0.5 * (lo1 + hi1);
             act0 = act0 && !(mid0 == lo0 || mid0 == hi0);
             act1 = act1 && !(mid1 == lo1 || mid1 == hi1);
             const double fm0 = poly_eval_t<DEG>(c, mid0), fm1 = poly_eval_t<DEG>(c, mid1);
             if (act0) {
-                if (fm0 == 0.0) { lo0 = mid0; hi0 = mid0; act0 = false; }
-                else if ((fm0 < 0.0) == (flo0 < 0.0)) { lo0 = mid0; flo0 = fm0; }
-                else { hi0 = mid0; }
+                if (fm0 == 0.0) { lo0 = mid0; hi0 = mid0; act0 = false; zero0 = true; }
+                else {
+                    if ((fm0 < 0.0) == (flo0 < 0.0)) { lo0 = mid0; flo0 = fm0; } else { hi0 = mid0; }
+                    act0 = !(hi0 - lo0 <= kRootRelWidth * (dabs(lo0) + dabs(hi0)));
+                }
             }
             if (act1) {
-                if (fm1 == 0.0) { lo1 = mid1; hi1 = mid1; act1 = false; }
-                else if ((fm1 < 0.0) == (flo1 < 0.0)) { lo1 = mid1; flo1 = fm1; }
-                else { hi1 = mid1; }
+                if (fm1 == 0.0) { lo1 = mid1; hi1 = mid1; act1 = false; zero1 = true; }
+                else {
+                    if ((fm1 < 0.0) == (flo1 < 0.0)) { lo1 = mid1; flo1 = fm1; } else { hi1 = mid1; }
+                    act1 = !(hi1 - lo1 <= kRootRelWidth * (dabs(lo1) + dabs(hi1)));
+                }
             }
         }
-        const double r0 = 0.5 * (lo0 + hi0), r1 = 0.5 * (lo1 + hi1);
+        double r0 = 0.5 * (lo0 + hi0), r1 = 0.5 * (lo1 + hi1);
+        // Newton phase: three steps each, accepted only strictly inside the bracket
+#pragma unroll
+        for (int n = 0; n < 3; ++n) {
+            const double f0 = poly_eval_t<DEG>(c, r0), f1 = poly_eval_t<DEG>(c, r1);
+            const double d0 = poly_eval_t<DEG - 1>(dc, r0), d1 = poly_eval_t<DEG - 1>(dc, r1);
+            const double n0 = r0 - f0 / d0, n1 = r1 - f1 / d1;
+            r0 = (!zero0 && n0 > lo0 && n0 < hi0) ? n0 : r0;
+            r1 = (!zero1 && n1 > lo1 && n1 < hi1) ? n1 : r1;
+        }
 #pragma unroll
         for (int i = 0; i < DEG; ++i) val[i] = (cur0 == i) ? r0 : ((two && cur1 == i) ? r1 : val[i]);
     }
@@ -412,9 +426,10 @@ struct RootChain {
     static AMC_HD int run(const double (&c)[DEG + 1], double (&roots)[R]) {
         double crit[R - 1];
         const int nc = RootChain<DEG, R - 1>::run(c, crit);
-        double d[R + 1];
+        double d[R + 1], dd[R];
         poly_derivative_t<DEG, DEG - R>(c, d);
-        return roots_between_t<R>(d, crit, nc, roots);
+        poly_derivative_t<DEG, DEG - R + 1>(c, dd);  // the derivative of d (= the next level down)
+        return roots_between_t<R>(d, dd, crit, nc, roots);
     }
 };
 template <int DEG>

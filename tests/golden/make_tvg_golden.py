@@ -1,4 +1,4 @@
-"""Generates tests/golden/tvg_golden_v3.npz: seeded two-view scenes with the oracle's
+"""Generates tests/golden/tvg_golden_v4.npz: seeded two-view scenes with the oracle's
 EstimateTwoViewGeometry (+ EstimateTwoViewGeometryPose) results.
 
 As for the match fixture, the reference holds no golden vectors for this path (SURVEY.md section
@@ -57,7 +57,7 @@ def main():
             for f in FIELDS:
                 out[f"{f}_{tag}"] = np.ascontiguousarray(r[f], dtype=np.float64).reshape(-1).view(np.uint64)
             print(k, pose, r["config_name"], r["num_inliers"], r["trials"], round(r["tri_angle"], 5))
-    np.savez_compressed(Path(__file__).with_name("tvg_golden_v3.npz"), **out)
+    np.savez_compressed(Path(__file__).with_name("tvg_golden_v4.npz"), **out)
 
 
 if __name__ == "__main__":

@@ -1,7 +1,7 @@
 """Seed-only scene definitions shared by the fixture generators (pure numpy + pycolmap_amd/synth.py loaded BY PATH, so
 that the scripts also run on a machine that has the real pycolmap and nothing of this repo built):
 
-  golden_scenes()  the 20 cases of tests/golden/tvg_golden_v3.npz (make_tvg_golden.py), same generator, same order
+  golden_scenes()  the 20 cases of tests/golden/tvg_golden_v4.npz (make_tvg_golden.py), same generator, same order
   bench_scenes()   the 64 calibrated scenes of bench.py's verify leg (default_rng(7))
 """
 import importlib.util
@@ -53,7 +53,7 @@ RANSAC_OPTION_KEYS = ("max_error", "min_inlier_ratio", "confidence", "dyn_num_tr
 
 def golden_scenes():
     """Yields dict(name, pts1, pts2, matches, cam1 = (model, params), cam2, prior, opts) - the scenes of
-    tvg_golden_v3.npz, bit for bit (same generator state sequence as make_tvg_golden.py)."""
+    tvg_golden_v4.npz, bit for bit (same generator state sequence as make_tvg_golden.py)."""
     rng = np.random.default_rng(GOLDEN_SEED)
     for k, (kw, prior, c1, c2, okw) in enumerate(CASES):
         sc = synth.two_view_scene(rng, **kw)

@@ -9,7 +9,7 @@ and reports, against the default oracle: identical config, identical inlier mask
 Hamming distance of the masks where they differ - split into pairs whose final models agree to rounding (the mask
 difference is then a residual within rounding of max_error^2) and pairs where the RANSAC took another path.
 
-Scenes: the 20 cases of tests/golden/tvg_golden_v3.npz, the 64 scenes of bench.py's verify leg, and `--random`
+Scenes: the 20 cases of tests/golden/tvg_golden_v4.npz, the 64 scenes of bench.py's verify leg, and `--random`
 (default 500) seeded random scenes with varied inlier / outlier counts, noise, planarity and priors.
 
   python tests/ref2/compare.py [--random N] [--no-ref2] [--out tests/ref2/deviation_budget.json]

@@ -1,9 +1,9 @@
-"""Loader of tests/golden/tvg_golden_v3.npz (made by tests/golden/make_tvg_golden.py)."""
+"""Loader of tests/golden/tvg_golden_v4.npz (made by tests/golden/make_tvg_golden.py)."""
 from pathlib import Path
 
 import numpy as np
 
-PATH = Path(__file__).parent / "golden" / "tvg_golden_v3.npz"
+PATH = Path(__file__).parent / "golden" / "tvg_golden_v4.npz"
 import sys
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 from pycolmap_amd import synth  # noqa: E402  (EXAMPLE_CAMERAS only: pure numpy)
