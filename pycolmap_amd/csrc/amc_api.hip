@@ -1607,8 +1607,8 @@ static int verify_impl(amc_ctx* c, int mode, const uint32_t* slot1, const uint32
         const uint32_t mc = std::max<uint32_t>(64, round_up(tp[p].M, 64));
         const size_t lds = tvg_lds_bytes(mc, 1) + 64;
         if (lds <= 160 * 1024 / (4 * (size_t)kTvgFhWavesPerSimd)) cls[0].push_back(p);
-        else if (lds <= 160 * 1024 / 4) cls[1].push_back(p);
-        else if (lds <= 160 * 1024) cls[2].push_back(p);
+        else if (lds + 9 * 1024 <= 160 * 1024 / 4) cls[1].push_back(p);  // 4-wave workgroups of either kernel fit a CU
+        else if (lds + 9 * 1024 <= 160 * 1024) cls[2].push_back(p);  // (+ the E kernel's root-finder scratch)
         else
             return fail(AMC_E_INVALID, "amc_verify_pairs: pair %zu has %u matches: more than the verification "
                         "kernel's per-pair state can index in LDS (limit ~38000)", p, tp[p].M);
@@ -1700,16 +1700,15 @@ static int verify_impl(amc_ctx* c, int mode, const uint32_t* slot1, const uint32
                 if (uses_E(idx[i])) sub_e.push_back(sub[i]);
             }
             const uint32_t mcap = std::max<uint32_t>(64, round_up(cm, 64));
-            const size_t lds_block = tvg_lds_bytes(mcap, wpb);
-            auto waves_for = [&](size_t n, int waves_per_simd) {
+            auto waves_for = [&](size_t n, int waves_per_simd, size_t lds_block) {
                 const uint32_t blocks_per_cu = (uint32_t)std::max<size_t>(
                     1, std::min<size_t>(4 * (size_t)waves_per_simd / wpb, (160 * 1024) / std::max<size_t>(lds_block, 1)));
                 uint32_t nw = (uint32_t)std::min<size_t>(n, (size_t)cus * blocks_per_cu * wpb);
                 return std::max<uint32_t>(wpb, (nw + wpb - 1) / wpb * wpb);
             };
             const bool run_fh = mode != 3;
-            const uint32_t waves_e = sub_e.empty() ? 0 : waves_for(sub_e.size(), kTvgEWavesPerSimd);
-            const uint32_t waves_fh = run_fh ? waves_for(idx.size(), kTvgFhWavesPerSimd) : 0;
+            const uint32_t waves_e = sub_e.empty() ? 0 : waves_for(sub_e.size(), kTvgEWavesPerSimd, tvg_lds_bytes_e(mcap, wpb));
+            const uint32_t waves_fh = run_fh ? waves_for(idx.size(), kTvgFhWavesPerSimd, tvg_lds_bytes(mcap, wpb)) : 0;
             HIPCHK(c->d_tpairs.ensure(idx.size()));
             HIPCHK(c->d_tpairs_e.ensure(std::max<size_t>(sub_e.size(), 1)));
             HIPCHK(c->d_tws.ensure((size_t)std::max(waves_e, waves_fh) * tvg_ws_doubles_host(mcap)));

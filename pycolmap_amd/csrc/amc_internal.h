@@ -293,7 +293,8 @@ size_t tvg_ws_mask_bytes_host(uint32_t mcap);
 #endif
 constexpr int kTvgEWavesPerSimd = AMC_E_WAVES;
 constexpr int kTvgFhWavesPerSimd = AMC_FH_WAVES;
-size_t tvg_lds_bytes(uint32_t mcap, int waves);
+size_t tvg_lds_bytes(uint32_t mcap, int waves);    // F/H kernel
+size_t tvg_lds_bytes_e(uint32_t mcap, int waves);  // essential-matrix kernel (+ its root finder's scratch)
 hipError_t launch_sampson(const double* p1, const double* p2, size_t n, const double* E9, double* out,
                           hipStream_t s);
 // the essential-matrix RANSAC of the listed (calibrated) pairs -> estate[pair.orig], emask + pair.mask_off

@@ -67,6 +67,15 @@ enum : int { WK_SAMPSON = 0, WK_HRES, WK_TRES, WK_E5MIN, WK_F7MIN, WK_H4MIN, WK_
               WK_TRIALS, WK_COUNT };
 __device__ __forceinline__ constexpr int wk_residual_slot(int kind) { return kind == K_H ? WK_HRES : (kind == K_T ? WK_TRES : WK_SAMPSON); }
 
+// LDS scratch of the essential-matrix kernel's wave-balanced root finder (real_roots10_lanes)
+struct RootScratch {
+    lds_f64* coef;  // coefficient k of lane l's polynomial at coef[k * 64 + l]
+    lds_f64* lo;    // kRootCap; a bracket's root comes back here
+    lds_f64* hi;
+    lds_f64* flo;
+    lds_u16* src;   // the lane whose polynomial the bracket belongs to
+};
+
 struct Wave {
     int lane;
     unsigned long long prof[8];
@@ -85,6 +94,7 @@ struct Wave {
     uint32_t stream_len;
     uint32_t soff;
     uint32_t* err;    // [0] += 1 when a RANSAC ran past the end of the stream table (the host retries with a longer one)
+    RootScratch rootscr;  // essential-matrix kernel only
     // global workspace
     double* ws;        // W_NUM_ARRAYS x mcap point arrays | AoS table | models
     uint8_t* masks;    // 4 x mcap
@@ -108,6 +118,21 @@ __host__ __device__ inline size_t tvg_lds_per_wave(uint32_t mcap) {
     return (per + 15) / 16 * 16;
 }
 __host__ __device__ inline size_t tvg_ws_bytes_extra(uint32_t mcap) { return (size_t)4 * mcap; }  // 4 masks
+// The essential-matrix kernel's minimal solves spread the root finder's brackets over the wave (real_roots10_lanes):
+// per wave the level's coefficients of every lane (11 x 64 doubles) and one pass of bracket records
+// (kRootCap x (lo, hi, f(lo)) + the owning lane), behind the common layout.
+constexpr int kRootCap = 128;  // = one pair of brackets per lane and pass
+constexpr size_t kRootScratchBytes = (size_t)11 * 64 * 8 + (size_t)3 * kRootCap * 8 + (size_t)kRootCap * 2;
+__host__ __device__ inline size_t tvg_lds_per_wave_e(uint32_t mcap) { return tvg_lds_per_wave(mcap) + kRootScratchBytes; }
+__device__ __forceinline__ RootScratch root_scratch_carve(AMC_LDS char* base) {
+    RootScratch S;
+    S.coef = reinterpret_cast<lds_f64*>(base);
+    S.lo = S.coef + 11 * 64;
+    S.hi = S.lo + kRootCap;
+    S.flo = S.hi + kRootCap;
+    S.src = reinterpret_cast<lds_u16*>(S.flo + kRootCap);
+    return S;
+}
 
 __device__ __forceinline__ void wave_carve(Wave& w, AMC_LDS char* base, uint32_t mcap) {
     w.jacA = reinterpret_cast<lds_f64*>(base);
@@ -1000,6 +1025,121 @@ __device__ __noinline__ int local_estimate(const LoCtx w, const Pts P, int K, do
     return 1;
 }
 
+// ---- real roots of 64 degree-10 polynomials, one per lane, the brackets of a level spread over the wave ------------
+// tvg_math.h's RootChain on a lane solves the lane's own sign-change brackets; a wave then pays, per derivative level,
+// for the lane with the most brackets times the slowest bracket, and about a third of the lanes do useful work (a
+// minimal 5-point solve has 32 brackets over its nine levels, 0 to 8 per level).  Here a level's brackets of ALL
+// lanes go to a list in LDS - (lo, hi, f(lo)) and the owning lane; the level's coefficients of every lane beside it -
+// and lane l solves records l and 64 + l of each 128-record pass, whoever they belong to, with bracket_pair_root:
+// the arithmetic of a bracket does not depend on which lane runs it, so the roots are the ones RootChain returns,
+// bit for bit, in the same order (classification and assembly stay with the owning lane, tvg_math.h's own code).
+template <int R>
+__device__ __forceinline__ void solve_level_balanced(const double (&d)[R + 1], RootLevel<R>& L, int lane, const RootScratch& S) {
+    const int nb = __popc(L.todo);
+    int incl = nb;
+#pragma unroll
+    for (int sh = 1; sh < 64; sh <<= 1) {
+        const int o = __shfl_up(incl, sh);
+        if (lane >= sh) incl += o;
+    }
+    const int T = __builtin_amdgcn_readlane(incl, 63);
+    if (T == 0) return;
+    const int base = incl - nb;
+#pragma unroll
+    for (int k = 0; k <= R; ++k) S.coef[k * 64 + lane] = d[k];
+    for (int p0 = 0; p0 < T; p0 += kRootCap) {
+        {   // this lane's records of the pass
+            int j = 0;
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+                const bool mine = (L.todo >> i) & 1u;
+                const int idx = base + j - p0;
+                if (mine && idx >= 0 && idx < kRootCap) {
+                    S.lo[idx] = L.edges[i];
+                    S.hi[idx] = L.edges[i + 1];
+                    S.flo[idx] = L.f[i];
+                    S.src[idx] = (uint16_t)lane;
+                }
+                j += mine ? 1 : 0;
+            }
+        }
+        wave_lds_sync();
+        const int n = min(kRootCap, T - p0);
+        const bool one = lane < n, two = 64 + lane < n;
+        const int q0 = one ? lane : 0, q1 = two ? 64 + lane : q0;
+        const double lo0 = S.lo[q0], hi0 = S.hi[q0], flo0 = S.flo[q0];
+        const double lo1 = S.lo[q1], hi1 = S.hi[q1], flo1 = S.flo[q1];
+        const int s0 = (int)S.src[q0], s1 = (int)S.src[q1];
+        double c0[R + 1], c1[R + 1], dc0[R], dc1[R];
+#pragma unroll
+        for (int k = 0; k <= R; ++k) {
+            c0[k] = S.coef[k * 64 + s0];
+            c1[k] = S.coef[k * 64 + s1];
+        }
+        // the derivative's coefficients: d'[m] = d[m + 1] * (m + 1) continues poly_derivative_t's chain of products by
+        // its last factor, so these are the bits RootChain gets from poly_derivative_t<DEG, DEG - R + 1>
+#pragma unroll
+        for (int m = 0; m < R; ++m) {
+            dc0[m] = c0[m + 1] * (double)(m + 1);
+            dc1[m] = c1[m + 1] * (double)(m + 1);
+        }
+        wave_lds_sync();  // every lane holds its records before the roots overwrite lo[]
+        double r0, r1;
+        bracket_pair_root<R>(c0, dc0, c1, dc1, lo0, hi0, flo0, lo1, hi1, flo1, one, two, r0, r1);
+        if (one) S.lo[lane] = r0;
+        if (two) S.lo[64 + lane] = r1;
+        wave_lds_sync();
+        {   // back to the owners
+            int j = 0;
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+                const bool mine = (L.todo >> i) & 1u;
+                const int idx = base + j - p0;
+                if (mine && idx >= 0 && idx < kRootCap) L.val[i] = S.lo[idx];
+                j += mine ? 1 : 0;
+            }
+        }
+        wave_lds_sync();
+    }
+    L.todo = 0u;
+}
+template <int DEG, int R>
+struct LaneRootChain {
+    static __device__ __forceinline__ int run(const double (&c)[DEG + 1], double (&roots)[R], bool act, int lane, const RootScratch& S) {
+        double crit[R - 1];
+        const int nc = LaneRootChain<DEG, R - 1>::run(c, crit, act, lane, S);
+        double d[R + 1];
+        poly_derivative_t<DEG, DEG - R>(c, d);
+        RootLevel<R> L;
+        roots_classify<R>(d, crit, nc, L);
+        if (!act) L.todo = 0u;  // (a lane without a problem keeps its brackets out of the list)
+        solve_level_balanced<R>(d, L, lane, S);
+        return roots_assemble<R>(L, roots);
+    }
+};
+template <int DEG>
+struct LaneRootChain<DEG, 1> {
+    static __device__ __forceinline__ int run(const double (&c)[DEG + 1], double (&roots)[1], bool, int, const RootScratch&) {
+        double d[2];
+        poly_derivative_t<DEG, DEG - 1>(c, d);
+        roots[0] = -d[0] / d[1];
+        return 1;
+    }
+};
+// = real_roots_t<10>(c, roots) on every lane with `act` (c[10] != 0); the others return 0 roots.  Called by the whole wave.
+__device__ __noinline__ int real_roots10_lanes(const double* c_in, double* roots_out, bool act, int lane, const RootScratch S_) {
+    RootScratch S;
+    S.coef = uni_lds(S_.coef); S.lo = uni_lds(S_.lo); S.hi = uni_lds(S_.hi); S.flo = uni_lds(S_.flo); S.src = uni_lds(S_.src);
+    double c[11];
+#pragma unroll
+    for (int i = 0; i <= 10; ++i) c[i] = act ? c_in[i] : (i == 10 ? 1.0 : 0.0);  // a harmless polynomial for idle lanes
+    double r[10];
+    const int nr = LaneRootChain<10, 10>::run(c, r, act, lane, S);
+#pragma unroll
+    for (int i = 0; i < 10; ++i) roots_out[i] = r[i];
+    return act ? nr : 0;
+}
+
 // ---- a chunk's minimal problems and the inlier count of every resulting model --------------------
 // One minimal problem per lane.  H / T models stay with the solving lane (mym); F and E models - up to 3 / 10 per
 // trial - go to the wave's global model table.  Then every model of the chunk is counted (count_chunk).  A model can
@@ -1351,7 +1491,7 @@ __device__ __forceinline__ int count_models_f64(const double* models, int nmod, 
 
 template <int EST>
 __device__ __noinline__ void solve_chunk(ChunkModels* out, const Pts P_, const lds_u16* sidx_, int nT_, int lane,
-                                         double* models_) {
+                                         double* models_, const RootScratch rootscr) {
     const unsigned long long c0 = __builtin_readcyclecounter();
     const Pts P = uni(P_);
     const lds_u16* sidx = uni_lds(sidx_);
@@ -1380,10 +1520,7 @@ __device__ __noinline__ void solve_chunk(ChunkModels* out, const Pts P_, const l
             estimate_h4(sx1, sy1, sx2, sy2, mym);
             nmod = 1;
         } else if (EST == K_E5) {
-            double sx1[5], sy1[5], sx2[5], sy2[5];
-#pragma unroll
-            for (int i = 0; i < 5; ++i) load_pt(P, sidx[lane * 8 + i], sx1[i], sy1[i], sx2[i], sy2[i]);
-            nmod = estimate_e5_minimal(sx1, sy1, sx2, sy2, models + (size_t)lane * kMaxModels * 9);
+            // (below: the 5-point solve is split around its root finder, which the wave runs as one)
         } else {  // K_T: model = dst - src of the single sample
             double a, b, c, d;
             load_pt(P, sidx[lane * 8], a, b, c, d);
@@ -1391,6 +1528,39 @@ __device__ __noinline__ void solve_chunk(ChunkModels* out, const Pts P_, const l
             mym[1] = d - b;
             nmod = 1;
         }
+    }
+    if (EST == K_E5) {
+        // estimate_e5_minimal (tvg_math.h) in its three steps - null space + constraint polynomials per lane, the real
+        // roots of the 64 determinant polynomials by the whole wave (real_roots10_lanes), the models per lane; the
+        // same functions in the same order, so the same bits as the per-lane call
+        const bool have = lane < nT;
+        double nsp[4 * 9];
+        E5Polys polys;
+#pragma unroll
+        for (int i = 0; i <= 10; ++i) polys.det[i] = 0.0;
+        if (have) {
+            double A[5][9];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                double x1, y1, x2, y2;
+                load_pt(P, sidx[lane * 8 + i], x1, y1, x2, y2);
+                A[i][0] = x2 * x1; A[i][1] = x2 * y1; A[i][2] = x2;
+                A[i][3] = y2 * x1; A[i][4] = y2 * y1; A[i][5] = y2;
+                A[i][6] = x1; A[i][7] = y1; A[i][8] = 1;
+            }
+            double ns[4][9];
+            nullspace_reg<5>(A, ns);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int j = 0; j < 9; ++j) nsp[k * 9 + j] = ns[k][j];
+            e5_build(nsp, polys);
+        }
+        double roots[10];
+        const bool full = have && polys.det[10] != 0.0;
+        int nr = real_roots10_lanes(polys.det, roots, full, lane, rootscr);
+        if (have && !full) nr = real_roots_t<10>(polys.det, roots);  // a vanishing leading coefficient: the plain chain
+        if (have) nmod = e5_models(nsp, polys, roots, nr, models + (size_t)lane * kMaxModels * 9);
     }
     wave_mem_sync();
 #pragma unroll
@@ -1544,7 +1714,7 @@ __device__ Report lo_ransac(Wave& w_io, const RansacCfg& cfg, const double* gx, 
         { const unsigned long long tp1 = __builtin_readcyclecounter(); w.prof[0] += tp1 - tp0; tp0 = tp1; }
         // ---- 64 minimal problems + the inlier count of every model ---------
         ChunkModels cm;
-        solve_chunk<EST>(&cm, P, w.sidx, nT, lane, models);
+        solve_chunk<EST>(&cm, P, w.sidx, nT, lane, models, w.rootscr);
         CountCtx cc;
         cc.P = P; cc.p64 = p64; cc.p32 = p32; cc.models = models; cc.mlist = w.mlist; cc.tmax = w.tmax;
         cc.M = M; cc.nT = nT; cc.thr = best.cnt; cc.fast = fast_count; cc.max_res = cfg.max_res; cc.cmax = cmax;

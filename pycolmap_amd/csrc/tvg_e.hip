@@ -140,7 +140,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(kTvgEWavesP
     const int wid = threadIdx.x >> 6;
     Wave w;
     w.lane = lane;
-    wave_carve(w, (AMC_LDS char*)smem + (size_t)wid * tvg_lds_per_wave(mcap), mcap);
+    AMC_LDS char* lds = (AMC_LDS char*)smem + (size_t)wid * tvg_lds_per_wave_e(mcap);
+    wave_carve(w, lds, mcap);
+    w.rootscr = root_scratch_carve(lds + tvg_lds_per_wave(mcap));
     const size_t gw = (size_t)blockIdx.x * (blockDim.x >> 6) + wid;
     w.ws = ws_all + gw * tvg_ws_doubles(mcap);
     w.masks = nullptr;
@@ -176,13 +178,15 @@ void tvg_diag_report_e() {
 void tvg_diag_report_e() {}
 #endif
 
+size_t tvg_lds_bytes_e(uint32_t mcap, int waves) { return (size_t)waves * tvg_lds_per_wave_e(mcap); }
+
 hipError_t launch_tvg_e(const TvgImage* imgs, const TvgPair* pairs, uint32_t npairs, const uint32_t* matches,
                         const uint32_t* trial_tabs, const TvgParams& P, double* ws, uint32_t mcap, uint32_t num_waves,
                         int waves_per_block, uint32_t* queue_head, TvgEState* estate, uint8_t* emask, TvgOut* out,
                         uint8_t* out_mask, hipStream_t s) {
     if (npairs == 0) return hipSuccess;
     const uint32_t blocks = (num_waves + waves_per_block - 1) / waves_per_block;
-    const size_t lds = (size_t)waves_per_block * tvg_lds_per_wave(mcap);
+    const size_t lds = (size_t)waves_per_block * tvg_lds_per_wave_e(mcap);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tvg_e_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;

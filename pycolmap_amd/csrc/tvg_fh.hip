@@ -263,6 +263,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(kTvgFhWaves
     w.stream_len = P.stream_len;
     w.err = P.stream_err;
     w.soff = 0;
+    w.rootscr = RootScratch{};  // (the essential-matrix kernel's)
 
     for (;;) {
         uint32_t q = 0;

@@ -286,119 +286,145 @@ AMC_HD double poly_eval(const double* c, int deg, double x) {
 // interval: f(lo) == 0 -> root lo unless it repeats the previous root; f(hi) == 0 or equal signs -> nothing; else
 // bracket_root): same roots, same bits, same order.
 constexpr double kRootRelWidth = 1.4901161193847656e-08;  // 2^-26
+// One level of the chain, as a lane holds it: the interval edges, the polynomial's values there, what each interval
+// [edges[i], edges[i + 1]] is (1 exact root at the lower edge, 2 sign change, 0 nothing), the sign-change intervals
+// still to be solved (bit i of todo) and their roots (val).
 template <int DEG>
-AMC_HD int roots_between_t(const double (&c)[DEG + 1], const double (&dc)[DEG], const double (&crit)[DEG - 1], int nc,
-                           double (&roots)[DEG]) {
+struct RootLevel {
+    double edges[DEG + 1], f[DEG + 1], val[DEG];
+    int kind[DEG];
+    int ne;
+    unsigned todo;
+};
+template <int DEG>
+AMC_HD void roots_classify(const double (&c)[DEG + 1], const double (&crit)[DEG - 1], int nc, RootLevel<DEG>& L) {
     double bound = 0.0;
 #pragma unroll
     for (int i = 0; i < DEG; ++i) bound = dmax(bound, dabs(c[i] / c[DEG]));
     bound = 1.0 + bound;
     // edges: -bound, the critical points inside (-bound, bound), bound
-    double edges[DEG + 1];
 #pragma unroll
-    for (int s = 0; s <= DEG; ++s) edges[s] = 0.0;
-    edges[0] = -bound;
+    for (int s = 0; s <= DEG; ++s) L.edges[s] = 0.0;
+    L.edges[0] = -bound;
     int ne = 1;
 #pragma unroll
     for (int j = 0; j < DEG - 1; ++j) {
         const bool put = j < nc && crit[j] > -bound && crit[j] < bound;
 #pragma unroll
-        for (int s = 1; s < DEG; ++s) edges[s] = (put && ne == s) ? crit[j] : edges[s];
+        for (int s = 1; s < DEG; ++s) L.edges[s] = (put && ne == s) ? crit[j] : L.edges[s];
         ne += put ? 1 : 0;
     }
 #pragma unroll
-    for (int s = 1; s <= DEG; ++s) edges[s] = (ne == s) ? bound : edges[s];
+    for (int s = 1; s <= DEG; ++s) L.edges[s] = (ne == s) ? bound : L.edges[s];
     ne += 1;
-    double f[DEG + 1];
+    L.ne = ne;
 #pragma unroll
-    for (int s = 0; s <= DEG; ++s) f[s] = poly_eval_t<DEG>(c, edges[s]);
-    // interval i = [edges[i], edges[i + 1]]: 1 exact root at the lower edge, 2 sign change, 0 nothing
-    int kind[DEG];
+    for (int s = 0; s <= DEG; ++s) L.f[s] = poly_eval_t<DEG>(c, L.edges[s]);
     unsigned todo = 0u;
 #pragma unroll
     for (int i = 0; i < DEG; ++i) {
         const bool valid = i + 1 < ne;
-        const bool zlo = f[i] == 0.0;
-        const bool chg = !zlo && f[i + 1] != 0.0 && ((f[i] < 0.0) != (f[i + 1] < 0.0));
-        kind[i] = valid ? (zlo ? 1 : (chg ? 2 : 0)) : 0;
+        const bool zlo = L.f[i] == 0.0;
+        const bool chg = !zlo && L.f[i + 1] != 0.0 && ((L.f[i] < 0.0) != (L.f[i + 1] < 0.0));
+        L.kind[i] = valid ? (zlo ? 1 : (chg ? 2 : 0)) : 0;
         todo |= (valid && chg) ? (1u << i) : 0u;
+        L.val[i] = 0.0;
     }
-    double val[DEG];
+    L.todo = todo;
+}
+// Two sign-change brackets at once (oracle: bracket_root, once per bracket): bisection until the bracket is narrower
+// than 2^-26 of where it sits, then three Newton steps accepted only strictly inside it.  The two brackets may belong
+// to different polynomials (c0 / c1, derivatives dc0 / dc1): a lane solving its own polynomial passes it twice, the
+// wave-balanced solver of tvg_core.h hands a lane brackets of other lanes' polynomials.  Each bracket sees exactly the
+// plain loop's arithmetic and its own 200-step cap; the second one is idle when `two` is false.
+template <int DEG>
+AMC_HD void bracket_pair_root(const double (&c0)[DEG + 1], const double (&dc0)[DEG], const double (&c1)[DEG + 1],
+                              const double (&dc1)[DEG], double lo0, double hi0, double flo0, double lo1, double hi1,
+                              double flo1, bool one, bool two, double& r0_out, double& r1_out) {
+    bool act0 = one, act1 = two, zero0 = false, zero1 = false;
+    for (int it = 0; it < 200 && (act0 || act1); ++it) {
+        const double mid0 = 0.5 * (lo0 + hi0), mid1 = 0.5 * (lo1 + hi1);
+        act0 = act0 && !(mid0 == lo0 || mid0 == hi0);
+        act1 = act1 && !(mid1 == lo1 || mid1 == hi1);
+        const double fm0 = poly_eval_t<DEG>(c0, mid0), fm1 = poly_eval_t<DEG>(c1, mid1);
+        if (act0) {
+            if (fm0 == 0.0) { lo0 = mid0; hi0 = mid0; act0 = false; zero0 = true; }
+            else {
+                if ((fm0 < 0.0) == (flo0 < 0.0)) { lo0 = mid0; flo0 = fm0; } else { hi0 = mid0; }
+                act0 = !(hi0 - lo0 <= kRootRelWidth * (dabs(lo0) + dabs(hi0)));
+            }
+        }
+        if (act1) {
+            if (fm1 == 0.0) { lo1 = mid1; hi1 = mid1; act1 = false; zero1 = true; }
+            else {
+                if ((fm1 < 0.0) == (flo1 < 0.0)) { lo1 = mid1; flo1 = fm1; } else { hi1 = mid1; }
+                act1 = !(hi1 - lo1 <= kRootRelWidth * (dabs(lo1) + dabs(hi1)));
+            }
+        }
+    }
+    double r0 = 0.5 * (lo0 + hi0), r1 = 0.5 * (lo1 + hi1);
 #pragma unroll
-    for (int i = 0; i < DEG; ++i) val[i] = 0.0;
+    for (int n = 0; n < 3; ++n) {
+        const double f0 = poly_eval_t<DEG>(c0, r0), f1 = poly_eval_t<DEG>(c1, r1);
+        const double d0 = poly_eval_t<DEG - 1>(dc0, r0), d1 = poly_eval_t<DEG - 1>(dc1, r1);
+        const double n0 = r0 - f0 / d0, n1 = r1 - f1 / d1;
+        r0 = (!zero0 && n0 > lo0 && n0 < hi0) ? n0 : r0;
+        r1 = (!zero1 && n1 > lo1 && n1 < hi1) ? n1 : r1;
+    }
+    r0_out = r0;
+    r1_out = r1;
+}
+// the lane's own sign-change brackets, two at a time
+template <int DEG>
+AMC_HD void roots_solve_own(const double (&c)[DEG + 1], const double (&dc)[DEG], RootLevel<DEG>& L) {
+    unsigned todo = L.todo;
     while (todo) {
         const int cur0 = __builtin_ctz(todo);
         todo &= todo - 1u;
         const bool two = todo != 0u;
         const int cur1 = two ? __builtin_ctz(todo) : cur0;
         todo = two ? (todo & (todo - 1u)) : todo;
-        double lo0 = edges[0], hi0 = edges[1], flo0 = f[0];
-        double lo1 = edges[0], hi1 = edges[1], flo1 = f[0];
+        double lo0 = L.edges[0], hi0 = L.edges[1], flo0 = L.f[0];
+        double lo1 = L.edges[0], hi1 = L.edges[1], flo1 = L.f[0];
 #pragma unroll
         for (int i = 1; i < DEG; ++i) {
             const bool me0 = cur0 == i, me1 = cur1 == i;
-            lo0 = me0 ? edges[i] : lo0;
-            hi0 = me0 ? edges[i + 1] : hi0;
-            flo0 = me0 ? f[i] : flo0;
-            lo1 = me1 ? edges[i] : lo1;
-            hi1 = me1 ? edges[i + 1] : hi1;
-            flo1 = me1 ? f[i] : flo1;
+            lo0 = me0 ? L.edges[i] : lo0;
+            hi0 = me0 ? L.edges[i + 1] : hi0;
+            flo0 = me0 ? L.f[i] : flo0;
+            lo1 = me1 ? L.edges[i] : lo1;
+            hi1 = me1 ? L.edges[i + 1] : hi1;
+            flo1 = me1 ? L.f[i] : flo1;
         }
-        // bisection phase of both brackets (act: still bisecting; zero: the midpoint was an exact root)
-        bool act0 = true, act1 = two, zero0 = false, zero1 = false;
-        for (int it = 0; it < 200 && (act0 || act1); ++it) {
-            const double mid0 = 0.5 * (lo0 + hi0), mid1 = 0.5 * (lo1 + hi1);
-            act0 = act0 && !(mid0 == lo0 || mid0 == hi0);
-            act1 = act1 && !(mid1 == lo1 || mid1 == hi1);
-            const double fm0 = poly_eval_t<DEG>(c, mid0), fm1 = poly_eval_t<DEG>(c, mid1);
-            if (act0) {
-                if (fm0 == 0.0) { lo0 = mid0; hi0 = mid0; act0 = false; zero0 = true; }
-                else {
-                    if ((fm0 < 0.0) == (flo0 < 0.0)) { lo0 = mid0; flo0 = fm0; } else { hi0 = mid0; }
-                    act0 = !(hi0 - lo0 <= kRootRelWidth * (dabs(lo0) + dabs(hi0)));
-                }
-            }
-            if (act1) {
-                if (fm1 == 0.0) { lo1 = mid1; hi1 = mid1; act1 = false; zero1 = true; }
-                else {
-                    if ((fm1 < 0.0) == (flo1 < 0.0)) { lo1 = mid1; flo1 = fm1; } else { hi1 = mid1; }
-                    act1 = !(hi1 - lo1 <= kRootRelWidth * (dabs(lo1) + dabs(hi1)));
-                }
-            }
-        }
-        double r0 = 0.5 * (lo0 + hi0), r1 = 0.5 * (lo1 + hi1);
-        // Newton phase: three steps each, accepted only strictly inside the bracket
+        double r0, r1;
+        bracket_pair_root<DEG>(c, dc, c, dc, lo0, hi0, flo0, lo1, hi1, flo1, true, two, r0, r1);
 #pragma unroll
-        for (int n = 0; n < 3; ++n) {
-            const double f0 = poly_eval_t<DEG>(c, r0), f1 = poly_eval_t<DEG>(c, r1);
-            const double d0 = poly_eval_t<DEG - 1>(dc, r0), d1 = poly_eval_t<DEG - 1>(dc, r1);
-            const double n0 = r0 - f0 / d0, n1 = r1 - f1 / d1;
-            r0 = (!zero0 && n0 > lo0 && n0 < hi0) ? n0 : r0;
-            r1 = (!zero1 && n1 > lo1 && n1 < hi1) ? n1 : r1;
-        }
-#pragma unroll
-        for (int i = 0; i < DEG; ++i) val[i] = (cur0 == i) ? r0 : ((two && cur1 == i) ? r1 : val[i]);
+        for (int i = 0; i < DEG; ++i) L.val[i] = (cur0 == i) ? r0 : ((two && cur1 == i) ? r1 : L.val[i]);
     }
-    // the ordered root list
+    L.todo = 0u;
+}
+// the ordered root list of a solved level
+template <int DEG>
+AMC_HD int roots_assemble(const RootLevel<DEG>& L, double (&roots)[DEG]) {
     int nr = 0;
     double last = 0.0;
 #pragma unroll
     for (int s = 0; s < DEG; ++s) roots[s] = 0.0;
 #pragma unroll
     for (int i = 0; i < DEG; ++i) {
-        const bool push = (kind[i] == 1 && (nr == 0 || last != edges[i])) || kind[i] == 2;
-        const double v = kind[i] == 1 ? edges[i] : val[i];
+        const bool push = (L.kind[i] == 1 && (nr == 0 || last != L.edges[i])) || L.kind[i] == 2;
+        const double v = L.kind[i] == 1 ? L.edges[i] : L.val[i];
 #pragma unroll
         for (int s = 0; s < DEG; ++s) roots[s] = (push && nr == s) ? v : roots[s];
         last = push ? v : last;
         nr += push ? 1 : 0;
     }
     {   // the upper end itself
-        double fe = f[1], ee = edges[1];
+        double fe = L.f[1], ee = L.edges[1];
 #pragma unroll
         for (int s = 2; s <= DEG; ++s) {
-            fe = (ne - 1 == s) ? f[s] : fe;
-            ee = (ne - 1 == s) ? edges[s] : ee;
+            fe = (L.ne - 1 == s) ? L.f[s] : fe;
+            ee = (L.ne - 1 == s) ? L.edges[s] : ee;
         }
         const bool push = fe == 0.0 && (nr == 0 || last != ee);
 #pragma unroll
@@ -406,6 +432,14 @@ AMC_HD int roots_between_t(const double (&c)[DEG + 1], const double (&dc)[DEG], 
         nr += push ? 1 : 0;
     }
     return nr;
+}
+template <int DEG>
+AMC_HD int roots_between_t(const double (&c)[DEG + 1], const double (&dc)[DEG], const double (&crit)[DEG - 1], int nc,
+                           double (&roots)[DEG]) {
+    RootLevel<DEG> L;
+    roots_classify<DEG>(c, crit, nc, L);
+    roots_solve_own<DEG>(c, dc, L);
+    return roots_assemble<DEG>(L, roots);
 }
 // J-th derivative of c (degree DEG), coefficient by coefficient as the chain of successive
 // derivatives produces it: d[m] = (...((c[m+J] * (m+J)) * (m+J-1)) ... * (m+1))
