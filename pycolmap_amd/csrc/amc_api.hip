@@ -1691,8 +1691,14 @@ static int verify_impl(amc_ctx* c, int mode, const uint32_t* slot1, const uint32
             // The waves pull pairs from a queue in this order.  A pair's cost grows with its match count (every
             // trial scores all matches), so the largest go first: what is left for the tail of the launch, when
             // most waves have run dry, are the cheap ones.  Results are stored by pair, the order is free.
-            std::vector<size_t> idx = cls[k];
-            std::stable_sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return tp[a].M > tp[b].M; });
+            // (stable counting sort by match count, descending: M <= 65535)
+            std::vector<size_t> idx(cls[k].size());
+            {
+                std::vector<uint32_t> start(65537, 0);
+                for (size_t p : cls[k]) ++start[65535 - tp[p].M + 1];
+                for (size_t b = 1; b <= 65536; ++b) start[b] += start[b - 1];
+                for (size_t p : cls[k]) idx[start[65535 - tp[p].M]++] = p;
+            }
             std::vector<TvgPair> sub(idx.size()), sub_e;
             for (size_t i = 0; i < idx.size(); ++i) {
                 sub[i] = tp[idx[i]];

@@ -488,17 +488,25 @@ __device__ __noinline__ Support score(const Model9 mv, const Pts P_, int M_, dou
     const double max_res = uni(max_res_);
     double acc = 0.0;
     int cnt = 0;
-    for (int k0 = 0; k0 < M; k0 += 64) {
-        const int k = k0 + lane;
-        bool in = false;
-        if (k < M) {
-            double a, b, c, d;
-            load_pt(P, k, a, b, c, d);
-            const double r = residual_t<KIND>(m, a, b, c, d);
-            in = r <= max_res;
-            if (in) acc += r;
+    // four batches of 64 at a time: their loads are issued together (the residual chain of a batch would otherwise
+    // start only when its own loads have come back, one round trip to L2 per batch); the lane's partial sum still
+    // takes its residuals in batch order
+    for (int k0 = 0; k0 < M; k0 += 256) {
+        double a[4], b[4], c[4], d[4];
+        bool val[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = k0 + 64 * u + lane;
+            val[u] = k < M;
+            load_pt(P, val[u] ? k : 0, a[u], b[u], c[u], d[u]);
         }
-        cnt += __popcll(__ballot(in));
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const double r = residual_t<KIND>(m, a[u], b[u], c[u], d[u]);
+            const bool in = val[u] && r <= max_res;
+            if (in) acc += r;
+            cnt += __popcll(__ballot(in));
+        }
     }
     Support s;
     s.cnt = cnt;
@@ -512,17 +520,23 @@ __device__ __noinline__ int extract_inliers(lds_u16* inl, int lane, int kind, co
                                             double max_res) {
     const double* model = mv.v;
     int base = 0;
-    for (int k0 = 0; k0 < M; k0 += 64) {
-        const int k = k0 + lane;
-        bool in = false;
-        if (k < M) {
-            double a, b, c, d;
-            load_pt(P, k, a, b, c, d);
-            in = residual_of(kind, model, a, b, c, d) <= max_res;
+    for (int k0 = 0; k0 < M; k0 += 256) {
+        double a[4], b[4], c[4], d[4];
+        bool val[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = k0 + 64 * u + lane;
+            val[u] = k < M;
+            load_pt(P, val[u] ? k : 0, a[u], b[u], c[u], d[u]);
         }
-        const unsigned long long bal = __ballot(in);
-        if (in) inl[base + __popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)k;
-        base += __popcll(bal);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = k0 + 64 * u + lane;
+            const bool in = val[u] && residual_of(kind, model, a[u], b[u], c[u], d[u]) <= max_res;
+            const unsigned long long bal = __ballot(in);
+            if (in) inl[base + __popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)k;
+            base += __popcll(bal);
+        }
     }
     wave_lds_sync();
     return base;
@@ -938,7 +952,7 @@ __device__ __noinline__ int e5_models_wave(const double* nsp, const E5Polys& P, 
 // Diagnostic build (-DAMC_TVG_LODIAG, tools/variant_build_tvg.sh): shader-clock cycles of the stages of the local
 // estimators, summed over all waves (lane 0 adds); printed by the host with AMC_TVG_PROFILE=1.
 #if defined(AMC_TVG_LODIAG)
-__device__ unsigned long long g_lo_diag[16];
+__device__ unsigned long long g_lo_diag[48];
 #define LODIAG_T0() unsigned long long lodiag_t_ = __builtin_readcyclecounter()
 #define LODIAG_LAP(slot) do { const unsigned long long n_ = __builtin_readcyclecounter(); \
                               if (lane == 0) atomicAdd(&g_lo_diag[slot], n_ - lodiag_t_); lodiag_t_ = n_; } while (0)
@@ -1448,7 +1462,13 @@ __device__ __forceinline__ int count_models_f64(const double* models, int nmod, 
         // an upper bound below thr.
         int ub = 0;
         unsigned long long und = 0ull;
-        constexpr int kSeg = 64, kFewAlive = 6;
+#ifndef AMC_CNT_SEG
+#define AMC_CNT_SEG 64
+#endif
+#ifndef AMC_CNT_FEW
+#define AMC_CNT_FEW 6
+#endif
+        constexpr int kSeg = AMC_CNT_SEG, kFewAlive = AMC_CNT_FEW;
         for (int k0 = 0; k0 < M; k0 += kSeg) {
             const int k1 = min(k0 + kSeg, M);
             count_lanes_f64(mm, tab, k0, k1, max_res, ub, und);
@@ -1663,6 +1683,10 @@ __device__ Report lo_ransac(Wave& w_io, const RansacCfg& cfg, const double* gx, 
 
     Pts P;
     P.g = gx; P.gs = gstride;
+    constexpr int kDiagBase = 16 + 8 * (EST == K_F7 ? 0 : (EST == K_H ? 1 : (EST == K_E5 ? 2 : 3)));
+    (void)kDiagBase;
+    LODIAG_T0();
+    LODIAG_COUNT(kDiagBase);
     // the tables of the counting loops (read back through the scalar cache), and the pair's largest |coordinate|
     int fast_count = 0;
     double cmax = 0.0;
@@ -1689,7 +1713,9 @@ __device__ Report lo_ransac(Wave& w_io, const RansacCfg& cfg, const double* gx, 
         // fast_inlier); a NaN coordinate leaves amax as it was or NaN - either way the comparison below decides
         fast_count = (cfg.no_fast_count == 0 && amax * amax <= 1e10 * cfg.max_res) ? 1 : 0;
         cmax = amax;
+        LODIAG_LAP(kDiagBase + 1);
         if (EST != K_T) scalar_table_sync();
+        LODIAG_LAP(kDiagBase + 2);
     }
 
     // sampler.Initialize(M).  The first kMin entries of the persistent permutation are touched by
@@ -1746,7 +1772,13 @@ __device__ Report lo_ransac(Wave& w_io, const RansacCfg& cfg, const double* gx, 
                 } else {
                     for (int i = 0; i < 9; ++i) sm[i] = readlane_f64(cm.mym[i], t);
                 }
+#if defined(AMC_TVG_LODIAG)
+                const unsigned long long sc0_ = __builtin_readcyclecounter();
+#endif
                 const Support sup = score<(EST == K_E5 ? K_F7 : EST)>(smv, P, M, cfg.max_res, lane, best.cnt);
+#if defined(AMC_TVG_LODIAG)
+                if (lane == 0) { atomicAdd(&g_lo_diag[kDiagBase + 3], 1ull); atomicAdd(&g_lo_diag[kDiagBase + 4], __builtin_readcyclecounter() - sc0_); }
+#endif
                 if (better(sup, best)) {
                     const unsigned long long tl0 = __builtin_readcyclecounter();
                     best = sup;
@@ -1840,6 +1872,9 @@ __device__ Report lo_ransac(Wave& w_io, const RansacCfg& cfg, const double* gx, 
         w.work[wk_residual_slot(best_is_local ? LOCAL : EST)] += (unsigned long long)M;
     if (best.cnt < kMin) return rep;
     rep.success = true;
+#if defined(AMC_TVG_LODIAG)
+    lodiag_t_ = __builtin_readcyclecounter();
+#endif
     const int fk = best_is_local ? LOCAL : EST;
     for (int k = lane; k < M; k += 64) {
         double a, b, c, d;
@@ -1847,6 +1882,7 @@ __device__ Report lo_ransac(Wave& w_io, const RansacCfg& cfg, const double* gx, 
         mask[k] = residual_of(fk, rep.model, a, b, c, d) <= cfg.max_res ? 1 : 0;
     }
     wave_mem_sync();
+    LODIAG_LAP(kDiagBase + 5);
     return rep;
 }
 

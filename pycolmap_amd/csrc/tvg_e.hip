@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(kTvgEWavesP
 
 #if defined(AMC_TVG_LODIAG)
 void tvg_diag_report_e() {
-    unsigned long long h[16];
+    unsigned long long h[48];
     if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_lo_diag), sizeof h) != hipSuccess) return;
     std::fprintf(stderr, "[amc tvg lodiag tvg_diag_report_e] local 5-point solves %llu: cycles per solve ata %.0f jacobi %.0f build %.0f roots %.0f models %.0f | "
                  "8-point solves %llu: ata %.0f jacobi %.0f finish %.0f | DLT solves %llu: ata %.0f jacobi %.0f finish %.0f\n",
@@ -171,7 +171,14 @@ void tvg_diag_report_e() {
                  (double)h[4] / (h[0] ? h[0] : 1), (double)h[5] / (h[0] ? h[0] : 1), h[8], (double)h[9] / (h[8] ? h[8] : 1),
                  (double)h[10] / (h[8] ? h[8] : 1), (double)h[11] / (h[8] ? h[8] : 1), h[12], (double)h[13] / (h[12] ? h[12] : 1),
                  (double)h[14] / (h[12] ? h[12] : 1), (double)h[15] / (h[12] ? h[12] : 1));
-    unsigned long long z[16] = {};
+    const char* nm[4] = {"F", "H", "E", "T"};
+    for (int k = 0; k < 4; ++k) {
+        const unsigned long long* q = h + 16 + 8 * k;
+        if (!q[0]) continue;
+        std::fprintf(stderr, "[amc tvg lodiag] %s RANSACs %llu: cycles per RANSAC tables %.0f, scalar sync %.0f, exact re-scores %.1f x %.0f, final mask %.0f\n",
+                     nm[k], q[0], (double)q[1] / q[0], (double)q[2] / q[0], (double)q[3] / q[0], q[3] ? (double)q[4] / q[3] : 0.0, (double)q[5] / q[0]);
+    }
+    unsigned long long z[48] = {};
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lo_diag), z, sizeof z);
 }
 #else
