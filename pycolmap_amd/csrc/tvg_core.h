@@ -1299,18 +1299,33 @@ __device__ __forceinline__ void f64_count1(const double (&m)[9], const F64Rec& r
     ub += (int)(in || amb);
     undmask |= __ballot(amb);
 }
-// correspondences [k0, k1) against the lane's model; ub / undmask are carried from segment to segment
+// correspondences [k0, k1) against the lane's model; ub / undmask are carried from segment to segment.  The records
+// are requested a few 64-byte lines at a time (see count_lanes_h32 on why: one "all loads back" wait per batch).
+typedef double d8v __attribute__((ext_vector_type(8)));
+#ifndef AMC_F64_BATCH
+#define AMC_F64_BATCH 4   // 64-byte lines (2 correspondences each) requested together
+#endif
 __device__ __forceinline__ void count_lanes_f64(const double (&m)[9], const AMC_CONST double* tab, int k0, int k1, double T,
                                                 int& ub, unsigned long long& undmask) {
-    F64Rec ra = f64_rec(tab, k0);
+    constexpr int kB = AMC_F64_BATCH;
     int k = k0;
-    for (; k + 2 <= k1; k += 2) {
-        const F64Rec rb = f64_rec(tab, k + 1);
-        f64_count1(m, ra, T, ub, undmask);
-        ra = f64_rec(tab, k + 2 < k1 ? k + 2 : k1 - 1);
-        f64_count1(m, rb, T, ub, undmask);
+    if ((k0 & 1) == 0) {  // (segments start on even correspondences: whole lines)
+        const AMC_CONST d8v* tabq = reinterpret_cast<const AMC_CONST d8v*>(tab);
+        for (; k + 2 * kB <= k1; k += 2 * kB) {
+            d8v q[kB];
+#pragma unroll
+            for (int j = 0; j < kB; ++j) q[j] = tabq[(k >> 1) + j];
+#pragma unroll
+            for (int j = 0; j < kB; ++j) {
+                F64Rec r0, r1;
+                r0.a = q[j][0]; r0.b = q[j][1]; r0.c = q[j][2]; r0.d = q[j][3];
+                r1.a = q[j][4]; r1.b = q[j][5]; r1.c = q[j][6]; r1.d = q[j][7];
+                f64_count1(m, r0, T, ub, undmask);
+                f64_count1(m, r1, T, ub, undmask);
+            }
+        }
     }
-    if (k < k1) f64_count1(m, ra, T, ub, undmask);
+    for (; k < k1; ++k) f64_count1(m, f64_rec(tab, k), T, ub, undmask);
 }
 // exact inlier count of one wave-uniform model over the correspondences [k0, M), lanes = correspondences
 template <int KIND>
@@ -1356,17 +1371,15 @@ __device__ __forceinline__ float fma_abs_f32(float a, float b, float c) {  // fm
     return r;
 }
 struct H32Splat {  // the lane's model with every coefficient in both halves of a register pair
-    v2f m[9], kE, c42;
-    float kW, K0;
+    v2f m[9], bS, cR, K1;
 };
 __device__ __forceinline__ H32Splat h32_splat(const H32Lane& h) {
     H32Splat s;
 #pragma unroll
     for (int i = 0; i < 9; ++i) s.m[i] = (v2f){h.m[i], h.m[i]};
-    s.kE = (v2f){h.kE, h.kE};
-    s.c42 = (v2f){4.2e-7f, 4.2e-7f};
-    s.kW = h.kW;
-    s.K0 = h.K0;
+    s.bS = (v2f){h.bS, h.bS};
+    s.cR = (v2f){h.cR, h.cR};
+    s.K1 = (v2f){h.K1, h.K1};
     return s;
 }
 // h32_eval (tvg_math.h) on two correspondences: the same operations in the same order, so t and band are the
@@ -1377,10 +1390,9 @@ __device__ __forceinline__ void h32_eval_pk(const H32Splat& h, v2f a, v2f b, v2f
     const v2f w = pk_fma(h.m[6], a, pk_fma(h.m[7], b, h.m[8]));
     const v2f u = pk_fma(cs, w, -p0), v = pk_fma(ds, w, -p1);
     const v2f R = w * w;
-    t = pk_fma(u, u, v * v) - R;
-    const v2f auv = (v2f){abs_add_f32(u.x, v.x), abs_add_f32(u.y, v.y)};
-    const v2f kw = (v2f){fma_abs_f32(h.kW, w.x, h.K0), fma_abs_f32(h.kW, w.y, h.K0)};
-    band = pk_fma(h.c42, R, pk_fma(h.kE, auv, kw));
+    const v2f S = pk_fma(u, u, v * v);
+    t = S - R;
+    band = pk_fma(h.bS, S, pk_fma(h.cR, R, h.K1));
 }
 struct H32Rec {  // two correspondences of the pre-filter table
     v2f a, b, cs, ds;
@@ -1402,27 +1414,40 @@ __device__ __forceinline__ void h32_count2(const H32Splat& h, const H32Rec& r, b
         undmask |= __ballot(!d0);
     }
 }
+typedef float f16v __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ H32Rec h32_rec_of(const f16v& q, int half) {  // record `half` (0 / 1) of a 64-byte line
+    H32Rec r;
+    if (half == 0) { r.a = (v2f){q[0], q[1]}; r.b = (v2f){q[2], q[3]}; r.cs = (v2f){q[4], q[5]}; r.ds = (v2f){q[6], q[7]}; }
+    else { r.a = (v2f){q[8], q[9]}; r.b = (v2f){q[10], q[11]}; r.cs = (v2f){q[12], q[13]}; r.ds = (v2f){q[14], q[15]}; }
+    return r;
+}
+#ifndef AMC_H32_BATCH
+#define AMC_H32_BATCH 4   // 64-byte lines (4 correspondences each) requested together
+#endif
 __device__ __forceinline__ unsigned long long count_lanes_h32(const H32Lane& hl, const AMC_CONST v2f* tab, int M, int& ub_out) {
     const H32Splat h = h32_splat(hl);
     int ub = 0;
     unsigned long long undmask = 0ull;
     const int np = M >> 1, last = ((M + 1) >> 1) - 1;  // full pairs; index of the table's last record
-    // two records in flight on alternating scalar registers: the one after next is requested before the current
-    // one is used, so the scalar-cache latency overlaps the arithmetic
-    H32Rec ra = h32_rec(tab, 0);
+    // The table streams through the scalar cache once per chunk and misses it nearly always (every wave of the CU
+    // walks a table of its own), and scalar loads return out of order - the only wait is "all of them".  So the
+    // requests go out in batches of AMC_H32_BATCH whole lines and the arithmetic of a batch follows in one piece:
+    // one exposed latency per 4 * AMC_H32_BATCH correspondences, covered by the other waves of the SIMD.
+    constexpr int kB = AMC_H32_BATCH;
+    const AMC_CONST f16v* tabq = reinterpret_cast<const AMC_CONST f16v*>(tab);
     int k = 0;
-    for (; k + 2 <= np; k += 2) {
-        const H32Rec rb = h32_rec(tab, k + 1);
-        h32_count2(h, ra, true, ub, undmask);
-        ra = h32_rec(tab, k + 2 <= last ? k + 2 : last);
-        h32_count2(h, rb, true, ub, undmask);
+    for (; k + 2 * kB <= np; k += 2 * kB) {
+        f16v q[kB];
+#pragma unroll
+        for (int j = 0; j < kB; ++j) q[j] = tabq[(k >> 1) + j];
+#pragma unroll
+        for (int j = 0; j < kB; ++j) {
+            h32_count2(h, h32_rec_of(q[j], 0), true, ub, undmask);
+            h32_count2(h, h32_rec_of(q[j], 1), true, ub, undmask);
+        }
     }
-    if (k < np) {
-        h32_count2(h, ra, true, ub, undmask);
-        ++k;
-        if (M & 1) ra = h32_rec(tab, last);
-    }
-    if (M & 1) h32_count2(h, ra, false, ub, undmask);  // the last, unpaired correspondence (second half: a copy, not counted)
+    for (; k < np; ++k) h32_count2(h, h32_rec(tab, k), true, ub, undmask);
+    if (M & 1) h32_count2(h, h32_rec(tab, last), false, ub, undmask);  // the last, unpaired correspondence (second half: a copy, not counted)
     ub_out = ub;
     return undmask;
 }
@@ -1746,6 +1771,9 @@ __device__ Report lo_ransac(Wave& w_io, const RansacCfg& cfg, const double* gx, 
         cc.M = M; cc.nT = nT; cc.thr = best.cnt; cc.fast = fast_count; cc.max_res = cfg.max_res; cc.cmax = cmax;
         count_chunk<EST>(&cm, cc, lane);
         w.prof[1] += cm.cyc_solve;
+#if defined(AMC_TVG_LODIAG)
+        if (lane == 0) { atomicAdd(&g_lo_diag[kDiagBase + 6], (unsigned long long)cm.cyc_solve); atomicAdd(&g_lo_diag[kDiagBase + 7], (unsigned long long)cm.cyc_count); }
+#endif
         w.prof[5] += cm.cyc_count;  // the counting loop alone (also part of prof[2])
         tp0 = __builtin_readcyclecounter();
         // ---- replay in trial order.  Only two kinds of trial can change anything: one holding a

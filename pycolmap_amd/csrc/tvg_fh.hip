@@ -292,8 +292,9 @@ void tvg_diag_report() {
     for (int k = 0; k < 4; ++k) {
         const unsigned long long* q = h + 16 + 8 * k;
         if (!q[0]) continue;
-        std::fprintf(stderr, "[amc tvg lodiag] %s RANSACs %llu: cycles per RANSAC tables %.0f, scalar sync %.0f, exact re-scores %.1f x %.0f, final mask %.0f\n",
-                     nm[k], q[0], (double)q[1] / q[0], (double)q[2] / q[0], (double)q[3] / q[0], q[3] ? (double)q[4] / q[3] : 0.0, (double)q[5] / q[0]);
+        std::fprintf(stderr, "[amc tvg lodiag] %s RANSACs %llu: cycles per RANSAC tables %.0f, scalar sync %.0f, exact re-scores %.1f x %.0f, final mask %.0f, minimal solves %.0f, counting %.0f\n",
+                     nm[k], q[0], (double)q[1] / q[0], (double)q[2] / q[0], (double)q[3] / q[0], q[3] ? (double)q[4] / q[3] : 0.0, (double)q[5] / q[0],
+                     (double)q[6] / q[0], (double)q[7] / q[0]);
     }
     unsigned long long z[48] = {};
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lo_diag), z, sizeof z);

@@ -976,9 +976,18 @@ AMC_HD int e5_from_ata(double* ata, double* models) {
 // The FP64 test is itself only trusted outside |t| <= 2e-8 R, so a point is decided iff
 //   |t32| > 4.2e-7 R32 + kE (|u32| + |v32|) + kW |w32| + K0,   kE = 2.05 E0, kW = 2.05 Ew, K0 = 2.05 (2 E0^2 + Ew^2)
 // (> 2 % of slack for the rounding of the bound itself and the 6u |t32| term; NaN / inf compare false = undecided).
+// The loop evaluates a bound that is no smaller and costs two fused multiply-adds on values it has anyway
+// (S32 = u32^2 + v32^2, R32): for any beta > 0,  kE (|u| + |v|) <= kE sqrt(2 S) <= beta S + kE^2 / (2 beta)  and
+// kW |w| = kW sqrt(R) <= beta R + kW^2 / (4 beta)  (2ab <= a^2 + b^2), hence
+//   band = bS S32 + cR R32 + K1 >= 4.2e-7 R32 + kE (|u32| + |v32|) + kW |w32| + K0,
+//   bS = beta (1 + 1e-4), cR = (4.2e-7 + beta)(1 + 1e-4), K1 = (K0 + kE^2 / (2 beta) + kW^2 / (4 beta))(1 + 1e-4)
+// (the 1e-4 covers S32 / R32 versus the exact squares and the two roundings of the sum of positive terms).  The
+// two sides meet where beta = kE / (2 |w|); beta is chosen per model for |w| ~ max(|m8|, Aw / 8) and kept within
+// [2^-22, 2^-6], so even a wild model decides everything farther than ~3 % from the threshold circle.
 struct H32Model {
     float m[9];
-    float kE, kW, K0;
+    float kE, kW, K0;   // the reference bound (h32_band_ref: tests compare the loop's bound against it)
+    float bS, cR, K1;   // the loop's bound
 };
 AMC_HD float f32_up(double v) {  // a float >= v (v >= 0)
     return (float)(v * (1.0 + 1e-6));
@@ -994,9 +1003,19 @@ AMC_HD H32Model h32_prepare(const double* model, double s, double C) {
     const double Ew = 5.0 * U * Aw;
     H32Model h;
     for (int i = 0; i < 9; ++i) h.m[i] = (float)msc[i];
-    h.kE = f32_up(2.05 * E0);
-    h.kW = f32_up(2.05 * Ew);
-    h.K0 = f32_up(2.05 * (2.0 * E0 * E0 + Ew * Ew) + 1e-30);
+    const double kE = 2.05 * E0, kW = 2.05 * Ew, K0 = 2.05 * (2.0 * E0 * E0 + Ew * Ew) + 1e-30;
+    h.kE = f32_up(kE);
+    h.kW = f32_up(kW);
+    h.K0 = f32_up(K0);
+    const double wt = dmax(dabs(msc[8]), 0.125 * Aw);
+    double beta = kE / (2.0 * wt);
+    if (!(beta >= 2.384185791015625e-07)) beta = 2.384185791015625e-07;  // 2^-22 (also catches NaN: wt = 0 / inf)
+    if (beta > 0.015625) beta = 0.015625;                                 // 2^-6
+    const double bs = (double)(float)(beta * 1.0001);   // the float the loop multiplies S32 by; everything else follows it
+    const double b0 = bs / 1.0001;
+    h.bS = (float)bs;
+    h.cR = f32_up((4.2e-7 + b0) * 1.0001);
+    h.K1 = f32_up((K0 + kE * kE / (2.0 * b0) + kW * kW / (4.0 * b0)) * 1.0001);
     return h;
 }
 // t = u'^2 + v'^2 - w^2 and the bound on its error, for one point (V = float) or for two at once (V = a two-float
@@ -1013,9 +1032,19 @@ AMC_HD void h32_eval(const H32Model& h, V a, V b, V cs, V ds, V& t, V& band) {
     const V w = Ops::fma(Ops::splat(h.m[6]), a, Ops::fma(Ops::splat(h.m[7]), b, Ops::splat(h.m[8])));
     const V u = Ops::fma(cs, w, -p0), v = Ops::fma(ds, w, -p1);
     const V R = w * w;
-    t = Ops::fma(u, u, v * v) - R;
-    const V auv = Ops::abs(u) + Ops::abs(v);
-    band = Ops::fma(Ops::splat(4.2e-7f), R, Ops::fma(Ops::splat(h.kE), auv, Ops::fma(Ops::splat(h.kW), Ops::abs(w), Ops::splat(h.K0))));
+    const V S = Ops::fma(u, u, v * v);
+    t = S - R;
+    band = Ops::fma(Ops::splat(h.bS), S, Ops::fma(Ops::splat(h.cR), R, Ops::splat(h.K1)));
+}
+// the reference bound of the same point (the right-hand side of the inequality above)
+AMC_HD float h32_band_ref(const H32Model& h, float a, float b, float cs, float ds) {
+    const float p0 = fmaf(h.m[0], a, fmaf(h.m[1], b, h.m[2]));
+    const float p1 = fmaf(h.m[3], a, fmaf(h.m[4], b, h.m[5]));
+    const float w = fmaf(h.m[6], a, fmaf(h.m[7], b, h.m[8]));
+    const float u = fmaf(cs, w, -p0), v = fmaf(ds, w, -p1);
+    const float R = w * w;
+    const float auv = fabsf(u) + fabsf(v);
+    return fmaf(4.2e-7f, R, fmaf(h.kE, auv, fmaf(h.kW, fabsf(w), h.K0)));
 }
 // one point (a, b: image-1 coordinates; cs, ds: image-2 coordinates times s, all rounded to float):
 // 1 inlier, 0 outlier, -1 undecided

@@ -174,6 +174,7 @@ def test_fp32_homography_prefilter_never_contradicts_the_reference(shim):
     and it must decide nearly everything that is not on the circle."""
     rng = np.random.default_rng(17)
     decided = undecided = 0
+    bands_ratio = []
     for trial in range(400):
         n = 256
         style = trial % 5
@@ -213,6 +214,12 @@ def test_fp32_homography_prefilter_never_contradicts_the_reference(shim):
         want = res <= max_res
         got = np.zeros(n, dtype=np.int8)
         shim.shim_h32_decisions(_p(Hc), C.c_double(max_res), _p(p1c), _p(p2c), n, _p(got))
+        band, band_ref = np.zeros(n, dtype=np.float32), np.zeros(n, dtype=np.float32)
+        shim.shim_h32_bands(_p(Hc), C.c_double(max_res), _p(p1c), _p(p2c), n, _p(band), _p(band_ref))
+        fin = np.isfinite(band_ref)
+        assert np.all(band[fin] >= band_ref[fin]), "the loop's bound must cover the reference bound of the error analysis"
+        if style in (0, 2):                          # tame models: the cheaper bound stays within a few times the reference
+            bands_ratio.append(float(np.median(band[fin] / band_ref[fin])))
         dec = got >= 0
         wrong = dec & ((got == 1) != want)
         assert not wrong.any(), f"trial {trial} style {style}: FP32 decided {got[wrong][:4]} against residuals {res[wrong][:4]} (max {max_res})"
@@ -223,6 +230,7 @@ def test_fp32_homography_prefilter_never_contradicts_the_reference(shim):
         decided += int(dec.sum())
         undecided += int((~dec).sum())
     assert decided > undecided               # (a third of the points sit on the circle by construction)
+    assert np.median(bands_ratio) < 4.0
 
 
 def test_closed_form_h4_on_degenerate_samples_against_the_svd_dlt(shim):
