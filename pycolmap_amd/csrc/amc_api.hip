@@ -1717,7 +1717,7 @@ static int verify_impl(amc_ctx* c, int mode, const uint32_t* slot1, const uint32
             const uint32_t waves_fh = run_fh ? waves_for(idx.size(), kTvgFhWavesPerSimd, tvg_lds_bytes(mcap, wpb)) : 0;
             HIPCHK(c->d_tpairs.ensure(idx.size()));
             HIPCHK(c->d_tpairs_e.ensure(std::max<size_t>(sub_e.size(), 1)));
-            HIPCHK(c->d_tws.ensure((size_t)std::max(waves_e, waves_fh) * tvg_ws_doubles_host(mcap)));
+            HIPCHK(c->d_tws.ensure(std::max((size_t)waves_e * tvg_ws_doubles_e_host(mcap), (size_t)waves_fh * tvg_ws_doubles_host(mcap))));
             HIPCHK(c->d_tmaskws.ensure((size_t)std::max<uint32_t>(waves_fh, 1) * tvg_ws_mask_bytes_host(mcap)));
             HIPCHK(hipMemcpyAsync(c->d_tpairs.p, sub.data(), sub.size() * sizeof(TvgPair), hipMemcpyHostToDevice, st));
             if (!sub_e.empty())

@@ -281,6 +281,7 @@ struct alignas(64) TvgEState {
 void tvg_diag_report();    // diagnostic builds (-DAMC_TVG_LODIAG): stage cycles of the local estimators, on stderr
 void tvg_diag_report_e();  // ... of the essential-matrix kernel
 size_t tvg_ws_doubles_host(uint32_t mcap);
+size_t tvg_ws_doubles_e_host(uint32_t mcap);   // the essential-matrix kernel's waves (larger model / staging region)
 size_t tvg_ws_mask_bytes_host(uint32_t mcap);
 // Target occupancy (waves per SIMD) of the two verification kernels: sets their VGPR budgets and LDS shares.
 // tvg_e_kernel holds the 5-point solver (~200 live doubles per lane): 2.  tvg_fh_kernel (7-point / 4-point solvers,

@@ -109,6 +109,13 @@ __host__ __device__ inline size_t tvg_ws_doubles(uint32_t mcap) {
     return (size_t)W_NUM_ARRAYS * mcap + (size_t)4 * mcap + (size_t)2 * mcap + kModelDoubles;
 }
 __device__ __forceinline__ double* ws_arr(const Wave& w, int a) { return w.ws + (size_t)a * w.mcap; }
+// the essential-matrix kernel's waves: the model region doubles as the staging area of the minimal solver's
+// constraint matrices (64 problems x (10 x 20 matrix + 6 x 10 result), element-major: e5_eliminate_quads)
+constexpr int kE5StageG = 200, kE5StageHl = 60;
+constexpr int kE5StageDoubles = 64 * (kE5StageG + kE5StageHl);
+__host__ __device__ inline size_t tvg_ws_doubles_e(uint32_t mcap) {
+    return tvg_ws_doubles(mcap) - kModelDoubles + (kE5StageDoubles > kModelDoubles ? kE5StageDoubles : kModelDoubles);
+}
 __device__ __forceinline__ double* ws_p64(const Wave& w) { return w.ws + (size_t)W_NUM_ARRAYS * w.mcap; }
 __device__ __forceinline__ float* ws_p32(const Wave& w) { return reinterpret_cast<float*>(w.ws + (size_t)(W_NUM_ARRAYS + 4) * w.mcap); }
 __device__ __forceinline__ double* ws_models(const Wave& w) { return w.ws + (size_t)(W_NUM_ARRAYS + 6) * w.mcap; }
@@ -1422,7 +1429,7 @@ __device__ __forceinline__ H32Rec h32_rec_of(const f16v& q, int half) {  // reco
     return r;
 }
 #ifndef AMC_H32_BATCH
-#define AMC_H32_BATCH 4   // 64-byte lines (4 correspondences each) requested together
+#define AMC_H32_BATCH 5   // 64-byte lines (4 correspondences each) requested together
 #endif
 __device__ __forceinline__ unsigned long long count_lanes_h32(const H32Lane& hl, const AMC_CONST v2f* tab, int M, int& ub_out) {
     const H32Splat h = h32_splat(hl);
@@ -1534,6 +1541,80 @@ __device__ __forceinline__ int count_models_f64(const double* models, int nmod, 
     return nmod > 0 ? r : -1;
 }
 
+// ---- the minimal 5-point solve's 10 x 20 elimination, four lanes per problem -----------------------------------------
+// One problem per lane keeps 200 doubles of matrix per lane: twice the register file, and the spill traffic - not the
+// arithmetic - was what the stage cost.  Here every lane builds its problem's rows (tvg_math.h e5_constraint_rows) and
+// hands them to a staging area in the wave's workspace (element-major, so the stores coalesce); then the wave
+// eliminates 16 problems at a time, lane 4 q + p holding columns 5 p .. 5 p + 4 of problem q (50 doubles).  Row
+// operations act on columns independently, so each lane performs exactly the operations e5_build performs on its
+// columns; the pivot row index, 1 / pivot and the multipliers come from the lane that owns the pivot column, by quad
+// broadcast (DPP).  Rows 4 .. 9 of the right half go back to the staging area for e5_finish, again one problem per lane.
+struct E5StageSink {
+    double* stg;
+    int lane;
+    __device__ __forceinline__ void operator()(int r, const double (&row)[20]) {
+#pragma unroll
+        for (int c = 0; c < 20; ++c) stg[(size_t)(r * 20 + c) * 64 + lane] = row[c];
+    }
+};
+template <int OWN>
+__device__ __forceinline__ int quad_bcast(int v) {
+    return __builtin_amdgcn_mov_dpp(v, OWN * 0x55, 0xf, 0xf, true);
+}
+template <int OWN>
+__device__ __forceinline__ double quad_bcast(double v) {
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    const unsigned lo = (unsigned)quad_bcast<OWN>((int)(unsigned)u), hi = (unsigned)quad_bcast<OWN>((int)(unsigned)(u >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+template <int COL>
+__device__ __forceinline__ void e5_elim_col(double (&g)[10][5]) {
+    constexpr int OWN = COL / 5, CL = COL % 5;
+    int piv = COL;
+    double pv = dabs(g[COL][CL]);
+#pragma unroll
+    for (int r = COL + 1; r < 10; ++r)
+        if (dabs(g[r][CL]) > pv) { pv = dabs(g[r][CL]); piv = r; }
+    piv = quad_bcast<OWN>(piv);
+    if (piv != COL) {
+#pragma unroll
+        for (int r = COL + 1; r < 10; ++r)
+            if (r == piv) {
+#pragma unroll
+                for (int c = 0; c < 5; ++c) { const double t = g[COL][c]; g[COL][c] = g[r][c]; g[r][c] = t; }
+            }
+    }
+    const double inv = quad_bcast<OWN>(1.0 / g[COL][CL]);
+#pragma unroll
+    for (int c = 0; c < 5; ++c) g[COL][c] = g[COL][c] * inv;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        if (r == COL) continue;
+        const double f = quad_bcast<OWN>(g[r][CL]);
+#pragma unroll
+        for (int c = 0; c < 5; ++c) g[r][c] = g[r][c] - f * g[COL][c];
+    }
+}
+__device__ __forceinline__ void e5_eliminate_quads(double* stg, int nT, int lane) {
+    const int q = lane >> 2, p = lane & 3;
+    for (int pass = 0; pass * 16 < nT; ++pass) {
+        const int T = pass * 16 + q;
+        double g[10][5];
+#pragma unroll
+        for (int r = 0; r < 10; ++r)
+#pragma unroll
+            for (int c = 0; c < 5; ++c) g[r][c] = stg[(size_t)(r * 20 + 5 * p + c) * 64 + T];
+        e5_elim_col<0>(g); e5_elim_col<1>(g); e5_elim_col<2>(g); e5_elim_col<3>(g); e5_elim_col<4>(g);
+        e5_elim_col<5>(g); e5_elim_col<6>(g); e5_elim_col<7>(g); e5_elim_col<8>(g); e5_elim_col<9>(g);
+        if (p >= 2) {
+#pragma unroll
+            for (int r = 0; r < 6; ++r)
+#pragma unroll
+                for (int c = 0; c < 5; ++c) stg[(size_t)(kE5StageG + r * 10 + 5 * (p - 2) + c) * 64 + T] = g[4 + r][c];
+        }
+    }
+}
+
 template <int EST>
 __device__ __noinline__ void solve_chunk(ChunkModels* out, const Pts P_, const lds_u16* sidx_, int nT_, int lane,
                                          double* models_, const RootScratch rootscr) {
@@ -1599,8 +1680,21 @@ __device__ __noinline__ void solve_chunk(ChunkModels* out, const Pts P_, const l
             for (int k = 0; k < 4; ++k)
 #pragma unroll
                 for (int j = 0; j < 9; ++j) nsp[k * 9 + j] = ns[k][j];
-            e5_build(nsp, polys);
+            E5StageSink sink{models, lane};
+            e5_constraint_rows(nsp, sink);
         }
+        wave_mem_sync();
+        e5_eliminate_quads(models, nT, lane);
+        wave_mem_sync();
+        if (have) {
+            double hl[6][10];
+#pragma unroll
+            for (int r = 0; r < 6; ++r)
+#pragma unroll
+                for (int c = 0; c < 10; ++c) hl[r][c] = models[(size_t)(kE5StageG + r * 10 + c) * 64 + lane];
+            e5_finish(hl, polys);
+        }
+        wave_mem_sync();  // (the model region is rewritten with the models below)
         double roots[10];
         const bool full = have && polys.det[10] != 0.0;
         int nr = real_roots10_lanes(polys.det, roots, full, lane, rootscr);

@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(kTvgEWavesP
     wave_carve(w, lds, mcap);
     w.rootscr = root_scratch_carve(lds + tvg_lds_per_wave(mcap));
     const size_t gw = (size_t)blockIdx.x * (blockDim.x >> 6) + wid;
-    w.ws = ws_all + gw * tvg_ws_doubles(mcap);
+    w.ws = ws_all + gw * tvg_ws_doubles_e(mcap);
     w.masks = nullptr;
     w.stream = P.stream;
     w.stream_len = P.stream_len;
@@ -186,6 +186,7 @@ void tvg_diag_report_e() {
 void tvg_diag_report_e() {}
 #endif
 
+size_t tvg_ws_doubles_e_host(uint32_t mcap) { return tvg_ws_doubles_e(mcap); }
 size_t tvg_lds_bytes_e(uint32_t mcap, int waves) { return (size_t)waves * tvg_lds_per_wave_e(mcap); }
 
 hipError_t launch_tvg_e(const TvgImage* imgs, const TvgPair* pairs, uint32_t npairs, const uint32_t* matches,

@@ -789,57 +789,93 @@ AMC_HD void e5_finish(const double (&hl)[6][10], E5Polys& P) {
         for (int i = 0; i <= 10; ++i) det[i] = (q0[i] - q1[i]) + q2[i];
     }
 }
-AMC_HD void e5_build(const double* nsp, E5Polys& P) {
+// The 10 x 20 constraint matrix (rows: det E = 0, then the nine entries of 2 E E^T E - tr(E E^T) E = 0; columns: the
+// cubic monomials in e5_m21's order), one row at a time: sink(r, row).  A row is handed over as soon as it is
+// complete, so that a caller which stores it elsewhere (the kernel's minimal solver: tvg_core.h) never holds the
+// whole matrix.
+template <class Sink>
+AMC_HD void e5_constraint_rows(const double* nsp, Sink& sink) {
     double e[9][4];
 #pragma unroll
     for (int k = 0; k < 9; ++k)
 #pragma unroll
         for (int d = 0; d < 4; ++d) e[k][d] = nsp[d * 9 + k];
-    double G[10][20];
-    {   // det(E) -> row 0
-        double a[10], b[10], d[10], t0[20], t1[20], t2[20];
+    {   // det(E) -> row 0: (t0 - t1) + t2
+        double a[10], b[10], d[10], t[20], row[20];
         e5_mul11(e[4], e[8], a); e5_mul11(e[5], e[7], b);
 #pragma unroll
         for (int i = 0; i < 10; ++i) d[i] = a[i] - b[i];
-        e5_mul21(d, e[0], t0);
+        e5_mul21(d, e[0], row);
         e5_mul11(e[3], e[8], a); e5_mul11(e[5], e[6], b);
 #pragma unroll
         for (int i = 0; i < 10; ++i) d[i] = a[i] - b[i];
-        e5_mul21(d, e[1], t1);
+        e5_mul21(d, e[1], t);
+#pragma unroll
+        for (int i = 0; i < 20; ++i) row[i] = row[i] - t[i];
         e5_mul11(e[3], e[7], a); e5_mul11(e[4], e[6], b);
 #pragma unroll
         for (int i = 0; i < 10; ++i) d[i] = a[i] - b[i];
-        e5_mul21(d, e[2], t2);
+        e5_mul21(d, e[2], t);
 #pragma unroll
-        for (int i = 0; i < 20; ++i) G[0][i] = (t0[i] - t1[i]) + t2[i];
+        for (int i = 0; i < 20; ++i) row[i] = row[i] + t[i];
+        sink(0, row);
     }
+    double tr[10];
+    {   // tr(E E^T) = (EEt[0][0] + EEt[1][1]) + EEt[2][2]
+        double dg[3][10];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            double a[10], b[10], c[10];
+            e5_mul11(e[3 * i], e[3 * i], a);
+            e5_mul11(e[3 * i + 1], e[3 * i + 1], b);
+            e5_mul11(e[3 * i + 2], e[3 * i + 2], c);
+#pragma unroll
+            for (int t = 0; t < 10; ++t) dg[i][t] = (a[t] + b[t]) + c[t];
+        }
+#pragma unroll
+        for (int t = 0; t < 10; ++t) tr[t] = (dg[0][t] + dg[1][t]) + dg[2][t];
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        double eet[3][10];  // row i of E E^T
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            double a[10], b[10], c[10];
+            e5_mul11(e[3 * i], e[3 * j], a);
+            e5_mul11(e[3 * i + 1], e[3 * j + 1], b);
+            e5_mul11(e[3 * i + 2], e[3 * j + 2], c);
+#pragma unroll
+            for (int t = 0; t < 10; ++t) eet[j][t] = (a[t] + b[t]) + c[t];
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {  // ((a + b) + c) * 2 - d
+            double row[20], t[20];
+            e5_mul21(eet[0], e[j], row);
+            e5_mul21(eet[1], e[3 + j], t);
+#pragma unroll
+            for (int q = 0; q < 20; ++q) row[q] = row[q] + t[q];
+            e5_mul21(eet[2], e[6 + j], t);
+#pragma unroll
+            for (int q = 0; q < 20; ++q) row[q] = row[q] + t[q];
+            e5_mul21(tr, e[3 * i + j], t);
+#pragma unroll
+            for (int q = 0; q < 20; ++q) row[q] = row[q] * 2.0 - t[q];
+            sink(1 + 3 * i + j, row);
+        }
+    }
+}
+struct E5MatrixSink {  // the rows into a 10 x 20 array
+    double (*G)[20];
+    AMC_HD void operator()(int r, const double (&row)[20]) {
+#pragma unroll
+        for (int c = 0; c < 20; ++c) G[r][c] = row[c];
+    }
+};
+AMC_HD void e5_build(const double* nsp, E5Polys& P) {
+    double G[10][20];
     {
-        double eet[9][10], tr[10];
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                double a[10], b[10], c[10];
-                e5_mul11(e[3 * i], e[3 * j], a);
-                e5_mul11(e[3 * i + 1], e[3 * j + 1], b);
-                e5_mul11(e[3 * i + 2], e[3 * j + 2], c);
-#pragma unroll
-                for (int t = 0; t < 10; ++t) eet[3 * i + j][t] = (a[t] + b[t]) + c[t];
-            }
-#pragma unroll
-        for (int t = 0; t < 10; ++t) tr[t] = (eet[0][t] + eet[4][t]) + eet[8][t];
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                double a[20], b[20], c[20], d[20];
-                e5_mul21(eet[3 * i], e[j], a);
-                e5_mul21(eet[3 * i + 1], e[3 + j], b);
-                e5_mul21(eet[3 * i + 2], e[6 + j], c);
-                e5_mul21(tr, e[3 * i + j], d);
-#pragma unroll
-                for (int t = 0; t < 20; ++t) G[1 + 3 * i + j][t] = ((a[t] + b[t]) + c[t]) * 2.0 - d[t];
-            }
+        E5MatrixSink sink{G};
+        e5_constraint_rows(nsp, sink);
     }
     // Gauss-Jordan with partial pivoting on the left 10 x 10 block.  The only run-time index is the
     // pivot row of the swap.
