@@ -1165,7 +1165,7 @@ __device__ __noinline__ int real_roots10_lanes(const double* c_in, double* roots
 // One minimal problem per lane.  H / T models stay with the solving lane (mym); F and E models - up to 3 / 10 per
 // trial - go to the wave's global model table.  Then every model of the chunk is counted (count_chunk).  A model can
 // only change the course of the sequential algorithm if its count reaches the best count so far, so all the replay
-// needs per trial is the largest count among its models (exact, or an upper bound below that threshold); the few
+// needs per trial is an upper bound of the largest count among its models; the few
 // trials that qualify are re-scored in full there.
 struct ChunkModels {
     double mym[9];
@@ -1216,6 +1216,31 @@ __device__ __forceinline__ void fast_inlier(const double (&m)[9], double a, doub
                                                                 // the reference's NaN <= max_res says
     in = sane && c1;
     amb = !sane || (c2 && !c1);
+}
+// the half of fast_inlier the counting loops use: false only for an outlier beyond doubt (`out` above), so that
+// the sum over the correspondences is an upper bound of the inlier count
+template <int KIND>
+__device__ __forceinline__ bool fast_not_outlier(const double (&m)[9], double a, double b, double c, double d, double T) {
+    double Lq, R;
+    if (KIND == K_H) {
+        const double pd0 = __fma_rn(m[0], a, __fma_rn(m[1], b, m[2]));
+        const double pd1 = __fma_rn(m[3], a, __fma_rn(m[4], b, m[5]));
+        const double pd2 = __fma_rn(m[6], a, __fma_rn(m[7], b, m[8]));
+        const double u = __fma_rn(c, pd2, -pd0), v = __fma_rn(d, pd2, -pd1);
+        Lq = __fma_rn(u, u, v * v);
+        R = T * (pd2 * pd2);
+    } else {
+        const double Ex1_0 = __fma_rn(m[0], a, __fma_rn(m[1], b, m[2]));
+        const double Ex1_1 = __fma_rn(m[3], a, __fma_rn(m[4], b, m[5]));
+        const double Ex1_2 = __fma_rn(m[6], a, __fma_rn(m[7], b, m[8]));
+        const double Etx2_0 = __fma_rn(m[0], c, __fma_rn(m[3], d, m[6]));
+        const double Etx2_1 = __fma_rn(m[1], c, __fma_rn(m[4], d, m[7]));
+        const double x2tEx1 = __fma_rn(c, Ex1_0, __fma_rn(d, Ex1_1, Ex1_2));
+        Lq = x2tEx1 * x2tEx1;
+        R = T * __fma_rn(Ex1_0, Ex1_0, __fma_rn(Ex1_1, Ex1_1, __fma_rn(Etx2_0, Etx2_0, Etx2_1 * Etx2_1)));
+    }
+    const bool sane = ((uint32_t)((unsigned long long)__double_as_longlong(R) >> 32) - 0x16700000u) < 0x53000000u;
+    return !sane || Lq < R * kFastHi;  // (a NaN Lq with a sane R: an outlier, as the reference's NaN <= max_res says)
 }
 
 // ---- counting, one model at a time, lanes = correspondences (the exact path) -------------------------
@@ -1282,15 +1307,14 @@ __device__ __forceinline__ int count_global_models_exact(const double* models, i
 // the per-wave tables in global memory by the scalar unit (s_load_dwordx8 through the scalar data cache) and enter the
 // vector FMAs as SGPR operands.  Per correspondence the loop is straight arithmetic plus two compare / add-with-carry
 // pairs - no popcounts, no readlane broadcasts, no dependence on a scalar result - and every lane counts
-//   ub  the points NOT decided outliers = decided inliers + the points its fast test left undecided (its band, or a
-//       degenerate right-hand side),
-// while a wave-wide mask (scalar registers: SALU ORs of the compare results) remembers which lanes had an undecided
-// point at all.  A model with undecided points whose ub reaches thr is recounted by the exact path above; for every
-// other model ub is its exact count (nothing undecided) or an upper bound below thr - all the replay compares with.
+//   ub  the points that are NOT outliers beyond doubt = inliers + the points its fast test cannot decide (its band, or
+//       a degenerate right-hand side): an upper bound of the model's inlier count, and the count itself for all but
+//       the few models with a point inside the band.
+// That is all the replay compares with: a trial whose bound reaches the best count so far is re-scored in full there
+// (score<>, the reference residual), one whose bound stays below cannot have changed anything.
 
 // Sampson test in FP64 (fundamental / essential models): table = (x1, y1, x2, y2) doubles per correspondence.
-// ub = correspondences NOT decided outliers (decided inliers + undecided); the lane's bit of the returned mask is set
-// when it left a correspondence undecided.  The next record is requested before the current one is used, so the
+// ub = correspondences that are not outliers beyond doubt.  The next record is requested before the current one is used, so the
 // scalar-cache latency overlaps the arithmetic.
 struct F64Rec {
     double a, b, c, d;
@@ -1300,20 +1324,17 @@ __device__ __forceinline__ F64Rec f64_rec(const AMC_CONST double* tab, int k) {
     r.a = tab[4 * k]; r.b = tab[4 * k + 1]; r.c = tab[4 * k + 2]; r.d = tab[4 * k + 3];
     return r;
 }
-__device__ __forceinline__ void f64_count1(const double (&m)[9], const F64Rec& r, double T, int& ub, unsigned long long& undmask) {
-    bool in, amb;
-    fast_inlier<K_F7>(m, r.a, r.b, r.c, r.d, T, in, amb);
-    ub += (int)(in || amb);
-    undmask |= __ballot(amb);
+__device__ __forceinline__ void f64_count1(const double (&m)[9], const F64Rec& r, double T, int& ub) {
+    ub += (int)fast_not_outlier<K_F7>(m, r.a, r.b, r.c, r.d, T);
 }
-// correspondences [k0, k1) against the lane's model; ub / undmask are carried from segment to segment.  The records
+// correspondences [k0, k1) against the lane's model; ub (an upper bound of the inlier count) is carried from segment to segment.  The records
 // are requested a few 64-byte lines at a time (see count_lanes_h32 on why: one "all loads back" wait per batch).
 typedef double d8v __attribute__((ext_vector_type(8)));
 #ifndef AMC_F64_BATCH
 #define AMC_F64_BATCH 4   // 64-byte lines (2 correspondences each) requested together
 #endif
 __device__ __forceinline__ void count_lanes_f64(const double (&m)[9], const AMC_CONST double* tab, int k0, int k1, double T,
-                                                int& ub, unsigned long long& undmask) {
+                                                int& ub) {
     constexpr int kB = AMC_F64_BATCH;
     int k = k0;
     if ((k0 & 1) == 0) {  // (segments start on even correspondences: whole lines)
@@ -1327,12 +1348,12 @@ __device__ __forceinline__ void count_lanes_f64(const double (&m)[9], const AMC_
                 F64Rec r0, r1;
                 r0.a = q[j][0]; r0.b = q[j][1]; r0.c = q[j][2]; r0.d = q[j][3];
                 r1.a = q[j][4]; r1.b = q[j][5]; r1.c = q[j][6]; r1.d = q[j][7];
-                f64_count1(m, r0, T, ub, undmask);
-                f64_count1(m, r1, T, ub, undmask);
+                f64_count1(m, r0, T, ub);
+                f64_count1(m, r1, T, ub);
             }
         }
     }
-    for (; k < k1; ++k) f64_count1(m, f64_rec(tab, k), T, ub, undmask);
+    for (; k < k1; ++k) f64_count1(m, f64_rec(tab, k), T, ub);
 }
 // exact inlier count of one wave-uniform model over the correspondences [k0, M), lanes = correspondences
 template <int KIND>
@@ -1378,28 +1399,33 @@ __device__ __forceinline__ float fma_abs_f32(float a, float b, float c) {  // fm
     return r;
 }
 struct H32Splat {  // the lane's model with every coefficient in both halves of a register pair
-    v2f m[9], bS, cR, K1;
+    v2f m[9], qS, qR, qK;
 };
 __device__ __forceinline__ H32Splat h32_splat(const H32Lane& h) {
     H32Splat s;
 #pragma unroll
     for (int i = 0; i < 9; ++i) s.m[i] = (v2f){h.m[i], h.m[i]};
-    s.bS = (v2f){h.bS, h.bS};
-    s.cR = (v2f){h.cR, h.cR};
-    s.K1 = (v2f){h.K1, h.K1};
+    s.qS = (v2f){h.qS, h.qS};
+    s.qR = (v2f){h.qR, h.qR};
+    s.qK = (v2f){h.qK, h.qK};
     return s;
 }
-// h32_eval (tvg_math.h) on two correspondences: the same operations in the same order, so t and band are the
-// values that function returns for each of them
-__device__ __forceinline__ void h32_eval_pk(const H32Splat& h, v2f a, v2f b, v2f cs, v2f ds, v2f& t, v2f& band) {
+// h32_outlier_q (tvg_math.h) on two correspondences: the same operations in the same order
+__device__ __forceinline__ v2f h32_q_pk(const H32Splat& h, v2f a, v2f b, v2f cs, v2f ds) {
     const v2f p0 = pk_fma(h.m[0], a, pk_fma(h.m[1], b, h.m[2]));
     const v2f p1 = pk_fma(h.m[3], a, pk_fma(h.m[4], b, h.m[5]));
     const v2f w = pk_fma(h.m[6], a, pk_fma(h.m[7], b, h.m[8]));
     const v2f u = pk_fma(cs, w, -p0), v = pk_fma(ds, w, -p1);
     const v2f R = w * w;
     const v2f S = pk_fma(u, u, v * v);
-    t = S - R;
-    band = pk_fma(h.bS, S, pk_fma(h.cR, R, h.K1));
+    return pk_fma(h.qS, S, pk_fma(h.qR, R, h.qK));
+}
+// 1.0 where q > 0 (q >= 2^-100; a fraction below that), 0.0 where q <= 0 or NaN: the product clamped to [0, 1] by the
+// instruction's output modifier (DX10 clamp: NaN -> 0).  Summed, it counts the outliers beyond doubt - never too many.
+__device__ __forceinline__ v2f pk_step(v2f q, v2f big) {
+    v2f r;
+    asm("v_pk_mul_f32 %0, %1, %2 clamp" : "=v"(r) : "v"(q), "v"(big));
+    return r;
 }
 struct H32Rec {  // two correspondences of the pre-filter table
     v2f a, b, cs, ds;
@@ -1408,18 +1434,6 @@ __device__ __forceinline__ H32Rec h32_rec(const AMC_CONST v2f* tab, int k) {
     H32Rec r;
     r.a = tab[4 * k]; r.b = tab[4 * k + 1]; r.cs = tab[4 * k + 2]; r.ds = tab[4 * k + 3];
     return r;
-}
-__device__ __forceinline__ void h32_count2(const H32Splat& h, const H32Rec& r, bool both, int& ub, unsigned long long& undmask) {
-    v2f t, band;
-    h32_eval_pk(h, r.a, r.b, r.cs, r.ds, t, band);
-    const bool d0 = __builtin_fabsf(t.x) > band.x, d1 = __builtin_fabsf(t.y) > band.y;
-    if (both) {
-        ub += (int)!(d0 && !(t.x < 0.0f)) + (int)!(d1 && !(t.y < 0.0f));
-        undmask |= __ballot(!d0) | __ballot(!d1);
-    } else {
-        ub += (int)!(d0 && !(t.x < 0.0f));
-        undmask |= __ballot(!d0);
-    }
 }
 typedef float f16v __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ H32Rec h32_rec_of(const f16v& q, int half) {  // record `half` (0 / 1) of a 64-byte line
@@ -1431,10 +1445,11 @@ __device__ __forceinline__ H32Rec h32_rec_of(const f16v& q, int half) {  // reco
 #ifndef AMC_H32_BATCH
 #define AMC_H32_BATCH 5   // 64-byte lines (4 correspondences each) requested together
 #endif
-__device__ __forceinline__ unsigned long long count_lanes_h32(const H32Lane& hl, const AMC_CONST v2f* tab, int M, int& ub_out) {
+// Upper bound of the lane's model's inlier count: M minus the correspondences that are outliers beyond doubt.
+__device__ __forceinline__ int count_lanes_h32(const H32Lane& hl, const AMC_CONST v2f* tab, int M) {
     const H32Splat h = h32_splat(hl);
-    int ub = 0;
-    unsigned long long undmask = 0ull;
+    const v2f big = (v2f){0x1p100f, 0x1p100f};
+    v2f nout = (v2f){0.0f, 0.0f};
     const int np = M >> 1, last = ((M + 1) >> 1) - 1;  // full pairs; index of the table's last record
     // The table streams through the scalar cache once per chunk and misses it nearly always (every wave of the CU
     // walks a table of its own), and scalar loads return out of order - the only wait is "all of them".  So the
@@ -1449,14 +1464,21 @@ __device__ __forceinline__ unsigned long long count_lanes_h32(const H32Lane& hl,
         for (int j = 0; j < kB; ++j) q[j] = tabq[(k >> 1) + j];
 #pragma unroll
         for (int j = 0; j < kB; ++j) {
-            h32_count2(h, h32_rec_of(q[j], 0), true, ub, undmask);
-            h32_count2(h, h32_rec_of(q[j], 1), true, ub, undmask);
+            const H32Rec r0 = h32_rec_of(q[j], 0), r1 = h32_rec_of(q[j], 1);
+            nout += pk_step(h32_q_pk(h, r0.a, r0.b, r0.cs, r0.ds), big);
+            nout += pk_step(h32_q_pk(h, r1.a, r1.b, r1.cs, r1.ds), big);
         }
     }
-    for (; k < np; ++k) h32_count2(h, h32_rec(tab, k), true, ub, undmask);
-    if (M & 1) h32_count2(h, h32_rec(tab, last), false, ub, undmask);  // the last, unpaired correspondence (second half: a copy, not counted)
-    ub_out = ub;
-    return undmask;
+    for (; k < np; ++k) {
+        const H32Rec r = h32_rec(tab, k);
+        nout += pk_step(h32_q_pk(h, r.a, r.b, r.cs, r.ds), big);
+    }
+    float total = nout.x + nout.y;
+    if (M & 1) {  // the last, unpaired correspondence (the record's second half is a copy: not counted)
+        const H32Rec r = h32_rec(tab, last);
+        total += pk_step(h32_q_pk(h, r.a, r.b, r.cs, r.ds), big).x;
+    }
+    return M - (int)total;  // (sums of 0 / 1 below 2^24 are exact; a fractional step only raises the bound)
 }
 
 // the models of an F / E chunk (global table, nmod per trial) by the lanes-as-models loop: the valid models are listed
@@ -1493,7 +1515,6 @@ __device__ __forceinline__ int count_models_f64(const double* models, int nmod, 
         // than to keep 64 lanes streaming for them.  A model that dropped out reports ub + (all it has not seen),
         // an upper bound below thr.
         int ub = 0;
-        unsigned long long und = 0ull;
 #ifndef AMC_CNT_SEG
 #define AMC_CNT_SEG 64
 #endif
@@ -1503,7 +1524,7 @@ __device__ __forceinline__ int count_models_f64(const double* models, int nmod, 
         constexpr int kSeg = AMC_CNT_SEG, kFewAlive = AMC_CNT_FEW;
         for (int k0 = 0; k0 < M; k0 += kSeg) {
             const int k1 = min(k0 + kSeg, M);
-            count_lanes_f64(mm, tab, k0, k1, max_res, ub, und);
+            count_lanes_f64(mm, tab, k0, k1, max_res, ub);
             if (k1 < M) {
                 unsigned long long alive = __ballot(valid && ub + (M - k1) >= thr);
                 if (__popcll(alive) <= kFewAlive) {
@@ -1521,16 +1542,6 @@ __device__ __forceinline__ int count_models_f64(const double* models, int nmod, 
                     break;
                 }
             }
-        }
-        unsigned long long redo = __ballot(valid && ub >= thr) & und;
-        while (redo) {  // practically never: a point of a near-threshold model inside the fast test's band
-            const int src_lane = (int)__builtin_ctzll(redo);
-            redo &= redo - 1;
-            double sm[9];
-#pragma unroll
-            for (int i = 0; i < 9; ++i) sm[i] = readlane_f64(mm[i], src_lane);
-            const int c = count_model_exact<K_F7>(sm, P, M, max_res, lane, thr);
-            if (lane == src_lane) ub = c;
         }
         if (valid) __hip_atomic_fetch_max(&tmax[t], ub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
     }
@@ -1739,18 +1750,7 @@ __device__ __noinline__ void count_chunk(ChunkModels* io, const CountCtx cc_, in
     } else if (EST == K_H) {
         const double s = 1.0 / dsqrt(max_res);
         const H32Lane hl = h32_prepare(mym, s, cmax);
-        int ub;
-        const unsigned long long und = count_lanes_h32(hl, as_const_table(reinterpret_cast<const v2f*>(uni_ptr(cc_.p32))), M, ub);
-        unsigned long long redo = __ballot(nmod > 0 && ub >= thr) & und;
-        while (redo) {  // a model near the best count with points the FP32 test could not decide: FP64, exactly
-            const int src_lane = (int)__builtin_ctzll(redo);
-            redo &= redo - 1;
-            double sm[9];
-#pragma unroll
-            for (int i = 0; i < 9; ++i) sm[i] = readlane_f64(mym[i], src_lane);
-            const int c = count_model_exact<K_H>(sm, P, M, max_res, lane, thr);
-            if (lane == src_lane) ub = c;
-        }
+        const int ub = count_lanes_h32(hl, as_const_table(reinterpret_cast<const v2f*>(uni_ptr(cc_.p32))), M);
         maxcnt = nmod > 0 ? ub : -1;
     } else {
         maxcnt = count_models_f64(models, nmod, uni_ptr(cc_.p64), P, M, max_res, nT, lane, thr, uni_lds(cc_.mlist),

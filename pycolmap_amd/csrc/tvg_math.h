@@ -1024,6 +1024,7 @@ struct H32Model {
     float m[9];
     float kE, kW, K0;   // the reference bound (h32_band_ref: tests compare the loop's bound against it)
     float bS, cR, K1;   // the loop's bound
+    float qS, qR, qK;   // the same test folded into one expression: q = qS S32 + qR R32 + qK > 0  =>  t32 - band > 0
 };
 AMC_HD float f32_up(double v) {  // a float >= v (v >= 0)
     return (float)(v * (1.0 + 1e-6));
@@ -1052,6 +1053,11 @@ AMC_HD H32Model h32_prepare(const double* model, double s, double C) {
     h.bS = (float)bs;
     h.cR = f32_up((4.2e-7 + b0) * 1.0001);
     h.K1 = f32_up((K0 + kE * kE / (2.0 * b0) + kW * kW / (4.0 * b0)) * 1.0001);
+    // q > 0 is meant to imply S32 - R32 > band + (rounding of q itself): 1e-6 of slack on every coefficient covers the
+    // three roundings of the folded expression (<= 3 x 2^-24 of the largest term)
+    h.qS = (float)((1.0 - (double)h.bS) * (1.0 - 1e-6));
+    h.qR = -f32_up((1.0 + (double)h.cR) * (1.0 + 1e-6));
+    h.qK = -f32_up((double)h.K1 * (1.0 + 1e-6));
     return h;
 }
 // t = u'^2 + v'^2 - w^2 and the bound on its error, for one point (V = float) or for two at once (V = a two-float
@@ -1071,6 +1077,20 @@ AMC_HD void h32_eval(const H32Model& h, V a, V b, V cs, V ds, V& t, V& band) {
     const V S = Ops::fma(u, u, v * v);
     t = S - R;
     band = Ops::fma(Ops::splat(h.bS), S, Ops::fma(Ops::splat(h.cR), R, Ops::splat(h.K1)));
+}
+// The counting loop only needs an UPPER bound of a model's inlier count (a model whose bound reaches the best count so
+// far is re-scored exactly anyway), i.e. the points that are outliers beyond doubt: q > 0 with
+//   q = qS S32 + qR R32 + qK,  qS <= 1 - bS,  qR <= -(1 + cR),  qK <= -K1   =>   t32 > band, an outlier by h32_eval.
+// NaN / inf make q NaN or -inf: not an outlier beyond doubt.
+template <class V, class Ops>
+AMC_HD V h32_outlier_q(const H32Model& h, V a, V b, V cs, V ds) {
+    const V p0 = Ops::fma(Ops::splat(h.m[0]), a, Ops::fma(Ops::splat(h.m[1]), b, Ops::splat(h.m[2])));
+    const V p1 = Ops::fma(Ops::splat(h.m[3]), a, Ops::fma(Ops::splat(h.m[4]), b, Ops::splat(h.m[5])));
+    const V w = Ops::fma(Ops::splat(h.m[6]), a, Ops::fma(Ops::splat(h.m[7]), b, Ops::splat(h.m[8])));
+    const V u = Ops::fma(cs, w, -p0), v = Ops::fma(ds, w, -p1);
+    const V R = w * w;
+    const V S = Ops::fma(u, u, v * v);
+    return Ops::fma(Ops::splat(h.qS), S, Ops::fma(Ops::splat(h.qR), R, Ops::splat(h.qK)));
 }
 // the reference bound of the same point (the right-hand side of the inequality above)
 AMC_HD float h32_band_ref(const H32Model& h, float a, float b, float cs, float ds) {

@@ -175,6 +175,7 @@ def test_fp32_homography_prefilter_never_contradicts_the_reference(shim):
     rng = np.random.default_rng(17)
     decided = undecided = 0
     bands_ratio = []
+    n_sure = n_out = 0
     for trial in range(400):
         n = 256
         style = trial % 5
@@ -220,6 +221,10 @@ def test_fp32_homography_prefilter_never_contradicts_the_reference(shim):
         assert np.all(band[fin] >= band_ref[fin]), "the loop's bound must cover the reference bound of the error analysis"
         if style in (0, 2):                          # tame models: the cheaper bound stays within a few times the reference
             bands_ratio.append(float(np.median(band[fin] / band_ref[fin])))
+        qv = np.zeros(n, dtype=np.float32)
+        shim.shim_h32_q(_p(Hc), C.c_double(max_res), _p(p1c), _p(p2c), n, _p(qv))
+        sure_out = qv > 0                            # the counting loop's "outlier beyond doubt"
+        assert not (sure_out & want).any() and not (sure_out & (got != 0)).any()
         dec = got >= 0
         wrong = dec & ((got == 1) != want)
         assert not wrong.any(), f"trial {trial} style {style}: FP32 decided {got[wrong][:4]} against residuals {res[wrong][:4]} (max {max_res})"
@@ -227,10 +232,13 @@ def test_fp32_homography_prefilter_never_contradicts_the_reference(shim):
         if style in (0, 4) and abs(np.log10(np.abs(H).max())) < 2:
             # tame models: everything 5 % away from the circle is decided
             assert dec[off_circle & np.isfinite(res)].mean() > 0.98
+            clear = off_circle & np.isfinite(res) & ~want
+            n_sure += int(sure_out[clear].sum()); n_out += int(clear.sum())
         decided += int(dec.sum())
         undecided += int((~dec).sum())
     assert decided > undecided               # (a third of the points sit on the circle by construction)
     assert np.median(bands_ratio) < 4.0
+    assert n_sure > 0.98 * n_out > 0             # and it recognises nearly every outlier
 
 
 def test_closed_form_h4_on_degenerate_samples_against_the_svd_dlt(shim):
