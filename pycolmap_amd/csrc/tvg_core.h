@@ -959,7 +959,7 @@ __device__ __noinline__ int e5_models_wave(const double* nsp, const E5Polys& P, 
 // Diagnostic build (-DAMC_TVG_LODIAG, tools/variant_build_tvg.sh): shader-clock cycles of the stages of the local
 // estimators, summed over all waves (lane 0 adds); printed by the host with AMC_TVG_PROFILE=1.
 #if defined(AMC_TVG_LODIAG)
-__device__ unsigned long long g_lo_diag[48];
+__device__ unsigned long long g_lo_diag[64];   // 48 .. 55: stages of the minimal 5-point chunk
 #define LODIAG_T0() unsigned long long lodiag_t_ = __builtin_readcyclecounter()
 #define LODIAG_LAP(slot) do { const unsigned long long n_ = __builtin_readcyclecounter(); \
                               if (lane == 0) atomicAdd(&g_lo_diag[slot], n_ - lodiag_t_); lodiag_t_ = n_; } while (0)
@@ -1671,6 +1671,8 @@ __device__ __noinline__ void solve_chunk(ChunkModels* out, const Pts P_, const l
         // roots of the 64 determinant polynomials by the whole wave (real_roots10_lanes), the models per lane; the
         // same functions in the same order, so the same bits as the per-lane call
         const bool have = lane < nT;
+        LODIAG_T0();
+        LODIAG_COUNT(48);
         double nsp[4 * 9];
         E5Polys polys;
 #pragma unroll
@@ -1695,8 +1697,10 @@ __device__ __noinline__ void solve_chunk(ChunkModels* out, const Pts P_, const l
             e5_constraint_rows(nsp, sink);
         }
         wave_mem_sync();
+        LODIAG_LAP(49);
         e5_eliminate_quads(models, nT, lane);
         wave_mem_sync();
+        LODIAG_LAP(50);
         if (have) {
             double hl[6][10];
 #pragma unroll
@@ -1706,11 +1710,14 @@ __device__ __noinline__ void solve_chunk(ChunkModels* out, const Pts P_, const l
             e5_finish(hl, polys);
         }
         wave_mem_sync();  // (the model region is rewritten with the models below)
+        LODIAG_LAP(51);
         double roots[10];
         const bool full = have && polys.det[10] != 0.0;
         int nr = real_roots10_lanes(polys.det, roots, full, lane, rootscr);
         if (have && !full) nr = real_roots_t<10>(polys.det, roots);  // a vanishing leading coefficient: the plain chain
+        LODIAG_LAP(52);
         if (have) nmod = e5_models(nsp, polys, roots, nr, models + (size_t)lane * kMaxModels * 9);
+        LODIAG_LAP(53);
     }
     wave_mem_sync();
 #pragma unroll

@@ -163,8 +163,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(kTvgEWavesP
 
 #if defined(AMC_TVG_LODIAG)
 void tvg_diag_report_e() {
-    unsigned long long h[48];
+    unsigned long long h[64];
     if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_lo_diag), sizeof h) != hipSuccess) return;
+    if (h[48]) std::fprintf(stderr, "[amc tvg lodiag] minimal 5-point chunks %llu: cycles per chunk rows %.0f, elimination %.0f, finish %.0f, roots %.0f, models %.0f\n", h[48],
+                            (double)h[49] / h[48], (double)h[50] / h[48], (double)h[51] / h[48], (double)h[52] / h[48], (double)h[53] / h[48]);
     std::fprintf(stderr, "[amc tvg lodiag tvg_diag_report_e] local 5-point solves %llu: cycles per solve ata %.0f jacobi %.0f build %.0f roots %.0f models %.0f | "
                  "8-point solves %llu: ata %.0f jacobi %.0f finish %.0f | DLT solves %llu: ata %.0f jacobi %.0f finish %.0f\n",
                  h[0], (double)h[1] / (h[0] ? h[0] : 1), (double)h[2] / (h[0] ? h[0] : 1), (double)h[3] / (h[0] ? h[0] : 1),
@@ -179,7 +181,7 @@ void tvg_diag_report_e() {
                      nm[k], q[0], (double)q[1] / q[0], (double)q[2] / q[0], (double)q[3] / q[0], q[3] ? (double)q[4] / q[3] : 0.0, (double)q[5] / q[0],
                      (double)q[6] / q[0], (double)q[7] / q[0]);
     }
-    unsigned long long z[48] = {};
+    unsigned long long z[64] = {};
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lo_diag), z, sizeof z);
 }
 #else
