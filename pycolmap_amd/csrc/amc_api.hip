@@ -1479,6 +1479,8 @@ static int verify_impl(amc_ctx* c, int mode, const uint32_t* slot1, const uint32
         P.force_slow_sampler = (e && e[0] == '1') ? 1 : 0;
         const char* e2 = std::getenv("AMC_TVG_EXACT_COUNT");
         P.no_fast_count = (e2 && e2[0] == '1') ? 1 : 0;
+        const char* e3 = std::getenv("AMC_TVG_NO_S32");
+        P.no_fast32 = (e3 && e3[0] == '1') ? 1 : 0;
         P.mode = mode;
         P.bad_index_count = c->d_scalars + 2;
     }

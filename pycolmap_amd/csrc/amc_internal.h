@@ -252,6 +252,7 @@ struct TvgParams {
         watermark_border_size, max_error;
     int32_t force_slow_sampler;  // test hook (AMC_TVG_SLOW_SAMPLER=1): draw-by-draw sampler path only
     int32_t no_fast_count;       // test hook (AMC_TVG_EXACT_COUNT=1): no division-free test in the counting loop
+    int32_t no_fast32;           // test hook (AMC_TVG_NO_S32=1): no FP32 Sampson pre-filter in the F / E counting loops
     int32_t mode;                // 0: EstimateTwoViewGeometry; 1 / 2 / 3: a single F / H / E LO-RANSAC
     uint32_t* bad_index_count;   // += 1 per pair whose matches index past an image's keypoints (the pair is skipped)
     // dyn_max_num_trials of the watermark (translation, 1-point) RANSAC.  Its sample count is the pair's inlier

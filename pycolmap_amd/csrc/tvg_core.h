@@ -1481,11 +1481,73 @@ __device__ __forceinline__ int count_lanes_h32(const H32Lane& hl, const AMC_CONS
     return M - (int)total;  // (sums of 0 / 1 below 2^24 are exact; a fractional step only raises the bound)
 }
 
+// ---- Sampson outliers in packed FP32 (tvg_math.h s32_outlier_q), two correspondences per instruction -----------------
+struct S32Splat {
+    v2f m[9], qS, qR, qK;
+};
+__device__ __forceinline__ S32Splat s32_splat(const S32Model& h) {
+    S32Splat s;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) s.m[i] = (v2f){h.m[i], h.m[i]};
+    s.qS = (v2f){h.qS, h.qS};
+    s.qR = (v2f){h.qR, h.qR};
+    s.qK = (v2f){h.qK, h.qK};
+    return s;
+}
+__device__ __forceinline__ v2f s32_q_pk(const S32Splat& h, v2f a, v2f b, v2f c, v2f d) {
+    const v2f e0 = pk_fma(h.m[0], a, pk_fma(h.m[1], b, h.m[2]));
+    const v2f e1 = pk_fma(h.m[3], a, pk_fma(h.m[4], b, h.m[5]));
+    const v2f e2 = pk_fma(h.m[6], a, pk_fma(h.m[7], b, h.m[8]));
+    const v2f t0 = pk_fma(h.m[0], c, pk_fma(h.m[3], d, h.m[6]));
+    const v2f t1 = pk_fma(h.m[1], c, pk_fma(h.m[4], d, h.m[7]));
+    const v2f cc = pk_fma(c, e0, pk_fma(d, e1, e2));
+    const v2f Lq = cc * cc;
+    const v2f den = pk_fma(e0, e0, pk_fma(e1, e1, pk_fma(t0, t0, t1 * t1)));
+    return pk_fma(h.qS, Lq, pk_fma(h.qR, den, h.qK));
+}
+#ifndef AMC_S32_BATCH
+#define AMC_S32_BATCH 4
+#endif
+// correspondences [k0, k1) (k0 even) against the lane's model: ub += those that are not outliers beyond doubt
+__device__ __forceinline__ void count_lanes_s32(const S32Splat& h, const AMC_CONST v2f* tab, int k0, int k1, int& ub) {
+    const v2f big = (v2f){0x1p100f, 0x1p100f};
+    v2f nout = (v2f){0.0f, 0.0f};
+    constexpr int kB = AMC_S32_BATCH;
+    const AMC_CONST f16v* tabq = reinterpret_cast<const AMC_CONST f16v*>(tab);
+    const int r1 = k1 >> 1;  // records [k0 / 2, r1) hold two counted correspondences each
+    int r = k0 >> 1;
+    if ((r & 1) == 0) {
+        for (; r + 2 * kB <= r1; r += 2 * kB) {
+            f16v q[kB];
+#pragma unroll
+            for (int j = 0; j < kB; ++j) q[j] = tabq[(r >> 1) + j];
+#pragma unroll
+            for (int j = 0; j < kB; ++j) {
+                const H32Rec x0 = h32_rec_of(q[j], 0), x1 = h32_rec_of(q[j], 1);
+                nout += pk_step(s32_q_pk(h, x0.a, x0.b, x0.cs, x0.ds), big);
+                nout += pk_step(s32_q_pk(h, x1.a, x1.b, x1.cs, x1.ds), big);
+            }
+        }
+    }
+    for (; r < r1; ++r) {
+        const H32Rec x = h32_rec(tab, r);
+        nout += pk_step(s32_q_pk(h, x.a, x.b, x.cs, x.ds), big);
+    }
+    float total = nout.x + nout.y;
+    if (k1 & 1) {  // the last, unpaired correspondence (the record's second half is a copy: not counted)
+        const H32Rec x = h32_rec(tab, r1);
+        total += pk_step(s32_q_pk(h, x.a, x.b, x.cs, x.ds), big).x;
+    }
+    ub += (k1 - k0) - (int)total;
+}
+
 // the models of an F / E chunk (global table, nmod per trial) by the lanes-as-models loop: the valid models are listed
 // in (trial, root) order, 64 of them are counted at a time, and the largest count of a trial's models is collected in
 // LDS (tmax).  Returns lane t's maxcnt.
-__device__ __forceinline__ int count_models_f64(const double* models, int nmod, const double* p64, const Pts& P, int M,
-                                                double max_res, int nT, int lane, int thr, lds_u16* mlist, lds_i32* tmax) {
+template <bool S32>
+__device__ __forceinline__ int count_models_lanes(const double* models, int nmod, const double* p64, const float* p32, const Pts& P,
+                                                  int M, double max_res, double cmax, int nT, int lane, int thr, lds_u16* mlist,
+                                                  lds_i32* tmax) {
     // exclusive prefix of nmod over the lanes
     int incl = nmod;
 #pragma unroll
@@ -1499,6 +1561,7 @@ __device__ __forceinline__ int count_models_f64(const double* models, int nmod, 
     tmax[lane] = -1;
     wave_lds_sync();
     const AMC_CONST double* tab = as_const_table(p64);
+    const AMC_CONST v2f* tab32 = as_const_table(reinterpret_cast<const v2f*>(p32));
     for (int g0 = 0; g0 < total; g0 += 64) {
         const int idx = g0 + lane;
         const bool valid = idx < total;
@@ -1522,9 +1585,12 @@ __device__ __forceinline__ int count_models_f64(const double* models, int nmod, 
 #define AMC_CNT_FEW 6
 #endif
         constexpr int kSeg = AMC_CNT_SEG, kFewAlive = AMC_CNT_FEW;
+        S32Splat hs;
+        if (S32) hs = s32_splat(s32_prepare(mm, max_res, cmax));
         for (int k0 = 0; k0 < M; k0 += kSeg) {
             const int k1 = min(k0 + kSeg, M);
-            count_lanes_f64(mm, tab, k0, k1, max_res, ub);
+            if (S32) count_lanes_s32(hs, tab32, k0, k1, ub);
+            else count_lanes_f64(mm, tab, k0, k1, max_res, ub);
             if (k1 < M) {
                 unsigned long long alive = __ballot(valid && ub + (M - k1) >= thr);
                 if (__popcll(alive) <= kFewAlive) {
@@ -1759,9 +1825,12 @@ __device__ __noinline__ void count_chunk(ChunkModels* io, const CountCtx cc_, in
         const H32Lane hl = h32_prepare(mym, s, cmax);
         const int ub = count_lanes_h32(hl, as_const_table(reinterpret_cast<const v2f*>(uni_ptr(cc_.p32))), M);
         maxcnt = nmod > 0 ? ub : -1;
+    } else if (uni(cc_.fast) == 2) {
+        maxcnt = count_models_lanes<true>(models, nmod, uni_ptr(cc_.p64), uni_ptr(cc_.p32), P, M, max_res, cmax, nT, lane, thr,
+                                          uni_lds(cc_.mlist), uni_lds(cc_.tmax));
     } else {
-        maxcnt = count_models_f64(models, nmod, uni_ptr(cc_.p64), P, M, max_res, nT, lane, thr, uni_lds(cc_.mlist),
-                                  uni_lds(cc_.tmax));
+        maxcnt = count_models_lanes<false>(models, nmod, uni_ptr(cc_.p64), uni_ptr(cc_.p32), P, M, max_res, cmax, nT, lane, thr,
+                                           uni_lds(cc_.mlist), uni_lds(cc_.tmax));
     }
     io->maxcnt = maxcnt;
     io->cyc_count = __builtin_readcyclecounter() - c1;
@@ -1782,6 +1851,7 @@ struct RansacCfg {
     const double* wm_cut;    // K_T only: inlier-ratio cut-offs by trial count (TvgParams::wm_cut), max_trials + 1 entries
     int force_slow_sampler;  // test hook: always take the draw-by-draw sampler path
     int no_fast_count;       // test hook (AMC_TVG_EXACT_COUNT=1): the counting loops evaluate the reference residual only
+    int no_fast32;           // test hook (AMC_TVG_NO_S32=1): the F / E counting loops stay in FP64
 };
 
 // LORANSAC<EST, LOCAL>::Estimate over the M correspondences in the four arrays at gx (x1 | y1 | x2 | y2, each gstride
@@ -1827,9 +1897,13 @@ __device__ Report lo_ransac(Wave& w_io, const RansacCfg& cfg, const double* gx, 
             if (EST == K_H) {
                 float* q = p32 + 8 * (size_t)(k >> 1) + (k & 1);
                 q[0] = (float)p0; q[2] = (float)p1; q[4] = (float)(p2 * s); q[6] = (float)(p3 * s);
-            } else if (EST != K_T && k < M) {
-                double* q = p64 + 4 * (size_t)k;
-                q[0] = p0; q[1] = p1; q[2] = p2; q[3] = p3;
+            } else if (EST != K_T) {
+                float* q = p32 + 8 * (size_t)(k >> 1) + (k & 1);   // the Sampson pre-filter's table: plain coordinates
+                q[0] = (float)p0; q[2] = (float)p1; q[4] = (float)p2; q[6] = (float)p3;
+                if (k < M) {
+                    double* q64 = p64 + 4 * (size_t)k;
+                    q64[0] = p0; q64[1] = p1; q64[2] = p2; q64[3] = p3;
+                }
             }
             amax = dmax(dmax(amax, dmax(dabs(p0), dabs(p1))), dmax(dabs(p2), dabs(p3)));
         }
@@ -1838,6 +1912,9 @@ __device__ Report lo_ransac(Wave& w_io, const RansacCfg& cfg, const double* gx, 
         // the division-free counting test is trusted only while (largest coordinate / max_error) <= 1e5 (see
         // fast_inlier); a NaN coordinate leaves amax as it was or NaN - either way the comparison below decides
         fast_count = (cfg.no_fast_count == 0 && amax * amax <= 1e10 * cfg.max_res) ? 1 : 0;
+        // ... and the FP32 Sampson pre-filter (s32_outlier_q) is worth its pass while its band stays within ~1 % of
+        // the threshold: (largest coordinate / max_error) <= 1e4.  Beyond that the FP64 loop counts.
+        if (EST != K_H && fast_count && amax * amax <= 1e8 * cfg.max_res && cfg.no_fast32 == 0) fast_count = 2;
         cmax = amax;
         LODIAG_LAP(kDiagBase + 1);
         if (EST != K_T) scalar_table_sync();

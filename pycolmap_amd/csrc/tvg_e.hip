@@ -93,6 +93,7 @@ __device__ __noinline__ void process_pair_e(Wave& w, uint32_t q, const TvgImage*
     cfg.min_trials = P.min_num_trials;
     cfg.force_slow_sampler = P.force_slow_sampler;
     cfg.no_fast_count = P.no_fast_count;
+    cfg.no_fast32 = P.no_fast32;
     // E threshold: (cam1.CamFromImgThreshold(e) + cam2.CamFromImgThreshold(e)) / 2
     const double e_err = (cam::cam_from_img_threshold(pim1->cam.model_id, pim1->cam.params, P.max_error) +
                           cam::cam_from_img_threshold(pim2->cam.model_id, pim2->cam.params, P.max_error)) / 2;

@@ -111,6 +111,7 @@ __device__ __noinline__ void process_pair_fh(Wave& w, uint32_t q, const TvgImage
     cfg.min_trials = P.min_num_trials;
     cfg.force_slow_sampler = P.force_slow_sampler;
     cfg.no_fast_count = P.no_fast_count;
+    cfg.no_fast32 = P.no_fast32;
     if (run_F) {
         cfg.max_res = P.max_error * P.max_error;
         cfg.max_trials = P.max_trials[1];

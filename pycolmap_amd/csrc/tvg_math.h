@@ -1111,6 +1111,60 @@ AMC_HD int h32_point(const H32Model& h, float a, float b, float cs, float ds) {
     return t < 0.0f ? 1 : 0;
 }
 
+// ---- Sampson outliers in FP32, with a bound on the evaluation's own error -----------------------------------------
+// The counting loop of the fundamental / essential RANSACs needs, like the homography one, only an upper bound of a
+// model's inlier count: the correspondences that are outliers beyond doubt.  With u = 2^-24, C = largest |coordinate|
+// of the pair, M the FP64 model, (A, B), (C', D') a correspondence, and in exact arithmetic
+//   E1_k = M_k0 A + M_k1 B + M_k2,  T2_k = M_0k C' + M_1k D' + M_2k,  cc = C' E1_0 + D' E1_1 + E1_2,
+//   den = E1_0^2 + E1_1^2 + T2_0^2 + T2_1^2                       (the point is an outlier iff cc^2 > T den),
+// the FP32 evaluation below (operands rounded to float, one rounding per fused multiply-add) satisfies
+//   |e1_k - E1_k| <= 4.01 u Ah_k,  Ah_k = (|M_k0| + |M_k1|) C + |M_k2|     (likewise t2_k with Bh_k)
+//   |cc32 - cc|   <= Ec = 8 u (C (Ah_0 + Ah_1) + Ah_2)
+//   |den32 - den| <= 8.03 u Dh + 4.1 u den32,  Dh = Ah_0^2 + Ah_1^2 + Bh_0^2 + Bh_1^2
+// and, since (|x| - E)^2 >= (1 - beta) x^2 - E^2 (1 / beta - 1)  (2 E |x| <= beta x^2 + E^2 / beta),
+//   q = qS Lq32 + qR den32 + qK > 0,   Lq32 = fl(cc32^2),
+//   qS <= (1 - beta)(1 - u),  qR <= -T (1 + 1e-7)(1 + 4.1 u),  qK <= -(Ec^2 (1 / beta - 1) + T (1 + 1e-7) 8.03 u Dh)
+// implies cc^2 > T (1 + 1e-7) den: an outlier for the reference's FP64 residual as well (when q > 0, |cc| exceeds
+// 16 Ec ~ 7.6e-6 x the sum of the magnitudes of its terms, so the FP64 evaluation is good to ~1e-11 - far inside the
+// 1e-7 margin).  beta = 2^-8; every coefficient carries 1e-6 of slack for the three roundings of q itself.  NaN / inf
+// anywhere make q NaN or -inf: not an outlier beyond doubt.  A model FP32 cannot resolve (Ec^2 / beta beyond T den)
+// simply decides nothing.
+struct S32Model {
+    float m[9];
+    float qS, qR, qK;
+};
+AMC_HD S32Model s32_prepare(const double* model, double T, double C) {
+    const double U = 5.9604644775390625e-08;  // 2^-24
+    const double* M = model;
+    const double A0 = (dabs(M[0]) + dabs(M[1])) * C + dabs(M[2]);
+    const double A1 = (dabs(M[3]) + dabs(M[4])) * C + dabs(M[5]);
+    const double A2 = (dabs(M[6]) + dabs(M[7])) * C + dabs(M[8]);
+    const double B0 = (dabs(M[0]) + dabs(M[3])) * C + dabs(M[6]);
+    const double B1 = (dabs(M[1]) + dabs(M[4])) * C + dabs(M[7]);
+    const double Ec = 8.0 * U * (C * (A0 + A1) + A2);
+    const double Dh = A0 * A0 + A1 * A1 + B0 * B0 + B1 * B1;
+    const double beta = 0.00390625;  // 2^-8
+    const double Tq = T * (1.0 + 1e-7);
+    S32Model h;
+    for (int i = 0; i < 9; ++i) h.m[i] = (float)M[i];
+    h.qS = (float)((1.0 - beta) * (1.0 - U) * (1.0 - 1e-6));
+    h.qR = -f32_up(Tq * (1.0 + 4.1 * U) * (1.0 + 1e-6));
+    h.qK = -f32_up((Ec * Ec * (1.0 / beta - 1.0) + Tq * 8.03 * U * Dh) * (1.0 + 1e-6) + 1e-30);
+    return h;
+}
+template <class V, class Ops>
+AMC_HD V s32_outlier_q(const S32Model& h, V a, V b, V c, V d) {
+    const V e0 = Ops::fma(Ops::splat(h.m[0]), a, Ops::fma(Ops::splat(h.m[1]), b, Ops::splat(h.m[2])));
+    const V e1 = Ops::fma(Ops::splat(h.m[3]), a, Ops::fma(Ops::splat(h.m[4]), b, Ops::splat(h.m[5])));
+    const V e2 = Ops::fma(Ops::splat(h.m[6]), a, Ops::fma(Ops::splat(h.m[7]), b, Ops::splat(h.m[8])));
+    const V t0 = Ops::fma(Ops::splat(h.m[0]), c, Ops::fma(Ops::splat(h.m[3]), d, Ops::splat(h.m[6])));
+    const V t1 = Ops::fma(Ops::splat(h.m[1]), c, Ops::fma(Ops::splat(h.m[4]), d, Ops::splat(h.m[7])));
+    const V cc = Ops::fma(c, e0, Ops::fma(d, e1, e2));
+    const V Lq = cc * cc;
+    const V den = Ops::fma(e0, e0, Ops::fma(e1, e1, Ops::fma(t0, t0, t1 * t1)));
+    return Ops::fma(Ops::splat(h.qS), Lq, Ops::fma(Ops::splat(h.qR), den, Ops::splat(h.qK)));
+}
+
 // ---- mt19937 tempering + libstdc++ uniform_int_distribution<uint32_t> (Lemire) ------------------
 AMC_HD uint32_t mt_temper(uint32_t y) {
     y ^= (y >> 11);

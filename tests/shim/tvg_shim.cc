@@ -58,6 +58,17 @@ void shim_h32_q(const double* model, double max_res, const double* p1, const dou
     for (int i = 0; i < n; ++i)
         q[i] = h32_outlier_q<float, H32Ops>(h, (float)p1[2 * i], (float)p1[2 * i + 1], (float)(p2[2 * i] * s), (float)(p2[2 * i + 1] * s));
 }
+// the FP32 Sampson outlier test of every point (tvg_math.h s32_outlier_q): q
+void shim_s32_q(const double* model, double max_res, const double* p1, const double* p2, int n, float* q) {
+    double C = 0.0;
+    for (int i = 0; i < n; ++i) {
+        C = dmax(C, dmax(dabs(p1[2 * i]), dabs(p1[2 * i + 1])));
+        C = dmax(C, dmax(dabs(p2[2 * i]), dabs(p2[2 * i + 1])));
+    }
+    const S32Model h = s32_prepare(model, max_res, C);
+    for (int i = 0; i < n; ++i)
+        q[i] = s32_outlier_q<float, H32Ops>(h, (float)p1[2 * i], (float)p1[2 * i + 1], (float)p2[2 * i], (float)p2[2 * i + 1]);
+}
 // the loop's bound and the reference bound of every point (tvg_math.h: h32_eval's band >= h32_band_ref)
 void shim_h32_bands(const double* model, double max_res, const double* p1, const double* p2, int n, float* band, float* band_ref) {
     double C = 0.0;

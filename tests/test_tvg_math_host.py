@@ -241,6 +241,77 @@ def test_fp32_homography_prefilter_never_contradicts_the_reference(shim):
     assert n_sure > 0.98 * n_out > 0             # and it recognises nearly every outlier
 
 
+def test_fp32_sampson_prefilter_never_calls_an_inlier_an_outlier(shim):
+    """tvg_math.h s32_outlier_q: the F / E counting loops drop a correspondence from a model's count only when q > 0.
+    Whatever it drops must be an outlier by the reference residual sampson(...) <= max_error^2 - for the true model,
+    minimal models of contaminated samples and wild matrices, in pixel coordinates (F) and normalised ones (E), with
+    points scattered, on the inlier side and within 1e-9 .. 1e-3 of the threshold - and on tame models it must drop
+    nearly every clear outlier."""
+    rng = np.random.default_rng(23)
+    n_sure = n_clear = 0
+    for trial in range(300):
+        sc, p1, p2 = scene_points(1000 + trial, num_inliers=120, num_outliers=136, noise=0.5)
+        n = len(p1)
+        normalised = trial % 2 == 1
+        if normalised:
+            Kinv = np.linalg.inv(sc["K"])
+            p1 = (np.c_[p1, np.ones(n)] @ Kinv.T)[:, :2]
+            p2 = (np.c_[p2, np.ones(n)] @ Kinv.T)[:, :2]
+            max_res = float(rng.choice([1.0, 4.0, 16.0])) / sc["K"][0, 0] ** 2
+        else:
+            max_res = float(rng.choice([0.25, 1.0, 16.0, 16.0, 100.0]))
+        style = (trial // 2) % 4
+        tame = style == 0
+        if style == 0:
+            Mx = sc["E_true"] if normalised else sc["F_true"]
+            Mx = Mx / np.linalg.norm(Mx) if normalised else Mx / Mx[2, 2]
+        elif style == 1:      # a minimal model of a random (mostly contaminated) sample
+            if normalised:
+                idx = rng.choice(n, 5, replace=False)
+                out = np.zeros((10, 9))
+                k = shim.shim_estimate_e5(_p(np.ascontiguousarray(p1[idx])), _p(np.ascontiguousarray(p2[idx])), _p(out))
+            else:
+                idx = rng.choice(n, 7, replace=False)
+                out = np.zeros((3, 9))
+                k = shim.shim_estimate_f7(_p(np.ascontiguousarray(p1[idx])), _p(np.ascontiguousarray(p2[idx])), _p(out))
+            if k == 0:
+                continue
+            Mx = out[int(rng.integers(k))].reshape(3, 3)
+        elif style == 2:
+            Mx = rng.normal(size=(3, 3)) * 10.0 ** rng.uniform(-6, 6, size=(3, 3))
+        else:
+            Mx = (sc["E_true"] if normalised else sc["F_true"]) * 10.0 ** rng.uniform(-30, 30)
+        # a third of the image-2 points moved onto the threshold (along the epipolar line's normal), +- a hair
+        p1 = np.ascontiguousarray(p1.astype(np.float32).astype(np.float64))
+        p2 = p2.copy()
+        l = np.c_[p1, np.ones(n)] @ Mx.T
+        nrm = np.hypot(l[:, 0], l[:, 1])
+        with np.errstate(all="ignore"):
+            dist = (np.einsum("ij,ij->i", np.c_[p2, np.ones(n)], l)) / nrm
+            near = np.arange(n) % 3 == 1
+            target = np.sqrt(max_res) * 1.41 * (1 + rng.uniform(-1, 1, size=n) * 10.0 ** rng.uniform(-9, -3, size=n))
+            shift = (target - dist)[:, None] * (l[:, :2] / nrm[:, None])
+        ok = near & np.isfinite(shift).all(axis=1)
+        p2[ok] += shift[ok]
+        p2 = np.ascontiguousarray(p2.astype(np.float32).astype(np.float64))
+        Mc = np.ascontiguousarray(Mx.reshape(9))
+        res = np.zeros(n)
+        shim.shim_residuals(0, _p(Mc), _p(p1), _p(p2), n, _p(res))
+        with np.errstate(invalid="ignore"):
+            inlier = res <= max_res
+        qv = np.zeros(n, dtype=np.float32)
+        shim.shim_s32_q(_p(Mc), C.c_double(max_res), _p(p1), _p(p2), n, _p(qv))
+        sure_out = qv > 0
+        bad = sure_out & inlier
+        assert not bad.any(), f"trial {trial} style {style}: dropped inliers, residuals {res[bad][:4]} (max {max_res})"
+        if tame:
+            with np.errstate(invalid="ignore"):
+                clear = np.isfinite(res) & (res > 1.05 * max_res)
+            n_sure += int(sure_out[clear].sum())
+            n_clear += int(clear.sum())
+    assert n_sure > 0.98 * n_clear > 0
+
+
 def test_closed_form_h4_on_degenerate_samples_against_the_svd_dlt(shim):
     """The minimal 4-point homography is a closed form (change of projective basis) where upstream solves the 8 x 9 DLT by
     SVD (tests/ref2/tvg_ref2.py estimate_h restates that).  On a proper sample the two give the same H up to scale; on a
