@@ -285,13 +285,14 @@ size_t tvg_ws_doubles_host(uint32_t mcap);
 size_t tvg_ws_doubles_e_host(uint32_t mcap);   // the essential-matrix kernel's waves (larger model / staging region)
 size_t tvg_ws_mask_bytes_host(uint32_t mcap);
 // Target occupancy (waves per SIMD) of the two verification kernels: sets their VGPR budgets and LDS shares.
-// tvg_e_kernel holds the 5-point solver (~200 live doubles per lane): 2.  tvg_fh_kernel (7-point / 4-point solvers,
-// counting loops with lane-resident models) runs more waves to hide its LDS / scalar-load / FP64 latencies.
+// tvg_e_kernel holds the 5-point solver and its root finder (256 VGPRs): 2.  tvg_fh_kernel: 3 - the 7-point solver's
+// 7 x 9 matrix (126 VGPRs) spills at 4 waves (128 VGPRs), and since the counting loops request their scalar-cache lines
+// in batches they are issue-bound, not latency-bound (measured round 3: 4 -> 3 waves +2.4 %, 2 waves -4 %).
 #ifndef AMC_E_WAVES
 #define AMC_E_WAVES 2
 #endif
 #ifndef AMC_FH_WAVES
-#define AMC_FH_WAVES 4
+#define AMC_FH_WAVES 3
 #endif
 constexpr int kTvgEWavesPerSimd = AMC_E_WAVES;
 constexpr int kTvgFhWavesPerSimd = AMC_FH_WAVES;
