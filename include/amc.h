@@ -257,7 +257,11 @@ typedef struct amc_verify_result {
      *   [0] Sampson residuals  [1] homography transfer residuals  [2] translation residuals
      *   [3] 5-point minimal solves  [4] 7-point solves  [5] 4-point DLT solves
      *   [6] local 5-point solves  [7] local 8-point solves  [8] local DLT solves
-     *   [9] inlier points summed over by the local solves  [10] 1-point (watermark) trials  [11] unused */
+     *   [9] inlier points summed over by the local solves  [10] 1-point (watermark) trials
+     *   [11] FP64 flop of the residuals the kernels evaluated with the reference expression (33 / 20 / 7 per Sampson /
+     *        transfer / translation residual): candidate re-scores, local-optimisation scores, inlier extraction, final
+     *        masks.  [0] and [1] count the ALGORITHM's residuals; most of those are decided by the packed-FP32
+     *        pre-filters of the counting loops and are not FP64 work. */
     uint64_t work[12];
     void* _priv;
 } amc_verify_result;

@@ -64,7 +64,7 @@ typedef AMC_LDS uint16_t lds_u16;
 // evaluate - every model of every trial up to the stopping trial against all M correspondences, every local model
 // against all M, one final residual pass per successful RANSAC - not what this kernel skips.
 enum : int { WK_SAMPSON = 0, WK_HRES, WK_TRES, WK_E5MIN, WK_F7MIN, WK_H4MIN, WK_LO_E5, WK_LO_F8, WK_LO_H, WK_LO_POINTS,
-              WK_TRIALS, WK_COUNT };
+              WK_TRIALS, WK_EXACT_FLOP, WK_COUNT };
 __device__ __forceinline__ constexpr int wk_residual_slot(int kind) { return kind == K_H ? WK_HRES : (kind == K_T ? WK_TRES : WK_SAMPSON); }
 
 // LDS scratch of the essential-matrix kernel's wave-balanced root finder (real_roots10_lanes)
@@ -1876,6 +1876,9 @@ __device__ Report lo_ransac(Wave& w_io, const RansacCfg& cfg, const double* gx, 
     for (int i = 0; i < 9; ++i) best_model[i] = 0.0;
     bool best_is_local = false;
     uint32_t dyn_max = (uint32_t)cfg.max_trials;
+    // residuals this RANSAC evaluates with the reference FP64 expression (candidate re-scores, local-optimisation scores,
+    // inlier extraction, the final mask; the whole counting loop where no pre-filter runs): work[WK_EXACT_FLOP]
+    unsigned long long exact_evals = 0ull;
 
     Pts P;
     P.g = gx; P.gs = gstride;
@@ -1982,6 +1985,7 @@ __device__ Report lo_ransac(Wave& w_io, const RansacCfg& cfg, const double* gx, 
                 const unsigned long long sc0_ = __builtin_readcyclecounter();
 #endif
                 const Support sup = score<(EST == K_E5 ? K_F7 : EST)>(smv, P, M, cfg.max_res, lane, best.cnt);
+                exact_evals += (unsigned long long)M;
 #if defined(AMC_TVG_LODIAG)
                 if (lane == 0) { atomicAdd(&g_lo_diag[kDiagBase + 3], 1ull); atomicAdd(&g_lo_diag[kDiagBase + 4], __builtin_readcyclecounter() - sc0_); }
 #endif
@@ -1998,6 +2002,7 @@ __device__ Report lo_ransac(Wave& w_io, const RansacCfg& cfg, const double* gx, 
                         for (int i = 0; i < 9; ++i) cur.v[i] = sm[i];
                         for (int lt = 0; lt < 10; ++lt) {
                             const int K = extract_inliers(w.inl, lane, cur_kind, cur, P, M, cfg.max_res);
+                            exact_evals += (unsigned long long)M;
                             double lm[(LOCAL == K_E5 ? kMaxModels : 1) * 9];
                             const unsigned long long tle = __builtin_readcyclecounter();
                             const int nl = local_estimate<LOCAL>(lo, P, K, lm);
@@ -2015,6 +2020,7 @@ __device__ Report lo_ransac(Wave& w_io, const RansacCfg& cfg, const double* gx, 
                                 Model9 lmv;
                                 for (int i = 0; i < 9; ++i) lmv.v[i] = lm[9 * q + i];
                                 const Support ls = score<(LOCAL == K_E5 || LOCAL == K_F8 ? K_F7 : LOCAL)>(lmv, P, M, cfg.max_res, lane, best.cnt);
+                                exact_evals += (unsigned long long)M;
                                 if (better(ls, best)) {
                                     best = ls;
                                     for (int i = 0; i < 9; ++i) best_model[i] = lm[9 * q + i];
@@ -2055,6 +2061,7 @@ __device__ Report lo_ransac(Wave& w_io, const RansacCfg& cfg, const double* gx, 
         {   // algorithmic work of the chunk: the trials the sequential loop ran, their models x M residuals
             const int upto = aborted ? abort_trial - chunk : nT - 1;
             const int nmodels = wave_sum_int(lane <= upto ? cm.nmod : 0);
+            if (EST == K_T || fast_count == 0) exact_evals += (unsigned long long)nmodels * (unsigned long long)M;
             if (lane == 0) {
                 w.work[wk_residual_slot(EST)] += (unsigned long long)nmodels * (unsigned long long)M;
                 w.work[EST == K_E5 ? WK_E5MIN : (EST == K_F7 ? WK_F7MIN : (EST == K_H ? WK_H4MIN : WK_TRIALS))] +=
@@ -2074,6 +2081,8 @@ __device__ Report lo_ransac(Wave& w_io, const RansacCfg& cfg, const double* gx, 
     for (int i = 0; i < 9; ++i) rep.model[i] = best_model[i];
     w_io.soff = w.soff;
     for (int i = 0; i < 8; ++i) w_io.prof[i] = w.prof[i];
+    if (best.cnt >= kMin) exact_evals += (unsigned long long)M;  // the final mask
+    if (lane == 0) w.work[WK_EXACT_FLOP] += exact_evals * (unsigned long long)(EST == K_H ? 20 : (EST == K_T ? 7 : 33));
     if (best.cnt >= kMin && lane == 0)
         w.work[wk_residual_slot(best_is_local ? LOCAL : EST)] += (unsigned long long)M;
     if (best.cnt < kMin) return rep;
