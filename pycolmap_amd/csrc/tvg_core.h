@@ -1399,13 +1399,12 @@ __device__ __forceinline__ float fma_abs_f32(float a, float b, float c) {  // fm
     return r;
 }
 struct H32Splat {  // the lane's model with every coefficient in both halves of a register pair
-    v2f m[9], qS, qR, qK;
+    v2f m[9], qR, qK;
 };
 __device__ __forceinline__ H32Splat h32_splat(const H32Lane& h) {
     H32Splat s;
 #pragma unroll
     for (int i = 0; i < 9; ++i) s.m[i] = (v2f){h.m[i], h.m[i]};
-    s.qS = (v2f){h.qS, h.qS};
     s.qR = (v2f){h.qR, h.qR};
     s.qK = (v2f){h.qK, h.qK};
     return s;
@@ -1417,8 +1416,7 @@ __device__ __forceinline__ v2f h32_q_pk(const H32Splat& h, v2f a, v2f b, v2f cs,
     const v2f w = pk_fma(h.m[6], a, pk_fma(h.m[7], b, h.m[8]));
     const v2f u = pk_fma(cs, w, -p0), v = pk_fma(ds, w, -p1);
     const v2f R = w * w;
-    const v2f S = pk_fma(u, u, v * v);
-    return pk_fma(h.qS, S, pk_fma(h.qR, R, h.qK));
+    return pk_fma(u, u, pk_fma(v, v, pk_fma(h.qR, R, h.qK)));
 }
 // 1.0 where q > 0 (q >= 2^-100; a fraction below that), 0.0 where q <= 0 or NaN: the product clamped to [0, 1] by the
 // instruction's output modifier (DX10 clamp: NaN -> 0).  Summed, it counts the outliers beyond doubt - never too many.
@@ -1483,13 +1481,12 @@ __device__ __forceinline__ int count_lanes_h32(const H32Lane& hl, const AMC_CONS
 
 // ---- Sampson outliers in packed FP32 (tvg_math.h s32_outlier_q), two correspondences per instruction -----------------
 struct S32Splat {
-    v2f m[9], qS, qR, qK;
+    v2f m[9], qR, qK;
 };
 __device__ __forceinline__ S32Splat s32_splat(const S32Model& h) {
     S32Splat s;
 #pragma unroll
     for (int i = 0; i < 9; ++i) s.m[i] = (v2f){h.m[i], h.m[i]};
-    s.qS = (v2f){h.qS, h.qS};
     s.qR = (v2f){h.qR, h.qR};
     s.qK = (v2f){h.qK, h.qK};
     return s;
@@ -1501,9 +1498,8 @@ __device__ __forceinline__ v2f s32_q_pk(const S32Splat& h, v2f a, v2f b, v2f c, 
     const v2f t0 = pk_fma(h.m[0], c, pk_fma(h.m[3], d, h.m[6]));
     const v2f t1 = pk_fma(h.m[1], c, pk_fma(h.m[4], d, h.m[7]));
     const v2f cc = pk_fma(c, e0, pk_fma(d, e1, e2));
-    const v2f Lq = cc * cc;
     const v2f den = pk_fma(e0, e0, pk_fma(e1, e1, pk_fma(t0, t0, t1 * t1)));
-    return pk_fma(h.qS, Lq, pk_fma(h.qR, den, h.qK));
+    return pk_fma(cc, cc, pk_fma(h.qR, den, h.qK));
 }
 #ifndef AMC_S32_BATCH
 #define AMC_S32_BATCH 4

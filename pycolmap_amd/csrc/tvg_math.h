@@ -1024,7 +1024,7 @@ struct H32Model {
     float m[9];
     float kE, kW, K0;   // the reference bound (h32_band_ref: tests compare the loop's bound against it)
     float bS, cR, K1;   // the loop's bound
-    float qS, qR, qK;   // the same test folded into one expression: q = qS S32 + qR R32 + qK > 0  =>  t32 - band > 0
+    float qR, qK;       // the same test folded into one expression: q = u32^2 + v32^2 + qR R32 + qK > 0  =>  t32 - band > 0
 };
 AMC_HD float f32_up(double v) {  // a float >= v (v >= 0)
     return (float)(v * (1.0 + 1e-6));
@@ -1053,11 +1053,12 @@ AMC_HD H32Model h32_prepare(const double* model, double s, double C) {
     h.bS = (float)bs;
     h.cR = f32_up((4.2e-7 + b0) * 1.0001);
     h.K1 = f32_up((K0 + kE * kE / (2.0 * b0) + kW * kW / (4.0 * b0)) * 1.0001);
-    // q > 0 is meant to imply S32 - R32 > band + (rounding of q itself): 1e-6 of slack on every coefficient covers the
-    // three roundings of the folded expression (<= 3 x 2^-24 of the largest term)
-    h.qS = (float)((1.0 - (double)h.bS) * (1.0 - 1e-6));
-    h.qR = -f32_up((1.0 + (double)h.cR) * (1.0 + 1e-6));
-    h.qK = -f32_up((double)h.K1 * (1.0 + 1e-6));
+    // q > 0 is meant to imply S - R > band + (rounding of q itself), S = u32^2 + v32^2: the inequality
+    // (1 - bS) S - (1 + cR) R - K1 > 0 divided by its first coefficient, with 1e-6 of slack on every coefficient for
+    // the three roundings of the folded expression (<= 3 x 2^-24 of the largest term)
+    const double qs = (1.0 - (double)h.bS) * (1.0 - 1e-6);
+    h.qR = -f32_up((1.0 + (double)h.cR) * (1.0 + 1e-6) / qs);
+    h.qK = -f32_up((double)h.K1 * (1.0 + 1e-6) / qs);
     return h;
 }
 // t = u'^2 + v'^2 - w^2 and the bound on its error, for one point (V = float) or for two at once (V = a two-float
@@ -1080,7 +1081,7 @@ AMC_HD void h32_eval(const H32Model& h, V a, V b, V cs, V ds, V& t, V& band) {
 }
 // The counting loop only needs an UPPER bound of a model's inlier count (a model whose bound reaches the best count so
 // far is re-scored exactly anyway), i.e. the points that are outliers beyond doubt: q > 0 with
-//   q = qS S32 + qR R32 + qK,  qS <= 1 - bS,  qR <= -(1 + cR),  qK <= -K1   =>   t32 > band, an outlier by h32_eval.
+//   q = u32^2 + v32^2 + qR R32 + qK,  qR <= -(1 + cR) / (1 - bS),  qK <= -K1 / (1 - bS)   =>   t32 > band, an outlier by h32_eval.
 // NaN / inf make q NaN or -inf: not an outlier beyond doubt.
 template <class V, class Ops>
 AMC_HD V h32_outlier_q(const H32Model& h, V a, V b, V cs, V ds) {
@@ -1089,8 +1090,7 @@ AMC_HD V h32_outlier_q(const H32Model& h, V a, V b, V cs, V ds) {
     const V w = Ops::fma(Ops::splat(h.m[6]), a, Ops::fma(Ops::splat(h.m[7]), b, Ops::splat(h.m[8])));
     const V u = Ops::fma(cs, w, -p0), v = Ops::fma(ds, w, -p1);
     const V R = w * w;
-    const V S = Ops::fma(u, u, v * v);
-    return Ops::fma(Ops::splat(h.qS), S, Ops::fma(Ops::splat(h.qR), R, Ops::splat(h.qK)));
+    return Ops::fma(u, u, Ops::fma(v, v, Ops::fma(Ops::splat(h.qR), R, Ops::splat(h.qK))));
 }
 // the reference bound of the same point (the right-hand side of the inequality above)
 AMC_HD float h32_band_ref(const H32Model& h, float a, float b, float cs, float ds) {
@@ -1122,8 +1122,8 @@ AMC_HD int h32_point(const H32Model& h, float a, float b, float cs, float ds) {
 //   |cc32 - cc|   <= Ec = 8 u (C (Ah_0 + Ah_1) + Ah_2)
 //   |den32 - den| <= 8.03 u Dh + 4.1 u den32,  Dh = Ah_0^2 + Ah_1^2 + Bh_0^2 + Bh_1^2
 // and, since (|x| - E)^2 >= (1 - beta) x^2 - E^2 (1 / beta - 1)  (2 E |x| <= beta x^2 + E^2 / beta),
-//   q = qS Lq32 + qR den32 + qK > 0,   Lq32 = fl(cc32^2),
-//   qS <= (1 - beta)(1 - u),  qR <= -T (1 + 1e-7)(1 + 4.1 u),  qK <= -(Ec^2 (1 / beta - 1) + T (1 + 1e-7) 8.03 u Dh)
+//   q = cc32^2 + qR den32 + qK > 0,   with  qS = (1 - beta)(1 - u)  divided out:
+//   qR <= -T (1 + 1e-7)(1 + 4.1 u) / qS,  qK <= -(Ec^2 (1 / beta - 1) + T (1 + 1e-7) 8.03 u Dh) / qS
 // implies cc^2 > T (1 + 1e-7) den: an outlier for the reference's FP64 residual as well (when q > 0, |cc| exceeds
 // 16 Ec ~ 7.6e-6 x the sum of the magnitudes of its terms, so the FP64 evaluation is good to ~1e-11 - far inside the
 // 1e-7 margin).  beta = 2^-8; every coefficient carries 1e-6 of slack for the three roundings of q itself.  NaN / inf
@@ -1131,7 +1131,7 @@ AMC_HD int h32_point(const H32Model& h, float a, float b, float cs, float ds) {
 // simply decides nothing.
 struct S32Model {
     float m[9];
-    float qS, qR, qK;
+    float qR, qK;
 };
 AMC_HD S32Model s32_prepare(const double* model, double T, double C) {
     const double U = 5.9604644775390625e-08;  // 2^-24
@@ -1147,9 +1147,9 @@ AMC_HD S32Model s32_prepare(const double* model, double T, double C) {
     const double Tq = T * (1.0 + 1e-7);
     S32Model h;
     for (int i = 0; i < 9; ++i) h.m[i] = (float)M[i];
-    h.qS = (float)((1.0 - beta) * (1.0 - U) * (1.0 - 1e-6));
-    h.qR = -f32_up(Tq * (1.0 + 4.1 * U) * (1.0 + 1e-6));
-    h.qK = -f32_up((Ec * Ec * (1.0 / beta - 1.0) + Tq * 8.03 * U * Dh) * (1.0 + 1e-6) + 1e-30);
+    const double qs = (1.0 - beta) * (1.0 - U) * (1.0 - 1e-6);
+    h.qR = -f32_up(Tq * (1.0 + 4.1 * U) * (1.0 + 1e-6) / qs);
+    h.qK = -f32_up(((Ec * Ec * (1.0 / beta - 1.0) + Tq * 8.03 * U * Dh) * (1.0 + 1e-6) + 1e-30) / qs);
     return h;
 }
 template <class V, class Ops>
@@ -1160,9 +1160,8 @@ AMC_HD V s32_outlier_q(const S32Model& h, V a, V b, V c, V d) {
     const V t0 = Ops::fma(Ops::splat(h.m[0]), c, Ops::fma(Ops::splat(h.m[3]), d, Ops::splat(h.m[6])));
     const V t1 = Ops::fma(Ops::splat(h.m[1]), c, Ops::fma(Ops::splat(h.m[4]), d, Ops::splat(h.m[7])));
     const V cc = Ops::fma(c, e0, Ops::fma(d, e1, e2));
-    const V Lq = cc * cc;
     const V den = Ops::fma(e0, e0, Ops::fma(e1, e1, Ops::fma(t0, t0, t1 * t1)));
-    return Ops::fma(Ops::splat(h.qS), Lq, Ops::fma(Ops::splat(h.qR), den, Ops::splat(h.qK)));
+    return Ops::fma(cc, cc, Ops::fma(Ops::splat(h.qR), den, Ops::splat(h.qK)));
 }
 
 // ---- mt19937 tempering + libstdc++ uniform_int_distribution<uint32_t> (Lemire) ------------------
