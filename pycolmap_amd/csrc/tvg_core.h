@@ -1931,8 +1931,17 @@ __device__ Report lo_ransac(Wave& w_io, const RansacCfg& cfg, const double* gx, 
     double* models = ws_models(w);
     bool aborted = false;
     int abort_trial = -1;
-    for (int chunk = 0; chunk < cfg.max_trials && !aborted; chunk += 64) {
-        const int nT = min(64, cfg.max_trials - chunk);
+    for (int chunk = 0, nT = 0; chunk < cfg.max_trials && !aborted; chunk += nT) {
+        nT = min(64, cfg.max_trials - chunk);
+        if (EST == K_E5) {
+            // The 5-point chunk costs what its trials cost (root finding is shared out by bracket, the elimination runs
+            // 16 problems at a time), and the adaptive limit only ever falls: trials far beyond it will not be looked
+            // at.  So the chunk ends a few trials after the limit (the first trial there that has a model stops the
+            // loop); should none of those have one, the next chunk carries on from where this one ended.
+            const long long lim = (long long)(dyn_max > (uint32_t)cfg.min_trials ? dyn_max : (uint32_t)cfg.min_trials);
+            const long long want = lim - (long long)chunk + 4;
+            if (want < (long long)nT) nT = (int)(want > 8 ? want : 8);
+        }
         // ---- draw the chunk's samples ----
         const uint32_t chunk_off = w.soff;
         unsigned long long tp0 = __builtin_readcyclecounter();
