@@ -332,6 +332,20 @@ AMC_HD void roots_classify(const double (&c)[DEG + 1], const double (&crit)[DEG 
     }
     L.todo = todo;
 }
+// one bisection step of a bracket, given f(mid); a bracket that is not active is left as it is
+AMC_HD void bracket_step(double mid, double fm, double& lo, double& hi, double& flo, bool& act, bool& zero) {
+    // (& and |, not && and ||: nothing here is worth a branch)
+    const bool hit = act & (fm == 0.0);
+    const bool move = act & !hit;
+    const bool left = (fm < 0.0) == (flo < 0.0);   // f(mid) has the sign of f(lo): the root is to the right of mid
+    const bool set_lo = hit | (move & left), set_hi = hit | (move & !left);
+    lo = set_lo ? mid : lo;
+    hi = set_hi ? mid : hi;
+    flo = (move & left) ? fm : flo;
+    zero = zero | hit;
+    const bool wide = !(hi - lo <= kRootRelWidth * (dabs(lo) + dabs(hi)));
+    act = move & wide;
+}
 // Two sign-change brackets at once (oracle: bracket_root, once per bracket): bisection until the bracket is narrower
 // than 2^-26 of where it sits, then three Newton steps accepted only strictly inside it.  The two brackets may belong
 // to different polynomials (c0 / c1, derivatives dc0 / dc1): a lane solving its own polynomial passes it twice, the
@@ -347,20 +361,11 @@ AMC_HD void bracket_pair_root(const double (&c0)[DEG + 1], const double (&dc0)[D
         act0 = act0 && !(mid0 == lo0 || mid0 == hi0);
         act1 = act1 && !(mid1 == lo1 || mid1 == hi1);
         const double fm0 = poly_eval_t<DEG>(c0, mid0), fm1 = poly_eval_t<DEG>(c1, mid1);
-        if (act0) {
-            if (fm0 == 0.0) { lo0 = mid0; hi0 = mid0; act0 = false; zero0 = true; }
-            else {
-                if ((fm0 < 0.0) == (flo0 < 0.0)) { lo0 = mid0; flo0 = fm0; } else { hi0 = mid0; }
-                act0 = !(hi0 - lo0 <= kRootRelWidth * (dabs(lo0) + dabs(hi0)));
-            }
-        }
-        if (act1) {
-            if (fm1 == 0.0) { lo1 = mid1; hi1 = mid1; act1 = false; zero1 = true; }
-            else {
-                if ((fm1 < 0.0) == (flo1 < 0.0)) { lo1 = mid1; flo1 = fm1; } else { hi1 = mid1; }
-                act1 = !(hi1 - lo1 <= kRootRelWidth * (dabs(lo1) + dabs(hi1)));
-            }
-        }
+        // the plain loop's step ("root hit: stop; same sign as f(lo): lo = mid, else hi = mid; narrow enough: stop")
+        // written with selects only, so that on the GPU the two brackets' Horner chains - the step's latency - run
+        // interleaved instead of one after the other inside two branches
+        bracket_step(mid0, fm0, lo0, hi0, flo0, act0, zero0);
+        bracket_step(mid1, fm1, lo1, hi1, flo1, act1, zero1);
     }
     double r0 = 0.5 * (lo0 + hi0), r1 = 0.5 * (lo1 + hi1);
 #pragma unroll
