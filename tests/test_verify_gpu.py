@@ -394,3 +394,40 @@ def test_result_views_equal_copies_and_outlive_the_call(amc_ctx):
     del b
     gc.collect()
     np.testing.assert_array_equal(part, want)      # the slice keeps the result alive
+
+
+@pytest.mark.parametrize("hook", ["AMC_TVG_NO_S32", "AMC_TVG_EXACT_COUNT", "AMC_TVG_SLOW_SAMPLER"])
+def test_alternative_counting_and_sampling_paths_agree_with_the_oracle(amc_ctx, monkeypatch, hook):
+    """The counting loops have three implementations per estimator - packed-FP32 filter, division-free FP64 test,
+    reference residual - and the sampler two (chunk-parallel, draw by draw); which one runs depends on the pair
+    (coordinate / max_error ratio, a rejected draw).  The hooks force the slower ones: all must reproduce the oracle
+    bit for bit, like the default path (checked by every other test of this file)."""
+    rng = np.random.default_rng(31)
+    scenes = [synth.two_view_scene(rng, num_inliers=220, num_outliers=120),
+              synth.two_view_scene(rng, num_inliers=150, num_outliers=200, planar=True),
+              synth.two_view_scene(rng, num_inliers=90, num_outliers=35, noise=1.2),
+              synth.two_view_scene(rng, num_inliers=300, num_outliers=80, pure_rotation=True),
+              synth.two_view_scene(rng, num_inliers=33, num_outliers=31)]
+    monkeypatch.setenv(hook, "1")
+    for priors in ([True] * 5, [False] * 5):
+        tvg, mask, off, want = run_both(amc_ctx, scenes, priors, seed=3)
+        for p in range(len(scenes)):
+            assert_pair_equal(p, tvg, mask, off, want)
+
+
+def test_large_coordinates_take_the_fp64_counting_loops(amc_ctx):
+    """Coordinates of 30,000 px with a 0.5 px threshold: (largest coordinate / max_error)^2 > 1e8, so the F / E loops
+    leave the packed-FP32 Sampson filter for the FP64 test - same results as the oracle."""
+    rng = np.random.default_rng(32)
+    scenes = []
+    for _ in range(3):
+        sc = synth.two_view_scene(rng, num_inliers=160, num_outliers=90, noise=0.2)
+        k = 30000.0 / sc["width"]
+        for key in ("pts1", "pts2"):
+            sc[key] = (sc[key] * k).astype(np.float32).astype(np.float64)   # (keypoints are float32 blobs)
+        sc["width"], sc["height"], sc["f"] = int(sc["width"] * k), int(sc["height"] * k), sc["f"] * k
+        scenes.append(sc)
+    for priors in ([True] * 3, [False] * 3):
+        tvg, mask, off, want = run_both(amc_ctx, scenes, priors, opts_kw={"ransac": {"max_error": 0.5}}, seed=1)
+        for p in range(3):
+            assert_pair_equal(p, tvg, mask, off, want)
