@@ -1180,45 +1180,16 @@ struct ChunkModels {
 //   Sampson     c^2 / den <= T                              <=>   c^2 <= T den               (den > 0)
 // evaluated here with fused multiply-adds (no division: a third of the instructions of the reference expression
 // and no rcp -> Newton -> fixup dependency chain).  The two sides are NOT the reference's roundings, so the test
-// is only trusted away from the boundary: with L and R the two sides, `in` when L <= R (1 - 1e-8), `out` when
-// L >= R (1 + 1e-8), and the (practically never taken) band in between - or an R that is not a normal positive
-// number - leaves the point undecided (`amb`).  Why the band suffices: both this
+// is only trusted away from the boundary: with L and R the two sides, the point is `out` - an outlier beyond doubt -
+// when L >= R (1 + 1e-8); below that, or with an R that is not a normal positive number, it stays in the model's
+// upper bound.  Why the band suffices: both this
 // expression and the reference one are backward-stable evaluations of the same real quantity whose relative error
 // at the boundary is <= ~10 eps x (largest coordinate / max_error) - the cancellation in d - p and in x2^T E x1;
 // lo_ransac switches the fast test off unless that ratio is below 1e5 (fast_count), which bounds both
 // errors by ~1e-10, a hundredth of the band.  A decided point is therefore decided as the reference decides it.
-constexpr double kFastLo = 1.0 - 1e-8, kFastHi = 1.0 + 1e-8;
-template <int KIND>
-__device__ __forceinline__ void fast_inlier(const double (&m)[9], double a, double b, double c, double d, double T,
-                                            bool& in, bool& amb) {
-    double Lq, R;
-    if (KIND == K_H) {
-        const double pd0 = __fma_rn(m[0], a, __fma_rn(m[1], b, m[2]));
-        const double pd1 = __fma_rn(m[3], a, __fma_rn(m[4], b, m[5]));
-        const double pd2 = __fma_rn(m[6], a, __fma_rn(m[7], b, m[8]));
-        const double u = __fma_rn(c, pd2, -pd0), v = __fma_rn(d, pd2, -pd1);
-        Lq = __fma_rn(u, u, v * v);
-        R = T * (pd2 * pd2);
-    } else {
-        const double Ex1_0 = __fma_rn(m[0], a, __fma_rn(m[1], b, m[2]));
-        const double Ex1_1 = __fma_rn(m[3], a, __fma_rn(m[4], b, m[5]));
-        const double Ex1_2 = __fma_rn(m[6], a, __fma_rn(m[7], b, m[8]));
-        const double Etx2_0 = __fma_rn(m[0], c, __fma_rn(m[3], d, m[6]));
-        const double Etx2_1 = __fma_rn(m[1], c, __fma_rn(m[4], d, m[7]));
-        const double x2tEx1 = __fma_rn(c, Ex1_0, __fma_rn(d, Ex1_1, Ex1_2));
-        Lq = x2tEx1 * x2tEx1;
-        R = T * __fma_rn(Ex1_0, Ex1_0, __fma_rn(Ex1_1, Ex1_1, __fma_rn(Etx2_0, Etx2_0, Etx2_1 * Etx2_1)));
-    }
-    // "R is a positive number of ordinary magnitude" (2^-664 <= R < 2^664): one integer range check on its exponent
-    // field - false for 0, denormals, huge values, inf, NaN and anything negative
-    const bool sane = ((uint32_t)((unsigned long long)__double_as_longlong(R) >> 32) - 0x16700000u) < 0x53000000u;
-    const bool c1 = Lq <= R * kFastLo, c2 = Lq < R * kFastHi;  // c1 implies c2; a NaN Lq fails both: an outlier, as
-                                                                // the reference's NaN <= max_res says
-    in = sane && c1;
-    amb = !sane || (c2 && !c1);
-}
-// the half of fast_inlier the counting loops use: false only for an outlier beyond doubt (`out` above), so that
-// the sum over the correspondences is an upper bound of the inlier count
+constexpr double kFastHi = 1.0 + 1e-8;
+// false only for an outlier beyond doubt (`out` above), so that the sum over the correspondences is an upper bound of
+// the inlier count - all the counting loops need (the `in` side of the test is not evaluated any more)
 template <int KIND>
 __device__ __forceinline__ bool fast_not_outlier(const double (&m)[9], double a, double b, double c, double d, double T) {
     double Lq, R;
@@ -1386,18 +1357,6 @@ __device__ __forceinline__ int count_range_exact(const double (&m)[9], const Pts
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef H32Model H32Lane;  // tvg_math.h: the scaled float model and the constants of its error bound (h32_prepare)
 __device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
-// packed FP32 instructions have no |x| source modifier (the compiler spends a v_and per component on it): the two
-// places the error bound takes absolute values are single instructions on the plain FP32 pipe instead
-__device__ __forceinline__ float abs_add_f32(float a, float b) {  // |a| + |b|
-    float r;
-    asm("v_add_f32 %0, |%1|, |%2|" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-__device__ __forceinline__ float fma_abs_f32(float a, float b, float c) {  // fma(a, |b|, c)
-    float r;
-    asm("v_fma_f32 %0, %1, |%2|, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
 struct H32Splat {  // the lane's model with every coefficient in both halves of a register pair
     v2f m[9], qR, qK;
 };
@@ -1909,7 +1868,7 @@ __device__ Report lo_ransac(Wave& w_io, const RansacCfg& cfg, const double* gx, 
 #pragma unroll
         for (int sh = 32; sh >= 1; sh >>= 1) amax = dmax(amax, __shfl_xor(amax, sh));
         // the division-free counting test is trusted only while (largest coordinate / max_error) <= 1e5 (see
-        // fast_inlier); a NaN coordinate leaves amax as it was or NaN - either way the comparison below decides
+        // fast_not_outlier); a NaN coordinate leaves amax as it was or NaN - either way the comparison below decides
         fast_count = (cfg.no_fast_count == 0 && amax * amax <= 1e10 * cfg.max_res) ? 1 : 0;
         // ... and the FP32 Sampson pre-filter (s32_outlier_q) is worth its pass while its band stays within ~1 % of
         // the threshold: (largest coordinate / max_error) <= 1e4.  Beyond that the FP64 loop counts.
