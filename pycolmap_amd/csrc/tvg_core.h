@@ -1,17 +1,19 @@
 // tvg_core.h — device code of the batched two-view geometric verification (COLMAP EstimateTwoViewGeometry,
 // SURVEY.md A.3) on gfx950: one LO-RANSAC (LORANSAC<Est, LocalEst>::Estimate) by one wavefront.  Included by the two
 // kernels that run it, each with its own register budget and occupancy:
-//   tvg_e.hip   the essential-matrix RANSAC (5-point solver: 200 live doubles per lane, 2 waves per SIMD)
-//   tvg_fh.hip  the fundamental-matrix and homography RANSACs, model selection, watermark test (AMC_FH_WAVES per SIMD)
+//   tvg_e.hip   the essential-matrix RANSAC (5-point solver and its degree-10 root finder: 256 VGPRs, 2 waves per SIMD)
+//   tvg_fh.hip  the fundamental-matrix and homography RANSACs, model selection, watermark test (AMC_FH_WAVES = 3 per SIMD)
 // (one translation unit each: a device function shared by kernels with different occupancy attributes is compiled
 // for the loosest of them).
 //
 // Mapping.  A persistent grid of wavefronts pulls image pairs from a queue; ONE WAVE owns one pair at a time (no
 // workgroup barriers anywhere), and inside the wave the 64 lanes are
-//   * 64 RANSAC trials for the minimal solvers (one trial per lane, tvg_math.h),
+//   * 64 RANSAC trials for the minimal solvers (one trial per lane, tvg_math.h; the 5-point solve's 10 x 20 elimination
+//     four lanes per trial, its root finding dealt out by sign-change bracket),
 //   * 64 MODELS for inlier counting: every lane keeps one model of the chunk in registers and the correspondences
-//     stream past through the scalar unit (s_load from a per-wave table -> SGPR operands of the vector FMAs): no
-//     ballots, no broadcasts, no cross-lane traffic in the inner loop,
+//     stream past through the scalar unit (s_load_dwordx16 batches from a per-wave table -> SGPR operands of packed-FP32
+//     FMAs): no ballots, no broadcasts, no cross-lane traffic in the inner loop.  What a lane counts is an UPPER BOUND
+//     of its model's inliers (the correspondences that are not outliers beyond the evaluation's own error bound),
 //   * 64 strided correspondences for exact residual scoring, normalisation sums and A^T A accumulation (the fixed
 //     64-way strided + butterfly order of the oracle's det_sum64, which is exactly what a wave computes with
 //     __shfl_xor),
@@ -27,8 +29,9 @@
 // order, re-scoring them in full (lo_ransac).  If a RANSAC stops inside a chunk, the position is set back to where
 // the sequential algorithm would have stopped drawing, because the next RANSAC of the pair continues the stream.
 //
-// FP64 everywhere a decision is final, -ffp-contract=off, IEEE divide/sqrt: results are bit-identical to
-// oracle/tvg_oracle.cc (inlier masks, configs, model bit patterns).
+// FP64 everywhere a decision is final (every model whose bound reaches the best count is re-scored with the reference
+// residual), -ffp-contract=off, IEEE divide/sqrt: results are bit-identical to oracle/tvg_oracle.cc (inlier masks,
+// configs, model bit patterns).
 #pragma once
 #include <algorithm>
 #include <cstdio>
