@@ -752,21 +752,20 @@ struct WaveRootChain {
         double val = 0.0;
         if (lane + 1 < ne) {
             double lo = tmp[lane], hi = tmp[lane + 1];
-            double flo = poly_eval_t<R>(d, lo);
+            const double flo = poly_eval_t<R>(d, lo);
             const double fhi = poly_eval_t<R>(d, hi);
             if (flo == 0.0) {
                 kind = 1;
                 val = lo;
             } else if (fhi != 0.0 && (flo < 0.0) != (fhi < 0.0)) {
                 // bracket_root: bisection to 2^-26 of the bracket's position, then three bracketed Newton steps
-                bool zero = false;
-                for (int it = 0; it < 200; ++it) {
+                bool zero = false, act = true;
+                const bool neg_lo = flo < 0.0;
+                for (int it = 0; it < 200 && act; ++it) {
                     const double mid = 0.5 * (lo + hi);
-                    if (mid == lo || mid == hi) break;
+                    act = !(mid == lo || mid == hi);
                     const double fm = poly_eval_t<R>(d, mid);
-                    if (fm == 0.0) { lo = mid; hi = mid; zero = true; break; }
-                    if ((fm < 0.0) == (flo < 0.0)) { lo = mid; flo = fm; } else { hi = mid; }
-                    if (hi - lo <= kRootRelWidth * (dabs(lo) + dabs(hi))) break;
+                    bracket_step(mid, fm, lo, hi, neg_lo, act, zero);  // (tvg_math.h: the plain loop's step, branch-free)
                 }
                 double r = 0.5 * (lo + hi);
 #pragma unroll

@@ -333,17 +333,19 @@ AMC_HD void roots_classify(const double (&c)[DEG + 1], const double (&crit)[DEG 
     L.todo = todo;
 }
 // one bisection step of a bracket, given f(mid); a bracket that is not active is left as it is
-AMC_HD void bracket_step(double mid, double fm, double& lo, double& hi, double& flo, bool& act, bool& zero) {
-    // (& and |, not && and ||: nothing here is worth a branch)
+AMC_HD void bracket_step(double mid, double fm, double& lo, double& hi, bool neg_lo, bool& act, bool& zero) {
+    // (& and |, not && and ||: nothing here is worth a branch.)  The plain loop keeps f(lo) and replaces it by f(mid)
+    // whenever lo moves; it only ever looks at its sign, and lo moves exactly when f(mid) has that sign - so the sign
+    // of f(lo) never changes and is all a bracket carries: neg_lo.  |x| through fabs (one source modifier on the GPU;
+    // x < 0 ? -x : x differs from it only in the sign of a zero, which the comparison below cannot see).
     const bool hit = act & (fm == 0.0);
     const bool move = act & !hit;
-    const bool left = (fm < 0.0) == (flo < 0.0);   // f(mid) has the sign of f(lo): the root is to the right of mid
+    const bool left = (fm < 0.0) == neg_lo;   // f(mid) has the sign of f(lo): the root is to the right of mid
     const bool set_lo = hit | (move & left), set_hi = hit | (move & !left);
     lo = set_lo ? mid : lo;
     hi = set_hi ? mid : hi;
-    flo = (move & left) ? fm : flo;
     zero = zero | hit;
-    const bool wide = !(hi - lo <= kRootRelWidth * (dabs(lo) + dabs(hi)));
+    const bool wide = !(hi - lo <= kRootRelWidth * (__builtin_fabs(lo) + __builtin_fabs(hi)));
     act = move & wide;
 }
 // Two sign-change brackets at once (oracle: bracket_root, once per bracket): bisection until the bracket is narrower
@@ -356,6 +358,7 @@ AMC_HD void bracket_pair_root(const double (&c0)[DEG + 1], const double (&dc0)[D
                               const double (&dc1)[DEG], double lo0, double hi0, double flo0, double lo1, double hi1,
                               double flo1, bool one, bool two, double& r0_out, double& r1_out) {
     bool act0 = one, act1 = two, zero0 = false, zero1 = false;
+    const bool neg0 = flo0 < 0.0, neg1 = flo1 < 0.0;
     for (int it = 0; it < 200 && (act0 || act1); ++it) {
         const double mid0 = 0.5 * (lo0 + hi0), mid1 = 0.5 * (lo1 + hi1);
         act0 = act0 && !(mid0 == lo0 || mid0 == hi0);
@@ -364,8 +367,8 @@ AMC_HD void bracket_pair_root(const double (&c0)[DEG + 1], const double (&dc0)[D
         // the plain loop's step ("root hit: stop; same sign as f(lo): lo = mid, else hi = mid; narrow enough: stop")
         // written with selects only, so that on the GPU the two brackets' Horner chains - the step's latency - run
         // interleaved instead of one after the other inside two branches
-        bracket_step(mid0, fm0, lo0, hi0, flo0, act0, zero0);
-        bracket_step(mid1, fm1, lo1, hi1, flo1, act1, zero1);
+        bracket_step(mid0, fm0, lo0, hi0, neg0, act0, zero0);
+        bracket_step(mid1, fm1, lo1, hi1, neg1, act1, zero1);
     }
     double r0 = 0.5 * (lo0 + hi0), r1 = 0.5 * (lo1 + hi1);
 #pragma unroll
