@@ -2,7 +2,7 @@
 """profiles/r03/pmc_tvg_r03.json from the text summary tools/pmc_tvg_r03.sh writes (per-call averages of the SQ counters
 of the two verification kernels + the derived ratios + the sha256 of the kernel sources the counters belong to;
 bench.py's verify.roofline.executed reads it while the sources still hash to the same values).
-    python tools/pmc_tvg_json.py profiles/r03/pmc_tvg_r03_v6.txt"""
+    python tools/pmc_tvg_json.py profiles/r03/pmc_tvg_r03_v7.txt"""
 import hashlib
 import json
 import re
