@@ -30,6 +30,15 @@ def _worker(rank, world, port, out_dir):
     a, b, mine = D.shard_pairs(s1, s2, rank, world)
     off, m = oracle_lib.match_pairs(imgs, a, b, threads=1)
     g_off, g_m = D.all_gather_match_tables(mine, off, m)
+    # the same exchange fed from a resident table (a tensor where the match kernels would have left it: here a CPU
+    # int32 view of the rows) with only rank 0 downloading the result - the form bench.py / the SQLite writer rank use
+    import torch
+    resident = torch.from_numpy(np.ascontiguousarray(m, dtype=np.uint32).view(np.int32).reshape(-1, 2).copy())
+    d_off, d_m = D.all_gather_match_tables(mine, off, None, device_matches=resident, download_rank=0)
+    if rank == 0:
+        assert np.array_equal(d_off, g_off) and np.array_equal(d_m, g_m)
+    else:
+        assert d_off is None and d_m is None
     np.savez(Path(out_dir) / f"rank{rank}.npz", g_off=g_off, g_m=g_m, mine=mine)
     dist.barrier()
     dist.destroy_process_group()
