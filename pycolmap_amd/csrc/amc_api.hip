@@ -1601,7 +1601,7 @@ static int verify_impl(amc_ctx* c, int mode, const uint32_t* slot1, const uint32
 
     // Size classes.  A wave's LDS share holds, besides a few KB of fixed state, two uint16 index arrays of mcap
     // entries (the sampler's permutation and the inlier list); everything else of a pair lives in the wave's global
-    // workspace.  Pairs up to ~1,500 matches run at the F/H kernel's full occupancy, 4 waves per workgroup; larger
+    // workspace.  Pairs up to ~2,300 matches run at the F/H kernel's full occupancy (3 waves per SIMD), 4 waves per workgroup; larger
     // ones in launches of their own with fewer resident waves; the largest (M <= ~38 k: covers
     // max_num_matches = 32768) one wave per workgroup with up to the whole 160 KB.
     std::vector<size_t> cls[3];
