@@ -1601,14 +1601,16 @@ static int verify_impl(amc_ctx* c, int mode, const uint32_t* slot1, const uint32
 
     // Size classes.  A wave's LDS share holds, besides a few KB of fixed state, two uint16 index arrays of mcap
     // entries (the sampler's permutation and the inlier list); everything else of a pair lives in the wave's global
-    // workspace.  Pairs up to ~2,300 matches run at the F/H kernel's full occupancy (3 waves per SIMD), 4 waves per workgroup; larger
+    // workspace.  Pairs up to ~1,800 matches run at both kernels' full occupancy (E 2, F/H 3 waves per SIMD), 4 waves per workgroup; larger
     // ones in launches of their own with fewer resident waves; the largest (M <= ~38 k: covers
     // max_num_matches = 32768) one wave per workgroup with up to the whole 160 KB.
     std::vector<size_t> cls[3];
     for (size_t p = 0; p < npairs; ++p) {
         const uint32_t mc = std::max<uint32_t>(64, round_up(tp[p].M, 64));
         const size_t lds = tvg_lds_bytes(mc, 1) + 64;
-        if (lds <= 160 * 1024 / (4 * (size_t)kTvgFhWavesPerSimd)) cls[0].push_back(p);
+        // (full occupancy of BOTH kernels: the E kernel's waves also carry the root finder's 9 KB)
+        if (lds <= 160 * 1024 / (4 * (size_t)kTvgFhWavesPerSimd) && lds + 9 * 1024 <= 160 * 1024 / (4 * (size_t)kTvgEWavesPerSimd))
+            cls[0].push_back(p);
         else if (lds + 9 * 1024 <= 160 * 1024 / 4) cls[1].push_back(p);  // 4-wave workgroups of either kernel fit a CU
         else if (lds + 9 * 1024 <= 160 * 1024) cls[2].push_back(p);  // (+ the E kernel's root-finder scratch)
         else
