@@ -464,6 +464,50 @@ def dense_leg(ctx_factory, device, steps: int, warmup: int, num_images: int, fea
                                   "python_free_previous_result": 1e3 * t_free / steps, "python_call": 1e3 * t_call / steps}}
 
 
+def ragged_leg(ctx_factory, device, steps: int, warmup: int, num_images: int, lo: int, hi: int, kernel: str,
+               uniform_value: float):
+    """configs[1] with image sizes a real capture has: n ~ U[lo, hi] descriptors per image (seeded), nothing a multiple
+    of the kernel's 128-row segments or 256-row chunks.  Same generator, same sparse overlap as the headline; reported
+    beside it in the same unit, with the scan kernel's own rate, so that a tiling that only suits 4096 = 4 x 1024 rows
+    shows."""
+    import torch
+    rng = np.random.default_rng(7)
+    rows = rng.integers(lo, hi + 1, size=num_images)
+    arena = make_arena_torch(num_images, hi, seed=2, device=device)   # rows are shuffled: a prefix is a random subset
+    ctx = ctx_factory()
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.reserve_slots(num_images)
+    for i in range(num_images):
+        ctx.upload_descriptors_device(i, arena[i].data_ptr(), int(rows[i]))
+    torch.cuda.synchronize()
+    from pycolmap_amd import synth
+    s1, s2 = synth.exhaustive_pairs(num_images)
+    for _ in range(warmup):
+        ctx.match_pairs(s1, s2, kernel=kernel)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    scan = cross = 0.0
+    launches = 0
+    for _ in range(steps):
+        off = m = None
+        off, m, st = ctx.match_pairs(s1, s2, kernel=kernel, copy=False)
+        scan += st["match_kernel_ms"]; cross += st["cross_kernel_ms"]; launches += st["match_kernel_launches"]
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ctx.close()
+    ndist = float(st["num_distances"])
+    value = ndist * steps / dt
+    scan_ops = ndist * steps * OPS_PER_DISTANCE / (scan * 1e-3) if scan > 0 else 0.0
+    return {"metric": "descriptor-pair distances/sec, ragged image sizes", "value": value, "unit": "distances/s",
+            "workload": f"{num_images} images, n ~ U[{lo}, {hi}] descriptors (seed 7; mean {float(rows.mean()):.0f}), "
+                        f"exhaustive match + ratio test + cross-check",
+            "steps": steps, "ms_per_step": 1e3 * dt / steps, "distances_per_step": ndist,
+            "vs_uniform": value / uniform_value if uniform_value > 0 else None,
+            "scan_frac_of_int8_peak": scan_ops / INT8_DENSE_PEAK_OPS,
+            "stage_ms_per_step": {"scan_kernel": scan / steps, "resolve_select_reverse_scan": cross / steps},
+            "scan_launches_per_step": launches // max(steps, 1), "matches": int(m.shape[0])}
+
+
 class _DryRunContext:
     """--cpu-dry-run only: stands where _capi.Context stands so that the multi-rank entry (sharding, exchange,
     reductions, the JSON line) can be exercised without a GPU.  The match kernels are replaced by the CPU oracle
@@ -776,6 +820,7 @@ def main():
                          "CPU oracle in place of the kernels; prints value = null.  For tests/, with tiny --images/--feats")
     ap.add_argument("--no-pipeline", action="store_true", help="skip the chained configs[2] leg")
     ap.add_argument("--no-dense", action="store_true", help="skip the dense-overlap match leg")
+    ap.add_argument("--no-ragged", action="store_true", help="skip the ragged-size match leg (n ~ U[2000, 6000])")
     args = ap.parse_args()
     if args.config is None:
         args.config = 1 if (args.gpus == 1 or args.weak) else 3
@@ -946,12 +991,20 @@ def main():
             out["verify"] = verify_leg(lambda: _capi.Context(local_rank), local_rank, args.verify_pairs,
                                        max(1, args.steps), min(1, args.warmup),
                                        0 if args.no_cpu_baseline else 256, distinct=args.verify_scenes)
+        def release_headline():   # the legs below bring their own contexts and arenas
+            nonlocal arena, ctx
+            if ctx is not None:
+                ctx.close()
+                ctx = arena = None
+                torch.cuda.empty_cache()
         if world == 1 and not args.no_pipeline:
-            ctx.close()          # the legs below bring their own contexts and arenas
-            del arena
-            torch.cuda.empty_cache()
+            release_headline()
             out["pipeline"] = pipeline_leg(lambda: _capi.Context(local_rank), max(1, min(args.steps, 2)), min(1, args.warmup),
                                            0 if args.no_cpu_baseline else 4 * host_cores(), args.images, args.feats)
+        if world == 1 and not args.no_ragged:
+            release_headline()
+            out["ragged"] = ragged_leg(lambda: _capi.Context(local_rank), device, max(1, min(args.steps, 2)),
+                                       min(1, args.warmup), args.images, 2000, 6000, args.kernel, value)
         if world == 1 and not args.no_dense:
             out["dense"] = dense_leg(lambda: _capi.Context(local_rank), device, max(1, min(args.steps, 2)),
                                      min(1, args.warmup), args.images, args.feats, args.kernel)

@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "amc_internal.h"
+#include "scan_accept.h"
 #include "camera_math.h"
 #include "pose_math.h"  // median_angle_host
 
@@ -181,11 +182,19 @@ struct amc_ctx {
     DevBuf<GridDev> d_grids;   // guided matching's keypoint grids, by slot (uploaded with d_imgs)
     float* d_lut = nullptr;
     std::vector<float> h_lut;
-    uint32_t* d_scalars = nullptr;  // [0] cursor, [1] queue head, [2] maxsq scratch
+    // the scan's accept-bit thresholds (scan_accept.h) for the last (max_ratio, max_distance) a match call used
+    ScanAccept* d_accept = nullptr;
+    ScanAccept h_accept{};
+    float accept_ratio = 0.f, accept_distance = 0.f;
+    bool accept_valid = false;
+    uint32_t* d_scalars = nullptr;  // [0] cursor, [1] queue head, [2] maxsq scratch, [3] resolve errors, [4] stream overrun, [5] mfma items
     // per-batch scratch
     DevBuf<PairDev> d_pairs;
     DevBuf<Dot4Work> d_work;
     DevBuf<uint32_t> d_order, d_order2;
+    // mfma work items: group cuts of the two queue orders, scratch of the packing kernels, the descriptors
+    DevBuf<uint32_t> d_grp, d_grp2, d_seg_base, d_grp_segs, d_grp_item_base;
+    DevBuf<SegDesc> d_segs;
     DevBuf<Top2> d_rowbuf, d_colbuf;
     DevBuf<uint32_t> d_accmask;  // one accept bit per row-table entry (mfma pairs)
     DevBuf<GuidedDev> d_guided;  // guided matching: one filter model per pair of the batch
@@ -202,6 +211,7 @@ struct amc_ctx {
     PinBuf<PairDev> h_pairs[2];
     PinBuf<Dot4Work> h_work[2];
     PinBuf<uint32_t> h_order[2], h_order2[2], h_pair_off[2], h_pair_cnt[2], h_matches[2], h_bscalars[2];
+    PinBuf<uint32_t> h_grp[2], h_grp2[2];  // where the streamed image changes in h_order / h_order2 (ngroups + 1 cuts)
     PinBuf<uint32_t> h_scalars;
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     hipEvent_t bev[2][5] = {{nullptr, nullptr, nullptr, nullptr, nullptr},
@@ -325,8 +335,11 @@ void amc_ctx_destroy(amc_ctx* c) {
     c->d_imgs.release();
     c->d_grids.release();
     if (c->d_lut) (void)hipFree(c->d_lut);
+    if (c->d_accept) (void)hipFree(c->d_accept);
     if (c->d_scalars) (void)hipFree(c->d_scalars);
     c->d_pairs.release(); c->d_work.release(); c->d_order.release(); c->d_order2.release();
+    c->d_grp.release(); c->d_grp2.release(); c->d_seg_base.release(); c->d_grp_segs.release();
+    c->d_grp_item_base.release(); c->d_segs.release();
     c->d_rowbuf.release(); c->d_colbuf.release(); c->d_accmask.release(); c->d_guided.release();
     c->d_pair_off.release(); c->d_pair_cnt.release(); c->d_matches.release();
     c->d_cand_cnt.release(); c->d_candbuf.release(); c->d_keep.release(); c->d_csr.release();
@@ -334,6 +347,7 @@ void amc_ctx_destroy(amc_ctx* c) {
     c->h_tout.release(); c->h_tmask.release();
     for (int k = 0; k < 2; ++k) {
         c->h_pairs[k].release(); c->h_work[k].release(); c->h_order[k].release(); c->h_order2[k].release();
+        c->h_grp[k].release(); c->h_grp2[k].release();
         c->h_pair_off[k].release(); c->h_pair_cnt[k].release(); c->h_matches[k].release();
         c->h_bscalars[k].release();
     }
@@ -371,6 +385,7 @@ int amc_ctx_trim(amc_ctx* c) {
     c->d_keep.release(); c->d_csr.release();
     c->resident_matches = 0;
     c->d_rowbuf.release(); c->d_colbuf.release(); c->d_accmask.release(); c->d_matches.release(); c->d_candbuf.release();
+    c->d_segs.release(); c->d_seg_base.release();
     c->d_tws.release(); c->d_tmaskws.release(); c->d_toutmask.release(); c->d_emask.release(); c->d_estate.release();
     c->d_tout.release(); c->d_tmatches.release(); c->d_pmatches.release(); c->d_pcos.release();
     c->h_tout.release(); c->h_tmask.release();
@@ -616,6 +631,19 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
     fp.cross_check = o.cross_check ? 1 : 0;
     fp.reserved = 0;
 
+    // the scan's accept thresholds for these options: built (and proven against the acos table) once per option pair
+    if (!c->accept_valid || std::memcmp(&c->accept_ratio, &fp.max_ratio, sizeof(float)) != 0 ||
+        std::memcmp(&c->accept_distance, &fp.max_distance, sizeof(float)) != 0) {
+        c->h_accept = build_scan_accept(c->h_lut.data(), (uint32_t)c->h_lut.size(), fp.max_ratio, fp.max_distance);
+        if (std::getenv("AMC_SCAN_ACCEPT_TRIVIAL")) c->h_accept.trivial = 1;  // (test hook: keep every row with best >= min_best)
+        if (!c->d_accept) HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->d_accept), sizeof(ScanAccept)));
+        HIPCHK(hipStreamSynchronize(st));  // a previous call's kernels may still read the old thresholds
+        HIPCHK(hipMemcpy(c->d_accept, &c->h_accept, sizeof(ScanAccept), hipMemcpyHostToDevice));
+        c->accept_ratio = fp.max_ratio;
+        c->accept_distance = fp.max_distance;
+        c->accept_valid = true;
+    }
+
     // A batch goes through four steps.  Steps of consecutive batches are interleaved so that the device
     // never waits for the host between them:
     //   prepare(k+1)   host only: route pairs to kernels, queue orders, staging set (k+1)&1   } while the device
@@ -625,6 +653,7 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
     struct Batch {
         size_t begin = 0, end = 0, nb = 0, top_rows = 0, top_cols = 0, cap = 0;
         size_t row_off = 0, nwork = 0, nord = 0, nwork_grid = 0;
+        size_t ngrp = 0, ngrp2 = 0, seg_cap = 0;  // mfma: groups of the two queue orders, descriptors to provide for
         int set = 0;
         uint32_t total = 0;
         bool grouped_resolve = true;
@@ -718,6 +747,31 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
                 return px.slot1 != py.slot1 ? px.slot1 < py.slot1 : px.slot2 < py.slot2;
             });
         }
+        // Cut both orders where the streamed image changes (the packing kernels fill whole items per image),
+        // and bound the number of segment descriptors: ceil(rows / 128) per pair plus up to one item of padding
+        // per group.  The reverse scan's X side is the candidate list, at most every row of image 2.
+        b.ngrp = b.ngrp2 = 0;
+        b.seg_cap = 0;
+        if (nord) {
+            if (!hc(c->h_grp[k].ensure(nord + 1), "pinned group cuts") ||
+                (o.cross_check && !hc(c->h_grp2[k].ensure(nord + 1), "pinned group cuts")))
+                return false;
+            size_t seg1 = 0, seg2 = 0;
+            for (size_t q = 0; q < nord; ++q) {
+                const PairDev& pq = hp[c->h_order[k].p[q]];
+                if (q == 0 || pq.slot2 != hp[c->h_order[k].p[q - 1]].slot2) c->h_grp[k].p[b.ngrp++] = (uint32_t)q;
+                seg1 += (c->slots[pq.slot1].dev.rows + kSegRows - 1) / kSegRows;
+                seg2 += (c->slots[pq.slot2].dev.rows + kSegRows - 1) / kSegRows;
+            }
+            c->h_grp[k].p[b.ngrp] = (uint32_t)nord;
+            if (o.cross_check) {
+                for (size_t q = 0; q < nord; ++q)
+                    if (q == 0 || hp[c->h_order2[k].p[q]].slot1 != hp[c->h_order2[k].p[q - 1]].slot1)
+                        c->h_grp2[k].p[b.ngrp2++] = (uint32_t)q;
+                c->h_grp2[k].p[b.ngrp2] = (uint32_t)nord;
+            }
+            b.seg_cap = std::max(seg1 + kSegsPerItem * b.ngrp, o.cross_check ? seg2 + kSegsPerItem * b.ngrp2 : 0);
+        }
         b.nwork_grid = 0;
         if (nwork) {
             if (!hc(c->h_work[k].ensure(nwork), "pinned work")) return false;
@@ -753,7 +807,9 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
                           c->d_rowbuf.cap < b.top_rows || c->d_colbuf.cap < b.top_cols ||
                           c->d_accmask.cap < b.top_rows / 32 + 8 || c->d_pair_off.cap < nb || c->d_pair_cnt.cap < nb ||
                           c->d_matches.cap < 2 * b.cap || c->d_cand_cnt.cap < nb || c->d_candbuf.cap < b.top_cols ||
-                          c->d_work.cap < nwork || (geoms && c->d_guided.cap < nb);
+                          c->d_work.cap < nwork || (geoms && c->d_guided.cap < nb) || c->d_segs.cap < b.seg_cap ||
+                          c->d_seg_base.cap < nord || c->d_grp.cap < b.ngrp + 1 || c->d_grp2.cap < b.ngrp2 + 1 ||
+                          c->d_grp_segs.cap < std::max(b.ngrp, b.ngrp2) || c->d_grp_item_base.cap < std::max(b.ngrp, b.ngrp2);
         if (grow && !hc(hipStreamSynchronize(st), "sync before growing device scratch")) return false;
         if (!hc(c->d_pairs.ensure(nb), "dev pairs") || !hc(c->d_order.ensure(nb), "dev order") ||
             !hc(c->d_order2.ensure(nb), "dev order2") ||
@@ -762,7 +818,11 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
             !hc(c->d_pair_off.ensure(nb), "pair_off") || !hc(c->d_pair_cnt.ensure(nb), "pair_cnt") ||
             !hc(c->d_matches.ensure(2 * b.cap), "dev matches") ||
             !hc(c->d_cand_cnt.ensure(nb), "cand_cnt") || !hc(c->d_candbuf.ensure(b.top_cols), "candbuf") ||
-            (nwork && !hc(c->d_work.ensure(nwork), "dev work")) || (geoms && !hc(c->d_guided.ensure(nb), "dev guided")))
+            (nwork && !hc(c->d_work.ensure(nwork), "dev work")) || (geoms && !hc(c->d_guided.ensure(nb), "dev guided")) ||
+            !hc(c->d_segs.ensure(b.seg_cap), "segment descriptors") || !hc(c->d_seg_base.ensure(nord), "segment bases") ||
+            !hc(c->d_grp.ensure(b.ngrp + 1), "group cuts") || !hc(c->d_grp2.ensure(b.ngrp2 + 1), "group cuts") ||
+            !hc(c->d_grp_segs.ensure(std::max(b.ngrp, b.ngrp2)), "group segments") ||
+            !hc(c->d_grp_item_base.ensure(std::max(b.ngrp, b.ngrp2)), "group items"))
             return false;
         bool okq = hc(hipMemcpyAsync(c->d_pairs.p, c->h_pairs[k].p, nb * sizeof(PairDev),
                                      hipMemcpyHostToDevice, st), "H2D pairs") &&
@@ -771,7 +831,9 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
         if (okq && nord)
             okq = hc(hipMemcpyAsync(c->d_order.p, c->h_order[k].p, nord * sizeof(uint32_t),
                                     hipMemcpyHostToDevice, st), "H2D order") &&
-                  // row blocks no wave owns (beyond an image's last row) never write their words
+                  hc(hipMemcpyAsync(c->d_grp.p, c->h_grp[k].p, (b.ngrp + 1) * sizeof(uint32_t),
+                                    hipMemcpyHostToDevice, st), "H2D group cuts") &&
+                  // segments no wave owns (beyond an image's last row) never write their words
                   hc(hipMemsetAsync(c->d_accmask.p, 0, (b.row_off / 32 + 8) * sizeof(uint32_t), st), "memset accmask");
         if (okq && nwork)
             okq = hc(hipMemcpyAsync(c->d_work.p, c->h_work[k].p, nwork * sizeof(Dot4Work),
@@ -780,11 +842,15 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
             okq = hc(hipMemcpyAsync(c->d_guided.p, h_guided.data() + b.begin, nb * sizeof(GuidedDev),
                                     hipMemcpyHostToDevice, st), "H2D guided");
         if (!okq) return false;
+        if (nord)  // pack the pairs' 128-row segments into items (per streamed image) ...
+            launch_build_segments(0, c->d_imgs.p, c->d_pairs.p, c->d_order.p, c->d_grp.p, (uint32_t)b.ngrp,
+                                  c->d_cand_cnt.p, c->d_candbuf.p, c->d_rowbuf.p, c->d_seg_base.p, c->d_grp_segs.p,
+                                  c->d_grp_item_base.p, c->d_segs.p, c->d_scalars + 5, st);
         (void)hipEventRecord(c->bev[k][0], st);
-        if (nord)
-            launch_match_mfma(0, c->d_imgs.p, c->d_pairs.p, c->d_order.p, (uint32_t)nord,
-                              c->d_scalars + 1, c->d_cand_cnt.p, c->d_candbuf.p, c->d_rowbuf.p,
-                              c->d_accmask.p, c->d_lut, fp, st);
+        if (nord) {  // ... and scan them (the events bracket the scan kernel alone: bench.py's roofline leg)
+            launch_match_mfma(0, c->d_segs.p, c->d_scalars + 5, (uint32_t)std::min<size_t>(b.seg_cap, 0xFFFFFFFFu),
+                              c->d_scalars + 1, c->d_accmask.p, c->d_accept, st);
+        }
         if (b.nwork_grid)
             launch_match_guided_grid(c->d_imgs.p, c->d_grids.p, c->d_pairs.p, c->d_work.p, (uint32_t)b.nwork_grid,
                                      c->d_rowbuf.p, c->d_colbuf.p, c->d_guided.p, st);
@@ -801,11 +867,16 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
             launch_select_candidates(c->d_imgs.p, c->d_pairs.p, (uint32_t)nb, c->d_rowbuf.p, c->d_accmask.p,
                                      c->d_lut, fp, c->d_cand_cnt.p, c->d_candbuf.p, st);
             if (!hc(hipMemcpyAsync(c->d_order2.p, c->h_order2[k].p, nord * sizeof(uint32_t),
-                                   hipMemcpyHostToDevice, st), "H2D order2"))
+                                   hipMemcpyHostToDevice, st), "H2D order2") ||
+                !hc(hipMemcpyAsync(c->d_grp2.p, c->h_grp2[k].p, (b.ngrp2 + 1) * sizeof(uint32_t),
+                                   hipMemcpyHostToDevice, st), "H2D group cuts"))
                 return false;
-            launch_match_mfma(1, c->d_imgs.p, c->d_pairs.p, c->d_order2.p, (uint32_t)nord,
-                              c->d_scalars + 1, c->d_cand_cnt.p, c->d_candbuf.p, c->d_colbuf.p,
-                              c->d_accmask.p, c->d_lut, fp, st);
+            // the candidate counts exist only on the device: the packing kernels read them there
+            launch_build_segments(1, c->d_imgs.p, c->d_pairs.p, c->d_order2.p, c->d_grp2.p, (uint32_t)b.ngrp2,
+                                  c->d_cand_cnt.p, c->d_candbuf.p, c->d_colbuf.p, c->d_seg_base.p, c->d_grp_segs.p,
+                                  c->d_grp_item_base.p, c->d_segs.p, c->d_scalars + 5, st);
+            launch_match_mfma(1, c->d_segs.p, c->d_scalars + 5, (uint32_t)std::min<size_t>(b.seg_cap, 0xFFFFFFFFu),
+                              c->d_scalars + 1, c->d_accmask.p, c->d_accept, st);
             launch_resolve_index(1, c->d_imgs.p, c->d_pairs.p, (uint32_t)nb, c->d_colbuf.p, c->d_accmask.p, c->d_lut,
                                  fp, c->d_cand_cnt.p, c->d_candbuf.p, c->d_scalars + 3, b.grouped_resolve, st);
         }

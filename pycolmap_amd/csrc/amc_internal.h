@@ -131,10 +131,28 @@ void launch_match_dot4(const ImageDev* imgs, const PairDev* pairs, const Dot4Wor
 void launch_match_guided_grid(const ImageDev* imgs, const GridDev* grids, const PairDev* pairs, const Dot4Work* work,
                               uint32_t nwork, Top2* rowbuf, Top2* colbuf, const GuidedDev* guided, hipStream_t s);
 
-// mfma: one workgroup per work item, dynamic queue over `order` (pair indices, sorted by the
-// streamed image for L2 reuse).  mode 0: rows of image 1 vs image 2 -> rowbuf + row_off.
-// mode 1: candidate rows of image 2 (candbuf + col_off, cand_cnt[pair] of them) vs image 1 ->
-// colbuf + col_off (scattered by row index).
+// mfma work items (match_mfma.hip).  A pair's X side - image 1's rows (mode 0: -> rowbuf + row_off) or the
+// candidate rows of image 2 (mode 1: candbuf + col_off, cand_cnt[pair] of them -> colbuf + col_off, scattered by
+// row index) - is cut into segments of kSegRows rows; the segments of all pairs that stream the same image are
+// packed kSegsPerItem to an item.  One 64-byte descriptor per segment holds every pointer a wave needs, so a
+// workgroup that pops an item is one round trip from its data whatever pairs its segments belong to.
+constexpr int kSegRows = 128;
+constexpr int kSegsPerItem = 8;
+struct alignas(64) SegDesc {
+    const uint8_t* xprep;   // mode 0: the segment's first prepared row; mode 1: the image's row 0
+    const int32_t* xrs;     // rs128, likewise
+    Top2* out;              // mode 0: the segment's first row of the row table; mode 1: the pair's column table
+    const uint32_t* list;   // mode 1: the segment's first entry of the pair's candidate list
+    const uint8_t* yprep;   // the streamed image (the same in all descriptors of an item)
+    const int32_t* yrs;
+    uint32_t cnt;           // rows of this segment, 1..kSegRows; 0: padding descriptor, nothing is stored
+    uint32_t accword;       // mode 0: accmask word of the segment's first row
+    uint32_t yrows;
+    uint32_t pad_;
+};
+#ifndef AMC_MFMA_DEFAULT_WAVES
+#define AMC_MFMA_DEFAULT_WAVES 8   // waves per workgroup of the mfma scan: 8 (x 4 X tiles) or 4 (x 8); AMC_MFMA_SHAPE overrides
+#endif
 // COLMAP's per-row acceptance tests (FindBestMatchesOneWayBruteForce) on a (best,
 // second) pair.  acos thresholds: lut[d] = acosf(min(d/512^2, 1)) built on the HOST with the host
 // libm; (float)d * 2^-18 is exact for d < 2^24, so indexing by min(d, 262144) reproduces COLMAP's
@@ -154,10 +172,19 @@ __device__ __forceinline__ bool one_way_accepts(const Top2 t, const float* __res
 // by the scan for rows that pass the acceptance tests with the preliminary second value, narrowed
 // by resolve_index (side 0) to the rows that pass with the exact one.  The later kernels walk the
 // bits instead of re-reading and re-testing every row.
-void launch_match_mfma(int mode, const ImageDev* imgs, const PairDev* pairs,
-                       const uint32_t* order, uint32_t nitems, uint32_t* queue_head,
-                       const uint32_t* cand_cnt, const uint32_t* candbuf, Top2* outbuf,
-                       uint32_t* accmask, const float* acos_lut, FinalizeParams fp, hipStream_t s);
+// Packs the segments of the pairs listed in `order` (sorted by the streamed image; grp_start cuts it where that
+// image changes) into items: segs[0 .. 8 * *nitems_dev).  seg_base (one per order entry), grp_segs and
+// grp_item_base (one per group) are scratch.  All on stream s; mode 1 reads cand_cnt on the device.
+void launch_build_segments(int mode, const ImageDev* imgs, const PairDev* pairs, const uint32_t* order,
+                           const uint32_t* grp_start, uint32_t ngroups, const uint32_t* cand_cnt,
+                           const uint32_t* candbuf, Top2* outbuf, uint32_t* seg_base, uint32_t* grp_segs,
+                           uint32_t* grp_item_base, SegDesc* segs, uint32_t* nitems_dev, hipStream_t s);
+// The scan over the packed items (persistent workgroups, dynamic queue).  max_items bounds the grid only.
+// accept_dev: the scan's accept-bit thresholds for the call's options (scan_accept.h), in device memory.
+struct ScanAccept;
+void launch_match_mfma(int mode, const SegDesc* segs, const uint32_t* nitems_dev, uint32_t max_items,
+                       uint32_t* queue_head, uint32_t* accmask, const ScanAccept* accept_dev, hipStream_t s);
+int match_mfma_shape();  // waves per workgroup in use (8 or 4)
 
 void launch_resolve_index(int side, const ImageDev* imgs, const PairDev* pairs, uint32_t npairs,
                           Top2* table, uint32_t* accmask, const float* acos_lut, FinalizeParams fp,

@@ -1,0 +1,496 @@
+// ubench_ladder.hip - bottom-up ladder under the match kernel's scan loop.
+//
+// Each rung adds one ingredient of match_mfma.hip's inner loop to a register-only int8 MFMA loop and reports
+// ns per MFMA per SIMD (13.33 ns = one v_mfma_i32_32x32x32_i8 per 32 clk at the nominal 2.4 GHz), for both
+// workgroup shapes of the kernel:
+//     <8 waves x 4 X tiles>  two waves per SIMD, 256 registers each
+//     <4 waves x 8 X tiles>  one wave per SIMD, X fragments in AGPRs
+//   rung 0  MFMAs only (A, B in registers; four dependent MFMAs per unit, units independent)
+//   rung 1  + the four A-fragment ds_read_b128 per Y tile
+//   rung 2  + the C-operand block (four more ds_read_b128 per Y tile; first MFMA of a unit takes it as C)
+//   rung 3  + the 12 VALU per unit (the kernel's three asm blocks), reads spread over the phases
+//   rung 4  (reference) rung 0 with v_mfma_i32_16x16x64_i8, the shape the guide's 3,944 TOPS was taken with
+// Run under rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE (tools/ladder_pmc.sh) for the
+// pipe-busy fraction and the clock each rung holds.
+//
+//   hipcc --offload-arch=gfx950 -O3 -o tools/bin/ubench_ladder tools/ubench_ladder.hip && tools/bin/ubench_ladder
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+template <bool BA>
+__device__ __forceinline__ void mfma_first(i32x16& d, const i32x4& a, const i32x4& b, const i32x16& c) {
+    if constexpr (BA)
+        asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "a"(b), "v"(c));
+    else
+        asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c));
+}
+template <bool BA>
+__device__ __forceinline__ void mfma_acc(i32x16& d, const i32x4& a, const i32x4& b) {
+    if constexpr (BA)
+        asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, %0" : "+v"(d) : "v"(a), "a"(b));
+    else
+        asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b));
+}
+
+constexpr int kLds = 2 * 32768 + 4096;
+
+template <int W, int XT, int LVL>
+__global__ __launch_bounds__(64 * W) void ladder_kernel(int tiles, const int* __restrict__ seed, int* __restrict__ out) {
+    constexpr bool BA = (W == 4);
+    __shared__ __attribute__((aligned(16))) char smem[kLds];
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
+    for (int i = tid; i < kLds / 4; i += 64 * W) reinterpret_cast<int*>(smem)[i] = seed[(i * 7 + blockIdx.x) & 4095];
+    __syncthreads();
+    i32x4 xf[XT][4];
+#pragma unroll
+    for (int xt = 0; xt < XT; ++xt)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int* p = seed + ((tid * 16 + xt * 64 + s * 4) & 4095);
+            if constexpr (BA)
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(xf[xt][s]) : "v"(p) : "memory");
+            else
+                xf[xt][s] = *reinterpret_cast<const i32x4*>(p);
+        }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int best[XT], sec[XT], btile[XT];
+#pragma unroll
+    for (int xt = 0; xt < XT; ++xt) best[xt] = sec[xt] = btile[xt] = 0;
+    struct YF { i32x4 f[4]; i32x16 ci; } y0, y1;
+    auto load_part = [&](YF& y, int yt, int part) __attribute__((always_inline)) {
+        const int row = (yt & 7) * 32 + l31;
+        if (part < 4) {
+            const int* rsb = reinterpret_cast<const int*>(smem + 65536) + (yt & 7) * 32 + 4 * lh;
+            const i32x4 v = *reinterpret_cast<const i32x4*>(rsb + 8 * part);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y.ci[4 * part + e] = v[e];
+        } else {
+            const int s = part - 4, sw = (row >> 1) & 7;
+            y.f[s] = *reinterpret_cast<const i32x4*>(smem + ((yt >> 3) & 1) * 32768 + row * 128 + (((2 * s + lh) ^ sw) * 16));
+        }
+    };
+#pragma unroll
+    for (int part = 0; part < 8; ++part) { load_part(y0, 0, part); load_part(y1, 1, part); }
+    i32x16 acc[2];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[0][e] = acc[1][e] = 0;
+    int pm = 0, ptile = 0;
+    auto phase = [&](i32x16& an, const YF& y, int xtn, const i32x16& ac, int xtc, int tile) __attribute__((always_inline)) {
+        if (LVL >= 2) mfma_first<BA>(an, y.f[0], xf[xtn][0], y.ci); else mfma_acc<BA>(an, y.f[0], xf[xtn][0]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (LVL >= 3) {
+            const int xi = (xtc + XT - 1) % XT;
+            asm volatile("v_cmp_gt_i32 vcc, %3, %0\n\tv_med3_i32 %1, %0, %1, %3\n\tv_max_i32 %0, %0, %3\n\tv_cndmask_b32 %2, %2, %4, vcc"
+                         : "+v"(best[xi]), "+v"(sec[xi]), "+v"(btile[xi]) : "v"(pm), "v"(ptile) : "vcc");
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        mfma_acc<BA>(an, y.f[1], xf[xtn][1]);
+        __builtin_amdgcn_sched_barrier(0);
+        int t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+        if (LVL >= 3) {
+            asm volatile("v_max3_i32 %0, %4, %5, %6\n\tv_max3_i32 %1, %7, %8, %9\n\tv_max3_i32 %2, %10, %11, %12\n\tv_max3_i32 %3, %13, %14, %15"
+                         : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+                         : "v"(ac[0]), "v"(ac[1]), "v"(ac[2]), "v"(ac[3]), "v"(ac[4]), "v"(ac[5]), "v"(ac[6]), "v"(ac[7]),
+                           "v"(ac[8]), "v"(ac[9]), "v"(ac[10]), "v"(ac[11]));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        mfma_acc<BA>(an, y.f[2], xf[xtn][2]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (LVL >= 3) {
+            int m4;
+            asm volatile("v_max3_i32 %1, %4, %5, %6\n\tv_max3_i32 %0, %0, %2, %3\n\tv_max3_i32 %1, %8, %1, %7\n\tv_max_i32 %0, %0, %1"
+                         : "+v"(t0), "=&v"(m4) : "v"(t1), "v"(t2), "v"(ac[12]), "v"(ac[13]), "v"(ac[14]), "v"(ac[15]), "v"(t3));
+            pm = t0;
+            ptile = tile;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        mfma_acc<BA>(an, y.f[3], xf[xtn][3]);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto step = [&](YF& yc, YF& yn, int yt) __attribute__((always_inline)) {
+        constexpr int RPP = 16 / XT;
+#pragma unroll
+        for (int xt = 0; xt < XT; ++xt) {
+            if (xt + 1 < XT) phase(acc[(xt + 1) & 1], yc, xt + 1, acc[xt & 1], xt, yt);
+            else phase(acc[0], yn, 0, acc[xt & 1], xt, yt);
+            if (xt < XT / 2) {
+#pragma unroll
+                for (int r = 0; r < RPP; ++r) {
+                    const int part = xt * RPP + r;
+                    if ((LVL >= 1 && part >= 4) || (LVL >= 2 && part < 4)) load_part(yn, yt + 1, part);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+#pragma unroll 1
+    for (int yt = 0; yt < tiles; yt += 2) {
+        step(y0, y1, yt);
+        step(y1, y0, yt + 1);
+    }
+    int r = pm;
+#pragma unroll
+    for (int xt = 0; xt < XT; ++xt) r ^= best[xt] ^ sec[xt] ^ btile[xt];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) r ^= acc[0][e] ^ acc[1][e];
+    if (r == 0x7fffffff) out[tid] = r;
+}
+
+// The same rungs with the units taken in PAIRS: the MFMAs of units u+2 and u+3 alternate (a0 b0 a1 b1 a2 b2 a3 b3), so
+// no MFMA ever issues directly behind the one it depends on, while the VALU reduces units u and u+1 (four accumulator
+// sets instead of two).  If the dependent back-to-back issue is what keeps the plain loop under the pipe's rate, this
+// order shows it.
+template <int W, int XT, int LVL>
+__global__ __launch_bounds__(64 * W) void ladder2_kernel(int tiles, const int* __restrict__ seed, int* __restrict__ out) {
+    constexpr bool BA = (W == 4);
+    __shared__ __attribute__((aligned(16))) char smem[kLds];
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
+    for (int i = tid; i < kLds / 4; i += 64 * W) reinterpret_cast<int*>(smem)[i] = seed[(i * 7 + blockIdx.x) & 4095];
+    __syncthreads();
+    i32x4 xf[XT][4];
+#pragma unroll
+    for (int xt = 0; xt < XT; ++xt)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int* p = seed + ((tid * 16 + xt * 64 + s * 4) & 4095);
+            if constexpr (BA)
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(xf[xt][s]) : "v"(p) : "memory");
+            else
+                xf[xt][s] = *reinterpret_cast<const i32x4*>(p);
+        }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int best[XT], sec[XT], btile[XT];
+#pragma unroll
+    for (int xt = 0; xt < XT; ++xt) best[xt] = sec[xt] = btile[xt] = 0;
+    struct YF { i32x4 f[4]; i32x16 ci; } y0, y1;
+    auto load_part = [&](YF& y, int yt, int part) __attribute__((always_inline)) {
+        const int row = (yt & 7) * 32 + l31;
+        if (part < 4) {
+            const int* rsb = reinterpret_cast<const int*>(smem + 65536) + (yt & 7) * 32 + 4 * lh;
+            const i32x4 v = *reinterpret_cast<const i32x4*>(rsb + 8 * part);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y.ci[4 * part + e] = v[e];
+        } else {
+            const int s = part - 4, sw = (row >> 1) & 7;
+            y.f[s] = *reinterpret_cast<const i32x4*>(smem + ((yt >> 3) & 1) * 32768 + row * 128 + (((2 * s + lh) ^ sw) * 16));
+        }
+    };
+#pragma unroll
+    for (int part = 0; part < 8; ++part) { load_part(y0, 0, part); load_part(y1, 1, part); }
+    i32x16 acc[4];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[0][e] = acc[1][e] = acc[2][e] = acc[3][e] = 0;
+    int pm[2] = {0, 0}, ptile = 0;
+    auto ins = [&](int xi, int m, int tile) __attribute__((always_inline)) {
+        asm volatile("v_cmp_gt_i32 vcc, %3, %0\n\tv_med3_i32 %1, %0, %1, %3\n\tv_max_i32 %0, %0, %3\n\tv_cndmask_b32 %2, %2, %4, vcc"
+                     : "+v"(best[xi]), "+v"(sec[xi]), "+v"(btile[xi]) : "v"(m), "v"(tile) : "vcc");
+    };
+    auto blkA = [&](const i32x16& ac, int& t0, int& t1, int& t2, int& t3) __attribute__((always_inline)) {
+        asm volatile("v_max3_i32 %0, %4, %5, %6\n\tv_max3_i32 %1, %7, %8, %9\n\tv_max3_i32 %2, %10, %11, %12\n\tv_max3_i32 %3, %13, %14, %15"
+                     : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+                     : "v"(ac[0]), "v"(ac[1]), "v"(ac[2]), "v"(ac[3]), "v"(ac[4]), "v"(ac[5]), "v"(ac[6]), "v"(ac[7]),
+                       "v"(ac[8]), "v"(ac[9]), "v"(ac[10]), "v"(ac[11]));
+    };
+    auto blkB = [&](const i32x16& ac, int& t0, int t1, int t2, int t3) __attribute__((always_inline)) {
+        int m4;
+        asm volatile("v_max3_i32 %1, %4, %5, %6\n\tv_max3_i32 %0, %0, %2, %3\n\tv_max3_i32 %1, %8, %1, %7\n\tv_max_i32 %0, %0, %1"
+                     : "+v"(t0), "=&v"(m4) : "v"(t1), "v"(t2), "v"(ac[12]), "v"(ac[13]), "v"(ac[14]), "v"(ac[15]), "v"(t3));
+    };
+    // pair phase: accumulate units (xn, xn+1) of tile `yn_` into an0/an1, reduce units (xc, xc+1) from ac0/ac1
+    auto pphase = [&](i32x16& an0, i32x16& an1, const YF& y, int xn, const i32x16& ac0, const i32x16& ac1, int xc, int tile)
+                      __attribute__((always_inline)) {
+        if (LVL >= 2) { mfma_first<BA>(an0, y.f[0], xf[xn][0], y.ci); mfma_first<BA>(an1, y.f[0], xf[xn + 1][0], y.ci); }
+        else { mfma_acc<BA>(an0, y.f[0], xf[xn][0]); mfma_acc<BA>(an1, y.f[0], xf[xn + 1][0]); }
+        __builtin_amdgcn_sched_barrier(0);
+        if (LVL >= 3) {
+            ins((xc + XT - 2) % XT, pm[0], ptile);
+            ins((xc + XT - 1) % XT, pm[1], ptile);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        mfma_acc<BA>(an0, y.f[1], xf[xn][1]);
+        mfma_acc<BA>(an1, y.f[1], xf[xn + 1][1]);
+        __builtin_amdgcn_sched_barrier(0);
+        int a0 = 0, a1 = 0, a2 = 0, a3 = 0, b0 = 0, b1 = 0, b2 = 0, b3 = 0;
+        if (LVL >= 3) {
+            blkA(ac0, a0, a1, a2, a3);
+            blkA(ac1, b0, b1, b2, b3);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        mfma_acc<BA>(an0, y.f[2], xf[xn][2]);
+        mfma_acc<BA>(an1, y.f[2], xf[xn + 1][2]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (LVL >= 3) {
+            blkB(ac0, a0, a1, a2, a3);
+            blkB(ac1, b0, b1, b2, b3);
+            pm[0] = a0; pm[1] = b0; ptile = tile;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        mfma_acc<BA>(an0, y.f[3], xf[xn][3]);
+        mfma_acc<BA>(an1, y.f[3], xf[xn + 1][3]);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto step = [&](YF& yc, YF& yn, int yt) __attribute__((always_inline)) {
+        constexpr int NP = XT / 2;      // pair phases per tile
+        constexpr int RPP = 8 / (NP > 1 ? NP / 2 : 1) > 8 ? 8 : 8 / (NP > 1 ? NP / 2 : 1);
+#pragma unroll
+        for (int pp = 0; pp < NP; ++pp) {
+            const int xc = 2 * pp;
+            i32x16& c0 = acc[(pp & 1) * 2];
+            i32x16& c1 = acc[(pp & 1) * 2 + 1];
+            i32x16& n0 = acc[((pp + 1) & 1) * 2];
+            i32x16& n1 = acc[((pp + 1) & 1) * 2 + 1];
+            if (pp + 1 < NP) pphase(n0, n1, yc, xc + 2, c0, c1, xc, yt);
+            else pphase(n0, n1, yn, 0, c0, c1, xc, yt);
+            if (pp < (NP > 1 ? NP / 2 : 1)) {
+#pragma unroll
+                for (int r = 0; r < RPP; ++r) {
+                    const int part = pp * RPP + r;
+                    if (part < 8 && ((LVL >= 1 && part >= 4) || (LVL >= 2 && part < 4))) load_part(yn, yt + 1, part);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+#pragma unroll 1
+    for (int yt = 0; yt < tiles; yt += 2) {
+        step(y0, y1, yt);
+        step(y1, y0, yt + 1);
+    }
+    int r = pm[0] ^ pm[1];
+#pragma unroll
+    for (int xt = 0; xt < XT; ++xt) r ^= best[xt] ^ sec[xt] ^ btile[xt];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) r ^= acc[0][e] ^ acc[1][e] ^ acc[2][e] ^ acc[3][e];
+    if (r == 0x7fffffff) out[tid] = r;
+}
+
+// The scan loop re-tiled for v_mfma_i32_16x16x64_i8 (4 passes, 4 accumulator registers): a unit is one 16-row X tile
+// against a PAIR of 16-row Y tiles (= the 32-row tile resolve_index recomputes), four MFMAs and 8 outputs per lane;
+// VALU per unit: maximum of 8 (4 ops) + one insertion (4 ops).  Same LDS bytes per MAC as the 32x32x32 loop, a third
+// more VALU per output.  LVL as above (0: MFMAs only ... 3: everything).
+typedef int i32x4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void mfma16_first(i32x4v& d, const i32x4v& a, const i32x4v& b, const i32x4v& c) {
+    asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c));
+}
+__device__ __forceinline__ void mfma16_acc(i32x4v& d, const i32x4v& a, const i32x4v& b) {
+    asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b));
+}
+template <int W, int LVL>
+__global__ __launch_bounds__(64 * W) void ladder16_kernel(int tiles, const int* __restrict__ seed, int* __restrict__ out) {
+    constexpr int XT = 8;  // 16-row X tiles per wave (128 rows)
+    __shared__ __attribute__((aligned(16))) char smem[kLds];
+    const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lq = lane >> 4;
+    for (int i = tid; i < kLds / 4; i += 64 * W) reinterpret_cast<int*>(smem)[i] = seed[(i * 7 + blockIdx.x) & 4095];
+    __syncthreads();
+    i32x4v xf[XT][2];
+#pragma unroll
+    for (int xt = 0; xt < XT; ++xt)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) xf[xt][s] = *reinterpret_cast<const i32x4v*>(seed + ((tid * 16 + xt * 64 + s * 4) & 4095));
+    int best[XT], sec[XT], btile[XT];
+#pragma unroll
+    for (int xt = 0; xt < XT; ++xt) best[xt] = sec[xt] = btile[xt] = 0;
+    struct YF { i32x4v f[2][2]; i32x4v ci[2]; } y0, y1;  // two 16-row tiles x two k halves; C blocks
+    auto load_part = [&](YF& y, int yt, int part) __attribute__((always_inline)) {
+        if (part < 2) {
+            const int* rsb = reinterpret_cast<const int*>(smem + 65536) + (yt & 7) * 32 + part * 16 + 4 * lq;
+            y.ci[part] = *reinterpret_cast<const i32x4v*>(rsb);
+        } else {
+            const int t = (part - 2) >> 1, s = (part - 2) & 1;
+            const int row = (yt & 7) * 32 + t * 16 + l15, sw = (row >> 1) & 7;
+            y.f[t][s] = *reinterpret_cast<const i32x4v*>(smem + ((yt >> 3) & 1) * 32768 + row * 128 + (((4 * s + lq) ^ sw) * 16));
+        }
+    };
+#pragma unroll
+    for (int part = 0; part < 6; ++part) { load_part(y0, 0, part); load_part(y1, 1, part); }
+    i32x4v acc[2][2];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[0][0][e] = acc[0][1][e] = acc[1][0][e] = acc[1][1][e] = 0;
+    int pm = 0, ptile = 0;
+    auto phase = [&](i32x4v (&an)[2], const YF& y, int xtn, const i32x4v (&ac)[2], int xtc, int tile) __attribute__((always_inline)) {
+        if (LVL >= 2) { mfma16_first(an[0], y.f[0][0], xf[xtn][0], y.ci[0]); mfma16_first(an[1], y.f[1][0], xf[xtn][0], y.ci[1]); }
+        else { mfma16_acc(an[0], y.f[0][0], xf[xtn][0]); mfma16_acc(an[1], y.f[1][0], xf[xtn][0]); }
+        __builtin_amdgcn_sched_barrier(0);
+        if (LVL >= 3) {
+            const int xi = (xtc + XT - 1) % XT;
+            asm volatile("v_cmp_gt_i32 vcc, %3, %0\n\tv_med3_i32 %1, %0, %1, %3\n\tv_max_i32 %0, %0, %3\n\tv_cndmask_b32 %2, %2, %4, vcc"
+                         : "+v"(best[xi]), "+v"(sec[xi]), "+v"(btile[xi]) : "v"(pm), "v"(ptile) : "vcc");
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        mfma16_acc(an[0], y.f[0][1], xf[xtn][1]);
+        mfma16_acc(an[1], y.f[1][1], xf[xtn][1]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (LVL >= 3) {
+            int t0, t1;
+            asm volatile("v_max3_i32 %0, %2, %3, %4\n\tv_max3_i32 %1, %5, %6, %7\n\tv_max3_i32 %0, %0, %8, %9\n\tv_max_i32 %0, %0, %1"
+                         : "=&v"(t0), "=&v"(t1)
+                         : "v"(ac[0][0]), "v"(ac[0][1]), "v"(ac[0][2]), "v"(ac[0][3]), "v"(ac[1][0]), "v"(ac[1][1]), "v"(ac[1][2]), "v"(ac[1][3]));
+            pm = t0;
+            ptile = tile;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto step = [&](YF& yc, YF& yn, int yt) __attribute__((always_inline)) {
+#pragma unroll
+        for (int xt = 0; xt < XT; ++xt) {
+            if (xt + 1 < XT) phase(acc[(xt + 1) & 1], yc, xt + 1, acc[xt & 1], xt, yt);
+            else phase(acc[0], yn, 0, acc[xt & 1], xt, yt);
+            if (xt < 6) {
+                const int part = xt;
+                if ((LVL >= 1 && part >= 2) || (LVL >= 2 && part < 2)) load_part(yn, yt + 1, part);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+#pragma unroll 1
+    for (int yt = 0; yt < tiles; yt += 2) {
+        step(y0, y1, yt);
+        step(y1, y0, yt + 1);
+    }
+    int r = pm;
+#pragma unroll
+    for (int xt = 0; xt < XT; ++xt) r ^= best[xt] ^ sec[xt] ^ btile[xt];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r ^= acc[0][0][e] ^ acc[0][1][e] ^ acc[1][0][e] ^ acc[1][1][e];
+    if (r == 0x7fffffff) out[tid] = r;
+}
+
+template <int W, int LVL>
+static void run16(const char* name, const int* d_seed, int* d_out, int cus);
+
+// register-only v_mfma_i32_16x16x64_i8: 8 independent accumulators, W waves
+template <int W>
+__global__ __launch_bounds__(64 * W) void mfma16_kernel(int iters, const int* __restrict__ seed, int* __restrict__ out) {
+    typedef int i32x4v __attribute__((ext_vector_type(4)));
+    const int tid = threadIdx.x;
+    i32x4v a = *reinterpret_cast<const i32x4v*>(seed + ((tid * 4) & 4095));
+    i32x4v b = *reinterpret_cast<const i32x4v*>(seed + ((tid * 4 + 1024) & 4095));
+    i32x4v acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = i32x4v{0, 0, 0, 0};
+#pragma unroll 1
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, acc[k], 0, 0, 0);
+    }
+    int r = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) r ^= acc[k][0] ^ acc[k][1] ^ acc[k][2] ^ acc[k][3];
+    if (r == 0x7fffffff) out[tid] = r;
+}
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); std::exit(1); } } while (0)
+
+template <int W, int XT, int LVL, int PAIRED>
+static void run(const char* name, const int* d_seed, int* d_out, int cus) {
+    const int tiles = 8192;  // Y tiles per launch: XT * 4 MFMAs each
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    auto launch = [&](int t) {
+        if (PAIRED) hipLaunchKernelGGL((ladder2_kernel<W, XT, LVL>), dim3(cus), dim3(64 * W), 0, 0, t, d_seed, d_out);
+        else hipLaunchKernelGGL((ladder_kernel<W, XT, LVL>), dim3(cus), dim3(64 * W), 0, 0, t, d_seed, d_out);
+    };
+    launch(256);  // warm-up
+    CHECK(hipDeviceSynchronize());
+    float best = 1e30f;
+    for (int rep = 0; rep < 3; ++rep) {
+        CHECK(hipEventRecord(e0));
+        launch(tiles);
+        CHECK(hipEventRecord(e1));
+        CHECK(hipEventSynchronize(e1));
+        float ms;
+        CHECK(hipEventElapsedTime(&ms, e0, e1));
+        if (ms < best) best = ms;
+    }
+    // per SIMD: waves per SIMD x tiles x XT x 4 MFMAs
+    const double mfma_per_simd = (double)(W / 4) * tiles * XT * 4;
+    const double ns = best * 1e6 / mfma_per_simd;
+    std::printf("%-34s W%dx%d %s rung %d: %8.3f ms  %6.2f ns/MFMA/SIMD  = %.3f of nominal (13.33 ns)\n", name, W, XT,
+                PAIRED ? "paired" : "chain ", LVL, best, ns, 13.3333 / ns);
+}
+
+template <int W, int LVL>
+static void run16(const char* name, const int* d_seed, int* d_out, int cus) {
+    const int tiles = 8192;  // 32-row Y tile pairs per launch: 8 X tiles x 4 MFMAs (16x16x64) each
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    hipLaunchKernelGGL((ladder16_kernel<W, LVL>), dim3(cus), dim3(64 * W), 0, 0, 256, d_seed, d_out);
+    CHECK(hipDeviceSynchronize());
+    float best = 1e30f;
+    for (int rep = 0; rep < 3; ++rep) {
+        CHECK(hipEventRecord(e0));
+        hipLaunchKernelGGL((ladder16_kernel<W, LVL>), dim3(cus), dim3(64 * W), 0, 0, tiles, d_seed, d_out);
+        CHECK(hipEventRecord(e1));
+        CHECK(hipEventSynchronize(e1));
+        float ms;
+        CHECK(hipEventElapsedTime(&ms, e0, e1));
+        if (ms < best) best = ms;
+    }
+    const double eq = (double)(W / 4) * tiles * 8 * 4 / 2;  // in 32x32x32-equivalents (half the MACs each)
+    const double ns = best * 1e6 / eq;
+    std::printf("%-34s W%d 16x16x64 rung %d: %8.3f ms  %6.2f ns/MFMA-equiv/SIMD = %.3f of nominal (13.33 ns)\n", name, W, LVL, best, ns, 13.3333 / ns);
+}
+
+int main() {
+    int dev = 0, cus = 256;
+    CHECK(hipGetDevice(&dev));
+    CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    std::vector<int> h(4096);
+    unsigned s = 12345;
+    for (auto& v : h) { s = s * 1664525u + 1013904223u; v = (int)s; }
+    int *d_seed, *d_out;
+    CHECK(hipMalloc(&d_seed, 4096 * sizeof(int) + 64));
+    CHECK(hipMalloc(&d_out, 4096 * sizeof(int)));
+    CHECK(hipMemcpy(d_seed, h.data(), 4096 * sizeof(int), hipMemcpyHostToDevice));
+    std::printf("CUs %d\n", cus);
+    run<8, 4, 0, 0>("MFMA only", d_seed, d_out, cus);
+    run<8, 4, 1, 0>("+ A-fragment ds_read_b128", d_seed, d_out, cus);
+    run<8, 4, 2, 0>("+ C-operand block", d_seed, d_out, cus);
+    run<8, 4, 3, 0>("+ 12 VALU per unit", d_seed, d_out, cus);
+    run<4, 8, 0, 0>("MFMA only", d_seed, d_out, cus);
+    run<4, 8, 1, 0>("+ A-fragment ds_read_b128", d_seed, d_out, cus);
+    run<4, 8, 2, 0>("+ C-operand block", d_seed, d_out, cus);
+    run<4, 8, 3, 0>("+ 12 VALU per unit", d_seed, d_out, cus);
+    run<8, 4, 0, 1>("MFMA only", d_seed, d_out, cus);
+    run<8, 4, 2, 1>("+ A fragments + C block", d_seed, d_out, cus);
+    run<8, 4, 3, 1>("+ 12 VALU per unit", d_seed, d_out, cus);
+    run<4, 8, 0, 1>("MFMA only", d_seed, d_out, cus);
+    run<4, 8, 2, 1>("+ A fragments + C block", d_seed, d_out, cus);
+    run<4, 8, 3, 1>("+ 12 VALU per unit", d_seed, d_out, cus);
+    run16<8, 0>("MFMA only", d_seed, d_out, cus);
+    run16<8, 1>("+ A-fragment ds_read_b128", d_seed, d_out, cus);
+    run16<8, 2>("+ C-operand block", d_seed, d_out, cus);
+    run16<8, 3>("+ 8 VALU per 8 outputs", d_seed, d_out, cus);
+    run16<4, 0>("MFMA only", d_seed, d_out, cus);
+    run16<4, 3>("+ reads + 8 VALU per 8 outputs", d_seed, d_out, cus);
+    for (int w : {4, 8}) {
+        hipEvent_t e0, e1;
+        CHECK(hipEventCreate(&e0));
+        CHECK(hipEventCreate(&e1));
+        const int iters = 1 << 17;
+        float best = 1e30f;
+        for (int rep = 0; rep < 4; ++rep) {
+            CHECK(hipEventRecord(e0));
+            if (w == 4) hipLaunchKernelGGL((mfma16_kernel<4>), dim3(cus), dim3(256), 0, 0, rep ? iters : 64, d_seed, d_out);
+            else hipLaunchKernelGGL((mfma16_kernel<8>), dim3(cus), dim3(512), 0, 0, rep ? iters : 64, d_seed, d_out);
+            CHECK(hipEventRecord(e1));
+            CHECK(hipEventSynchronize(e1));
+            float ms;
+            CHECK(hipEventElapsedTime(&ms, e0, e1));
+            if (rep && ms < best) best = ms;
+        }
+        // a 16x16x64 MFMA is half a 32x32x32 one: report per 32x32x32-equivalent
+        const double eq = (double)(w / 4) * iters * 8 / 2;
+        const double ns = best * 1e6 / eq;
+        std::printf("%-34s W%d    rung 4: %8.3f ms  %6.2f ns/MFMA-equiv/SIMD = %.3f of nominal\n", "16x16x64 register-only", w, best, ns, 13.3333 / ns);
+    }
+    return 0;
+}
