@@ -152,6 +152,7 @@ __global__ __launch_bounds__(64 * W) void match_mfma_kernel(const SegDesc* __res
     const int l31 = lane & 31, lh = lane >> 5;
     volatile uint32_t* s_q = reinterpret_cast<volatile uint32_t*>(smem + kOffQ);
     const uint32_t nitems = *nitems_p;
+    const ScanAccept sa = *accept;  // twelve scalar registers for the whole kernel (re-read per row block it is four dependent scalar-cache round trips per X tile)
 
     // a wave's SPW descriptors of item q, one dword per lane (lanes 16*SPW.. hold 0)
     auto load_desc = [&](uint32_t q) -> int {
@@ -480,7 +481,7 @@ __global__ __launch_bounds__(64 * W) void match_mfma_kernel(const SegDesc* __res
                     out[row] = o;
                     // a larger second only ever rejects: rows failing now can be forgotten
                     // (scan_accept.h: thresholds instead of acos; a superset of what the exact tests keep)
-                    if (MODE == 0) acc_bit = scan_may_accept(*accept, o.best_v, o.second_v);
+                    if (MODE == 0) acc_bit = scan_may_accept(sa, o.best_v, o.second_v);
 #endif
                 }
                 if (MODE == 0 && cnt > 0) {  // accept bits of the 32 rows of this X tile (lanes 0..31)

@@ -443,9 +443,31 @@ int main() {
     int dev = 0, cus = 256;
     CHECK(hipGetDevice(&dev));
     CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    // operand data: the matrix pipe's power (hence the clock the chip holds) depends on what it multiplies.
+    //   LADDER_DATA=0 random bytes (default) | 1 SIFT-like under the kernel's zero point (0x80 + small values)
+    //   2 small positive bytes (what a zero point of 0 would feed) | 3 zeros | 4 all 0x80
+    const int mode = std::getenv("LADDER_DATA") ? std::atoi(std::getenv("LADDER_DATA")) : 0;
     std::vector<int> h(4096);
     unsigned s = 12345;
-    for (auto& v : h) { s = s * 1664525u + 1013904223u; v = (int)s; }
+    auto rnd = [&] { s = s * 1664525u + 1013904223u; return s >> 8; };
+    for (auto& v : h) {
+        unsigned w = 0;
+        for (int b = 0; b < 4; ++b) {
+            unsigned byte;
+            const unsigned r = rnd();
+            const unsigned small = (r & 1) ? (r >> 1) % 12 : ((r >> 1) % 64);  // half near zero, half up to 63
+            switch (mode) {
+                case 1: byte = 0x80u + small; break;
+                case 2: byte = small; break;
+                case 3: byte = 0; break;
+                case 4: byte = 0x80u; break;
+                default: byte = r & 255u;
+            }
+            w |= byte << (8 * b);
+        }
+        v = (int)w;
+    }
+    std::printf("data mode %d\n", mode);
     int *d_seed, *d_out;
     CHECK(hipMalloc(&d_seed, 4096 * sizeof(int) + 64));
     CHECK(hipMalloc(&d_out, 4096 * sizeof(int)));
