@@ -579,8 +579,10 @@ __global__ __launch_bounds__(1024) void seg_scan_kernel(const uint32_t* __restri
     if (tid == 0) *nitems_out = running;
 }
 
-// one 256-thread block per group: a wave per pair in turn writes the pair's descriptors (lane = segment),
-// then the block pads the group's last item
+// kFillY 256-thread blocks per group: a wave per pair in turn writes the pair's descriptors (lane = segment);
+// the group's first block pads its last item.  (One block per group left the 500 groups of an exhaustive launch
+// to 500 blocks: 2 ms per launch on the dense set.)
+constexpr uint32_t kFillY = 8;
 __global__ __launch_bounds__(256) void seg_fill_kernel(int mode, const ImageDev* __restrict__ imgs,
                                                        const PairDev* __restrict__ pairs,
                                                        const uint32_t* __restrict__ order,
@@ -591,7 +593,7 @@ __global__ __launch_bounds__(256) void seg_fill_kernel(int mode, const ImageDev*
                                                        const uint32_t* __restrict__ grp_segs,
                                                        const uint32_t* __restrict__ grp_item_base,
                                                        Top2* __restrict__ outbuf, SegDesc* __restrict__ segs) {
-    const uint32_t g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const uint32_t g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = blockIdx.y * 4 + (tid >> 6);
     const uint32_t i0 = grp_start[g], i1 = grp_start[g + 1];
     if (i0 >= i1) return;
     const uint32_t total = grp_segs[g];
@@ -600,7 +602,7 @@ __global__ __launch_bounds__(256) void seg_fill_kernel(int mode, const ImageDev*
     // the group's streamed image (the same for all of its pairs)
     const PairDev p0 = pairs[order[i0]];
     const ImageDev Y = imgs[mode == 0 ? p0.slot2 : p0.slot1];
-    for (uint32_t i = i0 + wid; i < i1; i += 4) {
+    for (uint32_t i = i0 + wid; i < i1; i += 4 * kFillY) {
         const uint32_t pi = order[i];
         const PairDev p = pairs[pi];
         uint32_t nx;
@@ -632,7 +634,7 @@ __global__ __launch_bounds__(256) void seg_fill_kernel(int mode, const ImageDev*
         }
     }
     const uint32_t padded = (total + kSegsPerItem - 1) / kSegsPerItem * kSegsPerItem;
-    if (tid < padded - total) {
+    if (blockIdx.y == 0 && tid < padded - total) {
         SegDesc d;
         d.xprep = Y.prep;  // any mapped rows: a null segment's results are never stored
         d.xrs = Y.rs128;
@@ -659,7 +661,7 @@ void launch_build_segments(int mode, const ImageDev* imgs, const PairDev* pairs,
     hipLaunchKernelGGL(seg_count_kernel, dim3(ngroups), dim3(256), 0, s, mode, imgs, pairs, order, grp_start,
                        cand_cnt, seg_base, grp_segs);
     hipLaunchKernelGGL(seg_scan_kernel, dim3(1), dim3(1024), 0, s, grp_segs, ngroups, grp_item_base, nitems_dev);
-    hipLaunchKernelGGL(seg_fill_kernel, dim3(ngroups), dim3(256), 0, s, mode, imgs, pairs, order, grp_start,
+    hipLaunchKernelGGL(seg_fill_kernel, dim3(ngroups, kFillY), dim3(256), 0, s, mode, imgs, pairs, order, grp_start,
                        cand_cnt, candbuf, seg_base, grp_segs, grp_item_base, outbuf, segs);
 }
 
