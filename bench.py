@@ -464,6 +464,50 @@ def dense_leg(ctx_factory, device, steps: int, warmup: int, num_images: int, fea
                                   "python_free_previous_result": 1e3 * t_free / steps, "python_call": 1e3 * t_call / steps}}
 
 
+def db_leg(num_images: int, feats: int, seed: int = 11):
+    """What a pycolmap user sees: `pycolmap.match_exhaustive(database_path)` (the drop-in of
+    /root/reference/pycolmap/pipeline/match_features.h:22-49, verification on, default options) on a COLMAP database
+    holding BASELINE configs[2]'s image set - SQLite read, upload, match + verify on the device, SQLite write - with
+    the controller's own breakdown (`last_run_stats()`), and the resume path (a second call finds everything there).
+    The kernel legs above time the device work; this leg is the wall clock around it."""
+    import sys as _sys
+    import tempfile
+    _sys.path.insert(0, str(ROOT / "tests"))
+    import colmap_db                      # writes the reference's schema with sqlite3 (test infrastructure: the fixture, not a checker)
+    import pycolmap_amd as pc
+    from pycolmap_amd import synth
+    rng = np.random.default_rng(seed)
+    images = synth.tower_scene(rng, num_images=num_images, n_feats=feats)
+    for k, im in enumerate(images):
+        im["name"] = f"im{k:05d}.jpg"
+        im["prior"] = True
+    with tempfile.TemporaryDirectory() as d:
+        db = os.path.join(d, "bench.db")
+        t0 = time.perf_counter()
+        colmap_db.create(db, images)
+        create_s = time.perf_counter() - t0
+        size_in = os.path.getsize(db)
+        t0 = time.perf_counter()
+        pc.match_exhaustive(db)
+        wall = time.perf_counter() - t0
+        st = {k: (float(v) if isinstance(v, (int, float)) else v) for k, v in dict(pc.last_run_stats()).items()}
+        dbo = pc.Database(db)
+        matched, verified = int(dbo.num_matched_image_pairs), int(dbo.num_verified_image_pairs)
+        nmatches, ninl = int(dbo.num_matches), int(dbo.num_inlier_matches)
+        del dbo
+        size_out = os.path.getsize(db)
+        t0 = time.perf_counter()
+        pc.match_exhaustive(db)
+        rerun = time.perf_counter() - t0
+    npairs = num_images * (num_images - 1) // 2
+    return {"metric": "pycolmap.match_exhaustive(database) wall time, verification on", "value": npairs / wall,
+            "unit": "image pairs/s through the API", "wall_s": wall, "rerun_wall_s": rerun,
+            "workload": f"{num_images} images x {feats} features (synth.tower_scene, seed {seed}), {npairs} pairs, default "
+                        f"SiftMatchingOptions / TwoViewGeometryOptions, COLMAP schema database on local disk",
+            "stats": st, "db_bytes_before": size_in, "db_bytes_after": size_out, "create_db_s": create_s,
+            "pairs_with_matches": matched, "pairs_verified": verified, "matches": nmatches, "inlier_matches": ninl}
+
+
 def ragged_leg(ctx_factory, device, steps: int, warmup: int, num_images: int, lo: int, hi: int, kernel: str,
                uniform_value: float):
     """configs[1] with image sizes a real capture has: n ~ U[lo, hi] descriptors per image (seeded), nothing a multiple
@@ -821,6 +865,7 @@ def main():
     ap.add_argument("--no-pipeline", action="store_true", help="skip the chained configs[2] leg")
     ap.add_argument("--no-dense", action="store_true", help="skip the dense-overlap match leg")
     ap.add_argument("--no-ragged", action="store_true", help="skip the ragged-size match leg (n ~ U[2000, 6000])")
+    ap.add_argument("--no-db", action="store_true", help="skip the database leg (pycolmap.match_exhaustive wall time)")
     args = ap.parse_args()
     if args.config is None:
         args.config = 1 if (args.gpus == 1 or args.weak) else 3
@@ -1008,6 +1053,12 @@ def main():
         if world == 1 and not args.no_dense:
             out["dense"] = dense_leg(lambda: _capi.Context(local_rank), device, max(1, min(args.steps, 2)),
                                      min(1, args.warmup), args.images, args.feats, args.kernel)
+        if world == 1 and not args.no_db:
+            release_headline()
+            try:
+                out["db"] = db_leg(args.images, args.feats)
+            except Exception as e:  # the API leg must not take the kernel legs' numbers down with it
+                out["db"] = {"error": f"{type(e).__name__}: {e}"}
         final_line = json.dumps(out)
     else:
         final_line = None

@@ -58,9 +58,8 @@ enum {
     AMC_E_STATE = -4    /* e.g. slot not uploaded */
 };
 
-/* Which match kernel to run.  AUTO picks the int8-MFMA kernel (exact for any u8 values) unless
- * image 2 has more than 32768 descriptors and cross_check is on (candidate bitmap limit), where
- * it uses the u8 dot4 kernel (see DESIGN.md "match kernels"). */
+/* Which match kernel to run.  AUTO picks the int8-MFMA kernel (exact for any u8 values and any image size up to
+ * 2^20 descriptors; beyond that, with cross_check on, the u8 dot4 kernel - see DESIGN.md "match kernels"). */
 enum { AMC_KERNEL_AUTO = 0, AMC_KERNEL_MFMA = 1, AMC_KERNEL_DOT4 = 2 };
 
 typedef struct amc_ctx amc_ctx;

@@ -653,6 +653,7 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
     struct Batch {
         size_t begin = 0, end = 0, nb = 0, top_rows = 0, top_cols = 0, cap = 0;
         size_t row_off = 0, nwork = 0, nord = 0, nwork_grid = 0;
+        uint32_t max_cols = 0;  // largest image 2 among the batch's mfma pairs (select_candidates' bitmap)
         size_t ngrp = 0, ngrp2 = 0, seg_cap = 0;  // mfma: groups of the two queue orders, descriptors to provide for
         int set = 0;
         uint32_t total = 0;
@@ -687,7 +688,7 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
             !hc(c->h_pair_cnt[k].ensure(nb), "pinned pair_cnt") || !hc(c->h_bscalars[k].ensure(16), "pinned scalars"))
             return false;
         // mfma: exact for any u8 values and sizes; the lazy cross check's candidate bitmap
-        // (select_candidates_kernel) holds kSelectMaxCols image-2 rows, larger images take the dot4 path.
+        // (select_candidates_kernel) holds kSelectMaxCols = 1 Mi image-2 rows, larger images take the dot4 path.
         std::vector<uint8_t> want_mfma(nb, 0);
         for (size_t i = 0; i < nb; ++i) {
             const Slot& x = c->slots[slot1[begin + i]];
@@ -724,6 +725,7 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
             if (want_mfma[i]) {
                 c->h_order[k].p[nord++] = (uint32_t)i;
                 ++n_mfma;
+                b.max_cols = std::max(b.max_cols, y.dev.rows);
                 // the tile-grouped resolve needs both images' tiles to fit its LDS histogram
                 if (std::max(x.dev.rows_pad, y.dev.rows_pad) > resolve_grouped_max_rows()) b.grouped_resolve = false;
             } else {
@@ -864,7 +866,7 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
                                  fp, c->d_cand_cnt.p, c->d_candbuf.p, c->d_scalars + 3, b.grouped_resolve, st);
         if (nord && o.cross_check) {
             // lazy cross check: reverse scan only for the columns accepted rows point at
-            launch_select_candidates(c->d_imgs.p, c->d_pairs.p, (uint32_t)nb, c->d_rowbuf.p, c->d_accmask.p,
+            launch_select_candidates(c->d_imgs.p, c->d_pairs.p, (uint32_t)nb, b.max_cols, c->d_rowbuf.p, c->d_accmask.p,
                                      c->d_lut, fp, c->d_cand_cnt.p, c->d_candbuf.p, st);
             if (!hc(hipMemcpyAsync(c->d_order2.p, c->h_order2[k].p, nord * sizeof(uint32_t),
                                    hipMemcpyHostToDevice, st), "H2D order2") ||

@@ -192,9 +192,10 @@ void launch_resolve_index(int side, const ImageDev* imgs, const PairDev* pairs, 
                           bool grouped, hipStream_t s);
 // largest image (padded rows) the tile-grouped variant of resolve_index handles (its LDS histogram)
 uint32_t resolve_grouped_max_rows();
-constexpr uint32_t kSelectMaxCols = 32768;  // select_candidates' LDS bitmap (4 KiB)
+constexpr uint32_t kSelectMaxCols = 1u << 20;  // select_candidates' LDS bitmap: at most 128 KiB of dynamic shared memory
 
-void launch_select_candidates(const ImageDev* imgs, const PairDev* pairs, uint32_t npairs,
+// max_cols: the largest image 2 (rows) among the launch's pairs - sizes the kernel's LDS bitmap
+void launch_select_candidates(const ImageDev* imgs, const PairDev* pairs, uint32_t npairs, uint32_t max_cols,
                               const Top2* rowbuf, const uint32_t* accmask, const float* acos_lut,
                               FinalizeParams fp, uint32_t* cand_cnt, uint32_t* candbuf, hipStream_t s);
 

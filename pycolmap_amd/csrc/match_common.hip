@@ -1,5 +1,7 @@
 // match_common.hip — descriptor preparation and the finalize (thresholds + cross-check +
 // ordered compaction) kernel shared by both match kernels.  gfx950 only.
+#include <algorithm>
+
 #include "amc_internal.h"
 
 namespace amc {
@@ -488,17 +490,17 @@ uint32_t resolve_grouped_max_rows() { return kResolveMaxTiles * 32; }
 // ---------------------------------------------------------------------------------------
 // select_candidates: which rows of image 2 ("columns") does the cross check need?  Exactly
 // those some accepted row of image 1 points at.  One workgroup per pair: rows that pass
-// COLMAP's one-way tests set bit best_idx in an LDS bitmap (<= kSelectMaxCols columns on the mfma path);
-// the bitmap is then compacted, ascending, into candbuf[col_off ...] and counted.
+// COLMAP's one-way tests set bit best_idx in an LDS bitmap; the bitmap is then compacted,
+// ascending, into candbuf[col_off ...] and counted.  The bitmap is dynamic shared memory sized
+// by the launch's largest image 2 (kSelectMaxCols = 1 Mi columns = 128 KiB bounds it): thread t
+// owns `per` consecutive words, so ascending column order is thread order.
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void select_candidates_kernel(
     const ImageDev* __restrict__ imgs, const PairDev* __restrict__ pairs,
     const Top2* __restrict__ rowbuf, const uint32_t* __restrict__ accmask,
     const float* __restrict__ lut, FinalizeParams fp, uint32_t* __restrict__ cand_cnt,
     uint32_t* __restrict__ candbuf) {
-    constexpr uint32_t kWords = kSelectMaxCols / 32;  // bitmap words
-    constexpr uint32_t kPer = kWords / 256;           // consecutive words per thread
-    __shared__ uint32_t bits[kWords];
+    extern __shared__ uint32_t bits[];  // 256 * per words (the launch's bound; this pair uses what its n2 needs)
     __shared__ uint32_t wsum[4];
     const PairDev p = pairs[blockIdx.x];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -507,8 +509,9 @@ __global__ __launch_bounds__(256) void select_candidates_kernel(
         return;
     }
     const uint32_t n1 = imgs[p.slot1].rows, n2 = imgs[p.slot2].rows;
+    const uint32_t per = ((n2 + 31) / 32 + 255) / 256;  // words per thread for THIS pair
     const Top2* rows = rowbuf + p.row_off;
-    for (uint32_t k = tid; k < kWords; k += 256) bits[k] = 0;
+    for (uint32_t k = tid; k < per * 256; k += 256) bits[k] = 0;
     __syncthreads();
     if (n2 != 0) {
         const uint32_t* mask = accmask + (p.row_off >> 5);  // final accept bits (resolve_index)
@@ -519,14 +522,8 @@ __global__ __launch_bounds__(256) void select_candidates_kernel(
         }
     }
     __syncthreads();
-    // thread t owns words [t*kPer, (t+1)*kPer): ascending column order is thread order
-    uint32_t w[kPer];
     uint32_t c = 0;
-#pragma unroll
-    for (uint32_t k = 0; k < kPer; ++k) {
-        w[k] = bits[tid * kPer + k];
-        c += __popc(w[k]);
-    }
+    for (uint32_t k = 0; k < per; ++k) c += __popc(bits[tid * per + k]);
     // inclusive scan over the 256 threads
     uint32_t inc = c;
 #pragma unroll
@@ -539,23 +536,30 @@ __global__ __launch_bounds__(256) void select_candidates_kernel(
     uint32_t base = 0;
     for (uint32_t k = 0; k < wid; ++k) base += wsum[k];
     uint32_t* dst = candbuf + p.col_off + base + inc - c;
-#pragma unroll
-    for (uint32_t k = 0; k < kPer; ++k) {
-        uint32_t ww = w[k];
+    for (uint32_t k = 0; k < per; ++k) {
+        uint32_t ww = bits[tid * per + k];
         while (ww) {
             const uint32_t b = __ffs(ww) - 1;
-            *dst++ = (tid * kPer + k) * 32 + b;
+            *dst++ = (tid * per + k) * 32 + b;
             ww &= ww - 1;
         }
     }
     if (tid == 255) cand_cnt[blockIdx.x] = base + inc;
 }
 
-void launch_select_candidates(const ImageDev* imgs, const PairDev* pairs, uint32_t npairs,
+void launch_select_candidates(const ImageDev* imgs, const PairDev* pairs, uint32_t npairs, uint32_t max_cols,
                               const Top2* rowbuf, const uint32_t* accmask, const float* acos_lut,
                               FinalizeParams fp, uint32_t* cand_cnt, uint32_t* candbuf, hipStream_t s) {
     if (npairs == 0) return;
-    hipLaunchKernelGGL(select_candidates_kernel, dim3(npairs), dim3(256), 0, s, imgs, pairs,
+    const uint32_t per = ((max_cols + 31) / 32 + 255) / 256;
+    const size_t shmem = (size_t)std::max(per, 1u) * 256 * sizeof(uint32_t);
+    static bool raised = false;
+    if (shmem > 48 * 1024 && !raised) {  // above the default dynamic-LDS limit: opt in once
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(select_candidates_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kSelectMaxCols / 8));
+        raised = true;
+    }
+    hipLaunchKernelGGL(select_candidates_kernel, dim3(npairs), dim3(256), shmem, s, imgs, pairs,
                        rowbuf, accmask, acos_lut, fp, cand_cnt, candbuf);
 }
 

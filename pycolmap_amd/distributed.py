@@ -40,10 +40,20 @@ def shard_pairs(slot1: np.ndarray, slot2: np.ndarray, rank: int, world: int, row
     return s1[mine], s2[mine], mine
 
 
+_last_gather_path = None   # "uneven" | "padded": which branch _gather_rows took last (tests and bench.py report it)
+
+
+def last_gather_path():
+    return _last_gather_path
+
+
 def _gather_rows(t, sizes, group=None):
     """All-gather of per-rank tensors with DIFFERENT numbers of rows: returns the list of every rank's rows.
-    RCCL (backend "nccl"): one uneven all_gather - each rank sends exactly its rows, nothing is padded.  gloo (CPU
-    tests) only gathers equal sizes: pad to the largest rank there."""
+    RCCL (backend "nccl"): ONE uneven all_gather - each rank sends exactly its rows, nothing is padded; a rank with no
+    rows sends a single dummy row (dropped on arrival), so that the same call serves every distribution of the rows
+    and no zero-byte collective is ever issued.  gloo (CPU tests) only gathers equal sizes: pad to the largest rank
+    there."""
+    global _last_gather_path
     import torch
     import torch.distributed as dist
 
@@ -51,10 +61,13 @@ def _gather_rows(t, sizes, group=None):
     sizes = [int(x) for x in sizes]
     t = t.contiguous()
     tail = tuple(t.shape[1:])
-    if dist.get_backend(group) == "nccl" and min(sizes) > 0:
-        outs = [torch.empty((n,) + tail, dtype=t.dtype, device=t.device) for n in sizes]
-        dist.all_gather(outs, t, group=group)
-        return outs
+    if dist.get_backend(group) == "nccl":
+        _last_gather_path = "uneven"
+        send = t if t.shape[0] else torch.zeros((1,) + tail, dtype=t.dtype, device=t.device)
+        outs = [torch.empty((max(n, 1),) + tail, dtype=t.dtype, device=t.device) for n in sizes]
+        dist.all_gather(outs, send, group=group)
+        return [o[:n] for o, n in zip(outs, sizes)]
+    _last_gather_path = "padded"
     mx = max(max(sizes), 1)
     pad = torch.zeros((mx,) + tail, dtype=t.dtype, device=t.device)
     if t.shape[0]:
@@ -93,8 +106,12 @@ def all_gather_match_tables(pair_index: np.ndarray, offsets: np.ndarray, matches
     dist.all_gather_into_tensor(all_sizes, sizes, group=group)
     all_sizes = all_sizes.view(world, 2).cpu()
 
+    pair_index = np.asarray(pair_index, dtype=np.int64)
+    if npairs and (int(pair_index.max()) >= 2 ** 31 or int(pair_index.min()) < 0 or int(counts.max()) >= 2 ** 31):
+        raise ValueError("all_gather_match_tables: pair indices and per-pair match counts travel as int32 "
+                         "(8 bytes per pair); an index or a count of 2^31 or more does not fit")
     meta_h = np.empty((npairs, 2), dtype=np.int32)          # (global index, count): 8 bytes per pair, the only H2D
-    meta_h[:, 0] = np.asarray(pair_index, dtype=np.int64)
+    meta_h[:, 0] = pair_index
     meta_h[:, 1] = counts
     meta = torch.from_numpy(meta_h).to(dev)
     if device_matches is not None:

@@ -200,8 +200,8 @@ def test_8192_rows(amc_ctx):
 
 
 def test_more_than_8192_rows_matches_oracle(amc_ctx):
-    """Images larger than BASELINE's biggest config (8192): still the mfma kernel (its candidate
-    bitmap holds 32768 columns), both kernels against the oracle.  Ragged, non-multiple-of-32 sizes."""
+    """Images larger than BASELINE's biggest config (8192): still the mfma kernel, both kernels against the oracle.
+    Ragged, non-multiple-of-32 sizes."""
     rng = np.random.default_rng(19)
     big = synth.scene_images(rng, 2, 9001, num_landmarks=14000, visible_frac=0.4)
     small = synth.scene_images(rng, 1, 777, num_landmarks=14000, visible_frac=0.4)[0]
@@ -219,6 +219,30 @@ def test_more_than_8192_rows_matches_oracle(amc_ctx):
     assert st_n["pairs_mfma"] == 3
     for p, (a, b) in enumerate(zip(s1, s2)):
         np.testing.assert_array_equal(m_n[off_n[p]:off_n[p + 1]], oracle_lib.match(imgs[a], imgs[b], cross_check=False))
+
+
+def test_40000_rows_stay_on_the_mfma_kernel(amc_ctx):
+    """Cross-checked images beyond 32,768 descriptors (round 3's limit: the candidate bitmap of select_candidates was 4 KiB
+    of static LDS) keep the mfma kernel: 40,000 x 39,871 rows, ragged against a small image, both directions; the per-row
+    resolve kernel takes over from the tile-grouped one above 65,536 rows, not here.  Against the dot4 kernel and, where the
+    host has AVX-512 VNNI (the literal oracle needs minutes at this size), the oracle itself."""
+    rng = np.random.default_rng(41)
+    big = synth.scene_images(rng, 2, 40000, num_landmarks=60000, visible_frac=0.4)
+    small = synth.scene_images(rng, 1, 1000, num_landmarks=60000, visible_frac=0.4)[0]
+    imgs = [big[0], big[1][:39871], small]
+    upload(amc_ctx, imgs)
+    s1, s2 = [0, 2, 0], [1, 1, 2]
+    off, m, st = amc_ctx.match_pairs(s1, s2, kernel="auto")
+    assert st["pairs_mfma"] == 3 and st["pairs_dot4"] == 0
+    off_d, m_d, _ = amc_ctx.match_pairs(s1, s2, kernel="dot4")
+    np.testing.assert_array_equal(off, off_d)
+    np.testing.assert_array_equal(m, m_d)
+    assert off[1] - off[0] > 2000
+    if oracle_lib.vnni_available():
+        for p, (a, b) in enumerate(zip(s1, s2)):
+            np.testing.assert_array_equal(m[off[p]:off[p + 1]], oracle_lib.match_vnni(imgs[a], imgs[b]))
+    else:
+        np.testing.assert_array_equal(m[off[1]:off[2]], oracle_lib.match(imgs[2], imgs[1]))
 
 
 @pytest.mark.parametrize("kernel", ["auto", "dot4"])

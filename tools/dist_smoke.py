@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
-"""One-rank RCCL run of the sharded match + verify exchange on a GPU (the N > 1 logic is covered by the gloo
-tests; this checks the same functions on device tensors over the nccl backend):
-    MASTER_ADDR=127.0.0.1 MASTER_PORT=29533 RANK=0 WORLD_SIZE=1 python tools/dist_smoke.py"""
+"""RCCL run of the sharded match + verify exchange on GPUs, one rank per device, against the single-process result
+(the N > 1 logic is covered by the gloo tests; this checks the same functions on device tensors over the nccl backend):
+    MASTER_ADDR=127.0.0.1 MASTER_PORT=29533 RANK=0 WORLD_SIZE=1 python tools/dist_smoke.py [--images N]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 tools/dist_smoke.py
+tests/test_multigpu_gpu.py runs both."""
 import os
 import sys
 
@@ -22,7 +24,8 @@ torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)))
 dist.init_process_group("nccl", rank=rank, world_size=world)
 dev = torch.device("cuda", torch.cuda.current_device())
 rng = np.random.default_rng(0)
-imgs = synth.multiview_scene(rng, num_images=6, n_feats=600, num_landmarks=800)
+num_images = int(sys.argv[sys.argv.index("--images") + 1]) if "--images" in sys.argv else 6   # 2: one pair, an empty rank at world 2
+imgs = synth.multiview_scene(rng, num_images=num_images, n_feats=600, num_landmarks=800)
 ctx = _capi.Context(torch.cuda.current_device())
 ctx.reserve_slots(len(imgs))
 for k, im in enumerate(imgs):
@@ -46,4 +49,5 @@ assert np.array_equal(g_im, wm[wmask]) and int(g_ioff[-1]) == int(wmask.sum())
 dist.barrier()
 dist.destroy_process_group()
 if rank == 0:
-    print(f"dist smoke ok: {len(s1_all)} pairs, {len(wm)} matches, {int(wmask.sum())} inlier matches, world {world}")
+    print(f"dist smoke ok: {len(s1_all)} pairs, {len(wm)} matches, {int(wmask.sum())} inlier matches, world {world}, "
+          f"gather path {D.last_gather_path()}")

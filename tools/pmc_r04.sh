@@ -7,7 +7,7 @@ R=$GRAFT_REPO_ROOT
 TAG=${1:-v1}
 O=$R/gpurun_out/r04
 mkdir -p $O
-BENCH="python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --verify-pairs 0 --no-pipeline --no-dense --no-ragged"
+BENCH="python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --verify-pairs 0 --no-pipeline --no-dense --no-ragged --no-db"
 run() {  # $1 = out file, $2 = tag, $3... = counters; a pass whose rocprofv3 dies (it happens on some boxes) is retried
   out=$1; tag=$2; shift; shift
   for try in 1 2 3; do
