@@ -705,8 +705,11 @@ def run_config34(args):
         # rank's kernels, so it holds the load imbalance as well as the transfer
         device_sync(args)
         te = time.perf_counter()
+        gen = None if dry else ctx.resident_generation
         r = fn()
         device_sync(args)
+        # the collective read the library's own device memory (resident()): no match call may have touched it meanwhile
+        assert dry or ctx.resident_view_valid(gen), "a match call ran while the exchange held the resident match table"
         exch["ms"] += 1e3 * (time.perf_counter() - te)
         return r
 
@@ -910,8 +913,12 @@ def main():
         if use_dist:
             # the exchange step: RCCL all-gather of the match tables (sizes, then padded tables);
             # afterwards every rank holds the whole match graph (rank 0 would feed the SQLite writer)
+            gen = ctx.resident_generation
             gathered = D.all_gather_match_tables(mine, off, m, device=device, as_numpy=False,
                                                  device_matches=ctx.resident_matches_tensor(local_rank))
+            # the view aliases library memory: the collectives that read it are done before the next match call
+            torch.cuda.current_stream().synchronize()
+            assert ctx.resident_view_valid(gen)
         return off, m, st, gathered
 
     def fence():

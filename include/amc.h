@@ -162,7 +162,12 @@ typedef struct amc_ransac_opts {
     double confidence;
     double dyn_num_trials_multiplier;
     int64_t min_num_trials;
-    int64_t max_num_trials;
+    int64_t max_num_trials; /* Every pair re-seeds std::mt19937, so all pairs read ONE table of its output words, laid out by
+                             * the host for the worst case: 17 words per allowed trial (5 + 7 + 4 + 1 draws of the E / F / H /
+                             * watermark RANSACs), 4 bytes each, per context - 0.3 MB at COLMAP's defaults, 0.7 GB at 1e7
+                             * trials.  Trial caps that need more than 2^28 words (about 1.6e7 trials at the default
+                             * min_inlier_ratio) return AMC_E_INVALID.  The table is rebuilt when the seed changes or it
+                             * must grow; amc_ctx_trim releases one larger than 16 MB. */
 } amc_ransac_opts;
 
 /* TwoViewGeometryOptions (/root/reference/pycolmap/estimators/two_view_geometry.h:41-63). */

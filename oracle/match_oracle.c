@@ -28,6 +28,12 @@
 
 #define AMC_DIM 128
 
+/* FROZEN (round 4): the integer matcher (M1-M3) and MatchGuided's float32 filter (D5: left-to-right 3-term sums) as
+ * restated below are the parity target of the HIP kernels and of tests/golden/match_golden_v1.npz;
+ * tests/test_oracle_frozen_cpu.py regenerates the fixture and fails on any difference. */
+#define ORACLE_MATCH_VERSION "match-r4: literal int32 matrix + two scans, host-libm acosf, D5 l2r float32 filter"
+const char* oracle_match_version(void) { return ORACLE_MATCH_VERSION; }
+
 /* colmap/feature/sift.cc ComputeSiftDistanceMatrix: dists(i1,i2) = <d1[i1], d2[i2]> in int32.
  * (SURVEY.md A.2 line "dist(i1,i2) = sum_k int(d1[i1][k]) * int(d2[i2][k])") */
 void oracle_sift_distance_matrix(const uint8_t* d1, int n1, const uint8_t* d2, int n2,

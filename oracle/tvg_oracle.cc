@@ -43,6 +43,12 @@
  *       reproducible run-to-run).
  * Compile with -ffp-contract=off (oracle/Makefile): no FMA contraction, IEEE double throughout.
  *
+ * FROZEN (round 4).  ORACLE_TVG_VERSION below names this arithmetic - D1..D4 as stated above.  It is the parity
+ * target of the HIP kernels and of the committed fixtures (tests/golden/tvg_golden_v4.npz,
+ * tests/ref2/deviation_budget.json); tests/test_oracle_frozen_cpu.py regenerates both from this file and fails on any
+ * difference.  A change of the arithmetic here - in particular another restatement of D1 / D2 to suit a kernel, as
+ * round 3 did with D2 - is a new version, new fixtures and a line in DESIGN.md section 2; it is not done for speed.
+ *
  * DEVIATION TOGGLES (oracle/Makefile builds one extra library per flag; tests/ref2 measures what each
  * deviation does to configs / masks / trial counts):
  *   -DORACLE_SEQ_SUMS         D3 off: every det_sum64 becomes the sequential sum COLMAP writes
@@ -1976,7 +1982,9 @@ Tvg estimate_multiple_two_view_geometries(const Camera& c1, const std::vector<Pt
     return out;
 }
 
+#define ORACLE_TVG_VERSION "tvg-r4: D1 jacobi-AtA/gauss-jordan, D2 bisect-2^-26+3-newton, D3 det_sum64, D4 reseed-per-pair"
 extern "C" {
+const char* oracle_tvg_version() { return ORACLE_TVG_VERSION; }
 
 struct oracle_tvg_options {
     int32_t min_num_inliers;

@@ -250,8 +250,13 @@ class Context:
         _check(self._lib.amc_ctx_create(device_id, C.byref(h)))
         self._h = h
         self.device_id = device_id
+        # Bumped by everything that may free or overwrite the resident match table (a match call of any kind, trim,
+        # close).  A holder of resident_matches_tensor() - memory the library owns - records it when it takes the view
+        # and checks it (resident_view_valid) before / after it hands the view to anything asynchronous.
+        self.resident_generation = 0
 
     def close(self) -> None:
+        self.resident_generation = getattr(self, "resident_generation", 0) + 1
         if getattr(self, "_h", None):
             self._lib.amc_ctx_destroy(self._h)
             self._h = None
@@ -278,13 +283,21 @@ class Context:
         _check(self._lib.amc_ctx_resident_matches(self._h, C.byref(ptr), C.byref(n)))
         return int(ptr.value or 0), int(n.value)
 
-    def resident_matches_tensor(self, device_index: int = 0):
-        """The same table as a torch int32 [n, 2] tensor that ALIASES the library's device memory (no copy): what the
-        exchange step hands to RCCL.  Same lifetime as resident_matches()."""
+    def resident_view_valid(self, generation: int) -> bool:
+        """True while a view taken at `generation` (= self.resident_generation at that time) still points at live memory."""
+        return generation == self.resident_generation and bool(getattr(self, "_h", None))
+
+    def resident_matches_tensor(self, device_index: int = 0, copy: bool = False):
+        """The same table as a torch int32 [n, 2] tensor.  copy=False: it ALIASES the library's device memory (no copy) -
+        what the exchange step hands to RCCL - and dies with the next match call / trim / close of this context: note
+        `self.resident_generation` when taking it and check `resident_view_valid()` before relying on it (bench.py and
+        tools/dist_smoke.py do, around their collectives).  copy=True: a private clone, valid for as long as it is held."""
         import torch
         ptr, n = self.resident_matches()
         if n == 0:
             return torch.zeros((0, 2), dtype=torch.int32, device=torch.device("cuda", device_index))
+        if copy:
+            return self.resident_matches_tensor(device_index, copy=False).clone()
 
         class _View:   # numpy-style CUDA array interface over the raw pointer (uint32 bit patterns viewed as int32)
             __cuda_array_interface__ = {"shape": (n, 2), "typestr": "<i4", "data": (ptr, False), "version": 3, "strides": None}
@@ -292,6 +305,7 @@ class Context:
 
     def trim(self) -> None:
         """Release per-call scratch, staging buffers and idle result buffers (amc_ctx_trim); uploaded images stay."""
+        self.resident_generation += 1
         _check(self._lib.amc_ctx_trim(self._h))
 
     def reserve_slots(self, n: int) -> None:
@@ -321,6 +335,7 @@ class Context:
             raise ValueError("slot1/slot2 must be equal-length 1-D arrays")
         opts = MatchOpts(max_ratio, max_distance, 1 if cross_check else 0, KERNELS[kernel])
         res = MatchResult()
+        self.resident_generation += 1
         _check(self._lib.amc_match_pairs(self._h, s1.ctypes.data_as(C.c_void_p),
                                          s2.ctypes.data_as(C.c_void_p), s1.size, C.byref(opts),
                                          C.byref(res)))
@@ -396,6 +411,7 @@ class Context:
         mo = MatchOpts(max_ratio, max_distance, 1 if cross_check else 0, KERNELS[kernel])
         o = opts or tvg_options()
         mres, vres = MatchResult(), VerifyResult()
+        self.resident_generation += 1
         _check(self._lib.amc_match_verify_pairs(self._h, s1.ctypes.data_as(C.c_void_p), s2.ctypes.data_as(C.c_void_p),
                                                 s1.size, C.byref(mo), C.byref(o), seed, C.byref(mres), C.byref(vres)))
         try:
@@ -418,6 +434,7 @@ class Context:
         assert C.sizeof(Tvg) == TVG_DTYPE.itemsize
         opts = MatchOpts(max_ratio, max_distance, 1 if cross_check else 0, KERNEL_AUTO)
         res = MatchResult()
+        self.resident_generation += 1
         _check(self._lib.amc_match_guided_pairs(self._h, s1.ctypes.data_as(C.c_void_p),
                                                 s2.ctypes.data_as(C.c_void_p), s1.size,
                                                 g.ctypes.data_as(C.c_void_p), float(max_error), C.byref(opts),

@@ -386,6 +386,12 @@ int amc_ctx_trim(amc_ctx* c) {
     c->resident_matches = 0;
     c->d_rowbuf.release(); c->d_colbuf.release(); c->d_accmask.release(); c->d_matches.release(); c->d_candbuf.release();
     c->d_segs.release(); c->d_seg_base.release();
+    // the verification kernels' sample-stream table is rebuilt on demand (a host mt19937 run + one upload): keep the
+    // default-sized one (~0.3 MB at COLMAP's default trial caps), drop one that a large max_num_trials blew up
+    if (c->d_stream.cap * sizeof(uint32_t) > ((size_t)16 << 20)) {
+        c->d_stream.release();
+        c->stream_len = 0;
+    }
     c->d_tws.release(); c->d_tmaskws.release(); c->d_toutmask.release(); c->d_emask.release(); c->d_estate.release();
     c->d_tout.release(); c->d_tmatches.release(); c->d_pmatches.release(); c->d_pcos.release();
     c->h_tout.release(); c->h_tmask.release();

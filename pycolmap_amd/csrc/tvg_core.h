@@ -1901,7 +1901,9 @@ __device__ Report lo_ransac(Wave& w_io, const RansacCfg& cfg, const double* gx, 
             // loop); should none of those have one, the next chunk carries on from where this one ended.
             const long long lim = (long long)(dyn_max > (uint32_t)cfg.min_trials ? dyn_max : (uint32_t)cfg.min_trials);
             const long long want = lim - (long long)chunk + 4;
-            if (want < (long long)nT) nT = (int)(want > 8 ? want : 8);
+            // (only ever shrink: with fewer than 8 trials left - a small user max_num_trials - the floor of 8 must not
+            // carry the chunk past max_trials)
+            if (want < (long long)nT) nT = min(nT, (int)(want > 8 ? want : 8));
         }
         // ---- draw the chunk's samples ----
         const uint32_t chunk_off = w.soff;

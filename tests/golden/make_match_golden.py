@@ -21,7 +21,8 @@ import oracle_lib  # noqa: E402
 from pycolmap_amd import synth  # noqa: E402
 
 
-def main():
+def build(verbose=True):
+    """Every array of the fixture, from the oracle as it is now (tests/test_oracle_frozen_cpu.py compares them with the file)."""
     rng = np.random.default_rng(20260923)
     imgs = synth.scene_images(rng, 4, 160, num_landmarks=300, visible_frac=0.45)
     imgs.append(synth.random_descriptors(rng, 97))          # ragged, unrelated
@@ -34,7 +35,7 @@ def main():
     adv[12, :64] = 255
     imgs.append(adv)
     s1, s2 = synth.exhaustive_pairs(len(imgs))
-    out = {"num_images": np.int64(len(imgs)), "slot1": s1, "slot2": s2}
+    out = {"num_images": np.int64(len(imgs)), "slot1": s1, "slot2": s2, "oracle_version": np.array(oracle_lib.match_version())}
     for k, im in enumerate(imgs):
         out[f"desc_{k}"] = im
     settings = {"default": (0.8, 0.7, True), "nocross": (0.8, 0.7, False),
@@ -44,8 +45,13 @@ def main():
         out[f"{name}_opts"] = np.array([r, d, float(cc)])
         out[f"{name}_offsets"] = off
         out[f"{name}_matches"] = m
-        print(name, "total matches", int(off[-1]))
-    np.savez_compressed(Path(__file__).with_name("match_golden_v1.npz"), **out)
+        if verbose:
+            print(name, "total matches", int(off[-1]))
+    return out
+
+
+def main():
+    np.savez_compressed(Path(__file__).with_name("match_golden_v1.npz"), **build())
 
 
 if __name__ == "__main__":

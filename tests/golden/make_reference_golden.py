@@ -24,6 +24,18 @@ What is recorded per scene (floating-point results as raw uint64 bit patterns):
     options.  These bindings do NOT reseed COLMAP's thread-local generator, so each call is preceded by a
     fundamental_matrix_estimation on a single point: SetPRNGSeed(0) runs, LORANSAC::Estimate returns before drawing;
   * squared_sampson_error (two_view_geometry.h:161-175) of the matched points under the estimated F.
+
+The MATCHER pin (round 4; `record_matching`, keys "mg_*").  COLMAP's default CPU matcher is FLANN - approximate,
+randomised, not a parity target - but `SiftCPUFeatureMatcher::MatchGuided` is an EXACT brute-force scan
+(ComputeSiftDistanceMatrix with the geometric filter, FindBestMatchesBruteForce), so it is the one place where the
+reference itself exercises M1-M3 on the CPU.  The kit writes a tiny seeded COLMAP database
+(tests/colmap_db.py: sqlite3 only), runs
+    pycolmap.match_exhaustive(db, sift_options=SiftMatchingOptions(guided_matching=True), device=cpu)
+(/root/reference/pycolmap/pipeline/match_features.h:95-98, 219-226) and records, for every stored two-view geometry,
+the configuration, the reference's OWN F / E / H and its guided inlier matches, next to the descriptors and float32
+keypoints.  The consuming tests re-run only the guided match - with the reference's models as input - through
+oracle_match_guided and through amc_match_guided_pairs and demand identical rows: whatever FLANN and the reference's
+RANSAC did upstream is input, not something to reproduce.
 """
 import argparse
 import importlib
@@ -141,16 +153,73 @@ def record_all(pc, module_name, limit=0, verbose=True):
     return out
 
 
+MG_IMAGES, MG_FEATS, MG_SEED = 6, 320, 424242
+
+
+def matching_scene():
+    """The tiny seeded image set of the matcher pin (pure numpy: pycolmap_amd/synth.py loaded by path)."""
+    synth = scenes.synth
+    rng = np.random.default_rng(MG_SEED)
+    images = synth.multiview_scene(rng, num_images=MG_IMAGES, n_feats=MG_FEATS, num_landmarks=480)
+    for k, im in enumerate(images):
+        im["name"] = f"mg{k:03d}.jpg"
+        im["prior"] = True
+    return images
+
+
+def record_matching(pc, module_name, workdir=None):
+    """match_exhaustive(guided_matching=True) on the tiny database through module `pc`; the rows it leaves."""
+    import tempfile
+    sys.path.insert(0, str(scenes.ROOT / "tests"))
+    import colmap_db
+    images = matching_scene()
+    out = {"mg_num_images": np.int64(len(images))}
+    for k, im in enumerate(images):
+        out[f"mg_desc_{k}"] = np.ascontiguousarray(im["descriptors"], dtype=np.uint8)
+        out[f"mg_kp_{k}"] = np.ascontiguousarray(im["keypoints"], dtype=np.float32)
+    sift = pc.SiftMatchingOptions()
+    sift.guided_matching = True
+    for key in ("max_ratio", "max_distance", "cross_check"):
+        out[f"mg_opt_{key}"] = np.float64(float(getattr(sift, key)))
+    # MatchGuided's threshold is the verification's TwoViewGeometryOptions.ransac.max_error (4 px by default)
+    out["mg_opt_max_error"] = np.float64(float(pc.TwoViewGeometryOptions().ransac.max_error))
+    with tempfile.TemporaryDirectory(dir=workdir) as d:
+        db = str(Path(d) / "mg.db")
+        ids = colmap_db.create(db, images)
+        is_amd = hasattr(pc, "has_hip") or module_name == "pycolmap_amd"
+        # the real module: the CPU matcher (MatchGuided's brute force is what is being pinned); this repo's module has
+        # no CPU path and raises for device=cpu - its dry run takes the device it has
+        pc.match_exhaustive(db, sift_options=sift, device=pc.Device.auto if is_amd else pc.Device.cpu)
+        _, tvgs = colmap_db.read_all(db)
+    pairs = []
+    for a in range(len(images)):
+        for b in range(a + 1, len(images)):
+            g = tvgs.get(colmap_db.pair_id(ids[a], ids[b]))
+            if g is None or g["F"] is None:
+                continue
+            n = len(pairs)
+            pairs.append((a, b))
+            out[f"mg_config_{n}"] = np.int64(g["config"])
+            for key in "FEH":
+                out[f"mg_{key}_{n}"] = bits(g[key] if g[key] is not None else np.zeros((3, 3)))
+            out[f"mg_inlier_matches_{n}"] = np.ascontiguousarray(g["inlier_matches"], dtype=np.uint32).reshape(-1, 2)
+    out["mg_pairs"] = np.array(pairs, dtype=np.int64).reshape(-1, 2)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--module", default="pycolmap", help="module to record (the real pycolmap; pycolmap_amd for a dry run)")
     ap.add_argument("--out", default=str(HERE / "reference_v1.npz"))
     ap.add_argument("--limit", type=int, default=0, help="only the first N scenes (dry runs)")
+    ap.add_argument("--no-matching", action="store_true", help="skip the matcher pin (match_exhaustive with guided matching)")
     args = ap.parse_args()
     if args.module == "pycolmap_amd":
         sys.path.insert(0, str(scenes.ROOT))
     pc = importlib.import_module(args.module)
     out = record_all(pc, args.module, args.limit)
+    if not args.no_matching:
+        out.update(record_matching(pc, args.module))
     if not int(out["is_reference"]) and Path(args.out).name == "reference_v1.npz":
         raise SystemExit("refusing to write reference_v1.npz from a module that is not the real pycolmap: pass --out")
     np.savez_compressed(args.out, **out)

@@ -28,9 +28,10 @@ from scenes import CAMS, CASES, GOLDEN_SEED  # noqa: E402  (shared with make_ref
 FIELDS = ("E", "F", "H", "qvec", "tvec", "R")
 
 
-def main():
+def build(verbose=True):
+    """Every array of the fixture, from the oracle as it is now (tests/test_oracle_frozen_cpu.py compares them with the file)."""
     rng = np.random.default_rng(GOLDEN_SEED)
-    out = {"num_cases": np.int64(len(CASES))}
+    out = {"num_cases": np.int64(len(CASES)), "oracle_version": np.array(o.tvg_version())}
     for k, (kw, prior, c1, c2, okw) in enumerate(CASES):
         sc = synth.two_view_scene(rng, **kw)
         if c1 >= 2 or c2 >= 2:
@@ -56,8 +57,13 @@ def main():
             out[f"tri_angle_{tag}"] = np.array([r["tri_angle"]]).view(np.uint64)
             for f in FIELDS:
                 out[f"{f}_{tag}"] = np.ascontiguousarray(r[f], dtype=np.float64).reshape(-1).view(np.uint64)
-            print(k, pose, r["config_name"], r["num_inliers"], r["trials"], round(r["tri_angle"], 5))
-    np.savez_compressed(Path(__file__).with_name("tvg_golden_v4.npz"), **out)
+            if verbose:
+                print(k, pose, r["config_name"], r["num_inliers"], r["trials"], round(r["tri_angle"], 5))
+    return out
+
+
+def main():
+    np.savez_compressed(Path(__file__).with_name("tvg_golden_v4.npz"), **build())
 
 
 if __name__ == "__main__":

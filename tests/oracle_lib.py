@@ -61,6 +61,19 @@ def distance_matrix(d1, d2):
     return out
 
 
+def tvg_version() -> str:
+    """ORACLE_TVG_VERSION of oracle/tvg_oracle.cc: the frozen arithmetic the fixtures and the HIP kernels are held to."""
+    lib = load()
+    lib.oracle_tvg_version.restype = C.c_char_p
+    return lib.oracle_tvg_version().decode()
+
+
+def match_version() -> str:
+    lib = load()
+    lib.oracle_match_version.restype = C.c_char_p
+    return lib.oracle_match_version().decode()
+
+
 def vnni_available() -> bool:
     """The AVX-512 VNNI variant of the matcher (oracle/match_vnni.c) can run on this host."""
     return bool(load().oracle_vnni_available())

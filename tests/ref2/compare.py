@@ -79,17 +79,13 @@ def compare(ref, got):
                 same_inl=list(ref["inl"]) == list(got["inl"]))
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--random", type=int, default=500)
-    ap.add_argument("--no-ref2", action="store_true")
-    ap.add_argument("--out", default=str(Path(__file__).with_name("deviation_budget.json")))
-    args = ap.parse_args()
-    scenes = scene_set(args.random)
-    names = list(variants.NAMES) + ([] if args.no_ref2 else ["ref2"])
+def _rows_of(args):
+    """rows of the scenes with index % workers == w, for the listed variants (a worker of evaluate())"""
+    num_random, names, w, workers = args
     rows = {n: [] for n in names}
-    t0 = time.time()
-    for i, (tag, c1, c2, prior, sc, okw) in enumerate(scenes):
+    for i, (tag, c1, c2, prior, sc, okw) in enumerate(scene_set(num_random)):
+        if i % workers != w:
+            continue
         cam1 = o.make_camera(c1[0], 1600, 1200, c1[1], prior=prior)
         cam2 = o.make_camera(c2[0], 1600, 1200, c2[1], prior=prior)
         opts = o.tvg_default_options(**okw)
@@ -104,10 +100,26 @@ def main():
             else:
                 got = variants.estimate_two_view_geometry(n, cam1, sc["pts1"], cam2, sc["pts2"], sc["matches"], opts, seed=0)
             r = compare(ref, got)
-            r.update(tag=tag, M=int(len(sc["matches"])), config=ref["config_name"], got_config=got["config_name"])
+            r.update(tag=tag, M=int(len(sc["matches"])), config=ref["config_name"], got_config=got["config_name"], index=i)
             rows[n].append(r)
-        if (i + 1) % 50 == 0:
-            print(f"{i + 1}/{len(scenes)} scenes, {time.time() - t0:.0f} s", flush=True)
+    return rows
+
+
+def evaluate(num_random: int = 500, no_ref2: bool = False, workers: int = 1, verbose: bool = True):
+    """The budget as a dict (what main() writes).  workers > 1: the scenes are dealt to that many forked processes; the
+    rows are merged back in scene order, so the result does not depend on the split."""
+    names = list(variants.NAMES) + ([] if no_ref2 else ["ref2"])
+    nscenes = 20 + 64 + num_random
+    if workers > 1:
+        import multiprocessing as mp
+        with mp.get_context("fork").Pool(workers) as pool:
+            parts = pool.map(_rows_of, [(num_random, names, w, workers) for w in range(workers)])
+    else:
+        parts = [_rows_of((num_random, names, 0, 1))]
+    rows = {n: sorted((r for part in parts for r in part[n]), key=lambda r: r["index"]) for n in names}
+    for n in names:
+        for r in rows[n]:
+            del r["index"]
     summary = {}
     for n in names:
         rs = rows[n]
@@ -130,13 +142,23 @@ def main():
             config_changes=sorted({f"{r['config']}->{r['got_config']}" for r in rs if not r["same_config"]}),
         )
         s = summary[n]
-        print(f"{n:13s} pairs {N:4d}  config = {s['identical_config']:4d}  mask = {s['identical_mask']:4d}  trials = "
-              f"{s['identical_trials']:4d}  | differing masks: {len(diff)} (same models {s['mask_differs_same_models']}, "
-              f"other path {s['mask_differs_other_ransac_path']}), Hamming mean {s['hamming_mean_where_differs']:.1f} "
-              f"max {s['hamming_max']}  config changes {s['config_changes']}")
-    Path(args.out).write_text(json.dumps(dict(scenes=len(scenes), random=args.random, summary=summary,
-                                              differing={n: [r for r in rows[n] if r["hamming"] or not r["same_config"]]
-                                                         for n in names}), indent=1))
+        if verbose:
+            print(f"{n:13s} pairs {N:4d}  config = {s['identical_config']:4d}  mask = {s['identical_mask']:4d}  trials = "
+                  f"{s['identical_trials']:4d}  | differing masks: {len(diff)} (same models {s['mask_differs_same_models']}, "
+                  f"other path {s['mask_differs_other_ransac_path']}), Hamming mean {s['hamming_mean_where_differs']:.1f} "
+                  f"max {s['hamming_max']}  config changes {s['config_changes']}")
+    return dict(scenes=nscenes, random=num_random, summary=summary,
+                differing={n: [r for r in rows[n] if r["hamming"] or not r["same_config"]] for n in names})
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--random", type=int, default=500)
+    ap.add_argument("--no-ref2", action="store_true")
+    ap.add_argument("--workers", type=int, default=1)
+    ap.add_argument("--out", default=str(Path(__file__).with_name("deviation_budget.json")))
+    args = ap.parse_args()
+    Path(args.out).write_text(json.dumps(evaluate(args.random, args.no_ref2, args.workers), indent=1))
     print("wrote", args.out)
 
 

@@ -107,3 +107,67 @@ def test_hip_path_against_the_reference_pin():
     ref = np.load(PATH)
     cand = kit.record_all(pycolmap_amd, "pycolmap_amd", limit=len(ref["names"]), verbose=False)
     check(ref, compare(ref, cand), "pycolmap_amd (HIP path)")
+
+
+# ---- the matcher pin: MatchGuided, the reference's exact brute-force CPU path (make_reference_golden.record_matching) ----
+GUIDED_CONFIGS = {2: "F", 3: "F", 4: "H", 5: "H", 6: "H"}   # CALIBRATED, UNCALIBRATED -> F; PLANAR, PANORAMIC, PLANAR_OR_PANORAMIC -> H
+
+
+def _mg_pairs(ref):
+    if "mg_pairs" not in ref.files:
+        pytest.skip("this pin was recorded without the matcher leg (--no-matching)")
+    for n, (a, b) in enumerate(ref["mg_pairs"].tolist()):
+        cfg = int(ref[f"mg_config_{n}"])
+        if cfg not in GUIDED_CONFIGS:
+            continue      # DEGENERATE / WATERMARK / MULTIPLE: MatchGuided keeps what it has
+        mats = {k: np.frombuffer(ref[f"mg_{k}_{n}"].tobytes(), dtype=np.float64).reshape(3, 3) for k in "FEH"}
+        yield n, a, b, cfg, mats, ref[f"mg_inlier_matches_{n}"]
+
+
+def test_oracle_guided_match_against_the_reference_rows():
+    """oracle_match_guided (oracle/match_oracle.c: M1-M3 + the float32 filter) fed with the reference's own models must
+    leave the reference's rows - for a real pin this is the one comparison of the integer matcher with COLMAP itself."""
+    import oracle_lib
+    ref = np.load(PATH)
+    opt = {k: float(ref[f"mg_opt_{k}"]) for k in ("max_ratio", "max_distance", "cross_check", "max_error")} if "mg_pairs" in ref.files else {}
+    checked = 0
+    for n, a, b, cfg, mats, want in _mg_pairs(ref):
+        got = oracle_lib.match_guided(ref[f"mg_desc_{a}"], ref[f"mg_kp_{a}"], ref[f"mg_desc_{b}"], ref[f"mg_kp_{b}"], cfg,
+                                      mats["F"], mats["H"], opt["max_error"], opt["max_ratio"], opt["max_distance"],
+                                      bool(opt["cross_check"]))
+        assert got is not None
+        # the controller drops guided results under min_num_inliers (15): rows exist only for the others
+        if len(want) == 0 and len(got) < 15:
+            continue
+        np.testing.assert_array_equal(got, want, err_msg=f"pair {n} ({a}, {b}) config {cfg}")
+        checked += 1
+    assert checked >= 3
+
+
+@pytest.mark.gpu
+def test_hip_guided_match_against_the_reference_rows():
+    from pycolmap_amd import _capi
+    ref = np.load(PATH)
+    pairs = list(_mg_pairs(ref))
+    opt = {k: float(ref[f"mg_opt_{k}"]) for k in ("max_ratio", "max_distance", "cross_check", "max_error")}
+    ni = int(ref["mg_num_images"])
+    with _capi.Context(0) as ctx:
+        ctx.reserve_slots(ni)
+        for k in range(ni):
+            ctx.upload_descriptors(k, ref[f"mg_desc_{k}"])
+            ctx.upload_keypoints(k, ref[f"mg_kp_{k}"])
+        tvg = np.zeros(len(pairs), dtype=_capi.TVG_DTYPE)
+        for i, (n, a, b, cfg, mats, want) in enumerate(pairs):
+            tvg[i]["config"] = cfg
+            for k in "EFH":
+                tvg[i][k] = mats[k]
+        off, m, st = ctx.match_guided_pairs([p[1] for p in pairs], [p[2] for p in pairs], tvg, opt["max_error"],
+                                            opt["max_ratio"], opt["max_distance"], bool(opt["cross_check"]))
+    checked = 0
+    for i, (n, a, b, cfg, mats, want) in enumerate(pairs):
+        got = m[int(off[i]):int(off[i + 1])]
+        if len(want) == 0 and len(got) < 15:
+            continue
+        np.testing.assert_array_equal(got, want, err_msg=f"pair {n} ({a}, {b}) config {cfg}")
+        checked += 1
+    assert checked >= 3

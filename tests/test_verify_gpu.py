@@ -152,6 +152,33 @@ def test_watermark_and_option_variants(amc_ctx):
         assert_pair_equal(1, tvg, mask, off, want)
 
 
+def test_small_max_num_trials_never_overrun_by_the_essential_chunk(amc_ctx):
+    """the essential-matrix RANSAC cuts its 64-trial chunks short once the adaptive limit is passed, with a floor
+    of 8 trials - which must not carry a chunk past a small user max_num_trials.  Trial caps just above a chunk boundary
+    (65 .. 71), min_num_trials at the cap or below it, on scenes where many 5-point samples give no model (mostly
+    collinear / repeated points) and on ordinary ones: report.num_trials <= max_num_trials and every field equal to the
+    oracle's sequential loop."""
+    rng = np.random.default_rng(77)
+    scenes = [synth.two_view_scene(rng, num_inliers=120, num_outliers=60),
+              synth.two_view_scene(rng, num_inliers=30, num_outliers=200)]
+    # degenerate layouts: points on a line / four distinct points repeated (5-point samples mostly rank deficient)
+    n = 90
+    t = rng.uniform(100, 1400, n)
+    line = np.c_[t, 0.5 * t + 50.0]
+    rep = np.array([[100.0, 100.0], [900.0, 200.0], [400.0, 800.0], [1200.0, 1000.0]])[rng.integers(0, 4, n)]
+    for p1 in (line, rep):
+        p2 = p1 + np.array([4.0, -3.0])
+        scenes.append(dict(pts1=p1.astype(np.float32).astype(np.float64), pts2=p2.astype(np.float32).astype(np.float64),
+                           matches=np.c_[np.arange(n), np.arange(n)].astype(np.uint32), width=1600, height=1200, f=1200.0))
+    for mx in (65, 66, 67, 70, 71, 130):
+        for mn in (0, 5, mx):
+            kw = dict(ransac=dict(min_num_trials=mn, max_num_trials=mx))
+            tvg, mask, off, want = run_both(amc_ctx, scenes, [True] * len(scenes), kw)
+            for p in range(len(scenes)):
+                assert_pair_equal(p, tvg, mask, off, want)
+                assert int(tvg["num_trials"][p][0]) <= mx, (mx, mn, p, tvg["num_trials"][p])
+
+
 def test_watermark_ransac_below_its_trial_cap(amc_ctx):
     """min_num_trials below the watermark RANSAC's trial cap (18 at the default ratios; the C++ RANSACOptions
     default is 0): its adaptive trial count decides when it stops.  Watermark-like scenes with a varying share

@@ -21,6 +21,9 @@ def cases():
     """Yields dicts: pts1, pts2, matches, cam1/cam2 = (model, params), prior, opts (dict), and
     want[pose] = dict(config, mask, trials, inl, points3D, tri_angle bits, E/F/H/qvec/tvec/R bits)."""
     z = np.load(PATH)
+    import oracle_lib
+    # the fixture pins ONE arithmetic: a fixture from another oracle version is not evidence of anything
+    assert str(z["oracle_version"]) == oracle_lib.tvg_version(), (str(z["oracle_version"]), oracle_lib.tvg_version())
     for k in range(int(z["num_cases"])):
         c1, c2, prior = (int(x) for x in z[f"cams_{k}"])
         opts = {}

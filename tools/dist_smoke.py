@@ -37,7 +37,10 @@ s1, s2, mine = D.shard_pairs(s1_all, s2_all, rank, world)
 off, m, _ = ctx.match_pairs(s1, s2)
 tvg, mask, _ = ctx.verify_pairs(s1, s2, off, m, _capi.tvg_options(compute_relative_pose=1))
 # the match table straight from the device memory the kernels wrote (no host round trip before the collective)
+gen = ctx.resident_generation
 d_off, d_m = D.all_gather_match_tables(mine, off, m, device=dev, device_matches=ctx.resident_matches_tensor(torch.cuda.current_device()))
+torch.cuda.synchronize()
+assert ctx.resident_view_valid(gen)   # nothing touched the library's table while the collectives read it
 g_tvg, g_off, g_m, g_ioff, g_im = D.all_gather_verification(mine, tvg, off, m, mask, len(s1_all), device=dev)
 assert np.array_equal(d_off, g_off) and np.array_equal(d_m, g_m)
 # single-process reference on the same device
