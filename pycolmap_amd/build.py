@@ -18,7 +18,8 @@ CSRC = PKG / "csrc"
 OBJ = CSRC / "_obj"
 LIB = PKG / "libamc.so"
 
-HIP_SOURCES = ["amc_api.hip", "match_common.hip", "match_dot4.hip", "match_guided.hip", "match_mfma.hip", "tvg_e.hip", "tvg_fh.hip", "pose.hip", "camera.hip"]
+HIP_SOURCES = ["amc_api.hip", "match_common.hip", "match_dot4.hip", "match_guided.hip", "match_mfma.hip", "tvg_e.hip", "tvg_fh.hip", "tvg_e_big.hip",
+               "tvg_fh_big.hip", "pose.hip", "camera.hip"]
 HIPCC_FLAGS = [
     "--offload-arch=gfx950",
     "-O3",
@@ -72,12 +73,15 @@ def build_libamc(force: bool = False, verbose: bool = True) -> Path:
             continue
         obj = OBJ / (src.stem + ".o")
         flags = " ".join(HIPCC_FLAGS)
-        if force or _stale(obj, [src] + headers, flags):
+        deps = [src] + headers
+        if src.stem.endswith("_big"):  # a second build of another source file (#include "tvg_e.hip"): that file is an input too
+            deps.append(CSRC / (src.stem[:-4] + ".hip"))
+        if force or _stale(obj, deps, flags):
             cmd = [hipcc, *HIPCC_FLAGS, "-c", str(src), "-o", str(obj)]
             if verbose:
                 print("[build]", " ".join(cmd), flush=True)
             subprocess.run(cmd, check=True)
-            _stamp(obj, [src] + headers, flags)
+            _stamp(obj, deps, flags)
         objs.append(obj)
     if force or _stale(LIB, objs):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB), *map(str, objs)]

@@ -1682,8 +1682,9 @@ static int verify_impl(amc_ctx* c, int mode, const uint32_t* slot1, const uint32
     // entries (the sampler's permutation and the inlier list); everything else of a pair lives in the wave's global
     // workspace.  Pairs up to ~1,800 matches run at both kernels' full occupancy (E 2, F/H 3 waves per SIMD), 4 waves per workgroup; larger
     // ones in launches of their own with fewer resident waves; the largest (M <= ~38 k: covers
-    // max_num_matches = 32768) one wave per workgroup with up to the whole 160 KB.
-    std::vector<size_t> cls[3];
+    // max_num_matches = 32768) one wave per workgroup with up to the whole 160 KB; beyond that (class 3, up to the
+    // 65,535 matches the 16-bit indices name) the "big" builds of the kernels keep the two arrays in global memory.
+    std::vector<size_t> cls[4];
     for (size_t p = 0; p < npairs; ++p) {
         const uint32_t mc = std::max<uint32_t>(64, round_up(tp[p].M, 64));
         const size_t lds = tvg_lds_bytes(mc, 1) + 64;
@@ -1692,9 +1693,7 @@ static int verify_impl(amc_ctx* c, int mode, const uint32_t* slot1, const uint32
             cls[0].push_back(p);
         else if (lds + 9 * 1024 <= 160 * 1024 / 4) cls[1].push_back(p);  // 4-wave workgroups of either kernel fit a CU
         else if (lds + 9 * 1024 <= 160 * 1024) cls[2].push_back(p);  // (+ the E kernel's root-finder scratch)
-        else
-            return fail(AMC_E_INVALID, "amc_verify_pairs: pair %zu has %u matches: more than the verification "
-                        "kernel's per-pair state can index in LDS (limit ~38000)", p, tp[p].M);
+        else cls[3].push_back(p);  // M <= 65535 was checked above
     }
     // which pairs run the essential-matrix RANSAC first (tvg_e_kernel), exactly as the F/H kernel decides it
     auto uses_E = [&](size_t p) {
@@ -1767,9 +1766,10 @@ static int verify_impl(amc_ctx* c, int mode, const uint32_t* slot1, const uint32
         HIPCHK(hipMemsetAsync(c->d_tout.p, 0, npairs * sizeof(TvgOut), st));
         kernel_ms = 0.0;
         launches = 0;
-        for (int k = 0; k < 3; ++k) {
+        for (int k = 0; k < 4; ++k) {
             if (cls[k].empty()) continue;
-            const int wpb = k == 2 ? 1 : 4;
+            const bool big = k == 3;  // index arrays in global memory (tvg_*_big.hip)
+            const int wpb = k >= 2 ? 1 : 4;
             uint32_t cm = 0;
             // The waves pull pairs from a queue in this order.  A pair's cost grows with its match count (every
             // trial scores all matches), so the largest go first: what is left for the tail of the launch, when
@@ -1796,11 +1796,13 @@ static int verify_impl(amc_ctx* c, int mode, const uint32_t* slot1, const uint32
                 return std::max<uint32_t>(wpb, (nw + wpb - 1) / wpb * wpb);
             };
             const bool run_fh = mode != 3;
-            const uint32_t waves_e = sub_e.empty() ? 0 : waves_for(sub_e.size(), kTvgEWavesPerSimd, tvg_lds_bytes_e(mcap, wpb));
-            const uint32_t waves_fh = run_fh ? waves_for(idx.size(), kTvgFhWavesPerSimd, tvg_lds_bytes(mcap, wpb)) : 0;
+            const uint32_t waves_e = sub_e.empty() ? 0 : waves_for(sub_e.size(), kTvgEWavesPerSimd, big ? tvg_big_lds_bytes_e(wpb) : tvg_lds_bytes_e(mcap, wpb));
+            const uint32_t waves_fh = run_fh ? waves_for(idx.size(), kTvgFhWavesPerSimd, big ? tvg_big_lds_bytes(wpb) : tvg_lds_bytes(mcap, wpb)) : 0;
             HIPCHK(c->d_tpairs.ensure(idx.size()));
             HIPCHK(c->d_tpairs_e.ensure(std::max<size_t>(sub_e.size(), 1)));
-            HIPCHK(c->d_tws.ensure(std::max((size_t)waves_e * tvg_ws_doubles_e_host(mcap), (size_t)waves_fh * tvg_ws_doubles_host(mcap))));
+            const size_t idx_ws = big ? tvg_big_idx_doubles_host(mcap) : 0;  // per wave, behind the point workspaces
+            HIPCHK(c->d_tws.ensure(std::max((size_t)waves_e * (tvg_ws_doubles_e_host(mcap) + idx_ws),
+                                            (size_t)waves_fh * (tvg_ws_doubles_host(mcap) + idx_ws))));
             HIPCHK(c->d_tmaskws.ensure((size_t)std::max<uint32_t>(waves_fh, 1) * tvg_ws_mask_bytes_host(mcap)));
             HIPCHK(hipMemcpyAsync(c->d_tpairs.p, sub.data(), sub.size() * sizeof(TvgPair), hipMemcpyHostToDevice, st));
             if (!sub_e.empty())
@@ -1808,13 +1810,13 @@ static int verify_impl(amc_ctx* c, int mode, const uint32_t* slot1, const uint32
             HIPCHK(hipStreamSynchronize(st));  // `sub` / `sub_e` go out of scope at the end of the iteration
             HIPCHK(hipEventRecord(c->ev[2], st));
             if (!sub_e.empty()) {
-                HIPCHK(launch_tvg_e(c->d_timgs.p, c->d_tpairs_e.p, (uint32_t)sub_e.size(), kernel_matches, c->d_ttabs.p, P,
+                HIPCHK((big ? launch_tvg_e_big : launch_tvg_e)(c->d_timgs.p, c->d_tpairs_e.p, (uint32_t)sub_e.size(), kernel_matches, c->d_ttabs.p, P,
                                     c->d_tws.p, mcap, waves_e, wpb, c->d_scalars + 1, c->d_estate.p, c->d_emask.p,
                                     c->d_tout.p, c->d_toutmask.p, st));
                 ++launches;
             }
             if (run_fh) {
-                HIPCHK(launch_tvg_fh(c->d_timgs.p, c->d_tpairs.p, (uint32_t)idx.size(), kernel_matches, c->d_ttabs.p, P,
+                HIPCHK((big ? launch_tvg_fh_big : launch_tvg_fh)(c->d_timgs.p, c->d_tpairs.p, (uint32_t)idx.size(), kernel_matches, c->d_ttabs.p, P,
                                      c->d_tws.p, c->d_tmaskws.p, mcap, waves_fh, wpb, c->d_scalars + 1, c->d_estate.p,
                                      c->d_emask.p, c->d_tout.p, c->d_toutmask.p, st));
                 ++launches;

@@ -339,4 +339,18 @@ hipError_t launch_tvg_fh(const TvgImage* imgs, const TvgPair* pairs, uint32_t np
                          uint32_t num_waves, int waves_per_block, uint32_t* queue_head, const TvgEState* estate,
                          const uint8_t* emask, TvgOut* out, uint8_t* out_mask, hipStream_t s);
 
+// the "big" builds of the two kernels (tvg_e_big.hip / tvg_fh_big.hip): index arrays in global memory, for pairs of
+// ~38,000 .. 65,535 matches.  ws holds, behind the num_waves point workspaces, tvg_big_idx_doubles_host(mcap) doubles per wave.
+size_t tvg_big_lds_bytes(int waves);
+size_t tvg_big_lds_bytes_e(int waves);
+size_t tvg_big_idx_doubles_host(uint32_t mcap);
+hipError_t launch_tvg_e_big(const TvgImage* imgs, const TvgPair* pairs, uint32_t npairs, const uint32_t* matches,
+                            const uint32_t* trial_tabs, const TvgParams& P, double* ws, uint32_t mcap, uint32_t num_waves,
+                            int waves_per_block, uint32_t* queue_head, TvgEState* estate, uint8_t* emask, TvgOut* out,
+                            uint8_t* out_mask, hipStream_t s);
+hipError_t launch_tvg_fh_big(const TvgImage* imgs, const TvgPair* pairs, uint32_t npairs, const uint32_t* matches,
+                             const uint32_t* trial_tabs, const TvgParams& P, double* ws, uint8_t* mask_ws, uint32_t mcap,
+                             uint32_t num_waves, int waves_per_block, uint32_t* queue_head, const TvgEState* estate,
+                             const uint8_t* emask, TvgOut* out, uint8_t* out_mask, hipStream_t s);
+
 }  // namespace amc

@@ -59,6 +59,15 @@ typedef AMC_LDS double lds_f64;
 typedef AMC_LDS uint32_t lds_u32;
 typedef AMC_LDS int32_t lds_i32;
 typedef AMC_LDS uint16_t lds_u16;
+// The two per-pair index arrays of mcap entries (the sampler's permutation, the inlier list).  They are what grows
+// with a pair's match count: in LDS (2 x 2 bytes per match) a workgroup's 160 KB end at ~38,000 matches.  The "big"
+// builds of the two kernels (tvg_e_big.hip / tvg_fh_big.hip: -DAMC_TVG_BIG) keep them in the wave's global workspace
+// instead - slower (flat accesses), for the few pairs beyond that, up to the 65,535 the 16-bit indices can name.
+#if defined(AMC_TVG_BIG)
+typedef uint16_t idx_u16;
+#else
+typedef lds_u16 idx_u16;
+#endif
 // Wave-uniform reads of global tables through the scalar data cache (s_load_*): the table is either never written by
 // the kernel (the sample stream) or written by this wave, drained and followed by s_dcache_inv (scalar_table_sync).
 #define AMC_CONST __attribute__((address_space(4)))
@@ -88,8 +97,8 @@ struct Wave {
     lds_u32* rawcnt;  // 64: raw words consumed up to and including trial t of the chunk
     lds_i32* tmax;    // 64: largest count among trial t's models (count_models)
     lds_u16* mlist;   // 64 x kMaxModels: the chunk's models in (trial, root) order (count_models)
-    lds_u16* perm;    // mcap: the sampler's persistent permutation
-    lds_u16* inl;     // mcap: ordered inlier index list of the local-optimisation step
+    idx_u16* perm;    // mcap: the sampler's persistent permutation
+    idx_u16* inl;     // mcap: ordered inlier index list of the local-optimisation step
     lds_f64* jacA;    // 81: A^T A / eigenvalues (and scratch of the wave-wide 5-point solve)
     lds_f64* jacV;    // 81: eigenvectors
     // the sample stream: tempered words of std::mt19937(seed), soff = words consumed so far (wave-uniform)
@@ -123,11 +132,22 @@ __device__ __forceinline__ double* ws_p64(const Wave& w) { return w.ws + (size_t
 __device__ __forceinline__ float* ws_p32(const Wave& w) { return reinterpret_cast<float*>(w.ws + (size_t)(W_NUM_ARRAYS + 4) * w.mcap); }
 __device__ __forceinline__ double* ws_models(const Wave& w) { return w.ws + (size_t)(W_NUM_ARRAYS + 6) * w.mcap; }
 // LDS bytes of one wave: jacA + jacV | sidx | rawcnt | tmax | mlist | perm | inl
-__host__ __device__ inline size_t tvg_lds_per_wave(uint32_t mcap) {
-    const size_t per = (size_t)162 * 8 + 64 * 8 * 2 + 64 * 4 + 64 * 4 + 64 * kMaxModels * 2 + (size_t)((mcap + 7) / 8 * 8) * 2 * 2;
+__host__ __device__ inline size_t tvg_idx_bytes(uint32_t mcap) { return (size_t)((mcap + 7) / 8 * 8) * 2 * 2; }  // perm + inl
+__host__ __device__ inline size_t tvg_lds_per_wave_fixed() {
+    const size_t per = (size_t)162 * 8 + 64 * 8 * 2 + 64 * 4 + 64 * 4 + 64 * kMaxModels * 2;
     return (per + 15) / 16 * 16;
 }
+__host__ __device__ inline size_t tvg_lds_per_wave(uint32_t mcap) {
+#if defined(AMC_TVG_BIG)
+    (void)mcap;
+    return tvg_lds_per_wave_fixed();
+#else
+    return (tvg_lds_per_wave_fixed() + tvg_idx_bytes(mcap) + 15) / 16 * 16;
+#endif
+}
 __host__ __device__ inline size_t tvg_ws_bytes_extra(uint32_t mcap) { return (size_t)4 * mcap; }  // 4 masks
+// big builds: the index arrays, one region per wave behind all waves' point workspaces (8-byte aligned)
+__host__ __device__ inline size_t tvg_idx_doubles(uint32_t mcap) { return (tvg_idx_bytes(mcap) + 7) / 8; }
 // The essential-matrix kernel's minimal solves spread the root finder's brackets over the wave (real_roots10_lanes):
 // per wave the level's coefficients of every lane (11 x 64 doubles) and one pass of bracket records
 // (kRootCap x (lo, hi, f(lo)) + the owning lane), behind the common layout.
@@ -151,10 +171,19 @@ __device__ __forceinline__ void wave_carve(Wave& w, AMC_LDS char* base, uint32_t
     w.rawcnt = reinterpret_cast<lds_u32*>(w.sidx + 64 * 8);
     w.tmax = reinterpret_cast<lds_i32*>(w.rawcnt + 64);
     w.mlist = reinterpret_cast<lds_u16*>(w.tmax + 64);
+#if !defined(AMC_TVG_BIG)
     w.perm = w.mlist + 64 * kMaxModels;
     w.inl = w.perm + (mcap + 7) / 8 * 8;
+#endif
     w.mcap = mcap;
 }
+#if defined(AMC_TVG_BIG)
+// the wave's index arrays in global memory (idx_ws: tvg_idx_doubles(mcap) doubles per wave)
+__device__ __forceinline__ void wave_carve_idx(Wave& w, double* idx_ws, uint32_t mcap) {
+    w.perm = reinterpret_cast<idx_u16*>(idx_ws);
+    w.inl = w.perm + (mcap + 7) / 8 * 8;
+}
+#endif
 
 // Global-memory hand-off between lanes of ONE wave (a lane reads what another lane of the same
 // wave stored): drain this wave's stores, then keep the compiler from moving accesses across.
@@ -174,9 +203,15 @@ __device__ __forceinline__ void scalar_table_sync() {
 // LDS hand-off inside the wave: LDS operations of a wave complete in order, the barrier only
 // stops the compiler from reordering across it
 __device__ __forceinline__ void wave_lds_sync() {
+#if defined(AMC_TVG_BIG)
+    // the index arrays are global memory here: a lane reads what another lane of the wave stored
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+#else
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
 }
 
 // broadcast lane `src`'s double to the whole wave through the scalar unit (src is wave-uniform)
@@ -213,6 +248,13 @@ template <class T>
 __device__ __forceinline__ AMC_LDS T* uni_lds(AMC_LDS T* p) {
     return (AMC_LDS T*)(uintptr_t)uni((uint32_t)(uintptr_t)p);
 }
+__device__ __forceinline__ idx_u16* uni_idx(idx_u16* p) {
+#if defined(AMC_TVG_BIG)
+    return uni_ptr(p);
+#else
+    return uni_lds(p);
+#endif
+}
 template <class T>
 __device__ __forceinline__ const AMC_CONST T* as_const_table(const T* p) {  // p wave-uniform
     return (const AMC_CONST T*)(unsigned long long)uni_ptr(p);
@@ -235,7 +277,7 @@ __device__ __forceinline__ uint32_t stream_word(const AMC_CONST uint32_t* stream
 }
 
 template <int kMin>
-__device__ __forceinline__ SamplerState sample_chunk_t(const uint32_t* stream, uint32_t slen, lds_u16* perm, lds_u16* sidx,
+__device__ __forceinline__ SamplerState sample_chunk_t(const uint32_t* stream, uint32_t slen, idx_u16* perm, lds_u16* sidx,
                                                        lds_u32* rawcnt, SamplerState st, int M, int nT, int lane,
                                                        int force_slow, uint32_t* err) {
     const int need = nT * kMin;
@@ -432,13 +474,13 @@ __device__ __forceinline__ SamplerState sample_chunk_t(const uint32_t* stream, u
 }
 
 template <int kMin>
-__device__ __noinline__ SamplerState sample_chunk(const uint32_t* stream_, uint32_t slen_, lds_u16* perm_, lds_u16* sidx_,
+__device__ __noinline__ SamplerState sample_chunk(const uint32_t* stream_, uint32_t slen_, idx_u16* perm_, lds_u16* sidx_,
                                                   lds_u32* rawcnt_, SamplerState st, int M_, int nT_, int lane,
                                                   int force_slow_, uint32_t* err_) {
     // everything but `lane` is wave-uniform: move it to scalar registers
     const uint32_t* stream = uni_ptr(stream_);
     uint32_t* err = uni_ptr(err_);
-    lds_u16* perm = uni_lds(perm_);
+    idx_u16* perm = uni_idx(perm_);
     lds_u16* sidx = uni_lds(sidx_);
     lds_u32* rawcnt = uni_lds(rawcnt_);
     const int M = uni(M_), nT = uni(nT_), force_slow = uni(force_slow_);
@@ -526,7 +568,7 @@ __device__ __noinline__ Support score(const Model9 mv, const Pts P_, int M_, dou
 
 // ---- local optimisation over the ordered inlier list w.inl[0..K) ---------------------------------
 // ordered compaction of the inlier indices of `model` (kind); returns K
-__device__ __noinline__ int extract_inliers(lds_u16* inl, int lane, int kind, const Model9 mv, const Pts P, int M,
+__device__ __noinline__ int extract_inliers(idx_u16* inl, int lane, int kind, const Model9 mv, const Pts P, int M,
                                             double max_res) {
     const double* model = mv.v;
     int base = 0;
@@ -556,7 +598,7 @@ __device__ __noinline__ int extract_inliers(lds_u16* inl, int lane, int kind, co
 // only the transform T is produced; the normalised coordinates are recomputed where they are
 // consumed (apply_T), with the operations of the reference loop, instead of being stored.
 struct LoCtx {  // what the local estimators need of the wave, passed by value (registers)
-    lds_u16* inl;
+    idx_u16* inl;
     lds_f64* jacA;
     lds_f64* jacV;
     int lane;

@@ -131,6 +131,10 @@ __device__ __noinline__ void process_pair_e(Wave& w, uint32_t q, const TvgImage*
     }
 }
 
+#if defined(AMC_TVG_BIG)   // second build of this file (tvg_e_big.hip): index arrays in global memory, own symbol names
+#define tvg_e_kernel tvg_e_big_kernel
+#define launch_tvg_e launch_tvg_e_big
+#endif
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(kTvgEWavesPerSimd, kTvgEWavesPerSimd))) void tvg_e_kernel(
     const TvgImage* __restrict__ imgs, const TvgPair* __restrict__ pairs, uint32_t npairs,
     const uint32_t* __restrict__ matches, const uint32_t* __restrict__ trial_tabs, TvgParams P,
@@ -146,6 +150,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(kTvgEWavesP
     w.rootscr = root_scratch_carve(lds + tvg_lds_per_wave(mcap));
     const size_t gw = (size_t)blockIdx.x * (blockDim.x >> 6) + wid;
     w.ws = ws_all + gw * tvg_ws_doubles_e(mcap);
+#if defined(AMC_TVG_BIG)
+    wave_carve_idx(w, ws_all + (size_t)gridDim.x * (blockDim.x >> 6) * tvg_ws_doubles_e(mcap) + gw * tvg_idx_doubles(mcap), mcap);
+#endif
     w.masks = nullptr;
     w.stream = P.stream;
     w.stream_len = P.stream_len;
@@ -162,7 +169,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(kTvgEWavesP
 }
 
 
-#if defined(AMC_TVG_LODIAG)
+#if defined(AMC_TVG_BIG)
+// (the diagnostics report belongs to the regular build)
+#elif defined(AMC_TVG_LODIAG)
 void tvg_diag_report_e() {
     unsigned long long h[64];
     if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_lo_diag), sizeof h) != hipSuccess) return;
@@ -189,8 +198,13 @@ void tvg_diag_report_e() {
 void tvg_diag_report_e() {}
 #endif
 
+#if !defined(AMC_TVG_BIG)
 size_t tvg_ws_doubles_e_host(uint32_t mcap) { return tvg_ws_doubles_e(mcap); }
 size_t tvg_lds_bytes_e(uint32_t mcap, int waves) { return (size_t)waves * tvg_lds_per_wave_e(mcap); }
+#else
+size_t tvg_big_lds_bytes_e(int waves) { return (size_t)waves * tvg_lds_per_wave_e(0); }
+size_t tvg_big_idx_doubles_host(uint32_t mcap) { return tvg_idx_doubles(mcap); }
+#endif
 
 hipError_t launch_tvg_e(const TvgImage* imgs, const TvgPair* pairs, uint32_t npairs, const uint32_t* matches,
                         const uint32_t* trial_tabs, const TvgParams& P, double* ws, uint32_t mcap, uint32_t num_waves,

@@ -245,6 +245,10 @@ __device__ __noinline__ void process_pair_fh(Wave& w, uint32_t q, const TvgImage
     }
 }
 
+#if defined(AMC_TVG_BIG)   // second build of this file (tvg_fh_big.hip): index arrays in global memory, own symbol names
+#define tvg_fh_kernel tvg_fh_big_kernel
+#define launch_tvg_fh launch_tvg_fh_big
+#endif
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(kTvgFhWavesPerSimd, kTvgFhWavesPerSimd))) void tvg_fh_kernel(
     const TvgImage* __restrict__ imgs, const TvgPair* __restrict__ pairs, uint32_t npairs,
     const uint32_t* __restrict__ matches, const uint32_t* __restrict__ trial_tabs, TvgParams P,
@@ -259,6 +263,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(kTvgFhWaves
     wave_carve(w, (AMC_LDS char*)smem + (size_t)wid * tvg_lds_per_wave(mcap), mcap);
     const size_t gw = (size_t)blockIdx.x * (blockDim.x >> 6) + wid;
     w.ws = ws_all + gw * tvg_ws_doubles(mcap);
+#if defined(AMC_TVG_BIG)
+    wave_carve_idx(w, ws_all + (size_t)gridDim.x * (blockDim.x >> 6) * tvg_ws_doubles(mcap) + gw * tvg_idx_doubles(mcap), mcap);
+#endif
     w.masks = mask_ws_all + gw * tvg_ws_bytes_extra(mcap);
     w.stream = P.stream;
     w.stream_len = P.stream_len;
@@ -275,11 +282,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(kTvgFhWaves
     }
 }
 
+#if !defined(AMC_TVG_BIG)
 size_t tvg_ws_doubles_host(uint32_t mcap) { return tvg_ws_doubles(mcap); }
 size_t tvg_ws_mask_bytes_host(uint32_t mcap) { return tvg_ws_bytes_extra(mcap); }
 size_t tvg_lds_bytes(uint32_t mcap, int waves) { return (size_t)waves * tvg_lds_per_wave(mcap); }
+#else
+size_t tvg_big_lds_bytes(int waves) { return (size_t)waves * tvg_lds_per_wave(0); }
+#endif
 
-#if defined(AMC_TVG_LODIAG)
+#if defined(AMC_TVG_BIG)
+// (the diagnostics report and the Sampson kernel belong to the regular build)
+#elif defined(AMC_TVG_LODIAG)
 void tvg_diag_report() {
     unsigned long long h[48];
     if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_lo_diag), sizeof h) != hipSuccess) return;
@@ -304,6 +317,7 @@ void tvg_diag_report() {
 void tvg_diag_report() {}
 #endif
 
+#if !defined(AMC_TVG_BIG)
 // ComputeSquaredSampsonError over n correspondences (points n x 2, E row-major)
 __global__ __launch_bounds__(256) void sampson_kernel(const double* __restrict__ p1, const double* __restrict__ p2,
                                                       size_t n, const double* __restrict__ E9,
@@ -321,6 +335,7 @@ hipError_t launch_sampson(const double* p1, const double* p2, size_t n, const do
     hipLaunchKernelGGL(sampson_kernel, dim3(blocks), dim3(256), 0, s, p1, p2, n, E9, out);
     return hipGetLastError();
 }
+#endif
 
 hipError_t launch_tvg_fh(const TvgImage* imgs, const TvgPair* pairs, uint32_t npairs, const uint32_t* matches,
                          const uint32_t* trial_tabs, const TvgParams& P, double* ws, uint8_t* mask_ws, uint32_t mcap,
@@ -328,7 +343,7 @@ hipError_t launch_tvg_fh(const TvgImage* imgs, const TvgPair* pairs, uint32_t np
                          const uint8_t* emask, TvgOut* out, uint8_t* out_mask, hipStream_t s) {
     if (npairs == 0) return hipSuccess;
     const uint32_t blocks = (num_waves + waves_per_block - 1) / waves_per_block;
-    const size_t lds = tvg_lds_bytes(mcap, waves_per_block);
+    const size_t lds = (size_t)waves_per_block * tvg_lds_per_wave(mcap);  // (this build's own layout: the big one has no index arrays in LDS)
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tvg_fh_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;

@@ -131,6 +131,26 @@ def test_large_match_counts(amc_ctx):
         assert_pair_equal(p, tvg, mask, off, want)
 
 
+def test_more_matches_than_the_index_arrays_fit_in_lds(amc_ctx):
+    """Round 3's limit: a pair's two 16-bit index arrays (sampler permutation, inlier list: 4 bytes per match) had to
+    fit one workgroup's LDS, ~38,000 matches.  Beyond it the "big" builds of the two kernels (tvg_e_big.hip /
+    tvg_fh_big.hip) keep the arrays in the wave's global workspace: 50,000 and 65,535 matches (the most 16-bit indices
+    name), calibrated and not, general and planar, next to small pairs of the same call - bit for bit the oracle."""
+    rng = np.random.default_rng(50)
+    scenes = [synth.two_view_scene(rng, num_inliers=46000, num_outliers=4000),
+              synth.two_view_scene(rng, num_inliers=200, num_outliers=80),
+              synth.two_view_scene(rng, num_inliers=60000, num_outliers=5535, planar=True),
+              synth.two_view_scene(rng, num_inliers=39000, num_outliers=3000)]
+    assert [len(sc["matches"]) for sc in scenes] == [50000, 280, 65535, 42000]
+    for priors in ([True, True, False, False], [False, False, True, True]):
+        tvg, mask, off, want = run_both(amc_ctx, scenes, priors)
+        for p in range(len(scenes)):
+            assert_pair_equal(p, tvg, mask, off, want)
+    one_more = synth.two_view_scene(rng, num_inliers=65000, num_outliers=536)
+    with pytest.raises(Exception, match="65535"):
+        run_both(amc_ctx, [one_more], [False])
+
+
 def test_watermark_and_option_variants(amc_ctx):
     rng = np.random.default_rng(9)
     w, h, n = 1600, 1200, 80
