@@ -71,6 +71,10 @@ constexpr int kBN = 256;                // Y rows per LDS chunk (= kRowPad); 512
 constexpr int kYT = kBN / 32;           // Y tiles per chunk
 constexpr int kChunkBytes = kBN * kDim; // 32 KiB
 constexpr int kSegTiles = kSegRows / 32;  // 32-row X tiles per segment
+#ifndef AMC_KEY_INSERT
+#define AMC_KEY_INSERT 1   // 0: the four-instruction insertion with an explicit tile register (A/B)
+#endif
+constexpr int kKeyShift = 7, kKeyCarried = 127;
 
 // single LDS object (a second __shared__ object de-pipelines the DMA waits).  THREE chunk buffers: while chunk c is
 // scanned, chunk c+1 has landed (or is landing) and chunk c+2 is being fetched into the buffer chunk c-1 left -
@@ -244,8 +248,13 @@ __global__ __launch_bounds__(64 * W) void match_mfma_kernel(const SegDesc* __res
             // acc = sum a'b' + 128*SY_j = v - (128*SX_i - 2^21)
             xterm[xt] = xrs[row] - (1 << 21);
             // COLMAP's floor best = second = 0  <=>  acc = -xterm
+#if AMC_KEY_INSERT
+            best[xt] = ((-xterm[xt]) << kKeyShift) | kKeyCarried;  // a key: value << 7 | tile code (see `insert`)
+            sec[xt] = best[xt];
+#else
             best[xt] = -xterm[xt];
             sec[xt] = -xterm[xt];
+#endif
             btile[xt] = -1;
         }
     };
@@ -295,7 +304,32 @@ __global__ __launch_bounds__(64 * W) void match_mfma_kernel(const SegDesc* __res
         // products anyway to find the index: it takes the second of those 32 as well and the
         // row's second is the larger of the two.
         // Insertion of a unit maximum into a lane's (best, second, tile) state, in place (no copies for the
-        // register allocator to make).  The compare comes first: on gfx950 a VALU read of VCC needs two
+        // register allocator to make).
+#if AMC_KEY_INSERT
+        // Three instructions: the state holds KEYS, value << 7 | code, code = 126 - (tile mod 64).  The accumulators stay
+        // below 2^24 in magnitude (|sum a'b'| <= 2^21, 128 SY < 2^22), so a key fits 32 bits; a larger value is a
+        // larger key, equal values are ordered first tile first (strict '>' of the reference scan), and the second
+        // largest key carries the second largest value, equal ones included.  Every 64 tiles (and at the end of the
+        // item) `flush` moves the tile of a best found since the last flush to btile and marks the key "carried"
+        // (code 127: it beats equal values of later tiles).  The tile code is wave-uniform: a scalar operand.
+        auto insert = [&](int xt, int m, int code) __attribute__((always_inline)) {
+            asm volatile(
+                "v_lshl_or_b32 %2, %2, 7, %3\n\t"
+                "v_med3_i32 %1, %0, %1, %2\n\t"  // sec <= best always: the new second of the maxima
+                "v_max_i32 %0, %0, %2"
+                : "+v"(best[xt]), "+v"(sec[xt]), "+v"(m)
+                : "s"(code));
+        };
+        auto flush = [&](int sb) __attribute__((always_inline)) {  // sb: the 64-tile block that ends here
+#pragma unroll
+            for (int xt = 0; xt < XT; ++xt) {
+                const int c = best[xt] & 127;
+                btile[xt] = c != kKeyCarried ? sb * 64 + (126 - c) : btile[xt];
+                best[xt] |= kKeyCarried;
+            }
+        };
+#else
+        // The compare comes first: on gfx950 a VALU read of VCC needs two
         // instructions between it and the VALU write.  Strict '>': the first tile wins ties.
         auto insert = [&](int xt, int m, int tile) __attribute__((always_inline)) {
             asm volatile(
@@ -307,10 +341,15 @@ __global__ __launch_bounds__(64 * W) void match_mfma_kernel(const SegDesc* __res
                 : "v"(m), "v"(tile)
                 : "vcc");
         };
+#endif
         // The insertion of a unit's maximum does not touch accumulators, so it is deferred into
         // the hazard slot of the NEXT phase (between its first two MFMAs): pm / ptile carry the
         // pending maximum (of X tile xtc - 1) from one phase to the next.
+#if AMC_KEY_INSERT
+        int pm = -(1 << 24), ptile = 0;  // a pending "maximum" below every accumulator: its key is below every floor key
+#else
         int pm = INT_MIN, ptile = 0;
+#endif
         auto phase = [&](i32x16& an, const YFrag& y, int xtn, const i32x16& ac, int xtc, int tile)
                          __attribute__((always_inline)) {
             mfma_first<BA>(an, y.f[0], xf[xtn][0], y.ci);
@@ -324,7 +363,13 @@ __global__ __launch_bounds__(64 * W) void match_mfma_kernel(const SegDesc* __res
             ptile = tile;
             (void)insert;
 #else
+#if AMC_KEY_INSERT
+            insert((xtc + XT - 1) % XT, pm, 126 - (ptile & 63));
+            // the last unit of a 64-tile block has just gone in: settle the tiles before the next block reuses the codes
+            if (xtc == 0 && tile != 0 && (tile & 63) == 0) flush((tile >> 6) - 1);
+#else
             insert((xtc + XT - 1) % XT, pm, ptile);
+#endif
             __builtin_amdgcn_sched_barrier(0);
             mfma_acc<BA>(an, y.f[1], xf[xtn][1]);
             __builtin_amdgcn_sched_barrier(0);
@@ -430,7 +475,19 @@ __global__ __launch_bounds__(64 * W) void match_mfma_kernel(const SegDesc* __res
             }
             cb = nb;
         }
+#if AMC_KEY_INSERT
+        if (active) {
+            insert(XT - 1, pm, 126 - (ptile & 63));  // the last unit's maximum is still pending
+            flush(ptile >> 6);
+#pragma unroll
+            for (int xt = 0; xt < XT; ++xt) {  // keys -> values
+                best[xt] >>= kKeyShift;
+                sec[xt] >>= kKeyShift;
+            }
+        }
+#else
         if (active) insert(XT - 1, pm, ptile);  // the last unit's maximum is still pending
+#endif
         __syncthreads();  // everyone is done with both LDS chunk buffers (and has read the queue slot)
 
         // ---- item done.  Start the next one's loads, then decode and store this one under them ----
