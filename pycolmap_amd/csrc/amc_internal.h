@@ -168,10 +168,6 @@ __device__ __forceinline__ bool one_way_accepts(const Top2 t, const float* __res
     return true;
 }
 
-// accmask: one bit per row of the mfma pairs' row tables (bit r of word (row_off + r) / 32): set
-// by the scan for rows that pass the acceptance tests with the preliminary second value, narrowed
-// by resolve_index (side 0) to the rows that pass with the exact one.  The later kernels walk the
-// bits instead of re-reading and re-testing every row.
 // Packs the segments of the pairs listed in `order` (sorted by the streamed image; grp_start cuts it where that
 // image changes) into items: segs[0 .. 8 * *nitems_dev).  seg_base (one per order entry), grp_segs and
 // grp_item_base (one per group) are scratch.  All on stream s; mode 1 reads cand_cnt on the device.
@@ -180,6 +176,10 @@ void launch_build_segments(int mode, const ImageDev* imgs, const PairDev* pairs,
                            const uint32_t* candbuf, Top2* outbuf, uint32_t* seg_base, uint32_t* grp_segs,
                            uint32_t* grp_item_base, SegDesc* segs, uint32_t* nitems_dev, hipStream_t s);
 // The scan over the packed items (persistent workgroups, dynamic queue).  max_items bounds the grid only.
+// accmask: one bit per row of the mfma pairs' row tables (bit r of word (row_off + r) / 32): set by the scan (mode 0)
+// for the rows that may pass the acceptance tests (scan_accept.h: a superset, with the preliminary second value),
+// narrowed by resolve_index (side 0) to the rows that pass with the exact one.  The later kernels walk the bits
+// instead of re-reading and re-testing every row.
 // accept_dev: the scan's accept-bit thresholds for the call's options (scan_accept.h), in device memory.
 struct ScanAccept;
 void launch_match_mfma(int mode, const SegDesc* segs, const uint32_t* nitems_dev, uint32_t max_items,
@@ -207,7 +207,7 @@ void launch_finalize(const ImageDev* imgs, const PairDev* pairs, uint32_t npairs
 void launch_reorder_matches(const uint32_t* src_off, const uint32_t* cnt, const uint64_t* dst_off, uint32_t npairs,
                             const uint32_t* src, uint32_t* dst, hipStream_t s);
 
-// ----- two-view verification (tvg.hip) ------------------------------------------------------
+// ----- two-view verification (tvg_core.h; kernels in tvg_e.hip, tvg_fh.hip and their _big builds) ------------------------------------------------------
 struct CameraDev {
     int32_t model_id;    // COLMAP camera model id 0..10 (camera_math.h)
     int32_t has_prior;
@@ -268,7 +268,7 @@ struct alignas(128) TvgOut {
     // shader-clock cycles spent per phase (diagnostics; printed with AMC_TVG_PROFILE=1):
     // 0 sampling, 1 minimal solvers, 2 scoring of sample models, 3 local optimisation, 4 total
     unsigned long long prof[8];
-    // algorithmic work of the pair (tvg.hip WK_*): residual evaluations by kind (Sampson, homography transfer,
+    // algorithmic work of the pair (tvg_core.h WK_*): residual evaluations by kind (Sampson, homography transfer,
     // translation), minimal solves (5-point, 7-point, 4-point), local solves (5-point, 8-point, DLT), the inlier
     // points those local solves summed over, 1-point trials - the inputs of bench.py's FP64 roofline
     unsigned long long work[12];

@@ -1,4 +1,4 @@
-// tvg_math.h — lane-local FP64 numerics of the two-view verification kernels (csrc/tvg.hip).
+// tvg_math.h — lane-local FP64 numerics of the two-view verification kernels (csrc/tvg_core.h, included by tvg_e.hip and tvg_fh.hip).
 //
 // Every function here is straight-line scalar code one GPU lane runs on its own data (one
 // RANSAC trial per lane for the minimal solvers; lane 0 for the local-optimisation solvers).
@@ -739,7 +739,7 @@ AMC_HD void e5_pmul(const double (&a)[DA + 1], const double (&b)[DB + 1], double
 }
 
 // The 5-point solver in three steps, so that the root finding in the middle can be swapped for a
-// wave-cooperative version where one problem is solved by a whole wave (tvg.hip, local optimisation):
+// wave-cooperative version where one problem is solved by a whole wave (tvg_core.h, local optimisation):
 //   e5_build:   nsp (4 x 9 basis; rows: x, y, z, 1 directions) -> B(z) (3 x 3 polynomial matrix) and
 //               det B(z), degree 10
 //   real roots of det B
@@ -1011,7 +1011,7 @@ AMC_HD int e5_from_ata(double* ata, double* models) {
 }
 
 // ---- homography inlier decisions in FP32, with a bound on their own error -------------------------
-// The counting loop's pre-filter (tvg.hip: count_h32 evaluates exactly this, two points per packed instruction).
+// The counting loop's pre-filter (tvg_core.h: count_lanes_h32 evaluates exactly this, two points per packed instruction).
 // With s = 1 / sqrt(T) folded into rows 0 / 1 of the model and into the image-2 coordinates, a point is an inlier
 // iff t = u'^2 + v'^2 - w^2 <= 0 (u' = c' w - p0', v' = d' w - p1').  Every operation below is one FP32 rounding
 // (u = 2^-24); C = largest |coordinate| of the pair; A0 = (|m0| + |m1|) C + |m2|, A1, Aw likewise (m = scaled model):

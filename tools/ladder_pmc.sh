@@ -38,8 +38,8 @@ for k, c in cnt.items():
         if kk[:40] == k[:40]: t = v
     if not t or "GRBM_GUI_ACTIVE" not in c: continue
     cycles = c["GRBM_GUI_ACTIVE"] / 8.0
-    ghz = cycles / t   # total in ns
+    ghz = cycles / t / 1e3   # top_kernels totals are in microseconds
     busy = c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (1024.0 * cycles)
-    print("  %-50s time %.3f ms clock %.3f GHz pipe-busy %.3f" % (k[:50], t / 1e6, ghz, busy))
+    print("  %-50s time %.3f ms clock %.3f GHz pipe-busy %.3f" % (k[:50], t / 1e3, ghz, busy))
 PY
 cat $OUT

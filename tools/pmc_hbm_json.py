@@ -31,9 +31,9 @@ if "TCC_EA0_WRREQ_sum" in cnt:
 if "GRBM_GUI_ACTIVE" in cnt:
     out["grbm_gui_active_per_launch"] = cnt["GRBM_GUI_ACTIVE"][2]
     if calls and total:
-        ms = total / calls / 1e6
+        ms = total / calls / 1e3   # top_kernels totals are in microseconds
         out["kernel_ms_under_pmc"] = ms
-        out["clock_ghz"] = cnt["GRBM_GUI_ACTIVE"][2] / 8 / (ms * 1e6)
+        out["clock_ghz"] = cnt["GRBM_GUI_ACTIVE"][2] / 8 / (ms * 1e6)   # cycles per XCD / (ms * 1e6 ns/ms) = GHz
 out["kernel_source_sha256"] = {f: hashlib.sha256((ROOT / f).read_bytes()).hexdigest()
                                for f in ("pycolmap_amd/csrc/match_mfma.hip",)}
 Path(sys.argv[2]).write_text(json.dumps(out, indent=1) + "\n")
