@@ -866,10 +866,12 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
             launch_match_dot4(c->d_imgs.p, c->d_pairs.p, c->d_work.p + b.nwork_grid, (uint32_t)(nwork - b.nwork_grid),
                               c->d_rowbuf.p, c->d_colbuf.p, geoms ? c->d_guided.p : nullptr, st);
         (void)hipEventRecord(c->bev[k][1], st);
+        const bool use_order = std::getenv("AMC_RESOLVE_PAIR_ORDER") == nullptr;  // (A/B hook: workgroups in batch order)
         kernel_launches += (nord ? 1 : 0) + (b.nwork_grid ? 1 : 0) + (nwork > b.nwork_grid ? 1 : 0);
         if (nord)  // tile -> exact index for the accepted rows
             launch_resolve_index(0, c->d_imgs.p, c->d_pairs.p, (uint32_t)nb, c->d_rowbuf.p, c->d_accmask.p, c->d_lut,
-                                 fp, c->d_cand_cnt.p, c->d_candbuf.p, c->d_scalars + 3, b.grouped_resolve, st);
+                                 fp, c->d_cand_cnt.p, c->d_candbuf.p, c->d_scalars + 3, b.grouped_resolve,
+                                 use_order ? c->d_order.p : nullptr, (uint32_t)nord, st);
         if (nord && o.cross_check) {
             // lazy cross check: reverse scan only for the columns accepted rows point at
             launch_select_candidates(c->d_imgs.p, c->d_pairs.p, (uint32_t)nb, b.max_cols, c->d_rowbuf.p, c->d_accmask.p,
@@ -886,7 +888,8 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
             launch_match_mfma(1, c->d_segs.p, c->d_scalars + 5, (uint32_t)std::min<size_t>(b.seg_cap, 0xFFFFFFFFu),
                               c->d_scalars + 1, c->d_accmask.p, c->d_accept, st);
             launch_resolve_index(1, c->d_imgs.p, c->d_pairs.p, (uint32_t)nb, c->d_colbuf.p, c->d_accmask.p, c->d_lut,
-                                 fp, c->d_cand_cnt.p, c->d_candbuf.p, c->d_scalars + 3, b.grouped_resolve, st);
+                                 fp, c->d_cand_cnt.p, c->d_candbuf.p, c->d_scalars + 3, b.grouped_resolve,
+                                 use_order ? c->d_order2.p : nullptr, (uint32_t)nord, st);
         }
         (void)hipEventRecord(c->bev[k][2], st);
         launch_finalize(c->d_imgs.p, c->d_pairs.p, (uint32_t)nb, c->d_rowbuf.p, c->d_colbuf.p,

@@ -189,7 +189,7 @@ int match_mfma_shape();  // waves per workgroup in use (8 or 4)
 void launch_resolve_index(int side, const ImageDev* imgs, const PairDev* pairs, uint32_t npairs,
                           Top2* table, uint32_t* accmask, const float* acos_lut, FinalizeParams fp,
                           const uint32_t* cand_cnt, const uint32_t* candbuf, uint32_t* err_count,
-                          bool grouped, hipStream_t s);
+                          bool grouped, const uint32_t* order, uint32_t norder, hipStream_t s);
 // largest image (padded rows) the tile-grouped variant of resolve_index handles (its LDS histogram)
 uint32_t resolve_grouped_max_rows();
 constexpr uint32_t kSelectMaxCols = 1u << 20;  // select_candidates' LDS bitmap: at most 128 KiB of dynamic shared memory

@@ -1,6 +1,8 @@
 // match_common.hip — descriptor preparation and the finalize (thresholds + cross-check +
 // ordered compaction) kernel shared by both match kernels.  gfx950 only.
 #include <algorithm>
+#include <climits>
+#include <cstdlib>
 
 #include "amc_internal.h"
 
@@ -158,12 +160,14 @@ __global__ __launch_bounds__(256) void resolve_index_kernel(
     int side, const ImageDev* __restrict__ imgs, const PairDev* __restrict__ pairs,
     Top2* __restrict__ table, uint32_t* __restrict__ accmask, const float* __restrict__ lut,
     FinalizeParams fp, const uint32_t* __restrict__ cand_cnt, const uint32_t* __restrict__ candbuf,
-    uint32_t* __restrict__ err_count) {
-    const PairDev p = pairs[blockIdx.x];
+    uint32_t* __restrict__ err_count,
+    const uint32_t* __restrict__ order) {
+    const uint32_t pi = order ? order[blockIdx.x] : blockIdx.x;  // (in the streamed image's order: neighbours share Y)
+    const PairDev p = pairs[pi];
     if (p.mode == 0) return;  // dot4 pairs carry exact indices already
     const ImageDev X = imgs[side == 0 ? p.slot1 : p.slot2];
     const ImageDev Y = imgs[side == 0 ? p.slot2 : p.slot1];
-    const uint32_t n = side == 0 ? X.rows : cand_cnt[blockIdx.x];
+    const uint32_t n = side == 0 ? X.rows : cand_cnt[pi];
     if (n == 0 || Y.rows == 0) return;
     Top2* tab = table + (side == 0 ? p.row_off : p.col_off);
     uint32_t* amask = accmask + (p.row_off >> 5);
@@ -252,7 +256,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     int side, const ImageDev* __restrict__ imgs, const PairDev* __restrict__ pairs,
     Top2* __restrict__ table, uint32_t* __restrict__ accmask, const float* __restrict__ lut,
     FinalizeParams fp, const uint32_t* __restrict__ cand_cnt, const uint32_t* __restrict__ candbuf,
-    uint32_t* __restrict__ err_count) {
+    uint32_t* __restrict__ err_count,
+    const uint32_t* __restrict__ order) {
     // 48 KB, three workgroups per CU.  While sorting: s_list | s_sorted | s_hist; while walking the rows the first
     // third holds the rows' dot products (`part`) and the last third the batch's X rows (over s_hist and beyond).
     __shared__ __attribute__((aligned(16))) uint32_t s_pool[3 * kResolveChunk];
@@ -264,11 +269,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     __shared__ uint32_t s_wsum[4];
     __shared__ uint32_t s_count;
     __shared__ uint32_t s_brow[4][32], s_btile[4][32];  // the batch's rows and tiles, by wave
-    const PairDev p = pairs[blockIdx.x];
+    const uint32_t pi = order ? order[blockIdx.x] : blockIdx.x;  // (in the streamed image's order: neighbours share Y)
+    const PairDev p = pairs[pi];
     if (p.mode == 0) return;  // dot4 pairs carry exact indices already
     const ImageDev X = imgs[side == 0 ? p.slot1 : p.slot2];
     const ImageDev Y = imgs[side == 0 ? p.slot2 : p.slot1];
-    const uint32_t n = side == 0 ? X.rows : cand_cnt[blockIdx.x];
+    const uint32_t n = side == 0 ? X.rows : cand_cnt[pi];
     if (n == 0 || Y.rows == 0) return;
     Top2* tab = table + (side == 0 ? p.row_off : p.col_off);
     uint32_t* amask = accmask + (p.row_off >> 5);
@@ -473,17 +479,240 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// resolve_index on the matrix core (round 4).  Same sort by tile as the grouped kernel above; the dot products of a
+// batch come from v_mfma_i32_32x32x32_i8 instead of 32 x 32 v_dot4 per accepted row.  Same values (the zero-point
+// identity is exact), same decisions, same table updates: test_dense_overlap_and_both_resolve_kernels holds the three
+// forms against each other.  Used whenever the grouped form would be (AMC_RESOLVE_DOT4=1 keeps that one, for A/B).
+// ---------------------------------------------------------------------------------------
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+constexpr uint32_t kResolveChunkM = 3840;  // rows per sort chunk of the mfma form: two lists of it + the histogram stay under 40 KB
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void resolve_index_mfma_kernel(
+    int side, const ImageDev* __restrict__ imgs, const PairDev* __restrict__ pairs,
+    Top2* __restrict__ table, uint32_t* __restrict__ accmask, const float* __restrict__ lut,
+    FinalizeParams fp, const uint32_t* __restrict__ cand_cnt, const uint32_t* __restrict__ candbuf,
+    uint32_t* __restrict__ err_count,
+    const uint32_t* __restrict__ order) {
+    // 38 KB, four workgroups per CU: the chunk's accepted rows, the same sorted by tile, the tile histogram
+    __shared__ __attribute__((aligned(16))) uint32_t s_pool[2 * kResolveChunkM + kResolveMaxTiles];
+    uint32_t* const s_list = s_pool;                        // (tile << 12) | position in the chunk
+    uint32_t* const s_sorted = s_pool + kResolveChunkM;
+    uint32_t* const s_hist = s_pool + 2 * kResolveChunkM;    // kResolveMaxTiles entries
+    __shared__ uint32_t s_wsum[4];
+    __shared__ uint32_t s_count;
+    __shared__ uint32_t s_brow[4][32];  // the batch's rows, by wave
+    const uint32_t pi = order ? order[blockIdx.x] : blockIdx.x;  // (in the streamed image's order: neighbours share Y)
+    const PairDev p = pairs[pi];
+    if (p.mode == 0) return;  // dot4 pairs carry exact indices already
+    const ImageDev X = imgs[side == 0 ? p.slot1 : p.slot2];
+    const ImageDev Y = imgs[side == 0 ? p.slot2 : p.slot1];
+    const uint32_t n = side == 0 ? X.rows : cand_cnt[pi];
+    if (n == 0 || Y.rows == 0) return;
+    Top2* tab = table + (side == 0 ? p.row_off : p.col_off);
+    uint32_t* amask = accmask + (p.row_off >> 5);
+    const uint32_t* list = candbuf + p.col_off;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const uint32_t l31 = lane & 31, half = lane >> 5;
+    const uint32_t ntiles = Y.rows_pad / 32;
+    constexpr uint32_t kPer = kResolveMaxTiles / 256;  // histogram bins per thread in the scan
+    for (uint32_t chunk0 = 0; chunk0 < n; chunk0 += kResolveChunkM) {
+        const uint32_t chunk_end = min(n, chunk0 + kResolveChunkM);
+        if (tid == 0) s_count = 0;
+        for (uint32_t k = tid; k < kResolveMaxTiles; k += 256) s_hist[k] = 0;
+        __syncthreads();
+        // ---- accepted rows of the chunk and the histogram of their tiles (four rows per thread and round: their table
+        // reads are independent and in flight together)
+        for (uint32_t e0 = chunk0 + tid; e0 < chunk_end; e0 += 4 * 256) {
+            bool acc[4];
+            uint32_t tile[4];
+            if (side == 0) {
+                uint32_t aw[4], bi[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t e = min(e0 + (uint32_t)u * 256, chunk_end - 1);
+                    aw[u] = amask[e >> 5];
+                    bi[u] = tab[e].best_idx;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t e = e0 + (uint32_t)u * 256;
+                    acc[u] = e < chunk_end && ((aw[u] >> (e & 31)) & 1u);
+                    tile[u] = bi[u];
+                }
+            } else {
+                uint32_t le[4];
+                Top2 tt[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) le[u] = list[min(e0 + (uint32_t)u * 256, chunk_end - 1)];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) tt[u] = tab[le[u]];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    acc[u] = e0 + (uint32_t)u * 256 < chunk_end && one_way_accepts(tt[u], lut, fp.max_ratio, fp.max_distance);
+                    tile[u] = tt[u].best_idx;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (!acc[u]) continue;
+                const uint32_t e = e0 + (uint32_t)u * 256;
+                if (tile[u] >= ntiles) {  // cannot happen (the scan only reports tiles it visited): counted, row left unresolved
+                    atomicAdd(err_count, 1u);
+                    continue;
+                }
+                const uint32_t pos = atomicAdd(&s_count, 1u);
+                s_list[pos] = (tile[u] << 12) | (e - chunk0);
+                atomicAdd(&s_hist[tile[u]], 1u);
+            }
+        }
+        __syncthreads();
+        const uint32_t cnt = s_count;
+        if (cnt == 0) { __syncthreads(); continue; }
+        // ---- exclusive scan of the histogram (thread t owns bins [t * kPer, (t + 1) * kPer))
+        uint32_t h[kPer], c = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < kPer; ++k) { h[k] = s_hist[tid * kPer + k]; c += h[k]; }
+        uint32_t inc = c;
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) {
+            const uint32_t o = __shfl_up(inc, m);
+            if (lane >= (uint32_t)m) inc += o;
+        }
+        if (lane == 63) s_wsum[wid] = inc;
+        __syncthreads();
+        uint32_t start = inc - c;
+        for (uint32_t k = 0; k < wid; ++k) start += s_wsum[k];
+#pragma unroll
+        for (uint32_t k = 0; k < kPer; ++k) { s_hist[tid * kPer + k] = start; start += h[k]; }
+        __syncthreads();
+        for (uint32_t k = tid; k < cnt; k += 256) {
+            const uint32_t v = s_list[k];
+            s_sorted[atomicAdd(&s_hist[v >> 12], 1u)] = v;
+        }
+        __syncthreads();
+        // ---- each wave walks a contiguous quarter of the sorted list in batches of 32 rows, and the batch's dot products
+        // come from the int8 matrix core: B operand = the batch's 32 X rows (prepared arena, fetched once per batch),
+        // A operand = one 32-row Y tile; four MFMAs give every (X row, Y row) product of the pair, the zero-point term
+        // 128 SY_j rides in as the C operand and the lane's own term is added at decode - the scan's arithmetic
+        // (match_mfma.hip), so the values are the exact u8 dot products.  The batch is sorted by tile: the rows of
+        // one tile are a run, and each distinct tile of the batch costs one visit (four MFMAs + ~50 VALU for all 32
+        // rows at once) instead of 32 x 32 v_dot4 per row.
+        // A lane's 16 outputs become keys, value << 5 | (31 - j): their maximum is the best value at its LOWEST row
+        // index (COLMAP's strict '>' keeps that one), their second-largest the second value with multiplicity.
+        const uint32_t kb = (uint32_t)(((uint64_t)cnt * wid) / 4), ke = (uint32_t)(((uint64_t)cnt * (wid + 1)) / 4);
+        int codes[16];  // 31 - (row of the tile that accumulator register r holds on this lane)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) codes[r] = 31 - ((r & 3) + 8 * (r >> 2) + 4 * (int)half);
+        for (uint32_t b0 = kb; b0 < ke; b0 += 32) {
+            const uint32_t nb = min(32u, ke - b0);
+            uint32_t my_row = 0, my_e = 0, my_tile = 0xFFFFFFFFu;
+            Top2 my_t{0u, 0u, 0u, 0u};
+            if (lane < nb) {
+                const uint32_t v = s_sorted[b0 + lane];
+                my_tile = v >> 12;
+                my_e = chunk0 + (v & 4095u);
+                my_row = side == 0 ? my_e : list[my_e];
+                my_t = tab[my_row];
+                s_brow[wid][lane] = my_row;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // B operand: X row l31 of the batch (rows past nb repeat row 0; their results are never read)
+            const uint32_t xrow = s_brow[wid][l31 < nb ? l31 : 0];
+            i32x4 xf[4];
+            {
+                const char* rp = reinterpret_cast<const char*>(X.prep) + (size_t)xrow * kDim;
+                const uint32_t sw = (xrow >> 1) & 7u;
+#pragma unroll
+                for (int sl = 0; sl < 4; ++sl) xf[sl] = *reinterpret_cast<const i32x4*>(rp + (((2 * sl + half) ^ sw) * 16));
+            }
+            const int xterm = X.rs128[xrow] - (1 << 21);  // dot = accumulator + xterm
+            bool found = false;
+            uint32_t first = 0, sw_val = 0;
+            unsigned long long todo = __ballot(lane < nb);
+            while (todo) {
+                const int src = __ffsll((long long)todo) - 1;
+                const uint32_t T = (uint32_t)__builtin_amdgcn_readlane((int)my_tile, src);  // the next tile of the batch
+                todo &= ~__ballot(lane < nb && my_tile == T);
+                // A operand + C block of tile T (rows T*32 .. +31 < rows_pad: padding rows are zero descriptors)
+                const uint32_t yrow = T * 32 + l31;
+                const char* yp = reinterpret_cast<const char*>(Y.prep) + (size_t)yrow * kDim;
+                const uint32_t ysw = (yrow >> 1) & 7u;
+                i32x4 yf[4];
+#pragma unroll
+                for (int sl = 0; sl < 4; ++sl) yf[sl] = *reinterpret_cast<const i32x4*>(yp + (((2 * sl + half) ^ ysw) * 16));
+                i32x16 acc;
+                const int* rsb = Y.rs128 + T * 32 + 4 * half;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const i32x4 v = *reinterpret_cast<const i32x4*>(rsb + 8 * g);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[4 * g + e] = v[e];
+                }
+#pragma unroll
+                for (int sl = 0; sl < 4; ++sl) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(yf[sl], xf[sl], acc, 0, 0, 0);
+                // top two keys of the lane's 16 outputs, then of the two lane halves (they hold different Y rows)
+                int k1 = (acc[0] << 5) | codes[0], k2 = INT_MIN;
+#pragma unroll
+                for (int r = 1; r < 16; ++r) {
+                    const int k = (acc[r] << 5) | codes[r];
+                    k2 = max(k2, min(k1, k));
+                    k1 = max(k1, k);
+                }
+                const int o1 = __shfl_xor(k1, 32), o2 = __shfl_xor(k2, 32);
+                const int K1 = max(k1, o1);
+                const int K2 = max(min(k1, o1), max(k2, o2));
+                if (my_tile == T) {  // (lanes 0 .. nb-1 carry the batch's rows: l31 == lane there)
+                    const uint32_t val = (uint32_t)((K1 >> 5) + xterm);
+                    const uint32_t j = 31u - (uint32_t)(K1 & 31);
+                    found = val == my_t.best_v && T * 32 + j < Y.rows;
+                    first = j;
+                    // the second of the tile: every other entry (a padding row counts 0, COLMAP's floor)
+                    const int s2 = (K2 >> 5) + xterm;
+                    sw_val = (uint32_t)max(s2, 0);
+                }
+            }
+            if (lane < nb) {
+                Top2 w2 = my_t;
+                w2.best_idx = found ? my_tile * 32 + first : 0xFFFFFFFFu;
+                w2.second_v = max(my_t.second_v, sw_val);
+                tab[my_row].best_idx = w2.best_idx;
+                tab[my_row].second_v = w2.second_v;
+                if (!found) atomicAdd(err_count, 1u);  // scan and recomputation disagree: a bug
+                // side 0: narrow the accept bits to the rows that pass with the exact second
+                if (side == 0 && !one_way_accepts(w2, lut, fp.max_ratio, fp.max_distance))
+                    atomicAnd(&amask[my_e >> 5], ~(1u << (my_e & 31)));
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        __syncthreads();
+    }
+}
+
 void launch_resolve_index(int side, const ImageDev* imgs, const PairDev* pairs, uint32_t npairs,
                           Top2* table, uint32_t* accmask, const float* acos_lut, FinalizeParams fp,
                           const uint32_t* cand_cnt, const uint32_t* candbuf, uint32_t* err_count,
-                          bool grouped, hipStream_t s) {
-    if (npairs == 0) return;
-    if (grouped)
-        hipLaunchKernelGGL(resolve_index_grouped_kernel, dim3(npairs), dim3(256), 0, s, side, imgs, pairs,
-                           table, accmask, acos_lut, fp, cand_cnt, candbuf, err_count);
+                          bool grouped, const uint32_t* order, uint32_t norder, hipStream_t s) {
+    // `order` (norder mfma pairs, sorted by the image this side STREAMS): a workgroup per listed pair, so that
+    // workgroups running at the same time read the same Y tiles - on the dense set a pair's workgroup reads all of
+    // image Y (512 KB of tiles) and a third of image X; in plain pair order (image 1 major) neighbours shared X only
+    // and the launch moved ~0.7 MB per pair from HBM.  Without it: one workgroup per pair of the batch.
+    const uint32_t grid = order ? norder : npairs;
+    if (grid == 0) return;
+    const bool dot4_form = std::getenv("AMC_RESOLVE_DOT4") != nullptr;  // (test hook / A/B: the v_dot4 form)
+    if (grouped && !dot4_form)
+        hipLaunchKernelGGL(resolve_index_mfma_kernel, dim3(grid), dim3(256), 0, s, side, imgs, pairs,
+                           table, accmask, acos_lut, fp, cand_cnt, candbuf, err_count, order);
+    else if (grouped)
+        hipLaunchKernelGGL(resolve_index_grouped_kernel, dim3(grid), dim3(256), 0, s, side, imgs, pairs,
+                           table, accmask, acos_lut, fp, cand_cnt, candbuf, err_count, order);
     else
-        hipLaunchKernelGGL(resolve_index_kernel, dim3(npairs), dim3(256), 0, s, side, imgs, pairs,
-                           table, accmask, acos_lut, fp, cand_cnt, candbuf, err_count);
+        hipLaunchKernelGGL(resolve_index_kernel, dim3(grid), dim3(256), 0, s, side, imgs, pairs,
+                           table, accmask, acos_lut, fp, cand_cnt, candbuf, err_count, order);
 }
 uint32_t resolve_grouped_max_rows() { return kResolveMaxTiles * 32; }
 

@@ -275,7 +275,8 @@ def test_many_batches_pipeline(amc_ctx, monkeypatch, kernel, entries):
 @pytest.mark.parametrize("cross_check", [True, False])
 def test_dense_overlap_and_both_resolve_kernels(amc_ctx, monkeypatch, cross_check):
     """Every pair overlapping (a third of the rows accepted, many accepted rows per Y tile): the tile-grouped
-    resolve_index kernel, the per-row one (AMC_RESOLVE_UNGROUPED=1) and the oracle agree; ragged sizes, an image
+    resolve_index kernel on the matrix core (the default), on v_dot4 (AMC_RESOLVE_DOT4=1), the per-row one
+    (AMC_RESOLVE_UNGROUPED=1) and the oracle agree; ragged sizes, an image
     above 4096 rows (two chunks of the grouped kernel's row list), the zero-copy result view."""
     rng = np.random.default_rng(42)
     sizes = [700, 1300, 4096, 5000, 64, 1]
@@ -296,6 +297,12 @@ def test_dense_overlap_and_both_resolve_kernels(amc_ctx, monkeypatch, cross_chec
     np.testing.assert_array_equal(np.asarray(voff), off)
     np.testing.assert_array_equal(np.asarray(vm), m)
     del voff, vm
+    # the tile-grouped form on v_dot4 (round 2; the default above is its matrix-core form), then the per-row form
+    monkeypatch.setenv("AMC_RESOLVE_DOT4", "1")
+    off3, m3, _ = amc_ctx.match_pairs(s1, s2, *opts, kernel="mfma")
+    np.testing.assert_array_equal(off3, off)
+    np.testing.assert_array_equal(m3, m)
+    monkeypatch.delenv("AMC_RESOLVE_DOT4")
     monkeypatch.setenv("AMC_RESOLVE_UNGROUPED", "1")
     off2, m2, _ = amc_ctx.match_pairs(s1, s2, *opts, kernel="mfma")
     np.testing.assert_array_equal(off2, off)
