@@ -82,21 +82,22 @@ def verify_flops(work):
 
 def executed_valu(kernel_s_per_pair):
     """Executed vector instructions of the verification kernels from the committed SQ counter pass
-    (profiles/r03/pmc_tvg_r03.json, tools/pmc_tvg_r03.sh), valid only while the kernels' sources hash to what they were
+    (profiles/rNN/pmc_tvg_rNN.json of the latest round, tools/pmc_tvg_r04.sh), valid only while the kernels' sources hash to what they were
     when the counters were taken: wave instructions x 64 lanes per pair, as a share of the FP64 issue rate."""
     try:
         import hashlib
-        pmc = json.loads((ROOT / "profiles" / "r03" / "pmc_tvg_r03.json").read_text())
+        pmc_path = sorted((ROOT / "profiles").glob("r*/pmc_tvg_r*.json"))[-1]   # the latest round's pass; null unless the sources still match
+        pmc = json.loads(pmc_path.read_text())
         if not all(hashlib.sha256((ROOT / f).read_bytes()).hexdigest() == h for f, h in pmc["kernel_source_sha256"].items()):
             return None
         lane_ops_per_pair = pmc["valu_wave_instructions_per_pair"] * 64.0
-        return {"valu_lane_ops_per_pair": lane_ops_per_pair, "source": "profiles/r03/pmc_tvg_r03.json",
+        return {"valu_lane_ops_per_pair": lane_ops_per_pair, "source": str(pmc_path.relative_to(ROOT)),
                 "valu_lane_ops_per_s": lane_ops_per_pair / kernel_s_per_pair if kernel_s_per_pair > 0 else 0.0,
                 "frac_of_valu_issue_peak": (lane_ops_per_pair / kernel_s_per_pair) / FP64_NO_FMA_CEILING if kernel_s_per_pair > 0 else 0.0,
                 "note": "ALL vector instructions the two kernels executed (FP64, packed FP32, integer, moves), one lane-op per "
                         "lane and instruction, against the 39.3 T lane-op/s the vector ALU issues at FP64 rate; the counters "
                         "were taken on the workload named in the file, the rate uses this run's kernel time"}
-    except (OSError, KeyError, ValueError):
+    except (OSError, KeyError, ValueError, IndexError):
         return None
 
 

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""profiles/r03/pmc_tvg_r03.json from the text summary tools/pmc_tvg_r03.sh writes (per-call averages of the SQ counters
+"""profiles/rNN/pmc_tvg_rNN.json from the text summary tools/pmc_tvg_r03.sh / pmc_tvg_r04.sh write (per-call averages of the SQ counters
 of the two verification kernels + the derived ratios + the sha256 of the kernel sources the counters belong to;
 bench.py's verify.roofline.executed reads it while the sources still hash to the same values).
-    python tools/pmc_tvg_json.py profiles/r03/pmc_tvg_r03_v7.txt"""
+    python tools/pmc_tvg_json.py profiles/r04/pmc_tvg_r04_v1.txt [out.json]"""
 import hashlib
 import json
 import re
@@ -16,7 +16,7 @@ PAIRS = 16384
 
 
 def main(txt):
-    out = {"source": f"{txt} (tools/pmc_tvg_r03.sh: rocprofv3 --kernel-trace --pmc, one counter group per pass; python bench.py "
+    out = {"source": f"{txt} (tools/pmc_tvg_r0N.sh: rocprofv3 --kernel-trace --pmc, one counter group per pass; python bench.py "
                      "--images 40 --steps 1 --warmup 0 --no-cpu-baseline --verify-pairs 16384 --no-pipeline --no-dense)",
            "workload": "16,384 pairs of bench.py's verify leg (4096 distinct seeded calibrated scenes, ~420 matches)",
            "pairs_per_call": PAIRS,
@@ -45,7 +45,8 @@ def main(txt):
         total += c["SQ_INSTS_VALU"]
     out["valu_wave_instructions_per_pair"] = total / PAIRS
     out["kernel_source_sha256"] = {f: hashlib.sha256((ROOT / f).read_bytes()).hexdigest() for f in SOURCES}
-    (ROOT / "profiles" / "r03" / "pmc_tvg_r03.json").write_text(json.dumps(out, indent=1) + "\n")
+    dst = Path(sys.argv[2]) if len(sys.argv) > 2 else ROOT / "profiles" / "r04" / "pmc_tvg_r04.json"
+    dst.write_text(json.dumps(out, indent=1) + "\n")
     print(json.dumps({k: out[k] for k in ("valu_wave_instructions_per_pair",)}, indent=1))
     for k in ("tvg_e_kernel", "tvg_fh_kernel"):
         print(k, {x: round(out[k][x], 3) for x in ("wait_any_over_wave_cycles", "mean_waves_per_simd", "valu_busy_share_of_simd_cycles",
