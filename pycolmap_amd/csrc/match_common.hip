@@ -782,12 +782,9 @@ void launch_select_candidates(const ImageDev* imgs, const PairDev* pairs, uint32
     if (npairs == 0) return;
     const uint32_t per = ((max_cols + 31) / 32 + 255) / 256;
     const size_t shmem = (size_t)std::max(per, 1u) * 256 * sizeof(uint32_t);
-    static bool raised = false;
-    if (shmem > 48 * 1024 && !raised) {  // above the default dynamic-LDS limit: opt in once
+    if (shmem > 48 * 1024)  // above the default dynamic-LDS limit (images beyond 393,216 descriptors): opt in, per device
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(select_candidates_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kSelectMaxCols / 8));
-        raised = true;
-    }
     hipLaunchKernelGGL(select_candidates_kernel, dim3(npairs), dim3(256), shmem, s, imgs, pairs,
                        rowbuf, accmask, acos_lut, fp, cand_cnt, candbuf);
 }
