@@ -6,6 +6,6 @@ cd "$(dirname "$0")/../pycolmap_amd/csrc"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -I../../include"
 for n in "$@"; do
   /opt/rocm/bin/hipcc $FLAGS -DAMC_DIAG=$n -c match_mfma.hip -o _obj/match_mfma_diag$n.o
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o _obj/libamc_diag$n.so _obj/amc_api.o _obj/match_common.o _obj/match_dot4.o _obj/match_guided.o _obj/match_mfma_diag$n.o _obj/tvg_e.o _obj/tvg_fh.o _obj/pose.o _obj/camera.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o _obj/libamc_diag$n.so _obj/amc_api.o _obj/match_common.o _obj/match_dot4.o _obj/match_guided.o _obj/match_mfma_diag$n.o _obj/tvg_e.o _obj/tvg_fh.o _obj/tvg_e_big.o _obj/tvg_fh_big.o _obj/pose.o _obj/camera.o
 done
 ls -la _obj/*.so

@@ -3,6 +3,7 @@ cd $GRAFT_REPO_ROOT
 O=gpurun_out/r04
 mkdir -p $O
 TAG=${1:-v2}
+mkdir -p tools/bin; [ -x tools/bin/ubench_ladder ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -o tools/bin/ubench_ladder tools/ubench_ladder.hip
 bash tools/pmc_r04.sh $TAG > $O/pmc_r04_$TAG.log 2>&1
 timeout 300 tools/bin/ubench_ladder > $O/ladder_$TAG.txt 2>&1
 LADDER_DATA=1 timeout 300 tools/bin/ubench_ladder > $O/ladder_siftlike_$TAG.txt 2>&1
