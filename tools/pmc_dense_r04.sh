@@ -15,7 +15,7 @@ run() {
   done
   echo "rc=$rc tries=$try" >> $OUT
   echo "=== pass $tag: $@" >> $OUT
-  [ -n "$db" ] && python $R/tools/pmc_summary.py $db amc:: | grep -E "resolve_index|match_mfma_kernel<1|finalize_kernel|select_candidates|seg_fill|reorder" | cut -c1-60,150-260 >> $OUT
+  [ -n "$db" ] && python $R/tools/pmc_summary.py $db amc:: | grep -E "resolve_index|match_mfma_kernel<1|finalize_kernel|select_candidates" | sed -E 's/\(amc::[^)]*\)?[^ ]* +/ /' | cut -c1-230 >> $OUT
 }
 run f FETCH_SIZE
 run w TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum
