@@ -665,10 +665,21 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
         uint32_t total = 0;
         bool grouped_resolve = true;
     };
+    // rows of image 1 (padded) from pair i to the end of the call: how much is left when a batch is carved
+    std::vector<uint64_t> rows_left(npairs + 1, 0);
+    for (size_t i = npairs; i-- > 0;) rows_left[i] = rows_left[i + 1] + c->slots[slot1[i]].dev.rows_pad;
+    const bool even_batches = std::getenv("AMC_MATCH_EVEN_BATCHES") != nullptr;  // (A/B hook)
     auto carve = [&](size_t begin, int set) {
         Batch b;
         b.begin = b.end = begin;
         b.set = set;
+        // The copy of a batch's matches to the host runs beside the NEXT batch's kernels; the last batch's copy has
+        // nothing to hide behind.  So a call of several batches ends on a small one: when what is left would be the
+        // last batch and is more than a quarter of a full one, this batch stops a quarter short of the end (on the
+        // dense 500 x 4096 set the exposed copy is 530 MB otherwise).
+        size_t limit = max_entries;
+        if (!even_batches && begin > 0 && rows_left[begin] <= max_entries && rows_left[begin] > max_entries / 4)
+            limit = (size_t)(rows_left[begin] - max_entries / 4);
         while (b.end < npairs) {
             const Slot& x = c->slots[slot1[b.end]];
             const Slot& y = c->slots[slot2[b.end]];
@@ -676,7 +687,7 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
             // cross-checked matches are one-to-one; without the cross check every row of image 1
             // may match (several rows may share a column)
             const size_t mc = o.cross_check ? std::min(x.dev.rows, y.dev.rows) : x.dev.rows;
-            if (b.end > b.begin && (b.top_rows + nr > max_entries || b.top_cols + nc > max_entries ||
+            if (b.end > b.begin && (b.top_rows + nr > limit || b.top_cols + nc > max_entries ||
                                     b.cap + mc > kMaxMatchCap || b.end - b.begin >= (1u << 24)))
                 break;
             b.top_rows += nr; b.top_cols += nc; b.cap += mc; ++b.end;
