@@ -589,6 +589,84 @@ void RunSequential(MatchController& c, const SequentialMatchingOptions& o) {
     }
 }
 
+// ---- spatial matching (COLMAP 3.9.1 feature/matching.cc, SpatialFeatureMatcher::Run) ------------------------------
+// COLMAP: images whose location prior is "unset" (x = y = 0 when ignore_z, x = y = z = 0 otherwise) are left out; the
+// others become rows of a float [n][3] matrix (GPS priors through GPSTransform::EllToXYZ, z forced to 0 under
+// ignore_z BEFORE the transform, i.e. altitude 0), a flann::LinearIndex (exhaustive, flann::L2<float>) answers
+// knn = min(max_num_neighbors, n) neighbours per row, and image i is matched with its neighbours in order of
+// distance until one is farther than max_distance (compared squared, as float); the query itself is skipped.
+// Restated here: the same float arithmetic (L2<float> adds diff * diff left to right for a 3-vector), the same result
+// order (KNNSimpleResultSet: ascending distance, equal distances in insertion = row order).
+// Deviation: an image whose prior columns are NULL reads as NaN in COLMAP, passes the "unset" test and enters the
+// index with NaN coordinates (its neighbours are then whatever NaN comparisons leave); here it is left out.
+std::array<double, 3> EllToXYZ(const std::array<double, 3>& ell) {
+    // GPSTransform's WGS84 constants: a = 6378137, b = 6356752.314245, e^2 = (a^2 - b^2) / a^2
+    const double a = 6378137.0, b = 6356752.314245;
+    const double e2 = (a * a - b * b) / (a * a);
+    const double deg = 0.0174532925199432954743716805978692718781530857086181640625;  // DegToRad's factor
+    const double lat = ell[0] * deg, lon = ell[1] * deg, alt = ell[2];
+    const double sin_lat = std::sin(lat), sin_lon = std::sin(lon), cos_lat = std::cos(lat), cos_lon = std::cos(lon);
+    const double N = a / std::sqrt(1 - e2 * sin_lat * sin_lat);
+    return {{(N + alt) * cos_lat * cos_lon, (N + alt) * cos_lat * sin_lon, (N * (1 - e2) + alt) * sin_lat}};
+}
+std::vector<ImagePairs> SpatialBlocks(const std::vector<image_t>& ids, const std::vector<std::array<double, 3>>& priors,
+                                      const SpatialMatchingOptions& o) {
+    if (ids.size() != priors.size()) throw std::invalid_argument("ids and priors differ in length");
+    if (o.max_num_neighbors <= 0) throw std::invalid_argument("max_num_neighbors must be > 0");
+    if (!(o.max_distance > 0.0)) throw std::invalid_argument("max_distance must be > 0");
+    std::vector<size_t> location_idxs;
+    std::vector<std::array<float, 3>> loc;
+    for (size_t i = 0; i < ids.size(); ++i) {
+        const auto& t = priors[i];
+        if (std::isnan(t[0]) || std::isnan(t[1]) || (!o.ignore_z && std::isnan(t[2]))) continue;  // (deviation above)
+        if ((t[0] == 0 && t[1] == 0 && o.ignore_z) || (t[0] == 0 && t[1] == 0 && t[2] == 0 && !o.ignore_z)) continue;
+        std::array<double, 3> x{{t[0], t[1], o.ignore_z ? 0.0 : t[2]}};
+        if (o.is_gps) x = EllToXYZ(x);
+        location_idxs.push_back(i);
+        loc.push_back({{static_cast<float>(x[0]), static_cast<float>(x[1]), static_cast<float>(x[2])}});
+    }
+    std::vector<ImagePairs> out;
+    const size_t n = loc.size();
+    if (n == 0) return out;
+    const size_t knn = std::min<size_t>(static_cast<size_t>(o.max_num_neighbors), n);
+    const float max_distance = static_cast<float>(o.max_distance * o.max_distance);
+    std::vector<std::pair<float, size_t>> best;  // the result set: ascending, at most knn entries
+    for (size_t i = 0; i < n; ++i) {
+        best.clear();
+        for (size_t j = 0; j < n; ++j) {
+            float d = 0.0f;
+            for (int k = 0; k < 3; ++k) {
+                const float diff = loc[i][k] - loc[j][k];
+                d += diff * diff;
+            }
+            if (best.size() == knn && !(d < best.back().first)) continue;  // addPoint: dist >= worst is dropped
+            if (best.size() < knn) best.emplace_back();
+            size_t at = best.size() - 1;
+            for (; at > 0 && best[at - 1].first > d; --at) best[at] = best[at - 1];
+            best[at] = {d, j};
+        }
+        ImagePairs pairs;
+        for (const auto& [d, j] : best) {
+            if (j == i) continue;
+            if (d > max_distance) break;
+            pairs.emplace_back(ids[location_idxs[i]], ids[location_idxs[j]]);
+        }
+        out.push_back(std::move(pairs));
+    }
+    return out;
+}
+void RunSpatial(MatchController& c, const SpatialMatchingOptions& o) {
+    std::vector<image_t> ids;
+    std::vector<std::array<double, 3>> priors;
+    for (const auto& im : c.Images()) {  // image_id order (COLMAP: the cache's hash-map order, which only decides ties)
+        ids.push_back(im.image_id);
+        priors.push_back(im.prior_t);
+    }
+    // (i, j) and (j, i) both appear when two images are each other's neighbours: Compute() drops the pair it has
+    // seen, as COLMAP's matcher drops the one whose rows exist
+    RunGrouped(c, SpatialBlocks(ids, priors, o));
+}
+
 // ImagePairsFeatureMatcher::Run: "name1 name2" lines, blank lines and '#' comments skipped
 void RunImagePairs(MatchController& c, const std::string& pairs_path, int block_size) {
     std::unordered_map<std::string, image_t> by_name;

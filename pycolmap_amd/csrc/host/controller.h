@@ -3,6 +3,7 @@
 // FeatureMatcherController + workers do, driving libamc.so.
 #pragma once
 
+#include <array>
 #include <atomic>
 #include <functional>
 #include <memory>
@@ -42,6 +43,12 @@ struct SequentialMatchingOptions {
     int loop_detection_num_images_after_verification = 0;
     int loop_detection_max_num_features = -1;
     std::string vocab_tree_path = "";
+};
+struct SpatialMatchingOptions {  // /root/reference/pycolmap/pipeline/match_features.h:154-175; defaults of COLMAP 3.9.1
+    bool is_gps = true;
+    bool ignore_z = true;
+    int max_num_neighbors = 50;
+    double max_distance = 100.0;
 };
 struct RANSACOptions {  // C++ defaults of TwoViewGeometryOptions::ransac_options
     double max_error = 4.0;
@@ -153,7 +160,16 @@ std::vector<ImagePairs> ExhaustiveBlocks(const std::vector<image_t>& ids, int bl
 std::vector<ImagePairs> SequentialBlocks(const std::vector<image_t>& ordered_ids, int overlap,
                                          bool quadratic_overlap);
 
+// SpatialFeatureMatcher::Run's pair generation: one block per image with a location prior, its up to
+// max_num_neighbors nearest images (exact search, squared float distances) closer than max_distance.
+// priors[i] = Image::TvecPrior of ids[i] (NaN = NULL column).
+std::vector<ImagePairs> SpatialBlocks(const std::vector<image_t>& ids, const std::vector<std::array<double, 3>>& priors,
+                                      const SpatialMatchingOptions& o);
+// GPSTransform(WGS84)::EllToXYZ: latitude / longitude in degrees, altitude in metres -> ECEF metres
+std::array<double, 3> EllToXYZ(const std::array<double, 3>& lat_lon_alt);
+
 void RunExhaustive(MatchController& c, const ExhaustiveMatchingOptions& o);
+void RunSpatial(MatchController& c, const SpatialMatchingOptions& o);
 void RunSequential(MatchController& c, const SequentialMatchingOptions& o);
 void RunImagePairs(MatchController& c, const std::string& pairs_path, int block_size = 1225);
 

@@ -235,12 +235,14 @@ std::vector<CameraRow> Database::ReadAllCameras() const {
 std::vector<ImageRow> Database::ReadAllImages() const {
     std::lock_guard<std::recursive_mutex> lock(mu_);
     std::vector<ImageRow> out;
-    Stmt st(db_, Prepared("SELECT image_id, name, camera_id FROM images ORDER BY image_id"));
+    Stmt st(db_, Prepared("SELECT image_id, name, camera_id, prior_tx, prior_ty, prior_tz FROM images ORDER BY image_id"));
     while (st.Step()) {
         ImageRow r;
         r.image_id = static_cast<image_t>(sqlite3_column_int64(st.s, 0));
         r.name = reinterpret_cast<const char*>(sqlite3_column_text(st.s, 1));
         r.camera_id = static_cast<camera_t>(sqlite3_column_int64(st.s, 2));
+        for (int k = 0; k < 3; ++k)
+            if (sqlite3_column_type(st.s, 3 + k) != SQLITE_NULL) r.prior_t[k] = sqlite3_column_double(st.s, 3 + k);
         out.push_back(std::move(r));
     }
     return out;

@@ -5,6 +5,7 @@
 #pragma once
 
 #include <array>
+#include <cmath>
 #include <cstdint>
 #include <stdexcept>
 #include <mutex>
@@ -34,6 +35,9 @@ struct ImageRow {
     image_t image_id = 0;
     std::string name;
     camera_t camera_id = 0;
+    // Image::TvecPrior: prior_tx / ty / tz (latitude, longitude, altitude when the priors are GPS coordinates);
+    // a NULL column reads as NaN, like COLMAP's Database::ReadImage
+    std::array<double, 3> prior_t{{std::nan(""), std::nan(""), std::nan("")}};
 };
 struct TwoViewGeometryRow {
     int config = 0;  // UNDEFINED

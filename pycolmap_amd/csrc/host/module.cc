@@ -2,7 +2,7 @@
 // surface for the match + verify path, implemented over libamc.so (C ABI) + SQLite.
 //
 // Mirrors (names, argument meaning, error behaviour):
-//   match_exhaustive / match_sequential / verify_matches    /root/reference/pycolmap/pipeline/match_features.h:22-68, 219-260
+//   match_exhaustive / match_sequential / match_spatial / verify_matches    /root/reference/pycolmap/pipeline/match_features.h:22-68, 219-260
 //   SiftMatchingOptions / ExhaustiveMatchingOptions / SequentialMatchingOptions      ...:71-152
 //   TwoViewGeometryOptions / TwoViewGeometryConfiguration / TwoViewGeometry
 //                                                           /root/reference/pycolmap/estimators/two_view_geometry.h:41-93
@@ -421,14 +421,9 @@ PYBIND11_MODULE(_pycolmap, m) {
                           "loop_detection_num_images_after_verification", "loop_detection_max_num_features",
                           "vocab_tree_path"});
 
-    // match_spatial / match_vocabtree are outside this library's scope, but their option classes
-    // exist so that a script written for the reference constructs them without error and fails at the call, with
-    // the reason (/root/reference/pycolmap/pipeline/match_features.h:154-214; defaults of COLMAP 3.9.1)
-    struct SpatialMatchingOptions {
-        bool is_gps = true, ignore_z = true;
-        int max_num_neighbors = 50;
-        double max_distance = 100.0;
-    };
+    // match_vocabtree is outside this library's scope, but its option class exists so that a
+    // script written for the reference constructs it without error and fails at the call, with the reason
+    // (/root/reference/pycolmap/pipeline/match_features.h:177-214; defaults of COLMAP 3.9.1)
     struct VocabTreeMatchingOptions {
         int num_images = 100, num_nearest_neighbors = 5, num_checks = 256, num_images_after_verification = 0;
         int max_num_features = -1;
@@ -436,10 +431,15 @@ PYBIND11_MODULE(_pycolmap, m) {
     };
     py::class_<SpatialMatchingOptions> PySp(m, "SpatialMatchingOptions");
     PySp.def(py::init<>())
-        .def_readwrite("is_gps", &SpatialMatchingOptions::is_gps)
-        .def_readwrite("ignore_z", &SpatialMatchingOptions::ignore_z)
-        .def_readwrite("max_num_neighbors", &SpatialMatchingOptions::max_num_neighbors)
-        .def_readwrite("max_distance", &SpatialMatchingOptions::max_distance);
+        .def_readwrite("is_gps", &SpatialMatchingOptions::is_gps,
+                       "Whether the location priors in the database are GPS coordinates in the form of longitude and "
+                       "latitude coordinates in degrees.")
+        .def_readwrite("ignore_z", &SpatialMatchingOptions::ignore_z,
+                       "Whether to ignore the Z-component of the location prior.")
+        .def_readwrite("max_num_neighbors", &SpatialMatchingOptions::max_num_neighbors,
+                       "The maximum number of nearest neighbors to match.")
+        .def_readwrite("max_distance", &SpatialMatchingOptions::max_distance,
+                       "The maximum distance between the query and nearest neighbor [meters].");
     MakeDataclass(PySp, {"is_gps", "ignore_z", "max_num_neighbors", "max_distance"});
     py::class_<VocabTreeMatchingOptions> PyVt(m, "VocabTreeMatchingOptions");
     PyVt.def(py::init<>())
@@ -721,6 +721,15 @@ PYBIND11_MODULE(_pycolmap, m) {
         "matching_options"_a = SequentialMatchingOptions(), "verification_options"_a = TwoViewGeometryOptions(),
         "device"_a = Device::AUTO, "Sequential feature matching");
     m.def(
+        "match_spatial",
+        [run_pipeline](const py::object& database_path, const SiftMatchingOptions& sift,
+                       const SpatialMatchingOptions& mo, const TwoViewGeometryOptions& tvg, Device device) {
+            run_pipeline(database_path, sift, tvg, device, [&](MatchController& c) { RunSpatial(c, mo); });
+        },
+        "database_path"_a, "sift_options"_a = SiftMatchingOptions(),
+        "matching_options"_a = SpatialMatchingOptions(), "verification_options"_a = TwoViewGeometryOptions(),
+        "device"_a = Device::AUTO, "Spatial feature matching");
+    m.def(
         "verify_matches",
         [run_pipeline](const py::object& database_path, const py::object& pairs_path,
                        const TwoViewGeometryOptions& tvg) {
@@ -736,15 +745,17 @@ PYBIND11_MODULE(_pycolmap, m) {
     auto unsupported = [](const char* what) {
         return [what](const py::args&, const py::kwargs&) {
             throw py::value_error(std::string(what) +
-                                  " needs FLANN / spatial indexing and is outside pycolmap_amd's scope "
-                                  "(SURVEY.md section 8f); use match_exhaustive, match_sequential or verify_matches.");
+                                  " needs a FLANN vocabulary-tree file and is outside pycolmap_amd's scope "
+                                  "(SURVEY.md section 8f); use match_exhaustive, match_sequential, match_spatial or verify_matches.");
         };
     };
     m.def("_exhaustive_blocks", &ExhaustiveBlocks, "image_ids"_a, "block_size"_a,
           "Pair blocks of ExhaustiveFeatureMatcher::Run (test hook)");
     m.def("_sequential_blocks", &SequentialBlocks, "ordered_image_ids"_a, "overlap"_a, "quadratic_overlap"_a,
           "Pair blocks of SequentialFeatureMatcher::Run (test hook)");
-    m.def("match_spatial", unsupported("match_spatial"));
+    m.def("_spatial_blocks", &SpatialBlocks, "image_ids"_a, "priors"_a, "options"_a,
+          "Pair blocks of SpatialFeatureMatcher::Run (test hook)");
+    m.def("_ell_to_xyz", &EllToXYZ, "lat_lon_alt"_a, "GPSTransform(WGS84)::EllToXYZ of one point (test hook)");
     m.def("match_vocabtree", unsupported("match_vocabtree"));
     m.attr("_last_stats") = py::dict();
     m.def("last_run_stats", []() { return py::module_::import("pycolmap_amd._pycolmap").attr("_last_stats"); },

@@ -33,7 +33,8 @@ def pair_id(id1: int, id2: int) -> int:
 
 def create(path, images):
     """images: list of dict(name, keypoints [n,c] float32, descriptors [n,128] uint8, model, width, height,
-    params, prior). One camera per image. Returns the image ids (1-based, like COLMAP)."""
+    params, prior, prior_t = (tx, ty, tz) location prior or absent = NULL columns). One camera per image.
+    Returns the image ids (1-based, like COLMAP)."""
     con = sqlite3.connect(path)
     con.executescript(SCHEMA)
     ids = []
@@ -43,7 +44,9 @@ def create(path, images):
                            np.asarray(im.get("params", (1200.0, 1200.0, 800.0, 600.0)), np.float64).tobytes(),
                            int(im.get("prior", False))))
         cam_id = cur.lastrowid
-        cur = con.execute("INSERT INTO images(name, camera_id) VALUES (?, ?)", (im["name"], cam_id))
+        tx, ty, tz = im.get("prior_t", (None, None, None))
+        cur = con.execute("INSERT INTO images(name, camera_id, prior_tx, prior_ty, prior_tz) VALUES (?, ?, ?, ?, ?)",
+                          (im["name"], cam_id, tx, ty, tz))
         iid = cur.lastrowid
         ids.append(iid)
         kp = np.ascontiguousarray(im["keypoints"], np.float32)

@@ -325,14 +325,13 @@ def test_concurrent_database_use_under_sanitizers(tmp_path, sanitizer):
     assert r.returncode == 0 and r.stdout.startswith("ok rows="), (r.returncode, r.stdout[-500:], r.stderr[-3000:])
 
 
-def test_out_of_scope_matchers_keep_their_option_classes():
-    """match_spatial / match_vocabtree are out of scope, but a script written for the reference can still construct
-    their options (reference match_features.h:154-214) and gets the reason at the call."""
+def test_out_of_scope_matcher_keeps_its_option_class():
+    """match_vocabtree is out of scope, but a script written for the reference can still construct its options
+    (reference match_features.h:177-214) and gets the reason at the call; match_spatial's options are live."""
     import pycolmap_amd as pc
     sp = pc.SpatialMatchingOptions(max_num_neighbors=20)
     assert sp.todict() == dict(is_gps=True, ignore_z=True, max_num_neighbors=20, max_distance=100.0)
     vt = pc.VocabTreeMatchingOptions({"num_images": 7})
     assert vt.num_images == 7 and vt.num_checks == 256 and vt.vocab_tree_path == ""
-    for f, o in ((pc.match_spatial, sp), (pc.match_vocabtree, vt)):
-        with pytest.raises(ValueError, match="outside pycolmap_amd's scope"):
-            f("nowhere.db", matching_options=o)
+    with pytest.raises(ValueError, match="outside pycolmap_amd's scope"):
+        pc.match_vocabtree("nowhere.db", matching_options=vt)

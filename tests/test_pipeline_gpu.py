@@ -125,6 +125,36 @@ def test_match_sequential_and_options(tmp_path):
     assert compare(db, exp_m, exp_t) >= 4
 
 
+def test_match_spatial(tmp_path):
+    """match_spatial = SpatialFeatureMatcher::Run's pairs through the same match + verify path: every image is matched
+    with its nearest neighbours by location prior; images without a prior are left alone."""
+    rng = np.random.default_rng(21)
+    images = synth.multiview_scene(rng, num_images=9, n_feats=400)
+    for k, im in enumerate(images[:8]):                                # a line of cameras 10 m apart; the last has no prior
+        im["prior_t"] = (10.0 * k + 1.0, 2.0, 7.0)
+    db = tmp_path / "db.db"
+    ids = colmap_db.create(db, images)
+    mo = pycolmap.SpatialMatchingOptions(is_gps=False, ignore_z=False, max_num_neighbors=4, max_distance=25.0)
+    pycolmap.match_spatial(db, matching_options=mo)
+    pri = [list(im.get("prior_t", (np.nan,) * 3)) for im in images]
+    blocks = pycolmap._pycolmap._spatial_blocks(ids, pri, mo)
+    assert len(blocks) == 8 and all(ids[8] not in p for b in blocks for p in b)
+    exp_m, exp_t = expected_rows(images, ids, blocks)
+    # neighbours within 25 m: +-1 and +-2 along the line (knn = 4 includes the query itself, so at most 3 others)
+    assert {tuple(sorted(p)) for b in blocks for p in b} == {(ids[a], ids[b]) for a in range(8) for b in range(a + 1, 8) if b - a <= 2}
+    assert compare(db, exp_m, exp_t) >= 4
+    st = pycolmap.last_run_stats()
+    assert st["pairs_matched"] == len(exp_m)
+    # GPS priors: same images a few metres apart on the ground
+    db2 = tmp_path / "db2.db"
+    for k, im in enumerate(images):
+        im["prior_t"] = (48.0 + 1e-4 * k, 11.0, 500.0 + k)              # 1e-4 degrees of latitude = 11.1 m
+    ids2 = colmap_db.create(db2, images)
+    pycolmap.match_spatial(db2, matching_options=dict(max_num_neighbors=3, max_distance=15.0))
+    got_m, _ = colmap_db.read_all(db2)
+    assert set(got_m) == {colmap_db.pair_id(ids2[a], ids2[a + 1]) for a in range(8)}
+
+
 def test_verify_matches_reads_stored_matches(tmp_path):
     rng = np.random.default_rng(3)
     images = synth.multiview_scene(rng, num_images=4, n_feats=512)
