@@ -201,7 +201,21 @@ def cpu_baseline(arena_cpu: np.ndarray, s1: np.ndarray, s2: np.ndarray, sample_p
         opt = {"value": ndist / vdt, "unit": "distances/s", "cores": min(threads, len(idx)), "kind": "optimised",
                "sample": f"the same {len(idx)} pairs, oracle/match_vnni.c (AVX-512 VNNI vpdpbusd, -O3, OpenMP, one pair per "
                          f"thread), {vdt:.2f} s", "identical_to_port": bool(np.array_equal(voff, off) and np.array_equal(vm, m))}
-    return ndist / dt, len(idx), dt, (idx, off, m), opt
+    # COLMAP's DEFAULT CPU matcher is not the brute-force one but a FLANN k-d forest (approximate; SURVEY.md section 8 row
+    # M4).  FLANN is not in this image; oracle/match_kdforest.cc restates it (4 trees, 128 checks, 2-NN, one index per
+    # image built inside the timed call).  Rated in the distances the brute-force matcher would have computed.
+    t2 = time.perf_counter()
+    koff, km = oracle_lib.match_pairs(imgs, a, b, threads=threads, variant="kdforest")
+    kdt = time.perf_counter() - t2
+    port = {(k, int(x), int(y)) for k in range(len(idx)) for x, y in m[int(off[k]):int(off[k + 1])]}
+    kdf = {(k, int(x), int(y)) for k in range(len(idx)) for x, y in km[int(koff[k]):int(koff[k + 1])]}
+    default_cpu = {"value": ndist / kdt, "unit": "distances/s (brute-force equivalent)", "pairs_per_s": len(idx) / kdt,
+                   "cores": min(threads, len(idx)), "kind": "port (approximate matcher, restated from the published algorithm)",
+                   "sample": f"the same {len(idx)} pairs, oracle/match_kdforest.cc (FLANN-style k-d forest: 4 trees, 128 checks; "
+                             f"{len(used)} indices built in the call), {kdt:.2f} s",
+                   "port_matches_found": len(port & kdf) / max(1, len(port)),
+                   "matches_that_are_port_matches": len(port & kdf) / max(1, len(kdf))}
+    return ndist / dt, len(idx), dt, (idx, off, m), opt, default_cpu
 
 
 def verify_leg(ctx_factory, device_index: int, npairs: int, steps: int, warmup: int, cpu_sample: int, distinct: int = 4096):
@@ -1024,7 +1038,7 @@ def main():
             cores = host_cores()
             arena_cpu = arena.cpu().numpy()
             sample = args.cpu_sample_pairs if args.cpu_sample_pairs > 0 else 8 * cores
-            v, npairs, dt, (idx, coff, cm), cpu_opt = cpu_baseline(arena_cpu, s1, s2, sample, cores)
+            v, npairs, dt, (idx, coff, cm), cpu_opt, cpu_default = cpu_baseline(arena_cpu, s1, s2, sample, cores)
             cores = min(cores, npairs)  # the oracle runs one pair per thread
             # the sample doubles as a full-size parity spot check of the timed GPU result
             mism = 0
@@ -1038,6 +1052,7 @@ def main():
                 "sample": f"{npairs} seeded pairs of the same {num_images}x{args.feats} workload, "
                           f"oracle/match_oracle.c (-O2, OpenMP, one pair per thread), {dt:.1f} s",
                 "gpu_vs_oracle_mismatching_pairs": mism,
+                "default_cpu_matcher": cpu_default,   # the k-d forest COLMAP's CPU path uses by default (approximate)
                 "optimised": cpu_opt,   # None on a host without AVX-512 VNNI
             }
         if args.verify_pairs > 0 and world == 1:

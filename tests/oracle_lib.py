@@ -33,6 +33,14 @@ def load() -> C.CDLL:
         lib.oracle_match_vnni.argtypes = lib.oracle_match.argtypes
         lib.oracle_match_vnni.restype = C.c_int
         lib.oracle_vnni_available.restype = C.c_int
+        lib.oracle_match_pairs_kdforest.argtypes = lib.oracle_match_pairs.argtypes
+        lib.oracle_match_pairs_kdforest.restype = C.c_int
+        lib.oracle_match_kdforest.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_double, C.c_double,
+                                              C.c_int, C.c_int, C.c_uint64, C.c_void_p]
+        lib.oracle_match_kdforest.restype = C.c_int64
+        lib.oracle_kdforest_knn.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_int, C.c_uint64,
+                                            C.c_void_p, C.c_void_p]
+        lib.oracle_kdforest_knn.restype = C.c_int
         lib.oracle_acos_lut.argtypes = [C.c_void_p]
         lib.oracle_acos_lut.restype = None
         _lib = lib
@@ -88,9 +96,31 @@ def match_vnni(d1: np.ndarray, d2: np.ndarray, max_ratio=0.8, max_distance=0.7, 
     return out[:n].copy()
 
 
+def match_kdforest(d1: np.ndarray, d2: np.ndarray, max_ratio=0.8, max_distance=0.7, cross_check=True, checks=0, seed=0):
+    """COLMAP's default CPU matcher (FLANN k-d forest: approximate), restated in oracle/match_kdforest.cc."""
+    d1 = np.ascontiguousarray(d1, np.uint8)
+    d2 = np.ascontiguousarray(d2, np.uint8)
+    out = np.zeros((max(1, len(d1)), 2), dtype=np.uint32)
+    n = load().oracle_match_kdforest(_p(d1), len(d1), _p(d2), len(d2), max_ratio, max_distance, int(cross_check),
+                                     int(checks), int(seed), _p(out))
+    assert n >= 0
+    return out[:n].copy()
+
+
+def kdforest_knn(index_pts: np.ndarray, queries: np.ndarray, checks=0, seed=0):
+    """(idx [nq,2] int32, squared L2 [nq,2] float32) from the k-d forest alone."""
+    a = np.ascontiguousarray(index_pts, np.uint8)
+    q = np.ascontiguousarray(queries, np.uint8)
+    idx = np.full((len(q), 2), -1, np.int32)
+    dist = np.full((len(q), 2), -1, np.float32)
+    assert load().oracle_kdforest_knn(_p(a), len(a), _p(q), len(q), int(checks), int(seed), _p(idx), _p(dist)) == 0
+    return idx, dist
+
+
 def match_pairs(images, slot1, slot2, max_ratio=0.8, max_distance=0.7, cross_check=True, threads=8, variant="literal"):
     """Batched oracle over a list of uint8 [n_i,128] images. Returns (offsets, matches).
-    variant "literal": oracle/match_oracle.c (the restatement); "vnni": oracle/match_vnni.c (same results, AVX-512 VNNI)."""
+    variant "literal": oracle/match_oracle.c (the restatement); "vnni": oracle/match_vnni.c (same results, AVX-512 VNNI);
+    "kdforest": oracle/match_kdforest.cc (COLMAP's default approximate CPU matcher, restated)."""
     rows = np.array([len(im) for im in images], dtype=np.uint32)
     row_off = np.zeros(len(images), dtype=np.uint64)
     row_off[1:] = np.cumsum(rows[:-1], dtype=np.uint64)
@@ -104,7 +134,8 @@ def match_pairs(images, slot1, slot2, max_ratio=0.8, max_distance=0.7, cross_che
     out_off[1:] = np.cumsum(cap)
     counts = np.zeros(len(s1), dtype=np.uint32)
     out = np.zeros((max(1, int(out_off[-1])), 2), dtype=np.uint32)
-    fn = load().oracle_match_pairs if variant == "literal" else load().oracle_match_pairs_vnni
+    fn = {"literal": load().oracle_match_pairs, "vnni": load().oracle_match_pairs_vnni,
+          "kdforest": load().oracle_match_pairs_kdforest}[variant]
     rc = fn(_p(arena), _p(row_off), _p(rows), _p(s1), _p(s2), len(s1),
             max_ratio, max_distance, int(cross_check), _p(out_off),
             _p(counts), _p(out), threads)
