@@ -856,12 +856,115 @@ __device__ __noinline__ int real_roots10_wave(const double* c_in, double* roots,
 
 // ---- the 5-point solve of ONE problem by the whole wave (local optimisation) -----------------------
 // e5_build keeps the 10 x 20 constraint matrix of a solve in one lane: 200 live doubles, most of them in scratch
-// memory, and with one problem per wave every lane did the same elimination.  Here the rows are still computed by
-// every lane (same expressions, row by row, so that only one row is live), but lane c < 20 keeps just column c,
-// and the Gauss-Jordan elimination runs on those 20 columns in parallel: per pivot the pivot column is broadcast
-// (ten readlanes), every lane searches the pivot and applies the row swap to its own column, and one multiply and
-// nine multiply-subtracts finish the step.  Every element goes through the operations e5_build applies to it, in
-// the same order: the same bits.  E E^T and its trace sit in `sc` (>= 100 doubles of LDS) between the two passes.
+// memory, and with one problem per wave every lane did the same elimination.  Here (round 4) the rows themselves are
+// dealt out: the nine entries of E E^T and then the nine rows of 2 (E E^T) E - tr(E E^T) E are one (i, j) per lane -
+// the same expressions on every lane, the operands read from LDS at an address that depends on the lane -, the
+// determinant row (another expression) is computed by every lane as before, and the rows reach the lanes that keep
+// the columns (lane c < 20 keeps column c) through LDS.  The Gauss-Jordan elimination runs on those 20 columns in
+// parallel: per pivot the pivot column is broadcast (ten readlanes), every lane searches the pivot and applies the
+// row swap to its own column, and one multiply and nine multiply-subtracts finish the step.  Every element goes
+// through the operations e5_build applies to it, in the same order: the same bits.
+// sc: >= 162 doubles of LDS (jacA + jacV).  Layout while the rows are built: [0, 90) E E^T, [100, 136) E's basis.
+#if !defined(AMC_TVG_E5_ROWS_ALL_LANES)
+__device__ __noinline__ void e5_build_wave(const double* nsp, E5Polys& P, lds_f64* sc, int lane) {
+    lds_f64* el = sc + 100;  // el[k * 4 + d] = e[k][d]
+    if (lane < 36) {
+        const int k = lane >> 2, d = lane & 3;
+        el[lane] = nsp[d * 9 + k];
+    }
+    wave_lds_sync();
+    const int l9 = lane < 9 ? lane : 0;  // lanes 9 .. 63 redo entry / row (0, 0) and drop it
+    const int ri = l9 / 3, rj = l9 - 3 * ri;
+    auto lde = [&](int k, double (&v)[4]) {
+#pragma unroll
+        for (int d = 0; d < 4; ++d) v[d] = el[k * 4 + d];
+    };
+    {   // E E^T: entry (ri, rj)
+        double x0[4], x1[4], x2[4], y0[4], y1[4], y2[4], a[10], b[10], c[10];
+        lde(3 * ri, x0); lde(3 * ri + 1, x1); lde(3 * ri + 2, x2);
+        lde(3 * rj, y0); lde(3 * rj + 1, y1); lde(3 * rj + 2, y2);
+        e5_mul11(x0, y0, a);
+        e5_mul11(x1, y1, b);
+        e5_mul11(x2, y2, c);
+        if (lane < 9) {
+#pragma unroll
+            for (int t = 0; t < 10; ++t) sc[l9 * 10 + t] = (a[t] + b[t]) + c[t];
+        }
+    }
+    wave_lds_sync();
+    double g[10];  // this lane's column of G
+    {   // det(E) -> row 0, on every lane (wave-uniform operands)
+        double e[9][4];
+#pragma unroll
+        for (int k = 0; k < 9; ++k)
+#pragma unroll
+            for (int d = 0; d < 4; ++d) e[k][d] = nsp[d * 9 + k];
+        double a[10], b[10], d[10], t0[20], t1[20], t2[20], row[20];
+        e5_mul11(e[4], e[8], a); e5_mul11(e[5], e[7], b);
+#pragma unroll
+        for (int i = 0; i < 10; ++i) d[i] = a[i] - b[i];
+        e5_mul21(d, e[0], t0);
+        e5_mul11(e[3], e[8], a); e5_mul11(e[5], e[6], b);
+#pragma unroll
+        for (int i = 0; i < 10; ++i) d[i] = a[i] - b[i];
+        e5_mul21(d, e[1], t1);
+        e5_mul11(e[3], e[7], a); e5_mul11(e[4], e[6], b);
+#pragma unroll
+        for (int i = 0; i < 10; ++i) d[i] = a[i] - b[i];
+        e5_mul21(d, e[2], t2);
+#pragma unroll
+        for (int i = 0; i < 20; ++i) row[i] = (t0[i] - t1[i]) + t2[i];
+        double x = row[19];
+#pragma unroll
+        for (int c = 18; c >= 0; --c) x = lane == c ? row[c] : x;
+        g[0] = x;
+    }
+    double row[20];
+    {   // row 1 + 3 ri + rj
+        double q[10], ev[4], acc[20], tmp[20], tr[10];
+#pragma unroll
+        for (int t = 0; t < 10; ++t) tr[t] = (sc[t] + sc[40 + t]) + sc[80 + t];
+#pragma unroll
+        for (int t = 0; t < 10; ++t) q[t] = sc[(3 * ri) * 10 + t];
+        lde(rj, ev);
+        e5_mul21(q, ev, acc);
+#pragma unroll
+        for (int t = 0; t < 10; ++t) q[t] = sc[(3 * ri + 1) * 10 + t];
+        lde(3 + rj, ev);
+        e5_mul21(q, ev, tmp);
+#pragma unroll
+        for (int t = 0; t < 20; ++t) acc[t] = acc[t] + tmp[t];
+#pragma unroll
+        for (int t = 0; t < 10; ++t) q[t] = sc[(3 * ri + 2) * 10 + t];
+        lde(6 + rj, ev);
+        e5_mul21(q, ev, tmp);
+#pragma unroll
+        for (int t = 0; t < 20; ++t) acc[t] = acc[t] + tmp[t];
+        lde(3 * ri + rj, ev);
+        e5_mul21(tr, ev, tmp);
+#pragma unroll
+        for (int t = 0; t < 20; ++t) row[t] = acc[t] * 2.0 - tmp[t];
+    }
+    wave_lds_sync();  // every read of E E^T and of the basis is done: sc carries the rows to the column lanes
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        if (lane < 9) {
+#pragma unroll
+            for (int c = 0; c < 10; ++c) sc[lane * 10 + c] = row[10 * half + c];
+        }
+        wave_lds_sync();
+        const int c = lane - 10 * half;
+        if (c >= 0 && c < 10) {
+#pragma unroll
+            for (int r = 0; r < 9; ++r) g[1 + r] = sc[r * 10 + c];
+        }
+        wave_lds_sync();
+    }
+    if (lane >= 20) {  // no column: defined values, never read
+#pragma unroll
+        for (int r = 1; r < 10; ++r) g[r] = 0.0;
+    }
+#else
 __device__ __noinline__ void e5_build_wave(const double* nsp, E5Polys& P, lds_f64* sc, int lane) {
     double e[9][4];
 #pragma unroll
@@ -937,6 +1040,7 @@ __device__ __noinline__ void e5_build_wave(const double* nsp, E5Polys& P, lds_f6
             for (int t = 0; t < 20; ++t) row[t] = acc[t] * 2.0 - tmp[t];
             keep(g[1 + 3 * i + j], row);
         }
+#endif
     // Gauss-Jordan with partial pivoting on the left 10 x 10 block, one column per lane
 #pragma unroll
     for (int col = 0; col < 10; ++col) {
