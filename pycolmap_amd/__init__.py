@@ -15,7 +15,7 @@ __version__ = "0.1.0"
 
 try:  # the compiled host layer; absent only before `python -m pycolmap_amd.build`
     from ._pycolmap import (  # noqa: F401
-        COLMAP_build, COLMAP_version, Camera, CameraModelId, Database, Device, ExhaustiveMatchingOptions, RANSACOptions, Rigid3d,
+        COLMAP_build, COLMAP_version, Camera, CameraModelId, Database, DatabaseTransaction, Device, ExhaustiveMatchingOptions, Image, RANSACOptions, Rigid3d,
         Rotation3d,
         SequentialMatchingOptions, SiftMatchingOptions, SpatialMatchingOptions, TwoViewGeometry, TwoViewGeometryConfiguration,
         VocabTreeMatchingOptions,

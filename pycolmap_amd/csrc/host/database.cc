@@ -73,7 +73,10 @@ void TwoViewGeometryRow::Invert() {
     }
 }
 
-Database::Database(const std::string& path) {
+Database::Database(const std::string& path) { Open(path); }
+void Database::Open(const std::string& path) {
+    std::lock_guard<std::recursive_mutex> lock(mu_);
+    Close();
     // Database::Open: the file and COLMAP's tables are created when missing
     if (sqlite3_open_v2(path.c_str(), &db_, SQLITE_OPEN_READWRITE | SQLITE_OPEN_CREATE, nullptr) != SQLITE_OK) {
         const std::string msg = db_ ? sqlite3_errmsg(db_) : "out of memory";
@@ -85,6 +88,20 @@ Database::Database(const std::string& path) {
     Exec("PRAGMA journal_mode=WAL");
     Exec("PRAGMA foreign_keys=ON");
     CreateTables();
+}
+void Database::Close() {
+    std::lock_guard<std::recursive_mutex> lock(mu_);
+    if (db_ && bulk_mode_) {
+        try {
+            SetBulkWriteMode(false);
+        } catch (...) {
+        }
+    }
+    for (auto& kv : stmts_) sqlite3_finalize(kv.second);
+    stmts_.clear();
+    if (db_) sqlite3_close(db_);
+    db_ = nullptr;
+    bulk_mode_ = false;
 }
 // Database::CreateTables (colmap/scene/database.cc): CREATE TABLE IF NOT EXISTS for every table of the schema
 void Database::CreateTables() const {
@@ -106,18 +123,10 @@ void Database::CreateTables() const {
     Exec("CREATE TABLE IF NOT EXISTS two_view_geometries (pair_id INTEGER PRIMARY KEY NOT NULL, rows INTEGER NOT NULL, "
          "cols INTEGER NOT NULL, data BLOB, config INTEGER NOT NULL, F BLOB, E BLOB, H BLOB, qvec BLOB, tvec BLOB);");
 }
-Database::~Database() {
-    if (db_ && bulk_mode_) {
-        try {
-            SetBulkWriteMode(false);
-        } catch (...) {
-        }
-    }
-    for (auto& kv : stmts_) sqlite3_finalize(kv.second);
-    if (db_) sqlite3_close(db_);
-}
+Database::~Database() { Close(); }
 std::string Database::SetBulkWriteMode(bool on) {
     std::lock_guard<std::recursive_mutex> lock(mu_);
+    if (!db_) throw std::runtime_error("the database is closed");
     // cached statements hold the schema; a journal-mode switch needs no statement in progress (all are reset)
     sqlite3_stmt* st = nullptr;
     const char* sql = on ? "PRAGMA journal_mode=TRUNCATE" : "PRAGMA journal_mode=WAL";
@@ -158,6 +167,7 @@ std::string Database::SetBulkWriteMode(bool on) {
 }
 sqlite3_stmt* Database::Prepared(const std::string& sql) const {
     std::lock_guard<std::recursive_mutex> lock(mu_);
+    if (!db_) throw std::runtime_error("the database is closed");
     auto it = stmts_.find(sql);
     if (it != stmts_.end()) return it->second;
     sqlite3_stmt* st = nullptr;
@@ -167,6 +177,7 @@ sqlite3_stmt* Database::Prepared(const std::string& sql) const {
 }
 void Database::Exec(const char* sql) const {
     std::lock_guard<std::recursive_mutex> lock(mu_);
+    if (!db_) throw std::runtime_error("the database is closed");
     char* err = nullptr;
     if (sqlite3_exec(db_, sql, nullptr, nullptr, &err) != SQLITE_OK) {
         const std::string msg = err ? err : "?";
@@ -214,38 +225,122 @@ size_t Database::SumRows(const char* table) const {
     return static_cast<size_t>(sqlite3_column_int64(st.s, 0));
 }
 
+namespace {
+constexpr const char* kCameraCols = "camera_id, model, width, height, params, prior_focal_length";
+constexpr const char* kImageCols = "image_id, name, camera_id, prior_qw, prior_qx, prior_qy, prior_qz, prior_tx, prior_ty, prior_tz";
+CameraRow CameraFromRow(sqlite3_stmt* st) {
+    CameraRow c;
+    c.camera_id = static_cast<camera_t>(sqlite3_column_int64(st, 0));
+    c.model_id = sqlite3_column_int(st, 1);
+    c.width = static_cast<uint64_t>(sqlite3_column_int64(st, 2));
+    c.height = static_cast<uint64_t>(sqlite3_column_int64(st, 3));
+    const int nbytes = sqlite3_column_bytes(st, 4);
+    c.params.resize(nbytes / sizeof(double));
+    if (nbytes) std::memcpy(c.params.data(), sqlite3_column_blob(st, 4), c.params.size() * sizeof(double));
+    c.has_prior_focal_length = sqlite3_column_int(st, 5) != 0;
+    return c;
+}
+ImageRow ImageFromRow(sqlite3_stmt* st) {  // Database::ReadImageRow: NULL prior columns read as NaN
+    ImageRow r;
+    r.image_id = static_cast<image_t>(sqlite3_column_int64(st, 0));
+    r.name = reinterpret_cast<const char*>(sqlite3_column_text(st, 1));
+    r.camera_id = static_cast<camera_t>(sqlite3_column_int64(st, 2));
+    for (int k = 0; k < 4; ++k)
+        if (sqlite3_column_type(st, 3 + k) != SQLITE_NULL) r.prior_q[k] = sqlite3_column_double(st, 3 + k);
+    for (int k = 0; k < 3; ++k)
+        if (sqlite3_column_type(st, 7 + k) != SQLITE_NULL) r.prior_t[k] = sqlite3_column_double(st, 7 + k);
+    return r;
+}
+}  // namespace
+
 std::vector<CameraRow> Database::ReadAllCameras() const {
     std::lock_guard<std::recursive_mutex> lock(mu_);
     std::vector<CameraRow> out;
-    Stmt st(db_, Prepared("SELECT camera_id, model, width, height, params, prior_focal_length FROM cameras ORDER BY camera_id"));
-    while (st.Step()) {
-        CameraRow c;
-        c.camera_id = static_cast<camera_t>(sqlite3_column_int64(st.s, 0));
-        c.model_id = sqlite3_column_int(st.s, 1);
-        c.width = static_cast<uint64_t>(sqlite3_column_int64(st.s, 2));
-        c.height = static_cast<uint64_t>(sqlite3_column_int64(st.s, 3));
-        const int nbytes = sqlite3_column_bytes(st.s, 4);
-        c.params.resize(nbytes / sizeof(double));
-        if (nbytes) std::memcpy(c.params.data(), sqlite3_column_blob(st.s, 4), c.params.size() * sizeof(double));
-        c.has_prior_focal_length = sqlite3_column_int(st.s, 5) != 0;
-        out.push_back(std::move(c));
-    }
+    Stmt st(db_, Prepared(std::string("SELECT ") + kCameraCols + " FROM cameras ORDER BY camera_id"));
+    while (st.Step()) out.push_back(CameraFromRow(st.s));
     return out;
 }
 std::vector<ImageRow> Database::ReadAllImages() const {
     std::lock_guard<std::recursive_mutex> lock(mu_);
     std::vector<ImageRow> out;
-    Stmt st(db_, Prepared("SELECT image_id, name, camera_id, prior_tx, prior_ty, prior_tz FROM images ORDER BY image_id"));
-    while (st.Step()) {
-        ImageRow r;
-        r.image_id = static_cast<image_t>(sqlite3_column_int64(st.s, 0));
-        r.name = reinterpret_cast<const char*>(sqlite3_column_text(st.s, 1));
-        r.camera_id = static_cast<camera_t>(sqlite3_column_int64(st.s, 2));
-        for (int k = 0; k < 3; ++k)
-            if (sqlite3_column_type(st.s, 3 + k) != SQLITE_NULL) r.prior_t[k] = sqlite3_column_double(st.s, 3 + k);
-        out.push_back(std::move(r));
-    }
+    Stmt st(db_, Prepared(std::string("SELECT ") + kImageCols + " FROM images ORDER BY image_id"));
+    while (st.Step()) out.push_back(ImageFromRow(st.s));
     return out;
+}
+bool Database::ExistsCamera(camera_t camera_id) const {
+    std::lock_guard<std::recursive_mutex> lock(mu_);
+    Stmt st(db_, Prepared("SELECT 1 FROM cameras WHERE camera_id = ?"));
+    sqlite3_bind_int64(st.s, 1, camera_id);
+    return st.Step();
+}
+bool Database::ExistsImage(image_t image_id) const {
+    std::lock_guard<std::recursive_mutex> lock(mu_);
+    Stmt st(db_, Prepared("SELECT 1 FROM images WHERE image_id = ?"));
+    sqlite3_bind_int64(st.s, 1, image_id);
+    return st.Step();
+}
+bool Database::ExistsImageWithName(const std::string& name) const {
+    std::lock_guard<std::recursive_mutex> lock(mu_);
+    Stmt st(db_, Prepared("SELECT 1 FROM images WHERE name = ?"));
+    sqlite3_bind_text(st.s, 1, name.c_str(), static_cast<int>(name.size()), SQLITE_STATIC);
+    return st.Step();
+}
+CameraRow Database::ReadCamera(camera_t camera_id) const {
+    std::lock_guard<std::recursive_mutex> lock(mu_);
+    Stmt st(db_, Prepared(std::string("SELECT ") + kCameraCols + " FROM cameras WHERE camera_id = ?"));
+    sqlite3_bind_int64(st.s, 1, camera_id);
+    if (!st.Step()) throw std::invalid_argument("camera " + std::to_string(camera_id) + " does not exist");
+    return CameraFromRow(st.s);
+}
+ImageRow Database::ReadImage(image_t image_id) const {
+    std::lock_guard<std::recursive_mutex> lock(mu_);
+    Stmt st(db_, Prepared(std::string("SELECT ") + kImageCols + " FROM images WHERE image_id = ?"));
+    sqlite3_bind_int64(st.s, 1, image_id);
+    if (!st.Step()) throw std::invalid_argument("image " + std::to_string(image_id) + " does not exist");
+    return ImageFromRow(st.s);
+}
+ImageRow Database::ReadImageWithName(const std::string& name) const {
+    std::lock_guard<std::recursive_mutex> lock(mu_);
+    Stmt st(db_, Prepared(std::string("SELECT ") + kImageCols + " FROM images WHERE name = ?"));
+    sqlite3_bind_text(st.s, 1, name.c_str(), static_cast<int>(name.size()), SQLITE_STATIC);
+    if (!st.Step()) throw std::invalid_argument("image \"" + name + "\" does not exist");
+    return ImageFromRow(st.s);
+}
+// Database::WriteCamera: camera_id NULL (SQLite assigns it) unless use_camera_id, which must not exist yet
+camera_t Database::WriteCamera(const CameraRow& c, bool use_camera_id) {
+    std::lock_guard<std::recursive_mutex> lock(mu_);
+    if (use_camera_id && ExistsCamera(c.camera_id))
+        throw std::invalid_argument("camera " + std::to_string(c.camera_id) + " exists already");
+    Stmt st(db_, Prepared("INSERT INTO cameras(camera_id, model, width, height, params, prior_focal_length) VALUES(?, ?, ?, ?, ?, ?)"));
+    if (use_camera_id) sqlite3_bind_int64(st.s, 1, c.camera_id); else sqlite3_bind_null(st.s, 1);
+    sqlite3_bind_int64(st.s, 2, c.model_id);
+    sqlite3_bind_int64(st.s, 3, static_cast<sqlite3_int64>(c.width));
+    sqlite3_bind_int64(st.s, 4, static_cast<sqlite3_int64>(c.height));
+    sqlite3_bind_blob(st.s, 5, c.params.data(), static_cast<int>(c.params.size() * sizeof(double)), SQLITE_STATIC);
+    sqlite3_bind_int64(st.s, 6, c.has_prior_focal_length ? 1 : 0);
+    st.Step();
+    return static_cast<camera_t>(sqlite3_last_insert_rowid(db_));
+}
+// Database::WriteImage: likewise; NaN priors become NULL columns (sqlite3_bind_double stores NaN as NULL)
+image_t Database::WriteImage(const ImageRow& im, bool use_image_id) {
+    std::lock_guard<std::recursive_mutex> lock(mu_);
+    if (use_image_id && ExistsImage(im.image_id))
+        throw std::invalid_argument("image " + std::to_string(im.image_id) + " exists already");
+    Stmt st(db_, Prepared("INSERT INTO images(image_id, name, camera_id, prior_qw, prior_qx, prior_qy, prior_qz, prior_tx, prior_ty, "
+                          "prior_tz) VALUES(?, ?, ?, ?, ?, ?, ?, ?, ?, ?)"));
+    if (use_image_id) sqlite3_bind_int64(st.s, 1, im.image_id); else sqlite3_bind_null(st.s, 1);
+    sqlite3_bind_text(st.s, 2, im.name.c_str(), static_cast<int>(im.name.size()), SQLITE_STATIC);
+    sqlite3_bind_int64(st.s, 3, im.camera_id);
+    for (int k = 0; k < 4; ++k) sqlite3_bind_double(st.s, 4 + k, im.prior_q[k]);
+    for (int k = 0; k < 3; ++k) sqlite3_bind_double(st.s, 8 + k, im.prior_t[k]);
+    st.Step();
+    return static_cast<image_t>(sqlite3_last_insert_rowid(db_));
+}
+size_t Database::RowsOf(const char* table, image_t image_id) const {
+    std::lock_guard<std::recursive_mutex> lock(mu_);
+    Stmt st(db_, Prepared(std::string("SELECT rows FROM ") + table + " WHERE image_id = ?"));
+    sqlite3_bind_int64(st.s, 1, image_id);
+    return st.Step() ? static_cast<size_t>(sqlite3_column_int64(st.s, 0)) : 0;
 }
 std::vector<float> Database::ReadKeypointsXY(image_t image_id, uint32_t* rows) const {
     std::lock_guard<std::recursive_mutex> lock(mu_);

@@ -38,6 +38,7 @@ struct ImageRow {
     // Image::TvecPrior: prior_tx / ty / tz (latitude, longitude, altitude when the priors are GPS coordinates);
     // a NULL column reads as NaN, like COLMAP's Database::ReadImage
     std::array<double, 3> prior_t{{std::nan(""), std::nan(""), std::nan("")}};
+    std::array<double, 4> prior_q{{std::nan(""), std::nan(""), std::nan(""), std::nan("")}};  // prior_qw, qx, qy, qz
 };
 struct TwoViewGeometryRow {
     int config = 0;  // UNDEFINED
@@ -71,6 +72,23 @@ class Database {
 
     std::vector<CameraRow> ReadAllCameras() const;
     std::vector<ImageRow> ReadAllImages() const;  // ordered by image_id
+    // Database::ExistsCamera / ExistsImage / ExistsImageWithName, ReadCamera / ReadImage / ReadImageWithName (a missing
+    // row throws std::invalid_argument), WriteCamera / WriteImage (the id is SQLite's unless use_*_id; returns it),
+    // NumKeypointsForImage / NumDescriptorsForImage (0 without a row)
+    bool ExistsCamera(camera_t camera_id) const;
+    bool ExistsImage(image_t image_id) const;
+    bool ExistsImageWithName(const std::string& name) const;
+    CameraRow ReadCamera(camera_t camera_id) const;
+    ImageRow ReadImage(image_t image_id) const;
+    ImageRow ReadImageWithName(const std::string& name) const;
+    camera_t WriteCamera(const CameraRow& camera, bool use_camera_id = false);
+    image_t WriteImage(const ImageRow& image, bool use_image_id = false);
+    size_t NumKeypointsForImage(image_t image_id) const { return RowsOf("keypoints", image_id); }
+    size_t NumDescriptorsForImage(image_t image_id) const { return RowsOf("descriptors", image_id); }
+    // Database::Open / Close: Close() finishes the prepared statements and the connection (idempotent); Open() closes
+    // what is open and opens `path`, creating COLMAP's tables when they are missing
+    void Open(const std::string& path);
+    void Close();
     // keypoints blob: rows x cols float32; returns x,y only (rows x 2)
     std::vector<float> ReadKeypointsXY(image_t image_id, uint32_t* rows) const;
     std::vector<uint8_t> ReadDescriptors(image_t image_id, uint32_t* rows) const;
@@ -112,6 +130,7 @@ class Database {
     void CreateTables() const;
     size_t Count(const char* table) const;
     size_t SumRows(const char* table) const;
+    size_t RowsOf(const char* table, image_t image_id) const;
     bool ExistsPair(const char* table, image_pair_t pair_id) const;
     void Exec(const char* sql) const;
     sqlite3_stmt* Prepared(const std::string& sql) const;  // prepared once per connection, then reused

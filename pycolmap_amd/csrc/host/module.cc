@@ -579,6 +579,103 @@ PYBIND11_MODULE(_pycolmap, m) {
         .def("__copy__", [](const PyTwoViewGeometry& s) { return PyTwoViewGeometry(s); })
         .def("__deepcopy__", [](const PyTwoViewGeometry& s, const py::dict&) { return PyTwoViewGeometry(s); });
 
+    // ---- Camera (estimators.h), Image ---------------------------------------------------------
+    BindCamera(m);
+    // Image: the database-facing part of /root/reference/pycolmap/scene/image.h:74-130 (identifiers, name, pose and pose
+    // prior, the keypoints it was constructed with); the reconstruction bookkeeping (points3D, observations) belongs
+    // to COLMAP's mapper and is not part of this library
+    struct PyImage {
+        uint32_t image_id = 0xFFFFFFFFu, camera_id = 0xFFFFFFFFu;  // kInvalidImageId / kInvalidCameraId
+        std::string name;
+        PyRigid3d cam_from_world, cam_from_world_prior;
+        std::vector<std::array<double, 2>> keypoints;
+        PyImage() {
+            const double nan = std::nan("");  // Image(): the prior is "unknown"
+            cam_from_world_prior.rotation.xyzw = {{nan, nan, nan, nan}};
+            cam_from_world_prior.translation = {{nan, nan, nan}};
+        }
+    };
+    auto image_from_row = [](const ImageRow& r) {
+        PyImage im;
+        im.image_id = r.image_id;
+        im.camera_id = r.camera_id;
+        im.name = r.name;
+        im.cam_from_world_prior.rotation.xyzw = {{r.prior_q[1], r.prior_q[2], r.prior_q[3], r.prior_q[0]}};
+        im.cam_from_world_prior.translation = r.prior_t;
+        return im;
+    };
+    auto row_from_image = [](const PyImage& im) {
+        ImageRow r;
+        r.image_id = im.image_id;
+        r.camera_id = im.camera_id;
+        r.name = im.name;
+        const auto& q = im.cam_from_world_prior.rotation.xyzw;
+        r.prior_q = {{q[3], q[0], q[1], q[2]}};
+        r.prior_t = im.cam_from_world_prior.translation;
+        return r;
+    };
+    auto camera_from_row = [](const CameraRow& r) {
+        PyCamera c;
+        c.camera_id = r.camera_id;
+        c.model = r.model_id;
+        c.width = r.width;
+        c.height = r.height;
+        c.params = r.params;
+        c.has_prior_focal_length = r.has_prior_focal_length;
+        return c;
+    };
+    auto row_from_camera = [](const PyCamera& c) {
+        c.CheckParams();
+        CameraRow r;
+        r.camera_id = c.camera_id;
+        r.model_id = c.model;
+        r.width = c.width;
+        r.height = c.height;
+        r.params = c.params;
+        r.has_prior_focal_length = c.has_prior_focal_length;
+        return r;
+    };
+    py::class_<PyImage>(m, "Image")
+        .def(py::init<>())
+        .def(py::init([](const std::string& name, const std::vector<std::array<double, 2>>& keypoints,
+                         const PyRigid3d& cam_from_world, uint32_t camera_id, uint32_t id) {
+                 PyImage im;
+                 im.name = name;
+                 im.keypoints = keypoints;
+                 im.cam_from_world = cam_from_world;
+                 im.camera_id = camera_id;
+                 im.image_id = id;
+                 return im;
+             }),
+             "name"_a = "", "keypoints"_a = std::vector<std::array<double, 2>>(), "cam_from_world"_a = PyRigid3d(),
+             "camera_id"_a = 0xFFFFFFFFu, "id"_a = 0xFFFFFFFFu)
+        .def_readwrite("image_id", &PyImage::image_id, "Unique identifier of image.")
+        .def_property(
+            "camera_id", [](const PyImage& im) { return im.camera_id; },
+            [](PyImage& im, uint32_t id) {
+                if (id == 0xFFFFFFFFu) throw py::value_error(CheckMessage(__FILE__, __LINE__, "camera_id != kInvalidCameraId"));
+                im.camera_id = id;
+            },
+            "Unique identifier of the camera.")
+        .def_readwrite("name", &PyImage::name, "Name of the image.")
+        .def_readwrite("cam_from_world", &PyImage::cam_from_world,
+                       "The pose of the image, defined as the transformation from world to camera space.")
+        .def_readwrite("cam_from_world_prior", &PyImage::cam_from_world_prior,
+                       "The pose prior of the image, e.g. extracted from EXIF tags.")
+        .def("has_camera", [](const PyImage& im) { return im.camera_id != 0xFFFFFFFFu; },
+             "Check whether identifier of camera has been set.")
+        .def("num_points2D", [](const PyImage& im) { return im.keypoints.size(); },
+             "Get the number of image points (keypoints).")
+        .def("__copy__", [](const PyImage& im) { return PyImage(im); })
+        .def("__deepcopy__", [](const PyImage& im, const py::dict&) { return PyImage(im); })
+        .def("__repr__", [](const PyImage& im) {
+            std::ostringstream ss;
+            ss << "Image(image_id=" << (im.image_id != 0xFFFFFFFFu ? std::to_string(im.image_id) : "Invalid")
+               << ", camera_id=" << (im.camera_id != 0xFFFFFFFFu ? std::to_string(im.camera_id) : "Invalid") << ", name=\""
+               << im.name << "\", triangulated=0/" << im.keypoints.size() << ")";
+            return ss.str();
+        });
+
     // ---- Database ---------------------------------------------------------------------------
     py::class_<Database>(m, "Database")
         .def(py::init([](const py::object& path) {
@@ -586,6 +683,41 @@ PYBIND11_MODULE(_pycolmap, m) {
                  return std::make_unique<Database>(PathToString(path));
              }),
              "path"_a)
+        .def("open", [](Database& db, const py::object& path) { db.Open(PathToString(path)); }, "path"_a)
+        .def("close", &Database::Close)
+        .def("num_keypoints_for_image", &Database::NumKeypointsForImage, "image_id"_a)
+        .def("num_descriptors_for_image", &Database::NumDescriptorsForImage, "image_id"_a)
+        .def("exists_camera", &Database::ExistsCamera, "camera_id"_a)
+        .def("exists_image", &Database::ExistsImage, "image_id"_a)
+        .def("read_camera", [camera_from_row](const Database& db, camera_t id) { return camera_from_row(db.ReadCamera(id)); },
+             "camera_id"_a)
+        .def("read_all_cameras",
+             [camera_from_row](const Database& db) {
+                 std::vector<PyCamera> out;
+                 for (const CameraRow& r : db.ReadAllCameras()) out.push_back(camera_from_row(r));
+                 return out;
+             })
+        .def("read_image", [image_from_row](const Database& db, image_t id) { return image_from_row(db.ReadImage(id)); },
+             "image_id"_a)
+        .def("read_image_with_name",
+             [image_from_row](const Database& db, const std::string& name) { return image_from_row(db.ReadImageWithName(name)); },
+             "name"_a)
+        .def("read_all_images",
+             [image_from_row](const Database& db) {
+                 std::vector<PyImage> out;
+                 for (const ImageRow& r : db.ReadAllImages()) out.push_back(image_from_row(r));
+                 return out;
+             })
+        .def("write_camera",
+             [row_from_camera](Database& db, const PyCamera& c, bool use_camera_id) {
+                 return db.WriteCamera(row_from_camera(c), use_camera_id);
+             },
+             "camera"_a, "use_camera_id"_a = false, "Returns the camera_id of the new row.")
+        .def("write_image",
+             [row_from_image](Database& db, const PyImage& im, bool use_image_id) {
+                 return db.WriteImage(row_from_image(im), use_image_id);
+             },
+             "image"_a, "use_image_id"_a = false, "Returns the image_id of the new row.")
         .def_property_readonly("num_cameras", &Database::NumCameras)
         .def_property_readonly("num_images", &Database::NumImages)
         .def_property_readonly("num_keypoints", &Database::NumKeypoints)
@@ -671,8 +803,35 @@ PYBIND11_MODULE(_pycolmap, m) {
              },
              "image_id1"_a, "image_id2"_a);
 
-    // ---- Camera + single-pair estimators (estimators.h) ------------------------------------------
-    BindCamera(m);
+    // DatabaseTransaction (/root/reference/pycolmap/scene/database.h:44-45): BEGIN on construction, END when the
+    // object goes away - COLMAP's scope guard as Python sees it; also usable as a context manager, where an exception
+    // rolls back (an extension)
+    struct PyDbTransaction {
+        Database* db;
+        bool open = true;
+        explicit PyDbTransaction(Database* d) : db(d) { db->BeginTransaction(); }
+        PyDbTransaction(const PyDbTransaction&) = delete;
+        void End(bool commit) {
+            if (!open) return;
+            open = false;
+            if (commit) db->EndTransaction(); else db->RollbackTransaction();
+        }
+        ~PyDbTransaction() {
+            try {
+                End(true);
+            } catch (...) {
+            }
+        }
+    };
+    py::class_<PyDbTransaction>(m, "DatabaseTransaction")
+        .def(py::init<Database*>(), "database"_a, py::keep_alive<1, 2>())
+        .def("__enter__", [](PyDbTransaction& t) -> PyDbTransaction& { return t; }, py::return_value_policy::reference)
+        .def("__exit__", [](PyDbTransaction& t, const py::object& type, const py::object&, const py::object&) {
+            t.End(type.is_none());
+            return false;
+        });
+
+    // ---- single-pair estimators (estimators.h) ----------------------------------------------------
     BindEstimators(m);
 
     // ---- pipeline entry points ----------------------------------------------------------------

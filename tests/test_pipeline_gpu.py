@@ -155,6 +155,27 @@ def test_match_spatial(tmp_path):
     assert set(got_m) == {colmap_db.pair_id(ids2[a], ids2[a + 1]) for a in range(8)}
 
 
+def test_database_built_through_the_api(tmp_path):
+    """A database populated with Database.write_camera / write_image / write_keypoints / write_descriptors (no sqlite3 on
+    the caller's side) gives the rows a COLMAP-written file gives."""
+    rng = np.random.default_rng(22)
+    images = synth.multiview_scene(rng, num_images=4, n_feats=400)
+    db = tmp_path / "api.db"
+    d = pycolmap.Database(db)
+    ids = []
+    with pycolmap.DatabaseTransaction(d):
+        for im in images:
+            cid = d.write_camera(pycolmap.Camera(model=im.get("model", 1), width=im["width"], height=im["height"], params=list(im["params"])))
+            iid = d.write_image(pycolmap.Image(name=im["name"], camera_id=cid))
+            d.write_keypoints(iid, im["keypoints"])
+            d.write_descriptors(iid, im["descriptors"])
+            ids.append(iid)
+    d.close()
+    pycolmap.match_exhaustive(db)
+    exp_m, exp_t = expected_rows(images, ids, pycolmap._pycolmap._exhaustive_blocks(ids, 50))
+    assert compare(db, exp_m, exp_t) >= 2
+
+
 def test_verify_matches_reads_stored_matches(tmp_path):
     rng = np.random.default_rng(3)
     images = synth.multiview_scene(rng, num_images=4, n_feats=512)
