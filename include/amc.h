@@ -379,6 +379,15 @@ void amc_ransac_result_free(amc_ransac_result* r);
 int amc_squared_sampson_error(amc_ctx* ctx, const double* points1, const double* points2, size_t n,
                               const double E[9], double* out);
 
+/* PoseFromHomographyMatrix (/root/reference/pycolmap/geometry/homography_matrix.h:13-31, "homography_decomposition"):
+ * the analytical decomposition of H (pixels; K1, K2 the calibration matrices, all 3 x 3 row-major) into its one
+ * (pure rotation) or four (R, t, n) candidates, and of those the one that puts the most of the n correspondences
+ * (points1 / points2: n x 2, camera coordinates) in front of both cameras - later candidates win ties.
+ * points3D: room for n x 3; the winner's triangulated points in input order, *num_points3D of them. */
+int amc_homography_decomposition(amc_ctx* ctx, const double H[9], const double K1[9], const double K2[9],
+                                 const double* points1, const double* points2, size_t n, double R[9], double t[3],
+                                 double normal[3], double* points3D, uint64_t* num_points3D);
+
 #ifdef __cplusplus
 }
 #endif

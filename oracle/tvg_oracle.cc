@@ -1733,7 +1733,7 @@ void check_cheirality(const Mat3& R, const V3& t, const std::vector<Pt>& p1, con
     }
 }
 
-struct PoseCandidates { std::vector<Mat3> R; std::vector<V3> t; };
+struct PoseCandidates { std::vector<Mat3> R; std::vector<V3> t; std::vector<V3> n; };  // n: plane normals (H only)
 
 // the candidate (later ones win ties) with the most points in front of both cameras
 void best_candidate(const PoseCandidates& c, const std::vector<Pt>& p1, const std::vector<Pt>& p2, Mat3* R, V3* t,
@@ -1785,10 +1785,11 @@ void decompose_homography(const Mat3& H, const Mat3& K1, const Mat3& K2, PoseCan
     S.m[0] -= 1.0; S.m[4] -= 1.0; S.m[8] -= 1.0;
     double inf_norm = 0.0;  // lpNorm<Infinity> of a matrix expression: largest absolute coefficient
     for (double x : S.m) inf_norm = std::max(inf_norm, std::fabs(x));
-    out->R.clear(); out->t.clear();
+    out->R.clear(); out->t.clear(); out->n.clear();
     if (inf_norm < 1e-3) {  // H is a rotation
         out->R = {Hn};
         out->t = {V3{{0, 0, 0}}};
+        out->n = {V3{{0, 0, 0}}};
         return;
     }
     const double M00 = opposite_of_minor(S, 0, 0), M11 = opposite_of_minor(S, 1, 1), M22 = opposite_of_minor(S, 2, 2);
@@ -1828,6 +1829,7 @@ void decompose_homography(const Mat3& H, const Mat3& K1, const Mat3& K2, PoseCan
     const V3 t2 = mat3_vec(R2, t2s);
     out->R = {R1, R1, R2, R2};
     out->t = {t1, v3_scale(t1, -1.0), t2, v3_scale(t2, -1.0)};
+    out->n = {v3_scale(n1, -1.0), n1, v3_scale(n2, -1.0), n2};
 }
 
 // Eigen::Quaterniond(rotation matrix) -> (w, x, y, z)
@@ -2134,6 +2136,39 @@ int oracle_estimate_two_view_geometry_pose(const oracle_camera* cam1, const doub
     out->num_inliers = static_cast<int32_t>(Mi);
     put_pose(p, out);
     return 0;
+}
+
+// PoseFromHomographyMatrix (colmap/geometry/homography_matrix.cc; pycolmap.homography_decomposition,
+// /root/reference/pycolmap/geometry/homography_matrix.h:13-31): the candidate of DecomposeHomographyMatrix with the most
+// points in front of both cameras (later candidates win ties), its plane normal and those points.  points: n x 2 in
+// camera coordinates; points3D: room for n x 3.  Returns the number of points3D.
+int oracle_pose_from_homography(const double* H9, const double* K1_9, const double* K2_9, const double* points1,
+                                const double* points2, size_t n, double* R9, double* t3, double* normal3,
+                                double* points3D) {
+    Mat3 H, K1, K2;
+    std::memcpy(H.m, H9, sizeof H.m);
+    std::memcpy(K1.m, K1_9, sizeof K1.m);
+    std::memcpy(K2.m, K2_9, sizeof K2.m);
+    std::vector<Pt> a(n), b(n);
+    for (size_t i = 0; i < n; ++i) {
+        a[i] = Pt{points1[2 * i], points1[2 * i + 1]};
+        b[i] = Pt{points2[2 * i], points2[2 * i + 1]};
+    }
+    PoseCandidates c;
+    decompose_homography(H, K1, K2, &c);
+    Mat3 R{};
+    V3 t{}, nrm{};
+    std::vector<V3> X;
+    for (size_t i = 0; i < c.R.size(); ++i) {
+        std::vector<V3> cand;
+        check_cheirality(c.R[i], c.t[i], a, b, &cand);
+        if (cand.size() >= X.size()) { R = c.R[i]; t = c.t[i]; nrm = c.n[i]; X = cand; }
+    }
+    std::memcpy(R9, R.m, sizeof R.m);
+    std::memcpy(t3, t.v, sizeof t.v);
+    std::memcpy(normal3, nrm.v, sizeof nrm.v);
+    for (size_t i = 0; i < X.size(); ++i) std::memcpy(points3D + 3 * i, X[i].v, sizeof X[i].v);
+    return static_cast<int>(X.size());
 }
 
 // The same for a batch of pairs, one pair per OpenMP thread at a time (used to time the oracle on

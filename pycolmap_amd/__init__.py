@@ -21,7 +21,7 @@ try:  # the compiled host layer; absent only before `python -m pycolmap_amd.buil
         VocabTreeMatchingOptions,
         TwoViewGeometryOptions, essential_matrix_estimation, estimate_calibrated_two_view_geometry,
         estimate_two_view_geometry, estimate_two_view_geometry_pose, fundamental_matrix_estimation, has_cuda,
-        has_hip, homography_matrix_estimation, last_run_stats, logging, match_exhaustive, match_sequential,
+        has_hip, homography_decomposition, homography_matrix_estimation, last_run_stats, logging, match_exhaustive, match_sequential,
         match_spatial, match_vocabtree, squared_sampson_error, verify_matches,
     )
     _HOST_LAYER_ERROR = None

@@ -29,6 +29,7 @@ EXPORTED_SYMBOLS = [
     "amc_verify_result_free", "amc_upload_points_f64", "amc_ransac_pairs", "amc_ransac_result_free",
     "amc_squared_sampson_error", "amc_match_guided_pairs", "amc_ctx_grow_slots", "amc_pose_pairs",
     "amc_cam_from_img", "amc_match_verify_pairs", "amc_ctx_trim", "amc_ctx_resident_matches",
+    "amc_homography_decomposition",
 ]
 RANSAC_F, RANSAC_H, RANSAC_E = 0, 1, 2
 RANSAC_KINDS = {"F": RANSAC_F, "H": RANSAC_H, "E": RANSAC_E}
@@ -209,6 +210,7 @@ def load() -> C.CDLL:
                                               C.c_void_p]
     lib.amc_pose_pairs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_void_p]
+    lib.amc_homography_decomposition.argtypes = [C.c_void_p] + [C.c_void_p] * 5 + [C.c_size_t] + [C.c_void_p] * 5
     _lib = lib
     return lib
 
@@ -512,6 +514,21 @@ class Context:
                                                    p2.ctypes.data_as(C.c_void_p), p1.shape[0],
                                                    e.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)))
         return out
+
+    def homography_decomposition(self, H, K1, K2, points1, points2) -> dict:
+        """PoseFromHomographyMatrix: dict(R [3,3], t [3], n [3], points3D [m,3])."""
+        p1 = np.ascontiguousarray(points1, dtype=np.float64).reshape(-1, 2)
+        p2 = np.ascontiguousarray(points2, dtype=np.float64).reshape(-1, 2)
+        if p1.shape != p2.shape:
+            raise ValueError("points1 and points2 must have the same shape")
+        mats = [np.ascontiguousarray(a, dtype=np.float64).reshape(9) for a in (H, K1, K2)]
+        R, t, n = np.empty(9), np.empty(3), np.empty(3)
+        X = np.empty((max(1, len(p1)), 3))
+        m = C.c_uint64(0)
+        v = lambda a: a.ctypes.data_as(C.c_void_p)
+        _check(self._lib.amc_homography_decomposition(self._h, v(mats[0]), v(mats[1]), v(mats[2]), v(p1), v(p2), len(p1),
+                                                      v(R), v(t), v(n), v(X), C.cast(C.byref(m), C.c_void_p)))
+        return dict(R=R.reshape(3, 3), t=t, n=n, points3D=X[:m.value].copy())
 
     def cam_from_img(self, model: str | int, params, points) -> np.ndarray:
         """Camera::CamFromImg of an N x 2 array of image points."""

@@ -2176,6 +2176,53 @@ int amc_squared_sampson_error(amc_ctx* c, const double* points1, const double* p
     return rc;
 }
 
+int amc_homography_decomposition(amc_ctx* c, const double H[9], const double K1[9], const double K2[9],
+                                 const double* points1, const double* points2, size_t n, double R[9], double t[3],
+                                 double normal[3], double* points3D, uint64_t* num_points3D) {
+    if (!c) return fail(AMC_E_INVALID, "amc_homography_decomposition: ctx is NULL");
+    if (!H || !K1 || !K2 || !R || !t || !normal || !num_points3D || (n > 0 && (!points1 || !points2 || !points3D)))
+        return fail(AMC_E_INVALID, "amc_homography_decomposition: NULL argument");
+    if (n > 0xFFFFFFFFull / 4) return fail(AMC_E_INVALID, "amc_homography_decomposition: too many points");
+    HIPCHK(hipSetDevice(c->device));
+    DevBuf<double> buf;
+    HIPCHK(buf.ensure(7 * n + 27 + 16 + 8));
+    double* d1 = buf.p;
+    double* d2 = d1 + 2 * n;
+    double* dX = d2 + 2 * n;
+    double* din = dX + 3 * n;
+    double* dout = din + 27;
+    hipStream_t st = c->stream;
+    int rc = AMC_OK;
+    auto chk = [&](hipError_t e, const char* what) {
+        if (e != hipSuccess && rc == AMC_OK) rc = fail(AMC_E_HIP, "amc_homography_decomposition: %s: %s", what, hipGetErrorString(e));
+    };
+    double in[27], o[16];
+    std::memcpy(in, H, 9 * sizeof(double));
+    std::memcpy(in + 9, K1, 9 * sizeof(double));
+    std::memcpy(in + 18, K2, 9 * sizeof(double));
+    if (n) {
+        chk(hipMemcpyAsync(d1, points1, 2 * n * sizeof(double), hipMemcpyHostToDevice, st), "copy points1");
+        chk(hipMemcpyAsync(d2, points2, 2 * n * sizeof(double), hipMemcpyHostToDevice, st), "copy points2");
+    }
+    chk(hipMemcpyAsync(din, in, sizeof in, hipMemcpyHostToDevice, st), "copy H, K1, K2");
+    if (rc == AMC_OK) chk(launch_homography_decomposition(din, d1, d2, (uint32_t)n, dout, dX, st), "launch");
+    if (rc == AMC_OK) chk(hipMemcpyAsync(o, dout, sizeof o, hipMemcpyDeviceToHost, st), "copy out");
+    chk(hipStreamSynchronize(st), "sync");
+    if (rc == AMC_OK) {
+        std::memcpy(R, o, 9 * sizeof(double));
+        std::memcpy(t, o + 9, 3 * sizeof(double));
+        std::memcpy(normal, o + 12, 3 * sizeof(double));
+        const uint64_t m = (uint64_t)o[15];
+        *num_points3D = m;
+        if (m) {
+            chk(hipMemcpyAsync(points3D, dX, 3 * m * sizeof(double), hipMemcpyDeviceToHost, st), "copy points3D");
+            chk(hipStreamSynchronize(st), "sync");
+        }
+    }
+    buf.release();
+    return rc;
+}
+
 void amc_verify_result_free(amc_verify_result* r) {
     if (!r) return;
     delete static_cast<VerifyPriv*>(r->_priv);

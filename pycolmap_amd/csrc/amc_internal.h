@@ -326,6 +326,9 @@ constexpr int kTvgEWavesPerSimd = AMC_E_WAVES;
 constexpr int kTvgFhWavesPerSimd = AMC_FH_WAVES;
 size_t tvg_lds_bytes(uint32_t mcap, int waves);    // F/H kernel
 size_t tvg_lds_bytes_e(uint32_t mcap, int waves);  // essential-matrix kernel (+ its root finder's scratch)
+// pose.hip: PoseFromHomographyMatrix on given points; in27 = H, K1, K2; out16 = R, t, n, count
+hipError_t launch_homography_decomposition(const double* in27, const double* p1, const double* p2, uint32_t n, double* out16,
+                                           double* points3D, hipStream_t s);
 hipError_t launch_sampson(const double* p1, const double* p2, size_t n, const double* E9, double* out,
                           hipStream_t s);
 // the essential-matrix RANSAC of the listed (calibrated) pairs -> estate[pair.orig], emask + pair.mask_off

@@ -503,6 +503,37 @@ inline void BindEstimators(py::module_& m) {
         },
         "points2D1"_a, "points2D2"_a, "E"_a,
         "Calculate the squared Sampson error for a given essential or fundamental matrix.");
+    // PyPoseFromHomographyMatrix (/root/reference/pycolmap/geometry/homography_matrix.h:13-40)
+    m.def(
+        "homography_decomposition",
+        [](const PointsArray& H, const PointsArray& K1, const PointsArray& K2, const PointsArray& p1, const PointsArray& p2) {
+            if (H.size() != 9 || K1.size() != 9 || K2.size() != 9) throw py::value_error("H, K1, K2 must be 3 x 3 matrices");
+            const size_t n1 = CheckPoints(p1, "points1"), n2 = CheckPoints(p2, "points2");
+            CheckSameSize(n1, n2, "points1.size() == points2.size()");
+            std::array<double, 9> R{};
+            std::array<double, 3> t{}, n{};
+            std::vector<double> X(3 * std::max<size_t>(n1, 1));
+            uint64_t m3 = 0;
+            {
+                py::gil_scoped_release release;
+                EstimatorCtx& ctx = TheEstimatorCtx();
+                std::lock_guard<std::mutex> lock(ctx.mu);
+                EstCheck(amc_homography_decomposition(ctx.Get(), H.data(), K1.data(), K2.data(), p1.data(), p2.data(), n1,
+                                                      R.data(), t.data(), n.data(), X.data(), &m3),
+                         "amc_homography_decomposition");
+            }
+            py::list pts;
+            for (uint64_t i = 0; i < m3; ++i) {
+                py::array_t<double> x(3);
+                std::memcpy(x.mutable_data(), X.data() + 3 * i, 3 * sizeof(double));
+                pts.append(x);
+            }
+            py::array_t<double> tv(3), nv(3);
+            std::memcpy(tv.mutable_data(), t.data(), sizeof(double) * 3);
+            std::memcpy(nv.mutable_data(), n.data(), sizeof(double) * 3);
+            return py::dict("R"_a = Mat3(R), "t"_a = tv, "n"_a = nv, "points3D"_a = pts);
+        },
+        "H"_a, "K1"_a, "K2"_a, "points1"_a, "points2"_a, "Analytical Homography Decomposition.");
 }
 
 }  // namespace amchost

@@ -214,7 +214,78 @@ __global__ __launch_bounds__(64) void pose_kernel(const TvgImage* __restrict__ i
     }
 }
 
+// PoseFromHomographyMatrix on given points (pycolmap.homography_decomposition): one wave.  in: H, K1, K2 (27 doubles);
+// out: R (9), t (3), n (3), then the number of points3D as a double.  points3D: the winner's points, in input order.
+__global__ __launch_bounds__(64) void homography_decomposition_kernel(const double* __restrict__ in, const double* __restrict__ p1,
+                                                                      const double* __restrict__ p2, uint32_t n,
+                                                                      double* __restrict__ out, double* __restrict__ points3D) {
+    __shared__ PoseCands cands;
+    const int lane = threadIdx.x;
+    if (lane == 0) {
+        PoseCands c;
+        double H[9], K1[9], K2[9];
+        for (int i = 0; i < 9; ++i) { H[i] = in[i]; K1[i] = in[9 + i]; K2[i] = in[18 + i]; }
+        pose_candidates_H<true>(H, K1, K2, c);
+        cands = c;
+    }
+    __syncthreads();
+    const int ncand = cands.n;
+    int best = 0;
+    uint32_t best_count = 0;
+    for (int k = 0; k < ncand; ++k) {
+        double R[9], t[3];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) R[i] = cands.R[k][i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) t[i] = cands.t[k][i];
+        const CheiralityBounds b = cheirality_bounds(R, t);
+        uint32_t cnt = 0;
+        for (uint32_t base = 0; base < n; base += 64) {
+            const uint32_t i = base + lane;
+            bool ok = false;
+            if (i < n) {
+                double X[3];
+                ok = cheirality_point(R, t, b, p1[2 * (size_t)i], p1[2 * (size_t)i + 1], p2[2 * (size_t)i], p2[2 * (size_t)i + 1], X);
+            }
+            cnt += (uint32_t)__popcll(__ballot(ok));
+        }
+        if (cnt >= best_count) { best = k; best_count = cnt; }  // CheckCheirality's >=: later candidates win ties
+    }
+    double R[9], t[3];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) R[i] = cands.R[best][i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) t[i] = cands.t[best][i];
+    const CheiralityBounds b = cheirality_bounds(R, t);
+    uint32_t m = 0;
+    for (uint32_t base = 0; base < n; base += 64) {
+        const uint32_t i = base + lane;
+        bool ok = false;
+        double X[3] = {0.0, 0.0, 0.0};
+        if (i < n) ok = cheirality_point(R, t, b, p1[2 * (size_t)i], p1[2 * (size_t)i + 1], p2[2 * (size_t)i], p2[2 * (size_t)i + 1], X);
+        const unsigned long long bal = __ballot(ok);
+        if (ok) {
+            double* dst = points3D + 3 * (size_t)(m + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull)));
+            dst[0] = X[0]; dst[1] = X[1]; dst[2] = X[2];
+        }
+        m += (uint32_t)__popcll(bal);
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) out[i] = R[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { out[9 + i] = t[i]; out[12 + i] = cands.nrm[best][i]; }
+        out[15] = (double)m;
+    }
+}
+
 }  // namespace
+
+hipError_t launch_homography_decomposition(const double* in27, const double* p1, const double* p2, uint32_t n, double* out16,
+                                           double* points3D, hipStream_t s) {
+    hipLaunchKernelGGL(homography_decomposition_kernel, dim3(1), dim3(64), 0, s, in27, p1, p2, n, out16, points3D);
+    return hipGetLastError();
+}
 
 hipError_t launch_pose(const TvgImage* imgs, const PosePair* pairs, uint32_t npairs, const uint32_t* matches,
                        const uint8_t* mask, double* cosine_ws, PoseOut* out, hipStream_t s) {

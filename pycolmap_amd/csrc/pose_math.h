@@ -150,6 +150,7 @@ struct PoseCands {
     int n;
     double R[4][9];
     double t[4][3];
+    double nrm[4][3];  // plane normals of a homography's candidates (pose_candidates_H with normals = true)
 };
 
 // DecomposeEssentialMatrix + the four combinations of PoseFromEssentialMatrix
@@ -198,6 +199,7 @@ AMC_HD void homography_rotation(const double* Hn, const double* tstar, const dou
     mat3_mul(Hn, M, R);
 }
 // DecomposeHomographyMatrix: one candidate (pure rotation) or four
+template <bool NORMALS = false>
 AMC_HD void pose_candidates_H(const double* H, const double* K1, const double* K2, PoseCands& c) {
     double K2i[9], T[9], Hn[9];
     mat3_inv(K2, K2i);
@@ -224,6 +226,7 @@ AMC_HD void pose_candidates_H(const double* H, const double* K1, const double* K
 #pragma unroll
         for (int i = 0; i < 9; ++i) c.R[0][i] = Hn[i];
         c.t[0][0] = 0.0; c.t[0][1] = 0.0; c.t[0][2] = 0.0;
+        if (NORMALS) { c.nrm[0][0] = 0.0; c.nrm[0][1] = 0.0; c.nrm[0][2] = 0.0; }
         return;
     }
     const double M00 = opposite_of_minor(S, 0, 0), M11 = opposite_of_minor(S, 1, 1), M22 = opposite_of_minor(S, 2, 2);
@@ -279,6 +282,10 @@ AMC_HD void pose_candidates_H(const double* H, const double* K1, const double* K
         for (int i = 0; i < 3; ++i) {
             const double tv = k < 2 ? t1[i] : t2[i];
             c.t[k][i] = (k & 1) ? tv * -1.0 : tv;
+            if (NORMALS) {  // n = {-n1, n1, -n2, n2}
+                const double nv = k < 2 ? n1[i] : n2[i];
+                c.nrm[k][i] = (k & 1) ? nv : nv * -1.0;
+            }
         }
     }
 }

@@ -344,6 +344,19 @@ def estimate_two_view_geometry_batch(cams1, pts1, cams2, pts2, matches, opts=Non
     return out
 
 
+def pose_from_homography(H, K1, K2, points1, points2):
+    """PoseFromHomographyMatrix: dict(R, t, n, points3D [m,3])."""
+    lib = load()
+    lib.oracle_pose_from_homography.restype = C.c_int
+    lib.oracle_pose_from_homography.argtypes = [C.c_void_p] * 5 + [C.c_size_t] + [C.c_void_p] * 4
+    p1 = np.ascontiguousarray(points1, np.float64).reshape(-1, 2)
+    p2 = np.ascontiguousarray(points2, np.float64).reshape(-1, 2)
+    mats = [np.ascontiguousarray(a, np.float64).reshape(9) for a in (H, K1, K2)]
+    R, t, n, X = np.empty(9), np.empty(3), np.empty(3), np.empty((max(1, len(p1)), 3))
+    m = lib.oracle_pose_from_homography(_p(mats[0]), _p(mats[1]), _p(mats[2]), _p(p1), _p(p2), len(p1), _p(R), _p(t), _p(n), _p(X))
+    return dict(R=R.reshape(3, 3), t=t, n=n, points3D=X[:m].copy())
+
+
 def ransac_estimate(kind, p1, p2, opts=None, seed=0):
     """kind: 'F' | 'H' | 'E'. Mirrors pycolmap's *_matrix_estimation (seed 0 per call)."""
     lib = load()
