@@ -70,6 +70,18 @@ struct PyCamera {
         if (!m) throw py::value_error("Camera: invalid camera model");
         return *m;
     }
+    // the parameter side of Camera::Rescale: principal point by axis, one focal length by the mean scale, two by axis
+    void RescaleParams(double sx, double sy) {
+        const int nf = Info().num_focal;
+        params[nf] *= sx;
+        params[nf + 1] *= sy;
+        if (nf == 1) {
+            params[0] *= (sx + sy) / 2.0;
+        } else {
+            params[0] *= sx;
+            params[1] *= sy;
+        }
+    }
     void CheckParams() const {
         if (static_cast<int>(params.size()) != Info().num_params)
             throw py::value_error(std::string("Camera: model ") + Info().name + " takes " +
@@ -198,6 +210,86 @@ inline void BindCamera(py::module_& m) {
                  for (size_t i = 0; i < c.params.size(); ++i) ss << (i ? ", " : "") << c.params[i];
                  return ss.str();
              })
+        // Camera::FocalLengthIdxs / PrincipalPointIdxs / ExtraParamsIdxs: positions in `params` (every model keeps the
+        // order focal length(s), principal point, extra parameters)
+        .def("focal_length_idxs",
+             [](const PyCamera& c) {
+                 std::vector<size_t> v;
+                 for (int i = 0; i < c.Info().num_focal; ++i) v.push_back(i);
+                 return v;
+             },
+             "Indices of focal length parameters in params property.")
+        .def("principal_point_idxs",
+             [](const PyCamera& c) {
+                 const size_t nf = c.Info().num_focal;
+                 return std::vector<size_t>{nf, nf + 1};
+             },
+             "Indices of principal point parameters in params property.")
+        .def("extra_params_idxs",
+             [](const PyCamera& c) {
+                 std::vector<size_t> v;
+                 for (int i = c.Info().num_focal + 2; i < c.Info().num_params; ++i) v.push_back(i);
+                 return v;
+             },
+             "Indices of extra parameters in params property.")
+        // Camera::HasBogusParams = bogus principal point || bogus focal length || bogus extra parameters
+        .def("has_bogus_params",
+             [](const PyCamera& c, double min_focal_length_ratio, double max_focal_length_ratio, double max_extra_param) {
+                 c.CheckParams();
+                 const int nf = c.Info().num_focal;
+                 const double cx = c.params[nf], cy = c.params[nf + 1];
+                 if (cx < 0 || cx > static_cast<double>(c.width) || cy < 0 || cy > static_cast<double>(c.height)) return true;
+                 const double max_size = static_cast<double>(std::max(c.width, c.height));
+                 for (int i = 0; i < nf; ++i) {
+                     const double ratio = c.params[i] / max_size;
+                     if (ratio < min_focal_length_ratio || ratio > max_focal_length_ratio) return true;
+                 }
+                 for (int i = nf + 2; i < c.Info().num_params; ++i)
+                     if (std::abs(c.params[i]) > max_extra_param) return true;
+                 return false;
+             },
+             "min_focal_length_ratio"_a, "max_focal_length_ratio"_a, "max_extra_param"_a,
+             "Check whether camera has bogus parameters.")
+        // Camera::Rescale(scale) / Rescale(width, height)
+        .def("rescale",
+             [](PyCamera& c, double scale) {
+                 if (!(scale > 0.0)) throw py::value_error(CheckMessage(__FILE__, __LINE__, "scale > 0.0"));
+                 c.CheckParams();
+                 const double sx = std::round(scale * c.width) / c.width, sy = std::round(scale * c.height) / c.height;
+                 c.width = static_cast<uint64_t>(std::round(scale * c.width));
+                 c.height = static_cast<uint64_t>(std::round(scale * c.height));
+                 c.RescaleParams(sx, sy);
+             },
+             "scale"_a, "Rescale camera dimensions by given factor and accordingly the focal length and the principal point.")
+        .def("rescale",
+             [](PyCamera& c, uint64_t new_width, uint64_t new_height) {
+                 c.CheckParams();
+                 const double sx = static_cast<double>(new_width) / c.width, sy = static_cast<double>(new_height) / c.height;
+                 c.width = new_width;
+                 c.height = new_height;
+                 c.RescaleParams(sx, sy);
+             },
+             "new_width"_a, "new_height"_a,
+             "Rescale camera dimensions to given size and accordingly the focal length and the principal point.")
+        .def("set_params_from_string",
+             [](PyCamera& c, const std::string& text) {  // CSVToVector<double>; false (and no change) on a wrong count
+                 std::vector<double> v;
+                 std::stringstream ss(text);
+                 std::string item;
+                 while (std::getline(ss, item, ',')) {
+                     const size_t a = item.find_first_not_of(" \t\r\n");
+                     if (a == std::string::npos) continue;
+                     try {
+                         v.push_back(std::stod(item.substr(a)));
+                     } catch (const std::exception&) {
+                         return false;
+                     }
+                 }
+                 if (static_cast<int>(v.size()) != c.Info().num_params) return false;
+                 c.params = std::move(v);
+                 return true;
+             },
+             "params"_a, "Set camera parameters from comma-separated list.")
         .def("__repr__", &PyCamera::Repr)
         .def("__copy__", [](const PyCamera& c) { return PyCamera(c); })
         .def("__deepcopy__", [](const PyCamera& c, const py::dict&) { return PyCamera(c); });

@@ -335,3 +335,30 @@ def test_out_of_scope_matcher_keeps_its_option_class():
     assert vt.num_images == 7 and vt.num_checks == 256 and vt.vocab_tree_path == ""
     with pytest.raises(ValueError, match="outside pycolmap_amd's scope"):
         pc.match_vocabtree("nowhere.db", matching_options=vt)
+
+
+def test_camera_parameter_helpers():
+    """Camera::FocalLengthIdxs / PrincipalPointIdxs / ExtraParamsIdxs, HasBogusParams, Rescale, SetParamsFromString
+    (/root/reference/pycolmap/scene/camera.h) - metadata and arithmetic on the parameter vector."""
+    import pycolmap_amd as pc
+    c = pc.Camera(model="OPENCV", width=640, height=480, params=[500, 510, 320, 240, 0.1, 0.01, 0.001, 0.002])
+    assert (c.focal_length_idxs(), c.principal_point_idxs(), c.extra_params_idxs()) == ([0, 1], [2, 3], [4, 5, 6, 7])
+    s = pc.Camera(model="SIMPLE_RADIAL", width=100, height=50, params=[80, 50, 25, 0.1])
+    assert (s.focal_length_idxs(), s.principal_point_idxs(), s.extra_params_idxs()) == ([0], [1, 2], [3])
+    assert pc.Camera(model="PINHOLE", width=1, height=1, params=[1, 1, 0, 0]).extra_params_idxs() == []
+    assert not c.has_bogus_params(0.1, 10, 1.0)
+    assert c.has_bogus_params(0.1, 10, 0.05)            # |k1| = 0.1 > 0.05
+    assert c.has_bogus_params(1.0, 10, 1.0)             # 500 / 640 < 1
+    off = pc.Camera(model="PINHOLE", width=10, height=10, params=[10, 10, 11, 5])
+    assert off.has_bogus_params(0.1, 10, 1.0)           # principal point outside the image
+    c.rescale(0.5)
+    assert (c.width, c.height, list(c.params[:4])) == (320, 240, [250.0, 255.0, 160.0, 120.0])
+    c.rescale(1280, 960)
+    assert (c.width, c.height, list(c.params[:4])) == (1280, 960, [1000.0, 1020.0, 640.0, 480.0])
+    s.rescale(0.33)                                     # 33 x 17 (rounded): the scales differ per axis, one focal length takes their mean
+    assert (s.width, s.height) == (33, 17)
+    np.testing.assert_allclose(list(s.params), [80 * (0.33 + 0.34) / 2, 50 * 0.33, 25 * 0.34, 0.1], rtol=1e-15)
+    with pytest.raises(ValueError):
+        s.rescale(0.0)
+    assert s.set_params_from_string("1, 2,3 ,4") and list(s.params) == [1.0, 2.0, 3.0, 4.0]
+    assert not s.set_params_from_string("1,2") and not s.set_params_from_string("a,b,c,d") and list(s.params) == [1.0, 2.0, 3.0, 4.0]
