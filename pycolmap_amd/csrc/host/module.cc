@@ -480,6 +480,50 @@ PYBIND11_MODULE(_pycolmap, m) {
                  return r;
              }),
              "xyzw"_a, "Quaternion in [x,y,z,w] format.")
+        .def(py::init([](const py::array_t<double, py::array::c_style | py::array::forcecast>& a) {
+                 // a 3 x 3 rotation matrix or an axis-angle 3-vector (the reference's two other constructors)
+                 if (a.ndim() == 2 && a.shape(0) == 3 && a.shape(1) == 3) {
+                     std::array<double, 9> m;
+                     std::memcpy(m.data(), a.data(), sizeof(double) * 9);
+                     return PyRotation3d::FromMatrix(m);
+                 }
+                 if (a.ndim() == 1 && a.shape(0) == 3) return PyRotation3d::FromAxisAngle({{a.at(0), a.at(1), a.at(2)}});
+                 if (a.ndim() == 1 && a.shape(0) == 4) {
+                     PyRotation3d r;
+                     r.xyzw = {{a.at(0), a.at(1), a.at(2), a.at(3)}};
+                     return r;
+                 }
+                 throw py::value_error("Rotation3d: expected a quaternion [x,y,z,w], a 3 x 3 rotation matrix or an axis-angle 3-vector");
+             }),
+             "rotmat_or_axis_angle"_a, "3x3 rotation matrix, or axis-angle 3D vector.")
+        .def("__mul__", [](const PyRotation3d& a, const PyRotation3d& b) { return a.Mul(b); }, py::is_operator())
+        .def("__mul__",
+             [](const PyRotation3d& r, const py::array_t<double, py::array::c_style | py::array::forcecast>& v) -> py::array_t<double> {
+                 if (v.ndim() == 1 && v.shape(0) == 3) {
+                     const std::array<double, 3> o = r.Rotate({{v.at(0), v.at(1), v.at(2)}});
+                     py::array_t<double> out(3);
+                     std::memcpy(out.mutable_data(), o.data(), sizeof(double) * 3);
+                     return out;
+                 }
+                 if (v.ndim() == 2 && v.shape(1) == 3) {  // points * R^T
+                     const std::array<double, 9> R = r.Matrix();
+                     py::array_t<double> out({v.shape(0), static_cast<py::ssize_t>(3)});
+                     for (py::ssize_t i = 0; i < v.shape(0); ++i)
+                         for (int j = 0; j < 3; ++j)
+                             out.mutable_at(i, j) = v.at(i, 0) * R[3 * j] + v.at(i, 1) * R[3 * j + 1] + v.at(i, 2) * R[3 * j + 2];
+                     return out;
+                 }
+                 throw py::value_error("Rotation3d * x: x must be a Rotation3d, a 3-vector or an N x 3 array");
+             },
+             py::is_operator())
+        .def("normalize",
+             [](PyRotation3d& r) {
+                 const double n = std::sqrt(r.SquaredNorm());
+                 for (double& c : r.xyzw) c /= n;
+             })
+        .def("angle", &PyRotation3d::Angle)
+        .def("angle_to", &PyRotation3d::AngleTo, "other"_a)
+        .def("inverse", &PyRotation3d::Inverse)
         .def_property(
             "quat",
             [](const PyRotation3d& r) {
@@ -508,6 +552,63 @@ PYBIND11_MODULE(_pycolmap, m) {
             x.translation = t;
             return x;
         }))
+        .def(py::init([](const py::array_t<double, py::array::c_style | py::array::forcecast>& a) {
+                 if (a.ndim() != 2 || a.shape(0) != 3 || a.shape(1) != 4) throw py::value_error("Rigid3d: expected a 3 x 4 matrix [R | t]");
+                 std::array<double, 9> m;
+                 PyRigid3d x;
+                 for (int i = 0; i < 3; ++i) {
+                     for (int j = 0; j < 3; ++j) m[3 * i + j] = a.at(i, j);
+                     x.translation[i] = a.at(i, 3);
+                 }
+                 x.rotation = PyRotation3d::FromMatrix(m);
+                 return x;
+             }),
+             "matrix"_a)
+        .def("__mul__", [](const PyRigid3d& a, const PyRigid3d& b) { return a.Mul(b); }, py::is_operator())
+        .def("__mul__",
+             [](const PyRigid3d& r, const py::array_t<double, py::array::c_style | py::array::forcecast>& v) -> py::array_t<double> {
+                 if (v.ndim() == 1 && v.shape(0) == 3) {
+                     const std::array<double, 3> o = r.Apply({{v.at(0), v.at(1), v.at(2)}});
+                     py::array_t<double> out(3);
+                     std::memcpy(out.mutable_data(), o.data(), sizeof(double) * 3);
+                     return out;
+                 }
+                 if (v.ndim() == 2 && v.shape(1) == 3) {  // points * R^T, + t to every row
+                     const std::array<double, 9> R = r.rotation.Matrix();
+                     py::array_t<double> out({v.shape(0), static_cast<py::ssize_t>(3)});
+                     for (py::ssize_t i = 0; i < v.shape(0); ++i)
+                         for (int j = 0; j < 3; ++j)
+                             out.mutable_at(i, j) =
+                                 (v.at(i, 0) * R[3 * j] + v.at(i, 1) * R[3 * j + 1] + v.at(i, 2) * R[3 * j + 2]) + r.translation[j];
+                     return out;
+                 }
+                 throw py::value_error("Rigid3d * x: x must be a Rigid3d, a 3-vector or an N x 3 array");
+             },
+             py::is_operator())
+        .def("inverse", &PyRigid3d::Inverse)
+        .def("essential_matrix",
+             [](const PyRigid3d& r) {  // EssentialMatrixFromPose: [t / |t|]_x R
+                 const double n = std::sqrt(r.translation[0] * r.translation[0] + r.translation[1] * r.translation[1] +
+                                            r.translation[2] * r.translation[2]);
+                 std::array<double, 3> t = r.translation;
+                 if (n > 0.0)
+                     for (double& c : t) c /= n;
+                 const std::array<double, 9> R = r.rotation.Matrix();
+                 const double X[9] = {0, -t[2], t[1], t[2], 0, -t[0], -t[1], t[0], 0};
+                 std::array<double, 9> E{};
+                 for (int i = 0; i < 3; ++i)
+                     for (int j = 0; j < 3; ++j) E[3 * i + j] = X[3 * i] * R[j] + X[3 * i + 1] * R[3 + j] + X[3 * i + 2] * R[6 + j];
+                 return Mat3(E);
+             })
+        .def_static(
+            "interpolate",
+            [](const PyRigid3d& a, const PyRigid3d& b, double t) {  // InterpolateCameraPoses: slerp + linear translation
+                PyRigid3d r;
+                r.rotation = a.rotation.Slerp(t, b.rotation);
+                for (int i = 0; i < 3; ++i) r.translation[i] = a.translation[i] + (b.translation[i] - a.translation[i]) * t;
+                return r;
+            },
+            "cam_from_world1"_a, "cam_from_world2"_a, "t"_a)
         .def_readwrite("rotation", &PyRigid3d::rotation)
         .def_property(
             "translation",

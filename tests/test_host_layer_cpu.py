@@ -362,3 +362,53 @@ def test_camera_parameter_helpers():
         s.rescale(0.0)
     assert s.set_params_from_string("1, 2,3 ,4") and list(s.params) == [1.0, 2.0, 3.0, 4.0]
     assert not s.set_params_from_string("1,2") and not s.set_params_from_string("a,b,c,d") and list(s.params) == [1.0, 2.0, 3.0, 4.0]
+
+
+def test_rotation_and_rigid_algebra():
+    """Rotation3d / Rigid3d operators of /root/reference/pycolmap/geometry/bindings.h:24-104 (Eigen's quaternion algebra,
+    colmap/geometry/rigid3.h), against scipy's rotations and plain matrix arithmetic."""
+    import pycolmap_amd as pc
+    from scipy.spatial.transform import Rotation as SR, Slerp
+    rng = np.random.default_rng(5)
+    for _ in range(20):
+        qa, qb = SR.random(random_state=int(rng.integers(1 << 30))), SR.random(random_state=int(rng.integers(1 << 30)))
+        a, b = pc.Rotation3d(qa.as_quat()), pc.Rotation3d(qb.as_quat())
+        np.testing.assert_allclose(a.matrix(), qa.as_matrix(), atol=1e-14)
+        np.testing.assert_allclose((a * b).matrix(), qa.as_matrix() @ qb.as_matrix(), atol=1e-14)
+        v = rng.normal(size=3)
+        np.testing.assert_allclose(a * v, qa.as_matrix() @ v, atol=1e-14)
+        P = rng.normal(size=(7, 3))
+        np.testing.assert_allclose(a * P, P @ qa.as_matrix().T, atol=1e-14)
+        np.testing.assert_allclose((a * a.inverse()).matrix(), np.eye(3), atol=1e-14)
+        assert abs(a.angle() - min(qa.magnitude(), 2 * np.pi - qa.magnitude())) < 1e-12
+        assert abs(a.angle_to(b) - (qa * qb.inv()).magnitude()) < 1e-12
+        # the other constructors
+        np.testing.assert_allclose(pc.Rotation3d(qa.as_matrix()).matrix(), qa.as_matrix(), atol=1e-14)
+        np.testing.assert_allclose(pc.Rotation3d(qa.as_rotvec()).matrix(), qa.as_matrix(), atol=1e-14)
+        # rigid transforms
+        ta, tb = rng.normal(size=3), rng.normal(size=3)
+        A, B = pc.Rigid3d(a, ta), pc.Rigid3d(b, tb)
+        Ma = np.vstack([A.matrix(), [0, 0, 0, 1]])
+        Mb = np.vstack([B.matrix(), [0, 0, 0, 1]])
+        np.testing.assert_allclose(np.vstack([(A * B).matrix(), [0, 0, 0, 1]]), Ma @ Mb, atol=1e-13)
+        np.testing.assert_allclose(np.vstack([A.inverse().matrix(), [0, 0, 0, 1]]), np.linalg.inv(Ma), atol=1e-13)
+        np.testing.assert_allclose(A * v, qa.as_matrix() @ v + ta, atol=1e-14)
+        np.testing.assert_allclose(A * P, P @ qa.as_matrix().T + ta, atol=1e-14)
+        np.testing.assert_allclose(pc.Rigid3d(A.matrix()).matrix(), A.matrix(), atol=1e-14)
+        tn = ta / np.linalg.norm(ta)
+        tx = np.array([[0, -tn[2], tn[1]], [tn[2], 0, -tn[0]], [-tn[1], tn[0], 0]])
+        np.testing.assert_allclose(A.essential_matrix(), tx @ qa.as_matrix(), atol=1e-14)
+        s = float(rng.uniform())
+        I = pc.Rigid3d.interpolate(A, B, s)
+        want = Slerp([0, 1], SR.concatenate([qa, qb]))([s])[0].as_matrix()
+        np.testing.assert_allclose(I.rotation.matrix(), want, atol=1e-12)
+        np.testing.assert_allclose(I.translation, ta + (tb - ta) * s, atol=1e-14)
+    r = pc.Rotation3d([0.0, 0.0, 0.6, 0.8])
+    r.quat = [0.0, 0.0, 3.0, 4.0]
+    r.normalize()
+    np.testing.assert_allclose(r.quat, [0, 0, 0.6, 0.8], atol=1e-15)
+    assert pc.Rotation3d([0.0, 0.0, 0.0]).quat.tolist() == [0.0, 0.0, 0.0, 1.0]     # zero axis-angle: identity
+    with pytest.raises(ValueError):
+        pc.Rotation3d(np.zeros((2, 2)))
+    with pytest.raises(ValueError):
+        pc.Rigid3d(np.zeros((3, 3)))
