@@ -231,6 +231,14 @@ struct amc_ctx {
     DevBuf<double> d_tws;
     DevBuf<uint8_t> d_tmaskws, d_toutmask;
     DevBuf<TvgOut> d_tout;
+    // the call's results in the caller's layout (pack_verify_kernel): records without their counters, masks at the
+    // input's CSR offsets - copied straight into the pinned buffers the result leases
+    DevBuf<amc_tvg> d_tvg_packed;
+    DevBuf<uint8_t> d_mask_packed;
+    DevBuf<uint64_t> d_moff;
+    DevBuf<TvgPair> d_tp_all;
+    DevBuf<unsigned long long> d_worksum;
+    std::shared_ptr<PinnedPool> verify_pool = std::make_shared<PinnedPool>();
     PinBuf<TvgOut> h_tout;    // where the records and masks of a verification call land (copied out before return)
     PinBuf<uint8_t> h_tmask;
     // dyn_max_num_trials tables by (match count, confidence, multiplier), see verify_impl
@@ -355,6 +363,7 @@ void amc_ctx_destroy(amc_ctx* c) {
     c->d_timgs.release(); c->d_tpairs.release(); c->d_tmatches.release(); c->d_ttabs.release();
     c->d_tpairs_e.release(); c->d_estate.release(); c->d_emask.release(); c->d_stream.release(); c->d_wmcut.release(); c->d_tws.release(); c->d_tmaskws.release(); c->d_toutmask.release();
     c->d_tout.release();
+    c->d_tvg_packed.release(); c->d_mask_packed.release(); c->d_moff.release(); c->d_tp_all.release(); c->d_worksum.release();
     c->d_ppairs.release(); c->d_pmatches.release(); c->d_pcos.release(); c->d_pout.release();
     for (auto& ev : c->ev)
         if (ev) (void)hipEventDestroy(ev);
@@ -394,6 +403,8 @@ int amc_ctx_trim(amc_ctx* c) {
     }
     c->d_tws.release(); c->d_tmaskws.release(); c->d_toutmask.release(); c->d_emask.release(); c->d_estate.release();
     c->d_tout.release(); c->d_tmatches.release(); c->d_pmatches.release(); c->d_pcos.release();
+    c->d_tvg_packed.release(); c->d_mask_packed.release(); c->d_moff.release(); c->d_tp_all.release();
+    c->verify_pool->trim();
     c->h_tout.release(); c->h_tmask.release();
     for (int k = 0; k < 2; ++k) {
         c->h_matches[k].release();
@@ -1385,6 +1396,16 @@ struct VerifyPriv {
     // zero tens of megabytes first)
     std::unique_ptr<amc_tvg[]> tvg_raw;
     std::unique_ptr<uint8_t[]> mask_raw;
+    // verify_impl: pinned buffers leased from the context's pool (the D2H copies land in them; amc_verify_result_free
+    // hands them back for the next call - no page faults on fresh heap memory, no copy out of a staging buffer)
+    std::shared_ptr<PinnedPool> pool;
+    PinBuf<uint32_t> tvg_pin, mask_pin;
+    ~VerifyPriv() {
+        if (pool) {
+            pool->give_back(tvg_pin);
+            pool->give_back(mask_pin);
+        }
+    }
 };
 
 void pose_default(amc_pose* q, int32_t config) {
@@ -1617,16 +1638,18 @@ static int verify_impl(amc_ctx* c, int mode, const uint32_t* slot1, const uint32
     lap(0);
     VerifyPriv* priv = new (std::nothrow) VerifyPriv();
     if (!priv) return fail(AMC_E_NOMEM, "amc_verify_pairs: out of host memory");
-    priv->tvg_raw.reset(new (std::nothrow) amc_tvg[std::max<size_t>(npairs, 1)]);
-    priv->mask_raw.reset(new (std::nothrow) uint8_t[std::max<uint64_t>(total, 1)]);
-    if (!priv->tvg_raw || !priv->mask_raw) {
+    priv->pool = c->verify_pool;
+    priv->tvg_pin = c->verify_pool->acquire();
+    priv->mask_pin = c->verify_pool->acquire();
+    if (priv->tvg_pin.ensure((std::max<size_t>(npairs, 1) * sizeof(amc_tvg) + 3) / 4) != hipSuccess ||
+        priv->mask_pin.ensure((size_t)(std::max<uint64_t>(total, 1) + 3) / 4) != hipSuccess) {
         delete priv;
-        return fail(AMC_E_NOMEM, "amc_verify_pairs: out of host memory");
+        return fail(AMC_E_NOMEM, "amc_verify_pairs: out of pinned host memory");
     }
     out->npairs = npairs;
     out->_priv = priv;
-    out->tvg = priv->tvg_raw.get();
-    out->inlier_mask = priv->mask_raw.get();
+    out->tvg = reinterpret_cast<amc_tvg*>(priv->tvg_pin.p);
+    out->inlier_mask = reinterpret_cast<uint8_t*>(priv->mask_pin.p);
     if (npairs == 0) return AMC_OK;
     // every failure below (HIPCHK returns included) frees the result's storage and hands back a zeroed struct
     struct Guard {
@@ -1770,11 +1793,9 @@ static int verify_impl(amc_ctx* c, int mode, const uint32_t* slot1, const uint32
     HIPCHK(hipStreamSynchronize(st));
     lap(2);
 
-    HIPCHK(c->h_tout.ensure(npairs));
-    HIPCHK(c->h_tmask.ensure(std::max<size_t>(mask_bytes, 1)));
+    if (std::getenv("AMC_TVG_PROFILE")) HIPCHK(c->h_tout.ensure(npairs));
     HIPCHK(c->d_tout.ensure(npairs));
-    const TvgOut* h_out = c->h_tout.p;
-    const uint8_t* h_mask = c->h_tmask.p;
+    const TvgOut* h_out = c->h_tout.p;  // (read under AMC_TVG_PROFILE only)
     double kernel_ms = 0.0;
     uint32_t launches = 0;
     for (int attempt = 0;; ++attempt) {
@@ -1857,10 +1878,26 @@ static int verify_impl(amc_ctx* c, int mode, const uint32_t* slot1, const uint32
             return fail(AMC_E_HIP, "amc_verify_pairs: the sample stream table was exhausted %d times", attempt + 1);
         HIPCHK(ensure_stream(c->stream_len * 2));
     }
-    // the kernel stores a pair's record at the caller's pair index (TvgPair::orig)
-    HIPCHK(hipMemcpyAsync(c->h_tout.p, c->d_tout.p, npairs * sizeof(TvgOut), hipMemcpyDeviceToHost, st));
-    if (mask_bytes)
-        HIPCHK(hipMemcpyAsync(c->h_tmask.p, c->d_toutmask.p, mask_bytes, hipMemcpyDeviceToHost, st));
+    // The kernel stores a pair's record at the caller's pair index (TvgPair::orig) and its mask at a 128-byte
+    // aligned offset; pack_verify_kernel lays both out as the caller reads them (records without their counters, masks
+    // at the input's CSR offsets) and sums the work counters, so the copies below land in the result itself.
+    HIPCHK(c->d_tvg_packed.ensure(npairs));
+    HIPCHK(c->d_mask_packed.ensure(std::max<uint64_t>(total, 1)));
+    HIPCHK(c->d_moff.ensure(npairs + 1));
+    HIPCHK(c->d_tp_all.ensure(npairs));
+    HIPCHK(c->d_worksum.ensure(12));
+    HIPCHK(hipMemcpyAsync(c->d_moff.p, match_offsets, (npairs + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(c->d_tp_all.p, tp.data(), npairs * sizeof(TvgPair), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemsetAsync(c->d_worksum.p, 0, 12 * sizeof(unsigned long long), st));
+    HIPCHK(launch_pack_verify(c->d_tout.p, c->d_tp_all.p, (uint32_t)npairs, c->d_toutmask.p, c->d_moff.p,
+                              c->d_tvg_packed.p, c->d_mask_packed.p, c->d_worksum.p, st));
+    HIPCHK(hipMemcpyAsync(out->tvg, c->d_tvg_packed.p, npairs * sizeof(amc_tvg), hipMemcpyDeviceToHost, st));
+    if (total) HIPCHK(hipMemcpyAsync(out->inlier_mask, c->d_mask_packed.p, total, hipMemcpyDeviceToHost, st));
+    unsigned long long worksum[12];
+    HIPCHK(hipMemcpyAsync(worksum, c->d_worksum.p, sizeof worksum, hipMemcpyDeviceToHost, st));
+    const bool want_prof = std::getenv("AMC_TVG_PROFILE") != nullptr;
+    if (want_prof)  // the per-pair cycle counters live in the full records
+        HIPCHK(hipMemcpyAsync(c->h_tout.p, c->d_tout.p, npairs * sizeof(TvgOut), hipMemcpyDeviceToHost, st));
     uint32_t bad_pairs = 0;
     HIPCHK(hipMemcpyAsync(&bad_pairs, c->d_scalars + 2, sizeof bad_pairs, hipMemcpyDeviceToHost, st));
     HIPCHK(hipEventRecord(c->ev[1], st));
@@ -1877,7 +1914,7 @@ static int verify_impl(amc_ctx* c, int mode, const uint32_t* slot1, const uint32
         }
         return fail(AMC_E_INVALID, "amc_verify_pairs: %u pairs index past the keypoints", bad_pairs);
     }
-    if (std::getenv("AMC_TVG_PROFILE")) {
+    if (want_prof) {
         tvg_diag_report();
         tvg_diag_report_e();
         unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1889,26 +1926,7 @@ static int verify_impl(amc_ctx* c, int mode, const uint32_t* slot1, const uint32
         std::fprintf(stderr, "[amc tvg profile] per pair: counting loop=%.0f local_estimate(E5)=%.0f local_estimate(F8)=%.0f\n",
                      (double)acc[5] / npairs, (double)acc[6] / npairs, (double)acc[7] / npairs);
     }
-    {   // records and masks into the result's arrays (disjoint ranges of pairs: a few host threads for large calls)
-        const unsigned nth = npairs >= 16384 ? std::min(4u, std::max(1u, std::thread::hardware_concurrency())) : 1u;
-        std::vector<std::array<uint64_t, 12>> wsum(nth);
-        auto part = [&](unsigned k) {
-            std::array<uint64_t, 12> w{};
-            for (size_t p = npairs * k / nth; p < npairs * (k + 1) / nth; ++p) {
-                priv->tvg_raw[p] = h_out[p].g;
-                if (tp[p].M)
-                    std::memcpy(priv->mask_raw.get() + match_offsets[p], h_mask + tp[p].mask_off, tp[p].M);
-                for (int i = 0; i < 12; ++i) w[i] += h_out[p].work[i];
-            }
-            wsum[k] = w;
-        };
-        std::vector<std::thread> th;
-        for (unsigned k = 1; k < nth; ++k) th.emplace_back(part, k);
-        part(0);
-        for (auto& t : th) t.join();
-        for (unsigned k = 0; k < nth; ++k)
-            for (int i = 0; i < 12; ++i) out->work[i] += wsum[k][i];
-    }
+    for (int i = 0; i < 12; ++i) out->work[i] += worksum[i];
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[1]);
     out->device_ms = ms;
@@ -1926,10 +1944,10 @@ static int verify_impl(amc_ctx* c, int mode, const uint32_t* slot1, const uint32
         for (size_t p = 0; p < npairs; ++p) moff[p] = tp[p].mask_off;
         priv->pose.resize(npairs);
         double pose_ms = 0.0;
-        const int rc = pose_impl(c, "amc_verify_pairs", slot1, slot2, npairs, match_offsets, matches, priv->tvg_raw.get(),
+        const int rc = pose_impl(c, "amc_verify_pairs", slot1, slot2, npairs, match_offsets, matches, out->tvg,
                                  priv->pose.data(), &pose_ms, moff.data(), dev_matches, dev_off);
         if (rc != AMC_OK) return rc;
-        for (size_t p = 0; p < npairs; ++p) priv->tvg_raw[p].config = priv->pose[p].config;
+        for (size_t p = 0; p < npairs; ++p) out->tvg[p].config = priv->pose[p].config;
         out->pose = priv->pose.data();
         out->device_ms += pose_ms;
         out->kernel_ms += pose_ms;

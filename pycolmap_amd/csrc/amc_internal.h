@@ -326,6 +326,10 @@ constexpr int kTvgEWavesPerSimd = AMC_E_WAVES;
 constexpr int kTvgFhWavesPerSimd = AMC_FH_WAVES;
 size_t tvg_lds_bytes(uint32_t mcap, int waves);    // F/H kernel
 size_t tvg_lds_bytes_e(uint32_t mcap, int waves);  // essential-matrix kernel (+ its root finder's scratch)
+// pose.hip: a verification call's records and masks in the caller's layout, work counters summed
+hipError_t launch_pack_verify(const TvgOut* out, const TvgPair* tp, uint32_t npairs, const uint8_t* mask_src,
+                              const uint64_t* moff, amc_tvg* tvg_dst, uint8_t* mask_dst, unsigned long long* work,
+                              hipStream_t s);
 // pose.hip: PoseFromHomographyMatrix on given points; in27 = H, K1, K2; out16 = R, t, n, count
 hipError_t launch_homography_decomposition(const double* in27, const double* p1, const double* p2, uint32_t n, double* out16,
                                            double* points3D, hipStream_t s);
