@@ -16,6 +16,7 @@
 #include <new>
 #include <string>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "amc_internal.h"
@@ -104,6 +105,74 @@ struct PinBuf {
         if (p) (void)hipHostFree(p);
         p = nullptr;
         cap = 0;
+    }
+};
+
+// Device memory of the image slots (descriptors, keypoints, grids): sub-allocated from a few large slabs.  A
+// 500-image database is 1,500 buffers; through hipMalloc / hipFree each costs 50-100 us at upload time and again at
+// teardown (measured: 100 ms of a 700 ms match_exhaustive call in amc_ctx_destroy alone).  Blocks are 256-byte
+// aligned; a freed block goes to a size-keyed free list and serves the next request it fits without wasting more than
+// half of it (a pipeline that re-uploads its slots reuses them exactly); slabs go back to the driver when the
+// context is destroyed or all slots are released (amc_ctx_reserve_slots).  Calls on one context are serialised by
+// its owner (include/amc.h), so no lock.
+struct SlotArena {
+    static constexpr size_t kSlabBytes = (size_t)256 << 20;
+    struct Slab {
+        char* p;
+        size_t cap, used;
+    };
+    std::vector<Slab> slabs;
+    std::multimap<size_t, void*> idle;          // freed blocks by size
+    std::unordered_map<void*, size_t> size_of;  // live and idle blocks
+    hipError_t alloc(void** out, size_t bytes) {
+        bytes = std::max<size_t>((bytes + 255) / 256 * 256, 256);
+        auto it = idle.lower_bound(bytes);
+        if (it != idle.end() && it->first <= 2 * bytes) {
+            *out = it->second;
+            idle.erase(it);
+            return hipSuccess;
+        }
+        if (slabs.empty() || slabs.back().cap - slabs.back().used < bytes) {
+            // what is left of the current slab stays usable through the free list
+            if (!slabs.empty() && slabs.back().cap - slabs.back().used >= 256) {
+                Slab& b = slabs.back();
+                void* rest = b.p + b.used;
+                size_of[rest] = b.cap - b.used;
+                idle.emplace(b.cap - b.used, rest);
+                b.used = b.cap;
+            }
+            Slab nb{nullptr, std::max(bytes, kSlabBytes), 0};
+            hipError_t e = hipMalloc(reinterpret_cast<void**>(&nb.p), nb.cap);
+            if (e != hipSuccess && nb.cap > bytes) {  // no room for a whole slab: exactly what is asked for
+                nb.cap = bytes;
+                e = hipMalloc(reinterpret_cast<void**>(&nb.p), nb.cap);
+            }
+            if (e != hipSuccess) return e;
+            slabs.push_back(nb);
+        }
+        Slab& b = slabs.back();
+        *out = b.p + b.used;
+        b.used += bytes;
+        size_of[*out] = bytes;
+        return hipSuccess;
+    }
+    template <class T>
+    hipError_t alloc(T** out, size_t bytes) {
+        void* p = nullptr;
+        const hipError_t e = alloc(&p, bytes);
+        *out = static_cast<T*>(p);
+        return e;
+    }
+    void free(void* p) {  // (the caller has synchronised with whatever read the block)
+        if (!p) return;
+        auto it = size_of.find(p);
+        if (it != size_of.end()) idle.emplace(it->second, p);
+    }
+    void release_all() {
+        for (Slab& b : slabs) (void)hipFree(b.p);
+        slabs.clear();
+        idle.clear();
+        size_of.clear();
     }
 };
 
@@ -206,6 +275,7 @@ struct amc_ctx {
     uint64_t resident_matches = 0;          // matches of the LAST match call, in its result's CSR order, at d_keep (amc_ctx_resident_matches)
     PinBuf<uint64_t> h_csr[2];
     std::shared_ptr<PinnedPool> result_pool = std::make_shared<PinnedPool>();
+    SlotArena arena;  // the slots' device memory
     // host staging of a match batch, two sets: batch k+1 is prepared and enqueued while the results of
     // batch k are still being copied out and scattered (match_impl)
     PinBuf<PairDev> h_pairs[2];
@@ -326,20 +396,22 @@ int amc_ctx_create(int device_id, amc_ctx** out) {
     return AMC_OK;
 }
 
-static void free_slot(Slot& s) {
-    if (s.base) (void)hipFree(s.base);
-    if (s.kp) (void)hipFree(s.kp);
-    if (s.kp64) (void)hipFree(s.kp64);
-    if (s.kpn) (void)hipFree(s.kpn);
-    if (s.grid_base) (void)hipFree(s.grid_base);
-    s = Slot();
-}
-
 void amc_ctx_destroy(amc_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    const bool dprof = std::getenv("AMC_DESTROY_PROFILE") != nullptr;  // wall-clock of the teardown's parts on stderr
+    auto tp0 = std::chrono::steady_clock::now();
+    auto dlap = [&](const char* what) {
+        if (!dprof) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[amc destroy] %s %.1f ms\n", what, std::chrono::duration<double, std::milli>(now - tp0).count());
+        tp0 = now;
+    };
     (void)hipDeviceSynchronize();
-    for (auto& s : c->slots) free_slot(s);
+    dlap("sync");
+    c->slots.clear();
+    c->arena.release_all();
+    dlap("slots");
     c->d_imgs.release();
     c->d_grids.release();
     if (c->d_lut) (void)hipFree(c->d_lut);
@@ -351,6 +423,7 @@ void amc_ctx_destroy(amc_ctx* c) {
     c->d_rowbuf.release(); c->d_colbuf.release(); c->d_accmask.release(); c->d_guided.release();
     c->d_pair_off.release(); c->d_pair_cnt.release(); c->d_matches.release();
     c->d_cand_cnt.release(); c->d_candbuf.release(); c->d_keep.release(); c->d_csr.release();
+    dlap("match device buffers");
     c->h_csr[0].release(); c->h_csr[1].release();
     c->h_tout.release(); c->h_tmask.release();
     for (int k = 0; k < 2; ++k) {
@@ -360,11 +433,13 @@ void amc_ctx_destroy(amc_ctx* c) {
         c->h_bscalars[k].release();
     }
     c->h_scalars.release();
+    dlap("pinned host buffers");
     c->d_timgs.release(); c->d_tpairs.release(); c->d_tmatches.release(); c->d_ttabs.release();
     c->d_tpairs_e.release(); c->d_estate.release(); c->d_emask.release(); c->d_stream.release(); c->d_wmcut.release(); c->d_tws.release(); c->d_tmaskws.release(); c->d_toutmask.release();
     c->d_tout.release();
     c->d_tvg_packed.release(); c->d_mask_packed.release(); c->d_moff.release(); c->d_tp_all.release(); c->d_worksum.release();
     c->d_ppairs.release(); c->d_pmatches.release(); c->d_pcos.release(); c->d_pout.release();
+    dlap("verify device buffers");
     for (auto& ev : c->ev)
         if (ev) (void)hipEventDestroy(ev);
     for (auto& set : c->bev)
@@ -374,7 +449,9 @@ void amc_ctx_destroy(amc_ctx* c) {
         if (ev) (void)hipEventDestroy(ev);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
-    delete c;
+    dlap("events and streams");
+    delete c;  // (the result pools' idle pinned buffers go with their last owner)
+    dlap("delete (pools)");
 }
 
 int amc_ctx_set_stream(amc_ctx* c, void* hip_stream) {
@@ -424,8 +501,8 @@ int amc_ctx_reserve_slots(amc_ctx* c, uint32_t num_slots) {
     if (!c) return fail(AMC_E_INVALID, "amc_ctx_reserve_slots: ctx is NULL");
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));
-    for (auto& s : c->slots) free_slot(s);
     c->slots.assign(num_slots, Slot());
+    c->arena.release_all();  // every slot is gone: the slabs go back to the driver
     c->table_dirty = true;
     return AMC_OK;
 }
@@ -452,7 +529,7 @@ static int upload_common(amc_ctx* c, uint32_t slot, const void* src, uint32_t ro
     Slot& s = c->slots[slot];
     if (s.base) {
         HIPCHK(hipStreamSynchronize(c->stream));
-        (void)hipFree(s.base);
+        c->arena.free(s.base);
         s.base = nullptr;
     }
     c->table_dirty = true;
@@ -463,7 +540,7 @@ static int upload_common(amc_ctx* c, uint32_t slot, const void* src, uint32_t ro
     if (rows == 0) return AMC_OK;
     const size_t rp = s.dev.rows_pad;
     const size_t bytes = rp * kDim * 2 + rp * sizeof(int32_t);
-    hipError_t e = hipMalloc(&s.base, bytes);
+    hipError_t e = c->arena.alloc(&s.base, bytes);
     if (e != hipSuccess) {
         s.valid = false;
         s.dev = ImageDev{};
@@ -1136,7 +1213,7 @@ void amc_tvg_opts_default(amc_tvg_opts* o) {
 
 // Guided matching's candidate generation (match_guided.hip): bucket the image's keypoints on a kGridDim^2 grid
 // over their bounding box.  No grid (grid.n = 0) when a coordinate is not finite: such pairs take the dense kernel.
-static int build_keypoint_grid(Slot& s, const float* xy, uint32_t rows) {
+static int build_keypoint_grid(amc_ctx* c, Slot& s, const float* xy, uint32_t rows) {
     guided::GridGeom gg;
     std::vector<uint32_t> sidx, start;
     if (!guided::build_grid(xy, rows, gg, sidx, start)) return AMC_OK;
@@ -1150,7 +1227,7 @@ static int build_keypoint_grid(Slot& s, const float* xy, uint32_t rows) {
         sxy[2 * (size_t)k + 1] = xy[2 * (size_t)sidx[k] + 1];
     }
     const size_t b_xy = sxy.size() * sizeof(float), b_idx = sidx.size() * sizeof(uint32_t), b_st = start.size() * sizeof(uint32_t);
-    hipError_t e = hipMalloc(&s.grid_base, b_xy + b_idx + b_st);
+    hipError_t e = c->arena.alloc(&s.grid_base, b_xy + b_idx + b_st);
     if (e != hipSuccess) return fail(AMC_E_NOMEM, "amc_upload_keypoints: hipMalloc (grid): %s", hipGetErrorString(e));
     char* base = static_cast<char*>(s.grid_base);
     HIPCHK(hipMemcpy(base, sxy.data(), b_xy, hipMemcpyHostToDevice));
@@ -1174,10 +1251,10 @@ int amc_upload_keypoints(amc_ctx* c, uint32_t slot, const float* xy, uint32_t ro
     Slot& s = c->slots[slot];
     if (s.kp || s.kp64 || s.kpn || s.grid_base) {
         HIPCHK(hipStreamSynchronize(c->stream));
-        if (s.kp) (void)hipFree(s.kp);
-        if (s.kp64) (void)hipFree(s.kp64);
-        if (s.kpn) (void)hipFree(s.kpn);
-        if (s.grid_base) (void)hipFree(s.grid_base);
+        c->arena.free(s.kp);
+        c->arena.free(s.kp64);
+        c->arena.free(s.kpn);
+        c->arena.free(s.grid_base);
         s.grid_base = nullptr;
         s.grid = GridDev{};
         s.kp = nullptr;
@@ -1196,7 +1273,7 @@ int amc_upload_keypoints(amc_ctx* c, uint32_t slot, const float* xy, uint32_t ro
         packed[2 * (size_t)i] = xy[(size_t)i * stride_floats];
         packed[2 * (size_t)i + 1] = xy[(size_t)i * stride_floats + 1];
     }
-    hipError_t e = hipMalloc(reinterpret_cast<void**>(&s.kp), packed.size() * sizeof(float));
+    hipError_t e = c->arena.alloc(&s.kp, packed.size() * sizeof(float));
     if (e != hipSuccess) {
         s.has_kp = false;
         return fail(AMC_E_NOMEM, "amc_upload_keypoints: hipMalloc: %s", hipGetErrorString(e));
@@ -1205,7 +1282,7 @@ int amc_upload_keypoints(amc_ctx* c, uint32_t slot, const float* xy, uint32_t ro
     s.dev.kp = s.kp;  // guided matching reads the float32 keypoints from the image table
     s.dev.kp_rows = rows;
     c->table_dirty = true;
-    return build_keypoint_grid(s, packed.data(), rows);
+    return build_keypoint_grid(c, s, packed.data(), rows);
 }
 
 int amc_upload_points_f64(amc_ctx* c, uint32_t slot, const double* xy, uint32_t rows) {
@@ -1217,10 +1294,10 @@ int amc_upload_points_f64(amc_ctx* c, uint32_t slot, const double* xy, uint32_t 
     Slot& s = c->slots[slot];
     if (s.kp || s.kp64 || s.kpn || s.grid_base) {
         HIPCHK(hipStreamSynchronize(c->stream));
-        if (s.kp) (void)hipFree(s.kp);
-        if (s.kp64) (void)hipFree(s.kp64);
-        if (s.kpn) (void)hipFree(s.kpn);
-        if (s.grid_base) (void)hipFree(s.grid_base);
+        c->arena.free(s.kp);
+        c->arena.free(s.kp64);
+        c->arena.free(s.kpn);
+        c->arena.free(s.grid_base);
         s.grid_base = nullptr;
         s.grid = GridDev{};
         s.kp = nullptr;
@@ -1234,7 +1311,7 @@ int amc_upload_points_f64(amc_ctx* c, uint32_t slot, const double* xy, uint32_t 
     s.kp_rows = rows;
     s.has_kp = true;
     if (rows == 0) return AMC_OK;
-    hipError_t e = hipMalloc(reinterpret_cast<void**>(&s.kp64), (size_t)rows * 2 * sizeof(double));
+    hipError_t e = c->arena.alloc(&s.kp64, (size_t)rows * 2 * sizeof(double));
     if (e != hipSuccess) {
         s.has_kp = false;
         return fail(AMC_E_NOMEM, "amc_upload_points_f64: hipMalloc: %s", hipGetErrorString(e));
@@ -1282,7 +1359,7 @@ static int ensure_normalized(amc_ctx* c, uint32_t slot) {
         return AMC_OK;
     }
     if (!s.kpn) {
-        hipError_t e = hipMalloc(reinterpret_cast<void**>(&s.kpn), (size_t)rows * 2 * sizeof(double));
+        hipError_t e = c->arena.alloc(&s.kpn, (size_t)rows * 2 * sizeof(double));
         if (e != hipSuccess) return fail(AMC_E_NOMEM, "CamFromImg buffer: hipMalloc: %s", hipGetErrorString(e));
     }
     if (!cam::needs_libm(s.cam.model_id)) {

@@ -133,13 +133,16 @@ void MatchController::Setup() {
                                 static_cast<int32_t>(r.cam->params.size()), r.cam->has_prior_focal_length),
               "amc_upload_camera");
     };
-    constexpr uint32_t kChunk = 64;  // images read from SQLite per round of parallel uploads
-    for (uint32_t s0 = 0; s0 < images_.size(); s0 += kChunk) {
-        const uint32_t s1 = std::min<uint32_t>(s0 + kChunk, static_cast<uint32_t>(images_.size()));
+    constexpr uint32_t kChunk = 64;  // images read from SQLite per round of uploads
+    const uint32_t nimg = static_cast<uint32_t>(images_.size());
+    for (uint32_t s = 0; s < nimg; ++s) slot_of_image_[images_[s].image_id] = s;
+    // SQLite is read by a worker thread one chunk ahead of the uploads (reading 295 MB of blobs and moving them to the
+    // device cost about the same: one hides behind the other)
+    auto read_chunk = [&](uint32_t s0) {
+        const uint32_t s1 = std::min<uint32_t>(s0 + kChunk, nimg);
         std::vector<Row> rows(s1 - s0);
         for (uint32_t s = s0; s < s1; ++s) {
             const ImageRow& im = images_[s];
-            slot_of_image_[im.image_id] = s;
             Row& r = rows[s - s0];
             uint32_t drows = 0;
             r.desc = db_->ReadDescriptors(im.image_id, &drows);
@@ -147,11 +150,25 @@ void MatchController::Setup() {
             // COLMAP's GPU matcher clamps to the first max_num_matches features
             // (WarnIfMaxNumMatchesReachedGPU; SiftMatchingOptions.max_num_matches)
             r.use = std::min<uint32_t>(drows, static_cast<uint32_t>(std::max(sift_.max_num_matches, 0)));
-            desc_rows_[s] = r.use;
             auto it = cam_by_id.find(im.camera_id);
             if (it == cam_by_id.end()) throw std::runtime_error("image " + im.name + " references a missing camera");
             r.cam = it->second;
         }
+        return rows;
+    };
+    std::future<std::vector<Row>> ahead;
+    if (nimg) ahead = std::async(std::launch::async, read_chunk, 0u);
+    for (uint32_t s0 = 0; s0 < nimg; s0 += kChunk) {
+        const uint32_t s1 = std::min<uint32_t>(s0 + kChunk, nimg);
+        const std::vector<Row> rows = ahead.get();  // (rethrows what the reader threw)
+        if (s1 < nimg) ahead = std::async(std::launch::async, read_chunk, s1);
+        struct Drain {  // an upload that throws must not leave the reader running into a dying controller
+            std::future<std::vector<Row>>& f;
+            ~Drain() {
+                if (f.valid()) f.wait();
+            }
+        } drain{ahead};
+        for (uint32_t s = s0; s < s1; ++s) desc_rows_[s] = rows[s - s0].use;
         if (ctxs_.size() == 1) {
             for (uint32_t s = s0; s < s1; ++s) upload(ctx_, s, rows[s - s0]);
         } else {

@@ -25,6 +25,7 @@
 #include <mutex>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <exception>
 #include <fstream>
 #include <sstream>
@@ -177,20 +178,29 @@ void MakeDataclass(py::class_<T>& cls, const std::vector<std::string>& fields) {
 // ---- interruptible blocking run (PyWait analogue) ------------------------------------------------
 void RunInterruptible(MatchController& ctrl, const std::function<void()>& work) {
     std::exception_ptr err;
-    std::atomic<bool> done{false};
+    std::mutex mu;
+    std::condition_variable cv;
+    bool done = false;
     std::thread th([&] {
         try {
             work();
         } catch (...) {
             err = std::current_exception();
         }
-        done.store(true);
+        {
+            std::lock_guard<std::mutex> lock(mu);
+            done = true;
+        }
+        cv.notify_one();
     });
     bool interrupted = false;
     {
         py::gil_scoped_release release;
-        while (!done.load()) {
-            std::this_thread::sleep_for(std::chrono::milliseconds(50));
+        for (;;) {
+            {   // woken when the work is done; every 50 ms to look for a pending signal
+                std::unique_lock<std::mutex> lock(mu);
+                if (cv.wait_for(lock, std::chrono::milliseconds(50), [&] { return done; })) break;
+            }
             py::gil_scoped_acquire acquire;
             if (PyErr_CheckSignals() != 0) {  // Ctrl-C: stop cooperatively between blocks
                 interrupted = true;
@@ -943,12 +953,24 @@ PYBIND11_MODULE(_pycolmap, m) {
         const std::string db_path = PathToString(database_path);
         AMC_THROW_CHECK_FILE_EXISTS(db_path);
         RequireAccelerator(device);
-        MatchController ctrl(db_path, sift, tvg, ParseGpuIndex(sift.gpu_index));
-        RunInterruptible(ctrl, [&] {
-            ctrl.Setup();
-            body(ctrl);
+        const auto t0 = std::chrono::steady_clock::now();
+        auto since = [](std::chrono::steady_clock::time_point t) {
+            return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count();
+        };
+        auto ctrl = std::make_unique<MatchController>(db_path, sift, tvg, ParseGpuIndex(sift.gpu_index));
+        RunInterruptible(*ctrl, [&] {
+            ctrl->Setup();
+            body(*ctrl);
         });
-        py::module_::import("pycolmap_amd._pycolmap").attr("_last_stats") = StatsDict(ctrl.stats);
+        py::dict st = StatsDict(ctrl->stats);
+        const auto t1 = std::chrono::steady_clock::now();
+        {
+            py::gil_scoped_release release;
+            ctrl.reset();  // closes the database (WAL again), frees the arena and the contexts' buffers
+        }
+        st["teardown_ms"] = since(t1);
+        st["call_ms"] = since(t0);  // the whole call as the caller's clock sees it
+        py::module_::import("pycolmap_amd._pycolmap").attr("_last_stats") = st;
     };
 
     m.def(
