@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <random>
 #include <array>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -1753,6 +1754,45 @@ static int verify_impl(amc_ctx* c, int mode, const uint32_t* slot1, const uint32
     std::vector<int64_t> tab_of_M((size_t)maxM + 1, -1);
     std::vector<TvgPair> tp(npairs);
     const int kmins[3] = {5, 7, 4};
+    auto make_table = [&](uint32_t M) {  // ComputeNumTrials for every inlier count 0 .. M and the three minimal sample sizes
+        std::vector<uint32_t> t3;
+        t3.reserve(3 * ((size_t)M + 1));
+        for (int t = 0; t < 3; ++t)
+            for (uint32_t i = 0; i <= M; ++i) {
+                const size_t v = M ? compute_num_trials_host(i, M, o.ransac.confidence, o.ransac.dyn_num_trials_multiplier, kmins[t]) : 0;
+                t3.push_back(v > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)v);
+            }
+        return t3;
+    };
+    // The tables this call needs and the cache does not hold (a pow and two logs per entry: the first call of a run
+    // sees a few hundred new match counts, ~40 ms on one core) are computed ahead on a few threads.
+    const bool tabs_cacheable = o.ransac.confidence == o.ransac.confidence &&
+                                o.ransac.dyn_num_trials_multiplier == o.ransac.dyn_num_trials_multiplier;
+    std::vector<uint32_t> fresh_M;
+    std::vector<std::vector<uint32_t>> fresh_tab;
+    std::vector<int32_t> fresh_of((size_t)maxM + 1, -1);
+    {
+        size_t words = 0;
+        for (size_t p = 0; p < npairs; ++p) {
+            const uint32_t M = (uint32_t)(match_offsets[p + 1] - match_offsets[p]);
+            if (fresh_of[M] != -1) continue;
+            fresh_of[M] = -2;  // seen
+            if (tabs_cacheable && c->trial_tabs.count(TrialTabKey{M, o.ransac.confidence, o.ransac.dyn_num_trials_multiplier})) continue;
+            fresh_of[M] = (int32_t)fresh_M.size();
+            fresh_M.push_back(M);
+            words += 3 * ((size_t)M + 1);
+        }
+        fresh_tab.resize(fresh_M.size());
+        const unsigned nth = words >= 65536 ? std::min(8u, std::max(1u, std::thread::hardware_concurrency())) : 1u;
+        std::atomic<size_t> next{0};
+        auto work = [&] {
+            for (size_t k; (k = next.fetch_add(1)) < fresh_M.size();) fresh_tab[k] = make_table(fresh_M[k]);
+        };
+        std::vector<std::thread> th;
+        for (unsigned k = 1; k < nth; ++k) th.emplace_back(work);
+        work();
+        for (auto& t : th) t.join();
+    }
     uint64_t mask_bytes = 0;
     for (size_t p = 0; p < npairs; ++p) {
         const uint32_t M = (uint32_t)(match_offsets[p + 1] - match_offsets[p]);
@@ -1765,15 +1805,7 @@ static int verify_impl(amc_ctx* c, int mode, const uint32_t* slot1, const uint32
             const bool cacheable = key.confidence == key.confidence && key.multiplier == key.multiplier;
             auto it = cacheable ? c->trial_tabs.find(key) : c->trial_tabs.end();
             if (it == c->trial_tabs.end()) {
-                std::vector<uint32_t> t3;
-                t3.reserve(3 * ((size_t)M + 1));
-                for (int t = 0; t < 3; ++t)
-                    for (uint32_t i = 0; i <= M; ++i) {
-                        const size_t v = M ? compute_num_trials_host(i, M, o.ransac.confidence,
-                                                                     o.ransac.dyn_num_trials_multiplier, kmins[t])
-                                           : 0;
-                        t3.push_back(v > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)v);
-                    }
+                std::vector<uint32_t> t3 = fresh_of[M] >= 0 ? std::move(fresh_tab[(size_t)fresh_of[M]]) : make_table(M);
                 if (!cacheable) {
                     tabs.insert(tabs.end(), t3.begin(), t3.end());
                 } else {
