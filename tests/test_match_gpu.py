@@ -324,3 +324,26 @@ def test_trim_releases_scratch_and_the_context_keeps_working(amc_ctx):
     np.testing.assert_array_equal(m, m2)
     woff, wm = oracle_lib.match_pairs(imgs, s1, s2)
     np.testing.assert_array_equal(m2, wm)
+
+
+def test_slots_uploaded_again_and_again(amc_ctx):
+    """The slots' device memory comes from a slab allocator with a size-keyed free list (amc_api.hip, SlotArena): slots
+    re-uploaded with other sizes - blocks freed, reused for requests up to half their size, slabs extended - keep
+    holding what was uploaded last, and the keypoint / grid buffers beside them as well."""
+    rng = np.random.default_rng(31)
+    n = 6
+    amc_ctx.reserve_slots(n)
+    pool = synth.scene_images(rng, n, 2600, num_landmarks=3200, visible_frac=0.6)   # rows are shuffled: a prefix is a random subset
+    imgs = [None] * n
+    for round_ in range(8):
+        for k in rng.permutation(n)[: int(rng.integers(2, n + 1))] if round_ else range(n):
+            rows = int(rng.choice([0, 1, 37, 300, 301, 650, 1200, 2600])) if round_ else 400
+            imgs[k] = np.ascontiguousarray(pool[int(rng.integers(n))][:rows])
+            amc_ctx.upload_descriptors(int(k), imgs[k])
+            amc_ctx.upload_keypoints(int(k), rng.uniform(0, 1000, (rows, 2)).astype(np.float32))
+        s1, s2 = synth.exhaustive_pairs(n)
+        assert_same(amc_ctx, imgs, s1, s2, "auto")
+    amc_ctx.reserve_slots(2)                                   # everything released; the context starts over
+    small = [synth.random_descriptors(rng, 200), synth.random_descriptors(rng, 100)]
+    upload(amc_ctx, small)
+    assert_same(amc_ctx, small, np.array([0], np.uint32), np.array([1], np.uint32), "auto")
