@@ -16,8 +16,13 @@ for line in txt.splitlines():
         cnt[m.group(2)] = (int(m.group(3)), float(m.group(4)), float(m.group(5)))
 out = {"source": f"{Path(sys.argv[1]).name} (tools/pmc_r04.sh: rocprofv3 --kernel-trace --pmc, one counter group per pass; python bench.py "
                  "--steps 1 --warmup 0 --no-cpu-baseline --verify-pairs 0 --no-pipeline --no-dense --no-ragged)",
-       "kernel": "match_mfma_kernel<0, 8, 4>", "workload": "500 images x 4096 descriptors, 124750 pairs, 2 launches per step",
-       "pairs_per_launch": 62375}
+       "kernel": "match_mfma_kernel<0, 8, 4>"}
+# one step, no warm-up: the kernel's calls are the step's launches (two full batches, or - since the last batch of a
+# multi-batch call is a quarter-size one - three); the counters below are averages over them, like bench.py's
+# avg_kernel_ms
+out["launches_per_step"] = calls
+out["pairs_per_launch"] = 124750 // calls if calls else None
+out["workload"] = f"500 images x 4096 descriptors, 124750 pairs, {calls} launches per step (per-launch figures are averages over them)"
 if "FETCH_SIZE" in cnt:
     out["fetch_size_kb_per_launch"] = cnt["FETCH_SIZE"][2]
     out["fetch_bytes_per_launch_corrected"] = cnt["FETCH_SIZE"][2] * 1024 * 2

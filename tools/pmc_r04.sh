@@ -1,4 +1,4 @@
-# round 4: counters of the match scan at the bench's default workload (500 images x 4096, 2 launches per step), one
+# round 4: counters of the match scan at the bench's default workload (500 images x 4096, the launches of one step), one
 # counter group per pass (--kernel-trace + --pmc only), plus the kernel-trace stats of the default bench command and of
 # the dense leg.  Writes gpurun_out/r04/pmc_match_r04_<tag>.txt, pmc_hbm_r04_<tag>.{txt,json}, rocprofv3_kernel_stats_*.csv
 #   bash tools/pmc_r04.sh [tag]
