@@ -23,7 +23,8 @@ What is recorded per scene (floating-point results as raw uint64 bit patterns):
   * estimate_two_view_geometry and estimate_calibrated_two_view_geometry (two_view_geometry.h:95-151) with the scene's
     options.  These bindings do NOT reseed COLMAP's thread-local generator, so each call is preceded by a
     fundamental_matrix_estimation on a single point: SetPRNGSeed(0) runs, LORANSAC::Estimate returns before drawing;
-  * squared_sampson_error (two_view_geometry.h:161-175) of the matched points under the estimated F.
+  * squared_sampson_error (two_view_geometry.h:161-175) of the matched points under the estimated F;
+  * homography_decomposition (geometry/homography_matrix.h:13-40) on six seeded planes (`record_homography_decomposition`).
 
 The MATCHER pin (round 4; `record_matching`, keys "mg_*").  COLMAP's default CPU matcher is FLANN - approximate,
 randomised, not a parity target - but `SiftCPUFeatureMatcher::MatchGuided` is an EXACT brute-force scan
@@ -207,6 +208,50 @@ def record_matching(pc, module_name, workdir=None):
     return out
 
 
+HD_SEEDS = (7001, 7002, 7003, 7004, 7005, 7006)
+
+
+def hd_scene(seed):
+    """A seeded plane seen by two PINHOLE cameras: (H in pixels, K1, K2, the correspondences in camera coordinates).
+    Pure numpy.  Seed 7006 is a pure rotation (one candidate); the second image's points carry a little noise, so
+    not every correspondence passes the cheirality test of every candidate."""
+    rng = np.random.default_rng(seed)
+    K1 = np.array([[900.0, 0, 640], [0, 910.0, 360], [0, 0, 1]])
+    K2 = np.array([[1100.0, 0, 600], [0, 1090.0, 400], [0, 0, 1]])
+    a = rng.normal(size=3)
+    a /= np.linalg.norm(a)
+    ang = float(rng.uniform(0.05, 0.5))
+    Kx = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+    R = np.eye(3) + np.sin(ang) * Kx + (1 - np.cos(ang)) * Kx @ Kx
+    t = np.zeros(3) if seed == HD_SEEDS[-1] else rng.normal(size=3) * 0.3
+    nrm = np.array([0.1, -0.2, 1.0])
+    nrm /= np.linalg.norm(nrm)
+    d = 5.0
+    n = int(rng.integers(20, 200))
+    rays = np.column_stack([rng.uniform(-0.4, 0.4, (n, 2)), np.ones(n)])
+    X = rays * (d / (rays @ nrm))[:, None]
+    X2 = X @ R.T + t
+    p1 = X[:, :2] / X[:, 2:]
+    p2 = X2[:, :2] / X2[:, 2:] + rng.normal(0, 1e-3, (n, 2))
+    H = K2 @ (R + np.outer(t, nrm) / d) @ np.linalg.inv(K1) * float(rng.uniform(0.5, 2.0))
+    return H, K1, K2, np.ascontiguousarray(p1), np.ascontiguousarray(p2)
+
+
+def record_homography_decomposition(pc):
+    """homography_decomposition (/root/reference/pycolmap/geometry/homography_matrix.h:13-40 = COLMAP's
+    PoseFromHomographyMatrix) on the seeded planes: keys "hd_*" - deterministic, no RANSAC, so against a real pin the
+    results agree to rounding (Eigen's SVD versus the oracle's Jacobi in the normalisation and the triangulation)."""
+    out = {"hd_seeds": np.array(HD_SEEDS, dtype=np.int64)}
+    for s in HD_SEEDS:
+        H, K1, K2, p1, p2 = hd_scene(s)
+        r = pc.homography_decomposition(H, K1, K2, p1, p2)
+        out[f"hd_R_{s}"] = bits(np.asarray(r["R"], dtype=np.float64))
+        out[f"hd_t_{s}"] = bits(np.asarray(r["t"], dtype=np.float64))
+        out[f"hd_n_{s}"] = bits(np.asarray(r["n"], dtype=np.float64))
+        out[f"hd_points3D_{s}"] = bits(np.asarray(r["points3D"], dtype=np.float64).reshape(-1, 3))
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--module", default="pycolmap", help="module to record (the real pycolmap; pycolmap_amd for a dry run)")
@@ -220,6 +265,8 @@ def main():
     out = record_all(pc, args.module, args.limit)
     if not args.no_matching:
         out.update(record_matching(pc, args.module))
+    if hasattr(pc, "homography_decomposition"):
+        out.update(record_homography_decomposition(pc))
     if not int(out["is_reference"]) and Path(args.out).name == "reference_v1.npz":
         raise SystemExit("refusing to write reference_v1.npz from a module that is not the real pycolmap: pass --out")
     np.savez_compressed(args.out, **out)

@@ -114,3 +114,8 @@ def estimate_calibrated_two_view_geometry(camera1, points1, camera2, points2, ma
 
 def squared_sampson_error(points2D1, points2D2, E):
     return list(o.sampson_error(np.asarray(points2D1, np.float64), np.asarray(points2D2, np.float64), np.asarray(E, np.float64)))
+
+
+def homography_decomposition(H, K1, K2, points1, points2):
+    r = o.pose_from_homography(H, K1, K2, points1, points2)
+    return dict(R=r["R"], t=r["t"], n=r["n"], points3D=[x for x in r["points3D"]])

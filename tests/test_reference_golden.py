@@ -171,3 +171,33 @@ def test_hip_guided_match_against_the_reference_rows():
         np.testing.assert_array_equal(got, want, err_msg=f"pair {n} ({a}, {b}) config {cfg}")
         checked += 1
     assert checked >= 3
+
+
+# ---- homography_decomposition (make_reference_golden.record_homography_decomposition) ----
+def _hd_check(ref, fn, who):
+    import make_reference_golden as kit
+    if "hd_seeds" not in ref.files:
+        pytest.skip("this pin was recorded before the homography_decomposition leg existed")
+    exact = not int(ref["is_reference"])
+    for s in ref["hd_seeds"].tolist():
+        H, K1, K2, p1, p2 = kit.hd_scene(int(s))
+        r = fn(H, K1, K2, p1, p2)
+        for k in ("R", "t", "n", "points3D"):
+            want = np.frombuffer(ref[f"hd_{k}_{s}"].tobytes(), dtype=np.float64)
+            got = np.asarray(r[k], dtype=np.float64).reshape(-1)
+            assert got.shape == want.shape, f"{who}: seed {s} {k}: {got.shape} vs {want.shape}"
+            if exact:      # a dry-run file: this repo's own results, bit for bit
+                np.testing.assert_array_equal(got.view(np.uint64), want.view(np.uint64), err_msg=f"{who}: seed {s} {k}")
+            else:          # the reference: the same candidate, the same points, equal to rounding
+                np.testing.assert_allclose(got, want, rtol=1e-9, atol=1e-9, err_msg=f"{who}: seed {s} {k}")
+
+
+def test_oracle_homography_decomposition_against_the_pin():
+    import oracle_pycolmap
+    _hd_check(np.load(PATH), oracle_pycolmap.homography_decomposition, "oracle")
+
+
+@pytest.mark.gpu
+def test_hip_homography_decomposition_against_the_pin():
+    import pycolmap_amd
+    _hd_check(np.load(PATH), pycolmap_amd.homography_decomposition, "pycolmap_amd")
