@@ -334,7 +334,8 @@ def pipeline_leg(ctx_factory, steps: int, warmup: int, cpu_pairs: int, num_image
     t0 = time.perf_counter()
     acc = dict(match_ms=0.0, scan_ms=0.0, cross_ms=0.0, verify_ms=0.0, verify_kernel_ms=0.0, launches=0)
     for _ in range(steps):
-        off, m, mst, tvg, mask, vst = ctx.match_verify_pairs(s1, s2, opts)
+        off = m = tvg = mask = vst = None                          # release the previous results first
+        off, m, mst, tvg, mask, vst = ctx.match_verify_pairs(s1, s2, opts, copy=False)   # views, as a C++ caller reads the results
         acc["match_ms"] += mst["device_ms"]; acc["scan_ms"] += mst["match_kernel_ms"]; acc["cross_ms"] += mst["cross_kernel_ms"]
         acc["verify_ms"] += vst["device_ms"]; acc["verify_kernel_ms"] += vst["kernel_ms"]; acc["launches"] += vst["kernel_launches"]
     dt = time.perf_counter() - t0

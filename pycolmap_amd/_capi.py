@@ -403,9 +403,11 @@ class Context:
         return tvg, mask, stats
 
     def match_verify_pairs(self, slot1, slot2, opts: TvgOpts | None = None, seed: int = 0, max_ratio: float = 0.8,
-                           max_distance: float = 0.7, cross_check: bool = True, kernel: str = "auto"):
+                           max_distance: float = 0.7, cross_check: bool = True, kernel: str = "auto", copy: bool = True):
         """amc_match_verify_pairs: match every pair, then EstimateTwoViewGeometry on its matches where the matcher
-        left them in HBM.  Returns (offsets, matches, match stats, tvg, inlier_mask, verify stats)."""
+        left them in HBM.  Returns (offsets, matches, match stats, tvg, inlier_mask, verify stats).  copy=False: the
+        arrays are views of the library's result buffers (as a C++ caller reads them), each result released when the last
+        array viewing it is garbage collected."""
         s1 = np.ascontiguousarray(slot1, dtype=np.uint32)
         s2 = np.ascontiguousarray(slot2, dtype=np.uint32)
         if s1.shape != s2.shape or s1.ndim != 1:
@@ -416,6 +418,11 @@ class Context:
         self.resident_generation += 1
         _check(self._lib.amc_match_verify_pairs(self._h, s1.ctypes.data_as(C.c_void_p), s2.ctypes.data_as(C.c_void_p),
                                                 s1.size, C.byref(mo), C.byref(o), seed, C.byref(mres), C.byref(vres)))
+        if not copy:
+            offsets, matches, mstats = self._unpack_match(mres, _MatchLease(self._lib, mres))
+            tvg, mask, vstats = self._unpack_verify(vres, matches.shape[0], bool(o.multiple_models),
+                                                    _VerifyLease(self._lib, vres))
+            return offsets, matches, mstats, tvg, mask, vstats
         try:
             offsets, matches, mstats = self._unpack_match(mres)
             tvg, mask, vstats = self._unpack_verify(vres, matches.shape[0], bool(o.multiple_models))
