@@ -257,7 +257,7 @@ struct amc_ctx {
     ScanAccept h_accept{};
     float accept_ratio = 0.f, accept_distance = 0.f;
     bool accept_valid = false;
-    uint32_t* d_scalars = nullptr;  // [0] cursor, [1] queue head, [2] maxsq scratch, [3] resolve errors, [4] stream overrun, [5] mfma items
+    uint32_t* d_scalars = nullptr;  // [0] cursor, [1] queue head, [2] maxsq scratch, [3] resolve errors, [4] stream overrun, [5] mfma items, [7] copy parts taken
     // per-batch scratch
     DevBuf<PairDev> d_pairs;
     DevBuf<Dot4Work> d_work;
@@ -758,6 +758,20 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
     std::vector<uint64_t> rows_left(npairs + 1, 0);
     for (size_t i = npairs; i-- > 0;) rows_left[i] = rows_left[i + 1] + c->slots[slot1[i]].dev.rows_pad;
     const bool even_batches = std::getenv("AMC_MATCH_EVEN_BATCHES") != nullptr;  // (A/B hook)
+    // How a batch's matches reach the host.  The copy of batch k is handed to batch k + 1's forward scan, whose first
+    // few workgroups carry it out (CopyJob, match_mfma.hip); the last batch's copy, and any the next launch cannot
+    // take, goes to the copy stream as a small-grid kernel (launch_host_copy).  AMC_D2H=memcpy: hipMemcpyAsync for
+    // all of them (A/B: its copy kernel takes every CU while PCIe moves the data, and the next scan waits);
+    // AMC_D2H=stream: never fused.
+    const char* d2h_env = std::getenv("AMC_D2H");
+    const int d2h_mode = !d2h_env ? 0 : (std::strcmp(d2h_env, "memcpy") == 0 ? 2 : (std::strcmp(d2h_env, "stream") == 0 ? 1 : 0));
+    struct PendingCopy {
+        void* dst = nullptr;
+        const void* src = nullptr;
+        size_t bytes = 0;
+        int set = -1;  // the batch set whose bev[set][4] marks the copy done; -1: nothing pending
+    } pending;
+    constexpr uint32_t kCopyParts = 8;
     auto carve = [&](size_t begin, int set) {
         Batch b;
         b.begin = b.end = begin;
@@ -963,8 +977,28 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
                                   c->d_grp_item_base.p, c->d_segs.p, c->d_scalars + 5, st);
         (void)hipEventRecord(c->bev[k][0], st);
         if (nord) {  // ... and scan them (the events bracket the scan kernel alone: bench.py's roofline leg)
+            CopyJob job;
+            const uintptr_t ps = reinterpret_cast<uintptr_t>(pending.src), pd = reinterpret_cast<uintptr_t>(pending.dst);
+            const bool take = pending.set >= 0 && d2h_mode == 0 && b.seg_cap > 0 && pending.bytes >= ((size_t)1 << 20) &&
+                              (ps & 15) == (pd & 15);
+            int done_set = -1;
+            if (take) {  // the previous batch's matches ride in this launch; head / tail bytes around the 16-byte units first
+                const size_t head = (ps & 15) ? 16 - (ps & 15) : 0, n16 = (pending.bytes - head) / 16;
+                const size_t tail = pending.bytes - head - n16 * 16;
+                if (head) (void)hipMemcpyAsync(pending.dst, pending.src, head, hipMemcpyDeviceToHost, st);
+                if (tail)
+                    (void)hipMemcpyAsync(static_cast<char*>(pending.dst) + head + n16 * 16,
+                                         static_cast<const char*>(pending.src) + head + n16 * 16, tail, hipMemcpyDeviceToHost, st);
+                job.src = static_cast<const char*>(pending.src) + head;
+                job.dst = static_cast<char*>(pending.dst) + head;
+                job.n16 = n16;
+                job.parts = kCopyParts;
+                done_set = pending.set;
+                pending.set = -1;
+            }
             launch_match_mfma(0, c->d_segs.p, c->d_scalars + 5, (uint32_t)std::min<size_t>(b.seg_cap, 0xFFFFFFFFu),
-                              c->d_scalars + 1, c->d_accmask.p, c->d_accept, st);
+                              c->d_scalars + 1, c->d_accmask.p, c->d_accept, st, job, c->d_scalars + 7);
+            if (done_set >= 0) (void)hipEventRecord(c->bev[done_set][4], st);  // that batch's matches are on the host when this scan is done
         }
         if (b.nwork_grid)
             launch_match_guided_grid(c->d_imgs.p, c->d_grids.p, c->d_pairs.p, c->d_work.p, (uint32_t)b.nwork_grid,
@@ -1070,17 +1104,33 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
                 !hc(hipMemcpyAsync(c->d_csr.p, c->h_csr[k].p, b.nb * sizeof(uint64_t), hipMemcpyHostToDevice, st), "H2D csr"))
                 return false;
             launch_reorder_matches(c->d_pair_off.p, c->d_pair_cnt.p, c->d_csr.p, (uint32_t)b.nb, c->d_matches.p, c->d_keep.p, st);
-            // the copy to the host runs on its own stream, beside the next batch's kernels (which write d_matches
-            // and, later, d_keep beyond this batch - never what is being copied)
-            if (!hc(hipGetLastError(), "reorder launch") || !hc(hipEventRecord(c->cev[k], st), "event record") ||
-                !hc(hipStreamWaitEvent(c->copy_stream, c->cev[k], 0), "stream wait") ||
-                !hc(hipMemcpyAsync(priv->matches.p + 2 * keep_used, c->d_keep.p + 2 * keep_used,
-                                   (size_t)b.total * 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->copy_stream), "D2H matches"))
-                return false;
+            // the copy to the host happens beside the next batch's kernels (which write d_matches and, later, d_keep
+            // beyond this batch - never what is being copied): flush_copy() or the next enqueue() issues it
+            if (!hc(hipGetLastError(), "reorder launch")) return false;
+            pending.dst = priv->matches.p + 2 * keep_used;
+            pending.src = c->d_keep.p + 2 * keep_used;
+            pending.bytes = (size_t)b.total * 2 * sizeof(uint32_t);
+            pending.set = k;
             keep_used += b.total;
-            return hc(hipEventRecord(c->bev[k][4], c->copy_stream), "event record");
+            return true;
         }
         return hc(hipEventRecord(c->bev[k][4], st), "event record");
+    };
+    // the pending copy on the copy stream (the last batch's, or one the next launch does not take)
+    auto flush_copy = [&]() {
+        if (pending.set < 0) return true;
+        const int k = pending.set;
+        pending.set = -1;
+        if (!hc(hipEventRecord(c->cev[k], st), "event record") || !hc(hipStreamWaitEvent(c->copy_stream, c->cev[k], 0), "stream wait"))
+            return false;
+        if (d2h_mode == 2) {
+            if (!hc(hipMemcpyAsync(pending.dst, pending.src, pending.bytes, hipMemcpyDeviceToHost, c->copy_stream), "D2H matches"))
+                return false;
+        } else {
+            launch_host_copy(pending.dst, pending.src, pending.bytes, c->copy_stream);
+            if (!hc(hipGetLastError(), "D2H matches")) return false;
+        }
+        return hc(hipEventRecord(c->bev[k][4], c->copy_stream), "event record");
     };
     // append the batch's matches to the result CSR (pairs keep the caller's order)
     auto scatter = [&](Batch& b) {
@@ -1116,6 +1166,7 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
             t_collect += since(tp);
             tp = std::chrono::steady_clock::now();
             if (ok && have_next) ok = enqueue(next);
+            ok = ok && flush_copy();  // (not taken by a scan launch: the last batch's, a small one, dot4-only batches)
             t_enqueue += since(tp);
             tp = std::chrono::steady_clock::now();
             ok = ok && scatter(cur);

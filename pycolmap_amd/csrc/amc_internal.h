@@ -182,8 +182,18 @@ void launch_build_segments(int mode, const ImageDev* imgs, const PairDev* pairs,
 // instead of re-reading and re-testing every row.
 // accept_dev: the scan's accept-bit thresholds for the call's options (scan_accept.h), in device memory.
 struct ScanAccept;
+// A device -> pinned-host copy that rides in a forward scan launch: the first `parts` workgroups to start copy one part
+// each (16-byte units, PCIe-bound) and then join the scan's queue like the others (match_mfma.hip, "the previous
+// batch's matches").  parts = 0: nothing to copy.
+struct CopyJob {
+    const void* src = nullptr;
+    void* dst = nullptr;
+    unsigned long long n16 = 0;
+    uint32_t parts = 0, pad_ = 0;
+};
 void launch_match_mfma(int mode, const SegDesc* segs, const uint32_t* nitems_dev, uint32_t max_items,
-                       uint32_t* queue_head, uint32_t* accmask, const ScanAccept* accept_dev, hipStream_t s);
+                       uint32_t* queue_head, uint32_t* accmask, const ScanAccept* accept_dev, hipStream_t s,
+                       const CopyJob& job = CopyJob(), uint32_t* copy_head = nullptr);
 int match_mfma_shape();  // waves per workgroup in use (8 or 4)
 
 void launch_resolve_index(int side, const ImageDev* imgs, const PairDev* pairs, uint32_t npairs,
@@ -204,6 +214,8 @@ void launch_finalize(const ImageDev* imgs, const PairDev* pairs, uint32_t npairs
                      const float* acos_lut, FinalizeParams fp, uint32_t* cursor, uint32_t capacity,
                      uint32_t* pair_off, uint32_t* pair_cnt, uint32_t* matches, hipStream_t s);
 
+// match_common.hip: device -> pinned host copy by a small-grid kernel that co-resides with the scan (bytes % 8 == 0)
+void launch_host_copy(void* dst_pinned, const void* src_dev, size_t bytes, hipStream_t s);
 void launch_reorder_matches(const uint32_t* src_off, const uint32_t* cnt, const uint64_t* dst_off, uint32_t npairs,
                             const uint32_t* src, uint32_t* dst, hipStream_t s);
 

@@ -811,6 +811,48 @@ void launch_reorder_matches(const uint32_t* src_off, const uint32_t* cnt, const 
                        reinterpret_cast<const uint2*>(src), reinterpret_cast<uint2*>(dst));
 }
 
+// ---------------------------------------------------------------------------------------
+// A batch's matches to the host, beside the NEXT batch's kernels.  hipMemcpyAsync(DeviceToHost) of a large buffer
+// is executed by a runtime copy kernel whose grid covers the whole buffer: launched in the gap between two
+// batches it takes every CU, moves 400 MB at PCIe speed for 10 ms, and the persistent scan behind it starts when
+// it is done (kernel trace of the dense set: 19 ms of 292 exposed).  This kernel is the same copy with a grid of a
+// few dozen workgroups and a dozen registers: it fits beside the scan's waves on CUs the scan fills (234 of 256
+// registers x 2 waves per SIMD leave room for a small wave) and PCIe, not the CUs, bounds it.  dst: pinned host
+// memory (hipHostMalloc: the same pointer on the device); bytes a multiple of 8.
+// ---------------------------------------------------------------------------------------
+constexpr int kHostCopyBlocks = 64;
+__global__ __launch_bounds__(256) void host_copy_kernel(uint4* __restrict__ dst, const uint4* __restrict__ src, size_t n16,
+                                                        uint2* __restrict__ dst_tail, const uint2* __restrict__ src_tail,
+                                                        uint32_t tail8) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // four independent 16-byte loads in flight per lane, then four posted writes
+    for (; i + 3 * stride < n16; i += 4 * stride) {
+        const uint4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+        dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+    }
+    for (; i < n16; i += stride) dst[i] = src[i];
+    if (blockIdx.x == 0 && threadIdx.x < tail8) dst_tail[threadIdx.x] = src_tail[threadIdx.x];
+}
+void launch_host_copy(void* dst_pinned, const void* src_dev, size_t bytes, hipStream_t s) {
+    if (bytes == 0) return;
+    // both pointers are 8-byte aligned (matches are uint32 pairs); the bulk runs from the first 16-byte boundary
+    const uintptr_t a = reinterpret_cast<uintptr_t>(src_dev);
+    const size_t head = (a & 15) && ((reinterpret_cast<uintptr_t>(dst_pinned) & 15) == (a & 15)) ? 16 - (a & 15) : 0;
+    const bool same_phase = (reinterpret_cast<uintptr_t>(dst_pinned) & 15) == (a & 15);
+    if (!same_phase || bytes < ((size_t)1 << 20)) {  // small, or the two sides are not 16-byte congruent: the runtime's copy
+        (void)hipMemcpyAsync(dst_pinned, src_dev, bytes, hipMemcpyDeviceToHost, s);
+        return;
+    }
+    const char* sp = static_cast<const char*>(src_dev);
+    char* dp = static_cast<char*>(dst_pinned);
+    if (head) (void)hipMemcpyAsync(dp, sp, head, hipMemcpyDeviceToHost, s);
+    const size_t body = bytes - head, n16 = body / 16, tail = body - n16 * 16;
+    hipLaunchKernelGGL(host_copy_kernel, dim3(kHostCopyBlocks), dim3(256), 0, s, reinterpret_cast<uint4*>(dp + head),
+                       reinterpret_cast<const uint4*>(sp + head), n16, reinterpret_cast<uint2*>(dp + head + n16 * 16),
+                       reinterpret_cast<const uint2*>(sp + head + n16 * 16), (uint32_t)(tail / 8));
+}
+
 void launch_finalize(const ImageDev* imgs, const PairDev* pairs, uint32_t npairs,
                      const Top2* rowbuf, const Top2* colbuf, const uint32_t* accmask,
                      const float* acos_lut, FinalizeParams fp, uint32_t* cursor, uint32_t capacity,

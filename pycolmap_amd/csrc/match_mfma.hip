@@ -138,12 +138,30 @@ struct YFrag {
     i32x16 ci;   // 128*SY_j for this lane's 16 Y rows (MFMA C operand)
 };
 
+// The previous batch's matches on their way to the host (CopyJob, amc_internal.h).  The runtime's own copy kernel
+// covers the buffer with its grid and takes every CU while PCIe moves 400 MB (10 ms, and the scan behind it waits:
+// kernel trace of the dense set, 19 ms of 292 per call); a small copy kernel on a second stream shares a hardware queue
+// with the scan's stream more often than not.  So the copy rides in the scan's own launch: the first `parts`
+// workgroups to arrive take one part each - 512 lanes with four 16-byte loads in flight per lane saturate PCIe from
+// a handful of workgroups - and then scan like the others; the scan loses parts x 10 ms of one workgroup's time.
+__device__ __noinline__ void copy_part(const uint4* __restrict__ src, uint4* __restrict__ dst, unsigned long long b,
+                                       unsigned long long e, int tid, int nthreads) {
+    unsigned long long i = b + (unsigned long long)tid;
+    const unsigned long long st = (unsigned long long)nthreads;
+    for (; i + 3 * st < e; i += 4 * st) {
+        const uint4 v0 = src[i], v1 = src[i + st], v2 = src[i + 2 * st], v3 = src[i + 3 * st];
+        dst[i] = v0; dst[i + st] = v1; dst[i + 2 * st] = v2; dst[i + 3 * st] = v3;
+    }
+    for (; i < e; i += st) dst[i] = src[i];
+}
+
 template <int MODE, int W, int XT>
 __global__ __launch_bounds__(64 * W) void match_mfma_kernel(const SegDesc* __restrict__ segs,
                                                             const uint32_t* __restrict__ nitems_p,
                                                             uint32_t* __restrict__ queue_head,
                                                             uint32_t* __restrict__ accmask,
-                                                            const ScanAccept* __restrict__ accept) {
+                                                            const ScanAccept* __restrict__ accept,
+                                                            CopyJob job, uint32_t* __restrict__ copy_head) {
     constexpr int SPW = XT / kSegTiles;  // segments per wave
     constexpr bool BA = (W == 4);        // X fragments in AGPRs (one wave per SIMD: 512 registers)
     static_assert(XT % kSegTiles == 0 && W * SPW == kSegsPerItem, "a workgroup takes one item");
@@ -155,6 +173,17 @@ __global__ __launch_bounds__(64 * W) void match_mfma_kernel(const SegDesc* __res
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, lh = lane >> 5;
     volatile uint32_t* s_q = reinterpret_cast<volatile uint32_t*>(smem + kOffQ);
+    if constexpr (MODE == 0) {
+        if (job.parts) {  // (wave-uniform: a kernel argument)
+            __shared__ uint32_t s_part;
+            if (tid == 0) s_part = atomicAdd(copy_head, 1u);
+            __syncthreads();
+            const uint32_t part = s_part;
+            if (part < job.parts)
+                copy_part(static_cast<const uint4*>(job.src), static_cast<uint4*>(job.dst), job.n16 * part / job.parts,
+                          job.n16 * (part + 1) / job.parts, tid, 64 * W);
+        }
+    }
     const uint32_t nitems = *nitems_p;
     const ScanAccept sa = *accept;  // twelve scalar registers for the whole kernel (re-read per row block it is four dependent scalar-cache round trips per X tile)
 
@@ -733,17 +762,21 @@ int match_mfma_shape() {
 }
 
 void launch_match_mfma(int mode, const SegDesc* segs, const uint32_t* nitems_dev, uint32_t max_items,
-                       uint32_t* queue_head, uint32_t* accmask, const ScanAccept* accept_dev, hipStream_t s) {
-    if (max_items == 0) return;
+                       uint32_t* queue_head, uint32_t* accmask, const ScanAccept* accept_dev, hipStream_t s,
+                       const CopyJob& job_in, uint32_t* copy_head) {
+    if (max_items == 0) return;  // (the caller checks: a job is only handed to a launch that happens)
+    CopyJob job = (mode == 0 && copy_head) ? job_in : CopyJob();
+    if (job.parts) (void)hipMemsetAsync(copy_head, 0, sizeof(uint32_t), s);
     int dev = 0, cus = 256;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const uint32_t grid = max_items < (uint32_t)cus ? max_items : (uint32_t)cus;  // 1 WG per CU
+    if (job.parts > grid) job.parts = grid;  // every part needs a workgroup
     (void)hipMemsetAsync(queue_head, 0, sizeof(uint32_t), s);
     const bool w4 = match_mfma_shape() == 4;
 #define AMC_LAUNCH(M, W, XT)                                                                             \
     hipLaunchKernelGGL((match_mfma_kernel<M, W, XT>), dim3(grid), dim3(64 * W), 0, s, segs, nitems_dev, \
-                       queue_head, accmask, accept_dev)
+                       queue_head, accmask, accept_dev, job, copy_head)
     if (mode == 0) {
         if (w4) AMC_LAUNCH(0, 4, 8); else AMC_LAUNCH(0, 8, 4);
     } else {
