@@ -297,6 +297,11 @@ int amc_upload_camera(amc_ctx* ctx, uint32_t slot, int32_t model_id, uint64_t wi
  * host libm for the fisheye family and FOV, whose distortion calls atan / tan / sin / cos). */
 int amc_cam_from_img(amc_ctx* ctx, int32_t model_id, const double* params, int32_t num_params,
                      const double* xy, size_t n, double* uv);
+/* Camera::ImgFromCam (/root/reference/pycolmap/scene/camera.h:166-196, "img_from_cam"): n points of the normalised image
+ * plane (uv: n x 2) -> pixels (xy: n x 2), the inverse direction of amc_cam_from_img with the same split (device kernel
+ * for the pinhole and polynomial-distortion models, host libm for the fisheye family and FOV). */
+int amc_img_from_cam(amc_ctx* ctx, int32_t model_id, const double* params, int32_t num_params,
+                     const double* uv, size_t n, double* xy);
 
 /* EstimateTwoViewGeometry for every listed pair.  matches of pair p: uint32 (idx1, idx2) rows
  * matches[2*match_offsets[p] .. 2*match_offsets[p+1]).  The PRNG is re-seeded with `seed` at the

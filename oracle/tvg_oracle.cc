@@ -1165,6 +1165,46 @@ Pt cam_from_img(const Camera& c, const Pt& p) {
     }
     return Pt{u, v};
 }
+// Camera::ImgFromCam (colmap/sensor/models.h): normalised image plane -> pixels.  Every model: distort, then
+// x = f1 * (u + du) + c1, y = f2 * (v + dv) + c2; FOV's Distortion returns the distorted point itself; the thin-prism
+// fisheye first maps the plane to the equidistant angle (theta = atan r).
+Pt img_from_cam(const Camera& c, const Pt& p) {
+    const ModelInfo& mi = kModels[c.model_id];
+    const double f1 = c.params[0], f2 = c.params[mi.num_focal - 1];
+    const double c1 = c.params[mi.num_focal], c2 = c.params[mi.num_focal + 1];
+    const double* extra = c.params + mi.num_focal + 2;
+    double u = p.x, v = p.y;
+    if (c.model_id <= 1) return Pt{f1 * u + c1, f2 * v + c2};
+    if (c.model_id == 7) {  // FOVCameraModel::Distortion
+        const double omega = extra[0];
+        const double kEpsilon = 1e-4;
+        const double radius2 = u * u + v * v;
+        const double omega2 = omega * omega;
+        double factor;
+        if (omega2 < kEpsilon) {
+            factor = (omega2 * radius2) / 3.0 - omega2 / 12.0 + 1.0;
+        } else if (radius2 < kEpsilon) {
+            const double tan_half_omega = std::tan(omega / 2.0);
+            factor = (-2.0 * tan_half_omega * (4.0 * radius2 * tan_half_omega * tan_half_omega - 3.0)) / (3.0 * omega);
+        } else {
+            const double radius = std::sqrt(radius2);
+            const double numerator = std::atan(radius * 2.0 * std::tan(omega / 2.0));
+            factor = numerator / (radius * omega);
+        }
+        return Pt{f1 * (u * factor) + c1, f2 * (v * factor) + c2};
+    }
+    if (c.model_id == 10) {
+        const double r = std::sqrt(u * u + v * v);
+        if (r > std::numeric_limits<double>::epsilon()) {
+            const double theta = std::atan(r);
+            u = theta * u / r;
+            v = theta * v / r;
+        }
+    }
+    double du, dv;
+    model_distortion(c.model_id, extra, u, v, &du, &dv);
+    return Pt{f1 * (u + du) + c1, f2 * (v + dv) + c2};
+}
 double cam_from_img_threshold(const Camera& c, double threshold) {
     const ModelInfo& mi = kModels[c.model_id];
     double mean_focal_length = 0;
@@ -2222,6 +2262,17 @@ int oracle_cam_from_img(const oracle_camera* cam, const double* xy, size_t n, do
         const Pt q = cam_from_img(c, Pt{xy[2 * i], xy[2 * i + 1]});
         uv[2 * i] = q.x;
         uv[2 * i + 1] = q.y;
+    }
+    return 0;
+}
+
+int oracle_img_from_cam(const oracle_camera* cam, const double* uv, size_t n, double* xy) {
+    const Camera c = to_cam(cam);
+    if (!camera_supported(c)) return -1;
+    for (size_t i = 0; i < n; ++i) {
+        const Pt q = img_from_cam(c, Pt{uv[2 * i], uv[2 * i + 1]});
+        xy[2 * i] = q.x;
+        xy[2 * i + 1] = q.y;
     }
     return 0;
 }

@@ -29,7 +29,7 @@ EXPORTED_SYMBOLS = [
     "amc_verify_result_free", "amc_upload_points_f64", "amc_ransac_pairs", "amc_ransac_result_free",
     "amc_squared_sampson_error", "amc_match_guided_pairs", "amc_ctx_grow_slots", "amc_pose_pairs",
     "amc_cam_from_img", "amc_match_verify_pairs", "amc_ctx_trim", "amc_ctx_resident_matches",
-    "amc_homography_decomposition",
+    "amc_homography_decomposition", "amc_img_from_cam",
 ]
 RANSAC_F, RANSAC_H, RANSAC_E = 0, 1, 2
 RANSAC_KINDS = {"F": RANSAC_F, "H": RANSAC_H, "E": RANSAC_E}
@@ -206,6 +206,7 @@ def load() -> C.CDLL:
     lib.amc_ransac_result_free.argtypes = [C.POINTER(RansacResult)]
     lib.amc_ransac_result_free.restype = None
     lib.amc_cam_from_img.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.amc_img_from_cam.argtypes = lib.amc_cam_from_img.argtypes
     lib.amc_squared_sampson_error.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
                                               C.c_void_p]
     lib.amc_pose_pairs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
@@ -545,6 +546,16 @@ class Context:
         out = np.empty_like(xy)
         _check(self._lib.amc_cam_from_img(self._h, mid, p.ctypes.data_as(C.c_void_p), p.size,
                                           xy.ctypes.data_as(C.c_void_p), xy.shape[0], out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def img_from_cam(self, model: str | int, params, points) -> np.ndarray:
+        """Camera::ImgFromCam of an N x 2 array of normalised image-plane points."""
+        p = np.ascontiguousarray(params, dtype=np.float64)
+        uv = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 2)
+        mid = CAMERA_MODELS[model] if isinstance(model, str) else int(model)
+        out = np.empty_like(uv)
+        _check(self._lib.amc_img_from_cam(self._h, mid, p.ctypes.data_as(C.c_void_p), p.size, uv.ctypes.data_as(C.c_void_p),
+                                          uv.shape[0], out.ctypes.data_as(C.c_void_p)))
         return out
 
     def upload_camera(self, slot: int, model: str | int, width: int, height: int, params,

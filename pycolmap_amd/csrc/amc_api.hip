@@ -1484,6 +1484,39 @@ int amc_cam_from_img(amc_ctx* c, int32_t model_id, const double* params, int32_t
     return rc;
 }
 
+int amc_img_from_cam(amc_ctx* c, int32_t model_id, const double* params, int32_t num_params, const double* uv,
+                     size_t n, double* xy) {
+    if (!c) return fail(AMC_E_INVALID, "amc_img_from_cam: ctx is NULL");
+    if (cam::num_params(model_id) < 0) return fail(AMC_E_INVALID, "amc_img_from_cam: unknown camera model id %d", model_id);
+    if (num_params != cam::num_params(model_id) || !params)
+        return fail(AMC_E_INVALID, "amc_img_from_cam: camera model %d takes %d parameters, got %d", model_id,
+                    cam::num_params(model_id), num_params);
+    if (n == 0) return AMC_OK;
+    if (!uv || !xy) return fail(AMC_E_INVALID, "amc_img_from_cam: NULL points");
+    if (n > 0x7FFFFFFFull) return fail(AMC_E_INVALID, "amc_img_from_cam: too many points");
+    if (cam::needs_libm(model_id)) {
+        for (size_t i = 0; i < n; ++i) cam::img_from_cam(model_id, params, uv[2 * i], uv[2 * i + 1], xy[2 * i], xy[2 * i + 1]);
+        return AMC_OK;
+    }
+    HIPCHK(hipSetDevice(c->device));
+    CameraDev cd{};
+    cd.model_id = model_id;
+    for (int i = 0; i < num_params; ++i) cd.params[i] = params[i];
+    DevBuf<double> buf;
+    HIPCHK(buf.ensure(4 * n));
+    hipStream_t st = c->stream;
+    int rc = AMC_OK;
+    auto chk = [&](hipError_t e, const char* what) {
+        if (e != hipSuccess && rc == AMC_OK) rc = fail(AMC_E_HIP, "amc_img_from_cam: %s: %s", what, hipGetErrorString(e));
+    };
+    chk(hipMemcpyAsync(buf.p, uv, 2 * n * sizeof(double), hipMemcpyHostToDevice, st), "copy in");
+    if (rc == AMC_OK) chk(launch_project(buf.p, (uint32_t)n, cd, buf.p + 2 * n, st), "launch");
+    if (rc == AMC_OK) chk(hipMemcpyAsync(xy, buf.p + 2 * n, 2 * n * sizeof(double), hipMemcpyDeviceToHost, st), "copy out");
+    chk(hipStreamSynchronize(st), "sync");
+    buf.release();
+    return rc;
+}
+
 static void fill_tvg_images(const amc_ctx* c, std::vector<TvgImage>& timgs) {
     timgs.resize(c->slots.size());
     for (size_t i = 0; i < timgs.size(); ++i) {

@@ -239,6 +239,7 @@ struct TvgImage {
 // Camera::CamFromImg of every keypoint of one image (polynomial distortion models only; camera.hip)
 hipError_t launch_undistort(const float* kp, const double* kp64, uint32_t rows, const CameraDev& cam, double* kpn,
                             hipStream_t s);
+hipError_t launch_project(const double* uv, uint32_t n, const CameraDev& cam, double* xy, hipStream_t s);
 struct TvgPair {
     uint32_t slot1, slot2;
     uint64_t match_off;   // into the batch's match array (in matches, not uint32s)

@@ -30,4 +30,19 @@ hipError_t launch_undistort(const float* kp, const double* kp64, uint32_t rows, 
     return hipGetLastError();
 }
 
+// Camera::ImgFromCam of n points of the normalised image plane (polynomial models; the libm models run on the host)
+__global__ __launch_bounds__(256) void project_kernel(const double* __restrict__ uv, uint32_t n, CameraDev cam, double* __restrict__ xy) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double x, y;
+    cam::img_from_cam(cam.model_id, cam.params, uv[2 * (size_t)i], uv[2 * (size_t)i + 1], x, y);
+    xy[2 * (size_t)i] = x;
+    xy[2 * (size_t)i + 1] = y;
+}
+hipError_t launch_project(const double* uv, uint32_t n, const CameraDev& cam, double* xy, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(project_kernel, dim3((n + 255) / 256), dim3(256), 0, s, uv, n, cam, xy);
+    return hipGetLastError();
+}
+
 }  // namespace amc

@@ -184,6 +184,26 @@ inline void undistortion_fov(const double* e, double u, double v, double& ou, do
     ou = u * factor;
     ov = v * factor;
 }
+// FOVCameraModel::Distortion: returns the distorted point itself (not an offset)
+inline void distortion_fov(const double* e, double u, double v, double& ou, double& ov) {
+    const double omega = e[0];
+    const double kEpsilon = 1e-4;
+    const double radius2 = u * u + v * v;
+    const double omega2 = omega * omega;
+    double factor;
+    if (omega2 < kEpsilon) {
+        factor = (omega2 * radius2) / 3.0 - omega2 / 12.0 + 1.0;
+    } else if (radius2 < kEpsilon) {
+        const double tan_half_omega = std::tan(omega / 2.0);
+        factor = (-2.0 * tan_half_omega * (4.0 * radius2 * tan_half_omega * tan_half_omega - 3.0)) / (3.0 * omega);
+    } else {
+        const double radius = std::sqrt(radius2);
+        const double numerator = std::atan(radius * 2.0 * std::tan(omega / 2.0));
+        factor = numerator / (radius * omega);
+    }
+    ou = u * factor;
+    ov = v * factor;
+}
 #endif
 
 AMC_HD void distortion(int model, const double* e, double u, double v, double& du, double& dv) {
@@ -270,6 +290,40 @@ AMC_HD void cam_from_img(int model, const double* p, double x, double y, double&
         }
     }
 #endif
+}
+
+// Camera::ImgFromCam: normalised image plane (u, v) -> pixel (x, y).  On the device only the models with
+// !needs_libm(model) may be passed.
+AMC_HD void img_from_cam(int model, const double* p, double u, double v, double& x, double& y) {
+    const int nf = num_focal(model);
+    const double f1 = p[0], f2 = p[nf - 1], c1 = p[nf], c2 = p[nf + 1];
+    if (is_pinhole(model)) {
+        x = f1 * u + c1;
+        y = f2 * v + c2;
+        return;
+    }
+    const double* e = p + nf + 2;
+#if !defined(__HIP_DEVICE_COMPILE__)
+    if (model == FOV) {
+        double du, dv;
+        distortion_fov(e, u, v, du, dv);
+        x = f1 * du + c1;
+        y = f2 * dv + c2;
+        return;
+    }
+    if (model == THIN_PRISM_FISHEYE) {
+        const double r = std::sqrt(u * u + v * v);
+        if (r > 2.220446049250313e-16) {
+            const double theta = std::atan(r);
+            u = theta * u / r;
+            v = theta * v / r;
+        }
+    }
+#endif
+    double du, dv;
+    distortion(model, e, u, v, du, dv);
+    x = f1 * (u + du) + c1;
+    y = f2 * (v + dv) + c2;
 }
 
 }  // namespace cam

@@ -114,6 +114,7 @@ inline int ParseCameraModel(const py::object& o) {
 }
 
 py::object CamFromImgPoints(const PyCamera& c, const py::object& points);  // below (uses the estimator context)
+py::object ImgFromCamPoints(const PyCamera& c, const py::object& points);
 
 inline void BindCamera(py::module_& m) {
     py::dict members("INVALID"_a = -1);
@@ -199,6 +200,9 @@ inline void BindCamera(py::module_& m) {
              "Convert pixel threshold in image plane to world space.")
         .def("cam_from_img", &CamFromImgPoints, "image_points"_a,
              "Project point(s) in image plane to world / infinity: one point (2,) or an N x 2 array.")
+        .def("img_from_cam", &ImgFromCamPoints, "world_points"_a,
+             "Project point(s) from the camera frame to image coordinates: N x 2 points of the normalised image plane, or "
+             "N x 3 points in front of the camera (divided by their depth first).")
         .def("verify_params",
              [](const PyCamera& c) {
                  const CameraModelInfo* mi = FindCameraModel(c.model);
@@ -353,6 +357,34 @@ inline py::object CamFromImgPoints(const PyCamera& c, const py::object& points) 
         EstCheck(amc_cam_from_img(E.Get(), c.model, c.params.data(), static_cast<int32_t>(c.params.size()), arr.data(), n,
                                   out.mutable_data()),
                  "amc_cam_from_img");
+    }
+    if (single) return out.attr("reshape")(2);
+    return std::move(out);
+}
+// Camera::ImgFromCam on N x 2 (normalised plane) or N x 3 (hnormalized first) points: /root/reference/pycolmap/scene/camera.h:166-196
+inline py::object ImgFromCamPoints(const PyCamera& c, const py::object& points) {
+    c.CheckParams();
+    auto arr = py::array_t<double, py::array::c_style | py::array::forcecast>::ensure(points);
+    if (!arr) throw py::value_error("img_from_cam: points must be convertible to a float64 array");
+    const bool single = arr.ndim() == 1 && (arr.shape(0) == 2 || arr.shape(0) == 3);
+    if (!single && !(arr.ndim() == 2 && (arr.shape(1) == 2 || arr.shape(1) == 3)) && arr.size() != 0)
+        throw py::value_error("img_from_cam: expected one point, an N x 2 or an N x 3 array");
+    const py::ssize_t cols = arr.size() == 0 ? 2 : (single ? arr.shape(0) : arr.shape(1));
+    const size_t n = static_cast<size_t>(arr.size() / cols);
+    std::vector<double> uv(2 * n);
+    for (size_t i = 0; i < n; ++i) {
+        const double* q = arr.data() + cols * i;
+        uv[2 * i] = cols == 3 ? q[0] / q[2] : q[0];
+        uv[2 * i + 1] = cols == 3 ? q[1] / q[2] : q[1];
+    }
+    py::array_t<double> out({static_cast<py::ssize_t>(n), static_cast<py::ssize_t>(2)});
+    {
+        py::gil_scoped_release release;
+        EstimatorCtx& E = TheEstimatorCtx();
+        std::lock_guard<std::mutex> lock(E.mu);
+        EstCheck(amc_img_from_cam(E.Get(), c.model, c.params.data(), static_cast<int32_t>(c.params.size()), uv.data(), n,
+                                  out.mutable_data()),
+                 "amc_img_from_cam");
     }
     if (single) return out.attr("reshape")(2);
     return std::move(out);

@@ -258,6 +258,16 @@ def cam_from_img(cam: OCamera, points) -> np.ndarray:
     return out
 
 
+def img_from_cam(cam: OCamera, points) -> np.ndarray:
+    """Camera::ImgFromCam of an N x 2 array of normalised image-plane points."""
+    lib = load()
+    lib.oracle_img_from_cam.restype = C.c_int
+    uv = np.ascontiguousarray(points, np.float64).reshape(-1, 2)
+    out = np.empty_like(uv)
+    assert lib.oracle_img_from_cam(C.byref(cam), _p(uv), C.c_size_t(len(uv)), _p(out)) == 0
+    return out
+
+
 def cam_from_img_threshold(cam: OCamera, threshold: float) -> float:
     lib = load()
     lib.oracle_cam_from_img_threshold.restype = C.c_double

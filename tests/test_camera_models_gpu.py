@@ -26,6 +26,28 @@ def test_cam_from_img_bit_exact(amc_ctx, model):
     assert len(amc_ctx.cam_from_img(model, prm, np.zeros((0, 2)))) == 0
 
 
+@pytest.mark.parametrize("model", MODELS)
+def test_img_from_cam_bit_exact(amc_ctx, model):
+    """Camera::ImgFromCam (amc_img_from_cam: device kernel for the polynomial models, host libm for the others) against
+    the oracle, and through the Camera binding for N x 2 and N x 3 points."""
+    import pycolmap_amd as pycolmap
+    rng = np.random.default_rng(6)
+    prm = synth.EXAMPLE_CAMERAS[model]
+    uv = rng.uniform(-0.5, 0.5, size=(5000, 2))
+    uv[0] = 0.0
+    got = amc_ctx.img_from_cam(model, prm, uv)
+    want = o.img_from_cam(o.make_camera(model, 1600, 1200, prm), uv)
+    np.testing.assert_array_equal(got.view(np.uint64), want.view(np.uint64))
+    assert len(amc_ctx.img_from_cam(model, prm, np.zeros((0, 2)))) == 0
+    cam = pycolmap.Camera(model=model, width=1600, height=1200, params=list(prm))
+    np.testing.assert_array_equal(cam.img_from_cam(uv[:100]), want[:100])
+    z = rng.uniform(1.0, 9.0, 100)
+    X = np.column_stack([uv[:100] * z[:, None], z])
+    np.testing.assert_array_equal(cam.img_from_cam(X), o.img_from_cam(o.make_camera(model, 1600, 1200, prm), X[:, :2] / X[:, 2:]))
+    assert cam.img_from_cam(uv[5]).shape == (2,)
+    np.testing.assert_allclose(cam.cam_from_img(cam.img_from_cam(uv[:50])), uv[:50], atol=1e-8)
+
+
 def test_cam_from_img_rejects_bad_parameter_vectors(amc_ctx):
     with pytest.raises(_capi.AmcError):
         amc_ctx.cam_from_img("OPENCV", (1000.0, 1000.0, 800.0, 600.0), np.zeros((1, 2)))     # 4 of 8 parameters
