@@ -246,6 +246,10 @@ struct amc_ctx {
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr;  // D2H of a batch's matches, beside the next batch's kernels
     hipEvent_t cev[2] = {nullptr, nullptr};  // batch k's matches are in place in d_keep
+    // verification: the launches of the larger size classes (few pairs, each several milliseconds on one wave) run on this
+    // stream beside the bulk class on `stream` instead of behind it, with their own pair lists and workspaces
+    hipStream_t aux_stream = nullptr;
+    hipEvent_t aev[2] = {nullptr, nullptr};
     std::vector<Slot> slots;
     bool table_dirty = true;
     DevBuf<ImageDev> d_imgs;
@@ -292,6 +296,9 @@ struct amc_ctx {
     DevBuf<TvgPair> d_tpairs;
     DevBuf<uint32_t> d_tmatches, d_ttabs;
     DevBuf<TvgPair> d_tpairs_e;       // the calibrated pairs of a launch, in the essential-matrix kernel's queue order
+    DevBuf<TvgPair> d_tpairs2, d_tpairs_e2;  // the same for a class launched on aux_stream
+    DevBuf<double> d_tws2;
+    DevBuf<uint8_t> d_tmaskws2;
     DevBuf<TvgEState> d_estate;       // essential-matrix kernel -> F/H kernel hand-off, by pair
     DevBuf<uint8_t> d_emask;          // ... and the E RANSAC's inlier masks (same layout as d_toutmask)
     // tempered words of std::mt19937(seed): the sample stream every pair consumes (TvgParams::stream)
@@ -375,6 +382,14 @@ int amc_ctx_create(int device_id, amc_ctx** out) {
         return fail(AMC_E_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
     }
     for (auto& ev : c->cev) (void)hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    {
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        // (lowest priority; measured: the priority makes no difference here - what matters is that the aux launches are
+        // issued first - so the one that can never be in the bulk class's way)
+        if (hipStreamCreateWithPriority(&c->aux_stream, hipStreamNonBlocking, lo) != hipSuccess) c->aux_stream = nullptr;
+        for (auto& ev : c->aev) (void)hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    }
     for (auto& ev : c->ev) (void)hipEventCreate(&ev);
     for (auto& set : c->bev)
         for (auto& ev : set) (void)hipEventCreate(&ev);
@@ -449,6 +464,10 @@ void amc_ctx_destroy(amc_ctx* c) {
     for (auto& ev : c->cev)
         if (ev) (void)hipEventDestroy(ev);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
+    for (auto& ev : c->aev)
+        if (ev) (void)hipEventDestroy(ev);
+    c->d_tpairs2.release(); c->d_tpairs_e2.release(); c->d_tws2.release(); c->d_tmaskws2.release();
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     dlap("events and streams");
     delete c;  // (the result pools' idle pinned buffers go with their last owner)
@@ -479,7 +498,9 @@ int amc_ctx_trim(amc_ctx* c) {
         c->d_stream.release();
         c->stream_len = 0;
     }
+    if (c->aux_stream) HIPCHK(hipStreamSynchronize(c->aux_stream));
     c->d_tws.release(); c->d_tmaskws.release(); c->d_toutmask.release(); c->d_emask.release(); c->d_estate.release();
+    c->d_tws2.release(); c->d_tmaskws2.release(); c->d_tpairs2.release(); c->d_tpairs_e2.release();
     c->d_tout.release(); c->d_tmatches.release(); c->d_pmatches.release(); c->d_pcos.release();
     c->d_tvg_packed.release(); c->d_mask_packed.release(); c->d_moff.release(); c->d_tp_all.release();
     c->verify_pool->trim();
@@ -2001,8 +2022,43 @@ static int verify_impl(amc_ctx* c, int mode, const uint32_t* slot1, const uint32
         HIPCHK(hipMemsetAsync(c->d_tout.p, 0, npairs * sizeof(TvgOut), st));
         kernel_ms = 0.0;
         launches = 0;
-        for (int k = 0; k < 4; ++k) {
-            if (cls[k].empty()) continue;
+        // The first non-empty class (the bulk of a call) runs on the call's stream; the others - few pairs, each
+        // several milliseconds on one wave whatever the machine around it does - on the low-priority stream, with
+        // their own lists and workspaces, so that they fill the bulk class's tails instead of adding two launches of
+        // pure latency behind it (a 9,585-pair call of mixed sizes: 40.5 ms of kernels, 9.2 of them class 1).
+        int nclasses = 0;
+        for (int k = 0; k < 4; ++k) nclasses += !cls[k].empty();
+        const bool overlap_classes = nclasses > 1 && c->aux_stream && !std::getenv("AMC_TVG_SERIAL_CLASSES");
+        bool aux_used = false;
+        if (overlap_classes) HIPCHK(hipEventRecord(c->aev[0], st));  // the memsets above, for the aux stream
+        HIPCHK(hipEventRecord(c->ev[2], st));
+        // launch order: the aux classes first - their few waves take their slots before the bulk class fills every
+        // register file with persistent waves - then the bulk class (the lowest non-empty one)
+        int bulk = 0;
+        while (cls[bulk].empty()) ++bulk;
+        int order[4], norder = 0;
+        if (overlap_classes) {
+            for (int k = 3; k > bulk; --k)
+                if (!cls[k].empty()) order[norder++] = k;
+            order[norder++] = bulk;
+        } else {
+            for (int k = 0; k < 4; ++k)
+                if (!cls[k].empty()) order[norder++] = k;
+        }
+        for (int oi = 0; oi < norder; ++oi) {
+            const int k = order[oi];
+            const bool on_aux = overlap_classes && k != bulk;
+            hipStream_t ks = on_aux ? c->aux_stream : st;
+            DevBuf<TvgPair>& b_pairs = on_aux ? c->d_tpairs2 : c->d_tpairs;
+            DevBuf<TvgPair>& b_pairs_e = on_aux ? c->d_tpairs_e2 : c->d_tpairs_e;
+            DevBuf<double>& b_ws = on_aux ? c->d_tws2 : c->d_tws;
+            DevBuf<uint8_t>& b_maskws = on_aux ? c->d_tmaskws2 : c->d_tmaskws;
+            uint32_t* const qhead = c->d_scalars + (on_aux ? 8 : 1);
+            if (on_aux) {
+                if (aux_used) HIPCHK(hipStreamSynchronize(c->aux_stream));  // its lists and workspaces are rewritten below
+                else HIPCHK(hipStreamWaitEvent(c->aux_stream, c->aev[0], 0));
+                aux_used = true;
+            }
             const bool big = k == 3;  // index arrays in global memory (tvg_*_big.hip)
             const int wpb = k >= 2 ? 1 : 4;
             uint32_t cm = 0;
@@ -2033,31 +2089,38 @@ static int verify_impl(amc_ctx* c, int mode, const uint32_t* slot1, const uint32
             const bool run_fh = mode != 3;
             const uint32_t waves_e = sub_e.empty() ? 0 : waves_for(sub_e.size(), kTvgEWavesPerSimd, big ? tvg_big_lds_bytes_e(wpb) : tvg_lds_bytes_e(mcap, wpb));
             const uint32_t waves_fh = run_fh ? waves_for(idx.size(), kTvgFhWavesPerSimd, big ? tvg_big_lds_bytes(wpb) : tvg_lds_bytes(mcap, wpb)) : 0;
-            HIPCHK(c->d_tpairs.ensure(idx.size()));
-            HIPCHK(c->d_tpairs_e.ensure(std::max<size_t>(sub_e.size(), 1)));
+            HIPCHK(b_pairs.ensure(idx.size()));
+            HIPCHK(b_pairs_e.ensure(std::max<size_t>(sub_e.size(), 1)));
             const size_t idx_ws = big ? tvg_big_idx_doubles_host(mcap) : 0;  // per wave, behind the point workspaces
-            HIPCHK(c->d_tws.ensure(std::max((size_t)waves_e * (tvg_ws_doubles_e_host(mcap) + idx_ws),
-                                            (size_t)waves_fh * (tvg_ws_doubles_host(mcap) + idx_ws))));
-            HIPCHK(c->d_tmaskws.ensure((size_t)std::max<uint32_t>(waves_fh, 1) * tvg_ws_mask_bytes_host(mcap)));
-            HIPCHK(hipMemcpyAsync(c->d_tpairs.p, sub.data(), sub.size() * sizeof(TvgPair), hipMemcpyHostToDevice, st));
+            HIPCHK(b_ws.ensure(std::max((size_t)waves_e * (tvg_ws_doubles_e_host(mcap) + idx_ws),
+                                        (size_t)waves_fh * (tvg_ws_doubles_host(mcap) + idx_ws))));
+            HIPCHK(b_maskws.ensure((size_t)std::max<uint32_t>(waves_fh, 1) * tvg_ws_mask_bytes_host(mcap)));
+            // (pageable sources: these copies are done when the calls return - `sub` / `sub_e` may go out of scope - and
+            // need no stream synchronisation, which on the aux stream would wait for the class before)
+            HIPCHK(hipMemcpy(b_pairs.p, sub.data(), sub.size() * sizeof(TvgPair), hipMemcpyHostToDevice));
             if (!sub_e.empty())
-                HIPCHK(hipMemcpyAsync(c->d_tpairs_e.p, sub_e.data(), sub_e.size() * sizeof(TvgPair), hipMemcpyHostToDevice, st));
-            HIPCHK(hipStreamSynchronize(st));  // `sub` / `sub_e` go out of scope at the end of the iteration
-            HIPCHK(hipEventRecord(c->ev[2], st));
+                HIPCHK(hipMemcpy(b_pairs_e.p, sub_e.data(), sub_e.size() * sizeof(TvgPair), hipMemcpyHostToDevice));
             if (!sub_e.empty()) {
-                HIPCHK((big ? launch_tvg_e_big : launch_tvg_e)(c->d_timgs.p, c->d_tpairs_e.p, (uint32_t)sub_e.size(), kernel_matches, c->d_ttabs.p, P,
-                                    c->d_tws.p, mcap, waves_e, wpb, c->d_scalars + 1, c->d_estate.p, c->d_emask.p,
-                                    c->d_tout.p, c->d_toutmask.p, st));
+                HIPCHK((big ? launch_tvg_e_big : launch_tvg_e)(c->d_timgs.p, b_pairs_e.p, (uint32_t)sub_e.size(), kernel_matches, c->d_ttabs.p, P,
+                                    b_ws.p, mcap, waves_e, wpb, qhead, c->d_estate.p, c->d_emask.p,
+                                    c->d_tout.p, c->d_toutmask.p, ks));
                 ++launches;
             }
             if (run_fh) {
-                HIPCHK((big ? launch_tvg_fh_big : launch_tvg_fh)(c->d_timgs.p, c->d_tpairs.p, (uint32_t)idx.size(), kernel_matches, c->d_ttabs.p, P,
-                                     c->d_tws.p, c->d_tmaskws.p, mcap, waves_fh, wpb, c->d_scalars + 1, c->d_estate.p,
-                                     c->d_emask.p, c->d_tout.p, c->d_toutmask.p, st));
+                HIPCHK((big ? launch_tvg_fh_big : launch_tvg_fh)(c->d_timgs.p, b_pairs.p, (uint32_t)idx.size(), kernel_matches, c->d_ttabs.p, P,
+                                     b_ws.p, b_maskws.p, mcap, waves_fh, wpb, qhead, c->d_estate.p,
+                                     c->d_emask.p, c->d_tout.p, c->d_toutmask.p, ks));
                 ++launches;
             }
-            HIPCHK(hipEventRecord(c->ev[3], st));
-            HIPCHK(hipStreamSynchronize(st));  // d_tpairs is rewritten by the next class
+            if (!overlap_classes) HIPCHK(hipStreamSynchronize(st));  // d_tpairs is rewritten by the next class
+        }
+        if (aux_used) {  // the call's stream joins the aux stream
+            HIPCHK(hipEventRecord(c->aev[1], c->aux_stream));
+            HIPCHK(hipStreamWaitEvent(st, c->aev[1], 0));
+        }
+        HIPCHK(hipEventRecord(c->ev[3], st));
+        HIPCHK(hipStreamSynchronize(st));
+        {
             float kms = 0.f;
             (void)hipEventElapsedTime(&kms, c->ev[2], c->ev[3]);
             kernel_ms += kms;
