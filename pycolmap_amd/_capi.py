@@ -206,12 +206,14 @@ def load() -> C.CDLL:
     lib.amc_ransac_result_free.argtypes = [C.POINTER(RansacResult)]
     lib.amc_ransac_result_free.restype = None
     lib.amc_cam_from_img.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p]
-    lib.amc_img_from_cam.argtypes = lib.amc_cam_from_img.argtypes
+    if hasattr(lib, "amc_img_from_cam"):   # (absent from a library built from an older revision: tools/ab_prev_lib.sh)
+        lib.amc_img_from_cam.argtypes = lib.amc_cam_from_img.argtypes
     lib.amc_squared_sampson_error.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
                                               C.c_void_p]
     lib.amc_pose_pairs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_void_p]
-    lib.amc_homography_decomposition.argtypes = [C.c_void_p] + [C.c_void_p] * 5 + [C.c_size_t] + [C.c_void_p] * 5
+    if hasattr(lib, "amc_homography_decomposition"):
+        lib.amc_homography_decomposition.argtypes = [C.c_void_p] + [C.c_void_p] * 5 + [C.c_size_t] + [C.c_void_p] * 5
     _lib = lib
     return lib
 

@@ -776,8 +776,10 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
         bool grouped_resolve = true;
     };
     // rows of image 1 (padded) from pair i to the end of the call: how much is left when a batch is carved
-    std::vector<uint64_t> rows_left(npairs + 1, 0);
-    for (size_t i = npairs; i-- > 0;) rows_left[i] = rows_left[i + 1] + c->slots[slot1[i]].dev.rows_pad;
+    // (a running total, not an array: a loop-closure call has 10^7 pairs, and 80 MB of suffix sums cost more than the
+    // tail they shape)
+    uint64_t rows_total = 0, rows_carved = 0;
+    for (size_t i = 0; i < npairs; ++i) rows_total += c->slots[slot1[i]].dev.rows_pad;
     const bool even_batches = std::getenv("AMC_MATCH_EVEN_BATCHES") != nullptr;  // (A/B hook)
     // How a batch's matches reach the host.  The copy of batch k is handed to batch k + 1's forward scan, whose first
     // few workgroups carry it out (CopyJob, match_mfma.hip); the last batch's copy, and any the next launch cannot
@@ -802,8 +804,9 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
         // last batch and is more than a quarter of a full one, this batch stops a quarter short of the end (on the
         // dense 500 x 4096 set the exposed copy is 530 MB otherwise).
         size_t limit = max_entries;
-        if (!even_batches && begin > 0 && rows_left[begin] <= max_entries && rows_left[begin] > max_entries / 4)
-            limit = (size_t)(rows_left[begin] - max_entries / 4);
+        const uint64_t rows_left = rows_total - rows_carved;  // (carve() is called for consecutive batches, in order)
+        if (!even_batches && begin > 0 && rows_left <= max_entries && rows_left > max_entries / 4)
+            limit = (size_t)(rows_left - max_entries / 4);
         while (b.end < npairs) {
             const Slot& x = c->slots[slot1[b.end]];
             const Slot& y = c->slots[slot2[b.end]];
@@ -817,6 +820,7 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
             b.top_rows += nr; b.top_cols += nc; b.cap += mc; ++b.end;
         }
         b.nb = b.end - b.begin;
+        rows_carved += b.top_rows;
         return b;
     };
     // host side of a batch: which kernel takes each pair, the work queues (mfma: one item per pair, in
@@ -1090,6 +1094,7 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
             c->h_csr[k].p[i] = run;
             if (keep_off) (*keep_off)[b.begin + i] = run;
             run += c->h_pair_cnt[k].p[i];
+            priv->offsets[b.begin + i + 1] = run;  // the result's CSR (offsets[0] = 0; batches are collected in order)
         }
         if (run - keep_used != b.total) {
             rc = fail(AMC_E_HIP, "amc_match_pairs: internal: pair counts (%llu) disagree with the cursor (%u)",
@@ -1160,9 +1165,7 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, c->bev[k][0], c->bev[k][1]) == hipSuccess) kernel_ms += ms;
         if (hipEventElapsedTime(&ms, c->bev[k][1], c->bev[k][2]) == hipSuccess) cross_ms += ms;
-        for (size_t i = 0; i < b.nb; ++i)
-            priv->offsets[b.begin + i + 1] = priv->offsets[b.begin + i] + c->h_pair_cnt[k].p[i];
-        return true;
+        return true;  // (the offsets were filled by collect(): this set's pinned counts may be gone by now)
     };
 
     if (npairs > 0) {
@@ -1173,6 +1176,12 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
         tp = std::chrono::steady_clock::now();
         ok = ok && enqueue(cur);
         t_enqueue += since(tp);
+        // The host runs one batch ahead of the device: while batch `cur` is scanned, the next batch's lists are
+        // prepared; the matches of the batch BEFORE cur are read out (scatter) only after that - their copy rides in
+        // cur's scan and is done when that scan is, and waiting for it earlier would leave the device idle while the
+        // host prepares (a 10^7-pair loop-closure call: 8 ms of preparation per batch against a 3 ms cross-check stage).
+        Batch prev;
+        bool have_prev = false;
         while (ok) {
             Batch next;
             const bool have_next = cur.end < npairs;
@@ -1183,16 +1192,23 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
                 t_prepare += since(tp);
             }
             tp = std::chrono::steady_clock::now();
+            if (ok && have_prev) ok = scatter(prev);  // (before enqueue(next) re-records that set's events)
+            t_scatter += since(tp);
+            tp = std::chrono::steady_clock::now();
             ok = ok && collect(cur);
             t_collect += since(tp);
             tp = std::chrono::steady_clock::now();
             if (ok && have_next) ok = enqueue(next);
             ok = ok && flush_copy();  // (not taken by a scan launch: the last batch's, a small one, dot4-only batches)
             t_enqueue += since(tp);
-            tp = std::chrono::steady_clock::now();
-            ok = ok && scatter(cur);
-            t_scatter += since(tp);
-            if (!have_next) break;
+            if (!have_next) {
+                tp = std::chrono::steady_clock::now();
+                ok = ok && scatter(cur);
+                t_scatter += since(tp);
+                break;
+            }
+            prev = cur;
+            have_prev = true;
             cur = next;
         }
         if (!ok && rc == AMC_OK) rc = fail(AMC_E_HIP, "amc_match_pairs: batch failed");
