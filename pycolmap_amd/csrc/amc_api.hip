@@ -795,6 +795,9 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
         int set = -1;  // the batch set whose bev[set][4] marks the copy done; -1: nothing pending
     } pending;
     constexpr uint32_t kCopyParts = 8;
+    // (smaller copies are not worth a scan's prologue; AMC_D2H_FUSE_MIN_BYTES lets the tests take the path with small inputs)
+    const char* fmin_env = std::getenv("AMC_D2H_FUSE_MIN_BYTES");
+    const size_t fuse_min_bytes = fmin_env ? (size_t)std::strtoull(fmin_env, nullptr, 10) : ((size_t)1 << 20);
     auto carve = [&](size_t begin, int set) {
         Batch b;
         b.begin = b.end = begin;
@@ -1004,7 +1007,7 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
         if (nord) {  // ... and scan them (the events bracket the scan kernel alone: bench.py's roofline leg)
             CopyJob job;
             const uintptr_t ps = reinterpret_cast<uintptr_t>(pending.src), pd = reinterpret_cast<uintptr_t>(pending.dst);
-            const bool take = pending.set >= 0 && d2h_mode == 0 && b.seg_cap > 0 && pending.bytes >= ((size_t)1 << 20) &&
+            const bool take = pending.set >= 0 && d2h_mode == 0 && b.seg_cap > 0 && pending.bytes >= fuse_min_bytes &&
                               (ps & 15) == (pd & 15);
             int done_set = -1;
             if (take) {  // the previous batch's matches ride in this launch; head / tail bytes around the 16-byte units first

@@ -270,6 +270,16 @@ def test_many_batches_pipeline(amc_ctx, monkeypatch, kernel, entries):
     e = np.full(5, 7, dtype=np.uint32)
     off, m, _ = amc_ctx.match_pairs(e, np.arange(5, dtype=np.uint32), kernel=kernel)
     assert off.tolist() == [0] * 6 and len(m) == 0
+    # the three ways a batch's matches reach the host: riding in the next batch's scan (forced for these small
+    # batches), the small copy kernel on the copy stream, the runtime's copy
+    for env in ({"AMC_D2H_FUSE_MIN_BYTES": "8"}, {"AMC_D2H": "stream"}, {"AMC_D2H": "memcpy"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        off, m, st = amc_ctx.match_pairs(s1, s2, kernel=kernel)
+        np.testing.assert_array_equal(off, ref[0])
+        np.testing.assert_array_equal(m, ref[1])
+        for k in env:
+            monkeypatch.delenv(k)
 
 
 @pytest.mark.parametrize("cross_check", [True, False])
