@@ -118,9 +118,13 @@ def test_tiny_match_counts(amc_ctx):
             assert_pair_equal(p, tvg, mask, off, want)
 
 
-def test_large_match_counts(amc_ctx):
+@pytest.mark.parametrize("serial", [False, True])
+def test_large_match_counts(amc_ctx, monkeypatch, serial):
     """Pairs whose correspondences do not fit a wave's LDS share (points stay in HBM), and pairs
-    whose index arrays need a whole workgroup's LDS (one wave per workgroup), mixed with small ones."""
+    whose index arrays need a whole workgroup's LDS (one wave per workgroup), mixed with small ones: three size
+    classes in one call - beside each other on two streams (the default), or one after the other."""
+    if serial:
+        monkeypatch.setenv("AMC_TVG_SERIAL_CLASSES", "1")
     rng = np.random.default_rng(21)
     scenes = [synth.two_view_scene(rng, num_inliers=ni, num_outliers=no, planar=pl, extra_keypoints=10)
               for ni, no, pl in [(3000, 2000, False), (100, 40, False), (6000, 3000, True), (900, 500, False),
