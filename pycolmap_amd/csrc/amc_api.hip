@@ -98,6 +98,8 @@ struct PinBuf {
         p = nullptr;
         cap = 0;
         size_t want = std::max(n, (size_t)16);
+        // default flags: mapped and coherent - kernels write it through the same pointer (the scan's copy parts,
+        // launch_host_copy) and the host sees the data once the kernel's completion event has been waited for
         hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&p), want * sizeof(T), 0);
         if (e == hipSuccess) cap = want;
         return e;
