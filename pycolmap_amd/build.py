@@ -66,7 +66,7 @@ def build_libamc(force: bool = False, verbose: bool = True) -> Path:
     hipcc = _hipcc()
     OBJ.mkdir(exist_ok=True)
     headers = list(CSRC.glob("*.h")) + list((ROOT / "include").glob("*.h"))
-    objs = []
+    objs, jobs = [], []
     for name in HIP_SOURCES:
         src = CSRC / name
         if not src.exists():
@@ -77,12 +77,21 @@ def build_libamc(force: bool = False, verbose: bool = True) -> Path:
         if src.stem.endswith("_big"):  # a second build of another source file (#include "tvg_e.hip"): that file is an input too
             deps.append(CSRC / (src.stem[:-4] + ".hip"))
         if force or _stale(obj, deps, flags):
-            cmd = [hipcc, *HIPCC_FLAGS, "-c", str(src), "-o", str(obj)]
-            if verbose:
-                print("[build]", " ".join(cmd), flush=True)
-            subprocess.run(cmd, check=True)
-            _stamp(obj, deps, flags)
+            jobs.append((src, obj, deps, flags))
         objs.append(obj)
+
+    def compile_one(job):
+        src, obj, deps, flags = job
+        cmd = [hipcc, *HIPCC_FLAGS, "-c", str(src), "-o", str(obj)]
+        if verbose:
+            print("[build]", " ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+        _stamp(obj, deps, flags)
+
+    if jobs:  # the translation units are independent: one hipcc per core, up to eight
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=max(1, min(8, os.cpu_count() or 1, len(jobs)))) as pool:
+            list(pool.map(compile_one, jobs))
     if force or _stale(LIB, objs):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB), *map(str, objs)]
         if verbose:

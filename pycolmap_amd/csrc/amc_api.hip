@@ -147,6 +147,7 @@ struct SlotArena {
             Slab nb{nullptr, std::max(bytes, kSlabBytes), 0};
             hipError_t e = hipMalloc(reinterpret_cast<void**>(&nb.p), nb.cap);
             if (e != hipSuccess && nb.cap > bytes) {  // no room for a whole slab: exactly what is asked for
+                (void)hipGetLastError();  // (the failed attempt is not this call's status: the runtime keeps the last error)
                 nb.cap = bytes;
                 e = hipMalloc(reinterpret_cast<void**>(&nb.p), nb.cap);
             }
@@ -383,18 +384,23 @@ int amc_ctx_create(int device_id, amc_ctx** out) {
         delete c;
         return fail(AMC_E_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
     }
-    for (auto& ev : c->cev) (void)hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    bool ev_ok = true;  // (an event that was never created would fail every later record: fail here instead)
+    for (auto& ev : c->cev) ev_ok &= hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess;
     {
         int lo = 0, hi = 0;
-        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);  // (0, 0 when it fails: the default priority)
         // (lowest priority; measured: the priority makes no difference here - what matters is that the aux launches are
         // issued first - so the one that can never be in the bulk class's way)
         if (hipStreamCreateWithPriority(&c->aux_stream, hipStreamNonBlocking, lo) != hipSuccess) c->aux_stream = nullptr;
-        for (auto& ev : c->aev) (void)hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+        for (auto& ev : c->aev) ev_ok &= hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess;
     }
-    for (auto& ev : c->ev) (void)hipEventCreate(&ev);
+    for (auto& ev : c->ev) ev_ok &= hipEventCreate(&ev) == hipSuccess;
     for (auto& set : c->bev)
-        for (auto& ev : set) (void)hipEventCreate(&ev);
+        for (auto& ev : set) ev_ok &= hipEventCreate(&ev) == hipSuccess;
+    if (!ev_ok) {
+        amc_ctx_destroy(c);
+        return fail(AMC_E_HIP, "amc_ctx_create: hipEventCreate failed");
+    }
     // acos table with the HOST libm (the same one COLMAP's CPU path and the oracle call)
     c->h_lut.resize(kAcosLutSize);
     const float kDistNorm = 1.0f / (512.0f * 512.0f);
@@ -579,10 +585,9 @@ static int upload_common(amc_ctx* c, uint32_t slot, const void* src, uint32_t ro
     s.dev.rs128 = rs;
     HIPCHK(hipMemcpyAsync(raw, src, (size_t)rows * kDim, kind, c->stream));
     if (rp > rows)
-        HIPCHK(hipMemsetAsync(raw + (size_t)rows * kDim, 0, (rp - rows) * kDim, c->stream));
-    HIPCHK(hipMemsetAsync(c->d_scalars + 2, 0, sizeof(uint32_t), c->stream));
-    launch_prep(raw, prep, rs, s.dev.rows_pad, c->d_scalars + 2, c->stream);
-    HIPCHK(hipGetLastError());
+        HIPCHK(memset_async(raw + (size_t)rows * kDim, 0, (rp - rows) * kDim, c->stream));
+    HIPCHK(memset_async(c->d_scalars + 2, 0, sizeof(uint32_t), c->stream));
+    HIPCHK(launch_prep(raw, prep, rs, s.dev.rows_pad, c->d_scalars + 2, c->stream));
     HIPCHK(hipMemcpyAsync(c->h_scalars.p + 2, c->d_scalars + 2, sizeof(uint32_t),
                           hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -714,35 +719,7 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
         c->table_dirty = false;
     }
 
-    ResultPriv* priv = new (std::nothrow) ResultPriv();
-    if (!priv) return fail(AMC_E_NOMEM, "amc_match_pairs: out of host memory");
-    priv->offsets.assign(npairs + 1, 0);
-    priv->pool = c->result_pool;
-    priv->matches = c->result_pool->acquire();
-    size_t keep_used = 0;  // matches of this call in c->d_keep so far (pair order: the result's CSR layout)
-    c->resident_matches = 0;
-    if (keep_off) keep_off->assign(npairs, 0);
-
     const float max_ratio_f = (float)o.max_ratio;
-    const size_t mfma_max_cols = kSelectMaxCols;  // cross-check candidate bitmap (image 2 rows)
-
-    uint64_t num_dist = 0, n_mfma = 0, n_dot4 = 0, n_grid = 0;
-    double kernel_ms = 0.0, cross_ms = 0.0;
-    uint32_t kernel_launches = 0;
-    HIPCHK(hipEventRecord(c->ev[0], st));
-
-    int rc = AMC_OK;
-    auto hc = [&](hipError_t e, const char* what) {
-        if (e != hipSuccess && rc == AMC_OK)
-            rc = fail(AMC_E_HIP, "amc_match_pairs: %s: %s", what, hipGetErrorString(e));
-        return e == hipSuccess;
-    };
-    // test hook: a smaller per-batch budget, so that small inputs exercise the multi-batch pipeline
-    size_t max_entries = kMaxTop2Entries;
-    if (const char* e = std::getenv("AMC_MATCH_BATCH_ENTRIES")) {
-        const long long v = std::atoll(e);
-        if (v > 0) max_entries = std::min<size_t>(kMaxTop2Entries, (size_t)v);
-    }
     FinalizeParams fp;
     fp.max_ratio = max_ratio_f;
     fp.max_distance = (float)o.max_distance;
@@ -760,6 +737,36 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
         c->accept_ratio = fp.max_ratio;
         c->accept_distance = fp.max_distance;
         c->accept_valid = true;
+    }
+    HIPCHK(hipEventRecord(c->ev[0], st));
+    // (everything above returns through HIPCHK: from here on errors go through rc / hc, which give the result's
+    // pinned lease back)
+    ResultPriv* priv = new (std::nothrow) ResultPriv();
+    if (!priv) return fail(AMC_E_NOMEM, "amc_match_pairs: out of host memory");
+    priv->offsets.assign(npairs + 1, 0);
+    priv->pool = c->result_pool;
+    priv->matches = c->result_pool->acquire();
+    size_t keep_used = 0;  // matches of this call in c->d_keep so far (pair order: the result's CSR layout)
+    c->resident_matches = 0;
+    if (keep_off) keep_off->assign(npairs, 0);
+
+    const size_t mfma_max_cols = kSelectMaxCols;  // cross-check candidate bitmap (image 2 rows)
+
+    uint64_t num_dist = 0, n_mfma = 0, n_dot4 = 0, n_grid = 0;
+    double kernel_ms = 0.0, cross_ms = 0.0;
+    uint32_t kernel_launches = 0;
+
+    int rc = AMC_OK;
+    auto hc = [&](hipError_t e, const char* what) {
+        if (e != hipSuccess && rc == AMC_OK)
+            rc = fail(AMC_E_HIP, "amc_match_pairs: %s: %s", what, hipGetErrorString(e));
+        return e == hipSuccess;
+    };
+    // test hook: a smaller per-batch budget, so that small inputs exercise the multi-batch pipeline
+    size_t max_entries = kMaxTop2Entries;
+    if (const char* e = std::getenv("AMC_MATCH_BATCH_ENTRIES")) {
+        const long long v = std::atoll(e);
+        if (v > 0) max_entries = std::min<size_t>(kMaxTop2Entries, (size_t)v);
     }
 
     // A batch goes through four steps.  Steps of consecutive batches are interleaved so that the device
@@ -985,15 +992,15 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
             return false;
         bool okq = hc(hipMemcpyAsync(c->d_pairs.p, c->h_pairs[k].p, nb * sizeof(PairDev),
                                      hipMemcpyHostToDevice, st), "H2D pairs") &&
-                   hc(hipMemsetAsync(c->d_scalars, 0, 2 * sizeof(uint32_t), st), "memset cursor") &&
-                   hc(hipMemsetAsync(c->d_scalars + 3, 0, sizeof(uint32_t), st), "memset errcount");
+                   hc(memset_async(c->d_scalars, 0, 2 * sizeof(uint32_t), st), "memset cursor") &&
+                   hc(memset_async(c->d_scalars + 3, 0, sizeof(uint32_t), st), "memset errcount");
         if (okq && nord)
             okq = hc(hipMemcpyAsync(c->d_order.p, c->h_order[k].p, nord * sizeof(uint32_t),
                                     hipMemcpyHostToDevice, st), "H2D order") &&
                   hc(hipMemcpyAsync(c->d_grp.p, c->h_grp[k].p, (b.ngrp + 1) * sizeof(uint32_t),
                                     hipMemcpyHostToDevice, st), "H2D group cuts") &&
                   // segments no wave owns (beyond an image's last row) never write their words
-                  hc(hipMemsetAsync(c->d_accmask.p, 0, (b.row_off / 32 + 8) * sizeof(uint32_t), st), "memset accmask");
+                  hc(memset_async(c->d_accmask.p, 0, (b.row_off / 32 + 8) * sizeof(uint32_t), st), "memset accmask");
         if (okq && nwork)
             okq = hc(hipMemcpyAsync(c->d_work.p, c->h_work[k].p, nwork * sizeof(Dot4Work),
                                     hipMemcpyHostToDevice, st), "H2D work");
@@ -1001,11 +1008,12 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
             okq = hc(hipMemcpyAsync(c->d_guided.p, h_guided.data() + b.begin, nb * sizeof(GuidedDev),
                                     hipMemcpyHostToDevice, st), "H2D guided");
         if (!okq) return false;
-        if (nord)  // pack the pairs' 128-row segments into items (per streamed image) ...
-            launch_build_segments(0, c->d_imgs.p, c->d_pairs.p, c->d_order.p, c->d_grp.p, (uint32_t)b.ngrp,
-                                  c->d_cand_cnt.p, c->d_candbuf.p, c->d_rowbuf.p, c->d_seg_base.p, c->d_grp_segs.p,
-                                  c->d_grp_item_base.p, c->d_segs.p, c->d_scalars + 5, st);
-        (void)hipEventRecord(c->bev[k][0], st);
+        if (nord &&  // pack the pairs' 128-row segments into items (per streamed image) ...
+            !hc(launch_build_segments(0, c->d_imgs.p, c->d_pairs.p, c->d_order.p, c->d_grp.p, (uint32_t)b.ngrp,
+                                      c->d_cand_cnt.p, c->d_candbuf.p, c->d_rowbuf.p, c->d_seg_base.p, c->d_grp_segs.p,
+                                      c->d_grp_item_base.p, c->d_segs.p, c->d_scalars + 5, st), "segment packing"))
+            return false;
+        if (!hc(hipEventRecord(c->bev[k][0], st), "event record")) return false;
         if (nord) {  // ... and scan them (the events bracket the scan kernel alone: bench.py's roofline leg)
             CopyJob job;
             const uintptr_t ps = reinterpret_cast<uintptr_t>(pending.src), pd = reinterpret_cast<uintptr_t>(pending.dst);
@@ -1015,10 +1023,12 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
             if (take) {  // the previous batch's matches ride in this launch; head / tail bytes around the 16-byte units first
                 const size_t head = (ps & 15) ? 16 - (ps & 15) : 0, n16 = (pending.bytes - head) / 16;
                 const size_t tail = pending.bytes - head - n16 * 16;
-                if (head) (void)hipMemcpyAsync(pending.dst, pending.src, head, hipMemcpyDeviceToHost, st);
-                if (tail)
-                    (void)hipMemcpyAsync(static_cast<char*>(pending.dst) + head + n16 * 16,
-                                         static_cast<const char*>(pending.src) + head + n16 * 16, tail, hipMemcpyDeviceToHost, st);
+                if (head && !hc(memcpy_async(pending.dst, pending.src, head, hipMemcpyDeviceToHost, st), "D2H matches (head)"))
+                    return false;
+                if (tail && !hc(memcpy_async(static_cast<char*>(pending.dst) + head + n16 * 16,
+                                             static_cast<const char*>(pending.src) + head + n16 * 16, tail,
+                                             hipMemcpyDeviceToHost, st), "D2H matches (tail)"))
+                    return false;
                 job.src = static_cast<const char*>(pending.src) + head;
                 job.dst = static_cast<char*>(pending.dst) + head;
                 job.n16 = n16;
@@ -1026,47 +1036,55 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
                 done_set = pending.set;
                 pending.set = -1;
             }
-            launch_match_mfma(0, c->d_segs.p, c->d_scalars + 5, (uint32_t)std::min<size_t>(b.seg_cap, 0xFFFFFFFFu),
-                              c->d_scalars + 1, c->d_accmask.p, c->d_accept, st, job, c->d_scalars + 7);
-            if (done_set >= 0) (void)hipEventRecord(c->bev[done_set][4], st);  // that batch's matches are on the host when this scan is done
+            if (!hc(launch_match_mfma(0, c->d_segs.p, c->d_scalars + 5, (uint32_t)std::min<size_t>(b.seg_cap, 0xFFFFFFFFu),
+                                      c->d_scalars + 1, c->d_accmask.p, c->d_accept, st, job, c->d_scalars + 7), "forward scan"))
+                return false;
+            // that batch's matches are on the host when this scan is done
+            if (done_set >= 0 && !hc(hipEventRecord(c->bev[done_set][4], st), "event record")) return false;
         }
-        if (b.nwork_grid)
-            launch_match_guided_grid(c->d_imgs.p, c->d_grids.p, c->d_pairs.p, c->d_work.p, (uint32_t)b.nwork_grid,
-                                     c->d_rowbuf.p, c->d_colbuf.p, c->d_guided.p, st);
-        if (nwork > b.nwork_grid)
-            launch_match_dot4(c->d_imgs.p, c->d_pairs.p, c->d_work.p + b.nwork_grid, (uint32_t)(nwork - b.nwork_grid),
-                              c->d_rowbuf.p, c->d_colbuf.p, geoms ? c->d_guided.p : nullptr, st);
-        (void)hipEventRecord(c->bev[k][1], st);
+        if (b.nwork_grid &&
+            !hc(launch_match_guided_grid(c->d_imgs.p, c->d_grids.p, c->d_pairs.p, c->d_work.p, (uint32_t)b.nwork_grid,
+                                         c->d_rowbuf.p, c->d_colbuf.p, c->d_guided.p, st), "guided scan"))
+            return false;
+        if (nwork > b.nwork_grid &&
+            !hc(launch_match_dot4(c->d_imgs.p, c->d_pairs.p, c->d_work.p + b.nwork_grid, (uint32_t)(nwork - b.nwork_grid),
+                                  c->d_rowbuf.p, c->d_colbuf.p, geoms ? c->d_guided.p : nullptr, st), "dot4 scan"))
+            return false;
+        if (!hc(hipEventRecord(c->bev[k][1], st), "event record")) return false;
         const bool use_order = std::getenv("AMC_RESOLVE_PAIR_ORDER") == nullptr;  // (A/B hook: workgroups in batch order)
         kernel_launches += (nord ? 1 : 0) + (b.nwork_grid ? 1 : 0) + (nwork > b.nwork_grid ? 1 : 0);
-        if (nord)  // tile -> exact index for the accepted rows
-            launch_resolve_index(0, c->d_imgs.p, c->d_pairs.p, (uint32_t)nb, c->d_rowbuf.p, c->d_accmask.p, c->d_lut,
-                                 fp, c->d_cand_cnt.p, c->d_candbuf.p, c->d_scalars + 3, b.grouped_resolve,
-                                 use_order ? c->d_order.p : nullptr, (uint32_t)nord, st);
+        if (nord &&  // tile -> exact index for the accepted rows
+            !hc(launch_resolve_index(0, c->d_imgs.p, c->d_pairs.p, (uint32_t)nb, c->d_rowbuf.p, c->d_accmask.p, c->d_lut,
+                                     fp, c->d_cand_cnt.p, c->d_candbuf.p, c->d_scalars + 3, b.grouped_resolve,
+                                     use_order ? c->d_order.p : nullptr, (uint32_t)nord, st), "resolve (rows)"))
+            return false;
         if (nord && o.cross_check) {
             // lazy cross check: reverse scan only for the columns accepted rows point at
-            launch_select_candidates(c->d_imgs.p, c->d_pairs.p, (uint32_t)nb, b.max_cols, c->d_rowbuf.p, c->d_accmask.p,
-                                     c->d_lut, fp, c->d_cand_cnt.p, c->d_candbuf.p, st);
+            if (!hc(launch_select_candidates(c->d_imgs.p, c->d_pairs.p, (uint32_t)nb, b.max_cols, c->d_rowbuf.p,
+                                             c->d_accmask.p, c->d_lut, fp, c->d_cand_cnt.p, c->d_candbuf.p, st),
+                    "candidate selection"))
+                return false;
             if (!hc(hipMemcpyAsync(c->d_order2.p, c->h_order2[k].p, nord * sizeof(uint32_t),
                                    hipMemcpyHostToDevice, st), "H2D order2") ||
                 !hc(hipMemcpyAsync(c->d_grp2.p, c->h_grp2[k].p, (b.ngrp2 + 1) * sizeof(uint32_t),
                                    hipMemcpyHostToDevice, st), "H2D group cuts"))
                 return false;
             // the candidate counts exist only on the device: the packing kernels read them there
-            launch_build_segments(1, c->d_imgs.p, c->d_pairs.p, c->d_order2.p, c->d_grp2.p, (uint32_t)b.ngrp2,
-                                  c->d_cand_cnt.p, c->d_candbuf.p, c->d_colbuf.p, c->d_seg_base.p, c->d_grp_segs.p,
-                                  c->d_grp_item_base.p, c->d_segs.p, c->d_scalars + 5, st);
-            launch_match_mfma(1, c->d_segs.p, c->d_scalars + 5, (uint32_t)std::min<size_t>(b.seg_cap, 0xFFFFFFFFu),
-                              c->d_scalars + 1, c->d_accmask.p, c->d_accept, st);
-            launch_resolve_index(1, c->d_imgs.p, c->d_pairs.p, (uint32_t)nb, c->d_colbuf.p, c->d_accmask.p, c->d_lut,
-                                 fp, c->d_cand_cnt.p, c->d_candbuf.p, c->d_scalars + 3, b.grouped_resolve,
-                                 use_order ? c->d_order2.p : nullptr, (uint32_t)nord, st);
+            if (!hc(launch_build_segments(1, c->d_imgs.p, c->d_pairs.p, c->d_order2.p, c->d_grp2.p, (uint32_t)b.ngrp2,
+                                          c->d_cand_cnt.p, c->d_candbuf.p, c->d_colbuf.p, c->d_seg_base.p, c->d_grp_segs.p,
+                                          c->d_grp_item_base.p, c->d_segs.p, c->d_scalars + 5, st), "segment packing (reverse)") ||
+                !hc(launch_match_mfma(1, c->d_segs.p, c->d_scalars + 5, (uint32_t)std::min<size_t>(b.seg_cap, 0xFFFFFFFFu),
+                                      c->d_scalars + 1, c->d_accmask.p, c->d_accept, st), "reverse scan") ||
+                !hc(launch_resolve_index(1, c->d_imgs.p, c->d_pairs.p, (uint32_t)nb, c->d_colbuf.p, c->d_accmask.p, c->d_lut,
+                                         fp, c->d_cand_cnt.p, c->d_candbuf.p, c->d_scalars + 3, b.grouped_resolve,
+                                         use_order ? c->d_order2.p : nullptr, (uint32_t)nord, st), "resolve (columns)"))
+                return false;
         }
-        (void)hipEventRecord(c->bev[k][2], st);
-        launch_finalize(c->d_imgs.p, c->d_pairs.p, (uint32_t)nb, c->d_rowbuf.p, c->d_colbuf.p,
-                        c->d_accmask.p, c->d_lut, fp, c->d_scalars, (uint32_t)std::min(b.cap, (size_t)0xFFFFFFFFu),
-                        c->d_pair_off.p, c->d_pair_cnt.p, c->d_matches.p, st);
-        if (!hc(hipGetLastError(), "kernel launch")) return false;
+        if (!hc(hipEventRecord(c->bev[k][2], st), "event record") ||
+            !hc(launch_finalize(c->d_imgs.p, c->d_pairs.p, (uint32_t)nb, c->d_rowbuf.p, c->d_colbuf.p,
+                                c->d_accmask.p, c->d_lut, fp, c->d_scalars, (uint32_t)std::min(b.cap, (size_t)0xFFFFFFFFu),
+                                c->d_pair_off.p, c->d_pair_cnt.p, c->d_matches.p, st), "finalize"))
+            return false;
         return hc(hipMemcpyAsync(c->h_bscalars[k].p, c->d_scalars, 4 * sizeof(uint32_t),
                                  hipMemcpyDeviceToHost, st), "D2H cursor") &&
                hc(hipMemcpyAsync(c->h_pair_off[k].p, c->d_pair_off.p, nb * sizeof(uint32_t),
@@ -1134,10 +1152,11 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
             if (!hc(c->d_csr.ensure(b.nb), "dev csr") ||
                 !hc(hipMemcpyAsync(c->d_csr.p, c->h_csr[k].p, b.nb * sizeof(uint64_t), hipMemcpyHostToDevice, st), "H2D csr"))
                 return false;
-            launch_reorder_matches(c->d_pair_off.p, c->d_pair_cnt.p, c->d_csr.p, (uint32_t)b.nb, c->d_matches.p, c->d_keep.p, st);
             // the copy to the host happens beside the next batch's kernels (which write d_matches and, later, d_keep
             // beyond this batch - never what is being copied): flush_copy() or the next enqueue() issues it
-            if (!hc(hipGetLastError(), "reorder launch")) return false;
+            if (!hc(launch_reorder_matches(c->d_pair_off.p, c->d_pair_cnt.p, c->d_csr.p, (uint32_t)b.nb, c->d_matches.p,
+                                           c->d_keep.p, st), "reorder launch"))
+                return false;
             pending.dst = priv->matches.p + 2 * keep_used;
             pending.src = c->d_keep.p + 2 * keep_used;
             pending.bytes = (size_t)b.total * 2 * sizeof(uint32_t);
@@ -1158,8 +1177,7 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
             if (!hc(hipMemcpyAsync(pending.dst, pending.src, pending.bytes, hipMemcpyDeviceToHost, c->copy_stream), "D2H matches"))
                 return false;
         } else {
-            launch_host_copy(pending.dst, pending.src, pending.bytes, c->copy_stream);
-            if (!hc(hipGetLastError(), "D2H matches")) return false;
+            if (!hc(launch_host_copy(pending.dst, pending.src, pending.bytes, c->copy_stream), "D2H matches")) return false;
         }
         return hc(hipEventRecord(c->bev[k][4], c->copy_stream), "event record");
     };
@@ -1222,17 +1240,15 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
             (void)hipStreamSynchronize(c->copy_stream);
         }
     }
+    // device_ms ends with the last result byte on the host: the stream joins the copy stream first
+    if (rc == AMC_OK && npairs > 0 &&
+        hc(hipEventRecord(c->cev[0], c->copy_stream), "event record"))
+        hc(hipStreamWaitEvent(st, c->cev[0], 0), "stream wait");
+    if (rc == AMC_OK && hc(hipEventRecord(c->ev[1], st), "event record")) hc(hipEventSynchronize(c->ev[1]), "wait for the call");
     if (rc != AMC_OK) {
         delete priv;
         return rc;
     }
-    // device_ms ends with the last result byte on the host: the stream joins the copy stream first
-    if (npairs > 0) {
-        HIPCHK(hipEventRecord(c->cev[0], c->copy_stream));
-        HIPCHK(hipStreamWaitEvent(st, c->cev[0], 0));
-    }
-    HIPCHK(hipEventRecord(c->ev[1], st));
-    HIPCHK(hipEventSynchronize(c->ev[1]));
     float total_ms = 0.f;
     (void)hipEventElapsedTime(&total_ms, c->ev[0], c->ev[1]);
 
@@ -1856,16 +1872,21 @@ static int verify_impl(amc_ctx* c, int mode, const uint32_t* slot1, const uint32
     out->inlier_mask = reinterpret_cast<uint8_t*>(priv->mask_pin.p);
     if (npairs == 0) return AMC_OK;
     // every failure below (HIPCHK returns included) frees the result's storage and hands back a zeroed struct
+    // - after nothing of the call is left in flight: a size class on the aux stream still runs when an error returns from
+    // the class loop, and the next call would rewrite that class's lists and workspaces under it
     struct Guard {
+        amc_ctx* c;
         VerifyPriv* p;
         amc_verify_result* o;
         ~Guard() {
             if (p) {
+                if (c->aux_stream) (void)hipStreamSynchronize(c->aux_stream);
+                (void)hipStreamSynchronize(c->stream);
                 delete p;
                 std::memset(o, 0, sizeof *o);
             }
         }
-    } guard{priv, out};
+    } guard{c, priv, out};
 
     // image table (cameras with distortion parameters: CamFromImg of their keypoints first)
     for (size_t i = 0; i < need_lift.size(); ++i)
@@ -2039,8 +2060,8 @@ static int verify_impl(amc_ctx* c, int mode, const uint32_t* slot1, const uint32
         P.stream_err = c->d_scalars + 4;
         // [2] pairs with a bad match index, [4] waves that ran off the stream table; the records' profile and work
         // counters are accumulated by both kernels
-        HIPCHK(hipMemsetAsync(c->d_scalars + 2, 0, 3 * sizeof(uint32_t), st));
-        HIPCHK(hipMemsetAsync(c->d_tout.p, 0, npairs * sizeof(TvgOut), st));
+        HIPCHK(memset_async(c->d_scalars + 2, 0, 3 * sizeof(uint32_t), st));
+        HIPCHK(memset_async(c->d_tout.p, 0, npairs * sizeof(TvgOut), st));
         kernel_ms = 0.0;
         launches = 0;
         // The first non-empty class (the bulk of a call) runs on the call's stream; the others - few pairs, each
@@ -2165,7 +2186,7 @@ static int verify_impl(amc_ctx* c, int mode, const uint32_t* slot1, const uint32
     HIPCHK(c->d_worksum.ensure(12));
     HIPCHK(hipMemcpyAsync(c->d_moff.p, match_offsets, (npairs + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(c->d_tp_all.p, tp.data(), npairs * sizeof(TvgPair), hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemsetAsync(c->d_worksum.p, 0, 12 * sizeof(unsigned long long), st));
+    HIPCHK(memset_async(c->d_worksum.p, 0, 12 * sizeof(unsigned long long), st));
     HIPCHK(launch_pack_verify(c->d_tout.p, c->d_tp_all.p, (uint32_t)npairs, c->d_toutmask.p, c->d_moff.p,
                               c->d_tvg_packed.p, c->d_mask_packed.p, c->d_worksum.p, st));
     HIPCHK(hipMemcpyAsync(out->tvg, c->d_tvg_packed.p, npairs * sizeof(amc_tvg), hipMemcpyDeviceToHost, st));

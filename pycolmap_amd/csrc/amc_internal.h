@@ -121,14 +121,25 @@ struct FinalizeParams {
 };
 
 // ----- launchers (defined in the .hip files) ---------------------------------------------
-void launch_prep(const uint8_t* raw, uint8_t* prep, int32_t* rs128, uint32_t rows_pad,
+// Every launcher returns the status of what it enqueued: a failed memset of a queue head or counter in front of a
+// persistent kernel must fail the call (AMC_E_HIP), not let the kernel pop from a stale counter.
+//
+// memset_async / memcpy_async: hipMemsetAsync / hipMemcpyAsync with a fault-injection hook in front (tests only):
+// with AMC_FAIL_NEXT_MEMSET=k (or AMC_FAIL_NEXT_MEMCPY=k) in the environment the k-th such call made while the
+// variable holds that value returns hipErrorInvalidValue without enqueuing anything - once; the count restarts
+// when the variable is unset or changed.  Every memset / small copy whose target a kernel of the match or
+// verification path reads goes through them.
+hipError_t memset_async(void* p, int value, size_t bytes, hipStream_t s);
+hipError_t memcpy_async(void* dst, const void* src, size_t bytes, hipMemcpyKind kind, hipStream_t s);
+
+hipError_t launch_prep(const uint8_t* raw, uint8_t* prep, int32_t* rs128, uint32_t rows_pad,
                  uint32_t* maxsq_out, hipStream_t s);
 
 // guided: nullptr, or one GuidedDev per PairDev of the batch (entries the filter rejects score 0)
-void launch_match_dot4(const ImageDev* imgs, const PairDev* pairs, const Dot4Work* work,
+hipError_t launch_match_dot4(const ImageDev* imgs, const PairDev* pairs, const Dot4Work* work,
                        uint32_t nwork, Top2* rowbuf, Top2* colbuf, const GuidedDev* guided, hipStream_t s);
 // guided matching by candidate generation (match_guided.hip): same work items and Top2 output as the dot4 kernel
-void launch_match_guided_grid(const ImageDev* imgs, const GridDev* grids, const PairDev* pairs, const Dot4Work* work,
+hipError_t launch_match_guided_grid(const ImageDev* imgs, const GridDev* grids, const PairDev* pairs, const Dot4Work* work,
                               uint32_t nwork, Top2* rowbuf, Top2* colbuf, const GuidedDev* guided, hipStream_t s);
 
 // mfma work items (match_mfma.hip).  A pair's X side - image 1's rows (mode 0: -> rowbuf + row_off) or the
@@ -171,7 +182,7 @@ __device__ __forceinline__ bool one_way_accepts(const Top2 t, const float* __res
 // Packs the segments of the pairs listed in `order` (sorted by the streamed image; grp_start cuts it where that
 // image changes) into items: segs[0 .. 8 * *nitems_dev).  seg_base (one per order entry), grp_segs and
 // grp_item_base (one per group) are scratch.  All on stream s; mode 1 reads cand_cnt on the device.
-void launch_build_segments(int mode, const ImageDev* imgs, const PairDev* pairs, const uint32_t* order,
+hipError_t launch_build_segments(int mode, const ImageDev* imgs, const PairDev* pairs, const uint32_t* order,
                            const uint32_t* grp_start, uint32_t ngroups, const uint32_t* cand_cnt,
                            const uint32_t* candbuf, Top2* outbuf, uint32_t* seg_base, uint32_t* grp_segs,
                            uint32_t* grp_item_base, SegDesc* segs, uint32_t* nitems_dev, hipStream_t s);
@@ -191,12 +202,12 @@ struct CopyJob {
     unsigned long long n16 = 0;
     uint32_t parts = 0, pad_ = 0;
 };
-void launch_match_mfma(int mode, const SegDesc* segs, const uint32_t* nitems_dev, uint32_t max_items,
+hipError_t launch_match_mfma(int mode, const SegDesc* segs, const uint32_t* nitems_dev, uint32_t max_items,
                        uint32_t* queue_head, uint32_t* accmask, const ScanAccept* accept_dev, hipStream_t s,
                        const CopyJob& job = CopyJob(), uint32_t* copy_head = nullptr);
 int match_mfma_shape();  // waves per workgroup in use (8 or 4)
 
-void launch_resolve_index(int side, const ImageDev* imgs, const PairDev* pairs, uint32_t npairs,
+hipError_t launch_resolve_index(int side, const ImageDev* imgs, const PairDev* pairs, uint32_t npairs,
                           Top2* table, uint32_t* accmask, const float* acos_lut, FinalizeParams fp,
                           const uint32_t* cand_cnt, const uint32_t* candbuf, uint32_t* err_count,
                           bool grouped, const uint32_t* order, uint32_t norder, hipStream_t s);
@@ -205,18 +216,18 @@ uint32_t resolve_grouped_max_rows();
 constexpr uint32_t kSelectMaxCols = 1u << 20;  // select_candidates' LDS bitmap: at most 128 KiB of dynamic shared memory
 
 // max_cols: the largest image 2 (rows) among the launch's pairs - sizes the kernel's LDS bitmap
-void launch_select_candidates(const ImageDev* imgs, const PairDev* pairs, uint32_t npairs, uint32_t max_cols,
+hipError_t launch_select_candidates(const ImageDev* imgs, const PairDev* pairs, uint32_t npairs, uint32_t max_cols,
                               const Top2* rowbuf, const uint32_t* accmask, const float* acos_lut,
                               FinalizeParams fp, uint32_t* cand_cnt, uint32_t* candbuf, hipStream_t s);
 
-void launch_finalize(const ImageDev* imgs, const PairDev* pairs, uint32_t npairs,
+hipError_t launch_finalize(const ImageDev* imgs, const PairDev* pairs, uint32_t npairs,
                      const Top2* rowbuf, const Top2* colbuf, const uint32_t* accmask,
                      const float* acos_lut, FinalizeParams fp, uint32_t* cursor, uint32_t capacity,
                      uint32_t* pair_off, uint32_t* pair_cnt, uint32_t* matches, hipStream_t s);
 
 // match_common.hip: device -> pinned host copy by a small-grid kernel that co-resides with the scan (bytes % 8 == 0)
-void launch_host_copy(void* dst_pinned, const void* src_dev, size_t bytes, hipStream_t s);
-void launch_reorder_matches(const uint32_t* src_off, const uint32_t* cnt, const uint64_t* dst_off, uint32_t npairs,
+hipError_t launch_host_copy(void* dst_pinned, const void* src_dev, size_t bytes, hipStream_t s);
+hipError_t launch_reorder_matches(const uint32_t* src_off, const uint32_t* cnt, const uint64_t* dst_off, uint32_t npairs,
                             const uint32_t* src, uint32_t* dst, hipStream_t s);
 
 // ----- two-view verification (tvg_core.h; kernels in tvg_e.hip, tvg_fh.hip and their _big builds) ------------------------------------------------------

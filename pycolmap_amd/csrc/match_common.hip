@@ -1,6 +1,7 @@
 // match_common.hip — descriptor preparation and the finalize (thresholds + cross-check +
 // ordered compaction) kernel shared by both match kernels.  gfx950 only.
 #include <algorithm>
+#include <atomic>
 #include <climits>
 #include <cstdlib>
 
@@ -49,12 +50,39 @@ __global__ __launch_bounds__(256) void prep_kernel(const uint8_t* __restrict__ r
     if ((threadIdx.x & 63) == 0) atomicMax(maxsq_out, sq);
 }
 
-void launch_prep(const uint8_t* raw, uint8_t* prep, int32_t* rs128, uint32_t rows_pad,
-                 uint32_t* maxsq_out, hipStream_t s) {
-    if (rows_pad == 0) return;
+// The test hook of memset_async / memcpy_async (amc_internal.h): true exactly once, on the k-th call made while the
+// variable holds the positive integer k.
+static bool fault_due(const char* name, std::atomic<long>& seen, std::atomic<long>& armed) {
+    const char* e = std::getenv(name);
+    const long k = e ? std::atol(e) : 0;
+    if (k <= 0) {
+        if (armed.load(std::memory_order_relaxed) != 0) {
+            armed.store(0);
+            seen.store(0);
+        }
+        return false;
+    }
+    if (armed.exchange(k) != k) seen.store(0);
+    return seen.fetch_add(1) + 1 == k;
+}
+hipError_t memset_async(void* p, int value, size_t bytes, hipStream_t s) {
+    static std::atomic<long> seen{0}, armed{0};
+    if (fault_due("AMC_FAIL_NEXT_MEMSET", seen, armed)) return hipErrorInvalidValue;
+    return hipMemsetAsync(p, value, bytes, s);
+}
+hipError_t memcpy_async(void* dst, const void* src, size_t bytes, hipMemcpyKind kind, hipStream_t s) {
+    static std::atomic<long> seen{0}, armed{0};
+    if (fault_due("AMC_FAIL_NEXT_MEMCPY", seen, armed)) return hipErrorInvalidValue;
+    return hipMemcpyAsync(dst, src, bytes, kind, s);
+}
+
+hipError_t launch_prep(const uint8_t* raw, uint8_t* prep, int32_t* rs128, uint32_t rows_pad,
+                       uint32_t* maxsq_out, hipStream_t s) {
+    if (rows_pad == 0) return hipSuccess;
     const uint32_t nthreads = rows_pad * 8u;
     hipLaunchKernelGGL(prep_kernel, dim3((nthreads + 255) / 256), dim3(256), 0, s, raw, prep,
                        rs128, rows_pad, maxsq_out);
+    return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------
@@ -693,7 +721,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     }
 }
 
-void launch_resolve_index(int side, const ImageDev* imgs, const PairDev* pairs, uint32_t npairs,
+hipError_t launch_resolve_index(int side, const ImageDev* imgs, const PairDev* pairs, uint32_t npairs,
                           Top2* table, uint32_t* accmask, const float* acos_lut, FinalizeParams fp,
                           const uint32_t* cand_cnt, const uint32_t* candbuf, uint32_t* err_count,
                           bool grouped, const uint32_t* order, uint32_t norder, hipStream_t s) {
@@ -702,7 +730,7 @@ void launch_resolve_index(int side, const ImageDev* imgs, const PairDev* pairs, 
     // image Y (512 KB of tiles) and a third of image X; in plain pair order (image 1 major) neighbours shared X only
     // and the launch moved ~0.7 MB per pair from HBM.  Without it: one workgroup per pair of the batch.
     const uint32_t grid = order ? norder : npairs;
-    if (grid == 0) return;
+    if (grid == 0) return hipSuccess;
     const bool dot4_form = std::getenv("AMC_RESOLVE_DOT4") != nullptr;  // (test hook / A/B: the v_dot4 form)
     if (grouped && !dot4_form)
         hipLaunchKernelGGL(resolve_index_mfma_kernel, dim3(grid), dim3(256), 0, s, side, imgs, pairs,
@@ -713,6 +741,7 @@ void launch_resolve_index(int side, const ImageDev* imgs, const PairDev* pairs, 
     else
         hipLaunchKernelGGL(resolve_index_kernel, dim3(grid), dim3(256), 0, s, side, imgs, pairs,
                            table, accmask, acos_lut, fp, cand_cnt, candbuf, err_count, order);
+    return hipGetLastError();
 }
 uint32_t resolve_grouped_max_rows() { return kResolveMaxTiles * 32; }
 
@@ -776,17 +805,20 @@ __global__ __launch_bounds__(256) void select_candidates_kernel(
     if (tid == 255) cand_cnt[blockIdx.x] = base + inc;
 }
 
-void launch_select_candidates(const ImageDev* imgs, const PairDev* pairs, uint32_t npairs, uint32_t max_cols,
+hipError_t launch_select_candidates(const ImageDev* imgs, const PairDev* pairs, uint32_t npairs, uint32_t max_cols,
                               const Top2* rowbuf, const uint32_t* accmask, const float* acos_lut,
                               FinalizeParams fp, uint32_t* cand_cnt, uint32_t* candbuf, hipStream_t s) {
-    if (npairs == 0) return;
+    if (npairs == 0) return hipSuccess;
     const uint32_t per = ((max_cols + 31) / 32 + 255) / 256;
     const size_t shmem = (size_t)std::max(per, 1u) * 256 * sizeof(uint32_t);
-    if (shmem > 48 * 1024)  // above the default dynamic-LDS limit (images beyond 393,216 descriptors): opt in, per device
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(select_candidates_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kSelectMaxCols / 8));
+    if (shmem > 48 * 1024) {  // above the default dynamic-LDS limit (images beyond 393,216 descriptors): opt in, per device
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(select_candidates_kernel),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kSelectMaxCols / 8));
+        if (e != hipSuccess) return e;
+    }
     hipLaunchKernelGGL(select_candidates_kernel, dim3(npairs), dim3(256), shmem, s, imgs, pairs,
                        rowbuf, accmask, acos_lut, fp, cand_cnt, candbuf);
+    return hipGetLastError();
 }
 
 // Pair p's matches sit at src + 2 * src_off[p] (finalize_kernel's atomic-cursor order); move them to
@@ -804,11 +836,12 @@ __global__ __launch_bounds__(256) void reorder_matches_kernel(const uint32_t* __
     uint2* d = dst + dst_off[p];
     for (uint32_t i = threadIdx.x & 63; i < n; i += 64) d[i] = s[i];
 }
-void launch_reorder_matches(const uint32_t* src_off, const uint32_t* cnt, const uint64_t* dst_off, uint32_t npairs,
-                            const uint32_t* src, uint32_t* dst, hipStream_t s) {
-    if (npairs == 0) return;
+hipError_t launch_reorder_matches(const uint32_t* src_off, const uint32_t* cnt, const uint64_t* dst_off, uint32_t npairs,
+                                  const uint32_t* src, uint32_t* dst, hipStream_t s) {
+    if (npairs == 0) return hipSuccess;
     hipLaunchKernelGGL(reorder_matches_kernel, dim3((npairs + 3) / 4), dim3(256), 0, s, src_off, cnt, dst_off, npairs,
                        reinterpret_cast<const uint2*>(src), reinterpret_cast<uint2*>(dst));
+    return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------
@@ -834,32 +867,36 @@ __global__ __launch_bounds__(256) void host_copy_kernel(uint4* __restrict__ dst,
     for (; i < n16; i += stride) dst[i] = src[i];
     if (blockIdx.x == 0 && threadIdx.x < tail8) dst_tail[threadIdx.x] = src_tail[threadIdx.x];
 }
-void launch_host_copy(void* dst_pinned, const void* src_dev, size_t bytes, hipStream_t s) {
-    if (bytes == 0) return;
+hipError_t launch_host_copy(void* dst_pinned, const void* src_dev, size_t bytes, hipStream_t s) {
+    if (bytes == 0) return hipSuccess;
     // both pointers are 8-byte aligned (matches are uint32 pairs); the bulk runs from the first 16-byte boundary
     const uintptr_t a = reinterpret_cast<uintptr_t>(src_dev);
     const size_t head = (a & 15) && ((reinterpret_cast<uintptr_t>(dst_pinned) & 15) == (a & 15)) ? 16 - (a & 15) : 0;
     const bool same_phase = (reinterpret_cast<uintptr_t>(dst_pinned) & 15) == (a & 15);
     if (!same_phase || bytes < ((size_t)1 << 20)) {  // small, or the two sides are not 16-byte congruent: the runtime's copy
-        (void)hipMemcpyAsync(dst_pinned, src_dev, bytes, hipMemcpyDeviceToHost, s);
-        return;
+        return memcpy_async(dst_pinned, src_dev, bytes, hipMemcpyDeviceToHost, s);
     }
     const char* sp = static_cast<const char*>(src_dev);
     char* dp = static_cast<char*>(dst_pinned);
-    if (head) (void)hipMemcpyAsync(dp, sp, head, hipMemcpyDeviceToHost, s);
+    if (head) {
+        const hipError_t e = memcpy_async(dp, sp, head, hipMemcpyDeviceToHost, s);
+        if (e != hipSuccess) return e;
+    }
     const size_t body = bytes - head, n16 = body / 16, tail = body - n16 * 16;
     hipLaunchKernelGGL(host_copy_kernel, dim3(kHostCopyBlocks), dim3(256), 0, s, reinterpret_cast<uint4*>(dp + head),
                        reinterpret_cast<const uint4*>(sp + head), n16, reinterpret_cast<uint2*>(dp + head + n16 * 16),
                        reinterpret_cast<const uint2*>(sp + head + n16 * 16), (uint32_t)(tail / 8));
+    return hipGetLastError();
 }
 
-void launch_finalize(const ImageDev* imgs, const PairDev* pairs, uint32_t npairs,
-                     const Top2* rowbuf, const Top2* colbuf, const uint32_t* accmask,
-                     const float* acos_lut, FinalizeParams fp, uint32_t* cursor, uint32_t capacity,
-                     uint32_t* pair_off, uint32_t* pair_cnt, uint32_t* matches, hipStream_t s) {
-    if (npairs == 0) return;
+hipError_t launch_finalize(const ImageDev* imgs, const PairDev* pairs, uint32_t npairs,
+                           const Top2* rowbuf, const Top2* colbuf, const uint32_t* accmask,
+                           const float* acos_lut, FinalizeParams fp, uint32_t* cursor, uint32_t capacity,
+                           uint32_t* pair_off, uint32_t* pair_cnt, uint32_t* matches, hipStream_t s) {
+    if (npairs == 0) return hipSuccess;
     hipLaunchKernelGGL(finalize_kernel, dim3(npairs), dim3(256), 0, s, imgs, pairs, rowbuf,
                        colbuf, accmask, acos_lut, fp, cursor, capacity, pair_off, pair_cnt, matches);
+    return hipGetLastError();
 }
 
 }  // namespace amc

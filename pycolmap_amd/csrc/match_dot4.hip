@@ -176,15 +176,16 @@ __global__ __launch_bounds__(256) void match_dot4_kernel(const ImageDev* __restr
     }
 }
 
-void launch_match_dot4(const ImageDev* imgs, const PairDev* pairs, const Dot4Work* work,
-                       uint32_t nwork, Top2* rowbuf, Top2* colbuf, const GuidedDev* guided, hipStream_t s) {
-    if (nwork == 0) return;
+hipError_t launch_match_dot4(const ImageDev* imgs, const PairDev* pairs, const Dot4Work* work,
+                             uint32_t nwork, Top2* rowbuf, Top2* colbuf, const GuidedDev* guided, hipStream_t s) {
+    if (nwork == 0) return hipSuccess;
     if (guided)
         hipLaunchKernelGGL((match_dot4_kernel<true>), dim3(nwork), dim3(256), 0, s, imgs, pairs, work,
                            rowbuf, colbuf, guided);
     else
         hipLaunchKernelGGL((match_dot4_kernel<false>), dim3(nwork), dim3(256), 0, s, imgs, pairs, work,
                            rowbuf, colbuf, guided);
+    return hipGetLastError();
 }
 
 }  // namespace amc

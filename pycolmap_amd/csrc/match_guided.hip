@@ -183,11 +183,12 @@ __global__ __launch_bounds__(256) void match_guided_grid_kernel(const ImageDev* 
     }
 }
 
-void launch_match_guided_grid(const ImageDev* imgs, const GridDev* grids, const PairDev* pairs, const Dot4Work* work,
-                              uint32_t nwork, Top2* rowbuf, Top2* colbuf, const GuidedDev* guided, hipStream_t s) {
-    if (nwork == 0) return;
+hipError_t launch_match_guided_grid(const ImageDev* imgs, const GridDev* grids, const PairDev* pairs, const Dot4Work* work,
+                                    uint32_t nwork, Top2* rowbuf, Top2* colbuf, const GuidedDev* guided, hipStream_t s) {
+    if (nwork == 0) return hipSuccess;
     hipLaunchKernelGGL(match_guided_grid_kernel, dim3(nwork), dim3(256), 0, s, imgs, grids, pairs, work, rowbuf, colbuf,
                        guided);
+    return hipGetLastError();
 }
 
 }  // namespace amc

@@ -736,19 +736,17 @@ __global__ __launch_bounds__(256) void seg_fill_kernel(int mode, const ImageDev*
     }
 }
 
-void launch_build_segments(int mode, const ImageDev* imgs, const PairDev* pairs, const uint32_t* order,
-                           const uint32_t* grp_start, uint32_t ngroups, const uint32_t* cand_cnt,
-                           const uint32_t* candbuf, Top2* outbuf, uint32_t* seg_base, uint32_t* grp_segs,
-                           uint32_t* grp_item_base, SegDesc* segs, uint32_t* nitems_dev, hipStream_t s) {
-    if (ngroups == 0) {
-        (void)hipMemsetAsync(nitems_dev, 0, sizeof(uint32_t), s);
-        return;
-    }
+hipError_t launch_build_segments(int mode, const ImageDev* imgs, const PairDev* pairs, const uint32_t* order,
+                                 const uint32_t* grp_start, uint32_t ngroups, const uint32_t* cand_cnt,
+                                 const uint32_t* candbuf, Top2* outbuf, uint32_t* seg_base, uint32_t* grp_segs,
+                                 uint32_t* grp_item_base, SegDesc* segs, uint32_t* nitems_dev, hipStream_t s) {
+    if (ngroups == 0) return memset_async(nitems_dev, 0, sizeof(uint32_t), s);
     hipLaunchKernelGGL(seg_count_kernel, dim3(ngroups), dim3(256), 0, s, mode, imgs, pairs, order, grp_start,
                        cand_cnt, seg_base, grp_segs);
     hipLaunchKernelGGL(seg_scan_kernel, dim3(1), dim3(1024), 0, s, grp_segs, ngroups, grp_item_base, nitems_dev);
     hipLaunchKernelGGL(seg_fill_kernel, dim3(ngroups, kFillY), dim3(256), 0, s, mode, imgs, pairs, order, grp_start,
                        cand_cnt, candbuf, seg_base, grp_segs, grp_item_base, outbuf, segs);
+    return hipGetLastError();
 }
 
 int match_mfma_shape() {
@@ -761,18 +759,20 @@ int match_mfma_shape() {
     return shape;
 }
 
-void launch_match_mfma(int mode, const SegDesc* segs, const uint32_t* nitems_dev, uint32_t max_items,
-                       uint32_t* queue_head, uint32_t* accmask, const ScanAccept* accept_dev, hipStream_t s,
-                       const CopyJob& job_in, uint32_t* copy_head) {
-    if (max_items == 0) return;  // (the caller checks: a job is only handed to a launch that happens)
+hipError_t launch_match_mfma(int mode, const SegDesc* segs, const uint32_t* nitems_dev, uint32_t max_items,
+                             uint32_t* queue_head, uint32_t* accmask, const ScanAccept* accept_dev, hipStream_t s,
+                             const CopyJob& job_in, uint32_t* copy_head) {
+    if (max_items == 0) return hipSuccess;  // (the caller checks: a job is only handed to a launch that happens)
     CopyJob job = (mode == 0 && copy_head) ? job_in : CopyJob();
-    if (job.parts) (void)hipMemsetAsync(copy_head, 0, sizeof(uint32_t), s);
+    // The persistent workgroups pop from these two counters: nothing is launched unless both were reset.
+    hipError_t e = job.parts ? memset_async(copy_head, 0, sizeof(uint32_t), s) : hipSuccess;
+    if (e != hipSuccess) return e;
     int dev = 0, cus = 256;
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
+    if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
     const uint32_t grid = max_items < (uint32_t)cus ? max_items : (uint32_t)cus;  // 1 WG per CU
     if (job.parts > grid) job.parts = grid;  // every part needs a workgroup
-    (void)hipMemsetAsync(queue_head, 0, sizeof(uint32_t), s);
+    if ((e = memset_async(queue_head, 0, sizeof(uint32_t), s)) != hipSuccess) return e;
     const bool w4 = match_mfma_shape() == 4;
 #define AMC_LAUNCH(M, W, XT)                                                                             \
     hipLaunchKernelGGL((match_mfma_kernel<M, W, XT>), dim3(grid), dim3(64 * W), 0, s, segs, nitems_dev, \
@@ -783,6 +783,7 @@ void launch_match_mfma(int mode, const SegDesc* segs, const uint32_t* nitems_dev
         if (w4) AMC_LAUNCH(1, 4, 8); else AMC_LAUNCH(1, 8, 4);
     }
 #undef AMC_LAUNCH
+    return hipGetLastError();
 }
 
 }  // namespace amc

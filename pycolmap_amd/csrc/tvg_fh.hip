@@ -347,7 +347,7 @@ hipError_t launch_tvg_fh(const TvgImage* imgs, const TvgPair* pairs, uint32_t np
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tvg_fh_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    e = hipMemsetAsync(queue_head, 0, sizeof(uint32_t), s);
+    e = memset_async(queue_head, 0, sizeof(uint32_t), s);  // (the persistent waves pop pairs from it)
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(tvg_fh_kernel, dim3(blocks), dim3(64 * waves_per_block), lds, s, imgs, pairs, npairs, matches,
                        trial_tabs, P, ws, mask_ws, mcap, queue_head, estate, emask, out, out_mask);

@@ -52,7 +52,7 @@ __global__ __launch_bounds__(64 * W) void ladder_kernel(int tiles, const int* __
     for (int xt = 0; xt < XT; ++xt)
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            const int* p = seed + ((tid * 16 + xt * 64 + s * 4) & 4095);
+            const int* p = seed + 4096 + ((tid * 16 + xt * 64 + s * 4) & 4095);  // (second half: the resident X side's bytes)
             if constexpr (BA)
                 asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(xf[xt][s]) : "v"(p) : "memory");
             else
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(64 * W) void ladder2_kernel(int tiles, const int* _
     for (int xt = 0; xt < XT; ++xt)
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            const int* p = seed + ((tid * 16 + xt * 64 + s * 4) & 4095);
+            const int* p = seed + 4096 + ((tid * 16 + xt * 64 + s * 4) & 4095);  // (second half: the resident X side's bytes)
             if constexpr (BA)
                 asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(xf[xt][s]) : "v"(p) : "memory");
             else
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(64 * W) void ladder16_kernel(int tiles, const int* 
 #pragma unroll
     for (int xt = 0; xt < XT; ++xt)
 #pragma unroll
-        for (int s = 0; s < 2; ++s) xf[xt][s] = *reinterpret_cast<const i32x4v*>(seed + ((tid * 16 + xt * 64 + s * 4) & 4095));
+        for (int s = 0; s < 2; ++s) xf[xt][s] = *reinterpret_cast<const i32x4v*>(seed + 4096 + ((tid * 16 + xt * 64 + s * 4) & 4095));
     int best[XT], sec[XT], btile[XT];
 #pragma unroll
     for (int xt = 0; xt < XT; ++xt) best[xt] = sec[xt] = btile[xt] = 0;
@@ -446,33 +446,48 @@ int main() {
     // operand data: the matrix pipe's power (hence the clock the chip holds) depends on what it multiplies.
     //   LADDER_DATA=0 random bytes (default) | 1 SIFT-like under the kernel's zero point (0x80 + small values)
     //   2 small positive bytes (what a zero point of 0 would feed) | 3 zeros | 4 all 0x80
+    //   5 small - 36 (a per-image zero point z = max byte - 127 of extractor-like data: small magnitudes of either sign)
+    //   6 small - 64
+    // LADDER_DATA_X: the same choice for the resident X side alone (default: what LADDER_DATA says) - the streamed Y side
+    // (A operand, through LDS) and the X side (B operand, registers) may be encoded independently.
     const int mode = std::getenv("LADDER_DATA") ? std::atoi(std::getenv("LADDER_DATA")) : 0;
-    std::vector<int> h(4096);
+    const int mode_x = std::getenv("LADDER_DATA_X") ? std::atoi(std::getenv("LADDER_DATA_X")) : mode;
+    std::vector<int> h(8192);
     unsigned s = 12345;
     auto rnd = [&] { s = s * 1664525u + 1013904223u; return s >> 8; };
-    for (auto& v : h) {
+    for (size_t i = 0; i < h.size(); ++i) {
+        const int md = i < 4096 ? mode : mode_x;
         unsigned w = 0;
         for (int b = 0; b < 4; ++b) {
             unsigned byte;
             const unsigned r = rnd();
             const unsigned small = (r & 1) ? (r >> 1) % 12 : ((r >> 1) % 64);  // half near zero, half up to 63
-            switch (mode) {
+            switch (md) {
                 case 1: byte = 0x80u + small; break;
                 case 2: byte = small; break;
                 case 3: byte = 0; break;
                 case 4: byte = 0x80u; break;
+                case 5: byte = (small - 36u) & 255u; break;
+                case 6: byte = (small - 64u) & 255u; break;
                 default: byte = r & 255u;
             }
             w |= byte << (8 * b);
         }
-        v = (int)w;
+        h[i] = (int)w;
     }
-    std::printf("data mode %d\n", mode);
+    std::printf("data mode %d (Y side), %d (X side)\n", mode, mode_x);
     int *d_seed, *d_out;
-    CHECK(hipMalloc(&d_seed, 4096 * sizeof(int) + 64));
+    CHECK(hipMalloc(&d_seed, 8192 * sizeof(int) + 64));
     CHECK(hipMalloc(&d_out, 4096 * sizeof(int)));
-    CHECK(hipMemcpy(d_seed, h.data(), 4096 * sizeof(int), hipMemcpyHostToDevice));
+    CHECK(hipMemcpy(d_seed, h.data(), 8192 * sizeof(int), hipMemcpyHostToDevice));
     std::printf("CUs %d\n", cus);
+    if (std::getenv("LADDER_QUICK")) {  // the bare loop and the kernel's loop only (data-mode sweeps)
+        run<8, 4, 0, 0>("MFMA only", d_seed, d_out, cus);
+        run<8, 4, 2, 0>("+ C-operand block", d_seed, d_out, cus);
+        run<8, 4, 3, 0>("+ 12 VALU per unit", d_seed, d_out, cus);
+        run<4, 8, 3, 0>("+ 12 VALU per unit", d_seed, d_out, cus);
+        return 0;
+    }
     run<8, 4, 0, 0>("MFMA only", d_seed, d_out, cus);
     run<8, 4, 1, 0>("+ A-fragment ds_read_b128", d_seed, d_out, cus);
     run<8, 4, 2, 0>("+ C-operand block", d_seed, d_out, cus);
