@@ -123,14 +123,16 @@ def fp64_roofline(work, kernel_s, launches, pairs=0):
     return out
 
 
-def make_arena_torch(num_images: int, feats: int, seed: int, device, overlap: str = "ring"):
+def make_arena_torch(num_images: int, feats: int, seed: int, device, overlap: str = "ring", stats: str = "l2"):
     """Seeded SIFT-like descriptors generated on the GPU (SURVEY.md section 8d recipe).
 
     Landmarks sit on a ring; image i views a window of the ring that overlaps its ~8 nearest
     neighbours on either side and nothing else — like an exhaustive match of a real capture,
     most of the N^2/2 pairs have no true overlap.  Per image: 60 % noisy copies of visible
     landmark prototypes + 40 % pure-noise features, shuffled, L2-normalised, x512, rounded,
-    clamped to uint8 (COLMAP's storage convention)."""
+    clamped to uint8 (COLMAP's storage convention).  stats="sift": what SIFT extractors really write - L2-normalise,
+    clamp at 0.2, normalise again, x512 (Lowe's illumination clamp; COLMAP's and VLFeat's descriptors): nearly all
+    bytes below 128, a handful above (the `sift_stats` leg)."""
     import torch
     g = torch.Generator(device=device)
     g.manual_seed(seed)
@@ -152,6 +154,9 @@ def make_arena_torch(num_images: int, feats: int, seed: int, device, overlap: st
             d = torch.cat([d, noise], 0)
         d = d[torch.randperm(feats, generator=g, device=device)].clamp_min(0)
         d = d / d.norm(dim=1, keepdim=True).clamp_min(1e-12)
+        if stats == "sift":
+            d = d.clamp_max(0.2)
+            d = d / d.norm(dim=1, keepdim=True).clamp_min(1e-12)
         arena[i] = torch.round(512.0 * d).clamp(0, 255).to(torch.uint8)
     return arena
 
@@ -438,7 +443,7 @@ def pipeline_leg(ctx_factory, steps: int, warmup: int, cpu_pairs: int, num_image
     return out
 
 
-def dense_leg(ctx_factory, device, steps: int, warmup: int, num_images: int, feats: int, kernel: str):
+def dense_leg(ctx_factory, device, steps: int, warmup: int, num_images: int, feats: int, kernel: str, check: bool = True):
     """configs[1] on a set where EVERY pair overlaps (all images look at the same landmarks): the share of accepted
     rows is ~100x that of the sparse set, so the reverse scan of the candidate columns and the D2H of the match
     table stop being negligible.  Reported beside the headline, same unit."""
@@ -468,12 +473,15 @@ def dense_leg(ctx_factory, device, steps: int, warmup: int, num_images: int, fea
         scan += st["match_kernel_ms"]; cross += st["cross_kernel_ms"]; dev += st["device_ms"]
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    # a seeded sample of the last step's pairs against the CPU oracle (~1,000 matches each)
+    chk = spot_check(lambda u: arena[u].cpu().numpy(), s1, s2, off, m, sample=6) if check else {}
     ctx.close()
     nm = int(m.shape[0])
     return {"metric": "descriptor-pair distances/sec, every pair overlapping", "value": float(st["num_distances"]) * steps / dt,
             "unit": "distances/s", "workload": f"{num_images} images x {feats} descriptors, all images share their landmarks",
             "steps": steps, "ms_per_step": 1e3 * dt / steps, "matches_per_pair": nm / max(len(s1), 1),
-            "match_table_bytes": nm * 8,
+            "match_table_bytes": nm * 8, **chk,
+            "scan_kernel_ms": scan / steps, "resolve_select_reverse_scan_ms": cross / steps,
             "stage_ms_per_step": {"scan_kernel": scan / steps, "resolve_select_reverse_scan": cross / steps,
                                   "device_total_incl_d2h": dev / steps,
                                   "host_side_of_the_call": 1e3 * dt / steps - dev / steps,
@@ -525,7 +533,7 @@ def db_leg(num_images: int, feats: int, seed: int = 11):
 
 
 def ragged_leg(ctx_factory, device, steps: int, warmup: int, num_images: int, lo: int, hi: int, kernel: str,
-               uniform_value: float):
+               uniform_value: float, check: bool = True):
     """configs[1] with image sizes a real capture has: n ~ U[lo, hi] descriptors per image (seeded), nothing a multiple
     of the kernel's 128-row segments or 256-row chunks.  Same generator, same sparse overlap as the headline; reported
     beside it in the same unit, with the scan kernel's own rate, so that a tiling that only suits 4096 = 4 x 1024 rows
@@ -554,11 +562,13 @@ def ragged_leg(ctx_factory, device, steps: int, warmup: int, num_images: int, lo
         scan += st["match_kernel_ms"]; cross += st["cross_kernel_ms"]; launches += st["match_kernel_launches"]
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    chk = spot_check(lambda u: arena[u, :int(rows[u])].cpu().numpy(), s1, s2, off, m, sample=8) if check else {}
     ctx.close()
     ndist = float(st["num_distances"])
     value = ndist * steps / dt
     scan_ops = ndist * steps * OPS_PER_DISTANCE / (scan * 1e-3) if scan > 0 else 0.0
-    return {"metric": "descriptor-pair distances/sec, ragged image sizes", "value": value, "unit": "distances/s",
+    return {"metric": "descriptor-pair distances/sec, ragged image sizes", "value": value, "unit": "distances/s", **chk,
+            "scan_kernel_ms": scan / steps, "resolve_select_reverse_scan_ms": cross / steps,
             "workload": f"{num_images} images, n ~ U[{lo}, {hi}] descriptors (seed 7; mean {float(rows.mean()):.0f}), "
                         f"exhaustive match + ratio test + cross-check",
             "steps": steps, "ms_per_step": 1e3 * dt / steps, "distances_per_step": ndist,
@@ -566,6 +576,49 @@ def ragged_leg(ctx_factory, device, steps: int, warmup: int, num_images: int, lo
             "scan_frac_of_int8_peak": scan_ops / INT8_DENSE_PEAK_OPS,
             "stage_ms_per_step": {"scan_kernel": scan / steps, "resolve_select_reverse_scan": cross / steps},
             "scan_launches_per_step": launches // max(steps, 1), "matches": int(m.shape[0])}
+
+
+def sift_stats_leg(ctx_factory, device, steps: int, warmup: int, num_images: int, feats: int, kernel: str,
+                   uniform_value: float, check: bool = True):
+    """configs[1] on descriptors with the byte statistics extractors really write (L2-normalise, clamp 0.2, renormalise,
+    x512: make_arena_torch(stats="sift")) - the same scene recipe, the same sparse overlap as the headline.  The scan is
+    bound by the chip's power budget and the clock it holds moves with the operand bytes: this leg
+    says what the headline's kernel does on data shaped like a real capture's."""
+    import torch
+    arena = make_arena_torch(num_images, feats, seed=3, device=device, stats="sift")
+    hi_share = float((arena >= 128).float().mean().item())
+    ctx = ctx_factory()
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.reserve_slots(num_images)
+    for i in range(num_images):
+        ctx.upload_descriptors_device(i, arena[i].data_ptr(), feats)
+    torch.cuda.synchronize()
+    from pycolmap_amd import synth
+    s1, s2 = synth.exhaustive_pairs(num_images)
+    for _ in range(warmup):
+        ctx.match_pairs(s1, s2, kernel=kernel)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    scan = cross = 0.0
+    launches = 0
+    for _ in range(steps):
+        off = m = None
+        off, m, st = ctx.match_pairs(s1, s2, kernel=kernel, copy=False)
+        scan += st["match_kernel_ms"]; cross += st["cross_kernel_ms"]; launches += st["match_kernel_launches"]
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    chk = spot_check(lambda u: arena[u].cpu().numpy(), s1, s2, off, m, sample=8) if check else {}
+    ctx.close()
+    ndist = float(st["num_distances"])
+    value = ndist * steps / dt
+    scan_ops = ndist * steps * OPS_PER_DISTANCE / (scan * 1e-3) if scan > 0 else 0.0
+    return {"metric": "descriptor-pair distances/sec, extractor byte statistics", "value": value, "unit": "distances/s", **chk,
+            "workload": f"{num_images} images x {feats} descriptors, L2-normalised, clamped at 0.2, renormalised, x512 "
+                        f"(share of bytes >= 128: {hi_share:.5f}); exhaustive match + ratio test + cross-check",
+            "steps": steps, "ms_per_step": 1e3 * dt / steps, "vs_headline": value / uniform_value if uniform_value > 0 else None,
+            "scan_frac_of_int8_peak": scan_ops / INT8_DENSE_PEAK_OPS, "scan_kernel_ms": scan / steps,
+            "resolve_select_reverse_scan_ms": cross / steps, "scan_launches_per_step": launches // max(steps, 1),
+            "matches": int(m.shape[0])}
 
 
 class _DryRunContext:
@@ -657,17 +710,44 @@ def device_sync(args):
         torch.cuda.synchronize()
 
 
-def run_config34(args):
+def spot_check(get_image, s1, s2, off, m, sample: int = 6, seed: int = 99):
+    """A seeded sample of the pairs a leg just matched, recomputed by the CPU oracle (oracle/match_oracle.c, the
+    literal port) and compared row for row with the GPU's result: {"gpu_vs_oracle_mismatching_pairs", "pairs_checked"}."""
+    sys.path.insert(0, str(ROOT / "tests"))
+    import oracle_lib
+    if len(s1) == 0:
+        return {"gpu_vs_oracle_mismatching_pairs": 0, "pairs_checked": 0}
+    rs = np.random.default_rng(seed)
+    idx = np.sort(rs.choice(len(s1), size=min(sample, len(s1)), replace=False))
+    used = np.unique(np.concatenate([s1[idx], s2[idx]]))
+    remap = {int(u): k for k, u in enumerate(used)}
+    imgs = [np.ascontiguousarray(get_image(int(u))) for u in used]
+    a = np.array([remap[int(x)] for x in s1[idx]], np.uint32)
+    b = np.array([remap[int(x)] for x in s2[idx]], np.uint32)
+    coff, cm = oracle_lib.match_pairs(imgs, a, b, threads=min(host_cores(), len(idx)))
+    mism = 0
+    for k, p in enumerate(idx):
+        g = m[int(off[p]):int(off[p + 1])]
+        c = cm[int(coff[k]):int(coff[k + 1])]
+        if g.shape != c.shape or not np.array_equal(g, c):
+            mism += 1
+    return {"gpu_vs_oracle_mismatching_pairs": int(mism), "pairs_checked": int(len(idx))}
+
+
+def config34_leg(args, config: int, steps: int, warmup: int, dist_state):
     """BASELINE configs[3] (2000 x 8192 exhaustive) and configs[4] (10000 x 4096 sequential + loop): a FIXED
     workload whose pairs are sharded over the ranks by work (sum of n1 * n2), the descriptor arena replicated on
-    every GPU, one RCCL all-gather of the match tables at the end of every step (inside the timed region)."""
+    every GPU, one all-gather of the match tables at the end of every step (inside the timed region) - through the
+    library's own entry point (amc_allgather_match_tables: RCCL called behind the C ABI, rows straight from the
+    device memory the kernels wrote).  Collective: every rank calls it; rank 0 gets the leg's dict, the others None."""
     import torch
     import torch.distributed as dist
     from pycolmap_amd import _capi, synth
     from pycolmap_amd import distributed as D
 
-    world, rank, local_rank, device, use_dist = dist_setup(args)
+    world, rank, local_rank, device, use_dist = dist_state
     dry = args.cpu_dry_run
+    args = argparse.Namespace(**{**vars(args), "config": config, "steps": steps, "warmup": warmup})
 
     if args.config == 3:
         num_images = 2000 if args.images == 500 else args.images
@@ -716,6 +796,12 @@ def run_config34(args):
     loop_num_images = min(50, num_images - 1)
     exch = {"ms": 0.0}
 
+    # the exchange's communicator: the library's own (C ABI) on the GPUs - also with one rank, where the step is the
+    # copy into the global order - and torch.distributed over gloo under --cpu-dry-run
+    comm = None if dry else D.make_comm(ctx)
+    do_exchange = use_dist or comm is not None
+    abi = {"rows_ms": 0.0, "reorder_ms": 0.0, "rows_sent": 0}
+
     def exchange(fn):
         # the exchange step, timed on its own (host clock between device synchronisations): it waits for the slowest
         # rank's kernels, so it holds the load imbalance as well as the transfer
@@ -727,11 +813,15 @@ def run_config34(args):
         # the collective read the library's own device memory (resident()): no match call may have touched it meanwhile
         assert dry or ctx.resident_view_valid(gen), "a match call ran while the exchange held the resident match table"
         exch["ms"] += 1e3 * (time.perf_counter() - te)
+        if comm is not None:
+            st_ = D.last_gather_stats()
+            abi["rows_ms"] += st_["rows_ms"]; abi["reorder_ms"] += st_["reorder_ms"]; abi["rows_sent"] = st_["rows_sent"]
         return r
 
     def resident():
-        # the match table where the kernels left it in HBM (no host round trip before the collective)
-        return None if dry else ctx.resident_matches_tensor(local_rank)
+        # the match table where the kernels left it in HBM (no host round trip before the collective); with the
+        # library's communicator the rows are read there by the library itself
+        return None if dry else True
 
     def step():
         off, m, st = ctx.match_pairs(s1, s2, kernel=args.kernel, copy=False)
@@ -740,10 +830,10 @@ def run_config34(args):
         parts = [(mine, off, m)]
         extra = {}
         gathered = None
-        if use_dist:
+        if do_exchange:
             # sequential / exhaustive pairs have global positions: one all-gather of the tables, fed from device memory
             gathered = [exchange(lambda: D.all_gather_match_tables(mine, off, m, device=device, as_numpy=False,
-                                                                   device_matches=resident()))]
+                                                                   device_matches=resident(), comm=comm))]
         if args.config == 4 and len(queries):
             # loop closure (SequentialFeatureMatcher::RunLoopDetection with the vocabulary tree replaced by exact
             # feature voting): every 10th image against every other image on the first 512
@@ -764,13 +854,14 @@ def run_config34(args):
             extra = dict(loop_queries=int(len(queries)), loop_scoring_pairs=int(len(q1)), loop_pairs=int(len(l1)),
                          loop_scoring_distances=int(vst["num_distances"]), loop_match_distances=int(lst["num_distances"]))
             parts.append((None, loff, lm))
-        if use_dist and args.config == 4:
+        if do_exchange and args.config == 4:
             # the loop pairs of a rank are numbered after those of the ranks before it (one small all-gather of the counts)
             have = len(parts) > 1
             lo_, lm_ = (parts[1][1], parts[1][2]) if have else (np.zeros(1, np.uint64), np.zeros((0, 2), np.uint32))
             gathered.append(exchange(lambda: D.all_gather_appended_tables(lo_, lm_, device=device, as_numpy=False,
-                                                                          device_matches=resident() if have else None)))
-        return nd, kms, kl, int(sum(p[2].shape[0] for p in parts)), extra, gathered
+                                                                          device_matches=resident() if have else None,
+                                                                          comm=comm)))
+        return nd, kms, kl, int(sum(p[2].shape[0] for p in parts)), extra, gathered, (off, m)
 
     def fence():
         device_sync(args)
@@ -785,8 +876,9 @@ def run_config34(args):
     t0 = time.perf_counter()
     nd = kms = kl = nm = 0
     extra = {}
+    last_tab = None
     for _ in range(args.steps):
-        d_, k_, l_, nm, extra, _ = step()
+        d_, k_, l_, nm, extra, _, last_tab = step()
         nd += d_; kms += k_; kl += l_
     fence()
     elapsed = time.perf_counter() - t0
@@ -805,7 +897,7 @@ def run_config34(args):
         allper = allper.cpu().view(world, 2)
         kernel_ms_by_rank = [float(x) for x in allper[:, 0]]
         exch_ms_by_rank = [float(x) for x in allper[:, 1]]
-    final_line = None
+    out = None
     if rank == 0:
         avg_kernel_s = (kms / max(kl, 1)) * 1e-3
         ach = (nd_rank * OPS_PER_DISTANCE / max(kl, 1)) / avg_kernel_s if avg_kernel_s > 0 else 0.0
@@ -821,11 +913,16 @@ def run_config34(args):
             "dtype": "u8 descriptors, int8 MFMA / int32 accumulate", "data": "synthetic",
             "config": {"workload": name, "pairs_total": int(len(a_all)), "pairs_rank0": int(len(s1)),
                        "distances_per_step_all_ranks": nd / args.steps, "matches_rank0": nm,
-                       "rccl_ranks": world if (use_dist and not dry) else 0, "backend": ("gloo" if dry else args.backend) if use_dist else None,
+                       "rccl_ranks": world if (comm is not None) else 0, "backend": ("gloo" if dry else args.backend) if use_dist else None,
+                       "gather_path": D.last_gather_path() if do_exchange else None,
                        "kernel_ms_per_step_by_rank": kernel_ms_by_rank,
                        "exchange_ms_per_step": max(exch_ms_by_rank), "exchange_ms_per_step_by_rank": exch_ms_by_rank,
+                       "exchange_rows_ms_per_step_rank0": abi["rows_ms"] / max(args.steps, 1),
+                       "exchange_reorder_ms_per_step_rank0": abi["reorder_ms"] / max(args.steps, 1),
+                       "exchange_rows_sent_rank0": abi["rows_sent"],
                        "sharding": "pairs sorted by image 2, contiguous slices of equal sum(n1*n2), arena replicated; "
-                                   "one all-gather of the match tables per step", **extra},
+                                   "one all-gather of the match tables per step (amc_allgather_match_tables: sizes, "
+                                   "per-pair records, rows from the resident table by grouped ncclSend / ncclRecv)", **extra},
             "roofline": {"bound": "mfma", "achieved": ach / 1e12, "peak": INT8_DENSE_PEAK_OPS / 1e12,
                          "unit": "TOP/s (int8; 256 ops per descriptor-pair distance)", "frac": ach / INT8_DENSE_PEAK_OPS,
                          "frac_of_measured_i8_ceiling": ach / INT8_MEASURED_CEILING_OPS, "traffic": None,
@@ -837,17 +934,53 @@ def run_config34(args):
             out["metric"] = "DRY RUN (CPU oracle in place of the kernels, gloo in place of RCCL): NOT a measurement - " + out["metric"]
             out["data"] = "synthetic (cpu dry run)"
             out["roofline"] = None
-        final_line = json.dumps(out)
-    if use_dist:
+        elif last_tab is not None:
+            # rank 0's share of the last step against the CPU oracle, on a seeded sample of its pairs
+            out["config"].update(spot_check(lambda u: arena[u].cpu().numpy(), s1, s2, last_tab[0], last_tab[1],
+                                            sample=4 if args.config == 3 else 6))
+    if comm is not None:
+        comm.close()
+    ctx.close()
+    return out
+
+
+def print_line(out):
+    """The ONE JSON line, last thing on stdout (RCCL writes a version banner to the C stdout buffer, which would
+    otherwise be flushed at exit AFTER it: drain that first)."""
+    if out is None:
+        return
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
+    print(json.dumps(out), flush=True)
+
+
+def run_config34(args):
+    """`--config 3 | 4`: that configuration alone, as the line."""
+    import torch.distributed as dist
+    state = dist_setup(args)
+    out = config34_leg(args, args.config, args.steps, args.warmup, state)
+    if state[4]:
         dist.barrier()
         dist.destroy_process_group()
-    if final_line is not None:
-        import ctypes
-        try:
-            ctypes.CDLL(None).fflush(None)
-        except OSError:
-            pass
-        print(final_line, flush=True)
+    print_line(out)
+
+
+def config3_summary(leg):
+    """The strong-scaling leg every `python bench.py --gpus N` line carries (BASELINE configs[3], the workload north_star
+    states its ">= 7x at 8 GPUs" on): the scalars the scaling curve is read from, then the leg's own line."""
+    c = leg["config"]
+    return {"metric": leg["metric"], "value": leg["value"], "unit": leg["unit"], "scaling": "strong", "n_gpus": leg["n_gpus"],
+            "steps": leg["steps"], "warmup": leg["warmup"], "ms_per_step": leg["ms_per_step"],
+            "exchange_ms_per_step": c["exchange_ms_per_step"], "per_rank_kernel_ms": c["kernel_ms_per_step_by_rank"],
+            "max_rank_kernel_ms": max(c["kernel_ms_per_step_by_rank"]), "rccl_ranks": c["rccl_ranks"],
+            "gather_path": c["gather_path"], "workload": c["workload"], "pairs_total": c["pairs_total"],
+            "gpu_vs_oracle_mismatching_pairs": c.get("gpu_vs_oracle_mismatching_pairs"),
+            "pairs_checked": c.get("pairs_checked"),
+            "scan_frac_of_int8_peak": (leg["roofline"] or {}).get("frac") if leg.get("roofline") else None,
+            "dry_run": bool(leg.get("dry_run")), "line": leg}
 
 
 def main():
@@ -874,8 +1007,7 @@ def main():
                     help="1: BASELINE configs[1] (+ verify / pipeline / dense legs; the default at N=1); "
                          "3: configs[3], 2000 x 8192 fixed pair set sharded over the ranks (strong scaling; the default "
                          "at N>1); 4: configs[4], 10000 x 4096 sequential + loop matching, sharded")
-    ap.add_argument("--weak", action="store_true",
-                    help="N>1: weak scaling of configs[1] (the image set grows as 500*sqrt(N)) instead of configs[3]")
+    ap.add_argument("--weak", action="store_true", help="(accepted for older command lines: the headline at N>1 IS the weak-scaled configs[1])")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend of the exchange step (nccl = RCCL; gloo only with --cpu-dry-run)")
     ap.add_argument("--cpu-dry-run", action="store_true",
@@ -884,16 +1016,18 @@ def main():
     ap.add_argument("--no-pipeline", action="store_true", help="skip the chained configs[2] leg")
     ap.add_argument("--no-dense", action="store_true", help="skip the dense-overlap match leg")
     ap.add_argument("--no-ragged", action="store_true", help="skip the ragged-size match leg (n ~ U[2000, 6000])")
+    ap.add_argument("--no-sift-stats", action="store_true", help="skip the extractor-statistics match leg")
     ap.add_argument("--no-db", action="store_true", help="skip the database leg (pycolmap.match_exhaustive wall time)")
+    ap.add_argument("--no-config3", action="store_true", help="skip the configs[3] strong-scaling leg of the default line")
+    ap.add_argument("--config3-steps", type=int, default=0,
+                    help="timed steps of the configs[3] leg (0 = one at N=1, where a step is ~11 s, two at N>1)")
     args = ap.parse_args()
     if args.config is None:
-        args.config = 1 if (args.gpus == 1 or args.weak) else 3
+        args.config = 1
     if args.weak and args.config != 1:
         raise SystemExit("--weak is the N>1 variant of --config 1")
     if args.cpu_dry_run:
         args.backend = "gloo"
-        if args.config == 1:
-            raise SystemExit("--cpu-dry-run covers the sharded configurations (--config 3 | 4)")
     elif args.backend != "nccl":
         raise SystemExit("--backend gloo is for --cpu-dry-run: the measured path exchanges over RCCL")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -905,7 +1039,9 @@ def main():
     import torch.distributed as dist
     from pycolmap_amd import _capi, synth
 
-    world, rank, local_rank, device, use_dist = dist_setup(args)
+    state = dist_setup(args)
+    world, rank, local_rank, device, use_dist = state
+    dry = args.cpu_dry_run
 
     # ---- workload ------------------------------------------------------------------------
     num_images = args.images if world == 1 else int(round(args.images * math.sqrt(world)))
@@ -915,33 +1051,39 @@ def main():
     from pycolmap_amd import distributed as D
     s1, s2, mine = D.shard_pairs(s1_all, s2_all, rank, world, rows=np.full(num_images, args.feats))
 
-    ctx = _capi.Context(local_rank)
-    stream = torch.cuda.current_stream()
-    ctx.set_stream(stream.cuda_stream)
-    ctx.reserve_slots(num_images)
-    for i in range(num_images):
-        ctx.upload_descriptors_device(i, arena[i].data_ptr(), args.feats)
-    torch.cuda.synchronize()
+    if dry:
+        ctx = _DryRunContext()
+        ctx.reserve_slots(num_images)
+        for i in range(num_images):
+            ctx.upload_descriptors(i, arena[i].numpy())
+    else:
+        ctx = _capi.Context(local_rank)
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        ctx.reserve_slots(num_images)
+        for i in range(num_images):
+            ctx.upload_descriptors_device(i, arena[i].data_ptr(), args.feats)
+    device_sync(args)
+    # the exchange step of the sharded headline: the library's own entry point (amc_allgather_match_tables) on the GPUs
+    comm = D.make_comm(ctx) if (use_dist and not dry) else None
 
     def step():
         off, m, st = ctx.match_pairs(s1, s2, kernel=args.kernel, cross_check=not args.no_cross_check, copy=False)
         gathered = None
         if use_dist:
-            # the exchange step: RCCL all-gather of the match tables (sizes, then padded tables);
-            # afterwards every rank holds the whole match graph (rank 0 would feed the SQLite writer)
-            gen = ctx.resident_generation
+            # the exchange step: all-gather of the match tables (sizes, per-pair records, rows from the device memory
+            # the kernels wrote); afterwards every rank holds the whole match graph (rank 0 would feed the SQLite writer)
+            gen = None if dry else ctx.resident_generation
             gathered = D.all_gather_match_tables(mine, off, m, device=device, as_numpy=False,
-                                                 device_matches=ctx.resident_matches_tensor(local_rank))
-            # the view aliases library memory: the collectives that read it are done before the next match call
-            torch.cuda.current_stream().synchronize()
-            assert ctx.resident_view_valid(gen)
+                                                 device_matches=None if dry else True, comm=comm)
+            device_sync(args)
+            assert dry or ctx.resident_view_valid(gen)
         return off, m, st, gathered
 
     def fence():
-        torch.cuda.synchronize()
+        device_sync(args)
         if use_dist:
             dist.barrier()
-            torch.cuda.synchronize()
+            device_sync(args)
 
     for _ in range(args.warmup):
         step()
@@ -964,7 +1106,15 @@ def main():
         ndist_total = float(nd.item())
     else:
         ndist_total = float(ndist_local)
+    headline_gather_path = D.last_gather_path() if use_dist else None
 
+    # ---- BASELINE configs[3], fixed size, sharded: the strong-scaling leg of every line (collective) -----------------
+    c3 = None
+    if not args.no_config3:
+        steps3 = args.config3_steps if args.config3_steps > 0 else (1 if world == 1 else 2)
+        c3 = config34_leg(args, 3, steps3, 0 if world == 1 else 1, state)
+
+    out = None
     if rank == 0:
         off, m, st, _ = last
         ms_per_step = 1e3 * elapsed / args.steps
@@ -976,7 +1126,7 @@ def main():
         achieved = ops_per_launch / avg_kernel_s if avg_kernel_s > 0 else 0.0
         out = {
             "metric": "descriptor-pair distances/sec (exhaustive SIFT match: dot + top-2 + ratio + cross-check)",
-            "value": value,
+            "value": None if dry else value,
             "unit": "distances/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -989,7 +1139,8 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"{num_images} images x {args.feats} descriptors, exhaustive match + "
-                            f"ratio test + cross-check (BASELINE.json configs[1] at N=1)",
+                            f"ratio test + cross-check (BASELINE.json configs[1] at N=1"
+                            + ("" if world == 1 else f"; weak scaling: 500 x sqrt({world}) images, ~124,750 pairs per rank") + ")",
                 "pairs_total": int(len(s1_all)),
                 "pairs_per_rank": int(len(s1)),
                 "distances_total": ndist_total,
@@ -997,10 +1148,11 @@ def main():
                 "pairs_mfma": st["pairs_mfma"],
                 "pairs_dot4": st["pairs_dot4"],
                 "matches_rank0": int(m.shape[0]),
+                "gather_path": headline_gather_path,
                 "sharding": "pairs sorted by image 2, contiguous slice per rank, arena replicated"
-                            + ("; RCCL all-gather of match tables per step" if world > 1 else ""),
+                            + ("; all-gather of the match tables per step (amc_allgather_match_tables over RCCL)" if world > 1 else ""),
             },
-            "roofline": {
+            "roofline": None if dry else {
                 "bound": "mfma",
                 "achieved": achieved / 1e12,
                 "peak": INT8_DENSE_PEAK_OPS / 1e12,
@@ -1008,17 +1160,30 @@ def main():
                 "frac": achieved / INT8_DENSE_PEAK_OPS,
                 "frac_of_measured_i8_ceiling": achieved / INT8_MEASURED_CEILING_OPS,
                 "measured_i8_ceiling": INT8_MEASURED_CEILING_OPS / 1e12,
+                "whole_step_frac": value * OPS_PER_DISTANCE / INT8_DENSE_PEAK_OPS / max(world, 1),
                 "traffic": None,  # filled below from the committed PMC pass when the launch shape is the same
                 "kernel": "match_mfma_kernel" if st["pairs_mfma"] else "match_dot4_kernel",
                 "avg_kernel_ms": avg_kernel_s * 1e3,
                 "launches_per_step": launches_per_step,
             },
         }
+        if dry:
+            out["dry_run"] = True
+            out["metric"] = "DRY RUN (CPU oracle in place of the kernels, gloo in place of RCCL): NOT a measurement - " + out["metric"]
+            out["data"] = "synthetic (cpu dry run)"
+        if c3 is not None:
+            out["config3"] = config3_summary(c3)
+            # (the same scalars at the top level: a reader that keeps only one level of the line still has the curve)
+            out["config3_value"] = c3["value"]
+            out["config3_ms_per_step"] = c3["ms_per_step"]
+            out["config3_exchange_ms_per_step"] = c3["config"]["exchange_ms_per_step"]
         # HBM bytes per launch of the dominant kernel: PMC counters cannot be collected inside this process, so the
         # number comes from the committed rocprofv3 --pmc pass of this same command (profiles/*/pmc_hbm_*.json) - and
         # only while (i) this run launches the same shape and (ii) the kernel's source still hashes to what it was when
         # the counters were taken (roofline.traffic_source_sha); otherwise the field stays null.
         try:
+            if dry:
+                raise OSError("dry run")
             import hashlib
             pmc_path = sorted((ROOT / "profiles").glob("r*/pmc_hbm_r*.json"))[-1]
             pmc = json.loads(pmc_path.read_text())
@@ -1027,15 +1192,20 @@ def main():
             same_source = bool(shas) and all(hashlib.sha256((ROOT / f).read_bytes()).hexdigest() == h for f, h in shas.items())
             out["roofline"]["traffic_source"] = str(pmc_path.relative_to(ROOT))
             out["roofline"]["traffic_source_sha"] = shas
+            out["roofline"]["traffic_source_sha16"] = ",".join(h[:16] for h in shas.values())
             out["roofline"]["traffic_source_current"] = same_source
+            out["roofline"]["traffic_note"] = ("HBM counters cannot be read inside this process: traffic is the committed rocprofv3 "
+                                               "--pmc pass of this same command (traffic_source), per launch; null unless the "
+                                               "kernel source still hashes to what it was when the pass was taken")
             if same_source and st["pairs_mfma"] and args.feats == 4096 and abs(per_launch - pmc["pairs_per_launch"]) <= 1:
                 out["roofline"]["traffic"] = pmc["fetch_bytes_per_launch_corrected"]
-                out["roofline"]["traffic_unit"] = "bytes read from HBM per launch (FETCH_SIZE x 1024 x 2, gfx950 correction)"
+                out["roofline"]["traffic_unit"] = ("bytes read from HBM per launch (FETCH_SIZE x 1024 x 2, gfx950 correction), from the "
+                                                   "committed PMC pass named in traffic_source - not counted in this run")
                 out["roofline"]["traffic_written"] = pmc.get("write_bytes_per_launch")
                 out["roofline"]["algorithmic_bytes"] = float(per_launch) * 2 * args.feats * 128
         except (OSError, KeyError, ValueError, IndexError):
             pass
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not dry:
             cores = host_cores()
             arena_cpu = arena.cpu().numpy()
             sample = args.cpu_sample_pairs if args.cpu_sample_pairs > 0 else 8 * cores
@@ -1053,52 +1223,65 @@ def main():
                 "sample": f"{npairs} seeded pairs of the same {num_images}x{args.feats} workload, "
                           f"oracle/match_oracle.c (-O2, OpenMP, one pair per thread), {dt:.1f} s",
                 "gpu_vs_oracle_mismatching_pairs": mism,
+                # the two other CPU rates as scalars (the objects follow): the AVX-512 VNNI variant of the same matcher -
+                # what the host's cores can really do - and COLMAP's DEFAULT CPU matcher (approximate k-d forest, restated)
+                "optimised_value": cpu_opt["value"] if cpu_opt else None,
+                "optimised_identical_to_port": cpu_opt["identical_to_port"] if cpu_opt else None,
+                "default_cpu_matcher_value": cpu_default["value"],
+                "default_cpu_matcher_pairs_per_s": cpu_default["pairs_per_s"],
+                "default_cpu_matcher_port_matches_found": cpu_default["port_matches_found"],
                 "default_cpu_matcher": cpu_default,   # the k-d forest COLMAP's CPU path uses by default (approximate)
                 "optimised": cpu_opt,   # None on a host without AVX-512 VNNI
             }
-        if args.verify_pairs > 0 and world == 1:
+        gpu_legs = world == 1 and not dry
+        if args.verify_pairs > 0 and gpu_legs:
             out["verify"] = verify_leg(lambda: _capi.Context(local_rank), local_rank, args.verify_pairs,
                                        max(1, args.steps), min(1, args.warmup),
                                        0 if args.no_cpu_baseline else 256, distinct=args.verify_scenes)
+            vr = out["verify"]["roofline"]
+            out["verify"].update(roofline_frac=vr["frac"], roofline_achieved_tflops=vr["achieved"],
+                                 executed_note="verify.roofline.executed comes from the committed SQ counter pass named in its "
+                                               "`source` (instructions per pair), divided by this run's kernel time")
         def release_headline():   # the legs below bring their own contexts and arenas
             nonlocal arena, ctx
             if ctx is not None:
                 ctx.close()
                 ctx = arena = None
                 torch.cuda.empty_cache()
-        if world == 1 and not args.no_pipeline:
+        if gpu_legs and not args.no_pipeline:
             release_headline()
             out["pipeline"] = pipeline_leg(lambda: _capi.Context(local_rank), max(1, min(args.steps, 2)), min(1, args.warmup),
                                            0 if args.no_cpu_baseline else 4 * host_cores(), args.images, args.feats)
-        if world == 1 and not args.no_ragged:
+            sm = out["pipeline"]["stage_ms_per_step"]
+            out["pipeline"].update(verify_ms=sm["verify_ms"], verify_kernel_ms=sm["verify_kernel_ms"], match_ms=sm["match_ms"],
+                                   scan_ms=sm["scan_ms"])
+        if gpu_legs and not args.no_ragged:
             release_headline()
             # (five steps: with two, one slow host-side moment - 16 ms once in this round's runs - moves vs_uniform by 8 %)
             out["ragged"] = ragged_leg(lambda: _capi.Context(local_rank), device, max(1, min(args.steps, 5)),
-                                       min(1, args.warmup), args.images, 2000, 6000, args.kernel, value)
-        if world == 1 and not args.no_dense:
+                                       min(1, args.warmup), args.images, 2000, 6000, args.kernel, value,
+                                       check=not args.no_cpu_baseline)
+        if gpu_legs and not args.no_sift_stats:
+            release_headline()
+            out["sift_stats"] = sift_stats_leg(lambda: _capi.Context(local_rank), device, max(1, min(args.steps, 5)),
+                                               min(1, args.warmup), args.images, args.feats, args.kernel, value,
+                                               check=not args.no_cpu_baseline)
+        if gpu_legs and not args.no_dense:
+            release_headline()
             out["dense"] = dense_leg(lambda: _capi.Context(local_rank), device, max(1, min(args.steps, 3)),
-                                     min(1, args.warmup), args.images, args.feats, args.kernel)
-        if world == 1 and not args.no_db:
+                                     min(1, args.warmup), args.images, args.feats, args.kernel, check=not args.no_cpu_baseline)
+        if gpu_legs and not args.no_db:
             release_headline()
             try:
                 out["db"] = db_leg(args.images, args.feats)
             except Exception as e:  # the API leg must not take the kernel legs' numbers down with it
                 out["db"] = {"error": f"{type(e).__name__}: {e}"}
-        final_line = json.dumps(out)
-    else:
-        final_line = None
+    if comm is not None:
+        comm.close()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
-    if final_line is not None:
-        # RCCL writes a version banner to the C stdout buffer, which would otherwise be flushed at
-        # exit AFTER this line: drain it first so that the JSON line is the last thing on stdout
-        import ctypes
-        try:
-            ctypes.CDLL(None).fflush(None)
-        except OSError:
-            pass
-        print(final_line, flush=True)
+    print_line(out)
 
 
 if __name__ == "__main__":

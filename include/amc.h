@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define AMC_ABI_VERSION 2
+#define AMC_ABI_VERSION 3 /* 3: the multi-GPU exchange (amc_comm_*, amc_allgather_match_tables) */
 #define AMC_DESC_DIM 128 /* SIFT descriptor bytes; /root/reference/pycolmap/feature/sift.h:76-77 */
 
 enum {
@@ -120,6 +120,61 @@ int amc_ctx_trim(amc_ctx* ctx);
  * SiftMatchingOptions.gpu_index, /root/reference/pycolmap/pipeline/match_features.h:76-81).  The pointer stays valid
  * until the next match call, amc_ctx_trim or amc_ctx_destroy on this ctx; NULL when the table is empty. */
 int amc_ctx_resident_matches(amc_ctx* ctx, const uint32_t** dev_matches, uint64_t* num_matches);
+
+/* ---- multi-GPU exchange -------------------------------------------------------------------
+ * Image pairs shard over the GPUs of a node (one ctx per GPU: one process per GPU, or one thread per GPU of one
+ * process); every rank matches its share and ONE exchange at the end gives every rank the whole match graph: an
+ * all-gather of the per-rank CSR match tables over RCCL / xGMI.  The reference's surface for several GPUs is
+ * SiftMatchingOptions.gpu_index (/root/reference/pycolmap/pipeline/match_features.h:76-81: COLMAP starts one matcher
+ * thread per listed GPU and collects their outputs on the host); a host that binds this library calls
+ * amc_allgather_match_tables where COLMAP's FeatureMatcherController joins its workers' output queues
+ * (match_features.h:45-47).  INTEGRATION.md shows the binding.
+ *
+ * RCCL is loaded at the first amc_comm_* call (the librccl.so.1 already in the process - e.g. PyTorch's - or the
+ * system's); the library has no link-time dependency on it.  Collectives run on the ctx's stream.
+ *
+ * amc_comm_unique_id: ncclGetUniqueId.  One rank calls it and hands the AMC_COMM_ID_BYTES to every rank by whatever
+ * channel the host has (MPI, a key-value store, torch.distributed, shared memory between threads).
+ * amc_comm_create: ncclCommInitRank on the ctx's device - collective: every rank calls it with the same id. */
+#define AMC_COMM_ID_BYTES 128
+typedef struct amc_comm amc_comm;
+int amc_comm_unique_id(void* id);
+int amc_comm_create(amc_ctx* ctx, int world_size, int rank, const void* id, amc_comm** out);
+void amc_comm_destroy(amc_comm* comm);
+
+/* The match graph of all ranks, in the global pair order: pair g owns rows offsets[g] .. offsets[g + 1]. */
+typedef struct amc_gathered_tables {
+    size_t npairs;                  /* pairs of all ranks */
+    const uint64_t* offsets;        /* npairs + 1 (host) */
+    const uint32_t* matches;        /* 2 * num_matches uint32 (pinned host), NULL unless `download` was set */
+    const uint32_t* matches_device; /* the same table in this ctx's device memory: valid until the next gather on this
+                                       comm or amc_comm_destroy */
+    uint64_t num_matches;
+    uint64_t rows_sent, rows_received;  /* match rows this rank sent to / received from other ranks (8 bytes each) */
+    int32_t world_size, rank;
+    /* wall clock of the phases on this rank (each ends with the stream drained): the (npairs, nmatches) sizes
+     * [ncclAllGather], the per-pair (position, count) records and the match rows [grouped ncclSend / ncclRecv of
+     * exactly each rank's rows, device memory to device memory], the reorder into the global CSR, the download */
+    double sizes_ms, meta_ms, rows_ms, reorder_ms, download_ms, total_ms;
+    void* _priv;
+} amc_gathered_tables;
+
+/* Collective: every rank of `comm` calls it once per exchange, after its match call.
+ *   pair_index  global position of each of this rank's npairs_local pairs (the positions of all ranks together
+ *               must be exactly 0 .. total - 1), or NULL: the ranks' lists are appended in rank order
+ *   offsets     this rank's CSR (npairs_local + 1), e.g. amc_match_result.offsets
+ *   matches     this rank's rows on the HOST, or NULL: the rows are taken from the ctx's device-resident match table
+ *               (amc_ctx_resident_matches: where the last match call's kernels left them - no host round trip;
+ *               offsets[npairs_local] must equal its row count)
+ *   download    non-zero: this rank also wants the gathered rows on the host (the rank that feeds the SQLite writer)
+ * Three steps, few and large: the sizes, the per-pair records (8 bytes per pair), the rows (8 bytes per match, each
+ * rank sends exactly what it has to every other rank at once: xGMI is point to point, so all links carry data
+ * at the same time).  Errors: AMC_E_INVALID (positions not a permutation, offsets / table disagree), AMC_E_HIP
+ * (HIP or RCCL failure; amc_last_error names the call). */
+int amc_allgather_match_tables(amc_ctx* ctx, amc_comm* comm, const uint64_t* pair_index, size_t npairs_local,
+                               const uint64_t* offsets, const uint32_t* matches, int download,
+                               amc_gathered_tables* out);
+void amc_gathered_tables_free(amc_gathered_tables* t);
 
 /* Size the image-slot table. Slots are dense ids 0..num_slots-1 chosen by the caller (the host
  * layer maps COLMAP image_ids to slots). Discards previously uploaded data. */

@@ -30,7 +30,9 @@ EXPORTED_SYMBOLS = [
     "amc_squared_sampson_error", "amc_match_guided_pairs", "amc_ctx_grow_slots", "amc_pose_pairs",
     "amc_cam_from_img", "amc_match_verify_pairs", "amc_ctx_trim", "amc_ctx_resident_matches",
     "amc_homography_decomposition", "amc_img_from_cam",
+    "amc_comm_unique_id", "amc_comm_create", "amc_comm_destroy", "amc_allgather_match_tables", "amc_gathered_tables_free",
 ]
+COMM_ID_BYTES = 128
 RANSAC_F, RANSAC_H, RANSAC_E = 0, 1, 2
 RANSAC_KINDS = {"F": RANSAC_F, "H": RANSAC_H, "E": RANSAC_E}
 
@@ -78,6 +80,15 @@ class AmcError(RuntimeError):
     def __init__(self, code: int, msg: str):
         super().__init__(f"amc error {code}: {msg}")
         self.code = code
+
+
+class GatheredTables(C.Structure):
+    """amc_gathered_tables (include/amc.h)."""
+    _fields_ = [("npairs", C.c_size_t), ("offsets", C.POINTER(C.c_uint64)), ("matches", C.POINTER(C.c_uint32)),
+                ("matches_device", C.c_void_p), ("num_matches", C.c_uint64), ("rows_sent", C.c_uint64),
+                ("rows_received", C.c_uint64), ("world_size", C.c_int32), ("rank", C.c_int32),
+                ("sizes_ms", C.c_double), ("meta_ms", C.c_double), ("rows_ms", C.c_double), ("reorder_ms", C.c_double),
+                ("download_ms", C.c_double), ("total_ms", C.c_double), ("_priv", C.c_void_p)]
 
 
 class MatchOpts(C.Structure):
@@ -214,6 +225,15 @@ def load() -> C.CDLL:
                                    C.c_void_p, C.c_void_p]
     if hasattr(lib, "amc_homography_decomposition"):
         lib.amc_homography_decomposition.argtypes = [C.c_void_p] + [C.c_void_p] * 5 + [C.c_size_t] + [C.c_void_p] * 5
+    if hasattr(lib, "amc_comm_create"):
+        lib.amc_comm_unique_id.argtypes = [C.c_void_p]
+        lib.amc_comm_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
+        lib.amc_comm_destroy.argtypes = [C.c_void_p]
+        lib.amc_comm_destroy.restype = None
+        lib.amc_allgather_match_tables.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
+                                                   C.c_int, C.POINTER(GatheredTables)]
+        lib.amc_gathered_tables_free.argtypes = [C.POINTER(GatheredTables)]
+        lib.amc_gathered_tables_free.restype = None
     _lib = lib
     return lib
 
@@ -246,8 +266,79 @@ def device_count() -> int:
     return n
 
 
+def comm_unique_id() -> bytes:
+    """amc_comm_unique_id (ncclGetUniqueId): one rank calls it, every rank passes the bytes to Context.comm_create."""
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    _check(load().amc_comm_unique_id(buf))
+    return buf.raw
+
+
+class Comm:
+    """One amc_comm: this context's rank in the RCCL communicator of the exchange step (include/amc.h)."""
+
+    def __init__(self, ctx: "Context", world_size: int, rank: int, unique_id: bytes):
+        if len(unique_id) != COMM_ID_BYTES:
+            raise ValueError(f"unique_id must be {COMM_ID_BYTES} bytes")
+        self._lib, self._ctx = ctx._lib, ctx
+        self.world_size, self.rank = int(world_size), int(rank)
+        h = C.c_void_p()
+        _check(self._lib.amc_comm_create(ctx._h, int(world_size), int(rank), unique_id, C.byref(h)))
+        self._h = h
+
+    def close(self) -> None:
+        if getattr(self, "_h", None) and getattr(self._ctx, "_h", None):
+            self._lib.amc_comm_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def allgather_match_tables(self, pair_index, offsets, matches=None, download: bool = True):
+        """amc_allgather_match_tables (collective).  pair_index: global positions of this rank's pairs, or None (the
+        ranks' lists are appended in rank order); offsets: this rank's CSR; matches: this rank's rows on the host, or
+        None = the context's device-resident table of the last match call.  Returns (global offsets uint64, global
+        matches [M, 2] uint32 or None when download is False, stats dict incl. the device pointer of the table)."""
+        off = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = off.size - 1
+        if n < 0:
+            raise ValueError("offsets must have npairs + 1 entries")
+        idx = None if pair_index is None else np.ascontiguousarray(pair_index, dtype=np.uint64)
+        if idx is not None and idx.shape != (n,):
+            raise ValueError("one global position per local pair")
+        m = None if matches is None else np.ascontiguousarray(matches, dtype=np.uint32).reshape(-1, 2)
+        res = GatheredTables()
+        _check(self._lib.amc_allgather_match_tables(
+            self._ctx._h, self._h, None if idx is None else idx.ctypes.data_as(C.c_void_p), n,
+            off.ctypes.data_as(C.c_void_p), None if m is None else m.ctypes.data_as(C.c_void_p), 1 if download else 0,
+            C.byref(res)))
+        try:
+            g_off = np.ctypeslib.as_array(res.offsets, shape=(int(res.npairs) + 1,)).copy()
+            total = int(res.num_matches)
+            g_m = None
+            if download:
+                g_m = (np.ctypeslib.as_array(res.matches, shape=(total, 2)).copy() if total
+                       else np.zeros((0, 2), dtype=np.uint32))
+            stats = {k: float(getattr(res, k)) for k in ("sizes_ms", "meta_ms", "rows_ms", "reorder_ms", "download_ms", "total_ms")}
+            stats.update(num_matches=total, rows_sent=int(res.rows_sent), rows_received=int(res.rows_received),
+                         world_size=int(res.world_size), rank=int(res.rank), device_ptr=int(res.matches_device or 0),
+                         gather_path="C ABI: ncclAllGather (sizes) + grouped ncclSend/ncclRecv (records, rows) from device memory")
+        finally:
+            self._lib.amc_gathered_tables_free(C.byref(res))
+        return g_off, g_m, stats
+
+
 class Context:
     """One amc_ctx (one GPU). Owns device copies of every uploaded image."""
+
+    def comm_create(self, world_size: int, rank: int, unique_id: bytes) -> Comm:
+        """amc_comm_create (collective over the ranks that share `unique_id`)."""
+        import weakref
+        comm = Comm(self, world_size, rank, unique_id)
+        self.__dict__.setdefault("_comms", []).append(weakref.ref(comm))   # closed with the context, before it
+        return comm
 
     def __init__(self, device_id: int = 0):
         self._lib = load()
@@ -262,6 +353,10 @@ class Context:
 
     def close(self) -> None:
         self.resident_generation = getattr(self, "resident_generation", 0) + 1
+        for ref in self.__dict__.pop("_comms", []):
+            comm = ref()
+            if comm is not None:
+                comm.close()
         if getattr(self, "_h", None):
             self._lib.amc_ctx_destroy(self._h)
             self._h = None

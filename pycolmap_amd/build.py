@@ -18,7 +18,7 @@ CSRC = PKG / "csrc"
 OBJ = CSRC / "_obj"
 LIB = PKG / "libamc.so"
 
-HIP_SOURCES = ["amc_api.hip", "match_common.hip", "match_dot4.hip", "match_guided.hip", "match_mfma.hip", "tvg_e.hip", "tvg_fh.hip", "tvg_e_big.hip",
+HIP_SOURCES = ["amc_api.hip", "amc_comm.hip", "match_common.hip", "match_dot4.hip", "match_guided.hip", "match_mfma.hip", "tvg_e.hip", "tvg_fh.hip", "tvg_e_big.hip",
                "tvg_fh_big.hip", "pose.hip", "camera.hip"]
 HIPCC_FLAGS = [
     "--offload-arch=gfx950",

@@ -332,6 +332,21 @@ struct amc_ctx {
     DevBuf<PoseOut> d_pout;
 };
 
+namespace amc {
+int api_fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+CtxView ctx_view(amc_ctx* c) {
+    return CtxView{c->device, c->stream, c->resident_matches ? c->d_keep.p : nullptr, c->resident_matches};
+}
+}  // namespace amc
+
 extern "C" {
 
 const char* amc_last_error(void) { return g_err.c_str(); }

@@ -120,6 +120,17 @@ struct FinalizeParams {
     int reserved;
 };
 
+// ----- for the translation units beside amc_api.hip that implement C-ABI entry points (amc_comm.hip) --------------
+// api_fail: sets the calling thread's amc_last_error() message and returns `code`.
+int api_fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+struct CtxView {
+    int device;
+    hipStream_t stream;        // the stream the ctx launches on (its own, or the host's: amc_ctx_set_stream)
+    const uint32_t* resident;  // the last match call's table in device memory (amc_ctx_resident_matches), 2 uint32 per row
+    uint64_t resident_rows;
+};
+CtxView ctx_view(amc_ctx* c);
+
 // ----- launchers (defined in the .hip files) ---------------------------------------------
 // Every launcher returns the status of what it enqueued: a failed memset of a queue head or counter in front of a
 // persistent kernel must fail the call (AMC_E_HIP), not let the kernel pop from a stale counter.

@@ -3,11 +3,15 @@
 Image pairs are independent units, so the path shards embarrassingly: one process per GPU
 (`torch.distributed`, backend "nccl" = RCCL over xGMI on MI355X, "gloo" on CPU for tests), the
 descriptor arena replicated on every GPU, the pair list dealt in contiguous slices, and ONE exchange
-step at the end: an all-gather of the per-rank match tables (sizes first, then the tables themselves: uneven
-all-gathers of 32-bit payloads, fed from the device memory the match kernels wrote) so that every rank — in particular
-the rank that owns the SQLite writer — holds the whole match graph.
-The functions here are pure tensor plumbing and work unchanged on CPU tensors (gloo) and GPU
-tensors (RCCL).
+step at the end: an all-gather of the per-rank match tables (sizes first, then the per-pair records, then the rows,
+fed from the device memory the match kernels wrote) so that every rank — in particular the rank that owns the SQLite
+writer — holds the whole match graph.
+
+On the GPUs the exchange is the library's own: `amc_allgather_match_tables` behind the C ABI (include/amc.h; RCCL
+called from C++, grouped ncclSend / ncclRecv of exactly each rank's rows straight from the resident match table) -
+`make_comm()` builds its communicator, `all_gather_match_tables(..., comm=comm)` calls it.  Without a `comm` the same
+three-step protocol runs as torch.distributed collectives: that is what the gloo tests on CPU exercise (and what a
+host without the library's communicator would use on RCCL).
 """
 from __future__ import annotations
 
@@ -40,11 +44,32 @@ def shard_pairs(slot1: np.ndarray, slot2: np.ndarray, rank: int, world: int, row
     return s1[mine], s2[mine], mine
 
 
-_last_gather_path = None   # "uneven" | "padded": which branch _gather_rows took last (tests and bench.py report it)
+_last_gather_path = None   # "c-abi" | "uneven" | "padded": which path the last exchange took (tests and bench.py report it)
+_last_gather_stats = None  # the C ABI's own phase timings of the last exchange through it
 
 
 def last_gather_path():
     return _last_gather_path
+
+
+def last_gather_stats():
+    return _last_gather_stats
+
+
+def make_comm(ctx, group=None):
+    """The library's RCCL communicator for the ranks of `group` (amc_comm_create): rank 0 draws the unique id
+    (ncclGetUniqueId), torch.distributed carries its 128 bytes to the others, every rank joins with its own context.
+    Collective.  Works with one rank (no process group needed)."""
+    from . import _capi
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()):
+        return ctx.comm_create(1, 0, _capi.comm_unique_id())
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    box = [_capi.comm_unique_id() if rank == 0 else None]
+    if world > 1:
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    return ctx.comm_create(world, rank, box[0])
 
 
 def _gather_rows(t, sizes, group=None):
@@ -78,7 +103,7 @@ def _gather_rows(t, sizes, group=None):
 
 
 def all_gather_match_tables(pair_index: np.ndarray, offsets: np.ndarray, matches: np.ndarray, device=None,
-                            group=None, as_numpy: bool = True, device_matches=None, download_rank=None):
+                            group=None, as_numpy: bool = True, device_matches=None, download_rank=None, comm=None):
     """Exchange per-rank CSR match tables.  Every rank passes the global indices of its pairs, its
     CSR offsets and its (M, 2) uint32 matches; every rank gets back the table for ALL pairs as
     (global_offsets, global_matches) in the global pair order.
@@ -90,7 +115,21 @@ def all_gather_match_tables(pair_index: np.ndarray, offsets: np.ndarray, matches
     point-to-point links want.  The reassembly into the global CSR is a handful of tensor ops on `device` (scatter of
     the counts, one cumulative sum, one indexed copy of the rows): no per-pair host work.
     as_numpy=False: device tensors are returned.  download_rank=r: only rank r copies the result to the host (the
-    rank that owns the SQLite writer), the others return (None, None)."""
+    rank that owns the SQLite writer), the others return (None, None).
+
+    comm: the library's communicator (make_comm): the exchange runs behind the C ABI (amc_allgather_match_tables) -
+    with `device_matches` given the rows come from the context's resident table, otherwise from `matches`; returns
+    (global offsets, global matches or None) as numpy arrays (as_numpy=False: (global offsets, None) - the table
+    stays in the library's device memory, last_gather_stats()["device_ptr"])."""
+    global _last_gather_path, _last_gather_stats
+    if comm is not None:
+        want = as_numpy and (download_rank is None or comm.rank == download_rank)
+        g_off, g_m, st = comm.allgather_match_tables(pair_index, offsets, None if device_matches is not None else matches,
+                                                     download=want)
+        _last_gather_path, _last_gather_stats = "c-abi", st
+        if as_numpy and not want:
+            return None, None
+        return g_off, g_m
     import torch
     import torch.distributed as dist
 
@@ -101,15 +140,18 @@ def all_gather_match_tables(pair_index: np.ndarray, offsets: np.ndarray, matches
     nm = int(device_matches.shape[0]) if device_matches is not None else int(matches.shape[0])
     if int(counts.sum()) != nm:
         raise ValueError("offsets and matches disagree")
-    sizes = torch.tensor([npairs, nm], dtype=torch.int64, device=dev)
-    all_sizes = torch.empty(world * 2, dtype=torch.int64, device=dev)
-    dist.all_gather_into_tensor(all_sizes, sizes, group=group)
-    all_sizes = all_sizes.view(world, 2).cpu()
-
+    # The per-pair records travel as int32: a rank whose positions or counts do not fit says so IN the size exchange,
+    # so that every rank raises together instead of one rank leaving the others inside the next collective.
     pair_index = np.asarray(pair_index, dtype=np.int64)
-    if npairs and (int(pair_index.max()) >= 2 ** 31 or int(pair_index.min()) < 0 or int(counts.max()) >= 2 ** 31):
+    too_big = bool(npairs and (int(pair_index.max()) >= 2 ** 31 or int(pair_index.min()) < 0 or int(counts.max()) >= 2 ** 31))
+    sizes = torch.tensor([npairs, nm, int(too_big)], dtype=torch.int64, device=dev)
+    all_sizes = torch.empty(world * 3, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(all_sizes, sizes, group=group)
+    all_sizes = all_sizes.view(world, 3).cpu()
+    if int(all_sizes[:, 2].sum()):
         raise ValueError("all_gather_match_tables: pair indices and per-pair match counts travel as int32 "
-                         "(8 bytes per pair); an index or a count of 2^31 or more does not fit")
+                         "(8 bytes per pair); an index or a count of 2^31 or more does not fit (rank(s) %s)"
+                         % [r for r in range(world) if int(all_sizes[r, 2])])
     meta_h = np.empty((npairs, 2), dtype=np.int32)          # (global index, count): 8 bytes per pair, the only H2D
     meta_h[:, 0] = pair_index
     meta_h[:, 1] = counts
@@ -142,11 +184,17 @@ def all_gather_match_tables(pair_index: np.ndarray, offsets: np.ndarray, matches
 
 
 def all_gather_appended_tables(offsets: np.ndarray, matches: np.ndarray, device=None, group=None, as_numpy: bool = True,
-                               device_matches=None):
+                               device_matches=None, comm=None):
     """all_gather_match_tables for pair lists that have no global numbering yet - e.g. the loop-closure pairs every
     rank retrieves for its own query images (BASELINE configs[4]): the lists are appended in rank order.  One more
     tiny all-gather (the per-rank pair counts) gives every rank its base position; returns what
     all_gather_match_tables returns plus this rank's base."""
+    global _last_gather_path, _last_gather_stats
+    if comm is not None:   # the C ABI appends the lists itself (pair_index = NULL)
+        g_off, g_m, st = comm.allgather_match_tables(None, offsets, None if device_matches is not None else matches,
+                                                     download=as_numpy)
+        _last_gather_path, _last_gather_stats = "c-abi", st
+        return g_off, g_m, None
     import torch
     import torch.distributed as dist
 

@@ -96,21 +96,38 @@ def _run_bench(*argv, timeout=600):
     return json.loads(lines[0])
 
 
-def test_multi_rank_entry_launches_itself_and_defaults_to_configs3():
+def test_multi_rank_entry_launches_itself_and_carries_the_configs3_leg():
     """`python bench.py --gpus 2` (no launcher around it, no --config): the entry starts its two ranks under
-    torch.distributed.run, picks BASELINE configs[3] (fixed pair set, strong scaling), shards the pairs, exchanges the
-    match tables and prints one line with the per-rank kernel times and the exchange time.  Run here without a GPU
-    (--cpu-dry-run: gloo, CPU oracle in place of the kernels, tiny sizes): a plumbing check, value is null."""
+    torch.distributed.run; the line is the weak-scaled configs[1] headline (the metric at every N) and carries
+    BASELINE configs[3] - fixed pair set, sharded, strong scaling: the curve north_star states its ">= 7x at 8 GPUs"
+    on - as the `config3` leg, with its scalars repeated at the top level.  Run here without a GPU (--cpu-dry-run:
+    gloo, CPU oracle in place of the kernels, tiny sizes): a plumbing check, every value is null."""
     d = _run_bench("--gpus", "2", "--cpu-dry-run", "--images", "9", "--feats", "64", "--steps", "1", "--warmup", "1")
     assert d["dry_run"] is True and d["value"] is None and d["metric"].startswith("DRY RUN")
-    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["higher_is_better"] is True
-    c = d["config"]
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["higher_is_better"] is True
+    assert "configs[1]" in d["config"]["workload"] and d["config"]["pairs_total"] == 13 * 12 // 2   # 9 x sqrt(2) images
+    assert 0 < d["config"]["pairs_per_rank"] < d["config"]["pairs_total"] and d["config"]["gather_path"] == "padded"
+    l3 = d["config3"]
+    for k in ("value", "ms_per_step", "exchange_ms_per_step", "per_rank_kernel_ms", "rccl_ranks", "gather_path"):
+        assert k in l3, k
+    assert l3["scaling"] == "strong" and l3["n_gpus"] == 2 and l3["value"] is None and l3["dry_run"] is True
+    assert d["config3_value"] is None and d["config3_ms_per_step"] == l3["ms_per_step"] > 0
+    assert d["config3_exchange_ms_per_step"] == l3["exchange_ms_per_step"] > 0
+    assert len(l3["per_rank_kernel_ms"]) == 2 and l3["rccl_ranks"] == 0 and l3["gather_path"] == "padded"
+    c = l3["line"]["config"]
     assert "configs[3]" in c["workload"] and c["workload"].startswith("REDUCED 9 x 64")
     assert c["pairs_total"] == 36 and 0 < c["pairs_rank0"] < 36
     assert c["distances_per_step_all_ranks"] == 36 * 64 * 64      # every pair matched exactly once over the two ranks
     assert c["backend"] == "gloo" and c["rccl_ranks"] == 0
     assert len(c["kernel_ms_per_step_by_rank"]) == 2 and len(c["exchange_ms_per_step_by_rank"]) == 2
     assert c["exchange_ms_per_step"] == max(c["exchange_ms_per_step_by_rank"]) > 0
+
+
+def test_configs3_alone_is_still_a_line_of_its_own():
+    d = _run_bench("--gpus", "2", "--cpu-dry-run", "--config", "3", "--images", "9", "--feats", "64", "--steps", "1",
+                   "--warmup", "0")
+    assert d["dry_run"] and d["scaling"] == "strong" and d["n_gpus"] == 2 and "config3" not in d
+    assert d["config"]["pairs_total"] == 36 and d["config"]["gather_path"] == "padded"
 
 
 def test_multi_rank_entry_configs4_dry_run():

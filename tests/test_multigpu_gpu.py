@@ -45,6 +45,41 @@ def test_one_rank_rccl_exchange_through_torchrun():
     assert r.returncode == 0, r.stderr[-2000:]
     assert "dist smoke ok" in r.stdout and "world 1" in r.stdout
     assert "gather path uneven" in r.stdout   # the RCCL branch of distributed._gather_rows, not the gloo padding
+    assert "C ABI exchange" in r.stdout       # ... and amc_allgather_match_tables (RCCL called by the library) agreed with it
+
+
+def test_one_rank_exchange_through_the_c_abi_without_torch_distributed(amc_ctx):
+    """amc_comm_* / amc_allgather_match_tables with a world of one, no process group anywhere: the library's own RCCL
+    calls (ncclCommInitRank, ncclAllGather of the sizes), the reorder into the global CSR, the download."""
+    from pycolmap_amd import _capi, synth
+    rng = np.random.default_rng(12)
+    imgs = synth.scene_images(rng, 5, 640)
+    amc_ctx.reserve_slots(len(imgs))
+    for k, im in enumerate(imgs):
+        amc_ctx.upload_descriptors(k, im)
+    s1, s2 = synth.exhaustive_pairs(len(imgs))
+    off, m, _ = amc_ctx.match_pairs(s1, s2)
+    assert len(m) > 100
+    comm = amc_ctx.comm_create(1, 0, _capi.comm_unique_id())
+    perm = np.random.default_rng(1).permutation(len(s1)).astype(np.uint64)    # the caller's global order differs from the rank's
+    g_off, g_m, st = comm.allgather_match_tables(perm, off, None)              # rows from the resident table
+    assert st["world_size"] == 1 and st["num_matches"] == len(m) and st["rows_sent"] == 0 and st["device_ptr"] != 0
+    h_off, h_m, _ = comm.allgather_match_tables(perm, off, m)                  # rows from the host
+    np.testing.assert_array_equal(g_off, h_off)
+    np.testing.assert_array_equal(g_m, h_m)
+    for k, g in enumerate(perm):
+        np.testing.assert_array_equal(g_m[int(g_off[g]):int(g_off[g + 1])], m[int(off[k]):int(off[k + 1])])
+    a_off, a_m, _ = comm.allgather_match_tables(None, off, None)
+    np.testing.assert_array_equal(a_off, off)
+    np.testing.assert_array_equal(a_m, m)
+    with pytest.raises(_capi.AmcError) as ei:                                  # positions must be a permutation
+        comm.allgather_match_tables(np.zeros(len(s1), np.uint64), off, m)
+    assert ei.value.code == _capi.AMC_E_INVALID
+    with pytest.raises(_capi.AmcError):                                        # offsets must describe the resident table
+        bad = off.copy()
+        bad[-1] += 1
+        comm.allgather_match_tables(perm, bad, None)
+    comm.close()
 
 
 @pytest.mark.skipif("_ngpus() < 2", reason="needs two GPUs")
@@ -52,7 +87,7 @@ def test_two_rank_rccl_exchange_equals_single_process():
     r = _torchrun(2, "tools/dist_smoke.py")
     assert r.returncode == 0, r.stderr[-2000:]
     assert "dist smoke ok" in r.stdout and "world 2" in r.stdout
-    assert "gather path uneven" in r.stdout
+    assert "gather path uneven" in r.stdout and "C ABI exchange" in r.stdout
 
 
 @pytest.mark.skipif("_ngpus() < 2", reason="needs two GPUs")
@@ -74,6 +109,38 @@ def test_bench_two_gpus_sharded_configuration():
     assert line["n_gpus"] == 2 and line["value"] > 0 and line["scaling"] == "strong"
     cfg = line["config"]
     assert cfg["rccl_ranks"] == 2 and len(cfg["kernel_ms_per_step_by_rank"]) == 2 and cfg["exchange_ms_per_step"] >= 0
+    assert cfg["gather_path"] == "c-abi" and cfg["gpu_vs_oracle_mismatching_pairs"] == 0
+
+
+@pytest.mark.skipif("_ngpus() < 2", reason="needs two GPUs")
+def test_bench_two_gpus_default_line_carries_both_curves():
+    """`python bench.py --gpus 2`: the weak-scaled configs[1] headline and the configs[3] strong-scaling leg in one line,
+    both exchanging through amc_allgather_match_tables."""
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--images", "48", "--feats", "1024", "--steps", "1",
+                        "--warmup", "1"], cwd=ROOT, capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0 and line["config"]["gather_path"] == "c-abi"
+    l3 = line["config3"]
+    assert l3["scaling"] == "strong" and l3["value"] == line["config3_value"] > 0 and l3["rccl_ranks"] == 2
+    assert l3["gather_path"] == "c-abi" and l3["gpu_vs_oracle_mismatching_pairs"] == 0
+
+
+def test_bench_one_gpu_line_carries_the_configs3_leg_through_the_c_abi():
+    """The same line at N = 1 (reduced sizes): the configs[3] leg runs its exchange step through the library's
+    communicator with one rank, and its sample of pairs agrees with the oracle."""
+    r = subprocess.run([sys.executable, "bench.py", "--images", "24", "--feats", "1024", "--steps", "1", "--warmup", "0",
+                        "--verify-pairs", "0", "--no-pipeline", "--no-ragged", "--no-sift-stats", "--no-dense", "--no-db"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    l3 = line["config3"]
+    assert line["n_gpus"] == 1 and l3["rccl_ranks"] == 1 and l3["gather_path"] == "c-abi" and l3["value"] > 0
+    assert l3["gpu_vs_oracle_mismatching_pairs"] == 0 and l3["pairs_checked"] > 0
+    assert line["cpu_baseline"]["optimised_value"] is None or line["cpu_baseline"]["optimised_value"] > 0
+    assert line["cpu_baseline"]["default_cpu_matcher_pairs_per_s"] > 0 and line["roofline"]["whole_step_frac"] > 0
 
 
 @pytest.mark.skipif("_ngpus() < 2", reason="needs two GPUs")

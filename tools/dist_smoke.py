@@ -35,6 +35,22 @@ for k, im in enumerate(imgs):
 s1_all, s2_all = synth.exhaustive_pairs(len(imgs))
 s1, s2, mine = D.shard_pairs(s1_all, s2_all, rank, world)
 off, m, _ = ctx.match_pairs(s1, s2)
+# ---- the exchange behind the C ABI (amc_allgather_match_tables: RCCL called by the library) ----
+comm = D.make_comm(ctx)
+c_off, c_m = D.all_gather_match_tables(mine, off, None, comm=comm, device_matches=True)   # rows from the resident table
+abi_stats = D.last_gather_stats()
+assert D.last_gather_path() == "c-abi" and abi_stats["world_size"] == world
+h_off, h_m = D.all_gather_match_tables(mine, off, m, comm=comm)                            # rows from the host
+assert np.array_equal(c_off, h_off) and np.array_equal(c_m, h_m)
+a_off, a_m, _ = D.all_gather_appended_tables(off, m, comm=comm)                            # lists appended in rank order
+assert int(a_off[-1]) == int(c_off[-1]) and len(a_off) == len(c_off)
+n_off, n_m = D.all_gather_match_tables(mine, off, None, comm=comm, device_matches=True, download_rank=0)
+assert (n_off is None) == (rank != 0)
+try:                                                                                       # positions that are no permutation:
+    D.all_gather_match_tables(np.zeros_like(mine), off, m, comm=comm)                      # every rank gets the error
+    assert len(s1_all) <= 1, "duplicate positions went through"
+except _capi.AmcError as e:
+    assert e.code == _capi.AMC_E_INVALID, e
 tvg, mask, _ = ctx.verify_pairs(s1, s2, off, m, _capi.tvg_options(compute_relative_pose=1))
 # the match table straight from the device memory the kernels wrote (no host round trip before the collective)
 gen = ctx.resident_generation
@@ -43,6 +59,7 @@ torch.cuda.synchronize()
 assert ctx.resident_view_valid(gen)   # nothing touched the library's table while the collectives read it
 g_tvg, g_off, g_m, g_ioff, g_im = D.all_gather_verification(mine, tvg, off, m, mask, len(s1_all), device=dev)
 assert np.array_equal(d_off, g_off) and np.array_equal(d_m, g_m)
+assert np.array_equal(c_off, g_off) and np.array_equal(c_m, g_m)   # the C ABI's exchange and torch's agree
 # single-process reference on the same device
 woff, wm, _ = ctx.match_pairs(s1_all, s2_all)
 wtvg, wmask, _ = ctx.verify_pairs(s1_all, s2_all, woff, wm, _capi.tvg_options(compute_relative_pose=1))
@@ -53,4 +70,6 @@ dist.barrier()
 dist.destroy_process_group()
 if rank == 0:
     print(f"dist smoke ok: {len(s1_all)} pairs, {len(wm)} matches, {int(wmask.sum())} inlier matches, world {world}, "
-          f"gather path {D.last_gather_path()}")
+          f"gather path {D.last_gather_path()}; C ABI exchange: {abi_stats['total_ms']:.2f} ms "
+          f"(sizes {abi_stats['sizes_ms']:.2f}, records {abi_stats['meta_ms']:.2f}, rows {abi_stats['rows_ms']:.2f}, reorder "
+          f"{abi_stats['reorder_ms']:.2f}, download {abi_stats['download_ms']:.2f}), {abi_stats['rows_sent']} rows sent")
