@@ -14,6 +14,7 @@
 //
 // RCCL is resolved with dlopen at the first call: the copy already in the process (PyTorch ships one) or the system's.
 #include <dlfcn.h>
+#include <link.h>
 #include <rccl/rccl.h>
 
 #include <chrono>
@@ -50,21 +51,42 @@ const Rccl* rccl(std::string* why) {
     static std::string err;
     std::lock_guard<std::mutex> lock(mu);
     if (r.handle) return &r;
+    // ONE RCCL per process, and never in the global symbol scope:
+    //  * a copy the process already holds is used as it is - found by walking the loaded objects (PyTorch maps its own
+    //    as "librccl.so" from its lib directory: no soname or path this code could guess);
+    //  * otherwise the loader's search path, then the ROCm install - with RTLD_LOCAL: a copy opened RTLD_GLOBAL would
+    //    interpose on one a host loads LATER (import torch after the first exchange: the two copies' allocators then
+    //    free each other's blocks at exit - "double free or corruption", seen in round 5's first GPU run).
     const char* forced = std::getenv("AMC_RCCL_LIBRARY");  // (a path: for hosts that keep RCCL somewhere else)
-    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     void* h = nullptr;
     std::string got;
     if (forced && *forced) {
-        h = dlopen(forced, RTLD_NOW | RTLD_GLOBAL);
+        h = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
         got = forced;
     }
-    // the copy the process already holds first (one RCCL per process: a second one would fight over the same devices' IPC
-    // handles), then the loader's search path, then the ROCm install
-    for (int pass = 0; pass < 2 && !h; ++pass)
-        for (const char* n : names) {
-            h = dlopen(n, pass == 0 ? (RTLD_NOW | RTLD_NOLOAD) : (RTLD_NOW | RTLD_GLOBAL));
+    if (!h) {
+        std::string found;
+        dl_iterate_phdr(
+            [](struct dl_phdr_info* info, size_t, void* data) -> int {
+                const char* name = info->dlpi_name;
+                if (!name || !*name) return 0;
+                const char* base = std::strrchr(name, '/');
+                base = base ? base + 1 : name;
+                if (std::strncmp(base, "librccl.so", 10) != 0) return 0;
+                *static_cast<std::string*>(data) = name;
+                return 1;
+            },
+            &found);
+        if (!found.empty()) {
+            h = dlopen(found.c_str(), RTLD_NOW | RTLD_NOLOAD | RTLD_LOCAL);
+            if (h) got = found + " (already loaded)";
+        }
+    }
+    if (!h)
+        for (const char* n : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
             if (h) {
-                got = std::string(n) + (pass == 0 ? " (already loaded)" : "");
+                got = n;
                 break;
             }
         }

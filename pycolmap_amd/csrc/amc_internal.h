@@ -232,7 +232,7 @@ hipError_t launch_select_candidates(const ImageDev* imgs, const PairDev* pairs, 
                               FinalizeParams fp, uint32_t* cand_cnt, uint32_t* candbuf, hipStream_t s);
 
 hipError_t launch_finalize(const ImageDev* imgs, const PairDev* pairs, uint32_t npairs,
-                     const Top2* rowbuf, const Top2* colbuf, const uint32_t* accmask,
+                     const Top2* rowbuf, const Top2* colbuf, uint32_t* accmask,
                      const float* acos_lut, FinalizeParams fp, uint32_t* cursor, uint32_t capacity,
                      uint32_t* pair_off, uint32_t* pair_cnt, uint32_t* matches, hipStream_t s);
 

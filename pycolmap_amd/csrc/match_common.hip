@@ -97,7 +97,7 @@ hipError_t launch_prep(const uint8_t* raw, uint8_t* prep, int32_t* rs128, uint32
 __global__ __launch_bounds__(256) void finalize_kernel(
     const ImageDev* __restrict__ imgs, const PairDev* __restrict__ pairs,
     const Top2* __restrict__ rowbuf, const Top2* __restrict__ colbuf,
-    const uint32_t* __restrict__ accmask, const float* __restrict__ lut, FinalizeParams fp,
+    uint32_t* accmask, const float* __restrict__ lut, FinalizeParams fp,
     uint32_t* __restrict__ cursor,
     uint32_t capacity, uint32_t* __restrict__ pair_off, uint32_t* __restrict__ pair_cnt,
     uint32_t* __restrict__ matches) {
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(
     const uint32_t n1 = imgs[p.slot1].rows, n2 = imgs[p.slot2].rows;
     const Top2* rows = rowbuf + p.row_off;
     const Top2* cols = colbuf + p.col_off;
-    const uint32_t* mask = accmask + (p.row_off >> 5);
+    uint32_t* mask = accmask + (p.row_off >> 5);  // read in pass 1, rewritten by it (the matches), read again in pass 2
     const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
 
     auto is_match = [&](uint32_t i, uint32_t& j_out) -> bool {
@@ -131,11 +131,16 @@ __global__ __launch_bounds__(256) void finalize_kernel(
         return c.best_idx == i;
     };
 
-    // pass 1: count
+    // pass 1: count - and leave the decisions in the pair's accept words (nobody reads them after this kernel; for
+    // dot4 pairs the words exist and are unused): pass 2 then walks bits instead of repeating the gathers of the
+    // column table (two 16-byte records in two 64-byte lines per accepted row, the bulk of this kernel's traffic)
     uint32_t local = 0;
     for (uint32_t base = 0; base < n1; base += 256) {
         uint32_t j;
-        local += is_match(base + tid, j) ? 1u : 0u;
+        const bool mm = is_match(base + tid, j);
+        local += mm ? 1u : 0u;
+        const unsigned long long bal = __ballot(mm);
+        if ((lane & 31u) == 0) mask[(base + tid) >> 5] = (uint32_t)(bal >> (lane & 32u));
     }
 #pragma unroll
     for (int m = 1; m < 64; m <<= 1) local += __shfl_xor(local, m);
@@ -152,8 +157,9 @@ __global__ __launch_bounds__(256) void finalize_kernel(
     uint32_t running = s_base;
     // pass 2: ordered write
     for (uint32_t base = 0; base < n1; base += 256) {
-        uint32_t j = 0;
-        const bool m = is_match(base + tid, j);
+        const uint32_t i = base + tid;
+        const bool m = i < n1 && ((mask[i >> 5] >> (i & 31)) & 1u);
+        const uint32_t j = m ? rows[i].best_idx : 0u;
         const unsigned long long bal = __ballot(m);
         const uint32_t before = __popcll(bal & ((1ull << lane) - 1ull));
         __syncthreads();
@@ -322,19 +328,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             bool acc[4];
             uint32_t tile[4];
             if (side == 0) {
-                uint32_t aw[4], bi[4];
+                // the accept words first (coalesced, a few lines per pair), then the table only where a bit is set: on a
+                // sparse set 1 row in 100 is accepted and the 64 KB of a pair's row table stay where they are
+                uint32_t aw[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const uint32_t e = min(e0 + (uint32_t)u * 256, chunk_end - 1);
-                    aw[u] = amask[e >> 5];
-                    bi[u] = tab[e].best_idx;
-                }
+                for (int u = 0; u < 4; ++u) aw[u] = amask[min(e0 + (uint32_t)u * 256, chunk_end - 1) >> 5];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const uint32_t e = e0 + (uint32_t)u * 256;
                     acc[u] = e < chunk_end && ((aw[u] >> (e & 31)) & 1u);
-                    tile[u] = bi[u];
                 }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) tile[u] = acc[u] ? tab[e0 + (uint32_t)u * 256].best_idx : 0u;
             } else {
                 uint32_t le[4];
                 Top2 tt[4];
@@ -555,19 +560,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             bool acc[4];
             uint32_t tile[4];
             if (side == 0) {
-                uint32_t aw[4], bi[4];
+                // the accept words first (coalesced, a few lines per pair), then the table only where a bit is set: on a
+                // sparse set 1 row in 100 is accepted and the 64 KB of a pair's row table stay where they are
+                uint32_t aw[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const uint32_t e = min(e0 + (uint32_t)u * 256, chunk_end - 1);
-                    aw[u] = amask[e >> 5];
-                    bi[u] = tab[e].best_idx;
-                }
+                for (int u = 0; u < 4; ++u) aw[u] = amask[min(e0 + (uint32_t)u * 256, chunk_end - 1) >> 5];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const uint32_t e = e0 + (uint32_t)u * 256;
                     acc[u] = e < chunk_end && ((aw[u] >> (e & 31)) & 1u);
-                    tile[u] = bi[u];
                 }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) tile[u] = acc[u] ? tab[e0 + (uint32_t)u * 256].best_idx : 0u;
             } else {
                 uint32_t le[4];
                 Top2 tt[4];
@@ -656,7 +660,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
                 for (int sl = 0; sl < 4; ++sl) xf[sl] = *reinterpret_cast<const i32x4*>(rp + (((2 * sl + half) ^ sw) * 16));
             }
-            const int xterm = X.rs128[xrow] - (1 << 21);  // dot = accumulator + xterm
+            // dot = accumulator + xterm, xterm = 128 * (sum of the row's bytes) - 2^21.  The sum comes from the fragments
+            // just loaded (prep = raw ^ 0x80; this lane holds 64 of the row's 128 bytes) instead of a 4-byte gather from
+            // rs128 - a 64-byte line per accepted row, a sixth of the kernel's traffic on overlapping pairs.
+            uint32_t rsum = 0;
+#pragma unroll
+            for (int sl = 0; sl < 4; ++sl)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    rsum = __builtin_amdgcn_udot4((uint32_t)xf[sl][e] ^ 0x80808080u, 0x01010101u, rsum, false);
+            rsum += (uint32_t)__shfl_xor((int)rsum, 32);
+            const int xterm = (int)(rsum * 128u) - (1 << 21);
             bool found = false;
             uint32_t first = 0, sw_val = 0;
             unsigned long long todo = __ballot(lane < nb);
@@ -890,7 +904,7 @@ hipError_t launch_host_copy(void* dst_pinned, const void* src_dev, size_t bytes,
 }
 
 hipError_t launch_finalize(const ImageDev* imgs, const PairDev* pairs, uint32_t npairs,
-                           const Top2* rowbuf, const Top2* colbuf, const uint32_t* accmask,
+                           const Top2* rowbuf, const Top2* colbuf, uint32_t* accmask,
                            const float* acos_lut, FinalizeParams fp, uint32_t* cursor, uint32_t capacity,
                            uint32_t* pair_off, uint32_t* pair_cnt, uint32_t* matches, hipStream_t s) {
     if (npairs == 0) return hipSuccess;
