@@ -1,6 +1,6 @@
 # HBM traffic of the match kernel at the bench's default workload (500 images x 4096, 2 launches per
 # step), FETCH_SIZE and WRITE_SIZE in SEPARATE passes (TCC slots: MI355X_MICROARCH.md, "rocprofv3 PMC
-# slots"), --kernel-trace + --pmc only.  Run on the GPU box:  bash tools/pmc_hbm.sh
+# slots"), --kernel-trace + --pmc only.  Run on the GPU box:  bash profiles/r01/recipes/pmc_hbm.sh
 set -x
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT

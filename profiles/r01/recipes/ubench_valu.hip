@@ -1,5 +1,5 @@
 // ubench_valu.hip — issue-rate microbenchmark for the integer VALU ops the match epilogue uses,
-// and the int8 MFMA they run beside.  Build: hipcc --offload-arch=gfx950 -O3 tools/ubench_valu.hip
+// and the int8 MFMA they run beside.  Build: hipcc --offload-arch=gfx950 -O3 profiles/r01/recipes/ubench_valu.hip
 // Prints lane-ops per clock per CU at the measured wall time (assumes 256 CUs).
 #include <hip/hip_runtime.h>
 #include <cstdio>

@@ -1,6 +1,6 @@
 # round 2: HBM traffic of the match kernel at the bench's default workload (500 images x 4096, 2 launches per
 # step).  FETCH_SIZE, TCC_EA0_WRREQ / _64B and GRBM_GUI_ACTIVE in SEPARATE passes (--kernel-trace + --pmc only).
-# Writes gpurun_out/r02/pmc_hbm_r02.txt.   bash tools/pmc_hbm_r02.sh
+# Writes gpurun_out/r02/pmc_hbm_r02.txt.   bash profiles/r02/recipes/pmc_hbm_r02.sh
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out/r02

@@ -1,5 +1,5 @@
 # SQ counters of the verification kernel (one pass; --kernel-trace + --pmc only) on 16,384 pairs of the bench's
-# verify workload.  Run on the GPU box:  bash tools/pmc_tvg.sh
+# verify workload.  Run on the GPU box:  bash profiles/r01/recipes/pmc_tvg.sh
 set -x
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; mkdir -p $R/gpurun_out/r02

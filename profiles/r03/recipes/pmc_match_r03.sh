@@ -1,6 +1,6 @@
 # round 3: SQ / GRBM counters of the match kernel at the bench's default workload (500 images x 4096, 2 launches per
 # step), one counter group per pass (--kernel-trace + --pmc only).  Writes gpurun_out/r03/pmc_match_r03.txt.
-#   bash tools/pmc_match_r03.sh [tag]
+#   bash profiles/r03/recipes/pmc_match_r03.sh [tag]
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 TAG=${1:-v1}

@@ -1,5 +1,5 @@
 # round 4, second evidence run (after the verification / host-layer work): default bench line, kernel-trace stats of the
-# same command, the verification kernels' counters, stress runs.   bash tools/r04_final2.sh v4
+# same command, the verification kernels' counters, stress runs.   bash profiles/r04/recipes/r04_final2.sh v4
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/r04
 mkdir -p $O

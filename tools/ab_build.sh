@@ -12,7 +12,7 @@ cd pycolmap_amd/csrc
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -I../../include -I."
 /opt/rocm/bin/hipcc $FLAGS -c _obj/${STEM}_prev.hip -o _obj/${STEM}_prev.o
 OBJS=""
-for o in amc_api match_common match_dot4 match_guided match_mfma tvg_e tvg_fh tvg_e_big tvg_fh_big pose camera; do
+for o in amc_api amc_comm match_common match_dot4 match_guided match_mfma tvg_e tvg_fh tvg_e_big tvg_fh_big pose camera; do
   if [ $o = $STEM ]; then OBJS="$OBJS _obj/${o}_prev.o"; else OBJS="$OBJS _obj/$o.o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o _obj/libamc_prev.so $OBJS

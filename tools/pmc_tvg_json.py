@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""profiles/rNN/pmc_tvg_rNN.json from the text summary tools/pmc_tvg_r03.sh / pmc_tvg_r04.sh write (per-call averages of the SQ counters
+"""profiles/rNN/pmc_tvg_rNN.json from the text summary profiles/r03/recipes/pmc_tvg_r03.sh / pmc_tvg_r04.sh write (per-call averages of the SQ counters
 of the two verification kernels + the derived ratios + the sha256 of the kernel sources the counters belong to;
 bench.py's verify.roofline.executed reads it while the sources still hash to the same values).
     python tools/pmc_tvg_json.py profiles/r04/pmc_tvg_r04_v1.txt [out.json]"""

@@ -8,5 +8,5 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-ma
 for f in tvg_e tvg_fh amc_api; do
   /opt/rocm/bin/hipcc $FLAGS -c $f.hip -o _obj/${f}_$NAME.o
 done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o _obj/libamc_$NAME.so _obj/amc_api_$NAME.o _obj/match_common.o _obj/match_dot4.o _obj/match_guided.o _obj/match_mfma.o _obj/tvg_e_$NAME.o _obj/tvg_fh_$NAME.o _obj/tvg_e_big.o _obj/tvg_fh_big.o _obj/pose.o _obj/camera.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o _obj/libamc_$NAME.so _obj/amc_api_$NAME.o _obj/amc_comm.o _obj/match_common.o _obj/match_dot4.o _obj/match_guided.o _obj/match_mfma.o _obj/tvg_e_$NAME.o _obj/tvg_fh_$NAME.o _obj/tvg_e_big.o _obj/tvg_fh_big.o _obj/pose.o _obj/camera.o
 ls -la _obj/libamc_$NAME.so
