@@ -82,6 +82,40 @@ def test_one_rank_exchange_through_the_c_abi_without_torch_distributed(amc_ctx):
     comm.close()
 
 
+def _fake_rccl() -> Path:
+    """tests/shim/fake_rccl.cc -> tests/shim/_build/libfakerccl.so (built here when missing or older than its source)."""
+    src = ROOT / "tests" / "shim" / "fake_rccl.cc"
+    out = ROOT / "tests" / "shim" / "_build" / "libfakerccl.so"
+    if not out.exists() or out.stat().st_mtime < src.stat().st_mtime:
+        out.parent.mkdir(exist_ok=True)
+        subprocess.run(["g++", "-O1", "-std=c++17", "-shared", "-fPIC", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                        str(src), "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib", "-o", str(out)], check=True)
+    return out
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_several_ranks_of_the_c_abi_exchange_on_one_device(world):
+    """The N > 1 logic of amc_allgather_match_tables with N ranks as threads on the ONE device this box has: RCCL itself
+    refuses two ranks per device, so a stand-in transport (tests/shim/fake_rccl.cc: rendezvous + device-to-device copies,
+    loaded through AMC_RCCL_LIBRARY) carries the bytes; displacements, exact per-rank counts, the reorder into the
+    global CSR, appended lists, downloads on one rank and the poisoned size exchange are the product's
+    (tests/comm_threads.py checks them against the single-context result)."""
+    env = dict(os.environ, AMC_RCCL_LIBRARY=str(_fake_rccl()), PYTHONPATH=str(ROOT))
+    r = subprocess.run([sys.executable, "tests/comm_threads.py", str(world), "--images", "7" if world == 2 else "5"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=200)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    assert f"comm threads ok: world {world}" in r.stdout
+
+
+def test_more_ranks_than_pairs_on_one_device():
+    """Two images = one pair over two ranks: one rank's table is empty (no rows sent, nothing received from it)."""
+    env = dict(os.environ, AMC_RCCL_LIBRARY=str(_fake_rccl()), PYTHONPATH=str(ROOT))
+    r = subprocess.run([sys.executable, "tests/comm_threads.py", "2", "--images", "2"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=200)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    assert "comm threads ok: world 2, 1 pairs as" in r.stdout
+
+
 @pytest.mark.skipif("_ngpus() < 2", reason="needs two GPUs")
 def test_two_rank_rccl_exchange_equals_single_process():
     r = _torchrun(2, "tools/dist_smoke.py")
