@@ -82,7 +82,7 @@ def verify_flops(work):
 
 def executed_valu(kernel_s_per_pair):
     """Executed vector instructions of the verification kernels from the committed SQ counter pass
-    (profiles/rNN/pmc_tvg_rNN.json of the latest round, tools/pmc_tvg_r04.sh), valid only while the kernels' sources hash to what they were
+    (profiles/rNN/pmc_tvg_rNN.json of the latest round, tools/pmc_tvg_r05.sh), valid only while the kernels' sources hash to what they were
     when the counters were taken: wave instructions x 64 lanes per pair, as a share of the FP64 issue rate."""
     try:
         import hashlib

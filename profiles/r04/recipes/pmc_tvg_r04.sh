@@ -1,6 +1,6 @@
 # round 4: SQ counters of the two verification kernels (tvg_e_kernel, tvg_fh_kernel) on 16,384 pairs of the bench's
 # verify workload, one counter group per pass (--kernel-trace + --pmc only; a pass whose rocprofv3 dies is retried).
-#   bash tools/pmc_tvg_r04.sh [tag]      -> gpurun_out/r04/pmc_tvg_r04_<tag>.txt
+#   bash profiles/r04/recipes/pmc_tvg_r04.sh [tag]      -> gpurun_out/r04/pmc_tvg_r04_<tag>.txt
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; TAG=${1:-v1}; mkdir -p $R/gpurun_out/r04
 OUT=$R/gpurun_out/r04/pmc_tvg_r04_$TAG.txt

@@ -5,8 +5,8 @@ mkdir -p $O
 TAG=${1:-v2}
 mkdir -p tools/bin; [ -x tools/bin/ubench_ladder ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -o tools/bin/ubench_ladder tools/ubench_ladder.hip
 timeout 900 python bench.py > $O/bench_line_unprofiled_$TAG.json 2> $O/bench_line_unprofiled_$TAG.err
-bash tools/pmc_r04.sh $TAG > $O/pmc_r04_$TAG.log 2>&1
-bash tools/pmc_dense_r04.sh $TAG > /dev/null 2>&1
+bash profiles/r04/recipes/pmc_r04.sh $TAG > $O/pmc_r04_$TAG.log 2>&1
+bash profiles/r04/recipes/pmc_dense_r04.sh $TAG > /dev/null 2>&1
 timeout 300 tools/bin/ubench_ladder > $O/ladder_$TAG.txt 2>&1
 LADDER_DATA=1 timeout 300 tools/bin/ubench_ladder > $O/ladder_siftlike_$TAG.txt 2>&1
 bash tools/ladder_pmc.sh $TAG > /dev/null 2>&1

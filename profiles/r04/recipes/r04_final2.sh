@@ -7,7 +7,7 @@ TAG=${1:-v4}
 timeout 900 python bench.py > $O/bench_line_unprofiled_$TAG.json 2> $O/bench_line_unprofiled_$TAG.err
 tail -c 600 $O/bench_line_unprofiled_$TAG.err
 (cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/kt4 && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt4 -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $GRAFT_REPO_ROOT/$O/bench_line_under_rocprofv3_$TAG.json 2> /tmp/kt4.err; f=$(find /tmp/kt4 -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $GRAFT_REPO_ROOT/$O/rocprofv3_kernel_stats_bench_steps3_$TAG.csv && head -8 $f | cut -c1-160)
-bash tools/pmc_tvg_r04.sh v2 > /dev/null 2>&1
+bash profiles/r04/recipes/pmc_tvg_r04.sh v2 > /dev/null 2>&1
 timeout 600 python tools/stress_match.py --rounds 20 > $O/stress_match_$TAG.txt 2>&1
 timeout 900 python tools/stress_verify.py > $O/stress_verify_$TAG.txt 2>&1
 tail -n 1 $O/stress_match_$TAG.txt; tail -n 1 $O/stress_verify_$TAG.txt

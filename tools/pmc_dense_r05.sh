@@ -1,14 +1,14 @@
-# round 4: memory-side counters of the cross-check stage's kernels on the dense set (every pair overlapping): what
-# "gather-bound" means in bytes.  One counter group per pass.   bash tools/pmc_dense_r04.sh [tag]
+# round 5: memory-side counters of the cross-check stage's kernels on the dense set (every pair overlapping): what
+# "gather-bound" means in bytes.  One counter group per pass.   bash tools/pmc_dense_r05.sh [tag]
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT; TAG=${1:-v1}; mkdir -p $R/gpurun_out/r04
-OUT=$R/gpurun_out/r04/pmc_dense_r04_$TAG.txt
+R=$GRAFT_REPO_ROOT; TAG=${1:-v1}; mkdir -p $R/gpurun_out/r05
+OUT=$R/gpurun_out/r05/pmc_dense_r05_$TAG.txt
 : > $OUT
 run() {
   tag=$1; shift
   for try in 1 2 3; do
     rm -rf /tmp/pmcd_$tag
-    timeout 400 rocprofv3 --kernel-trace --pmc "$@" -d /tmp/pmcd_$tag -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --verify-pairs 0 --no-pipeline --no-ragged --no-db > /tmp/pmcd_$tag.log 2>&1
+    timeout 400 rocprofv3 --kernel-trace --pmc "$@" -d /tmp/pmcd_$tag -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --verify-pairs 0 --no-pipeline --no-ragged --no-db --no-sift-stats --no-config3 > /tmp/pmcd_$tag.log 2>&1
     rc=$?
     db=$(find /tmp/pmcd_$tag -name "*.db" 2>/dev/null | head -1)
     [ -n "$db" ] && break

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""profiles/rNN/pmc_tvg_rNN.json from the text summary profiles/r03/recipes/pmc_tvg_r03.sh / pmc_tvg_r04.sh write (per-call averages of the SQ counters
+"""profiles/rNN/pmc_tvg_rNN.json from the text summary profiles/r03/recipes/pmc_tvg_r03.sh / pmc_tvg_r05.sh write (per-call averages of the SQ counters
 of the two verification kernels + the derived ratios + the sha256 of the kernel sources the counters belong to;
 bench.py's verify.roofline.executed reads it while the sources still hash to the same values).
-    python tools/pmc_tvg_json.py profiles/r04/pmc_tvg_r04_v1.txt [out.json]"""
+    python tools/pmc_tvg_json.py gpurun_out/r05/pmc_tvg_r05_v1.txt [out.json]"""
 import hashlib
 import json
 import re
@@ -45,7 +45,7 @@ def main(txt):
         total += c["SQ_INSTS_VALU"]
     out["valu_wave_instructions_per_pair"] = total / PAIRS
     out["kernel_source_sha256"] = {f: hashlib.sha256((ROOT / f).read_bytes()).hexdigest() for f in SOURCES}
-    dst = Path(sys.argv[2]) if len(sys.argv) > 2 else ROOT / "profiles" / "r04" / "pmc_tvg_r04.json"
+    dst = Path(sys.argv[2]) if len(sys.argv) > 2 else ROOT / "profiles" / "r05" / "pmc_tvg_r05.json"
     dst.write_text(json.dumps(out, indent=1) + "\n")
     print(json.dumps({k: out[k] for k in ("valu_wave_instructions_per_pair",)}, indent=1))
     for k in ("tvg_e_kernel", "tvg_fh_kernel"):
