@@ -337,9 +337,10 @@ def test_trim_releases_scratch_and_the_context_keeps_working(amc_ctx):
 
 
 def test_slots_uploaded_again_and_again(amc_ctx):
-    """The slots' device memory comes from a slab allocator with a size-keyed free list (amc_api.hip, SlotArena): slots
-    re-uploaded with other sizes - blocks freed, reused for requests up to half their size, slabs extended - keep
-    holding what was uploaded last, and the keypoint / grid buffers beside them as well."""
+    """The slots' device memory comes from a slab allocator (amc_api.hip, SlotArena: best fit, blocks split on
+    allocation and merged with their free neighbours when freed, idle slabs given back at amc_ctx_trim): slots
+    re-uploaded with other sizes keep holding what was uploaded last, and the keypoint / grid buffers beside them as
+    well; a trim between two rounds changes nothing."""
     rng = np.random.default_rng(31)
     n = 6
     amc_ctx.reserve_slots(n)
@@ -353,6 +354,9 @@ def test_slots_uploaded_again_and_again(amc_ctx):
             amc_ctx.upload_keypoints(int(k), rng.uniform(0, 1000, (rows, 2)).astype(np.float32))
         s1, s2 = synth.exhaustive_pairs(n)
         assert_same(amc_ctx, imgs, s1, s2, "auto")
+        if round_ in (3, 6):
+            amc_ctx.trim()                                     # scratch and idle slabs go; the uploaded images stay
+            assert_same(amc_ctx, imgs, s1, s2, "auto")
     amc_ctx.reserve_slots(2)                                   # everything released; the context starts over
     small = [synth.random_descriptors(rng, 200), synth.random_descriptors(rng, 100)]
     upload(amc_ctx, small)

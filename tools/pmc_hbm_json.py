@@ -23,6 +23,14 @@ out = {"source": f"{Path(sys.argv[1]).name} (tools/pmc_r05.sh: rocprofv3 --kerne
 out["launches_per_step"] = calls
 out["pairs_per_launch"] = 124750 // calls if calls else None
 out["workload"] = f"500 images x 4096 descriptors, 124750 pairs, {calls} launches per step (per-launch figures are averages over them)"
+if "FETCH_SIZE" not in cnt and "TCC_EA0_RDREQ_sum" in cnt:
+    # rocprofv3 dies on the derived FETCH_SIZE on some boxes (rc 139); the guide's HBM section gives its definition -
+    # FETCH_SIZE = TCC_EA0_RDREQ x 64 B, in KB - so the raw request counter of a separate pass stands in for it
+    cnt["FETCH_SIZE"] = (cnt["TCC_EA0_RDREQ_sum"][0], cnt["TCC_EA0_RDREQ_sum"][1] * 64 / 1024, cnt["TCC_EA0_RDREQ_sum"][2] * 64 / 1024)
+    out["fetch_size_from"] = "TCC_EA0_RDREQ_sum x 64 B (the definition of FETCH_SIZE, MI355X_MICROARCH.md HBM section); the derived counter's pass died"
+    out["read_requests_per_launch"] = cnt["TCC_EA0_RDREQ_sum"][2]
+    if "TCC_EA0_RDREQ_32B_sum" in cnt:
+        out["read_requests_32B_per_launch"] = cnt["TCC_EA0_RDREQ_32B_sum"][2]
 if "FETCH_SIZE" in cnt:
     out["fetch_size_kb_per_launch"] = cnt["FETCH_SIZE"][2]
     out["fetch_bytes_per_launch_corrected"] = cnt["FETCH_SIZE"][2] * 1024 * 2
