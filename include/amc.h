@@ -135,7 +135,8 @@ int amc_ctx_resident_matches(amc_ctx* ctx, const uint32_t** dev_matches, uint64_
  *
  * amc_comm_unique_id: ncclGetUniqueId.  One rank calls it and hands the AMC_COMM_ID_BYTES to every rank by whatever
  * channel the host has (MPI, a key-value store, torch.distributed, shared memory between threads).
- * amc_comm_create: ncclCommInitRank on the ctx's device - collective: every rank calls it with the same id. */
+ * amc_comm_create: ncclCommInitRank on the ctx's device - collective: every rank calls it with the same id.
+ * amc_comm_destroy: before the ctx it was created on (it owns device buffers of that ctx's device). */
 #define AMC_COMM_ID_BYTES 128
 typedef struct amc_comm amc_comm;
 int amc_comm_unique_id(void* id);

@@ -325,7 +325,7 @@ def test_concurrent_database_use_under_sanitizers(tmp_path, sanitizer):
     assert r.returncode == 0 and r.stdout.startswith("ok rows="), (r.returncode, r.stdout[-500:], r.stderr[-3000:])
 
 
-@pytest.mark.parametrize("seed", [1, 2, 3])
+@pytest.mark.parametrize("seed", [1, 2])
 def test_slot_arena_bookkeeping_under_asan(tmp_path, seed):
     """The sub-allocator behind the image slots' device memory (pycolmap_amd/csrc/slot_arena.h: best fit, split, merge
     with free neighbours, idle slabs released at trim) over a fake raw allocator, 20,000 random alloc / free / trim
