@@ -1949,11 +1949,12 @@ static int verify_impl(amc_ctx* c, int mode, const uint32_t* slot1, const uint32
     for (size_t p = 0; p < npairs; ++p) {
         const uint32_t mc = std::max<uint32_t>(64, round_up(tp[p].M, 64));
         const size_t lds = tvg_lds_bytes(mc, 1) + 64;
-        // (full occupancy of BOTH kernels: the E kernel's waves also carry the root finder's 9 KB)
-        if (lds <= 160 * 1024 / (4 * (size_t)kTvgFhWavesPerSimd) && lds + 9 * 1024 <= 160 * 1024 / (4 * (size_t)kTvgEWavesPerSimd))
+        const size_t lds_e = tvg_lds_bytes_e(mc, 1) + 64;  // (the E kernel's waves also carry the root finder's coefficients)
+        // (full occupancy of BOTH kernels)
+        if (lds <= 160 * 1024 / (4 * (size_t)kTvgFhWavesPerSimd) && lds_e <= 160 * 1024 / (4 * (size_t)kTvgEWavesPerSimd))
             cls[0].push_back(p);
-        else if (lds + 9 * 1024 <= 160 * 1024 / 4) cls[1].push_back(p);  // 4-wave workgroups of either kernel fit a CU
-        else if (lds + 9 * 1024 <= 160 * 1024) cls[2].push_back(p);  // (+ the E kernel's root-finder scratch)
+        else if (lds_e <= 160 * 1024 / 4) cls[1].push_back(p);  // 4-wave workgroups of either kernel fit a CU
+        else if (lds_e <= 160 * 1024) cls[2].push_back(p);
         else cls[3].push_back(p);  // M <= 65535 was checked above
     }
     // which pairs run the essential-matrix RANSAC first (tvg_e_kernel), exactly as the F/H kernel decides it

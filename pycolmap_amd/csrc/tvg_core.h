@@ -150,17 +150,27 @@ __host__ __device__ inline size_t tvg_ws_bytes_extra(uint32_t mcap) { return (si
 __host__ __device__ inline size_t tvg_idx_doubles(uint32_t mcap) { return (tvg_idx_bytes(mcap) + 7) / 8; }
 // The essential-matrix kernel's minimal solves spread the root finder's brackets over the wave (real_roots10_lanes):
 // per wave the level's coefficients of every lane (11 x 64 doubles) and one pass of bracket records
-// (kRootCap x (lo, hi, f(lo)) + the owning lane), behind the common layout.
+// (kRootCap x (lo, hi, f(lo)) + the owning lane).  Only the coefficients get LDS of their own, behind the common
+// layout; the bracket records lie OVER parts of the common layout that hold nothing while the root finder runs
+// (round 5: 8,960 -> 5,632 bytes per wave, so that a wave's share of a CU's 160 KB at three waves per SIMD - 13.3 KB -
+// holds pairs of up to ~970 matches instead of none):
+//   lo, hi, src over jacA | jacV | sidx   (the Jacobi scratch is the local optimisation's; the chunk's sample indices
+//                                          were consumed by the constraint rows before the root finder starts)
+//   flo         over tmax | mlist         (written by count_chunk, after solve_chunk)
+// rawcnt, between them, stays: the sampler's draw counts are read again when a trial aborts the chunk.
 constexpr int kRootCap = 128;  // = one pair of brackets per lane and pass
-constexpr size_t kRootScratchBytes = (size_t)11 * 64 * 8 + (size_t)3 * kRootCap * 8 + (size_t)kRootCap * 2;
+constexpr size_t kRootScratchBytes = (size_t)11 * 64 * 8;
 __host__ __device__ inline size_t tvg_lds_per_wave_e(uint32_t mcap) { return tvg_lds_per_wave(mcap) + kRootScratchBytes; }
-__device__ __forceinline__ RootScratch root_scratch_carve(AMC_LDS char* base) {
+__device__ __forceinline__ RootScratch root_scratch_carve(AMC_LDS char* wave_base, AMC_LDS char* behind) {
+    constexpr size_t kJac = (size_t)162 * 8, kSidx = (size_t)64 * 8 * 2, kRaw = 64 * 4, kTmax = 64 * 4, kMlist = (size_t)64 * kMaxModels * 2;
+    static_assert((size_t)2 * kRootCap * 8 + kRootCap * 2 <= kJac + kSidx, "lo | hi | src fit in front of rawcnt");
+    static_assert((size_t)kRootCap * 8 <= kTmax + kMlist, "flo fits behind rawcnt");
     RootScratch S;
-    S.coef = reinterpret_cast<lds_f64*>(base);
-    S.lo = S.coef + 11 * 64;
+    S.coef = reinterpret_cast<lds_f64*>(behind);
+    S.lo = reinterpret_cast<lds_f64*>(wave_base);
     S.hi = S.lo + kRootCap;
-    S.flo = S.hi + kRootCap;
-    S.src = reinterpret_cast<lds_u16*>(S.flo + kRootCap);
+    S.src = reinterpret_cast<lds_u16*>(S.hi + kRootCap);
+    S.flo = reinterpret_cast<lds_f64*>(wave_base + kJac + kSidx + kRaw);
     return S;
 }
 

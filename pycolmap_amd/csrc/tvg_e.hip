@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(kTvgEWavesP
     w.lane = lane;
     AMC_LDS char* lds = (AMC_LDS char*)smem + (size_t)wid * tvg_lds_per_wave_e(mcap);
     wave_carve(w, lds, mcap);
-    w.rootscr = root_scratch_carve(lds + tvg_lds_per_wave(mcap));
+    w.rootscr = root_scratch_carve(lds, lds + tvg_lds_per_wave(mcap));
     const size_t gw = (size_t)blockIdx.x * (blockDim.x >> 6) + wid;
     w.ws = ws_all + gw * tvg_ws_doubles_e(mcap);
 #if defined(AMC_TVG_BIG)
