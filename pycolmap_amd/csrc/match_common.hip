@@ -155,24 +155,33 @@ __global__ __launch_bounds__(256) void finalize_kernel(
     }
     __syncthreads();
     uint32_t running = s_base;
-    // pass 2: ordered write
-    for (uint32_t base = 0; base < n1; base += 256) {
-        const uint32_t i = base + tid;
-        const bool m = i < n1 && ((mask[i >> 5] >> (i & 31)) & 1u);
-        const uint32_t j = m ? rows[i].best_idx : 0u;
-        const unsigned long long bal = __ballot(m);
-        const uint32_t before = __popcll(bal & ((1ull << lane) - 1ull));
+    // pass 2: ordered write, by accept word: thread t owns words t, t + 256, ... of the pair (32 rows each, the bits
+    // pass 1 left), a block-wide prefix of their popcounts places them, and a thread writes its word's matches in row
+    // order.  A 4,096-row image is 128 words: one round and two barriers, where a round per 256 rows took thirty-two.
+    const uint32_t nwords = (n1 + 31) / 32;
+    for (uint32_t wbase = 0; wbase < nwords; wbase += 256) {
+        const uint32_t w = wbase + tid;
+        uint32_t bits = w < nwords ? mask[w] : 0u;
+        const uint32_t c = __popc(bits);
+        uint32_t inc = c;
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) {
+            const uint32_t o = __shfl_up(inc, m);
+            if (lane >= (uint32_t)m) inc += o;
+        }
+        __syncthreads();  // (wave_cnt is still being read from the round before)
+        if (lane == 63) wave_cnt[wid] = inc;
         __syncthreads();
-        if (lane == 0) wave_cnt[wid] = __popcll(bal);
-        __syncthreads();
-        uint32_t woff = 0;
-        for (uint32_t w = 0; w < wid; ++w) woff += wave_cnt[w];
-        if (m) {
-            const uint32_t dst = running + woff + before;
+        uint32_t dst = running + inc - c;
+        for (uint32_t k = 0; k < wid; ++k) dst += wave_cnt[k];
+        while (bits) {
+            const uint32_t i = w * 32 + (uint32_t)(__ffs(bits) - 1);
+            bits &= bits - 1;
             if (dst < capacity) {
-                matches[2ull * dst] = base + tid;
-                matches[2ull * dst + 1] = j;
+                matches[2ull * dst] = i;
+                matches[2ull * dst + 1] = rows[i].best_idx;
             }
+            ++dst;
         }
         running += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
     }
@@ -520,6 +529,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 // ---------------------------------------------------------------------------------------
 typedef int i32x16 __attribute__((ext_vector_type(16)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
+constexpr uint32_t kResolveFewRows = 96;   // up to so many accepted rows in a chunk are walked unsorted (below)
 constexpr uint32_t kResolveChunkM = 3840;  // rows per sort chunk of the mfma form: two lists of it + the histogram stay under 40 KB
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void resolve_index_mfma_kernel(
     int side, const ImageDev* __restrict__ imgs, const PairDev* __restrict__ pairs,
@@ -552,7 +562,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     for (uint32_t chunk0 = 0; chunk0 < n; chunk0 += kResolveChunkM) {
         const uint32_t chunk_end = min(n, chunk0 + kResolveChunkM);
         if (tid == 0) s_count = 0;
-        for (uint32_t k = tid; k < kResolveMaxTiles; k += 256) s_hist[k] = 0;
         __syncthreads();
         // ---- accepted rows of the chunk and the histogram of their tiles (four rows per thread and round: their table
         // reads are independent and in flight together)
@@ -595,34 +604,45 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 }
                 const uint32_t pos = atomicAdd(&s_count, 1u);
                 s_list[pos] = (tile[u] << 12) | (e - chunk0);
-                atomicAdd(&s_hist[tile[u]], 1u);
             }
         }
         __syncthreads();
         const uint32_t cnt = s_count;
         if (cnt == 0) { __syncthreads(); continue; }
-        // ---- exclusive scan of the histogram (thread t owns bins [t * kPer, (t + 1) * kPer))
-        uint32_t h[kPer], c = 0;
+        // Few accepted rows (a pair without overlap: a handful of chance matches - 97 % of an exhaustive job's pairs):
+        // they sit in as many tiles as there are rows, sorting could not merge a single visit, so the waves walk the
+        // list as it was collected and the histogram is never touched (zeroing, counting, scanning and sorting it was
+        // most of this kernel's time on such pairs).  The order of the rows is free: each is resolved on its own.
+        const bool few = cnt <= kResolveFewRows;
+        const uint32_t* const walk = few ? s_list : s_sorted;
+        if (!few) {
+            for (uint32_t k = tid; k < kResolveMaxTiles; k += 256) s_hist[k] = 0;
+            __syncthreads();
+            for (uint32_t k = tid; k < cnt; k += 256) atomicAdd(&s_hist[s_list[k] >> 12], 1u);
+            __syncthreads();
+            // ---- exclusive scan of the histogram (thread t owns bins [t * kPer, (t + 1) * kPer))
+            uint32_t h[kPer], c = 0;
 #pragma unroll
-        for (uint32_t k = 0; k < kPer; ++k) { h[k] = s_hist[tid * kPer + k]; c += h[k]; }
-        uint32_t inc = c;
+            for (uint32_t k = 0; k < kPer; ++k) { h[k] = s_hist[tid * kPer + k]; c += h[k]; }
+            uint32_t inc = c;
 #pragma unroll
-        for (int m = 1; m < 64; m <<= 1) {
-            const uint32_t o = __shfl_up(inc, m);
-            if (lane >= (uint32_t)m) inc += o;
+            for (int m = 1; m < 64; m <<= 1) {
+                const uint32_t o = __shfl_up(inc, m);
+                if (lane >= (uint32_t)m) inc += o;
+            }
+            if (lane == 63) s_wsum[wid] = inc;
+            __syncthreads();
+            uint32_t start = inc - c;
+            for (uint32_t k = 0; k < wid; ++k) start += s_wsum[k];
+#pragma unroll
+            for (uint32_t k = 0; k < kPer; ++k) { s_hist[tid * kPer + k] = start; start += h[k]; }
+            __syncthreads();
+            for (uint32_t k = tid; k < cnt; k += 256) {
+                const uint32_t v = s_list[k];
+                s_sorted[atomicAdd(&s_hist[v >> 12], 1u)] = v;
+            }
+            __syncthreads();
         }
-        if (lane == 63) s_wsum[wid] = inc;
-        __syncthreads();
-        uint32_t start = inc - c;
-        for (uint32_t k = 0; k < wid; ++k) start += s_wsum[k];
-#pragma unroll
-        for (uint32_t k = 0; k < kPer; ++k) { s_hist[tid * kPer + k] = start; start += h[k]; }
-        __syncthreads();
-        for (uint32_t k = tid; k < cnt; k += 256) {
-            const uint32_t v = s_list[k];
-            s_sorted[atomicAdd(&s_hist[v >> 12], 1u)] = v;
-        }
-        __syncthreads();
         // ---- each wave walks a contiguous quarter of the sorted list in batches of 32 rows, and the batch's dot products
         // come from the int8 matrix core: B operand = the batch's 32 X rows (prepared arena, fetched once per batch),
         // A operand = one 32-row Y tile; four MFMAs give every (X row, Y row) product of the pair, the zero-point term
@@ -641,7 +661,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             uint32_t my_row = 0, my_e = 0, my_tile = 0xFFFFFFFFu;
             Top2 my_t{0u, 0u, 0u, 0u};
             if (lane < nb) {
-                const uint32_t v = s_sorted[b0 + lane];
+                const uint32_t v = walk[b0 + lane];
                 my_tile = v >> 12;
                 my_e = chunk0 + (v & 4095u);
                 my_row = side == 0 ? my_e : list[my_e];
