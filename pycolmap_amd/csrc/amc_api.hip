@@ -135,12 +135,21 @@ struct PinnedPool {
     static constexpr size_t kMaxIdleBytes = (size_t)3 << 29;  // 1.5 GiB
     std::mutex mu;
     std::vector<PinBuf<uint32_t>> idle;
-    PinBuf<uint32_t> acquire() {
+    // want (elements): the smallest idle buffer that holds it, else the largest (the caller grows it).  A call that leases
+    // two buffers of different sizes (verification: records and masks) would otherwise hand the larger one to whichever
+    // lease comes first and re-allocate the other - a hipHostMalloc of tens of MB in every early call of a run.
+    PinBuf<uint32_t> acquire(size_t want = 0) {
         std::lock_guard<std::mutex> lock(mu);
         if (idle.empty()) return PinBuf<uint32_t>();
+        auto better = [&](const PinBuf<uint32_t>& a, const PinBuf<uint32_t>& b) {
+            const bool fa = a.cap >= want, fb = b.cap >= want;
+            if (want && fa != fb) return fa;       // one that fits beats one that does not
+            if (want && fa) return a.cap < b.cap;  // both fit: the smaller
+            return a.cap > b.cap;                  // neither fits (or no wish): the larger
+        };
         size_t best = 0;
         for (size_t i = 1; i < idle.size(); ++i)
-            if (idle[i].cap > idle[best].cap) best = i;
+            if (better(idle[i], idle[best])) best = i;
         PinBuf<uint32_t> b = idle[best];
         idle.erase(idle.begin() + best);
         return b;
@@ -1820,8 +1829,8 @@ static int verify_impl(amc_ctx* c, int mode, const uint32_t* slot1, const uint32
     VerifyPriv* priv = new (std::nothrow) VerifyPriv();
     if (!priv) return fail(AMC_E_NOMEM, "amc_verify_pairs: out of host memory");
     priv->pool = c->verify_pool;
-    priv->tvg_pin = c->verify_pool->acquire();
-    priv->mask_pin = c->verify_pool->acquire();
+    priv->tvg_pin = c->verify_pool->acquire((std::max<size_t>(npairs, 1) * sizeof(amc_tvg) + 3) / 4);
+    priv->mask_pin = c->verify_pool->acquire((size_t)(std::max<uint64_t>(total, 1) + 3) / 4);
     if (priv->tvg_pin.ensure((std::max<size_t>(npairs, 1) * sizeof(amc_tvg) + 3) / 4) != hipSuccess ||
         priv->mask_pin.ensure((size_t)(std::max<uint64_t>(total, 1) + 3) / 4) != hipSuccess) {
         delete priv;
