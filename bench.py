@@ -35,6 +35,7 @@ Prints ONE JSON line (rank 0).
 from __future__ import annotations
 
 import argparse
+import gc
 import json
 import math
 import os
@@ -63,6 +64,14 @@ FLOP_SAMPSON, FLOP_HRES, FLOP_TRES = 33, 20, 7
 FLOP_E5_MIN, FLOP_F7_MIN, FLOP_H4_MIN = 30000, 2900, 1300
 FLOP_LO_E5, FLOP_LO_F8, FLOP_LO_H = 72000, 44000, 44000      # 9 x 9 Jacobi (+ 5-point set-up / roots)
 FLOP_LO_POINT = 200                                           # normalisation + design row + 45 MACs per inlier
+
+
+def quiet_gc():
+    """The timed loops hold large numpy / ctypes object graphs; a generation-2 collection in the middle of a step is a
+    host-side stall of tens of milliseconds (seen once in five ragged steps).  The collector runs HERE, between the
+    legs, and not by itself (reference counting still frees everything that is not a cycle).  Nothing measured changes."""
+    gc.collect()
+    gc.disable()
 
 
 def verify_flops(work):
@@ -229,6 +238,7 @@ def verify_leg(ctx_factory, device_index: int, npairs: int, steps: int, warmup: 
     model selection + watermark test all run), ~300 planted inliers + ~100 outliers each, a
     quarter of the scenes planar.  `distinct` seeded scenes (default 4096: different trial counts, branches and
     correspondences from pair to pair), reused round-robin to fill the 124,750 pairs."""
+    quiet_gc()
     from pycolmap_amd import _capi, synth
     rng = np.random.default_rng(7)
     distinct = max(1, min(distinct, npairs))
@@ -321,6 +331,7 @@ def pipeline_leg(ctx_factory, steps: int, warmup: int, cpu_pairs: int, num_image
     every pair with >= 15 matches, on ONE scene with real geometry (synth.tower_scene: an orbit capture, sparse
     overlap), the two stages chained on the device: amc_match_verify_pairs - the verification kernel reads the
     matches where the matcher left them in HBM."""
+    quiet_gc()
     from pycolmap_amd import _capi, synth
     rng = np.random.default_rng(11)
     t0 = time.perf_counter()
@@ -447,6 +458,7 @@ def dense_leg(ctx_factory, device, steps: int, warmup: int, num_images: int, fea
     """configs[1] on a set where EVERY pair overlaps (all images look at the same landmarks): the share of accepted
     rows is ~100x that of the sparse set, so the reverse scan of the candidate columns and the D2H of the match
     table stop being negligible.  Reported beside the headline, same unit."""
+    quiet_gc()
     import torch
     arena = make_arena_torch(num_images, feats, seed=1, device=device, overlap="all")
     ctx = ctx_factory()
@@ -494,6 +506,7 @@ def db_leg(num_images: int, feats: int, seed: int = 11):
     holding BASELINE configs[2]'s image set - SQLite read, upload, match + verify on the device, SQLite write - with
     the controller's own breakdown (`last_run_stats()`), and the resume path (a second call finds everything there).
     The kernel legs above time the device work; this leg is the wall clock around it."""
+    quiet_gc()
     import sys as _sys
     import tempfile
     _sys.path.insert(0, str(ROOT / "tests"))
@@ -538,6 +551,7 @@ def ragged_leg(ctx_factory, device, steps: int, warmup: int, num_images: int, lo
     of the kernel's 128-row segments or 256-row chunks.  Same generator, same sparse overlap as the headline; reported
     beside it in the same unit, with the scan kernel's own rate, so that a tiling that only suits 4096 = 4 x 1024 rows
     shows."""
+    quiet_gc()
     import torch
     rng = np.random.default_rng(7)
     rows = rng.integers(lo, hi + 1, size=num_images)
@@ -584,6 +598,7 @@ def sift_stats_leg(ctx_factory, device, steps: int, warmup: int, num_images: int
     x512: make_arena_torch(stats="sift")) - the same scene recipe, the same sparse overlap as the headline.  The scan is
     bound by the chip's power budget and the clock it holds moves with the operand bytes: this leg
     says what the headline's kernel does on data shaped like a real capture's."""
+    quiet_gc()
     import torch
     arena = make_arena_torch(num_images, feats, seed=3, device=device, stats="sift")
     hi_share = float((arena >= 128).float().mean().item())
@@ -740,6 +755,7 @@ def config34_leg(args, config: int, steps: int, warmup: int, dist_state):
     every GPU, one all-gather of the match tables at the end of every step (inside the timed region) - through the
     library's own entry point (amc_allgather_match_tables: RCCL called behind the C ABI, rows straight from the
     device memory the kernels wrote).  Collective: every rank calls it; rank 0 gets the leg's dict, the others None."""
+    quiet_gc()
     import torch
     import torch.distributed as dist
     from pycolmap_amd import _capi, synth
@@ -1042,6 +1058,7 @@ def main():
     state = dist_setup(args)
     world, rank, local_rank, device, use_dist = state
     dry = args.cpu_dry_run
+    quiet_gc()
 
     # ---- workload ------------------------------------------------------------------------
     num_images = args.images if world == 1 else int(round(args.images * math.sqrt(world)))
