@@ -46,7 +46,8 @@
 extern "C" {
 #endif
 
-#define AMC_ABI_VERSION 3 /* 3: the multi-GPU exchange (amc_comm_*, amc_allgather_match_tables) */
+#define AMC_ABI_VERSION 4 /* 3: the multi-GPU exchange (amc_comm_*, amc_allgather_match_tables); 4: its verification half
+                             (amc_allgather_pair_records, amc_allgather_inlier_tables) */
 #define AMC_DESC_DIM 128 /* SIFT descriptor bytes; /root/reference/pycolmap/feature/sift.h:76-77 */
 
 enum {
@@ -176,6 +177,40 @@ int amc_allgather_match_tables(amc_ctx* ctx, amc_comm* comm, const uint64_t* pai
                                const uint64_t* offsets, const uint32_t* matches, int download,
                                amc_gathered_tables* out);
 void amc_gathered_tables_free(amc_gathered_tables* t);
+
+/* The verification half of the exchange (the payload of a sharded match + verify run is
+ * [pair, count, matches, (config, F / E / H, inlier list)]; the reference's surface is the same
+ * SiftMatchingOptions.gpu_index, /root/reference/pycolmap/pipeline/match_features.h:76-81 - COLMAP's verifier
+ * threads hand FeatureMatcherData{matches, two_view_geometry} to ONE database writer).
+ *
+ * amc_allgather_pair_records: one fixed-size record per pair, all ranks, in the global pair order.
+ *   records       this rank's npairs_local records of record_bytes each on the HOST (any plain struct: amc_tvg,
+ *                 amc_pose, ...), or NULL: the amc_tvg records of the LAST amc_verify_pairs / amc_match_verify_pairs
+ *                 call on this ctx, taken where the verification kernels left them in device memory (record_bytes must
+ *                 be sizeof(amc_tvg), npairs_local that call's npairs)
+ *   record_bytes  a multiple of 8, the same on every rank
+ * Pairs no rank owns cannot occur: positions must be a permutation of 0 .. total - 1, as for the match tables.
+ *
+ * amc_allgather_inlier_tables: the inlier matches of the LAST verification call on this ctx (the rows of its input
+ * matches whose inlier_mask byte is non-zero, ordered as ExtractInlierMatches orders them), compacted on the device
+ * from the match table and the masks where they lie, and exchanged like the match tables: out->offsets / matches are
+ * the `two_view_geometries.data` blobs of all pairs.  Same collective protocol and errors as
+ * amc_allgather_match_tables; AMC_E_NOMEM when a rank cannot allocate its buffers (every rank returns it together). */
+typedef struct amc_gathered_records {
+    size_t npairs;               /* pairs of all ranks */
+    size_t record_bytes;
+    const void* records;         /* npairs * record_bytes (pinned host), NULL unless `download` was set */
+    const void* records_device;  /* the same in this ctx's device memory: valid until the next record gather on this comm */
+    uint64_t bytes_sent, bytes_received;
+    int32_t world_size, rank;
+    double total_ms;
+    void* _priv;
+} amc_gathered_records;
+int amc_allgather_pair_records(amc_ctx* ctx, amc_comm* comm, const uint64_t* pair_index, size_t npairs_local,
+                               const void* records, size_t record_bytes, int download, amc_gathered_records* out);
+void amc_gathered_records_free(amc_gathered_records* r);
+int amc_allgather_inlier_tables(amc_ctx* ctx, amc_comm* comm, const uint64_t* pair_index, size_t npairs_local,
+                                int download, amc_gathered_tables* out);
 
 /* Size the image-slot table. Slots are dense ids 0..num_slots-1 chosen by the caller (the host
  * layer maps COLMAP image_ids to slots). Discards previously uploaded data. */

@@ -31,6 +31,7 @@ EXPORTED_SYMBOLS = [
     "amc_cam_from_img", "amc_match_verify_pairs", "amc_ctx_trim", "amc_ctx_resident_matches",
     "amc_homography_decomposition", "amc_img_from_cam",
     "amc_comm_unique_id", "amc_comm_create", "amc_comm_destroy", "amc_allgather_match_tables", "amc_gathered_tables_free",
+    "amc_allgather_pair_records", "amc_gathered_records_free", "amc_allgather_inlier_tables",
 ]
 COMM_ID_BYTES = 128
 RANSAC_F, RANSAC_H, RANSAC_E = 0, 1, 2
@@ -89,6 +90,13 @@ class GatheredTables(C.Structure):
                 ("rows_received", C.c_uint64), ("world_size", C.c_int32), ("rank", C.c_int32),
                 ("sizes_ms", C.c_double), ("meta_ms", C.c_double), ("rows_ms", C.c_double), ("reorder_ms", C.c_double),
                 ("download_ms", C.c_double), ("total_ms", C.c_double), ("_priv", C.c_void_p)]
+
+
+class GatheredRecords(C.Structure):
+    """amc_gathered_records (include/amc.h)."""
+    _fields_ = [("npairs", C.c_size_t), ("record_bytes", C.c_size_t), ("records", C.c_void_p), ("records_device", C.c_void_p),
+                ("bytes_sent", C.c_uint64), ("bytes_received", C.c_uint64), ("world_size", C.c_int32), ("rank", C.c_int32),
+                ("total_ms", C.c_double), ("_priv", C.c_void_p)]
 
 
 class MatchOpts(C.Structure):
@@ -234,6 +242,13 @@ def load() -> C.CDLL:
                                                    C.c_int, C.POINTER(GatheredTables)]
         lib.amc_gathered_tables_free.argtypes = [C.POINTER(GatheredTables)]
         lib.amc_gathered_tables_free.restype = None
+    if hasattr(lib, "amc_allgather_pair_records"):
+        lib.amc_allgather_pair_records.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                                   C.c_int, C.POINTER(GatheredRecords)]
+        lib.amc_gathered_records_free.argtypes = [C.POINTER(GatheredRecords)]
+        lib.amc_gathered_records_free.restype = None
+        lib.amc_allgather_inlier_tables.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int,
+                                                    C.POINTER(GatheredTables)]
     _lib = lib
     return lib
 
@@ -296,24 +311,7 @@ class Comm:
         except Exception:
             pass
 
-    def allgather_match_tables(self, pair_index, offsets, matches=None, download: bool = True):
-        """amc_allgather_match_tables (collective).  pair_index: global positions of this rank's pairs, or None (the
-        ranks' lists are appended in rank order); offsets: this rank's CSR; matches: this rank's rows on the host, or
-        None = the context's device-resident table of the last match call.  Returns (global offsets uint64, global
-        matches [M, 2] uint32 or None when download is False, stats dict incl. the device pointer of the table)."""
-        off = np.ascontiguousarray(offsets, dtype=np.uint64)
-        n = off.size - 1
-        if n < 0:
-            raise ValueError("offsets must have npairs + 1 entries")
-        idx = None if pair_index is None else np.ascontiguousarray(pair_index, dtype=np.uint64)
-        if idx is not None and idx.shape != (n,):
-            raise ValueError("one global position per local pair")
-        m = None if matches is None else np.ascontiguousarray(matches, dtype=np.uint32).reshape(-1, 2)
-        res = GatheredTables()
-        _check(self._lib.amc_allgather_match_tables(
-            self._ctx._h, self._h, None if idx is None else idx.ctypes.data_as(C.c_void_p), n,
-            off.ctypes.data_as(C.c_void_p), None if m is None else m.ctypes.data_as(C.c_void_p), 1 if download else 0,
-            C.byref(res)))
+    def _tables_out(self, res, download):
         try:
             g_off = np.ctypeslib.as_array(res.offsets, shape=(int(res.npairs) + 1,)).copy()
             total = int(res.num_matches)
@@ -328,6 +326,87 @@ class Comm:
         finally:
             self._lib.amc_gathered_tables_free(C.byref(res))
         return g_off, g_m, stats
+
+    def allgather_match_tables(self, pair_index, offsets, matches=None, download: bool = True):
+        """amc_allgather_match_tables (collective).  pair_index: global positions of this rank's pairs, or None (the
+        ranks' lists are appended in rank order); offsets: this rank's CSR; matches: this rank's rows on the host, or
+        None = the context's device-resident table of the last match call.  Returns (global offsets uint64, global
+        matches [M, 2] uint32 or None when download is False, stats dict incl. the device pointer of the table).
+
+        Arguments this wrapper itself finds wrong (shapes, a `matches` array that does not hold offsets[-1] rows - the C
+        entry point takes no length and would read past it) do NOT raise here, before the collective: the other ranks
+        would wait for this one for ever.  The rank enters the exchange with offsets the library rejects ([1, 0]:
+        "offsets[0] != 0"), so that every rank raises together; the local reason is appended to this rank's message."""
+        off = np.ascontiguousarray(offsets, dtype=np.uint64).reshape(-1)
+        n = off.size - 1
+        idx = None if pair_index is None else np.ascontiguousarray(pair_index, dtype=np.uint64)
+        m = None if matches is None else np.ascontiguousarray(matches, dtype=np.uint32).reshape(-1, 2)
+        local = None
+        if n < 0:
+            local = "offsets must have npairs + 1 entries"
+        elif idx is not None and idx.shape != (n,):
+            local = "one global position per local pair"
+        elif m is not None and m.shape[0] != int(off[-1]) - int(off[0]):
+            local = "offsets and matches disagree (%d rows for offsets[-1] = %d)" % (m.shape[0], int(off[-1]))
+        if local is not None:   # poisoned entry: a one-pair CSR the library refuses collectively
+            off, n, idx, m = np.array([1, 0], dtype=np.uint64), 1, None, np.zeros((1, 2), dtype=np.uint32)
+        res = GatheredTables()
+        rc = self._lib.amc_allgather_match_tables(
+            self._ctx._h, self._h, None if idx is None else idx.ctypes.data_as(C.c_void_p), n,
+            off.ctypes.data_as(C.c_void_p), None if m is None else m.ctypes.data_as(C.c_void_p), 1 if download else 0,
+            C.byref(res))
+        if local is not None:
+            raise AmcError(rc if rc != AMC_OK else AMC_E_INVALID, "amc_allgather_match_tables: " + local)
+        _check(rc)
+        return self._tables_out(res, download)
+
+    def allgather_pair_records(self, pair_index, records=None, download: bool = True, dtype=None):
+        """amc_allgather_pair_records (collective): one fixed-size record per pair of every rank, in the global pair
+        order.  records: a 1-D structured / plain array with one element per local pair (itemsize a multiple of 8), or
+        None = the amc_tvg records of this context's last verification call, read in device memory (then pair_index
+        must have that call's number of pairs and the result has TVG_DTYPE).  Returns (records of all pairs or None when
+        download is False, stats)."""
+        idx = None if pair_index is None else np.ascontiguousarray(pair_index, dtype=np.uint64).reshape(-1)
+        rec = None if records is None else np.ascontiguousarray(records).reshape(-1)
+        rdt = TVG_DTYPE if rec is None else rec.dtype
+        if dtype is not None:
+            rdt = np.dtype(dtype)
+        n = len(rec) if rec is not None else (len(idx) if idx is not None else 0)
+        width = rdt.itemsize
+        if rec is not None and idx is not None and len(idx) != n:   # (collective error, as above: a record size the library refuses)
+            width, bad = 4, "one global position per local record"
+        else:
+            bad = None
+        res = GatheredRecords()
+        rc = self._lib.amc_allgather_pair_records(
+            self._ctx._h, self._h, None if idx is None else idx.ctypes.data_as(C.c_void_p), n,
+            None if rec is None else rec.ctypes.data_as(C.c_void_p), width, 1 if download else 0, C.byref(res))
+        if bad is not None:
+            raise AmcError(rc if rc != AMC_OK else AMC_E_INVALID, "amc_allgather_pair_records: " + bad)
+        _check(rc)
+        try:
+            total = int(res.npairs)
+            out = None
+            if download:
+                out = (np.frombuffer(C.string_at(res.records, total * width), dtype=rdt).copy() if total
+                       else np.zeros(0, dtype=rdt))
+            stats = dict(npairs=total, record_bytes=int(res.record_bytes), bytes_sent=int(res.bytes_sent),
+                         bytes_received=int(res.bytes_received), world_size=int(res.world_size), rank=int(res.rank),
+                         total_ms=float(res.total_ms), device_ptr=int(res.records_device or 0))
+        finally:
+            self._lib.amc_gathered_records_free(C.byref(res))
+        return out, stats
+
+    def allgather_inlier_tables(self, pair_index, npairs_local: int | None = None, download: bool = True):
+        """amc_allgather_inlier_tables (collective): the inlier matches of this context's last verification call
+        (compacted on the device from the match table and the masks), of every rank, in the global pair order - the
+        `two_view_geometries.data` blobs.  Returns what allgather_match_tables returns."""
+        idx = None if pair_index is None else np.ascontiguousarray(pair_index, dtype=np.uint64).reshape(-1)
+        n = len(idx) if idx is not None else int(npairs_local or 0)
+        res = GatheredTables()
+        _check(self._lib.amc_allgather_inlier_tables(self._ctx._h, self._h, None if idx is None else idx.ctypes.data_as(C.c_void_p),
+                                                     n, 1 if download else 0, C.byref(res)))
+        return self._tables_out(res, download)
 
 
 class Context:

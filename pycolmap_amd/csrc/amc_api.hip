@@ -273,6 +273,7 @@ struct amc_ctx {
     DevBuf<uint64_t> d_moff;
     DevBuf<TvgPair> d_tp_all;
     DevBuf<unsigned long long> d_worksum;
+    amc::VerifyResident vres;  // the last verification call's results, where they lie (amc_internal.h)
     std::shared_ptr<PinnedPool> verify_pool = std::make_shared<PinnedPool>();
     PinBuf<TvgOut> h_tout;    // where the records and masks of a verification call land (copied out before return)
     PinBuf<uint8_t> h_tmask;
@@ -299,6 +300,7 @@ int api_fail(int code, const char* fmt, ...) {
 CtxView ctx_view(amc_ctx* c) {
     return CtxView{c->device, c->stream, c->resident_matches ? c->d_keep.p : nullptr, c->resident_matches};
 }
+VerifyResident verify_resident(amc_ctx* c) { return c->vres; }
 }  // namespace amc
 
 extern "C" {
@@ -467,6 +469,7 @@ int amc_ctx_trim(amc_ctx* c) {
     c->result_pool->trim();
     c->d_keep.release(); c->d_csr.release();
     c->resident_matches = 0;
+    c->vres = amc::VerifyResident{};
     c->d_rowbuf.release(); c->d_colbuf.release(); c->d_accmask.release(); c->d_matches.release(); c->d_candbuf.release();
     c->d_segs.release(); c->d_seg_base.release();
     // the verification kernels' sample-stream table is rebuilt on demand (a host mt19937 run + one upload): keep the
@@ -718,6 +721,7 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
     priv->matches = c->result_pool->acquire();
     size_t keep_used = 0;  // matches of this call in c->d_keep so far (pair order: the result's CSR layout)
     c->resident_matches = 0;
+    c->vres = amc::VerifyResident{};  // (a resident verification result indexes the table this call rewrites)
     if (keep_off) keep_off->assign(npairs, 0);
 
     const size_t mfma_max_cols = kSelectMaxCols;  // cross-check candidate bitmap (image 2 rows)
@@ -1722,6 +1726,7 @@ static int verify_impl(amc_ctx* c, int mode, const uint32_t* slot1, const uint32
                        const uint32_t* dev_matches = nullptr, const uint64_t* dev_off = nullptr) {
     if (!c || !out) return fail(AMC_E_INVALID, "amc_verify_pairs: NULL ctx/out");
     std::memset(out, 0, sizeof *out);
+    c->vres = amc::VerifyResident{};
     if (npairs > 0 && (!slot1 || !slot2 || !match_offsets))
         return fail(AMC_E_INVALID, "amc_verify_pairs: NULL pair arrays");
     // AMC_VERIFY_PROFILE=1: wall-clock of the call's host phases on stderr
@@ -2224,6 +2229,16 @@ static int verify_impl(amc_ctx* c, int mode, const uint32_t* slot1, const uint32
         out->kernel_launches += 1;
     }
     guard.p = nullptr;
+    if (mode == 0) {  // what the exchange step's verification half reads in place (amc_allgather_pair_records / _inlier_tables)
+        c->vres.npairs = npairs;
+        c->vres.total = total;
+        // (EstimateTwoViewGeometryPose settles PLANAR_OR_PANORAMIC on the host copy of the records only)
+        c->vres.tvg = o.compute_relative_pose ? nullptr : c->d_tvg_packed.p;
+        c->vres.mask = c->d_mask_packed.p;
+        c->vres.moff = c->d_moff.p;
+        c->vres.tp = c->d_tp_all.p;
+        c->vres.matches = kernel_matches;
+    }
     return AMC_OK;
 }
 
@@ -2342,6 +2357,7 @@ static int verify_multiple(amc_ctx* c, const uint32_t* slot1, const uint32_t* sl
     out->kernel_ms = kernel_ms;
     out->kernel_launches = launches;
     for (int i = 0; i < 12; ++i) out->work[i] = work[i];
+    c->vres = amc::VerifyResident{};  // (the rounds' calls left the LAST round's shrunken lists: not this call's result)
     return AMC_OK;
 }
 

@@ -130,6 +130,21 @@ struct CtxView {
     uint64_t resident_rows;
 };
 CtxView ctx_view(amc_ctx* c);
+// What the last amc_verify_pairs / amc_match_verify_pairs call left in device memory, in the caller's pair order (the
+// exchange step's verification half reads it there): the packed amc_tvg records, the masks at the input's CSR offsets
+// `moff`, the pairs' TvgPair records (match_off / M index `matches`).  npairs == 0: nothing resident (no such call yet,
+// or a later match / verification call / trim has reused the buffers).
+struct TvgPair;
+struct VerifyResident {
+    size_t npairs = 0;
+    uint64_t total = 0;
+    const amc_tvg* tvg = nullptr;
+    const uint8_t* mask = nullptr;
+    const uint64_t* moff = nullptr;
+    const TvgPair* tp = nullptr;
+    const uint32_t* matches = nullptr;
+};
+VerifyResident verify_resident(amc_ctx* c);
 
 // ----- launchers (defined in the .hip files) ---------------------------------------------
 // Every launcher returns the status of what it enqueued: a failed memset of a queue head or counter in front of a

@@ -52,7 +52,11 @@ __global__ __launch_bounds__(256) void prep_kernel(const uint8_t* __restrict__ r
 
 // The test hook of memset_async / memcpy_async (amc_internal.h): true exactly once, on the k-th call made while the
 // variable holds the positive integer k.
+// The hooks exist only in a process that had AMC_TEST_HOOKS in its environment when the library made its first such
+// call (read once): a production process pays one cached flag per memset / copy, not a getenv.
 static bool fault_due(const char* name, std::atomic<long>& seen, std::atomic<long>& armed) {
+    static const bool hooks = std::getenv("AMC_TEST_HOOKS") != nullptr;
+    if (!hooks) return false;
     const char* e = std::getenv(name);
     const long k = e ? std::atol(e) : 0;
     if (k <= 0) {
@@ -94,7 +98,12 @@ hipError_t launch_prep(const uint8_t* raw, uint8_t* prep, int32_t* rs128, uint32
 // (float)d * 2^-18 is exact for d < 2^24, so indexing by min(d, 262144) reproduces COLMAP's
 // float expression bit-for-bit without depending on the device's acosf.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void finalize_kernel(
+// Pass 1 writes accept words for rows up to round_up(n1, 256) (the block size): that stays inside the pair's own region of
+// the accept mask because a pair's rows are padded to kRowPad - a multiple of it.  Change either and a workgroup would
+// zero its neighbour pair's accept bits while that pair's workgroup reads them.
+constexpr int kFinalizeThreads = 256;
+static_assert(kRowPad % kFinalizeThreads == 0, "finalize_kernel's pass 1 rounds a pair's rows up to its block size");
+__global__ __launch_bounds__(kFinalizeThreads) void finalize_kernel(
     const ImageDev* __restrict__ imgs, const PairDev* __restrict__ pairs,
     const Top2* __restrict__ rowbuf, const Top2* __restrict__ colbuf,
     uint32_t* accmask, const float* __restrict__ lut, FinalizeParams fp,
@@ -928,7 +937,7 @@ hipError_t launch_finalize(const ImageDev* imgs, const PairDev* pairs, uint32_t 
                            const float* acos_lut, FinalizeParams fp, uint32_t* cursor, uint32_t capacity,
                            uint32_t* pair_off, uint32_t* pair_cnt, uint32_t* matches, hipStream_t s) {
     if (npairs == 0) return hipSuccess;
-    hipLaunchKernelGGL(finalize_kernel, dim3(npairs), dim3(256), 0, s, imgs, pairs, rowbuf,
+    hipLaunchKernelGGL(finalize_kernel, dim3(npairs), dim3(kFinalizeThreads), 0, s, imgs, pairs, rowbuf,
                        colbuf, accmask, acos_lut, fp, cursor, capacity, pair_off, pair_cnt, matches);
     return hipGetLastError();
 }

@@ -190,11 +190,18 @@ def all_gather_appended_tables(offsets: np.ndarray, matches: np.ndarray, device=
     tiny all-gather (the per-rank pair counts) gives every rank its base position; returns what
     all_gather_match_tables returns plus this rank's base."""
     global _last_gather_path, _last_gather_stats
-    if comm is not None:   # the C ABI appends the lists itself (pair_index = NULL)
+    if comm is not None:
+        # The C ABI appends the lists itself (pair_index = NULL).  This rank's base = the pairs of the ranks before it:
+        # one 8-byte record per rank through amc_allgather_pair_records (the tiny count all-gather of the torch path).
+        # as_numpy=False: the table stays in the library's device memory (last_gather_stats()["device_ptr"]) and the
+        # second value is None - there is no torch tensor to return on this path.
+        n = len(offsets) - 1
+        counts, _ = comm.allgather_pair_records(np.array([comm.rank], dtype=np.uint64), np.array([n], dtype=np.uint64))
+        base = int(counts[:comm.rank].sum())
         g_off, g_m, st = comm.allgather_match_tables(None, offsets, None if device_matches is not None else matches,
                                                      download=as_numpy)
         _last_gather_path, _last_gather_stats = "c-abi", st
-        return g_off, g_m, None
+        return g_off, g_m, base
     import torch
     import torch.distributed as dist
 
@@ -245,12 +252,45 @@ def all_gather_pair_records(pair_index: np.ndarray, records: np.ndarray, total_p
 
 
 def all_gather_verification(pair_index: np.ndarray, tvg: np.ndarray, match_offsets: np.ndarray, matches: np.ndarray,
-                            inlier_mask: np.ndarray, total_pairs: int, device=None, group=None):
+                            inlier_mask: np.ndarray, total_pairs: int, device=None, group=None, comm=None,
+                            resident: bool = False, download_rank=None):
     """The exchange step of a sharded match + verify run: every rank passes the two-view geometries of its pairs (the
     structured array `Context.verify_pairs` returns), their matches (CSR) and inlier mask; every rank gets back, in the
     global pair order, (tvg records, match offsets, matches, inlier-match offsets, inlier matches) - what rank 0 needs
-    to write COLMAP's `matches` and `two_view_geometries` tables."""
+    to write COLMAP's `matches` and `two_view_geometries` tables.
+
+    comm: the library's communicator (make_comm): all three exchanges run behind the C ABI - amc_allgather_pair_records
+    for the records, amc_allgather_match_tables for the matches, amc_allgather_inlier_tables for the inlier lists.
+    resident=True (the ranks ran Context.match_verify_pairs and nothing since): records, match rows and inlier rows are
+    all taken where the kernels left them in device memory (the inlier lists compacted there from the masks), `tvg` /
+    `matches` / `inlier_mask` are not read; otherwise they travel from the host arrays.  download_rank=r: only rank r
+    copies the results to the host, the others get Nones for the row arrays."""
+    global _last_gather_path, _last_gather_stats
     off = np.asarray(match_offsets, dtype=np.int64)
+    if comm is not None:
+        want = download_rank is None or comm.rank == download_rank
+        idx = np.asarray(pair_index, dtype=np.uint64)
+        if resident:
+            g_tvg, st_r = comm.allgather_pair_records(idx, None, download=want)
+            g_off, g_m, st_m = comm.allgather_match_tables(idx, off, None, download=want)
+            g_ioff, g_im, st_i = comm.allgather_inlier_tables(idx, download=want)
+        else:
+            m = np.ascontiguousarray(matches, dtype=np.uint32).reshape(-1, 2)
+            mask = np.asarray(inlier_mask).astype(np.uint8)
+            keep = np.flatnonzero(mask)
+            csum = np.zeros(len(mask) + 1, dtype=np.int64)
+            csum[1:] = np.cumsum(mask != 0)
+            # per pair by (mask byte, position): ExtractInlierMatches' order, the per-geometry lists of a MULTIPLE
+            # geometry one after the other (all bytes are 1 otherwise and this is the position order)
+            pair_of = np.repeat(np.arange(len(off) - 1), np.diff(off))[keep]
+            inl = m[keep[np.lexsort((keep, mask[keep], pair_of))]]
+            g_tvg, st_r = comm.allgather_pair_records(idx, tvg, download=want)
+            g_off, g_m, st_m = comm.allgather_match_tables(idx, off, m, download=want)
+            g_ioff, g_im, st_i = comm.allgather_match_tables(idx, csum[off], inl, download=want)
+        _last_gather_path = "c-abi"
+        _last_gather_stats = dict(st_m, records=st_r, inliers=st_i,
+                                  total_ms=st_r["total_ms"] + st_m["total_ms"] + st_i["total_ms"])
+        return g_tvg, g_off, g_m, g_ioff, g_im
     m = np.ascontiguousarray(matches, dtype=np.uint32).reshape(-1, 2)
     mask = np.asarray(inlier_mask).astype(bool)
     csum = np.zeros(len(mask) + 1, dtype=np.int64)
@@ -260,3 +300,28 @@ def all_gather_verification(pair_index: np.ndarray, tvg: np.ndarray, match_offse
     g_off, g_m = all_gather_match_tables(pair_index, off, m, device=device, group=group)
     g_ioff, g_im = all_gather_match_tables(pair_index, inl_off, m[mask], device=device, group=group)
     return g_tvg, g_off, g_m, g_ioff, g_im
+
+
+def shard_pairs_by_cost(slot1: np.ndarray, slot2: np.ndarray, cost: np.ndarray, rank: int, world: int):
+    """shard_pairs with an explicit per-pair cost instead of n1 * n2: a sharded match + VERIFY run is cut where the
+    cumulative cost is equal - e.g. cost = n1 * n2 * c_scan + matches * c_verify, with the match counts of a previous
+    pass (or a model of them) - because verification time follows the matches, not the image sizes (data-dependent
+    trial counts on a few overlapping pairs, nothing on the many that do not overlap).  Same ordering (image 2, then
+    image 1) and the same contiguous slices as shard_pairs; returns (slot1, slot2, index)."""
+    s1 = np.asarray(slot1, dtype=np.uint32)
+    s2 = np.asarray(slot2, dtype=np.uint32)
+    order = np.lexsort((s1, s2))
+    if len(order) == 0:
+        return s1[order], s2[order], order
+    c = np.asarray(cost, dtype=np.float64)[order]
+    if not np.all(c >= 0):
+        raise ValueError("costs must be >= 0")
+    work = np.cumsum(c)
+    total = work[-1]
+    if total <= 0:
+        return shard_pairs(s1, s2, rank, world)
+    mid = work - 0.5 * c
+    owner = np.minimum((mid * world / total).astype(np.int64), world - 1)
+    lo, hi = np.searchsorted(owner, [rank, rank + 1])
+    mine = order[lo:hi]
+    return s1[mine], s2[mine], mine

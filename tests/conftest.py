@@ -5,6 +5,9 @@ from pathlib import Path
 import pytest
 
 ROOT = Path(__file__).resolve().parent.parent
+# libamc.so's fault-injection hooks (AMC_FAIL_NEXT_MEMSET / _MEMCPY, csrc/match_common.hip) exist only in a process that
+# had this set when the library made its first checked memset: the test processes do, production does not
+os.environ.setdefault("AMC_TEST_HOOKS", "1")
 sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "tests"))
 

@@ -39,16 +39,24 @@ struct World {
     int arrived = 0;
     uint64_t generation = 0;
     std::vector<Post> posts;
-    void barrier() {  // all n ranks
+    bool aborted = false;  // ncclCommAbort by any rank: every pending and later rendezvous fails on every rank
+    bool barrier() {  // all n ranks; false = the world was aborted
         std::unique_lock<std::mutex> lock(mu);
+        if (aborted) return false;
         const uint64_t g = generation;
         if (++arrived == n) {
             arrived = 0;
             ++generation;
             cv.notify_all();
         } else {
-            cv.wait(lock, [&] { return generation != g; });
+            cv.wait(lock, [&] { return generation != g || aborted; });
         }
+        return !aborted;
+    }
+    void abort() {
+        std::unique_lock<std::mutex> lock(mu);
+        aborted = true;
+        cv.notify_all();
     }
 };
 
@@ -91,7 +99,7 @@ ncclResult_t run_group(std::vector<GroupState::Op>& ops) {
     mine.sends.clear();
     for (const auto& op : ops)
         if (op.is_send) mine.sends.push_back(Post::P2p{op.peer, op.ptr, op.bytes});
-    w->barrier();  // every rank's sends are posted
+    if (!w->barrier()) return 6;  // every rank's sends are posted (6: the world was aborted)
     ncclResult_t rc = 0;
     std::vector<size_t> next_from(w->n, 0);  // k-th recv from a peer matches that peer's k-th send to this rank
     for (const auto& op : ops) {
@@ -109,9 +117,14 @@ ncclResult_t run_group(std::vector<GroupState::Op>& ops) {
             rc = 2;  // a send / recv pair that does not match: a protocol bug in the caller
             continue;
         }
-        if (op.bytes && hipMemcpy(op.ptr, match->ptr, op.bytes, hipMemcpyDeviceToDevice) != hipSuccess) rc = 1;
+        // on the receiver's own stream, like RCCL's recv, and drained before the rendezvous below: a device-to-device
+        // hipMemcpy on the null stream may return before the copy is done, and the caller's stream (non-blocking) would
+        // then read the buffer ahead of it (seen once as a stale record on a two-rank run)
+        if (op.bytes && hipMemcpyAsync(op.ptr, match->ptr, op.bytes, hipMemcpyDeviceToDevice, op.stream) != hipSuccess) rc = 1;
     }
-    w->barrier();  // nobody reuses a send buffer before its readers are done
+    for (const auto& op : ops)
+        if (!op.is_send && hipStreamSynchronize(op.stream) != hipSuccess) rc = 1;
+    if (!w->barrier()) return 6;  // nobody reuses a send buffer before its readers are done
     return rc;
 }
 
@@ -145,6 +158,12 @@ ncclResult_t ncclCommInitRank(ncclComm_t* comm, int nranks, ncclUniqueId id, int
     return 0;
 }
 
+ncclResult_t ncclCommAbort(ncclComm_t comm) {  // the peers' pending and later calls fail instead of waiting for this rank
+    comm->world->abort();
+    delete comm;
+    return 0;
+}
+
 ncclResult_t ncclCommDestroy(ncclComm_t comm) {
     delete comm;  // (worlds are leaked: a test process)
     return 0;
@@ -156,14 +175,15 @@ ncclResult_t ncclAllGather(const void* send, void* recv, size_t count, ncclDataT
     const size_t bytes = count * dtype_size(dt);
     if (hipStreamSynchronize(s) != hipSuccess) return 1;
     w->posts[c->rank].send = send;
-    w->barrier();
+    if (!w->barrier()) return 6;
     ncclResult_t rc = 0;
     for (int r = 0; r < w->n; ++r) {
         void* dst = static_cast<char*>(recv) + (size_t)r * bytes;
         if (dst == w->posts[r].send) continue;  // in place
-        if (bytes && hipMemcpy(dst, w->posts[r].send, bytes, hipMemcpyDeviceToDevice) != hipSuccess) rc = 1;
+        if (bytes && hipMemcpyAsync(dst, w->posts[r].send, bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) rc = 1;
     }
-    w->barrier();
+    if (hipStreamSynchronize(s) != hipSuccess) rc = 1;  // (see run_group: the copies are done before anybody moves on)
+    if (!w->barrier()) return 6;
     return rc;
 }
 
@@ -205,6 +225,7 @@ const char* ncclGetErrorString(ncclResult_t e) {
         case 0: return "no error";
         case 1: return "fake rccl: HIP failure";
         case 2: return "fake rccl: a send and its recv do not match";
+        case 6: return "fake rccl: the communicator was aborted (ncclCommAbort on some rank)";
         default: return "fake rccl: invalid usage";
     }
 }

@@ -144,3 +144,19 @@ def test_bench_refuses_gloo_for_a_measurement():
     r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "1", "--backend", "gloo"], capture_output=True,
                        text=True, timeout=120, cwd=str(ROOT))
     assert r.returncode != 0 and "cpu-dry-run" in (r.stdout + r.stderr)
+
+
+def test_eight_rank_entry_dry_run():
+    """`python bench.py --gpus 8` as the driver will launch it on the 8-GPU node, rehearsed without a GPU: eight ranks,
+    the weak-scaled headline (500 * sqrt(8) images' worth of pairs at the reduced size) and the configs[3] strong-scaling
+    leg, every pair matched exactly once over the eight ranks, one JSON line from rank 0."""
+    d = _run_bench("--gpus", "8", "--cpu-dry-run", "--images", "6", "--feats", "32", "--steps", "1", "--warmup", "0",
+                   timeout=900)
+    assert d["dry_run"] is True and d["n_gpus"] == 8 and d["scaling"] == "weak" and d["value"] is None
+    n_img = d["config"]["images"] if "images" in d["config"] else None
+    assert d["config"]["pairs_total"] >= 8 and 0 <= d["config"]["pairs_per_rank"] <= d["config"]["pairs_total"]
+    l3 = d["config3"]
+    assert l3["n_gpus"] == 8 and l3["scaling"] == "strong" and len(l3["per_rank_kernel_ms"]) == 8
+    c = l3["line"]["config"] if "line" in l3 else l3["config"]
+    assert c["pairs_total"] == 15 and c["distances_per_step_all_ranks"] == 15 * 32 * 32
+    assert len(c["kernel_ms_per_step_by_rank"]) == 8

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for name in decl:
         assert hasattr(lib, name), f"libamc.so does not export {name}"
     assert set(_capi.EXPORTED_SYMBOLS) <= set(decl)
-    assert lib.amc_abi_version() == 3
+    assert lib.amc_abi_version() == 4
 
 
 def test_no_gpu_means_loud_failure_not_fallback():
@@ -37,10 +37,34 @@ def test_no_gpu_means_loud_failure_not_fallback():
         _capi.Context(0)
 
 
+def test_a_missing_rccl_library_is_an_error_code_not_a_crash():
+    """amc_comm_* resolve RCCL with dlopen at the first call.  A library that cannot be loaded (AMC_RCCL_LIBRARY names a
+    file that is not there: an explicit choice is honoured or refused, never replaced silently) must come back as
+    AMC_E_HIP with the loader's message - round 5's code read dlerror() twice and built a std::string from the NULL the
+    second call returns.  Own process: a process resolves RCCL once."""
+    import os
+    import subprocess
+    import sys
+    code = ("from pycolmap_amd import _capi\n"
+            "try:\n    _capi.comm_unique_id()\n"
+            "except _capi.AmcError as e:\n"
+            "    assert e.code == _capi.AMC_E_HIP, e\n"
+            "    assert 'AMC_RCCL_LIBRARY=/nonexistent/librccl.so.1' in str(e) and 'cannot open shared object file' in str(e), e\n"
+            "    print('refused')\n"
+            "try:\n    _capi.comm_unique_id()\n"          # the failure is not cached as success
+            "except _capi.AmcError as e:\n    print('refused again')\n")
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True,
+                       env=dict(os.environ, AMC_RCCL_LIBRARY="/nonexistent/librccl.so.1", PYTHONPATH=str(ROOT)))
+    assert r.returncode == 0 and r.stdout.split() == ["refused", "refused", "again"], (r.returncode, r.stdout, r.stderr[-2000:])
+
+
 def test_struct_layout_matches_header():
     # amc_match_opts: 2 doubles + 2 int32 = 24 bytes; amc_match_result ends with a pointer
     assert ctypes.sizeof(_capi.MatchOpts) == 24
     assert ctypes.sizeof(_capi.MatchResult) == 8 * 3 + 8 * 4 + 8 * 3 + 8 + 8
+    # amc_gathered_records: 2 size_t, 2 pointers, 2 uint64, 2 int32, a double, a pointer
+    assert ctypes.sizeof(_capi.GatheredRecords) == 8 * 2 + 8 * 2 + 8 * 2 + 4 * 2 + 8 + 8
+    assert ctypes.sizeof(_capi.Tvg) == _capi.TVG_DTYPE.itemsize == 280 and _capi.TVG_DTYPE.itemsize % 8 == 0
 
 
 def test_submodules_import_on_an_unbuilt_tree(tmp_path):

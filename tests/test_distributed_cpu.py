@@ -234,3 +234,107 @@ def test_config4_exchange_dry_run(tmp_path, world):
         np.testing.assert_array_equal(x["g_m"], want_m)
         np.testing.assert_array_equal(x["a_off"], lw_off)
         np.testing.assert_array_equal(x["a_m"], lw_m)
+
+
+# ---- configs[2] sharded: shards cut by a matches-weighted cost, world 8 ------------------------------------------
+def test_shard_pairs_by_cost_balances_verification_work():
+    """A sharded match + VERIFY run: verification time follows the matches (a few overlapping pairs carry all of it), not
+    n1 * n2.  Cuts at equal cumulative cost keep every rank's cost near the mean where equal-n1*n2 cuts leave one rank
+    with most of the verification; the shards stay contiguous in the (image 2, image 1) order and partition the list."""
+    from pycolmap_amd import distributed as D
+    from pycolmap_amd import synth
+    rng = np.random.default_rng(21)
+    n = 64
+    s1, s2 = synth.exhaustive_pairs(n)
+    rows = np.full(n, 4096)
+    matches = np.zeros(len(s1))
+    near = np.abs(s1.astype(np.int64) - s2.astype(np.int64)) <= 2          # an orbit: only neighbours overlap ...
+    matches[near] = rng.integers(200, 900, size=int(near.sum()))
+    matches[(s2 > 48) & near] *= 6                                          # ... and one stretch of it much more
+    scan, verify = 4096.0 * 4096.0 * 8.5e-14, matches * 4.0e-6              # seconds per pair: scan rate, per-match verify cost
+    cost = scan + verify
+    for world in (2, 4, 8):
+        parts = [D.shard_pairs_by_cost(s1, s2, cost, r, world) for r in range(world)]
+        idx = np.concatenate([p[2] for p in parts])
+        assert sorted(idx.tolist()) == list(range(len(s1)))
+        per_rank = np.array([cost[p[2]].sum() for p in parts])
+        assert per_rank.max() <= 1.15 * per_rank.mean(), (world, per_rank)   # (one heavy pair is a third of a rank's share)
+        by_rows = np.array([cost[D.shard_pairs(s1, s2, r, world, rows=rows)[2]].sum() for r in range(world)])
+        assert per_rank.max() <= by_rows.max() + 1e-12
+        if world == 8:
+            assert by_rows.max() > 1.3 * by_rows.mean()                     # what the n1 * n2 cut would have cost
+        for a, b, _ in parts:
+            assert np.all(np.diff(b.astype(np.int64)) >= 0)
+    assert D.shard_pairs_by_cost(s1[:0], s2[:0], cost[:0], 0, 2)[0].size == 0
+    with pytest.raises(ValueError):
+        D.shard_pairs_by_cost(s1, s2, -cost, 0, 2)
+    # all-zero costs fall back to equal counts
+    assert sum(len(D.shard_pairs_by_cost(s1, s2, np.zeros(len(s1)), r, 3)[2]) for r in range(3)) == len(s1)
+
+
+def _config2_worker(rank, world, port, out_dir):
+    """BASELINE configs[2] sharded, as a dry run: every rank matches + verifies its shard with the CPU oracles; the shards
+    are cut by cost (matches-weighted, from a cheap first pass: here the true counts), and the exchange step hands every
+    rank the whole result."""
+    sys.path.insert(0, str(ROOT))
+    sys.path.insert(0, str(ROOT / "tests"))
+    import torch.distributed as dist
+
+    import oracle_lib as o
+    from pycolmap_amd import distributed as D
+    from pycolmap_amd import synth
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    images = synth.multiview_scene(np.random.default_rng(17), num_images=7, n_feats=160, num_landmarks=260)
+    s1, s2 = synth.exhaustive_pairs(len(images))
+    descs = [im["descriptors"] for im in images]
+    counts = np.load(Path(out_dir) / "counts.npy")
+    a, b, mine = D.shard_pairs_by_cost(s1, s2, 160.0 * 160.0 * 1e-3 + counts, rank, world)
+    off, m = o.match_pairs(descs, a, b, threads=1) if len(a) else (np.zeros(1, np.uint64), np.zeros((0, 2), np.uint32))
+    cam = o.make_camera("PINHOLE", images[0]["width"], images[0]["height"], images[0]["params"], prior=True)
+    tvg = np.zeros(len(a), dtype=TVG_DT)
+    mask = np.zeros(len(m), dtype=np.uint8)
+    for k in range(len(a)):
+        mm = m[int(off[k]):int(off[k + 1])]
+        r = o.estimate_two_view_geometry(cam, images[int(a[k])]["keypoints"][:, :2].astype(np.float64), cam,
+                                         images[int(b[k])]["keypoints"][:, :2].astype(np.float64), mm)
+        tvg[k] = (r["config"], r["num_inliers"], r["E"], r["F"], r["H"])
+        mask[int(off[k]):int(off[k + 1])] = r["inlier_mask"]
+    g = D.all_gather_verification(mine, tvg, off, m, mask, len(s1))
+    np.savez(Path(out_dir) / f"c2_{rank}.npz", tvg=g[0], off=g[1], m=g[2], ioff=g[3], im=g[4], n=len(mine))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_config2_sharded_by_cost_dry_run_world8(tmp_path):
+    """8 ranks (the node north_star names), 21 pairs of one scene, shards cut by matches-weighted cost: some ranks own
+    one pair, every rank ends with the geometries, matches and inlier matches of ALL pairs = the single-process result."""
+    import torch.multiprocessing as mp
+    sys.path.insert(0, str(ROOT / "tests"))
+    import oracle_lib as o
+    from pycolmap_amd import synth
+    images = synth.multiview_scene(np.random.default_rng(17), num_images=7, n_feats=160, num_landmarks=260)
+    s1, s2 = synth.exhaustive_pairs(len(images))
+    woff, wm = o.match_pairs([im["descriptors"] for im in images], s1, s2, threads=4)
+    counts = np.diff(woff.astype(np.int64)).astype(np.float64)
+    np.save(tmp_path / "counts.npy", counts)
+    world = 8
+    mp.spawn(_config2_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    cam = o.make_camera("PINHOLE", images[0]["width"], images[0]["height"], images[0]["params"], prior=True)
+    z = [np.load(tmp_path / f"c2_{r}.npz") for r in range(world)]
+    assert sum(int(x["n"]) for x in z) == len(s1)
+    cfgs = []
+    for p in range(len(s1)):
+        mm = wm[int(woff[p]):int(woff[p + 1])]
+        r = o.estimate_two_view_geometry(cam, images[int(s1[p])]["keypoints"][:, :2].astype(np.float64), cam,
+                                         images[int(s2[p])]["keypoints"][:, :2].astype(np.float64), mm)
+        cfgs.append(r["config"])
+        for x in z:
+            assert x["tvg"]["config"][p] == r["config"] and x["tvg"]["num_inliers"][p] == r["num_inliers"]
+            assert np.array_equal(x["tvg"]["F"][p].view(np.uint64), np.asarray(r["F"]).view(np.uint64))
+            np.testing.assert_array_equal(x["im"][int(x["ioff"][p]):int(x["ioff"][p + 1])], mm[np.asarray(r["inlier_mask"], bool)])
+    assert sum(c > 1 for c in cfgs) >= 3
+    for x in z:
+        np.testing.assert_array_equal(x["off"], woff)
+        np.testing.assert_array_equal(x["m"], wm)

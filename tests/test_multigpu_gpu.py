@@ -93,7 +93,7 @@ def _fake_rccl() -> Path:
     return out
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_several_ranks_of_the_c_abi_exchange_on_one_device(world):
     """The N > 1 logic of amc_allgather_match_tables with N ranks as threads on the ONE device this box has: RCCL itself
     refuses two ranks per device, so a stand-in transport (tests/shim/fake_rccl.cc: rendezvous + device-to-device copies,
@@ -101,10 +101,28 @@ def test_several_ranks_of_the_c_abi_exchange_on_one_device(world):
     global CSR, appended lists, downloads on one rank and the poisoned size exchange are the product's
     (tests/comm_threads.py checks them against the single-context result)."""
     env = dict(os.environ, AMC_RCCL_LIBRARY=str(_fake_rccl()), PYTHONPATH=str(ROOT))
+    # world 8 = the node the exchange is written for: 5 images are 10 pairs, so at least one rank of eight is empty
     r = subprocess.run([sys.executable, "tests/comm_threads.py", str(world), "--images", "7" if world == 2 else "5"],
-                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=200)
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     assert f"comm threads ok: world {world}" in r.stdout
+
+
+@pytest.mark.parametrize("world,images,chunk", [(2, 6, None), (3, 6, "5"), (8, 5, None), (8, 7, "64")])
+def test_verification_half_of_the_exchange_on_one_device(world, images, chunk):
+    """amc_allgather_pair_records + amc_allgather_inlier_tables + amc_allgather_match_tables of a sharded match + verify
+    run (tests/comm_threads.py --verify): the geometries and the inlier lists of every rank from device memory, in the
+    global pair order, equal to the single-context call; empty ranks (8 ranks, 10 pairs); the allocation-failure
+    agreement (every rank returns AMC_E_NOMEM, the communicator survives); a record size that differs between ranks and
+    a short row array on one rank as collective errors.  chunk: AMC_COMM_CHUNK_WORDS - the pieces a transfer is cut into
+    (1 GiB in production, so that no byte count above 2^31 reaches a transport call) are exercised with small inputs."""
+    env = dict(os.environ, AMC_RCCL_LIBRARY=str(_fake_rccl()), PYTHONPATH=str(ROOT))
+    if chunk:
+        env["AMC_COMM_CHUNK_WORDS"] = chunk
+    r = subprocess.run([sys.executable, "tests/comm_threads.py", str(world), "--images", str(images), "--verify"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=400)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    assert f"comm threads verify ok: world {world}" in r.stdout
 
 
 def test_more_ranks_than_pairs_on_one_device():
