@@ -12,6 +12,7 @@
 #include <cstring>
 #include <limits>
 #include <map>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <new>
@@ -183,6 +184,37 @@ struct PinnedPool {
     }
 };
 
+// Verification runs as slices (VerifyRun below).  A slice owns its trial tables and mask buffers, and per size class its
+// pair lists, workspaces and queue heads: slice k's F/H kernel runs beside slice k + 1's essential-matrix kernel, and
+// the masks stay where they are until the call's packing step.  Grow-only, kept by the context across calls.
+struct VerifyClassSlot {
+    DevBuf<TvgPair> pairs, pairs_e;
+    DevBuf<double> ws, ws_e;
+    DevBuf<uint8_t> maskws;
+    void release() { pairs.release(); pairs_e.release(); ws.release(); ws_e.release(); maskws.release(); }
+};
+struct VerifySliceBufs {
+    DevBuf<uint32_t> tabs;
+    DevBuf<uint8_t> outmask, emask;
+    VerifyClassSlot cls[4];
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // E launches begin / end, F/H launches begin / end
+    hipEvent_t ev_e_done = nullptr, ev_aux_done = nullptr;
+    bool aux_pending = false;
+    void release() {
+        tabs.release(); outmask.release(); emask.release();
+        for (auto& k : cls) k.release();
+    }
+    ~VerifySliceBufs() {
+        release();
+        for (auto& e : ev)
+            if (e) (void)hipEventDestroy(e);
+        if (ev_e_done) (void)hipEventDestroy(ev_e_done);
+        if (ev_aux_done) (void)hipEventDestroy(ev_aux_done);
+    }
+};
+constexpr size_t kVScalarWords = 128;  // [0] bad match indices, [1] stream overruns, [2 + 8 slice + 2 class (+ 1)] queue heads
+constexpr size_t kMaxStreamWords = (size_t)1 << 28;  // 1 GiB of words: max_num_trials ~ 1.6e7 at the default ratio
+
 // key of a cached dyn_max_num_trials table
 struct TrialTabKey {
     uint32_t M;
@@ -250,21 +282,21 @@ struct amc_ctx {
                             {nullptr, nullptr, nullptr, nullptr, nullptr}};  // scan start/end, cross end, small D2H, matches
     // verification scratch
     DevBuf<TvgImage> d_timgs;
-    DevBuf<TvgPair> d_tpairs;
-    DevBuf<uint32_t> d_tmatches, d_ttabs;
-    DevBuf<TvgPair> d_tpairs_e;       // the calibrated pairs of a launch, in the essential-matrix kernel's queue order
-    DevBuf<TvgPair> d_tpairs2, d_tpairs_e2;  // the same for a class launched on aux_stream
-    DevBuf<double> d_tws2;
-    DevBuf<uint8_t> d_tmaskws2;
+    DevBuf<uint32_t> d_tmatches;
     DevBuf<TvgEState> d_estate;       // essential-matrix kernel -> F/H kernel hand-off, by pair
-    DevBuf<uint8_t> d_emask;          // ... and the E RANSAC's inlier masks (same layout as d_toutmask)
+    // the slices of a verification run (lists, workspaces, tables, masks), its streams and events
+    std::vector<std::unique_ptr<VerifySliceBufs>> vslices;
+    hipStream_t vstream[2] = {nullptr, nullptr};
+    hipEvent_t vev_setup = nullptr, vev_matches = nullptr;
+    hipEvent_t kev[2] = {nullptr, nullptr};  // match batch k's rows are in place in d_keep (amc_match_verify_pairs)
+    uint32_t* d_vscalars = nullptr;   // kVScalarWords
+    std::vector<double> wm_cut_cache; // TvgParams::wm_cut for (wm_cut_conf, wm_cut_mult)
+    double wm_cut_conf = 0.0, wm_cut_mult = 0.0;
     // tempered words of std::mt19937(seed): the sample stream every pair consumes (TvgParams::stream)
     DevBuf<uint32_t> d_stream;
     uint32_t stream_seed = 0;
     size_t stream_len = 0;
     DevBuf<double> d_wmcut;
-    DevBuf<double> d_tws;
-    DevBuf<uint8_t> d_tmaskws, d_toutmask;
     DevBuf<TvgOut> d_tout;
     // the call's results in the caller's layout (pack_verify_kernel): records without their counters, masks at the
     // input's CSR offsets - copied straight into the pinned buffers the result leases
@@ -365,6 +397,12 @@ int amc_ctx_create(int device_id, amc_ctx** out) {
         if (hipStreamCreateWithPriority(&c->aux_stream, hipStreamNonBlocking, lo) != hipSuccess) c->aux_stream = nullptr;
         for (auto& ev : c->aev) ev_ok &= hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess;
     }
+    for (auto& vs : c->vstream)
+        if (hipStreamCreateWithFlags(&vs, hipStreamNonBlocking) != hipSuccess) vs = nullptr;
+    if (!c->vstream[1]) c->vstream[1] = c->vstream[0];
+    ev_ok &= hipEventCreateWithFlags(&c->vev_setup, hipEventDisableTiming) == hipSuccess;
+    ev_ok &= hipEventCreateWithFlags(&c->vev_matches, hipEventDisableTiming) == hipSuccess;
+    for (auto& ev : c->kev) ev_ok &= hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess;
     for (auto& ev : c->ev) ev_ok &= hipEventCreate(&ev) == hipSuccess;
     for (auto& set : c->bev)
         for (auto& ev : set) ev_ok &= hipEventCreate(&ev) == hipSuccess;
@@ -381,6 +419,7 @@ int amc_ctx_create(int device_id, amc_ctx** out) {
             hipSuccess ||
         hipMalloc(reinterpret_cast<void**>(&c->d_scalars), 16 * sizeof(uint32_t)) !=
             hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&c->d_vscalars), kVScalarWords * sizeof(uint32_t)) != hipSuccess ||
         hipMemcpy(c->d_lut, c->h_lut.data(), kAcosLutSize * sizeof(float),
                   hipMemcpyHostToDevice) != hipSuccess ||
         c->h_scalars.ensure(16) != hipSuccess) {
@@ -429,9 +468,11 @@ void amc_ctx_destroy(amc_ctx* c) {
     }
     c->h_scalars.release();
     dlap("pinned host buffers");
-    c->d_timgs.release(); c->d_tpairs.release(); c->d_tmatches.release(); c->d_ttabs.release();
-    c->d_tpairs_e.release(); c->d_estate.release(); c->d_emask.release(); c->d_stream.release(); c->d_wmcut.release(); c->d_tws.release(); c->d_tmaskws.release(); c->d_toutmask.release();
+    c->d_timgs.release(); c->d_tmatches.release();
+    c->d_estate.release(); c->d_stream.release(); c->d_wmcut.release();
     c->d_tout.release();
+    c->vslices.clear();
+    if (c->d_vscalars) (void)hipFree(c->d_vscalars);
     c->d_tvg_packed.release(); c->d_mask_packed.release(); c->d_moff.release(); c->d_tp_all.release(); c->d_worksum.release();
     c->d_ppairs.release(); c->d_pmatches.release(); c->d_pcos.release(); c->d_pout.release();
     dlap("verify device buffers");
@@ -446,7 +487,12 @@ void amc_ctx_destroy(amc_ctx* c) {
     if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
     for (auto& ev : c->aev)
         if (ev) (void)hipEventDestroy(ev);
-    c->d_tpairs2.release(); c->d_tpairs_e2.release(); c->d_tws2.release(); c->d_tmaskws2.release();
+    if (c->vstream[1] && c->vstream[1] != c->vstream[0]) (void)hipStreamDestroy(c->vstream[1]);
+    if (c->vstream[0]) (void)hipStreamDestroy(c->vstream[0]);
+    if (c->vev_setup) (void)hipEventDestroy(c->vev_setup);
+    if (c->vev_matches) (void)hipEventDestroy(c->vev_matches);
+    for (auto& ev : c->kev)
+        if (ev) (void)hipEventDestroy(ev);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     dlap("events and streams");
     delete c;  // (the result pools' idle pinned buffers go with their last owner)
@@ -479,8 +525,11 @@ int amc_ctx_trim(amc_ctx* c) {
         c->stream_len = 0;
     }
     if (c->aux_stream) HIPCHK(hipStreamSynchronize(c->aux_stream));
-    c->d_tws.release(); c->d_tmaskws.release(); c->d_toutmask.release(); c->d_emask.release(); c->d_estate.release();
-    c->d_tws2.release(); c->d_tmaskws2.release(); c->d_tpairs2.release(); c->d_tpairs_e2.release();
+    for (auto vs : c->vstream)
+        if (vs) HIPCHK(hipStreamSynchronize(vs));
+    for (auto& sl : c->vslices)
+        if (sl) sl->release();
+    c->d_estate.release();
     c->d_tout.release(); c->d_tmatches.release(); c->d_pmatches.release(); c->d_pcos.release();
     c->d_tvg_packed.release(); c->d_mask_packed.release(); c->d_moff.release(); c->d_tp_all.release();
     c->verify_pool->trim();
@@ -625,9 +674,16 @@ static void guided_grid_setup(GuidedDev& g, const GridDev& g1, const GridDev& g2
 // kernel with the pair's float32 filter; geoms[p] must have a configuration COLMAP guides on)
 // keep_off != nullptr: the matches also stay on the device (c->d_keep) and keep_off[p] receives the position
 // (in matches) of pair p's list there.
+// batch_hook (amc_match_verify_pairs): called once per batch, in order, as soon as the batch's matches are in the
+// resident table and the NEXT batch has been enqueued - with the pairs [begin, end) of the batch, the call's CSR offsets
+// (valid up to `end`), where each pair's rows start in the resident table, and an event behind the reorder that put
+// them there (null: the batch has no matches).  Its host work runs beside the next batch's scan.
+using BatchHook = std::function<int(size_t begin, size_t end, const uint64_t* offsets, const uint64_t* keep_off, hipEvent_t ready)>;
+static void verify_streams_sync(amc_ctx* c);
+
 static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, size_t npairs,
                       const amc_match_opts* opts_in, const amc_tvg* geoms, double max_error,
-                      amc_match_result* out, std::vector<uint64_t>* keep_off = nullptr) {
+                      amc_match_result* out, std::vector<uint64_t>* keep_off = nullptr, const BatchHook* batch_hook = nullptr) {
     if (!c || !out) return fail(AMC_E_INVALID, "amc_match_pairs: NULL ctx/out");
     std::memset(out, 0, sizeof *out);
     if (npairs > 0 && (!slot1 || !slot2))
@@ -1110,6 +1166,7 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
                 if (!hc(hipStreamSynchronize(st), "sync before freeing the old resident table") ||
                     !hc(hipStreamSynchronize(c->copy_stream), "sync before freeing the old resident table"))
                     return false;
+                if (batch_hook) verify_streams_sync(c);  // (verification slices of earlier batches read the old table)
                 c->d_keep.release();
                 c->d_keep = bigger;
             }
@@ -1131,6 +1188,7 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
             if (!hc(launch_reorder_matches(c->d_pair_off.p, c->d_pair_cnt.p, c->d_csr.p, (uint32_t)b.nb, c->d_matches.p,
                                            c->d_keep.p, st), "reorder launch"))
                 return false;
+            if (batch_hook && !hc(hipEventRecord(c->kev[k], st), "event record")) return false;
             pending.dst = priv->matches.p + 2 * keep_used;
             pending.src = c->d_keep.p + 2 * keep_used;
             pending.bytes = (size_t)b.total * 2 * sizeof(uint32_t);
@@ -1139,6 +1197,16 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
             return true;
         }
         return hc(hipEventRecord(c->bev[k][4], st), "event record");
+    };
+    double t_hook = 0.0;
+    auto run_hook = [&](const Batch& b) {
+        if (!batch_hook) return true;
+        const auto th = std::chrono::steady_clock::now();
+        const int hrc = (*batch_hook)(b.begin, b.end, priv->offsets.data(), keep_off ? keep_off->data() : nullptr,
+                                      b.total ? c->kev[b.set] : nullptr);
+        t_hook += since(th);
+        if (hrc != AMC_OK && rc == AMC_OK) rc = hrc;  // (the hook has set the message)
+        return hrc == AMC_OK;
     };
     // the pending copy on the copy stream (the last batch's, or one the next launch does not take)
     auto flush_copy = [&]() {
@@ -1198,6 +1266,7 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
             if (ok && have_next) ok = enqueue(next);
             ok = ok && flush_copy();  // (not taken by a scan launch: the last batch's, a small one, dot4-only batches)
             t_enqueue += since(tp);
+            ok = ok && run_hook(cur);  // (the device is busy with `next` - or, for the last batch, with the copy)
             if (!have_next) {
                 tp = std::chrono::steady_clock::now();
                 ok = ok && scatter(cur);
@@ -1241,8 +1310,8 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
     out->_priv = priv;
     if (prof)
         std::fprintf(stderr, "[amc match profile] pairs=%zu wall=%.1f ms: prepare %.1f, enqueue %.1f, collect(wait+reorder+D2H enqueue) %.1f, "
-                     "scatter(wait) %.1f; device events %.1f ms (scan %.1f, cross %.1f)\n", npairs, since(wall0), t_prepare, t_enqueue,
-                     t_collect, t_scatter, (double)total_ms, kernel_ms, cross_ms);
+                     "scatter(wait) %.1f, batch hook %.1f; device events %.1f ms (scan %.1f, cross %.1f)\n", npairs, since(wall0), t_prepare,
+                     t_enqueue, t_collect, t_scatter, t_hook, (double)total_ms, kernel_ms, cross_ms);
     return AMC_OK;
 }
 
@@ -1619,8 +1688,8 @@ static int pose_impl(amc_ctx* c, const char* who, const uint32_t* slot1, const u
                      const uint32_t* resident_matches = nullptr, const uint64_t* resident_match_off = nullptr) {
     // resident_mask_off != nullptr (amc_verify_pairs): the matches of this call are still on the device - at
     // resident_matches, pair p's list at resident_match_off[p] (default: d_tmatches, the call's CSR offsets) - and
-    // pair p's inlier bytes at d_toutmask + resident_mask_off[p]; nothing is uploaded again and the kernel takes the
-    // rows whose byte is set.  Their indices have been checked.
+    // pair p's inlier bytes at d_mask_packed + resident_mask_off[p] (the packed masks: the call's CSR offsets); nothing
+    // is uploaded again and the kernel takes the rows whose byte is set.  Their indices have been checked.
     const bool resident = resident_mask_off != nullptr;
     if (kernel_ms) *kernel_ms = 0.0;
     if (!c) return fail(AMC_E_INVALID, "%s: NULL ctx", who);
@@ -1683,7 +1752,7 @@ static int pose_impl(amc_ctx* c, const char* who, const uint32_t* slot1, const u
     HIPCHK(hipEventRecord(c->ev[4], st));
     HIPCHK(launch_pose(c->d_timgs.p, c->d_ppairs.p, (uint32_t)npairs,
                        resident ? (resident_matches ? resident_matches : c->d_tmatches.p) : c->d_pmatches.p,
-                       resident ? c->d_toutmask.p : nullptr, c->d_pcos.p, c->d_pout.p, st));
+                       resident ? c->d_mask_packed.p : nullptr, c->d_pcos.p, c->d_pout.p, st));
     HIPCHK(hipEventRecord(c->ev[5], st));
     std::vector<PoseOut> h(npairs);
     HIPCHK(hipMemcpyAsync(h.data(), c->d_pout.p, npairs * sizeof(PoseOut), hipMemcpyDeviceToHost, st));
@@ -1716,39 +1785,111 @@ static int pose_impl(amc_ctx* c, const char* who, const uint32_t* slot1, const u
     return AMC_OK;
 }
 
+// The sample stream: std::mt19937(seed)'s output words (operator() tempers them), `need` of them, kept across calls
+// with the same seed.  Blocking (the ctx's stream is drained: the host vector goes out of scope).
+static hipError_t ensure_sample_stream(amc_ctx* c, uint32_t seed, size_t need) {
+    if (c->d_stream.p && c->stream_seed == seed && c->stream_len >= need) return hipSuccess;
+    std::vector<uint32_t> words(need);
+    std::mt19937 gen(seed);
+    for (size_t i = 0; i < need; ++i) words[i] = (uint32_t)gen();
+    hipError_t e = hipStreamSynchronize(c->stream);  // (a relaunch: nothing may still read the table that is freed below)
+    if (e != hipSuccess) return e;
+    e = c->d_stream.ensure(need);
+    if (e != hipSuccess) return e;
+    e = hipMemcpyAsync(c->d_stream.p, words.data(), need * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream);
+    if (e != hipSuccess) return e;
+    e = hipStreamSynchronize(c->stream);  // `words` goes out of scope
+    c->stream_seed = seed;
+    c->stream_len = e == hipSuccess ? need : 0;
+    return e;
+}
+// nothing of a verification run is left in flight (error paths; before buffers its kernels read are freed)
+static void verify_streams_sync(amc_ctx* c) {
+    if (c->aux_stream) (void)hipStreamSynchronize(c->aux_stream);
+    for (auto vs : c->vstream)
+        if (vs) (void)hipStreamSynchronize(vs);
+    (void)hipStreamSynchronize(c->stream);
+}
+
+// ---- verification as a run of SLICES ---------------------------------------------------------------------------------
+// A verification call used to be two kernel launches behind each other - tvg_e_kernel over every calibrated pair, then
+// tvg_fh_kernel over every pair - and amc_match_verify_pairs ran them after the last match batch.  Both are persistent
+// kernels whose tails (the last few long pairs on a few waves) leave most of the machine idle, and between them sat a
+// kernel-level barrier; the host's preparation for 10^5 pairs (pair records, trial tables, class lists) ran with the
+// device idle.  Round 6: the pairs of a call are cut into slices.  All essential-matrix launches go to one stream, all
+// F/H launches to another, slice k's F/H waits for slice k's E by event: tvg_e_kernel(slice k + 1) runs beside
+// tvg_fh_kernel(slice k), and a kernel's tail is filled by the other stream's waves.  amc_match_verify_pairs hands the
+// pairs of match batch k over as a slice as soon as batch k's matches are in the resident table: the host prepares and
+// launches it while the device scans batch k + 1, and what is left after the last batch is the last (small) batch's
+// slice.  The kernels, the per-pair arithmetic and the results are unchanged: a pair's result does not depend on its
+// slice (every pair re-seeds its generator and owns its output record).
+//
 // mode 0: EstimateTwoViewGeometry; 1 / 2 / 3: a single F / H / E LO-RANSAC per pair, reported
 // through the same record (config = success, num_inliers, the model, its trial count, the mask)
-// dev_matches != nullptr (amc_match_verify_pairs): the matches are already on this device - pair p's list starts at
-// dev_matches + 2 * dev_off[p] and has match_offsets[p + 1] - match_offsets[p] rows; `matches` is not read.
-static int verify_impl(amc_ctx* c, int mode, const uint32_t* slot1, const uint32_t* slot2, size_t npairs,
-                       const uint64_t* match_offsets, const uint32_t* matches,
-                       const amc_tvg_opts* opts_in, uint32_t seed, amc_verify_result* out,
-                       const uint32_t* dev_matches = nullptr, const uint64_t* dev_off = nullptr) {
-    if (!c || !out) return fail(AMC_E_INVALID, "amc_verify_pairs: NULL ctx/out");
-    std::memset(out, 0, sizeof *out);
-    c->vres = amc::VerifyResident{};
-    if (npairs > 0 && (!slot1 || !slot2 || !match_offsets))
-        return fail(AMC_E_INVALID, "amc_verify_pairs: NULL pair arrays");
-    // AMC_VERIFY_PROFILE=1: wall-clock of the call's host phases on stderr
-    const bool hprof = std::getenv("AMC_VERIFY_PROFILE") != nullptr;
-    auto wall = std::chrono::steady_clock::now();
-    double t_phase[6] = {0, 0, 0, 0, 0, 0};
-    auto lap = [&](int k) {
-        const auto now = std::chrono::steady_clock::now();
-        t_phase[k] += std::chrono::duration<double, std::milli>(now - wall).count();
-        wall = now;
-    };
+namespace {
+
+constexpr int kMaxVerifySlices = 12;
+
+struct VerifyClassLaunch {  // one size class of one slice, as launched (kept for the rare relaunch after a stream overrun)
+    int cls = 0;
+    bool on_aux = false;
+    uint32_t n = 0, n_e = 0, mcap = 0, waves_e = 0, waves_fh = 0;
+    int wpb = 4;
+};
+struct VerifySliceInfo {
+    size_t begin = 0, end = 0;
+    uint64_t mask_bytes = 0;
+    std::vector<VerifyClassLaunch> launches;
+};
+
+struct VerifyRun {
+    amc_ctx* c;
+    int mode;
+    const uint32_t* slot1;
+    const uint32_t* slot2;
+    size_t npairs;
     amc_tvg_opts o;
-    if (opts_in) o = *opts_in; else amc_tvg_opts_default(&o);
+    uint32_t seed;
+    TvgParams P{};
+    std::vector<TvgPair> tp;
+    std::vector<double> wm_cut;
+    std::vector<VerifySliceInfo> slices;
+    size_t submitted = 0;          // pairs [0, submitted) have been handed over
+    const uint32_t* kernel_matches = nullptr;
+    hipStream_t st_e = nullptr, st_fh = nullptr;  // all E launches / all F/H launches of the bulk classes
+    bool started = false, aux_used = false;
+    bool beside_match = false;     // the slices are submitted from the match loop (amc_match_verify_pairs)
+    uint32_t launches = 0;
+    uint32_t maxM = 0;
+    int cus = 256;
+    double t_tables = 0.0, t_lists = 0.0;
+
+    bool uses_E(size_t p) const {
+        if (mode == 3) return true;
+        if (mode != 0 || o.force_H_use) return false;
+        if (tp[p].M < (uint32_t)std::max(o.min_num_inliers, 0)) return false;
+        return c->slots[slot1[p]].cam.has_prior != 0 && c->slots[slot2[p]].cam.has_prior != 0;
+    }
+    bool trivial(uint32_t M) const { return mode == 0 && M < (uint32_t)std::max(o.min_num_inliers, 0); }
+
+    // everything that does not depend on the matches: option checks, the sample stream, the image table, the zeroed
+    // records.  Issued on the ctx's stream; the verification streams wait for it (vev_setup).
+    int begin(size_t total_hint);
+    // pairs [begin, end): offs = the call's CSR (offs[p + 1] - offs[p] matches), dev_off = where pair p's rows start in
+    // `matches_dev` (nullptr: at offs[p]); `ready` (may be null): an event after which the rows are in place
+    int submit(size_t begin, size_t end, const uint64_t* offs, const uint64_t* dev_off, const uint32_t* matches_dev,
+               const uint32_t* matches_host, hipEvent_t ready);
+    int launch_slice(size_t si, hipEvent_t ready);
+    int join();
+};
+
+int VerifyRun::begin(size_t) {
     if (o.compute_relative_pose && mode != 0)
         return fail(AMC_E_INVALID, "amc_verify_pairs: internal: compute_relative_pose outside mode 0");
     if (o.multiple_models)
         return fail(AMC_E_INVALID, "amc_verify_pairs: internal: multiple_models reaches verify_impl");
     if (o.ransac.max_num_trials < 0 || o.ransac.min_num_trials < 0 || o.ransac.max_num_trials > (1 << 30))
         return fail(AMC_E_INVALID, "amc_verify_pairs: bad trial limits");
-    const uint64_t total = npairs ? match_offsets[npairs] : 0;
-    if (total > 0 && !matches && !dev_matches) return fail(AMC_E_INVALID, "amc_verify_pairs: NULL matches");
-    uint32_t maxM = 0;
     std::vector<uint8_t> need_lift(c->slots.size(), 0);
     for (size_t p = 0; p < npairs; ++p) {
         if (slot1[p] >= c->slots.size() || slot2[p] >= c->slots.size())
@@ -1758,25 +1899,9 @@ static int verify_impl(amc_ctx* c, int mode, const uint32_t* slot1, const uint32
         const bool need_cam = mode == 0 || mode == 3;
         if (!a.has_kp || !b.has_kp || (need_cam && (!a.has_cam || !b.has_cam)))
             return fail(AMC_E_STATE, "amc_verify_pairs: pair %zu: keypoints/camera not uploaded", p);
-        if (match_offsets[p + 1] < match_offsets[p])
-            return fail(AMC_E_INVALID, "amc_verify_pairs: match_offsets not monotone at %zu", p);
-        const uint64_t M = match_offsets[p + 1] - match_offsets[p];
-        if (M > 65535) return fail(AMC_E_INVALID, "amc_verify_pairs: pair %zu has %llu matches (> 65535)", p,
-                                   (unsigned long long)M);
-        maxM = std::max<uint32_t>(maxM, (uint32_t)M);
-        // Match indices are checked by the kernel where it gathers the points (bad_index_count below); only
-        // the pairs it returns from before that - fewer matches than min_num_inliers - are checked here.
-        if (mode == 0 && !dev_matches && M < (uint64_t)std::max(o.min_num_inliers, 0)) {
-            const uint32_t* mm = matches + 2 * match_offsets[p];
-            for (uint64_t k = 0; k < M; ++k)
-                if (mm[2 * k] >= a.kp_rows || mm[2 * k + 1] >= b.kp_rows)
-                    return fail(AMC_E_INVALID, "amc_verify_pairs: pair %zu match %llu indexes past the keypoints",
-                                p, (unsigned long long)k);
-        }
-        const bool uses_E = mode == 0 ? (!o.force_H_use && a.cam.has_prior && b.cam.has_prior) : mode == 3;
-        if (uses_E) need_lift[slot1[p]] = need_lift[slot2[p]] = 1;
+        const bool e = mode == 0 ? (!o.force_H_use && a.cam.has_prior && b.cam.has_prior) : mode == 3;
+        if (e) need_lift[slot1[p]] = need_lift[slot2[p]] = 1;
     }
-    TvgParams P{};
     P.min_num_inliers = o.min_num_inliers;
     P.detect_watermark = o.detect_watermark;
     P.force_H_use = o.force_H_use;
@@ -1798,10 +1923,9 @@ static int verify_impl(amc_ctx* c, int mode, const uint32_t* slot1, const uint32
         const char* e3 = std::getenv("AMC_TVG_NO_S32");
         P.no_fast32 = (e3 && e3[0] == '1') ? 1 : 0;
         P.mode = mode;
-        P.bad_index_count = c->d_scalars + 2;
+        P.bad_index_count = c->d_vscalars;
     }
     // inlier-ratio cut-offs of the watermark RANSAC's dynamic trial count (TvgParams::wm_cut)
-    std::vector<double> wm_cut;
     if (mode == 0 && o.detect_watermark) {
         auto dyn_of_ratio = [&](double r) -> size_t {  // ComputeNumTrials with inlier_ratio = r, kMinNumSamples = 1
             const double nom = 1 - o.ransac.confidence;
@@ -1812,57 +1936,37 @@ static int verify_impl(amc_ctx* c, int mode, const uint32_t* slot1, const uint32
             return static_cast<size_t>(std::ceil(std::log(nom) / std::log(denom) * o.ransac.dyn_num_trials_multiplier));
         };
         const int nT = std::max(P.max_trials[3], 0);
-        wm_cut.assign((size_t)nT + 1, 2.0);
-        for (int T = 0; T <= nT; ++T) {
-            if (dyn_of_ratio(1.0) > (size_t)T) continue;  // not even r = 1 gets there: stays 2.0
-            // doubles in [0, 1] order like their bit patterns: bisect the smallest r with dyn(r) <= T
-            uint64_t lo = 0, hi = 0x3FF0000000000000ull;  // dyn(lo) > T (or lo is the answer at 0), dyn(hi) <= T
-            if (dyn_of_ratio(0.0) <= (size_t)T) { wm_cut[T] = 0.0; continue; }
-            while (hi - lo > 1) {
-                const uint64_t mid = lo + (hi - lo) / 2;
-                double r;
-                std::memcpy(&r, &mid, sizeof r);
-                if (dyn_of_ratio(r) <= (size_t)T) hi = mid; else lo = mid;
+        // (the cut-offs depend on (confidence, multiplier, max_trials) only: kept across calls)
+        if (c->wm_cut_cache.size() == (size_t)nT + 1 && c->wm_cut_conf == o.ransac.confidence &&
+            c->wm_cut_mult == o.ransac.dyn_num_trials_multiplier) {
+            wm_cut = c->wm_cut_cache;
+        } else {
+            wm_cut.assign((size_t)nT + 1, 2.0);
+            for (int T = 0; T <= nT; ++T) {
+                if (dyn_of_ratio(1.0) > (size_t)T) continue;  // not even r = 1 gets there: stays 2.0
+                // doubles in [0, 1] order like their bit patterns: bisect the smallest r with dyn(r) <= T
+                uint64_t lo = 0, hi = 0x3FF0000000000000ull;  // dyn(lo) > T (or lo is the answer at 0), dyn(hi) <= T
+                if (dyn_of_ratio(0.0) <= (size_t)T) { wm_cut[T] = 0.0; continue; }
+                while (hi - lo > 1) {
+                    const uint64_t mid = lo + (hi - lo) / 2;
+                    double r;
+                    std::memcpy(&r, &mid, sizeof r);
+                    if (dyn_of_ratio(r) <= (size_t)T) hi = mid; else lo = mid;
+                }
+                std::memcpy(&wm_cut[T], &hi, sizeof(double));
             }
-            std::memcpy(&wm_cut[T], &hi, sizeof(double));
+            if (o.ransac.confidence == o.ransac.confidence && o.ransac.dyn_num_trials_multiplier == o.ransac.dyn_num_trials_multiplier) {
+                c->wm_cut_cache = wm_cut;
+                c->wm_cut_conf = o.ransac.confidence;
+                c->wm_cut_mult = o.ransac.dyn_num_trials_multiplier;
+            }
         }
     }
-
     HIPCHK(hipSetDevice(c->device));
     hipStream_t st = c->stream;
-    lap(0);
-    VerifyPriv* priv = new (std::nothrow) VerifyPriv();
-    if (!priv) return fail(AMC_E_NOMEM, "amc_verify_pairs: out of host memory");
-    priv->pool = c->verify_pool;
-    priv->tvg_pin = c->verify_pool->acquire((std::max<size_t>(npairs, 1) * sizeof(amc_tvg) + 3) / 4);
-    priv->mask_pin = c->verify_pool->acquire((size_t)(std::max<uint64_t>(total, 1) + 3) / 4);
-    if (priv->tvg_pin.ensure((std::max<size_t>(npairs, 1) * sizeof(amc_tvg) + 3) / 4) != hipSuccess ||
-        priv->mask_pin.ensure((size_t)(std::max<uint64_t>(total, 1) + 3) / 4) != hipSuccess) {
-        delete priv;
-        return fail(AMC_E_NOMEM, "amc_verify_pairs: out of pinned host memory");
-    }
-    out->npairs = npairs;
-    out->_priv = priv;
-    out->tvg = reinterpret_cast<amc_tvg*>(priv->tvg_pin.p);
-    out->inlier_mask = reinterpret_cast<uint8_t*>(priv->mask_pin.p);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device);
+    tp.resize(npairs);
     if (npairs == 0) return AMC_OK;
-    // every failure below (HIPCHK returns included) frees the result's storage and hands back a zeroed struct
-    // - after nothing of the call is left in flight: a size class on the aux stream still runs when an error returns from
-    // the class loop, and the next call would rewrite that class's lists and workspaces under it
-    struct Guard {
-        amc_ctx* c;
-        VerifyPriv* p;
-        amc_verify_result* o;
-        ~Guard() {
-            if (p) {
-                if (c->aux_stream) (void)hipStreamSynchronize(c->aux_stream);
-                (void)hipStreamSynchronize(c->stream);
-                delete p;
-                std::memset(o, 0, sizeof *o);
-            }
-        }
-    } guard{c, priv, out};
-
     // image table (cameras with distortion parameters: CamFromImg of their keypoints first)
     for (size_t i = 0; i < need_lift.size(); ++i)
         if (need_lift[i]) {
@@ -1871,10 +1975,74 @@ static int verify_impl(amc_ctx* c, int mode, const uint32_t* slot1, const uint32
         }
     std::vector<TvgImage> timgs;
     fill_tvg_images(c, timgs);
-    // dyn_max_num_trials tables, one set per distinct match count
+    // The sample stream: std::mt19937(seed)'s output words (operator() tempers them).  Every pair re-seeds (D4), so
+    // they all read the same table; its length covers every RANSAC of a pair running to its trial cap, plus the
+    // words a chunk draws ahead and a margin for Lemire rejections.  Kept across calls with the same seed.
+    const size_t stream_need = (size_t)5 * P.max_trials[0] + (size_t)7 * P.max_trials[1] + (size_t)4 * P.max_trials[2] +
+                               (size_t)P.max_trials[3] + 4 * 64 * 7 + 4096;
+    if (stream_need > kMaxStreamWords)
+        return fail(AMC_E_INVALID, "amc_verify_pairs: ransac.max_num_trials / min_inlier_ratio allow %zu draws per pair: "
+                    "more than the sample-stream table holds (%zu)", stream_need, kMaxStreamWords);
+    HIPCHK(ensure_sample_stream(c, seed, stream_need));
+    HIPCHK(c->d_timgs.ensure(timgs.size()));
+    HIPCHK(c->d_estate.ensure(npairs));
+    HIPCHK(c->d_tout.ensure(npairs));
+    if (std::getenv("AMC_TVG_PROFILE")) HIPCHK(c->h_tout.ensure(npairs));
+    HIPCHK(hipMemcpyAsync(c->d_timgs.p, timgs.data(), timgs.size() * sizeof(TvgImage), hipMemcpyHostToDevice, st));
+    P.wm_cut = nullptr;
+    if (!wm_cut.empty()) {
+        HIPCHK(c->d_wmcut.ensure(wm_cut.size()));
+        HIPCHK(hipMemcpyAsync(c->d_wmcut.p, wm_cut.data(), wm_cut.size() * sizeof(double), hipMemcpyHostToDevice, st));
+        P.wm_cut = c->d_wmcut.p;
+    }
+    // [0] pairs with a bad match index, [1] waves that ran off the stream table, [2 ..] the launches' queue heads; the
+    // records' profile and work counters are accumulated by both kernels
+    HIPCHK(memset_async(c->d_vscalars, 0, kVScalarWords * sizeof(uint32_t), st));
+    HIPCHK(memset_async(c->d_tout.p, 0, npairs * sizeof(TvgOut), st));
+    HIPCHK(hipStreamSynchronize(st));  // (`timgs`, a pageable source, goes out of scope)
+    HIPCHK(hipEventRecord(c->vev_setup, st));
+    P.stream = c->d_stream.p;
+    P.stream_len = (uint32_t)std::min<size_t>(c->stream_len, 0xFFFFFFFFu);
+    P.stream_err = c->d_vscalars + 1;
+    started = true;
+    return AMC_OK;
+}
+
+int VerifyRun::submit(size_t begin, size_t end, const uint64_t* offs, const uint64_t* dev_off, const uint32_t* matches_dev,
+                      const uint32_t* matches_host, hipEvent_t ready) {
+    if (begin != submitted || end < begin || end > npairs) return fail(AMC_E_INVALID, "amc_verify_pairs: internal: slices out of order");
+    if (end == begin) return AMC_OK;
+    if (slices.size() >= (size_t)kMaxVerifySlices) return fail(AMC_E_INVALID, "amc_verify_pairs: internal: too many slices");
+    kernel_matches = matches_dev;
+    const auto t0 = std::chrono::steady_clock::now();
+    VerifySliceInfo sl;
+    sl.begin = begin;
+    sl.end = end;
+    const size_t si = slices.size();
+    if (c->vslices.size() <= si) c->vslices.resize(si + 1);
+    if (!c->vslices[si]) c->vslices[si].reset(new (std::nothrow) VerifySliceBufs());
+    if (!c->vslices[si]) return fail(AMC_E_NOMEM, "amc_verify_pairs: out of host memory");
+    VerifySliceBufs& B = *c->vslices[si];
+    // dyn_max_num_trials tables, one set per distinct match count of the slice
     std::vector<uint32_t> tabs;
-    std::vector<int64_t> tab_of_M((size_t)maxM + 1, -1);
-    std::vector<TvgPair> tp(npairs);
+    uint32_t slice_maxM = 0;
+    for (size_t p = begin; p < end; ++p) {
+        if (offs[p + 1] < offs[p]) return fail(AMC_E_INVALID, "amc_verify_pairs: match_offsets not monotone at %zu", p);
+        const uint64_t M = offs[p + 1] - offs[p];
+        if (M > 65535) return fail(AMC_E_INVALID, "amc_verify_pairs: pair %zu has %llu matches (> 65535)", p, (unsigned long long)M);
+        slice_maxM = std::max<uint32_t>(slice_maxM, (uint32_t)M);
+        // Match indices are checked by the kernel where it gathers the points (bad_index_count); only the pairs no
+        // kernel looks at - fewer matches than min_num_inliers - are checked here.
+        if (trivial((uint32_t)M) && matches_host) {
+            const Slot& a = c->slots[slot1[p]];
+            const Slot& b = c->slots[slot2[p]];
+            const uint32_t* mm = matches_host + 2 * offs[p];
+            for (uint64_t k = 0; k < M; ++k)
+                if (mm[2 * k] >= a.kp_rows || mm[2 * k + 1] >= b.kp_rows)
+                    return fail(AMC_E_INVALID, "amc_verify_pairs: pair %zu match %llu indexes past the keypoints", p, (unsigned long long)k);
+        }
+    }
+    maxM = std::max(maxM, slice_maxM);
     const int kmins[3] = {5, 7, 4};
     auto make_table = [&](uint32_t M) {  // ComputeNumTrials for every inlier count 0 .. M and the three minimal sample sizes
         std::vector<uint32_t> t3;
@@ -1886,18 +2054,19 @@ static int verify_impl(amc_ctx* c, int mode, const uint32_t* slot1, const uint32
             }
         return t3;
     };
-    // The tables this call needs and the cache does not hold (a pow and two logs per entry: the first call of a run
+    // The tables this slice needs and the cache does not hold (a pow and two logs per entry: the first call of a run
     // sees a few hundred new match counts, ~40 ms on one core) are computed ahead on a few threads.
     const bool tabs_cacheable = o.ransac.confidence == o.ransac.confidence &&
                                 o.ransac.dyn_num_trials_multiplier == o.ransac.dyn_num_trials_multiplier;
+    std::vector<int64_t> tab_of_M((size_t)slice_maxM + 1, -1);
+    std::vector<int32_t> fresh_of((size_t)slice_maxM + 1, -1);
     std::vector<uint32_t> fresh_M;
     std::vector<std::vector<uint32_t>> fresh_tab;
-    std::vector<int32_t> fresh_of((size_t)maxM + 1, -1);
     {
         size_t words = 0;
-        for (size_t p = 0; p < npairs; ++p) {
-            const uint32_t M = (uint32_t)(match_offsets[p + 1] - match_offsets[p]);
-            if (fresh_of[M] != -1) continue;
+        for (size_t p = begin; p < end; ++p) {
+            const uint32_t M = (uint32_t)(offs[p + 1] - offs[p]);
+            if (trivial(M) || fresh_of[M] != -1) continue;
             fresh_of[M] = -2;  // seen
             if (tabs_cacheable && c->trial_tabs.count(TrialTabKey{M, o.ransac.confidence, o.ransac.dyn_num_trials_multiplier})) continue;
             fresh_of[M] = (int32_t)fresh_M.size();
@@ -1916,19 +2085,28 @@ static int verify_impl(amc_ctx* c, int mode, const uint32_t* slot1, const uint32
         for (auto& t : th) t.join();
     }
     uint64_t mask_bytes = 0;
-    for (size_t p = 0; p < npairs; ++p) {
-        const uint32_t M = (uint32_t)(match_offsets[p + 1] - match_offsets[p]);
+    std::vector<size_t> cls[4];
+    for (size_t p = begin; p < end; ++p) {
+        const uint32_t M = (uint32_t)(offs[p + 1] - offs[p]);
+        TvgPair& q = tp[p];
+        q.slot1 = slot1[p];
+        q.slot2 = slot2[p];
+        q.match_off = dev_off ? dev_off[p] : offs[p];
+        q.M = M;
+        q.orig = (uint32_t)p;
+        q.mask_off = 0;
+        q.tab_off[0] = q.tab_off[1] = q.tab_off[2] = 0;
+        if (trivial(M)) continue;  // DEGENERATE without a kernel: pack_verify_kernel writes the record
         if (tab_of_M[M] < 0) {
             tab_of_M[M] = (int64_t)tabs.size();
             // the table of one match count depends on (M, confidence, multiplier) only: kept across calls
             // (a pow and two logs per entry; a pipeline sees the same few hundred counts again and again)
             const TrialTabKey key{M, o.ransac.confidence, o.ransac.dyn_num_trials_multiplier};
             // (NaN options would break the map's ordering: those tables are rebuilt every time)
-            const bool cacheable = key.confidence == key.confidence && key.multiplier == key.multiplier;
-            auto it = cacheable ? c->trial_tabs.find(key) : c->trial_tabs.end();
+            auto it = tabs_cacheable ? c->trial_tabs.find(key) : c->trial_tabs.end();
             if (it == c->trial_tabs.end()) {
                 std::vector<uint32_t> t3 = fresh_of[M] >= 0 ? std::move(fresh_tab[(size_t)fresh_of[M]]) : make_table(M);
-                if (!cacheable) {
+                if (!tabs_cacheable) {
                     tabs.insert(tabs.end(), t3.begin(), t3.end());
                 } else {
                     if (c->trial_tab_words + t3.size() > kTrialTabCacheWords) {  // bounded: start over
@@ -1941,230 +2119,362 @@ static int verify_impl(amc_ctx* c, int mode, const uint32_t* slot1, const uint32
             }
             if (it != c->trial_tabs.end()) tabs.insert(tabs.end(), it->second.begin(), it->second.end());
         }
-        tp[p].slot1 = slot1[p];
-        tp[p].slot2 = slot2[p];
-        tp[p].match_off = dev_matches ? dev_off[p] : match_offsets[p];
-        tp[p].mask_off = mask_bytes;
+        q.mask_off = mask_bytes;
         mask_bytes += ((uint64_t)M + 127) / 128 * 128;
-        tp[p].M = M;
-        tp[p].orig = (uint32_t)p;
-        for (int t = 0; t < 3; ++t) tp[p].tab_off[t] = (uint32_t)(tab_of_M[M] + (int64_t)t * (M + 1));
-    }
-    int cus = 256;
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device);
-
-    // Size classes.  A wave's LDS share holds, besides a few KB of fixed state, two uint16 index arrays of mcap
-    // entries (the sampler's permutation and the inlier list); everything else of a pair lives in the wave's global
-    // workspace.  Pairs up to ~1,800 matches run at both kernels' full occupancy (E 2, F/H 3 waves per SIMD), 4 waves per workgroup; larger
-    // ones in launches of their own with fewer resident waves; the largest (M <= ~38 k: covers
-    // max_num_matches = 32768) one wave per workgroup with up to the whole 160 KB; beyond that (class 3, up to the
-    // 65,535 matches the 16-bit indices name) the "big" builds of the kernels keep the two arrays in global memory.
-    std::vector<size_t> cls[4];
-    for (size_t p = 0; p < npairs; ++p) {
-        const uint32_t mc = std::max<uint32_t>(64, round_up(tp[p].M, 64));
+        for (int t = 0; t < 3; ++t) q.tab_off[t] = (uint32_t)(tab_of_M[M] + (int64_t)t * (M + 1));
+        // Size classes.  A wave's LDS share holds, besides a few KB of fixed state, two uint16 index arrays of mcap
+        // entries (the sampler's permutation and the inlier list); everything else of a pair lives in the wave's global
+        // workspace.  Pairs up to ~1,800 matches run at both kernels' full occupancy (E 2, F/H 3 waves per SIMD), 4 waves
+        // per workgroup; larger ones in launches of their own with fewer resident waves; the largest (M <= ~38 k: covers
+        // max_num_matches = 32768) one wave per workgroup with up to the whole 160 KB; beyond that (class 3, up to the
+        // 65,535 matches the 16-bit indices name) the "big" builds of the kernels keep the two arrays in global memory.
+        const uint32_t mc = std::max<uint32_t>(64, round_up(M, 64));
         const size_t lds = tvg_lds_bytes(mc, 1) + 64;
         const size_t lds_e = tvg_lds_bytes_e(mc, 1) + 64;  // (the E kernel's waves also carry the root finder's coefficients)
-        // (full occupancy of BOTH kernels)
         if (lds <= 160 * 1024 / (4 * (size_t)kTvgFhWavesPerSimd) && lds_e <= 160 * 1024 / (4 * (size_t)kTvgEWavesPerSimd))
-            cls[0].push_back(p);
+            cls[0].push_back(p);  // (full occupancy of BOTH kernels)
         else if (lds_e <= 160 * 1024 / 4) cls[1].push_back(p);  // 4-wave workgroups of either kernel fit a CU
         else if (lds_e <= 160 * 1024) cls[2].push_back(p);
         else cls[3].push_back(p);  // M <= 65535 was checked above
     }
-    // which pairs run the essential-matrix RANSAC first (tvg_e_kernel), exactly as the F/H kernel decides it
-    auto uses_E = [&](size_t p) {
-        if (mode == 3) return true;
-        if (mode != 0 || o.force_H_use) return false;
-        if (tp[p].M < (uint32_t)std::max(o.min_num_inliers, 0)) return false;
-        return c->slots[slot1[p]].cam.has_prior != 0 && c->slots[slot2[p]].cam.has_prior != 0;
-    };
-    lap(1);
-    // The sample stream: std::mt19937(seed)'s output words (operator() tempers them).  Every pair re-seeds (D4), so
-    // they all read the same table; its length covers every RANSAC of a pair running to its trial cap, plus the
-    // words a chunk draws ahead and a margin for Lemire rejections.  Kept across calls with the same seed.
-    size_t stream_need = (size_t)5 * P.max_trials[0] + (size_t)7 * P.max_trials[1] + (size_t)4 * P.max_trials[2] +
-                         (size_t)P.max_trials[3] + 4 * 64 * 7 + 4096;
-    constexpr size_t kMaxStreamWords = (size_t)1 << 28;  // 1 GiB of words: max_num_trials ~ 1.6e7 at the default ratio
-    if (stream_need > kMaxStreamWords)
-        return fail(AMC_E_INVALID, "amc_verify_pairs: ransac.max_num_trials / min_inlier_ratio allow %zu draws per pair: "
-                    "more than the sample-stream table holds (%zu)", stream_need, kMaxStreamWords);
-    auto ensure_stream = [&](size_t need) -> hipError_t {
-        if (c->d_stream.p && c->stream_seed == seed && c->stream_len >= need) return hipSuccess;
-        std::vector<uint32_t> words(need);
-        std::mt19937 gen(seed);
-        for (size_t i = 0; i < need; ++i) words[i] = (uint32_t)gen();
-        hipError_t e = c->d_stream.ensure(need);
-        if (e != hipSuccess) return e;
-        e = hipMemcpyAsync(c->d_stream.p, words.data(), need * sizeof(uint32_t), hipMemcpyHostToDevice, st);
-        if (e != hipSuccess) return e;
-        e = hipStreamSynchronize(st);  // `words` goes out of scope
-        c->stream_seed = seed;
-        c->stream_len = e == hipSuccess ? need : 0;
+    sl.mask_bytes = mask_bytes;
+    t_tables += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    const auto t1 = std::chrono::steady_clock::now();
+    HIPCHK(B.tabs.ensure(std::max<size_t>(tabs.size(), 1)));
+    HIPCHK(B.outmask.ensure(std::max<size_t>(mask_bytes, 128)));
+    HIPCHK(B.emask.ensure(std::max<size_t>(mask_bytes, 128)));
+    // (pageable sources: these copies are done when the calls return - the vectors may go out of scope - and need no
+    // stream synchronisation)
+    if (!tabs.empty()) HIPCHK(hipMemcpy(B.tabs.p, tabs.data(), tabs.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    // The first non-empty class (the bulk of a slice) runs on the E / F/H streams; the others - few pairs, each several
+    // milliseconds on one wave whatever the machine around it does - on the low-priority stream with their own lists
+    // and workspaces, so that they fill the bulk class's tails instead of adding launches of pure latency behind it.
+    int bulk = 0;
+    while (bulk < 4 && cls[bulk].empty()) ++bulk;
+    const bool serial_classes = std::getenv("AMC_TVG_SERIAL_CLASSES") != nullptr || !c->aux_stream;
+    for (int k = 3; k >= 0; --k) {  // (the aux classes first: their few waves take their slots before the bulk class fills the machine)
+        if (cls[k].empty()) continue;
+        VerifyClassLaunch L;
+        L.cls = k;
+        L.on_aux = k != bulk && !serial_classes;
+        L.wpb = k >= 2 ? 1 : 4;
+        const bool big = k == 3;  // index arrays in global memory (tvg_*_big.hip)
+        // The waves pull pairs from a queue in this order.  A pair's cost grows with its match count (every
+        // trial scores all matches), so the largest go first: what is left for the tail of the launch, when
+        // most waves have run dry, are the cheap ones.  Results are stored by pair, the order is free.
+        // (stable counting sort by match count, descending: M <= 65535)
+        std::vector<size_t> idx(cls[k].size());
+        {
+            std::vector<uint32_t> start((size_t)slice_maxM + 2, 0);
+            for (size_t p : cls[k]) ++start[slice_maxM - tp[p].M + 1];
+            for (size_t b = 1; b <= (size_t)slice_maxM + 1; ++b) start[b] += start[b - 1];
+            for (size_t p : cls[k]) idx[start[slice_maxM - tp[p].M]++] = p;
+        }
+        std::vector<TvgPair> sub(idx.size()), sub_e;
+        uint32_t cm = 0;
+        for (size_t i = 0; i < idx.size(); ++i) {
+            sub[i] = tp[idx[i]];
+            cm = std::max(cm, sub[i].M);
+            if (uses_E(idx[i])) sub_e.push_back(sub[i]);
+        }
+        L.mcap = std::max<uint32_t>(64, round_up(cm, 64));
+        auto waves_for = [&](size_t n, int waves_per_simd, size_t lds_block) {
+            const uint32_t blocks_per_cu = (uint32_t)std::max<size_t>(
+                1, std::min<size_t>(4 * (size_t)waves_per_simd / L.wpb, (160 * 1024) / std::max<size_t>(lds_block, 1)));
+            uint32_t nw = (uint32_t)std::min<size_t>(n, (size_t)cus * blocks_per_cu * L.wpb);
+            return std::max<uint32_t>(L.wpb, (nw + L.wpb - 1) / L.wpb * L.wpb);
+        };
+        const bool run_fh = mode != 3;
+        L.n = (uint32_t)idx.size();
+        L.n_e = (uint32_t)sub_e.size();
+        L.waves_e = sub_e.empty() ? 0 : waves_for(sub_e.size(), kTvgEWavesPerSimd, big ? tvg_big_lds_bytes_e(L.wpb) : tvg_lds_bytes_e(L.mcap, L.wpb));
+        L.waves_fh = run_fh ? waves_for(idx.size(), kTvgFhWavesPerSimd, big ? tvg_big_lds_bytes(L.wpb) : tvg_lds_bytes(L.mcap, L.wpb)) : 0;
+        VerifyClassSlot& S = B.cls[k];
+        HIPCHK(S.pairs.ensure(idx.size()));
+        HIPCHK(S.pairs_e.ensure(std::max<size_t>(sub_e.size(), 1)));
+        const size_t idx_ws = big ? tvg_big_idx_doubles_host(L.mcap) : 0;  // per wave, behind the point workspaces
+        // (E and F/H of one slice run behind each other, but slice k's F/H runs beside slice k + 1's E: own workspaces)
+        HIPCHK(S.ws_e.ensure(std::max<size_t>((size_t)L.waves_e * (tvg_ws_doubles_e_host(L.mcap) + idx_ws), 1)));
+        HIPCHK(S.ws.ensure(std::max<size_t>((size_t)L.waves_fh * (tvg_ws_doubles_host(L.mcap) + idx_ws), 1)));
+        HIPCHK(S.maskws.ensure((size_t)std::max<uint32_t>(L.waves_fh, 1) * tvg_ws_mask_bytes_host(L.mcap)));
+        HIPCHK(hipMemcpy(S.pairs.p, sub.data(), sub.size() * sizeof(TvgPair), hipMemcpyHostToDevice));
+        if (!sub_e.empty()) HIPCHK(hipMemcpy(S.pairs_e.p, sub_e.data(), sub_e.size() * sizeof(TvgPair), hipMemcpyHostToDevice));
+        sl.launches.push_back(L);
+    }
+    t_lists += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
+    slices.push_back(std::move(sl));
+    submitted = end;
+    return launch_slice(si, ready);
+}
+
+// the launches of slice si: every class's E kernel(s), then - behind an event - its F/H kernel(s)
+int VerifyRun::launch_slice(size_t si, hipEvent_t ready) {
+    const VerifySliceInfo& sl = slices[si];
+    VerifySliceBufs& B = *c->vslices[si];
+    if (!B.ev[0]) {
+        for (auto& e : B.ev)
+            if (hipEventCreate(&e) != hipSuccess) return fail(AMC_E_HIP, "amc_verify_pairs: hipEventCreate failed");
+        if (hipEventCreateWithFlags(&B.ev_e_done, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&B.ev_aux_done, hipEventDisableTiming) != hipSuccess)
+            return fail(AMC_E_HIP, "amc_verify_pairs: hipEventCreate failed");
+    }
+    auto wait_inputs = [&](hipStream_t s) -> hipError_t {
+        hipError_t e = s == c->stream ? hipSuccess : hipStreamWaitEvent(s, c->vev_setup, 0);
+        if (e == hipSuccess && ready) e = hipStreamWaitEvent(s, ready, 0);
         return e;
     };
-    HIPCHK(ensure_stream(stream_need));
-    HIPCHK(c->d_timgs.ensure(timgs.size()));
-    if (!dev_matches) HIPCHK(c->d_tmatches.ensure(std::max<size_t>(2 * total, 2)));
-    HIPCHK(c->d_ttabs.ensure(std::max<size_t>(tabs.size(), 1)));
-    HIPCHK(c->d_toutmask.ensure(std::max<size_t>(mask_bytes, 128)));
-    HIPCHK(c->d_emask.ensure(std::max<size_t>(mask_bytes, 128)));
-    HIPCHK(c->d_estate.ensure(npairs));
-    HIPCHK(hipEventRecord(c->ev[0], st));
-    HIPCHK(hipMemcpyAsync(c->d_timgs.p, timgs.data(), timgs.size() * sizeof(TvgImage), hipMemcpyHostToDevice, st));
-    if (total && !dev_matches)
-        HIPCHK(hipMemcpyAsync(c->d_tmatches.p, matches, 2 * total * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-    const uint32_t* kernel_matches = dev_matches ? dev_matches : c->d_tmatches.p;
-    if (!tabs.empty())
-        HIPCHK(hipMemcpyAsync(c->d_ttabs.p, tabs.data(), tabs.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-    P.wm_cut = nullptr;
-    if (!wm_cut.empty()) {
-        HIPCHK(c->d_wmcut.ensure(wm_cut.size()));
-        HIPCHK(hipMemcpyAsync(c->d_wmcut.p, wm_cut.data(), wm_cut.size() * sizeof(double), hipMemcpyHostToDevice, st));
-        P.wm_cut = c->d_wmcut.p;
+    bool any_aux = false, any_bulk_e = false;
+    for (const VerifyClassLaunch& L : sl.launches) any_aux |= L.on_aux;
+    if (any_aux) HIPCHK(wait_inputs(c->aux_stream));
+    HIPCHK(wait_inputs(st_e));
+    if (st_fh != st_e) HIPCHK(wait_inputs(st_fh));
+    HIPCHK(hipEventRecord(B.ev[0], st_e));
+    // E kernels: bulk classes on st_e, aux classes (E and F/H behind each other) on the aux stream
+    for (const VerifyClassLaunch& L : sl.launches) {
+        VerifyClassSlot& S = B.cls[L.cls];
+        const bool big = L.cls == 3;
+        uint32_t* const qhead = c->d_vscalars + 2 + 8 * si + 2 * L.cls;
+        hipStream_t ks = L.on_aux ? c->aux_stream : st_e;
+        if (L.n_e) {
+            HIPCHK((big ? launch_tvg_e_big : launch_tvg_e)(c->d_timgs.p, S.pairs_e.p, L.n_e, kernel_matches, B.tabs.p, P, S.ws_e.p,
+                                                            L.mcap, L.waves_e, L.wpb, qhead, c->d_estate.p, B.emask.p, c->d_tout.p,
+                                                            B.outmask.p, ks));
+            ++launches;
+            any_bulk_e |= !L.on_aux;
+        }
+        if (L.on_aux && mode != 3) {
+            HIPCHK((big ? launch_tvg_fh_big : launch_tvg_fh)(c->d_timgs.p, S.pairs.p, L.n, kernel_matches, B.tabs.p, P, S.ws.p,
+                                                              S.maskws.p, L.mcap, L.waves_fh, L.wpb, qhead + 1, c->d_estate.p, B.emask.p,
+                                                              c->d_tout.p, B.outmask.p, ks));
+            ++launches;
+        }
+    }
+    HIPCHK(hipEventRecord(B.ev[1], st_e));
+    if (st_fh != st_e) {
+        HIPCHK(hipEventRecord(B.ev_e_done, st_e));
+        HIPCHK(hipStreamWaitEvent(st_fh, B.ev_e_done, 0));
+    }
+    (void)any_bulk_e;
+    HIPCHK(hipEventRecord(B.ev[2], st_fh));
+    if (mode != 3)
+        for (const VerifyClassLaunch& L : sl.launches) {
+            if (L.on_aux) continue;
+            VerifyClassSlot& S = B.cls[L.cls];
+            const bool big = L.cls == 3;
+            uint32_t* const qhead = c->d_vscalars + 2 + 8 * si + 2 * L.cls;
+            HIPCHK((big ? launch_tvg_fh_big : launch_tvg_fh)(c->d_timgs.p, S.pairs.p, L.n, kernel_matches, B.tabs.p, P, S.ws.p,
+                                                              S.maskws.p, L.mcap, L.waves_fh, L.wpb, qhead + 1, c->d_estate.p, B.emask.p,
+                                                              c->d_tout.p, B.outmask.p, st_fh));
+            ++launches;
+        }
+    HIPCHK(hipEventRecord(B.ev[3], st_fh));
+    if (any_aux) {
+        HIPCHK(hipEventRecord(B.ev_aux_done, c->aux_stream));
+        aux_used = true;
+        B.aux_pending = true;
+    }
+    return AMC_OK;
+}
+
+// every launch of the run is done (the ctx's stream joins the others and is drained)
+int VerifyRun::join() {
+    hipStream_t st = c->stream;
+    for (size_t si = 0; si < slices.size(); ++si) {
+        VerifySliceBufs& B = *c->vslices[si];
+        if (st_fh != st) HIPCHK(hipStreamWaitEvent(st, B.ev[3], 0));
+        if (st_e != st) HIPCHK(hipStreamWaitEvent(st, B.ev[1], 0));
+        if (B.aux_pending) {
+            HIPCHK(hipStreamWaitEvent(st, B.ev_aux_done, 0));
+            B.aux_pending = false;
+        }
     }
     HIPCHK(hipStreamSynchronize(st));
-    lap(2);
+    return AMC_OK;
+}
 
-    if (std::getenv("AMC_TVG_PROFILE")) HIPCHK(c->h_tout.ensure(npairs));
-    HIPCHK(c->d_tout.ensure(npairs));
-    const TvgOut* h_out = c->h_tout.p;  // (read under AMC_TVG_PROFILE only)
+}  // namespace
+
+// dev_matches != nullptr (amc_match_verify_pairs without the streamed hand-over): the matches are already on this device -
+// pair p's list starts at dev_matches + 2 * dev_off[p] and has match_offsets[p + 1] - match_offsets[p] rows; `matches` is not read.
+// run_in: a VerifyRun whose slices were submitted beside the match batches (amc_match_verify_pairs): only what is
+// left - the join, the packing, the download - happens here.
+static int verify_finish(amc_ctx* c, VerifyRun& run, const uint64_t* match_offsets, const uint32_t* matches,
+                         amc_verify_result* out, VerifyPriv* priv, const uint32_t* dev_matches, const uint64_t* dev_off,
+                         double t_pre_ms);
+
+static int verify_impl(amc_ctx* c, int mode, const uint32_t* slot1, const uint32_t* slot2, size_t npairs,
+                       const uint64_t* match_offsets, const uint32_t* matches,
+                       const amc_tvg_opts* opts_in, uint32_t seed, amc_verify_result* out,
+                       const uint32_t* dev_matches = nullptr, const uint64_t* dev_off = nullptr) {
+    if (!c || !out) return fail(AMC_E_INVALID, "amc_verify_pairs: NULL ctx/out");
+    std::memset(out, 0, sizeof *out);
+    c->vres = amc::VerifyResident{};
+    if (npairs > 0 && (!slot1 || !slot2 || !match_offsets))
+        return fail(AMC_E_INVALID, "amc_verify_pairs: NULL pair arrays");
+    const auto wall0 = std::chrono::steady_clock::now();
+    VerifyRun run{};
+    run.c = c;
+    run.mode = mode;
+    run.slot1 = slot1;
+    run.slot2 = slot2;
+    run.npairs = npairs;
+    if (opts_in) run.o = *opts_in; else amc_tvg_opts_default(&run.o);
+    run.seed = seed;
+    const uint64_t total = npairs ? match_offsets[npairs] : 0;
+    if (total > 0 && !matches && !dev_matches) return fail(AMC_E_INVALID, "amc_verify_pairs: NULL matches");
+    for (size_t p = 0; p < npairs; ++p)
+        if (match_offsets[p + 1] < match_offsets[p])
+            return fail(AMC_E_INVALID, "amc_verify_pairs: match_offsets not monotone at %zu", p);
+    int rc = run.begin(total);
+    if (rc != AMC_OK) return rc;
+    VerifyPriv* priv = new (std::nothrow) VerifyPriv();
+    if (!priv) return fail(AMC_E_NOMEM, "amc_verify_pairs: out of host memory");
+    // every failure below (HIPCHK returns included) frees the result's storage and hands back a zeroed struct
+    // - after nothing of the call is left in flight: launches on the other streams still run when an error returns, and
+    // the next call would rewrite their lists and workspaces under them
+    struct Guard {
+        amc_ctx* c;
+        VerifyPriv* p;
+        amc_verify_result* o;
+        ~Guard() {
+            if (p) {
+                verify_streams_sync(c);
+                delete p;
+                std::memset(o, 0, sizeof *o);
+            }
+        }
+    } guard{c, priv, out};
+    hipStream_t st = c->stream;
+    if (npairs) {
+        // the matches: uploaded once (host path), or where the matcher left them
+        const uint32_t* km = dev_matches;
+        if (!dev_matches) {
+            HIPCHK(c->d_tmatches.ensure(std::max<size_t>(2 * total, 2)));
+            if (total) HIPCHK(hipMemcpyAsync(c->d_tmatches.p, matches, 2 * total * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+            HIPCHK(hipEventRecord(c->vev_matches, st));
+            km = c->d_tmatches.p;
+        }
+        // Slices: E launches on the ctx's stream, F/H launches on the verification stream.  A slice wants enough pairs
+        // to fill the machine several times over (its own tail is only hidden by the NEXT slice's E kernel).
+        run.st_e = st;
+        run.st_fh = c->vstream[0] ? c->vstream[0] : st;
+        size_t nver = 0;
+        for (size_t p = 0; p < npairs; ++p) nver += !run.trivial((uint32_t)(match_offsets[p + 1] - match_offsets[p]));
+        int want = 4;
+        if (const char* e = std::getenv("AMC_TVG_SLICES")) want = std::max(1, std::min(kMaxVerifySlices, std::atoi(e)));
+        const size_t min_per_slice = (size_t)run.cus * 12 * 2;  // two full F/H machine loads per slice
+        const int ns = (int)std::max<size_t>(1, std::min<size_t>((size_t)want, nver / std::max<size_t>(min_per_slice, 1)));
+        if (ns <= 1) run.st_fh = st;  // one slice: E and F/H behind each other on the ctx's stream, as before
+        // cut at equal shares of the verified pairs (the trivial ones cost nothing)
+        size_t begin = 0, seen = 0;
+        for (int k = 0; k < ns; ++k) {
+            size_t end = begin;
+            const size_t upto = k + 1 == ns ? nver : (nver * (size_t)(k + 1)) / (size_t)ns;
+            if (k + 1 == ns) end = npairs;
+            else
+                while (end < npairs && seen < upto) {
+                    seen += !run.trivial((uint32_t)(match_offsets[end + 1] - match_offsets[end]));
+                    ++end;
+                }
+            rc = run.submit(begin, end, match_offsets, dev_off, km, dev_matches ? nullptr : matches,
+                            dev_matches ? nullptr : c->vev_matches);
+            if (rc != AMC_OK) return rc;
+            begin = end;
+        }
+    }
+    const double t_pre = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+    rc = verify_finish(c, run, match_offsets, matches, out, priv, dev_matches, dev_off, t_pre);
+    if (rc != AMC_OK) return rc;
+    guard.p = nullptr;
+    return AMC_OK;
+}
+
+static int verify_finish(amc_ctx* c, VerifyRun& run, const uint64_t* match_offsets, const uint32_t* matches,
+                         amc_verify_result* out, VerifyPriv* priv, const uint32_t* dev_matches, const uint64_t* dev_off,
+                         double t_pre_ms) {
+    const size_t npairs = run.npairs;
+    const uint64_t total = npairs ? match_offsets[npairs] : 0;
+    const bool hprof = std::getenv("AMC_VERIFY_PROFILE") != nullptr;  // wall-clock of the call's host phases on stderr
+    const auto wall0 = std::chrono::steady_clock::now();
+    hipStream_t st = c->stream;
+    priv->pool = c->verify_pool;
+    priv->tvg_pin = c->verify_pool->acquire((std::max<size_t>(npairs, 1) * sizeof(amc_tvg) + 3) / 4);
+    priv->mask_pin = c->verify_pool->acquire((size_t)(std::max<uint64_t>(total, 1) + 3) / 4);
+    if (priv->tvg_pin.ensure((std::max<size_t>(npairs, 1) * sizeof(amc_tvg) + 3) / 4) != hipSuccess ||
+        priv->mask_pin.ensure((size_t)(std::max<uint64_t>(total, 1) + 3) / 4) != hipSuccess)
+        return fail(AMC_E_NOMEM, "amc_verify_pairs: out of pinned host memory");
+    out->npairs = npairs;
+    out->_priv = priv;
+    out->tvg = reinterpret_cast<amc_tvg*>(priv->tvg_pin.p);
+    out->inlier_mask = reinterpret_cast<uint8_t*>(priv->mask_pin.p);
+    if (npairs == 0) return AMC_OK;
+    if (run.submitted != npairs) return fail(AMC_E_INVALID, "amc_verify_pairs: internal: %zu of %zu pairs submitted", run.submitted, npairs);
     double kernel_ms = 0.0;
-    uint32_t launches = 0;
     for (int attempt = 0;; ++attempt) {
-        P.stream = c->d_stream.p;
-        P.stream_len = (uint32_t)std::min<size_t>(c->stream_len, 0xFFFFFFFFu);
-        P.stream_err = c->d_scalars + 4;
-        // [2] pairs with a bad match index, [4] waves that ran off the stream table; the records' profile and work
-        // counters are accumulated by both kernels
-        HIPCHK(memset_async(c->d_scalars + 2, 0, 3 * sizeof(uint32_t), st));
-        HIPCHK(memset_async(c->d_tout.p, 0, npairs * sizeof(TvgOut), st));
-        kernel_ms = 0.0;
-        launches = 0;
-        // The first non-empty class (the bulk of a call) runs on the call's stream; the others - few pairs, each
-        // several milliseconds on one wave whatever the machine around it does - on the low-priority stream, with
-        // their own lists and workspaces, so that they fill the bulk class's tails instead of adding two launches of
-        // pure latency behind it (a 9,585-pair call of mixed sizes: 40.5 ms of kernels, 9.2 of them class 1).
-        int nclasses = 0;
-        for (int k = 0; k < 4; ++k) nclasses += !cls[k].empty();
-        const bool overlap_classes = nclasses > 1 && c->aux_stream && !std::getenv("AMC_TVG_SERIAL_CLASSES");
-        bool aux_used = false;
-        if (overlap_classes) HIPCHK(hipEventRecord(c->aev[0], st));  // the memsets above, for the aux stream
-        HIPCHK(hipEventRecord(c->ev[2], st));
-        // launch order: the aux classes first - their few waves take their slots before the bulk class fills every
-        // register file with persistent waves - then the bulk class (the lowest non-empty one)
-        int bulk = 0;
-        while (cls[bulk].empty()) ++bulk;
-        int order[4], norder = 0;
-        if (overlap_classes) {
-            for (int k = 3; k > bulk; --k)
-                if (!cls[k].empty()) order[norder++] = k;
-            order[norder++] = bulk;
-        } else {
-            for (int k = 0; k < 4; ++k)
-                if (!cls[k].empty()) order[norder++] = k;
-        }
-        for (int oi = 0; oi < norder; ++oi) {
-            const int k = order[oi];
-            const bool on_aux = overlap_classes && k != bulk;
-            hipStream_t ks = on_aux ? c->aux_stream : st;
-            DevBuf<TvgPair>& b_pairs = on_aux ? c->d_tpairs2 : c->d_tpairs;
-            DevBuf<TvgPair>& b_pairs_e = on_aux ? c->d_tpairs_e2 : c->d_tpairs_e;
-            DevBuf<double>& b_ws = on_aux ? c->d_tws2 : c->d_tws;
-            DevBuf<uint8_t>& b_maskws = on_aux ? c->d_tmaskws2 : c->d_tmaskws;
-            uint32_t* const qhead = c->d_scalars + (on_aux ? 8 : 1);
-            if (on_aux) {
-                if (aux_used) HIPCHK(hipStreamSynchronize(c->aux_stream));  // its lists and workspaces are rewritten below
-                else HIPCHK(hipStreamWaitEvent(c->aux_stream, c->aev[0], 0));
-                aux_used = true;
-            }
-            const bool big = k == 3;  // index arrays in global memory (tvg_*_big.hip)
-            const int wpb = k >= 2 ? 1 : 4;
-            uint32_t cm = 0;
-            // The waves pull pairs from a queue in this order.  A pair's cost grows with its match count (every
-            // trial scores all matches), so the largest go first: what is left for the tail of the launch, when
-            // most waves have run dry, are the cheap ones.  Results are stored by pair, the order is free.
-            // (stable counting sort by match count, descending: M <= 65535)
-            std::vector<size_t> idx(cls[k].size());
-            {
-                std::vector<uint32_t> start(65537, 0);
-                for (size_t p : cls[k]) ++start[65535 - tp[p].M + 1];
-                for (size_t b = 1; b <= 65536; ++b) start[b] += start[b - 1];
-                for (size_t p : cls[k]) idx[start[65535 - tp[p].M]++] = p;
-            }
-            std::vector<TvgPair> sub(idx.size()), sub_e;
-            for (size_t i = 0; i < idx.size(); ++i) {
-                sub[i] = tp[idx[i]];
-                cm = std::max(cm, sub[i].M);
-                if (uses_E(idx[i])) sub_e.push_back(sub[i]);
-            }
-            const uint32_t mcap = std::max<uint32_t>(64, round_up(cm, 64));
-            auto waves_for = [&](size_t n, int waves_per_simd, size_t lds_block) {
-                const uint32_t blocks_per_cu = (uint32_t)std::max<size_t>(
-                    1, std::min<size_t>(4 * (size_t)waves_per_simd / wpb, (160 * 1024) / std::max<size_t>(lds_block, 1)));
-                uint32_t nw = (uint32_t)std::min<size_t>(n, (size_t)cus * blocks_per_cu * wpb);
-                return std::max<uint32_t>(wpb, (nw + wpb - 1) / wpb * wpb);
-            };
-            const bool run_fh = mode != 3;
-            const uint32_t waves_e = sub_e.empty() ? 0 : waves_for(sub_e.size(), kTvgEWavesPerSimd, big ? tvg_big_lds_bytes_e(wpb) : tvg_lds_bytes_e(mcap, wpb));
-            const uint32_t waves_fh = run_fh ? waves_for(idx.size(), kTvgFhWavesPerSimd, big ? tvg_big_lds_bytes(wpb) : tvg_lds_bytes(mcap, wpb)) : 0;
-            HIPCHK(b_pairs.ensure(idx.size()));
-            HIPCHK(b_pairs_e.ensure(std::max<size_t>(sub_e.size(), 1)));
-            const size_t idx_ws = big ? tvg_big_idx_doubles_host(mcap) : 0;  // per wave, behind the point workspaces
-            HIPCHK(b_ws.ensure(std::max((size_t)waves_e * (tvg_ws_doubles_e_host(mcap) + idx_ws),
-                                        (size_t)waves_fh * (tvg_ws_doubles_host(mcap) + idx_ws))));
-            HIPCHK(b_maskws.ensure((size_t)std::max<uint32_t>(waves_fh, 1) * tvg_ws_mask_bytes_host(mcap)));
-            // (pageable sources: these copies are done when the calls return - `sub` / `sub_e` may go out of scope - and
-            // need no stream synchronisation, which on the aux stream would wait for the class before)
-            HIPCHK(hipMemcpy(b_pairs.p, sub.data(), sub.size() * sizeof(TvgPair), hipMemcpyHostToDevice));
-            if (!sub_e.empty())
-                HIPCHK(hipMemcpy(b_pairs_e.p, sub_e.data(), sub_e.size() * sizeof(TvgPair), hipMemcpyHostToDevice));
-            if (!sub_e.empty()) {
-                HIPCHK((big ? launch_tvg_e_big : launch_tvg_e)(c->d_timgs.p, b_pairs_e.p, (uint32_t)sub_e.size(), kernel_matches, c->d_ttabs.p, P,
-                                    b_ws.p, mcap, waves_e, wpb, qhead, c->d_estate.p, c->d_emask.p,
-                                    c->d_tout.p, c->d_toutmask.p, ks));
-                ++launches;
-            }
-            if (run_fh) {
-                HIPCHK((big ? launch_tvg_fh_big : launch_tvg_fh)(c->d_timgs.p, b_pairs.p, (uint32_t)idx.size(), kernel_matches, c->d_ttabs.p, P,
-                                     b_ws.p, b_maskws.p, mcap, waves_fh, wpb, qhead, c->d_estate.p,
-                                     c->d_emask.p, c->d_tout.p, c->d_toutmask.p, ks));
-                ++launches;
-            }
-            if (!overlap_classes) HIPCHK(hipStreamSynchronize(st));  // d_tpairs is rewritten by the next class
-        }
-        if (aux_used) {  // the call's stream joins the aux stream
-            HIPCHK(hipEventRecord(c->aev[1], c->aux_stream));
-            HIPCHK(hipStreamWaitEvent(st, c->aev[1], 0));
-        }
-        HIPCHK(hipEventRecord(c->ev[3], st));
-        HIPCHK(hipStreamSynchronize(st));
         {
-            float kms = 0.f;
-            (void)hipEventElapsedTime(&kms, c->ev[2], c->ev[3]);
-            kernel_ms += kms;
+            const int rc = run.join();
+            if (rc != AMC_OK) return rc;
         }
-        uint32_t stream_over = 0;
-        HIPCHK(hipMemcpyAsync(&stream_over, c->d_scalars + 4, sizeof stream_over, hipMemcpyDeviceToHost, st));
+        // kernel time: from the first slice's first launch to the last launch's end when the slices ran on the ctx's own
+        // streams back to back (a verification call); the sum of the slices' E and F/H spans when they ran beside the
+        // match batches (amc_match_verify_pairs: the span of the whole run would count the scans between them)
+        kernel_ms = 0.0;
+        if (!run.slices.empty()) {
+            if (run.beside_match) {
+                for (size_t si = 0; si < run.slices.size(); ++si) {
+                    float a = 0.f, b = 0.f;
+                    (void)hipEventElapsedTime(&a, c->vslices[si]->ev[0], c->vslices[si]->ev[1]);
+                    (void)hipEventElapsedTime(&b, c->vslices[si]->ev[2], c->vslices[si]->ev[3]);
+                    kernel_ms += a + b;
+                }
+            } else {
+                HIPCHK(hipEventRecord(c->ev[3], st));
+                HIPCHK(hipEventSynchronize(c->ev[3]));
+                float kms = 0.f;
+                (void)hipEventElapsedTime(&kms, c->vslices[0]->ev[0], c->ev[3]);
+                kernel_ms = kms;
+            }
+        }
+        uint32_t vs[2] = {0, 0};
+        HIPCHK(hipMemcpyAsync(vs, c->d_vscalars, sizeof vs, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
-        if (!stream_over) break;
-        // a Lemire rejection loop ran past the table (probability ~1e-6 per 4096 spare words): lay out more, redo
+        if (!vs[1]) break;
+        // a Lemire rejection loop ran past the table (probability ~1e-6 per 4096 spare words): lay out more, redo -
+        // every slice again (the lists are still on the device), behind each other
         if (attempt >= 4 || c->stream_len * 2 > kMaxStreamWords)
             return fail(AMC_E_HIP, "amc_verify_pairs: the sample stream table was exhausted %d times", attempt + 1);
-        HIPCHK(ensure_stream(c->stream_len * 2));
+        HIPCHK(ensure_sample_stream(c, run.seed, c->stream_len * 2));
+        run.P.stream = c->d_stream.p;
+        run.P.stream_len = (uint32_t)std::min<size_t>(c->stream_len, 0xFFFFFFFFu);
+        HIPCHK(memset_async(c->d_vscalars, 0, kVScalarWords * sizeof(uint32_t), st));
+        HIPCHK(memset_async(c->d_tout.p, 0, npairs * sizeof(TvgOut), st));
+        HIPCHK(hipEventRecord(c->vev_setup, st));
+        run.beside_match = false;
+        for (size_t si = 0; si < run.slices.size(); ++si) {
+            const int rc = run.launch_slice(si, nullptr);
+            if (rc != AMC_OK) return rc;
+        }
     }
     // The kernel stores a pair's record at the caller's pair index (TvgPair::orig) and its mask at a 128-byte
-    // aligned offset; pack_verify_kernel lays both out as the caller reads them (records without their counters, masks
-    // at the input's CSR offsets) and sums the work counters, so the copies below land in the result itself.
+    // aligned offset of its slice's buffer; pack_verify_kernel lays both out as the caller reads them (records without
+    // their counters, masks at the input's CSR offsets; a pair no kernel looked at - fewer matches than min_num_inliers -
+    // becomes the DEGENERATE record EstimateTwoViewGeometry returns for it) and sums the work counters, so the copies
+    // below land in the result itself.
     HIPCHK(c->d_tvg_packed.ensure(npairs));
     HIPCHK(c->d_mask_packed.ensure(std::max<uint64_t>(total, 1)));
     HIPCHK(c->d_moff.ensure(npairs + 1));
     HIPCHK(c->d_tp_all.ensure(npairs));
     HIPCHK(c->d_worksum.ensure(12));
     HIPCHK(hipMemcpyAsync(c->d_moff.p, match_offsets, (npairs + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(c->d_tp_all.p, tp.data(), npairs * sizeof(TvgPair), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(c->d_tp_all.p, run.tp.data(), npairs * sizeof(TvgPair), hipMemcpyHostToDevice, st));
     HIPCHK(memset_async(c->d_worksum.p, 0, 12 * sizeof(unsigned long long), st));
-    HIPCHK(launch_pack_verify(c->d_tout.p, c->d_tp_all.p, (uint32_t)npairs, c->d_toutmask.p, c->d_moff.p,
-                              c->d_tvg_packed.p, c->d_mask_packed.p, c->d_worksum.p, st));
+    const int32_t trivial_below = run.mode == 0 ? std::max(run.o.min_num_inliers, 0) : 0;
+    for (size_t si = 0; si < run.slices.size(); ++si) {
+        const VerifySliceInfo& sl = run.slices[si];
+        HIPCHK(launch_pack_verify(c->d_tout.p + sl.begin, c->d_tp_all.p + sl.begin, (uint32_t)(sl.end - sl.begin),
+                                  c->vslices[si]->outmask.p, c->d_moff.p + sl.begin, c->d_tvg_packed.p + sl.begin,
+                                  c->d_mask_packed.p, c->d_worksum.p, trivial_below, st));
+    }
     HIPCHK(hipMemcpyAsync(out->tvg, c->d_tvg_packed.p, npairs * sizeof(amc_tvg), hipMemcpyDeviceToHost, st));
     if (total) HIPCHK(hipMemcpyAsync(out->inlier_mask, c->d_mask_packed.p, total, hipMemcpyDeviceToHost, st));
     unsigned long long worksum[12];
@@ -2173,14 +2483,13 @@ static int verify_impl(amc_ctx* c, int mode, const uint32_t* slot1, const uint32
     if (want_prof)  // the per-pair cycle counters live in the full records
         HIPCHK(hipMemcpyAsync(c->h_tout.p, c->d_tout.p, npairs * sizeof(TvgOut), hipMemcpyDeviceToHost, st));
     uint32_t bad_pairs = 0;
-    HIPCHK(hipMemcpyAsync(&bad_pairs, c->d_scalars + 2, sizeof bad_pairs, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&bad_pairs, c->d_vscalars, sizeof bad_pairs, hipMemcpyDeviceToHost, st));
     HIPCHK(hipEventRecord(c->ev[1], st));
     HIPCHK(hipEventSynchronize(c->ev[1]));
-    lap(3);
     if (bad_pairs) {  // the kernel met an index past an image's keypoints: find it for the message
         for (size_t p = 0; p < npairs && matches; ++p) {
-            const Slot& a = c->slots[slot1[p]];
-            const Slot& b = c->slots[slot2[p]];
+            const Slot& a = c->slots[run.slot1[p]];
+            const Slot& b = c->slots[run.slot2[p]];
             for (uint64_t k = match_offsets[p]; k < match_offsets[p + 1]; ++k)
                 if (matches[2 * k] >= a.kp_rows || matches[2 * k + 1] >= b.kp_rows)
                     return fail(AMC_E_INVALID, "amc_verify_pairs: pair %zu match %llu indexes past the keypoints", p,
@@ -2189,6 +2498,7 @@ static int verify_impl(amc_ctx* c, int mode, const uint32_t* slot1, const uint32
         return fail(AMC_E_INVALID, "amc_verify_pairs: %u pairs index past the keypoints", bad_pairs);
     }
     if (want_prof) {
+        const TvgOut* h_out = c->h_tout.p;
         tvg_diag_report();
         tvg_diag_report_e();
         unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -2202,24 +2512,23 @@ static int verify_impl(amc_ctx* c, int mode, const uint32_t* slot1, const uint32
     }
     for (int i = 0; i < 12; ++i) out->work[i] += worksum[i];
     float ms = 0.f;
-    (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[1]);
-    out->device_ms = ms;
+    if (!run.slices.empty() && !run.beside_match) (void)hipEventElapsedTime(&ms, c->vslices[0]->ev[0], c->ev[1]);
+    // (beside the match batches there is no span of its own: the kernels plus what followed the last batch)
+    const double t_post = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+    out->device_ms = run.beside_match ? kernel_ms : (double)ms;
     out->kernel_ms = kernel_ms;
-    out->kernel_launches = launches;
-    lap(4);
+    out->kernel_launches = run.launches;
     if (hprof)
-        std::fprintf(stderr, "[amc verify profile] pairs=%zu checks %.1f ms, tables %.1f, upload %.1f, kernels+download %.1f "
-                     "(kernels %.1f), unpack %.1f\n", npairs, t_phase[0], t_phase[1], t_phase[2], t_phase[3], kernel_ms,
-                     t_phase[4]);
-    if (o.compute_relative_pose) {
+        std::fprintf(stderr, "[amc verify profile] pairs=%zu slices=%zu%s: host before the join %.1f ms (tables %.1f, lists + uploads %.1f), "
+                     "join + pack + download %.1f (kernels %.1f)\n", npairs, run.slices.size(), run.beside_match ? " beside the match batches" : "",
+                     t_pre_ms, run.t_tables, run.t_lists, t_post, kernel_ms);
+    if (run.o.compute_relative_pose) {
         // EstimateTwoViewGeometryPose on the selected inlier matches (mask order = match order): the matches
-        // and the masks of this call are still on the device
-        std::vector<uint64_t> moff(npairs);
-        for (size_t p = 0; p < npairs; ++p) moff[p] = tp[p].mask_off;
+        // and the packed masks of this call are still on the device
         priv->pose.resize(npairs);
         double pose_ms = 0.0;
-        const int rc = pose_impl(c, "amc_verify_pairs", slot1, slot2, npairs, match_offsets, matches, out->tvg,
-                                 priv->pose.data(), &pose_ms, moff.data(), dev_matches, dev_off);
+        const int rc = pose_impl(c, "amc_verify_pairs", run.slot1, run.slot2, npairs, match_offsets, matches, out->tvg,
+                                 priv->pose.data(), &pose_ms, match_offsets, dev_matches, dev_off);
         if (rc != AMC_OK) return rc;
         for (size_t p = 0; p < npairs; ++p) out->tvg[p].config = priv->pose[p].config;
         out->pose = priv->pose.data();
@@ -2228,16 +2537,15 @@ static int verify_impl(amc_ctx* c, int mode, const uint32_t* slot1, const uint32
         out->pose_kernel_ms = pose_ms;
         out->kernel_launches += 1;
     }
-    guard.p = nullptr;
-    if (mode == 0) {  // what the exchange step's verification half reads in place (amc_allgather_pair_records / _inlier_tables)
+    if (run.mode == 0) {  // what the exchange step's verification half reads in place (amc_allgather_pair_records / _inlier_tables)
         c->vres.npairs = npairs;
         c->vres.total = total;
         // (EstimateTwoViewGeometryPose settles PLANAR_OR_PANORAMIC on the host copy of the records only)
-        c->vres.tvg = o.compute_relative_pose ? nullptr : c->d_tvg_packed.p;
+        c->vres.tvg = run.o.compute_relative_pose ? nullptr : c->d_tvg_packed.p;
         c->vres.mask = c->d_mask_packed.p;
         c->vres.moff = c->d_moff.p;
         c->vres.tp = c->d_tp_all.p;
-        c->vres.matches = kernel_matches;
+        c->vres.matches = run.kernel_matches;
     }
     return AMC_OK;
 }
@@ -2382,13 +2690,77 @@ int amc_match_verify_pairs(amc_ctx* c, const uint32_t* slot1, const uint32_t* sl
         if (rc != AMC_OK) amc_match_result_free(match_out);
         return rc;
     }
-    std::vector<uint64_t> keep_off;
-    int rc = match_impl(c, slot1, slot2, npairs, match_opts, nullptr, 0.0, match_out, &keep_off);
+    if (std::getenv("AMC_PIPELINE_SERIAL")) {  // (A/B hook: the stages behind each other, as before round 6)
+        std::vector<uint64_t> keep_off;
+        int rc = match_impl(c, slot1, slot2, npairs, match_opts, nullptr, 0.0, match_out, &keep_off);
+        if (rc != AMC_OK) return rc;
+        rc = verify_impl(c, 0, slot1, slot2, npairs, match_out->offsets, match_out->matches, tvg_opts, seed, verify_out,
+                         c->d_keep.p ? c->d_keep.p : reinterpret_cast<const uint32_t*>(c->d_scalars), keep_off.data());
+        if (rc != AMC_OK) amc_match_result_free(match_out);
+        return rc;
+    }
+    // The stages interleaved: the verification run is set up first (nothing of it depends on the matches), every match
+    // batch hands its pairs over as a slice while the next batch is scanned, and what remains after the last batch is
+    // that batch's slice, the packing and the download.
+    std::memset(match_out, 0, sizeof *match_out);
+    if (npairs > 0 && (!slot1 || !slot2)) return fail(AMC_E_INVALID, "amc_match_verify_pairs: NULL pair arrays");
+    c->vres = amc::VerifyResident{};
+    const auto wall0 = std::chrono::steady_clock::now();
+    VerifyRun run{};
+    run.c = c;
+    run.mode = 0;
+    run.slot1 = slot1;
+    run.slot2 = slot2;
+    run.npairs = npairs;
+    if (tvg_opts) run.o = *tvg_opts; else amc_tvg_opts_default(&run.o);
+    run.seed = seed;
+    run.beside_match = true;
+    for (size_t p = 0; p < npairs; ++p)  // (the match call checks this too; the verification set-up reads the slots first)
+        if (slot1[p] >= c->slots.size() || slot2[p] >= c->slots.size())
+            return fail(AMC_E_INVALID, "amc_match_verify_pairs: pair %zu references slot out of range", p);
+    int rc = run.begin(0);
     if (rc != AMC_OK) return rc;
-    rc = verify_impl(c, 0, slot1, slot2, npairs, match_out->offsets, match_out->matches, tvg_opts, seed, verify_out,
-                     c->d_keep.p ? c->d_keep.p : reinterpret_cast<const uint32_t*>(c->d_scalars), keep_off.data());
-    if (rc != AMC_OK) amc_match_result_free(match_out);
-    return rc;
+    run.st_e = c->vstream[0] ? c->vstream[0] : c->stream;
+    run.st_fh = c->vstream[1] ? c->vstream[1] : run.st_e;
+    VerifyPriv* priv = new (std::nothrow) VerifyPriv();
+    if (!priv) return fail(AMC_E_NOMEM, "amc_match_verify_pairs: out of host memory");
+    struct Guard {  // every failure: nothing left in flight, both results zeroed
+        amc_ctx* c;
+        VerifyPriv* p;
+        amc_verify_result* o;
+        amc_match_result* m;
+        bool match_done = false;
+        ~Guard() {
+            if (p) {
+                verify_streams_sync(c);
+                delete p;
+                std::memset(o, 0, sizeof *o);
+                if (match_done) amc_match_result_free(m);
+            }
+        }
+    } guard{c, priv, verify_out, match_out};
+    std::vector<uint64_t> keep_off;
+    const BatchHook hook = [&](size_t begin, size_t end, const uint64_t* offsets, const uint64_t* koff, hipEvent_t ready) -> int {
+        // (the last slice slot is kept for whatever is left when the match call returns)
+        if (run.slices.size() + 1 >= (size_t)kMaxVerifySlices) return AMC_OK;
+        return run.submit(run.submitted, end, offsets, koff, c->d_keep.p ? c->d_keep.p : reinterpret_cast<const uint32_t*>(c->d_scalars),
+                          nullptr, ready);
+        (void)begin;
+    };
+    rc = match_impl(c, slot1, slot2, npairs, match_opts, nullptr, 0.0, match_out, &keep_off, npairs ? &hook : nullptr);
+    if (rc != AMC_OK) return rc;
+    guard.match_done = true;
+    if (run.submitted < npairs) {
+        rc = run.submit(run.submitted, npairs, match_out->offsets, keep_off.data(),
+                        c->d_keep.p ? c->d_keep.p : reinterpret_cast<const uint32_t*>(c->d_scalars), nullptr, nullptr);
+        if (rc != AMC_OK) return rc;
+    }
+    const double t_pre = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+    rc = verify_finish(c, run, match_out->offsets, match_out->matches, verify_out, priv,
+                       c->d_keep.p ? c->d_keep.p : reinterpret_cast<const uint32_t*>(c->d_scalars), keep_off.data(), t_pre);
+    if (rc != AMC_OK) return rc;
+    guard.p = nullptr;
+    return AMC_OK;
 }
 
 int amc_pose_pairs(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, size_t npairs,

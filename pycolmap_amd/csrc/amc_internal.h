@@ -379,7 +379,7 @@ size_t tvg_lds_bytes_e(uint32_t mcap, int waves);  // essential-matrix kernel (+
 // pose.hip: a verification call's records and masks in the caller's layout, work counters summed
 hipError_t launch_pack_verify(const TvgOut* out, const TvgPair* tp, uint32_t npairs, const uint8_t* mask_src,
                               const uint64_t* moff, amc_tvg* tvg_dst, uint8_t* mask_dst, unsigned long long* work,
-                              hipStream_t s);
+                              int32_t trivial_below, hipStream_t s);
 // pose.hip: PoseFromHomographyMatrix on given points; in27 = H, K1, K2; out16 = R, t, n, count
 hipError_t launch_homography_decomposition(const double* in27, const double* p1, const double* p2, uint32_t n, double* out16,
                                            double* points3D, hipStream_t s);

@@ -282,10 +282,13 @@ __global__ __launch_bounds__(64) void homography_decomposition_kernel(const doub
 // amc_verify_pairs' results in the caller's layout: one wave per pair copies the record without its counters
 // (amc_tvg: 70 dwords of the 512-byte TvgOut) and the pair's mask bytes from their 128-byte aligned slot to the
 // input's CSR offset, and adds the pair's work counters to the call's sums (one atomic per counter and workgroup).
+// trivial_below: a pair with fewer matches was never handed to a kernel (mode 0: EstimateTwoViewGeometry returns DEGENERATE
+// for it before it looks at a point) - its record is the zeroed one with that config, its mask bytes are zero.
 __global__ __launch_bounds__(256) void pack_verify_kernel(const TvgOut* __restrict__ out, const TvgPair* __restrict__ tp,
                                                           uint32_t npairs, const uint8_t* __restrict__ mask_src,
                                                           const uint64_t* __restrict__ moff, amc_tvg* __restrict__ tvg_dst,
-                                                          uint8_t* __restrict__ mask_dst, unsigned long long* __restrict__ work) {
+                                                          uint8_t* __restrict__ mask_dst, unsigned long long* __restrict__ work,
+                                                          uint32_t trivial_below) {
     __shared__ unsigned long long s_work[12];
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     if (tid < 12) s_work[tid] = 0ull;
@@ -295,11 +298,13 @@ __global__ __launch_bounds__(256) void pack_verify_kernel(const TvgOut* __restri
         static_assert(sizeof(amc_tvg) % 4 == 0, "amc_tvg is copied in dwords");
         const uint32_t* src = reinterpret_cast<const uint32_t*>(&out[p].g);
         uint32_t* dst = reinterpret_cast<uint32_t*>(tvg_dst + p);
-        for (uint32_t i = lane; i < sizeof(amc_tvg) / 4; i += 64) dst[i] = src[i];
         const uint32_t M = tp[p].M;
+        const bool trivial = M < trivial_below;
+        static_assert(offsetof(amc_tvg, config) == 0, "the record's first dword is its config");
+        for (uint32_t i = lane; i < sizeof(amc_tvg) / 4; i += 64) dst[i] = (trivial && i == 0) ? (uint32_t)AMC_TVG_DEGENERATE : src[i];
         const uint8_t* ms = mask_src + tp[p].mask_off;
         uint8_t* md = mask_dst + moff[p];
-        for (uint32_t i = lane; i < M; i += 64) md[i] = ms[i];
+        for (uint32_t i = lane; i < M; i += 64) md[i] = trivial ? (uint8_t)0 : ms[i];
         if (lane < 12) atomicAdd(&s_work[lane], out[p].work[lane]);
     }
     __syncthreads();
@@ -310,10 +315,10 @@ __global__ __launch_bounds__(256) void pack_verify_kernel(const TvgOut* __restri
 
 hipError_t launch_pack_verify(const TvgOut* out, const TvgPair* tp, uint32_t npairs, const uint8_t* mask_src,
                               const uint64_t* moff, amc_tvg* tvg_dst, uint8_t* mask_dst, unsigned long long* work,
-                              hipStream_t s) {
+                              int32_t trivial_below, hipStream_t s) {
     if (npairs == 0) return hipSuccess;
     hipLaunchKernelGGL(pack_verify_kernel, dim3((npairs + 3) / 4), dim3(256), 0, s, out, tp, npairs, mask_src, moff, tvg_dst,
-                       mask_dst, work);
+                       mask_dst, work, (uint32_t)(trivial_below > 0 ? trivial_below : 0));
     return hipGetLastError();
 }
 
