@@ -1030,6 +1030,7 @@ def main():
                     help="no GPU: run the multi-rank plumbing (sharding, exchange, reductions, JSON line) over gloo with the "
                          "CPU oracle in place of the kernels; prints value = null.  For tests/, with tiny --images/--feats")
     ap.add_argument("--no-pipeline", action="store_true", help="skip the chained configs[2] leg")
+    ap.add_argument("--pipeline-steps", type=int, default=0, help="timed steps of the chained configs[2] leg (default: min(steps, 2))")
     ap.add_argument("--no-dense", action="store_true", help="skip the dense-overlap match leg")
     ap.add_argument("--no-ragged", action="store_true", help="skip the ragged-size match leg (n ~ U[2000, 6000])")
     ap.add_argument("--no-sift-stats", action="store_true", help="skip the extractor-statistics match leg")
@@ -1267,7 +1268,7 @@ def main():
                 torch.cuda.empty_cache()
         if gpu_legs and not args.no_pipeline:
             release_headline()
-            out["pipeline"] = pipeline_leg(lambda: _capi.Context(local_rank), max(1, min(args.steps, 2)), min(1, args.warmup),
+            out["pipeline"] = pipeline_leg(lambda: _capi.Context(local_rank), args.pipeline_steps or max(1, min(args.steps, 2)), min(1, args.warmup),
                                            0 if args.no_cpu_baseline else 4 * host_cores(), args.images, args.feats)
             sm = out["pipeline"]["stage_ms_per_step"]
             out["pipeline"].update(verify_ms=sm["verify_ms"], verify_kernel_ms=sm["verify_kernel_ms"], match_ms=sm["match_ms"],

@@ -678,7 +678,13 @@ static void guided_grid_setup(GuidedDev& g, const GridDev& g1, const GridDev& g2
 // resident table and the NEXT batch has been enqueued - with the pairs [begin, end) of the batch, the call's CSR offsets
 // (valid up to `end`), where each pair's rows start in the resident table, and an event behind the reorder that put
 // them there (null: the batch has no matches).  Its host work runs beside the next batch's scan.
-using BatchHook = std::function<int(size_t begin, size_t end, const uint64_t* offsets, const uint64_t* keep_off, hipEvent_t ready)>;
+// plan: called right after the batch's counts are on the host and BEFORE the next batch is enqueued, with the next
+// batch's scan time as the host estimates it (0: there is no next batch) - returns how many CUs that scan shall leave
+// free for the work the hook is about to launch; the same number comes back in `cus_free`.
+struct BatchHook {
+    std::function<int(size_t begin, size_t end, const uint64_t* offsets, double next_scan_ms)> plan;
+    std::function<int(size_t begin, size_t end, const uint64_t* offsets, const uint64_t* keep_off, hipEvent_t ready, int cus_free)> submit;
+};
 static void verify_streams_sync(amc_ctx* c);
 
 static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, size_t npairs,
@@ -819,7 +825,18 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
     // tail they shape)
     uint64_t rows_total = 0, rows_carved = 0;
     for (size_t i = 0; i < npairs; ++i) rows_total += c->slots[slot1[i]].dev.rows_pad;
-    const bool even_batches = std::getenv("AMC_MATCH_EVEN_BATCHES") != nullptr;  // (A/B hook)
+    bool even_batches = std::getenv("AMC_MATCH_EVEN_BATCHES") != nullptr;  // (A/B hook)
+    if (batch_hook && batch_hook->plan) {
+        // amc_match_verify_pairs with AMC_PIPELINE_INTERLEAVE=1: batch k's verification runs beside batch k + 1's scan, so (a) what is exposed is the LAST
+        // batch's verification - more and equal batches make it small (the copy of the last batch's matches hides behind
+        // it) - and (b) every batch but the first wants a scan long enough to hide a slice behind: up to six batches of
+        // at least 32 Mi image-1 rows (an ~11 ms scan at 4,096 columns).  AMC_PIPELINE_BATCHES: A/B hook.
+        size_t want = std::min<size_t>(6, std::max<size_t>(1, (size_t)(rows_total / ((uint64_t)32 << 20))));
+        if (const char* e = std::getenv("AMC_PIPELINE_BATCHES")) want = (size_t)std::max(1, std::atoi(e));
+        const size_t per = (size_t)((rows_total + want - 1) / want) + 4096;
+        if (!std::getenv("AMC_MATCH_BATCH_ENTRIES")) max_entries = std::min(max_entries, std::max<size_t>(per, 1));
+        even_batches = true;
+    }
     // How a batch's matches reach the host.  The copy of batch k is handed to batch k + 1's forward scan, whose first
     // few workgroups carry it out (CopyJob, match_mfma.hip); the last batch's copy, and any the next launch cannot
     // take, goes to the copy stream as a small-grid kernel (launch_host_copy).  AMC_D2H=memcpy: hipMemcpyAsync for
@@ -995,7 +1012,7 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
         return true;
     };
     // device side of a batch, all on the stream: H2D of the queues, the kernels, D2H of the counters
-    auto enqueue = [&](Batch& b) {
+    auto enqueue = [&](Batch& b, int leave_cus = 0) {
         const int k = b.set;
         const size_t nb = b.nb, nord = b.nord, nwork = b.nwork;
         // device scratch only ever grows; growing frees the old allocation, so drain the stream first
@@ -1067,7 +1084,7 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
                 pending.set = -1;
             }
             if (!hc(launch_match_mfma(0, c->d_segs.p, c->d_scalars + 5, (uint32_t)std::min<size_t>(b.seg_cap, 0xFFFFFFFFu),
-                                      c->d_scalars + 1, c->d_accmask.p, c->d_accept, st, job, c->d_scalars + 7), "forward scan"))
+                                      c->d_scalars + 1, c->d_accmask.p, c->d_accept, st, job, c->d_scalars + 7, leave_cus), "forward scan"))
                 return false;
             // that batch's matches are on the host when this scan is done
             if (done_set >= 0 && !hc(hipEventRecord(c->bev[done_set][4], st), "event record")) return false;
@@ -1199,11 +1216,23 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
         return hc(hipEventRecord(c->bev[k][4], st), "event record");
     };
     double t_hook = 0.0;
+    int cus_free = 0;  // what the scan being enqueued leaves to the hook's launches
+    auto plan_hook = [&](const Batch& b, const Batch* next) {
+        cus_free = 0;
+        if (!batch_hook || !batch_hook->plan) return;
+        double next_ms = 0.0;
+        if (next) {  // the next batch's forward scan at the rate this kernel holds (~1.2e13 distances/s)
+            double nd = 0.0;
+            for (size_t i = next->begin; i < next->end; ++i) nd += (double)c->slots[slot1[i]].dev.rows * (double)c->slots[slot2[i]].dev.rows;
+            next_ms = nd / 1.2e10;
+        }
+        cus_free = batch_hook->plan(b.begin, b.end, priv->offsets.data(), next_ms);
+    };
     auto run_hook = [&](const Batch& b) {
-        if (!batch_hook) return true;
+        if (!batch_hook || !batch_hook->submit) return true;
         const auto th = std::chrono::steady_clock::now();
-        const int hrc = (*batch_hook)(b.begin, b.end, priv->offsets.data(), keep_off ? keep_off->data() : nullptr,
-                                      b.total ? c->kev[b.set] : nullptr);
+        const int hrc = batch_hook->submit(b.begin, b.end, priv->offsets.data(), keep_off ? keep_off->data() : nullptr,
+                                           b.total ? c->kev[b.set] : nullptr, cus_free);
         t_hook += since(th);
         if (hrc != AMC_OK && rc == AMC_OK) rc = hrc;  // (the hook has set the message)
         return hrc == AMC_OK;
@@ -1263,7 +1292,8 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
             ok = ok && collect(cur);
             t_collect += since(tp);
             tp = std::chrono::steady_clock::now();
-            if (ok && have_next) ok = enqueue(next);
+            if (ok) plan_hook(cur, have_next ? &next : nullptr);
+            if (ok && have_next) ok = enqueue(next, cus_free);
             ok = ok && flush_copy();  // (not taken by a scan launch: the last batch's, a small one, dot4-only batches)
             t_enqueue += since(tp);
             ok = ok && run_hook(cur);  // (the device is busy with `next` - or, for the last batch, with the copy)
@@ -1833,6 +1863,7 @@ constexpr int kMaxVerifySlices = 12;
 struct VerifyClassLaunch {  // one size class of one slice, as launched (kept for the rare relaunch after a stream overrun)
     int cls = 0;
     bool on_aux = false;
+    bool one_stream = false;  // E and F/H behind each other on the E stream (a slice confined to a few CUs beside a scan)
     uint32_t n = 0, n_e = 0, mcap = 0, waves_e = 0, waves_fh = 0;
     int wpb = 4;
 };
@@ -1879,8 +1910,33 @@ struct VerifyRun {
     // `matches_dev` (nullptr: at offs[p]); `ready` (may be null): an event after which the rows are in place
     int submit(size_t begin, size_t end, const uint64_t* offs, const uint64_t* dev_off, const uint32_t* matches_dev,
                const uint32_t* matches_host, hipEvent_t ready);
+    // the two halves of submit(): pairs join the open slice (host only: checks, records, trial tables, size classes);
+    // the slice is closed (class lists, uploads, launches).  amc_match_verify_pairs adds every match batch's pairs beside
+    // the next batch's scan and closes ONE slice behind the last batch.
+    int add_pairs(size_t begin, size_t end, const uint64_t* offs, const uint64_t* dev_off, const uint32_t* matches_dev,
+                  const uint32_t* matches_host);
+    int close_slice(hipEvent_t ready);
+    struct OpenSlice {
+        bool active = false;
+        size_t begin = 0;
+        uint32_t maxM = 0;
+        uint64_t mask_bytes = 0;
+        std::vector<uint32_t> tabs;
+        std::vector<int64_t> tab_of_M;
+        std::vector<size_t> cls[4];
+    } open;
     int launch_slice(size_t si, hipEvent_t ready);
     int join();
+    // amc_match_verify_pairs: how many CUs the next batch's scan shall leave to the verification of pairs [begin, end)
+    int plan_cus(size_t begin, size_t end, const uint64_t* offs, double next_scan_ms) const;
+    int slice_cus = 0;  // the slice being submitted runs beside a scan that left this many CUs free (0: the whole machine)
+    bool defer_launch = false;  // submit() prepares and uploads; the launches follow when the caller says so (launch_deferred)
+    int launch_deferred() {
+        for (size_t si = 0; si < slices.size(); ++si)
+            if (const int rc = launch_slice(si, nullptr)) return rc;
+        return AMC_OK;
+    }
+    double est_ms_total = 0.0;
 };
 
 int VerifyRun::begin(size_t) {
@@ -2008,29 +2064,24 @@ int VerifyRun::begin(size_t) {
     return AMC_OK;
 }
 
-int VerifyRun::submit(size_t begin, size_t end, const uint64_t* offs, const uint64_t* dev_off, const uint32_t* matches_dev,
-                      const uint32_t* matches_host, hipEvent_t ready) {
+// add_pairs: pairs [begin, end) join the OPEN slice - checks, pair records, trial tables, size classes (host only).
+int VerifyRun::add_pairs(size_t begin, size_t end, const uint64_t* offs, const uint64_t* dev_off, const uint32_t* matches_dev,
+                         const uint32_t* matches_host) {
     if (begin != submitted || end < begin || end > npairs) return fail(AMC_E_INVALID, "amc_verify_pairs: internal: slices out of order");
     if (end == begin) return AMC_OK;
-    if (slices.size() >= (size_t)kMaxVerifySlices) return fail(AMC_E_INVALID, "amc_verify_pairs: internal: too many slices");
     kernel_matches = matches_dev;
     const auto t0 = std::chrono::steady_clock::now();
-    VerifySliceInfo sl;
-    sl.begin = begin;
-    sl.end = end;
-    const size_t si = slices.size();
-    if (c->vslices.size() <= si) c->vslices.resize(si + 1);
-    if (!c->vslices[si]) c->vslices[si].reset(new (std::nothrow) VerifySliceBufs());
-    if (!c->vslices[si]) return fail(AMC_E_NOMEM, "amc_verify_pairs: out of host memory");
-    VerifySliceBufs& B = *c->vslices[si];
-    // dyn_max_num_trials tables, one set per distinct match count of the slice
-    std::vector<uint32_t> tabs;
-    uint32_t slice_maxM = 0;
+    if (!open.active) {
+        open = OpenSlice{};
+        open.active = true;
+        open.begin = begin;
+    }
+    uint32_t add_maxM = 0;
     for (size_t p = begin; p < end; ++p) {
         if (offs[p + 1] < offs[p]) return fail(AMC_E_INVALID, "amc_verify_pairs: match_offsets not monotone at %zu", p);
         const uint64_t M = offs[p + 1] - offs[p];
         if (M > 65535) return fail(AMC_E_INVALID, "amc_verify_pairs: pair %zu has %llu matches (> 65535)", p, (unsigned long long)M);
-        slice_maxM = std::max<uint32_t>(slice_maxM, (uint32_t)M);
+        add_maxM = std::max<uint32_t>(add_maxM, (uint32_t)M);
         // Match indices are checked by the kernel where it gathers the points (bad_index_count); only the pairs no
         // kernel looks at - fewer matches than min_num_inliers - are checked here.
         if (trivial((uint32_t)M) && matches_host) {
@@ -2042,7 +2093,9 @@ int VerifyRun::submit(size_t begin, size_t end, const uint64_t* offs, const uint
                     return fail(AMC_E_INVALID, "amc_verify_pairs: pair %zu match %llu indexes past the keypoints", p, (unsigned long long)k);
         }
     }
-    maxM = std::max(maxM, slice_maxM);
+    maxM = std::max(maxM, add_maxM);
+    open.maxM = std::max(open.maxM, add_maxM);
+    if (open.tab_of_M.size() < (size_t)open.maxM + 1) open.tab_of_M.resize((size_t)open.maxM + 1, -1);
     const int kmins[3] = {5, 7, 4};
     auto make_table = [&](uint32_t M) {  // ComputeNumTrials for every inlier count 0 .. M and the three minimal sample sizes
         std::vector<uint32_t> t3;
@@ -2054,19 +2107,18 @@ int VerifyRun::submit(size_t begin, size_t end, const uint64_t* offs, const uint
             }
         return t3;
     };
-    // The tables this slice needs and the cache does not hold (a pow and two logs per entry: the first call of a run
+    // The tables these pairs need and the cache does not hold (a pow and two logs per entry: the first call of a run
     // sees a few hundred new match counts, ~40 ms on one core) are computed ahead on a few threads.
     const bool tabs_cacheable = o.ransac.confidence == o.ransac.confidence &&
                                 o.ransac.dyn_num_trials_multiplier == o.ransac.dyn_num_trials_multiplier;
-    std::vector<int64_t> tab_of_M((size_t)slice_maxM + 1, -1);
-    std::vector<int32_t> fresh_of((size_t)slice_maxM + 1, -1);
+    std::vector<int32_t> fresh_of((size_t)add_maxM + 1, -1);
     std::vector<uint32_t> fresh_M;
     std::vector<std::vector<uint32_t>> fresh_tab;
     {
         size_t words = 0;
         for (size_t p = begin; p < end; ++p) {
             const uint32_t M = (uint32_t)(offs[p + 1] - offs[p]);
-            if (trivial(M) || fresh_of[M] != -1) continue;
+            if (trivial(M) || fresh_of[M] != -1 || open.tab_of_M[M] >= 0) continue;
             fresh_of[M] = -2;  // seen
             if (tabs_cacheable && c->trial_tabs.count(TrialTabKey{M, o.ransac.confidence, o.ransac.dyn_num_trials_multiplier})) continue;
             fresh_of[M] = (int32_t)fresh_M.size();
@@ -2084,8 +2136,7 @@ int VerifyRun::submit(size_t begin, size_t end, const uint64_t* offs, const uint
         work();
         for (auto& t : th) t.join();
     }
-    uint64_t mask_bytes = 0;
-    std::vector<size_t> cls[4];
+    std::vector<uint32_t>& tabs = open.tabs;
     for (size_t p = begin; p < end; ++p) {
         const uint32_t M = (uint32_t)(offs[p + 1] - offs[p]);
         TvgPair& q = tp[p];
@@ -2097,15 +2148,15 @@ int VerifyRun::submit(size_t begin, size_t end, const uint64_t* offs, const uint
         q.mask_off = 0;
         q.tab_off[0] = q.tab_off[1] = q.tab_off[2] = 0;
         if (trivial(M)) continue;  // DEGENERATE without a kernel: pack_verify_kernel writes the record
-        if (tab_of_M[M] < 0) {
-            tab_of_M[M] = (int64_t)tabs.size();
+        if (open.tab_of_M[M] < 0) {
+            open.tab_of_M[M] = (int64_t)tabs.size();
             // the table of one match count depends on (M, confidence, multiplier) only: kept across calls
             // (a pow and two logs per entry; a pipeline sees the same few hundred counts again and again)
             const TrialTabKey key{M, o.ransac.confidence, o.ransac.dyn_num_trials_multiplier};
             // (NaN options would break the map's ordering: those tables are rebuilt every time)
             auto it = tabs_cacheable ? c->trial_tabs.find(key) : c->trial_tabs.end();
             if (it == c->trial_tabs.end()) {
-                std::vector<uint32_t> t3 = fresh_of[M] >= 0 ? std::move(fresh_tab[(size_t)fresh_of[M]]) : make_table(M);
+                std::vector<uint32_t> t3 = (M <= add_maxM && fresh_of[M] >= 0) ? std::move(fresh_tab[(size_t)fresh_of[M]]) : make_table(M);
                 if (!tabs_cacheable) {
                     tabs.insert(tabs.end(), t3.begin(), t3.end());
                 } else {
@@ -2119,9 +2170,9 @@ int VerifyRun::submit(size_t begin, size_t end, const uint64_t* offs, const uint
             }
             if (it != c->trial_tabs.end()) tabs.insert(tabs.end(), it->second.begin(), it->second.end());
         }
-        q.mask_off = mask_bytes;
-        mask_bytes += ((uint64_t)M + 127) / 128 * 128;
-        for (int t = 0; t < 3; ++t) q.tab_off[t] = (uint32_t)(tab_of_M[M] + (int64_t)t * (M + 1));
+        q.mask_off = open.mask_bytes;
+        open.mask_bytes += ((uint64_t)M + 127) / 128 * 128;
+        for (int t = 0; t < 3; ++t) q.tab_off[t] = (uint32_t)(open.tab_of_M[M] + (int64_t)t * (M + 1));
         // Size classes.  A wave's LDS share holds, besides a few KB of fixed state, two uint16 index arrays of mcap
         // entries (the sampler's permutation and the inlier list); everything else of a pair lives in the wave's global
         // workspace.  Pairs up to ~1,800 matches run at both kernels' full occupancy (E 2, F/H 3 waves per SIMD), 4 waves
@@ -2132,17 +2183,36 @@ int VerifyRun::submit(size_t begin, size_t end, const uint64_t* offs, const uint
         const size_t lds = tvg_lds_bytes(mc, 1) + 64;
         const size_t lds_e = tvg_lds_bytes_e(mc, 1) + 64;  // (the E kernel's waves also carry the root finder's coefficients)
         if (lds <= 160 * 1024 / (4 * (size_t)kTvgFhWavesPerSimd) && lds_e <= 160 * 1024 / (4 * (size_t)kTvgEWavesPerSimd))
-            cls[0].push_back(p);  // (full occupancy of BOTH kernels)
-        else if (lds_e <= 160 * 1024 / 4) cls[1].push_back(p);  // 4-wave workgroups of either kernel fit a CU
-        else if (lds_e <= 160 * 1024) cls[2].push_back(p);
-        else cls[3].push_back(p);  // M <= 65535 was checked above
+            open.cls[0].push_back(p);  // (full occupancy of BOTH kernels)
+        else if (lds_e <= 160 * 1024 / 4) open.cls[1].push_back(p);  // 4-wave workgroups of either kernel fit a CU
+        else if (lds_e <= 160 * 1024) open.cls[2].push_back(p);
+        else open.cls[3].push_back(p);  // M <= 65535 was checked above
     }
-    sl.mask_bytes = mask_bytes;
+    submitted = end;
     t_tables += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return AMC_OK;
+}
+
+// close_slice: the open slice's class lists (largest pairs first), its uploads and - unless deferred - its launches
+int VerifyRun::close_slice(hipEvent_t ready) {
+    if (!open.active) return AMC_OK;
+    if (slices.size() >= (size_t)kMaxVerifySlices) return fail(AMC_E_INVALID, "amc_verify_pairs: internal: too many slices");
     const auto t1 = std::chrono::steady_clock::now();
+    VerifySliceInfo sl;
+    sl.begin = open.begin;
+    sl.end = submitted;
+    sl.mask_bytes = open.mask_bytes;
+    const size_t si = slices.size();
+    if (c->vslices.size() <= si) c->vslices.resize(si + 1);
+    if (!c->vslices[si]) c->vslices[si].reset(new (std::nothrow) VerifySliceBufs());
+    if (!c->vslices[si]) return fail(AMC_E_NOMEM, "amc_verify_pairs: out of host memory");
+    VerifySliceBufs& B = *c->vslices[si];
+    const std::vector<uint32_t>& tabs = open.tabs;
+    const uint32_t slice_maxM = open.maxM;
+    std::vector<size_t>(&cls)[4] = open.cls;
     HIPCHK(B.tabs.ensure(std::max<size_t>(tabs.size(), 1)));
-    HIPCHK(B.outmask.ensure(std::max<size_t>(mask_bytes, 128)));
-    HIPCHK(B.emask.ensure(std::max<size_t>(mask_bytes, 128)));
+    HIPCHK(B.outmask.ensure(std::max<size_t>(open.mask_bytes, 128)));
+    HIPCHK(B.emask.ensure(std::max<size_t>(open.mask_bytes, 128)));
     // (pageable sources: these copies are done when the calls return - the vectors may go out of scope - and need no
     // stream synchronisation)
     if (!tabs.empty()) HIPCHK(hipMemcpy(B.tabs.p, tabs.data(), tabs.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
@@ -2156,7 +2226,8 @@ int VerifyRun::submit(size_t begin, size_t end, const uint64_t* offs, const uint
         if (cls[k].empty()) continue;
         VerifyClassLaunch L;
         L.cls = k;
-        L.on_aux = k != bulk && !serial_classes;
+        L.on_aux = k != bulk && !serial_classes && slice_cus == 0;
+        L.one_stream = slice_cus > 0;
         L.wpb = k >= 2 ? 1 : 4;
         const bool big = k == 3;  // index arrays in global memory (tvg_*_big.hip)
         // The waves pull pairs from a queue in this order.  A pair's cost grows with its match count (every
@@ -2181,7 +2252,8 @@ int VerifyRun::submit(size_t begin, size_t end, const uint64_t* offs, const uint
         auto waves_for = [&](size_t n, int waves_per_simd, size_t lds_block) {
             const uint32_t blocks_per_cu = (uint32_t)std::max<size_t>(
                 1, std::min<size_t>(4 * (size_t)waves_per_simd / L.wpb, (160 * 1024) / std::max<size_t>(lds_block, 1)));
-            uint32_t nw = (uint32_t)std::min<size_t>(n, (size_t)cus * blocks_per_cu * L.wpb);
+            const size_t use_cus = slice_cus > 0 ? (size_t)std::min(slice_cus, cus) : (size_t)cus;
+            uint32_t nw = (uint32_t)std::min<size_t>(n, use_cus * blocks_per_cu * L.wpb);
             return std::max<uint32_t>(L.wpb, (nw + L.wpb - 1) / L.wpb * L.wpb);
         };
         const bool run_fh = mode != 3;
@@ -2203,14 +2275,25 @@ int VerifyRun::submit(size_t begin, size_t end, const uint64_t* offs, const uint
     }
     t_lists += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
     slices.push_back(std::move(sl));
-    submitted = end;
+    open = OpenSlice{};
+    if (defer_launch) return AMC_OK;
     return launch_slice(si, ready);
+}
+
+int VerifyRun::submit(size_t begin, size_t end, const uint64_t* offs, const uint64_t* dev_off, const uint32_t* matches_dev,
+                      const uint32_t* matches_host, hipEvent_t ready) {
+    if (const int rc = add_pairs(begin, end, offs, dev_off, matches_dev, matches_host)) return rc;
+    return close_slice(ready);
 }
 
 // the launches of slice si: every class's E kernel(s), then - behind an event - its F/H kernel(s)
 int VerifyRun::launch_slice(size_t si, hipEvent_t ready) {
     const VerifySliceInfo& sl = slices[si];
     VerifySliceBufs& B = *c->vslices[si];
+    // (a slice confined to a few CUs beside a scan: one stream, E and F/H behind each other - two persistent grids side by
+    // side would want twice the CUs the scan left)
+    const bool one = !sl.launches.empty() && sl.launches[0].one_stream;
+    hipStream_t st_fh = one ? st_e : this->st_fh;
     if (!B.ev[0]) {
         for (auto& e : B.ev)
             if (hipEventCreate(&e) != hipSuccess) return fail(AMC_E_HIP, "amc_verify_pairs: hipEventCreate failed");
@@ -2281,8 +2364,8 @@ int VerifyRun::join() {
     hipStream_t st = c->stream;
     for (size_t si = 0; si < slices.size(); ++si) {
         VerifySliceBufs& B = *c->vslices[si];
-        if (st_fh != st) HIPCHK(hipStreamWaitEvent(st, B.ev[3], 0));
-        if (st_e != st) HIPCHK(hipStreamWaitEvent(st, B.ev[1], 0));
+        HIPCHK(hipStreamWaitEvent(st, B.ev[3], 0));
+        HIPCHK(hipStreamWaitEvent(st, B.ev[1], 0));
         if (B.aux_pending) {
             HIPCHK(hipStreamWaitEvent(st, B.ev_aux_done, 0));
             B.aux_pending = false;
@@ -2290,6 +2373,26 @@ int VerifyRun::join() {
     }
     HIPCHK(hipStreamSynchronize(st));
     return AMC_OK;
+}
+
+// The verification of pairs [begin, end) as machine-milliseconds (what the two kernels take with every CU: ~1.2 us per
+// pair + ~6 ns per match, bench.py's verify and pipeline legs), against the scan that will run beside it: the share of
+// the CUs that lets it finish within that scan, with 15 % to spare, between 8 and 96 CUs.  The scan is bound by the
+// chip's power budget, not by its CU count - 48 of 256 CUs cost it 8 % of its rate (profiles/r06/scan_grid_v1.txt) - so
+// the CUs it gives up are worth more to the verification than to the scan.
+int VerifyRun::plan_cus(size_t begin, size_t end, const uint64_t* offs, double next_scan_ms) const {
+    if (next_scan_ms <= 0.0) return 0;
+    if (const char* e = std::getenv("AMC_VERIFY_CUS")) return std::max(0, std::min(128, std::atoi(e)));  // (A/B hook)
+    double est = 0.0;
+    for (size_t p = begin; p < end; ++p) {
+        const uint64_t M = offs[p + 1] - offs[p];
+        if (!trivial((uint32_t)M)) est += 1.2e-3 + 6.0e-6 * (double)M;
+    }
+    if (est < 0.25) return 0;  // (a launch's fixed costs are not worth hiding)
+    // (confined to a few CUs the kernels do ~1.5x the work per CU they do with the whole machine - 35 ms x 256 CUs against
+    // 123 ms x 48, profiles/r06/ab_cus_v1.txt: fewer waves share the fabric their workspaces stream through)
+    const int v = (int)std::ceil((double)cus * 1.15 * est / (1.5 * next_scan_ms));
+    return std::max(8, std::min(96, v));
 }
 
 }  // namespace
@@ -2360,7 +2463,8 @@ static int verify_impl(amc_ctx* c, int mode, const uint32_t* slot1, const uint32
         run.st_fh = c->vstream[0] ? c->vstream[0] : st;
         size_t nver = 0;
         for (size_t p = 0; p < npairs; ++p) nver += !run.trivial((uint32_t)(match_offsets[p + 1] - match_offsets[p]));
-        int want = 4;
+        int want = 2;  // (measured on 124,750 pairs, kernels: 1 slice 433-439 ms, 2: 434-435, 4: 441, 8: 480 - profiles/r06/ab_pipeline_v1.txt;
+                       //  the whole call: 2 slices 446 ms against 449-456 for one and 451-452 for round 5's library, ab_prev_v1.txt)
         if (const char* e = std::getenv("AMC_TVG_SLICES")) want = std::max(1, std::min(kMaxVerifySlices, std::atoi(e)));
         const size_t min_per_slice = (size_t)run.cus * 12 * 2;  // two full F/H machine loads per slice
         const int ns = (int)std::max<size_t>(1, std::min<size_t>((size_t)want, nver / std::max<size_t>(min_per_slice, 1)));
@@ -2699,9 +2803,14 @@ int amc_match_verify_pairs(amc_ctx* c, const uint32_t* slot1, const uint32_t* sl
         if (rc != AMC_OK) amc_match_result_free(match_out);
         return rc;
     }
-    // The stages interleaved: the verification run is set up first (nothing of it depends on the matches), every match
-    // batch hands its pairs over as a slice while the next batch is scanned, and what remains after the last batch is
-    // that batch's slice, the packing and the download.
+    // The HOST sides of the two stages interleaved: the verification run is set up first (nothing of it depends on the
+    // matches), and every match batch hands its pairs over while the next batch is scanned - their checks, pair records,
+    // trial tables and size classes are done beside that scan.  ONE slice is closed and launched when the last batch
+    // is done (three slices of ~3,000 verified pairs each have three tails: 38.9 ms of kernels against 35.3 for one,
+    // profiles/r06/ab_final_v1.txt): on the device the stages stay behind each other, because the chip is bound by its
+    // power budget - verification beside a scan takes from the scan what it gets (profiles/r06/ab_cus_v2.txt: the scan
+    // leaving 24 .. 96 CUs to the verification of the batch before, 3 .. 8 batches, all within 1 % of the serial order).
+    // AMC_PIPELINE_INTERLEAVE=1 keeps that variant reachable for the A/B.
     std::memset(match_out, 0, sizeof *match_out);
     if (npairs > 0 && (!slot1 || !slot2)) return fail(AMC_E_INVALID, "amc_match_verify_pairs: NULL pair arrays");
     c->vres = amc::VerifyResident{};
@@ -2720,6 +2829,7 @@ int amc_match_verify_pairs(amc_ctx* c, const uint32_t* slot1, const uint32_t* sl
             return fail(AMC_E_INVALID, "amc_match_verify_pairs: pair %zu references slot out of range", p);
     int rc = run.begin(0);
     if (rc != AMC_OK) return rc;
+    const double t_setup = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
     run.st_e = c->vstream[0] ? c->vstream[0] : c->stream;
     run.st_fh = c->vstream[1] ? c->vstream[1] : run.st_e;
     VerifyPriv* priv = new (std::nothrow) VerifyPriv();
@@ -2740,19 +2850,41 @@ int amc_match_verify_pairs(amc_ctx* c, const uint32_t* slot1, const uint32_t* sl
         }
     } guard{c, priv, verify_out, match_out};
     std::vector<uint64_t> keep_off;
-    const BatchHook hook = [&](size_t begin, size_t end, const uint64_t* offsets, const uint64_t* koff, hipEvent_t ready) -> int {
-        // (the last slice slot is kept for whatever is left when the match call returns)
-        if (run.slices.size() + 1 >= (size_t)kMaxVerifySlices) return AMC_OK;
-        return run.submit(run.submitted, end, offsets, koff, c->d_keep.p ? c->d_keep.p : reinterpret_cast<const uint32_t*>(c->d_scalars),
-                          nullptr, ready);
+    const bool interleave = std::getenv("AMC_PIPELINE_INTERLEAVE") != nullptr;
+    run.defer_launch = !interleave;
+    BatchHook hook;
+    if (interleave) hook.plan = [&](size_t begin, size_t end, const uint64_t* offsets, double next_scan_ms) -> int {
+        if (run.slices.size() + 1 >= (size_t)kMaxVerifySlices) return 0;
         (void)begin;
+        return run.plan_cus(run.submitted, end, offsets, next_scan_ms);
+    };
+    hook.submit = [&](size_t begin, size_t end, const uint64_t* offsets, const uint64_t* koff, hipEvent_t ready, int cus_free) -> int {
+        // (the last slice slot is kept for whatever is left when the match call returns)
+        (void)begin;
+        if (run.slices.size() + 1 >= (size_t)kMaxVerifySlices) return AMC_OK;
+        const uint32_t* km = c->d_keep.p ? c->d_keep.p : reinterpret_cast<const uint32_t*>(c->d_scalars);
+        if (!interleave) return run.add_pairs(run.submitted, end, offsets, koff, km, nullptr);  // (host only; one slice, closed below)
+        run.slice_cus = cus_free;
+        return run.submit(run.submitted, end, offsets, koff, km, nullptr, ready);
     };
     rc = match_impl(c, slot1, slot2, npairs, match_opts, nullptr, 0.0, match_out, &keep_off, npairs ? &hook : nullptr);
     if (rc != AMC_OK) return rc;
     guard.match_done = true;
-    if (run.submitted < npairs) {
-        rc = run.submit(run.submitted, npairs, match_out->offsets, keep_off.data(),
-                        c->d_keep.p ? c->d_keep.p : reinterpret_cast<const uint32_t*>(c->d_scalars), nullptr, nullptr);
+    const double t_match = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+    {
+        const uint32_t* km = c->d_keep.p ? c->d_keep.p : reinterpret_cast<const uint32_t*>(c->d_scalars);
+        run.slice_cus = 0;
+        if (run.submitted < npairs) {
+            rc = run.add_pairs(run.submitted, npairs, match_out->offsets, keep_off.data(), km, nullptr);
+            if (rc != AMC_OK) return rc;
+        }
+        run.kernel_matches = km;  // (the resident table may have moved while it grew)
+        if (!interleave) {  // the one slice of this call: E and F/H behind each other on the ctx's stream
+            run.beside_match = false;
+            run.defer_launch = false;
+            run.st_e = run.st_fh = c->stream;
+        }
+        rc = run.close_slice(nullptr);
         if (rc != AMC_OK) return rc;
     }
     const double t_pre = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
@@ -2760,6 +2892,10 @@ int amc_match_verify_pairs(amc_ctx* c, const uint32_t* slot1, const uint32_t* sl
                        c->d_keep.p ? c->d_keep.p : reinterpret_cast<const uint32_t*>(c->d_scalars), keep_off.data(), t_pre);
     if (rc != AMC_OK) return rc;
     guard.p = nullptr;
+    if (std::getenv("AMC_VERIFY_PROFILE"))  // the call's timeline on the host (ms since entry)
+        std::fprintf(stderr, "[amc pipeline profile] pairs=%zu: verification set up at %.2f, match call back at %.2f, slice closed + launched at %.2f, "
+                     "results on the host at %.2f\n", npairs, t_setup, t_match, t_pre,
+                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count());
     return AMC_OK;
 }
 

@@ -230,7 +230,9 @@ struct CopyJob {
 };
 hipError_t launch_match_mfma(int mode, const SegDesc* segs, const uint32_t* nitems_dev, uint32_t max_items,
                        uint32_t* queue_head, uint32_t* accmask, const ScanAccept* accept_dev, hipStream_t s,
-                       const CopyJob& job = CopyJob(), uint32_t* copy_head = nullptr);
+                       const CopyJob& job = CopyJob(), uint32_t* copy_head = nullptr, int leave_cus = 0);
+// leave_cus: launch that many workgroups fewer than the device has CUs (a workgroup owns its CU): the CUs stay free for
+// what runs beside the scan - amc_match_verify_pairs' verification of the batch before
 int match_mfma_shape();  // waves per workgroup in use (8 or 4)
 
 hipError_t launch_resolve_index(int side, const ImageDev* imgs, const PairDev* pairs, uint32_t npairs,

@@ -761,7 +761,7 @@ int match_mfma_shape() {
 
 hipError_t launch_match_mfma(int mode, const SegDesc* segs, const uint32_t* nitems_dev, uint32_t max_items,
                              uint32_t* queue_head, uint32_t* accmask, const ScanAccept* accept_dev, hipStream_t s,
-                             const CopyJob& job_in, uint32_t* copy_head) {
+                             const CopyJob& job_in, uint32_t* copy_head, int leave_cus) {
     if (max_items == 0) return hipSuccess;  // (the caller checks: a job is only handed to a launch that happens)
     CopyJob job = (mode == 0 && copy_head) ? job_in : CopyJob();
     // The persistent workgroups pop from these two counters: nothing is launched unless both were reset.
@@ -770,7 +770,15 @@ hipError_t launch_match_mfma(int mode, const SegDesc* segs, const uint32_t* nite
     int dev = 0, cus = 256;
     if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
     if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
-    const uint32_t grid = max_items < (uint32_t)cus ? max_items : (uint32_t)cus;  // 1 WG per CU
+    // 1 WG per CU.  AMC_SCAN_GRID (A/B hook, read once): fewer workgroups - the CUs left over stay free for whatever
+    // else is in flight (round 6's question: does a power-bound scan lose less than its share of CUs?  DESIGN.md section 6)
+    static const int grid_cap = [] {
+        const char* e = std::getenv("AMC_SCAN_GRID");
+        return e ? std::atoi(e) : 0;
+    }();
+    if (grid_cap > 0 && grid_cap < cus) cus = grid_cap;
+    if (leave_cus > 0) cus = std::max(cus - leave_cus, cus / 2);
+    const uint32_t grid = max_items < (uint32_t)cus ? max_items : (uint32_t)cus;
     if (job.parts > grid) job.parts = grid;  // every part needs a workgroup
     if ((e = memset_async(queue_head, 0, sizeof(uint32_t), s)) != hipSuccess) return e;
     const bool w4 = match_mfma_shape() == 4;
