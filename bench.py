@@ -101,6 +101,8 @@ def executed_valu(kernel_s_per_pair):
             return None
         lane_ops_per_pair = pmc["valu_wave_instructions_per_pair"] * 64.0
         return {"valu_lane_ops_per_pair": lane_ops_per_pair, "source": str(pmc_path.relative_to(ROOT)),
+                "lane_utilisation": pmc.get("lane_utilisation"),
+                "read_bytes_per_pair": pmc.get("read_bytes_per_pair"), "write_bytes_per_pair": pmc.get("write_bytes_per_pair"),
                 "valu_lane_ops_per_s": lane_ops_per_pair / kernel_s_per_pair if kernel_s_per_pair > 0 else 0.0,
                 "frac_of_valu_issue_peak": (lane_ops_per_pair / kernel_s_per_pair) / FP64_NO_FMA_CEILING if kernel_s_per_pair > 0 else 0.0,
                 "note": "ALL vector instructions the two kernels executed (FP64, packed FP32, integer, moves), one lane-op per "
@@ -129,6 +131,15 @@ def fp64_roofline(work, kernel_s, launches, pairs=0):
                    "separately, not in the numerator.  Useful work per second, not issue rate"}
     if pairs:
         out["executed"] = executed_valu(kernel_s / pairs)
+        ex = out["executed"] or {}
+        if ex.get("read_bytes_per_pair") is not None:
+            # bytes through the L2's memory side per launch (a call = one E + one F/H launch: `launches` counts both), from
+            # the committed counter pass named in executed.source - workspaces and spill slots, not inputs
+            per_launch = pairs / max(launches, 1)
+            out["traffic"] = ex["read_bytes_per_pair"] * per_launch
+            out["traffic_written"] = ex["write_bytes_per_pair"] * per_launch
+            out["traffic_rate_tb_s"] = (ex["read_bytes_per_pair"] + ex["write_bytes_per_pair"]) * pairs / kernel_s / 1e12 if kernel_s > 0 else None
+            out["bound"] = "fp64 vector (VALU); no MFMA; workspace + spill traffic through the L2's memory side reported as `traffic`"
     return out
 
 
@@ -845,6 +856,7 @@ def config34_leg(args, config: int, steps: int, warmup: int, dist_state):
         kms, kl = st["match_kernel_ms"], st["match_kernel_launches"]
         parts = [(mine, off, m)]
         extra = {}
+        seq = (st["num_distances"], st["match_kernel_ms"], st["match_kernel_launches"], st["device_ms"])
         gathered = None
         if do_exchange:
             # sequential / exhaustive pairs have global positions: one all-gather of the tables, fed from device memory
@@ -867,8 +879,18 @@ def config34_leg(args, config: int, steps: int, warmup: int, dist_state):
             nd += vst["num_distances"] + lst["num_distances"]
             kms += vst["match_kernel_ms"] + lst["match_kernel_ms"]
             kl += vst["match_kernel_launches"] + lst["match_kernel_launches"]
+            def part(d, k, n, dev):   # one match call of the step: its forward scans against the int8 peak, and the call's device time
+                return {"distances": int(d), "scan_ms": round(k, 2), "scan_launches": int(n), "device_ms": round(dev, 2),
+                        "scan_frac": (d * OPS_PER_DISTANCE / (k * 1e-3) / INT8_DENSE_PEAK_OPS) if k > 0 else None}
             extra = dict(loop_queries=int(len(queries)), loop_scoring_pairs=int(len(q1)), loop_pairs=int(len(l1)),
-                         loop_scoring_distances=int(vst["num_distances"]), loop_match_distances=int(lst["num_distances"]))
+                         loop_scoring_distances=int(vst["num_distances"]), loop_match_distances=int(lst["num_distances"]),
+                         # where the step's scan time goes: 4096 x 4096 sequential pairs run at the headline's rate; the
+                         # loop-closure VOTING matches 512 x 512 images (two 256-row chunks of Y per item: the item's fixed
+                         # costs - X fragments, epilogue, 16 B of row table per row and pair - against a sixteenth of the scan)
+                         parts={"sequential": part(*seq), "loop_voting_512x512": part(vst["num_distances"], vst["match_kernel_ms"],
+                                                                                      vst["match_kernel_launches"], vst["device_ms"]),
+                                "loop_matches": part(lst["num_distances"], lst["match_kernel_ms"], lst["match_kernel_launches"],
+                                                     lst["device_ms"])})
             parts.append((None, loff, lm))
         if do_exchange and args.config == 4:
             # the loop pairs of a rank are numbered after those of the ranks before it (one small all-gather of the counts)
@@ -960,7 +982,98 @@ def config34_leg(args, config: int, steps: int, warmup: int, dist_state):
     return out
 
 
-def print_line(out):
+def _short(v, n=60):
+    return v if not isinstance(v, str) or len(v) <= n else v[:n - 1] + "~"
+
+
+def _num(v):
+    """floats to 5 significant digits (the line is read by people and by a driver that keeps its tail)"""
+    if isinstance(v, float):
+        return float(f"{v:.5g}")
+    if isinstance(v, list):
+        return [_num(x) for x in v]
+    if isinstance(v, dict):
+        return {k: _num(x) for k, x in v.items()}
+    return v
+
+
+def _pick(d, keys):
+    return {k: _short(d[k]) for k in keys if isinstance(d, dict) and k in d and d[k] is not None}
+
+
+def compact_line(out):
+    """The line as printed: every contract key, `roofline`, `cpu_baseline` and every leg with its value and the few scalars
+    a reader needs, strings cut to 60 characters, under 6 KB - the driver keeps known keys and the TAIL of stdout, and a
+    15 KB line of workload descriptions lost `verify.value` there (VERDICT r5).  The explanations are DESIGN.md section 5;
+    the detailed line is `--full-line` / `--detail-json`."""
+    c = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                             "vs_baseline", "dtype", "data") if k in out}
+    if "dry_run" in out:
+        c["dry_run"] = out["dry_run"]
+    cfg = out.get("config") or {}
+    c["config"] = {"workload": _short(cfg.get("workload", ""), 120), **_pick(cfg, ("pairs_total", "pairs_per_rank", "distances_total", "kernel",
+                                                                               "matches_rank0", "gather_path"))}
+    r = out.get("roofline")
+    c["roofline"] = None if r is None else _pick(r, ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_written", "algorithmic_bytes",
+                                                      "whole_step_frac", "avg_kernel_ms", "launches_per_step", "kernel", "traffic_source",
+                                                      "traffic_source_current", "frac_of_measured_i8_ceiling"))
+    if r is not None and "traffic" not in c["roofline"]:
+        c["roofline"]["traffic"] = None
+    b = out.get("cpu_baseline")
+    if b is not None:
+        c["cpu_baseline"] = _pick(b, ("value", "unit", "cores", "kind", "sample", "gpu_vs_oracle_mismatching_pairs", "optimised_value",
+                                      "optimised_identical_to_port", "default_cpu_matcher_value", "default_cpu_matcher_pairs_per_s"))
+    for name in ("config3", "config4"):
+        leg = out.get(name)
+        if leg is None:
+            continue
+        c[name] = _pick(leg, ("value", "unit", "scaling", "n_gpus", "steps", "ms_per_step", "exchange_ms_per_step", "per_rank_kernel_ms",
+                              "max_rank_kernel_ms", "rccl_ranks", "gather_path", "pairs_total", "gpu_vs_oracle_mismatching_pairs",
+                              "pairs_checked", "scan_frac_of_int8_peak", "dry_run"))
+        c[name]["workload"] = _short(leg.get("workload", ""), 100)
+        if leg.get("parts"):
+            c[name]["parts"] = {k: _pick(v, ("distances", "scan_ms", "device_ms", "scan_frac")) for k, v in leg["parts"].items()}
+    for k in ("config3_value", "config3_ms_per_step", "config3_exchange_ms_per_step", "config4_value"):
+        if k in out:
+            c[k] = out[k]
+    v = out.get("verify")
+    if v is not None:
+        vr = v.get("roofline") or {}
+        c["verify"] = {**_pick(v, ("value", "unit", "pairs", "steps", "ms_per_step", "kernel_ms_per_step", "mean_matches_per_pair",
+                                   "mean_trials_E_F_H", "roofline_frac")),
+                       "roofline": {**_pick(vr, ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_written", "frac_of_no_fma_ceiling",
+                                                 "flop_per_launch", "avg_kernel_ms")),
+                                    "valu_issue_frac": (vr.get("executed") or {}).get("frac_of_valu_issue_peak"),
+                                    "lane_utilisation": (vr.get("executed") or {}).get("lane_utilisation")},
+                       "with_relative_pose_value": (v.get("with_relative_pose") or {}).get("value"),
+                       "gpu_vs_oracle_mismatching_pairs": (v.get("cpu_baseline") or {}).get("gpu_vs_oracle_mismatching_pairs"),
+                       "cpu_value": (v.get("cpu_baseline") or {}).get("value")}
+        if "traffic" not in c["verify"]["roofline"]:
+            c["verify"]["roofline"]["traffic"] = None
+    p_ = out.get("pipeline")
+    if p_ is not None:
+        sm = p_.get("stage_ms_per_step") or {}
+        c["pipeline"] = {**_pick(p_, ("value", "unit", "pairs_total", "pairs_verified", "steps", "ms_per_step")),
+                         **{k: sm.get(k) for k in ("match_ms", "scan_ms", "cross_ms", "verify_ms", "verify_kernel_ms")},
+                         "non_scan_ms": (p_["ms_per_step"] - sm["scan_ms"]) if "scan_ms" in sm else None,
+                         "verify_frac_fp64": (p_.get("roofline") or {}).get("frac"),
+                         "guided_value": (p_.get("guided") or {}).get("value"),
+                         "cpu_value": (p_.get("cpu_baseline") or {}).get("value"),
+                         "gpu_vs_oracle_mismatching_pairs": (p_.get("cpu_baseline") or {}).get("gpu_vs_oracle_mismatching_pairs"),
+                         "verified_pairs_mismatching": (p_.get("cpu_baseline") or {}).get("verified_pairs_mismatching")}
+    for name, keys in (("ragged", ("value", "unit", "ms_per_step", "vs_uniform", "scan_frac_of_int8_peak", "scan_kernel_ms",
+                                   "resolve_select_reverse_scan_ms", "gpu_vs_oracle_mismatching_pairs", "pairs_checked")),
+                       ("sift_stats", ("value", "unit", "ms_per_step", "vs_headline", "scan_frac_of_int8_peak", "scan_kernel_ms",
+                                       "gpu_vs_oracle_mismatching_pairs", "pairs_checked")),
+                       ("dense", ("value", "unit", "ms_per_step", "matches_per_pair", "scan_kernel_ms", "resolve_select_reverse_scan_ms",
+                                  "gpu_vs_oracle_mismatching_pairs", "pairs_checked")),
+                       ("db", ("value", "unit", "wall_s", "rerun_wall_s", "pairs_with_matches", "pairs_verified", "error"))):
+        if out.get(name) is not None:
+            c[name] = _pick(out[name], keys)
+    return _num(c)
+
+
+def print_line(out, args=None):
     """The ONE JSON line, last thing on stdout (RCCL writes a version banner to the C stdout buffer, which would
     otherwise be flushed at exit AFTER it: drain that first)."""
     if out is None:
@@ -970,7 +1083,10 @@ def print_line(out):
         ctypes.CDLL(None).fflush(None)
     except OSError:
         pass
-    print(json.dumps(out), flush=True)
+    if args is not None and getattr(args, "detail_json", ""):
+        Path(args.detail_json).write_text(json.dumps(out) + "\n")
+    full = args is None or getattr(args, "full_line", False) or out.get("dry_run")
+    print(json.dumps(out if full else compact_line(out)), flush=True)
 
 
 def run_config34(args):
@@ -981,7 +1097,7 @@ def run_config34(args):
     if state[4]:
         dist.barrier()
         dist.destroy_process_group()
-    print_line(out)
+    print_line(out, args)
 
 
 def config3_summary(leg):
@@ -1030,6 +1146,11 @@ def main():
                     help="no GPU: run the multi-rank plumbing (sharding, exchange, reductions, JSON line) over gloo with the "
                          "CPU oracle in place of the kernels; prints value = null.  For tests/, with tiny --images/--feats")
     ap.add_argument("--no-pipeline", action="store_true", help="skip the chained configs[2] leg")
+    ap.add_argument("--no-config4", action="store_true", help="skip the one-step BASELINE configs[4] leg of the N=1 line")
+    ap.add_argument("--full-line", action="store_true",
+                    help="print the detailed line (every leg's workload text, notes and sub-objects: ~15 KB) instead of the "
+                         "compact one; --detail-json PATH writes it to a file beside the compact line")
+    ap.add_argument("--detail-json", default="", help="also write the detailed line to this file")
     ap.add_argument("--pipeline-steps", type=int, default=0, help="timed steps of the chained configs[2] leg (default: min(steps, 2))")
     ap.add_argument("--no-dense", action="store_true", help="skip the dense-overlap match leg")
     ap.add_argument("--no-ragged", action="store_true", help="skip the ragged-size match leg (n ~ U[2000, 6000])")
@@ -1132,6 +1253,12 @@ def main():
         steps3 = args.config3_steps if args.config3_steps > 0 else (1 if world == 1 else 2)
         c3 = config34_leg(args, 3, steps3, 0 if world == 1 else 1, state)
 
+    c4 = None
+    if world == 1 and not dry and not args.no_config4 and args.images == 500 and args.feats == 4096:
+        # BASELINE configs[4] (10,000 x 4096, sequential + loop matching) at N = 1, one step: what the driver's default
+        # line would otherwise never show (`--config 4` alone is the full line)
+        c4 = config34_leg(args, 4, 1, 0, state)
+
     out = None
     if rank == 0:
         off, m, st, _ = last
@@ -1195,6 +1322,10 @@ def main():
             out["config3_value"] = c3["value"]
             out["config3_ms_per_step"] = c3["ms_per_step"]
             out["config3_exchange_ms_per_step"] = c3["config"]["exchange_ms_per_step"]
+        if c4 is not None:
+            out["config4"] = config3_summary(c4)
+            out["config4"]["parts"] = c4["config"].get("parts")
+            out["config4_value"] = c4["value"]
         # HBM bytes per launch of the dominant kernel: PMC counters cannot be collected inside this process, so the
         # number comes from the committed rocprofv3 --pmc pass of this same command (profiles/*/pmc_hbm_*.json) - and
         # only while (i) this run launches the same shape and (ii) the kernel's source still hashes to what it was when
@@ -1299,7 +1430,7 @@ def main():
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
-    print_line(out)
+    print_line(out, args)
 
 
 if __name__ == "__main__":

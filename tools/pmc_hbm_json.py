@@ -14,8 +14,11 @@ for line in txt.splitlines():
     m = re.match(r"\s+(\S.*?)\s+(\w+)\s+n=(\d+)\s+sum=(\S+)\s+avg=(\S+)", line)
     if m and "match_mfma_kernel<0" in m.group(1):
         cnt[m.group(2)] = (int(m.group(3)), float(m.group(4)), float(m.group(5)))
-out = {"source": f"{Path(sys.argv[1]).name} (tools/pmc_r05.sh: rocprofv3 --kernel-trace --pmc, one counter group per pass; python bench.py "
-                 "--steps 1 --warmup 0 --no-cpu-baseline --verify-pairs 0 --no-pipeline --no-dense --no-ragged --no-sift-stats --no-config3)",
+box = next((ln[4:].strip() for ln in txt.splitlines() if ln.startswith("box:")), None)
+out = {"source": f"{Path(sys.argv[1]).name} (tools/pmc_r06.sh: rocprofv3 --kernel-trace --pmc, ONE counter per pass, every pass on the box named "
+                 "in `box`; python bench.py --steps 1 --warmup 0 --no-cpu-baseline --verify-pairs 0 --no-pipeline --no-dense --no-ragged "
+                 "--no-sift-stats --no-config3 --no-config4)",
+       "box": box, "passes_ok": txt.count("rc=0"), "passes": txt.count("rc="),
        "kernel": "match_mfma_kernel<0, 8, 4>"}
 # one step, no warm-up: the kernel's calls are the step's launches (two full batches, or - since the last batch of a
 # multi-batch call is a quarter-size one - three); the counters below are averages over them, like bench.py's
