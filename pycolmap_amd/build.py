@@ -138,5 +138,31 @@ def build_all(force: bool = False, verbose: bool = True) -> None:
     build_host(force=force, verbose=verbose)
 
 
+def clean_variants(verbose: bool = True) -> list[str]:
+    """Remove what the A/B tools leave under csrc/_obj/ beside the product's own objects: variant libraries
+    (tools/variant_build_tvg.sh, tools/diag_build.sh: libamc_<name>.so), their objects (<file>_<name>.o), the previous
+    revision's source copies and library (tools/ab_prev_lib.sh: prev_src/, libamc_prev.so; tools/ab_build.sh: *_prev.hip).
+    They are git-ignored but ride to the GPU box with every `gpurun` push and confuse anyone grepping csrc/ - run this
+    when an A/B is over (`python -m pycolmap_amd.build clean-variants`).  Returns the names it removed."""
+    keep = {Path(n).stem + ".o" for n in HIP_SOURCES} | {Path(n).stem + ".o.inputs" for n in HIP_SOURCES}
+    gone = []
+    if not OBJ.exists():
+        return gone
+    for f in sorted(OBJ.iterdir()):
+        if f.name in keep:
+            continue
+        if f.is_dir():
+            shutil.rmtree(f)
+        else:
+            f.unlink()
+        gone.append(f.name)
+    if verbose:
+        print(f"[build] removed {len(gone)} A/B artefacts from {OBJ.relative_to(ROOT)}: {' '.join(gone[:12])}{' ...' if len(gone) > 12 else ''}")
+    return gone
+
+
 if __name__ == "__main__":
-    build_all(force="--force" in sys.argv)
+    if "clean-variants" in sys.argv:
+        clean_variants()
+    else:
+        build_all(force="--force" in sys.argv)

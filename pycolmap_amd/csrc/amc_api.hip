@@ -2034,8 +2034,11 @@ int VerifyRun::begin(size_t) {
     // The sample stream: std::mt19937(seed)'s output words (operator() tempers them).  Every pair re-seeds (D4), so
     // they all read the same table; its length covers every RANSAC of a pair running to its trial cap, plus the
     // words a chunk draws ahead and a margin for Lemire rejections.  Kept across calls with the same seed.
-    const size_t stream_need = (size_t)5 * P.max_trials[0] + (size_t)7 * P.max_trials[1] + (size_t)4 * P.max_trials[2] +
-                               (size_t)P.max_trials[3] + 4 * 64 * 7 + 4096;
+    size_t stream_need = (size_t)5 * P.max_trials[0] + (size_t)7 * P.max_trials[1] + (size_t)4 * P.max_trials[2] +
+                         (size_t)P.max_trials[3] + 4 * 64 * 7 + 4096;
+    // (test hook: a table a quarter as long, so that long RANSACs run off it and the relaunch path - every slice again on
+    // a table twice as long - is exercised; production tables only ever overrun by a Lemire rejection streak)
+    if (std::getenv("AMC_TVG_STREAM_SHORT")) stream_need = std::max<size_t>(8192, stream_need / 4);
     if (stream_need > kMaxStreamWords)
         return fail(AMC_E_INVALID, "amc_verify_pairs: ransac.max_num_trials / min_inlier_ratio allow %zu draws per pair: "
                     "more than the sample-stream table holds (%zu)", stream_need, kMaxStreamWords);
@@ -2466,7 +2469,8 @@ static int verify_impl(amc_ctx* c, int mode, const uint32_t* slot1, const uint32
         int want = 2;  // (measured on 124,750 pairs, kernels: 1 slice 433-439 ms, 2: 434-435, 4: 441, 8: 480 - profiles/r06/ab_pipeline_v1.txt;
                        //  the whole call: 2 slices 446 ms against 449-456 for one and 451-452 for round 5's library, ab_prev_v1.txt)
         if (const char* e = std::getenv("AMC_TVG_SLICES")) want = std::max(1, std::min(kMaxVerifySlices, std::atoi(e)));
-        const size_t min_per_slice = (size_t)run.cus * 12 * 2;  // two full F/H machine loads per slice
+        size_t min_per_slice = (size_t)run.cus * 12 * 2;  // two full F/H machine loads per slice
+        if (const char* e = std::getenv("AMC_TVG_MIN_PER_SLICE")) min_per_slice = (size_t)std::max(1, std::atoi(e));  // (test hook)
         const int ns = (int)std::max<size_t>(1, std::min<size_t>((size_t)want, nver / std::max<size_t>(min_per_slice, 1)));
         if (ns <= 1) run.st_fh = st;  // one slice: E and F/H behind each other on the ctx's stream, as before
         // cut at equal shares of the verified pairs (the trivial ones cost nothing)

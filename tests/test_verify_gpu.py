@@ -404,9 +404,19 @@ def test_fused_match_verify_equals_the_two_calls(amc_ctx, monkeypatch, pose):
     off, m, _ = amc_ctx.match_pairs(s1, s2)
     tvg, mask, st = amc_ctx.verify_pairs(s1, s2, off, m, opts, seed=0)
     assert (tvg["config"] == 1).any() and (tvg["config"] >= 2).sum() >= 6     # DEGENERATE (too few matches) and real ones
-    for batch_entries in (None, "4096"):
+    # the shipped order (host sides interleaved, one slice behind the last batch), then with many small batches; the
+    # stages fully behind each other (AMC_PIPELINE_SERIAL); the device-interleaved variant kept for the A/B - slices
+    # beside the next batch's scan, more batches than slice slots (the rest joins the last slice), the scan leaving 16
+    # CUs to them
+    for batch_entries, variant in ((None, {}), ("4096", {}), ("4096", {"AMC_PIPELINE_SERIAL": "1"}),
+                                   ("4096", {"AMC_PIPELINE_INTERLEAVE": "1"}),
+                                   ("20000", {"AMC_PIPELINE_INTERLEAVE": "1", "AMC_VERIFY_CUS": "16"})):
         if batch_entries:
             monkeypatch.setenv("AMC_MATCH_BATCH_ENTRIES", batch_entries)
+        for k in ("AMC_PIPELINE_SERIAL", "AMC_PIPELINE_INTERLEAVE", "AMC_VERIFY_CUS"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in variant.items():
+            monkeypatch.setenv(k, v)
         foff, fm, fmst, ftvg, fmask, fst = amc_ctx.match_verify_pairs(s1, s2, opts, seed=0)
         np.testing.assert_array_equal(foff, off)
         np.testing.assert_array_equal(fm, m)
@@ -482,3 +492,70 @@ def test_large_coordinates_take_the_fp64_counting_loops(amc_ctx):
         tvg, mask, off, want = run_both(amc_ctx, scenes, priors, opts_kw={"ransac": {"max_error": 0.5}}, seed=1)
         for p in range(3):
             assert_pair_equal(p, tvg, mask, off, want)
+
+
+@pytest.mark.parametrize("slices", [2, 3, 7])
+def test_sliced_verification_equals_one_slice(amc_ctx, monkeypatch, slices):
+    """A verification call cut into slices (round 6: E launches on one stream, F/H launches on another, slice k's F/H
+    beside slice k + 1's E; per-slice tables, masks and workspaces; pairs no kernel looks at packed as DEGENERATE) returns
+    what one slice returns, bit for bit - a pair's result does not depend on the slice it ran in - and what the oracle
+    says.  Mixed batch: trivial pairs (< 15 matches) between real ones, a pair large enough for the class that runs on
+    the aux stream, uncalibrated pairs that skip the E kernel."""
+    rng = np.random.default_rng(31)
+    scenes, priors = [], []
+    for k in range(23):
+        if k % 5 == 2:
+            scenes.append(synth.two_view_scene(rng, num_inliers=int(rng.integers(0, 8)), num_outliers=int(rng.integers(0, 6))))
+        elif k == 11:
+            scenes.append(synth.two_view_scene(rng, num_inliers=2100, num_outliers=700))
+        else:
+            scenes.append(synth.two_view_scene(rng, num_inliers=int(rng.integers(20, 260)), num_outliers=int(rng.integers(10, 120)),
+                                               planar=bool(k % 4 == 0)))
+        priors.append(k % 3 != 0)
+    monkeypatch.setenv("AMC_TVG_SLICES", "1")
+    tvg1, mask1, off, want = run_both(amc_ctx, scenes, priors)
+    for p in range(len(scenes)):
+        assert_pair_equal(p, tvg1, mask1, off, want)
+    assert (tvg1["config"] == 1).sum() >= 4 and (tvg1["config"] >= 2).sum() >= 12
+    monkeypatch.setenv("AMC_TVG_SLICES", str(slices))
+    monkeypatch.setenv("AMC_TVG_MIN_PER_SLICE", "1")
+    slots, cams = build_batch(scenes, priors)
+    s1 = np.arange(0, len(slots), 2, dtype=np.uint32)
+    matches = np.concatenate([sc["matches"] for sc in scenes])
+    for opts in (_capi.tvg_options(), _capi.tvg_options(compute_relative_pose=1)):
+        if opts.compute_relative_pose:
+            monkeypatch.setenv("AMC_TVG_SLICES", "1")
+            want_tvg, want_mask, want_st = amc_ctx.verify_pairs(s1, s1 + 1, off, matches, opts, seed=0)
+            monkeypatch.setenv("AMC_TVG_SLICES", str(slices))
+        else:
+            want_tvg, want_mask, want_st = tvg1, mask1, None
+        tvg, mask, st = amc_ctx.verify_pairs(s1, s1 + 1, off, matches, opts, seed=0)
+        assert tvg.tobytes() == want_tvg.tobytes() or all(
+            np.array_equal(bits(tvg[f]), bits(want_tvg[f])) if f in "EFH" else np.array_equal(tvg[f], want_tvg[f]) for f in tvg.dtype.names)
+        np.testing.assert_array_equal(mask, want_mask)
+        if want_st is not None:
+            assert st["work"] == want_st["work"]
+            for f in ("qvec", "tvec", "tri_angle"):
+                np.testing.assert_array_equal(bits(st["pose"][f]), bits(want_st["pose"][f]), err_msg=f)
+
+
+def test_a_short_sample_stream_is_relaunched_on_a_longer_one(monkeypatch):
+    """A RANSAC that runs off the sample-stream table flags it and the call lays out a table twice as long and runs every
+    slice again (in production only a streak of Lemire rejections gets there).  AMC_TVG_STREAM_SHORT builds the first
+    table a quarter as long as the trial caps need: pairs with few inliers run to the cap, overrun, and the relaunch -
+    two slices here - must return exactly what a full-length table returns."""
+    rng = np.random.default_rng(41)
+    scenes = [synth.two_view_scene(rng, num_inliers=int(rng.integers(16, 40)), num_outliers=int(rng.integers(150, 260))) for _ in range(9)]
+    scenes += [synth.two_view_scene(rng, num_inliers=150, num_outliers=30) for _ in range(3)]
+    priors = [True] * len(scenes)
+    with _capi.Context(0) as ctx:
+        tvg, mask, off, want = run_both(ctx, scenes, priors, seed=5)
+    assert max(int(t["num_trials"][1]) for t in tvg) > 4000          # some F RANSAC ran (nearly) to its cap
+    monkeypatch.setenv("AMC_TVG_STREAM_SHORT", "1")
+    monkeypatch.setenv("AMC_TVG_SLICES", "2")
+    monkeypatch.setenv("AMC_TVG_MIN_PER_SLICE", "1")
+    with _capi.Context(0) as ctx:                                      # (a fresh context: no table of the full length around)
+        tvg2, mask2, off2, _ = run_both(ctx, scenes, priors, seed=5)
+    for p in range(len(scenes)):
+        assert_pair_equal(p, tvg2, mask2, off2, want)
+    np.testing.assert_array_equal(mask2, mask)

@@ -17,7 +17,7 @@ run() {
   done
   echo "rc=$rc tries=$try" >> $OUT
   echo "=== pass $tag: $@" >> $OUT
-  [ -n "$db" ] && python $R/tools/pmc_summary.py $db amc:: | grep -E "resolve_index|match_mfma_kernel<|finalize_kernel|select_candidates" | sed -E 's/\(amc::[^)]*\)?[^ ]* +/ /' | cut -c1-230 >> $OUT
+  [ -n "$db" ] && python $R/tools/pmc_dispatches.py $db resolve_index match_mfma_kernel finalize_kernel select_candidates >> $OUT
 }
 run f FETCH_SIZE
 run r TCC_EA0_RDREQ_sum
@@ -25,6 +25,7 @@ run w TCC_EA0_WRREQ_sum
 run w64 TCC_EA0_WRREQ_64B_sum
 run h TCC_HIT_sum
 run m TCC_MISS_sum
+run t GRBM_GUI_ACTIVE
 run i SQ_INSTS_VALU_MFMA_I8 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE
 python -c "
 import json; d=json.loads(open('/tmp/dense_line.json').read())['dense']; print('dense leg under the profiler:', {k: d[k] for k in ('ms_per_step','matches_per_pair','scan_kernel_ms','resolve_select_reverse_scan_ms')})" >> $OUT 2>/dev/null

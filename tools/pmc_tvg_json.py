@@ -16,13 +16,14 @@ PAIRS = 16384
 
 
 def main(txt):
-    out = {"source": f"{txt} (tools/pmc_tvg_r0N.sh: rocprofv3 --kernel-trace --pmc, one counter group per pass; python bench.py "
-                     "--images 40 --steps 1 --warmup 0 --no-cpu-baseline --verify-pairs 16384 --no-pipeline --no-dense)",
+    out = {"source": f"{txt} (tools/pmc_tvg_r0N.sh: rocprofv3 --kernel-trace --pmc, one counter group per pass; AMC_TVG_SLICES=1 python bench.py "
+                     "--images 40 --steps 1 --warmup 0 --no-cpu-baseline --verify-pairs 16384 --no-pipeline --no-dense: one E and one F/H "
+                     "launch per call, behind each other - the per-kernel occupancy figures are those of a kernel alone on the machine)",
            "workload": "16,384 pairs of bench.py's verify leg (4096 distinct seeded calibrated scenes, ~420 matches)",
            "pairs_per_call": PAIRS,
            "units": "per-call averages; SQ_* cycle counters are in quad-cycles (x4 = shader clocks), summed over all SIMDs; "
                     "GRBM_GUI_ACTIVE is summed over the 8 XCDs"}
-    pat = re.compile(r"amc::(tvg_(?:e|fh)_kernel)\S*.*?\s(SQ_\w+|GRBM_\w+)\s+n=(\d+)\s+sum=(\S+)\s+avg=(\S+)")
+    pat = re.compile(r"amc::(tvg_(?:e|fh)_kernel)\S*.*?\s(SQ_\w+|GRBM_\w+|FETCH_SIZE|TCC_\w+)\s+n=(\d+)\s+sum=(\S+)\s+avg=(\S+)")
     tim = re.compile(r"amc::(tvg_(?:e|fh)_kernel)\(.*calls=(\d+)\s+total=(\S+)\s+avg=(\S+)")
     for line in Path(txt).read_text().splitlines():
         m = pat.search(line)

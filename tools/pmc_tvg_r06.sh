@@ -9,7 +9,7 @@ run() {
   tag=$1; shift
   for try in 1 2 3; do
     rm -rf /tmp/pmct_$tag
-    timeout 300 rocprofv3 --kernel-trace --pmc "$@" -d /tmp/pmct_$tag -- python $R/bench.py --images 40 --steps 1 --warmup 0 --no-cpu-baseline --verify-pairs 16384 --no-pipeline --no-dense --no-ragged --no-db --no-sift-stats --no-config3 > /tmp/pmct_$tag.log 2>&1
+    AMC_TVG_SLICES=1 timeout 300 rocprofv3 --kernel-trace --pmc "$@" -d /tmp/pmct_$tag -- python $R/bench.py --images 40 --steps 1 --warmup 0 --no-cpu-baseline --verify-pairs 16384 --no-pipeline --no-dense --no-ragged --no-db --no-sift-stats --no-config3 > /tmp/pmct_$tag.log 2>&1
     rc=$?
     db=$(find /tmp/pmct_$tag -name "*.db" 2>/dev/null | head -1)
     [ -n "$db" ] && break
