@@ -112,8 +112,16 @@ struct Wave {
     uint8_t* masks;    // 4 x mcap
     uint32_t mcap;
 };
-// per-wave global workspace: SoA point arrays (doubles, mcap each) ...
+// per-wave global workspace: two point regions of mcap correspondences - the pair's matched points and the watermark
+// test's inlier subset - as ARRAYS OF RECORDS, (x1, y1, x2, y2) in 32 bytes (round 6; four arrays of mcap doubles
+// before).  The minimal solvers gather their samples from here, every lane another correspondence: a record is one
+// 64-byte line per lane where the four arrays were four, and the regions of a CU's waves together (13.5 KB each at 420
+// matches, 384 F/H waves per XCD) are far beyond the XCD's 4 MB of L2 - these gathers were most of the kernels' reads
+// from the memory side (profiles/r06/pmc_tvg_r06.json) ...
 enum : int { W_X1 = 0, W_Y1, W_X2, W_Y2, W_AX1, W_AY1, W_AX2, W_AY2, W_NUM_ARRAYS };
+struct alignas(32) PtRec {
+    double x1, y1, x2, y2;
+};
 // ... then the tables the counting loops read through the scalar cache: (x1, y1, x2, y2) as doubles, one 32-byte
 // record per correspondence, and the packed-FP32 table of the homography pre-filter (16 bytes per correspondence,
 // two correspondences interleaved: a0 a1 b0 b1 c0' c1' d0' d1'), then the chunk's models (E / F: kMaxModels per trial)
@@ -121,6 +129,8 @@ __host__ __device__ inline size_t tvg_ws_doubles(uint32_t mcap) {
     return (size_t)W_NUM_ARRAYS * mcap + (size_t)4 * mcap + (size_t)2 * mcap + kModelDoubles;
 }
 __device__ __forceinline__ double* ws_arr(const Wave& w, int a) { return w.ws + (size_t)a * w.mcap; }
+// the two point regions (W_X1 .. W_Y2 and W_AX1 .. W_AY2 as blocks of 4 x mcap doubles: mcap records)
+__device__ __forceinline__ PtRec* ws_pts(const Wave& w, int region) { return reinterpret_cast<PtRec*>(w.ws + (size_t)region * 4 * w.mcap); }
 // the essential-matrix kernel's waves: the model region doubles as the staging area of the minimal solver's
 // constraint matrices (64 problems x (10 x 20 matrix + 6 x 10 result), element-major: e5_eliminate_quads)
 constexpr int kE5StageG = 200, kE5StageHl = 60;
@@ -503,8 +513,8 @@ __device__ __noinline__ SamplerState sample_chunk(const uint32_t* stream_, uint3
 
 // ---- the active RANSAC's correspondences: four arrays in the wave's global workspace -----------------
 struct Pts {
-    const double* g;   // x1 | y1 | x2 | y2, each `gs` long
-    uint32_t gs;
+    const double* g;   // records of (x1, y1, x2, y2), 32-byte aligned (PtRec)
+    uint32_t gs;       // (capacity of the region: unused by the record layout)
 };
 __device__ __forceinline__ Pts uni(Pts P) {
     Pts Q;
@@ -513,7 +523,11 @@ __device__ __forceinline__ Pts uni(Pts P) {
     return Q;
 }
 __device__ __forceinline__ void load_pt(const Pts& P, int k, double& a, double& b, double& c, double& d) {
-    a = P.g[k]; b = P.g[P.gs + k]; c = P.g[2 * (size_t)P.gs + k]; d = P.g[3 * (size_t)P.gs + k];
+#if defined(AMC_TVG_ABL_PTS)  // timing ablation (results wrong by construction): every point read hits the same four cache lines
+    k &= 7;
+#endif
+    const PtRec r = reinterpret_cast<const PtRec*>(P.g)[k];  // two 16-byte loads from one line
+    a = r.x1; b = r.y1; c = r.x2; d = r.y2;
 }
 
 template <int KIND>
@@ -2002,24 +2016,23 @@ __device__ Report lo_ransac(Wave& w_io, const RansacCfg& cfg, const double* gx, 
     // the tables of the counting loops (read back through the scalar cache), and the pair's largest |coordinate|
     int fast_count = 0;
     double cmax = 0.0;
-    double* p64 = ws_p64(w);
+    // (the FP64 table of the counting loops IS the point region since the points are records: no second copy - 13.5 KB
+    // less per wave to keep in the L2)
+    const double* p64 = gx;
     float* p32 = ws_p32(w);
     {
         const double s = 1.0 / dsqrt(cfg.max_res);
         double amax = 0.0;
         for (int k = lane; k < M + (M & 1); k += 64) {
             const int kk = k < M ? k : M - 1;  // odd M: the pre-filter table's last pair repeats the last point
-            const double p0 = gx[kk], p1 = gx[gstride + kk], p2 = gx[2 * (size_t)gstride + kk], p3 = gx[3 * (size_t)gstride + kk];
+            const PtRec rk = reinterpret_cast<const PtRec*>(gx)[kk];
+            const double p0 = rk.x1, p1 = rk.y1, p2 = rk.x2, p3 = rk.y2;
             if (EST == K_H) {
                 float* q = p32 + 8 * (size_t)(k >> 1) + (k & 1);
                 q[0] = (float)p0; q[2] = (float)p1; q[4] = (float)(p2 * s); q[6] = (float)(p3 * s);
             } else if (EST != K_T) {
                 float* q = p32 + 8 * (size_t)(k >> 1) + (k & 1);   // the Sampson pre-filter's table: plain coordinates
                 q[0] = (float)p0; q[2] = (float)p1; q[4] = (float)p2; q[6] = (float)p3;
-                if (k < M) {
-                    double* q64 = p64 + 4 * (size_t)k;
-                    q64[0] = p0; q64[1] = p1; q64[2] = p2; q64[3] = p3;
-                }
             }
             amax = dmax(dmax(amax, dmax(dabs(p0), dabs(p1))), dmax(dabs(p2), dabs(p3)));
         }

@@ -29,7 +29,7 @@ __device__ __noinline__ void process_pair_e(Wave& w, uint32_t q, const TvgImage*
     // ---- Camera::CamFromImg of the matched points.  SIMPLE_PINHOLE / PINHOLE: (x - c) / f of the keypoint
     //      (FeatureKeypointsToPointsVector: float -> double).  Cameras with distortion parameters: the keypoints
     //      were lifted once per image (kpn), gather from there.
-    double *N1x = ws_arr(w, W_X1), *N1y = ws_arr(w, W_Y1), *N2x = ws_arr(w, W_X2), *N2y = ws_arr(w, W_Y2);
+    PtRec* NP = ws_pts(w, 0);  // (x1, y1, x2, y2) records, normalised
     const uint32_t* mm = matches + 2 * pr.match_off;
     bool bad = false;
     {
@@ -53,22 +53,22 @@ __device__ __noinline__ void process_pair_e(Wave& w, uint32_t q, const TvgImage*
                 continue;
             }
             if (kn1) {
-                N1x[k] = kn1[2 * (size_t)i1];
-                N1y[k] = kn1[2 * (size_t)i1 + 1];
+                NP[k].x1 = kn1[2 * (size_t)i1];
+                NP[k].y1 = kn1[2 * (size_t)i1 + 1];
             } else {
                 const double x = kd1 ? kd1[2 * (size_t)i1] : (double)kp1[2 * (size_t)i1];
                 const double y = kd1 ? kd1[2 * (size_t)i1 + 1] : (double)kp1[2 * (size_t)i1 + 1];
-                N1x[k] = (x - c1x) / f1x;
-                N1y[k] = (y - c1y) / f1y;
+                NP[k].x1 = (x - c1x) / f1x;
+                NP[k].y1 = (y - c1y) / f1y;
             }
             if (kn2) {
-                N2x[k] = kn2[2 * (size_t)i2];
-                N2y[k] = kn2[2 * (size_t)i2 + 1];
+                NP[k].x2 = kn2[2 * (size_t)i2];
+                NP[k].y2 = kn2[2 * (size_t)i2 + 1];
             } else {
                 const double x = kd2 ? kd2[2 * (size_t)i2] : (double)kp2[2 * (size_t)i2];
                 const double y = kd2 ? kd2[2 * (size_t)i2 + 1] : (double)kp2[2 * (size_t)i2 + 1];
-                N2x[k] = (x - c2x) / f2x;
-                N2y[k] = (y - c2y) / f2y;
+                NP[k].x2 = (x - c2x) / f2x;
+                NP[k].y2 = (y - c2y) / f2y;
             }
         }
     }
@@ -100,7 +100,7 @@ __device__ __noinline__ void process_pair_e(Wave& w, uint32_t q, const TvgImage*
     cfg.max_res = e_err * e_err;
     cfg.max_trials = P.max_trials[0];
     cfg.dyn_tab = trial_tabs + pr.tab_off[0];
-    const Report E_rep = lo_ransac<K_E5, K_E5>(w, cfg, N1x, mcap, M, maskE);
+    const Report E_rep = lo_ransac<K_E5, K_E5>(w, cfg, &NP[0].x1, mcap, M, maskE);
     if (lane == 0) {
         TvgEState* es = estate + oq;
         for (int i = 0; i < 9; ++i) es->model[i] = E_rep.model[i];

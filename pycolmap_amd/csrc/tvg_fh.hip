@@ -46,7 +46,8 @@ __device__ __noinline__ void process_pair_fh(Wave& w, uint32_t q, const TvgImage
         return;
     }
     // ---- matched points (FeatureKeypointsToPointsVector: float -> double) ------------------
-    double *X1 = ws_arr(w, W_X1), *Y1 = ws_arr(w, W_Y1), *X2 = ws_arr(w, W_X2), *Y2 = ws_arr(w, W_Y2);
+    PtRec* XP = ws_pts(w, 0);  // (x1, y1, x2, y2) records, pixels
+    const double* X1 = &XP[0].x1;
     const uint32_t* mm = matches + 2 * pr.match_off;
     // The indices are checked here, where they are read anyway (the host only checks the pairs that
     // return above): a pair with a match past an image's keypoints is counted and not estimated - the
@@ -64,10 +65,12 @@ __device__ __noinline__ void process_pair_fh(Wave& w, uint32_t q, const TvgImage
                 bad = true;
                 continue;
             }
-            X1[k] = kd1 ? kd1[2 * (size_t)i1] : (double)kp1[2 * (size_t)i1];
-            Y1[k] = kd1 ? kd1[2 * (size_t)i1 + 1] : (double)kp1[2 * (size_t)i1 + 1];
-            X2[k] = kd2 ? kd2[2 * (size_t)i2] : (double)kp2[2 * (size_t)i2];
-            Y2[k] = kd2 ? kd2[2 * (size_t)i2 + 1] : (double)kp2[2 * (size_t)i2 + 1];
+            PtRec r;
+            r.x1 = kd1 ? kd1[2 * (size_t)i1] : (double)kp1[2 * (size_t)i1];
+            r.y1 = kd1 ? kd1[2 * (size_t)i1 + 1] : (double)kp1[2 * (size_t)i1 + 1];
+            r.x2 = kd2 ? kd2[2 * (size_t)i2] : (double)kp2[2 * (size_t)i2];
+            r.y2 = kd2 ? kd2[2 * (size_t)i2 + 1] : (double)kp2[2 * (size_t)i2 + 1];
+            XP[k] = r;
         }
     }
     if (__any(bad)) {
@@ -208,7 +211,8 @@ __device__ __noinline__ void process_pair_fh(Wave& w, uint32_t q, const TvgImage
             const double maxx1 = (double)w1 - minx1, maxy1 = (double)h1 - miny1;
             const double minx2 = P.watermark_border_size * diagonal2, miny2 = minx2;
             const double maxx2 = (double)w2 - minx2, maxy2 = (double)h2 - miny2;
-            double *ix1 = ws_arr(w, W_AX1), *iy1 = ws_arr(w, W_AY1), *ix2 = ws_arr(w, W_AX2), *iy2 = ws_arr(w, W_AY2);
+            PtRec* IP = ws_pts(w, 1);  // the inlier subset, same record layout
+            const double* ix1 = &IP[0].x1;
             int basep = 0, border = 0;
             for (int k0 = 0; k0 < M; k0 += 64) {
                 const int k = k0 + lane;
@@ -216,9 +220,10 @@ __device__ __noinline__ void process_pair_fh(Wave& w, uint32_t q, const TvgImage
                 const unsigned long long bal = __ballot(in);
                 if (in) {
                     const int pos = basep + __popcll(bal & ((1ull << lane) - 1ull));
-                    ix1[pos] = X1[k]; iy1[pos] = Y1[k]; ix2[pos] = X2[k]; iy2[pos] = Y2[k];
-                    if (!in_bbox(X1[k], Y1[k], minx1, maxx1, miny1, maxy1) &&
-                        !in_bbox(X2[k], Y2[k], minx2, maxx2, miny2, maxy2))
+                    const PtRec r = XP[k];
+                    IP[pos] = r;
+                    if (!in_bbox(r.x1, r.y1, minx1, maxx1, miny1, maxy1) &&
+                        !in_bbox(r.x2, r.y2, minx2, maxx2, miny2, maxy2))
                         ++border;
                 }
                 basep += __popcll(bal);
