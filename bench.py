@@ -360,9 +360,21 @@ def pipeline_leg(ctx_factory, steps: int, warmup: int, cpu_pairs: int, num_image
         ctx.match_verify_pairs(s1, s2, opts)
     t0 = time.perf_counter()
     acc = dict(match_ms=0.0, scan_ms=0.0, cross_ms=0.0, verify_ms=0.0, verify_kernel_ms=0.0, launches=0)
+    tl = dict(c_call_ms=0.0, verify_setup_ms=0.0, match_call_ms=0.0, close_and_launch_ms=0.0, verify_wait_pack_download_ms=0.0,
+              batch_handover_host_ms_hidden=0.0, python_free_previous_ms=0.0, step_ms_max=0.0)
     for _ in range(steps):
+        ts0 = time.perf_counter()
         off = m = tvg = mask = vst = None                          # release the previous results first
+        tl["python_free_previous_ms"] += 1e3 * (time.perf_counter() - ts0)
         off, m, mst, tvg, mask, vst = ctx.match_verify_pairs(s1, s2, opts, copy=False)   # views, as a C++ caller reads the results
+        tl["step_ms_max"] = max(tl["step_ms_max"], 1e3 * (time.perf_counter() - ts0))
+        if hasattr(ctx, "last_timeline"):   # the library's own clock inside the call (amc_ctx_last_timeline)
+            t_ = ctx.last_timeline()
+            tl["c_call_ms"] += t_["call_returned"]; tl["verify_setup_ms"] += t_["verify_setup_done"]
+            tl["match_call_ms"] += t_["match_returned"] - t_["verify_setup_done"]
+            tl["close_and_launch_ms"] += t_["verify_launched"] - t_["match_returned"]
+            tl["verify_wait_pack_download_ms"] += t_["verify_results_on_host"] - t_["verify_launched"]
+            tl["batch_handover_host_ms_hidden"] += t_["batch_handover_host_ms_hidden"]
         acc["match_ms"] += mst["device_ms"]; acc["scan_ms"] += mst["match_kernel_ms"]; acc["cross_ms"] += mst["cross_kernel_ms"]
         acc["verify_ms"] += vst["device_ms"]; acc["verify_kernel_ms"] += vst["kernel_ms"]; acc["launches"] += vst["kernel_launches"]
     dt = time.perf_counter() - t0
@@ -378,6 +390,10 @@ def pipeline_leg(ctx_factory, steps: int, warmup: int, cpu_pairs: int, num_image
         "pairs_total": int(len(s1)), "pairs_verified": nver, "steps": steps, "ms_per_step": 1e3 * dt / steps,
         "distances_per_s_whole_pipeline": float(mst["num_distances"]) * steps / dt,
         "stage_ms_per_step": {k: v / steps for k, v in acc.items() if k != "launches"},
+        # where a step's wall time goes on the HOST (the library's clock inside the call + Python around it): the call's
+        # phases add up to c_call_ms; ms_per_step - c_call_ms is Python (argument conversion, result views, freeing the
+        # previous results); step_ms_max is the slowest step (a stall shows there, not in the kernels' spans)
+        "host_timeline_ms_per_step": {k: (v if k == "step_ms_max" else v / steps) for k, v in tl.items()},
         "matches_per_verified_pair": {"mean": float(counts[ver].mean()) if nver else 0.0,
                                       "max": int(counts.max()) if len(counts) else 0},
         "mean_inliers_per_verified_pair": float(tvg["num_inliers"][ver].mean()) if nver else 0.0,
@@ -1056,6 +1072,10 @@ def compact_line(out):
         c["pipeline"] = {**_pick(p_, ("value", "unit", "pairs_total", "pairs_verified", "steps", "ms_per_step")),
                          **{k: sm.get(k) for k in ("match_ms", "scan_ms", "cross_ms", "verify_ms", "verify_kernel_ms")},
                          "non_scan_ms": (p_["ms_per_step"] - sm["scan_ms"]) if "scan_ms" in sm else None,
+                         "host": _pick(p_.get("host_timeline_ms_per_step") or {}, ("c_call_ms", "verify_setup_ms", "match_call_ms",
+                                                                                    "close_and_launch_ms", "verify_wait_pack_download_ms",
+                                                                                    "batch_handover_host_ms_hidden", "python_free_previous_ms",
+                                                                                    "step_ms_max")),
                          "verify_frac_fp64": (p_.get("roofline") or {}).get("frac"),
                          "guided_value": (p_.get("guided") or {}).get("value"),
                          "cpu_value": (p_.get("cpu_baseline") or {}).get("value"),

@@ -415,6 +415,14 @@ int amc_match_verify_pairs(amc_ctx* ctx, const uint32_t* slot1, const uint32_t* 
                            const amc_match_opts* match_opts, const amc_tvg_opts* tvg_opts, uint32_t seed,
                            amc_match_result* match_out, amc_verify_result* verify_out);
 
+/* Host-side timeline of the LAST amc_match_verify_pairs call on this ctx, milliseconds since the call was entered (what
+ * the kernels' own spans in the two results do not show - VERDICT r5 asked where the milliseconds between them go):
+ *   [0] verification set up (options, sample stream, image table, zeroed records)   [1] the match call returned
+ *   [2] the verification slice closed (class lists, uploads) and launched            [3] verification results on the host
+ *   [4] the call returned   [5] host time of the per-batch hand-over, hidden beside the scans (not a point in time)
+ *   [6], [7] reserved (0).  All zero before the first such call. */
+int amc_ctx_last_timeline(amc_ctx* ctx, double out_ms[8]);
+
 /* EstimateTwoViewGeometryPose (/root/reference/pycolmap/estimators/two_view_geometry.h:153-159) on given
  * geometries: geoms[p] supplies config, E and H; inlier_matches (CSR, as amc_verify_pairs' matches)
  * are the geometry's inlier_matches.  Both images need points and a camera.

@@ -31,7 +31,7 @@ EXPORTED_SYMBOLS = [
     "amc_cam_from_img", "amc_match_verify_pairs", "amc_ctx_trim", "amc_ctx_resident_matches",
     "amc_homography_decomposition", "amc_img_from_cam",
     "amc_comm_unique_id", "amc_comm_create", "amc_comm_destroy", "amc_allgather_match_tables", "amc_gathered_tables_free",
-    "amc_allgather_pair_records", "amc_gathered_records_free", "amc_allgather_inlier_tables",
+    "amc_allgather_pair_records", "amc_gathered_records_free", "amc_allgather_inlier_tables", "amc_ctx_last_timeline",
 ]
 COMM_ID_BYTES = 128
 RANSAC_F, RANSAC_H, RANSAC_E = 0, 1, 2
@@ -197,6 +197,8 @@ def load() -> C.CDLL:
     lib.amc_ctx_trim.restype = C.c_int
     lib.amc_ctx_resident_matches.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.amc_ctx_resident_matches.restype = C.c_int
+    if hasattr(lib, "amc_ctx_last_timeline"):
+        lib.amc_ctx_last_timeline.argtypes = [C.c_void_p, C.c_void_p]
     lib.amc_ctx_reserve_slots.argtypes = [C.c_void_p, C.c_uint32]
     lib.amc_ctx_grow_slots.argtypes = [C.c_void_p, C.c_uint32]
     lib.amc_upload_descriptors.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
@@ -454,6 +456,13 @@ class Context:
 
     def set_stream(self, hip_stream: int | None) -> None:
         _check(self._lib.amc_ctx_set_stream(self._h, C.c_void_p(hip_stream or 0)))
+
+    def last_timeline(self) -> dict:
+        """amc_ctx_last_timeline: the host-side timeline of the last match_verify_pairs call (ms since its entry)."""
+        buf = (C.c_double * 8)()
+        _check(self._lib.amc_ctx_last_timeline(self._h, buf))
+        return dict(verify_setup_done=buf[0], match_returned=buf[1], verify_launched=buf[2], verify_results_on_host=buf[3],
+                    call_returned=buf[4], batch_handover_host_ms_hidden=buf[5])
 
     def resident_matches(self):
         """(device pointer, number of matches) of the last match call's table in device memory (amc_ctx_resident_matches):

@@ -188,12 +188,14 @@ struct PinnedPool {
 // pair lists, workspaces and queue heads: slice k's F/H kernel runs beside slice k + 1's essential-matrix kernel, and
 // the masks stay where they are until the call's packing step.  Grow-only, kept by the context across calls.
 struct VerifyClassSlot {
+    PinBuf<TvgPair> h_pairs, h_pairs_e;  // pinned staging of the two lists
     DevBuf<TvgPair> pairs, pairs_e;
     DevBuf<double> ws, ws_e;
     DevBuf<uint8_t> maskws;
-    void release() { pairs.release(); pairs_e.release(); ws.release(); ws_e.release(); maskws.release(); }
+    void release() { pairs.release(); pairs_e.release(); ws.release(); ws_e.release(); maskws.release(); h_pairs.release(); h_pairs_e.release(); }
 };
 struct VerifySliceBufs {
+    PinBuf<uint32_t> h_tabs;
     DevBuf<uint32_t> tabs;
     DevBuf<uint8_t> outmask, emask;
     VerifyClassSlot cls[4];
@@ -201,7 +203,7 @@ struct VerifySliceBufs {
     hipEvent_t ev_e_done = nullptr, ev_aux_done = nullptr;
     bool aux_pending = false;
     void release() {
-        tabs.release(); outmask.release(); emask.release();
+        tabs.release(); outmask.release(); emask.release(); h_tabs.release();
         for (auto& k : cls) k.release();
     }
     ~VerifySliceBufs() {
@@ -292,6 +294,14 @@ struct amc_ctx {
     uint32_t* d_vscalars = nullptr;   // kVScalarWords
     std::vector<double> wm_cut_cache; // TvgParams::wm_cut for (wm_cut_conf, wm_cut_mult)
     double wm_cut_conf = 0.0, wm_cut_mult = 0.0;
+    bool wm_cut_on_device = false;    // d_wmcut holds wm_cut_cache
+    // Every upload of a verification call comes from pinned memory (round 6: the pageable ones - a few hundred KB each -
+    // stalled a call by 10-20 ms once in ten to twenty calls, profiles/r06/pipeline_timeline_v1.txt), and the image table
+    // is uploaded only when it changed.
+    PinBuf<TvgImage> h_timgs;
+    std::vector<TvgImage> timgs_on_device;
+    PinBuf<TvgPair> h_tp;             // the call's pair records in the caller's order (VerifyRun::tp)
+    PinBuf<uint64_t> h_moff;
     // tempered words of std::mt19937(seed): the sample stream every pair consumes (TvgParams::stream)
     DevBuf<uint32_t> d_stream;
     uint32_t stream_seed = 0;
@@ -306,6 +316,8 @@ struct amc_ctx {
     DevBuf<TvgPair> d_tp_all;
     DevBuf<unsigned long long> d_worksum;
     amc::VerifyResident vres;  // the last verification call's results, where they lie (amc_internal.h)
+    double timeline[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // amc_ctx_last_timeline
+    double last_hook_ms = 0.0;
     std::shared_ptr<PinnedPool> verify_pool = std::make_shared<PinnedPool>();
     PinBuf<TvgOut> h_tout;    // where the records and masks of a verification call land (copied out before return)
     PinBuf<uint8_t> h_tmask;
@@ -472,6 +484,7 @@ void amc_ctx_destroy(amc_ctx* c) {
     c->d_estate.release(); c->d_stream.release(); c->d_wmcut.release();
     c->d_tout.release();
     c->vslices.clear();
+    c->h_timgs.release(); c->h_tp.release(); c->h_moff.release();
     if (c->d_vscalars) (void)hipFree(c->d_vscalars);
     c->d_tvg_packed.release(); c->d_mask_packed.release(); c->d_moff.release(); c->d_tp_all.release(); c->d_worksum.release();
     c->d_ppairs.release(); c->d_pmatches.release(); c->d_pcos.release(); c->d_pout.release();
@@ -529,6 +542,7 @@ int amc_ctx_trim(amc_ctx* c) {
         if (vs) HIPCHK(hipStreamSynchronize(vs));
     for (auto& sl : c->vslices)
         if (sl) sl->release();
+    c->h_tp.release(); c->h_moff.release();
     c->d_estate.release();
     c->d_tout.release(); c->d_tmatches.release(); c->d_pmatches.release(); c->d_pcos.release();
     c->d_tvg_packed.release(); c->d_mask_packed.release(); c->d_moff.release(); c->d_tp_all.release();
@@ -1338,6 +1352,7 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
     out->match_kernel_launches = kernel_launches;
     out->cross_kernel_ms = cross_ms;
     out->_priv = priv;
+    c->last_hook_ms = t_hook;
     if (prof)
         std::fprintf(stderr, "[amc match profile] pairs=%zu wall=%.1f ms: prepare %.1f, enqueue %.1f, collect(wait+reorder+D2H enqueue) %.1f, "
                      "scatter(wait) %.1f, batch hook %.1f; device events %.1f ms (scan %.1f, cross %.1f)\n", npairs, since(wall0), t_prepare,
@@ -1882,7 +1897,7 @@ struct VerifyRun {
     amc_tvg_opts o;
     uint32_t seed;
     TvgParams P{};
-    std::vector<TvgPair> tp;
+    TvgPair* tp = nullptr;  // npairs records in the ctx's pinned buffer (uploaded as they are by the packing step)
     std::vector<double> wm_cut;
     std::vector<VerifySliceInfo> slices;
     size_t submitted = 0;          // pairs [0, submitted) have been handed over
@@ -2021,7 +2036,8 @@ int VerifyRun::begin(size_t) {
     HIPCHK(hipSetDevice(c->device));
     hipStream_t st = c->stream;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device);
-    tp.resize(npairs);
+    HIPCHK(c->h_tp.ensure(std::max<size_t>(npairs, 1)));
+    tp = c->h_tp.p;
     if (npairs == 0) return AMC_OK;
     // image table (cameras with distortion parameters: CamFromImg of their keypoints first)
     for (size_t i = 0; i < need_lift.size(); ++i)
@@ -2047,18 +2063,33 @@ int VerifyRun::begin(size_t) {
     HIPCHK(c->d_estate.ensure(npairs));
     HIPCHK(c->d_tout.ensure(npairs));
     if (std::getenv("AMC_TVG_PROFILE")) HIPCHK(c->h_tout.ensure(npairs));
-    HIPCHK(hipMemcpyAsync(c->d_timgs.p, timgs.data(), timgs.size() * sizeof(TvgImage), hipMemcpyHostToDevice, st));
+    // the image table: uploaded (from pinned memory) only when it differs from what the device holds
+    if (c->timgs_on_device.size() != timgs.size() ||
+        (!timgs.empty() && std::memcmp(c->timgs_on_device.data(), timgs.data(), timgs.size() * sizeof(TvgImage)) != 0)) {
+        HIPCHK(hipStreamSynchronize(st));  // (h_timgs may still feed an earlier copy)
+        HIPCHK(c->h_timgs.ensure(std::max<size_t>(timgs.size(), 1)));
+        if (!timgs.empty()) std::memcpy(c->h_timgs.p, timgs.data(), timgs.size() * sizeof(TvgImage));
+        c->timgs_on_device.clear();
+        HIPCHK(hipMemcpyAsync(c->d_timgs.p, c->h_timgs.p, timgs.size() * sizeof(TvgImage), hipMemcpyHostToDevice, st));
+        c->timgs_on_device = timgs;
+    }
     P.wm_cut = nullptr;
     if (!wm_cut.empty()) {
-        HIPCHK(c->d_wmcut.ensure(wm_cut.size()));
-        HIPCHK(hipMemcpyAsync(c->d_wmcut.p, wm_cut.data(), wm_cut.size() * sizeof(double), hipMemcpyHostToDevice, st));
+        const bool same = c->wm_cut_on_device && c->wm_cut_cache.size() == wm_cut.size() && c->d_wmcut.cap >= wm_cut.size() &&
+                          std::memcmp(c->wm_cut_cache.data(), wm_cut.data(), wm_cut.size() * sizeof(double)) == 0;
+        if (!same) {
+            HIPCHK(c->d_wmcut.ensure(wm_cut.size()));
+            c->wm_cut_on_device = false;
+            HIPCHK(hipMemcpy(c->d_wmcut.p, wm_cut.data(), wm_cut.size() * sizeof(double), hipMemcpyHostToDevice));  // (rare: options changed)
+            c->wm_cut_on_device = c->wm_cut_cache.size() == wm_cut.size() &&
+                                  std::memcmp(c->wm_cut_cache.data(), wm_cut.data(), wm_cut.size() * sizeof(double)) == 0;
+        }
         P.wm_cut = c->d_wmcut.p;
     }
     // [0] pairs with a bad match index, [1] waves that ran off the stream table, [2 ..] the launches' queue heads; the
     // records' profile and work counters are accumulated by both kernels
     HIPCHK(memset_async(c->d_vscalars, 0, kVScalarWords * sizeof(uint32_t), st));
     HIPCHK(memset_async(c->d_tout.p, 0, npairs * sizeof(TvgOut), st));
-    HIPCHK(hipStreamSynchronize(st));  // (`timgs`, a pageable source, goes out of scope)
     HIPCHK(hipEventRecord(c->vev_setup, st));
     P.stream = c->d_stream.p;
     P.stream_len = (uint32_t)std::min<size_t>(c->stream_len, 0xFFFFFFFFu);
@@ -2218,7 +2249,11 @@ int VerifyRun::close_slice(hipEvent_t ready) {
     HIPCHK(B.emask.ensure(std::max<size_t>(open.mask_bytes, 128)));
     // (pageable sources: these copies are done when the calls return - the vectors may go out of scope - and need no
     // stream synchronisation)
-    if (!tabs.empty()) HIPCHK(hipMemcpy(B.tabs.p, tabs.data(), tabs.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    if (!tabs.empty()) {
+        HIPCHK(B.h_tabs.ensure(tabs.size()));
+        std::memcpy(B.h_tabs.p, tabs.data(), tabs.size() * sizeof(uint32_t));
+        HIPCHK(hipMemcpy(B.tabs.p, B.h_tabs.p, tabs.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
     // The first non-empty class (the bulk of a slice) runs on the E / F/H streams; the others - few pairs, each several
     // milliseconds on one wave whatever the machine around it does - on the low-priority stream with their own lists
     // and workspaces, so that they fill the bulk class's tails instead of adding launches of pure latency behind it.
@@ -2244,12 +2279,17 @@ int VerifyRun::close_slice(hipEvent_t ready) {
             for (size_t b = 1; b <= (size_t)slice_maxM + 1; ++b) start[b] += start[b - 1];
             for (size_t p : cls[k]) idx[start[slice_maxM - tp[p].M]++] = p;
         }
-        std::vector<TvgPair> sub(idx.size()), sub_e;
+        VerifyClassSlot& S = B.cls[k];
+        HIPCHK(S.h_pairs.ensure(std::max<size_t>(idx.size(), 1)));
+        HIPCHK(S.h_pairs_e.ensure(std::max<size_t>(idx.size(), 1)));
+        TvgPair* const sub = S.h_pairs.p;      // the lists are written where the copies read them: pinned memory
+        TvgPair* const sub_e = S.h_pairs_e.p;
+        size_t n_e = 0;
         uint32_t cm = 0;
         for (size_t i = 0; i < idx.size(); ++i) {
             sub[i] = tp[idx[i]];
             cm = std::max(cm, sub[i].M);
-            if (uses_E(idx[i])) sub_e.push_back(sub[i]);
+            if (uses_E(idx[i])) sub_e[n_e++] = sub[i];
         }
         L.mcap = std::max<uint32_t>(64, round_up(cm, 64));
         auto waves_for = [&](size_t n, int waves_per_simd, size_t lds_block) {
@@ -2261,19 +2301,18 @@ int VerifyRun::close_slice(hipEvent_t ready) {
         };
         const bool run_fh = mode != 3;
         L.n = (uint32_t)idx.size();
-        L.n_e = (uint32_t)sub_e.size();
-        L.waves_e = sub_e.empty() ? 0 : waves_for(sub_e.size(), kTvgEWavesPerSimd, big ? tvg_big_lds_bytes_e(L.wpb) : tvg_lds_bytes_e(L.mcap, L.wpb));
+        L.n_e = (uint32_t)n_e;
+        L.waves_e = n_e == 0 ? 0 : waves_for(n_e, kTvgEWavesPerSimd, big ? tvg_big_lds_bytes_e(L.wpb) : tvg_lds_bytes_e(L.mcap, L.wpb));
         L.waves_fh = run_fh ? waves_for(idx.size(), kTvgFhWavesPerSimd, big ? tvg_big_lds_bytes(L.wpb) : tvg_lds_bytes(L.mcap, L.wpb)) : 0;
-        VerifyClassSlot& S = B.cls[k];
         HIPCHK(S.pairs.ensure(idx.size()));
-        HIPCHK(S.pairs_e.ensure(std::max<size_t>(sub_e.size(), 1)));
+        HIPCHK(S.pairs_e.ensure(std::max<size_t>(n_e, 1)));
         const size_t idx_ws = big ? tvg_big_idx_doubles_host(L.mcap) : 0;  // per wave, behind the point workspaces
         // (E and F/H of one slice run behind each other, but slice k's F/H runs beside slice k + 1's E: own workspaces)
         HIPCHK(S.ws_e.ensure(std::max<size_t>((size_t)L.waves_e * (tvg_ws_doubles_e_host(L.mcap) + idx_ws), 1)));
         HIPCHK(S.ws.ensure(std::max<size_t>((size_t)L.waves_fh * (tvg_ws_doubles_host(L.mcap) + idx_ws), 1)));
         HIPCHK(S.maskws.ensure((size_t)std::max<uint32_t>(L.waves_fh, 1) * tvg_ws_mask_bytes_host(L.mcap)));
-        HIPCHK(hipMemcpy(S.pairs.p, sub.data(), sub.size() * sizeof(TvgPair), hipMemcpyHostToDevice));
-        if (!sub_e.empty()) HIPCHK(hipMemcpy(S.pairs_e.p, sub_e.data(), sub_e.size() * sizeof(TvgPair), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(S.pairs.p, sub, idx.size() * sizeof(TvgPair), hipMemcpyHostToDevice));
+        if (n_e) HIPCHK(hipMemcpy(S.pairs_e.p, sub_e, n_e * sizeof(TvgPair), hipMemcpyHostToDevice));
         sl.launches.push_back(L);
     }
     t_lists += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
@@ -2573,8 +2612,10 @@ static int verify_finish(amc_ctx* c, VerifyRun& run, const uint64_t* match_offse
     HIPCHK(c->d_moff.ensure(npairs + 1));
     HIPCHK(c->d_tp_all.ensure(npairs));
     HIPCHK(c->d_worksum.ensure(12));
-    HIPCHK(hipMemcpyAsync(c->d_moff.p, match_offsets, (npairs + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(c->d_tp_all.p, run.tp.data(), npairs * sizeof(TvgPair), hipMemcpyHostToDevice, st));
+    HIPCHK(c->h_moff.ensure(npairs + 1));
+    std::memcpy(c->h_moff.p, match_offsets, (npairs + 1) * sizeof(uint64_t));
+    HIPCHK(hipMemcpyAsync(c->d_moff.p, c->h_moff.p, (npairs + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(c->d_tp_all.p, run.tp, npairs * sizeof(TvgPair), hipMemcpyHostToDevice, st));
     HIPCHK(memset_async(c->d_worksum.p, 0, 12 * sizeof(unsigned long long), st));
     const int32_t trivial_below = run.mode == 0 ? std::max(run.o.min_num_inliers, 0) : 0;
     for (size_t si = 0; si < run.slices.size(); ++si) {
@@ -2896,10 +2937,21 @@ int amc_match_verify_pairs(amc_ctx* c, const uint32_t* slot1, const uint32_t* sl
                        c->d_keep.p ? c->d_keep.p : reinterpret_cast<const uint32_t*>(c->d_scalars), keep_off.data(), t_pre);
     if (rc != AMC_OK) return rc;
     guard.p = nullptr;
+    {
+        const double t_end = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+        const double tl[8] = {t_setup, t_match, t_pre, t_end, t_end, c->last_hook_ms, 0.0, 0.0};
+        std::memcpy(c->timeline, tl, sizeof tl);
+    }
     if (std::getenv("AMC_VERIFY_PROFILE"))  // the call's timeline on the host (ms since entry)
         std::fprintf(stderr, "[amc pipeline profile] pairs=%zu: verification set up at %.2f, match call back at %.2f, slice closed + launched at %.2f, "
                      "results on the host at %.2f\n", npairs, t_setup, t_match, t_pre,
                      std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count());
+    return AMC_OK;
+}
+
+int amc_ctx_last_timeline(amc_ctx* c, double out_ms[8]) {
+    if (!c || !out_ms) return fail(AMC_E_INVALID, "amc_ctx_last_timeline: NULL argument");
+    std::memcpy(out_ms, c->timeline, sizeof c->timeline);
     return AMC_OK;
 }
 
