@@ -493,8 +493,11 @@ __device__ __forceinline__ SamplerState sample_chunk_t(const uint32_t* stream, u
     return st;
 }
 
+#ifndef AMC_SAMPLE_INLINE
+#define AMC_SAMPLE_INLINE __noinline__
+#endif
 template <int kMin>
-__device__ __noinline__ SamplerState sample_chunk(const uint32_t* stream_, uint32_t slen_, idx_u16* perm_, lds_u16* sidx_,
+__device__ AMC_SAMPLE_INLINE SamplerState sample_chunk(const uint32_t* stream_, uint32_t slen_, idx_u16* perm_, lds_u16* sidx_,
                                                   lds_u32* rawcnt_, SamplerState st, int M_, int nT_, int lane,
                                                   int force_slow_, uint32_t* err_) {
     // everything but `lane` is wave-uniform: move it to scalar registers
@@ -554,8 +557,16 @@ __device__ __forceinline__ bool better(const Support a, const Support b) {
 // InlierSupportMeasurer::Evaluate.  The count comes from ballots (wave-uniform by construction);
 // the residual sum is only ever consulted when the count ties or beats the best so far
 // (Compare()), so its 64-way butterfly is skipped otherwise (`need_sum_from` = that count).
+// (A/B hooks, round 6, same box, kernels per 124,750 pairs: score() inlined into the replay loop 421.1 -> 417.1 / 419.8 ->
+// 415.5 ms - the caller's live registers are not spilled around ~50 calls per RANSAC; extract_inliers inlined 450 ms: no)
+#ifndef AMC_SCORE_INLINE
+#define AMC_SCORE_INLINE __forceinline__
+#endif
+#ifndef AMC_EXTRACT_INLINE
+#define AMC_EXTRACT_INLINE __noinline__
+#endif
 template <int KIND>
-__device__ __noinline__ Support score(const Model9 mv, const Pts P_, int M_, double max_res_, int lane, int need_sum_from) {
+__device__ AMC_SCORE_INLINE Support score(const Model9 mv, const Pts P_, int M_, double max_res_, int lane, int need_sum_from) {
     double m[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) m[i] = uni(mv.v[i]);
@@ -592,7 +603,7 @@ __device__ __noinline__ Support score(const Model9 mv, const Pts P_, int M_, dou
 
 // ---- local optimisation over the ordered inlier list w.inl[0..K) ---------------------------------
 // ordered compaction of the inlier indices of `model` (kind); returns K
-__device__ __noinline__ int extract_inliers(idx_u16* inl, int lane, int kind, const Model9 mv, const Pts P, int M,
+__device__ AMC_EXTRACT_INLINE int extract_inliers(idx_u16* inl, int lane, int kind, const Model9 mv, const Pts P, int M,
                                             double max_res) {
     const double* model = mv.v;
     int base = 0;
@@ -1143,8 +1154,11 @@ __device__ unsigned long long g_lo_diag[64];   // 48 .. 55: stages of the minima
 #endif
 
 // local estimator on the K listed inlier correspondences -> models (uniform), count
+#ifndef AMC_LOCAL_INLINE
+#define AMC_LOCAL_INLINE __noinline__
+#endif
 template <int LOCAL>
-__device__ __noinline__ int local_estimate(const LoCtx w, const Pts P, int K, double* models) {
+__device__ AMC_LOCAL_INLINE int local_estimate(const LoCtx w, const Pts P, int K, double* models) {
     const int lane = w.lane;
     if (LOCAL == K_T) {
         double a = 0, b = 0, c = 0, d = 0;
@@ -1339,6 +1353,14 @@ __device__ __noinline__ int real_roots10_lanes(const double* c_in, double* roots
 // only change the course of the sequential algorithm if its count reaches the best count so far, so all the replay
 // needs per trial is an upper bound of the largest count among its models; the few
 // trials that qualify are re-scored in full there.
+// (A/B hooks, round 6: the chunk's per-lane record crosses these two calls through memory - scratch, 64 lanes x 4 bytes per
+// dword and store - when they are not inlined; -DAMC_SOLVE_CHUNK_INLINE=__forceinline__ / -DAMC_COUNT_CHUNK_INLINE=...)
+#ifndef AMC_SOLVE_CHUNK_INLINE
+#define AMC_SOLVE_CHUNK_INLINE __noinline__
+#endif
+#ifndef AMC_COUNT_CHUNK_INLINE
+#define AMC_COUNT_CHUNK_INLINE __forceinline__   // (same box, kernels per 124,750 pairs: 419.6 / 421.7 ms as a call, 414.3 / 417.3 inlined)
+#endif
 struct ChunkModels {
     double mym[9];
     int nmod;    // models of this lane's trial
@@ -1820,7 +1842,7 @@ __device__ __forceinline__ void e5_eliminate_quads(double* stg, int nT, int lane
 }
 
 template <int EST>
-__device__ __noinline__ void solve_chunk(ChunkModels* out, const Pts P_, const lds_u16* sidx_, int nT_, int lane,
+__device__ AMC_SOLVE_CHUNK_INLINE void solve_chunk(ChunkModels* out, const Pts P_, const lds_u16* sidx_, int nT_, int lane,
                                          double* models_, const RootScratch rootscr) {
     const unsigned long long c0 = __builtin_readcyclecounter();
     const Pts P = uni(P_);
@@ -1930,7 +1952,7 @@ struct CountCtx {  // wave-uniform inputs of count_chunk
     double max_res, cmax;
 };
 template <int EST>
-__device__ __noinline__ void count_chunk(ChunkModels* io, const CountCtx cc_, int lane) {
+__device__ AMC_COUNT_CHUNK_INLINE void count_chunk(ChunkModels* io, const CountCtx cc_, int lane) {
     const unsigned long long c1 = __builtin_readcyclecounter();
     const Pts P = uni(cc_.P);
     const int M = uni(cc_.M), nT = uni(cc_.nT), thr = uni(cc_.thr);
