@@ -368,6 +368,7 @@ def pipeline_leg(ctx_factory, steps: int, warmup: int, cpu_pairs: int, num_image
         tl["python_free_previous_ms"] += 1e3 * (time.perf_counter() - ts0)
         off, m, mst, tvg, mask, vst = ctx.match_verify_pairs(s1, s2, opts, copy=False)   # views, as a C++ caller reads the results
         tl["step_ms_max"] = max(tl["step_ms_max"], 1e3 * (time.perf_counter() - ts0))
+        tl["steps_ms"] = tl.get("steps_ms", []) + [round(1e3 * (time.perf_counter() - ts0), 2)]
         if hasattr(ctx, "last_timeline"):   # the library's own clock inside the call (amc_ctx_last_timeline)
             t_ = ctx.last_timeline()
             tl["c_call_ms"] += t_["call_returned"]; tl["verify_setup_ms"] += t_["verify_setup_done"]
@@ -393,7 +394,7 @@ def pipeline_leg(ctx_factory, steps: int, warmup: int, cpu_pairs: int, num_image
         # where a step's wall time goes on the HOST (the library's clock inside the call + Python around it): the call's
         # phases add up to c_call_ms; ms_per_step - c_call_ms is Python (argument conversion, result views, freeing the
         # previous results); step_ms_max is the slowest step (a stall shows there, not in the kernels' spans)
-        "host_timeline_ms_per_step": {k: (v if k == "step_ms_max" else v / steps) for k, v in tl.items()},
+        "host_timeline_ms_per_step": {k: (v if k in ("step_ms_max", "steps_ms") else v / steps) for k, v in tl.items()},
         "matches_per_verified_pair": {"mean": float(counts[ver].mean()) if nver else 0.0,
                                       "max": int(counts.max()) if len(counts) else 0},
         "mean_inliers_per_verified_pair": float(tvg["num_inliers"][ver].mean()) if nver else 0.0,
