@@ -7,51 +7,87 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
 
 
-def latest_line():
-    files = sorted((ROOT / "profiles").glob("r*/bench_line_unprofiled_v*.json"),
-                   key=lambda p: (p.parent.name, int(p.stem.rsplit("v", 1)[1])))
-    assert files, "no committed bench line under profiles/"
+def _latest(pattern):
+    files = sorted((ROOT / "profiles").glob(pattern), key=lambda p: (p.parent.name, int(p.stem.rsplit("v", 1)[1])))
+    assert files, f"no committed {pattern} under profiles/"
     text = files[-1].read_text().strip().splitlines()
     return files[-1], json.loads(text[-1])
 
 
+def latest_line():
+    """The line as the driver sees it on stdout (round 6: the COMPACT line, floats at 5 significant digits)."""
+    return _latest("r*/bench_line_unprofiled_v*.json")
+
+
+def detail_line():
+    """The detailed objects behind it (`--detail-json`)."""
+    return _latest("r*/bench_detail_v*.json")
+
+
 def test_committed_bench_line_has_the_contract_keys():
     path, d = latest_line()
+    assert len(json.dumps(d)) < 6144, f"{path.name}: the printed line is {len(json.dumps(d))} bytes (the driver keeps the tail of stdout)"
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, f"{path.name}: missing {k}"
     assert d["n_gpus"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
     assert d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
     assert d["unit"] == "distances/s" and d["value"] > 5e9                      # BASELINE.json's target
-    assert abs(d["value"] - d["config"]["distances_total"] / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    assert abs(d["value"] - d["config"]["distances_total"] / (d["ms_per_step"] * 1e-3)) < 1e-3 * d["value"]
     r = d["roofline"]
-    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0 < r["frac"] <= 1
-    assert "traffic" in r and (r["traffic"] is None or r["traffic"] > 0)
+    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4 and 0 < r["frac"] <= 1
+    assert "traffic" in r and (r["traffic"] is None or r["traffic"] > 0) and 0 < r["whole_step_frac"] < r["frac"]
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["sample"] and c["unit"] == d["unit"]
     assert c.get("gpu_vs_oracle_mismatching_pairs", 0) == 0
-    v = d.get("verify")
-    if v:
-        assert v["unit"] == "pairs/s" and v["value"] > 0 and v["cpu_baseline"]["gpu_vs_oracle_mismatching_pairs"] == 0
-        vr = v["roofline"]                                     # the second metric's own roofline (FP64 vector)
-        assert abs(vr["frac"] - vr["achieved"] / vr["peak"]) < 1e-9 and 0 < vr["frac"] < 1
-        assert abs(vr["frac_of_no_fma_ceiling"] - 2 * vr["frac"]) < 1e-6 and vr["kernel"] in ("tvg_kernel", "tvg_e_kernel + tvg_fh_kernel")
-    pl = d.get("pipeline")
-    if pl:                                                     # configs[2] chained on the device
-        assert pl["unit"] == "verified pairs/s" and pl["pairs_verified"] > 1000 and pl["pairs_total"] == 124750
-        assert abs(pl["value"] - pl["pairs_verified"] / (pl["ms_per_step"] * 1e-3)) < 1e-6 * pl["value"]
-        assert pl["cpu_baseline"]["gpu_vs_oracle_mismatching_pairs"] == 0
-        assert pl["cpu_baseline"]["verified_pairs_mismatching"] == 0 and pl["cpu_baseline"]["verified_pairs_checked"] > 0
-        assert 0 < pl["roofline"]["frac"] < 1
-        g = pl.get("guided")
-        if g:                                                  # the guided re-match of the verified pairs
-            assert g["unit"] == "entries/s" and g["value"] > 1.6e12            # >= 3 x 5.3e11
-            assert g["pairs"] == sum(g["pairs_by_kernel"].values()) and g["pairs_by_kernel"]["candidate_generation"] > 0
-            assert g["cpu_baseline"]["gpu_vs_oracle_mismatching_pairs"] == 0
-    dn = d.get("dense")
-    if dn:
-        assert dn["unit"] == "distances/s" and dn["matches_per_pair"] > 500
-        assert abs(dn["value"] - d["config"]["distances_total"] / (dn["ms_per_step"] * 1e-3)) < 1e-6 * dn["value"]
+    # every leg's value is IN the printed line (VERDICT r5: the driver's stdout tail had lost verify.value)
+    for leg in ("verify", "pipeline", "dense", "ragged", "sift_stats", "config3", "config4", "db"):
+        assert d[leg]["value"] > 0, leg
+    for leg in ("verify", "pipeline", "dense", "ragged", "sift_stats", "config3", "config4"):
+        assert d[leg].get("gpu_vs_oracle_mismatching_pairs", 0) == 0, leg
+    v = d["verify"]
+    assert v["unit"] == "pairs/s" and abs(v["roofline"]["frac"] - v["roofline"]["achieved"] / v["roofline"]["peak"]) < 1e-4
+    assert v["roofline"]["traffic"] is None or v["roofline"]["traffic"] > 0
+    pl = d["pipeline"]
+    assert pl["unit"] == "verified pairs/s" and pl["pairs_verified"] > 1000 and pl["pairs_total"] == 124750
+    assert abs(pl["value"] - pl["pairs_verified"] / (pl["ms_per_step"] * 1e-3)) < 1e-3 * pl["value"]
+    assert abs(pl["non_scan_ms"] - (pl["ms_per_step"] - pl["scan_ms"])) < 0.05 and pl["verified_pairs_mismatching"] == 0
+    h = pl["host"]                                             # the call's own timeline adds up
+    assert abs(h["c_call_ms"] - (h["verify_setup_ms"] + h["match_call_ms"] + h["close_and_launch_ms"] + h["verify_wait_pack_download_ms"])) < 0.05
+    assert h["c_call_ms"] <= pl["ms_per_step"] + 0.05
+    c4 = d["config4"]
+    assert set(c4["parts"]) == {"sequential", "loop_voting_512x512", "loop_matches"} and c4["parts"]["sequential"]["scan_frac"] > 0.55
+    dn = d["dense"]
+    assert dn["unit"] == "distances/s" and dn["matches_per_pair"] > 500
+    assert abs(dn["value"] - d["config"]["distances_total"] / (dn["ms_per_step"] * 1e-3)) < 1e-3 * dn["value"]
+
+
+def test_committed_detail_line_is_consistent():
+    path, d = detail_line()
+    assert abs(d["value"] - d["config"]["distances_total"] / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    r = d["roofline"]
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    v = d["verify"]
+    assert v["cpu_baseline"]["gpu_vs_oracle_mismatching_pairs"] == 0
+    vr = v["roofline"]                                         # the second metric's own roofline (FP64 vector)
+    assert abs(vr["frac"] - vr["achieved"] / vr["peak"]) < 1e-9 and 0 < vr["frac"] < 1
+    assert abs(vr["frac_of_no_fma_ceiling"] - 2 * vr["frac"]) < 1e-6 and vr["kernel"] in ("tvg_kernel", "tvg_e_kernel + tvg_fh_kernel")
+    pl = d["pipeline"]                                         # configs[2] chained on the device
+    assert abs(pl["value"] - pl["pairs_verified"] / (pl["ms_per_step"] * 1e-3)) < 1e-6 * pl["value"]
+    assert pl["cpu_baseline"]["gpu_vs_oracle_mismatching_pairs"] == 0
+    assert pl["cpu_baseline"]["verified_pairs_mismatching"] == 0 and pl["cpu_baseline"]["verified_pairs_checked"] > 0
+    assert 0 < pl["roofline"]["frac"] < 1
+    g = pl["guided"]                                           # the guided re-match of the verified pairs
+    assert g["unit"] == "entries/s" and g["value"] > 1.6e12                    # VERDICT r1: >= 3 x 5.3e11
+    assert g["pairs"] == sum(g["pairs_by_kernel"].values()) and g["pairs_by_kernel"]["candidate_generation"] > 0
+    assert g["cpu_baseline"]["gpu_vs_oracle_mismatching_pairs"] == 0
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_for_compact", ROOT / "bench.py")
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    c = bench.compact_line(d)                                  # the printed line is a function of the detailed one
+    assert c["verify"]["value"] == bench._num(d["verify"]["value"]) and c["pipeline"]["value"] == bench._num(d["pipeline"]["value"])
+    assert len(json.dumps(c)) < 6144
 
 
 def test_committed_scaled_config_lines():
