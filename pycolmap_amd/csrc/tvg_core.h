@@ -526,9 +526,6 @@ __device__ __forceinline__ Pts uni(Pts P) {
     return Q;
 }
 __device__ __forceinline__ void load_pt(const Pts& P, int k, double& a, double& b, double& c, double& d) {
-#if defined(AMC_TVG_ABL_PTS)  // timing ablation (results wrong by construction): every point read hits the same four cache lines
-    k &= 7;
-#endif
     const PtRec r = reinterpret_cast<const PtRec*>(P.g)[k];  // two 16-byte loads from one line
     a = r.x1; b = r.y1; c = r.x2; d = r.y2;
 }
