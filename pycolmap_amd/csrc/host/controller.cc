@@ -316,6 +316,16 @@ void MatchController::ComputeOn(amc_ctx* ctx, std::vector<Job>& all_jobs, size_t
         Check(amc_match_verify_pairs(ctx_, s1.data(), s2.data(), which.size(), &mo, &to, /*seed=*/0, &r, &vr),
               "amc_match_verify_pairs");
         stats.match_call_ms += NowMs() - t_call;  // both stages: the device times below split it
+        {
+            double tl[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (amc_ctx_last_timeline(ctx_, tl) == AMC_OK) {
+                stats.fused_setup_ms += tl[0];
+                stats.fused_match_ms += tl[1] - tl[0];
+                stats.fused_launch_ms += tl[2] - tl[1];
+                stats.fused_verify_wait_ms += tl[3] - tl[2];
+                stats.fused_handover_hidden_ms += tl[5];
+            }
+        }
         take_matches(r);
         v1 = s1;
         v2 = s2;
@@ -421,6 +431,8 @@ void MatchController::ComputeOn(amc_ctx* ctx, std::vector<Job>& all_jobs, size_t
         t.match_device_ms += stats.match_device_ms; t.verify_device_ms += stats.verify_device_ms;
         t.guided_device_ms += stats.guided_device_ms; t.match_call_ms += stats.match_call_ms;
         t.verify_call_ms += stats.verify_call_ms; t.num_distances += stats.num_distances;
+        t.fused_setup_ms += stats.fused_setup_ms; t.fused_match_ms += stats.fused_match_ms; t.fused_launch_ms += stats.fused_launch_ms;
+        t.fused_verify_wait_ms += stats.fused_verify_wait_ms; t.fused_handover_hidden_ms += stats.fused_handover_hidden_ms;
     }
 }
 

@@ -89,6 +89,10 @@ struct MatchStats {
     // wall time of the library calls (device time + the library's host side) and of Match() as a whole
     double match_call_ms = 0, verify_call_ms = 0, match_total_ms = 0, setup_ms = 0;
     double write_ms = 0;  // writing both tables (a worker thread: overlaps the next group's device work)
+    // amc_ctx_last_timeline of the fused calls, summed (ms): where amc_match_verify_pairs' wall time goes on the host -
+    // verification set-up, the match call, closing + launching the verification slice, waiting for / packing /
+    // downloading its results, and the per-batch hand-over that runs hidden beside the scans
+    double fused_setup_ms = 0, fused_match_ms = 0, fused_launch_ms = 0, fused_verify_wait_ms = 0, fused_handover_hidden_ms = 0;
     uint64_t num_distances = 0;
 };
 

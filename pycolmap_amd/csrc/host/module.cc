@@ -231,7 +231,11 @@ py::dict StatsDict(const MatchStats& s) {
                     "match_total_ms"_a = s.match_total_ms, "setup_ms"_a = s.setup_ms, "write_ms"_a = s.write_ms,
                     "num_distances"_a = s.num_distances, "pairs_guided"_a = s.pairs_guided,
                     "guided_device_ms"_a = s.guided_device_ms, "loop_queries"_a = s.loop_queries,
-                    "loop_pairs_scored"_a = s.loop_pairs_scored, "loop_device_ms"_a = s.loop_device_ms);
+                    "loop_pairs_scored"_a = s.loop_pairs_scored, "loop_device_ms"_a = s.loop_device_ms,
+                    "fused_call_timeline_ms"_a = py::dict("verify_setup"_a = s.fused_setup_ms, "match_call"_a = s.fused_match_ms,
+                                                        "close_and_launch"_a = s.fused_launch_ms,
+                                                        "verify_wait_pack_download"_a = s.fused_verify_wait_ms,
+                                                        "batch_handover_hidden"_a = s.fused_handover_hidden_ms));
 }
 
 }  // namespace

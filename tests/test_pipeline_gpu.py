@@ -102,6 +102,11 @@ def test_match_exhaustive_end_to_end(tmp_path, prior):
     assert compare(db, exp_m, exp_t) >= 5
     st = pycolmap.last_run_stats()
     assert st["pairs_matched"] == 21 and st["pairs_skipped"] == 0
+    # the fused calls' own host timeline (amc_ctx_last_timeline): its phases are there and fit inside the calls' wall time
+    tl = st["fused_call_timeline_ms"]
+    assert set(tl) == {"verify_setup", "match_call", "close_and_launch", "verify_wait_pack_download", "batch_handover_hidden"}
+    assert all(v >= 0 for v in tl.values()) and tl["match_call"] > 0 and tl["verify_wait_pack_download"] > 0
+    assert tl["verify_setup"] + tl["match_call"] + tl["close_and_launch"] + tl["verify_wait_pack_download"] <= st["match_call_ms"] + 0.5
     # resume: everything exists -> nothing recomputed, rows unchanged
     pycolmap.match_exhaustive(db, matching_options={"block_size": 3})
     st = pycolmap.last_run_stats()
