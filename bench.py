@@ -1172,7 +1172,7 @@ def main():
                     help="print the detailed line (every leg's workload text, notes and sub-objects: ~15 KB) instead of the "
                          "compact one; --detail-json PATH writes it to a file beside the compact line")
     ap.add_argument("--detail-json", default="", help="also write the detailed line to this file")
-    ap.add_argument("--pipeline-steps", type=int, default=0, help="timed steps of the chained configs[2] leg (default: min(steps, 2))")
+    ap.add_argument("--pipeline-steps", type=int, default=0, help="timed steps of the chained configs[2] leg (default: min(steps, 5))")
     ap.add_argument("--no-dense", action="store_true", help="skip the dense-overlap match leg")
     ap.add_argument("--no-ragged", action="store_true", help="skip the ragged-size match leg (n ~ U[2000, 6000])")
     ap.add_argument("--no-sift-stats", action="store_true", help="skip the extractor-statistics match leg")
@@ -1420,7 +1420,8 @@ def main():
                 torch.cuda.empty_cache()
         if gpu_legs and not args.no_pipeline:
             release_headline()
-            out["pipeline"] = pipeline_leg(lambda: _capi.Context(local_rank), args.pipeline_steps or max(1, min(args.steps, 2)), min(1, args.warmup),
+            # (five steps: with two, one 20 ms host-side stall - seen once in this round's six runs of the line - is 10 ms of the figure)
+            out["pipeline"] = pipeline_leg(lambda: _capi.Context(local_rank), args.pipeline_steps or max(1, min(args.steps, 5)), min(1, args.warmup),
                                            0 if args.no_cpu_baseline else 4 * host_cores(), args.images, args.feats)
             sm = out["pipeline"]["stage_ms_per_step"]
             out["pipeline"].update(verify_ms=sm["verify_ms"], verify_kernel_ms=sm["verify_kernel_ms"], match_ms=sm["match_ms"],
