@@ -157,6 +157,16 @@ def test_multi_rank_entry_launches_itself_and_carries_the_configs3_leg():
     assert c["backend"] == "gloo" and c["rccl_ranks"] == 0
     assert len(c["kernel_ms_per_step_by_rank"]) == 2 and len(c["exchange_ms_per_step_by_rank"]) == 2
     assert c["exchange_ms_per_step"] == max(c["exchange_ms_per_step_by_rank"]) > 0
+    # what a measured multi-rank run PRINTS is the compact form of such a line (dry runs print the detailed one):
+    # the scaling curve's scalars survive it
+    spec = importlib.util.spec_from_file_location("bench_for_compact2", ROOT / "bench.py")
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    k = bench.compact_line(d)
+    assert len(json.dumps(k)) < 6144 and k["n_gpus"] == 2 and k["scaling"] == "weak" and "roofline" in k and k["config"]["pairs_total"] == 78
+    k3 = k["config3"]
+    assert k3["n_gpus"] == 2 and k3["scaling"] == "strong" and len(k3["per_rank_kernel_ms"]) == 2 and k3["gather_path"] == "padded"
+    assert k3["exchange_ms_per_step"] > 0 and abs(k["config3_ms_per_step"] - l3["ms_per_step"]) < 1e-3 * l3["ms_per_step"] and "config3_value" in k
 
 
 def test_configs3_alone_is_still_a_line_of_its_own():
