@@ -35,6 +35,7 @@
 #pragma once
 #include <algorithm>
 #include <cstdio>
+#include <vector>
 
 #include "amc_internal.h"
 #include "camera_math.h"
@@ -51,6 +52,12 @@ __device__ __forceinline__ constexpr int kmin_of(int kind) {
 
 constexpr int kMaxModels = 10;
 constexpr int kModelDoubles = 64 * kMaxModels * 9;
+// The chunk's model table (E / F: up to kMaxModels per trial) is element-major: entry i of model m of trial t at
+// (m * 9 + i) * 64 + t.  Round 6 - it was (t * kMaxModels + m) * 9 + i, every lane writing its trial's models into
+// 720 bytes of its own: a store instruction of the solving lanes touched 64 lines (5,760 partial-line writes per
+// 5-point chunk, and the wave waited for them before the counting loop could read the table); element-major a store
+// is 512 contiguous bytes.
+__device__ __forceinline__ constexpr size_t model_at(int m, int i, int t) { return (size_t)(m * 9 + i) * 64 + (size_t)t; }
 
 // LDS objects are addressed through address-space-3 pointers so that every access is a ds_* instruction (a generic
 // pointer makes the compiler emit flat_* loads, which take the vector-memory path and cost several hundred cycles).
@@ -71,6 +78,18 @@ typedef lds_u16 idx_u16;
 // Wave-uniform reads of global tables through the scalar data cache (s_load_*): the table is either never written by
 // the kernel (the sample stream) or written by this wave, drained and followed by s_dcache_inv (scalar_table_sync).
 #define AMC_CONST __attribute__((address_space(4)))
+// The waves' workspaces are global memory, but the pointers to them travel through structs and calls, where the compiler
+// loses the address space and emits flat_* accesses (64-bit address arithmetic on the vector unit, and a flat access
+// counts on the LDS counter too: every LDS wait then also waits for the outstanding loads from memory).  gptr() names
+// the address space where a workspace is touched: global_load / global_store with a scalar base (AMC_TVG_FLAT=1: the
+// round-6 code, for A/B runs).
+#if defined(AMC_TVG_FLAT)
+#define AMC_GLOBAL
+#else
+#define AMC_GLOBAL __attribute__((address_space(1)))
+#endif
+template <class T>
+__device__ __forceinline__ AMC_GLOBAL T* gptr(T* p) { return (AMC_GLOBAL T*)p; }
 
 // Algorithmic work of a pair, counted as the sequential algorithm does it (TvgOut::work): what COLMAP's loops
 // evaluate - every model of every trial up to the stopping trial against all M correspondences, every local model
@@ -122,6 +141,7 @@ enum : int { W_X1 = 0, W_Y1, W_X2, W_Y2, W_AX1, W_AY1, W_AX2, W_AY2, W_NUM_ARRAY
 struct alignas(32) PtRec {
     double x1, y1, x2, y2;
 };
+typedef double pt4 __attribute__((ext_vector_type(4)));  // a record as one 32-byte value (loads through gptr())
 // ... then the tables the counting loops read through the scalar cache: (x1, y1, x2, y2) as doubles, one 32-byte
 // record per correspondence, and the packed-FP32 table of the homography pre-filter (16 bytes per correspondence,
 // two correspondences interleaved: a0 a1 b0 b1 c0' c1' d0' d1'), then the chunk's models (E / F: kMaxModels per trial)
@@ -296,11 +316,28 @@ __device__ __forceinline__ uint32_t stream_word(const AMC_CONST uint32_t* stream
     return stream[pos < len ? pos : len - 1];
 }
 
+// N consecutive plain trials of one slot of the permutation's head (sample_chunk_t): trial k reads perm[jk[k]] and
+// stores there what trial k - 1 read (the head's value `a` for the first), which is also trial k - 1's sample - the read
+// of a trial is in flight while the previous one's value is stored.  Returns the head's value after the run.
+template <int N>
+__device__ __forceinline__ uint32_t swap_run(idx_u16* perm, lds_u16* srow, const uint32_t (&jk)[8], uint32_t a) {
+    uint32_t v[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        v[k] = perm[jk[k]];
+        perm[jk[k]] = (uint16_t)(k == 0 ? a : v[k - 1]);
+        if (k > 0) srow[(k - 1) * 8] = (uint16_t)v[k - 1];
+    }
+    srow[(N - 1) * 8] = (uint16_t)v[N - 1];
+    return v[N - 1];
+}
+
 template <int kMin>
 __device__ __forceinline__ SamplerState sample_chunk_t(const uint32_t* stream, uint32_t slen, idx_u16* perm, lds_u16* sidx,
-                                                       lds_u32* rawcnt, SamplerState st, int M, int nT, int lane,
+                                                       lds_u32* rawcnt, lds_u16* jt, SamplerState st, int M, int nT, int lane,
                                                        int force_slow, uint32_t* err) {
     const int need = nT * kMin;
+    static_assert((size_t)7 * 64 * 2 <= (size_t)162 * 8, "the transposed draws fit over jacA | jacV");
     // ---- parallel: tempered word -> j, for the whole chunk ----
     bool slowflag = force_slow != 0;
     const bool fits = st.off + (uint32_t)need <= slen;
@@ -312,7 +349,9 @@ __device__ __forceinline__ SamplerState sample_chunk_t(const uint32_t* stream, u
                 const uint32_t range = (uint32_t)(M - i);
                 const uint64_t product = (uint64_t)stream[st.off + (uint32_t)n] * (uint64_t)range;
                 if ((uint32_t)product < range) slowflag = true;
-                sidx[t * 8 + i] = (uint16_t)((uint32_t)i + (uint32_t)(product >> 32));
+                const uint16_t jv = (uint16_t)((uint32_t)i + (uint32_t)(product >> 32));
+                sidx[t * 8 + i] = jv;
+                jt[i * 64 + t] = jv;
             }
         }
     } else {
@@ -321,15 +360,15 @@ __device__ __forceinline__ SamplerState sample_chunk_t(const uint32_t* stream, u
     wave_lds_sync();
     if (__ballot(slowflag) == 0ull) {
         // ---- sequential swaps ----
-        // Lane i < kMin owns slot i of the permutation's head (prv); one trial is, per slot, v = perm[j],
-        // perm[j] = prv, prv = v - independent across slots as long as the trial's j are distinct and
-        // none falls into the head.  Those trials (classified up front, lane t looks at trial t) take
-        // one LDS read + two writes per lane, and the only dependence from trial to trial is the read
-        // of t feeding the write of t + 1, so consecutive trials overlap in the in-order LDS queue.
+        // Lane i < kMin owns slot i of the permutation's head (its value: `a`); one trial is, per slot, v = perm[j],
+        // perm[j] = a, a = v - independent across slots as long as the trial's j are distinct and none falls into
+        // the head.  Those trials (classified up front, lane t looks at trial t) take one LDS read and two writes per
+        // slot lane, and the only dependence from trial to trial is the read of t feeding the write of t + 1.
         // The others (a few per cent) run the scalar, slot-by-slot code on the gathered head.
-        // Lane t keeps trial t's draws in registers (jj); the loop below fetches them with readlane, so the
-        // LDS queue only carries the permutation traffic and the wait before a trial's write is for the read
-        // issued one trial earlier (sidx of trial t is stored during trial t + 1 for the same reason).
+        // Round 6: the slot lanes take their draws from the transposed copy jt[i * 64 + t] - eight trials in one
+        // 16-byte read, every draw then a bit field of a register - instead of one v_readlane + select per draw and
+        // trial from the registers of lane t: ~6 instructions per trial instead of ~30 (the loop is bound by
+        // instruction issue beside the SIMD's other waves, not by the LDS: ~475 cycles per trial before).
         unsigned long long slowmask;
         uint32_t jj[7];
         {
@@ -347,69 +386,53 @@ __device__ __forceinline__ SamplerState sample_chunk_t(const uint32_t* stream, u
             slowmask = __ballot(odd && lane < nT);
         }
         wave_lds_sync();  // every lane has its draws before the rows are overwritten with the samples
-        uint32_t prv = 0;
+        uint32_t a = 0;
 #pragma unroll
-        for (int i = 0; i < 7; ++i) prv = lane == i ? st.pr[i] : prv;
+        for (int i = 0; i < 7; ++i) a = lane == i ? st.pr[i] : a;
         const bool slot = lane < kMin;
-        int t = 0;
-        while (t < nT) {
+        const lds_u16* jrow = jt + (slot ? lane : 0) * 64;
+        int t_ = 0;
+        while (t_ < nT) {
+            // a run of plain trials: up to the next odd trial, the end of the chunk or of the 8-trial block of draws
+            // (t, run: wave-uniform - named so, or the loop's control flow is compiled as vector branches)
+            const int t = uni(t_);
             const unsigned long long rest = slowmask >> t;
-            int run = rest ? (int)__builtin_ctzll(rest) : 64;
-            run = min(run, nT - t);
-            // two trials per round on alternating registers: the value read by one trial is stored by the
-            // next, and nothing in between needs it (no copy, so no wait on the read just issued).  `pend` is
-            // the trial whose samples (the value about to be stored) are not in sidx yet; at the start of a
-            // run that store repeats what trial t - 1 already wrote (row 0 when there is none: rewritten below).
-            int pend = max(t - 1, 0);
-            uint32_t a = prv;
-            const int e = t + run;
-            while (t + 1 < e) {
-                uint32_t j0 = 0, j1 = 0;
-#pragma unroll
-                for (int i = 0; i < 7; ++i)
-                    if (i < kMin) {
-                        const uint32_t x0 = (uint32_t)__builtin_amdgcn_readlane((int)jj[i], t);
-                        const uint32_t x1 = (uint32_t)__builtin_amdgcn_readlane((int)jj[i], t + 1);
-                        j0 = lane == i ? x0 : j0;
-                        j1 = lane == i ? x1 : j1;
-                    }
+            const int k0 = t & 7;
+            int run_ = rest ? (int)__builtin_ctzll(rest) : 64;
+            run_ = min(min(run_, nT - t), 8 - k0);
+            const int run = uni(run_);
+            t_ = t + (run > 0 ? run : 1);
+            if (run > 0) {
                 if (slot) {
-                    const uint32_t b = perm[j0];
-                    perm[j0] = (uint16_t)a;
-                    sidx[pend * 8 + lane] = (uint16_t)a;
-                    a = perm[j1];
-                    perm[j1] = (uint16_t)b;
-                    sidx[t * 8 + lane] = (uint16_t)b;
-                }
-                pend = t + 1;
-                t += 2;
-            }
-            if (t < e) {
-                uint32_t j0 = 0;
-#pragma unroll
-                for (int i = 0; i < 7; ++i)
-                    if (i < kMin) {
-                        const uint32_t x0 = (uint32_t)__builtin_amdgcn_readlane((int)jj[i], t);
-                        j0 = lane == i ? x0 : j0;
+                    // this slot's draws of trials [t - k0, t - k0 + 8), two per register; the run's first one moved to bit 0
+                    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                    const u32x4 qv = *reinterpret_cast<const AMC_LDS u32x4*>(jrow + (t - k0));
+                    unsigned long long lo = ((unsigned long long)qv[1] << 32) | qv[0], hi = ((unsigned long long)qv[3] << 32) | qv[2];
+                    const int sh = 16 * k0;
+                    if (sh >= 64) { lo = hi >> (sh - 64); hi = 0ull; }
+                    else if (sh > 0) { lo = (lo >> sh) | (hi << (64 - sh)); hi >>= sh; }
+                    const uint32_t w0 = (uint32_t)lo, w1 = (uint32_t)(lo >> 32), w2 = (uint32_t)hi, w3 = (uint32_t)(hi >> 32);
+                    const uint32_t jk[8] = {w0 & 0xFFFFu, w0 >> 16, w1 & 0xFFFFu, w1 >> 16, w2 & 0xFFFFu, w2 >> 16, w3 & 0xFFFFu, w3 >> 16};
+                    lds_u16* srow = sidx + t * 8 + lane;
+                    switch (run) {   // (one straight-line piece of code per length: the waits are then placed per access)
+                        case 1: a = swap_run<1>(perm, srow, jk, a); break;
+                        case 2: a = swap_run<2>(perm, srow, jk, a); break;
+                        case 3: a = swap_run<3>(perm, srow, jk, a); break;
+                        case 4: a = swap_run<4>(perm, srow, jk, a); break;
+                        case 5: a = swap_run<5>(perm, srow, jk, a); break;
+                        case 6: a = swap_run<6>(perm, srow, jk, a); break;
+                        case 7: a = swap_run<7>(perm, srow, jk, a); break;
+                        default: a = swap_run<8>(perm, srow, jk, a); break;
                     }
-                if (slot) {
-                    const uint32_t b = perm[j0];
-                    perm[j0] = (uint16_t)a;
-                    sidx[pend * 8 + lane] = (uint16_t)a;
-                    a = b;
                 }
-                pend = t;
-                ++t;
+                continue;
             }
-            if (run > 0 && slot) sidx[pend * 8 + lane] = (uint16_t)a;
-            prv = a;
-            if (t >= nT) break;
             // trial t touches the head or draws an index twice: slot by slot on the gathered head
             uint32_t j[7], pr[7];
 #pragma unroll
             for (int i = 0; i < 7; ++i) {
                 j[i] = i < kMin ? (uint32_t)__builtin_amdgcn_readlane((int)jj[i], t) : 0xFFFFu;
-                pr[i] = i < kMin ? (uint32_t)__builtin_amdgcn_readlane((int)prv, i) : 0u;
+                pr[i] = i < kMin ? (uint32_t)__builtin_amdgcn_readlane((int)a, i) : 0u;
             }
 #pragma unroll
             for (int i = 0; i < 7; ++i) {
@@ -430,12 +453,11 @@ __device__ __forceinline__ SamplerState sample_chunk_t(const uint32_t* stream, u
                 }
             }
 #pragma unroll
-            for (int i = 0; i < 7; ++i) prv = (i < kMin && lane == i) ? pr[i] : prv;
-            if (slot) sidx[t * 8 + lane] = (uint16_t)prv;
-            ++t;
+            for (int i = 0; i < 7; ++i) a = (i < kMin && lane == i) ? pr[i] : a;
+            if (slot) sidx[t * 8 + lane] = (uint16_t)a;
         }
 #pragma unroll
-        for (int i = 0; i < 7; ++i) st.pr[i] = i < kMin ? (uint32_t)__builtin_amdgcn_readlane((int)prv, i) : st.pr[i];
+        for (int i = 0; i < 7; ++i) st.pr[i] = i < kMin ? (uint32_t)__builtin_amdgcn_readlane((int)a, i) : st.pr[i];
         st.off += (uint32_t)need;
         wave_lds_sync();
         return st;
@@ -498,7 +520,7 @@ __device__ __forceinline__ SamplerState sample_chunk_t(const uint32_t* stream, u
 #endif
 template <int kMin>
 __device__ AMC_SAMPLE_INLINE SamplerState sample_chunk(const uint32_t* stream_, uint32_t slen_, idx_u16* perm_, lds_u16* sidx_,
-                                                  lds_u32* rawcnt_, SamplerState st, int M_, int nT_, int lane,
+                                                  lds_u32* rawcnt_, lds_u16* jt_, SamplerState st, int M_, int nT_, int lane,
                                                   int force_slow_, uint32_t* err_) {
     // everything but `lane` is wave-uniform: move it to scalar registers
     const uint32_t* stream = uni_ptr(stream_);
@@ -506,12 +528,13 @@ __device__ AMC_SAMPLE_INLINE SamplerState sample_chunk(const uint32_t* stream_, 
     idx_u16* perm = uni_idx(perm_);
     lds_u16* sidx = uni_lds(sidx_);
     lds_u32* rawcnt = uni_lds(rawcnt_);
+    lds_u16* jt = uni_lds(jt_);
     const int M = uni(M_), nT = uni(nT_), force_slow = uni(force_slow_);
     const uint32_t slen = uni(slen_);
     st.off = uni(st.off);
 #pragma unroll
     for (int i = 0; i < 7; ++i) st.pr[i] = sgpr(st.pr[i]);
-    return sample_chunk_t<kMin>(stream, slen, perm, sidx, rawcnt, st, M, nT, lane, force_slow, err);
+    return sample_chunk_t<kMin>(stream, slen, perm, sidx, rawcnt, jt, st, M, nT, lane, force_slow, err);
 }
 
 // ---- the active RANSAC's correspondences: four arrays in the wave's global workspace -----------------
@@ -526,8 +549,8 @@ __device__ __forceinline__ Pts uni(Pts P) {
     return Q;
 }
 __device__ __forceinline__ void load_pt(const Pts& P, int k, double& a, double& b, double& c, double& d) {
-    const PtRec r = reinterpret_cast<const PtRec*>(P.g)[k];  // two 16-byte loads from one line
-    a = r.x1; b = r.y1; c = r.x2; d = r.y2;
+    const pt4 r = gptr(reinterpret_cast<const pt4*>(P.g))[k];  // two 16-byte loads from one line
+    a = r[0]; b = r[1]; c = r[2]; d = r[3];
 }
 
 template <int KIND>
@@ -1144,7 +1167,34 @@ __device__ unsigned long long g_lo_diag[64];   // 48 .. 55: stages of the minima
 #define LODIAG_LAP(slot) do { const unsigned long long n_ = __builtin_readcyclecounter(); \
                               if (lane == 0) atomicAdd(&g_lo_diag[slot], n_ - lodiag_t_); lodiag_t_ = n_; } while (0)
 #define LODIAG_COUNT(slot) do { if (lane == 0) atomicAdd(&g_lo_diag[slot], 1ull); } while (0)
+// when a persistent wave started and when it found the queue empty (100 MHz wall clock): how long the machine drains
+// while the last pairs are finished (one launch per kernel: AMC_TVG_SLICES=1, one size class)
+__device__ unsigned long long g_wave_span[2][4096];
+#define LODIAG_WAVE_START(gw) do { if (lane == 0 && (gw) < 4096) g_wave_span[0][gw] = wall_clock64(); } while (0)
+#define LODIAG_WAVE_END(gw) do { if (lane == 0 && (gw) < 4096) g_wave_span[1][gw] = wall_clock64(); } while (0)
+inline void lodiag_report_spans(const char* name) {
+    static unsigned long long h[2][4096];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_wave_span), sizeof h) != hipSuccess) return;
+    std::vector<double> st, en;
+    for (int i = 0; i < 4096; ++i)
+        if (h[0][i] && h[1][i]) { st.push_back((double)h[0][i]); en.push_back((double)h[1][i]); }
+    if (st.empty()) return;
+    const double t0 = *std::min_element(st.begin(), st.end());
+    std::sort(en.begin(), en.end());
+    const double last = en.back();
+    double idle = 0;
+    for (double e : en) idle += last - e;
+    const size_t n = en.size();
+    std::fprintf(stderr, "[amc tvg lodiag spans] %s: %zu waves, span %.2f ms; waves done at min %.2f p10 %.2f median %.2f p90 %.2f max %.2f ms; "
+                 "wave-slots idle before the kernel ends %.3f of the span\n", name, n, (last - t0) * 1e-5, (en[0] - t0) * 1e-5,
+                 (en[n / 10] - t0) * 1e-5, (en[n / 2] - t0) * 1e-5, (en[n * 9 / 10] - t0) * 1e-5, (last - t0) * 1e-5,
+                 idle / ((last - t0) * (double)n));
+    static unsigned long long z[2][4096] = {};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_wave_span), z, sizeof z);
+}
 #else
+#define LODIAG_WAVE_START(gw) do {} while (0)
+#define LODIAG_WAVE_END(gw) do {} while (0)
 #define LODIAG_T0() do {} while (0)
 #define LODIAG_LAP(slot) do {} while (0)
 #define LODIAG_COUNT(slot) do {} while (0)
@@ -1453,10 +1503,10 @@ __device__ __forceinline__ int count_global_models_exact(const double* models, i
     for (int t = 0; t < nT; ++t) {
         const int n = __builtin_amdgcn_readlane(nmod, t);
         for (int m = 0; m < n; ++m) {
-            const double* src = models + ((size_t)t * kMaxModels + m) * 9;
+            const AMC_GLOBAL double* src = gptr(models);
             double sm[9];
 #pragma unroll
-            for (int i = 0; i < 9; ++i) sm[i] = readlane_f64(src[i], 0);
+            for (int i = 0; i < 9; ++i) sm[i] = readlane_f64(src[model_at(m, i, t)], 0);
             const int c = count_model_exact<K_F7>(sm, P, M, max_res, lane, thr);
             if (lane == t) maxcnt = max(maxcnt, c);
         }
@@ -1594,7 +1644,15 @@ __device__ __forceinline__ H32Rec h32_rec_of(const f16v& q, int half) {  // reco
 #define AMC_H32_BATCH 5   // 64-byte lines (4 correspondences each) requested together
 #endif
 // Upper bound of the lane's model's inlier count: M minus the correspondences that are outliers beyond doubt.
-__device__ __forceinline__ int count_lanes_h32(const H32Lane& hl, const AMC_CONST v2f* tab, int M) {
+// Round 6: the loop ends as soon as NO model of the chunk (`have`: the lane holds one) can reach `thr` any more even if
+// every correspondence to come were an inlier - the replay only asks whether a bound reaches the best count so far, and
+// a bound that counts the unseen correspondences as inliers is still a bound below it.  The homography RANSAC of a
+// non-planar pair (thousands of trials, best count ~ a fifth of the matches, sampled models with a few per cent) stops
+// after ~80 % of the table.
+#ifndef AMC_H32_EXIT_EVERY
+#define AMC_H32_EXIT_EVERY 2   // batches between two looks at the bound (0: never - the round-5 loop)
+#endif
+__device__ __forceinline__ int count_lanes_h32(const H32Lane& hl, const AMC_CONST v2f* tab, int M, int thr, bool have) {
     const H32Splat h = h32_splat(hl);
     const v2f big = (v2f){0x1p100f, 0x1p100f};
     v2f nout = (v2f){0.0f, 0.0f};
@@ -1606,6 +1664,10 @@ __device__ __forceinline__ int count_lanes_h32(const H32Lane& hl, const AMC_CONS
     constexpr int kB = AMC_H32_BATCH;
     const AMC_CONST f16v* tabq = reinterpret_cast<const AMC_CONST f16v*>(tab);
     int k = 0;
+    // a lane is out of the race once its outliers exceed M - thr (sums of 0 / 1 in FP32: exact; a fractional step only
+    // keeps it in longer); lanes without a model never were in it
+    const float dead_above = have ? (float)(M - thr) : -1.0f;
+    int since = 0;
     for (; k + 2 * kB <= np; k += 2 * kB) {
         f16v q[kB];
 #pragma unroll
@@ -1615,6 +1677,10 @@ __device__ __forceinline__ int count_lanes_h32(const H32Lane& hl, const AMC_CONS
             const H32Rec r0 = h32_rec_of(q[j], 0), r1 = h32_rec_of(q[j], 1);
             nout += pk_step(h32_q_pk(h, r0.a, r0.b, r0.cs, r0.ds), big);
             nout += pk_step(h32_q_pk(h, r1.a, r1.b, r1.cs, r1.ds), big);
+        }
+        if (AMC_H32_EXIT_EVERY > 0 && ++since == AMC_H32_EXIT_EVERY) {
+            since = 0;
+            if (__ballot(nout.x + nout.y <= dead_above) == 0ull) return M - (int)(nout.x + nout.y);
         }
     }
     for (; k < np; ++k) {
@@ -1713,10 +1779,10 @@ __device__ __forceinline__ int count_models_lanes(const double* models, int nmod
         const bool valid = idx < total;
         const int e = (int)mlist[valid ? idx : 0];
         const int t = e >> 4, mi = e & 15;
-        const double* src = models + ((size_t)t * kMaxModels + mi) * 9;
+        const AMC_GLOBAL double* src = gptr(models);
         double mm[9];
 #pragma unroll
-        for (int i = 0; i < 9; ++i) mm[i] = src[i];
+        for (int i = 0; i < 9; ++i) mm[i] = src[model_at(mi, i, t)];
         // 64 correspondences at a time.  After each segment the models that can still reach thr - even if every
         // correspondence to come were an inlier - are counted: the RANSACs this path serves (E, F) have a high best
         // count, most sampled models are far below it, and once only a handful of the group's models are alive the
@@ -1776,8 +1842,9 @@ struct E5StageSink {
     double* stg;
     int lane;
     __device__ __forceinline__ void operator()(int r, const double (&row)[20]) {
+        AMC_GLOBAL double* g = gptr(stg);
 #pragma unroll
-        for (int c = 0; c < 20; ++c) stg[(size_t)(r * 20 + c) * 64 + lane] = row[c];
+        for (int c = 0; c < 20; ++c) g[(size_t)(r * 20 + c) * 64 + lane] = row[c];
     }
 };
 template <int OWN>
@@ -1818,7 +1885,8 @@ __device__ __forceinline__ void e5_elim_col(double (&g)[10][5]) {
         for (int c = 0; c < 5; ++c) g[r][c] = g[r][c] - f * g[COL][c];
     }
 }
-__device__ __forceinline__ void e5_eliminate_quads(double* stg, int nT, int lane) {
+__device__ __forceinline__ void e5_eliminate_quads(double* stg_, int nT, int lane) {
+    AMC_GLOBAL double* stg = gptr(stg_);
     const int q = lane >> 2, p = lane & 3;
     for (int pass = 0; pass * 16 < nT; ++pass) {
         const int T = pass * 16 + q;
@@ -1859,9 +1927,9 @@ __device__ AMC_SOLVE_CHUNK_INLINE void solve_chunk(ChunkModels* out, const Pts P
 #pragma unroll
             for (int i = 0; i < 27; ++i) fm[i] = 0.0;
             nmod = estimate_f7(sx1, sy1, sx2, sy2, fm);
-            double* dst = models + (size_t)lane * kMaxModels * 9;
+            AMC_GLOBAL double* dst = gptr(models);
 #pragma unroll
-            for (int i = 0; i < 27; ++i) dst[i] = fm[i];
+            for (int i = 0; i < 27; ++i) dst[model_at(i / 9, i % 9, lane)] = fm[i];
         } else if (EST == K_H) {
             double sx1[4], sy1[4], sx2[4], sy2[4];
 #pragma unroll
@@ -1918,7 +1986,7 @@ __device__ AMC_SOLVE_CHUNK_INLINE void solve_chunk(ChunkModels* out, const Pts P
 #pragma unroll
             for (int r = 0; r < 6; ++r)
 #pragma unroll
-                for (int c = 0; c < 10; ++c) hl[r][c] = models[(size_t)(kE5StageG + r * 10 + c) * 64 + lane];
+                for (int c = 0; c < 10; ++c) hl[r][c] = gptr(models)[(size_t)(kE5StageG + r * 10 + c) * 64 + lane];
             e5_finish(hl, polys);
         }
         wave_mem_sync();  // (the model region is rewritten with the models below)
@@ -1928,7 +1996,18 @@ __device__ AMC_SOLVE_CHUNK_INLINE void solve_chunk(ChunkModels* out, const Pts P
         int nr = real_roots10_lanes(polys.det, roots, full, lane, rootscr);
         if (have && !full) nr = real_roots_t<10>(polys.det, roots);  // a vanishing leading coefficient: the plain chain
         LODIAG_LAP(52);
-        if (have) nmod = e5_models(nsp, polys, roots, nr, models + (size_t)lane * kMaxModels * 9);
+        if (have) {   // e5_models (tvg_math.h) with the element-major table as its output
+            AMC_GLOBAL double* dst = gptr(models);
+#pragma unroll
+            for (int i = 0; i < 10; ++i) {
+                double E[9];
+                if (i < nr && e5_model_from_root(nsp, polys, roots[i], E)) {
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) dst[model_at(nmod, k, lane)] = E[k];
+                    ++nmod;
+                }
+            }
+        }
         LODIAG_LAP(53);
     }
     wave_mem_sync();
@@ -1969,7 +2048,7 @@ __device__ AMC_COUNT_CHUNK_INLINE void count_chunk(ChunkModels* io, const CountC
     } else if (EST == K_H) {
         const double s = 1.0 / dsqrt(max_res);
         const H32Lane hl = h32_prepare(mym, s, cmax);
-        const int ub = count_lanes_h32(hl, as_const_table(reinterpret_cast<const v2f*>(uni_ptr(cc_.p32))), M);
+        const int ub = count_lanes_h32(hl, as_const_table(reinterpret_cast<const v2f*>(uni_ptr(cc_.p32))), M, thr, nmod > 0);
         maxcnt = nmod > 0 ? ub : -1;
     } else if (uni(cc_.fast) == 2) {
         maxcnt = count_models_lanes<true>(models, nmod, uni_ptr(cc_.p64), uni_ptr(cc_.p32), P, M, max_res, cmax, nT, lane, thr,
@@ -2006,6 +2085,11 @@ template <int EST, int LOCAL>
 __device__ Report lo_ransac(Wave& w_io, const RansacCfg& cfg, const double* gx, uint32_t gstride, int M, uint8_t* mask) {
     Wave w = w_io;  // by-value copy: the fields live in registers, not behind a pointer
     const int lane = w.lane;
+    // the trial limits as SCALAR values: kept in a vector register, max_trials was spilled and - round 6, when the
+    // sampler changed the register allocation of the watermark RANSAC - reloaded by the compiler inside the final mask
+    // loop's exit block, where EXEC is still zero: report.num_trials came back as whatever the loop had left in the
+    // register.  A scalar register does not depend on EXEC.
+    const int max_trials = uni(cfg.max_trials), min_trials = uni(cfg.min_trials);
     constexpr int kMin = kmin_of(EST), kLocalMin = kmin_of(LOCAL);
     LoCtx lo;
     lo.inl = w.inl; lo.jacA = w.jacA; lo.jacV = w.jacV; lo.lane = lane;
@@ -2021,7 +2105,7 @@ __device__ Report lo_ransac(Wave& w_io, const RansacCfg& cfg, const double* gx, 
     double best_model[9];
     for (int i = 0; i < 9; ++i) best_model[i] = 0.0;
     bool best_is_local = false;
-    uint32_t dyn_max = (uint32_t)cfg.max_trials;
+    uint32_t dyn_max = (uint32_t)max_trials;
     // residuals this RANSAC evaluates with the reference FP64 expression (candidate re-scores, local-optimisation scores,
     // inlier extraction, the final mask; the whole counting loop where no pre-filter runs): work[WK_EXACT_FLOP]
     unsigned long long exact_evals = 0ull;
@@ -2044,13 +2128,13 @@ __device__ Report lo_ransac(Wave& w_io, const RansacCfg& cfg, const double* gx, 
         double amax = 0.0;
         for (int k = lane; k < M + (M & 1); k += 64) {
             const int kk = k < M ? k : M - 1;  // odd M: the pre-filter table's last pair repeats the last point
-            const PtRec rk = reinterpret_cast<const PtRec*>(gx)[kk];
-            const double p0 = rk.x1, p1 = rk.y1, p2 = rk.x2, p3 = rk.y2;
+            const pt4 rk = gptr(reinterpret_cast<const pt4*>(gx))[kk];
+            const double p0 = rk[0], p1 = rk[1], p2 = rk[2], p3 = rk[3];
             if (EST == K_H) {
-                float* q = p32 + 8 * (size_t)(k >> 1) + (k & 1);
+                AMC_GLOBAL float* q = gptr(p32) + 8 * (size_t)(k >> 1) + (k & 1);
                 q[0] = (float)p0; q[2] = (float)p1; q[4] = (float)(p2 * s); q[6] = (float)(p3 * s);
             } else if (EST != K_T) {
-                float* q = p32 + 8 * (size_t)(k >> 1) + (k & 1);   // the Sampson pre-filter's table: plain coordinates
+                AMC_GLOBAL float* q = gptr(p32) + 8 * (size_t)(k >> 1) + (k & 1);   // the Sampson pre-filter's table: plain coordinates
                 q[0] = (float)p0; q[2] = (float)p1; q[4] = (float)p2; q[6] = (float)p3;
             }
             amax = dmax(dmax(amax, dmax(dabs(p0), dabs(p1))), dmax(dabs(p2), dabs(p3)));
@@ -2080,14 +2164,14 @@ __device__ Report lo_ransac(Wave& w_io, const RansacCfg& cfg, const double* gx, 
     double* models = ws_models(w);
     bool aborted = false;
     int abort_trial = -1;
-    for (int chunk = 0, nT = 0; chunk < cfg.max_trials && !aborted; chunk += nT) {
-        nT = min(64, cfg.max_trials - chunk);
+    for (int chunk = 0, nT = 0; chunk < max_trials && !aborted; chunk += nT) {
+        nT = min(64, max_trials - chunk);
         if (EST == K_E5) {
             // The 5-point chunk costs what its trials cost (root finding is shared out by bracket, the elimination runs
             // 16 problems at a time), and the adaptive limit only ever falls: trials far beyond it will not be looked
             // at.  So the chunk ends a few trials after the limit (the first trial there that has a model stops the
             // loop); should none of those have one, the next chunk carries on from where this one ended.
-            const long long lim = (long long)(dyn_max > (uint32_t)cfg.min_trials ? dyn_max : (uint32_t)cfg.min_trials);
+            const long long lim = (long long)(dyn_max > (uint32_t)min_trials ? dyn_max : (uint32_t)min_trials);
             const long long want = lim - (long long)chunk + 4;
             // (only ever shrink: with fewer than 8 trials left - a small user max_num_trials - the floor of 8 must not
             // carry the chunk past max_trials)
@@ -2097,7 +2181,9 @@ __device__ Report lo_ransac(Wave& w_io, const RansacCfg& cfg, const double* gx, 
         const uint32_t chunk_off = w.soff;
         unsigned long long tp0 = __builtin_readcyclecounter();
         ss.off = w.soff;
-        ss = sample_chunk<kMin>(w.stream, w.stream_len, w.perm, w.sidx, w.rawcnt, ss, M, nT, lane, cfg.force_slow_sampler, w.err);
+        // (the transposed draws lie over jacA | jacV: the local optimisation's scratch holds nothing between two chunks)
+        ss = sample_chunk<kMin>(w.stream, w.stream_len, w.perm, w.sidx, w.rawcnt, reinterpret_cast<lds_u16*>(w.jacA), ss, M, nT, lane,
+                                cfg.force_slow_sampler, w.err);
         w.soff = ss.off;
         { const unsigned long long tp1 = __builtin_readcyclecounter(); w.prof[0] += tp1 - tp0; tp0 = tp1; }
         // ---- 64 minimal problems + the inlier count of every model ---------
@@ -2120,7 +2206,7 @@ __device__ Report lo_ransac(Wave& w_io, const RansacCfg& cfg, const double* gx, 
         const unsigned long long live = nT == 64 ? ~0ull : ((1ull << nT) - 1ull);
         int t = 0;
         while (!aborted) {
-            const long long lim = (long long)(dyn_max > (uint32_t)cfg.min_trials ? dyn_max : (uint32_t)cfg.min_trials) - chunk;
+            const long long lim = (long long)(dyn_max > (uint32_t)min_trials ? dyn_max : (uint32_t)min_trials) - chunk;
             const unsigned long long cand = __ballot(cm.nmod > 0 && cm.maxcnt >= best.cnt);
             const unsigned long long stop = __ballot(cm.nmod > 0 && (long long)lane >= lim);
             const unsigned long long ev = (cand | stop) & live & (t >= 64 ? 0ull : (~0ull << t));
@@ -2132,8 +2218,8 @@ __device__ Report lo_ransac(Wave& w_io, const RansacCfg& cfg, const double* gx, 
                 Model9 smv;
                 double* sm = smv.v;
                 if (EST == K_E5 || EST == K_F7) {
-                    const double* src = models + ((size_t)t * kMaxModels + m) * 9;
-                    for (int i = 0; i < 9; ++i) sm[i] = src[i];
+                    const AMC_GLOBAL double* src = gptr(models);
+                    for (int i = 0; i < 9; ++i) sm[i] = src[model_at(m, i, t)];
                 } else {
                     for (int i = 0; i < 9; ++i) sm[i] = readlane_f64(cm.mym[i], t);
                 }
@@ -2193,18 +2279,18 @@ __device__ Report lo_ransac(Wave& w_io, const RansacCfg& cfg, const double* gx, 
                     } else if (cfg.wm_cut) {
                         // first T in [0, max_trials] with r >= wm_cut[T] (the cut-offs do not increase with T)
                         const double r = (double)best.cnt / (double)M;
-                        int lo_t = 0, hi_t = cfg.max_trials + 1;  // answer in [lo_t, hi_t]; hi_t = none
+                        int lo_t = 0, hi_t = max_trials + 1;  // answer in [lo_t, hi_t]; hi_t = none
                         while (lo_t < hi_t) {
                             const int mid = (lo_t + hi_t) >> 1;
                             if (r >= cfg.wm_cut[mid]) hi_t = mid; else lo_t = mid + 1;
                         }
-                        dyn_max = lo_t <= cfg.max_trials ? (uint32_t)lo_t : 0xFFFFFFFFu;
+                        dyn_max = lo_t <= max_trials ? (uint32_t)lo_t : 0xFFFFFFFFu;
                     } else {
                         dyn_max = 0xFFFFFFFFu;
                     }
                     w.prof[3] += __builtin_readcyclecounter() - tl0;
                 }
-                if ((uint32_t)trial >= dyn_max && trial >= cfg.min_trials) {
+                if ((uint32_t)trial >= dyn_max && trial >= min_trials) {
                     aborted = true;
                     abort_trial = trial;
                     break;
@@ -2231,8 +2317,8 @@ __device__ Report lo_ransac(Wave& w_io, const RansacCfg& cfg, const double* gx, 
         }
     }
     // report.num_trials exactly as the for/abort dance of loransac.h leaves it
-    rep.num_trials = aborted ? ((abort_trial + 1 < cfg.max_trials) ? abort_trial + 2 : abort_trial + 1)
-                             : cfg.max_trials;
+    rep.num_trials = aborted ? ((abort_trial + 1 < max_trials) ? abort_trial + 2 : abort_trial + 1)
+                             : max_trials;
     rep.support = best;
     for (int i = 0; i < 9; ++i) rep.model[i] = best_model[i];
     w_io.soff = w.soff;
@@ -2250,7 +2336,7 @@ __device__ Report lo_ransac(Wave& w_io, const RansacCfg& cfg, const double* gx, 
     for (int k = lane; k < M; k += 64) {
         double a, b, c, d;
         load_pt(P, k, a, b, c, d);
-        mask[k] = residual_of(fk, rep.model, a, b, c, d) <= cfg.max_res ? 1 : 0;
+        gptr(mask)[k] = residual_of(fk, rep.model, a, b, c, d) <= cfg.max_res ? 1 : 0;
     }
     wave_mem_sync();
     LODIAG_LAP(kDiagBase + 5);

@@ -159,6 +159,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(kTvgEWavesP
     w.err = P.stream_err;
     w.soff = 0;
 
+    LODIAG_WAVE_START(gw);
     for (;;) {
         uint32_t q = 0;
         if (lane == 0) q = atomicAdd(queue_head, 1u);
@@ -166,6 +167,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(kTvgEWavesP
         if (q >= npairs) break;
         process_pair_e(w, q, imgs, pairs, matches, trial_tabs, P, estate, emask, out, out_mask);
     }
+    LODIAG_WAVE_END(gw);
 }
 
 
@@ -193,6 +195,7 @@ void tvg_diag_report_e() {
     }
     unsigned long long z[64] = {};
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lo_diag), z, sizeof z);
+    lodiag_report_spans("tvg_e_kernel");
 }
 #else
 void tvg_diag_report_e() {}

@@ -278,6 +278,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(kTvgFhWaves
     w.soff = 0;
     w.rootscr = RootScratch{};  // (the essential-matrix kernel's)
 
+    LODIAG_WAVE_START(gw);
     for (;;) {
         uint32_t q = 0;
         if (lane == 0) q = atomicAdd(queue_head, 1u);
@@ -285,6 +286,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(kTvgFhWaves
         if (q >= npairs) break;
         process_pair_fh(w, q, imgs, pairs, matches, trial_tabs, P, estate, emask, out, out_mask);
     }
+    LODIAG_WAVE_END(gw);
 }
 
 #if !defined(AMC_TVG_BIG)
@@ -317,6 +319,7 @@ void tvg_diag_report() {
     }
     unsigned long long z[48] = {};
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lo_diag), z, sizeof z);
+    lodiag_report_spans("tvg_fh_kernel");
 }
 #else
 void tvg_diag_report() {}
