@@ -2653,9 +2653,14 @@ static int verify_finish(amc_ctx* c, VerifyRun& run, const uint64_t* match_offse
         unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         for (size_t p = 0; p < npairs; ++p)
             for (int i = 0; i < 8; ++i) acc[i] += h_out[p].prof[i];
+        if (acc[4] == 0)
+            std::fprintf(stderr, "[amc tvg profile] the kernels' cycle counters are compiled out of this build (-DAMC_TVG_PROF or the "
+                         "-DAMC_TVG_LODIAG build: tools/variant_build_tvg.sh)\n");
+        else
         std::fprintf(stderr, "[amc tvg profile] pairs=%zu cycles/pair: sampling=%.0f minimal=%.0f replay+score=%.0f "
                      "(of which LO=%.0f) total=%.0f\n", npairs, (double)acc[0] / npairs, (double)acc[1] / npairs,
                      (double)acc[2] / npairs, (double)acc[3] / npairs, (double)acc[4] / npairs);
+        if (acc[4] != 0)
         std::fprintf(stderr, "[amc tvg profile] per pair: counting loop=%.0f local_estimate(E5)=%.0f local_estimate(F8)=%.0f\n",
                      (double)acc[5] / npairs, (double)acc[6] / npairs, (double)acc[7] / npairs);
     }

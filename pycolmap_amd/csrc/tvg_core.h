@@ -57,10 +57,30 @@ constexpr int kModelDoubles = 64 * kMaxModels * 9;
 // 720 bytes of its own: a store instruction of the solving lanes touched 64 lines (5,760 partial-line writes per
 // 5-point chunk, and the wave waited for them before the counting loop could read the table); element-major a store
 // is 512 contiguous bytes.
+#if defined(AMC_MODELS_BY_TRIAL)   // (A/B hook: the round-5 layout)
+__device__ __forceinline__ constexpr size_t model_at(int m, int i, int t) { return ((size_t)t * kMaxModels + m) * 9 + i; }
+#else
 __device__ __forceinline__ constexpr size_t model_at(int m, int i, int t) { return (size_t)(m * 9 + i) * 64 + (size_t)t; }
+#endif
 
 // LDS objects are addressed through address-space-3 pointers so that every access is a ds_* instruction (a generic
 // pointer makes the compiler emit flat_* loads, which take the vector-memory path and cost several hundred cycles).
+// The per-pair cycle counters (TvgOut::prof, printed by the host with AMC_TVG_PROFILE=1) are compiled in only with
+// -DAMC_TVG_PROF or in the -DAMC_TVG_LODIAG build (round 6): eight 64-bit counters live through the whole pair and a
+// dozen clock reads per 64-trial chunk - each one a wait for every outstanding LDS and scalar access - cost registers
+// (spills around the chunk's calls) in the build that ships.
+#if defined(AMC_TVG_LODIAG) || defined(AMC_TVG_PROF)
+#define AMC_TVG_PROF_ON 1
+#else
+#define AMC_TVG_PROF_ON 0
+#endif
+__device__ __forceinline__ unsigned long long prof_clock() {
+#if AMC_TVG_PROF_ON
+    return __builtin_readcyclecounter();
+#else
+    return 0ull;
+#endif
+}
 #define AMC_LDS __attribute__((address_space(3)))
 typedef AMC_LDS double lds_f64;
 typedef AMC_LDS uint32_t lds_u32;
@@ -1644,15 +1664,9 @@ __device__ __forceinline__ H32Rec h32_rec_of(const f16v& q, int half) {  // reco
 #define AMC_H32_BATCH 5   // 64-byte lines (4 correspondences each) requested together
 #endif
 // Upper bound of the lane's model's inlier count: M minus the correspondences that are outliers beyond doubt.
-// Round 6: the loop ends as soon as NO model of the chunk (`have`: the lane holds one) can reach `thr` any more even if
-// every correspondence to come were an inlier - the replay only asks whether a bound reaches the best count so far, and
-// a bound that counts the unseen correspondences as inliers is still a bound below it.  The homography RANSAC of a
-// non-planar pair (thousands of trials, best count ~ a fifth of the matches, sampled models with a few per cent) stops
-// after ~80 % of the table.
-#ifndef AMC_H32_EXIT_EVERY
-#define AMC_H32_EXIT_EVERY 2   // batches between two looks at the bound (0: never - the round-5 loop)
-#endif
-__device__ __forceinline__ int count_lanes_h32(const H32Lane& hl, const AMC_CONST v2f* tab, int M, int thr, bool have) {
+// (Round 6: leaving the loop once no model of the chunk can reach the best count any more - ~80 % into the table of a
+// non-planar pair - measured: no gain, the look at the bound every 40 correspondences costs what the skipped tail saves.)
+__device__ __forceinline__ int count_lanes_h32(const H32Lane& hl, const AMC_CONST v2f* tab, int M) {
     const H32Splat h = h32_splat(hl);
     const v2f big = (v2f){0x1p100f, 0x1p100f};
     v2f nout = (v2f){0.0f, 0.0f};
@@ -1664,10 +1678,6 @@ __device__ __forceinline__ int count_lanes_h32(const H32Lane& hl, const AMC_CONS
     constexpr int kB = AMC_H32_BATCH;
     const AMC_CONST f16v* tabq = reinterpret_cast<const AMC_CONST f16v*>(tab);
     int k = 0;
-    // a lane is out of the race once its outliers exceed M - thr (sums of 0 / 1 in FP32: exact; a fractional step only
-    // keeps it in longer); lanes without a model never were in it
-    const float dead_above = have ? (float)(M - thr) : -1.0f;
-    int since = 0;
     for (; k + 2 * kB <= np; k += 2 * kB) {
         f16v q[kB];
 #pragma unroll
@@ -1677,10 +1687,6 @@ __device__ __forceinline__ int count_lanes_h32(const H32Lane& hl, const AMC_CONS
             const H32Rec r0 = h32_rec_of(q[j], 0), r1 = h32_rec_of(q[j], 1);
             nout += pk_step(h32_q_pk(h, r0.a, r0.b, r0.cs, r0.ds), big);
             nout += pk_step(h32_q_pk(h, r1.a, r1.b, r1.cs, r1.ds), big);
-        }
-        if (AMC_H32_EXIT_EVERY > 0 && ++since == AMC_H32_EXIT_EVERY) {
-            since = 0;
-            if (__ballot(nout.x + nout.y <= dead_above) == 0ull) return M - (int)(nout.x + nout.y);
         }
     }
     for (; k < np; ++k) {
@@ -1909,7 +1915,7 @@ __device__ __forceinline__ void e5_eliminate_quads(double* stg_, int nT, int lan
 template <int EST>
 __device__ AMC_SOLVE_CHUNK_INLINE void solve_chunk(ChunkModels* out, const Pts P_, const lds_u16* sidx_, int nT_, int lane,
                                          double* models_, const RootScratch rootscr) {
-    const unsigned long long c0 = __builtin_readcyclecounter();
+    const unsigned long long c0 = prof_clock();
     const Pts P = uni(P_);
     const lds_u16* sidx = uni_lds(sidx_);
     const int nT = uni(nT_);
@@ -1998,10 +2004,13 @@ __device__ AMC_SOLVE_CHUNK_INLINE void solve_chunk(ChunkModels* out, const Pts P
         LODIAG_LAP(52);
         if (have) {   // e5_models (tvg_math.h) with the element-major table as its output
             AMC_GLOBAL double* dst = gptr(models);
+#pragma unroll 1
+            for (int i = 0; i < nr; ++i) {
+                double z = roots[0];   // roots[i] by selects: the array stays in registers
 #pragma unroll
-            for (int i = 0; i < 10; ++i) {
+                for (int q = 1; q < 10; ++q) z = i == q ? roots[q] : z;
                 double E[9];
-                if (i < nr && e5_model_from_root(nsp, polys, roots[i], E)) {
+                if (e5_model_from_root(nsp, polys, z, E)) {
 #pragma unroll
                     for (int k = 0; k < 9; ++k) dst[model_at(nmod, k, lane)] = E[k];
                     ++nmod;
@@ -2014,7 +2023,7 @@ __device__ AMC_SOLVE_CHUNK_INLINE void solve_chunk(ChunkModels* out, const Pts P
 #pragma unroll
     for (int i = 0; i < 9; ++i) out->mym[i] = mym[i];
     out->nmod = nmod;
-    out->cyc_solve = __builtin_readcyclecounter() - c0;
+    out->cyc_solve = prof_clock() - c0;
 }
 
 struct CountCtx {  // wave-uniform inputs of count_chunk
@@ -2029,7 +2038,7 @@ struct CountCtx {  // wave-uniform inputs of count_chunk
 };
 template <int EST>
 __device__ AMC_COUNT_CHUNK_INLINE void count_chunk(ChunkModels* io, const CountCtx cc_, int lane) {
-    const unsigned long long c1 = __builtin_readcyclecounter();
+    const unsigned long long c1 = prof_clock();
     const Pts P = uni(cc_.P);
     const int M = uni(cc_.M), nT = uni(cc_.nT), thr = uni(cc_.thr);
     const bool fast = uni(cc_.fast) != 0;
@@ -2048,7 +2057,7 @@ __device__ AMC_COUNT_CHUNK_INLINE void count_chunk(ChunkModels* io, const CountC
     } else if (EST == K_H) {
         const double s = 1.0 / dsqrt(max_res);
         const H32Lane hl = h32_prepare(mym, s, cmax);
-        const int ub = count_lanes_h32(hl, as_const_table(reinterpret_cast<const v2f*>(uni_ptr(cc_.p32))), M, thr, nmod > 0);
+        const int ub = count_lanes_h32(hl, as_const_table(reinterpret_cast<const v2f*>(uni_ptr(cc_.p32))), M);
         maxcnt = nmod > 0 ? ub : -1;
     } else if (uni(cc_.fast) == 2) {
         maxcnt = count_models_lanes<true>(models, nmod, uni_ptr(cc_.p64), uni_ptr(cc_.p32), P, M, max_res, cmax, nT, lane, thr,
@@ -2058,7 +2067,7 @@ __device__ AMC_COUNT_CHUNK_INLINE void count_chunk(ChunkModels* io, const CountC
                                            uni_lds(cc_.mlist), uni_lds(cc_.tmax));
     }
     io->maxcnt = maxcnt;
-    io->cyc_count = __builtin_readcyclecounter() - c1;
+    io->cyc_count = prof_clock() - c1;
 }
 
 struct Report {
@@ -2179,13 +2188,13 @@ __device__ Report lo_ransac(Wave& w_io, const RansacCfg& cfg, const double* gx, 
         }
         // ---- draw the chunk's samples ----
         const uint32_t chunk_off = w.soff;
-        unsigned long long tp0 = __builtin_readcyclecounter();
+        unsigned long long tp0 = prof_clock();
         ss.off = w.soff;
         // (the transposed draws lie over jacA | jacV: the local optimisation's scratch holds nothing between two chunks)
         ss = sample_chunk<kMin>(w.stream, w.stream_len, w.perm, w.sidx, w.rawcnt, reinterpret_cast<lds_u16*>(w.jacA), ss, M, nT, lane,
                                 cfg.force_slow_sampler, w.err);
         w.soff = ss.off;
-        { const unsigned long long tp1 = __builtin_readcyclecounter(); w.prof[0] += tp1 - tp0; tp0 = tp1; }
+        { const unsigned long long tp1 = prof_clock(); w.prof[0] += tp1 - tp0; tp0 = tp1; }
         // ---- 64 minimal problems + the inlier count of every model ---------
         ChunkModels cm;
         solve_chunk<EST>(&cm, P, w.sidx, nT, lane, models, w.rootscr);
@@ -2198,7 +2207,7 @@ __device__ Report lo_ransac(Wave& w_io, const RansacCfg& cfg, const double* gx, 
         if (lane == 0) { atomicAdd(&g_lo_diag[kDiagBase + 6], (unsigned long long)cm.cyc_solve); atomicAdd(&g_lo_diag[kDiagBase + 7], (unsigned long long)cm.cyc_count); }
 #endif
         w.prof[5] += cm.cyc_count;  // the counting loop alone (also part of prof[2])
-        tp0 = __builtin_readcyclecounter();
+        tp0 = prof_clock();
         // ---- replay in trial order.  Only two kinds of trial can change anything: one holding a
         //      model whose count reaches the best so far (candidate: re-scored in full, exactly as
         //      the sequential loop would), and the first trial with a model at or beyond the
@@ -2224,15 +2233,15 @@ __device__ Report lo_ransac(Wave& w_io, const RansacCfg& cfg, const double* gx, 
                     for (int i = 0; i < 9; ++i) sm[i] = readlane_f64(cm.mym[i], t);
                 }
 #if defined(AMC_TVG_LODIAG)
-                const unsigned long long sc0_ = __builtin_readcyclecounter();
+                const unsigned long long sc0_ = prof_clock();
 #endif
                 const Support sup = score<(EST == K_E5 ? K_F7 : EST)>(smv, P, M, cfg.max_res, lane, best.cnt);
                 exact_evals += (unsigned long long)M;
 #if defined(AMC_TVG_LODIAG)
-                if (lane == 0) { atomicAdd(&g_lo_diag[kDiagBase + 3], 1ull); atomicAdd(&g_lo_diag[kDiagBase + 4], __builtin_readcyclecounter() - sc0_); }
+                if (lane == 0) { atomicAdd(&g_lo_diag[kDiagBase + 3], 1ull); atomicAdd(&g_lo_diag[kDiagBase + 4], prof_clock() - sc0_); }
 #endif
                 if (better(sup, best)) {
-                    const unsigned long long tl0 = __builtin_readcyclecounter();
+                    const unsigned long long tl0 = prof_clock();
                     best = sup;
                     for (int i = 0; i < 9; ++i) best_model[i] = sm[i];
                     best_is_local = false;
@@ -2246,7 +2255,7 @@ __device__ Report lo_ransac(Wave& w_io, const RansacCfg& cfg, const double* gx, 
                             const int K = extract_inliers(w.inl, lane, cur_kind, cur, P, M, cfg.max_res);
                             exact_evals += (unsigned long long)M;
                             double lm[(LOCAL == K_E5 ? kMaxModels : 1) * 9];
-                            const unsigned long long tle = __builtin_readcyclecounter();
+                            const unsigned long long tle = prof_clock();
                             const int nl = local_estimate<LOCAL>(lo, P, K, lm);
                             if (lane == 0) {
                                 w.work[wk_residual_slot(LOCAL)] += (unsigned long long)nl * (unsigned long long)M;
@@ -2255,8 +2264,8 @@ __device__ Report lo_ransac(Wave& w_io, const RansacCfg& cfg, const double* gx, 
                                 else if (LOCAL == K_H) w.work[WK_LO_H] += 1;
                                 w.work[WK_LO_POINTS] += (unsigned long long)K;
                             }
-                            if (LOCAL == K_E5) w.prof[6] += __builtin_readcyclecounter() - tle;
-                            else if (LOCAL == K_F8) w.prof[7] += __builtin_readcyclecounter() - tle;
+                            if (LOCAL == K_E5) w.prof[6] += prof_clock() - tle;
+                            else if (LOCAL == K_F8) w.prof[7] += prof_clock() - tle;
                             const int prev = best.cnt;
                             for (int q = 0; q < nl; ++q) {
                                 Model9 lmv;
@@ -2288,7 +2297,7 @@ __device__ Report lo_ransac(Wave& w_io, const RansacCfg& cfg, const double* gx, 
                     } else {
                         dyn_max = 0xFFFFFFFFu;
                     }
-                    w.prof[3] += __builtin_readcyclecounter() - tl0;
+                    w.prof[3] += prof_clock() - tl0;
                 }
                 if ((uint32_t)trial >= dyn_max && trial >= min_trials) {
                     aborted = true;
@@ -2299,7 +2308,7 @@ __device__ Report lo_ransac(Wave& w_io, const RansacCfg& cfg, const double* gx, 
             ++t;
         }
         w.prof[2] += cm.cyc_count;
-        { const unsigned long long tp1 = __builtin_readcyclecounter(); w.prof[2] += tp1 - tp0; }
+        { const unsigned long long tp1 = prof_clock(); w.prof[2] += tp1 - tp0; }
         {   // algorithmic work of the chunk: the trials the sequential loop ran, their models x M residuals
             const int upto = aborted ? abort_trial - chunk : nT - 1;
             const int nmodels = wave_sum_int(lane <= upto ? cm.nmod : 0);
@@ -2330,7 +2339,7 @@ __device__ Report lo_ransac(Wave& w_io, const RansacCfg& cfg, const double* gx, 
     if (best.cnt < kMin) return rep;
     rep.success = true;
 #if defined(AMC_TVG_LODIAG)
-    lodiag_t_ = __builtin_readcyclecounter();
+    lodiag_t_ = prof_clock();
 #endif
     const int fk = best_is_local ? LOCAL : EST;
     for (int k = lane; k < M; k += 64) {

@@ -19,7 +19,7 @@ __device__ __noinline__ void process_pair_e(Wave& w, uint32_t q, const TvgImage*
     const TvgPair pr = pairs[q];
     const uint32_t oq = pr.orig;
     w.work = out[oq].work;
-    const unsigned long long tstart = __builtin_readcyclecounter();
+    const unsigned long long tstart = prof_clock();
     const TvgImage* __restrict__ pim1 = imgs + pr.slot1;
     const TvgImage* __restrict__ pim2 = imgs + pr.slot2;
     const int M = (int)pr.M;
@@ -126,8 +126,8 @@ __device__ __noinline__ void process_pair_e(Wave& w, uint32_t q, const TvgImage*
         if (lane == 0) out[oq].g = g;
     }
     if (lane == 0) {
-        w.prof[4] = __builtin_readcyclecounter() - tstart;
-        for (int i = 0; i < 8; ++i) out[oq].prof[i] += w.prof[i];
+        w.prof[4] = prof_clock() - tstart;
+        if (AMC_TVG_PROF_ON) for (int i = 0; i < 8; ++i) out[oq].prof[i] += w.prof[i];
     }
 }
 

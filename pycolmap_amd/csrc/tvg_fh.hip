@@ -25,7 +25,7 @@ __device__ __noinline__ void process_pair_fh(Wave& w, uint32_t q, const TvgImage
     const TvgPair pr = pairs[q];
     const uint32_t oq = pr.orig;  // results are stored by the caller's pair index, whatever the queue order
     w.work = out[oq].work;        // zeroed by the host before the launches; both kernels add to it
-    const unsigned long long tstart = __builtin_readcyclecounter();
+    const unsigned long long tstart = prof_clock();
     // the image records are read field by field where they are needed (wave-uniform scalar loads): a by-value
     // copy of both would hold 2 x 38 dwords of camera parameters in scalar registers for the whole pair
     const TvgImage* __restrict__ pim1 = imgs + pr.slot1;
@@ -145,8 +145,8 @@ __device__ __noinline__ void process_pair_fh(Wave& w, uint32_t q, const TvgImage
             for (int k = lane; k < M; k += 64) omask[k] = rm[k];
         if (lane == 0) {
             out[oq].g = g;
-            w.prof[4] = __builtin_readcyclecounter() - tstart;
-            for (int i = 0; i < 8; ++i) out[oq].prof[i] += w.prof[i];
+            w.prof[4] = prof_clock() - tstart;
+            if (AMC_TVG_PROF_ON) for (int i = 0; i < 8; ++i) out[oq].prof[i] += w.prof[i];
         }
         return;
     }
@@ -245,8 +245,8 @@ __device__ __noinline__ void process_pair_fh(Wave& w, uint32_t q, const TvgImage
     }
     if (lane == 0) {
         out[oq].g = g;
-        w.prof[4] = __builtin_readcyclecounter() - tstart;
-        for (int i = 0; i < 8; ++i) out[oq].prof[i] += w.prof[i];
+        w.prof[4] = prof_clock() - tstart;
+        if (AMC_TVG_PROF_ON) for (int i = 0; i < 8; ++i) out[oq].prof[i] += w.prof[i];
     }
 }
 
