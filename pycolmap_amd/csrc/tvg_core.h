@@ -2094,6 +2094,23 @@ template <int EST, int LOCAL>
 __device__ Report lo_ransac(Wave& w_io, const RansacCfg& cfg, const double* gx, uint32_t gstride, int M, uint8_t* mask) {
     Wave w = w_io;  // by-value copy: the fields live in registers, not behind a pointer
     const int lane = w.lane;
+#if !defined(AMC_TVG_NO_UNIFORM_STATE)
+    // ... and, round 6, in SCALAR registers: every field is wave-uniform, but it arrives through memory (the Wave of
+    // the kernel's frame), so the compiler kept ~40 vector registers of pointers and positions alive across the chunk
+    // loop's calls and spilled them to scratch around each one (scratch traffic is most of what these kernels move
+    // through the memory side; a scalar that does not fit goes to a lane of a vector register instead).  Same for the
+    // best model and support below, and the sampler's state.
+    w.sidx = uni_lds(w.sidx); w.rawcnt = uni_lds(w.rawcnt); w.tmax = uni_lds(w.tmax); w.mlist = uni_lds(w.mlist);
+    w.perm = uni_idx(w.perm); w.inl = uni_idx(w.inl); w.jacA = uni_lds(w.jacA); w.jacV = uni_lds(w.jacV);
+    w.stream = uni_ptr(w.stream); w.stream_len = uni(w.stream_len); w.soff = uni(w.soff); w.err = uni_ptr(w.err);
+    w.ws = uni_ptr(w.ws); w.masks = uni_ptr(w.masks); w.mcap = uni(w.mcap); w.work = uni_ptr(w.work);
+    w.rootscr.coef = uni_lds(w.rootscr.coef); w.rootscr.lo = uni_lds(w.rootscr.lo); w.rootscr.hi = uni_lds(w.rootscr.hi);
+    w.rootscr.flo = uni_lds(w.rootscr.flo); w.rootscr.src = uni_lds(w.rootscr.src);
+    gx = uni_ptr(gx); gstride = uni(gstride); M = uni(M); mask = uni_ptr(mask);
+#define AMC_UNI(x) uni(x)
+#else
+#define AMC_UNI(x) (x)
+#endif
     // the trial limits as SCALAR values: kept in a vector register, max_trials was spilled and - round 6, when the
     // sampler changed the register allocation of the watermark RANSAC - reloaded by the compiler inside the final mask
     // loop's exit block, where EXEC is still zero: report.num_trials came back as whatever the loop had left in the
@@ -2193,6 +2210,9 @@ __device__ Report lo_ransac(Wave& w_io, const RansacCfg& cfg, const double* gx, 
         // (the transposed draws lie over jacA | jacV: the local optimisation's scratch holds nothing between two chunks)
         ss = sample_chunk<kMin>(w.stream, w.stream_len, w.perm, w.sidx, w.rawcnt, reinterpret_cast<lds_u16*>(w.jacA), ss, M, nT, lane,
                                 cfg.force_slow_sampler, w.err);
+        ss.off = AMC_UNI(ss.off);
+#pragma unroll
+        for (int i = 0; i < 7; ++i) ss.pr[i] = AMC_UNI(ss.pr[i]);
         w.soff = ss.off;
         { const unsigned long long tp1 = prof_clock(); w.prof[0] += tp1 - tp0; tp0 = tp1; }
         // ---- 64 minimal problems + the inlier count of every model ---------
@@ -2242,8 +2262,8 @@ __device__ Report lo_ransac(Wave& w_io, const RansacCfg& cfg, const double* gx, 
 #endif
                 if (better(sup, best)) {
                     const unsigned long long tl0 = prof_clock();
-                    best = sup;
-                    for (int i = 0; i < 9; ++i) best_model[i] = sm[i];
+                    best.cnt = AMC_UNI(sup.cnt); best.sum = AMC_UNI(sup.sum);
+                    for (int i = 0; i < 9; ++i) best_model[i] = AMC_UNI(sm[i]);
                     best_is_local = false;
                     if (sup.cnt > kMin && sup.cnt >= kLocalMin) {
                         // recursive local optimisation: inliers of the sample model first, then of
@@ -2273,8 +2293,8 @@ __device__ Report lo_ransac(Wave& w_io, const RansacCfg& cfg, const double* gx, 
                                 const Support ls = score<(LOCAL == K_E5 || LOCAL == K_F8 ? K_F7 : LOCAL)>(lmv, P, M, cfg.max_res, lane, best.cnt);
                                 exact_evals += (unsigned long long)M;
                                 if (better(ls, best)) {
-                                    best = ls;
-                                    for (int i = 0; i < 9; ++i) best_model[i] = lm[9 * q + i];
+                                    best.cnt = AMC_UNI(ls.cnt); best.sum = AMC_UNI(ls.sum);
+                                    for (int i = 0; i < 9; ++i) best_model[i] = AMC_UNI(lm[9 * q + i]);
                                     best_is_local = true;
                                 }
                             }
