@@ -1160,7 +1160,7 @@ __device__ __noinline__ void e5_build_wave(const double* nsp, E5Polys& P, lds_f6
     e5_finish(hl, P);
 }
 // e5_models with root i on lane i; the models come back wave-uniform, in root order
-__device__ __noinline__ int e5_models_wave(const double* nsp, const E5Polys& P, const double* roots, int nr, double* models,
+__device__ __noinline__ int e5_models_wave(const double* nsp, const E5Polys& P, const double* roots, int nr, lds_f64* models,
                                            int lane) {
     double z = roots[0];
 #pragma unroll
@@ -1173,7 +1173,10 @@ __device__ __noinline__ int e5_models_wave(const double* nsp, const E5Polys& P, 
         const int src = (int)__builtin_ctzll(mask);
         mask &= mask - 1;
 #pragma unroll
-        for (int i = 0; i < 9; ++i) models[9 * nm + i] = readlane_f64(E[i], src);
+        for (int i = 0; i < 9; ++i) {
+            const double e = readlane_f64(E[i], src);
+            if (lane == 0) models[9 * nm + i] = e;
+        }
         ++nm;
     }
     return nm;
@@ -1224,9 +1227,18 @@ inline void lodiag_report_spans(const char* name) {
 #ifndef AMC_LOCAL_INLINE
 #define AMC_LOCAL_INLINE __noinline__
 #endif
+// The models come back in LDS, at w.jacA (round 6: they are wave-uniform, and as a private array of the caller every
+// lane stored its copy to scratch - 46 KB per local 5-point solve - and read it back).
+__device__ __forceinline__ void put_models(lds_f64* dst, const double* m, int n, int lane) {
+    wave_lds_sync();  // (every lane has read what the solve kept in jacA | jacV)
+    if (lane == 0)
+        for (int i = 0; i < n; ++i) dst[i] = m[i];
+}
 template <int LOCAL>
-__device__ AMC_LOCAL_INLINE int local_estimate(const LoCtx w, const Pts P, int K, double* models) {
+__device__ AMC_LOCAL_INLINE int local_estimate(const LoCtx w, const Pts P, int K) {
     const int lane = w.lane;
+    lds_f64* out = w.jacA;
+    double models[9];
     if (LOCAL == K_T) {
         double a = 0, b = 0, c = 0, d = 0;
         for (int k = lane; k < K; k += 64) {
@@ -1239,13 +1251,16 @@ __device__ AMC_LOCAL_INLINE int local_estimate(const LoCtx w, const Pts P, int K
         for (int i = 0; i < 9; ++i) models[i] = 0.0;
         models[0] = dx - sx;
         models[1] = dy - sy;
+        put_models(out, models, 9, lane);
         return 1;
     }
     if (LOCAL == K_E5) {
         if (K == 5) {
-            double a[5], b[5], c[5], d[5];
+            double a[5], b[5], c[5], d[5], em[kMaxModels * 9];
             for (int i = 0; i < 5; ++i) load_pt(P, w.inl[i], a[i], b[i], c[i], d[i]);
-            return estimate_e5_minimal(a, b, c, d, models);
+            const int nm = estimate_e5_minimal(a, b, c, d, em);
+            put_models(out, em, 9 * nm, lane);
+            return nm;
         }
         LODIAG_T0();
         LODIAG_COUNT(0);
@@ -1262,7 +1277,8 @@ __device__ AMC_LOCAL_INLINE int local_estimate(const LoCtx w, const Pts P, int K
         double roots[10];
         const int nr = real_roots10_wave(polys.det, roots, w.jacA, lane);
         LODIAG_LAP(4);
-        const int nm = e5_models_wave(nsp, polys, roots, nr, models, lane);
+        wave_lds_sync();  // (the root finder is done with jacA)
+        const int nm = e5_models_wave(nsp, polys, roots, nr, out, lane);
         LODIAG_LAP(5);
         return nm;
     }
@@ -1270,6 +1286,7 @@ __device__ AMC_LOCAL_INLINE int local_estimate(const LoCtx w, const Pts P, int K
         double a[4], b[4], c[4], d[4];
         for (int i = 0; i < 4; ++i) load_pt(P, w.inl[i], a[i], b[i], c[i], d[i]);
         estimate_h4(a, b, c, d, models);
+        put_models(out, models, 9, lane);
         return 1;
     }
     double T1[9], T2[9];
@@ -1296,6 +1313,7 @@ __device__ AMC_LOCAL_INLINE int local_estimate(const LoCtx w, const Pts P, int K
         h_denormalize(h, T1, T2, models);
         LODIAG_LAP(15);
     }
+    put_models(out, models, 9, lane);
     return 1;
 }
 
@@ -1428,8 +1446,7 @@ __device__ __noinline__ int real_roots10_lanes(const double* c_in, double* roots
 #ifndef AMC_COUNT_CHUNK_INLINE
 #define AMC_COUNT_CHUNK_INLINE __forceinline__   // (same box, kernels per 124,750 pairs: 419.6 / 421.7 ms as a call, 414.3 / 417.3 inlined)
 #endif
-struct ChunkModels {
-    double mym[9];
+struct ChunkModels {   // returned by value (registers); the models themselves are in the wave's model table
     int nmod;    // models of this lane's trial
     int maxcnt;  // max inlier count over them (-1: none)
     unsigned long long cyc_solve, cyc_count;
@@ -1913,8 +1930,8 @@ __device__ __forceinline__ void e5_eliminate_quads(double* stg_, int nT, int lan
 }
 
 template <int EST>
-__device__ AMC_SOLVE_CHUNK_INLINE void solve_chunk(ChunkModels* out, const Pts P_, const lds_u16* sidx_, int nT_, int lane,
-                                         double* models_, const RootScratch rootscr) {
+__device__ AMC_SOLVE_CHUNK_INLINE ChunkModels solve_chunk(const Pts P_, const lds_u16* sidx_, int nT_, int lane,
+                                                double* models_, const RootScratch rootscr) {
     const unsigned long long c0 = prof_clock();
     const Pts P = uni(P_);
     const lds_u16* sidx = uni_lds(sidx_);
@@ -2019,11 +2036,18 @@ __device__ AMC_SOLVE_CHUNK_INLINE void solve_chunk(ChunkModels* out, const Pts P
         }
         LODIAG_LAP(53);
     }
-    wave_mem_sync();
+    if (EST == K_H || EST == K_T) {   // one model per trial: slot 0 of the table (round 6: it crossed to the caller through
+        AMC_GLOBAL double* dst = gptr(models);   // a struct in scratch, was reloaded and spilled again for the replay)
 #pragma unroll
-    for (int i = 0; i < 9; ++i) out->mym[i] = mym[i];
-    out->nmod = nmod;
-    out->cyc_solve = prof_clock() - c0;
+        for (int i = 0; i < 9; ++i) dst[model_at(0, i, lane)] = mym[i];
+    }
+    wave_mem_sync();
+    ChunkModels out;
+    out.nmod = nmod;
+    out.maxcnt = -1;
+    out.cyc_solve = prof_clock() - c0;
+    out.cyc_count = 0;
+    return out;
 }
 
 struct CountCtx {  // wave-uniform inputs of count_chunk
@@ -2045,8 +2069,14 @@ __device__ AMC_COUNT_CHUNK_INLINE void count_chunk(ChunkModels* io, const CountC
     const double max_res = uni(cc_.max_res), cmax = uni(cc_.cmax);
     const double* models = uni_ptr(cc_.models);
     double mym[9];
+    if (EST == K_H || EST == K_T) {
+        const AMC_GLOBAL double* src = gptr(models);
 #pragma unroll
-    for (int i = 0; i < 9; ++i) mym[i] = io->mym[i];
+        for (int i = 0; i < 9; ++i) mym[i] = src[model_at(0, i, lane)];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) mym[i] = 0.0;
+    }
     const int nmod = io->nmod;
     int maxcnt;
     if (EST == K_T) {
@@ -2216,8 +2246,7 @@ __device__ Report lo_ransac(Wave& w_io, const RansacCfg& cfg, const double* gx, 
         w.soff = ss.off;
         { const unsigned long long tp1 = prof_clock(); w.prof[0] += tp1 - tp0; tp0 = tp1; }
         // ---- 64 minimal problems + the inlier count of every model ---------
-        ChunkModels cm;
-        solve_chunk<EST>(&cm, P, w.sidx, nT, lane, models, w.rootscr);
+        ChunkModels cm = solve_chunk<EST>(P, w.sidx, nT, lane, models, w.rootscr);
         CountCtx cc;
         cc.P = P; cc.p64 = p64; cc.p32 = p32; cc.models = models; cc.mlist = w.mlist; cc.tmax = w.tmax;
         cc.M = M; cc.nT = nT; cc.thr = best.cnt; cc.fast = fast_count; cc.max_res = cfg.max_res; cc.cmax = cmax;
@@ -2250,7 +2279,8 @@ __device__ Report lo_ransac(Wave& w_io, const RansacCfg& cfg, const double* gx, 
                     const AMC_GLOBAL double* src = gptr(models);
                     for (int i = 0; i < 9; ++i) sm[i] = src[model_at(m, i, t)];
                 } else {
-                    for (int i = 0; i < 9; ++i) sm[i] = readlane_f64(cm.mym[i], t);
+                    const AMC_GLOBAL double* src = gptr(models);
+                    for (int i = 0; i < 9; ++i) sm[i] = src[model_at(0, i, t)];
                 }
 #if defined(AMC_TVG_LODIAG)
                 const unsigned long long sc0_ = prof_clock();
@@ -2274,9 +2304,10 @@ __device__ Report lo_ransac(Wave& w_io, const RansacCfg& cfg, const double* gx, 
                         for (int lt = 0; lt < 10; ++lt) {
                             const int K = extract_inliers(w.inl, lane, cur_kind, cur, P, M, cfg.max_res);
                             exact_evals += (unsigned long long)M;
-                            double lm[(LOCAL == K_E5 ? kMaxModels : 1) * 9];
+                            const lds_f64* lm = lo.jacA;   // the local models, wave-uniform, in LDS
                             const unsigned long long tle = prof_clock();
-                            const int nl = local_estimate<LOCAL>(lo, P, K, lm);
+                            const int nl = AMC_UNI(local_estimate<LOCAL>(lo, P, K));
+                            wave_lds_sync();
                             if (lane == 0) {
                                 w.work[wk_residual_slot(LOCAL)] += (unsigned long long)nl * (unsigned long long)M;
                                 if (LOCAL == K_E5) w.work[WK_LO_E5] += 1;
