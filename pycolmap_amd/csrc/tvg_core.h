@@ -210,6 +210,7 @@ __host__ __device__ inline size_t tvg_idx_doubles(uint32_t mcap) { return (tvg_i
 // rawcnt, between them, stays: the sampler's draw counts are read again when a trial aborts the chunk.
 constexpr int kRootCap = 128;  // = one pair of brackets per lane and pass
 constexpr size_t kRootScratchBytes = (size_t)11 * 64 * 8;
+static_assert((size_t)102 * 8 <= kRootScratchBytes, "the local 5-point solve's uniform data (kE5UniDoubles) fits the coefficient area");
 __host__ __device__ inline size_t tvg_lds_per_wave_e(uint32_t mcap) { return tvg_lds_per_wave(mcap) + kRootScratchBytes; }
 __device__ __forceinline__ RootScratch root_scratch_carve(AMC_LDS char* wave_base, AMC_LDS char* behind) {
     constexpr size_t kJac = (size_t)162 * 8, kSidx = (size_t)64 * 8 * 2, kRaw = 64 * 4, kTmax = 64 * 4, kMlist = (size_t)64 * kMaxModels * 2;
@@ -676,8 +677,15 @@ struct LoCtx {  // what the local estimators need of the wave, passed by value (
     idx_u16* inl;
     lds_f64* jacA;
     lds_f64* jacV;
+    lds_f64* uni;   // essential-matrix kernel: >= kE5UniDoubles of LDS for the local 5-point solve's wave-uniform data
     int lane;
 };
+// The local 5-point solve's wave-uniform working set - null-space basis (36), constraint polynomials B (45) and det (11),
+// roots (10) - lives in LDS (round 6; over the minimal solver's coefficient area, idle during the local optimisation).
+// As arrays of the calling function they were private memory: every lane kept its copy in scratch, 512 bytes per
+// double and store, written and read back across the solve's four calls - most of what the essential-matrix kernel
+// moved through the memory side.
+constexpr int kE5UniNsp = 0, kE5UniB = 36, kE5UniDet = 81, kE5UniRoots = 92, kE5UniDoubles = 102;
 __device__ __forceinline__ void center_T(const LoCtx& w, const Pts& P, int img, int K, double* T) {
     const int lane = w.lane;
     double ax = 0.0, ay = 0.0;
@@ -701,6 +709,35 @@ __device__ __forceinline__ void center_T(const LoCtx& w, const Pts& P, int img, 
     T[0] = nf; T[1] = 0; T[2] = -nf * cx;
     T[3] = 0; T[4] = nf; T[5] = -nf * cy;
     T[6] = 0; T[7] = 0; T[8] = 1;
+}
+// both images' transforms in two passes over the listed records instead of four (round 6): a record holds both
+// images' coordinates, and each image's sums see the addends center_T gives them, in the same order
+__device__ __forceinline__ void center_T_both(const LoCtx& w, const Pts& P, int K, double* T1, double* T2) {
+    const int lane = w.lane;
+    double ax1 = 0.0, ay1 = 0.0, ax2 = 0.0, ay2 = 0.0;
+    for (int k = lane; k < K; k += 64) {
+        double p[4];
+        load_pt(P, w.inl[k], p[0], p[1], p[2], p[3]);
+        ax1 += p[0]; ay1 += p[1]; ax2 += p[2]; ay2 += p[3];
+    }
+    const double cx1 = butterfly(ax1) / (double)K, cy1 = butterfly(ay1) / (double)K;
+    const double cx2 = butterfly(ax2) / (double)K, cy2 = butterfly(ay2) / (double)K;
+    double ar1 = 0.0, ar2 = 0.0;
+    for (int k = lane; k < K; k += 64) {
+        double p[4];
+        load_pt(P, w.inl[k], p[0], p[1], p[2], p[3]);
+        const double dx1 = p[0] - cx1, dy1 = p[1] - cy1, dx2 = p[2] - cx2, dy2 = p[3] - cy2;
+        ar1 += dx1 * dx1 + dy1 * dy1;
+        ar2 += dx2 * dx2 + dy2 * dy2;
+    }
+    const double rms1 = dsqrt(butterfly(ar1) / (double)K), rms2 = dsqrt(butterfly(ar2) / (double)K);
+    const double nf1 = dsqrt(2.0) / rms1, nf2 = dsqrt(2.0) / rms2;
+    T1[0] = nf1; T1[1] = 0; T1[2] = -nf1 * cx1;
+    T1[3] = 0; T1[4] = nf1; T1[5] = -nf1 * cy1;
+    T1[6] = 0; T1[7] = 0; T1[8] = 1;
+    T2[0] = nf2; T2[1] = 0; T2[2] = -nf2 * cx2;
+    T2[3] = 0; T2[4] = nf2; T2[5] = -nf2 * cy2;
+    T2[6] = 0; T2[7] = 0; T2[8] = 1;
 }
 __device__ __forceinline__ void apply_T(const double* T, double p0, double p1, double& o0, double& o1) {
     const double np0 = T[0] * p0 + T[1] * p1 + T[2];
@@ -921,12 +958,20 @@ struct WaveRootChain<DEG, 1> {
     }
 };
 // all real roots of a degree-10 polynomial (wave-uniform input), ascending; = real_roots_t<10>
-__device__ __noinline__ int real_roots10_wave(const double* c_in, double* roots, lds_f64* tmp, int lane) {
-    double c[11];
+__device__ __noinline__ int real_roots10_wave(const lds_f64* c_in, lds_f64* roots_out, lds_f64* tmp, int lane) {
+    double c[11], roots[10];
 #pragma unroll
     for (int i = 0; i <= 10; ++i) c[i] = c_in[i];
-    if (c[10] == 0.0) return real_roots_t<10>(c, roots);  // degenerate leading coefficient: plain path
-    return WaveRootChain<10, 10>::run(c, roots, tmp, lane);
+#pragma unroll
+    for (int i = 0; i < 10; ++i) roots[i] = 0.0;
+    const int nr = c[10] == 0.0 ? real_roots_t<10>(c, roots)  // degenerate leading coefficient: plain path
+                                : WaveRootChain<10, 10>::run(c, roots, tmp, lane);
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 10; ++i) roots_out[i] = roots[i];
+    }
+    wave_lds_sync();
+    return nr;
 }
 
 // ---- the 5-point solve of ONE problem by the whole wave (local optimisation) -----------------------
@@ -941,7 +986,7 @@ __device__ __noinline__ int real_roots10_wave(const double* c_in, double* roots,
 // through the operations e5_build applies to it, in the same order: the same bits.
 // sc: >= 162 doubles of LDS (jacA + jacV).  Layout while the rows are built: [0, 90) E E^T, [100, 136) E's basis.
 #if !defined(AMC_TVG_E5_ROWS_ALL_LANES)
-__device__ __noinline__ void e5_build_wave(const double* nsp, E5Polys& P, lds_f64* sc, int lane) {
+__device__ __noinline__ void e5_build_wave(const lds_f64* nsp, lds_f64* PB, lds_f64* Pdet, lds_f64* sc, int lane) {
     lds_f64* el = sc + 100;  // el[k * 4 + d] = e[k][d]
     if (lane < 36) {
         const int k = lane >> 2, d = lane & 3;
@@ -1040,7 +1085,7 @@ __device__ __noinline__ void e5_build_wave(const double* nsp, E5Polys& P, lds_f6
         for (int r = 1; r < 10; ++r) g[r] = 0.0;
     }
 #else
-__device__ __noinline__ void e5_build_wave(const double* nsp, E5Polys& P, lds_f64* sc, int lane) {
+__device__ __noinline__ void e5_build_wave(const lds_f64* nsp, lds_f64* PB, lds_f64* Pdet, lds_f64* sc, int lane) {
     double e[9][4];
 #pragma unroll
     for (int k = 0; k < 9; ++k)
@@ -1157,14 +1202,36 @@ __device__ __noinline__ void e5_build_wave(const double* nsp, E5Polys& P, lds_f6
 #pragma unroll
         for (int c = 0; c < 10; ++c) hl[r][c] = sc[r * 10 + c];
     wave_lds_sync();  // sc is the root finder's scratch next
+    E5Polys P;
     e5_finish(hl, P);
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int d = 0; d < 5; ++d) PB[(k * 3 + t) * 5 + d] = P.B[k][t][d];
+#pragma unroll
+        for (int i = 0; i <= 10; ++i) Pdet[i] = P.det[i];
+    }
+    wave_lds_sync();
 }
 // e5_models with root i on lane i; the models come back wave-uniform, in root order
-__device__ __noinline__ int e5_models_wave(const double* nsp, const E5Polys& P, const double* roots, int nr, lds_f64* models,
+__device__ __noinline__ int e5_models_wave(const lds_f64* nsp_, const lds_f64* PB, const lds_f64* roots, int nr, lds_f64* models,
                                            int lane) {
-    double z = roots[0];
+    const double z = roots[lane < 10 ? lane : 0];
+    double nsp[36];
+    E5Polys P;
 #pragma unroll
-    for (int i = 1; i < 10; ++i) z = lane == i ? roots[i] : z;
+    for (int i = 0; i < 36; ++i) nsp[i] = nsp_[i];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int d = 0; d < 5; ++d) P.B[k][t][d] = PB[(k * 3 + t) * 5 + d];
+#pragma unroll
+    for (int i = 0; i <= 10; ++i) P.det[i] = 0.0;  // (not read by e5_model_from_root)
     double E[9];
     const bool ok = e5_model_from_root(nsp, P, z, E) && lane < nr;
     unsigned long long mask = __ballot(ok);
@@ -1268,17 +1335,28 @@ __device__ AMC_LOCAL_INLINE int local_estimate(const LoCtx w, const Pts P, int K
         LODIAG_LAP(1);
         jacobi_eigen_wave(w.jacA, w.jacV, lane);
         LODIAG_LAP(2);
-        double nsp[4 * 9];
-        e5_nullspace_from_eig(w.jacA, w.jacV, nsp);
+        lds_f64* nsp = w.uni + kE5UniNsp;
+        {   // e5_nullspace_from_eig (tvg_math.h): the four eigenvectors of the smallest eigenvalues, entry `lane` by lane `lane`
+            int order[9];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) order[i] = i;
+#pragma unroll
+            for (int i = 0; i < 9; ++i)
+#pragma unroll
+                for (int j = i + 1; j < 9; ++j)
+                    if (w.jacA[order[j] * 9 + order[j]] < w.jacA[order[i] * 9 + order[i]]) { const int t = order[i]; order[i] = order[j]; order[j] = t; }
+            if (lane < 36) {
+                const int k = lane / 9, i = lane - 9 * k;
+                const int col = k == 0 ? order[3] : (k == 1 ? order[2] : (k == 2 ? order[1] : order[0]));
+                nsp[lane] = w.jacV[i * 9 + col];
+            }
+        }
         wave_lds_sync();  // jacA doubles as the root finder's scratch from here on
-        E5Polys polys;
-        e5_build_wave(nsp, polys, w.jacA, lane);
+        e5_build_wave(nsp, w.uni + kE5UniB, w.uni + kE5UniDet, w.jacA, lane);
         LODIAG_LAP(3);
-        double roots[10];
-        const int nr = real_roots10_wave(polys.det, roots, w.jacA, lane);
+        const int nr = real_roots10_wave(w.uni + kE5UniDet, w.uni + kE5UniRoots, w.jacA, lane);
         LODIAG_LAP(4);
-        wave_lds_sync();  // (the root finder is done with jacA)
-        const int nm = e5_models_wave(nsp, polys, roots, nr, out, lane);
+        const int nm = e5_models_wave(nsp, w.uni + kE5UniB, w.uni + kE5UniRoots, nr, out, lane);
         LODIAG_LAP(5);
         return nm;
     }
@@ -1290,8 +1368,12 @@ __device__ AMC_LOCAL_INLINE int local_estimate(const LoCtx w, const Pts P, int K
         return 1;
     }
     double T1[9], T2[9];
+#if defined(AMC_TVG_CENTER_SEPARATE)   // (A/B hook: one image at a time, four passes)
     center_T(w, P, 0, K, T1);
     center_T(w, P, 1, K, T2);
+#else
+    center_T_both(w, P, K, T1, T2);
+#endif
     LODIAG_T0();
     LODIAG_COUNT(LOCAL == K_F8 ? 8 : 12);
     if (LOCAL == K_F8) {
@@ -2148,7 +2230,7 @@ __device__ Report lo_ransac(Wave& w_io, const RansacCfg& cfg, const double* gx, 
     const int max_trials = uni(cfg.max_trials), min_trials = uni(cfg.min_trials);
     constexpr int kMin = kmin_of(EST), kLocalMin = kmin_of(LOCAL);
     LoCtx lo;
-    lo.inl = w.inl; lo.jacA = w.jacA; lo.jacV = w.jacV; lo.lane = lane;
+    lo.inl = w.inl; lo.jacA = w.jacA; lo.jacV = w.jacV; lo.uni = w.rootscr.coef; lo.lane = lane;
     Report rep;
     rep.success = false;
     rep.num_trials = 0;
