@@ -365,14 +365,16 @@ size_t tvg_ws_doubles_host(uint32_t mcap);
 size_t tvg_ws_doubles_e_host(uint32_t mcap);   // the essential-matrix kernel's waves (larger model / staging region)
 size_t tvg_ws_mask_bytes_host(uint32_t mcap);
 // Target occupancy (waves per SIMD) of the two verification kernels: sets their VGPR budgets and LDS shares.
-// tvg_e_kernel holds the 5-point solver and its root finder (256 VGPRs): 2.  tvg_fh_kernel: 3 - the 7-point solver's
-// 7 x 9 matrix (126 VGPRs) spills at 4 waves (128 VGPRs), and since the counting loops request their scalar-cache lines
-// in batches they are issue-bound, not latency-bound (measured round 3: 4 -> 3 waves +2.4 %, 2 waves -4 %).
+// tvg_e_kernel holds the 5-point solver and its root finder (256 VGPRs): 2 (round 6, final code: 3 waves -1.7 %).
+// tvg_fh_kernel: 4 since round 6 (128 VGPRs; 3 waves -5.5 %, same box).  Rounds 3 to 5 ran it at 3: the 7-point solver's
+// 7 x 9 matrix (126 VGPRs) spills at 4 waves, and with the scratch traffic those builds had (wave-uniform state and
+// models spilled around every chunk's calls) more waves only added to it (round 3: 4 -> 3 waves +2.4 %).  With that
+// traffic gone (tvg_core.h lo_ransac) the fourth wave hides what latency is left.
 #ifndef AMC_E_WAVES
 #define AMC_E_WAVES 2
 #endif
 #ifndef AMC_FH_WAVES
-#define AMC_FH_WAVES 3
+#define AMC_FH_WAVES 4
 #endif
 constexpr int kTvgEWavesPerSimd = AMC_E_WAVES;
 constexpr int kTvgFhWavesPerSimd = AMC_FH_WAVES;

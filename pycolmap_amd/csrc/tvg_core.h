@@ -673,6 +673,10 @@ __device__ AMC_EXTRACT_INLINE int extract_inliers(idx_u16* inl, int lane, int ki
 // CenterAndNormalizeImagePoints over the K listed points of image `img` (0: x1,y1; 1: x2,y2):
 // only the transform T is produced; the normalised coordinates are recomputed where they are
 // consumed (apply_T), with the operations of the reference loop, instead of being stored.
+// the steps of a local solve as calls (default) or inlined into local_estimate (-DAMC_LO_SUB=__forceinline__: A/B hook)
+#ifndef AMC_LO_SUB
+#define AMC_LO_SUB __noinline__
+#endif
 struct LoCtx {  // what the local estimators need of the wave, passed by value (registers)
     idx_u16* inl;
     lds_f64* jacA;
@@ -823,7 +827,7 @@ __device__ __forceinline__ void jacobi_pair9(int r, int e, int& p, int& q) {
     p = x < y ? x : y;
     q = x < y ? y : x;
 }
-__device__ __noinline__ void jacobi_eigen_wave(lds_f64* A, lds_f64* V, int lane) {
+__device__ AMC_LO_SUB void jacobi_eigen_wave(lds_f64* A, lds_f64* V, int lane) {
     constexpr int n = 9, rounds = 9, np = 4;  // the only size the kernel decomposes as a wave
     for (int i = lane; i < n * n; i += 64) V[i] = ((i / n) == (i % n)) ? 1.0 : 0.0;
     wave_lds_sync();
@@ -958,7 +962,7 @@ struct WaveRootChain<DEG, 1> {
     }
 };
 // all real roots of a degree-10 polynomial (wave-uniform input), ascending; = real_roots_t<10>
-__device__ __noinline__ int real_roots10_wave(const lds_f64* c_in, lds_f64* roots_out, lds_f64* tmp, int lane) {
+__device__ AMC_LO_SUB int real_roots10_wave(const lds_f64* c_in, lds_f64* roots_out, lds_f64* tmp, int lane) {
     double c[11], roots[10];
 #pragma unroll
     for (int i = 0; i <= 10; ++i) c[i] = c_in[i];
@@ -986,7 +990,7 @@ __device__ __noinline__ int real_roots10_wave(const lds_f64* c_in, lds_f64* root
 // through the operations e5_build applies to it, in the same order: the same bits.
 // sc: >= 162 doubles of LDS (jacA + jacV).  Layout while the rows are built: [0, 90) E E^T, [100, 136) E's basis.
 #if !defined(AMC_TVG_E5_ROWS_ALL_LANES)
-__device__ __noinline__ void e5_build_wave(const lds_f64* nsp, lds_f64* PB, lds_f64* Pdet, lds_f64* sc, int lane) {
+__device__ AMC_LO_SUB void e5_build_wave(const lds_f64* nsp, lds_f64* PB, lds_f64* Pdet, lds_f64* sc, int lane) {
     lds_f64* el = sc + 100;  // el[k * 4 + d] = e[k][d]
     if (lane < 36) {
         const int k = lane >> 2, d = lane & 3;
@@ -1085,7 +1089,7 @@ __device__ __noinline__ void e5_build_wave(const lds_f64* nsp, lds_f64* PB, lds_
         for (int r = 1; r < 10; ++r) g[r] = 0.0;
     }
 #else
-__device__ __noinline__ void e5_build_wave(const lds_f64* nsp, lds_f64* PB, lds_f64* Pdet, lds_f64* sc, int lane) {
+__device__ AMC_LO_SUB void e5_build_wave(const lds_f64* nsp, lds_f64* PB, lds_f64* Pdet, lds_f64* sc, int lane) {
     double e[9][4];
 #pragma unroll
     for (int k = 0; k < 9; ++k)
@@ -1217,7 +1221,7 @@ __device__ __noinline__ void e5_build_wave(const lds_f64* nsp, lds_f64* PB, lds_
     wave_lds_sync();
 }
 // e5_models with root i on lane i; the models come back wave-uniform, in root order
-__device__ __noinline__ int e5_models_wave(const lds_f64* nsp_, const lds_f64* PB, const lds_f64* roots, int nr, lds_f64* models,
+__device__ AMC_LO_SUB int e5_models_wave(const lds_f64* nsp_, const lds_f64* PB, const lds_f64* roots, int nr, lds_f64* models,
                                            int lane) {
     const double z = roots[lane < 10 ? lane : 0];
     double nsp[36];
