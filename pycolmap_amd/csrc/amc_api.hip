@@ -2505,8 +2505,12 @@ static int verify_impl(amc_ctx* c, int mode, const uint32_t* slot1, const uint32
         run.st_fh = c->vstream[0] ? c->vstream[0] : st;
         size_t nver = 0;
         for (size_t p = 0; p < npairs; ++p) nver += !run.trivial((uint32_t)(match_offsets[p + 1] - match_offsets[p]));
-        int want = 2;  // (measured on 124,750 pairs, kernels: 1 slice 433-439 ms, 2: 434-435, 4: 441, 8: 480 - profiles/r06/ab_pipeline_v1.txt;
-                       //  the whole call: 2 slices 446 ms against 449-456 for one and 451-452 for round 5's library, ab_prev_v1.txt)
+        // One slice by default since the kernels lost their scratch traffic (round 6, final code, 124,750 pairs, kernels:
+        // 1 slice 338 ms, 2: 343, 3: 350, 4: 355 - profiles/r06/ab_slices_final_v1.txt): a SIMD that holds an E wave beside
+        // F/H waves runs fewer of them, and the kernels' own tails are ~1 % of such a call.  Before that two slices were
+        // +1.2 % (1 slice 433-439 ms, 2: 434-435, 4: 441, 8: 480 - ab_pipeline_v1.txt).  AMC_TVG_SLICES: the A/B hook and the
+        // tests' way to the sliced path, which amc_match_verify_pairs' batches still take.
+        int want = 1;
         if (const char* e = std::getenv("AMC_TVG_SLICES")) want = std::max(1, std::min(kMaxVerifySlices, std::atoi(e)));
         size_t min_per_slice = (size_t)run.cus * 12 * 2;  // two full F/H machine loads per slice
         if (const char* e = std::getenv("AMC_TVG_MIN_PER_SLICE")) min_per_slice = (size_t)std::max(1, std::atoi(e));  // (test hook)

@@ -881,6 +881,17 @@ __device__ __forceinline__ void smallest_eigvec9_wave(const lds_f64* A, const ld
         if (A[i * 9 + i] < A[best * 9 + best]) best = i;
     for (int i = 0; i < 9; ++i) x[i] = V[i * 9 + best];
 }
+// value of lane OWN of every quad, in all four lanes of the quad (DPP quad_perm: no LDS, no scalar unit)
+template <int OWN>
+__device__ __forceinline__ int quad_bcast(int v) {
+    return __builtin_amdgcn_mov_dpp(v, OWN * 0x55, 0xf, 0xf, true);
+}
+template <int OWN>
+__device__ __forceinline__ double quad_bcast(double v) {
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    const unsigned lo = (unsigned)quad_bcast<OWN>((int)(unsigned)u), hi = (unsigned)quad_bcast<OWN>((int)(unsigned)(u >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
 // ---- real roots of ONE polynomial by the whole wave (local optimisation's 5-point solve) ----------
 // tvg_math.h's RootChain walks the chain of derivatives and, per level, solves the sign-change
 // brackets two at a time.  The brackets of a level are independent, so here lane i takes
@@ -905,11 +916,18 @@ struct WaveRootChain {
             if (crit[i] > -bound && crit[i] < bound) tmp[ne++] = crit[i];
         tmp[ne++] = bound;
         wave_lds_sync();
-        // one bracket per lane: 0 nothing, 1 exact root at the lower edge, 2 bracketed root
+        // one bracket per QUAD of lanes (round 6; one per lane before): 0 nothing, 1 exact root at the lower edge, 2
+        // bracketed root.  At most ten of the wave's lanes had work, and a bracket's bisection is one dependent chain -
+        // Horner, then the step's comparisons - so the level cost the latency of ~40 such steps.  The quad takes two steps
+        // per round: lane 0 evaluates the midpoint and takes the step; lanes 1 and 2 at the same time take the step
+        // that follows if the upper / the lower end moves - its midpoint is known before the first step is decided -
+        // and the outcome that applies is picked afterwards (quad broadcasts).  Every step that counts sees the plain
+        // loop's operands in the plain loop's order: the same brackets, the same roots, bit for bit.
         int kind = 0;
         double val = 0.0;
-        if (lane + 1 < ne) {
-            double lo = tmp[lane], hi = tmp[lane + 1];
+        const int qb = lane >> 2, role = lane & 3;
+        if (qb + 1 < ne) {
+            double lo = tmp[qb], hi = tmp[qb + 1];
             const double flo = poly_eval_t<R>(d, lo);
             const double fhi = poly_eval_t<R>(d, hi);
             if (flo == 0.0) {
@@ -919,11 +937,27 @@ struct WaveRootChain {
                 // bracket_root: bisection to 2^-26 of the bracket's position, then three bracketed Newton steps
                 bool zero = false, act = true;
                 const bool neg_lo = flo < 0.0;
-                for (int it = 0; it < 200 && act; ++it) {
-                    const double mid = 0.5 * (lo + hi);
-                    act = !(mid == lo || mid == hi);
-                    const double fm = poly_eval_t<R>(d, mid);
-                    bracket_step(mid, fm, lo, hi, neg_lo, act, zero);  // (tvg_math.h: the plain loop's step, branch-free)
+                for (int it = 0; it < 200 && act; it += 2) {
+                    const double mid0 = 0.5 * (lo + hi);
+                    // this lane's step: the first one (roles 0, 3), or the second one after hi <- mid0 (1) / lo <- mid0 (2)
+                    double blo = role == 2 ? mid0 : lo, bhi = role == 1 ? mid0 : hi;
+                    const double bx = 0.5 * (blo + bhi);
+                    bool bact = !(bx == blo || bx == bhi), bzero = zero;
+                    const double fm = poly_eval_t<R>(d, bx);
+                    bracket_step(bx, fm, blo, bhi, neg_lo, bact, bzero);  // (tvg_math.h: the plain loop's step, branch-free)
+                    const int bflags = (bact ? 1 : 0) | (bzero ? 2 : 0);
+                    const double lo1 = quad_bcast<0>(blo), hi1 = quad_bcast<0>(bhi);
+                    const int fl1 = quad_bcast<0>(bflags);
+                    const double loL = quad_bcast<1>(blo), hiL = quad_bcast<1>(bhi), loR = quad_bcast<2>(blo), hiR = quad_bcast<2>(bhi);
+                    const int flL = quad_bcast<1>(bflags), flR = quad_bcast<2>(bflags);
+                    // still active after the first step: exactly one end moved to mid0, and the second step is the one
+                    // taken on that assumption (a first step that is the 200th is never followed: 200 is even)
+                    const bool second = (fl1 & 1) != 0, moved_lo = lo1 == mid0;
+                    lo = second ? (moved_lo ? loR : loL) : lo1;
+                    hi = second ? (moved_lo ? hiR : hiL) : hi1;
+                    const int fl = second ? (moved_lo ? flR : flL) : fl1;
+                    act = (fl & 1) != 0;
+                    zero = (fl & 2) != 0;
                 }
                 double r = 0.5 * (lo + hi);
 #pragma unroll
@@ -940,8 +974,8 @@ struct WaveRootChain {
         wave_lds_sync();  // tmp is rewritten by the next level
         int nr = 0;
         for (int i = 0; i + 1 < ne; ++i) {
-            const int k = __builtin_amdgcn_readlane(kind, i);
-            const double r = readlane_f64(val, i);
+            const int k = __builtin_amdgcn_readlane(kind, 4 * i);
+            const double r = readlane_f64(val, 4 * i);
             if (k == 1) {
                 if (nr == 0 || roots[nr - 1] != r) roots[nr++] = r;
             } else if (k == 2) {
@@ -1956,16 +1990,6 @@ struct E5StageSink {
         for (int c = 0; c < 20; ++c) g[(size_t)(r * 20 + c) * 64 + lane] = row[c];
     }
 };
-template <int OWN>
-__device__ __forceinline__ int quad_bcast(int v) {
-    return __builtin_amdgcn_mov_dpp(v, OWN * 0x55, 0xf, 0xf, true);
-}
-template <int OWN>
-__device__ __forceinline__ double quad_bcast(double v) {
-    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
-    const unsigned lo = (unsigned)quad_bcast<OWN>((int)(unsigned)u), hi = (unsigned)quad_bcast<OWN>((int)(unsigned)(u >> 32));
-    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
-}
 template <int COL>
 __device__ __forceinline__ void e5_elim_col(double (&g)[10][5]) {
     constexpr int OWN = COL / 5, CL = COL % 5;
