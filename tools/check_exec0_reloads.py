@@ -24,11 +24,12 @@ def scan(path):
                 found.append((n2, l2))
     return found
 
-rc = 0
-for p in sys.argv[1:]:
-    f = scan(p)
-    print(p, "vector instructions under EXEC = 0 after a loop:", len(f))
-    for n, l in f[:40]:
-        print("   line", n, l)
-    rc |= bool(f)
-sys.exit(rc)
+if __name__ == "__main__":
+    rc = 0
+    for p in sys.argv[1:]:
+        f = scan(p)
+        print(p, "vector instructions under EXEC = 0 after a loop:", len(f))
+        for n, l in f[:40]:
+            print("   line", n, l)
+        rc |= bool(f)
+    sys.exit(rc)
