@@ -253,17 +253,39 @@ struct amc_ctx {
     float accept_ratio = 0.f, accept_distance = 0.f;
     bool accept_valid = false;
     uint32_t* d_scalars = nullptr;  // [0] cursor, [1] queue head, [2] maxsq scratch, [3] resolve errors, [4] stream overrun, [5] mfma items, [7] copy parts taken
-    // per-batch scratch
-    DevBuf<PairDev> d_pairs;
-    DevBuf<Dot4Work> d_work;
-    DevBuf<uint32_t> d_order, d_order2;
-    // mfma work items: group cuts of the two queue orders, scratch of the packing kernels, the descriptors
-    DevBuf<uint32_t> d_grp, d_grp2, d_seg_base, d_grp_segs, d_grp_item_base;
-    DevBuf<SegDesc> d_segs;
-    DevBuf<Top2> d_rowbuf, d_colbuf;
-    DevBuf<uint32_t> d_accmask;  // one accept bit per row-table entry (mfma pairs)
-    DevBuf<GuidedDev> d_guided;  // guided matching: one filter model per pair of the batch
-    DevBuf<uint32_t> d_pair_off, d_pair_cnt, d_matches, d_cand_cnt, d_candbuf;
+    // per-batch scratch: TWO sets (round 6).  With one set a batch's cross-check chain (resolve, candidate selection,
+    // reverse scan, finalize) has to finish before the next batch's forward scan may write the tables; with two the
+    // next scan is launched right behind this one and the chain runs beside it on chain_stream (match_impl).  Set 0's
+    // scalars are d_scalars itself.
+    struct MatchScratch {
+        uint32_t* scalars = nullptr;  // [0] cursor, [1] queue head, [3] resolve errors, [5] mfma items, [7] copy parts taken
+        DevBuf<PairDev> d_pairs;
+        DevBuf<Dot4Work> d_work;
+        DevBuf<uint32_t> d_order, d_order2;
+        // mfma work items: group cuts of the two queue orders, scratch of the packing kernels, the descriptors
+        DevBuf<uint32_t> d_grp, d_grp2, d_seg_base, d_grp_segs, d_grp_item_base;
+        DevBuf<SegDesc> d_segs;
+        DevBuf<Top2> d_rowbuf, d_colbuf;
+        DevBuf<uint32_t> d_accmask;  // one accept bit per row-table entry (mfma pairs)
+        DevBuf<GuidedDev> d_guided;  // guided matching: one filter model per pair of the batch
+        DevBuf<uint32_t> d_pair_off, d_pair_cnt, d_matches, d_cand_cnt, d_candbuf;
+        void release_all() {
+            d_pairs.release(); d_work.release(); d_order.release(); d_order2.release();
+            d_grp.release(); d_grp2.release(); d_seg_base.release(); d_grp_segs.release();
+            d_grp_item_base.release(); d_segs.release();
+            d_rowbuf.release(); d_colbuf.release(); d_accmask.release(); d_guided.release();
+            d_pair_off.release(); d_pair_cnt.release(); d_matches.release();
+            d_cand_cnt.release(); d_candbuf.release();
+        }
+        void release_large() {  // (amc_ctx_trim)
+            d_rowbuf.release(); d_colbuf.release(); d_accmask.release(); d_matches.release(); d_candbuf.release();
+            d_segs.release(); d_seg_base.release();
+        }
+    };
+    MatchScratch ms[2];
+    uint32_t* d_scalars_alt = nullptr;  // set 1's scalars (16 words)
+    hipStream_t chain_stream = nullptr; // the cross-check chain of batch k beside the forward scan of batch k + 1
+    hipEvent_t sev[2] = {nullptr, nullptr};  // set k's tables are free again (chain and reorder of its batch are done)
     // amc_match_verify_pairs: the matches of every batch of the call stay here (appended batch after batch), so
     // that the verification kernel reads them where the matcher left them instead of from a host round trip
     DevBuf<uint32_t> d_keep;
@@ -401,6 +423,8 @@ int amc_ctx_create(int device_id, amc_ctx** out) {
     }
     bool ev_ok = true;  // (an event that was never created would fail every later record: fail here instead)
     for (auto& ev : c->cev) ev_ok &= hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess;
+    for (auto& ev : c->sev) ev_ok &= hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess;
+    if (hipStreamCreateWithFlags(&c->chain_stream, hipStreamNonBlocking) != hipSuccess) c->chain_stream = nullptr;
     {
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);  // (0, 0 when it fails: the default priority)
@@ -431,6 +455,7 @@ int amc_ctx_create(int device_id, amc_ctx** out) {
             hipSuccess ||
         hipMalloc(reinterpret_cast<void**>(&c->d_scalars), 16 * sizeof(uint32_t)) !=
             hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&c->d_scalars_alt), 16 * sizeof(uint32_t)) != hipSuccess ||
         hipMalloc(reinterpret_cast<void**>(&c->d_vscalars), kVScalarWords * sizeof(uint32_t)) != hipSuccess ||
         hipMemcpy(c->d_lut, c->h_lut.data(), kAcosLutSize * sizeof(float),
                   hipMemcpyHostToDevice) != hipSuccess ||
@@ -438,6 +463,8 @@ int amc_ctx_create(int device_id, amc_ctx** out) {
         amc_ctx_destroy(c);
         return fail(AMC_E_HIP, "amc_ctx_create: device allocation failed");
     }
+    c->ms[0].scalars = c->d_scalars;
+    c->ms[1].scalars = c->d_scalars_alt;
     *out = c;
     return AMC_OK;
 }
@@ -463,12 +490,9 @@ void amc_ctx_destroy(amc_ctx* c) {
     if (c->d_lut) (void)hipFree(c->d_lut);
     if (c->d_accept) (void)hipFree(c->d_accept);
     if (c->d_scalars) (void)hipFree(c->d_scalars);
-    c->d_pairs.release(); c->d_work.release(); c->d_order.release(); c->d_order2.release();
-    c->d_grp.release(); c->d_grp2.release(); c->d_seg_base.release(); c->d_grp_segs.release();
-    c->d_grp_item_base.release(); c->d_segs.release();
-    c->d_rowbuf.release(); c->d_colbuf.release(); c->d_accmask.release(); c->d_guided.release();
-    c->d_pair_off.release(); c->d_pair_cnt.release(); c->d_matches.release();
-    c->d_cand_cnt.release(); c->d_candbuf.release(); c->d_keep.release(); c->d_csr.release();
+    for (auto& m : c->ms) m.release_all();
+    if (c->d_scalars_alt) (void)hipFree(c->d_scalars_alt);
+    c->d_keep.release(); c->d_csr.release();
     dlap("match device buffers");
     c->h_csr[0].release(); c->h_csr[1].release();
     c->h_tout.release(); c->h_tmask.release();
@@ -497,6 +521,9 @@ void amc_ctx_destroy(amc_ctx* c) {
     for (auto& ev : c->cev)
         if (ev) (void)hipEventDestroy(ev);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    if (c->chain_stream) (void)hipStreamDestroy(c->chain_stream);
+    for (auto& ev : c->sev)
+        if (ev) (void)hipEventDestroy(ev);
     if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
     for (auto& ev : c->aev)
         if (ev) (void)hipEventDestroy(ev);
@@ -523,14 +550,14 @@ int amc_ctx_trim(amc_ctx* c) {
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));
     if (c->copy_stream) HIPCHK(hipStreamSynchronize(c->copy_stream));
+    if (c->chain_stream) HIPCHK(hipStreamSynchronize(c->chain_stream));
     // per-call scratch and result staging: everything a later call re-allocates on demand (uploaded images, the acos
     // table, the sample stream and the trial tables stay)
     c->result_pool->trim();
     c->d_keep.release(); c->d_csr.release();
     c->resident_matches = 0;
     c->vres = amc::VerifyResident{};
-    c->d_rowbuf.release(); c->d_colbuf.release(); c->d_accmask.release(); c->d_matches.release(); c->d_candbuf.release();
-    c->d_segs.release(); c->d_seg_base.release();
+    for (auto& m : c->ms) m.release_large();
     // the verification kernels' sample-stream table is rebuilt on demand (a host mt19937 run + one upload): keep the
     // default-sized one (~0.3 MB at COLMAP's default trial caps), drop one that a large max_num_trials blew up
     if (c->d_stream.cap * sizeof(uint32_t) > ((size_t)16 << 20)) {
@@ -667,6 +694,10 @@ int ceil_log2(uint32_t x) {
 
 // limits for one batch (bytes of device scratch)
 // sized for 288 GB of HBM: few, large batches (each batch ends in a host synchronisation)
+#ifndef AMC_MATCH_OVERLAP_DEFAULT
+#define AMC_MATCH_OVERLAP_DEFAULT 0
+#endif
+constexpr bool kMatchOverlapDefault = AMC_MATCH_OVERLAP_DEFAULT != 0;  // match_impl: a batch's chain beside the next batch's scan
 constexpr size_t kMaxTop2Entries = (size_t)256 << 20;  // 256 Mi entries x 16 B = 4 GiB per side
 constexpr size_t kMaxMatchCap = (size_t)256 << 20;     // worst-case matches of a batch: x 8 B = 2 GiB (device)
 
@@ -868,6 +899,20 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
     // (smaller copies are not worth a scan's prologue; AMC_D2H_FUSE_MIN_BYTES lets the tests take the path with small inputs)
     const char* fmin_env = std::getenv("AMC_D2H_FUSE_MIN_BYTES");
     const size_t fuse_min_bytes = fmin_env ? (size_t)std::strtoull(fmin_env, nullptr, 10) : ((size_t)1 << 20);
+    // The cross-check chain of batch k BESIDE the forward scan of batch k + 1 (round 6).  The scan's
+    // workgroups take a CU's whole register file, so nothing shares a CU with them: the next scan is launched with
+    // `chain_cus` workgroups fewer (a power-bound kernel: 8 of 256 CUs cost it ~1 %, profiles/r06/scan_grid_v1.txt) and
+    // the chain's kernels - on chain_stream, behind the scan of their own batch by event - run on the CUs left over.
+    // Needs the second set of batch tables (amc_ctx::ms).  AMC_MATCH_OVERLAP=0/1, AMC_CHAIN_CUS=n: A/B hooks.
+    const char* ov_env = std::getenv("AMC_MATCH_OVERLAP");
+    const bool overlap = c->chain_stream && !(batch_hook && batch_hook->plan) &&
+                         (ov_env ? ov_env[0] == '1' : kMatchOverlapDefault);
+    int chain_cus = 8;
+    if (const char* e = std::getenv("AMC_CHAIN_CUS")) chain_cus = std::max(0, std::atoi(e));
+    hipStream_t cs = overlap ? c->chain_stream : st;  // where a batch's chain, its reorder and its counters' download go
+    auto sync_batch_streams = [&](const char* what) {
+        return hc(hipStreamSynchronize(st), what) && (!overlap || hc(hipStreamSynchronize(cs), what));
+    };
     auto carve = [&](size_t begin, int set) {
         Batch b;
         b.begin = b.end = begin;
@@ -1025,54 +1070,63 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
         b.nord = nord;
         return true;
     };
-    // device side of a batch, all on the stream: H2D of the queues, the kernels, D2H of the counters
-    auto enqueue = [&](Batch& b, int leave_cus = 0) {
+    // a batch table's copy: the runtime's asynchronous copy, or - with the chain on its own stream - a kernel: the
+    // runtime's copies of all streams share one in-order DMA queue, and a copy of the chain's stream waiting for its
+    // kernels held the next scan's uploads behind it (launch_copy_words, match_common.hip)
+    auto tcopy = [&](void* dst, const void* src, size_t bytes, hipMemcpyKind kind, hipStream_t s) {
+        return overlap ? launch_copy_words(dst, src, bytes, s) : hipMemcpyAsync(dst, src, bytes, kind, s);
+    };
+    // device side of a batch, first part, on the stream: H2D of the queues, segment packing, the scans
+    auto enqueue_scan = [&](Batch& b, int leave_cus = 0) {
         const int k = b.set;
+        amc_ctx::MatchScratch& S = c->ms[overlap ? k : 0];
         const size_t nb = b.nb, nord = b.nord, nwork = b.nwork;
         // device scratch only ever grows; growing frees the old allocation, so drain the stream first
-        const bool grow = c->d_pairs.cap < nb || c->d_order.cap < nb || c->d_order2.cap < nb ||
-                          c->d_rowbuf.cap < b.top_rows || c->d_colbuf.cap < b.top_cols ||
-                          c->d_accmask.cap < b.top_rows / 32 + 8 || c->d_pair_off.cap < nb || c->d_pair_cnt.cap < nb ||
-                          c->d_matches.cap < 2 * b.cap || c->d_cand_cnt.cap < nb || c->d_candbuf.cap < b.top_cols ||
-                          c->d_work.cap < nwork || (geoms && c->d_guided.cap < nb) || c->d_segs.cap < b.seg_cap ||
-                          c->d_seg_base.cap < nord || c->d_grp.cap < b.ngrp + 1 || c->d_grp2.cap < b.ngrp2 + 1 ||
-                          c->d_grp_segs.cap < std::max(b.ngrp, b.ngrp2) || c->d_grp_item_base.cap < std::max(b.ngrp, b.ngrp2);
-        if (grow && !hc(hipStreamSynchronize(st), "sync before growing device scratch")) return false;
-        if (!hc(c->d_pairs.ensure(nb), "dev pairs") || !hc(c->d_order.ensure(nb), "dev order") ||
-            !hc(c->d_order2.ensure(nb), "dev order2") ||
-            !hc(c->d_rowbuf.ensure(b.top_rows), "row top2") || !hc(c->d_colbuf.ensure(b.top_cols), "col top2") ||
-            !hc(c->d_accmask.ensure(b.top_rows / 32 + 8), "accept mask") ||
-            !hc(c->d_pair_off.ensure(nb), "pair_off") || !hc(c->d_pair_cnt.ensure(nb), "pair_cnt") ||
-            !hc(c->d_matches.ensure(2 * b.cap), "dev matches") ||
-            !hc(c->d_cand_cnt.ensure(nb), "cand_cnt") || !hc(c->d_candbuf.ensure(b.top_cols), "candbuf") ||
-            (nwork && !hc(c->d_work.ensure(nwork), "dev work")) || (geoms && !hc(c->d_guided.ensure(nb), "dev guided")) ||
-            !hc(c->d_segs.ensure(b.seg_cap), "segment descriptors") || !hc(c->d_seg_base.ensure(nord), "segment bases") ||
-            !hc(c->d_grp.ensure(b.ngrp + 1), "group cuts") || !hc(c->d_grp2.ensure(b.ngrp2 + 1), "group cuts") ||
-            !hc(c->d_grp_segs.ensure(std::max(b.ngrp, b.ngrp2)), "group segments") ||
-            !hc(c->d_grp_item_base.ensure(std::max(b.ngrp, b.ngrp2)), "group items"))
+        const bool grow = S.d_pairs.cap < nb || S.d_order.cap < nb || S.d_order2.cap < nb ||
+                          S.d_rowbuf.cap < b.top_rows || S.d_colbuf.cap < b.top_cols ||
+                          S.d_accmask.cap < b.top_rows / 32 + 8 || S.d_pair_off.cap < nb || S.d_pair_cnt.cap < nb ||
+                          S.d_matches.cap < 2 * b.cap || S.d_cand_cnt.cap < nb || S.d_candbuf.cap < b.top_cols ||
+                          S.d_work.cap < nwork || (geoms && S.d_guided.cap < nb) || S.d_segs.cap < b.seg_cap ||
+                          S.d_seg_base.cap < nord || S.d_grp.cap < b.ngrp + 1 || S.d_grp2.cap < b.ngrp2 + 1 ||
+                          S.d_grp_segs.cap < std::max(b.ngrp, b.ngrp2) || S.d_grp_item_base.cap < std::max(b.ngrp, b.ngrp2);
+        if (grow && !sync_batch_streams("sync before growing device scratch")) return false;
+        // this set's tables are free when the chain and the reorder of the batch that used them last are done
+        if (overlap && !hc(hipStreamWaitEvent(st, c->sev[k], 0), "stream wait")) return false;
+        if (!hc(S.d_pairs.ensure(nb), "dev pairs") || !hc(S.d_order.ensure(nb), "dev order") ||
+            !hc(S.d_order2.ensure(nb), "dev order2") ||
+            !hc(S.d_rowbuf.ensure(b.top_rows), "row top2") || !hc(S.d_colbuf.ensure(b.top_cols), "col top2") ||
+            !hc(S.d_accmask.ensure(b.top_rows / 32 + 8), "accept mask") ||
+            !hc(S.d_pair_off.ensure(nb), "pair_off") || !hc(S.d_pair_cnt.ensure(nb), "pair_cnt") ||
+            !hc(S.d_matches.ensure(2 * b.cap), "dev matches") ||
+            !hc(S.d_cand_cnt.ensure(nb), "cand_cnt") || !hc(S.d_candbuf.ensure(b.top_cols), "candbuf") ||
+            (nwork && !hc(S.d_work.ensure(nwork), "dev work")) || (geoms && !hc(S.d_guided.ensure(nb), "dev guided")) ||
+            !hc(S.d_segs.ensure(b.seg_cap), "segment descriptors") || !hc(S.d_seg_base.ensure(nord), "segment bases") ||
+            !hc(S.d_grp.ensure(b.ngrp + 1), "group cuts") || !hc(S.d_grp2.ensure(b.ngrp2 + 1), "group cuts") ||
+            !hc(S.d_grp_segs.ensure(std::max(b.ngrp, b.ngrp2)), "group segments") ||
+            !hc(S.d_grp_item_base.ensure(std::max(b.ngrp, b.ngrp2)), "group items"))
             return false;
-        bool okq = hc(hipMemcpyAsync(c->d_pairs.p, c->h_pairs[k].p, nb * sizeof(PairDev),
+        bool okq = hc(tcopy(S.d_pairs.p, c->h_pairs[k].p, nb * sizeof(PairDev),
                                      hipMemcpyHostToDevice, st), "H2D pairs") &&
-                   hc(memset_async(c->d_scalars, 0, 2 * sizeof(uint32_t), st), "memset cursor") &&
-                   hc(memset_async(c->d_scalars + 3, 0, sizeof(uint32_t), st), "memset errcount");
+                   hc(memset_async(S.scalars, 0, 2 * sizeof(uint32_t), st), "memset cursor") &&
+                   hc(memset_async(S.scalars + 3, 0, sizeof(uint32_t), st), "memset errcount");
         if (okq && nord)
-            okq = hc(hipMemcpyAsync(c->d_order.p, c->h_order[k].p, nord * sizeof(uint32_t),
+            okq = hc(tcopy(S.d_order.p, c->h_order[k].p, nord * sizeof(uint32_t),
                                     hipMemcpyHostToDevice, st), "H2D order") &&
-                  hc(hipMemcpyAsync(c->d_grp.p, c->h_grp[k].p, (b.ngrp + 1) * sizeof(uint32_t),
+                  hc(tcopy(S.d_grp.p, c->h_grp[k].p, (b.ngrp + 1) * sizeof(uint32_t),
                                     hipMemcpyHostToDevice, st), "H2D group cuts") &&
                   // segments no wave owns (beyond an image's last row) never write their words
-                  hc(memset_async(c->d_accmask.p, 0, (b.row_off / 32 + 8) * sizeof(uint32_t), st), "memset accmask");
+                  hc(memset_async(S.d_accmask.p, 0, (b.row_off / 32 + 8) * sizeof(uint32_t), st), "memset accmask");
         if (okq && nwork)
-            okq = hc(hipMemcpyAsync(c->d_work.p, c->h_work[k].p, nwork * sizeof(Dot4Work),
+            okq = hc(tcopy(S.d_work.p, c->h_work[k].p, nwork * sizeof(Dot4Work),
                                     hipMemcpyHostToDevice, st), "H2D work");
         if (okq && geoms)  // this batch's slice of the filter models (pageable source: the copy is staged)
-            okq = hc(hipMemcpyAsync(c->d_guided.p, h_guided.data() + b.begin, nb * sizeof(GuidedDev),
+            okq = hc(hipMemcpyAsync(S.d_guided.p, h_guided.data() + b.begin, nb * sizeof(GuidedDev),
                                     hipMemcpyHostToDevice, st), "H2D guided");
         if (!okq) return false;
         if (nord &&  // pack the pairs' 128-row segments into items (per streamed image) ...
-            !hc(launch_build_segments(0, c->d_imgs.p, c->d_pairs.p, c->d_order.p, c->d_grp.p, (uint32_t)b.ngrp,
-                                      c->d_cand_cnt.p, c->d_candbuf.p, c->d_rowbuf.p, c->d_seg_base.p, c->d_grp_segs.p,
-                                      c->d_grp_item_base.p, c->d_segs.p, c->d_scalars + 5, st), "segment packing"))
+            !hc(launch_build_segments(0, c->d_imgs.p, S.d_pairs.p, S.d_order.p, S.d_grp.p, (uint32_t)b.ngrp,
+                                      S.d_cand_cnt.p, S.d_candbuf.p, S.d_rowbuf.p, S.d_seg_base.p, S.d_grp_segs.p,
+                                      S.d_grp_item_base.p, S.d_segs.p, S.scalars + 5, st), "segment packing"))
             return false;
         if (!hc(hipEventRecord(c->bev[k][0], st), "event record")) return false;
         if (nord) {  // ... and scan them (the events bracket the scan kernel alone: bench.py's roofline leg)
@@ -1097,66 +1151,77 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
                 done_set = pending.set;
                 pending.set = -1;
             }
-            if (!hc(launch_match_mfma(0, c->d_segs.p, c->d_scalars + 5, (uint32_t)std::min<size_t>(b.seg_cap, 0xFFFFFFFFu),
-                                      c->d_scalars + 1, c->d_accmask.p, c->d_accept, st, job, c->d_scalars + 7, leave_cus), "forward scan"))
+            if (!hc(launch_match_mfma(0, S.d_segs.p, S.scalars + 5, (uint32_t)std::min<size_t>(b.seg_cap, 0xFFFFFFFFu),
+                                      S.scalars + 1, S.d_accmask.p, c->d_accept, st, job, S.scalars + 7, leave_cus), "forward scan"))
                 return false;
             // that batch's matches are on the host when this scan is done
             if (done_set >= 0 && !hc(hipEventRecord(c->bev[done_set][4], st), "event record")) return false;
         }
         if (b.nwork_grid &&
-            !hc(launch_match_guided_grid(c->d_imgs.p, c->d_grids.p, c->d_pairs.p, c->d_work.p, (uint32_t)b.nwork_grid,
-                                         c->d_rowbuf.p, c->d_colbuf.p, c->d_guided.p, st), "guided scan"))
+            !hc(launch_match_guided_grid(c->d_imgs.p, c->d_grids.p, S.d_pairs.p, S.d_work.p, (uint32_t)b.nwork_grid,
+                                         S.d_rowbuf.p, S.d_colbuf.p, S.d_guided.p, st), "guided scan"))
             return false;
         if (nwork > b.nwork_grid &&
-            !hc(launch_match_dot4(c->d_imgs.p, c->d_pairs.p, c->d_work.p + b.nwork_grid, (uint32_t)(nwork - b.nwork_grid),
-                                  c->d_rowbuf.p, c->d_colbuf.p, geoms ? c->d_guided.p : nullptr, st), "dot4 scan"))
+            !hc(launch_match_dot4(c->d_imgs.p, S.d_pairs.p, S.d_work.p + b.nwork_grid, (uint32_t)(nwork - b.nwork_grid),
+                                  S.d_rowbuf.p, S.d_colbuf.p, geoms ? S.d_guided.p : nullptr, st), "dot4 scan"))
             return false;
-        if (!hc(hipEventRecord(c->bev[k][1], st), "event record")) return false;
-        const bool use_order = std::getenv("AMC_RESOLVE_PAIR_ORDER") == nullptr;  // (A/B hook: workgroups in batch order)
         kernel_launches += (nord ? 1 : 0) + (b.nwork_grid ? 1 : 0) + (nwork > b.nwork_grid ? 1 : 0);
+        return hc(hipEventRecord(c->bev[k][1], st), "event record");
+    };
+    // second part, on the chain's stream (the same stream unless the chain runs beside the next scan): tile -> index,
+    // lazy cross check, finalize, D2H of the counters
+    auto enqueue_chain = [&](Batch& b) {
+        const int k = b.set;
+        amc_ctx::MatchScratch& S = c->ms[overlap ? k : 0];
+        const size_t nb = b.nb, nord = b.nord;
+        hipStream_t st = cs;  // (everything below is the chain)
+        if (overlap && !hc(hipStreamWaitEvent(st, c->bev[k][1], 0), "stream wait")) return false;
+        const bool use_order = std::getenv("AMC_RESOLVE_PAIR_ORDER") == nullptr;  // (A/B hook: workgroups in batch order)
         if (nord &&  // tile -> exact index for the accepted rows
-            !hc(launch_resolve_index(0, c->d_imgs.p, c->d_pairs.p, (uint32_t)nb, c->d_rowbuf.p, c->d_accmask.p, c->d_lut,
-                                     fp, c->d_cand_cnt.p, c->d_candbuf.p, c->d_scalars + 3, b.grouped_resolve,
-                                     use_order ? c->d_order.p : nullptr, (uint32_t)nord, st), "resolve (rows)"))
+            !hc(launch_resolve_index(0, c->d_imgs.p, S.d_pairs.p, (uint32_t)nb, S.d_rowbuf.p, S.d_accmask.p, c->d_lut,
+                                     fp, S.d_cand_cnt.p, S.d_candbuf.p, S.scalars + 3, b.grouped_resolve,
+                                     use_order ? S.d_order.p : nullptr, (uint32_t)nord, st), "resolve (rows)"))
             return false;
         if (nord && o.cross_check) {
             // lazy cross check: reverse scan only for the columns accepted rows point at
-            if (!hc(launch_select_candidates(c->d_imgs.p, c->d_pairs.p, (uint32_t)nb, b.max_cols, c->d_rowbuf.p,
-                                             c->d_accmask.p, c->d_lut, fp, c->d_cand_cnt.p, c->d_candbuf.p, st),
+            if (!hc(launch_select_candidates(c->d_imgs.p, S.d_pairs.p, (uint32_t)nb, b.max_cols, S.d_rowbuf.p,
+                                             S.d_accmask.p, c->d_lut, fp, S.d_cand_cnt.p, S.d_candbuf.p, st),
                     "candidate selection"))
                 return false;
-            if (!hc(hipMemcpyAsync(c->d_order2.p, c->h_order2[k].p, nord * sizeof(uint32_t),
+            if (!hc(tcopy(S.d_order2.p, c->h_order2[k].p, nord * sizeof(uint32_t),
                                    hipMemcpyHostToDevice, st), "H2D order2") ||
-                !hc(hipMemcpyAsync(c->d_grp2.p, c->h_grp2[k].p, (b.ngrp2 + 1) * sizeof(uint32_t),
+                !hc(tcopy(S.d_grp2.p, c->h_grp2[k].p, (b.ngrp2 + 1) * sizeof(uint32_t),
                                    hipMemcpyHostToDevice, st), "H2D group cuts"))
                 return false;
             // the candidate counts exist only on the device: the packing kernels read them there
-            if (!hc(launch_build_segments(1, c->d_imgs.p, c->d_pairs.p, c->d_order2.p, c->d_grp2.p, (uint32_t)b.ngrp2,
-                                          c->d_cand_cnt.p, c->d_candbuf.p, c->d_colbuf.p, c->d_seg_base.p, c->d_grp_segs.p,
-                                          c->d_grp_item_base.p, c->d_segs.p, c->d_scalars + 5, st), "segment packing (reverse)") ||
-                !hc(launch_match_mfma(1, c->d_segs.p, c->d_scalars + 5, (uint32_t)std::min<size_t>(b.seg_cap, 0xFFFFFFFFu),
-                                      c->d_scalars + 1, c->d_accmask.p, c->d_accept, st), "reverse scan") ||
-                !hc(launch_resolve_index(1, c->d_imgs.p, c->d_pairs.p, (uint32_t)nb, c->d_colbuf.p, c->d_accmask.p, c->d_lut,
-                                         fp, c->d_cand_cnt.p, c->d_candbuf.p, c->d_scalars + 3, b.grouped_resolve,
-                                         use_order ? c->d_order2.p : nullptr, (uint32_t)nord, st), "resolve (columns)"))
+            if (!hc(launch_build_segments(1, c->d_imgs.p, S.d_pairs.p, S.d_order2.p, S.d_grp2.p, (uint32_t)b.ngrp2,
+                                          S.d_cand_cnt.p, S.d_candbuf.p, S.d_colbuf.p, S.d_seg_base.p, S.d_grp_segs.p,
+                                          S.d_grp_item_base.p, S.d_segs.p, S.scalars + 5, st), "segment packing (reverse)") ||
+                !hc(launch_match_mfma(1, S.d_segs.p, S.scalars + 5, (uint32_t)std::min<size_t>(b.seg_cap, 0xFFFFFFFFu),
+                                      S.scalars + 1, S.d_accmask.p, c->d_accept, st), "reverse scan") ||
+                !hc(launch_resolve_index(1, c->d_imgs.p, S.d_pairs.p, (uint32_t)nb, S.d_colbuf.p, S.d_accmask.p, c->d_lut,
+                                         fp, S.d_cand_cnt.p, S.d_candbuf.p, S.scalars + 3, b.grouped_resolve,
+                                         use_order ? S.d_order2.p : nullptr, (uint32_t)nord, st), "resolve (columns)"))
                 return false;
         }
         if (!hc(hipEventRecord(c->bev[k][2], st), "event record") ||
-            !hc(launch_finalize(c->d_imgs.p, c->d_pairs.p, (uint32_t)nb, c->d_rowbuf.p, c->d_colbuf.p,
-                                c->d_accmask.p, c->d_lut, fp, c->d_scalars, (uint32_t)std::min(b.cap, (size_t)0xFFFFFFFFu),
-                                c->d_pair_off.p, c->d_pair_cnt.p, c->d_matches.p, st), "finalize"))
+            !hc(launch_finalize(c->d_imgs.p, S.d_pairs.p, (uint32_t)nb, S.d_rowbuf.p, S.d_colbuf.p,
+                                S.d_accmask.p, c->d_lut, fp, S.scalars, (uint32_t)std::min(b.cap, (size_t)0xFFFFFFFFu),
+                                S.d_pair_off.p, S.d_pair_cnt.p, S.d_matches.p, st), "finalize"))
             return false;
-        return hc(hipMemcpyAsync(c->h_bscalars[k].p, c->d_scalars, 4 * sizeof(uint32_t),
+        return hc(tcopy(c->h_bscalars[k].p, S.scalars, 4 * sizeof(uint32_t),
                                  hipMemcpyDeviceToHost, st), "D2H cursor") &&
-               hc(hipMemcpyAsync(c->h_pair_off[k].p, c->d_pair_off.p, nb * sizeof(uint32_t),
+               hc(tcopy(c->h_pair_off[k].p, S.d_pair_off.p, nb * sizeof(uint32_t),
                                  hipMemcpyDeviceToHost, st), "D2H pair_off") &&
-               hc(hipMemcpyAsync(c->h_pair_cnt[k].p, c->d_pair_cnt.p, nb * sizeof(uint32_t),
+               hc(tcopy(c->h_pair_cnt[k].p, S.d_pair_cnt.p, nb * sizeof(uint32_t),
                                  hipMemcpyDeviceToHost, st), "D2H pair_cnt") &&
                hc(hipEventRecord(c->bev[k][3], st), "event record");
     };
     // the batch's counters are on the host: check them, enqueue the copy of exactly `total` matches
     auto collect = [&](Batch& b) {
         const int k = b.set;
+        amc_ctx::MatchScratch& S = c->ms[overlap ? k : 0];
+        hipStream_t st = cs;  // (the reorder follows the chain)
         if (!hc(hipEventSynchronize(c->bev[k][3]), "wait for the batch")) return false;
         b.total = c->h_bscalars[k].p[0];
         if (c->h_bscalars[k].p[3] != 0) {
@@ -1194,7 +1259,7 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
                     !hc(hipMemcpyAsync(bigger.p, c->d_keep.p, 2 * keep_used * sizeof(uint32_t), hipMemcpyDeviceToDevice, st),
                         "move resident match table"))
                     return false;
-                if (!hc(hipStreamSynchronize(st), "sync before freeing the old resident table") ||
+                if (!sync_batch_streams("sync before freeing the old resident table") ||
                     !hc(hipStreamSynchronize(c->copy_stream), "sync before freeing the old resident table"))
                     return false;
                 if (batch_hook) verify_streams_sync(c);  // (verification slices of earlier batches read the old table)
@@ -1202,7 +1267,7 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
                 c->d_keep = bigger;
             }
             if (need > priv->matches.cap) {  // grow the result buffer (first calls only: the pool keeps it)
-                if (!hc(hipStreamSynchronize(st), "sync before growing the result buffer") ||
+                if (!sync_batch_streams("sync before growing the result buffer") ||
                     !hc(hipStreamSynchronize(c->copy_stream), "sync before growing the result buffer"))
                     return false;
                 PinBuf<uint32_t> bigger;
@@ -1212,14 +1277,15 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
                 priv->matches = bigger;
             }
             if (!hc(c->d_csr.ensure(b.nb), "dev csr") ||
-                !hc(hipMemcpyAsync(c->d_csr.p, c->h_csr[k].p, b.nb * sizeof(uint64_t), hipMemcpyHostToDevice, st), "H2D csr"))
+                !hc(tcopy(c->d_csr.p, c->h_csr[k].p, b.nb * sizeof(uint64_t), hipMemcpyHostToDevice, st), "H2D csr"))
                 return false;
             // the copy to the host happens beside the next batch's kernels (which write d_matches and, later, d_keep
             // beyond this batch - never what is being copied): flush_copy() or the next enqueue() issues it
-            if (!hc(launch_reorder_matches(c->d_pair_off.p, c->d_pair_cnt.p, c->d_csr.p, (uint32_t)b.nb, c->d_matches.p,
+            if (!hc(launch_reorder_matches(S.d_pair_off.p, S.d_pair_cnt.p, c->d_csr.p, (uint32_t)b.nb, S.d_matches.p,
                                            c->d_keep.p, st), "reorder launch"))
                 return false;
             if (batch_hook && !hc(hipEventRecord(c->kev[k], st), "event record")) return false;
+            if (overlap && !hc(hipEventRecord(c->sev[k], st), "event record")) return false;
             pending.dst = priv->matches.p + 2 * keep_used;
             pending.src = c->d_keep.p + 2 * keep_used;
             pending.bytes = (size_t)b.total * 2 * sizeof(uint32_t);
@@ -1227,6 +1293,7 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
             keep_used += b.total;
             return true;
         }
+        if (overlap && !hc(hipEventRecord(c->sev[k], st), "event record")) return false;
         return hc(hipEventRecord(c->bev[k][4], st), "event record");
     };
     double t_hook = 0.0;
@@ -1256,7 +1323,7 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
         if (pending.set < 0) return true;
         const int k = pending.set;
         pending.set = -1;
-        if (!hc(hipEventRecord(c->cev[k], st), "event record") || !hc(hipStreamWaitEvent(c->copy_stream, c->cev[k], 0), "stream wait"))
+        if (!hc(hipEventRecord(c->cev[k], cs), "event record") || !hc(hipStreamWaitEvent(c->copy_stream, c->cev[k], 0), "stream wait"))
             return false;
         if (d2h_mode == 2) {
             if (!hc(hipMemcpyAsync(pending.dst, pending.src, pending.bytes, hipMemcpyDeviceToHost, c->copy_stream), "D2H matches"))
@@ -1282,7 +1349,7 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
         bool ok = prepare(cur);
         t_prepare += since(tp);
         tp = std::chrono::steady_clock::now();
-        ok = ok && enqueue(cur);
+        ok = ok && enqueue_scan(cur) && enqueue_chain(cur);
         t_enqueue += since(tp);
         // The host runs one batch ahead of the device: while batch `cur` is scanned, the next batch's lists are
         // prepared; the matches of the batch BEFORE cur are read out (scatter) only after that - their copy rides in
@@ -1302,12 +1369,17 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
             tp = std::chrono::steady_clock::now();
             if (ok && have_prev) ok = scatter(prev);  // (before enqueue(next) re-records that set's events)
             t_scatter += since(tp);
+            // (two sets: the next scan goes out BEFORE the wait for this batch's counters - it runs right behind this
+            //  batch's scan, on all CUs but the few its chain gets)
+            tp = std::chrono::steady_clock::now();
+            if (ok && have_next && overlap) ok = enqueue_scan(next, chain_cus);
+            t_enqueue += since(tp);
             tp = std::chrono::steady_clock::now();
             ok = ok && collect(cur);
             t_collect += since(tp);
             tp = std::chrono::steady_clock::now();
             if (ok) plan_hook(cur, have_next ? &next : nullptr);
-            if (ok && have_next) ok = enqueue(next, cus_free);
+            if (ok && have_next) ok = (overlap || enqueue_scan(next, cus_free)) && enqueue_chain(next);
             ok = ok && flush_copy();  // (not taken by a scan launch: the last batch's, a small one, dot4-only batches)
             t_enqueue += since(tp);
             ok = ok && run_hook(cur);  // (the device is busy with `next` - or, for the last batch, with the copy)
@@ -1324,6 +1396,7 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
         if (!ok && rc == AMC_OK) rc = fail(AMC_E_HIP, "amc_match_pairs: batch failed");
         if (rc != AMC_OK) {  // nothing of this call stays in flight
             (void)hipStreamSynchronize(st);
+            if (overlap) (void)hipStreamSynchronize(cs);
             (void)hipStreamSynchronize(c->copy_stream);
         }
     }
@@ -1331,6 +1404,8 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
     if (rc == AMC_OK && npairs > 0 &&
         hc(hipEventRecord(c->cev[0], c->copy_stream), "event record"))
         hc(hipStreamWaitEvent(st, c->cev[0], 0), "stream wait");
+    if (rc == AMC_OK && npairs > 0 && overlap && hc(hipEventRecord(c->cev[1], cs), "event record"))
+        hc(hipStreamWaitEvent(st, c->cev[1], 0), "stream wait");  // (and the chain's stream)
     if (rc == AMC_OK && hc(hipEventRecord(c->ev[1], st), "event record")) hc(hipEventSynchronize(c->ev[1]), "wait for the call");
     if (rc != AMC_OK) {
         delete priv;

@@ -255,6 +255,8 @@ hipError_t launch_finalize(const ImageDev* imgs, const PairDev* pairs, uint32_t 
 
 // match_common.hip: device -> pinned host copy by a small-grid kernel that co-resides with the scan (bytes % 8 == 0)
 hipError_t launch_host_copy(void* dst_pinned, const void* src_dev, size_t bytes, hipStream_t s);
+// a small copy as a kernel on the stream (pinned host or device memory on either side, 4-byte units): match_common.hip
+hipError_t launch_copy_words(void* dst, const void* src, size_t bytes, hipStream_t s);
 hipError_t launch_reorder_matches(const uint32_t* src_off, const uint32_t* cnt, const uint64_t* dst_off, uint32_t npairs,
                             const uint32_t* src, uint32_t* dst, hipStream_t s);
 

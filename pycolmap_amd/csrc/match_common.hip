@@ -932,6 +932,39 @@ hipError_t launch_host_copy(void* dst_pinned, const void* src_dev, size_t bytes,
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------
+// The batch tables' small copies as a kernel (either side may be pinned host memory; both 4-byte aligned, bytes a
+// multiple of 4).  The runtime's asynchronous copies of ALL streams go through one in-order DMA queue: a copy that waits
+// for a kernel of its own stream holds up every other stream's copies behind it - with a batch's chain beside the
+// next batch's scan (match_impl) that serialised the two (profiles/r06/overlap_timeline_v2.txt).  A kernel only
+// waits for its own stream.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void copy_words_kernel(uint32_t* __restrict__ dst, const uint32_t* __restrict__ src, size_t nwords,
+                                                         int vec) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (vec) {
+        const size_t n16 = nwords / 4;
+        const uint4* s4 = reinterpret_cast<const uint4*>(src);
+        uint4* d4 = reinterpret_cast<uint4*>(dst);
+        for (size_t j = i; j < n16; j += stride) d4[j] = s4[j];
+        for (size_t j = n16 * 4 + i; j < nwords; j += stride) dst[j] = src[j];
+    } else {
+        for (; i < nwords; i += stride) dst[i] = src[i];
+    }
+}
+hipError_t launch_copy_words(void* dst, const void* src, size_t bytes, hipStream_t s) {
+    if (bytes == 0) return hipSuccess;
+    if ((bytes & 3) || (reinterpret_cast<uintptr_t>(dst) & 3) || (reinterpret_cast<uintptr_t>(src) & 3)) return hipErrorInvalidValue;
+    const size_t nwords = bytes / 4;
+    const int vec = ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15) == 0;
+    const size_t units = vec ? (nwords + 3) / 4 : nwords;
+    const unsigned blocks = (unsigned)std::min<size_t>(32, (units + 255) / 256);
+    hipLaunchKernelGGL(copy_words_kernel, dim3(blocks), dim3(256), 0, s, static_cast<uint32_t*>(dst),
+                       static_cast<const uint32_t*>(src), nwords, vec);
+    return hipGetLastError();
+}
+
 hipError_t launch_finalize(const ImageDev* imgs, const PairDev* pairs, uint32_t npairs,
                            const Top2* rowbuf, const Top2* colbuf, uint32_t* accmask,
                            const float* acos_lut, FinalizeParams fp, uint32_t* cursor, uint32_t capacity,

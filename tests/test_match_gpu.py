@@ -280,6 +280,20 @@ def test_many_batches_pipeline(amc_ctx, monkeypatch, kernel, entries):
         np.testing.assert_array_equal(m, ref[1])
         for k in env:
             monkeypatch.delenv(k)
+    # a batch's cross-check chain on its own stream beside the next batch's scan, on the second set of batch tables
+    # (AMC_MATCH_OVERLAP=1; measured and not the default: DESIGN.md section 5), with CUs left to it and without
+    for cus in ("8", "0"):
+        monkeypatch.setenv("AMC_MATCH_OVERLAP", "1")
+        monkeypatch.setenv("AMC_CHAIN_CUS", cus)
+        for opts in ((0.8, 0.7, True), (0.9, 1.0, False)):
+            assert_same(amc_ctx, imgs, s1, s2, kernel, opts)
+        off, m, st = amc_ctx.match_pairs(s1, s2, kernel=kernel)
+        np.testing.assert_array_equal(off, ref[0])
+        np.testing.assert_array_equal(m, ref[1])
+    monkeypatch.delenv("AMC_MATCH_OVERLAP")
+    monkeypatch.delenv("AMC_CHAIN_CUS")
+    off, m, st = amc_ctx.match_pairs(s1, s2, kernel=kernel)   # back on one set, one stream
+    np.testing.assert_array_equal(m, ref[1])
 
 
 @pytest.mark.parametrize("cross_check", [True, False])
