@@ -356,8 +356,9 @@ def pipeline_leg(ctx_factory, steps: int, warmup: int, cpu_pairs: int, num_image
         ctx.upload_camera(k, im["model"], im["width"], im["height"], im["params"], True)
     s1, s2 = synth.exhaustive_pairs(num_images)
     opts = _capi.tvg_options()
-    for _ in range(warmup):
-        ctx.match_verify_pairs(s1, s2, opts)
+    for _ in range(warmup):   # (the timed loop's own call: result views, released before the next call)
+        w_ = ctx.match_verify_pairs(s1, s2, opts, copy=False)
+        w_ = None
     t0 = time.perf_counter()
     acc = dict(match_ms=0.0, scan_ms=0.0, cross_ms=0.0, verify_ms=0.0, verify_kernel_ms=0.0, launches=0)
     tl = dict(c_call_ms=0.0, verify_setup_ms=0.0, match_call_ms=0.0, close_and_launch_ms=0.0, verify_wait_pack_download_ms=0.0,
@@ -1421,7 +1422,7 @@ def main():
         if gpu_legs and not args.no_pipeline:
             release_headline()
             # (five steps: with two, one 20 ms host-side stall - seen once in this round's six runs of the line - is 10 ms of the figure)
-            out["pipeline"] = pipeline_leg(lambda: _capi.Context(local_rank), args.pipeline_steps or max(1, min(args.steps, 5)), min(1, args.warmup),
+            out["pipeline"] = pipeline_leg(lambda: _capi.Context(local_rank), args.pipeline_steps or max(1, min(args.steps, 5)), min(2, args.warmup),
                                            0 if args.no_cpu_baseline else 4 * host_cores(), args.images, args.feats)
             sm = out["pipeline"]["stage_ms_per_step"]
             out["pipeline"].update(verify_ms=sm["verify_ms"], verify_kernel_ms=sm["verify_kernel_ms"], match_ms=sm["match_ms"],

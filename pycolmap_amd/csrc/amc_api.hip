@@ -697,6 +697,7 @@ int ceil_log2(uint32_t x) {
 #ifndef AMC_MATCH_OVERLAP_DEFAULT
 #define AMC_MATCH_OVERLAP_DEFAULT 0
 #endif
+constexpr size_t kFirstBatchDiv = 0;  // match_impl: a call's first batch as a fraction of a full one (0: a full one)
 constexpr bool kMatchOverlapDefault = AMC_MATCH_OVERLAP_DEFAULT != 0;  // match_impl: a batch's chain beside the next batch's scan
 constexpr size_t kMaxTop2Entries = (size_t)256 << 20;  // 256 Mi entries x 16 B = 4 GiB per side
 constexpr size_t kMaxMatchCap = (size_t)256 << 20;     // worst-case matches of a batch: x 8 B = 2 GiB (device)
@@ -913,6 +914,8 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
     auto sync_batch_streams = [&](const char* what) {
         return hc(hipStreamSynchronize(st), what) && (!overlap || hc(hipStreamSynchronize(cs), what));
     };
+    size_t first_div = kFirstBatchDiv;
+    if (const char* e = std::getenv("AMC_MATCH_FIRST_DIV")) first_div = (size_t)std::max(0, std::atoi(e));
     auto carve = [&](size_t begin, int set) {
         Batch b;
         b.begin = b.end = begin;
@@ -925,6 +928,10 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
         const uint64_t rows_left = rows_total - rows_carved;  // (carve() is called for consecutive batches, in order)
         if (!even_batches && begin > 0 && rows_left <= max_entries && rows_left > max_entries / 4)
             limit = (size_t)(rows_left - max_entries / 4);
+        // ... and begins on a small one: the device is idle while the host prepares the call's FIRST batch (queue orders
+        // of 62 k pairs: 0.7 ms of a 177 ms step), the next batches' lists are made beside a scan.  AMC_MATCH_FIRST_DIV=d
+        // (A/B hook): the first batch of a call of more than one full batch is 1 / d of a full one (0: off).
+        if (!even_batches && begin == 0 && first_div > 1 && rows_total > max_entries) limit = max_entries / first_div;
         while (b.end < npairs) {
             const Slot& x = c->slots[slot1[b.end]];
             const Slot& y = c->slots[slot2[b.end]];
