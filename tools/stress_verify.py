@@ -32,6 +32,9 @@ def main():
     ap.add_argument("--rounds", type=int, default=10)
     ap.add_argument("--pairs", type=int, default=200)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--wide", action="store_true",
+                    help="also: multiple_models rounds (two-motion scenes, inlier labels compared), a few pairs of "
+                         "thousands of matches per round (the larger size classes of the kernels)")
     args = ap.parse_args()
     import oracle_lib as o
     from pycolmap_amd import _capi, synth
@@ -52,13 +55,28 @@ def main():
                   force_H_use=int(rng.random() < 0.15), max_H_inlier_ratio=float(rng.choice([0.5, 0.8, 0.95])),
                   min_E_F_inlier_ratio=float(rng.choice([0.8, 0.95])), compute_relative_pose=int(rng.integers(0, 2)),
                   ransac=ransac)
+        multi = bool(args.wide and rng.random() < 0.25)
+        if multi:   # EstimateMultipleTwoViewGeometries: no pose, the mask bytes are geometry labels
+            kw["multiple_models"] = 1
+            kw["compute_relative_pose"] = 0
+            kw["multiple_ignore_watermark"] = int(rng.integers(0, 2))
         seed = int(rng.integers(0, 2 ** 31))
         scenes, priors = [], []
-        for _ in range(args.pairs):
+        for q in range(args.pairs):
             kind = rng.integers(0, 4)
-            sc = synth.two_view_scene(rng, num_inliers=int(rng.integers(5, 500)), num_outliers=int(rng.integers(0, 300)),
+            big = args.wide and q < 3   # a few pairs of thousands of matches: the kernels' larger size classes
+            sc = synth.two_view_scene(rng, num_inliers=int(rng.integers(1500, 6000)) if big else int(rng.integers(5, 500)),
+                                      num_outliers=int(rng.integers(0, 3000)) if big else int(rng.integers(0, 300)),
                                       noise=float(rng.choice([0.2, 0.5, 1.5])), planar=kind == 1,
                                       pure_rotation=kind == 2, extra_keypoints=5)
+            if multi and not big and rng.random() < 0.6:   # a second rigid motion glued on (tests/test_verify_gpu.py: two_motion_scene)
+                b = synth.two_view_scene(rng, num_inliers=int(rng.integers(20, 250)), num_outliers=0, extra_keypoints=5)
+                o1, o2 = len(sc["pts1"]), len(sc["pts2"])
+                m = np.concatenate([sc["matches"].astype(np.int64), b["matches"].astype(np.int64) + [o1, o2]])
+                sc = dict(sc)
+                sc["pts1"] = np.concatenate([sc["pts1"], b["pts1"]])
+                sc["pts2"] = np.concatenate([sc["pts2"], b["pts2"]])
+                sc["matches"] = m[rng.permutation(len(m))].astype(np.uint32)
             scenes.append(sc)
             priors.append(bool(rng.integers(0, 2)))
         ctx.reserve_slots(2 * len(scenes))
@@ -89,10 +107,16 @@ def main():
         want = list(pool.map(ref, range(len(scenes))))
         for p, w in enumerate(want):
             g = tvg[p]
-            ok = (_capi.CONFIG_NAMES[g["config"]] == w["config_name"] and g["num_trials"].tolist() == w["trials"] and
-                  g["model_inliers"].tolist() == w["inl"] and g["num_inliers"] == w["num_inliers"] and
-                  np.array_equal(mask[int(off[p]):int(off[p + 1])], w["inlier_mask"]) and
-                  all(np.array_equal(bits(g[k]), bits(w[k])) for k in "EFH"))
+            if multi:
+                ok = (_capi.CONFIG_NAMES[g["config"]] == w["config_name"] and g["num_inliers"] == w["num_inliers"] and
+                      np.array_equal(vst["inlier_labels"][int(off[p]):int(off[p + 1])], w["inlier_label"]) and
+                      all(np.array_equal(bits(g[k]), bits(w[k])) for k in "EFH") and
+                      (w["config_name"] == "MULTIPLE" or g["num_trials"].tolist() == w["trials"]))
+            else:
+                ok = (_capi.CONFIG_NAMES[g["config"]] == w["config_name"] and g["num_trials"].tolist() == w["trials"] and
+                      g["model_inliers"].tolist() == w["inl"] and g["num_inliers"] == w["num_inliers"] and
+                      np.array_equal(mask[int(off[p]):int(off[p + 1])], w["inlier_mask"]) and
+                      all(np.array_equal(bits(g[k]), bits(w[k])) for k in "EFH"))
             if ok and kw["compute_relative_pose"]:
                 q = vst["pose"][p]
                 ok = (bool(q["ok"]) == w["pose_ok"] and int(q["num_points3D"]) == w["num_points3D"] and
