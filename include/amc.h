@@ -46,8 +46,9 @@
 extern "C" {
 #endif
 
-#define AMC_ABI_VERSION 4 /* 3: the multi-GPU exchange (amc_comm_*, amc_allgather_match_tables); 4: its verification half
-                             (amc_allgather_pair_records, amc_allgather_inlier_tables) */
+#define AMC_ABI_VERSION 5 /* 3: the multi-GPU exchange (amc_comm_*, amc_allgather_match_tables); 4: its verification half
+                             (amc_allgather_pair_records, amc_allgather_inlier_tables); 5: amc_upload_matches and
+                             amc_verify_pairs on the resident match table (matches = NULL) */
 #define AMC_DESC_DIM 128 /* SIFT descriptor bytes; /root/reference/pycolmap/feature/sift.h:76-77 */
 
 enum {
@@ -121,6 +122,15 @@ int amc_ctx_trim(amc_ctx* ctx);
  * SiftMatchingOptions.gpu_index, /root/reference/pycolmap/pipeline/match_features.h:76-81).  The pointer stays valid
  * until the next match call, amc_ctx_trim or amc_ctx_destroy on this ctx; NULL when the table is empty. */
 int amc_ctx_resident_matches(amc_ctx* ctx, const uint32_t** dev_matches, uint64_t* num_matches);
+
+/* Match rows from the HOST into that resident table: num_matches (idx1, idx2) uint32 rows in the CSR order of the pair
+ * list they belong to - what verify_matches reads from the database's `matches` table before it verifies
+ * (/root/reference/pycolmap/pipeline/match_features.h:51-68: CreateImagePairsFeatureMatcher on stored matches).  The
+ * rows stay in device memory like uploaded descriptors and keypoints do, so that amc_verify_pairs(matches = NULL) -
+ * once, or again with other options - reads them there instead of taking them over PCIe in every call.  Replaces
+ * whatever the table held (a match call's rows); the next match call, amc_ctx_trim and amc_ctx_destroy drop it.
+ * Blocking.  Errors: AMC_E_INVALID (NULL rows with num_matches > 0), AMC_E_HIP. */
+int amc_upload_matches(amc_ctx* ctx, const uint32_t* matches, uint64_t num_matches);
 
 /* ---- multi-GPU exchange -------------------------------------------------------------------
  * Image pairs shard over the GPUs of a node (one ctx per GPU: one process per GPU, or one thread per GPU of one
@@ -398,7 +408,11 @@ int amc_img_from_cam(amc_ctx* ctx, int32_t model_id, const double* params, int32
  * matches[2*match_offsets[p] .. 2*match_offsets[p+1]).  The PRNG is re-seeded with `seed` at the
  * start of every pair (COLMAP's pipeline PRNG is thread_local and not reproducible across
  * pairs; pycolmap's single-pair estimators reseed with 0:
- * /root/reference/pycolmap/estimators/fundamental_matrix.h:21).  Blocking. */
+ * /root/reference/pycolmap/estimators/fundamental_matrix.h:21).  Blocking.
+ * matches = NULL (with match_offsets[npairs] > 0): the rows are read from the ctx's resident match table - where the
+ * last match call left them or amc_upload_matches put them; match_offsets[npairs] must equal its row count
+ * (AMC_E_STATE otherwise).  Not with multiple_models (EstimateMultipleTwoViewGeometries shrinks the lists on the host:
+ * AMC_E_INVALID). */
 int amc_verify_pairs(amc_ctx* ctx, const uint32_t* slot1, const uint32_t* slot2, size_t npairs,
                      const uint64_t* match_offsets, const uint32_t* matches,
                      const amc_tvg_opts* opts, uint32_t seed, amc_verify_result* out);

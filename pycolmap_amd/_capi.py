@@ -32,6 +32,7 @@ EXPORTED_SYMBOLS = [
     "amc_homography_decomposition", "amc_img_from_cam",
     "amc_comm_unique_id", "amc_comm_create", "amc_comm_destroy", "amc_allgather_match_tables", "amc_gathered_tables_free",
     "amc_allgather_pair_records", "amc_gathered_records_free", "amc_allgather_inlier_tables", "amc_ctx_last_timeline",
+    "amc_upload_matches",
 ]
 COMM_ID_BYTES = 128
 RANSAC_F, RANSAC_H, RANSAC_E = 0, 1, 2
@@ -197,6 +198,8 @@ def load() -> C.CDLL:
     lib.amc_ctx_trim.restype = C.c_int
     lib.amc_ctx_resident_matches.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.amc_ctx_resident_matches.restype = C.c_int
+    lib.amc_upload_matches.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+    lib.amc_upload_matches.restype = C.c_int
     if hasattr(lib, "amc_ctx_last_timeline"):
         lib.amc_ctx_last_timeline.argtypes = [C.c_void_p, C.c_void_p]
     lib.amc_ctx_reserve_slots.argtypes = [C.c_void_p, C.c_uint32]
@@ -470,6 +473,15 @@ class Context:
         ptr, n = C.c_void_p(), C.c_uint64()
         _check(self._lib.amc_ctx_resident_matches(self._h, C.byref(ptr), C.byref(n)))
         return int(ptr.value or 0), int(n.value)
+
+    def upload_matches(self, matches) -> int:
+        """Match rows (uint32 [n, 2], the CSR order of the pair list they belong to) into the resident match table
+        (amc_upload_matches): verify_pairs(..., matches=None) reads them there - once, or again with other options -
+        instead of taking them over PCIe in every call.  Returns the number of rows."""
+        m = np.ascontiguousarray(matches, dtype=np.uint32).reshape(-1, 2)
+        self.resident_generation += 1
+        _check(self._lib.amc_upload_matches(self._h, m.ctypes.data_as(C.c_void_p), C.c_uint64(m.shape[0])))
+        return int(m.shape[0])
 
     def resident_view_valid(self, generation: int) -> bool:
         """True while a view taken at `generation` (= self.resident_generation at that time) still points at live memory."""
@@ -755,24 +767,30 @@ class Context:
                      copy: bool = True):
         """EstimateTwoViewGeometry per pair. Returns (tvg structured array [npairs], inlier_mask
         bool [total matches], stats).  copy=False: the arrays are views of the library's result buffers (as a C++
-        caller reads them), released when the last of them is garbage collected."""
+        caller reads them), released when the last of them is garbage collected.  matches=None: the rows are read from
+        the resident match table (upload_matches, or the last match call's) - match_offsets[-1] must be its row count."""
         s1 = np.ascontiguousarray(slot1, dtype=np.uint32)
         s2 = np.ascontiguousarray(slot2, dtype=np.uint32)
         off = np.ascontiguousarray(match_offsets, dtype=np.uint64)
-        m = np.ascontiguousarray(matches, dtype=np.uint32).reshape(-1, 2)
         if off.shape != (s1.size + 1,) or s1.shape != s2.shape:
             raise ValueError("match_offsets must have npairs + 1 entries")
-        if int(off[-1]) != m.shape[0]:
-            raise ValueError("match_offsets[-1] must equal the number of matches")
+        if matches is None:
+            m, nrows = None, int(off[-1]) if off.size else 0
+        else:
+            m = np.ascontiguousarray(matches, dtype=np.uint32).reshape(-1, 2)
+            nrows = m.shape[0]
+            if int(off[-1]) != nrows:
+                raise ValueError("match_offsets[-1] must equal the number of matches")
         o = opts if opts is not None else tvg_options()
         res = VerifyResult()
         _check(self._lib.amc_verify_pairs(self._h, s1.ctypes.data_as(C.c_void_p), s2.ctypes.data_as(C.c_void_p),
-                                          s1.size, off.ctypes.data_as(C.c_void_p), m.ctypes.data_as(C.c_void_p),
+                                          s1.size, off.ctypes.data_as(C.c_void_p),
+                                          m.ctypes.data_as(C.c_void_p) if m is not None else None,
                                           C.byref(o), seed, C.byref(res)))
         if not copy:
-            return self._unpack_verify(res, m.shape[0], bool(o.multiple_models), _VerifyLease(self._lib, res))
+            return self._unpack_verify(res, nrows, bool(o.multiple_models), _VerifyLease(self._lib, res))
         try:
-            tvg, mask, stats = self._unpack_verify(res, m.shape[0], bool(o.multiple_models))
+            tvg, mask, stats = self._unpack_verify(res, nrows, bool(o.multiple_models))
         finally:
             self._lib.amc_verify_result_free(C.byref(res))
         return tvg, mask, stats

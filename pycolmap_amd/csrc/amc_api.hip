@@ -590,6 +590,21 @@ int amc_ctx_resident_matches(amc_ctx* c, const uint32_t** dev_matches, uint64_t*
     return AMC_OK;
 }
 
+int amc_upload_matches(amc_ctx* c, const uint32_t* matches, uint64_t num_matches) {
+    if (!c) return fail(AMC_E_INVALID, "amc_upload_matches: ctx is NULL");
+    if (num_matches > 0 && !matches) return fail(AMC_E_INVALID, "amc_upload_matches: NULL rows");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));  // (nothing of an earlier call reads the table any more: every entry point blocks)
+    c->resident_matches = 0;
+    c->vres = amc::VerifyResident{};  // (a resident verification result indexes the table this call rewrites)
+    if (num_matches == 0) return AMC_OK;
+    HIPCHK(c->d_keep.ensure((size_t)(2 * num_matches)));
+    HIPCHK(hipMemcpyAsync(c->d_keep.p, matches, (size_t)(2 * num_matches) * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->resident_matches = num_matches;
+    return AMC_OK;
+}
+
 int amc_ctx_reserve_slots(amc_ctx* c, uint32_t num_slots) {
     if (!c) return fail(AMC_E_INVALID, "amc_ctx_reserve_slots: ctx is NULL");
     HIPCHK(hipSetDevice(c->device));
@@ -2912,6 +2927,23 @@ static int verify_multiple(amc_ctx* c, const uint32_t* slot1, const uint32_t* sl
 int amc_verify_pairs(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, size_t npairs,
                      const uint64_t* match_offsets, const uint32_t* matches,
                      const amc_tvg_opts* opts_in, uint32_t seed, amc_verify_result* out) {
+    const uint64_t total = (c && out && npairs > 0 && match_offsets) ? match_offsets[npairs] : 0;
+    if (total > 0 && !matches) {
+        // the resident match table (amc_upload_matches, or the last match call's rows) instead of rows over PCIe
+        if (opts_in && opts_in->multiple_models) {
+            std::memset(out, 0, sizeof *out);
+            return fail(AMC_E_INVALID, "amc_verify_pairs: multiple_models needs the match rows on the host (matches is NULL)");
+        }
+        if (c->resident_matches != total) {
+            std::memset(out, 0, sizeof *out);
+            return fail(AMC_E_STATE, "amc_verify_pairs: matches is NULL and the resident match table holds %llu rows, not the "
+                        "%llu of match_offsets", (unsigned long long)c->resident_matches, (unsigned long long)total);
+        }
+        const uint64_t keep = c->resident_matches;  // (verify_impl drops a resident verification result, not the match table)
+        const int rc = verify_impl(c, 0, slot1, slot2, npairs, match_offsets, nullptr, opts_in, seed, out, c->d_keep.p, match_offsets);
+        c->resident_matches = keep;
+        return rc;
+    }
     if (c && out && opts_in && opts_in->multiple_models)
         return verify_multiple(c, slot1, slot2, npairs, match_offsets, matches, *opts_in, seed, out);
     return verify_impl(c, 0, slot1, slot2, npairs, match_offsets, matches, opts_in, seed, out);

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for name in decl:
         assert hasattr(lib, name), f"libamc.so does not export {name}"
     assert set(_capi.EXPORTED_SYMBOLS) <= set(decl)
-    assert lib.amc_abi_version() == 4
+    assert lib.amc_abi_version() == 5
 
 
 def test_no_gpu_means_loud_failure_not_fallback():

@@ -457,6 +457,45 @@ def test_result_views_equal_copies_and_outlive_the_call(amc_ctx):
     np.testing.assert_array_equal(part, want)      # the slice keeps the result alive
 
 
+def test_verification_on_uploaded_resident_matches(amc_ctx):
+    """amc_upload_matches + amc_verify_pairs(matches = NULL): the match rows stay in device memory like descriptors and
+    keypoints do, a verification call (and a second one with other options, and one with the relative pose) reads them
+    there.  Same results as the call that takes the rows over PCIe - and as the oracle; the table's size is checked."""
+    rng = np.random.default_rng(83)
+    scenes = [synth.two_view_scene(rng, num_inliers=int(n), num_outliers=int(k), planar=pl, extra_keypoints=5)
+              for n, k, pl in ((200, 80, False), (60, 10, True), (9, 30, False), (300, 0, False), (3, 2, False), (150, 150, False))]
+    priors = [True, False, True, True, False, False]
+    tvg, mask, off, want = run_both(amc_ctx, scenes, priors)          # rows over PCIe (uploads slots, checks nothing yet)
+    for p in range(len(scenes)):
+        assert_pair_equal(p, tvg, mask, off, want)
+    s1 = np.arange(0, 2 * len(scenes), 2, dtype=np.uint32)
+    matches = np.concatenate([sc["matches"] for sc in scenes])
+    assert amc_ctx.upload_matches(matches) == len(matches)
+    ptr, n = amc_ctx.resident_matches()
+    assert ptr != 0 and n == len(matches)
+    for kw in ({}, dict(compute_relative_pose=1), dict(ransac=dict(max_error=2.0, confidence=0.99))):
+        a = amc_ctx.verify_pairs(s1, s1 + 1, off, matches, _capi.tvg_options(**kw))
+        assert amc_ctx.upload_matches(matches) == len(matches)     # (a host-rows call may reuse the table's memory)
+        b = amc_ctx.verify_pairs(s1, s1 + 1, off, None, _capi.tvg_options(**kw))
+        c = amc_ctx.verify_pairs(s1, s1 + 1, off, None, _capi.tvg_options(**kw), copy=False)   # the table is still there
+        assert a[0].tobytes() == b[0].tobytes() == c[0].tobytes()
+        np.testing.assert_array_equal(a[1], b[1])
+        np.testing.assert_array_equal(a[1], c[1])
+        if kw.get("compute_relative_pose"):
+            assert a[2]["pose"].tobytes() == b[2]["pose"].tobytes()
+        del c
+    # a sub-list of the pairs does not match the table's size; multiple_models needs the rows on the host
+    with pytest.raises(_capi.AmcError):
+        amc_ctx.verify_pairs(s1[:2], s1[:2] + 1, off[:3], None, _capi.tvg_options())
+    with pytest.raises(_capi.AmcError):
+        amc_ctx.verify_pairs(s1, s1 + 1, off, None, _capi.tvg_options(multiple_models=1))
+    # an empty upload empties the table
+    assert amc_ctx.upload_matches(np.zeros((0, 2), np.uint32)) == 0
+    assert amc_ctx.resident_matches() == (0, 0)
+    with pytest.raises(_capi.AmcError):
+        amc_ctx.verify_pairs(s1, s1 + 1, off, None, _capi.tvg_options())
+
+
 @pytest.mark.parametrize("hook", ["AMC_TVG_NO_S32", "AMC_TVG_EXACT_COUNT", "AMC_TVG_SLOW_SAMPLER"])
 def test_alternative_counting_and_sampling_paths_agree_with_the_oracle(amc_ctx, monkeypatch, hook):
     """The counting loops have three implementations per estimator - packed-FP32 filter, division-free FP64 test,
