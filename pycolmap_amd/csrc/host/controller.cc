@@ -1,5 +1,6 @@
 #include "controller.h"
 
+#include <cstdlib>
 #include <algorithm>
 #include <chrono>
 #include <cstring>
@@ -539,8 +540,17 @@ std::vector<ImagePairs> ExhaustiveBlocks(const std::vector<image_t>& ids, int bl
 // merged until a device call has kGroupPairs pairs (a sequential block is ~17 pairs, far too few for
 // 1024 resident waves), then matched, verified and written in one transaction.  What ends up in the
 // database is the same; only the granularity of a resumed, interrupted run changes.
-constexpr size_t kGroupPairs = 32768;  // the verification kernel's launch tail: 64 k pairs/s at 4 k pairs, 95 k at 64 k
+constexpr size_t kGroupPairsDefault = 32768;  // the verification kernel's launch tail: 64 k pairs/s at 4 k pairs, 95 k at 64 k
+static size_t GroupPairs() {  // AMC_GROUP_PAIRS: A/B hook (read once)
+    static const size_t v = [] {
+        const char* e = std::getenv("AMC_GROUP_PAIRS");
+        const long long n = e ? std::atoll(e) : 0;
+        return n > 0 ? static_cast<size_t>(n) : kGroupPairsDefault;
+    }();
+    return v;
+}
 static void RunGrouped(MatchController& c, const std::vector<ImagePairs>& blocks) {
+    const size_t kGroupPairs = GroupPairs();
     // One group's rows are written by a worker thread (one transaction per group) while the device
     // matches and verifies the next group: SQLite's share of a run hides behind the kernels.
     ImagePairs group;
