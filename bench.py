@@ -904,15 +904,21 @@ def config34_leg(args, config: int, steps: int, warmup: int, dist_state):
             # loop closure (SequentialFeatureMatcher::RunLoopDetection with the vocabulary tree replaced by exact
             # feature voting): every 10th image against every other image on the first 512
             # descriptors, the 50 best-voted candidates are then matched at full size
-            cand = np.arange(num_images, dtype=np.uint32)
-            q1 = np.repeat(queries.astype(np.uint32), num_images - 1)
-            q2 = np.concatenate([cand[cand != q] for q in queries])
-            voff, _, vst = ctx.match_pairs(num_images + q1, num_images + q2, kernel=args.kernel)
-            votes = np.diff(voff.astype(np.int64)).reshape(len(queries), num_images - 1)
-            order = np.argsort(-votes, axis=1, kind="stable")[:, :loop_num_images]
-            keep = np.take_along_axis(votes, order, axis=1) > 0
-            l1 = np.repeat(queries.astype(np.uint32), loop_num_images).reshape(len(queries), -1)[keep]
-            l2 = q2.reshape(len(queries), num_images - 1)[np.arange(len(queries))[:, None], order][keep]
+            qs = queries.astype(np.uint32)
+            q1 = np.repeat(qs, num_images - 1)
+            base = np.arange(num_images - 1, dtype=np.uint32)
+            q2 = np.tile(base, (len(qs), 1))                     # every image but the query itself, ascending
+            q2 += base[None, :] >= qs[:, None]
+            voff, _, vst = ctx.match_pairs(num_images + q1, num_images + q2.reshape(-1), kernel=args.kernel)
+            votes = np.diff(voff).reshape(len(qs), num_images - 1)
+            # per query the loop_num_images best-voted candidates, more votes first, ties by image order, none without a
+            # vote (= a stable sort of every row by -votes, cut, zero votes dropped: only the voted-for entries are sorted)
+            r, c = np.nonzero(votes)
+            so = np.lexsort((c, -votes[r, c].astype(np.int64), r))
+            r, c = r[so], c[so]
+            sel = (np.arange(len(r)) - np.searchsorted(r, np.arange(len(qs)))[r]) < loop_num_images
+            l1 = qs[r[sel]]
+            l2 = q2[r[sel], c[sel]]
             loff, lm, lst = ctx.match_pairs(l1, l2, kernel=args.kernel)
             nd += vst["num_distances"] + lst["num_distances"]
             kms += vst["match_kernel_ms"] + lst["match_kernel_ms"]
