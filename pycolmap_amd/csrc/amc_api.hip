@@ -766,12 +766,14 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
     if (opts_in) o = *opts_in; else amc_match_opts_default(&o);
     if (o.kernel != AMC_KERNEL_AUTO && o.kernel != AMC_KERNEL_MFMA && o.kernel != AMC_KERNEL_DOT4)
         return fail(AMC_E_INVALID, "amc_match_pairs: unknown kernel %d", o.kernel);
+    uint64_t rows_total = 0;  // rows of image 1 (padded) over the call: what is left when a batch is carved
     for (size_t i = 0; i < npairs; ++i) {
         if (slot1[i] >= c->slots.size() || slot2[i] >= c->slots.size())
             return fail(AMC_E_INVALID, "amc_match_pairs: pair %zu references slot out of range", i);
         if (!c->slots[slot1[i]].valid || !c->slots[slot2[i]].valid)
             return fail(AMC_E_STATE, "amc_match_pairs: pair %zu references a slot with no "
                         "descriptors uploaded", i);
+        rows_total += c->slots[slot1[i]].dev.rows_pad;  // (one pass over the pair list: a loop-closure call has 10^7 pairs)
     }
     std::vector<GuidedDev> h_guided;
     const bool guided_dense_only = std::getenv("AMC_GUIDED_DENSE") != nullptr;  // (test hook: the dense kernel for every pair)
@@ -884,8 +886,7 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
     // rows of image 1 (padded) from pair i to the end of the call: how much is left when a batch is carved
     // (a running total, not an array: a loop-closure call has 10^7 pairs, and 80 MB of suffix sums cost more than the
     // tail they shape)
-    uint64_t rows_total = 0, rows_carved = 0;
-    for (size_t i = 0; i < npairs; ++i) rows_total += c->slots[slot1[i]].dev.rows_pad;
+    uint64_t rows_carved = 0;
     bool even_batches = std::getenv("AMC_MATCH_EVEN_BATCHES") != nullptr;  // (A/B hook)
     if (batch_hook && batch_hook->plan) {
         // amc_match_verify_pairs with AMC_PIPELINE_INTERLEAVE=1: batch k's verification runs beside batch k + 1's scan, so (a) what is exposed is the LAST
