@@ -351,6 +351,8 @@ struct amc_ctx {
     DevBuf<uint32_t> d_pmatches;
     DevBuf<double> d_pcos;
     DevBuf<PoseOut> d_pout;
+    PinBuf<PosePair> h_ppairs;  // pose_impl's staging (pinned, kept: 10^5 pairs are 23 + 32 MB; pageable vectors cost their
+    PinBuf<PoseOut> h_pout;     //  first touch and a staged copy in every call)
 };
 
 namespace amc {
@@ -512,6 +514,7 @@ void amc_ctx_destroy(amc_ctx* c) {
     if (c->d_vscalars) (void)hipFree(c->d_vscalars);
     c->d_tvg_packed.release(); c->d_mask_packed.release(); c->d_moff.release(); c->d_tp_all.release(); c->d_worksum.release();
     c->d_ppairs.release(); c->d_pmatches.release(); c->d_pcos.release(); c->d_pout.release();
+    c->h_ppairs.release(); c->h_pout.release();
     dlap("verify device buffers");
     for (auto& ev : c->ev)
         if (ev) (void)hipEventDestroy(ev);
@@ -569,7 +572,7 @@ int amc_ctx_trim(amc_ctx* c) {
         if (vs) HIPCHK(hipStreamSynchronize(vs));
     for (auto& sl : c->vslices)
         if (sl) sl->release();
-    c->h_tp.release(); c->h_moff.release();
+    c->h_tp.release(); c->h_moff.release(); c->h_ppairs.release(); c->h_pout.release();
     c->d_estate.release();
     c->d_tout.release(); c->d_tmatches.release(); c->d_pmatches.release(); c->d_pcos.release();
     c->d_tvg_packed.release(); c->d_mask_packed.release(); c->d_moff.release(); c->d_tp_all.release();
@@ -1842,7 +1845,10 @@ static int pose_impl(amc_ctx* c, const char* who, const uint32_t* slot1, const u
     const uint64_t total = match_offsets[npairs];
     if (total > 0 && !inlier_matches && !resident) return fail(AMC_E_INVALID, "%s: NULL matches", who);
     if (npairs > 0xFFFFFFFFull) return fail(AMC_E_INVALID, "%s: too many pairs", who);
-    std::vector<PosePair> pp(npairs);
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));  // (an earlier call's upload of the staging buffer is over: every entry point blocks)
+    HIPCHK(c->h_ppairs.ensure(npairs));
+    PosePair* pp = c->h_ppairs.p;
     std::vector<uint8_t> need_lift(c->slots.size(), 0);
     for (size_t p = 0; p < npairs; ++p) {
         if (slot1[p] >= c->slots.size() || slot2[p] >= c->slots.size())
@@ -1889,7 +1895,7 @@ static int pose_impl(amc_ctx* c, const char* who, const uint32_t* slot1, const u
     HIPCHK(c->d_pcos.ensure(std::max<size_t>(total, 1)));
     HIPCHK(c->d_pout.ensure(npairs));
     HIPCHK(hipMemcpyAsync(c->d_timgs.p, timgs.data(), timgs.size() * sizeof(TvgImage), hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(c->d_ppairs.p, pp.data(), npairs * sizeof(PosePair), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(c->d_ppairs.p, pp, npairs * sizeof(PosePair), hipMemcpyHostToDevice, st));
     if (total && !resident)
         HIPCHK(hipMemcpyAsync(c->d_pmatches.p, inlier_matches, 2 * total * sizeof(uint32_t), hipMemcpyHostToDevice, st));
     HIPCHK(hipEventRecord(c->ev[4], st));
@@ -1897,8 +1903,9 @@ static int pose_impl(amc_ctx* c, const char* who, const uint32_t* slot1, const u
                        resident ? (resident_matches ? resident_matches : c->d_tmatches.p) : c->d_pmatches.p,
                        resident ? c->d_mask_packed.p : nullptr, c->d_pcos.p, c->d_pout.p, st));
     HIPCHK(hipEventRecord(c->ev[5], st));
-    std::vector<PoseOut> h(npairs);
-    HIPCHK(hipMemcpyAsync(h.data(), c->d_pout.p, npairs * sizeof(PoseOut), hipMemcpyDeviceToHost, st));
+    HIPCHK(c->h_pout.ensure(npairs));
+    const PoseOut* h = c->h_pout.p;
+    HIPCHK(hipMemcpyAsync(c->h_pout.p, c->d_pout.p, npairs * sizeof(PoseOut), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     if (kernel_ms) {
         float ms = 0.f;
