@@ -910,7 +910,7 @@ def config34_leg(args, config: int, steps: int, warmup: int, dist_state):
             base = np.arange(num_images - 1, dtype=np.uint32)
             q2 = np.tile(base, (len(qs), 1))                     # every image but the query itself, ascending
             q2 += base[None, :] >= qs[:, None]
-            voff, _, vst = ctx.match_pairs(num_images + q1, num_images + q2.reshape(-1), kernel=args.kernel)
+            voff, _, vst = ctx.match_pairs(num_images + q1, num_images + q2.reshape(-1), kernel=args.kernel, copy=False)
             votes = np.diff(voff).reshape(len(qs), num_images - 1)
             # per query the loop_num_images best-voted candidates, more votes first, ties by image order, none without a
             # vote (= a stable sort of every row by -votes, cut, zero votes dropped: only the voted-for entries are sorted)
@@ -918,6 +918,7 @@ def config34_leg(args, config: int, steps: int, warmup: int, dist_state):
             so = np.lexsort((c, -votes[r, c].astype(np.int64), r))
             r, c = r[so], c[so]
             sel = (np.arange(len(r)) - np.searchsorted(r, np.arange(len(qs)))[r]) < loop_num_images
+            voff = _ = None                                      # (the voting call's result goes back to the pool)
             l1 = qs[r[sel]]
             l2 = q2[r[sel], c[sel]]
             loff, lm, lst = ctx.match_pairs(l1, l2, kernel=args.kernel)
