@@ -478,18 +478,36 @@ void MatchController::SetupLoopIndex(int max_features) {
 
 std::vector<image_t> MatchController::RetrieveLoopCandidates(image_t query, const std::vector<image_t>& candidates,
                                                              int num_images, int max_features) {
-    if (num_images <= 0 || candidates.empty()) return {};
+    return RetrieveLoopCandidatesBatch({query}, candidates, num_images, max_features)[0];
+}
+
+// Several queries in ONE device call (round 6): a query against 10^4 candidates is 10^4 pairs of max_features^2 - a
+// third of a millisecond of scan behind a call's fixed costs; the pairs of a batch of queries are independent, so the
+// votes, and with them the retrieved images, are those of one call per query.
+std::vector<std::vector<image_t>> MatchController::RetrieveLoopCandidatesBatch(const std::vector<image_t>& queries,
+                                                                               const std::vector<image_t>& candidates,
+                                                                               int num_images, int max_features) {
+    std::vector<std::vector<image_t>> found(queries.size());
+    if (num_images <= 0 || candidates.empty() || queries.empty()) return found;
     SetupLoopIndex(max_features > 0 ? max_features : kLoopIndexDefaultFeatures);
     const uint32_t n = static_cast<uint32_t>(images_.size());
     std::vector<uint32_t> s1, s2;
     std::vector<image_t> who;
-    for (image_t c : candidates) {
-        if (c == query) continue;
-        s1.push_back(n + SlotOf(query));
-        s2.push_back(n + SlotOf(c));
-        who.push_back(c);
+    std::vector<size_t> first(queries.size() + 1, 0);  // query q's pairs: [first[q], first[q + 1])
+    s1.reserve(queries.size() * candidates.size());
+    s2.reserve(queries.size() * candidates.size());
+    who.reserve(queries.size() * candidates.size());
+    for (size_t q = 0; q < queries.size(); ++q) {
+        const uint32_t qs = n + SlotOf(queries[q]);
+        for (image_t c : candidates) {
+            if (c == queries[q]) continue;
+            s1.push_back(qs);
+            s2.push_back(n + SlotOf(c));
+            who.push_back(c);
+        }
+        first[q + 1] = who.size();
     }
-    if (who.empty()) return {};
+    if (who.empty()) return found;
     amc_match_opts mo;
     amc_match_opts_default(&mo);
     mo.max_ratio = sift_.max_ratio;
@@ -497,21 +515,21 @@ std::vector<image_t> MatchController::RetrieveLoopCandidates(image_t query, cons
     mo.cross_check = sift_.cross_check;
     amc_match_result r;
     Check(amc_match_pairs(ctx_, s1.data(), s2.data(), who.size(), &mo, &r), "amc_match_pairs (loop index)");
-    std::vector<size_t> order(who.size());
-    std::vector<uint64_t> votes(who.size());
-    for (size_t i = 0; i < who.size(); ++i) {
-        order[i] = i;
-        votes[i] = r.offsets[i + 1] - r.offsets[i];
-    }
     stats.loop_device_ms += r.device_ms;
     stats.loop_pairs_scored += who.size();
-    ++stats.loop_queries;
+    stats.loop_queries += queries.size();
+    std::vector<size_t> order;
+    for (size_t q = 0; q < queries.size(); ++q) {
+        const size_t b = first[q], e = first[q + 1];
+        order.resize(e - b);
+        for (size_t i = b; i < e; ++i) order[i - b] = i;
+        auto votes = [&](size_t i) { return r.offsets[i + 1] - r.offsets[i]; };
+        std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t c) { return votes(a) > votes(c); });
+        for (size_t k = 0; k < order.size() && found[q].size() < static_cast<size_t>(num_images); ++k)
+            if (votes(order[k]) > 0) found[q].push_back(who[order[k]]);  // an image without a single vote is no candidate
+    }
     amc_match_result_free(&r);
-    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return votes[a] > votes[b]; });
-    std::vector<image_t> out;
-    for (size_t k = 0; k < order.size() && out.size() < static_cast<size_t>(num_images); ++k)
-        if (votes[order[k]] > 0) out.push_back(who[order[k]]);  // an image without a single vote is no candidate
-    return out;
+    return found;
 }
 
 // ExhaustiveFeatureMatcher::Run: block pairs, one transaction + Match() each
@@ -617,13 +635,28 @@ void RunSequential(MatchController& c, const SequentialMatchingOptions& o) {
     // order) is matched against its loop_detection_num_images retrieved images
     if (o.loop_detection) {
         std::vector<ImagePairs> loop_blocks;
+        // queries per device call: as many as make ~2^16 pairs, at least one.  Measured on a 3,000-image database (300
+        // queries, profiles/r06/ab_loop_v2.txt, _v3.txt): one query per call 213 ms of device time, 10 - 21 per call
+        // 124 - 127, 42: 154 - 158, 84 and more: 220 - 276 (few, large calls pay the growth of their result buffers)
+        size_t per_call = std::max<size_t>(1, (size_t(1) << 16) / std::max<size_t>(ids.size(), 1));
+        if (const char* e = std::getenv("AMC_LOOP_QUERIES_PER_CALL")) per_call = static_cast<size_t>(std::max(1, std::atoi(e)));  // (A/B hook)
+        std::vector<image_t> queries;
+        auto flush = [&] {
+            if (queries.empty()) return;
+            const std::vector<std::vector<image_t>> found = c.RetrieveLoopCandidatesBatch(
+                queries, ids, o.loop_detection_num_images, o.loop_detection_max_num_features);
+            for (size_t q = 0; q < queries.size(); ++q) {
+                ImagePairs pairs;
+                for (image_t j : found[q]) pairs.emplace_back(queries[q], j);
+                loop_blocks.push_back(std::move(pairs));
+            }
+            queries.clear();
+        };
         for (size_t i = 0; i < ids.size() && !c.StopRequested(); i += kLoopDetectionPeriod) {
-            const std::vector<image_t> found =
-                c.RetrieveLoopCandidates(ids[i], ids, o.loop_detection_num_images, o.loop_detection_max_num_features);
-            ImagePairs pairs;
-            for (image_t j : found) pairs.emplace_back(ids[i], j);
-            loop_blocks.push_back(std::move(pairs));
+            queries.push_back(ids[i]);
+            if (queries.size() >= per_call) flush();
         }
+        if (!c.StopRequested()) flush();
         RunGrouped(c, loop_blocks);
     }
 }

@@ -125,6 +125,10 @@ class MatchController {
     // descriptors of both images, most first, ties in `candidates` order.
     std::vector<image_t> RetrieveLoopCandidates(image_t query, const std::vector<image_t>& candidates,
                                                 int num_images, int max_features);
+    // the same for several queries in one device call (one list per query)
+    std::vector<std::vector<image_t>> RetrieveLoopCandidatesBatch(const std::vector<image_t>& queries,
+                                                                  const std::vector<image_t>& candidates, int num_images,
+                                                                  int max_features);
     const std::vector<ImageRow>& Images() const { return images_; }
     Database& Db() { return *db_; }
     void RequestStop() { stop_.store(true); }
