@@ -933,8 +933,9 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
     auto sync_batch_streams = [&](const char* what) {
         return hc(hipStreamSynchronize(st), what) && (!overlap || hc(hipStreamSynchronize(cs), what));
     };
-    const bool hook_split = batch_hook && batch_hook->submit && !batch_hook->plan &&
-                            !(std::getenv("AMC_HOOK_SPLIT") && std::getenv("AMC_HOOK_SPLIT")[0] == '0');
+    const char* hs_env = std::getenv("AMC_HOOK_SPLIT");  // "0": off; "2": also calls of a few pairs (the tests' way to the path)
+    const bool hook_split = batch_hook && batch_hook->submit && !batch_hook->plan && !(hs_env && hs_env[0] == '0');
+    const size_t hook_split_min_pairs = (hs_env && hs_env[0] == '2') ? 2 : 4096;
     size_t first_div = kFirstBatchDiv;
     if (const char* e = std::getenv("AMC_MATCH_FIRST_DIV")) first_div = (size_t)std::max(0, std::atoi(e));
     auto carve = [&](size_t begin, int set) {
@@ -956,7 +957,7 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
         // amc_match_verify_pairs hands a batch's pairs to the verification's host side (checks, trial tables, class lists:
         // 3 - 25 ms for 33 k pairs) when the batch's counts are on the host - beside the NEXT batch's scan.  A call that
         // fits one batch has no next scan to hide that behind: it is cut in two (AMC_HOOK_SPLIT=0: A/B hook).
-        if (!even_batches && begin == 0 && hook_split && rows_total <= max_entries && npairs >= 4096)
+        if (!even_batches && begin == 0 && hook_split && rows_total <= max_entries && npairs >= hook_split_min_pairs)
             limit = (size_t)(rows_total * 6 / 10);
         while (b.end < npairs) {
             const Slot& x = c->slots[slot1[b.end]];

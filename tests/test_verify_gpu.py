@@ -408,16 +408,22 @@ def test_fused_match_verify_equals_the_two_calls(amc_ctx, monkeypatch, pose):
     # stages fully behind each other (AMC_PIPELINE_SERIAL); the device-interleaved variant kept for the A/B - slices
     # beside the next batch's scan, more batches than slice slots (the rest joins the last slice), the scan leaving 16
     # CUs to them
-    for batch_entries, variant in ((None, {}), ("4096", {}), ("4096", {"AMC_PIPELINE_SERIAL": "1"}),
+    # ... and a call that fits one batch cut in two (what calls of >= 4096 pairs get: AMC_HOOK_SPLIT=2 takes this small one there)
+    for batch_entries, variant in ((None, {}), (None, {"AMC_HOOK_SPLIT": "2"}), (None, {"AMC_HOOK_SPLIT": "0"}),
+                                   ("4096", {}), ("4096", {"AMC_PIPELINE_SERIAL": "1"}),
                                    ("4096", {"AMC_PIPELINE_INTERLEAVE": "1"}),
                                    ("20000", {"AMC_PIPELINE_INTERLEAVE": "1", "AMC_VERIFY_CUS": "16"})):
         if batch_entries:
             monkeypatch.setenv("AMC_MATCH_BATCH_ENTRIES", batch_entries)
-        for k in ("AMC_PIPELINE_SERIAL", "AMC_PIPELINE_INTERLEAVE", "AMC_VERIFY_CUS"):
+        for k in ("AMC_PIPELINE_SERIAL", "AMC_PIPELINE_INTERLEAVE", "AMC_VERIFY_CUS", "AMC_HOOK_SPLIT"):
             monkeypatch.delenv(k, raising=False)
         for k, v in variant.items():
             monkeypatch.setenv(k, v)
         foff, fm, fmst, ftvg, fmask, fst = amc_ctx.match_verify_pairs(s1, s2, opts, seed=0)
+        if variant.get("AMC_HOOK_SPLIT") == "2":
+            split_launches = fmst["match_kernel_launches"]
+        elif variant.get("AMC_HOOK_SPLIT") == "0":
+            assert split_launches > fmst["match_kernel_launches"]      # the cut call really ran as two batches
         np.testing.assert_array_equal(foff, off)
         np.testing.assert_array_equal(fm, m)
         np.testing.assert_array_equal(fmask, mask)
