@@ -519,8 +519,9 @@ def dense_leg(ctx_factory, device, steps: int, warmup: int, num_images: int, fea
     torch.cuda.synchronize()
     from pycolmap_amd import synth
     s1, s2 = synth.exhaustive_pairs(num_images)
-    for _ in range(warmup):
-        ctx.match_pairs(s1, s2, kernel=kernel)
+    for _ in range(warmup):   # (the timed loop's own call: result views, released before the next call)
+        w_ = ctx.match_pairs(s1, s2, kernel=kernel, copy=False)
+        w_ = None
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     scan = cross = dev = 0.0
@@ -614,8 +615,9 @@ def ragged_leg(ctx_factory, device, steps: int, warmup: int, num_images: int, lo
     torch.cuda.synchronize()
     from pycolmap_amd import synth
     s1, s2 = synth.exhaustive_pairs(num_images)
-    for _ in range(warmup):
-        ctx.match_pairs(s1, s2, kernel=kernel)
+    for _ in range(warmup):   # (the timed loop's own call: result views, released before the next call)
+        w_ = ctx.match_pairs(s1, s2, kernel=kernel, copy=False)
+        w_ = None
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     scan = cross = 0.0
@@ -660,8 +662,9 @@ def sift_stats_leg(ctx_factory, device, steps: int, warmup: int, num_images: int
     torch.cuda.synchronize()
     from pycolmap_amd import synth
     s1, s2 = synth.exhaustive_pairs(num_images)
-    for _ in range(warmup):
-        ctx.match_pairs(s1, s2, kernel=kernel)
+    for _ in range(warmup):   # (the timed loop's own call: result views, released before the next call)
+        w_ = ctx.match_pairs(s1, s2, kernel=kernel, copy=False)
+        w_ = None
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     scan = cross = 0.0
@@ -1459,19 +1462,20 @@ def main():
                                    scan_ms=sm["scan_ms"])
         if gpu_legs and not args.no_ragged:
             release_headline()
-            # (five steps: with two, one slow host-side moment - 16 ms once in this round's runs - moves vs_uniform by 8 %)
+            # (five steps: with two, one slow host-side moment - 16 ms once in this round's runs - moves vs_uniform by 8 %;
+            #  two warm-up calls: that moment was the first timed call after ONE warm-up in profiles/r06's v8 and v11 lines)
             out["ragged"] = ragged_leg(lambda: _capi.Context(local_rank), device, max(1, min(args.steps, 5)),
-                                       min(1, args.warmup), args.images, 2000, 6000, args.kernel, value,
+                                       min(2, args.warmup), args.images, 2000, 6000, args.kernel, value,
                                        check=not args.no_cpu_baseline)
         if gpu_legs and not args.no_sift_stats:
             release_headline()
             out["sift_stats"] = sift_stats_leg(lambda: _capi.Context(local_rank), device, max(1, min(args.steps, 5)),
-                                               min(1, args.warmup), args.images, args.feats, args.kernel, value,
+                                               min(2, args.warmup), args.images, args.feats, args.kernel, value,
                                                check=not args.no_cpu_baseline)
         if gpu_legs and not args.no_dense:
             release_headline()
             out["dense"] = dense_leg(lambda: _capi.Context(local_rank), device, max(1, min(args.steps, 3)),
-                                     min(1, args.warmup), args.images, args.feats, args.kernel, check=not args.no_cpu_baseline)
+                                     min(2, args.warmup), args.images, args.feats, args.kernel, check=not args.no_cpu_baseline)
         if gpu_legs and not args.no_db:
             release_headline()
             try:
