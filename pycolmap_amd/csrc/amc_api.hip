@@ -889,7 +889,7 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
     // rows of image 1 (padded) from pair i to the end of the call: how much is left when a batch is carved
     // (a running total, not an array: a loop-closure call has 10^7 pairs, and 80 MB of suffix sums cost more than the
     // tail they shape)
-    uint64_t rows_carved = 0;
+    uint64_t rows_carved = 0, rows_collected = 0;
     bool even_batches = std::getenv("AMC_MATCH_EVEN_BATCHES") != nullptr;  // (A/B hook)
     if (batch_hook && batch_hook->plan) {
         // amc_match_verify_pairs with AMC_PIPELINE_INTERLEAVE=1: batch k's verification runs beside batch k + 1's scan, so (a) what is exposed is the LAST
@@ -1284,11 +1284,19 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
                       (unsigned long long)(run - keep_used), b.total);
             return false;
         }
+        rows_collected += b.top_rows;
         if (b.total) {
             const size_t need = 2 * (keep_used + (size_t)b.total);
+            // what the whole call will need if the batches to come match like the ones so far (+ 10 %): a table that has to
+            // grow is sized for that at once - three batches otherwise pin (and copy) 2.4 times the final result
+            size_t want = need;
+            if (rows_collected > 0 && rows_collected < rows_total) {
+                const double est = (double)need * ((double)rows_total / (double)rows_collected) * 1.1;
+                if (est < 4.0e10) want = std::max(need, (size_t)est / 2 * 2);
+            }
             if (need > c->d_keep.cap) {
                 DevBuf<uint32_t> bigger;
-                if (!hc(bigger.ensure(std::max(need, 2 * c->d_keep.cap)), "resident match table")) return false;
+                if (!hc(bigger.ensure(std::max(want, 2 * c->d_keep.cap)), "resident match table")) return false;
                 if (keep_used &&
                     !hc(hipMemcpyAsync(bigger.p, c->d_keep.p, 2 * keep_used * sizeof(uint32_t), hipMemcpyDeviceToDevice, st),
                         "move resident match table"))
@@ -1305,7 +1313,7 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
                     !hc(hipStreamSynchronize(c->copy_stream), "sync before growing the result buffer"))
                     return false;
                 PinBuf<uint32_t> bigger;
-                if (!hc(bigger.ensure(std::max(need, 2 * priv->matches.cap)), "pinned result")) return false;
+                if (!hc(bigger.ensure(std::max(want, 2 * priv->matches.cap)), "pinned result")) return false;
                 if (keep_used) std::memcpy(bigger.p, priv->matches.p, 2 * keep_used * sizeof(uint32_t));
                 priv->matches.release();
                 priv->matches = bigger;
