@@ -1286,17 +1286,22 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
         }
         rows_collected += b.top_rows;
         if (b.total) {
+            const auto tgrow = std::chrono::steady_clock::now();
             const size_t need = 2 * (keep_used + (size_t)b.total);
             // what the whole call will need if the batches to come match like the ones so far (+ 10 %): a table that has to
             // grow is sized for that at once - three batches otherwise pin (and copy) 2.4 times the final result
+            // (at most four times what is needed now, and what is needed now if the larger request fails)
             size_t want = need;
             if (rows_collected > 0 && rows_collected < rows_total) {
-                const double est = (double)need * ((double)rows_total / (double)rows_collected) * 1.1;
-                if (est < 4.0e10) want = std::max(need, (size_t)est / 2 * 2);
+                const double est = std::min((double)need * ((double)rows_total / (double)rows_collected) * 1.1, 4.0 * (double)need);
+                want = std::max(need, (size_t)est / 2 * 2);
             }
             if (need > c->d_keep.cap) {
                 DevBuf<uint32_t> bigger;
-                if (!hc(bigger.ensure(std::max(want, 2 * c->d_keep.cap)), "resident match table")) return false;
+                if (bigger.ensure(std::max(want, 2 * c->d_keep.cap)) != hipSuccess) {
+                    (void)hipGetLastError();
+                    if (!hc(bigger.ensure(need), "resident match table")) return false;
+                }
                 if (keep_used &&
                     !hc(hipMemcpyAsync(bigger.p, c->d_keep.p, 2 * keep_used * sizeof(uint32_t), hipMemcpyDeviceToDevice, st),
                         "move resident match table"))
@@ -1313,11 +1318,18 @@ static int match_impl(amc_ctx* c, const uint32_t* slot1, const uint32_t* slot2, 
                     !hc(hipStreamSynchronize(c->copy_stream), "sync before growing the result buffer"))
                     return false;
                 PinBuf<uint32_t> bigger;
-                if (!hc(bigger.ensure(std::max(want, 2 * priv->matches.cap)), "pinned result")) return false;
+                if (bigger.ensure(std::max(want, 2 * priv->matches.cap)) != hipSuccess) {
+                    (void)hipGetLastError();
+                    if (prof) std::fprintf(stderr, "[amc match profile] pinned result: %zu words refused, asking for %zu\n", want, need);
+                    if (!hc(bigger.ensure(need), "pinned result")) return false;
+                }
                 if (keep_used) std::memcpy(bigger.p, priv->matches.p, 2 * keep_used * sizeof(uint32_t));
                 priv->matches.release();
                 priv->matches = bigger;
             }
+            if (prof && since(tgrow) > 5.0)
+                std::fprintf(stderr, "[amc match profile] batch of %zu pairs: %.1f ms growing the result tables to %zu words\n", b.nb,
+                             since(tgrow), priv->matches.cap);
             if (!hc(c->d_csr.ensure(b.nb), "dev csr") ||
                 !hc(tcopy(c->d_csr.p, c->h_csr[k].p, b.nb * sizeof(uint64_t), hipMemcpyHostToDevice, st), "H2D csr"))
                 return false;
